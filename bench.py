@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): 1M x 768-D f32 cosine, k=10, exact distance sweep + fused
+GPU top-k (HnswIndex::search_brute_force semantics, recall@10 = 1.0 by construction).
+A "step" = one batch of --batch queries searched against the HBM-resident corpus through the
+C ABI's device-pointer entry point (vdb_hip_index_search_batch_dev); value = whole-job queries/s.
+
+    python bench.py                       # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Headline = replica mode (every GPU holds the corpus, the query
+stream is split: no data-path collective, weak scaling).  The same run also measures the
+range-sharded mode (every GPU holds a different 1M-row shard, per-shard top-k, ONE RCCL
+all-gather of k (id,score) pairs per query, merge) and reports it under "sharded".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rows", type=int, default=1_000_000)
+    p.add_argument("--dim", type=int, default=768)
+    p.add_argument("--k", type=int, default=10)
+    p.add_argument("--batch", type=int, default=64, help="queries per step")
+    p.add_argument("--metric", default="cosine")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-rows", type=int, default=262_144)
+    p.add_argument("--cpu-sample-queries", type=int, default=32)
+    p.add_argument("--check-queries", type=int, default=2)
+    return p.parse_args()
+
+
+def main():
+    a = parse()
+    import torch  # first: the HIP runtime it loads is the one libvelesdb_hip.so binds to
+    import torch.distributed as dist
+    import numpy as np
+    import velesdb_amd as va
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available() and va.device_count() > 0, "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    metric = {"cosine": va.DistanceMetric.Cosine, "euclidean": va.DistanceMetric.Euclidean,
+              "dot": va.DistanceMetric.DotProduct}[a.metric]
+    N, D, K, Q = a.rows, a.dim, a.k, a.batch
+
+    # ---- synthetic corpus, generated on the device (same seed on every rank = replica) ----
+    g = torch.Generator(device=dev)
+    g.manual_seed(42)
+    corpus = torch.randn((N, D), generator=g, device=dev, dtype=torch.float32)
+    g.manual_seed(43)
+    n_query_pool = max(Q * 4, 256)
+    queries = torch.randn((n_query_pool, D), generator=g, device=dev, dtype=torch.float32)
+    ix = va.HnswIndex(D, metric, va.HnswParams(32, 400, N), device=local)
+    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
+    ix.upload_dev(0, corpus.data_ptr(), N, stream)
+    sample_rows = min(a.cpu_sample_rows, N)
+    host_sample = corpus[:sample_rows].cpu().numpy() if rank == 0 else None
+    host_full = None
+    if rank == 0 and a.check_queries > 0:
+        host_full = corpus.cpu().numpy()
+    del corpus
+    torch.cuda.empty_cache()
+
+    out_ids = torch.empty((Q, K), dtype=torch.int64, device=dev)
+    out_sc = torch.empty((Q, K), dtype=torch.float32, device=dev)
+    out_n = torch.empty((Q,), dtype=torch.int32, device=dev)
+
+    def step(i, mode=va.MODE_BRUTE):
+        # each rank takes its own slice of the query stream (replica mode)
+        off = ((i * world + rank) * Q) % (n_query_pool - Q + 1)
+        ix.search_batch_dev(queries[off:off + Q].data_ptr(), Q, K, 0, mode, out_ids.data_ptr(),
+                            out_sc.data_ptr(), out_n.data_ptr(), stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    va.set_kernel_timing(True)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms, kernel_launches = ix.last_kernel_ms()  # HIP events around the sweep kernel, last step
+    va.set_kernel_timing(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    qps = world * Q * a.steps / dt
+
+    # ---- roofline of the dominant kernel (the sweep): algorithmic bytes / measured duration ----
+    tile = 8 if Q >= 8 else (4 if Q >= 4 else (2 if Q >= 2 else 1))
+    alg_bytes = N * D * 4 + (N * 4 if a.metric == "cosine" else 0) + tile * D * 4
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": f"sweep_topk_f32<{a.metric},B={tile},CPL={D // 256 if D % 256 == 0 else 0}>",
+                "kernel_ms": round(kernel_ms, 4), "launches_timed": kernel_launches,
+                "alg_bytes_per_launch": alg_bytes, "queries_per_launch": tile}
+
+    # ---- single-query latency mode (one corpus pass per query) ----
+    lat = {}
+    if rank == 0:
+        torch.cuda.synchronize()
+        va.set_kernel_timing(True)
+        reps = 20
+        t1 = time.perf_counter()
+        for i in range(reps):
+            ix.search_batch_dev(queries[i:i + 1].data_ptr(), 1, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
+                                out_sc.data_ptr(), out_n.data_ptr(), stream)
+        torch.cuda.synchronize()
+        l_dt = (time.perf_counter() - t1) / reps
+        kms, _ = ix.last_kernel_ms()
+        va.set_kernel_timing(False)
+        b1 = N * D * 4 + (N * 4 if a.metric == "cosine" else 0) + D * 4
+        lat = {"ms_per_query": round(l_dt * 1e3, 4), "qps": round(1.0 / l_dt, 1), "sweep_kernel_ms": round(kms, 4),
+               "hbm_gbs": round(b1 / (kms * 1e-3) / 1e9, 1) if kms > 0 else 0.0,
+               "hbm_frac": round(b1 / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else 0.0}
+
+    # ---- range-sharded mode: per-shard top-k + one RCCL all-gather + merge ----
+    sharded = None
+    if world > 1:
+        g_ids = torch.empty((world, Q, K), dtype=torch.int64, device=dev)
+        g_sc = torch.empty((world, Q, K), dtype=torch.float32, device=dev)
+
+        def sharded_step(i):
+            off = (i * Q) % (n_query_pool - Q + 1)  # every rank searches the SAME queries
+            ix.search_batch_dev(queries[off:off + Q].data_ptr(), Q, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
+                                out_sc.data_ptr(), out_n.data_ptr(), stream)
+            shard_ids = out_ids + rank * N  # global row id = shard offset + local row
+            dist.all_gather_into_tensor(g_ids, shard_ids)
+            dist.all_gather_into_tensor(g_sc, out_sc)
+            cand_sc = g_sc.permute(1, 0, 2).reshape(Q, world * K)
+            cand_id = g_ids.permute(1, 0, 2).reshape(Q, world * K)
+            top = torch.topk(cand_sc, K, dim=1, largest=metric.higher_is_better(), sorted=True)
+            return torch.gather(cand_id, 1, top.indices), top.values
+
+        for i in range(a.warmup):
+            sharded_step(i)
+        barrier()
+        t2 = time.perf_counter()
+        for i in range(a.steps):
+            sharded_step(a.warmup + i)
+        barrier()
+        sdt = time.perf_counter() - t2
+        t = torch.tensor([sdt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sdt = float(t.item())
+        sharded = {"qps": round(Q * a.steps / sdt, 1), "corpus_rows": world * N, "ms_per_step": round(sdt / a.steps * 1e3, 4),
+                   "collective": "all_gather_into_tensor(ids u64, scores f32), %d B/query/GPU" % (K * 12)}
+
+    # ---- exactness / recall check against the oracle on the full corpus (rank 0) ----
+    recall = None
+    check = {}
+    cpu = None
+    if rank == 0:
+        from oracle import pyoracle as po
+        om = {"cosine": po.COSINE, "euclidean": po.EUCLIDEAN, "dot": po.DOT}[a.metric]
+        ncores = os.cpu_count() or 1
+        if host_full is not None:
+            nchk = a.check_queries
+            qh = queries[:nchk].cpu().numpy()
+            gi, gs, gc = ix.search_batch_brute_force(qh, K)
+            ci, cs = po.scan_topk(om, host_full, qh, K, po.MODE_C, nthreads=ncores)
+            ri, rs = po.scan_topk(om, host_full, qh, K, po.MODE_R, nthreads=ncores)
+            check = {"queries": nchk, "ids_equal_oracle_canonical": bool(np.array_equal(gi, ci)),
+                     "scores_bit_equal_oracle_canonical": bool(np.array_equal(gs.view(np.uint32), cs.view(np.uint32))),
+                     "ids_equal_reference_order": bool(np.array_equal(gi, ri)),
+                     "max_rel_diff_vs_reference_order": float(np.max(np.abs(gs - rs) / np.abs(rs)))}
+            recall = float(np.mean([len(set(gi[i].tolist()) & set(ri[i].tolist())) / K for i in range(nchk)]))
+            del host_full
+        if not a.no_cpu_baseline:
+            sq = min(a.cpu_sample_queries, n_query_pool)
+            qh = queries[:sq].cpu().numpy()
+            t3 = time.perf_counter()
+            po.scan_topk(om, host_sample, qh, K, po.MODE_R, nthreads=ncores)
+            cdt = time.perf_counter() - t3
+            cpu_qps_sample = sq / cdt
+            cpu = {"value": round(cpu_qps_sample * sample_rows / N, 3), "unit": "queries/s", "cores": ncores,
+                   "kind": "port",
+                   "sample": f"oracle mode R (wide16 AVX2+FMA restatement of brute_force_search_parallel) on the first "
+                             f"{sample_rows} rows x {sq} queries, {ncores} threads, {cdt:.2f} s; value = measured "
+                             f"{cpu_qps_sample:.1f} q/s scaled by {sample_rows}/{N} to the full corpus",
+                   "measured_qps_on_sample": round(cpu_qps_sample, 2)}
+
+    if rank == 0:
+        line = {
+            "metric": "qps_at_recall10_1Mx768_k10", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{N}x{D} f32 {a.metric}, k={K}, exact distance sweep + fused GPU top-k "
+                                   f"(BASELINE configs[1]); {Q} queries/step, 8 queries per corpus pass",
+                       "rows": N, "dim": D, "k": K, "queries_per_step": Q,
+                       "parallelism": "replicas x%d (query stream split, no collective)" % world},
+            "recall_at_10": recall, "parity_check": check,
+            "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "sharded": sharded,
+            "device": va.device_name(local),
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

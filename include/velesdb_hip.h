@@ -1,0 +1,165 @@
+/*
+ * velesdb_hip.h — C ABI of libvelesdb_hip.so: an MI355X (gfx950) implementation of
+ * velesdb-core's HNSW similarity-search hot path.
+ *
+ * This is the drop-in boundary.  A Rust `velesdb-hip` shim binds these
+ * symbols and implements the reference's own traits over the opaque handle:
+ *   trait VectorIndex          crates/velesdb-core/src/index/mod.rs:30-83
+ *   impl VectorIndex for HnswIndex   .../index/hnsw/index/trait_impl.rs:8-71
+ *   HnswIndex inherent methods .../index/hnsw/index/search.rs, batch.rs, constructors.rs
+ *   trait DistanceEngine       .../index/hnsw/native/distance.rs:14-28
+ *   GpuAccelerator             crates/velesdb-core/src/gpu/gpu_backend.rs:33,136,157,355,397
+ *
+ * Conventions
+ *   - every call returns an int32 status (0 = VDB_OK, >0 informational, <0 error); nothing
+ *     unwinds across the boundary; vdb_hip_last_error() gives the thread-local message.
+ *   - all buffers are caller-owned, plain pointers + sizes, row-major, little-endian.
+ *   - "host" entry points take host pointers (what a Rust &[f32] is); "_dev" entry points take
+ *     device pointers and a hipStream_t (as void*) and enqueue without synchronising.
+ *   - a handle may be used from any thread (internally synchronised: Send + Sync).
+ *   - there is NO CPU fallback: without a HIP device every compute call fails with
+ *     VDB_ERR_NO_DEVICE (the reference's GpuAccelerator::new() == None, gpu_backend.rs:33).
+ *   - result order: best first; equal scores are ordered by internal insertion index
+ *     ascending (declared canonical tie-break; the reference's tie order is an artefact of
+ *     heap / hash-map layout, SURVEY.md §8a note 8).
+ */
+#ifndef VELESDB_HIP_H
+#define VELESDB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vdb_hip_index vdb_hip_index; /* opaque */
+
+/* DistanceMetric, same discriminants as the reference's on-disk order
+ * (index/hnsw/index/constructors.rs:204-210; core/distance.rs:16-38). */
+enum vdb_metric {
+  VDB_COSINE = 0,
+  VDB_EUCLIDEAN = 1,
+  VDB_DOT = 2,
+  VDB_HAMMING = 3,
+  VDB_JACCARD = 4
+};
+
+enum vdb_status {
+  VDB_OK = 0,
+  VDB_DUPLICATE_IGNORED = 1,  /* insert of an existing id: no-op (trait_impl.rs:23-25) */
+  VDB_ERR_INVALID_ARG = -1,
+  VDB_ERR_DIM_MISMATCH = -2,  /* the shim panics "… dimension mismatch: expected {}, got {}" */
+  VDB_ERR_NO_DEVICE = -3,
+  VDB_ERR_HIP = -4,
+  VDB_ERR_IO = -5,
+  VDB_ERR_OOM = -6,
+  VDB_ERR_UNSUPPORTED = -7,
+  VDB_ERR_STATE = -8
+};
+
+/* search `mode` */
+enum vdb_search_mode {
+  VDB_SEARCH_AUTO = 0,  /* HnswIndex::search_with_quality (search.rs:59-94): brute force when
+                           len<=100, else HNSW with `ef`; scores = transform_score           */
+  VDB_SEARCH_BRUTE = 1, /* HnswIndex::search_brute_force (search.rs:176-219): exact scan, raw
+                           similarity/distance scores, metric.sort_results order             */
+  VDB_SEARCH_HNSW = 2   /* always the graph (search_batch_parallel, batch.rs:180-194)        */
+};
+
+/* score convention of vdb_hip_batch_distance */
+enum vdb_distance_kind {
+  VDB_KIND_ENGINE = 0, /* DistanceEngine::distance (native/distance.rs:75-85): 1-cos, sqrt(l2),
+                          -dot, hamming, 1-jaccard                                          */
+  VDB_KIND_RAW = 1     /* HnswIndex::compute_distance / GpuAccelerator::batch_* (search.rs:30-38;
+                          gpu_backend.rs:157,355,397): cos, sqrt(l2), dot, hamming, jaccard */
+};
+
+/* ---- device discovery: GpuAccelerator::new()/is_available() (gpu_backend.rs:33,136) ---- */
+int32_t vdb_hip_device_count(int32_t* n);
+int32_t vdb_hip_device_name(int32_t device, char* buf, size_t cap);
+
+/* ---- lifecycle: HnswIndex::with_params (constructors.rs:117-160) ----
+ * M = max_connections, M0 = 2M (native/graph.rs:62); max_elements is a capacity hint
+ * (storage grows); `device` is a HIP device ordinal.  row_id_base is added to internal row
+ * numbers nowhere visible to the caller; it exists so a range-shard can be created with
+ * the same ids as the unsharded index. */
+int32_t vdb_hip_index_create(uint32_t dim, int32_t metric, uint32_t M, uint32_t ef_construction,
+                             uint64_t max_elements, int32_t device, vdb_hip_index** out);
+void vdb_hip_index_destroy(vdb_hip_index* idx);
+
+/* ---- VectorIndex::insert (index/mod.rs:46, trait_impl.rs:10-36) ---- */
+int32_t vdb_hip_index_insert(vdb_hip_index* idx, uint64_t id, const float* vec, uint32_t vec_len);
+/* HnswIndex::insert_batch_sequential / insert_batch_parallel (batch.rs:83-149): rows are
+ * dim floats each; *inserted = number of new ids (duplicates skipped). */
+int32_t vdb_hip_index_insert_batch(vdb_hip_index* idx, const uint64_t* ids, const float* vecs_rowmajor,
+                                   uint64_t n, uint64_t* inserted);
+/* bulk upload without graph construction: vectors become searchable by VDB_SEARCH_BRUTE at
+ * once; the graph is absent until vdb_hip_index_build_graph / load_reference_files.
+ * (HnswIndex keeps exact search available independently of the graph, search.rs:176-219.) */
+int32_t vdb_hip_index_upload(vdb_hip_index* idx, const uint64_t* ids, const float* vecs_rowmajor,
+                             uint64_t n, uint64_t* inserted);
+/* same, rows already resident in HBM on the index's device (device pointer), ids = base..base+n-1 */
+int32_t vdb_hip_index_upload_dev(vdb_hip_index* idx, uint64_t id_base, const float* d_vecs_rowmajor,
+                                 uint64_t n, void* stream);
+
+/* ---- VectorIndex::remove / len / dimension / metric (index/mod.rs:62-82) ---- */
+int32_t vdb_hip_index_remove(vdb_hip_index* idx, uint64_t id, int32_t* removed); /* soft delete */
+int32_t vdb_hip_index_len(const vdb_hip_index* idx, uint64_t* n);
+int32_t vdb_hip_index_dimension(const vdb_hip_index* idx, uint32_t* dim);
+int32_t vdb_hip_index_metric(const vdb_hip_index* idx, int32_t* metric);
+/* number of graph nodes (NativeHnsw::len, native/graph.rs:130-132; includes soft-deleted) */
+int32_t vdb_hip_index_node_count(const vdb_hip_index* idx, uint64_t* n);
+
+/* ---- VectorIndex::search + HnswIndex::search_with_quality/search_brute_force ----
+ * ef = 0 => SearchQuality::Balanced rule max(128, 4k) (params.rs:309-319).
+ * out_ids/out_scores hold k entries; *out_n <= k (soft-deleted rows can shorten HNSW results,
+ * search.rs:86-91). */
+int32_t vdb_hip_index_search(vdb_hip_index* idx, const float* query, uint32_t query_len, uint32_t k,
+                             uint32_t ef, int32_t mode, uint64_t* out_ids, float* out_scores,
+                             uint32_t* out_n);
+/* HnswIndex::search_batch_parallel (batch.rs:159-197) for mode HNSW; one launch for all
+ * queries.  out_ids/out_scores are nq*k, out_n is nq. */
+int32_t vdb_hip_index_search_batch(vdb_hip_index* idx, const float* queries_rowmajor, uint32_t nq,
+                                   uint32_t k, uint32_t ef, int32_t mode, uint64_t* out_ids,
+                                   float* out_scores, uint32_t* out_n);
+/* device-resident variant: d_queries nq*dim f32, outputs device buffers of nq*k / nq; enqueued
+ * on `stream`, no host synchronisation. */
+int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* idx, const float* d_queries, uint32_t nq,
+                                       uint32_t k, uint32_t ef, int32_t mode, uint64_t* d_out_ids,
+                                       float* d_out_scores, uint32_t* d_out_n, void* stream);
+
+/* ---- DistanceEngine::batch_distance / GpuAccelerator::batch_{cosine_similarity,
+ * euclidean_distance,dot_product} (native/distance.rs:21-24; gpu_backend.rs:157,355,397) ----
+ * n rows of dim floats against one query; out has n floats, same order as the rows. */
+int32_t vdb_hip_batch_distance(int32_t device, int32_t metric, int32_t kind, const float* query,
+                               const float* vecs_rowmajor, uint64_t n, uint32_t dim, float* out);
+int32_t vdb_hip_batch_distance_dev(int32_t metric, int32_t kind, const float* d_query,
+                                   const float* d_vecs_rowmajor, uint64_t n, uint32_t dim, float* d_out,
+                                   void* stream);
+
+/* ---- persistence hand-off: NativeHnsw::file_dump / file_load, format v1
+ * (native/backend_adapter.rs:184-381): <dir>/<basename>.vectors and .graph ---- */
+int32_t vdb_hip_index_load_reference_files(vdb_hip_index* idx, const char* dir, const char* basename);
+int32_t vdb_hip_index_save_reference_files(vdb_hip_index* idx, const char* dir, const char* basename);
+
+/* ---- introspection used by tests and the bench ---- */
+/* neighbours of `node` on `layer`; returns count in *n, writes up to cap ids */
+int32_t vdb_hip_index_get_neighbors(vdb_hip_index* idx, uint32_t layer, uint64_t node, uint32_t* out,
+                                    uint32_t cap, uint32_t* n);
+int32_t vdb_hip_index_graph_info(vdb_hip_index* idx, uint32_t* num_layers, uint32_t* max_layer,
+                                 int64_t* entry_point);
+/* counters of the last HNSW search batch: distance evaluations and expansions */
+int32_t vdb_hip_index_last_search_stats(vdb_hip_index* idx, uint64_t* n_dist, uint64_t* n_expand);
+/* average duration (ms) of the dominant kernel in the last search call, measured with HIP
+ * events on the launch stream; 0 if timing is off.  Enable with vdb_hip_set_kernel_timing(1). */
+int32_t vdb_hip_set_kernel_timing(int32_t on);
+int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* idx, float* ms, uint32_t* launches);
+
+const char* vdb_hip_last_error(void); /* thread-local, never NULL */
+const char* vdb_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VELESDB_HIP_H */

@@ -1,0 +1,90 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/velesdb_hip.h declares, the Python binding declares the same set, and — with no GPU —
+compute entry points fail loudly with VDB_ERR_NO_DEVICE instead of falling back to a CPU path."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "velesdb_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(vdb_hip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_surface():
+    names = declared_functions()
+    for must in ("vdb_hip_index_create", "vdb_hip_index_insert", "vdb_hip_index_search",
+                 "vdb_hip_index_search_batch", "vdb_hip_index_remove", "vdb_hip_index_len",
+                 "vdb_hip_batch_distance", "vdb_hip_index_load_reference_files", "vdb_hip_device_count",
+                 "vdb_hip_last_error", "vdb_hip_index_destroy"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from velesdb_amd import _ffi
+    assert os.path.exists(_ffi.LIB_PATH), "run `python -m velesdb_amd.build` first"
+    L = C.CDLL(_ffi.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(L, name), f"{name} declared in velesdb_hip.h but not exported"
+    assert sorted(_ffi.SIGNATURES) == declared_functions()
+
+
+def test_header_is_plain_c():
+    # the boundary must compile as C (no C++/torch types in signatures)
+    r = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", HEADER], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_library_has_gfx950_code_object_only():
+    # the fat binary must carry exactly one device target: gfx950 (no dual paths)
+    from velesdb_amd import _ffi
+    blob = open(_ffi.LIB_PATH, "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import velesdb_amd as va
+    if va.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(va.VelesHipError) as e:
+        va.HnswIndex(8, va.DistanceMetric.Cosine)
+    assert e.value.code == -3
+    with pytest.raises(va.VelesHipError):
+        va.HipDistance(va.DistanceMetric.Cosine).batch_distance(np.ones(4, np.float32), np.ones((2, 4), np.float32))
+    assert va.GpuAccelerator.new() is None  # gpu_backend.rs:33 -> None without a device
+    assert not va.GpuAccelerator.is_available()
+
+
+def test_product_never_references_the_oracle():
+    # the product path must not import/link anything under oracle/
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "velesdb_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"(from|import)\s+oracle|pyoracle|libvdb_oracle|#include\s*[<\"][^>\"]*oracle", txt):
+                    bad.append(f)
+    assert not bad, bad
+    from velesdb_amd import _ffi
+    needed = subprocess.run(["readelf", "-d", _ffi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in needed
+
+
+def test_params_mirror_reference_presets():
+    from velesdb_amd import HnswParams, SearchQuality
+    assert HnswParams.auto(768) == HnswParams(32, 400, 100_000)      # params.rs:41-57
+    assert HnswParams.auto(128) == HnswParams(24, 300, 100_000)
+    assert HnswParams.million_scale(768) == HnswParams(128, 1600, 1_500_000)  # params.rs:124-139
+    assert HnswParams.for_dataset_size(128, 50_000) == HnswParams(64, 800, 150_000)
+    assert SearchQuality.Fast.ef_search(10) == 64 and SearchQuality.Balanced.ef_search(10) == 128
+    assert SearchQuality.Accurate.ef_search(50) == 800 and SearchQuality.Perfect.ef_search(10) == 4096
+    assert SearchQuality.Custom(30).ef_search(50) == 50

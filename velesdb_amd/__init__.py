@@ -1,0 +1,13 @@
+"""velesdb_amd — MI355X-native implementation of velesdb-core's HNSW search hot path.
+
+The product is libvelesdb_hip.so (hand-written HIP for gfx950) behind the C ABI in
+include/velesdb_hip.h; this package is the host-side mirror of the reference's
+VectorIndex / HnswIndex / DistanceEngine / GpuAccelerator interfaces over that ABI.
+"""
+from ._ffi import LIB_PATH, VelesHipError, lib  # noqa: F401
+from .index import (GpuAccelerator, HipDistance, HnswIndex, MODE_AUTO, MODE_BRUTE, MODE_HNSW,  # noqa: F401
+                    device_count, device_name, set_kernel_timing)
+from .params import DistanceMetric, HnswParams, SearchQuality  # noqa: F401
+
+__all__ = ["HnswIndex", "HipDistance", "GpuAccelerator", "DistanceMetric", "HnswParams", "SearchQuality",
+           "device_count", "device_name", "set_kernel_timing", "lib", "VelesHipError"]

@@ -1,0 +1,238 @@
+// graph.hip — graph side of the index: persistence hand-off in the reference's format v1
+// (NativeHnsw::file_dump / file_load, native/backend_adapter.rs:184-381), introspection, and the
+// launch paths of the traversal / construction kernels (hnsw_kernels.hip).
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "vdb_index.hpp"
+#include "vdb_kernels.hpp"
+
+using namespace vdb;
+
+namespace vdb {
+
+int32_t ensure_layers(vdb_hip_index* ix, uint32_t num_layers) {
+  while (ix->layers.size() < num_layers) {
+    GraphLayer L;
+    L.stride = ix->M;  // upper layers: M links (graph.rs:204-208)
+    hipError_t e = L.nbr.reserve(ix->capacity * L.stride * 4, false, ix->stream);
+    if (e == hipSuccess) e = L.cnt.reserve(ix->capacity * 4, false, ix->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(L.cnt.p, 0, L.cnt.cap, ix->stream);
+    if (e != hipSuccess) return fail(VDB_ERR_OOM, std::string("graph layer: ") + hipGetErrorString(e));
+    ix->layers.push_back(L);
+  }
+  return VDB_OK;
+}
+
+// traversal / construction launch paths: filled in by hnsw_kernels.hip
+int32_t hnsw_search_dev(vdb_hip_index* ix, const float*, uint64_t, uint32_t, uint32_t, uint32_t, uint64_t*, float*,
+                        uint32_t*, hipStream_t) {
+  if (!ix->graph_valid) return fail(VDB_ERR_STATE, "HNSW graph not built for all rows (use mode BRUTE or build it)");
+  return fail(VDB_ERR_UNSUPPORTED, "HNSW traversal kernel not built in this library");
+}
+int32_t graph_insert_rows(vdb_hip_index*, uint64_t, uint64_t) {
+  return fail(VDB_ERR_UNSUPPORTED, "HNSW construction kernel not built in this library");
+}
+
+}  // namespace vdb
+
+extern "C" {
+
+int32_t vdb_hip_index_graph_info(vdb_hip_index* ix, uint32_t* num_layers, uint32_t* max_layer,
+                                 int64_t* entry_point) {
+  if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  if (num_layers) *num_layers = (uint32_t)ix->layers.size();
+  if (max_layer) *max_layer = ix->max_layer;
+  if (entry_point) *entry_point = ix->graph_valid ? ix->entry_point : -1;
+  return VDB_OK;
+}
+
+int32_t vdb_hip_index_get_neighbors(vdb_hip_index* ix, uint32_t layer, uint64_t node, uint32_t* out, uint32_t cap,
+                                    uint32_t* n) {
+  if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  *n = 0;
+  if (layer >= ix->layers.size() || node >= ix->n_rows) return VDB_OK;  // layer.rs:33-39: empty
+  VDB_HIP(hipSetDevice(ix->device));
+  GraphLayer& L = ix->layers[layer];
+  uint32_t c = 0;
+  VDB_HIP(hipMemcpyAsync(&c, L.cnt.as<uint32_t>() + node, 4, hipMemcpyDeviceToHost, ix->stream));
+  VDB_HIP(hipStreamSynchronize(ix->stream));
+  *n = c;
+  uint32_t w = std::min(c, cap);
+  if (w && out) {
+    VDB_HIP(hipMemcpyAsync(out, L.nbr.as<uint32_t>() + node * L.stride, (size_t)w * 4, hipMemcpyDeviceToHost,
+                           ix->stream));
+    VDB_HIP(hipStreamSynchronize(ix->stream));
+  }
+  return VDB_OK;
+}
+
+// NativeHnsw::file_load — native/backend_adapter.rs:273-381.  The index must be empty; dim must
+// match; M/M0/ef_construction are taken from the file like the reference does.  External ids are
+// the node ids (the reference keeps its id mappings in a separate bincode file that is out of
+// scope; HnswIndex::load re-associates them, constructors.rs:190-253).
+int32_t vdb_hip_index_load_reference_files(vdb_hip_index* ix, const char* dir, const char* basename) {
+  if (!ix || !dir || !basename) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  if (ix->n_rows != 0) return fail(VDB_ERR_STATE, "load_reference_files needs an empty index");
+  VDB_HIP(hipSetDevice(ix->device));
+  const std::string vp = std::string(dir) + "/" + basename + ".vectors";
+  const std::string gp = std::string(dir) + "/" + basename + ".graph";
+  FILE* f = std::fopen(vp.c_str(), "rb");
+  if (!f) return fail(VDB_ERR_IO, "cannot open " + vp);
+  uint32_t version = 0, dim = 0;
+  uint64_t count = 0;
+  bool ok = std::fread(&version, 4, 1, f) == 1 && std::fread(&count, 8, 1, f) == 1 && std::fread(&dim, 4, 1, f) == 1;
+  if (!ok || version != 1) {
+    std::fclose(f);
+    return fail(VDB_ERR_IO, "Unsupported version: " + std::to_string(version));  // backend_adapter.rs:285-290
+  }
+  if (count && dim != ix->dim) {
+    std::fclose(f);
+    return fail(VDB_ERR_DIM_MISMATCH, "file dimension " + std::to_string(dim) + " != index dimension " +
+                                          std::to_string(ix->dim));
+  }
+  std::vector<float> vecs((size_t)count * dim);
+  ok = std::fread(vecs.data(), 4, vecs.size(), f) == vecs.size();
+  std::fclose(f);
+  if (!ok) return fail(VDB_ERR_IO, "truncated " + vp);
+  f = std::fopen(gp.c_str(), "rb");
+  if (!f) return fail(VDB_ERR_IO, "cannot open " + gp);
+  uint32_t num_layers = 0, M = 0, M0 = 0, efc = 0, max_layer = 0;
+  uint64_t ep = 0, count2 = 0;
+  ok = std::fread(&version, 4, 1, f) == 1 && version == 1 && std::fread(&num_layers, 4, 1, f) == 1 &&
+       std::fread(&M, 4, 1, f) == 1 && std::fread(&M0, 4, 1, f) == 1 && std::fread(&efc, 4, 1, f) == 1 &&
+       std::fread(&ep, 8, 1, f) == 1 && std::fread(&max_layer, 4, 1, f) == 1 && std::fread(&count2, 8, 1, f) == 1;
+  if (!ok || num_layers == 0 || num_layers > 64 || M < 1) {
+    std::fclose(f);
+    return fail(VDB_ERR_IO, "bad graph header in " + gp);
+  }
+  // adopt the file's parameters (backend_adapter.rs:368-379)
+  ix->M = M;
+  ix->M0 = M0;
+  ix->efc = efc;
+  for (auto& L : ix->layers) {
+    L.nbr.release();
+    L.cnt.release();
+  }
+  ix->layers.clear();
+  std::vector<std::vector<uint32_t>> h_nbr(num_layers), h_cnt(num_layers);
+  for (uint32_t l = 0; l < num_layers && ok; l++) {
+    const uint32_t stride = l == 0 ? M0 : M;
+    uint64_t nn = 0;
+    ok = std::fread(&nn, 8, 1, f) == 1;
+    if (!ok) break;
+    h_nbr[l].assign((size_t)count * stride, 0);
+    h_cnt[l].assign((size_t)count, 0);
+    std::vector<uint32_t> tmp;
+    for (uint64_t i = 0; i < nn && ok; i++) {
+      uint32_t kk = 0;
+      ok = std::fread(&kk, 4, 1, f) == 1;
+      tmp.resize(kk);
+      if (ok && kk) ok = std::fread(tmp.data(), 4, kk, f) == kk;
+      if (!ok) break;
+      if (i >= count) continue;
+      if (kk > stride) {
+        std::fclose(f);
+        return fail(VDB_ERR_IO, "node with more neighbours than the layer's max_connections");
+      }
+      for (uint32_t j = 0; j < kk; j++) {
+        if (tmp[j] >= count) {
+          std::fclose(f);
+          return fail(VDB_ERR_IO, "neighbour id out of range");
+        }
+        h_nbr[l][(size_t)i * stride + j] = tmp[j];
+      }
+      h_cnt[l][i] = kk;
+    }
+  }
+  std::fclose(f);
+  if (!ok) return fail(VDB_ERR_IO, "truncated " + gp);
+  // vectors + ids
+  std::vector<uint64_t> ids(count);
+  for (uint64_t i = 0; i < count; i++) ids[i] = i;
+  int32_t rc = ensure_capacity(ix, std::max<uint64_t>(count, 1));
+  if (rc != VDB_OK) return rc;
+  uint64_t ins = 0, first = 0;
+  rc = append_host_rows(ix, ids.data(), vecs.data(), count, &ins, &first);
+  if (rc != VDB_OK) return rc;
+  for (uint32_t l = 0; l < num_layers; l++) {
+    GraphLayer L;
+    L.stride = l == 0 ? M0 : M;
+    hipError_t e = L.nbr.reserve(std::max<size_t>(ix->capacity * L.stride * 4, 4), false, ix->stream);
+    if (e == hipSuccess) e = L.cnt.reserve(ix->capacity * 4, false, ix->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(L.cnt.p, 0, L.cnt.cap, ix->stream);
+    if (e == hipSuccess && count)
+      e = hipMemcpyAsync(L.nbr.p, h_nbr[l].data(), h_nbr[l].size() * 4, hipMemcpyHostToDevice, ix->stream);
+    if (e == hipSuccess && count)
+      e = hipMemcpyAsync(L.cnt.p, h_cnt[l].data(), h_cnt[l].size() * 4, hipMemcpyHostToDevice, ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("graph upload: ") + hipGetErrorString(e));
+    ix->layers.push_back(L);
+  }
+  ix->entry_point = count ? (int64_t)ep : -1;
+  ix->max_layer = max_layer;
+  ix->graph_nodes = count;
+  ix->graph_valid = true;
+  ix->rng_state = 0x5DEECE66D1A4B5B5ull;  // backend_adapter.rs:373
+  return VDB_OK;
+}
+
+// NativeHnsw::file_dump — native/backend_adapter.rs:184-261
+int32_t vdb_hip_index_save_reference_files(vdb_hip_index* ix, const char* dir, const char* basename) {
+  if (!ix || !dir || !basename) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  if (!ix->graph_valid) return fail(VDB_ERR_STATE, "graph not built for all rows");
+  VDB_HIP(hipSetDevice(ix->device));
+  const uint64_t count = ix->n_rows;
+  std::vector<float> vecs((size_t)count * ix->dim);
+  if (count) {
+    VDB_HIP(hipMemcpy2DAsync(vecs.data(), (size_t)ix->dim * 4, ix->rows.p, ix->row_stride * 4, (size_t)ix->dim * 4,
+                             count, hipMemcpyDeviceToHost, ix->stream));
+    VDB_HIP(hipStreamSynchronize(ix->stream));
+  }
+  const std::string vp = std::string(dir) + "/" + basename + ".vectors";
+  const std::string gp = std::string(dir) + "/" + basename + ".graph";
+  FILE* f = std::fopen(vp.c_str(), "wb");
+  if (!f) return fail(VDB_ERR_IO, "cannot create " + vp);
+  uint32_t version = 1, dim = count ? ix->dim : 0;
+  std::fwrite(&version, 4, 1, f);
+  std::fwrite(&count, 8, 1, f);
+  std::fwrite(&dim, 4, 1, f);
+  std::fwrite(vecs.data(), 4, vecs.size(), f);
+  std::fclose(f);
+  f = std::fopen(gp.c_str(), "wb");
+  if (!f) return fail(VDB_ERR_IO, "cannot create " + gp);
+  uint32_t num_layers = (uint32_t)ix->layers.size(), M = ix->M, M0 = ix->M0, efc = ix->efc, max_layer = ix->max_layer;
+  uint64_t ep = ix->entry_point < 0 ? 0 : (uint64_t)ix->entry_point;
+  std::fwrite(&version, 4, 1, f);
+  std::fwrite(&num_layers, 4, 1, f);
+  std::fwrite(&M, 4, 1, f);
+  std::fwrite(&M0, 4, 1, f);
+  std::fwrite(&efc, 4, 1, f);
+  std::fwrite(&ep, 8, 1, f);
+  std::fwrite(&max_layer, 4, 1, f);
+  std::fwrite(&count, 8, 1, f);
+  for (auto& L : ix->layers) {
+    std::vector<uint32_t> nbr((size_t)count * L.stride), cnt(count);
+    if (count) {
+      VDB_HIP(hipMemcpyAsync(nbr.data(), L.nbr.p, nbr.size() * 4, hipMemcpyDeviceToHost, ix->stream));
+      VDB_HIP(hipMemcpyAsync(cnt.data(), L.cnt.p, cnt.size() * 4, hipMemcpyDeviceToHost, ix->stream));
+      VDB_HIP(hipStreamSynchronize(ix->stream));
+    }
+    uint64_t nn = count;
+    std::fwrite(&nn, 8, 1, f);
+    for (uint64_t i = 0; i < count; i++) {
+      std::fwrite(&cnt[i], 4, 1, f);
+      std::fwrite(nbr.data() + (size_t)i * L.stride, 4, cnt[i], f);
+    }
+  }
+  std::fclose(f);
+  return VDB_OK;
+}
+
+}  // extern "C"

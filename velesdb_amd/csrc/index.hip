@@ -1,0 +1,647 @@
+// index.hip — host side of libvelesdb_hip.so: the C ABI declared in include/velesdb_hip.h.
+// Each entry point names the reference interface it replaces.  No CPU compute path exists
+// here: every score, norm, bit-pack, top-k and traversal runs in a HIP kernel.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "vdb_index.hpp"
+#include "vdb_kernels.hpp"
+
+namespace vdb {
+
+static thread_local std::string g_last_error;
+static int g_timing = 0;
+
+void set_last_error(const std::string& s) { g_last_error = s; }
+int32_t fail(int32_t code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+hipError_t DevBuf::reserve(size_t bytes, bool keep, hipStream_t st) {
+  if (bytes <= cap) return hipSuccess;
+  size_t ncap = std::max(bytes, cap + cap / 2);
+  ncap = (ncap + 255) & ~(size_t)255;
+  void* np = nullptr;
+  hipError_t e = hipMalloc(&np, ncap);
+  if (e != hipSuccess) return e;
+  if (keep && p && cap) {
+    e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      (void)hipFree(np);
+      return e;
+    }
+  }
+  if (p) (void)hipFree(p);
+  p = np;
+  cap = ncap;
+  return hipSuccess;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+static bool higher_is_better_host(int metric) {  // core/distance.rs:76-82
+  return metric == VDB_COSINE || metric == VDB_DOT || metric == VDB_JACCARD;
+}
+static bool is_bits_metric(int metric) { return metric == VDB_HAMMING || metric == VDB_JACCARD; }
+
+static int32_t check_device(int32_t* n_out) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    if (n_out) *n_out = 0;
+    return fail(VDB_ERR_NO_DEVICE, "no HIP device visible (hipGetDeviceCount)");
+  }
+  if (n_out) *n_out = n;
+  return VDB_OK;
+}
+
+// ---- capacity management: all per-row arrays grow together ---------------------------------
+int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
+  if (want <= ix->capacity) return VDB_OK;
+  uint64_t ncap = std::max<uint64_t>(want, ix->capacity + ix->capacity / 2);
+  ncap = std::max<uint64_t>(ncap, 1024);
+  hipStream_t st = ix->stream;
+  hipError_t e;
+  if ((e = ix->rows.reserve(ncap * ix->row_stride * 4, true, st)) != hipSuccess ||
+      (e = ix->alive.reserve(ncap, true, st)) != hipSuccess ||
+      (e = ix->ext_ids.reserve(ncap * 8, true, st)) != hipSuccess)
+    return fail(e == hipErrorOutOfMemory ? VDB_ERR_OOM : VDB_ERR_HIP, std::string("grow: ") + hipGetErrorString(e));
+  if (ix->metric == VDB_COSINE && (e = ix->norms.reserve(ncap * 4, true, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("grow norms: ") + hipGetErrorString(e));
+  if (is_bits_metric(ix->metric) && (e = ix->bits.reserve(ncap * ix->words * 4, true, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("grow bits: ") + hipGetErrorString(e));
+  for (auto& L : ix->layers) {
+    if ((e = L.nbr.reserve(ncap * L.stride * 4, true, st)) != hipSuccess ||
+        (e = L.cnt.reserve(ncap * 4, true, st)) != hipSuccess)
+      return fail(VDB_ERR_OOM, std::string("grow graph: ") + hipGetErrorString(e));
+    // rows beyond the old capacity have no links yet (Layer::ensure_capacity, layer.rs:26-30)
+    if ((e = hipMemsetAsync(L.cnt.as<uint32_t>() + ix->capacity, 0, (ncap - ix->capacity) * 4, st)) != hipSuccess)
+      return fail(VDB_ERR_HIP, std::string("grow graph: ") + hipGetErrorString(e));
+  }
+  ix->capacity = ncap;
+  return VDB_OK;
+}
+
+// appends n rows that are already laid out with row_stride on the device at rows[n_rows..]
+static int32_t finish_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
+  PrepArgs pa{};
+  pa.rows = ix->rows.as<float>();
+  pa.norms = ix->metric == VDB_COSINE ? ix->norms.as<float>() : nullptr;
+  pa.bits = is_bits_metric(ix->metric) ? ix->bits.as<uint32_t>() : nullptr;
+  pa.row_stride = ix->row_stride;
+  pa.row0 = (uint32_t)first;
+  pa.n_rows = (uint32_t)n;
+  pa.dim = ix->dim;
+  pa.words = ix->words;
+  if (pa.norms || pa.bits) launch_prep_rows(pa, ix->stream);
+  VDB_HIP(hipGetLastError());
+  return VDB_OK;
+}
+
+// registers ids (duplicates skipped), copies rows H2D; returns the list of accepted source rows
+int32_t append_host_rows(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, uint64_t n,
+                                uint64_t* inserted, uint64_t* first_row) {
+  std::vector<uint64_t> src;
+  src.reserve(n);
+  std::vector<uint64_t> new_ids;
+  for (uint64_t i = 0; i < n; i++) {
+    if (ix->id_to_idx.count(ids[i])) continue;  // trait_impl.rs:23-25: duplicate id => skipped
+    // duplicates inside the batch itself: first one wins
+    ix->id_to_idx[ids[i]] = ix->n_rows + src.size();
+    src.push_back(i);
+    new_ids.push_back(ids[i]);
+  }
+  const uint64_t m = src.size();
+  *first_row = ix->n_rows;
+  if (inserted) *inserted = m;
+  if (m == 0) return VDB_OK;
+  if (ix->n_rows + m > 0xFFFFFFF0ull) {
+    for (uint64_t id : new_ids) ix->id_to_idx.erase(id);
+    return fail(VDB_ERR_UNSUPPORTED, "more than 2^32-16 rows per index");
+  }
+  int32_t rc = ensure_capacity(ix, ix->n_rows + m);
+  if (rc != VDB_OK) {
+    for (uint64_t id : new_ids) ix->id_to_idx.erase(id);
+    return rc;
+  }
+  float* drows = ix->rows.as<float>() + ix->n_rows * ix->row_stride;
+  const bool contiguous = (m == n);
+  hipError_t e = hipSuccess;
+  if (contiguous) {
+    e = hipMemcpy2DAsync(drows, ix->row_stride * 4, vecs, (size_t)ix->dim * 4, (size_t)ix->dim * 4, m,
+                         hipMemcpyHostToDevice, ix->stream);
+  } else {
+    for (uint64_t j = 0; j < m && e == hipSuccess; j++)
+      e = hipMemcpyAsync(drows + j * ix->row_stride, vecs + src[j] * ix->dim, (size_t)ix->dim * 4,
+                         hipMemcpyHostToDevice, ix->stream);
+  }
+  if (e == hipSuccess && ix->row_stride != ix->dim) {
+    // zero the padding floats so the storage is fully defined (never enters a chain)
+    e = hipMemset2DAsync(drows + ix->dim, ix->row_stride * 4, 0, (ix->row_stride - ix->dim) * 4, m, ix->stream);
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(ix->ext_ids.as<uint64_t>() + ix->n_rows, new_ids.data(), m * 8, hipMemcpyHostToDevice,
+                       ix->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(ix->alive.as<uint8_t>() + ix->n_rows, 1, m, ix->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);  // new_ids / vecs are caller memory
+  if (e != hipSuccess) {
+    for (uint64_t id : new_ids) ix->id_to_idx.erase(id);
+    return fail(VDB_ERR_HIP, std::string("upload: ") + hipGetErrorString(e));
+  }
+  ix->idx_to_id.insert(ix->idx_to_id.end(), new_ids.begin(), new_ids.end());
+  ix->idx_live.insert(ix->idx_live.end(), m, 1);
+  ix->live += m;
+  const uint64_t first = ix->n_rows;
+  ix->n_rows += m;
+  return finish_append(ix, first, m);
+}
+
+static EventPair* next_events(vdb_hip_index* ix) {
+  if (!g_timing) return nullptr;
+  if (ix->ev_used == ix->ev_pool.size()) {
+    if (ix->ev_pool.size() >= 8192) return nullptr;
+    EventPair p;
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+    ix->ev_pool.push_back(p);
+  }
+  return &ix->ev_pool[ix->ev_used++];
+}
+
+static uint32_t pick_B(uint32_t nq) { return nq >= 8 ? 8 : (nq >= 4 ? 4 : (nq >= 2 ? 2 : 1)); }
+static int blocks_for(const vdb_hip_index* ix, int B, uint32_t ngroups) {
+  const int occ = (B == 1) ? 4 : (B == 8 ? 2 : 3);  // resident 256-thread blocks per CU (VGPR-limited)
+  int64_t want = ((int64_t)ngroups + 3) / 4;
+  int64_t cap = (int64_t)ix->n_cus * occ;
+  return (int)std::max<int64_t>(1, std::min(want, cap));
+}
+
+// HnswIndex::search_brute_force (search.rs:176-219) for nq device-resident queries.
+// Outputs are device buffers; nothing synchronises.
+static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k,
+                         uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st) {
+  if (nq == 0) return VDB_OK;
+  if (k == 0 || ix->n_rows == 0) {
+    VDB_HIP(hipMemsetAsync(d_n, 0, (size_t)nq * 4, st));
+    return VDB_OK;
+  }
+  const bool hib = higher_is_better_host(ix->metric);
+  const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
+  if (is_bits_metric(ix->metric)) {
+    if ((size_t)4 * k * 8 + (size_t)ix->words * 4 > 60 * 1024)
+      return fail(VDB_ERR_UNSUPPORTED, "k too large for the fused top-k path");
+    // pack the queries with the same kernel that packs rows
+    hipError_t e = ix->s_qbits.reserve((size_t)nq * ix->words * 4, false, st);
+    if (e != hipSuccess) return fail(VDB_ERR_OOM, "qbits scratch");
+    PrepArgs pa{};
+    pa.rows = d_q;
+    pa.bits = ix->s_qbits.as<uint32_t>();
+    pa.row_stride = q_stride;
+    pa.n_rows = nq;
+    pa.dim = ix->dim;
+    pa.words = ix->words;
+    launch_prep_rows(pa, st);
+    const uint32_t nchunks = (uint32_t)((ix->n_rows + 63) / 64);
+    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + 3) / 4, (int64_t)ix->n_cus * 4));
+    const uint32_t nw = (uint32_t)blocks * 4;
+    if ((e = ix->s_part_keys.reserve((size_t)nq * nw * k * 8, false, st)) != hipSuccess ||
+        (e = ix->s_part_cnt.reserve((size_t)nq * nw * 4, false, st)) != hipSuccess)
+      return fail(VDB_ERR_OOM, "top-k scratch");
+    BitsArgs ba{};
+    ba.bits = ix->bits.as<uint32_t>();
+    ba.qbits = ix->s_qbits.as<uint32_t>();
+    ba.alive = alive;
+    ba.part_keys = ix->s_part_keys.as<uint64_t>();
+    ba.part_cnt = ix->s_part_cnt.as<uint32_t>();
+    ba.n_rows = (uint32_t)ix->n_rows;
+    ba.words = ix->words;
+    ba.k = k;
+    EventPair* ev = next_events(ix);
+    if (ev) (void)hipEventRecord(ev->a, st);
+    launch_sweep_bits(ix->metric, ba, blocks, nq, st);
+    if (ev) (void)hipEventRecord(ev->b, st);
+    MergeArgs m{};
+    m.part_keys = ba.part_keys;
+    m.part_cnt = ba.part_cnt;
+    m.ext_ids = ix->ext_ids.as<uint64_t>();
+    m.out_ids = d_ids;
+    m.out_scores = d_scores;
+    m.out_n = d_n;
+    m.n_lists = nw;
+    m.k = k;
+    launch_merge(hib, m, nq, st);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+  }
+  for (uint32_t q0 = 0; q0 < nq;) {
+    const uint32_t B = pick_B(nq - q0);
+    const uint32_t tile = std::min<uint32_t>(B, nq - q0);
+    const int cpl = sweep_cpl_for_dim(ix->dim);
+    if (sweep_lds_bytes((int)B, k, ix->dim, cpl) > 60 * 1024)
+      return fail(VDB_ERR_UNSUPPORTED, "k (x dim) too large for the fused top-k path");
+    const uint32_t rpg = 64 / B;
+    const uint32_t ngroups = (uint32_t)((ix->n_rows + rpg - 1) / rpg);
+    const int blocks = blocks_for(ix, (int)B, ngroups);
+    const uint32_t nw = (uint32_t)blocks * 4;
+    hipError_t e;
+    if ((e = ix->s_part_keys.reserve((size_t)B * nw * k * 8, false, st)) != hipSuccess ||
+        (e = ix->s_part_cnt.reserve((size_t)B * nw * 4, false, st)) != hipSuccess)
+      return fail(VDB_ERR_OOM, "top-k scratch");
+    SweepArgs a{};
+    a.rows = ix->rows.as<float>();
+    a.norms = ix->norms.as<float>();
+    a.alive = alive;
+    a.queries = d_q + (size_t)q0 * q_stride;
+    a.part_keys = ix->s_part_keys.as<uint64_t>();
+    a.part_cnt = ix->s_part_cnt.as<uint32_t>();
+    a.row_stride = ix->row_stride;
+    a.q_stride = q_stride;
+    a.n_rows = (uint32_t)ix->n_rows;
+    a.dim = ix->dim;
+    a.nq = tile;
+    a.k = k;
+    EventPair* ev = next_events(ix);
+    if (ev) (void)hipEventRecord(ev->a, st);
+    launch_sweep_f32(ix->metric, (int)B, a, blocks, st);
+    if (ev) (void)hipEventRecord(ev->b, st);
+    MergeArgs m{};
+    m.part_keys = a.part_keys;
+    m.part_cnt = a.part_cnt;
+    m.ext_ids = ix->ext_ids.as<uint64_t>();
+    m.out_ids = d_ids + (size_t)q0 * k;
+    m.out_scores = d_scores + (size_t)q0 * k;
+    m.out_n = d_n + q0;
+    m.n_lists = nw;
+    m.k = k;
+    launch_merge(hib, m, tile, st);
+    q0 += tile;
+  }
+  VDB_HIP(hipGetLastError());
+  return VDB_OK;
+}
+
+static uint32_t balanced_ef(uint32_t k) { return std::max<uint32_t>(128, k * 4); }  // params.rs:313
+
+// dispatch of search_with_quality (search.rs:59-94) for device-resident queries
+static int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k,
+                          uint32_t ef, int32_t mode, uint64_t* d_ids, float* d_scores, uint32_t* d_n,
+                          hipStream_t st) {
+  ix->ev_used = 0;
+  if (mode == VDB_SEARCH_BRUTE) return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
+  if (mode == VDB_SEARCH_AUTO && ix->live <= 100 && ix->n_rows > 0)  // search.rs:75-77
+    return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
+  if (mode != VDB_SEARCH_AUTO && mode != VDB_SEARCH_HNSW) return fail(VDB_ERR_INVALID_ARG, "bad search mode");
+  if (ef == 0) ef = balanced_ef(k);
+  ef = std::max(ef, k);  // SearchQuality::Custom(ef) = max(ef, k), params.rs:317
+  return hnsw_search_dev(ix, d_q, q_stride, nq, k, ef, d_ids, d_scores, d_n, st);
+}
+
+}  // namespace vdb
+
+using namespace vdb;
+
+// =============================================================================================
+extern "C" {
+
+const char* vdb_hip_last_error(void) { return g_last_error.c_str(); }
+const char* vdb_hip_version(void) { return "velesdb-hip 0.1.0 (gfx950)"; }
+
+int32_t vdb_hip_set_kernel_timing(int32_t on) {
+  g_timing = on ? 1 : 0;
+  return VDB_OK;
+}
+
+// GpuAccelerator::new() / is_available() — gpu/gpu_backend.rs:33,136
+int32_t vdb_hip_device_count(int32_t* n) {
+  if (!n) return fail(VDB_ERR_INVALID_ARG, "n is null");
+  int32_t rc = check_device(n);
+  return rc == VDB_ERR_NO_DEVICE ? VDB_OK : rc;  // 0 devices is an answer, not an error
+}
+int32_t vdb_hip_device_name(int32_t device, char* buf, size_t cap) {
+  if (!buf || cap == 0) return fail(VDB_ERR_INVALID_ARG, "buf is null");
+  int32_t rc = check_device(nullptr);
+  if (rc != VDB_OK) return rc;
+  hipDeviceProp_t p;
+  VDB_HIP(hipGetDeviceProperties(&p, device));
+  std::snprintf(buf, cap, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  return VDB_OK;
+}
+
+// HnswIndex::with_params — index/hnsw/index/constructors.rs:117-160
+int32_t vdb_hip_index_create(uint32_t dim, int32_t metric, uint32_t M, uint32_t ef_construction,
+                             uint64_t max_elements, int32_t device, vdb_hip_index** out) {
+  if (!out) return fail(VDB_ERR_INVALID_ARG, "out is null");
+  *out = nullptr;
+  if (dim == 0 || metric < 0 || metric > 4 || M < 2) return fail(VDB_ERR_INVALID_ARG, "bad dim/metric/M");
+  int32_t ndev = 0;
+  int32_t rc = check_device(&ndev);
+  if (rc != VDB_OK) return rc;
+  if (device < 0 || device >= ndev) return fail(VDB_ERR_INVALID_ARG, "bad device ordinal");
+  VDB_HIP(hipSetDevice(device));
+  std::unique_ptr<vdb_hip_index> ix(new vdb_hip_index());
+  ix->device = device;
+  hipDeviceProp_t p;
+  VDB_HIP(hipGetDeviceProperties(&p, device));
+  ix->n_cus = p.multiProcessorCount;
+  ix->dim = dim;
+  ix->metric = metric;
+  ix->M = M;
+  ix->M0 = M * 2;  // native/graph.rs:62
+  ix->efc = ef_construction;
+  ix->row_stride = ((uint64_t)dim + 3) / 4 * 4;
+  ix->words = ((dim + 31) / 32 + 3) / 4 * 4;
+  VDB_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+  GraphLayer l0;
+  l0.stride = ix->M0;
+  ix->layers.push_back(l0);  // graph.rs:68 vec![Layer::new(max_elements)]
+  rc = ensure_capacity(ix.get(), std::max<uint64_t>(max_elements, 1));
+  if (rc != VDB_OK) return rc;
+  *out = ix.release();
+  return VDB_OK;
+}
+
+void vdb_hip_index_destroy(vdb_hip_index* ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  (void)hipStreamSynchronize(ix->stream);
+  for (DevBuf* b : {&ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids, &ix->s_queries, &ix->s_part_keys,
+                    &ix->s_part_cnt, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc})
+    b->release();
+  for (auto& L : ix->layers) {
+    L.nbr.release();
+    L.cnt.release();
+  }
+  for (auto& e : ix->ev_pool) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  (void)hipStreamDestroy(ix->stream);
+  delete ix;
+}
+
+// VectorIndex::insert — index/mod.rs:46; trait_impl.rs:10-36
+int32_t vdb_hip_index_insert(vdb_hip_index* ix, uint64_t id, const float* vec, uint32_t vec_len) {
+  if (!ix || !vec) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (vec_len != ix->dim)
+    return fail(VDB_ERR_DIM_MISMATCH, "Vector dimension mismatch: expected " + std::to_string(ix->dim) + ", got " +
+                                          std::to_string(vec_len));
+  std::lock_guard<std::mutex> g(ix->mu);
+  VDB_HIP(hipSetDevice(ix->device));
+  uint64_t ins = 0, first = 0;
+  int32_t rc = append_host_rows(ix, &id, vec, 1, &ins, &first);
+  if (rc != VDB_OK) return rc;
+  if (ins == 0) return VDB_DUPLICATE_IGNORED;
+  if (ix->graph_valid) {
+    rc = graph_insert_rows(ix, first, 1);
+    if (rc != VDB_OK) return rc;
+  }
+  return VDB_OK;
+}
+
+// HnswIndex::insert_batch_sequential — batch.rs:128-149 (deterministic order)
+int32_t vdb_hip_index_insert_batch(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, uint64_t n,
+                                   uint64_t* inserted) {
+  if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  VDB_HIP(hipSetDevice(ix->device));
+  uint64_t ins = 0, first = 0;
+  int32_t rc = append_host_rows(ix, ids, vecs, n, &ins, &first);
+  if (inserted) *inserted = ins;
+  if (rc != VDB_OK) return rc;
+  if (ins && ix->graph_valid) rc = graph_insert_rows(ix, first, ins);
+  return rc;
+}
+
+int32_t vdb_hip_index_upload(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, uint64_t n,
+                             uint64_t* inserted) {
+  if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  VDB_HIP(hipSetDevice(ix->device));
+  uint64_t ins = 0, first = 0;
+  int32_t rc = append_host_rows(ix, ids, vecs, n, &ins, &first);
+  if (inserted) *inserted = ins;
+  if (ins) ix->graph_valid = false;
+  if (rc == VDB_OK) VDB_HIP(hipStreamSynchronize(ix->stream));
+  return rc;
+}
+
+int32_t vdb_hip_index_upload_dev(vdb_hip_index* ix, uint64_t id_base, const float* d_vecs, uint64_t n, void* stream) {
+  if (!ix || (n && !d_vecs)) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  VDB_HIP(hipSetDevice(ix->device));
+  if (n == 0) return VDB_OK;
+  for (uint64_t i = 0; i < n; i++)
+    if (ix->id_to_idx.count(id_base + i)) return fail(VDB_ERR_INVALID_ARG, "upload_dev: id range overlaps existing ids");
+  if (ix->n_rows + n > 0xFFFFFFF0ull) return fail(VDB_ERR_UNSUPPORTED, "more than 2^32-16 rows per index");
+  int32_t rc = ensure_capacity(ix, ix->n_rows + n);
+  if (rc != VDB_OK) return rc;
+  hipStream_t caller = reinterpret_cast<hipStream_t>(stream);
+  VDB_HIP(hipStreamSynchronize(caller));  // d_vecs must be complete before our stream reads it
+  float* drows = ix->rows.as<float>() + ix->n_rows * ix->row_stride;
+  VDB_HIP(hipMemcpy2DAsync(drows, ix->row_stride * 4, d_vecs, (size_t)ix->dim * 4, (size_t)ix->dim * 4, n,
+                           hipMemcpyDeviceToDevice, ix->stream));
+  if (ix->row_stride != ix->dim)
+    VDB_HIP(hipMemset2DAsync(drows + ix->dim, ix->row_stride * 4, 0, (ix->row_stride - ix->dim) * 4, n, ix->stream));
+  std::vector<uint64_t> new_ids(n);
+  for (uint64_t i = 0; i < n; i++) {
+    new_ids[i] = id_base + i;
+    ix->id_to_idx[id_base + i] = ix->n_rows + i;
+  }
+  VDB_HIP(hipMemcpyAsync(ix->ext_ids.as<uint64_t>() + ix->n_rows, new_ids.data(), n * 8, hipMemcpyHostToDevice,
+                         ix->stream));
+  VDB_HIP(hipMemsetAsync(ix->alive.as<uint8_t>() + ix->n_rows, 1, n, ix->stream));
+  ix->idx_to_id.insert(ix->idx_to_id.end(), new_ids.begin(), new_ids.end());
+  ix->idx_live.insert(ix->idx_live.end(), n, 1);
+  ix->live += n;
+  const uint64_t first = ix->n_rows;
+  ix->n_rows += n;
+  ix->graph_valid = false;
+  rc = finish_append(ix, first, n);
+  if (rc != VDB_OK) return rc;
+  VDB_HIP(hipStreamSynchronize(ix->stream));
+  return VDB_OK;
+}
+
+// VectorIndex::remove — soft delete (trait_impl.rs:54-58)
+int32_t vdb_hip_index_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed) {
+  if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  auto it = ix->id_to_idx.find(id);
+  if (it == ix->id_to_idx.end()) {
+    if (removed) *removed = 0;
+    return VDB_OK;
+  }
+  const uint64_t idx = it->second;
+  VDB_HIP(hipSetDevice(ix->device));
+  VDB_HIP(hipMemsetAsync(ix->alive.as<uint8_t>() + idx, 0, 1, ix->stream));
+  VDB_HIP(hipStreamSynchronize(ix->stream));
+  ix->idx_live[idx] = 0;
+  ix->id_to_idx.erase(it);
+  ix->live--;
+  ix->any_dead = true;
+  if (removed) *removed = 1;
+  return VDB_OK;
+}
+
+int32_t vdb_hip_index_len(const vdb_hip_index* ix, uint64_t* n) {  // trait_impl.rs:60-62 mappings.len()
+  if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  *n = ix->live;
+  return VDB_OK;
+}
+int32_t vdb_hip_index_node_count(const vdb_hip_index* ix, uint64_t* n) {
+  if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  *n = ix->n_rows;
+  return VDB_OK;
+}
+int32_t vdb_hip_index_dimension(const vdb_hip_index* ix, uint32_t* dim) {
+  if (!ix || !dim) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  *dim = ix->dim;
+  return VDB_OK;
+}
+int32_t vdb_hip_index_metric(const vdb_hip_index* ix, int32_t* metric) {
+  if (!ix || !metric) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  *metric = ix->metric;
+  return VDB_OK;
+}
+
+int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* ix, const float* d_queries, uint32_t nq, uint32_t k,
+                                       uint32_t ef, int32_t mode, uint64_t* d_out_ids, float* d_out_scores,
+                                       uint32_t* d_out_n, void* stream) {
+  if (!ix || (nq && (!d_queries || !d_out_ids || !d_out_scores || !d_out_n)))
+    return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  VDB_HIP(hipSetDevice(ix->device));
+  return search_dev(ix, d_queries, ix->dim, nq, k, ef, mode, d_out_ids, d_out_scores, d_out_n,
+                    reinterpret_cast<hipStream_t>(stream));
+}
+
+// HnswIndex::search_batch_parallel (batch.rs:159-197) / search_with_quality / search_brute_force
+int32_t vdb_hip_index_search_batch(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef,
+                                   int32_t mode, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
+  if (!ix || (nq && (!queries || !out_n)) || (nq && k && (!out_ids || !out_scores)))
+    return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (nq == 0) return VDB_OK;
+  std::lock_guard<std::mutex> g(ix->mu);
+  VDB_HIP(hipSetDevice(ix->device));
+  hipStream_t st = ix->stream;
+  const size_t kk = std::max<uint32_t>(k, 1);
+  hipError_t e;
+  if ((e = ix->s_queries.reserve((size_t)nq * ix->row_stride * 4, false, st)) != hipSuccess ||
+      (e = ix->s_out_ids.reserve((size_t)nq * kk * 8, false, st)) != hipSuccess ||
+      (e = ix->s_out_scores.reserve((size_t)nq * kk * 4, false, st)) != hipSuccess ||
+      (e = ix->s_out_n.reserve((size_t)nq * 4, false, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("search scratch: ") + hipGetErrorString(e));
+  float* dq = ix->s_queries.as<float>();
+  if (ix->row_stride != ix->dim) VDB_HIP(hipMemsetAsync(dq, 0, (size_t)nq * ix->row_stride * 4, st));
+  VDB_HIP(hipMemcpy2DAsync(dq, ix->row_stride * 4, queries, (size_t)ix->dim * 4, (size_t)ix->dim * 4, nq,
+                           hipMemcpyHostToDevice, st));
+  int32_t rc = search_dev(ix, dq, ix->row_stride, nq, k, ef, mode, ix->s_out_ids.as<uint64_t>(),
+                          ix->s_out_scores.as<float>(), ix->s_out_n.as<uint32_t>(), st);
+  if (rc != VDB_OK) {
+    (void)hipStreamSynchronize(st);
+    return rc;
+  }
+  if (k) {
+    VDB_HIP(hipMemcpyAsync(out_ids, ix->s_out_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
+    VDB_HIP(hipMemcpyAsync(out_scores, ix->s_out_scores.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
+  }
+  VDB_HIP(hipMemcpyAsync(out_n, ix->s_out_n.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+  VDB_HIP(hipStreamSynchronize(st));
+  return VDB_OK;
+}
+
+// VectorIndex::search — index/mod.rs:58; trait_impl.rs:38-42
+int32_t vdb_hip_index_search(vdb_hip_index* ix, const float* query, uint32_t query_len, uint32_t k, uint32_t ef,
+                             int32_t mode, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
+  if (!ix || !query) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (query_len != ix->dim)
+    return fail(VDB_ERR_DIM_MISMATCH, "Query dimension mismatch: expected " + std::to_string(ix->dim) + ", got " +
+                                          std::to_string(query_len));
+  return vdb_hip_index_search_batch(ix, query, 1, k, ef, mode, out_ids, out_scores, out_n);
+}
+
+// DistanceEngine::batch_distance (native/distance.rs:21-24) /
+// GpuAccelerator::batch_cosine_similarity|batch_euclidean_distance|batch_dot_product
+// (gpu/gpu_backend.rs:157,355,397)
+int32_t vdb_hip_batch_distance_dev(int32_t metric, int32_t kind, const float* d_query, const float* d_vecs,
+                                   uint64_t n, uint32_t dim, float* d_out, void* stream) {
+  if (metric < 0 || metric > 4 || (kind != 0 && kind != 1)) return fail(VDB_ERR_INVALID_ARG, "bad metric/kind");
+  if (n == 0 || dim == 0) return VDB_OK;  // gpu_backend.rs:163-169: empty in, empty out
+  if (!d_query || !d_vecs || !d_out) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  ScoreArgs a{};
+  a.query = d_query;
+  a.rows = d_vecs;
+  a.out = d_out;
+  a.n_rows = n;
+  a.dim = dim;
+  a.kind = kind;
+  a.aligned16 = (dim % 4 == 0 && ((uintptr_t)d_query % 16) == 0 && ((uintptr_t)d_vecs % 16) == 0) ? 1 : 0;
+  launch_score_rows(metric, a, reinterpret_cast<hipStream_t>(stream));
+  VDB_HIP(hipGetLastError());
+  return VDB_OK;
+}
+
+int32_t vdb_hip_batch_distance(int32_t device, int32_t metric, int32_t kind, const float* query, const float* vecs,
+                               uint64_t n, uint32_t dim, float* out) {
+  if (metric < 0 || metric > 4 || (kind != 0 && kind != 1)) return fail(VDB_ERR_INVALID_ARG, "bad metric/kind");
+  int32_t ndev = 0;
+  int32_t rc = check_device(&ndev);
+  if (rc != VDB_OK) return rc;
+  if (n == 0 || dim == 0) return VDB_OK;
+  if (!query || !vecs || !out) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (device < 0 || device >= ndev) return fail(VDB_ERR_INVALID_ARG, "bad device ordinal");
+  VDB_HIP(hipSetDevice(device));
+  float *dq = nullptr, *dv = nullptr, *dout = nullptr;
+  hipError_t e = hipMalloc(&dq, (size_t)dim * 4);
+  if (e == hipSuccess) e = hipMalloc(&dv, (size_t)n * dim * 4);
+  if (e == hipSuccess) e = hipMalloc(&dout, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMemcpy(dq, query, (size_t)dim * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dv, vecs, (size_t)n * dim * 4, hipMemcpyHostToDevice);
+  rc = VDB_OK;
+  if (e == hipSuccess) rc = vdb_hip_batch_distance_dev(metric, kind, dq, dv, n, dim, dout, nullptr);
+  if (e == hipSuccess && rc == VDB_OK) e = hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(dq);
+  (void)hipFree(dv);
+  (void)hipFree(dout);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? VDB_ERR_OOM : VDB_ERR_HIP,
+                                   std::string("batch_distance: ") + hipGetErrorString(e));
+  return rc;
+}
+
+int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* ix, float* ms, uint32_t* launches) {
+  if (!ix || !ms) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  double total = 0.0;
+  uint32_t cnt = 0;
+  for (size_t i = 0; i < ix->ev_used; i++) {
+    float t = 0.f;
+    if (hipEventSynchronize(ix->ev_pool[i].b) == hipSuccess &&
+        hipEventElapsedTime(&t, ix->ev_pool[i].a, ix->ev_pool[i].b) == hipSuccess) {
+      total += t;
+      cnt++;
+    }
+  }
+  *ms = cnt ? (float)(total / cnt) : 0.0f;
+  if (launches) *launches = cnt;
+  return VDB_OK;
+}
+
+int32_t vdb_hip_index_last_search_stats(vdb_hip_index* ix, uint64_t* n_dist, uint64_t* n_expand) {
+  if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  if (n_dist) *n_dist = ix->last_n_dist;
+  if (n_expand) *n_expand = ix->last_n_expand;
+  return VDB_OK;
+}
+
+}  // extern "C"

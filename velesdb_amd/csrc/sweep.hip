@@ -1,0 +1,531 @@
+// sweep.hip — exact "distance sweep + top-k" kernels (HnswIndex::search_brute_force,
+// crates/velesdb-core/src/index/hnsw/index/search.rs:176-219; brute_force_search_parallel,
+// batch.rs:223-244) and the score-all kernels behind DistanceEngine::batch_distance /
+// GpuAccelerator::batch_* (native/distance.rs:21-24; gpu/gpu_backend.rs:157,355,397).
+//
+// Design (MI355X-first, HBM-bound):
+//   * corpus rows are contiguous in HBM (row stride = dim rounded up to 4 floats), so a wave
+//     reads a row as float4 per lane: 1 KiB per load instruction, fully coalesced;
+//   * one wave owns whole rows: lane l keeps ONE fmaf chain per (row, query) over chunks
+//     l, l+64, ... (the canonical order) — queries live in VGPRs, rows are streamed once;
+//   * 64 (row,query) partials per lane are combined by a transposed xor-butterfly so each lane
+//     ends with one finished score: 63 shuffles per 64 scores instead of 384;
+//   * top-k is fused: each wave keeps a sorted k-list per query in LDS and only touches it
+//     when a score beats the current k-th best (ballot-driven, rare after warm-up);
+//   * per-wave lists go to HBM (k*8 B each) and a one-wave-per-query merge kernel finishes.
+// Algorithmic HBM bytes per launch: n_rows * dim * 4 (+ 4 B/row of norms for cosine).
+#include "vdb_device.hpp"
+#include "vdb_kernels.hpp"
+
+namespace vdb {
+
+enum Op : int { kOpDot = 0, kOpL2 = 1 };
+
+template <int OP>
+__device__ __forceinline__ float chain4(float acc, const float4& q, const float4& v) {
+  if (OP == kOpL2) {
+    float d0 = q.x - v.x, d1 = q.y - v.y, d2 = q.z - v.z, d3 = q.w - v.w;
+    acc = __builtin_fmaf(d0, d0, acc);
+    acc = __builtin_fmaf(d1, d1, acc);
+    acc = __builtin_fmaf(d2, d2, acc);
+    acc = __builtin_fmaf(d3, d3, acc);
+  } else {
+    acc = __builtin_fmaf(q.x, v.x, acc);
+    acc = __builtin_fmaf(q.y, v.y, acc);
+    acc = __builtin_fmaf(q.z, v.z, acc);
+    acc = __builtin_fmaf(q.w, v.w, acc);
+  }
+  return acc;
+}
+// tail chunk: only elements with index < dim exist
+template <int OP>
+__device__ __forceinline__ float chain4_tail(float acc, const float4& q, const float4& v, int nvalid) {
+  const float qa[4] = {q.x, q.y, q.z, q.w};
+  const float va[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    if (e < nvalid) {
+      if (OP == kOpL2) {
+        float d = qa[e] - va[e];
+        acc = __builtin_fmaf(d, d, acc);
+      } else {
+        acc = __builtin_fmaf(qa[e], va[e], acc);
+      }
+    }
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// final score of one (row, query) pair from the canonical sums
+template <int METRIC>
+__device__ __forceinline__ float finish_score(float sum, float qnorm, float vnorm) {
+  if (METRIC == kCosine) {
+    // simd_avx512.rs:344-351: dot / (sqrt(na) * sqrt(nb)); 0.0 if either norm is 0
+    if (qnorm == 0.0f || vnorm == 0.0f) return 0.0f;
+    return sum / (qnorm * vnorm);
+  } else if (METRIC == kEuclidean) {
+    return sqrtf(sum);  // simd_avx512.rs:119-121
+  } else {
+    return sum;
+  }
+}
+
+constexpr bool higher_is_better(int metric) {  // core/distance.rs:76-82
+  return metric == kCosine || metric == kDot || metric == kJaccard;
+}
+
+// ------------------------------------------------------------------------------------------
+// f32 sweep with fused top-k.  B = queries per pass (power of two <= 64), RPG = 64/B rows per
+// group, CPL = float4 chunks per lane (dim == CPL*256) or 0 for any dim (generic, slower).
+// grid.x * 4 waves; wave w owns row groups w, w+W, ...   LDS: lists[4][B][k] u64 + cnt[4][B].
+// ------------------------------------------------------------------------------------------
+template <int METRIC, int B, int CPL>
+__global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
+  constexpr int OP = (METRIC == kEuclidean) ? kOpL2 : kOpDot;
+  constexpr int RPG = 64 / B;
+  constexpr bool HIB = higher_is_better(METRIC);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int wib = (int)(threadIdx.x >> 6);
+  const uint32_t wave = blockIdx.x * 4 + wib;
+  const uint32_t nwaves = gridDim.x * 4;
+  const uint32_t k = a.k;
+  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * B * k;
+  uint32_t* cnts = reinterpret_cast<uint32_t*>(smem + (size_t)4 * B * k * 8) + wib * B;
+  float* qgen = reinterpret_cast<float*>(smem + (size_t)4 * B * k * 8 + 4 * B * 4);  // generic path only
+  if (lane < B) cnts[lane] = 0;
+
+  const int d4 = (int)((a.dim + 3) / 4);  // chunks per row
+  // ---- queries into registers (CPL>0) or LDS (generic), plus their canonical norms ----
+  float4 q[B][CPL > 0 ? CPL : 1];
+  float qnorm_mine = 0.0f;  // lane l keeps the norm of query (l % B)
+  if (CPL > 0) {
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      float nacc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < CPL; j++) {
+        q[b][j] = (b < (int)a.nq) ? ld4(a.queries + (size_t)b * a.q_stride + (size_t)(j * 64 + lane) * 4)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        nacc = chain4<kOpDot>(nacc, q[b][j], q[b][j]);
+      }
+      if (METRIC == kCosine) {
+        float n = sqrtf(butterfly_all(nacc));
+        if ((lane % B) == b) qnorm_mine = n;
+      }
+    }
+  } else {
+    // generic: stage queries (zero padded to d4*4) in LDS, shared by the 4 waves
+    const int qlen = d4 * 4;
+    for (int i = threadIdx.x; i < B * qlen; i += 256) {
+      int b = i / qlen, e = i % qlen;
+      qgen[i] = (b < (int)a.nq && e < (int)a.dim) ? a.queries[(size_t)b * a.q_stride + e] : 0.0f;
+    }
+    __syncthreads();
+    if (METRIC == kCosine) {
+      for (int b = 0; b < B; b++) {
+        float nacc = 0.0f;
+        for (int c = lane; c < d4; c += 64) {
+          float4 x = ld4(qgen + (size_t)b * qlen + c * 4);
+          int nv = (int)a.dim - c * 4;
+          nacc = nv >= 4 ? chain4<kOpDot>(nacc, x, x) : chain4_tail<kOpDot>(nacc, x, x, nv);
+        }
+        float n = sqrtf(butterfly_all(nacc));
+        if ((lane % B) == b) qnorm_mine = n;
+      }
+    }
+  }
+
+  const uint32_t ngroups = (a.n_rows + RPG - 1) / RPG;
+  for (uint32_t g = wave; g < ngroups; g += nwaves) {
+    float acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) acc[i] = 0.0f;
+    const uint32_t row0 = g * RPG;
+    if (CPL > 0) {
+      constexpr int RB = (RPG >= 4) ? 4 : RPG;  // rows loaded together
+#pragma unroll
+      for (int r = 0; r < RPG; r += RB) {
+        float4 v[RB][CPL > 0 ? CPL : 1];
+#pragma unroll
+        for (int rr = 0; rr < RB; rr++) {
+          uint32_t row = row0 + r + rr;
+          row = row < a.n_rows ? row : a.n_rows - 1;  // tail rows: re-read the last row, masked later
+          const float* p = a.rows + (size_t)row * a.row_stride + (size_t)lane * 4;
+#pragma unroll
+          for (int j = 0; j < CPL; j++) v[rr][j] = ld4(p + j * 256);
+        }
+#pragma unroll
+        for (int rr = 0; rr < RB; rr++)
+#pragma unroll
+          for (int b = 0; b < B; b++) {
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < CPL; j++) s = chain4<OP>(s, q[b][j], v[rr][j]);
+            acc[(r + rr) * B + b] = s;
+          }
+      }
+    } else {
+      const int qlen = d4 * 4;
+#pragma unroll
+      for (int r = 0; r < RPG; r++) {
+        uint32_t row = row0 + r;
+        row = row < a.n_rows ? row : a.n_rows - 1;
+        const float* p = a.rows + (size_t)row * a.row_stride;
+        for (int c = lane; c < d4; c += 64) {
+          float4 x = ld4(p + c * 4);
+          int nv = (int)a.dim - c * 4;
+#pragma unroll
+          for (int b = 0; b < B; b++) {
+            float4 qq = ld4(qgen + (size_t)b * qlen + c * 4);
+            acc[r * B + b] = nv >= 4 ? chain4<OP>(acc[r * B + b], qq, x) : chain4_tail<OP>(acc[r * B + b], qq, x, nv);
+          }
+        }
+      }
+    }
+    treduce64(acc, lane);
+    // lane l now owns pair idx = l: row r = l / B, query b = l % B
+    const int b = lane % B;
+    const uint32_t row = row0 + lane / B;
+    bool valid = row < a.n_rows && b < (int)a.nq;
+    if (valid && a.alive) valid = a.alive[row] != 0;
+    float vnorm = 1.0f;
+    if (METRIC == kCosine && valid) vnorm = a.norms[row];
+    const float score = finish_score<METRIC>(acc[0], qnorm_mine, vnorm);
+    const uint64_t key = valid ? make_key<HIB>(score, row) : kKeyInvalid;
+    const uint32_t c_b = cnts[b];
+    const uint64_t tau = (c_b == k) ? lists[(size_t)b * k + (k - 1)] : kKeyInvalid;
+    uint64_t mask = __ballot(key < tau);
+    while (mask) {
+      const int src = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const uint64_t kk = readlane64(key, src);
+      const int bb = src % B;
+      uint32_t c = cnts[bb];
+      wave_list_insert(lists + (size_t)bb * k, c, k, kk, lane);
+      if (lane == 0) cnts[bb] = c;
+    }
+  }
+  // ---- per-wave lists to HBM: part_keys[q][wave][k], part_cnt[q][wave] ----
+  for (int b = 0; b < (int)a.nq && b < B; b++) {
+    const uint32_t c = cnts[b];
+    uint64_t* dst = a.part_keys + ((size_t)b * nwaves + wave) * k;
+    for (uint32_t e = lane; e < c; e += 64) dst[e] = lists[(size_t)b * k + e];
+    if (lane == 0) a.part_cnt[(size_t)b * nwaves + wave] = c;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// merge: one wave per query scans the per-wave lists with the same threshold + insert scheme
+// and writes ids / scores best-first.
+// ------------------------------------------------------------------------------------------
+template <bool HIB>
+__global__ __launch_bounds__(64) void merge_topk(MergeArgs m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem);
+  const int lane = lane_id();
+  const uint32_t qi = blockIdx.x;
+  const uint32_t k = m.k;
+  uint32_t cnt = 0;
+  const uint64_t* keys = m.part_keys + (size_t)qi * m.n_lists * k;
+  const uint32_t* pc = m.part_cnt + (size_t)qi * m.n_lists;
+  const uint64_t total = (uint64_t)m.n_lists * k;
+  for (uint64_t base = 0; base < total; base += 64) {
+    const uint64_t i = base + lane;
+    uint64_t key = kKeyInvalid;
+    if (i < total) {
+      const uint32_t l = (uint32_t)(i / k), e = (uint32_t)(i % k);
+      if (e < pc[l]) key = keys[i];
+    }
+    const uint64_t tau = (cnt == k) ? list[k - 1] : kKeyInvalid;
+    uint64_t mask = __ballot(key < tau);
+    while (mask) {
+      const int src = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      wave_list_insert(list, cnt, k, readlane64(key, src), lane);
+    }
+  }
+  for (uint32_t e = lane; e < k; e += 64) {
+    if (e < cnt) {
+      const uint64_t key = list[e];
+      const uint32_t row = key_row(key);
+      const float s = key_score<HIB>(key);  // raw compute_distance value (search.rs:209)
+      m.out_ids[(size_t)qi * k + e] = m.ext_ids ? m.ext_ids[row] : (uint64_t)row + m.row_base;
+      m.out_scores[(size_t)qi * k + e] = s;
+    } else {
+      m.out_ids[(size_t)qi * k + e] = ~0ull;
+      m.out_scores[(size_t)qi * k + e] = __uint_as_float(0x7FC00000u);
+    }
+  }
+  if (lane == 0) m.out_n[qi] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------
+// packed-bit sweep for Hamming / Jaccard (simd_explicit.rs:234-287,372-443 on the exact
+// re-encoding bit = (x > 0.5)).  Lane per row; grid.y = query.  Rows are W words (16-B
+// aligned), read as dwordx4.  Algorithmic bytes per launch: n_rows * W * 4 per query.
+// ------------------------------------------------------------------------------------------
+template <int METRIC>
+__global__ __launch_bounds__(256) void sweep_topk_bits(BitsArgs a) {
+  constexpr bool HIB = higher_is_better(METRIC);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int wib = (int)(threadIdx.x >> 6);
+  const uint32_t wave = blockIdx.x * 4 + wib;
+  const uint32_t nwaves = gridDim.x * 4;
+  const uint32_t qi = blockIdx.y;
+  const uint32_t k = a.k;
+  const uint32_t W = a.words;  // multiple of 4
+  volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k;
+  uint32_t* qw = reinterpret_cast<uint32_t*>(smem + (size_t)4 * k * 8);
+  for (uint32_t i = threadIdx.x; i < W; i += 256) qw[i] = a.qbits[(size_t)qi * W + i];
+  __syncthreads();
+  uint32_t cnt = 0;
+  for (uint64_t base = (uint64_t)wave * 64; base < a.n_rows; base += (uint64_t)nwaves * 64) {
+    const uint32_t row = (uint32_t)base + lane;
+    bool valid = row < a.n_rows;
+    if (valid && a.alive) valid = a.alive[row] != 0;
+    uint32_t ham = 0, inter = 0, uni = 0;
+    if (valid) {
+      const uint4* p = reinterpret_cast<const uint4*>(a.bits + (size_t)row * W);
+      for (uint32_t w = 0; w < W; w += 4) {
+        const uint4 x = p[w / 4];
+        const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const uint32_t qq = qw[w + e];
+          if (METRIC == kHamming) {
+            ham += __popc(xs[e] ^ qq);
+          } else {
+            inter += __popc(xs[e] & qq);
+            uni += __popc(xs[e] | qq);
+          }
+        }
+      }
+    }
+    float score;
+    if (METRIC == kHamming) {
+      score = (float)ham;
+    } else {
+      score = (uni == 0) ? 1.0f : (float)inter / (float)uni;  // simd_explicit.rs:431-442
+    }
+    const uint64_t key = valid ? make_key<HIB>(score, row) : kKeyInvalid;
+    const uint64_t tau = (cnt == k) ? list[k - 1] : kKeyInvalid;
+    uint64_t mask = __ballot(key < tau);
+    while (mask) {
+      const int src = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      wave_list_insert(list, cnt, k, readlane64(key, src), lane);
+    }
+  }
+  uint64_t* dst = a.part_keys + ((size_t)qi * nwaves + wave) * k;
+  for (uint32_t e = lane; e < cnt; e += 64) dst[e] = list[e];
+  if (lane == 0) a.part_cnt[(size_t)qi * nwaves + wave] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------
+// Insert-time row preparation: canonical norms (cosine) and packed threshold bits.
+// One wave per row.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_rows(PrepArgs a) {
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4;
+  const int d4 = (int)((a.dim + 3) / 4);
+  for (uint32_t r = wave; r < a.n_rows; r += nwaves) {
+    const uint32_t row = a.row0 + r;
+    const float* p = a.rows + (size_t)row * a.row_stride;
+    if (a.norms) {
+      float acc = 0.0f;
+      for (int c = lane; c < d4; c += 64) {
+        float4 x = ld4(p + c * 4);
+        int nv = (int)a.dim - c * 4;
+        acc = nv >= 4 ? chain4<kOpDot>(acc, x, x) : chain4_tail<kOpDot>(acc, x, x, nv);
+      }
+      float n = sqrtf(butterfly_all(acc));
+      if (lane == 0) a.norms[row] = n;
+    }
+    if (a.bits) {
+      uint32_t* dst = a.bits + (size_t)row * a.words;
+      for (uint32_t e0 = 0; e0 < a.words * 32; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        const bool bit = e < a.dim && p[e] > 0.5f;  // NaN > 0.5 is false, as on the CPU
+        const uint64_t m = __ballot(bit);
+        if (lane == 0) {
+          dst[e0 / 32] = (uint32_t)m;
+          if (e0 / 32 + 1 < a.words) dst[e0 / 32 + 1] = (uint32_t)(m >> 32);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// score-all kernel: DistanceEngine::batch_distance / GpuAccelerator::batch_* over an arbitrary
+// row-major buffer (row stride = dim, any alignment >= 4 B handled by the scalar path).
+// One wave per row; every metric computed from the raw f32 rows.
+// ------------------------------------------------------------------------------------------
+template <int METRIC>
+__global__ __launch_bounds__(256) void score_rows(ScoreArgs a) {
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4;
+  const int d4 = (int)((a.dim + 3) / 4);
+  const bool vec_ok = a.aligned16 != 0;
+  // query norm (cosine)
+  float qn = 0.0f;
+  if (METRIC == kCosine) {
+    float acc = 0.0f;
+    for (int c = lane; c < d4; c += 64)
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        int i = c * 4 + e;
+        if (i < (int)a.dim) acc = __builtin_fmaf(a.query[i], a.query[i], acc);
+      }
+    qn = sqrtf(butterfly_all(acc));
+  }
+  for (uint64_t r = wave; r < a.n_rows; r += nwaves) {
+    const float* p = a.rows + (size_t)r * a.dim;
+    float out;
+    if (METRIC == kHamming || METRIC == kJaccard) {
+      uint32_t ham = 0, inter = 0, uni = 0;
+      for (uint32_t e0 = 0; e0 < a.dim; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        const bool x = e < a.dim && p[e] > 0.5f;
+        const bool y = e < a.dim && a.query[e] > 0.5f;
+        ham += (uint32_t)__popcll(__ballot(x != y));
+        inter += (uint32_t)__popcll(__ballot(x && y));
+        uni += (uint32_t)__popcll(__ballot(x || y));
+      }
+      if (METRIC == kHamming) {
+        out = (float)ham;
+      } else {
+        float sim = (uni == 0) ? 1.0f : (float)inter / (float)uni;
+        out = (a.kind == 0) ? 1.0f - sim : sim;  // native/distance.rs:83
+      }
+    } else {
+      constexpr int OP = (METRIC == kEuclidean) ? kOpL2 : kOpDot;
+      float acc = 0.0f, nacc = 0.0f;
+      for (int c = lane; c < d4; c += 64) {
+        float4 x, qq;
+        int nv = (int)a.dim - c * 4;
+        if (vec_ok && nv >= 4) {
+          x = ld4(p + c * 4);
+          qq = ld4(a.query + c * 4);
+        } else {
+          float xa[4] = {0, 0, 0, 0}, qa[4] = {0, 0, 0, 0};
+          for (int e = 0; e < 4 && e < nv; e++) {
+            xa[e] = p[c * 4 + e];
+            qa[e] = a.query[c * 4 + e];
+          }
+          x = make_float4(xa[0], xa[1], xa[2], xa[3]);
+          qq = make_float4(qa[0], qa[1], qa[2], qa[3]);
+        }
+        if (nv >= 4) {
+          acc = chain4<OP>(acc, qq, x);
+          if (METRIC == kCosine) nacc = chain4<kOpDot>(nacc, x, x);
+        } else {
+          acc = chain4_tail<OP>(acc, qq, x, nv);
+          if (METRIC == kCosine) nacc = chain4_tail<kOpDot>(nacc, x, x, nv);
+        }
+      }
+      float sum = butterfly_all(acc);
+      float vn = 1.0f;
+      if (METRIC == kCosine) vn = sqrtf(butterfly_all(nacc));
+      float s = finish_score<METRIC>(sum, qn, vn);
+      if (a.kind == 0) {  // DistanceEngine::distance (native/distance.rs:78-80)
+        if (METRIC == kCosine) s = 1.0f - s;
+        if (METRIC == kDot) s = -s;
+      }
+      out = s;
+    }
+    if (lane == 0) a.out[r] = out;
+  }
+}
+
+// ---- host-callable launchers ------------------------------------------------------------
+template <int METRIC, int B, int CPL>
+static void launch_sweep_t(const SweepArgs& a, int blocks, size_t lds, hipStream_t st) {
+  hipLaunchKernelGGL((sweep_topk_f32<METRIC, B, CPL>), dim3(blocks), dim3(256), lds, st, a);
+}
+template <int METRIC, int B>
+static void launch_sweep_cpl(const SweepArgs& a, int cpl, int blocks, size_t lds, hipStream_t st) {
+  switch (cpl) {
+    case 1: launch_sweep_t<METRIC, B, 1>(a, blocks, lds, st); break;
+    case 2: launch_sweep_t<METRIC, B, 2>(a, blocks, lds, st); break;
+    case 3: launch_sweep_t<METRIC, B, 3>(a, blocks, lds, st); break;
+    case 4: launch_sweep_t<METRIC, B, 4>(a, blocks, lds, st); break;
+    default: launch_sweep_t<METRIC, B, 0>(a, blocks, lds, st); break;
+  }
+}
+template <int METRIC>
+static void launch_sweep_b(const SweepArgs& a, int B, int cpl, int blocks, size_t lds, hipStream_t st) {
+  switch (B) {
+    case 1: launch_sweep_cpl<METRIC, 1>(a, cpl, blocks, lds, st); break;
+    case 2: launch_sweep_cpl<METRIC, 2>(a, cpl, blocks, lds, st); break;
+    case 4: launch_sweep_cpl<METRIC, 4>(a, cpl, blocks, lds, st); break;
+    default: launch_sweep_cpl<METRIC, 8>(a, cpl, blocks, lds, st); break;
+  }
+}
+
+size_t sweep_lds_bytes(int B, uint32_t k, uint32_t dim, int cpl) {
+  size_t s = (size_t)4 * B * k * 8 + (size_t)4 * B * 4;
+  if (cpl == 0) s += (size_t)B * ((dim + 3) / 4) * 16;
+  return (s + 15) & ~(size_t)15;
+}
+
+int sweep_cpl_for_dim(uint32_t dim) {
+  if (dim % 256 != 0) return 0;
+  int c = (int)(dim / 256);
+  return (c >= 1 && c <= 4) ? c : 0;
+}
+
+void launch_sweep_f32(int metric, int B, const SweepArgs& a, int blocks, hipStream_t st) {
+  const int cpl = sweep_cpl_for_dim(a.dim);
+  const size_t lds = sweep_lds_bytes(B, a.k, a.dim, cpl);
+  switch (metric) {
+    case kCosine: launch_sweep_b<kCosine>(a, B, cpl, blocks, lds, st); break;
+    case kEuclidean: launch_sweep_b<kEuclidean>(a, B, cpl, blocks, lds, st); break;
+    default: launch_sweep_b<kDot>(a, B, cpl, blocks, lds, st); break;
+  }
+}
+
+void launch_merge(bool hib, const MergeArgs& m, uint32_t nq, hipStream_t st) {
+  const size_t lds = ((size_t)m.k * 8 + 15) & ~(size_t)15;
+  if (hib)
+    hipLaunchKernelGGL((merge_topk<true>), dim3(nq), dim3(64), lds, st, m);
+  else
+    hipLaunchKernelGGL((merge_topk<false>), dim3(nq), dim3(64), lds, st, m);
+}
+
+void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st) {
+  const size_t lds = (((size_t)4 * a.k * 8 + (size_t)a.words * 4) + 15) & ~(size_t)15;
+  if (metric == kHamming)
+    hipLaunchKernelGGL((sweep_topk_bits<kHamming>), dim3(blocks, nq), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL((sweep_topk_bits<kJaccard>), dim3(blocks, nq), dim3(256), lds, st, a);
+}
+
+void launch_prep_rows(const PrepArgs& a, hipStream_t st) {
+  if (a.n_rows == 0) return;
+  int blocks = (int)((a.n_rows + 3) / 4);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(prep_rows, dim3(blocks), dim3(256), 0, st, a);
+}
+
+void launch_score_rows(int metric, const ScoreArgs& a, hipStream_t st) {
+  if (a.n_rows == 0) return;
+  uint64_t want = (a.n_rows + 3) / 4;
+  int blocks = (int)(want > 4096 ? 4096 : want);
+  switch (metric) {
+    case kCosine: hipLaunchKernelGGL((score_rows<kCosine>), dim3(blocks), dim3(256), 0, st, a); break;
+    case kEuclidean: hipLaunchKernelGGL((score_rows<kEuclidean>), dim3(blocks), dim3(256), 0, st, a); break;
+    case kDot: hipLaunchKernelGGL((score_rows<kDot>), dim3(blocks), dim3(256), 0, st, a); break;
+    case kHamming: hipLaunchKernelGGL((score_rows<kHamming>), dim3(blocks), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((score_rows<kJaccard>), dim3(blocks), dim3(256), 0, st, a); break;
+  }
+}
+
+}  // namespace vdb

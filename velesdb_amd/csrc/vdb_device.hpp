@@ -1,0 +1,116 @@
+// vdb_device.hpp — device-side building blocks shared by every kernel of libvelesdb_hip.
+// gfx950 (MI355X, CDNA4) only: 64-wide wavefronts are assumed everywhere.
+//
+// CANONICAL ARITHMETIC ("mode C" of the oracle, oracle/vdb_oracle.cpp reduceC/butterfly64)
+//   For a pair of f32 vectors of length n
+//     * element i belongs to float4-chunk c = i/4; chunk c belongs to lane c % 64
+//     * every lane runs ONE fmaf chain from +0.0f over its elements in increasing i
+//       (elements i >= n do not exist: tails are predicated, never zero-padded into the chain)
+//     * lanes are combined with the xor butterfly 32,16,8,4,2,1 : t[l] = t[l] + t[l^s]
+//   f32 add is commutative, so a kernel may run the butterfly "transposed" (64 values per lane
+//   in, one finished value per lane out) and still produce the same bits.
+//   No fast-math anywhere; fma only where written; sqrt and divide correctly rounded.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vdb {
+
+constexpr int kWave = 64;
+constexpr uint64_t kKeyInvalid = ~0ull;
+
+enum Metric : int { kCosine = 0, kEuclidean = 1, kDot = 2, kHamming = 3, kJaccard = 4 };
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ float shx(float v, int s) { return __shfl_xor(v, s, 64); }
+
+// every lane ends with the canonical sum of the 64 per-lane partials
+__device__ __forceinline__ float butterfly_all(float t) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) t = t + shx(t, s);
+  return t;
+}
+
+// Transposed butterfly: N = 64 partials per lane in a[0..N); lane l finishes with the canonical
+// 64-lane sum of partial index l in a[0].  Stage s pairs lane bit s with index bit s.
+template <int N, int S>
+struct TReduce {
+  static __device__ __forceinline__ void run(float* a, int lane) {
+    constexpr int H = N / 2;
+    const bool up = (lane & S) != 0;
+#pragma unroll
+    for (int i = 0; i < H; i++) {
+      const float keep = up ? a[i + H] : a[i];
+      const float send = up ? a[i] : a[i + H];
+      a[i] = keep + shx(send, S);
+    }
+    TReduce<H, S / 2>::run(a, lane);
+  }
+};
+template <int S>
+struct TReduce<1, S> {
+  static __device__ __forceinline__ void run(float*, int) {}
+};
+__device__ __forceinline__ void treduce64(float* a, int lane) { TReduce<64, 32>::run(a, lane); }
+
+// ---- IEEE total order keys (f32::total_cmp; native/ordered_float.rs:31-36) --------------
+// asc_key: u32 whose unsigned order equals total_cmp order.
+__device__ __forceinline__ uint32_t asc_key(float f) {
+  uint32_t b = __float_as_uint(f);
+  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float asc_key_inv(uint32_t k) {
+  uint32_t b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+  return __uint_as_float(b);
+}
+// 64-bit selection key: smaller = better; ties broken by row index ascending.
+template <bool HIGHER_IS_BETTER>
+__device__ __forceinline__ uint64_t make_key(float score, uint32_t row) {
+  uint32_t k = asc_key(score);
+  if (HIGHER_IS_BETTER) k = ~k;
+  return ((uint64_t)k << 32) | row;
+}
+template <bool HIGHER_IS_BETTER>
+__device__ __forceinline__ float key_score(uint64_t key) {
+  uint32_t k = (uint32_t)(key >> 32);
+  if (HIGHER_IS_BETTER) k = ~k;
+  return asc_key_inv(k);
+}
+__device__ __forceinline__ uint32_t key_row(uint64_t key) { return (uint32_t)key; }
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
+  uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, src);
+  uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// ---- wave-owned sorted top-k list in LDS -------------------------------------------------
+// list[0..*cnt) ascending u64 keys, capacity k.  All 64 lanes call together with a
+// wave-uniform key.  Returns nothing; *cnt is updated by lane 0 semantics (uniform value).
+__device__ __forceinline__ void wave_list_insert(volatile uint64_t* list, uint32_t& cnt, uint32_t k,
+                                                 uint64_t key, int lane) {
+  if (cnt == k && key >= list[k - 1]) return;  // uniform
+  // position = number of elements < key
+  uint32_t pos = 0;
+  for (uint32_t c = 0; c < cnt; c += 64) {
+    uint32_t e = c + lane;
+    bool less = e < cnt && list[e] < key;
+    pos += (uint32_t)__popcll(__ballot(less));
+  }
+  const uint32_t newcnt = cnt < k ? cnt + 1 : k;
+  // shift [pos, newcnt-1) up by one, top chunk first
+  if (newcnt - 1 > pos) {
+    const uint32_t span = newcnt - 1 - pos;  // elements to move: pos .. newcnt-2
+    for (int32_t c = (int32_t)((span - 1) / 64) * 64; c >= 0; c -= 64) {
+      uint32_t e = pos + (uint32_t)c + lane;
+      bool mv = e < newcnt - 1;
+      uint64_t v = mv ? list[e] : 0;
+      if (mv) list[e + 1] = v;
+    }
+  }
+  if (lane == 0) list[pos] = key;
+  cnt = newcnt;
+}
+
+}  // namespace vdb

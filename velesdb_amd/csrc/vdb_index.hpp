@@ -1,0 +1,102 @@
+// vdb_index.hpp — host-side index object behind the C ABI (include/velesdb_hip.h).
+// Mirrors the state of the reference's HnswIndex (index/hnsw/index/mod.rs:93-131):
+// id mappings (sharded_mappings.rs:32-93), vector storage, and the graph — except that
+// vectors and adjacency live in HBM, contiguous (the reference keeps Vec<Vec<f32>>,
+// native/graph.rs:22).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/velesdb_hip.h"
+
+namespace vdb {
+
+void set_last_error(const std::string& s);
+int32_t fail(int32_t code, const std::string& msg);
+bool hip_ok(hipError_t e, const char* what);
+
+#define VDB_HIP(call)                                                  \
+  do {                                                                 \
+    hipError_t _e = (call);                                            \
+    if (_e != hipSuccess) {                                            \
+      return ::vdb::fail(VDB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e)); \
+    }                                                                  \
+  } while (0)
+
+// growable device buffer (never shrinks); content preserved on growth when keep=true
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes, bool keep, hipStream_t st);
+  void release();
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+struct GraphLayer {
+  DevBuf nbr;  // [capacity][stride] u32
+  DevBuf cnt;  // [capacity] u32
+  uint32_t stride = 0;
+};
+
+struct EventPair {
+  hipEvent_t a = nullptr, b = nullptr;
+};
+
+}  // namespace vdb
+
+struct vdb_hip_index {
+  int device = 0;
+  int n_cus = 256;
+  uint32_t dim = 0;
+  int metric = 0;
+  uint32_t M = 0, M0 = 0, efc = 0;
+  uint64_t row_stride = 0;  // floats
+  uint32_t words = 0;       // packed-bit words per row (multiple of 4)
+  uint64_t capacity = 0;    // rows allocated
+  uint64_t n_rows = 0;      // rows/nodes present (including soft-deleted)
+  hipStream_t stream = nullptr;
+
+  vdb::DevBuf rows, norms, bits, alive, ext_ids;
+  // graph
+  std::vector<vdb::GraphLayer> layers;
+  bool graph_valid = true;   // false once rows exist that are not linked into the graph
+  int64_t entry_point = -1;
+  uint32_t max_layer = 0;
+  uint64_t graph_nodes = 0;  // nodes linked
+  uint64_t rng_state = 0x5DEECE66D1A4B5B5ull;  // native/graph.rs:72
+
+  // id mappings (host)
+  std::unordered_map<uint64_t, uint64_t> id_to_idx;
+  std::vector<uint64_t> idx_to_id;
+  std::vector<uint8_t> idx_live;
+  uint64_t live = 0;
+  bool any_dead = false;
+
+  // scratch
+  vdb::DevBuf s_queries, s_part_keys, s_part_cnt, s_out_ids, s_out_scores, s_out_n, s_qbits, s_misc;
+  std::vector<vdb::EventPair> ev_pool;
+  size_t ev_used = 0;
+  uint64_t last_n_dist = 0, last_n_expand = 0;
+
+  mutable std::mutex mu;
+};
+
+namespace vdb {
+// index.hip
+int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want);
+int32_t append_host_rows(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, uint64_t n, uint64_t* inserted,
+                         uint64_t* first_row);
+// graph.hip
+int32_t ensure_layers(vdb_hip_index* ix, uint32_t num_layers);
+int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint32_t ef,
+                        uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st);
+int32_t graph_insert_rows(vdb_hip_index* ix, uint64_t first, uint64_t n);
+}  // namespace vdb

@@ -1,0 +1,316 @@
+"""Host-side mirror of the reference's operator interface for the hot path, over the C ABI.
+
+`HnswIndex` has the surface of crates/velesdb-core/src/index/hnsw/index/*.rs (the concrete
+type `Collection` holds, core/collection/types.rs:146) and implements `VectorIndex`
+(index/mod.rs:30-83): same method names, argument meaning, result conventions and panics
+(as AssertionError with the reference's message).  `HipDistance` mirrors `DistanceEngine`
+(native/distance.rs:14-28) and `GpuAccelerator` mirrors gpu/gpu_backend.rs:33-415.
+
+All compute happens in libvelesdb_hip.so; this file only marshals numpy buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, lib
+from .params import DistanceMetric, HnswParams, SearchQuality
+
+MODE_AUTO, MODE_BRUTE, MODE_HNSW = 0, 1, 2
+KIND_ENGINE, KIND_RAW = 0, 1
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    check(lib().vdb_hip_device_count(C.byref(n)))
+    return int(n.value)
+
+
+def device_name(device: int = 0) -> str:
+    buf = C.create_string_buffer(256)
+    check(lib().vdb_hip_device_name(device, buf, 256))
+    return buf.value.decode()
+
+
+def set_kernel_timing(on: bool) -> None:
+    check(lib().vdb_hip_set_kernel_timing(1 if on else 0))
+
+
+class HnswIndex:
+    """HNSW index whose vectors, graph and search run on one MI355X."""
+
+    def __init__(self, dimension: int, metric: DistanceMetric, params: Optional[HnswParams] = None,
+                 device: int = 0):
+        # HnswIndex::new / with_params — constructors.rs:28-32,117-160
+        self._h = C.c_void_p()
+        self._dimension = int(dimension)
+        self._metric = DistanceMetric(metric)
+        self.params = params or HnswParams.auto(dimension)
+        check(lib().vdb_hip_index_create(dimension, int(self._metric), self.params.max_connections,
+                                         self.params.ef_construction, self.params.max_elements, device,
+                                         C.byref(self._h)))
+
+    @classmethod
+    def with_params(cls, dimension, metric, params, device=0):
+        return cls(dimension, metric, params, device)
+
+    @classmethod
+    def new_turbo(cls, dimension, metric, device=0):  # constructors.rs:86-91
+        p = HnswParams.auto(dimension)
+        return cls(dimension, metric, HnswParams(p.max_connections, p.ef_construction * 3 // 2, p.max_elements), device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().vdb_hip_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- VectorIndex ------------------------------------------------------------------
+    def insert(self, id: int, vector) -> None:
+        """VectorIndex::insert (index/mod.rs:46).  Duplicate ids are skipped silently."""
+        v = _f32(vector).reshape(-1)
+        assert v.size == self._dimension, \
+            f"Vector dimension mismatch: expected {self._dimension}, got {v.size}"  # trait_impl.rs:12-18
+        check(lib().vdb_hip_index_insert(self._h, int(id), _ptr(v), v.size))
+
+    def search(self, query, k: int) -> List[Tuple[int, float]]:
+        """VectorIndex::search (index/mod.rs:58) = search_with_quality(Balanced) (trait_impl.rs:38-42)."""
+        return self.search_with_quality(query, k, SearchQuality.Balanced)
+
+    def remove(self, id: int) -> bool:
+        r = C.c_int32(0)
+        check(lib().vdb_hip_index_remove(self._h, int(id), C.byref(r)))
+        return bool(r.value)
+
+    def len(self) -> int:
+        n = C.c_uint64(0)
+        check(lib().vdb_hip_index_len(self._h, C.byref(n)))
+        return int(n.value)
+
+    __len__ = len
+
+    def is_empty(self) -> bool:
+        return self.len() == 0
+
+    def dimension(self) -> int:
+        return self._dimension
+
+    def metric(self) -> DistanceMetric:
+        return self._metric
+
+    # ---- HnswIndex inherent methods ----------------------------------------------------
+    def _validate(self, q: np.ndarray, what="Query"):
+        assert q.shape[-1] == self._dimension, \
+            f"{what} dimension mismatch: expected {self._dimension}, got {q.shape[-1]}"  # search.rs:16-23
+
+    def _search_raw(self, queries: np.ndarray, k: int, ef: int, mode: int):
+        nq = queries.shape[0]
+        kk = max(k, 1)
+        ids = np.empty((nq, kk), dtype=np.uint64)
+        sc = np.empty((nq, kk), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        check(lib().vdb_hip_index_search_batch(self._h, _ptr(queries), nq, k, ef, mode, _ptr(ids), _ptr(sc),
+                                               _ptr(cnt)))
+        return ids, sc, cnt
+
+    @staticmethod
+    def _tuples(ids, sc, n) -> List[Tuple[int, float]]:
+        return [(int(ids[i]), float(sc[i])) for i in range(int(n))]
+
+    def search_with_quality(self, query, k: int, quality: SearchQuality) -> List[Tuple[int, float]]:
+        """search.rs:59-94."""
+        q = _f32(query).reshape(1, -1)
+        self._validate(q)
+        if quality.kind == "perfect":  # search.rs:68-70
+            ids, sc, cnt = self._search_raw(q, k, 0, MODE_BRUTE)
+        else:
+            ids, sc, cnt = self._search_raw(q, k, quality.ef_search(k), MODE_AUTO)
+        return self._tuples(ids[0], sc[0], cnt[0])
+
+    def search_brute_force(self, query, k: int) -> List[Tuple[int, float]]:
+        """search.rs:176-219: exact scan, raw scores, metric.sort_results order."""
+        q = _f32(query).reshape(1, -1)
+        self._validate(q)
+        ids, sc, cnt = self._search_raw(q, k, 0, MODE_BRUTE)
+        return self._tuples(ids[0], sc[0], cnt[0])
+
+    search_brute_force_buffered = search_brute_force  # search.rs:367-370
+    brute_force_search_parallel = search_brute_force  # batch.rs:223-244 (same result contract)
+
+    def search_brute_force_gpu(self, query, k: int) -> Optional[List[Tuple[int, float]]]:
+        """search.rs:229-279: None when no GPU is available."""
+        if device_count() == 0:
+            return None
+        return self.search_brute_force(query, k)
+
+    def search_batch_parallel(self, queries, k: int, quality: SearchQuality) -> List[List[Tuple[int, float]]]:
+        """batch.rs:159-197: always the graph, one launch for the whole batch."""
+        qs = _f32(queries)
+        if qs.ndim == 1:
+            qs = qs.reshape(1, -1)
+        if qs.shape[0] == 0:
+            return []
+        for i in range(qs.shape[0]):
+            assert qs.shape[1] == self._dimension, \
+                f"Query {i} dimension mismatch: expected {self._dimension}, got {qs.shape[1]}"
+        ids, sc, cnt = self._search_raw(qs, k, quality.ef_search(k), MODE_HNSW)
+        return [self._tuples(ids[i], sc[i], cnt[i]) for i in range(qs.shape[0])]
+
+    def search_batch_brute_force(self, queries, k: int):
+        """Batched exact search (one corpus pass per tile of queries); numpy outputs."""
+        qs = _f32(queries)
+        if qs.ndim == 1:
+            qs = qs.reshape(1, -1)
+        self._validate(qs)
+        return self._search_raw(qs, k, 0, MODE_BRUTE)
+
+    def insert_batch_sequential(self, vectors: Iterable[Tuple[int, Sequence[float]]]) -> int:
+        """batch.rs:128-149."""
+        items = list(vectors)
+        if not items:
+            return 0
+        ids = np.ascontiguousarray([i for i, _ in items], dtype=np.uint64)
+        for _, v in items:
+            assert len(v) == self._dimension, \
+                f"Vector dimension mismatch: expected {self._dimension}, got {len(v)}"
+        vecs = _f32([v for _, v in items])
+        n = C.c_uint64(0)
+        check(lib().vdb_hip_index_insert_batch(self._h, _ptr(ids), _ptr(vecs), len(items), C.byref(n)))
+        return int(n.value)
+
+    insert_batch_parallel = insert_batch_sequential  # batch.rs:83-108 (deterministic here)
+
+    def upload(self, ids, vectors) -> int:
+        """Bulk upload without graph construction (exact search only until a graph exists)."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        vecs = _f32(vectors)
+        assert vecs.ndim == 2 and vecs.shape[1] == self._dimension, \
+            f"Vector dimension mismatch: expected {self._dimension}, got {vecs.shape[-1]}"
+        n = C.c_uint64(0)
+        check(lib().vdb_hip_index_upload(self._h, _ptr(ids), _ptr(vecs), vecs.shape[0], C.byref(n)))
+        return int(n.value)
+
+    def set_searching_mode(self) -> None:  # search.rs:380-384: no-op for the native engine
+        pass
+
+    def save(self, directory: str, basename: str = "native_hnsw") -> None:
+        """Graph + vectors in the reference's format v1 (backend_adapter.rs:184-261)."""
+        check(lib().vdb_hip_index_save_reference_files(self._h, directory.encode(), basename.encode()))
+
+    def load_reference_files(self, directory: str, basename: str = "native_hnsw") -> None:
+        check(lib().vdb_hip_index_load_reference_files(self._h, directory.encode(), basename.encode()))
+
+    # ---- introspection ------------------------------------------------------------------
+    def node_count(self) -> int:
+        n = C.c_uint64(0)
+        check(lib().vdb_hip_index_node_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def neighbors(self, layer: int, node: int) -> List[int]:
+        buf = np.empty(1024, dtype=np.uint32)
+        n = C.c_uint32(0)
+        check(lib().vdb_hip_index_get_neighbors(self._h, layer, node, _ptr(buf), buf.size, C.byref(n)))
+        return buf[: n.value].tolist()
+
+    def graph_info(self):
+        nl, ml, ep = C.c_uint32(0), C.c_uint32(0), C.c_int64(-1)
+        check(lib().vdb_hip_index_graph_info(self._h, C.byref(nl), C.byref(ml), C.byref(ep)))
+        return int(nl.value), int(ml.value), int(ep.value)
+
+    def last_search_stats(self):
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        check(lib().vdb_hip_index_last_search_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def last_kernel_ms(self):
+        ms, n = C.c_float(0), C.c_uint32(0)
+        check(lib().vdb_hip_index_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    # ---- device-pointer entry points (torch / raw HIP pointers) --------------------------
+    def upload_dev(self, id_base: int, d_ptr: int, n: int, stream: int = 0) -> None:
+        check(lib().vdb_hip_index_upload_dev(self._h, id_base, C.c_void_p(d_ptr), n, C.c_void_p(stream)))
+
+    def search_batch_dev(self, d_queries: int, nq: int, k: int, ef: int, mode: int, d_ids: int, d_scores: int,
+                         d_n: int, stream: int = 0) -> None:
+        check(lib().vdb_hip_index_search_batch_dev(self._h, C.c_void_p(d_queries), nq, k, ef, mode,
+                                                   C.c_void_p(d_ids), C.c_void_p(d_scores), C.c_void_p(d_n),
+                                                   C.c_void_p(stream)))
+
+
+class HipDistance:
+    """DistanceEngine (native/distance.rs:14-28) whose batch_distance runs on the GPU."""
+
+    def __init__(self, metric: DistanceMetric, device: int = 0):
+        self._metric = DistanceMetric(metric)
+        self.device = device
+
+    def metric(self) -> DistanceMetric:
+        return self._metric
+
+    def batch_distance(self, query, candidates) -> np.ndarray:
+        q = _f32(query).reshape(-1)
+        c = _f32(candidates)
+        if c.size == 0:
+            return np.empty(0, dtype=np.float32)
+        assert c.ndim == 2 and c.shape[1] == q.size, "Vector dimensions must match"
+        out = np.empty(c.shape[0], dtype=np.float32)
+        check(lib().vdb_hip_batch_distance(self.device, int(self._metric), KIND_ENGINE, _ptr(q), _ptr(c),
+                                           c.shape[0], q.size, _ptr(out)))
+        return out
+
+    def distance(self, a, b) -> float:
+        return float(self.batch_distance(a, _f32(b).reshape(1, -1))[0])
+
+
+class GpuAccelerator:
+    """gpu/gpu_backend.rs:33-415: new() -> None without a GPU; batch_* return raw similarities."""
+
+    def __init__(self, device: int = 0):
+        self.device = device
+
+    @staticmethod
+    def new(device: int = 0) -> Optional["GpuAccelerator"]:
+        return GpuAccelerator(device) if device_count() > 0 else None
+
+    @staticmethod
+    def is_available() -> bool:
+        return device_count() > 0
+
+    def _batch(self, metric, vectors, query, dimension) -> np.ndarray:
+        v = _f32(vectors).reshape(-1)
+        q = _f32(query).reshape(-1)
+        if dimension == 0 or v.size == 0:
+            return np.empty(0, dtype=np.float32)  # gpu_backend.rs:163-169
+        n = v.size // dimension
+        if n == 0:
+            return np.empty(0, dtype=np.float32)
+        out = np.empty(n, dtype=np.float32)
+        check(lib().vdb_hip_batch_distance(self.device, int(metric), KIND_RAW, _ptr(q), _ptr(v), n, dimension,
+                                           _ptr(out)))
+        return out
+
+    def batch_cosine_similarity(self, vectors, query, dimension) -> np.ndarray:
+        return self._batch(DistanceMetric.Cosine, vectors, query, dimension)
+
+    def batch_euclidean_distance(self, vectors, query, dimension) -> np.ndarray:
+        return self._batch(DistanceMetric.Euclidean, vectors, query, dimension)
+
+    def batch_dot_product(self, vectors, query, dimension) -> np.ndarray:
+        return self._batch(DistanceMetric.DotProduct, vectors, query, dimension)

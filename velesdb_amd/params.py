@@ -1,0 +1,81 @@
+"""HnswParams presets and SearchQuality — host logic mirrored from
+crates/velesdb-core/src/index/hnsw/params.rs (cited per function)."""
+from __future__ import annotations
+
+import enum
+from dataclasses import dataclass
+
+
+class DistanceMetric(enum.IntEnum):
+    """core/distance.rs:16-38; discriminants = on-disk order (constructors.rs:204-210)."""
+    Cosine = 0
+    Euclidean = 1
+    DotProduct = 2
+    Hamming = 3
+    Jaccard = 4
+
+    def higher_is_better(self) -> bool:  # core/distance.rs:76-82
+        return self in (DistanceMetric.Cosine, DistanceMetric.DotProduct, DistanceMetric.Jaccard)
+
+
+@dataclass(frozen=True)
+class HnswParams:
+    """params.rs:14-28 (storage_mode is out of scope: Full only)."""
+    max_connections: int
+    ef_construction: int
+    max_elements: int = 100_000
+
+    @staticmethod
+    def auto(dimension: int) -> "HnswParams":  # params.rs:41-57
+        return HnswParams(24, 300, 100_000) if dimension <= 256 else HnswParams(32, 400, 100_000)
+
+    @staticmethod
+    def for_dataset_size(dimension: int, expected_vectors: int) -> "HnswParams":  # params.rs:72-147
+        small = dimension <= 256
+        if expected_vectors <= 10_000:
+            return HnswParams(24, 200, 20_000) if small else HnswParams(32, 400, 20_000)
+        if expected_vectors <= 100_000:
+            return HnswParams(64, 800, 150_000) if small else HnswParams(128, 1600, 150_000)
+        if expected_vectors <= 500_000:
+            return HnswParams(96, 1200, 750_000) if small else HnswParams(128, 2000, 750_000)
+        return HnswParams(64, 800, 1_500_000) if small else HnswParams(128, 1600, 1_500_000)
+
+    @staticmethod
+    def million_scale(dimension: int) -> "HnswParams":  # params.rs:155-157
+        return HnswParams.for_dataset_size(dimension, 1_000_000)
+
+    @staticmethod
+    def fast() -> "HnswParams":  # params.rs:161-169
+        return HnswParams(16, 150, 100_000)
+
+    @staticmethod
+    def turbo() -> "HnswParams":  # params.rs:189-197
+        return HnswParams(12, 100, 100_000)
+
+    @staticmethod
+    def custom(max_connections: int, ef_construction: int, max_elements: int) -> "HnswParams":  # :248-259
+        return HnswParams(max_connections, ef_construction, max_elements)
+
+
+class SearchQuality:
+    """params.rs:287-320.  Use the class attributes or SearchQuality.Custom(ef)."""
+
+    def __init__(self, kind: str, ef: int = 0):
+        self.kind, self.ef = kind, ef
+
+    def ef_search(self, k: int) -> int:  # params.rs:309-319
+        return {"fast": max(64, k * 2), "balanced": max(128, k * 4), "accurate": max(512, k * 16),
+                "perfect": max(4096, k * 100), "custom": max(self.ef, k)}[self.kind]
+
+    @staticmethod
+    def Custom(ef: int) -> "SearchQuality":
+        return SearchQuality("custom", ef)
+
+    def __repr__(self):
+        return f"SearchQuality.{self.kind}" + (f"({self.ef})" if self.kind == "custom" else "")
+
+
+SearchQuality.Fast = SearchQuality("fast")
+SearchQuality.Balanced = SearchQuality("balanced")
+SearchQuality.Accurate = SearchQuality("accurate")
+SearchQuality.Perfect = SearchQuality("perfect")
