@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""GPU probe: per-launch time of the sweep kernel for each query-tile size, and end-to-end time per
+search call, on a synthetic N x D corpus.  Not part of the product or the test-suite."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import velesdb_amd as va  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument("--rows", type=int, default=1_000_000)
+p.add_argument("--dim", type=int, default=768)
+p.add_argument("--k", type=int, default=10)
+p.add_argument("--metric", default="cosine")
+p.add_argument("--nqs", default="1,2,4,8,16,64")
+a = p.parse_args()
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev)
+g.manual_seed(42)
+corpus = torch.randn((a.rows, a.dim), generator=g, device=dev)
+queries = torch.randn((256, a.dim), generator=g, device=dev)
+metric = {"cosine": va.DistanceMetric.Cosine, "euclidean": va.DistanceMetric.Euclidean, "dot": va.DistanceMetric.DotProduct}[a.metric]
+ix = va.HnswIndex(a.dim, metric, va.HnswParams(32, 400, a.rows))
+torch.cuda.synchronize()
+st = torch.cuda.current_stream().cuda_stream
+ix.upload_dev(0, corpus.data_ptr(), a.rows, st)
+del corpus
+alg = a.rows * a.dim * 4 + (a.rows * 4 if a.metric == "cosine" else 0)
+for nq in [int(x) for x in a.nqs.split(",")]:
+    ids = torch.empty((nq, a.k), dtype=torch.int64, device=dev)
+    sc = torch.empty((nq, a.k), dtype=torch.float32, device=dev)
+    n = torch.empty((nq,), dtype=torch.int32, device=dev)
+    for _ in range(3):
+        ix.search_batch_dev(queries.data_ptr(), nq, a.k, 0, va.MODE_BRUTE, ids.data_ptr(), sc.data_ptr(), n.data_ptr(), st)
+    torch.cuda.synchronize()
+    va.set_kernel_timing(True)
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ix.search_batch_dev(queries.data_ptr(), nq, a.k, 0, va.MODE_BRUTE, ids.data_ptr(), sc.data_ptr(), n.data_ptr(), st)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    kms, nl = ix.last_kernel_ms()
+    va.set_kernel_timing(False)
+    print(f"nq={nq:3d}: call {dt*1e3:8.3f} ms  ({nq/dt:9.1f} qps)  sweep kernel {kms:7.4f} ms x{nl}  "
+          f"{alg/(kms*1e-3)/1e9:7.1f} GB/s ({alg/(kms*1e-3)/1e9/8000:.3f} of 8 TB/s)")

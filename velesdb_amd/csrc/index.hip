@@ -196,7 +196,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
   const bool hib = higher_is_better_host(ix->metric);
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
   if (is_bits_metric(ix->metric)) {
-    if ((size_t)4 * k * 8 + (size_t)ix->words * 4 > 60 * 1024)
+    if ((size_t)4 * k * 8 + (size_t)ix->words * 4 + 32 > 60 * 1024)
       return fail(VDB_ERR_UNSUPPORTED, "k too large for the fused top-k path");
     // pack the queries with the same kernel that packs rows
     hipError_t e = ix->s_qbits.reserve((size_t)nq * ix->words * 4, false, st);
@@ -211,7 +211,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     launch_prep_rows(pa, st);
     const uint32_t nchunks = (uint32_t)((ix->n_rows + 63) / 64);
     int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + 3) / 4, (int64_t)ix->n_cus * 4));
-    const uint32_t nw = (uint32_t)blocks * 4;
+    const uint32_t nw = (uint32_t)blocks;  // one list per block
     if ((e = ix->s_part_keys.reserve((size_t)nq * nw * k * 8, false, st)) != hipSuccess ||
         (e = ix->s_part_cnt.reserve((size_t)nq * nw * 4, false, st)) != hipSuccess)
       return fail(VDB_ERR_OOM, "top-k scratch");
@@ -250,7 +250,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     const uint32_t rpg = 64 / B;
     const uint32_t ngroups = (uint32_t)((ix->n_rows + rpg - 1) / rpg);
     const int blocks = blocks_for(ix, (int)B, ngroups);
-    const uint32_t nw = (uint32_t)blocks * 4;
+    const uint32_t nw = (uint32_t)blocks;  // one list per block
     hipError_t e;
     if ((e = ix->s_part_keys.reserve((size_t)B * nw * k * 8, false, st)) != hipSuccess ||
         (e = ix->s_part_cnt.reserve((size_t)B * nw * 4, false, st)) != hipSuccess)
@@ -295,6 +295,10 @@ static int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride
                           uint32_t ef, int32_t mode, uint64_t* d_ids, float* d_scores, uint32_t* d_n,
                           hipStream_t st) {
   ix->ev_used = 0;
+  if (ix->n_rows == 0) {  // empty index: no entry point => empty result (native/graph.rs:252-255)
+    if (nq) VDB_HIP(hipMemsetAsync(d_n, 0, (size_t)nq * 4, st));
+    return VDB_OK;
+  }
   if (mode == VDB_SEARCH_BRUTE) return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
   if (mode == VDB_SEARCH_AUTO && ix->live <= 100 && ix->n_rows > 0)  // search.rs:75-77
     return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);

@@ -12,7 +12,8 @@
 //     ends with one finished score: 63 shuffles per 64 scores instead of 384;
 //   * top-k is fused: each wave keeps a sorted k-list per query in LDS and only touches it
 //     when a score beats the current k-th best (ballot-driven, rare after warm-up);
-//   * per-wave lists go to HBM (k*8 B each) and a one-wave-per-query merge kernel finishes.
+//   * the 4 waves of a block fold their lists in LDS; one k-list per block goes to HBM and a
+//     one-block-per-query merge kernel finishes (same threshold + insert scheme).
 // Algorithmic HBM bytes per launch: n_rows * dim * 4 (+ 4 B/row of norms for cosine).
 #include "vdb_device.hpp"
 #include "vdb_kernels.hpp"
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
   const uint32_t nwaves = gridDim.x * 4;
   const uint32_t k = a.k;
   volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * B * k;
-  uint32_t* cnts = reinterpret_cast<uint32_t*>(smem + (size_t)4 * B * k * 8) + wib * B;
+  // volatile: counts are written by lane 0 and read by every lane of the same wave; without it the
+  // compiler may keep a stale per-thread copy across the insert loop
+  volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(smem + (size_t)4 * B * k * 8) + wib * B;
   float* qgen = reinterpret_cast<float*>(smem + (size_t)4 * B * k * 8 + 4 * B * 4);  // generic path only
   if (lane < B) cnts[lane] = 0;
 
@@ -208,12 +211,27 @@ __global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
       if (lane == 0) cnts[bb] = c;
     }
   }
-  // ---- per-wave lists to HBM: part_keys[q][wave][k], part_cnt[q][wave] ----
-  for (int b = 0; b < (int)a.nq && b < B; b++) {
-    const uint32_t c = cnts[b];
-    uint64_t* dst = a.part_keys + ((size_t)b * nwaves + wave) * k;
-    for (uint32_t e = lane; e < c; e += 64) dst[e] = lists[(size_t)b * k + e];
-    if (lane == 0) a.part_cnt[(size_t)b * nwaves + wave] = c;
+  // ---- block-level merge in LDS: query b is finished by wave (b % 4), which folds the other three
+  // waves' lists for b into wave 0's; then one list per block goes to HBM, padded with invalid keys
+  __syncthreads();
+  {
+    volatile uint64_t* all_lists = reinterpret_cast<volatile uint64_t*>(smem);
+    volatile uint32_t* all_cnts = reinterpret_cast<volatile uint32_t*>(smem + (size_t)4 * B * k * 8);
+    for (int b = wib; b < (int)a.nq && b < B; b += 4) {
+      volatile uint64_t* dst = all_lists + (size_t)b * k;  // wave 0's list for query b
+      uint32_t c = all_cnts[b];
+      for (int w = 1; w < 4; w++) {
+        volatile uint64_t* src = all_lists + ((size_t)w * B + b) * k;
+        const uint32_t cs = all_cnts[w * B + b];
+        for (uint32_t e = 0; e < cs; e++) {
+          const uint64_t key = src[e];
+          if (c == k && key >= dst[k - 1]) break;  // sources are sorted: the rest cannot enter
+          wave_list_insert(dst, c, k, key, lane);
+        }
+      }
+      uint64_t* out = a.part_keys + ((size_t)b * gridDim.x + blockIdx.x) * k;
+      for (uint32_t e = lane; e < k; e += 64) out[e] = e < c ? dst[e] : kKeyInvalid;
+    }
   }
 }
 
@@ -222,29 +240,48 @@ __global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
 // and writes ids / scores best-first.
 // ------------------------------------------------------------------------------------------
 template <bool HIB>
-__global__ __launch_bounds__(64) void merge_topk(MergeArgs m) {
+__global__ __launch_bounds__(256) void merge_topk(MergeArgs m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem);
   const int lane = lane_id();
+  const int wib = (int)(threadIdx.x >> 6);
   const uint32_t qi = blockIdx.x;
   const uint32_t k = m.k;
+  volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k;
+  volatile uint32_t* wcnt = reinterpret_cast<volatile uint32_t*>(smem + (size_t)4 * k * 8);
   uint32_t cnt = 0;
   const uint64_t* keys = m.part_keys + (size_t)qi * m.n_lists * k;
-  const uint32_t* pc = m.part_cnt + (size_t)qi * m.n_lists;
-  const uint64_t total = (uint64_t)m.n_lists * k;
-  for (uint64_t base = 0; base < total; base += 64) {
-    const uint64_t i = base + lane;
-    uint64_t key = kKeyInvalid;
-    if (i < total) {
-      const uint32_t l = (uint32_t)(i / k), e = (uint32_t)(i % k);
-      if (e < pc[l]) key = keys[i];
+  const uint32_t total = m.n_lists * k;  // slots beyond a list's count hold kKeyInvalid
+  // wave w scans the slice [lo, hi); 4 independent loads in flight per lane
+  const uint32_t per = ((total + 3) / 4 + 255) / 256 * 256;
+  const uint32_t lo = wib * per, hi = min(total, lo + per);
+  for (uint32_t base = lo; base < hi; base += 256) {
+    uint64_t key[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t i = base + u * 64 + lane;
+      key[u] = i < hi ? keys[i] : kKeyInvalid;
     }
-    const uint64_t tau = (cnt == k) ? list[k - 1] : kKeyInvalid;
-    uint64_t mask = __ballot(key < tau);
-    while (mask) {
-      const int src = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      wave_list_insert(list, cnt, k, readlane64(key, src), lane);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint64_t tau = (cnt == k) ? list[k - 1] : kKeyInvalid;
+      uint64_t mask = __ballot(key[u] < tau);
+      while (mask) {
+        const int src = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        wave_list_insert(list, cnt, k, readlane64(key[u], src), lane);
+      }
+    }
+  }
+  if (lane == 0) wcnt[wib] = cnt;
+  __syncthreads();
+  if (wib != 0) return;
+  for (int w = 1; w < 4; w++) {
+    volatile uint64_t* src = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)w * k;
+    const uint32_t cs = wcnt[w];
+    for (uint32_t e = 0; e < cs; e++) {
+      const uint64_t kk = src[e];
+      if (cnt == k && kk >= list[k - 1]) break;
+      wave_list_insert(list, cnt, k, kk, lane);
     }
   }
   for (uint32_t e = lane; e < k; e += 64) {
@@ -320,9 +357,21 @@ __global__ __launch_bounds__(256) void sweep_topk_bits(BitsArgs a) {
       wave_list_insert(list, cnt, k, readlane64(key, src), lane);
     }
   }
-  uint64_t* dst = a.part_keys + ((size_t)qi * nwaves + wave) * k;
-  for (uint32_t e = lane; e < cnt; e += 64) dst[e] = list[e];
-  if (lane == 0) a.part_cnt[(size_t)qi * nwaves + wave] = cnt;
+  volatile uint32_t* wcnt = reinterpret_cast<volatile uint32_t*>(smem + (size_t)4 * k * 8 + (size_t)W * 4);
+  if (lane == 0) wcnt[wib] = cnt;
+  __syncthreads();
+  if (wib != 0) return;
+  for (int w = 1; w < 4; w++) {
+    volatile uint64_t* src = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)w * k;
+    const uint32_t cs = wcnt[w];
+    for (uint32_t e = 0; e < cs; e++) {
+      const uint64_t kk = src[e];
+      if (cnt == k && kk >= list[k - 1]) break;
+      wave_list_insert(list, cnt, k, kk, lane);
+    }
+  }
+  uint64_t* dst = a.part_keys + ((size_t)qi * gridDim.x + blockIdx.x) * k;
+  for (uint32_t e = lane; e < k; e += 64) dst[e] = e < cnt ? list[e] : kKeyInvalid;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -493,15 +542,15 @@ void launch_sweep_f32(int metric, int B, const SweepArgs& a, int blocks, hipStre
 }
 
 void launch_merge(bool hib, const MergeArgs& m, uint32_t nq, hipStream_t st) {
-  const size_t lds = ((size_t)m.k * 8 + 15) & ~(size_t)15;
+  const size_t lds = ((size_t)4 * m.k * 8 + 16 + 15) & ~(size_t)15;
   if (hib)
-    hipLaunchKernelGGL((merge_topk<true>), dim3(nq), dim3(64), lds, st, m);
+    hipLaunchKernelGGL((merge_topk<true>), dim3(nq), dim3(256), lds, st, m);
   else
-    hipLaunchKernelGGL((merge_topk<false>), dim3(nq), dim3(64), lds, st, m);
+    hipLaunchKernelGGL((merge_topk<false>), dim3(nq), dim3(256), lds, st, m);
 }
 
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st) {
-  const size_t lds = (((size_t)4 * a.k * 8 + (size_t)a.words * 4) + 15) & ~(size_t)15;
+  const size_t lds = (((size_t)4 * a.k * 8 + (size_t)a.words * 4 + 16) + 15) & ~(size_t)15;
   if (metric == kHamming)
     hipLaunchKernelGGL((sweep_topk_bits<kHamming>), dim3(blocks, nq), dim3(256), lds, st, a);
   else

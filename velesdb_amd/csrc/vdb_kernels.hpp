@@ -11,8 +11,8 @@ struct SweepArgs {
   const float* norms;      // [n_rows] canonical sqrt(sum sq) (cosine only)
   const uint8_t* alive;    // [n_rows] 0 = soft-deleted (nullable = all alive)
   const float* queries;    // [nq][q_stride]
-  uint64_t* part_keys;     // [nq][n_waves][k]
-  uint32_t* part_cnt;      // [nq][n_waves]
+  uint64_t* part_keys;     // [nq][n_blocks][k], unused slots = invalid key
+  uint32_t* part_cnt;      // unused (kept for ABI stability of the arg block)
   uint64_t row_stride;     // floats
   uint64_t q_stride;       // floats
   uint32_t n_rows;
@@ -22,8 +22,8 @@ struct SweepArgs {
 };
 
 struct MergeArgs {
-  const uint64_t* part_keys;  // [nq][n_lists][k]
-  const uint32_t* part_cnt;   // [nq][n_lists]
+  const uint64_t* part_keys;  // [nq][n_lists][k], unused slots = invalid key
+  const uint32_t* part_cnt;   // unused
   const uint64_t* ext_ids;    // [n_rows] external ids (nullable -> row + row_base)
   uint64_t* out_ids;          // [nq][k]
   float* out_scores;          // [nq][k]
