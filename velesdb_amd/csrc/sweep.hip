@@ -20,63 +20,6 @@
 
 namespace vdb {
 
-enum Op : int { kOpDot = 0, kOpL2 = 1 };
-
-template <int OP>
-__device__ __forceinline__ float chain4(float acc, const float4& q, const float4& v) {
-  if (OP == kOpL2) {
-    float d0 = q.x - v.x, d1 = q.y - v.y, d2 = q.z - v.z, d3 = q.w - v.w;
-    acc = __builtin_fmaf(d0, d0, acc);
-    acc = __builtin_fmaf(d1, d1, acc);
-    acc = __builtin_fmaf(d2, d2, acc);
-    acc = __builtin_fmaf(d3, d3, acc);
-  } else {
-    acc = __builtin_fmaf(q.x, v.x, acc);
-    acc = __builtin_fmaf(q.y, v.y, acc);
-    acc = __builtin_fmaf(q.z, v.z, acc);
-    acc = __builtin_fmaf(q.w, v.w, acc);
-  }
-  return acc;
-}
-// tail chunk: only elements with index < dim exist
-template <int OP>
-__device__ __forceinline__ float chain4_tail(float acc, const float4& q, const float4& v, int nvalid) {
-  const float qa[4] = {q.x, q.y, q.z, q.w};
-  const float va[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int e = 0; e < 4; e++) {
-    if (e < nvalid) {
-      if (OP == kOpL2) {
-        float d = qa[e] - va[e];
-        acc = __builtin_fmaf(d, d, acc);
-      } else {
-        acc = __builtin_fmaf(qa[e], va[e], acc);
-      }
-    }
-  }
-  return acc;
-}
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-// final score of one (row, query) pair from the canonical sums
-template <int METRIC>
-__device__ __forceinline__ float finish_score(float sum, float qnorm, float vnorm) {
-  if (METRIC == kCosine) {
-    // simd_avx512.rs:344-351: dot / (sqrt(na) * sqrt(nb)); 0.0 if either norm is 0
-    if (qnorm == 0.0f || vnorm == 0.0f) return 0.0f;
-    return sum / (qnorm * vnorm);
-  } else if (METRIC == kEuclidean) {
-    return sqrtf(sum);  // simd_avx512.rs:119-121
-  } else {
-    return sum;
-  }
-}
-
-constexpr bool higher_is_better(int metric) {  // core/distance.rs:76-82
-  return metric == kCosine || metric == kDot || metric == kJaccard;
-}
-
 // ------------------------------------------------------------------------------------------
 // f32 sweep with fused top-k.  B = queries per pass (power of two <= 64), RPG = 64/B rows per
 // group, CPL = float4 chunks per lane (dim == CPL*256) or 0 for any dim (generic, slower).
