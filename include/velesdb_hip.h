@@ -123,8 +123,10 @@ int32_t vdb_hip_index_search(vdb_hip_index* idx, const float* query, uint32_t qu
 int32_t vdb_hip_index_search_batch(vdb_hip_index* idx, const float* queries_rowmajor, uint32_t nq,
                                    uint32_t k, uint32_t ef, int32_t mode, uint64_t* out_ids,
                                    float* out_scores, uint32_t* out_n);
-/* device-resident variant: d_queries nq*dim f32, outputs device buffers of nq*k / nq; enqueued
- * on `stream`, no host synchronisation. */
+/* device-resident variant: d_queries nq*dim f32 (16-byte aligned), outputs device buffers of
+ * nq*k / nq; enqueued on `stream`, no host synchronisation.  In HNSW mode d_out_n[i] ==
+ * 0xFFFFFFFF marks a query whose LDS candidate list overflowed (needs very many exact distance
+ * ties); the host variant above re-runs such batches with a larger list by itself. */
 int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* idx, const float* d_queries, uint32_t nq,
                                        uint32_t k, uint32_t ef, int32_t mode, uint64_t* d_out_ids,
                                        float* d_out_scores, uint32_t* d_out_n, void* stream);

@@ -26,12 +26,7 @@ int32_t ensure_layers(vdb_hip_index* ix, uint32_t num_layers) {
   return VDB_OK;
 }
 
-// traversal / construction launch paths: filled in by hnsw_kernels.hip
-int32_t hnsw_search_dev(vdb_hip_index* ix, const float*, uint64_t, uint32_t, uint32_t, uint32_t, uint64_t*, float*,
-                        uint32_t*, hipStream_t) {
-  if (!ix->graph_valid) return fail(VDB_ERR_STATE, "HNSW graph not built for all rows (use mode BRUTE or build it)");
-  return fail(VDB_ERR_UNSUPPORTED, "HNSW traversal kernel not built in this library");
-}
+// construction launch path: filled in by hnsw_build.hip
 int32_t graph_insert_rows(vdb_hip_index*, uint64_t, uint64_t) {
   return fail(VDB_ERR_UNSUPPORTED, "HNSW construction kernel not built in this library");
 }

@@ -1,0 +1,626 @@
+// hnsw_kernels.hip — graph traversal on the GPU: NativeHnsw::search (native/graph.rs:251-270) =
+// greedy descent search_layer_single (graph.rs:405-428) on layers max_layer..1, then the layer-0
+// best-first beam search_layer (graph.rs:438-520); result mapping of HnswIndex::search_with_quality
+// (index/hnsw/index/search.rs:79-93, transform_score backend_adapter.rs:160-168).
+//
+// Design (MI355X-first; the path is bound by random 3 KB row gathers from HBM):
+//   * one 256-thread block per query in flight ("slot"); slots loop over the batch.  With 4 blocks
+//     per CU that is 1024 queries x 4 waves x 8 rows x 3 KB = several hundred KB of loads in flight
+//     per CU, far more than the latency-bandwidth product needs.
+//   * a step = (leader wave decides what to evaluate) -> barrier -> (all 4 waves evaluate up to
+//     `nbmax` distances: wave w takes groups of 8 neighbours, every row is read as float4 per lane,
+//     1 KiB per load instruction, canonical per-lane fmaf chains + xor-butterfly, vdb_device.hpp)
+//     -> barrier.  The decision logic is the reference's, statement for statement, executed by one
+//     wave with wave-uniform control flow; the 64 lanes are used for the list operations.
+//   * candidates + results live in ONE sorted list in LDS keyed by (total-order(dist), node) with
+//     an "expanded" flag per entry:  results  = the first min(len, ef) entries (the reference's
+//     max-heap bounded to ef holds exactly the ef smallest keys pushed so far), candidates = the
+//     entries not yet expanded (the reference pushes every admitted node to both heaps).  Entries
+//     past position ef were evicted from results; they stay only while the reference's
+//     termination test `c_dist > furthest` (graph.rs:474) could still let them be expanded
+//     (exact ties with the current furthest distance: common for Hamming, never for f32).
+//   * visited set = one bit per node in HBM per slot (atomicOr test-and-set, L2-resident), undone
+//     after each query from a log of the ids it set.
+// Algorithmic HBM bytes per query: n_dist * dim * 4 + n_expand * M0 * 4, with n_dist / n_expand
+// counted by the kernel (stats), SURVEY.md §8(d).
+#include <algorithm>
+
+#include "vdb_device.hpp"
+#include "vdb_index.hpp"
+#include "vdb_kernels.hpp"
+
+namespace vdb {
+
+namespace {
+
+enum Phase : int {
+  P_START = 0,   // evaluate dist(q, cur) on `layer`
+  P_G_ENTRY,     // consume it as best_dist (graph.rs:407)
+  P_G_LOAD,      // load neighbours of best (graph.rs:410)
+  P_G_SCAN,      // scan them with strict < (graph.rs:413-421)
+  P_G_DONE,      // no improvement: next layer down
+  P_Z_ENTRY,     // layer 0: push the entry point (graph.rs:464-469)
+  P_Z_POP,       // pop nearest candidate, termination test, gather unvisited neighbours (:471-499)
+  P_Z_ADMIT,     // admission of the evaluated neighbours in list order (:500-511)
+  P_FINISH
+};
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ float rflf(float v) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
+}
+__device__ __forceinline__ uint64_t lt_mask(int lane) { return (1ull << lane) - 1ull; }
+__device__ __forceinline__ float key_dist(uint64_t key) { return asc_key_inv((uint32_t)(key >> 32)); }
+
+// R per-lane partials per lane in a[0..R); afterwards lane l holds in a[0] the canonical 64-lane sum
+// of partial index l % R (stages 32..R are plain butterflies, stages R/2..1 are transposed).
+template <int R>
+__device__ __forceinline__ void reduce_rows(float* a, int lane) {
+#pragma unroll
+  for (int s = 32; s >= R; s >>= 1) {
+#pragma unroll
+    for (int i = 0; i < R; i++) a[i] = a[i] + shx(a[i], s);
+  }
+  TReduce<R, R / 2>::run(a, lane);
+}
+
+// Sorted list insert with per-entry flags.  Wave-uniform arguments, all 64 lanes participate.
+// If the list is at capacity its last entry is dropped and reported (key + flag).
+__device__ __forceinline__ void list_insert(volatile uint64_t* keys, volatile uint8_t* flags, uint32_t& cnt,
+                                            uint32_t cap, uint64_t key, int lane, uint64_t& dropped,
+                                            uint32_t& dropped_flag) {
+  dropped = kKeyInvalid;
+  dropped_flag = 1;
+  uint32_t pos = 0;
+  for (uint32_t c = 0; c < cnt; c += 64) {
+    const uint32_t e = c + lane;
+    const bool less = e < cnt && keys[e] < key;
+    pos += (uint32_t)__popcll(__ballot(less));
+  }
+  if (pos >= cap) {
+    dropped = key;
+    dropped_flag = 0;
+    return;
+  }
+  if (cnt == cap) {
+    dropped = keys[cap - 1];
+    dropped_flag = flags[cap - 1];
+  }
+  const uint32_t newcnt = cnt < cap ? cnt + 1 : cap;
+  if (newcnt - 1 > pos) {
+    const uint32_t span = newcnt - 1 - pos;
+    for (int32_t c = (int32_t)((span - 1) / 64) * 64; c >= 0; c -= 64) {
+      const uint32_t e = pos + (uint32_t)c + lane;
+      const bool mv = e < newcnt - 1;
+      const uint64_t v = mv ? keys[e] : 0;
+      const uint8_t f = mv ? flags[e] : (uint8_t)0;
+      if (mv) {
+        keys[e + 1] = v;
+        flags[e + 1] = f;
+      }
+    }
+  }
+  if (lane == 0) {
+    keys[pos] = key;
+    flags[pos] = 0;
+  }
+  cnt = newcnt;
+}
+
+// entries past ef stay only up to the last one the termination test could still expand
+__device__ __forceinline__ void list_truncate(volatile uint64_t* keys, uint32_t& cnt, uint32_t ef, int lane) {
+  if (cnt <= ef) return;
+  const float wd = key_dist(keys[ef - 1]);
+  uint32_t last = ef - 1;
+  for (uint32_t c = ef; c < cnt; c += 64) {
+    const uint32_t e = c + lane;
+    const bool alive = e < cnt && !(key_dist(keys[e]) > wd);  // negation of graph.rs:474's raw compare
+    const uint64_t mask = __ballot(alive);
+    if (mask) last = c + 63u - (uint32_t)__clzll((long long)mask);
+  }
+  cnt = last + 1;
+}
+
+__device__ __forceinline__ float transform_score_dev(int metric, float d) {  // backend_adapter.rs:160-168
+  if (metric == kCosine) {
+    float s = 1.0f - d;
+    if (s < 0.0f) s = 0.0f;
+    if (s > 1.0f) s = 1.0f;
+    return s;
+  }
+  if (metric == kDot) return -d;
+  return d;
+}
+
+// ---- distance evaluation of nb_id[0..m) -> nb_d[0..m): DistanceEngine::distance (native/distance.rs:75-85)
+template <int METRIC, int CPL>
+__device__ __forceinline__ void dist_phase_f32(const HnswSearchArgs& a, const float4* q, float qnorm,
+                                               const float* qgen, uint32_t m, volatile uint32_t* nb_id,
+                                               volatile float* nb_d, int lane, int wib) {
+  constexpr int OP = (METRIC == kEuclidean) ? kOpL2 : kOpDot;
+  constexpr int R = 8;
+  const int d4 = (int)((a.dim + 3) / 4);
+  for (uint32_t j0 = (uint32_t)wib * R; j0 < m; j0 += 4 * R) {
+    float acc[R];
+    if (CPL > 0) {
+      float4 v[R][CPL > 0 ? CPL : 1];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const uint32_t j = j0 + r < m ? j0 + r : m - 1;
+        const float* p = a.rows + (size_t)nb_id[j] * a.row_stride + (size_t)lane * 4;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) v[r][c] = ld4(p + c * 256);
+      }
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) s = chain4<OP>(s, q[c], v[r][c]);
+        acc[r] = s;
+      }
+    } else {
+      const float* rp[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const uint32_t j = j0 + r < m ? j0 + r : m - 1;
+        rp[r] = a.rows + (size_t)nb_id[j] * a.row_stride;
+        acc[r] = 0.0f;
+      }
+      for (int c = lane; c < d4; c += 64) {
+        const float4 qq = ld4(qgen + c * 4);
+        const int nv = (int)a.dim - c * 4;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const float4 x = ld4(rp[r] + c * 4);
+          acc[r] = nv >= 4 ? chain4<OP>(acc[r], qq, x) : chain4_tail<OP>(acc[r], qq, x, nv);
+        }
+      }
+    }
+    reduce_rows<R>(acc, lane);
+    const uint32_t j = j0 + (uint32_t)(lane & (R - 1));
+    if (lane < R && j < m) {
+      float vnorm = 1.0f;
+      if (METRIC == kCosine) vnorm = a.norms[nb_id[j]];
+      const float s = finish_score<METRIC>(acc[0], qnorm, vnorm);
+      nb_d[j] = (METRIC == kCosine) ? 1.0f - s : ((METRIC == kDot) ? -s : s);
+    }
+  }
+}
+
+template <int METRIC>
+__device__ __forceinline__ void dist_phase_bits(const HnswSearchArgs& a, const uint32_t* qbits, uint32_t m,
+                                                volatile uint32_t* nb_id, volatile float* nb_d) {
+  const uint32_t W = a.words;
+  for (uint32_t t = threadIdx.x; t < m; t += 256) {
+    const uint4* p = reinterpret_cast<const uint4*>(a.bits + (size_t)nb_id[t] * W);
+    uint32_t ham = 0, inter = 0, uni = 0;
+    for (uint32_t w = 0; w < W; w += 4) {
+      const uint4 x = p[w / 4];
+      const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const uint32_t qq = qbits[w + e];
+        if (METRIC == kHamming) {
+          ham += __popc(xs[e] ^ qq);
+        } else {
+          inter += __popc(xs[e] & qq);
+          uni += __popc(xs[e] | qq);
+        }
+      }
+    }
+    if (METRIC == kHamming) {
+      nb_d[t] = (float)ham;  // simd_explicit.rs:234-287 on the exact re-encoding bit = (x > 0.5)
+    } else {
+      const float sim = (uni == 0) ? 1.0f : (float)inter / (float)uni;  // simd_explicit.rs:431-442
+      nb_d[t] = 1.0f - sim;                                              // native/distance.rs:83
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// LDS: keys[cap] u64 | nb_id[nbmax] u32 | nb_d[nbmax] f32 | ctl[4] u32 | flags[cap] u8 (padded to 16)
+//      | query scratch: generic f32 dims: d4*4 floats; bit metrics: `words` u32
+// ------------------------------------------------------------------------------------------
+template <int METRIC, int CPL>
+__global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
+  constexpr bool BITS = (METRIC == kHamming || METRIC == kJaccard);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int wib = (int)rfl(threadIdx.x >> 6);
+  const uint32_t cap = a.cap, nbmax = a.nbmax, ef = a.ef;
+  volatile uint64_t* keys = reinterpret_cast<volatile uint64_t*>(smem);
+  volatile uint32_t* nb_id = reinterpret_cast<volatile uint32_t*>(smem + (size_t)cap * 8);
+  volatile float* nb_d = reinterpret_cast<volatile float*>(smem + (size_t)cap * 8 + (size_t)nbmax * 4);
+  volatile uint32_t* ctl = reinterpret_cast<volatile uint32_t*>(smem + (size_t)cap * 8 + (size_t)nbmax * 8);
+  volatile uint8_t* flags = smem + (size_t)cap * 8 + (size_t)nbmax * 8 + 16;
+  const size_t qoff = (size_t)cap * 8 + (size_t)nbmax * 8 + 16 + (((size_t)cap + 15) & ~(size_t)15);
+  float* qgen = reinterpret_cast<float*>(smem + qoff);
+  uint32_t* qbits = reinterpret_cast<uint32_t*>(smem + qoff);
+
+  uint32_t* vis = a.visited + (size_t)blockIdx.x * a.vis_words;
+  uint32_t* vlog = a.vlog + (size_t)blockIdx.x * a.vlog_cap;
+  const int d4 = (int)((a.dim + 3) / 4);
+
+  for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
+    const float* qp = a.queries + (size_t)qi * a.q_stride;
+    float4 q[CPL > 0 ? CPL : 1];
+    float qnorm = 0.0f;
+    if (BITS) {
+      for (uint32_t w = threadIdx.x; w < a.words; w += 256) {
+        uint32_t bitsw = 0;
+        for (uint32_t e = 0; e < 32; e++) {
+          const uint32_t i = w * 32 + e;
+          if (i < a.dim && qp[i] > 0.5f) bitsw |= 1u << e;
+        }
+        qbits[w] = bitsw;
+      }
+    } else if (CPL > 0) {
+      float nacc = 0.0f;
+#pragma unroll
+      for (int c = 0; c < CPL; c++) {
+        q[c] = ld4(qp + (size_t)(c * 64 + lane) * 4);
+        nacc = chain4<kOpDot>(nacc, q[c], q[c]);
+      }
+      if (METRIC == kCosine) qnorm = sqrtf(butterfly_all(nacc));
+    } else {
+      const int qlen = d4 * 4;
+      for (int i = threadIdx.x; i < qlen; i += 256) qgen[i] = i < (int)a.dim ? qp[i] : 0.0f;
+      __syncthreads();
+      if (METRIC == kCosine) {
+        float nacc = 0.0f;
+        for (int c = lane; c < d4; c += 64) {
+          const float4 x = ld4(qgen + c * 4);
+          const int nv = (int)a.dim - c * 4;
+          nacc = nv >= 4 ? chain4<kOpDot>(nacc, x, x) : chain4_tail<kOpDot>(nacc, x, x, nv);
+        }
+        qnorm = sqrtf(butterfly_all(nacc));
+      }
+    }
+    __syncthreads();
+
+    // ---- leader state (meaningful in wave 0 only; every value is wave-uniform) ----
+    uint32_t cnt = 0, n_dist = 0, n_expand = 0, logn = 0, overflow = 0, m_prev = 0;
+    int phase = P_START;
+    int layer = (int)a.max_layer;
+    uint32_t cur = a.entry_point;
+    float best_d = 0.0f;
+
+    for (;;) {
+      if (wib == 0) {
+        bool ready = false;
+        uint32_t m = 0, done = 0;
+        while (!ready) {
+          if (phase == P_START) {
+            if (lane == 0) nb_id[0] = cur;
+            m = 1;
+            ready = true;
+            phase = layer > 0 ? P_G_ENTRY : P_Z_ENTRY;
+          } else if (phase == P_G_ENTRY) {
+            best_d = rflf(nb_d[0]);
+            n_dist += 1;
+            phase = P_G_LOAD;
+          } else if (phase == P_G_LOAD) {
+            const HnswLayerRef L = a.layers[layer];
+            uint32_t nc = rfl(L.cnt[cur]);
+            nc = min(nc, min(L.stride, nbmax));
+            for (uint32_t base = 0; base < nc; base += 64) {
+              const uint32_t t = base + lane;
+              if (t < nc) nb_id[t] = L.nbr[(size_t)cur * L.stride + t];
+            }
+            if (nc == 0) {
+              phase = P_G_DONE;
+            } else {
+              m = nc;
+              ready = true;
+              phase = P_G_SCAN;
+            }
+          } else if (phase == P_G_SCAN) {
+            n_dist += m_prev;
+            // sequential scan with strict `<` == first index attaining the minimum, if below best
+            float mn = 0.0f;
+            uint32_t besti = 0xFFFFFFFFu;
+            for (uint32_t base = 0; base < m_prev; base += 64) {
+              const uint32_t t = base + lane;
+              const float d = t < m_prev ? nb_d[t] : 0.0f;
+              const bool ok = t < m_prev && d < best_d;  // raw compare: NaN never improves
+              const uint64_t okm = __ballot(ok);
+              if (okm) {
+                float v = ok ? d : __uint_as_float(0x7F800000u);
+#pragma unroll
+                for (int s = 32; s >= 1; s >>= 1) v = fminf(v, shx(v, s));
+                v = rflf(v);
+                if (besti == 0xFFFFFFFFu || v < mn) {
+                  const uint64_t eq = __ballot(ok && d == v);
+                  besti = base + (uint32_t)__ffsll((long long)eq) - 1;
+                  mn = v;
+                }
+              }
+            }
+            if (besti != 0xFFFFFFFFu) {
+              cur = rfl(nb_id[besti]);
+              best_d = rflf(nb_d[besti]);
+              phase = P_G_LOAD;
+            } else {
+              phase = P_G_DONE;
+            }
+          } else if (phase == P_G_DONE) {
+            layer -= 1;
+            phase = P_START;
+          } else if (phase == P_Z_ENTRY) {
+            const float d = rflf(nb_d[0]);
+            n_dist += 1;
+            uint64_t dr;
+            uint32_t df;
+            list_insert(keys, flags, cnt, cap, make_key<false>(d, cur), lane, dr, df);
+            if (lane == 0) {
+              atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+              if (a.vlog_cap) vlog[0] = cur;
+            }
+            logn = 1;
+            phase = P_Z_POP;
+          } else if (phase == P_Z_POP) {
+            uint32_t idx = 0xFFFFFFFFu;
+            for (uint32_t c = 0; c < cnt; c += 64) {
+              const uint32_t e = c + lane;
+              const uint64_t un = __ballot(e < cnt && flags[e] == 0);
+              if (un) {
+                idx = c + (uint32_t)__ffsll((long long)un) - 1;
+                break;
+              }
+            }
+            if (idx == 0xFFFFFFFFu) {
+              phase = P_FINISH;  // candidates empty (graph.rs:471)
+            } else {
+              const uint64_t ckey = keys[idx];
+              bool stop = false;
+              if (cnt >= ef) stop = key_dist(ckey) > key_dist(keys[ef - 1]);  // graph.rs:474
+              if (stop) {
+                phase = P_FINISH;
+              } else {
+                if (lane == 0) flags[idx] = 1;
+                n_expand += 1;
+                const uint32_t cnode = (uint32_t)ckey;
+                const HnswLayerRef L = a.layers[0];
+                uint32_t nc = rfl(L.cnt[cnode]);
+                nc = min(nc, min(L.stride, nbmax));
+                for (uint32_t base = 0; base < nc; base += 64) {
+                  const uint32_t t = base + lane;
+                  const bool valid = t < nc;
+                  uint32_t nb = 0;
+                  bool newly = false;
+                  if (valid) {
+                    nb = L.nbr[(size_t)cnode * L.stride + t];
+                    const uint32_t bit = 1u << (nb & 31);
+                    newly = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;  // visited.insert (graph.rs:499)
+                  }
+                  const uint64_t mask = __ballot(newly);
+                  const uint32_t before = (uint32_t)__popcll(mask & lt_mask(lane));
+                  if (newly) {
+                    nb_id[m + before] = nb;
+                    if (logn + before < a.vlog_cap) vlog[logn + before] = nb;
+                  }
+                  m += (uint32_t)__popcll(mask);
+                  logn += (uint32_t)__popcll(mask);
+                }
+                if (m != 0) {
+                  ready = true;
+                  phase = P_Z_ADMIT;
+                }
+              }
+            }
+          } else if (phase == P_Z_ADMIT) {
+            n_dist += m_prev;
+            for (uint32_t base = 0; base < m_prev; base += 64) {
+              const uint32_t t = base + lane;
+              const float d = t < m_prev ? nb_d[t] : 0.0f;
+              uint32_t size = cnt < ef ? cnt : ef;
+              float far = key_dist(keys[size - 1]);
+              // pre-filter against the furthest distance at chunk start: it only decreases while the
+              // result set is full, so a neighbour rejected now would be rejected at its turn too
+              uint64_t mask = __ballot(t < m_prev && (d < far || size < ef));
+              while (mask) {
+                const int src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const float dj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d), src));
+                size = cnt < ef ? cnt : ef;
+                far = key_dist(keys[size - 1]);
+                if (dj < far || size < ef) {  // graph.rs:503
+                  const uint32_t nbj = nb_id[base + src];
+                  uint64_t dr;
+                  uint32_t df;
+                  list_insert(keys, flags, cnt, cap, make_key<false>(dj, nbj), lane, dr, df);
+                  if (dr != kKeyInvalid && df == 0) overflow = 1;  // an unexpanded candidate fell off the list
+                  list_truncate(keys, cnt, ef, lane);
+                }
+              }
+            }
+            phase = P_Z_POP;
+          } else {  // P_FINISH
+            done = 1;
+            ready = true;
+          }
+        }
+        if (lane == 0) {
+          ctl[0] = m;
+          ctl[1] = done;
+          ctl[2] = logn;
+        }
+        m_prev = m;
+      }
+      __syncthreads();
+      const uint32_t m = ctl[0];
+      if (ctl[1]) break;
+      if (BITS)
+        dist_phase_bits<METRIC>(a, qbits, m, nb_id, nb_d);
+      else
+        dist_phase_f32<METRIC, CPL>(a, q, qnorm, qgen, m, nb_id, nb_d, lane, wib);
+      __syncthreads();
+    }
+
+    // ---- results: first k of the sorted result set, soft-deleted rows dropped after the cut
+    // (search.rs:86-91), scores through transform_score ----
+    if (wib == 0) {
+      const uint32_t size = cnt < ef ? cnt : ef;
+      const uint32_t kk = a.k < size ? a.k : size;
+      uint32_t outn = 0;
+      for (uint32_t base = 0; base < kk; base += 64) {
+        const uint32_t e = base + lane;
+        const bool v = e < kk;
+        const uint64_t key = v ? keys[e] : 0;
+        const uint32_t node = (uint32_t)key;
+        bool al = v;
+        if (v && a.alive) al = a.alive[node] != 0;
+        const uint64_t mask = __ballot(al);
+        const uint32_t p = outn + (uint32_t)__popcll(mask & lt_mask(lane));
+        if (al) {
+          a.out_ids[(size_t)qi * a.k + p] = a.ext_ids ? a.ext_ids[node] : (uint64_t)node;
+          a.out_scores[(size_t)qi * a.k + p] = transform_score_dev(METRIC, key_dist(key));
+        }
+        outn += (uint32_t)__popcll(mask);
+      }
+      for (uint32_t e = outn + lane; e < a.k; e += 64) {
+        a.out_ids[(size_t)qi * a.k + e] = ~0ull;
+        a.out_scores[(size_t)qi * a.k + e] = __uint_as_float(0x7FC00000u);
+      }
+      if (lane == 0) {
+        a.out_n[qi] = overflow ? 0xFFFFFFFFu : outn;
+        if (a.stats) {
+          atomicAdd(&a.stats[0], (unsigned long long)n_dist);
+          atomicAdd(&a.stats[1], (unsigned long long)n_expand);
+        }
+      }
+    }
+    // ---- undo the visited bits of this query ----
+    const uint32_t nlog = ctl[2];
+    if (nlog <= a.vlog_cap) {
+      for (uint32_t i = threadIdx.x; i < nlog; i += 256) vis[vlog[i] >> 5] = 0;
+    } else {
+      for (uint64_t i = threadIdx.x; i < a.vis_words; i += 256) vis[i] = 0;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------
+size_t hnsw_lds_bytes(uint32_t cap, uint32_t nbmax, uint32_t dim, uint32_t words, int metric) {
+  size_t s = (size_t)cap * 8 + (size_t)nbmax * 8 + 16 + (((size_t)cap + 15) & ~(size_t)15);
+  if (metric == kHamming || metric == kJaccard)
+    s += (size_t)words * 4;
+  else if (sweep_cpl_for_dim(dim) == 0)
+    s += (size_t)((dim + 3) / 4) * 16;
+  return (s + 15) & ~(size_t)15;
+}
+
+template <int METRIC, int CPL>
+static hipError_t launch_t(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_search_kernel<METRIC, CPL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((hnsw_search_kernel<METRIC, CPL>), dim3(slots), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+template <int METRIC>
+static hipError_t launch_cpl(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
+  switch (sweep_cpl_for_dim(a.dim)) {
+    case 1: return launch_t<METRIC, 1>(a, slots, lds, st);
+    case 2: return launch_t<METRIC, 2>(a, slots, lds, st);
+    case 3: return launch_t<METRIC, 3>(a, slots, lds, st);
+    case 4: return launch_t<METRIC, 4>(a, slots, lds, st);
+    default: return launch_t<METRIC, 0>(a, slots, lds, st);
+  }
+}
+
+hipError_t launch_hnsw_search(const HnswSearchArgs& a, int slots, hipStream_t st) {
+  const size_t lds = hnsw_lds_bytes(a.cap, a.nbmax, a.dim, a.words, a.metric);
+  switch (a.metric) {
+    case kCosine: return launch_cpl<kCosine>(a, slots, lds, st);
+    case kEuclidean: return launch_cpl<kEuclidean>(a, slots, lds, st);
+    case kDot: return launch_cpl<kDot>(a, slots, lds, st);
+    case kHamming: return launch_t<kHamming, 0>(a, slots, lds, st);
+    default: return launch_t<kJaccard, 0>(a, slots, lds, st);
+  }
+}
+
+// NativeHnsw::search for nq device-resident queries (graph.rs:251-270) + result mapping
+// (search.rs:79-93).  Enqueues on `st`; no host synchronisation.
+int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint32_t ef,
+                        uint32_t cap_mult, uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st) {
+  if (!ix->graph_valid) return fail(VDB_ERR_STATE, "HNSW graph not built for all rows (use mode BRUTE or build it)");
+  if (nq == 0) return VDB_OK;
+  if (ix->entry_point < 0 || ix->graph_nodes == 0 || k == 0) {  // graph.rs:252-255: no entry point => empty
+    VDB_HIP(hipMemsetAsync(d_n, 0, (size_t)nq * 4, st));
+    return VDB_OK;
+  }
+  if (ix->layers.size() > (size_t)kMaxLayers) return fail(VDB_ERR_UNSUPPORTED, "more than 16 graph layers");
+  HnswSearchArgs a{};
+  uint32_t nbmax = 0;
+  for (size_t l = 0; l < ix->layers.size(); l++) {
+    a.layers[l].nbr = ix->layers[l].nbr.as<uint32_t>();
+    a.layers[l].cnt = ix->layers[l].cnt.as<uint32_t>();
+    a.layers[l].stride = ix->layers[l].stride;
+    nbmax = std::max(nbmax, ix->layers[l].stride);
+  }
+  nbmax = (nbmax + 63) / 64 * 64;
+  // list capacity: ef results + room for evicted candidates that tie with the furthest result
+  uint64_t cap = (uint64_t)ef + std::max<uint64_t>(64, (uint64_t)ef * cap_mult / 2);
+  cap = (cap + 63) / 64 * 64;
+  const size_t lds = hnsw_lds_bytes((uint32_t)cap, nbmax, ix->dim, ix->words, ix->metric);
+  if (cap > 0xFFFFFFFFull || lds > 160 * 1024)
+    return fail(VDB_ERR_UNSUPPORTED, "ef too large for the LDS-resident candidate list (" + std::to_string(lds) + " B)");
+  // slots: resident blocks; 4 per CU unless LDS limits it
+  int per_cu = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / lds));
+  int slots = (int)std::min<int64_t>((int64_t)nq, (int64_t)ix->n_cus * per_cu);
+  const uint64_t vis_words = (ix->capacity + 31) / 32;
+  const uint32_t vlog_cap = 16384;
+  const int max_slots = ix->n_cus * 4;
+  if (ix->vis_words != vis_words || ix->s_visited.cap < (size_t)max_slots * vis_words * 4) {
+    hipError_t e = ix->s_visited.reserve((size_t)max_slots * vis_words * 4, false, st);
+    if (e == hipSuccess) e = ix->s_vlog.reserve((size_t)max_slots * vlog_cap * 4, false, st);
+    if (e == hipSuccess) e = ix->s_stats.reserve(64, false, st);
+    if (e == hipSuccess) e = hipMemsetAsync(ix->s_visited.p, 0, ix->s_visited.cap, ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) return fail(VDB_ERR_OOM, std::string("visited scratch: ") + hipGetErrorString(e));
+    ix->vis_words = vis_words;
+  }
+  VDB_HIP(hipMemsetAsync(ix->s_stats.p, 0, 16, st));
+  a.rows = ix->rows.as<float>();
+  a.norms = ix->norms.as<float>();
+  a.bits = ix->bits.as<uint32_t>();
+  a.alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
+  a.ext_ids = ix->ext_ids.as<uint64_t>();
+  a.queries = d_q;
+  a.row_stride = ix->row_stride;
+  a.q_stride = q_stride;
+  a.visited = ix->s_visited.as<uint32_t>();
+  a.vlog = ix->s_vlog.as<uint32_t>();
+  a.vis_words = vis_words;
+  a.out_ids = d_ids;
+  a.out_scores = d_scores;
+  a.out_n = d_n;
+  a.stats = ix->s_stats.as<unsigned long long>();
+  a.dim = ix->dim;
+  a.words = ix->words;
+  a.n_rows = (uint32_t)ix->n_rows;
+  a.nq = nq;
+  a.k = k;
+  a.ef = ef;
+  a.cap = (uint32_t)cap;
+  a.nbmax = nbmax;
+  a.vlog_cap = vlog_cap;
+  a.max_layer = ix->max_layer;
+  a.entry_point = (uint32_t)ix->entry_point;
+  a.metric = ix->metric;
+  EventPair* ev = next_events(ix);
+  if (ev) (void)hipEventRecord(ev->a, st);
+  hipError_t e = launch_hnsw_search(a, slots, st);
+  if (ev) (void)hipEventRecord(ev->b, st);
+  if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("hnsw_search launch: ") + hipGetErrorString(e));
+  ix->stats_pending = true;
+  return VDB_OK;
+}
+
+}  // namespace vdb

@@ -165,7 +165,7 @@ int32_t append_host_rows(vdb_hip_index* ix, const uint64_t* ids, const float* ve
   return finish_append(ix, first, m);
 }
 
-static EventPair* next_events(vdb_hip_index* ix) {
+EventPair* next_events(vdb_hip_index* ix) {
   if (!g_timing) return nullptr;
   if (ix->ev_used == ix->ev_pool.size()) {
     if (ix->ev_pool.size() >= 8192) return nullptr;
@@ -293,7 +293,8 @@ static uint32_t balanced_ef(uint32_t k) { return std::max<uint32_t>(128, k * 4);
 // dispatch of search_with_quality (search.rs:59-94) for device-resident queries
 static int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k,
                           uint32_t ef, int32_t mode, uint64_t* d_ids, float* d_scores, uint32_t* d_n,
-                          hipStream_t st) {
+                          hipStream_t st, uint32_t cap_mult = 1, bool* used_hnsw = nullptr) {
+  if (used_hnsw) *used_hnsw = false;
   ix->ev_used = 0;
   if (ix->n_rows == 0) {  // empty index: no entry point => empty result (native/graph.rs:252-255)
     if (nq) VDB_HIP(hipMemsetAsync(d_n, 0, (size_t)nq * 4, st));
@@ -305,7 +306,8 @@ static int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride
   if (mode != VDB_SEARCH_AUTO && mode != VDB_SEARCH_HNSW) return fail(VDB_ERR_INVALID_ARG, "bad search mode");
   if (ef == 0) ef = balanced_ef(k);
   ef = std::max(ef, k);  // SearchQuality::Custom(ef) = max(ef, k), params.rs:317
-  return hnsw_search_dev(ix, d_q, q_stride, nq, k, ef, d_ids, d_scores, d_n, st);
+  if (used_hnsw) *used_hnsw = true;
+  return hnsw_search_dev(ix, d_q, q_stride, nq, k, ef, cap_mult, d_ids, d_scores, d_n, st);
 }
 
 }  // namespace vdb
@@ -377,7 +379,7 @@ void vdb_hip_index_destroy(vdb_hip_index* ix) {
   (void)hipSetDevice(ix->device);
   (void)hipStreamSynchronize(ix->stream);
   for (DevBuf* b : {&ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids, &ix->s_queries, &ix->s_part_keys,
-                    &ix->s_part_cnt, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc})
+                    &ix->s_part_cnt, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc, &ix->s_visited, &ix->s_vlog, &ix->s_stats})
     b->release();
   for (auto& L : ix->layers) {
     L.nbr.release();
@@ -549,17 +551,27 @@ int32_t vdb_hip_index_search_batch(vdb_hip_index* ix, const float* queries, uint
   if (ix->row_stride != ix->dim) VDB_HIP(hipMemsetAsync(dq, 0, (size_t)nq * ix->row_stride * 4, st));
   VDB_HIP(hipMemcpy2DAsync(dq, ix->row_stride * 4, queries, (size_t)ix->dim * 4, (size_t)ix->dim * 4, nq,
                            hipMemcpyHostToDevice, st));
-  int32_t rc = search_dev(ix, dq, ix->row_stride, nq, k, ef, mode, ix->s_out_ids.as<uint64_t>(),
-                          ix->s_out_scores.as<float>(), ix->s_out_n.as<uint32_t>(), st);
-  if (rc != VDB_OK) {
-    (void)hipStreamSynchronize(st);
-    return rc;
+  // The traversal kernel reports (out_n = 0xFFFFFFFF) a query whose candidate list overflowed its LDS
+  // capacity (only possible with many exact distance ties); such a batch is re-run with more room.
+  for (uint32_t cap_mult = 1;; cap_mult *= 4) {
+    bool used_hnsw = false;
+    int32_t rc = search_dev(ix, dq, ix->row_stride, nq, k, ef, mode, ix->s_out_ids.as<uint64_t>(),
+                            ix->s_out_scores.as<float>(), ix->s_out_n.as<uint32_t>(), st, cap_mult, &used_hnsw);
+    if (rc != VDB_OK) {
+      (void)hipStreamSynchronize(st);
+      return rc;
+    }
+    VDB_HIP(hipMemcpyAsync(out_n, ix->s_out_n.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    VDB_HIP(hipStreamSynchronize(st));
+    bool overflow = false;
+    if (used_hnsw)
+      for (uint32_t i = 0; i < nq; i++) overflow |= out_n[i] == 0xFFFFFFFFu;
+    if (!overflow) break;
   }
   if (k) {
     VDB_HIP(hipMemcpyAsync(out_ids, ix->s_out_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
     VDB_HIP(hipMemcpyAsync(out_scores, ix->s_out_scores.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
   }
-  VDB_HIP(hipMemcpyAsync(out_n, ix->s_out_n.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
   VDB_HIP(hipStreamSynchronize(st));
   return VDB_OK;
 }
@@ -643,6 +655,15 @@ int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* ix, float* ms, uint32_t* lau
 int32_t vdb_hip_index_last_search_stats(vdb_hip_index* ix, uint64_t* n_dist, uint64_t* n_expand) {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   std::lock_guard<std::mutex> g(ix->mu);
+  if (ix->stats_pending) {
+    unsigned long long h[2] = {0, 0};
+    VDB_HIP(hipSetDevice(ix->device));
+    VDB_HIP(hipDeviceSynchronize());
+    VDB_HIP(hipMemcpy(h, ix->s_stats.p, 16, hipMemcpyDeviceToHost));
+    ix->last_n_dist = h[0];
+    ix->last_n_expand = h[1];
+    ix->stats_pending = false;
+  }
   if (n_dist) *n_dist = ix->last_n_dist;
   if (n_expand) *n_expand = ix->last_n_expand;
   return VDB_OK;

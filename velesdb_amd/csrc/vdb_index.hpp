@@ -82,6 +82,9 @@ struct vdb_hip_index {
 
   // scratch
   vdb::DevBuf s_queries, s_part_keys, s_part_cnt, s_out_ids, s_out_scores, s_out_n, s_qbits, s_misc;
+  vdb::DevBuf s_visited, s_vlog, s_stats;  // HNSW traversal scratch (hnsw_kernels.hip)
+  uint64_t vis_words = 0;
+  bool stats_pending = false;
   std::vector<vdb::EventPair> ev_pool;
   size_t ev_used = 0;
   uint64_t last_n_dist = 0, last_n_expand = 0;
@@ -96,7 +99,9 @@ int32_t append_host_rows(vdb_hip_index* ix, const uint64_t* ids, const float* ve
                          uint64_t* first_row);
 // graph.hip
 int32_t ensure_layers(vdb_hip_index* ix, uint32_t num_layers);
+EventPair* next_events(vdb_hip_index* ix);  // nullptr when kernel timing is off
+// hnsw_kernels.hip; cap_mult scales the room for tie candidates beyond ef (1 = default)
 int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint32_t ef,
-                        uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st);
+                        uint32_t cap_mult, uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st);
 int32_t graph_insert_rows(vdb_hip_index* ix, uint64_t first, uint64_t n);
 }  // namespace vdb

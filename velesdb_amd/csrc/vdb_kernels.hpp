@@ -65,6 +65,37 @@ struct ScoreArgs {
   int32_t aligned16;  // rows, query 16-B aligned and dim % 4 == 0
 };
 
+// ---- HNSW traversal (hnsw_kernels.hip) ----------------------------------------------------
+constexpr int kMaxLayers = 16;  // random_layer caps levels at 15 (native/graph.rs:401)
+struct HnswLayerRef {
+  const uint32_t* nbr;  // [capacity][stride] neighbour ids
+  const uint32_t* cnt;  // [capacity] neighbour counts
+  uint32_t stride;
+  uint32_t pad;
+};
+struct HnswSearchArgs {
+  const float* rows;
+  const float* norms;       // cosine only
+  const uint32_t* bits;     // hamming / jaccard only
+  const uint8_t* alive;     // nullable
+  const uint64_t* ext_ids;  // nullable -> node id
+  const float* queries;     // [nq][q_stride]
+  uint64_t row_stride, q_stride;
+  HnswLayerRef layers[kMaxLayers];
+  uint32_t* visited;        // [slots][vis_words] bitmaps, all zero between launches
+  uint32_t* vlog;           // [slots][vlog_cap] ids whose bit was set (for the per-query clean-up)
+  uint64_t vis_words;
+  uint64_t* out_ids;        // [nq][k]
+  float* out_scores;        // [nq][k]
+  uint32_t* out_n;          // [nq]; 0xFFFFFFFF = candidate list overflow (caller must re-run with a larger cap)
+  unsigned long long* stats;  // [2] += distance evaluations, expansions
+  uint32_t dim, words, n_rows, nq, k, ef, cap, nbmax, vlog_cap, max_layer, entry_point;
+  int32_t metric;
+};
+size_t hnsw_lds_bytes(uint32_t cap, uint32_t nbmax, uint32_t dim, uint32_t words, int metric);
+// returns hipSuccess or the launch error; grid = slots blocks of 256 threads
+hipError_t launch_hnsw_search(const HnswSearchArgs& a, int slots, hipStream_t st);
+
 size_t sweep_lds_bytes(int B, uint32_t k, uint32_t dim, int cpl);
 int sweep_cpl_for_dim(uint32_t dim);
 void launch_sweep_f32(int metric, int B, const SweepArgs& a, int blocks, hipStream_t st);
