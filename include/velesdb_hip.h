@@ -94,6 +94,16 @@ int32_t vdb_hip_index_insert(vdb_hip_index* idx, uint64_t id, const float* vec, 
  * dim floats each; *inserted = number of new ids (duplicates skipped). */
 int32_t vdb_hip_index_insert_batch(vdb_hip_index* idx, const uint64_t* ids, const float* vecs_rowmajor,
                                    uint64_t n, uint64_t* inserted);
+/* HnswIndex::insert_batch_parallel (batch.rs:83-108).  The reference inserts with rayon and is
+ * non-deterministic; here the batch is inserted batch-synchronously (every node of a sub-batch
+ * searches the graph as it was before the sub-batch, links applied sources ascending): deterministic,
+ * restated in oracle/vdb_oracle.cpp hnsw_insert_batch_sync.  max_batch = largest sub-batch (0 =
+ * default 2048; 1 = identical to insert_batch). */
+int32_t vdb_hip_index_insert_batch_parallel(vdb_hip_index* idx, const uint64_t* ids, const float* vecs_rowmajor,
+                                            uint64_t n, uint32_t max_batch, uint64_t* inserted);
+/* links every row that is not in the graph yet (rows that arrived through upload/upload_dev), same
+ * schedule as insert_batch_parallel; afterwards the HNSW search modes are available. */
+int32_t vdb_hip_index_build_graph(vdb_hip_index* idx, uint32_t max_batch);
 /* bulk upload without graph construction: vectors become searchable by VDB_SEARCH_BRUTE at
  * once; the graph is absent until vdb_hip_index_build_graph / load_reference_files.
  * (HnswIndex keeps exact search available independently of the graph, search.rs:176-219.) */

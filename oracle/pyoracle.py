@@ -78,6 +78,11 @@ def _declare(L):
     L.vo_hnsw_set_alpha.restype, L.vo_hnsw_set_alpha.argtypes = None, [vp, C.c_float]
     L.vo_hnsw_insert.restype, L.vo_hnsw_insert.argtypes = C.c_uint64, [vp, _f32p]
     L.vo_hnsw_len.restype, L.vo_hnsw_len.argtypes = C.c_uint64, [vp]
+    L.vo_hnsw_set_build_tie.restype, L.vo_hnsw_set_build_tie.argtypes = None, [vp, C.c_int]
+    L.vo_hnsw_insert_batch_sync.restype, L.vo_hnsw_insert_batch_sync.argtypes = None, [vp, _f32p, C.c_uint64]
+    L.vo_build_batch_size.restype, L.vo_build_batch_size.argtypes = C.c_uint32, [C.c_uint64, C.c_uint32]
+    L.vo_hnsw_build_batched.restype = None
+    L.vo_hnsw_build_batched.argtypes = [vp, _f32p, C.c_uint64, C.c_uint32]
     L.vo_hnsw_max_layer.restype, L.vo_hnsw_max_layer.argtypes = C.c_uint32, [vp]
     L.vo_hnsw_entry_point.restype, L.vo_hnsw_entry_point.argtypes = C.c_int64, [vp]
     L.vo_hnsw_num_layers.restype, L.vo_hnsw_num_layers.argtypes = C.c_uint32, [vp]
@@ -281,6 +286,17 @@ class NativeHnsw:
         v = _f(v)
         assert v.size == self.dim
         return int(lib().vo_hnsw_insert(self._h, v))
+
+    def set_build_tie(self, tie):
+        lib().vo_hnsw_set_build_tie(self._h, tie)
+
+    def insert_batch_sync(self, vecs):
+        vecs = _f(vecs).reshape(-1, self.dim)
+        lib().vo_hnsw_insert_batch_sync(self._h, vecs, vecs.shape[0])
+
+    def build_batched(self, vecs, max_batch):
+        vecs = _f(vecs).reshape(-1, self.dim)
+        lib().vo_hnsw_build_batched(self._h, vecs, vecs.shape[0], max_batch)
 
     def __len__(self):
         return int(lib().vo_hnsw_len(self._h))

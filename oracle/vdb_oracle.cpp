@@ -658,6 +658,7 @@ struct vo_hnsw {
   size_t M = 0, M0 = 0, efc = 0;                             // graph.rs:34-38, M0 = 2M :62
   double level_mult = 0.0;                                   // graph.rs:63
   float alpha = 1.0f;                                        // graph.rs:77
+  int build_tie = VO_TIE_REFERENCE;                          // order among equal distances fed to select_neighbors
   mutable std::vector<uint32_t> stamp;                       // visited set (membership only)
   mutable uint32_t epoch = 0;
 
@@ -840,7 +841,7 @@ uint64_t hnsw_insert(vo_hnsw& g, const float* v) {
     for (size_t l = max_layer; l >= node_layer + 1 && l > 0; l--)  // :189-192
       cur = search_layer_single(g, qv, cur, l);
     for (size_t li = node_layer + 1; li-- > 0;) {  // :195-223  (0..=node_layer).rev()
-      auto neighbors = search_layer(g, qv, {cur}, g.efc, li, VO_TIE_REFERENCE);
+      auto neighbors = search_layer(g, qv, {cur}, g.efc, li, g.build_tie);
       size_t max_conn = li == 0 ? g.M0 : g.M;
       std::vector<uint64_t> selected = select_neighbors(g, neighbors, max_conn);
       g.layers[li][node_id] = selected;  // set_neighbors :213
@@ -856,6 +857,86 @@ uint64_t hnsw_insert(vo_hnsw& g, const float* v) {
   }
   g.count++;
   return node_id;
+}
+
+// ---------------------------------------------------------------------------
+// Batch-synchronous insertion: the deterministic stand-in for NativeHnsw::parallel_insert
+// (backend_adapter.rs:110-123, rayon; non-deterministic in the reference).  Every node of the
+// batch runs the searches + select_neighbors of insert() (graph.rs:183-223) against the graph as
+// it was BEFORE the batch (same entry point / max layer for all); then the links are applied with
+// the reference's own rules (set_neighbors, add_bidirectional_connection), sources in ascending
+// node order.  A batch of one node is exactly hnsw_insert().  This is the algorithm of the GPU's
+// batched construction (velesdb_amd/csrc/hnsw_build.hip), restated here so it can be checked
+// link for link.
+// ---------------------------------------------------------------------------
+void hnsw_insert_batch_sync(vo_hnsw& g, const float* vecs, size_t n) {
+  if (n == 0) return;
+  const uint64_t first = g.vectors.size() / g.dim;
+  g.vectors.insert(g.vectors.end(), vecs, vecs + n * g.dim);
+  std::vector<size_t> level(n);
+  size_t top = 0;
+  for (size_t b = 0; b < n; b++) {
+    level[b] = random_layer(g.rng_state, g.level_mult);
+    top = std::max(top, level[b]);
+  }
+  while (g.layers.size() <= top) g.layers.emplace_back();
+  for (auto& L : g.layers)
+    if (L.size() < first + n) L.resize(first + n);
+  struct Sel {
+    uint64_t node;
+    float dist;
+  };
+  std::vector<std::vector<std::vector<Sel>>> sel(n);  // [b][layer] -> selected (id, dist to the new node)
+  const int64_t ep0 = g.entry_point;
+  const size_t max0 = g.max_layer;
+  for (size_t b = 0; b < n && ep0 >= 0; b++) {
+    const uint64_t node_id = first + b;
+    const float* qv = g.vec(node_id);
+    const size_t node_layer = level[b];
+    sel[b].resize(node_layer + 1);
+    uint64_t cur = (uint64_t)ep0;
+    for (size_t l = max0; l >= node_layer + 1 && l > 0; l--) cur = search_layer_single(g, qv, cur, l);
+    for (size_t li = node_layer + 1; li-- > 0;) {
+      auto neighbors = search_layer(g, qv, {cur}, g.efc, li, g.build_tie);
+      size_t max_conn = li == 0 ? g.M0 : g.M;
+      std::vector<uint64_t> selected = select_neighbors(g, neighbors, max_conn);
+      for (uint64_t s : selected) {
+        float d = 0.f;
+        for (auto& p : neighbors)
+          if (p.first == s) d = p.second;
+        sel[b][li].push_back({s, d});
+      }
+      if (!neighbors.empty()) cur = neighbors[0].first;
+    }
+  }
+  for (size_t b = 0; b < n; b++) {
+    const uint64_t node_id = first + b;
+    if (ep0 >= 0) {
+      for (size_t li = level[b] + 1; li-- > 0;) {
+        size_t max_conn = li == 0 ? g.M0 : g.M;
+        std::vector<uint64_t> ids;
+        for (auto& s : sel[b][li]) ids.push_back(s.node);
+        g.layers[li][node_id] = ids;
+        for (uint64_t nb : ids) add_bidirectional_connection(g, node_id, nb, li, max_conn);
+      }
+    } else if (g.entry_point < 0) {
+      g.entry_point = (int64_t)node_id;  // first node of an empty graph (graph.rs:226)
+    }
+    if (level[b] > g.max_layer) {
+      g.max_layer = level[b];
+      g.entry_point = (int64_t)node_id;
+    }
+    g.count++;
+  }
+}
+
+// deterministic batch schedule of the batched build: one node at a time while the graph is tiny,
+// then a sixteenth of the linked nodes per batch, capped
+uint32_t build_batch_size(uint64_t linked, uint32_t max_batch) {
+  uint64_t b = linked / 16;
+  if (b < 1) b = 1;
+  if (b > max_batch) b = max_batch;
+  return (uint32_t)b;
 }
 
 // graph.rs:251-270
@@ -1021,6 +1102,20 @@ vo_hnsw* vo_hnsw_new(uint32_t dim, int metric, int mode, uint32_t M, uint32_t ef
 }
 void vo_hnsw_free(vo_hnsw* g) { delete g; }
 void vo_hnsw_set_alpha(vo_hnsw* g, float alpha) { g->alpha = alpha; }
+void vo_hnsw_set_build_tie(vo_hnsw* g, int tie) { g->build_tie = tie; }
+void vo_hnsw_insert_batch_sync(vo_hnsw* g, const float* vecs, uint64_t n) { hnsw_insert_batch_sync(*g, vecs, n); }
+uint32_t vo_build_batch_size(uint64_t linked, uint32_t max_batch) { return build_batch_size(linked, max_batch); }
+/* whole build with the batched schedule: rows [0,n) appended to the graph */
+void vo_hnsw_build_batched(vo_hnsw* g, const float* vecs, uint64_t n, uint32_t max_batch) {
+  uint64_t pos = 0;
+  while (pos < n) {
+    uint64_t b = build_batch_size(g->count, max_batch);
+    if (g->entry_point < 0) b = 1;
+    if (b > n - pos) b = n - pos;
+    hnsw_insert_batch_sync(*g, vecs + pos * g->dim, b);
+    pos += b;
+  }
+}
 uint64_t vo_hnsw_insert(vo_hnsw* g, const float* v) { return hnsw_insert(*g, v); }
 uint64_t vo_hnsw_len(const vo_hnsw* g) { return g->count; }
 uint32_t vo_hnsw_max_layer(const vo_hnsw* g) { return (uint32_t)g->max_layer; }

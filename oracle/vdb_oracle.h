@@ -94,6 +94,15 @@ vo_hnsw* vo_hnsw_new(uint32_t dim, int metric, int mode, uint32_t M, uint32_t ef
 void vo_hnsw_free(vo_hnsw*);
 void vo_hnsw_set_alpha(vo_hnsw*, float alpha);
 uint64_t vo_hnsw_insert(vo_hnsw*, const float* vec); /* returns node id */
+/* order among equal distances in the candidate list that insert() feeds to select_neighbors:
+ * VO_TIE_REFERENCE (default, heap artefact) or VO_TIE_CANONICAL ((distance, node id) ascending, what
+ * the GPU construction kernels use). Identical whenever no two candidates are at the same distance. */
+void vo_hnsw_set_build_tie(vo_hnsw*, int tie);
+/* batch-synchronous insertion (deterministic stand-in for parallel_insert, backend_adapter.rs:110-123):
+ * all n searches see the graph as it was before the call, links applied sources ascending. n==1 == insert */
+void vo_hnsw_insert_batch_sync(vo_hnsw*, const float* vecs, uint64_t n);
+uint32_t vo_build_batch_size(uint64_t linked, uint32_t max_batch);
+void vo_hnsw_build_batched(vo_hnsw*, const float* vecs, uint64_t n, uint32_t max_batch);
 uint64_t vo_hnsw_len(const vo_hnsw*);
 uint32_t vo_hnsw_max_layer(const vo_hnsw*);
 int64_t vo_hnsw_entry_point(const vo_hnsw*); /* -1 if none */

@@ -1,0 +1,152 @@
+"""GPU parity tests for graph construction: NativeHnsw::insert (graph.rs:158-237), select_neighbors
+(graph.rs:526-581), add_bidirectional_connection (graph.rs:592-639) through the C ABI.
+
+Bar: the adjacency lists of EVERY node on EVERY layer, the entry point and the max layer are identical to
+the oracle's graph (oracle mode C arithmetic, canonical tie order) — for the sequential insert path and for
+the batch-synchronous path (oracle: hnsw_insert_batch_sync, same schedule)."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+va = pytest.importorskip("velesdb_amd")
+DM = va.DistanceMetric
+SQ = va.SearchQuality
+PO_METRIC = {DM.Cosine: po.COSINE, DM.Euclidean: po.EUCLIDEAN, DM.DotProduct: po.DOT, DM.Hamming: po.HAMMING,
+             DM.Jaccard: po.JACCARD}
+
+
+def data(rng, n, d, metric):
+    if metric in (DM.Hamming, DM.Jaccard):
+        return (rng.random((n, d)) > 0.6915).astype(np.float32)
+    return rng.standard_normal((n, d)).astype(np.float32)
+
+
+def oracle_graph(rows, metric, M, efc, max_batch=None):
+    g = po.NativeHnsw(rows.shape[1], PO_METRIC[metric], M, efc, po.MODE_C)
+    g.set_build_tie(po.TIE_CANONICAL)
+    if max_batch is None:
+        for v in rows:
+            g.insert(v)
+    else:
+        g.build_batched(rows, max_batch)
+    return g
+
+
+def assert_same_graph(g, ix, n):
+    nl, ml, ep = ix.graph_info()
+    assert (ml, ep) == (g.max_layer, g.entry_point)
+    assert nl == g.num_layers
+    for layer in range(g.num_layers):
+        for node in range(n):
+            a, b = ix.neighbors(layer, node), g.neighbors(layer, node)
+            assert a == b, f"layer {layer} node {node}:\n gpu {a}\n ora {b}"
+
+
+@pytest.mark.parametrize("metric", [DM.Cosine, DM.Euclidean, DM.DotProduct, DM.Hamming, DM.Jaccard])
+@pytest.mark.parametrize("n,dim,M,efc", [(500, 64, 6, 40), (300, 768, 8, 60)])
+def test_sequential_insert_link_for_link(metric, n, dim, M, efc):
+    rng = np.random.default_rng(100 + n + dim)
+    rows = data(rng, n, dim, metric)
+    g = oracle_graph(rows, metric, M, efc)
+    ix = va.HnswIndex(dim, metric, va.HnswParams(M, efc, n))
+    half = n // 2
+    for i in range(half):                     # VectorIndex::insert one by one
+        ix.insert(i, rows[i])
+    assert ix.insert_batch_sequential([(i, rows[i]) for i in range(half, n)]) == n - half
+    assert_same_graph(g, ix, n)
+    qs = data(rng, 8, dim, metric)
+    res = ix.search_batch_parallel(qs, 10, SQ.Custom(64))
+    for q, r in zip(qs, res):
+        oid, _ = g.search(q, 10, 64, po.TIE_CANONICAL)
+        assert [x[0] for x in r] == oid.tolist()
+
+
+@pytest.mark.parametrize("metric", [DM.Cosine, DM.Euclidean, DM.Hamming])
+def test_batched_build_link_for_link(metric):
+    n, dim, M, efc, mb = 2500, 96, 8, 60, 64
+    rng = np.random.default_rng(77)
+    rows = data(rng, n, dim, metric)
+    g = oracle_graph(rows, metric, M, efc, max_batch=mb)
+    ix = va.HnswIndex(dim, metric, va.HnswParams(M, efc, n))
+    ix.upload(np.arange(n), rows)
+    ix.build_graph(mb)
+    assert_same_graph(g, ix, n)
+    # insert_batch_parallel continues with the same schedule
+    more = data(rng, 300, dim, metric)
+    g.build_batched(more, mb)
+    assert ix.insert_batch_parallel([(n + i, more[i]) for i in range(300)], mb) == 300
+    assert_same_graph(g, ix, n + 300)
+
+
+def test_reference_fixture_graphs_built_on_gpu():
+    # native/graph_tests.rs:10-30 (ramp, Euclidean) and native/tests.rs:32-91 (sinusoid B, cosine recall >= 0.8)
+    rows = np.array([[32.0 * i + j for j in range(32)] for i in range(100)], dtype=np.float32)
+    ix = va.HnswIndex(32, DM.Euclidean, va.HnswParams(16, 100, 100))
+    for i, v in enumerate(rows):
+        ix.insert(i, v)
+    r = ix.search_batch_parallel(rows[:1], 10, SQ.Custom(50))[0]
+    assert r[0][0] == 0 and len(r) <= 10
+    assert_same_graph(oracle_graph(rows, DM.Euclidean, 16, 100), ix, 100)
+
+    i, j = np.meshgrid(np.arange(200), np.arange(128), indexing="ij")
+    rows = np.sin(0.001 * (128.0 * i + j)).astype(np.float32)
+    ix = va.HnswIndex(128, DM.Cosine, va.HnswParams(16, 100, 200))
+    ix.insert_batch_sequential([(k, rows[k]) for k in range(200)])
+    rec = []
+    for qi in (0, 40, 80, 120, 160):
+        r = ix.search_batch_parallel(rows[qi:qi + 1], 10, SQ.Custom(128))[0]
+        gt, _ = po.scan_topk(po.COSINE, rows, rows[qi:qi + 1], 10, po.MODE_C)
+        rec.append(len({x for x, _ in r} & set(gt[0].tolist())) / 10)
+    assert np.mean(rec) >= 0.8
+
+
+def test_duplicates_skipped_and_ids_mapped():
+    # trait_impl.rs:23-25: duplicate external id => no-op; results carry external ids
+    rng = np.random.default_rng(9)
+    rows = rng.standard_normal((200, 32)).astype(np.float32)
+    ix = va.HnswIndex(32, DM.Cosine, va.HnswParams(8, 50, 200))
+    for i in range(200):
+        ix.insert(1000 + 7 * i, rows[i])
+    ix.insert(1000, rows[5])  # duplicate id: ignored
+    assert ix.len() == 200 and ix.node_count() == 200
+    r = ix.search(rows[17], 5)
+    assert r[0][0] == 1000 + 7 * 17 and r[0][1] == pytest.approx(1.0, abs=1e-5)
+
+
+def test_recall_of_batched_build_20k():
+    # index_tests.rs:1106-1158 style gate (recall@10 >= 0.95), at a size where the batch schedule matters
+    n, dim = 20000, 128
+    rng = np.random.default_rng(42)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    qs = rng.standard_normal((100, dim)).astype(np.float32)
+    ix = va.HnswIndex(dim, DM.Cosine, va.HnswParams(16, 200, n))
+    ix.upload(np.arange(n), rows)
+    ix.build_graph(0)
+    res = ix.search_batch_parallel(qs, 10, SQ.Custom(256))
+    gt, _, _ = ix.search_batch_brute_force(qs, 10)
+    rec = np.mean([len({x for x, _ in r} & set(gt[i].tolist())) / 10 for i, r in enumerate(res)])
+    assert rec >= 0.95, rec
+
+
+def test_save_load_roundtrip_and_insert_after_load(tmp_path):
+    # file format v1 (backend_adapter.rs:184-381): GPU-built graph -> files -> oracle; oracle files -> GPU,
+    # then further inserts (distance cache recomputed on the device) stay link-for-link with the oracle
+    rng = np.random.default_rng(21)
+    rows = rng.standard_normal((400, 48)).astype(np.float32)
+    ix = va.HnswIndex(48, DM.Euclidean, va.HnswParams(8, 50, 600))
+    ix.insert_batch_sequential([(i, rows[i]) for i in range(400)])
+    ix.save(str(tmp_path), "native_hnsw")
+    g = po.NativeHnsw.file_load(str(tmp_path), "native_hnsw", po.EUCLIDEAN, po.MODE_C)
+    g.dim = 48
+    g.set_build_tie(po.TIE_CANONICAL)
+    assert_same_graph(g, ix, 400)
+    ix2 = va.HnswIndex(48, DM.Euclidean, va.HnswParams(8, 50, 600))
+    ix2.load_reference_files(str(tmp_path), "native_hnsw")
+    more = rng.standard_normal((150, 48)).astype(np.float32)
+    for i, v in enumerate(more):   # both sides restart the level RNG after a load (backend_adapter.rs:373)
+        g.insert(v)
+        ix2.insert(400 + i, v)
+    assert_same_graph(g, ix2, 550)

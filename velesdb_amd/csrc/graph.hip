@@ -20,15 +20,11 @@ int32_t ensure_layers(vdb_hip_index* ix, uint32_t num_layers) {
     hipError_t e = L.nbr.reserve(ix->capacity * L.stride * 4, false, ix->stream);
     if (e == hipSuccess) e = L.cnt.reserve(ix->capacity * 4, false, ix->stream);
     if (e == hipSuccess) e = hipMemsetAsync(L.cnt.p, 0, L.cnt.cap, ix->stream);
+    if (e == hipSuccess && ix->ndist_valid) e = L.ndist.reserve(ix->capacity * L.stride * 4, false, ix->stream);
     if (e != hipSuccess) return fail(VDB_ERR_OOM, std::string("graph layer: ") + hipGetErrorString(e));
     ix->layers.push_back(L);
   }
   return VDB_OK;
-}
-
-// construction launch path: filled in by hnsw_build.hip
-int32_t graph_insert_rows(vdb_hip_index*, uint64_t, uint64_t) {
-  return fail(VDB_ERR_UNSUPPORTED, "HNSW construction kernel not built in this library");
 }
 
 }  // namespace vdb
@@ -113,8 +109,10 @@ int32_t vdb_hip_index_load_reference_files(vdb_hip_index* ix, const char* dir, c
   for (auto& L : ix->layers) {
     L.nbr.release();
     L.cnt.release();
+    L.ndist.release();
   }
   ix->layers.clear();
+  ix->ndist_valid = false;  // the files carry no distances; recomputed before the first insert
   std::vector<std::vector<uint32_t>> h_nbr(num_layers), h_cnt(num_layers);
   for (uint32_t l = 0; l < num_layers && ok; l++) {
     const uint32_t stride = l == 0 ? M0 : M;

@@ -81,7 +81,8 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
     return fail(VDB_ERR_OOM, std::string("grow bits: ") + hipGetErrorString(e));
   for (auto& L : ix->layers) {
     if ((e = L.nbr.reserve(ncap * L.stride * 4, true, st)) != hipSuccess ||
-        (e = L.cnt.reserve(ncap * 4, true, st)) != hipSuccess)
+        (e = L.cnt.reserve(ncap * 4, true, st)) != hipSuccess ||
+        (ix->ndist_valid && (e = L.ndist.reserve(ncap * L.stride * 4, true, st)) != hipSuccess))
       return fail(VDB_ERR_OOM, std::string("grow graph: ") + hipGetErrorString(e));
     // rows beyond the old capacity have no links yet (Layer::ensure_capacity, layer.rs:26-30)
     if ((e = hipMemsetAsync(L.cnt.as<uint32_t>() + ix->capacity, 0, (ncap - ix->capacity) * 4, st)) != hipSuccess)
@@ -379,11 +380,13 @@ void vdb_hip_index_destroy(vdb_hip_index* ix) {
   (void)hipSetDevice(ix->device);
   (void)hipStreamSynchronize(ix->stream);
   for (DevBuf* b : {&ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids, &ix->s_queries, &ix->s_part_keys,
-                    &ix->s_part_cnt, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc, &ix->s_visited, &ix->s_vlog, &ix->s_stats})
+                    &ix->s_part_cnt, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels,
+                    &ix->s_req_keys, &ix->s_req_vals, &ix->s_sort_tmp})
     b->release();
   for (auto& L : ix->layers) {
     L.nbr.release();
     L.cnt.release();
+    L.ndist.release();
   }
   for (auto& e : ix->ev_pool) {
     (void)hipEventDestroy(e.a);
@@ -406,7 +409,7 @@ int32_t vdb_hip_index_insert(vdb_hip_index* ix, uint64_t id, const float* vec, u
   if (rc != VDB_OK) return rc;
   if (ins == 0) return VDB_DUPLICATE_IGNORED;
   if (ix->graph_valid) {
-    rc = graph_insert_rows(ix, first, 1);
+    rc = graph_insert_rows(ix, first, 1, 1);
     if (rc != VDB_OK) return rc;
   }
   return VDB_OK;
@@ -422,7 +425,33 @@ int32_t vdb_hip_index_insert_batch(vdb_hip_index* ix, const uint64_t* ids, const
   int32_t rc = append_host_rows(ix, ids, vecs, n, &ins, &first);
   if (inserted) *inserted = ins;
   if (rc != VDB_OK) return rc;
-  if (ins && ix->graph_valid) rc = graph_insert_rows(ix, first, ins);
+  if (ins && ix->graph_valid) rc = graph_insert_rows(ix, first, ins, 1);
+  return rc;
+}
+
+// HnswIndex::insert_batch_parallel — batch.rs:83-108 (rayon in the reference, non-deterministic there;
+// here batch-synchronous and deterministic, hnsw_build.hip)
+int32_t vdb_hip_index_insert_batch_parallel(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, uint64_t n,
+                                            uint32_t max_batch, uint64_t* inserted) {
+  if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  VDB_HIP(hipSetDevice(ix->device));
+  uint64_t ins = 0, first = 0;
+  int32_t rc = append_host_rows(ix, ids, vecs, n, &ins, &first);
+  if (inserted) *inserted = ins;
+  if (rc != VDB_OK) return rc;
+  if (ins && ix->graph_valid) rc = graph_insert_rows(ix, first, ins, max_batch);
+  return rc;
+}
+
+// links every row that is not in the graph yet (rows that arrived through upload / upload_dev)
+int32_t vdb_hip_index_build_graph(vdb_hip_index* ix, uint32_t max_batch) {
+  if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  VDB_HIP(hipSetDevice(ix->device));
+  int32_t rc = VDB_OK;
+  if (ix->graph_nodes < ix->n_rows) rc = graph_insert_rows(ix, ix->graph_nodes, ix->n_rows - ix->graph_nodes, max_batch);
+  if (rc == VDB_OK) ix->graph_valid = true;
   return rc;
 }
 

@@ -43,6 +43,7 @@ struct DevBuf {
 struct GraphLayer {
   DevBuf nbr;  // [capacity][stride] u32
   DevBuf cnt;  // [capacity] u32
+  DevBuf ndist;  // [capacity][stride] f32: distance node <-> neighbour (construction cache, hnsw_build.hip)
   uint32_t stride = 0;
 };
 
@@ -83,6 +84,8 @@ struct vdb_hip_index {
   // scratch
   vdb::DevBuf s_queries, s_part_keys, s_part_cnt, s_out_ids, s_out_scores, s_out_n, s_qbits, s_misc;
   vdb::DevBuf s_visited, s_vlog, s_stats;  // HNSW traversal scratch (hnsw_kernels.hip)
+  vdb::DevBuf s_levels, s_req_keys, s_req_vals, s_sort_tmp;  // construction scratch (hnsw_build.hip)
+  bool ndist_valid = true;  // false for a graph loaded from files until the cache is recomputed
   uint64_t vis_words = 0;
   bool stats_pending = false;
   std::vector<vdb::EventPair> ev_pool;
@@ -103,5 +106,8 @@ EventPair* next_events(vdb_hip_index* ix);  // nullptr when kernel timing is off
 // hnsw_kernels.hip; cap_mult scales the room for tie candidates beyond ef (1 = default)
 int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint32_t ef,
                         uint32_t cap_mult, uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st);
-int32_t graph_insert_rows(vdb_hip_index* ix, uint64_t first, uint64_t n);
+// hnsw_build.hip; max_batch 1 = the reference's sequential insert, 0 = default batched schedule
+int32_t graph_insert_rows(vdb_hip_index* ix, uint64_t first, uint64_t n, uint32_t max_batch);
+int32_t ensure_traversal_scratch(vdb_hip_index* ix, hipStream_t st);  // visited bitmaps + logs + stats
+constexpr uint32_t kVlogCap = 16384;
 }  // namespace vdb

@@ -194,7 +194,24 @@ class HnswIndex:
         check(lib().vdb_hip_index_insert_batch(self._h, _ptr(ids), _ptr(vecs), len(items), C.byref(n)))
         return int(n.value)
 
-    insert_batch_parallel = insert_batch_sequential  # batch.rs:83-108 (deterministic here)
+    def insert_batch_parallel(self, vectors: Iterable[Tuple[int, Sequence[float]]], max_batch: int = 0) -> int:
+        """batch.rs:83-108.  Batch-synchronous and deterministic here (rayon, non-deterministic, there)."""
+        items = list(vectors)
+        if not items:
+            return 0
+        ids = np.ascontiguousarray([i for i, _ in items], dtype=np.uint64)
+        for _, v in items:
+            assert len(v) == self._dimension, \
+                f"Vector dimension mismatch: expected {self._dimension}, got {len(v)}"
+        vecs = _f32([v for _, v in items])
+        n = C.c_uint64(0)
+        check(lib().vdb_hip_index_insert_batch_parallel(self._h, _ptr(ids), _ptr(vecs), len(items), max_batch,
+                                                        C.byref(n)))
+        return int(n.value)
+
+    def build_graph(self, max_batch: int = 0) -> None:
+        """Links every uploaded row that is not in the graph yet (batched GPU construction)."""
+        check(lib().vdb_hip_index_build_graph(self._h, max_batch))
 
     def upload(self, ids, vectors) -> int:
         """Bulk upload without graph construction (exact search only until a graph exists)."""
