@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): 1M x 768-D f32 cosine, k=10, exact distance sweep + fused
-GPU top-k (HnswIndex::search_brute_force semantics, recall@10 = 1.0 by construction).
-A "step" = one batch of --batch queries searched against the HBM-resident corpus through the
-C ABI's device-pointer entry point (vdb_hip_index_search_batch_dev); value = whole-job queries/s.
+Headline workload (BASELINE.json configs[1]): 1M x 768-D f32 cosine, k=10, exact distance sweep + fused
+GPU top-k (HnswIndex::search_brute_force semantics, recall@10 = 1.0 by construction).  A "step" = one batch
+of --batch queries searched against the HBM-resident corpus through the C ABI's device-pointer entry point
+(vdb_hip_index_search_batch_dev); value = whole-job queries/s, inputs resident in HBM.
+
+The same run also measures configs[2] (the "hnsw" object): the HNSW graph is built on the GPU over the same
+corpus (batched construction), then --hnsw-batch queries per step go through the traversal kernel at
+ef = --ef; recall@10 against the exact result, distance evaluations / expansions counted by the kernel =>
+algorithmic bytes => achieved HBM GB/s.  Rank 0 times the CPU restatement of the reference beside both legs
+(oracle mode R brute force; oracle HNSW search over the very same graph, all host cores).
 
     python bench.py                       # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU.  Headline = replica mode (every GPU holds the corpus, the query
-stream is split: no data-path collective, weak scaling).  The same run also measures the
-range-sharded mode (every GPU holds a different 1M-row shard, per-shard top-k, ONE RCCL
-all-gather of k (id,score) pairs per query, merge) and reports it under "sharded".
+N > 1: one process per GPU.  Headline = replica mode (every GPU holds the corpus, the query stream is split:
+no data-path collective, weak scaling).  The same run also measures the range-sharded mode (every GPU holds a
+different 1M-row shard, per-shard top-k, ONE RCCL all-gather of k (id,score) pairs per query, merge) and
+reports it under "sharded".
 """
 import argparse
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,12 +43,21 @@ def parse():
     p.add_argument("--rows", type=int, default=1_000_000)
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--k", type=int, default=10)
-    p.add_argument("--batch", type=int, default=64, help="queries per step")
+    p.add_argument("--batch", type=int, default=64, help="queries per step (exact sweep)")
     p.add_argument("--metric", default="cosine")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=int, default=262_144)
     p.add_argument("--cpu-sample-queries", type=int, default=32)
     p.add_argument("--check-queries", type=int, default=2)
+    # graph leg (configs[2])
+    p.add_argument("--no-hnsw", action="store_true")
+    p.add_argument("--hnsw-batch", type=int, default=8192, help="queries per step (graph traversal)")
+    p.add_argument("--hnsw-steps", type=int, default=5)
+    p.add_argument("--ef", type=int, default=128)
+    p.add_argument("--M", type=int, default=32)
+    p.add_argument("--efc", type=int, default=400)
+    p.add_argument("--recall-queries", type=int, default=1000)
+    p.add_argument("--cpu-hnsw-queries", type=int, default=20000)
     return p.parse_args()
 
 
@@ -72,9 +89,9 @@ def main():
     g.manual_seed(42)
     corpus = torch.randn((N, D), generator=g, device=dev, dtype=torch.float32)
     g.manual_seed(43)
-    n_query_pool = max(Q * 4, 256)
+    n_query_pool = max(Q * 4, 256, 0 if a.no_hnsw else a.hnsw_batch)
     queries = torch.randn((n_query_pool, D), generator=g, device=dev, dtype=torch.float32)
-    ix = va.HnswIndex(D, metric, va.HnswParams(32, 400, N), device=local)
+    ix = va.HnswIndex(D, metric, va.HnswParams(a.M, a.efc, N), device=local)
     stream = torch.cuda.current_stream().cuda_stream
     torch.cuda.synchronize()
     ix.upload_dev(0, corpus.data_ptr(), N, stream)
@@ -101,6 +118,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
     for i in range(a.warmup):
         step(i)
     barrier()
@@ -112,10 +136,7 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms, kernel_launches = ix.last_kernel_ms()  # HIP events around the sweep kernel, last step
     va.set_kernel_timing(False)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt)
     qps = world * Q * a.steps / dt
 
     # ---- roofline of the dominant kernel (the sweep): algorithmic bytes / measured duration ----
@@ -172,12 +193,62 @@ def main():
         for i in range(a.steps):
             sharded_step(a.warmup + i)
         barrier()
-        sdt = time.perf_counter() - t2
-        t = torch.tensor([sdt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        sdt = float(t.item())
+        sdt = max_over_ranks(time.perf_counter() - t2)
         sharded = {"qps": round(Q * a.steps / sdt, 1), "corpus_rows": world * N, "ms_per_step": round(sdt / a.steps * 1e3, 4),
                    "collective": "all_gather_into_tensor(ids u64, scores f32), %d B/query/GPU" % (K * 12)}
+
+    # ---- graph leg (configs[2]): GPU construction + traversal kernel ----
+    hnsw = None
+    graph_dir = None
+    if not a.no_hnsw:
+        HQ = min(a.hnsw_batch, n_query_pool)
+        h_ids = torch.empty((HQ, K), dtype=torch.int64, device=dev)
+        h_sc = torch.empty((HQ, K), dtype=torch.float32, device=dev)
+        h_n = torch.empty((HQ,), dtype=torch.int32, device=dev)
+        barrier()
+        tb = time.perf_counter()
+        ix.build_graph(0)
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - tb
+
+        def hstep():
+            ix.search_batch_dev(queries.data_ptr(), HQ, K, a.ef, va.MODE_HNSW, h_ids.data_ptr(), h_sc.data_ptr(),
+                                h_n.data_ptr(), stream)
+
+        hstep()
+        barrier()
+        va.set_kernel_timing(True)
+        th = time.perf_counter()
+        for _ in range(a.hnsw_steps):
+            hstep()
+        barrier()
+        hdt = max_over_ranks(time.perf_counter() - th)
+        hk_ms, hk_n = ix.last_kernel_ms()
+        va.set_kernel_timing(False)
+        n_dist, n_expand = ix.last_search_stats()  # of the last batch
+        hbytes = n_dist * D * 4 + n_expand * 2 * a.M * 4
+        hgbs = hbytes / (hk_ms * 1e-3) / 1e9 if hk_ms > 0 else 0.0
+        # recall@10 against the exact top-k (the sweep, itself bit-checked against the oracle)
+        RQ = min(a.recall_queries, HQ)
+        rq = queries[:RQ].cpu().numpy()
+        gt, _, _ = ix.search_batch_brute_force(rq, K)
+        hi = h_ids[:RQ].cpu().numpy()
+        recall_h = float(np.mean([len(set(hi[i].tolist()) & set(gt[i].tolist())) / K for i in range(RQ)]))
+        hnsw = {"workload": f"{N}x{D} f32 {a.metric}, HNSW graph in HBM (M={a.M}, M0={2 * a.M}, ef_construction={a.efc}, "
+                            f"built on the GPU), k={K}, ef={a.ef}, {HQ} queries/step (BASELINE configs[2])",
+                "qps": round(world * HQ * a.hnsw_steps / hdt, 1), "ms_per_step": round(hdt / a.hnsw_steps * 1e3, 3),
+                "recall_at_10": round(recall_h, 4), "recall_queries": RQ,
+                "build_seconds": round(build_s, 2), "build_inserts_per_s": round(N / build_s, 1),
+                "n_dist_per_query": round(n_dist / HQ, 1), "n_expand_per_query": round(n_expand / HQ, 1),
+                "roofline": {"bound": "hbm", "achieved": round(hgbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(hgbs / HBM_PEAK_GBS, 4), "traffic": None,
+                             "kernel": f"hnsw_search_kernel<{a.metric},CPL={D // 256 if D % 256 == 0 else 0}>",
+                             "kernel_ms": round(hk_ms, 4), "launches_timed": hk_n,
+                             "alg_bytes_per_launch": hbytes,
+                             "alg_bytes_rule": "n_dist*dim*4 + n_expand*M0*4, counters from the kernel"}}
+        if rank == 0 and not a.no_cpu_baseline:
+            graph_dir = tempfile.mkdtemp(prefix="vdb_bench_")
+            ix.save(graph_dir, "native_hnsw")
 
     # ---- exactness / recall check against the oracle on the full corpus (rank 0) ----
     recall = None
@@ -212,6 +283,40 @@ def main():
                              f"{sample_rows} rows x {sq} queries, {ncores} threads, {cdt:.2f} s; value = measured "
                              f"{cpu_qps_sample:.1f} q/s scaled by {sample_rows}/{N} to the full corpus",
                    "measured_qps_on_sample": round(cpu_qps_sample, 2)}
+            if graph_dir is not None:
+                # the reference's graph search on the host cores, over the SAME graph (loaded from the files the
+                # GPU index wrote in the reference's format), mode R arithmetic, reference tie order
+                tl = time.perf_counter()
+                og = po.NativeHnsw.file_load(graph_dir, "native_hnsw", om, po.MODE_R)
+                load_s = time.perf_counter() - tl
+                cq = min(a.cpu_hnsw_queries, n_query_pool)
+                qh = queries[:cq].cpu().numpy()
+                t4 = time.perf_counter()
+                oi, od, oc, ond, one = og.search_batch(qh, K, a.ef, po.TIE_REFERENCE, nthreads=ncores)
+                hdt_cpu = time.perf_counter() - t4
+                # parity of the GPU traversal with the canonical oracle on a few queries of the same graph
+                og_c = po.NativeHnsw.file_load(graph_dir, "native_hnsw", om, po.MODE_C)
+                pq = min(8, cq)
+                ci, cd, cc, _, _ = og_c.search_batch(qh[:pq], K, a.ef, po.TIE_CANONICAL, nthreads=min(pq, ncores))
+                gi = h_ids[:pq].cpu().numpy().astype(np.uint64)
+                gsim = h_sc[:pq].cpu().numpy()
+                exp_sim = np.array([[po.transform_score(om, float(x)) for x in row] for row in cd], dtype=np.float32)
+                rq_n = min(RQ, cq)
+                rec_cpu = float(np.mean([len(set(oi[i].tolist()) & set(gt[i].tolist())) / K for i in range(rq_n)]))
+                hnsw["cpu_baseline"] = {
+                    "value": round(cq / hdt_cpu, 1), "unit": "queries/s", "cores": ncores, "kind": "port",
+                    "recall_at_10": round(rec_cpu, 4),
+                    "sample": f"oracle NativeHnsw::search (mode R, reference heap/tie order, reference's neighbour "
+                              f"prefetch) over the same {N}-node graph, {cq} queries, ef={a.ef}, {ncores} threads, "
+                              f"{hdt_cpu:.2f} s (+{load_s:.1f} s loading the graph files)",
+                    "n_dist_per_query": round(ond / cq, 1)}
+                hnsw["parity_check"] = {"queries": pq, "ids_equal_oracle_canonical": bool(np.array_equal(gi, ci)),
+                                        "scores_bit_equal_oracle_canonical":
+                                            bool(np.array_equal(gsim.view(np.uint32), exp_sim.view(np.uint32)))}
+                hnsw["gpu_over_cpu"] = round(hnsw["qps"] / (cq / hdt_cpu), 2)
+                del og, og_c
+        if graph_dir is not None:
+            shutil.rmtree(graph_dir, ignore_errors=True)
 
     if rank == 0:
         line = {
@@ -223,7 +328,7 @@ def main():
                        "rows": N, "dim": D, "k": K, "queries_per_step": Q,
                        "parallelism": "replicas x%d (query stream split, no collective)" % world},
             "recall_at_10": recall, "parity_check": check,
-            "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "sharded": sharded,
+            "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "sharded": sharded, "hnsw": hnsw,
             "device": va.device_name(local),
         }
         print(json.dumps(line))

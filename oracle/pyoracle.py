@@ -91,6 +91,9 @@ def _declare(L):
     L.vo_hnsw_vector.restype, L.vo_hnsw_vector.argtypes = C.POINTER(C.c_float), [vp, C.c_uint64]
     L.vo_hnsw_search.restype = C.c_uint32
     L.vo_hnsw_search.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_int, _u64p, _f32p]
+    L.vo_hnsw_search_batch.restype = None
+    L.vo_hnsw_search_batch.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, _u64p,
+                                       _f32p, _u32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.vo_hnsw_last_stats.restype = None
     L.vo_hnsw_last_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.vo_hnsw_search_layer_single.restype = C.c_uint64
@@ -328,6 +331,17 @@ class NativeHnsw:
         ds = np.empty(max(k, 1), dtype=np.float32)
         n = lib().vo_hnsw_search(self._h, q, k, ef, tie, ids, ds)
         return ids[:n].copy(), ds[:n].copy()
+
+    def search_batch(self, queries, k, ef, tie=TIE_REFERENCE, nthreads=1):
+        """-> (nodes [nq,k], dist [nq,k], count [nq], total n_dist, total n_expand)"""
+        queries = _f(queries)
+        nq = queries.shape[0]
+        ids = np.zeros((nq, k), dtype=np.uint64)
+        ds = np.zeros((nq, k), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        lib().vo_hnsw_search_batch(self._h, queries, nq, k, ef, tie, nthreads, ids, ds, cnt, C.byref(a), C.byref(b))
+        return ids, ds, cnt, int(a.value), int(b.value)
 
     @staticmethod
     def last_stats():

@@ -1409,6 +1409,99 @@ void vo_index_search_batch(const vo_index* ix, const float* queries, uint32_t nq
   }
 }
 
+// NativeHnsw::search over a batch of queries with nthreads host threads (one search per thread at a
+// time, like rayon in search_batch_parallel, batch.rs:180-194), on a bare graph (e.g. one loaded from
+// the reference's files).  Used by bench.py's CPU leg for the graph path; includes the reference's
+// software prefetch of upcoming neighbour vectors (graph.rs:482-497: first cache line, T0, 16 ahead
+// when dim >= 384) — a performance hint with no effect on results.
+void vo_hnsw_search_batch(const vo_hnsw* gp, const float* queries, uint32_t nq, uint32_t k, uint32_t ef_in,
+                          int tie, uint32_t nthreads, uint64_t* out_nodes, float* out_dist, uint32_t* out_n,
+                          uint64_t* total_n_dist, uint64_t* total_n_expand) {
+  const vo_hnsw& g = *gp;
+  const size_t ef = std::max<size_t>(ef_in, k);
+  if (nthreads < 1) nthreads = 1;
+  std::atomic<uint32_t> next(0);
+  std::atomic<uint64_t> nd_total(0), ne_total(0);
+  const size_t pd = std::min<size_t>(16, std::max<size_t>(4, (size_t)g.dim * 4 / 64));  // core/simd.rs:40-51
+  auto worker = [&]() {
+    std::vector<uint32_t> stamp(g.vectors.size() / g.dim, 0);
+    uint32_t epoch = 0;
+    tl_n_dist = 0;
+    uint64_t n_expand = 0;
+    for (;;) {
+      uint32_t qi = next.fetch_add(1);
+      if (qi >= nq) break;
+      const float* q = queries + (size_t)qi * g.dim;
+      std::vector<std::pair<uint64_t, float>> res;
+      if (g.entry_point >= 0) {
+        uint64_t cur = (uint64_t)g.entry_point;
+        for (size_t l = g.max_layer; l >= 1; l--) cur = search_layer_single(g, q, cur, l);
+        if (++epoch == 0) {
+          std::fill(stamp.begin(), stamp.end(), 0);
+          epoch = 1;
+        }
+        RustHeap<true> candidates;
+        RustHeap<false> results;
+        {
+          float d = g.dist(q, g.vec(cur));
+          candidates.push({d, cur});
+          results.push({d, cur});
+          stamp[cur] = epoch;
+        }
+        while (!candidates.empty()) {
+          HeapItem c = candidates.pop();
+          float furthest = results.empty() ? std::numeric_limits<float>::max() : results.peek().d;
+          if (c.d > furthest && results.size() >= ef) break;
+          n_expand++;
+          const std::vector<uint64_t>& nbs = g.nbrs(0, c.node);
+          const bool pf = g.dim >= 384 && nbs.size() > pd;
+          if (pf)
+            for (size_t i = 0; i < pd; i++) __builtin_prefetch(g.vec(nbs[i]), 0, 3);
+          for (size_t i = 0; i < nbs.size(); i++) {
+            if (g.dim >= 384 && i + pd < nbs.size()) __builtin_prefetch(g.vec(nbs[i + pd]), 0, 3);
+            const uint64_t nb = nbs[i];
+            if (stamp[nb] == epoch) continue;
+            stamp[nb] = epoch;
+            float d = g.dist(q, g.vec(nb));
+            float far = results.empty() ? std::numeric_limits<float>::max() : results.peek().d;
+            if (d < far || results.size() < ef) {
+              candidates.push({d, nb});
+              results.push({d, nb});
+              if (results.size() > ef) results.pop();
+            }
+          }
+        }
+        for (const HeapItem& it : results.data) res.emplace_back(it.node, it.d);
+        if (tie == VO_TIE_CANONICAL)
+          std::sort(res.begin(), res.end(), [](const auto& a, const auto& b) {
+            int c = total_cmp(a.second, b.second);
+            return c ? c < 0 : a.first < b.first;
+          });
+        else
+          std::stable_sort(res.begin(), res.end(),
+                           [](const auto& a, const auto& b) { return total_cmp(a.second, b.second) < 0; });
+        if (res.size() > k) res.resize(k);
+      }
+      for (size_t i = 0; i < res.size(); i++) {
+        out_nodes[(size_t)qi * k + i] = res[i].first;
+        out_dist[(size_t)qi * k + i] = res[i].second;
+      }
+      out_n[qi] = (uint32_t)res.size();
+    }
+    nd_total += tl_n_dist;
+    ne_total += n_expand;
+  };
+  if (nthreads == 1) {
+    worker();
+  } else {
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nthreads; t++) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+  }
+  if (total_n_dist) *total_n_dist = nd_total.load();
+  if (total_n_expand) *total_n_expand = ne_total.load();
+}
+
 // Flat exact scan used by bench.py's cpu_baseline leg and by the large-N parity tests:
 // search_brute_force semantics (hnsw/index/search.rs:197-218) over a row-major corpus,
 // rows split over nthreads like brute_force_search_parallel (hnsw/index/batch.rs:223-244).

@@ -114,6 +114,11 @@ const float* vo_hnsw_vector(const vo_hnsw*, uint64_t node);
 /* search(query,k,ef) (graph.rs:251-270); returns count */
 uint32_t vo_hnsw_search(const vo_hnsw*, const float* q, uint32_t k, uint32_t ef, int tie,
                         uint64_t* out_nodes, float* out_dist);
+/* batch of searches on nthreads host threads (rayon-style, batch.rs:180-194) with the reference's
+ * neighbour prefetch; totals of distance evaluations / expansions are returned if non-NULL */
+void vo_hnsw_search_batch(const vo_hnsw*, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int tie,
+                          uint32_t nthreads, uint64_t* out_nodes, float* out_dist, uint32_t* out_n,
+                          uint64_t* total_n_dist, uint64_t* total_n_expand);
 /* search statistics of the last vo_hnsw_search on this thread: distance evals, expansions */
 void vo_hnsw_last_stats(uint64_t* n_dist, uint64_t* n_expand);
 uint64_t vo_hnsw_search_layer_single(const vo_hnsw*, const float* q, uint64_t entry,
