@@ -166,6 +166,9 @@ int32_t vdb_hip_index_last_search_stats(vdb_hip_index* idx, uint64_t* n_dist, ui
 /* average duration (ms) of the dominant kernel in the last search call, measured with HIP
  * events on the launch stream; 0 if timing is off.  Enable with vdb_hip_set_kernel_timing(1). */
 int32_t vdb_hip_set_kernel_timing(int32_t on);
+/* tuning knob of the exact sweep: largest number of queries served by one corpus pass
+ * (1,2,4,8 register-resident tiles; 16,32 LDS-resident tiles).  Default 32.  Results do not depend on it. */
+int32_t vdb_hip_set_max_query_tile(uint32_t b);
 int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* idx, float* ms, uint32_t* launches);
 
 const char* vdb_hip_last_error(void); /* thread-local, never NULL */

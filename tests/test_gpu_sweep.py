@@ -96,7 +96,8 @@ def test_brute_force_ids_ranks_scores_exact(gpu_required, metric, n, dim):
     ids = (np.arange(n, dtype=np.uint64) * 3 + 11)
     ix = va.HnswIndex(dim, metric)
     assert ix.upload(ids, rows) == n
-    for nq, k in [(1, 10), (3, 1), (8, 10), (17, 5), (2, 64), (1, 100), (5, 200)]:
+    # nq >= 12 on dims that are multiples of 256 takes the LDS-resident query tiles (16 / 32 per pass)
+    for nq, k in [(1, 10), (3, 1), (8, 10), (17, 5), (2, 64), (1, 100), (5, 200), (45, 10), (33, 70), (13, 3)]:
         Q = rand_rows(rng, nq, dim, metric)
         gid, gsc, gcnt = ix.search_batch_brute_force(Q, k)
         exp = oracle_brute(metric, rows, ids, Q, k)
@@ -106,6 +107,27 @@ def test_brute_force_ids_ranks_scores_exact(gpu_required, metric, n, dim):
             assert np.array_equal(gid[qi, :gcnt[qi]], eid), (metric, nq, k, qi)
             assert np.array_equal(bits(gsc[qi, :gcnt[qi]]), bits(esc))
     ix.close()
+
+
+def test_query_tile_size_does_not_change_results(gpu_required):
+    rng = np.random.default_rng(99)
+    rows = rng.standard_normal((20000, 768)).astype(np.float32)
+    Q = rng.standard_normal((70, 768)).astype(np.float32)
+    ix = va.HnswIndex(768, DM.Cosine)
+    ix.upload(np.arange(20000), rows)
+    ref = None
+    try:
+        for tile in (1, 8, 16, 32):
+            va.set_max_query_tile(tile)
+            out = ix.search_batch_brute_force(Q, 10)
+            if ref is None:
+                ref = out
+            else:
+                assert np.array_equal(out[0], ref[0]) and np.array_equal(bits(out[1]), bits(ref[1]))
+    finally:
+        va.set_max_query_tile(32)
+    eid, esc = po.scan_topk(po.COSINE, rows, Q, 10, po.MODE_C, nthreads=4)
+    assert np.array_equal(ref[0], eid) and np.array_equal(bits(ref[1]), bits(esc))
 
 
 def test_brute_force_single_query_api_and_order(gpu_required):

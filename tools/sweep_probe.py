@@ -15,8 +15,10 @@ p.add_argument("--rows", type=int, default=1_000_000)
 p.add_argument("--dim", type=int, default=768)
 p.add_argument("--k", type=int, default=10)
 p.add_argument("--metric", default="cosine")
-p.add_argument("--nqs", default="1,2,4,8,16,64")
+p.add_argument("--nqs", default="1,8,16,32,64,256")
+p.add_argument("--tile", type=int, default=32)
 a = p.parse_args()
+va.set_max_query_tile(a.tile)
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(42)

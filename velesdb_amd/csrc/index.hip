@@ -14,6 +14,7 @@ namespace vdb {
 
 static thread_local std::string g_last_error;
 static int g_timing = 0;
+static uint32_t g_max_tile = 32;  // largest query tile of the exact sweep (tuning knob, vdb_hip_set_max_query_tile)
 
 void set_last_error(const std::string& s) { g_last_error = s; }
 int32_t fail(int32_t code, const std::string& msg) {
@@ -177,7 +178,10 @@ EventPair* next_events(vdb_hip_index* ix) {
   return &ix->ev_pool[ix->ev_used++];
 }
 
-static uint32_t pick_B(uint32_t nq) { return nq >= 8 ? 8 : (nq >= 4 ? 4 : (nq >= 2 ? 2 : 1)); }
+static uint32_t pick_B(uint32_t nq) {
+  uint32_t b = nq >= 8 ? 8 : (nq >= 4 ? 4 : (nq >= 2 ? 2 : 1));
+  return std::min(b, std::min<uint32_t>(g_max_tile, 8));
+}
 static int blocks_for(const vdb_hip_index* ix, int B, uint32_t ngroups) {
   const int occ = (B == 1) ? 4 : (B == 8 ? 2 : 3);  // resident 256-thread blocks per CU (VGPR-limited)
   int64_t want = ((int64_t)ngroups + 3) / 4;
@@ -243,14 +247,37 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     return VDB_OK;
   }
   for (uint32_t q0 = 0; q0 < nq;) {
-    const uint32_t B = pick_B(nq - q0);
-    const uint32_t tile = std::min<uint32_t>(B, nq - q0);
+    uint32_t B = pick_B(nq - q0);
     const int cpl = sweep_cpl_for_dim(ix->dim);
-    if (sweep_lds_bytes((int)B, k, ix->dim, cpl) > 60 * 1024)
+    // large tiles: queries in LDS, 16 or 32 per corpus pass (dims that are a multiple of 256, <= 1024)
+    bool qlds = false;
+    const uint32_t max_tile = g_max_tile;
+    if (cpl > 0 && nq - q0 >= 12 && max_tile >= 16) {
+      const uint32_t want = (nq - q0 >= 24 && max_tile >= 32) ? 32 : 16;
+      for (uint32_t b = want; b >= 16; b /= 2) {
+        const int waves = b == 32 ? kQldsWaves32 : kQldsWaves16;
+        if (sweep_qlds_lds_bytes((int)b, k, ix->dim, waves) <= 160 * 1024) {
+          B = b;
+          qlds = true;
+          break;
+        }
+      }
+    }
+    const uint32_t tile = std::min<uint32_t>(B, nq - q0);
+    if (!qlds && sweep_lds_bytes((int)B, k, ix->dim, cpl) > 60 * 1024)
       return fail(VDB_ERR_UNSUPPORTED, "k (x dim) too large for the fused top-k path");
     const uint32_t rpg = 64 / B;
     const uint32_t ngroups = (uint32_t)((ix->n_rows + rpg - 1) / rpg);
-    const int blocks = blocks_for(ix, (int)B, ngroups);
+    int blocks;
+    if (qlds) {
+      const int waves = B == 32 ? kQldsWaves32 : kQldsWaves16;
+      const size_t lds = sweep_qlds_lds_bytes((int)B, k, ix->dim, waves);
+      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, (size_t)(B == 32 ? 1 : 3)));
+      blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ngroups + waves - 1) / waves,
+                                                           (int64_t)ix->n_cus * per_cu));
+    } else {
+      blocks = blocks_for(ix, (int)B, ngroups);
+    }
     const uint32_t nw = (uint32_t)blocks;  // one list per block
     hipError_t e;
     if ((e = ix->s_part_keys.reserve((size_t)B * nw * k * 8, false, st)) != hipSuccess ||
@@ -271,7 +298,12 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     a.k = k;
     EventPair* ev = next_events(ix);
     if (ev) (void)hipEventRecord(ev->a, st);
-    launch_sweep_f32(ix->metric, (int)B, a, blocks, st);
+    if (qlds) {
+      hipError_t le = launch_sweep_f32_qlds(ix->metric, (int)B, a, blocks, st);
+      if (le != hipSuccess) return fail(VDB_ERR_HIP, std::string("sweep launch: ") + hipGetErrorString(le));
+    } else {
+      launch_sweep_f32(ix->metric, (int)B, a, blocks, st);
+    }
     if (ev) (void)hipEventRecord(ev->b, st);
     MergeArgs m{};
     m.part_keys = a.part_keys;
@@ -320,6 +352,12 @@ extern "C" {
 
 const char* vdb_hip_last_error(void) { return g_last_error.c_str(); }
 const char* vdb_hip_version(void) { return "velesdb-hip 0.1.0 (gfx950)"; }
+
+int32_t vdb_hip_set_max_query_tile(uint32_t b) {
+  if (b != 1 && b != 2 && b != 4 && b != 8 && b != 16 && b != 32) return fail(VDB_ERR_INVALID_ARG, "tile must be 1..32, power of 2");
+  g_max_tile = b;
+  return VDB_OK;
+}
 
 int32_t vdb_hip_set_kernel_timing(int32_t on) {
   g_timing = on ? 1 : 0;

@@ -23,7 +23,8 @@ namespace vdb {
 // ------------------------------------------------------------------------------------------
 // f32 sweep with fused top-k.  B = queries per pass (power of two <= 64), RPG = 64/B rows per
 // group, CPL = float4 chunks per lane (dim == CPL*256) or 0 for any dim (generic, slower).
-// grid.x * 4 waves; wave w owns row groups w, w+W, ...   LDS: lists[4][B][k] u64 + cnt[4][B].
+// grid.x * 4 waves; wave w owns row groups w, w+W, ...   LDS: lists[B][k] u64 | cnt[B] | lock[B] (block-shared
+// top-k lists, vdb_device.hpp shared_list_offer) | generic-dim query scratch.
 // ------------------------------------------------------------------------------------------
 template <int METRIC, int B, int CPL>
 __global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
@@ -36,12 +37,15 @@ __global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
   const uint32_t wave = blockIdx.x * 4 + wib;
   const uint32_t nwaves = gridDim.x * 4;
   const uint32_t k = a.k;
-  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * B * k;
-  // volatile: counts are written by lane 0 and read by every lane of the same wave; without it the
-  // compiler may keep a stale per-thread copy across the insert loop
-  volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(smem + (size_t)4 * B * k * 8) + wib * B;
-  float* qgen = reinterpret_cast<float*>(smem + (size_t)4 * B * k * 8 + 4 * B * 4);  // generic path only
-  if (lane < B) cnts[lane] = 0;
+  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(smem);
+  volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(smem + (size_t)B * k * 8);
+  uint32_t* locks = reinterpret_cast<uint32_t*>(smem + (size_t)B * k * 8 + (size_t)B * 4);
+  float* qgen = reinterpret_cast<float*>(smem + ((((size_t)B * k * 8 + (size_t)B * 8) + 15) & ~(size_t)15));  // generic path only
+  if (threadIdx.x < B) {
+    cnts[threadIdx.x] = 0;
+    locks[threadIdx.x] = 0;
+  }
+  __syncthreads();
 
   const int d4 = (int)((a.dim + 3) / 4);  // chunks per row
   // ---- queries into registers (CPL>0) or LDS (generic), plus their canonical norms ----
@@ -135,8 +139,7 @@ __global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
     // lane l now owns pair idx = l: row r = l / B, query b = l % B
     const int b = lane % B;
     const uint32_t row = row0 + lane / B;
-    bool valid = row < a.n_rows && b < (int)a.nq;
-    if (valid && a.alive) valid = a.alive[row] != 0;
+    const bool valid = row < a.n_rows && b < (int)a.nq;
     float vnorm = 1.0f;
     if (METRIC == kCosine && valid) vnorm = a.norms[row];
     const float score = finish_score<METRIC>(acc[0], qnorm_mine, vnorm);
@@ -148,33 +151,153 @@ __global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
       const int src = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
       const uint64_t kk = readlane64(key, src);
+      if (a.alive && a.alive[key_row(kk)] == 0) continue;  // soft-deleted rows are filtered where it is rare
       const int bb = src % B;
-      uint32_t c = cnts[bb];
-      wave_list_insert(lists + (size_t)bb * k, c, k, kk, lane);
-      if (lane == 0) cnts[bb] = c;
+      shared_list_offer(lists + (size_t)bb * k, cnts + bb, locks + bb, k, kk, lane);
     }
   }
-  // ---- block-level merge in LDS: query b is finished by wave (b % 4), which folds the other three
-  // waves' lists for b into wave 0's; then one list per block goes to HBM, padded with invalid keys
+  // ---- one list per query per block goes to HBM, padded with invalid keys ----
   __syncthreads();
-  {
-    volatile uint64_t* all_lists = reinterpret_cast<volatile uint64_t*>(smem);
-    volatile uint32_t* all_cnts = reinterpret_cast<volatile uint32_t*>(smem + (size_t)4 * B * k * 8);
-    for (int b = wib; b < (int)a.nq && b < B; b += 4) {
-      volatile uint64_t* dst = all_lists + (size_t)b * k;  // wave 0's list for query b
-      uint32_t c = all_cnts[b];
-      for (int w = 1; w < 4; w++) {
-        volatile uint64_t* src = all_lists + ((size_t)w * B + b) * k;
-        const uint32_t cs = all_cnts[w * B + b];
-        for (uint32_t e = 0; e < cs; e++) {
-          const uint64_t key = src[e];
-          if (c == k && key >= dst[k - 1]) break;  // sources are sorted: the rest cannot enter
-          wave_list_insert(dst, c, k, key, lane);
+  for (int b = wib; b < (int)a.nq && b < B; b += 4) {
+    const uint32_t c = cnts[b];
+    uint64_t* out = a.part_keys + ((size_t)b * gridDim.x + blockIdx.x) * k;
+    for (uint32_t e = lane; e < k; e += 64) out[e] = e < c ? lists[(size_t)b * k + e] : kKeyInvalid;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// f32 sweep for LARGE query tiles: B = 16 or 32 queries per corpus pass.  Same arithmetic, same
+// top-k scheme and the same output layout as sweep_topk_f32, but the queries live in LDS (B x dim
+// floats, read back as ds_read_b128: lane l reads its own chunk, conflict-free) instead of VGPRs,
+// so the per-lane state is only the 64 (row, query) partials + RPG = 64/B rows in flight.
+// WAVES waves per block share the query tile.  dim == CPL*256 only.
+// LDS: q[B][dim] f32 | lists[WAVES][B][k] u64 | cnt[WAVES][B] u32.
+// VALU work per row is B*dim FMAs: at B = 32 that is ~0.3 ms per 1M x 768 rows, still under the
+// ~0.5 ms the HBM stream needs, so the kernel stays bandwidth-bound while serving 4x the queries of
+// the register-resident B = 8 tile.
+// ------------------------------------------------------------------------------------------
+template <int METRIC, int B, int CPL, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, (B == 32 ? 4 : 3)) void sweep_topk_f32_qlds(SweepArgs a) {
+  constexpr int OP = (METRIC == kEuclidean) ? kOpL2 : kOpDot;
+  constexpr int RPG = 64 / B;
+  constexpr bool HIB = higher_is_better(METRIC);
+  constexpr int DIM = CPL * 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform => scalar row addressing
+  const uint32_t wave = blockIdx.x * WAVES + wib;
+  const uint32_t nwaves = gridDim.x * WAVES;
+  const uint32_t k = a.k;
+  float* qs = reinterpret_cast<float*>(smem);
+  unsigned char* lbase = smem + (size_t)B * DIM * 4;
+  // ONE sorted k-list per query per block, shared by the block's waves under a per-query LDS lock: a wave
+  // streams only n_rows / (#waves) rows, so per-wave lists would each need their own ~k*ln(rows/k) insertions
+  // (x B queries x thousands of waves); shared, the threshold tightens WAVES times faster.
+  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(lbase);
+  volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(lbase + (size_t)B * k * 8);
+  uint32_t* locks = reinterpret_cast<uint32_t*>(lbase + (size_t)B * k * 8 + (size_t)B * 4);
+  if (threadIdx.x < B) {
+    cnts[threadIdx.x] = 0;
+    locks[threadIdx.x] = 0;
+  }
+  for (int i = threadIdx.x; i < B * (DIM / 4); i += WAVES * 64) {
+    const int b = i / (DIM / 4), c = i % (DIM / 4);
+    const float4 v = (b < (int)a.nq) ? ld4(a.queries + (size_t)b * a.q_stride + (size_t)c * 4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(qs + (size_t)b * DIM + c * 4) = v;
+  }
+  __syncthreads();
+  float qnorm_mine = 0.0f;  // lane l keeps the norm of query (l % B)
+  if (METRIC == kCosine) {
+#pragma unroll 1
+    for (int b = 0; b < B; b++) {
+      float nacc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < CPL; j++) {
+        const float4 x = ld4(qs + (size_t)b * DIM + (j * 64 + lane) * 4);
+        nacc = chain4<kOpDot>(nacc, x, x);
+      }
+      const float n = sqrtf(butterfly_all(nacc));
+      if ((lane % B) == b) qnorm_mine = n;
+    }
+  }
+
+  const uint32_t ngroups = (a.n_rows + RPG - 1) / RPG;
+  // Software pipeline: the row chunks of step (g, j+1) are requested from HBM before the FMAs of step
+  // (g, j) start, and the query chunk of b+1 is requested from LDS before the FMAs of b; only
+  // 2*RPG float4 of row data and 2 float4 of query data are live next to the 64 partials.
+  auto row_ptr = [&](uint32_t g, int r) -> const float* {
+    uint32_t row = g * RPG + r;
+    row = row < a.n_rows ? row : a.n_rows - 1;  // tail rows: re-read the last row, masked later
+    return a.rows + (size_t)row * a.row_stride + (size_t)lane * 4;  // scalar base + lane offset
+  };
+  const int myb = lane % B;
+  float4 cur[RPG], nxt[RPG];
+  if (wave < ngroups) {
+#pragma unroll
+    for (int r = 0; r < RPG; r++) cur[r] = ld4(row_ptr(wave, r));
+  }
+  for (uint32_t g = wave; g < ngroups; g += nwaves) {
+    float acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) acc[i] = 0.0f;
+    const uint32_t row0 = g * RPG;
+    const uint32_t gn = g + nwaves < ngroups ? g + nwaves : g;  // last group: harmless re-read
+    const uint32_t row = row0 + lane / B;
+    const bool valid = row < a.n_rows && myb < (int)a.nq;
+    float vnorm = 1.0f;
+#pragma unroll
+    for (int j = 0; j < CPL; j++) {
+      const float* qj = qs + (size_t)(j * 64 + lane) * 4;
+      float4 q0 = ld4(qj);
+      // sched_barrier: keep the requests ahead of the FMAs that hide them (the scheduler otherwise sinks
+      // every load to its first use to save registers)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < B; b += 2) {
+        const float4 q1 = ld4(qj + (size_t)(b + 1) * DIM);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < RPG; r++) acc[r * B + b] = chain4<OP>(acc[r * B + b], q0, cur[r]);
+        if (b + 2 < B) q0 = ld4(qj + (size_t)(b + 2) * DIM);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < RPG; r++) acc[r * B + b + 1] = chain4<OP>(acc[r * B + b + 1], q1, cur[r]);
+        if (b == 0) {
+          // HBM requests of the NEXT step go out here, behind the first FMAs of this step: the wait in front
+          // of those FMAs (conservatively vmcnt(0) at the loop head) then only covers rows that are due anyway.
+          // The row norm is requested first so that waiting for it later does not wait for the prefetches.
+          if (j == 0 && METRIC == kCosine) vnorm = a.norms[row < a.n_rows ? row : a.n_rows - 1];
+#pragma unroll
+          for (int r = 0; r < RPG; r++)
+            nxt[r] = (j + 1 < CPL) ? ld4(row_ptr(g, r) + (j + 1) * 256) : ld4(row_ptr(gn, r));
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      uint64_t* out = a.part_keys + ((size_t)b * gridDim.x + blockIdx.x) * k;
-      for (uint32_t e = lane; e < k; e += 64) out[e] = e < c ? dst[e] : kKeyInvalid;
+#pragma unroll
+      for (int r = 0; r < RPG; r++) cur[r] = nxt[r];
     }
+    treduce64(acc, lane);
+    const int b = myb;
+    const float score = finish_score<METRIC>(acc[0], qnorm_mine, vnorm);
+    const uint64_t key = valid ? make_key<HIB>(score, row) : kKeyInvalid;
+    const uint32_t c_b = cnts[b];
+    const uint64_t tau = (c_b == k) ? lists[(size_t)b * k + (k - 1)] : kKeyInvalid;
+    uint64_t mask = __ballot(key < tau);
+    while (mask) {
+      const int src = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const uint64_t kk = readlane64(key, src);
+      if (a.alive && a.alive[key_row(kk)] == 0) continue;  // soft-deleted rows are filtered where it is rare
+      const int bb = src % B;
+      shared_list_offer(lists + (size_t)bb * k, cnts + bb, locks + bb, k, kk, lane);
+    }
+  }
+  __syncthreads();
+  for (int b = wib; b < (int)a.nq && b < B; b += WAVES) {
+    const uint32_t c = cnts[b];
+    uint64_t* out = a.part_keys + ((size_t)b * gridDim.x + blockIdx.x) * k;
+    for (uint32_t e = lane; e < k; e += 64) out[e] = e < c ? lists[(size_t)b * k + e] : kKeyInvalid;
   }
 }
 
@@ -258,15 +381,20 @@ __global__ __launch_bounds__(256) void sweep_topk_bits(BitsArgs a) {
   const uint32_t qi = blockIdx.y;
   const uint32_t k = a.k;
   const uint32_t W = a.words;  // multiple of 4
-  volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k;
-  uint32_t* qw = reinterpret_cast<uint32_t*>(smem + (size_t)4 * k * 8);
+  // LDS: list[k] u64 (block-shared, locked) | cnt, lock | query words
+  volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem);
+  volatile uint32_t* cnt = reinterpret_cast<volatile uint32_t*>(smem + (size_t)k * 8);
+  uint32_t* lock = reinterpret_cast<uint32_t*>(smem + (size_t)k * 8 + 4);
+  uint32_t* qw = reinterpret_cast<uint32_t*>(smem + (((size_t)k * 8 + 8 + 15) & ~(size_t)15));
+  if (threadIdx.x == 0) {
+    *cnt = 0;
+    *lock = 0;
+  }
   for (uint32_t i = threadIdx.x; i < W; i += 256) qw[i] = a.qbits[(size_t)qi * W + i];
   __syncthreads();
-  uint32_t cnt = 0;
   for (uint64_t base = (uint64_t)wave * 64; base < a.n_rows; base += (uint64_t)nwaves * 64) {
     const uint32_t row = (uint32_t)base + lane;
-    bool valid = row < a.n_rows;
-    if (valid && a.alive) valid = a.alive[row] != 0;
+    const bool valid = row < a.n_rows;
     uint32_t ham = 0, inter = 0, uni = 0;
     if (valid) {
       const uint4* p = reinterpret_cast<const uint4*>(a.bits + (size_t)row * W);
@@ -292,29 +420,21 @@ __global__ __launch_bounds__(256) void sweep_topk_bits(BitsArgs a) {
       score = (uni == 0) ? 1.0f : (float)inter / (float)uni;  // simd_explicit.rs:431-442
     }
     const uint64_t key = valid ? make_key<HIB>(score, row) : kKeyInvalid;
-    const uint64_t tau = (cnt == k) ? list[k - 1] : kKeyInvalid;
+    const uint64_t tau = (*cnt == k) ? list[k - 1] : kKeyInvalid;
     uint64_t mask = __ballot(key < tau);
     while (mask) {
       const int src = __ffsll((long long)mask) - 1;
       mask &= mask - 1;
-      wave_list_insert(list, cnt, k, readlane64(key, src), lane);
+      const uint64_t kk = readlane64(key, src);
+      if (a.alive && a.alive[key_row(kk)] == 0) continue;  // soft-deleted rows are filtered where it is rare
+      shared_list_offer(list, cnt, lock, k, kk, lane);
     }
   }
-  volatile uint32_t* wcnt = reinterpret_cast<volatile uint32_t*>(smem + (size_t)4 * k * 8 + (size_t)W * 4);
-  if (lane == 0) wcnt[wib] = cnt;
   __syncthreads();
   if (wib != 0) return;
-  for (int w = 1; w < 4; w++) {
-    volatile uint64_t* src = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)w * k;
-    const uint32_t cs = wcnt[w];
-    for (uint32_t e = 0; e < cs; e++) {
-      const uint64_t kk = src[e];
-      if (cnt == k && kk >= list[k - 1]) break;
-      wave_list_insert(list, cnt, k, kk, lane);
-    }
-  }
+  const uint32_t c = *cnt;
   uint64_t* dst = a.part_keys + ((size_t)qi * gridDim.x + blockIdx.x) * k;
-  for (uint32_t e = lane; e < k; e += 64) dst[e] = e < cnt ? list[e] : kKeyInvalid;
+  for (uint32_t e = lane; e < k; e += 64) dst[e] = e < c ? list[e] : kKeyInvalid;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -463,7 +583,7 @@ static void launch_sweep_b(const SweepArgs& a, int B, int cpl, int blocks, size_
 }
 
 size_t sweep_lds_bytes(int B, uint32_t k, uint32_t dim, int cpl) {
-  size_t s = (size_t)4 * B * k * 8 + (size_t)4 * B * 4;
+  size_t s = (((size_t)B * k * 8 + (size_t)B * 8) + 15) & ~(size_t)15;
   if (cpl == 0) s += (size_t)B * ((dim + 3) / 4) * 16;
   return (s + 15) & ~(size_t)15;
 }
@@ -484,6 +604,48 @@ void launch_sweep_f32(int metric, int B, const SweepArgs& a, int blocks, hipStre
   }
 }
 
+// ---- large-tile launcher -------------------------------------------------------------------
+size_t sweep_qlds_lds_bytes(int B, uint32_t k, uint32_t dim, int waves) {
+  (void)waves;
+  return (((size_t)B * dim * 4 + (size_t)B * k * 8 + (size_t)B * 8) + 15) & ~(size_t)15;
+}
+template <int METRIC, int B, int CPL, int WAVES>
+static hipError_t launch_qlds_t(const SweepArgs& a, int blocks, size_t lds, hipStream_t st) {
+  static bool attr_done = false;  // per instantiation
+  if (lds > 64 * 1024 && !attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_f32_qlds<METRIC, B, CPL, WAVES>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((sweep_topk_f32_qlds<METRIC, B, CPL, WAVES>), dim3(blocks), dim3(WAVES * 64), lds, st, a);
+  return hipGetLastError();
+}
+template <int METRIC, int B, int WAVES>
+static hipError_t launch_qlds_cpl(const SweepArgs& a, int blocks, size_t lds, hipStream_t st) {
+  switch (sweep_cpl_for_dim(a.dim)) {
+    case 1: return launch_qlds_t<METRIC, B, 1, WAVES>(a, blocks, lds, st);
+    case 2: return launch_qlds_t<METRIC, B, 2, WAVES>(a, blocks, lds, st);
+    case 3: return launch_qlds_t<METRIC, B, 3, WAVES>(a, blocks, lds, st);
+    case 4: return launch_qlds_t<METRIC, B, 4, WAVES>(a, blocks, lds, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+template <int METRIC>
+static hipError_t launch_qlds_m(int B, const SweepArgs& a, int blocks, size_t lds, hipStream_t st) {
+  if (B == 32) return launch_qlds_cpl<METRIC, 32, kQldsWaves32>(a, blocks, lds, st);
+  return launch_qlds_cpl<METRIC, 16, kQldsWaves16>(a, blocks, lds, st);
+}
+hipError_t launch_sweep_f32_qlds(int metric, int B, const SweepArgs& a, int blocks, hipStream_t st) {
+  const int waves = B == 32 ? kQldsWaves32 : kQldsWaves16;
+  const size_t lds = sweep_qlds_lds_bytes(B, a.k, a.dim, waves);
+  switch (metric) {
+    case kCosine: return launch_qlds_m<kCosine>(B, a, blocks, lds, st);
+    case kEuclidean: return launch_qlds_m<kEuclidean>(B, a, blocks, lds, st);
+    default: return launch_qlds_m<kDot>(B, a, blocks, lds, st);
+  }
+}
+
 void launch_merge(bool hib, const MergeArgs& m, uint32_t nq, hipStream_t st) {
   const size_t lds = ((size_t)4 * m.k * 8 + 16 + 15) & ~(size_t)15;
   if (hib)
@@ -493,7 +655,7 @@ void launch_merge(bool hib, const MergeArgs& m, uint32_t nq, hipStream_t st) {
 }
 
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st) {
-  const size_t lds = (((size_t)4 * a.k * 8 + (size_t)a.words * 4 + 16) + 15) & ~(size_t)15;
+  const size_t lds = ((((size_t)a.k * 8 + 8 + 15) & ~(size_t)15) + (size_t)a.words * 4 + 15) & ~(size_t)15;
   if (metric == kHamming)
     hipLaunchKernelGGL((sweep_topk_bits<kHamming>), dim3(blocks, nq), dim3(256), lds, st, a);
   else

@@ -113,6 +113,26 @@ __device__ __forceinline__ void wave_list_insert(volatile uint64_t* list, uint32
   cnt = newcnt;
 }
 
+// ---- block-shared sorted top-k list in LDS, one per query, guarded by a per-list lock ----------
+// A wave streams only n_rows / #waves rows, so a private list per wave costs ~k*ln(rows_per_wave/k)
+// insertions per wave and query; sharing the list between the waves of a block tightens the threshold
+// (#waves in the block) times faster.  The final content is the k smallest keys offered, whatever the
+// interleaving (keys are unique), so results stay deterministic.  Lane 0 spins; a wave never holds two
+// locks and never reaches a barrier while holding one.
+__device__ __forceinline__ void shared_list_offer(volatile uint64_t* list, volatile uint32_t* cnt, uint32_t* lock,
+                                                  uint32_t k, uint64_t key, int lane) {
+  if (*cnt == k && key >= list[k - 1]) return;  // unlocked pre-check: the k-th best only ever improves
+  if (lane == 0) {
+    while (atomicCAS(lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  uint32_t c = *cnt;
+  wave_list_insert(list, c, k, key, lane);  // re-checks against the current k-th under the lock
+  if (lane == 0) *cnt = c;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) atomicExch(lock, 0u);
+}
+
 // ---- canonical per-lane chains (shared by the sweep, traversal and construction kernels) ----
 enum Op : int { kOpDot = 0, kOpL2 = 1 };
 

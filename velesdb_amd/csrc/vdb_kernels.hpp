@@ -99,6 +99,11 @@ hipError_t launch_hnsw_search(const HnswSearchArgs& a, int slots, hipStream_t st
 size_t sweep_lds_bytes(int B, uint32_t k, uint32_t dim, int cpl);
 int sweep_cpl_for_dim(uint32_t dim);
 void launch_sweep_f32(int metric, int B, const SweepArgs& a, int blocks, hipStream_t st);
+// large query tiles (B = 16 / 32) with the queries in LDS; dim % 256 == 0 and dim <= 1024 only
+constexpr int kQldsWaves16 = 4;   // waves per block for B = 16 (3 blocks per CU)
+constexpr int kQldsWaves32 = 16;  // waves per block for B = 32
+size_t sweep_qlds_lds_bytes(int B, uint32_t k, uint32_t dim, int waves);
+hipError_t launch_sweep_f32_qlds(int metric, int B, const SweepArgs& a, int blocks, hipStream_t st);
 void launch_merge(bool higher_is_better, const MergeArgs& m, uint32_t nq, hipStream_t st);
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st);
 void launch_prep_rows(const PrepArgs& a, hipStream_t st);

@@ -47,6 +47,11 @@ def set_kernel_timing(on: bool) -> None:
     check(lib().vdb_hip_set_kernel_timing(1 if on else 0))
 
 
+def set_max_query_tile(b: int) -> None:
+    """Tuning knob of the exact sweep: queries served per corpus pass (1..32).  Results do not depend on it."""
+    check(lib().vdb_hip_set_max_query_tile(b))
+
+
 class HnswIndex:
     """HNSW index whose vectors, graph and search run on one MI355X."""
 
