@@ -45,6 +45,7 @@ def parse():
     p.add_argument("--k", type=int, default=10)
     p.add_argument("--batch", type=int, default=64, help="queries per step (exact sweep)")
     p.add_argument("--metric", default="cosine")
+    p.add_argument("--tile", type=int, default=32, help="largest query tile of the sweep (1,2,4,8,16,32)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=int, default=262_144)
     p.add_argument("--cpu-sample-queries", type=int, default=32)
@@ -94,6 +95,7 @@ def main():
     ix = va.HnswIndex(D, metric, va.HnswParams(a.M, a.efc, N), device=local)
     stream = torch.cuda.current_stream().cuda_stream
     torch.cuda.synchronize()
+    va.set_max_query_tile(a.tile)
     ix.upload_dev(0, corpus.data_ptr(), N, stream)
     sample_rows = min(a.cpu_sample_rows, N)
     host_sample = corpus[:sample_rows].cpu().numpy() if rank == 0 else None
@@ -140,14 +142,63 @@ def main():
     qps = world * Q * a.steps / dt
 
     # ---- roofline of the dominant kernel (the sweep): algorithmic bytes / measured duration ----
-    tile = 8 if Q >= 8 else (4 if Q >= 4 else (2 if Q >= 2 else 1))
-    alg_bytes = N * D * 4 + (N * 4 if a.metric == "cosine" else 0) + tile * D * 4
+    def tile_for(nq, max_tile):  # the library's tile choice (index.hip brute_dev)
+        lds_tiles = D % 256 == 0 and D <= 1024
+        if lds_tiles and nq >= 24 and max_tile >= 32:
+            return 32
+        if lds_tiles and nq >= 12 and max_tile >= 16:
+            return 16
+        return min(8 if nq >= 8 else (4 if nq >= 4 else (2 if nq >= 2 else 1)), max_tile, 8)
+
+    def kernel_name(t):
+        cpl = D // 256 if D % 256 == 0 and D <= 1024 else 0
+        return (f"sweep_topk_f32_qlds<{a.metric},B={t},CPL={cpl}>" if t >= 16
+                else f"sweep_topk_f32<{a.metric},B={t},CPL={cpl}>")
+
+    def alg_bytes_for(t):  # N*D*4 (+ N*4 precomputed norms) per corpus pass + the query tile
+        return N * D * 4 + (N * 4 if a.metric == "cosine" else 0) + t * D * 4
+
+    tile = tile_for(Q, a.tile)
+    alg_bytes = alg_bytes_for(tile)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    flops = 2.0 * N * D * tile
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": f"sweep_topk_f32<{a.metric},B={tile},CPL={D // 256 if D % 256 == 0 else 0}>",
+                "kernel": kernel_name(tile),
                 "kernel_ms": round(kernel_ms, 4), "launches_timed": kernel_launches,
-                "alg_bytes_per_launch": alg_bytes, "queries_per_launch": tile}
+                "alg_bytes_per_launch": alg_bytes, "queries_per_launch": tile,
+                "valu_tflops": round(flops / (kernel_ms * 1e-3) / 1e12, 1) if kernel_ms > 0 else 0.0,
+                "note": "one corpus pass serves `queries_per_launch` queries; at 32 per pass the f32 VALU FMA rate "
+                        "(peak 157 TFLOP/s) bounds the kernel before HBM does; see `tiles` for the per-tile figures"}
+
+    # ---- the same sweep at every tile size (queries per corpus pass): kernel time, HBM rate, throughput ----
+    tiles = []
+    if rank == 0:
+        for t in (1, 8, 16, 32):
+            if t > a.tile:
+                continue
+            va.set_max_query_tile(t)
+            nq_t = max(t, 8) if t > 1 else 1
+            eff = tile_for(nq_t, t)
+            for _ in range(2):
+                ix.search_batch_dev(queries.data_ptr(), nq_t, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
+                                    out_sc.data_ptr(), out_n.data_ptr(), stream)
+            torch.cuda.synchronize()
+            va.set_kernel_timing(True)
+            reps = 10
+            tt = time.perf_counter()
+            for _ in range(reps):
+                ix.search_batch_dev(queries.data_ptr(), nq_t, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
+                                    out_sc.data_ptr(), out_n.data_ptr(), stream)
+            torch.cuda.synchronize()
+            t_dt = (time.perf_counter() - tt) / reps
+            kms, nl = ix.last_kernel_ms()
+            va.set_kernel_timing(False)
+            gbs = alg_bytes_for(eff) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+            tiles.append({"queries_per_pass": eff, "kernel": kernel_name(eff), "kernel_ms": round(kms, 4),
+                          "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                          "qps": round(nq_t / t_dt, 1)})
+        va.set_max_query_tile(a.tile)
 
     # ---- single-query latency mode (one corpus pass per query) ----
     lat = {}
@@ -324,11 +375,12 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{N}x{D} f32 {a.metric}, k={K}, exact distance sweep + fused GPU top-k "
-                                   f"(BASELINE configs[1]); {Q} queries/step, 8 queries per corpus pass",
+                                   f"(BASELINE configs[1]); {Q} queries/step, {tile} queries per corpus pass",
                        "rows": N, "dim": D, "k": K, "queries_per_step": Q,
                        "parallelism": "replicas x%d (query stream split, no collective)" % world},
             "recall_at_10": recall, "parity_check": check,
-            "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "sharded": sharded, "hnsw": hnsw,
+            "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "tiles": tiles, "sharded": sharded,
+            "hnsw": hnsw,
             "device": va.device_name(local),
         }
         print(json.dumps(line))

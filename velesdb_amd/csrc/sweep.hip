@@ -200,21 +200,34 @@ __global__ __launch_bounds__(WAVES * 64, (B == 32 ? 4 : 3)) void sweep_topk_f32_
     cnts[threadIdx.x] = 0;
     locks[threadIdx.x] = 0;
   }
+  // query tile -> LDS, two queries interleaved element by element: slot ((p*CPL + j)*2 + h)*64 + lane holds
+  // {q[2p][e], q[2p+1][e], q[2p][e+1], q[2p+1][e+1]} for e = 4*(j*64+lane) + 2h, so ONE v_pk_fma_f32 advances the
+  // chains of two queries by one element (same fmaf chain per query as everywhere else) and every
+  // ds_read_b128 is contiguous across lanes
   for (int i = threadIdx.x; i < B * (DIM / 4); i += WAVES * 64) {
     const int b = i / (DIM / 4), c = i % (DIM / 4);
     const float4 v = (b < (int)a.nq) ? ld4(a.queries + (size_t)b * a.q_stride + (size_t)c * 4)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(qs + (size_t)b * DIM + c * 4) = v;
+    const int pr = b >> 1, sl = b & 1, j = c >> 6, l = c & 63;
+    float* d0 = qs + ((size_t)((pr * CPL + j) * 2 + 0) * 64 + l) * 4;
+    float* d1 = qs + ((size_t)((pr * CPL + j) * 2 + 1) * 64 + l) * 4;
+    d0[sl] = v.x;
+    d0[2 + sl] = v.y;
+    d1[sl] = v.z;
+    d1[2 + sl] = v.w;
   }
   __syncthreads();
   float qnorm_mine = 0.0f;  // lane l keeps the norm of query (l % B)
   if (METRIC == kCosine) {
 #pragma unroll 1
     for (int b = 0; b < B; b++) {
+      const int pr = b >> 1, sl = b & 1;
       float nacc = 0.0f;
 #pragma unroll
       for (int j = 0; j < CPL; j++) {
-        const float4 x = ld4(qs + (size_t)b * DIM + (j * 64 + lane) * 4);
+        const float* d0 = qs + ((size_t)((pr * CPL + j) * 2 + 0) * 64 + lane) * 4;
+        const float* d1 = qs + ((size_t)((pr * CPL + j) * 2 + 1) * 64 + lane) * 4;
+        const float4 x = make_float4(d0[sl], d0[2 + sl], d1[sl], d1[2 + sl]);
         nacc = chain4<kOpDot>(nacc, x, x);
       }
       const float n = sqrtf(butterfly_all(nacc));
@@ -232,15 +245,21 @@ __global__ __launch_bounds__(WAVES * 64, (B == 32 ? 4 : 3)) void sweep_topk_f32_
     return a.rows + (size_t)row * a.row_stride + (size_t)lane * 4;  // scalar base + lane offset
   };
   const int myb = lane % B;
-  float4 cur[RPG], nxt[RPG];
+  // row chunks are requested TWO steps ahead (cur = this step, n1 = next, n2 = the one after): with one step
+  // of lookahead a CU has only #waves x RPG KiB in flight, below the latency-bandwidth product of HBM
+  float4 cur[RPG], n1[RPG], n2[RPG];
   if (wave < ngroups) {
+    const uint32_t g1 = (CPL > 1) ? wave : (wave + nwaves < ngroups ? wave + nwaves : wave);
 #pragma unroll
-    for (int r = 0; r < RPG; r++) cur[r] = ld4(row_ptr(wave, r));
+    for (int r = 0; r < RPG; r++) {
+      cur[r] = ld4(row_ptr(wave, r));
+      n1[r] = ld4(row_ptr(g1, r) + (CPL > 1 ? 256 : 0));
+    }
   }
   for (uint32_t g = wave; g < ngroups; g += nwaves) {
-    float acc[64];
+    f32x2 acc2[32];
 #pragma unroll
-    for (int i = 0; i < 64; i++) acc[i] = 0.0f;
+    for (int i = 0; i < 32; i++) acc2[i] = f32x2{0.0f, 0.0f};
     const uint32_t row0 = g * RPG;
     const uint32_t gn = g + nwaves < ngroups ? g + nwaves : g;  // last group: harmless re-read
     const uint32_t row = row0 + lane / B;
@@ -248,34 +267,53 @@ __global__ __launch_bounds__(WAVES * 64, (B == 32 ? 4 : 3)) void sweep_topk_f32_
     float vnorm = 1.0f;
 #pragma unroll
     for (int j = 0; j < CPL; j++) {
-      const float* qj = qs + (size_t)(j * 64 + lane) * 4;
-      float4 q0 = ld4(qj);
+      const float* qj = qs + (size_t)(j * 2 * 64 + lane) * 4;  // pair 0, half 0 of chunk j
+      constexpr int PSTRIDE = CPL * 2 * 64 * 4;                 // floats between consecutive pairs
+      float4 h0 = ld4(qj), h1 = ld4(qj + 64 * 4);
       // sched_barrier: keep the requests ahead of the FMAs that hide them (the scheduler otherwise sinks
       // every load to its first use to save registers)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int b = 0; b < B; b += 2) {
-        const float4 q1 = ld4(qj + (size_t)(b + 1) * DIM);
+      for (int pr = 0; pr < B / 2; pr++) {
+        float4 n0 = h0, n1 = h1;
+        if (pr + 1 < B / 2) {
+          n0 = ld4(qj + (size_t)(pr + 1) * PSTRIDE);
+          n1 = ld4(qj + (size_t)(pr + 1) * PSTRIDE + 64 * 4);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < RPG; r++) acc[r * B + b] = chain4<OP>(acc[r * B + b], q0, cur[r]);
-        if (b + 2 < B) q0 = ld4(qj + (size_t)(b + 2) * DIM);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < RPG; r++) acc[r * B + b + 1] = chain4<OP>(acc[r * B + b + 1], q1, cur[r]);
-        if (b == 0) {
+        for (int r = 0; r < RPG; r++) {
+          f32x2 t = acc2[(r * B) / 2 + pr];
+          t = pk_step<OP>(t, f32x2{h0.x, h0.y}, cur[r].x);
+          t = pk_step<OP>(t, f32x2{h0.z, h0.w}, cur[r].y);
+          t = pk_step<OP>(t, f32x2{h1.x, h1.y}, cur[r].z);
+          t = pk_step<OP>(t, f32x2{h1.z, h1.w}, cur[r].w);
+          acc2[(r * B) / 2 + pr] = t;
+        }
+        h0 = n0;
+        h1 = n1;
+        if (pr == 0) {
           // HBM requests of the NEXT step go out here, behind the first FMAs of this step: the wait in front
           // of those FMAs (conservatively vmcnt(0) at the loop head) then only covers rows that are due anyway.
           // The row norm is requested first so that waiting for it later does not wait for the prefetches.
           if (j == 0 && METRIC == kCosine) vnorm = a.norms[row < a.n_rows ? row : a.n_rows - 1];
 #pragma unroll
           for (int r = 0; r < RPG; r++)
-            nxt[r] = (j + 1 < CPL) ? ld4(row_ptr(g, r) + (j + 1) * 256) : ld4(row_ptr(gn, r));
+            n2[r] = (j + 2 < CPL) ? ld4(row_ptr(g, r) + (j + 2) * 256) : ld4(row_ptr(gn, r) + (j + 2 - CPL) * 256);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
-      for (int r = 0; r < RPG; r++) cur[r] = nxt[r];
+      for (int r = 0; r < RPG; r++) {
+        cur[r] = n1[r];
+        n1[r] = n2[r];
+      }
+    }
+    float acc[64];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      acc[2 * i] = acc2[i].x;
+      acc[2 * i + 1] = acc2[i].y;
     }
     treduce64(acc, lane);
     const int b = myb;

@@ -25,25 +25,82 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 __device__ __forceinline__ float shx(float v, int s) { return __shfl_xor(v, s, 64); }
 
+// ---- cross-lane exchange without the LDS crossbar ------------------------------------------------
+// gfx950 has v_permlane32_swap / v_permlane16_swap (swap the odd 32/16-lane rows of one register with
+// the even rows of another) and DPP row rotations / quad permutes: every stage of the xor butterfly maps
+// onto one of them, so reductions cost no LDS cycles (ds_bpermute shares the LDS pipe with the query
+// reads of the sweep).  Lane mappings verified on hardware with tools/probes/xlane_check.hip.
+//   swap32(X,Y): X' = {X[0..31], Y[0..31]},  Y' = {X[32..63], Y[32..63]}
+//   swap16(X,Y): X' = {X[0..15], Y[0..15], X[32..47], Y[32..47]},  Y' = the other four 16-lane rows
+template <int S>
+__device__ __forceinline__ float lane_xor(float v) {  // value of lane (l ^ S), S in {8,4,2,1}
+  const uint32_t u = __float_as_uint(v);
+  uint32_t r;
+  if (S == 8) {
+    r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xf, 0xf, false);  // row_ror:8
+  } else if (S == 4) {
+    r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x104, 0xf, 0x5, false);       // row_shl:4 -> banks 0,2
+    r = (uint32_t)__builtin_amdgcn_update_dpp((int)r, (int)u, 0x114, 0xf, 0xa, false);  // row_shr:4 -> banks 1,3
+  } else if (S == 2) {
+    r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+  } else {
+    r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+  }
+  return __uint_as_float(r);
+}
+// t[l] + t[l ^ S] in every lane (one butterfly stage)
+template <int S>
+__device__ __forceinline__ float add_xor(float v) {
+  if (S == 32) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  } else if (S == 16) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  } else {
+    return v + lane_xor<S>(v);
+  }
+}
+
 // every lane ends with the canonical sum of the 64 per-lane partials
 __device__ __forceinline__ float butterfly_all(float t) {
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) t = t + shx(t, s);
+  t = add_xor<32>(t);
+  t = add_xor<16>(t);
+  t = add_xor<8>(t);
+  t = add_xor<4>(t);
+  t = add_xor<2>(t);
+  t = add_xor<1>(t);
   return t;
 }
 
-// Transposed butterfly: N = 64 partials per lane in a[0..N); lane l finishes with the canonical
-// 64-lane sum of partial index l in a[0].  Stage s pairs lane bit s with index bit s.
+// Transposed butterfly: N partials per lane in a[0..N); lane l finishes with the canonical 64-lane sum of
+// partial index (l mod N) in a[0] (N = 64: index l).  Stage S pairs lane bit S with index bit S: the lane
+// keeps one half of its values and receives the partner's copy of the same half.
 template <int N, int S>
 struct TReduce {
   static __device__ __forceinline__ void run(float* a, int lane) {
     constexpr int H = N / 2;
-    const bool up = (lane & S) != 0;
+    if (S == 32 || S == 16) {
 #pragma unroll
-    for (int i = 0; i < H; i++) {
-      const float keep = up ? a[i + H] : a[i];
-      const float send = up ? a[i] : a[i + H];
-      a[i] = keep + shx(send, S);
+      for (int i = 0; i < H; i++) {
+        // after the swap the first register holds, in every lane, the value the lane keeps and the second
+        // the partner's value of the same index (see the row maps above)
+        if (S == 32) {
+          auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[i]), __float_as_uint(a[i + H]), false, false);
+          a[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        } else {
+          auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(a[i + H]), false, false);
+          a[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+      }
+    } else {
+      const bool up = (lane & S) != 0;
+#pragma unroll
+      for (int i = 0; i < H; i++) {
+        const float keep = up ? a[i + H] : a[i];
+        const float send = up ? a[i] : a[i + H];
+        a[i] = keep + lane_xor<S>(send);
+      }
     }
     TReduce<H, S / 2>::run(a, lane);
   }
@@ -152,6 +209,19 @@ __device__ __forceinline__ float chain4(float acc, const float4& q, const float4
   }
   return acc;
 }
+// two chains (two queries) advanced by one element with ONE packed instruction (v_pk_fma_f32): each half is
+// the same IEEE fmaf as chain4's, so results are bit-identical to the unpacked form
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int OP>
+__device__ __forceinline__ f32x2 pk_step(f32x2 acc, f32x2 qpair, float v) {
+  const f32x2 vv = {v, v};
+  if (OP == kOpL2) {
+    const f32x2 d = qpair - vv;
+    return __builtin_elementwise_fma(d, d, acc);
+  }
+  return __builtin_elementwise_fma(qpair, vv, acc);
+}
+
 // tail chunk: only elements with index < dim exist
 template <int OP>
 __device__ __forceinline__ float chain4_tail(float acc, const float4& q, const float4& v, int nvalid) {

@@ -26,13 +26,17 @@ __device__ __forceinline__ float key_dist(uint64_t key) { return asc_key_inv((ui
 
 // R per-lane partials per lane in a[0..R); afterwards lane l holds in a[0] the canonical 64-lane sum
 // of partial index l % R (stages 32..R are plain butterflies, stages R/2..1 are transposed).
+template <int R, int S>
+struct PlainStages {  // butterfly stages S, S/2, ... R applied to all R values (every lane keeps every index)
+  static __device__ __forceinline__ void run(float* a) {
+#pragma unroll
+    for (int i = 0; i < R; i++) a[i] = add_xor<S>(a[i]);
+    if (S > R) PlainStages<R, (S > R ? S / 2 : S)>::run(a);
+  }
+};
 template <int R>
 __device__ __forceinline__ void reduce_rows(float* a, int lane) {
-#pragma unroll
-  for (int s = 32; s >= R; s >>= 1) {
-#pragma unroll
-    for (int i = 0; i < R; i++) a[i] = a[i] + shx(a[i], s);
-  }
+  PlainStages<R, 32>::run(a);
   TReduce<R, R / 2>::run(a, lane);
 }
 
