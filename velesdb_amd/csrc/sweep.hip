@@ -247,13 +247,17 @@ __global__ __launch_bounds__(WAVES * 64, (B == 32 ? 4 : 3)) void sweep_topk_f32_
   const int myb = lane % B;
   // row chunks are requested TWO steps ahead (cur = this step, n1 = next, n2 = the one after): with one step
   // of lookahead a CU has only #waves x RPG KiB in flight, below the latency-bandwidth product of HBM
-  float4 cur[RPG], n1[RPG], n2[RPG];
+  // Ring of three buffers: step s computes from ring[s % 3] and requests step s+2 into ring[(s+2) % 3].  With
+  // CPL a multiple of 3 the roles repeat every group and the ring index is a compile-time constant (no
+  // register moves); otherwise the buffers are rotated by moves.
+  constexpr bool STATIC_RING = (CPL % 3) == 0;
+  float4 ring[3][RPG];
   if (wave < ngroups) {
     const uint32_t g1 = (CPL > 1) ? wave : (wave + nwaves < ngroups ? wave + nwaves : wave);
 #pragma unroll
     for (int r = 0; r < RPG; r++) {
-      cur[r] = ld4(row_ptr(wave, r));
-      n1[r] = ld4(row_ptr(g1, r) + (CPL > 1 ? 256 : 0));
+      ring[0][r] = ld4(row_ptr(wave, r));
+      ring[1][r] = ld4(row_ptr(g1, r) + (CPL > 1 ? 256 : 0));
     }
   }
   for (uint32_t g = wave; g < ngroups; g += nwaves) {
@@ -267,6 +271,11 @@ __global__ __launch_bounds__(WAVES * 64, (B == 32 ? 4 : 3)) void sweep_topk_f32_
     float vnorm = 1.0f;
 #pragma unroll
     for (int j = 0; j < CPL; j++) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int ic = STATIC_RING ? (j % 3) : 0, in2 = STATIC_RING ? ((j + 2) % 3) : 2;
+      float4(&cur)[RPG] = ring[ic];
+      float4(&n2)[RPG] = ring[in2];
       const float* qj = qs + (size_t)(j * 2 * 64 + lane) * 4;  // pair 0, half 0 of chunk j
       constexpr int PSTRIDE = CPL * 2 * 64 * 4;                 // floats between consecutive pairs
       float4 h0 = ld4(qj), h1 = ld4(qj + 64 * 4);
@@ -281,15 +290,20 @@ __global__ __launch_bounds__(WAVES * 64, (B == 32 ? 4 : 3)) void sweep_topk_f32_
           n1 = ld4(qj + (size_t)(pr + 1) * PSTRIDE + 64 * 4);
         }
         __builtin_amdgcn_sched_barrier(0);
+        // element-major order: the RPG accumulators touched between two steps of the same chain are independent,
+        // so the packed FMAs issue back to back without dependency stalls
 #pragma unroll
-        for (int r = 0; r < RPG; r++) {
-          f32x2 t = acc2[(r * B) / 2 + pr];
-          t = pk_step<OP>(t, f32x2{h0.x, h0.y}, cur[r].x);
-          t = pk_step<OP>(t, f32x2{h0.z, h0.w}, cur[r].y);
-          t = pk_step<OP>(t, f32x2{h1.x, h1.y}, cur[r].z);
-          t = pk_step<OP>(t, f32x2{h1.z, h1.w}, cur[r].w);
-          acc2[(r * B) / 2 + pr] = t;
-        }
+        for (int r = 0; r < RPG; r++)
+          acc2[(r * B) / 2 + pr] = pk_step<OP>(acc2[(r * B) / 2 + pr], f32x2{h0.x, h0.y}, cur[r].x);
+#pragma unroll
+        for (int r = 0; r < RPG; r++)
+          acc2[(r * B) / 2 + pr] = pk_step<OP>(acc2[(r * B) / 2 + pr], f32x2{h0.z, h0.w}, cur[r].y);
+#pragma unroll
+        for (int r = 0; r < RPG; r++)
+          acc2[(r * B) / 2 + pr] = pk_step<OP>(acc2[(r * B) / 2 + pr], f32x2{h1.x, h1.y}, cur[r].z);
+#pragma unroll
+        for (int r = 0; r < RPG; r++)
+          acc2[(r * B) / 2 + pr] = pk_step<OP>(acc2[(r * B) / 2 + pr], f32x2{h1.z, h1.w}, cur[r].w);
         h0 = n0;
         h1 = n1;
         if (pr == 0) {
@@ -303,10 +317,12 @@ __global__ __launch_bounds__(WAVES * 64, (B == 32 ? 4 : 3)) void sweep_topk_f32_
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if (!STATIC_RING) {
 #pragma unroll
-      for (int r = 0; r < RPG; r++) {
-        cur[r] = n1[r];
-        n1[r] = n2[r];
+        for (int r = 0; r < RPG; r++) {
+          ring[0][r] = ring[1][r];
+          ring[1][r] = ring[2][r];
+        }
       }
     }
     float acc[64];
