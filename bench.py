@@ -222,20 +222,14 @@ def main():
     # ---- range-sharded mode: per-shard top-k + one RCCL all-gather + merge ----
     sharded = None
     if world > 1:
-        g_ids = torch.empty((world, Q, K), dtype=torch.int64, device=dev)
-        g_sc = torch.empty((world, Q, K), dtype=torch.float32, device=dev)
+        from velesdb_amd.sharded import merge_shard_topk
 
         def sharded_step(i):
-            off = (i * Q) % (n_query_pool - Q + 1)  # every rank searches the SAME queries
+            off = (i * Q) % (n_query_pool - Q + 1)  # every rank searches the SAME queries against ITS shard
             ix.search_batch_dev(queries[off:off + Q].data_ptr(), Q, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
                                 out_sc.data_ptr(), out_n.data_ptr(), stream)
-            shard_ids = out_ids + rank * N  # global row id = shard offset + local row
-            dist.all_gather_into_tensor(g_ids, shard_ids)
-            dist.all_gather_into_tensor(g_sc, out_sc)
-            cand_sc = g_sc.permute(1, 0, 2).reshape(Q, world * K)
-            cand_id = g_ids.permute(1, 0, 2).reshape(Q, world * K)
-            top = torch.topk(cand_sc, K, dim=1, largest=metric.higher_is_better(), sorted=True)
-            return torch.gather(cand_id, 1, top.indices), top.values
+            # global row id = shard offset + local row; one all-gather of k (id, score) pairs per query, merge
+            return merge_shard_topk(out_ids, out_sc, out_n, rank * N, K, metric.higher_is_better())
 
         for i in range(a.warmup):
             sharded_step(i)

@@ -1,0 +1,86 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU composition in velesdb_amd/sharded.py: range-sharded exact
+search = per-shard top-k + one all-gather + merge must equal the exact top-k over the whole corpus, ties
+included; replica mode must split a query batch without loss or overlap.  The per-shard top-k (the GPU sweep in
+production) is supplied here by the oracle, so the test exercises exactly the N>1 logic that has no GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import pyoracle as po
+from velesdb_amd.sharded import merge_shard_topk, query_slice
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, metric, hib, n, dim, nq, k, seed, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(seed)
+        if metric == po.HAMMING:
+            rows = (rng.random((n, dim)) > 0.6915).astype(np.float32)   # integer distances: many exact ties
+            qs = (rng.random((nq, dim)) > 0.6915).astype(np.float32)
+        else:
+            rows = rng.standard_normal((n, dim)).astype(np.float32)
+            qs = rng.standard_normal((nq, dim)).astype(np.float32)
+        # uneven shards: rank 0 gets 1/3, the last shard may hold fewer than k rows
+        cuts = [0, n // 3, n] if world == 2 else np.linspace(0, n, world + 1).astype(int).tolist()
+        lo, hi = cuts[rank], cuts[rank + 1]
+        kk = min(k, hi - lo)
+        lid, lsc = po.scan_topk(metric, rows[lo:hi], qs, kk, po.MODE_C)
+        ids = np.zeros((nq, k), dtype=np.int64)
+        sc = np.zeros((nq, k), dtype=np.float32)
+        ids[:, :kk] = lid
+        sc[:, :kk] = lsc
+        cnt = torch.full((nq,), kk, dtype=torch.int32)
+        gi, gs, gc = merge_shard_topk(torch.from_numpy(ids), torch.from_numpy(sc), cnt, lo, k, hib)
+        eid, esc = po.scan_topk(metric, rows, qs, min(k, n), po.MODE_C)
+        ok = bool(np.array_equal(gi.numpy()[:, :eid.shape[1]].astype(np.uint64), eid)
+                  and np.array_equal(gs.numpy()[:, :esc.shape[1]].view(np.uint32), esc.view(np.uint32))
+                  and int(gc.min()) == min(k, n))
+        # replica mode: the slices of all ranks tile [0, nq)
+        sl = torch.tensor(list(query_slice(nq, rank, world)), dtype=torch.int64)
+        allsl = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allsl, sl)
+        tiles = allsl[0][0].item() == 0 and allsl[-1][1].item() == nq and all(
+            allsl[i][1].item() == allsl[i + 1][0].item() for i in range(world - 1))
+        out[rank] = ok and tiles
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric,hib,n,dim,k", [
+    (po.COSINE, True, 3000, 64, 10),
+    (po.EUCLIDEAN, False, 2000, 48, 10),
+    (po.HAMMING, False, 4000, 64, 10),   # ties across shards must come out in global-id order
+    (po.DOT, True, 25, 16, 10),          # second shard smaller than... first shard has 8 rows < k
+])
+def test_range_sharded_topk_world2(metric, hib, n, dim, k):
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, metric, hib, n, dim, 17, k, 1234, out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def test_query_slice_properties():
+    for nq in (0, 1, 7, 64, 1000):
+        for world in (1, 2, 3, 8):
+            parts = [query_slice(nq, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == nq
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
