@@ -133,6 +133,13 @@ int32_t vdb_hip_index_search(vdb_hip_index* idx, const float* query, uint32_t qu
 int32_t vdb_hip_index_search_batch(vdb_hip_index* idx, const float* queries_rowmajor, uint32_t nq,
                                    uint32_t k, uint32_t ef, int32_t mode, uint64_t* out_ids,
                                    float* out_scores, uint32_t* out_n);
+/* HnswIndex::search_with_rerank (search.rs:118-160) / search_with_rerank_quality (search.rs:297-350) for nq
+ * queries: candidates = search_with_quality(query, rerank_k, quality) (ef = 0 => Accurate: max(512, 16*rerank_k);
+ * otherwise Custom(ef)), re-scored with the raw compute_distance, stable-sorted in the metric's order, cut to
+ * k.  Scores are RAW (similarity for Cosine/Dot/Jaccard, distance for Euclidean/Hamming), like search_brute_force. */
+int32_t vdb_hip_index_search_rerank(vdb_hip_index* idx, const float* queries_rowmajor, uint32_t nq, uint32_t k,
+                                    uint32_t rerank_k, uint32_t ef, uint64_t* out_ids, float* out_scores,
+                                    uint32_t* out_n);
 /* device-resident variant: d_queries nq*dim f32 (16-byte aligned), outputs device buffers of
  * nq*k / nq; enqueued on `stream`, no host synchronisation.  In HNSW mode d_out_n[i] ==
  * 0xFFFFFFFF marks a query whose LDS candidate list overflowed (needs very many exact distance

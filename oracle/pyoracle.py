@@ -119,6 +119,9 @@ def _declare(L):
     L.vo_index_search_brute_force.argtypes = [vp, _f32p, C.c_uint32, _u64p, _f32p]
     L.vo_index_search_with_rerank.restype = C.c_uint32
     L.vo_index_search_with_rerank.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, _u64p, _f32p]
+    L.vo_index_search_with_rerank_quality.restype = C.c_uint32
+    L.vo_index_search_with_rerank_quality.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int,
+                                                      _u64p, _f32p]
     L.vo_index_search_batch.restype = None
     L.vo_index_search_batch.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int,
                                         C.c_uint32, _u64p, _f32p, _u32p]
@@ -438,6 +441,13 @@ class HnswIndex:
         ids = np.empty(max(k, 1), dtype=np.uint64)
         sc = np.empty(max(k, 1), dtype=np.float32)
         n = lib().vo_index_search_with_rerank(self._h, q, k, rerank_k, ids, sc)
+        return ids[:n].copy(), sc[:n].copy()
+
+    def search_with_rerank_quality(self, q, k, rerank_k, quality=Q_ACCURATE, custom_ef=0, tie=TIE_REFERENCE):
+        q = _f(q)
+        ids = np.empty(max(k, 1), dtype=np.uint64)
+        sc = np.empty(max(k, 1), dtype=np.float32)
+        n = lib().vo_index_search_with_rerank_quality(self._h, q, k, rerank_k, quality, custom_ef, tie, ids, sc)
         return ids[:n].copy(), sc[:n].copy()
 
     def search_batch(self, queries, k, quality=Q_BALANCED, custom_ef=0, tie=TIE_REFERENCE, nthreads=1):

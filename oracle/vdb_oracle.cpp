@@ -1315,6 +1315,21 @@ uint32_t vo_index_search_brute_force(const vo_index* ix, const float* q, uint32_
   return emit(index_brute_force(*ix, q, k), out_ids, out_scores);
 }
 // hnsw/index/search.rs:118-160
+uint32_t vo_index_search_with_rerank_quality(const vo_index* ix, const float* q, uint32_t k, uint32_t rerank_k,
+                                             int quality, uint32_t custom_ef, int tie, uint64_t* out_ids,
+                                             float* out_scores) {  // hnsw/index/search.rs:297-350
+  if (quality == 3) quality = 2;  // Perfect -> Accurate (:305-310)
+  auto cand = index_search_with_quality(*ix, q, rerank_k, quality, custom_ef, tie);
+  std::vector<std::pair<uint64_t, float>> rr;
+  for (auto& c : cand) {
+    auto it = ix->id_to_idx.find(c.first);
+    if (it == ix->id_to_idx.end()) continue;
+    rr.emplace_back(c.first, index_compute_distance(ix->g.metric, ix->g.mode, q, ix->g.vec(it->second), ix->g.dim));
+  }
+  sort_results(ix->g.metric, rr);
+  if (rr.size() > k) rr.resize(k);
+  return emit(rr, out_ids, out_scores);
+}
 uint32_t vo_index_search_with_rerank(const vo_index* ix, const float* q, uint32_t k, uint32_t rerank_k,
                                      uint64_t* out_ids, float* out_scores) {
   auto cand = index_search_with_quality(*ix, q, rerank_k, 2, 0, VO_TIE_REFERENCE);

@@ -152,6 +152,10 @@ void vo_index_search_batch(const vo_index*, const float* queries, uint32_t nq, u
                            uint64_t* out_ids, float* out_scores, uint32_t* out_n);
 uint32_t vo_index_search_with_rerank(const vo_index*, const float* q, uint32_t k,
                                      uint32_t rerank_k, uint64_t* out_ids, float* out_scores);
+/* search_with_rerank_quality (search.rs:297-350) with a choice of tie order for the candidate search */
+uint32_t vo_index_search_with_rerank_quality(const vo_index*, const float* q, uint32_t k, uint32_t rerank_k,
+                                             int quality, uint32_t custom_ef, int tie, uint64_t* out_ids,
+                                             float* out_scores);
 
 /* ---- flat brute-force scan used by the CPU baseline (no index object) ---- */
 /* exact top-k of rows by compute_distance, canonical tie order (score, row asc); nthreads>=1 */

@@ -180,3 +180,31 @@ def test_empty_graph_and_unbuilt_rows(tmp_path):
     ix.upload(np.arange(200), np.random.default_rng(0).standard_normal((200, 16)).astype(np.float32))
     with pytest.raises(va.VelesHipError):  # rows uploaded without a graph: HNSW mode must fail loudly
         ix.search_batch_parallel(np.zeros((1, 16), np.float32), 5, SQ.Fast)
+
+
+@pytest.mark.parametrize("metric", [DM.Cosine, DM.Euclidean, DM.DotProduct, DM.Hamming, DM.Jaccard])
+def test_search_with_rerank(tmp_path, metric):
+    # search.rs:118-160 / 297-350: candidates from the graph (k = rerank_k), raw exact re-scoring, stable sort
+    n, dim = 1500, 96
+    rng = np.random.default_rng(31)
+    if metric in (DM.Hamming, DM.Jaccard):
+        rows = (rng.random((n, dim)) > 0.6915).astype(np.float32)
+        qs = (rng.random((6, dim)) > 0.6915).astype(np.float32)
+    else:
+        rows = rng.standard_normal((n, dim)).astype(np.float32)
+        qs = rng.standard_normal((6, dim)).astype(np.float32)
+    oix = po.HnswIndex(dim, PO_METRIC[metric], po.MODE_C, 8, 60)
+    for i, v in enumerate(rows):
+        oix.insert(i, v)
+    g = oix.graph
+    g.file_dump(str(tmp_path), "native_hnsw")
+    ix = va.HnswIndex(dim, metric, va.HnswParams(8, 60, n))
+    ix.load_reference_files(str(tmp_path), "native_hnsw")
+    for q in qs:
+        for k, rk, quality, oq, oef in [(10, 50, SQ.Accurate, po.Q_ACCURATE, 0), (5, 5, SQ.Fast, 0, 0),
+                                        (10, 100, SQ.Custom(300), 4, 300), (20, 7, SQ.Balanced, po.Q_BALANCED, 0)]:
+            r = ix.search_with_rerank_quality(q, k, rk, quality)
+            eid, esc = oix.search_with_rerank_quality(q, k, rk, oq, oef, po.TIE_CANONICAL)
+            assert [x[0] for x in r] == eid.tolist(), (metric, k, rk)
+            assert np.array_equal(bits([x[1] for x in r]), bits(esc))
+    assert ix.search_with_rerank(qs[0], 10, 50) == ix.search_with_rerank_quality(qs[0], 10, 50, SQ.Accurate)

@@ -41,7 +41,8 @@ enum Phase : int {
   P_Z_ENTRY,     // layer 0: push the entry point (graph.rs:464-469)
   P_Z_POP,       // pop nearest candidate, termination test, gather unvisited neighbours (:471-499)
   P_Z_ADMIT,     // admission of the evaluated neighbours in list order (:500-511)
-  P_FINISH
+  P_FINISH,
+  P_R_DONE       // rerank: raw scores of the candidates are in nb_d
 };
 
 }  // namespace
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
     __syncthreads();
 
     // ---- leader state (meaningful in wave 0 only; every value is wave-uniform) ----
-    uint32_t cnt = 0, n_dist = 0, n_expand = 0, logn = 0, overflow = 0, m_prev = 0;
+    uint32_t cnt = 0, n_dist = 0, n_expand = 0, logn = 0, overflow = 0, m_prev = 0, rr_m = 0;
     int phase = P_START;
     int layer = (int)a.max_layer;
     uint32_t cur = a.entry_point;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
     for (;;) {
       if (wib == 0) {
         bool ready = false;
-        uint32_t m = 0, done = 0;
+        uint32_t m = 0, done = 0, raw = 0;
         while (!ready) {
           if (phase == P_START) {
             if (lane == 0) nb_id[0] = cur;
@@ -265,7 +266,32 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
               }
             }
             phase = P_Z_POP;
-          } else {  // P_FINISH
+          } else if (phase == P_FINISH) {
+            if (a.rerank_k == 0) {
+              done = 1;
+              ready = true;
+            } else {
+              // search_with_rerank (search.rs:118-160): candidates = the search result for k = rerank_k (soft-deleted
+              // rows dropped, search.rs:86-91); their rows are re-scored with the raw compute_distance
+              const uint32_t size = cnt < ef ? cnt : ef;
+              const uint32_t kk = a.rerank_k < size ? a.rerank_k : size;
+              for (uint32_t base = 0; base < kk; base += 64) {
+                const uint32_t e = base + lane;
+                const bool v = e < kk;
+                const uint32_t node = v ? (uint32_t)keys[e] : 0;
+                bool al = v;
+                if (v && a.alive) al = a.alive[node] != 0;
+                const uint64_t mask = __ballot(al);
+                if (al) nb_id[m + (uint32_t)__popcll(mask & lt_mask(lane))] = node;
+                m += (uint32_t)__popcll(mask);
+              }
+              raw = 1;
+              rr_m = m;
+              phase = P_R_DONE;
+              if (m == 0) done = 1;
+              ready = true;
+            }
+          } else {  // P_R_DONE
             done = 1;
             ready = true;
           }
@@ -274,19 +300,52 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
           ctl[0] = m;
           ctl[1] = done;
           ctl[2] = logn;
+          ctl[3] = raw;
         }
         m_prev = m;
       }
       __syncthreads();
       const uint32_t m = ctl[0];
       if (ctl[1]) break;
+      const bool raw = ctl[3] != 0;
       if (BITS)
-        dist_phase_bits<METRIC>(dc, qbits, m, nb_id, nb_d);
+        dist_phase_bits<METRIC>(dc, qbits, m, nb_id, nb_d, raw);
       else
-        dist_phase_f32<METRIC, CPL>(dc, q, qnorm, qgen, m, nb_id, nb_d, lane, wib);
+        dist_phase_f32<METRIC, CPL>(dc, q, qnorm, qgen, m, nb_id, nb_d, lane, wib, raw);
       __syncthreads();
     }
 
+    // ---- rerank results: stable sort of the re-scored candidates in the metric's order (distance.rs:95-103),
+    // cut to k.  sort key = (order-key(score) << 32 | candidate position): unique, rank = #smaller keys ----
+    if (a.rerank_k != 0) {
+      if (wib == 0) {
+        const uint32_t m = rr_m;  // candidates re-scored in the last distance phase (0 if none)
+        constexpr bool HIB = higher_is_better(METRIC);
+        const uint32_t outn = m < a.k ? m : a.k;
+        for (uint32_t i = lane; i < m; i += 64) keys[i] = make_key<HIB>(nb_d[i], i);
+        for (uint32_t i = lane; i < m; i += 64) {
+          const uint64_t mine = keys[i];
+          uint32_t rank = 0;
+          for (uint32_t j = 0; j < m; j++) rank += keys[j] < mine ? 1u : 0u;
+          if (rank < a.k) {
+            const uint32_t node = nb_id[i];
+            a.out_ids[(size_t)qi * a.k + rank] = a.ext_ids ? a.ext_ids[node] : (uint64_t)node;
+            a.out_scores[(size_t)qi * a.k + rank] = nb_d[i];
+          }
+        }
+        for (uint32_t e = outn + lane; e < a.k; e += 64) {
+          a.out_ids[(size_t)qi * a.k + e] = ~0ull;
+          a.out_scores[(size_t)qi * a.k + e] = __uint_as_float(0x7FC00000u);
+        }
+        if (lane == 0) {
+          a.out_n[qi] = overflow ? 0xFFFFFFFFu : outn;
+          if (a.stats) {
+            atomicAdd(&a.stats[0], (unsigned long long)n_dist);
+            atomicAdd(&a.stats[1], (unsigned long long)n_expand);
+          }
+        }
+      }
+    } else
     // ---- results: first k of the sorted result set, soft-deleted rows dropped after the cut
     // (search.rs:86-91), scores through transform_score ----
     if (wib == 0) {
@@ -392,7 +451,8 @@ int32_t ensure_traversal_scratch(vdb_hip_index* ix, hipStream_t st) {
 // NativeHnsw::search for nq device-resident queries (graph.rs:251-270) + result mapping
 // (search.rs:79-93).  Enqueues on `st`; no host synchronisation.
 int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint32_t ef,
-                        uint32_t cap_mult, uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st) {
+                        uint32_t cap_mult, uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st,
+                        uint32_t rerank_k) {
   if (!ix->graph_valid) return fail(VDB_ERR_STATE, "HNSW graph not built for all rows (use mode BRUTE or build it)");
   if (nq == 0) return VDB_OK;
   if (ix->entry_point < 0 || ix->graph_nodes == 0 || k == 0) {  // graph.rs:252-255: no entry point => empty
@@ -408,7 +468,7 @@ int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     a.layers[l].stride = ix->layers[l].stride;
     nbmax = std::max(nbmax, ix->layers[l].stride);
   }
-  nbmax = (nbmax + 63) / 64 * 64;
+  nbmax = (std::max(nbmax, rerank_k) + 63) / 64 * 64;
   // list capacity: ef results + room for evicted candidates that tie with the furthest result
   uint64_t cap = (uint64_t)ef + std::max<uint64_t>(64, (uint64_t)ef * cap_mult / 2);
   cap = (cap + 63) / 64 * 64;
@@ -450,6 +510,7 @@ int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   a.max_layer = ix->max_layer;
   a.entry_point = (uint32_t)ix->entry_point;
   a.metric = ix->metric;
+  a.rerank_k = rerank_k;
   EventPair* ev = next_events(ix);
   if (ev) (void)hipEventRecord(ev->a, st);
   hipError_t e = launch_hnsw_search(a, slots, st);

@@ -326,7 +326,7 @@ static uint32_t balanced_ef(uint32_t k) { return std::max<uint32_t>(128, k * 4);
 // dispatch of search_with_quality (search.rs:59-94) for device-resident queries
 static int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k,
                           uint32_t ef, int32_t mode, uint64_t* d_ids, float* d_scores, uint32_t* d_n,
-                          hipStream_t st, uint32_t cap_mult = 1, bool* used_hnsw = nullptr) {
+                          hipStream_t st, uint32_t cap_mult = 1, bool* used_hnsw = nullptr, uint32_t rerank_k = 0) {
   if (used_hnsw) *used_hnsw = false;
   ix->ev_used = 0;
   if (ix->n_rows == 0) {  // empty index: no entry point => empty result (native/graph.rs:252-255)
@@ -337,10 +337,16 @@ static int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride
   if (mode == VDB_SEARCH_AUTO && ix->live <= 100 && ix->n_rows > 0)  // search.rs:75-77
     return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
   if (mode != VDB_SEARCH_AUTO && mode != VDB_SEARCH_HNSW) return fail(VDB_ERR_INVALID_ARG, "bad search mode");
-  if (ef == 0) ef = balanced_ef(k);
-  ef = std::max(ef, k);  // SearchQuality::Custom(ef) = max(ef, k), params.rs:317
+  if (rerank_k) {
+    // search_with_rerank(_quality): the candidate search runs with k = rerank_k (search.rs:124,310)
+    if (ef == 0) ef = std::max<uint32_t>(512, rerank_k * 16);  // SearchQuality::Accurate, params.rs:314
+    ef = std::max(ef, rerank_k);
+  } else {
+    if (ef == 0) ef = balanced_ef(k);
+    ef = std::max(ef, k);  // SearchQuality::Custom(ef) = max(ef, k), params.rs:317
+  }
   if (used_hnsw) *used_hnsw = true;
-  return hnsw_search_dev(ix, d_q, q_stride, nq, k, ef, cap_mult, d_ids, d_scores, d_n, st);
+  return hnsw_search_dev(ix, d_q, q_stride, nq, k, ef, cap_mult, d_ids, d_scores, d_n, st, rerank_k);
 }
 
 }  // namespace vdb
@@ -599,8 +605,9 @@ int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* ix, const float* d_queries
 }
 
 // HnswIndex::search_batch_parallel (batch.rs:159-197) / search_with_quality / search_brute_force
-int32_t vdb_hip_index_search_batch(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef,
-                                   int32_t mode, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
+static int32_t search_batch_host(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef,
+                                 int32_t mode, uint32_t rerank_k, uint64_t* out_ids, float* out_scores,
+                                 uint32_t* out_n) {
   if (!ix || (nq && (!queries || !out_n)) || (nq && k && (!out_ids || !out_scores)))
     return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (nq == 0) return VDB_OK;
@@ -623,7 +630,8 @@ int32_t vdb_hip_index_search_batch(vdb_hip_index* ix, const float* queries, uint
   for (uint32_t cap_mult = 1;; cap_mult *= 4) {
     bool used_hnsw = false;
     int32_t rc = search_dev(ix, dq, ix->row_stride, nq, k, ef, mode, ix->s_out_ids.as<uint64_t>(),
-                            ix->s_out_scores.as<float>(), ix->s_out_n.as<uint32_t>(), st, cap_mult, &used_hnsw);
+                            ix->s_out_scores.as<float>(), ix->s_out_n.as<uint32_t>(), st, cap_mult, &used_hnsw,
+                            rerank_k);
     if (rc != VDB_OK) {
       (void)hipStreamSynchronize(st);
       return rc;
@@ -633,7 +641,12 @@ int32_t vdb_hip_index_search_batch(vdb_hip_index* ix, const float* queries, uint
     bool overflow = false;
     if (used_hnsw)
       for (uint32_t i = 0; i < nq; i++) overflow |= out_n[i] == 0xFFFFFFFFu;
-    if (!overflow) break;
+    if (!overflow) {
+      // rerank over the <=100-vector exact shortcut: at most rerank_k candidates exist (search.rs:124)
+      if (rerank_k && !used_hnsw)
+        for (uint32_t i = 0; i < nq; i++) out_n[i] = std::min(out_n[i], rerank_k);
+      break;
+    }
   }
   if (k) {
     VDB_HIP(hipMemcpyAsync(out_ids, ix->s_out_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
@@ -641,6 +654,18 @@ int32_t vdb_hip_index_search_batch(vdb_hip_index* ix, const float* queries, uint
   }
   VDB_HIP(hipStreamSynchronize(st));
   return VDB_OK;
+}
+
+int32_t vdb_hip_index_search_batch(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef,
+                                   int32_t mode, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
+  return search_batch_host(ix, queries, nq, k, ef, mode, 0, out_ids, out_scores, out_n);
+}
+
+// HnswIndex::search_with_rerank / search_with_rerank_quality — search.rs:118-160,297-350
+int32_t vdb_hip_index_search_rerank(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t rerank_k,
+                                    uint32_t ef, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
+  if (rerank_k == 0) return fail(VDB_ERR_INVALID_ARG, "rerank_k must be > 0");
+  return search_batch_host(ix, queries, nq, k, ef, VDB_SEARCH_AUTO, rerank_k, out_ids, out_scores, out_n);
 }
 
 // VectorIndex::search — index/mod.rs:58; trait_impl.rs:38-42

@@ -112,7 +112,7 @@ __device__ __forceinline__ float transform_score_dev(int metric, float d) {  // 
 template <int METRIC, int CPL>
 __device__ __forceinline__ void dist_phase_f32(const DistCtx& a, const float4* q, float qnorm,
                                                const float* qgen, uint32_t m, volatile uint32_t* nb_id,
-                                               volatile float* nb_d, int lane, int wib) {
+                                               volatile float* nb_d, int lane, int wib, bool raw = false) {
   constexpr int OP = (METRIC == kEuclidean) ? kOpL2 : kOpDot;
   constexpr int R = 8;
   const int d4 = (int)((a.dim + 3) / 4);
@@ -158,14 +158,15 @@ __device__ __forceinline__ void dist_phase_f32(const DistCtx& a, const float4* q
       float vnorm = 1.0f;
       if (METRIC == kCosine) vnorm = a.norms[nb_id[j]];
       const float s = finish_score<METRIC>(acc[0], qnorm, vnorm);
-      nb_d[j] = (METRIC == kCosine) ? 1.0f - s : ((METRIC == kDot) ? -s : s);
+      // raw = HnswIndex::compute_distance (search.rs:30-38), otherwise DistanceEngine::distance
+      nb_d[j] = raw ? s : ((METRIC == kCosine) ? 1.0f - s : ((METRIC == kDot) ? -s : s));
     }
   }
 }
 
 template <int METRIC>
 __device__ __forceinline__ void dist_phase_bits(const DistCtx& a, const uint32_t* qbits, uint32_t m,
-                                                volatile uint32_t* nb_id, volatile float* nb_d) {
+                                                volatile uint32_t* nb_id, volatile float* nb_d, bool raw = false) {
   const uint32_t W = a.words;
   for (uint32_t t = threadIdx.x; t < m; t += 256) {
     const uint4* p = reinterpret_cast<const uint4*>(a.bits + (size_t)nb_id[t] * W);
@@ -188,7 +189,7 @@ __device__ __forceinline__ void dist_phase_bits(const DistCtx& a, const uint32_t
       nb_d[t] = (float)ham;  // simd_explicit.rs:234-287 on the exact re-encoding bit = (x > 0.5)
     } else {
       const float sim = (uni == 0) ? 1.0f : (float)inter / (float)uni;  // simd_explicit.rs:431-442
-      nb_d[t] = 1.0f - sim;                                              // native/distance.rs:83
+      nb_d[t] = raw ? sim : 1.0f - sim;                                  // native/distance.rs:83
     }
   }
 }

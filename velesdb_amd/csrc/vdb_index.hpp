@@ -105,7 +105,8 @@ int32_t ensure_layers(vdb_hip_index* ix, uint32_t num_layers);
 EventPair* next_events(vdb_hip_index* ix);  // nullptr when kernel timing is off
 // hnsw_kernels.hip; cap_mult scales the room for tie candidates beyond ef (1 = default)
 int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint32_t ef,
-                        uint32_t cap_mult, uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st);
+                        uint32_t cap_mult, uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st,
+                        uint32_t rerank_k = 0);
 // hnsw_build.hip; max_batch 1 = the reference's sequential insert, 0 = default batched schedule
 int32_t graph_insert_rows(vdb_hip_index* ix, uint64_t first, uint64_t n, uint32_t max_batch);
 int32_t ensure_traversal_scratch(vdb_hip_index* ix, hipStream_t st);  // visited bitmaps + logs + stats

@@ -91,6 +91,8 @@ struct HnswSearchArgs {
   unsigned long long* stats;  // [2] += distance evaluations, expansions
   uint32_t dim, words, n_rows, nq, k, ef, cap, nbmax, vlog_cap, max_layer, entry_point;
   int32_t metric;
+  uint32_t rerank_k;  // > 0: search_with_rerank (search.rs:118-160): the first rerank_k results are re-scored with the
+                      // raw compute_distance, stable-sorted in the metric's order and cut to k
 };
 size_t hnsw_lds_bytes(uint32_t cap, uint32_t nbmax, uint32_t dim, uint32_t words, int metric);
 // returns hipSuccess or the launch error; grid = slots blocks of 256 threads

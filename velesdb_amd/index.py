@@ -177,6 +177,24 @@ class HnswIndex:
         ids, sc, cnt = self._search_raw(qs, k, quality.ef_search(k), MODE_HNSW)
         return [self._tuples(ids[i], sc[i], cnt[i]) for i in range(qs.shape[0])]
 
+    def search_with_rerank(self, query, k: int, rerank_k: int) -> List[Tuple[int, float]]:
+        """search.rs:118-160: HNSW candidates (Accurate) re-scored exactly; raw scores, metric order."""
+        return self.search_with_rerank_quality(query, k, rerank_k, SearchQuality.Accurate)
+
+    def search_with_rerank_quality(self, query, k: int, rerank_k: int, initial_quality: SearchQuality):
+        """search.rs:297-350 (Perfect is replaced by Accurate to avoid recursion, :305-310)."""
+        q = _f32(query).reshape(1, -1)
+        self._validate(q)
+        if initial_quality.kind == "perfect":
+            initial_quality = SearchQuality.Accurate
+        ef = initial_quality.ef_search(rerank_k)
+        kk = max(k, 1)
+        ids = np.empty((1, kk), dtype=np.uint64)
+        sc = np.empty((1, kk), dtype=np.float32)
+        cnt = np.zeros(1, dtype=np.uint32)
+        check(lib().vdb_hip_index_search_rerank(self._h, _ptr(q), 1, k, rerank_k, ef, _ptr(ids), _ptr(sc), _ptr(cnt)))
+        return self._tuples(ids[0], sc[0], cnt[0])
+
     def search_batch_brute_force(self, queries, k: int):
         """Batched exact search (one corpus pass per tile of queries); numpy outputs."""
         qs = _f32(queries)
