@@ -209,17 +209,21 @@ __global__ __launch_bounds__(256) void hnsw_insert_kernel(HnswInsertArgs a) {
               if (lane == 0) flags[idx] = 1;
               const uint32_t cnode = (uint32_t)ckey;
               const HnswLayerMut L = a.layers[layer];
+              // the neighbour ids are requested together with the count (one memory round trip instead of two)
+              const uint32_t lim = min(L.stride, nbmax);
+              uint32_t nb0 = 0;
+              if ((uint32_t)lane < lim) nb0 = L.nbr[(size_t)cnode * L.stride + lane];
               uint32_t nc = rfl(L.cnt[cnode]);
-              nc = min(nc, min(L.stride, nbmax));
+              nc = min(nc, lim);
               for (uint32_t base = 0; base < nc; base += 64) {
                 const uint32_t t = base + lane;
                 const bool valid = t < nc;
-                uint32_t nb = 0;
+                uint32_t nb = nb0;
                 bool newly = false;
                 if (valid) {
-                  nb = L.nbr[(size_t)cnode * L.stride + t];
+                  if (base != 0) nb = L.nbr[(size_t)cnode * L.stride + t];
                   const uint32_t bit = 1u << (nb & 31);
-                  newly = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;
+                  newly = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;  // visited.insert (graph.rs:499)
                 }
                 const uint64_t mask = __ballot(newly);
                 const uint32_t before = (uint32_t)__popcll(mask & lt_mask(lane));

@@ -51,7 +51,7 @@ enum Phase : int {
 // LDS: keys[cap] u64 | nb_id[nbmax] u32 | nb_d[nbmax] f32 | ctl[4] u32 | flags[cap] u8 (padded to 16)
 //      | query scratch: generic f32 dims: d4*4 floats; bit metrics: `words` u32
 // ------------------------------------------------------------------------------------------
-template <int METRIC, int CPL>
+template <int METRIC, int CPL, int NS>
 __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
   constexpr bool BITS = (METRIC == kHamming || METRIC == kJaccard);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -110,7 +110,9 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
     __syncthreads();
 
     // ---- leader state (meaningful in wave 0 only; every value is wave-uniform) ----
-    uint32_t cnt = 0, n_dist = 0, n_expand = 0, logn = 0, overflow = 0, m_prev = 0, rr_m = 0;
+    CandList<NS> list;
+    list.init(keys, flags, cap);
+    uint32_t n_dist = 0, n_expand = 0, logn = 0, overflow = 0, m_prev = 0, rr_m = 0;
     int phase = P_START;
     int layer = (int)a.max_layer;
     uint32_t cur = a.entry_point;
@@ -180,9 +182,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
           } else if (phase == P_Z_ENTRY) {
             const float d = rflf(nb_d[0]);
             n_dist += 1;
-            uint64_t dr;
-            uint32_t df;
-            list_insert(keys, flags, cnt, cap, make_key<false>(d, cur), lane, dr, df);
+            list.insert(make_key<false>(d, cur), lane, overflow);
             if (lane == 0) {
               atomicOr(&vis[cur >> 5], 1u << (cur & 31));
               if (a.vlog_cap) vlog[0] = cur;
@@ -190,37 +190,33 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
             logn = 1;
             phase = P_Z_POP;
           } else if (phase == P_Z_POP) {
-            uint32_t idx = 0xFFFFFFFFu;
-            for (uint32_t c = 0; c < cnt; c += 64) {
-              const uint32_t e = c + lane;
-              const uint64_t un = __ballot(e < cnt && flags[e] == 0);
-              if (un) {
-                idx = c + (uint32_t)__ffsll((long long)un) - 1;
-                break;
-              }
-            }
-            if (idx == 0xFFFFFFFFu) {
+            const uint32_t idx = list.first_unexpanded(lane);
+            if (idx == kNoIndex) {
               phase = P_FINISH;  // candidates empty (graph.rs:471)
             } else {
-              const uint64_t ckey = keys[idx];
+              const uint64_t ckey = list.key_at(idx, lane);
               bool stop = false;
-              if (cnt >= ef) stop = key_dist(ckey) > key_dist(keys[ef - 1]);  // graph.rs:474
+              if (list.size() >= ef) stop = key_dist(ckey) > key_dist(list.key_at(ef - 1, lane));  // graph.rs:474
               if (stop) {
                 phase = P_FINISH;
               } else {
-                if (lane == 0) flags[idx] = 1;
+                list.mark_expanded(idx, lane);
                 n_expand += 1;
                 const uint32_t cnode = (uint32_t)ckey;
                 const HnswLayerRef L = a.layers[0];
+                // the neighbour ids are requested together with the count (one memory round trip instead of two)
+                const uint32_t lim = min(L.stride, nbmax);
+                uint32_t nb0 = 0;
+                if ((uint32_t)lane < lim) nb0 = L.nbr[(size_t)cnode * L.stride + lane];
                 uint32_t nc = rfl(L.cnt[cnode]);
-                nc = min(nc, min(L.stride, nbmax));
+                nc = min(nc, lim);
                 for (uint32_t base = 0; base < nc; base += 64) {
                   const uint32_t t = base + lane;
                   const bool valid = t < nc;
-                  uint32_t nb = 0;
+                  uint32_t nb = nb0;
                   bool newly = false;
                   if (valid) {
-                    nb = L.nbr[(size_t)cnode * L.stride + t];
+                    if (base != 0) nb = L.nbr[(size_t)cnode * L.stride + t];
                     const uint32_t bit = 1u << (nb & 31);
                     newly = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;  // visited.insert (graph.rs:499)
                   }
@@ -244,8 +240,8 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
             for (uint32_t base = 0; base < m_prev; base += 64) {
               const uint32_t t = base + lane;
               const float d = t < m_prev ? nb_d[t] : 0.0f;
-              uint32_t size = cnt < ef ? cnt : ef;
-              float far = key_dist(keys[size - 1]);
+              uint32_t size = list.size() < ef ? list.size() : ef;
+              float far = key_dist(list.key_at(size - 1, lane));
               // pre-filter against the furthest distance at chunk start: it only decreases while the
               // result set is full, so a neighbour rejected now would be rejected at its turn too
               uint64_t mask = __ballot(t < m_prev && (d < far || size < ef));
@@ -253,15 +249,12 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
                 const int src = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
                 const float dj = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d), src));
-                size = cnt < ef ? cnt : ef;
-                far = key_dist(keys[size - 1]);
+                size = list.size() < ef ? list.size() : ef;
+                far = key_dist(list.key_at(size - 1, lane));
                 if (dj < far || size < ef) {  // graph.rs:503
                   const uint32_t nbj = nb_id[base + src];
-                  uint64_t dr;
-                  uint32_t df;
-                  list_insert(keys, flags, cnt, cap, make_key<false>(dj, nbj), lane, dr, df);
-                  if (dr != kKeyInvalid && df == 0) overflow = 1;  // an unexpanded candidate fell off the list
-                  list_truncate(keys, cnt, ef, lane);
+                  list.insert(make_key<false>(dj, nbj), lane, overflow);
+                  list.truncate(ef, lane);
                 }
               }
             }
@@ -273,12 +266,12 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
             } else {
               // search_with_rerank (search.rs:118-160): candidates = the search result for k = rerank_k (soft-deleted
               // rows dropped, search.rs:86-91); their rows are re-scored with the raw compute_distance
-              const uint32_t size = cnt < ef ? cnt : ef;
+              const uint32_t size = list.size() < ef ? list.size() : ef;
               const uint32_t kk = a.rerank_k < size ? a.rerank_k : size;
               for (uint32_t base = 0; base < kk; base += 64) {
                 const uint32_t e = base + lane;
                 const bool v = e < kk;
-                const uint32_t node = v ? (uint32_t)keys[e] : 0;
+                const uint32_t node = v ? (uint32_t)list.chunk_key(base, lane) : 0;
                 bool al = v;
                 if (v && a.alive) al = a.alive[node] != 0;
                 const uint64_t mask = __ballot(al);
@@ -349,13 +342,13 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
     // ---- results: first k of the sorted result set, soft-deleted rows dropped after the cut
     // (search.rs:86-91), scores through transform_score ----
     if (wib == 0) {
-      const uint32_t size = cnt < ef ? cnt : ef;
+      const uint32_t size = list.size() < ef ? list.size() : ef;
       const uint32_t kk = a.k < size ? a.k : size;
       uint32_t outn = 0;
       for (uint32_t base = 0; base < kk; base += 64) {
         const uint32_t e = base + lane;
         const bool v = e < kk;
-        const uint64_t key = v ? keys[e] : 0;
+        const uint64_t key = v ? list.chunk_key(base, lane) : 0;
         const uint32_t node = (uint32_t)key;
         bool al = v;
         if (v && a.alive) al = a.alive[node] != 0;
@@ -400,15 +393,28 @@ size_t hnsw_lds_bytes(uint32_t cap, uint32_t nbmax, uint32_t dim, uint32_t words
   return (s + 15) & ~(size_t)15;
 }
 
-template <int METRIC, int CPL>
-static hipError_t launch_t(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
+template <int METRIC, int CPL, int NS>
+static hipError_t launch_ns(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_search_kernel<METRIC, CPL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_search_kernel<METRIC, CPL, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((hnsw_search_kernel<METRIC, CPL>), dim3(slots), dim3(256), lds, st, a);
+  // resident blocks per CU of THIS instantiation (registers / LDS): a grid larger than what is resident would
+  // queue whole blocks behind the persistent ones
+  int occ = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, hnsw_search_kernel<METRIC, CPL, NS>, 256, lds);
+  if (e != hipSuccess) return e;
+  occ = std::max(1, std::min(occ, 4));
+  const int grid = (int)std::min<int64_t>((int64_t)slots, (int64_t)a.n_cus * occ);
+  hipLaunchKernelGGL((hnsw_search_kernel<METRIC, CPL, NS>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
+}
+// list_slots: 0 = LDS list (any ef), kSearchRegSlots = register list (ef + 64 <= kSearchRegSlots * 64)
+template <int METRIC, int CPL>
+static hipError_t launch_t(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
+  if (a.list_slots == kSearchRegSlots) return launch_ns<METRIC, CPL, kSearchRegSlots>(a, slots, lds, st);
+  return launch_ns<METRIC, CPL, 0>(a, slots, lds, st);
 }
 template <int METRIC>
 static hipError_t launch_cpl(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
@@ -472,6 +478,10 @@ int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   // list capacity: ef results + room for evicted candidates that tie with the furthest result
   uint64_t cap = (uint64_t)ef + std::max<uint64_t>(64, (uint64_t)ef * cap_mult / 2);
   cap = (cap + 63) / 64 * 64;
+  // small ef: the list lives in registers (first attempt only; an overflow re-run uses the larger LDS list)
+  const bool reg_list = cap_mult == 1 && rerank_k == 0 && (uint64_t)ef + 64 <= (uint64_t)kSearchRegSlots * 64 &&
+                        ix->n_rows < (1ull << 31);
+  if (reg_list) cap = (uint64_t)kSearchRegSlots * 64;
   const size_t lds = hnsw_lds_bytes((uint32_t)cap, nbmax, ix->dim, ix->words, ix->metric);
   if (cap > 0xFFFFFFFFull || lds > 160 * 1024)
     return fail(VDB_ERR_UNSUPPORTED, "ef too large for the LDS-resident candidate list (" + std::to_string(lds) + " B)");
@@ -511,6 +521,8 @@ int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   a.entry_point = (uint32_t)ix->entry_point;
   a.metric = ix->metric;
   a.rerank_k = rerank_k;
+  a.list_slots = reg_list ? kSearchRegSlots : 0;
+  a.n_cus = (uint32_t)ix->n_cus;
   EventPair* ev = next_events(ix);
   if (ev) (void)hipEventRecord(ev->a, st);
   hipError_t e = launch_hnsw_search(a, slots, st);

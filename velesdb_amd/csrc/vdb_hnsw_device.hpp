@@ -97,6 +97,157 @@ __device__ __forceinline__ void list_truncate(volatile uint64_t* keys, uint32_t&
   cnt = last + 1;
 }
 
+// ---- the candidate/result list behind one interface ---------------------------------------------
+// Two implementations with identical semantics (the reference's two heaps, see hnsw_kernels.hip):
+//   CandList<0>   sorted keys + flags in LDS (any capacity that fits LDS)
+//   CandList<NS>  NS*64 entries held in REGISTERS of the leader wave: entry e lives in lane e%64, slot e/64,
+//                 sorted ascending, empty slots = ~0.  An insert is one DPP wave_shr:1 per slot (the lane
+//                 below hands its entry up; mapping verified with tools/probes/wave_shr_check.hip) + selects:
+//                 ~12 VALU instructions per slot, no LDS traffic and no loops — the LDS version spends
+//                 hundreds of cycles per admitted neighbour, and admission is the serial part of a step.
+// External key = (total-order(dist) << 32 | node).  The register form shifts the node up by one bit and keeps
+// the "expanded" flag in bit 0 (node ids < 2^31).
+constexpr uint32_t kNoIndex = 0xFFFFFFFFu;
+
+template <int NS>
+struct CandList {
+  uint64_t k[NS];
+  uint32_t cnt;
+  static constexpr uint32_t CAP = NS * 64;
+
+  static __device__ __forceinline__ uint64_t enc(uint64_t ext) {
+    return (ext & 0xFFFFFFFF00000000ull) | ((ext & 0xFFFFFFFFull) << 1);
+  }
+  static __device__ __forceinline__ uint64_t dec(uint64_t in) {
+    return (in & 0xFFFFFFFF00000000ull) | ((in & 0xFFFFFFFFull) >> 1);
+  }
+  // lane l receives v of lane l-1; lane 0 receives `carry` (wave-uniform)
+  static __device__ __forceinline__ uint64_t shr1(uint64_t v, uint64_t carry) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)carry, (int)(uint32_t)v, 0x138, 0xf, 0xf, false);
+    const uint32_t hi =
+        (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(carry >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+  }
+  __device__ __forceinline__ void init(volatile uint64_t*, volatile uint8_t*, uint32_t) { reset(); }
+  __device__ __forceinline__ void reset() {
+#pragma unroll
+    for (int s = 0; s < NS; s++) k[s] = ~0ull;
+    cnt = 0;
+  }
+  __device__ __forceinline__ uint32_t size() const { return cnt; }
+  __device__ __forceinline__ void insert(uint64_t ext, int lane, uint32_t& overflow) {
+    const uint64_t key = enc(ext);
+    const uint64_t last = readlane64(k[NS - 1], 63);
+    uint64_t nk[NS];
+#pragma unroll
+    for (int s = NS - 1; s >= 0; s--) {
+      const uint64_t carry = s > 0 ? readlane64(k[s > 0 ? s - 1 : 0], 63) : 0ull;
+      const uint64_t prev = shr1(k[s], carry);
+      const bool ge = !(k[s] < key);
+      const bool pl = (s == 0 && lane == 0) ? true : (prev < key);
+      nk[s] = ge ? (pl ? key : prev) : k[s];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; s++) k[s] = nk[s];
+    if (last != ~0ull) {  // the list was full: its last entry (or the key itself, if it is the largest) fell off
+      const uint64_t dropped = (last < key) ? key : last;
+      if ((dropped & 1ull) == 0) overflow = 1;
+    } else {
+      cnt += 1;
+    }
+  }
+  __device__ __forceinline__ uint32_t first_unexpanded(int) const {
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const uint64_t un = __ballot((k[s] & 1ull) == 0);  // empty slots are ~0: bit 0 set
+      if (un) return (uint32_t)s * 64 + (uint32_t)__ffsll((long long)un) - 1;
+    }
+    return kNoIndex;
+  }
+  __device__ __forceinline__ uint64_t key_at(uint32_t idx, int) const {  // idx wave-uniform
+    // (mask-and-or instead of a select chain: the compiler turns the chain into a dynamically indexed load,
+    // which forces the whole list into scratch memory)
+    const uint32_t slot = idx >> 6;
+    uint64_t v = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) v |= k[s] & ((slot == (uint32_t)s) ? ~0ull : 0ull);
+    return dec(readlane64(v, (int)(idx & 63)));
+  }
+  __device__ __forceinline__ void mark_expanded(uint32_t idx, int lane) {
+    const uint32_t slot = idx >> 6, l = idx & 63;
+#pragma unroll
+    for (int s = 0; s < NS; s++) k[s] |= (slot == (uint32_t)s && (uint32_t)lane == l) ? 1ull : 0ull;
+  }
+  __device__ __forceinline__ void truncate(uint32_t ef, int lane) {
+    if (cnt <= ef) return;
+    const float wd = key_dist(key_at(ef - 1, lane));
+    uint32_t last = ef - 1;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const uint32_t e = (uint32_t)s * 64 + lane;
+      const bool alive = e >= ef && e < cnt && !(key_dist(k[s]) > wd);  // negation of graph.rs:474's raw compare
+      const uint64_t mask = __ballot(alive);
+      if (mask) last = (uint32_t)s * 64 + 63u - (uint32_t)__clzll((long long)mask);
+    }
+    cnt = last + 1;
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+      if ((uint32_t)s * 64 + lane >= cnt) k[s] = ~0ull;
+  }
+  // external key of entry base + lane (base a multiple of 64, wave-uniform); meaningless beyond size()
+  __device__ __forceinline__ uint64_t chunk_key(uint32_t base, int) const {
+    const uint32_t slot = base >> 6;
+    uint64_t v = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) v |= k[s] & ((slot == (uint32_t)s) ? ~0ull : 0ull);
+    return dec(v);
+  }
+  // copy the first n entries to LDS as external keys (construction: select_neighbors works on LDS arrays)
+  __device__ __forceinline__ void dump(volatile uint64_t* keys, uint32_t n, int lane) const {
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const uint32_t e = (uint32_t)s * 64 + lane;
+      if (e < n) keys[e] = dec(k[s]);
+    }
+  }
+};
+
+template <>
+struct CandList<0> {
+  volatile uint64_t* keys;
+  volatile uint8_t* flags;
+  uint32_t cnt, cap;
+  __device__ __forceinline__ void init(volatile uint64_t* k_, volatile uint8_t* f_, uint32_t cap_) {
+    keys = k_;
+    flags = f_;
+    cap = cap_;
+    cnt = 0;
+  }
+  __device__ __forceinline__ void reset() { cnt = 0; }
+  __device__ __forceinline__ uint32_t size() const { return cnt; }
+  __device__ __forceinline__ void insert(uint64_t ext, int lane, uint32_t& overflow) {
+    uint64_t dr;
+    uint32_t df;
+    list_insert(keys, flags, cnt, cap, ext, lane, dr, df);
+    if (dr != kKeyInvalid && df == 0) overflow = 1;  // an unexpanded candidate fell off the list
+  }
+  __device__ __forceinline__ uint32_t first_unexpanded(int lane) const {
+    for (uint32_t c = 0; c < cnt; c += 64) {
+      const uint32_t e = c + lane;
+      const uint64_t un = __ballot(e < cnt && flags[e] == 0);
+      if (un) return c + (uint32_t)__ffsll((long long)un) - 1;
+    }
+    return kNoIndex;
+  }
+  __device__ __forceinline__ uint64_t key_at(uint32_t idx, int) const { return keys[idx]; }
+  __device__ __forceinline__ void mark_expanded(uint32_t idx, int lane) {
+    if (lane == 0) flags[idx] = 1;
+  }
+  __device__ __forceinline__ void truncate(uint32_t ef, int lane) { list_truncate(keys, cnt, ef, lane); }
+  __device__ __forceinline__ uint64_t chunk_key(uint32_t base, int lane) const { return keys[base + lane]; }
+  __device__ __forceinline__ void dump(volatile uint64_t*, uint32_t, int) const {}
+};
+
 __device__ __forceinline__ float transform_score_dev(int metric, float d) {  // backend_adapter.rs:160-168
   if (metric == kCosine) {
     float s = 1.0f - d;

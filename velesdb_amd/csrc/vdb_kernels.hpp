@@ -66,6 +66,8 @@ struct ScoreArgs {
 };
 
 // ---- HNSW traversal (hnsw_kernels.hip) ----------------------------------------------------
+constexpr int kSearchRegSlots = 4;  // register-resident candidate list of the traversal kernel: 256 entries
+constexpr int kBuildRegSlots = 8;   // ... of the construction kernel: 512 entries (ef_construction <= 448)
 constexpr int kMaxLayers = 16;  // random_layer caps levels at 15 (native/graph.rs:401)
 struct HnswLayerRef {
   const uint32_t* nbr;  // [capacity][stride] neighbour ids
@@ -91,6 +93,8 @@ struct HnswSearchArgs {
   unsigned long long* stats;  // [2] += distance evaluations, expansions
   uint32_t dim, words, n_rows, nq, k, ef, cap, nbmax, vlog_cap, max_layer, entry_point;
   int32_t metric;
+  uint32_t n_cus;       // launch sizing only
+  uint32_t list_slots;  // 0: candidate list in LDS; kSearchRegSlots: in registers (ef + 64 <= slots * 64)
   uint32_t rerank_k;  // > 0: search_with_rerank (search.rs:118-160): the first rerank_k results are re-scored with the
                       // raw compute_distance, stable-sorted in the metric's order and cut to k
 };
