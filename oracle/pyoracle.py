@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "libvdb_oracle.so")
 
 COSINE, EUCLIDEAN, DOT, HAMMING, JACCARD = 0, 1, 2, 3, 4
 METRICS = {"cosine": COSINE, "euclidean": EUCLIDEAN, "dot": DOT, "hamming": HAMMING, "jaccard": JACCARD}
-MODE_R, MODE_C, MODE_SCALAR, MODE_NATIVE, MODE_R_NOFMA = 0, 1, 2, 3, 4
+MODE_R, MODE_C, MODE_SCALAR, MODE_NATIVE, MODE_R_NOFMA, MODE_M = 0, 1, 2, 3, 4, 5
 TIE_REFERENCE, TIE_CANONICAL = 0, 1
 Q_FAST, Q_BALANCED, Q_ACCURATE, Q_PERFECT, Q_CUSTOM = 0, 1, 2, 3, 4
 

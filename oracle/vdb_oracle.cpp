@@ -344,6 +344,21 @@ float reduceC(const float* a, const float* b, size_t n) {
   return butterfly64(t);
 }
 inline float dotC(const float* a, const float* b, size_t n) { return reduceC<OP_DOT>(a, b, n); }
+// matrix-core order (v_mfma_f32_16x16x4_f32 in velesdb_amd/csrc/sweep.hip sweep_topk_mfma_f32): the instruction
+// adds its four k-slots as a k-ordered fmaf chain, one rounding per product; the kernel feeds slot kk of step
+// (T, e) with element 32T + 8kk + e and pads the vectors with zeros to a multiple of 32
+inline float dotM(const float* a, const float* b, size_t n) {
+  float acc = 0.0f;
+  const size_t KT = (n + 31) / 32;
+  for (size_t T = 0; T < KT; T++)
+    for (size_t e = 0; e < 8; e++)
+      for (size_t kk = 0; kk < 4; kk++) {
+        const size_t k = 32 * T + 8 * kk + e;
+        const float x = k < n ? a[k] : 0.0f, y = k < n ? b[k] : 0.0f;
+        acc = std::fmaf(x, y, acc);
+      }
+  return acc;
+}
 inline float sql2C(const float* a, const float* b, size_t n) { return reduceC<OP_SQL2>(a, b, n); }
 inline float normsqC(const float* a, size_t n) { return reduceC<OP_DOT>(a, a, n); }
 inline float cosineC(const float* a, const float* b, size_t n) {
@@ -495,6 +510,7 @@ inline float scalar_engine_distance(int metric, const float* a, const float* b, 
 inline float k_dot(int mode, const float* a, const float* b, size_t n) {
   switch (mode) {
     case VO_MODE_C: return dotC(a, b, n);
+    case VO_MODE_M: return dotM(a, b, n);
     case VO_MODE_NATIVE: return native16<OP_DOT>(a, b, n);
     case VO_MODE_R_NOFMA: return dot_auto<false>(a, b, n);
     case VO_MODE_SCALAR: {
@@ -508,6 +524,7 @@ inline float k_dot(int mode, const float* a, const float* b, size_t n) {
 inline float k_sql2(int mode, const float* a, const float* b, size_t n) {
   switch (mode) {
     case VO_MODE_C: return sql2C(a, b, n);
+    case VO_MODE_M: return sql2C(a, b, n);
     case VO_MODE_NATIVE: return native16<OP_SQL2>(a, b, n);
     case VO_MODE_R_NOFMA: return sql2_auto<false>(a, b, n);
     case VO_MODE_SCALAR: {
@@ -524,6 +541,12 @@ inline float k_sql2(int mode, const float* a, const float* b, size_t n) {
 inline float k_cosine(int mode, const float* a, const float* b, size_t n) {
   switch (mode) {
     case VO_MODE_C: return cosineC(a, b, n);
+    case VO_MODE_M: {
+      float dot = dotM(a, b, n);
+      float norm_a = std::sqrt(normsqC(a, n)), norm_b = std::sqrt(normsqC(b, n));
+      if (norm_a == 0.0f || norm_b == 0.0f) return 0.0f;
+      return dot / (norm_a * norm_b);
+    }
     case VO_MODE_NATIVE: return cosine_native(a, b, n);
     case VO_MODE_R_NOFMA: return cosine_auto<false>(a, b, n);
     case VO_MODE_SCALAR: return 1.0f - scalar_engine_distance(VO_COSINE, a, b, n);

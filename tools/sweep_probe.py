@@ -17,8 +17,10 @@ p.add_argument("--k", type=int, default=10)
 p.add_argument("--metric", default="cosine")
 p.add_argument("--nqs", default="1,8,16,32,64,256")
 p.add_argument("--tile", type=int, default=32)
+p.add_argument("--engine", type=int, default=0)
 a = p.parse_args()
 va.set_max_query_tile(a.tile)
+va.set_sweep_engine(a.engine)
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(42)

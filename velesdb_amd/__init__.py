@@ -6,8 +6,8 @@ VectorIndex / HnswIndex / DistanceEngine / GpuAccelerator interfaces over that A
 """
 from ._ffi import LIB_PATH, VelesHipError, lib  # noqa: F401
 from .index import (GpuAccelerator, HipDistance, HnswIndex, MODE_AUTO, MODE_BRUTE, MODE_HNSW,  # noqa: F401
-                    device_count, device_name, set_kernel_timing, set_max_query_tile)
+                    device_count, device_name, set_kernel_timing, set_max_query_tile, set_sweep_engine)
 from .params import DistanceMetric, HnswParams, SearchQuality  # noqa: F401
 
 __all__ = ["HnswIndex", "HipDistance", "GpuAccelerator", "DistanceMetric", "HnswParams", "SearchQuality",
-           "device_count", "device_name", "set_kernel_timing", "set_max_query_tile", "lib", "VelesHipError"]
+           "device_count", "device_name", "set_kernel_timing", "set_max_query_tile", "set_sweep_engine", "lib", "VelesHipError"]

@@ -14,6 +14,7 @@ namespace vdb {
 
 static thread_local std::string g_last_error;
 static int g_timing = 0;
+static int g_sweep_engine = 0;  // 0: VALU kernels (mode C); 1: MFMA for cosine / dot (mode M)
 static uint32_t g_max_tile = 32;  // largest query tile of the exact sweep (tuning knob, vdb_hip_set_max_query_tile)
 
 void set_last_error(const std::string& s) { g_last_error = s; }
@@ -249,6 +250,55 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
   for (uint32_t q0 = 0; q0 < nq;) {
     uint32_t B = pick_B(nq - q0);
     const int cpl = sweep_cpl_for_dim(ix->dim);
+    // matrix-core engine (cosine / dot): one or two 16-query tiles per corpus pass
+    int mfma_nqt = 0;
+    if (g_sweep_engine == 1 && (ix->metric == VDB_COSINE || ix->metric == VDB_DOT)) {
+      int want = (nq - q0 > 16 && g_max_tile >= 32) ? 2 : 1;
+      for (; want >= 1; want--)
+        if (sweep_mfma_lds_bytes(want, k, ix->dim) <= 160 * 1024) break;
+      mfma_nqt = want;  // 0: does not fit the LDS (very large dim or k): VALU kernels
+    }
+    if (mfma_nqt) {
+      const uint32_t Bm = (uint32_t)mfma_nqt * 16;
+      const uint32_t tile_m = std::min<uint32_t>(Bm, nq - q0);
+      const int waves = mfma_nqt == 2 ? kMfmaWaves2 : kMfmaWaves1;
+      const size_t lds = sweep_mfma_lds_bytes(mfma_nqt, k, ix->dim);
+      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, (size_t)(16 / waves)));
+      const uint32_t ntiles = (uint32_t)((ix->n_rows + 31) / 32);
+      const int blocks_m = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ntiles + waves - 1) / waves,
+                                                                     (int64_t)ix->n_cus * per_cu));
+      hipError_t e2;
+      if ((e2 = ix->s_part_keys.reserve((size_t)Bm * blocks_m * k * 8, false, st)) != hipSuccess)
+        return fail(VDB_ERR_OOM, "top-k scratch");
+      SweepArgs am{};
+      am.rows = ix->rows.as<float>();
+      am.norms = ix->norms.as<float>();
+      am.alive = alive;
+      am.queries = d_q + (size_t)q0 * q_stride;
+      am.part_keys = ix->s_part_keys.as<uint64_t>();
+      am.row_stride = ix->row_stride;
+      am.q_stride = q_stride;
+      am.n_rows = (uint32_t)ix->n_rows;
+      am.dim = ix->dim;
+      am.nq = tile_m;
+      am.k = k;
+      EventPair* evm = next_events(ix);
+      if (evm) (void)hipEventRecord(evm->a, st);
+      e2 = launch_sweep_mfma(ix->metric, mfma_nqt, am, blocks_m, st);
+      if (evm) (void)hipEventRecord(evm->b, st);
+      if (e2 != hipSuccess) return fail(VDB_ERR_HIP, std::string("mfma sweep launch: ") + hipGetErrorString(e2));
+      MergeArgs mm{};
+      mm.part_keys = am.part_keys;
+      mm.ext_ids = ix->ext_ids.as<uint64_t>();
+      mm.out_ids = d_ids + (size_t)q0 * k;
+      mm.out_scores = d_scores + (size_t)q0 * k;
+      mm.out_n = d_n + q0;
+      mm.n_lists = (uint32_t)blocks_m;
+      mm.k = k;
+      launch_merge(hib, mm, tile_m, st);
+      q0 += tile_m;
+      continue;
+    }
     // large tiles: queries in LDS, 16 or 32 per corpus pass (dims that are a multiple of 256, <= 1024)
     bool qlds = false;
     const uint32_t max_tile = g_max_tile;
@@ -362,6 +412,12 @@ const char* vdb_hip_version(void) { return "velesdb-hip 0.1.0 (gfx950)"; }
 int32_t vdb_hip_set_max_query_tile(uint32_t b) {
   if (b != 1 && b != 2 && b != 4 && b != 8 && b != 16 && b != 32) return fail(VDB_ERR_INVALID_ARG, "tile must be 1..32, power of 2");
   g_max_tile = b;
+  return VDB_OK;
+}
+
+int32_t vdb_hip_set_sweep_engine(int32_t engine) {
+  if (engine != 0 && engine != 1) return fail(VDB_ERR_INVALID_ARG, "engine must be 0 (VALU) or 1 (MFMA)");
+  g_sweep_engine = engine;
   return VDB_OK;
 }
 

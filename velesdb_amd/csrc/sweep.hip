@@ -356,6 +356,206 @@ __global__ __launch_bounds__(WAVES * 64, (B == 32 ? 4 : 3)) void sweep_topk_f32_
 }
 
 // ------------------------------------------------------------------------------------------
+// MFMA f32 sweep for Cosine / DotProduct: corpus rows x query tile as a true f32 contraction on the matrix
+// cores (v_mfma_f32_16x16x4_f32: exact f32, every product rounded once, k-ordered chain — the f32 VALU rate
+// without spending VALU issue slots, and no cross-lane reduction at all).  The VALU kernels above top out
+// near 50 TFLOP/s, which makes a 32-query pass compute-bound; the matrix pipe sustains ~3x that, so a pass
+// over the corpus with 32 queries stays close to the HBM time.
+//   * a wave owns 32 rows (two 16-row A fragments) and NQT*16 queries; lane l = (i = l&15, kk = l>>4).
+//   * A operand straight from HBM: per 32-float super-step T the lane reads 2 float4 of row i at
+//     k = 32T + 8kk .. +7: the four kk lanes of a row cover one full 128-B line per super-step.
+//   * B operand from LDS, stored once per block in fragment order [T][tile][half][lane][4] so every
+//     ds_read_b128 is contiguous across lanes; 16*NQT MFMAs per 2*NQT LDS reads and 4 HBM loads.
+//   * summation order ("mode M" of the oracle): for T, for e in 0..7, for kk in 0..3: k = 32T + 8kk + e,
+//     one fmaf chain per (row, query), dim zero-padded to a multiple of 32.
+//   * epilogue: D[i = 4*(l>>4)+r][j = l&15]; scores finished with the canonical norms, offered to the
+//     block-shared top-k lists exactly like the VALU kernels.
+// LDS: q fragments KT*NQT*2 KiB | lists[B][k] u64 | cnt[B] | lock[B] | qnorm[B].
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int METRIC, int NQT, int WAVES, bool FULL32>
+__global__ __launch_bounds__(WAVES * 64) void sweep_topk_mfma_f32(SweepArgs a, uint32_t KT) {
+  constexpr int B = NQT * 16;
+  constexpr bool HIB = true;  // cosine and dot: higher is better
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t wave = blockIdx.x * WAVES + wib;
+  const uint32_t nwaves = gridDim.x * WAVES;
+  const uint32_t k = a.k;
+  float* qs = reinterpret_cast<float*>(smem);
+  const size_t qbytes = (size_t)KT * NQT * 2048;
+  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(smem + qbytes);
+  volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(smem + qbytes + (size_t)B * k * 8);
+  uint32_t* locks = reinterpret_cast<uint32_t*>(smem + qbytes + (size_t)B * k * 8 + (size_t)B * 4);
+  float* qn = reinterpret_cast<float*>(smem + qbytes + (size_t)B * k * 8 + (size_t)B * 8);
+  const int d4 = (int)((a.dim + 3) / 4);
+
+  for (uint32_t i = threadIdx.x; i < KT * NQT * 512; i += WAVES * 64) qs[i] = 0.0f;
+  if (threadIdx.x < B) {
+    cnts[threadIdx.x] = 0;
+    locks[threadIdx.x] = 0;
+    qn[threadIdx.x] = 0.0f;
+  }
+  __syncthreads();
+  for (uint32_t idx = threadIdx.x; idx < (uint32_t)B * a.dim; idx += WAVES * 64) {
+    const uint32_t b = idx / a.dim, kx = idx % a.dim;
+    if (b < a.nq) {
+      const uint32_t t = b >> 4, j = b & 15, T = kx >> 5, kk = (kx >> 3) & 3, e = kx & 7;
+      qs[((((size_t)T * NQT + t) * 2 + (e >> 2)) * 64 + kk * 16 + j) * 4 + (e & 3)] = a.queries[(size_t)b * a.q_stride + kx];
+    }
+  }
+  if (METRIC == kCosine) {  // canonical query norms (same as every other kernel)
+    for (uint32_t b = wib; b < (uint32_t)B && b < a.nq; b += WAVES) {
+      const float* qp = a.queries + (size_t)b * a.q_stride;
+      float nacc = 0.0f;
+      for (int c = lane; c < d4; c += 64) {
+        const int nv = (int)a.dim - c * 4;
+        float4 x;
+        if (nv >= 4) {
+          x = ld4(qp + c * 4);
+          nacc = chain4<kOpDot>(nacc, x, x);
+        } else {
+          x = make_float4(qp[c * 4], nv > 1 ? qp[c * 4 + 1] : 0.f, nv > 2 ? qp[c * 4 + 2] : 0.f, 0.f);
+          nacc = chain4_tail<kOpDot>(nacc, x, x, nv);
+        }
+      }
+      const float n = sqrtf(butterfly_all(nacc));
+      if (lane == 0) qn[b] = n;
+    }
+  }
+  __syncthreads();
+  float qn_t[NQT];
+#pragma unroll
+  for (int t = 0; t < NQT; t++) qn_t[t] = qn[t * 16 + (lane & 15)];
+
+  const uint32_t kk8 = (uint32_t)(lane >> 4) * 8;  // this lane's offset inside a 32-float super-step
+  const uint32_t ntiles = (a.n_rows + 31) / 32;
+  for (uint32_t g = wave; g < ntiles; g += nwaves) {
+    const float* rp[2];
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+      uint32_t row = g * 32 + f * 16 + (lane & 15);
+      row = row < a.n_rows ? row : a.n_rows - 1;  // tail rows: re-read the last row, masked in the epilogue
+      rp[f] = a.rows + (size_t)row * a.row_stride + kk8;
+    }
+    // norms of the rows this lane finishes: D row = 4*(lane>>4) + r
+    float vn[2][4];
+#pragma unroll
+    for (int f = 0; f < 2; f++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t row = g * 32 + f * 16 + 4 * (lane >> 4) + r;
+        vn[f][r] = (METRIC == kCosine) ? a.norms[row < a.n_rows ? row : a.n_rows - 1] : 1.0f;
+      }
+    f32x4 acc[2][NQT];
+#pragma unroll
+    for (int f = 0; f < 2; f++)
+#pragma unroll
+      for (int t = 0; t < NQT; t++) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load_a = [&](uint32_t T, float4(&dst)[2][2]) {
+#pragma unroll
+      for (int f = 0; f < 2; f++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const uint32_t k0 = T * 32 + kk8 + h * 4;
+          if (FULL32 ? (T < KT) : (k0 < (uint32_t)a.row_stride))
+            dst[f][h] = ld4(rp[f] + (size_t)T * 32 + h * 4);
+          else
+            dst[f][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto compute = [&](uint32_t T, const float4(&av)[2][2]) {
+      float4 bq[NQT][2];
+#pragma unroll
+      for (int t = 0; t < NQT; t++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) bq[t][h] = ld4(qs + ((((size_t)T * NQT + t) * 2 + h) * 64 + lane) * 4);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const float ax[2][4] = {{av[0][h].x, av[0][h].y, av[0][h].z, av[0][h].w},
+                                {av[1][h].x, av[1][h].y, av[1][h].z, av[1][h].w}};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+#pragma unroll
+          for (int t = 0; t < NQT; t++) {
+            const float bx = c == 0 ? bq[t][h].x : (c == 1 ? bq[t][h].y : (c == 2 ? bq[t][h].z : bq[t][h].w));
+#pragma unroll
+            for (int f = 0; f < 2; f++) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[f][c], bx, acc[f][t], 0, 0, 0);
+          }
+        }
+      }
+    };
+    float4 A0[2][2], A1[2][2], A2[2][2];
+    load_a(0, A0);
+    load_a(1, A1);
+    for (uint32_t T = 0; T < KT; T += 3) {
+      load_a(T + 2, A2);
+      compute(T, A0);
+      if (T + 1 < KT) {
+        load_a(T + 3, A0);
+        compute(T + 1, A1);
+      }
+      if (T + 2 < KT) {
+        load_a(T + 4, A1);
+        compute(T + 2, A2);
+      }
+    }
+    // ---- epilogue: 2 x NQT x 4 raw dots per lane.  Almost none of them can enter a top-k list once the lists
+    // have warmed up, so the exact finish (IEEE divide for cosine, key packing, LDS reads) runs only behind a
+    // cheap conservative filter: an approximate score (multiply by a reciprocal, ~1 ulp) is compared with the
+    // k-th best score of its query minus a 16-ulp margin; whatever passes is finished exactly and offered. ----
+    float tau_f[NQT];  // k-th best score of this lane's query in tile t (-inf while the list is not full)
+#pragma unroll
+    for (int t = 0; t < NQT; t++) {
+      const uint32_t b = t * 16 + (lane & 15);
+      tau_f[t] = (cnts[b] == k) ? key_score<HIB>(lists[(size_t)b * k + (k - 1)]) : __uint_as_float(0xFF800000u);
+    }
+#pragma unroll
+    for (int f = 0; f < 2; f++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t row = g * 32 + f * 16 + 4 * (lane >> 4) + r;
+        float rq[NQT];
+#pragma unroll
+        for (int t = 0; t < NQT; t++)
+          rq[t] = (METRIC == kCosine) ? __builtin_amdgcn_rcpf(qn_t[t] * vn[f][r]) : 1.0f;
+#pragma unroll
+        for (int t = 0; t < NQT; t++) {
+          const uint32_t b = t * 16 + (lane & 15);
+          const float dotv = acc[f][t][r];
+          const float approx = dotv * rq[t];
+          // pass unless clearly below the threshold; NaN / inf / zero-norm cases always pass to the exact path
+          const float margin = fabsf(tau_f[t]) * 1.9073486e-6f + 1e-37f;
+          const bool maybe = !(approx < tau_f[t] - margin) && row < a.n_rows && b < a.nq;
+          uint64_t mask = __ballot(maybe);
+          if (mask == 0) continue;
+          const float score = finish_score<METRIC>(dotv, qn_t[t], vn[f][r]);
+          const uint64_t key = maybe ? make_key<HIB>(score, row) : kKeyInvalid;
+          const uint64_t tau = (cnts[b] == k) ? lists[(size_t)b * k + (k - 1)] : kKeyInvalid;
+          mask = __ballot(key < tau);
+          while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const uint64_t kk = readlane64(key, src);
+            if (a.alive && a.alive[key_row(kk)] == 0) continue;
+            const int bb = t * 16 + (src & 15);
+            shared_list_offer(lists + (size_t)bb * k, cnts + bb, locks + bb, k, kk, lane);
+          }
+        }
+      }
+  }
+  __syncthreads();
+  for (int b = wib; b < (int)a.nq && b < B; b += WAVES) {
+    const uint32_t c = cnts[b];
+    uint64_t* out = a.part_keys + ((size_t)b * gridDim.x + blockIdx.x) * k;
+    for (uint32_t e = lane; e < k; e += 64) out[e] = e < c ? lists[(size_t)b * k + e] : kKeyInvalid;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // merge: one wave per query scans the per-wave lists with the same threshold + insert scheme
 // and writes ids / scores best-first.
 // ------------------------------------------------------------------------------------------
@@ -698,6 +898,46 @@ hipError_t launch_sweep_f32_qlds(int metric, int B, const SweepArgs& a, int bloc
     case kEuclidean: return launch_qlds_m<kEuclidean>(B, a, blocks, lds, st);
     default: return launch_qlds_m<kDot>(B, a, blocks, lds, st);
   }
+}
+
+// ---- MFMA launcher ---------------------------------------------------------------------------
+size_t sweep_mfma_lds_bytes(int nqt, uint32_t k, uint32_t dim) {
+  const size_t KT = (dim + 31) / 32, B = (size_t)nqt * 16;
+  return ((KT * nqt * 2048 + B * k * 8 + B * 12) + 15) & ~(size_t)15;
+}
+template <int METRIC, int NQT, int WAVES>
+static hipError_t launch_mfma_t(const SweepArgs& a, int blocks, size_t lds, hipStream_t st) {
+  const uint32_t KT = (a.dim + 31) / 32;
+  const bool full32 = (a.dim % 32) == 0;
+  if (full32) {
+    static bool done = false;
+    if (lds > 64 * 1024 && !done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_mfma_f32<METRIC, NQT, WAVES, true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      done = true;
+    }
+    hipLaunchKernelGGL((sweep_topk_mfma_f32<METRIC, NQT, WAVES, true>), dim3(blocks), dim3(WAVES * 64), lds, st, a, KT);
+  } else {
+    static bool done = false;
+    if (lds > 64 * 1024 && !done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_mfma_f32<METRIC, NQT, WAVES, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      done = true;
+    }
+    hipLaunchKernelGGL((sweep_topk_mfma_f32<METRIC, NQT, WAVES, false>), dim3(blocks), dim3(WAVES * 64), lds, st, a, KT);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_sweep_mfma(int metric, int nqt, const SweepArgs& a, int blocks, hipStream_t st) {
+  const size_t lds = sweep_mfma_lds_bytes(nqt, a.k, a.dim);
+  if (metric == kCosine) {
+    if (nqt == 2) return launch_mfma_t<kCosine, 2, kMfmaWaves2>(a, blocks, lds, st);
+    return launch_mfma_t<kCosine, 1, kMfmaWaves1>(a, blocks, lds, st);
+  }
+  if (nqt == 2) return launch_mfma_t<kDot, 2, kMfmaWaves2>(a, blocks, lds, st);
+  return launch_mfma_t<kDot, 1, kMfmaWaves1>(a, blocks, lds, st);
 }
 
 void launch_merge(bool hib, const MergeArgs& m, uint32_t nq, hipStream_t st) {

@@ -110,6 +110,11 @@ constexpr int kQldsWaves16 = 4;   // waves per block for B = 16 (3 blocks per CU
 constexpr int kQldsWaves32 = 16;  // waves per block for B = 32
 size_t sweep_qlds_lds_bytes(int B, uint32_t k, uint32_t dim, int waves);
 hipError_t launch_sweep_f32_qlds(int metric, int B, const SweepArgs& a, int blocks, hipStream_t st);
+// MFMA f32 sweep (cosine / dot): nqt = 1 (16 queries per pass) or 2 (32)
+constexpr int kMfmaWaves1 = 8;   // waves per block for one 16-query tile
+constexpr int kMfmaWaves2 = 16;  // ... for two tiles (the 96 KiB query fragments fill most of the LDS)
+size_t sweep_mfma_lds_bytes(int nqt, uint32_t k, uint32_t dim);
+hipError_t launch_sweep_mfma(int metric, int nqt, const SweepArgs& a, int blocks, hipStream_t st);
 void launch_merge(bool higher_is_better, const MergeArgs& m, uint32_t nq, hipStream_t st);
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st);
 void launch_prep_rows(const PrepArgs& a, hipStream_t st);

@@ -52,6 +52,11 @@ def set_max_query_tile(b: int) -> None:
     check(lib().vdb_hip_set_max_query_tile(b))
 
 
+def set_sweep_engine(engine: int) -> None:
+    """0 = vector-ALU sweep kernels (oracle mode C), 1 = matrix-core kernel for Cosine/Dot (oracle mode M)."""
+    check(lib().vdb_hip_set_sweep_engine(engine))
+
+
 class HnswIndex:
     """HNSW index whose vectors, graph and search run on one MI355X."""
 
