@@ -346,17 +346,18 @@ float reduceC(const float* a, const float* b, size_t n) {
 inline float dotC(const float* a, const float* b, size_t n) { return reduceC<OP_DOT>(a, b, n); }
 // matrix-core order (v_mfma_f32_16x16x4_f32 in velesdb_amd/csrc/sweep.hip sweep_topk_mfma_f32): the instruction
 // adds its four k-slots as a k-ordered fmaf chain, one rounding per product; the kernel feeds slot kk of step
-// (T, e) with element 32T + 8kk + e and pads the vectors with zeros to a multiple of 32
+// (U, m, c) with element 128U + 16m + 4kk + c and pads the vectors with zeros to a multiple of 128
 inline float dotM(const float* a, const float* b, size_t n) {
   float acc = 0.0f;
-  const size_t KT = (n + 31) / 32;
-  for (size_t T = 0; T < KT; T++)
-    for (size_t e = 0; e < 8; e++)
-      for (size_t kk = 0; kk < 4; kk++) {
-        const size_t k = 32 * T + 8 * kk + e;
-        const float x = k < n ? a[k] : 0.0f, y = k < n ? b[k] : 0.0f;
-        acc = std::fmaf(x, y, acc);
-      }
+  const size_t KU = (n + 127) / 128;
+  for (size_t U = 0; U < KU; U++)
+    for (size_t m = 0; m < 8; m++)
+      for (size_t c = 0; c < 4; c++)
+        for (size_t kk = 0; kk < 4; kk++) {
+          const size_t k = 128 * U + 16 * m + 4 * kk + c;
+          const float x = k < n ? a[k] : 0.0f, y = k < n ? b[k] : 0.0f;
+          acc = std::fmaf(x, y, acc);
+        }
   return acc;
 }
 inline float sql2C(const float* a, const float* b, size_t n) { return reduceC<OP_SQL2>(a, b, n); }

@@ -43,8 +43,8 @@ enum {
   VO_MODE_SCALAR = 2, /* reference CpuDistance scalar engine (native/distance.rs:158-217) */
   VO_MODE_NATIVE = 3, /* reference NativeSimdDistance: simd_native.rs 16-lane AVX-512F shape */
   VO_MODE_M = 5,      /* matrix-core order of the HIP MFMA sweep (cosine / dot brute force only): ONE fmaf chain per
-                         pair over k = 32T + 8kk + e for T, then e in 0..7, then kk in 0..3, the vectors
-                         zero-padded to a multiple of 32; norms (cosine) in the canonical mode-C order; every
+                         pair over k = 128U + 16m + 4kk + c for U, then m in 0..7, c in 0..3, kk in 0..3, the
+                         vectors zero-padded to a multiple of 128; norms (cosine) in the canonical mode-C order; every
                          other kernel of mode M is mode C */
   VO_MODE_R_NOFMA = 4 /* mode R with wide::mul_add un-fused (a*b+c, two roundings): what
                          `wide` emits when compiled without target_feature=fma         */

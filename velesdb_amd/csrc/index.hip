@@ -264,7 +264,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
       const int waves = mfma_nqt == 2 ? kMfmaWaves2 : kMfmaWaves1;
       const size_t lds = sweep_mfma_lds_bytes(mfma_nqt, k, ix->dim);
       const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, (size_t)(16 / waves)));
-      const uint32_t ntiles = (uint32_t)((ix->n_rows + 31) / 32);
+      const uint32_t ntiles = (uint32_t)((ix->n_rows + 15) / 16);
       const int blocks_m = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ntiles + waves - 1) / waves,
                                                                      (int64_t)ix->n_cus * per_cu));
       hipError_t e2;

@@ -359,23 +359,23 @@ __global__ __launch_bounds__(WAVES * 64, (B == 32 ? 4 : 3)) void sweep_topk_f32_
 // MFMA f32 sweep for Cosine / DotProduct: corpus rows x query tile as a true f32 contraction on the matrix
 // cores (v_mfma_f32_16x16x4_f32: exact f32, every product rounded once, k-ordered chain — the f32 VALU rate
 // without spending VALU issue slots, and no cross-lane reduction at all).  The VALU kernels above top out
-// near 50 TFLOP/s, which makes a 32-query pass compute-bound; the matrix pipe sustains ~3x that, so a pass
-// over the corpus with 32 queries stays close to the HBM time.
-//   * a wave owns 32 rows (two 16-row A fragments) and NQT*16 queries; lane l = (i = l&15, kk = l>>4).
-//   * A operand straight from HBM: per 32-float super-step T the lane reads 2 float4 of row i at
-//     k = 32T + 8kk .. +7: the four kk lanes of a row cover one full 128-B line per super-step.
-//   * B operand from LDS, stored once per block in fragment order [T][tile][half][lane][4] so every
-//     ds_read_b128 is contiguous across lanes; 16*NQT MFMAs per 2*NQT LDS reads and 4 HBM loads.
-//   * summation order ("mode M" of the oracle): for T, for e in 0..7, for kk in 0..3: k = 32T + 8kk + e,
-//     one fmaf chain per (row, query), dim zero-padded to a multiple of 32.
-//   * epilogue: D[i = 4*(l>>4)+r][j = l&15]; scores finished with the canonical norms, offered to the
-//     block-shared top-k lists exactly like the VALU kernels.
-// LDS: q fragments KT*NQT*2 KiB | lists[B][k] u64 | cnt[B] | lock[B] | qnorm[B].
+// near 50 TFLOP/s, which makes a 32-query pass compute-bound; the matrix pipe sustains ~3x that.
+//   * a wave owns 16 rows and NQT*16 queries; lane l = (i = l&15, kk = l>>4).
+//   * A operand straight from HBM: load m of macro step U reads, for row i, the 64 contiguous bytes
+//     k = 128U + 16m .. +15 (the four kk lanes take 16 B each), so a 128-B line is consumed by two
+//     back-to-back load instructions and a macro step covers 512 contiguous bytes per row.
+//   * B operand from LDS, stored once per block in fragment order [U][tile][m][lane][4] so every
+//     ds_read_b128 is contiguous across lanes; 4*NQT MFMAs per NQT LDS reads.
+//   * summation order ("mode M" of the oracle): for U, for m in 0..7, for c in 0..3, for kk in 0..3:
+//     k = 128U + 16m + 4kk + c — one fmaf chain per (row, query), dim zero-padded to a multiple of 128.
+//   * epilogue: D[i = 4*(l>>4)+r][j = l&15]; a cheap conservative filter (reciprocal multiply, 16-ulp margin)
+//     in front of the exact finish + the block-shared top-k lists.
+// LDS: q fragments KU*NQT*8 KiB | lists[B][k] u64 | cnt[B] | lock[B] | qnorm[B].
 // ------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int METRIC, int NQT, int WAVES, bool FULL32>
-__global__ __launch_bounds__(WAVES * 64) void sweep_topk_mfma_f32(SweepArgs a, uint32_t KT) {
+template <int METRIC, int NQT, int WAVES, bool FULL128>
+__global__ __launch_bounds__(WAVES * 64, 4) void sweep_topk_mfma_f32(SweepArgs a, uint32_t KU) {
   constexpr int B = NQT * 16;
   constexpr bool HIB = true;  // cosine and dot: higher is better
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -385,14 +385,14 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_topk_mfma_f32(SweepArgs a, u
   const uint32_t nwaves = gridDim.x * WAVES;
   const uint32_t k = a.k;
   float* qs = reinterpret_cast<float*>(smem);
-  const size_t qbytes = (size_t)KT * NQT * 2048;
+  const size_t qbytes = (size_t)KU * NQT * 8192;
   volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(smem + qbytes);
   volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(smem + qbytes + (size_t)B * k * 8);
   uint32_t* locks = reinterpret_cast<uint32_t*>(smem + qbytes + (size_t)B * k * 8 + (size_t)B * 4);
   float* qn = reinterpret_cast<float*>(smem + qbytes + (size_t)B * k * 8 + (size_t)B * 8);
   const int d4 = (int)((a.dim + 3) / 4);
 
-  for (uint32_t i = threadIdx.x; i < KT * NQT * 512; i += WAVES * 64) qs[i] = 0.0f;
+  for (uint32_t i = threadIdx.x; i < KU * NQT * 2048; i += WAVES * 64) qs[i] = 0.0f;
   if (threadIdx.x < B) {
     cnts[threadIdx.x] = 0;
     locks[threadIdx.x] = 0;
@@ -402,8 +402,8 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_topk_mfma_f32(SweepArgs a, u
   for (uint32_t idx = threadIdx.x; idx < (uint32_t)B * a.dim; idx += WAVES * 64) {
     const uint32_t b = idx / a.dim, kx = idx % a.dim;
     if (b < a.nq) {
-      const uint32_t t = b >> 4, j = b & 15, T = kx >> 5, kk = (kx >> 3) & 3, e = kx & 7;
-      qs[((((size_t)T * NQT + t) * 2 + (e >> 2)) * 64 + kk * 16 + j) * 4 + (e & 3)] = a.queries[(size_t)b * a.q_stride + kx];
+      const uint32_t t = b >> 4, j = b & 15, U = kx >> 7, m = (kx >> 4) & 7, kk = (kx >> 2) & 3, c = kx & 3;
+      qs[((((size_t)U * NQT + t) * 8 + m) * 64 + kk * 16 + j) * 4 + c] = a.queries[(size_t)b * a.q_stride + kx];
     }
   }
   if (METRIC == kCosine) {  // canonical query norms (same as every other kernel)
@@ -430,80 +430,83 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_topk_mfma_f32(SweepArgs a, u
 #pragma unroll
   for (int t = 0; t < NQT; t++) qn_t[t] = qn[t * 16 + (lane & 15)];
 
-  const uint32_t kk8 = (uint32_t)(lane >> 4) * 8;  // this lane's offset inside a 32-float super-step
-  const uint32_t ntiles = (a.n_rows + 31) / 32;
-  for (uint32_t g = wave; g < ntiles; g += nwaves) {
-    const float* rp[2];
-#pragma unroll
-    for (int f = 0; f < 2; f++) {
-      uint32_t row = g * 32 + f * 16 + (lane & 15);
-      row = row < a.n_rows ? row : a.n_rows - 1;  // tail rows: re-read the last row, masked in the epilogue
-      rp[f] = a.rows + (size_t)row * a.row_stride + kk8;
-    }
-    // norms of the rows this lane finishes: D row = 4*(lane>>4) + r
-    float vn[2][4];
-#pragma unroll
-    for (int f = 0; f < 2; f++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const uint32_t row = g * 32 + f * 16 + 4 * (lane >> 4) + r;
-        vn[f][r] = (METRIC == kCosine) ? a.norms[row < a.n_rows ? row : a.n_rows - 1] : 1.0f;
-      }
-    f32x4 acc[2][NQT];
-#pragma unroll
-    for (int f = 0; f < 2; f++)
-#pragma unroll
-      for (int t = 0; t < NQT; t++) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t kk32 = (uint32_t)(lane >> 4) * 4;  // this lane's float offset inside every 16-float load group
+  const uint32_t ntiles = (a.n_rows + 15) / 16;
 
-    auto load_a = [&](uint32_t T, float4(&dst)[2][2]) {
+  auto row_ptr = [&](uint32_t g) -> const float* {
+    uint32_t row = g * 16 + (lane & 15);
+    row = row < a.n_rows ? row : a.n_rows - 1;  // tail rows: re-read the last row, masked in the epilogue
+    return a.rows + (size_t)row * a.row_stride + kk32;
+  };
+  auto load_a = [&](const float* rp, uint32_t U, float4(&dst)[8]) {
 #pragma unroll
-      for (int f = 0; f < 2; f++)
+    for (int m = 0; m < 8; m++) {
+      const uint32_t k0 = U * 128 + m * 16 + kk32;
+      if (FULL128 || k0 < (uint32_t)a.row_stride)
+        dst[m] = ld4(rp + (size_t)U * 128 + m * 16);
+      else
+        dst[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  float4 A0[8], A1[8];
+  if (wave < ntiles) load_a(row_ptr(wave), 0, A0);
+  for (uint32_t g = wave; g < ntiles; g += nwaves) {
+    const float* rp = row_ptr(g);
+    const uint32_t gnext = g + nwaves < ntiles ? g + nwaves : g;
+    const float* rpn = row_ptr(gnext);
+    float vn[4];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const uint32_t k0 = T * 32 + kk8 + h * 4;
-          if (FULL32 ? (T < KT) : (k0 < (uint32_t)a.row_stride))
-            dst[f][h] = ld4(rp[f] + (size_t)T * 32 + h * 4);
-          else
-            dst[f][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < 4; r++) {
+      const uint32_t row = g * 16 + 4 * (lane >> 4) + r;
+      vn[r] = (METRIC == kCosine) ? a.norms[row < a.n_rows ? row : a.n_rows - 1] : 1.0f;
+    }
+    f32x4 acc[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](uint32_t U, const float4(&av)[8]) {
+      const float* qb = qs + ((size_t)U * NQT * 8 * 64 + lane) * 4;
+      float4 bq[NQT], bn[NQT];
+#pragma unroll
+      for (int t = 0; t < NQT; t++) bq[t] = ld4(qb + (size_t)(t * 8) * 256);
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        if (m + 1 < 8) {
+#pragma unroll
+          for (int t = 0; t < NQT; t++) bn[t] = ld4(qb + (size_t)(t * 8 + m + 1) * 256);
         }
-    };
-    auto compute = [&](uint32_t T, const float4(&av)[2][2]) {
-      float4 bq[NQT][2];
-#pragma unroll
-      for (int t = 0; t < NQT; t++)
-#pragma unroll
-        for (int h = 0; h < 2; h++) bq[t][h] = ld4(qs + ((((size_t)T * NQT + t) * 2 + h) * 64 + lane) * 4);
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const float ax[2][4] = {{av[0][h].x, av[0][h].y, av[0][h].z, av[0][h].w},
-                                {av[1][h].x, av[1][h].y, av[1][h].z, av[1][h].w}};
+        const float ax[4] = {av[m].x, av[m].y, av[m].z, av[m].w};
 #pragma unroll
         for (int c = 0; c < 4; c++) {
 #pragma unroll
           for (int t = 0; t < NQT; t++) {
-            const float bx = c == 0 ? bq[t][h].x : (c == 1 ? bq[t][h].y : (c == 2 ? bq[t][h].z : bq[t][h].w));
-#pragma unroll
-            for (int f = 0; f < 2; f++) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[f][c], bx, acc[f][t], 0, 0, 0);
+            const float bx = c == 0 ? bq[t].x : (c == 1 ? bq[t].y : (c == 2 ? bq[t].z : bq[t].w));
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[c], bx, acc[t], 0, 0, 0);
           }
         }
+#pragma unroll
+        for (int t = 0; t < NQT; t++) bq[t] = bn[t];
       }
     };
-    float4 A0[2][2], A1[2][2], A2[2][2];
-    load_a(0, A0);
-    load_a(1, A1);
-    for (uint32_t T = 0; T < KT; T += 3) {
-      load_a(T + 2, A2);
-      compute(T, A0);
-      if (T + 1 < KT) {
-        load_a(T + 3, A0);
-        compute(T + 1, A1);
-      }
-      if (T + 2 < KT) {
-        load_a(T + 4, A1);
-        compute(T + 2, A2);
+    // macro steps, two at a time so the ring roles are static; the next tile's first chunk is requested
+    // during the last step of this one
+    for (uint32_t U = 0; U < KU; U += 2) {
+      if (U + 1 < KU) load_a(rp, U + 1, A1); else load_a(rpn, 0, A1);
+      __builtin_amdgcn_sched_barrier(0);  // one macro step of lookahead, no more (registers)
+      compute(U, A0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (U + 1 < KU) {
+        if (U + 2 < KU) load_a(rp, U + 2, A0); else load_a(rpn, 0, A0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(U + 1, A1);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+#pragma unroll
+        for (int m = 0; m < 8; m++) A0[m] = A1[m];
       }
     }
-    // ---- epilogue: 2 x NQT x 4 raw dots per lane.  Almost none of them can enter a top-k list once the lists
+    // ---- epilogue: NQT x 4 raw dots per lane.  Almost none of them can enter a top-k list once the lists
     // have warmed up, so the exact finish (IEEE divide for cosine, key packing, LDS reads) runs only behind a
     // cheap conservative filter: an approximate score (multiply by a reciprocal, ~1 ulp) is compared with the
     // k-th best score of its query minus a 16-ulp margin; whatever passes is finished exactly and offered. ----
@@ -514,38 +517,33 @@ __global__ __launch_bounds__(WAVES * 64) void sweep_topk_mfma_f32(SweepArgs a, u
       tau_f[t] = (cnts[b] == k) ? key_score<HIB>(lists[(size_t)b * k + (k - 1)]) : __uint_as_float(0xFF800000u);
     }
 #pragma unroll
-    for (int f = 0; f < 2; f++)
+    for (int r = 0; r < 4; r++) {
+      const uint32_t row = g * 16 + 4 * (lane >> 4) + r;
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const uint32_t row = g * 32 + f * 16 + 4 * (lane >> 4) + r;
-        float rq[NQT];
-#pragma unroll
-        for (int t = 0; t < NQT; t++)
-          rq[t] = (METRIC == kCosine) ? __builtin_amdgcn_rcpf(qn_t[t] * vn[f][r]) : 1.0f;
-#pragma unroll
-        for (int t = 0; t < NQT; t++) {
-          const uint32_t b = t * 16 + (lane & 15);
-          const float dotv = acc[f][t][r];
-          const float approx = dotv * rq[t];
-          // pass unless clearly below the threshold; NaN / inf / zero-norm cases always pass to the exact path
-          const float margin = fabsf(tau_f[t]) * 1.9073486e-6f + 1e-37f;
-          const bool maybe = !(approx < tau_f[t] - margin) && row < a.n_rows && b < a.nq;
-          uint64_t mask = __ballot(maybe);
-          if (mask == 0) continue;
-          const float score = finish_score<METRIC>(dotv, qn_t[t], vn[f][r]);
-          const uint64_t key = maybe ? make_key<HIB>(score, row) : kKeyInvalid;
-          const uint64_t tau = (cnts[b] == k) ? lists[(size_t)b * k + (k - 1)] : kKeyInvalid;
-          mask = __ballot(key < tau);
-          while (mask) {
-            const int src = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const uint64_t kk = readlane64(key, src);
-            if (a.alive && a.alive[key_row(kk)] == 0) continue;
-            const int bb = t * 16 + (src & 15);
-            shared_list_offer(lists + (size_t)bb * k, cnts + bb, locks + bb, k, kk, lane);
-          }
+      for (int t = 0; t < NQT; t++) {
+        const uint32_t b = t * 16 + (lane & 15);
+        const float dotv = acc[t][r];
+        const float rq = (METRIC == kCosine) ? __builtin_amdgcn_rcpf(qn_t[t] * vn[r]) : 1.0f;
+        const float approx = dotv * rq;
+        // pass unless clearly below the threshold; NaN / inf / zero-norm cases always pass to the exact path
+        const float margin = fabsf(tau_f[t]) * 1.9073486e-6f + 1e-37f;
+        const bool maybe = !(approx < tau_f[t] - margin) && row < a.n_rows && b < a.nq;
+        uint64_t mask = __ballot(maybe);
+        if (mask == 0) continue;
+        const float score = finish_score<METRIC>(dotv, qn_t[t], vn[r]);
+        const uint64_t key = maybe ? make_key<HIB>(score, row) : kKeyInvalid;
+        const uint64_t tau = (cnts[b] == k) ? lists[(size_t)b * k + (k - 1)] : kKeyInvalid;
+        mask = __ballot(key < tau);
+        while (mask) {
+          const int src = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const uint64_t kk = readlane64(key, src);
+          if (a.alive && a.alive[key_row(kk)] == 0) continue;
+          const int bb = t * 16 + (src & 15);
+          shared_list_offer(lists + (size_t)bb * k, cnts + bb, locks + bb, k, kk, lane);
         }
       }
+    }
   }
   __syncthreads();
   for (int b = wib; b < (int)a.nq && b < B; b += WAVES) {
@@ -902,13 +900,13 @@ hipError_t launch_sweep_f32_qlds(int metric, int B, const SweepArgs& a, int bloc
 
 // ---- MFMA launcher ---------------------------------------------------------------------------
 size_t sweep_mfma_lds_bytes(int nqt, uint32_t k, uint32_t dim) {
-  const size_t KT = (dim + 31) / 32, B = (size_t)nqt * 16;
-  return ((KT * nqt * 2048 + B * k * 8 + B * 12) + 15) & ~(size_t)15;
+  const size_t KU = (dim + 127) / 128, B = (size_t)nqt * 16;
+  return ((KU * nqt * 8192 + B * k * 8 + B * 12) + 15) & ~(size_t)15;
 }
 template <int METRIC, int NQT, int WAVES>
 static hipError_t launch_mfma_t(const SweepArgs& a, int blocks, size_t lds, hipStream_t st) {
-  const uint32_t KT = (a.dim + 31) / 32;
-  const bool full32 = (a.dim % 32) == 0;
+  const uint32_t KT = (a.dim + 127) / 128;
+  const bool full32 = (a.dim % 128) == 0;
   if (full32) {
     static bool done = false;
     if (lds > 64 * 1024 && !done) {
