@@ -307,7 +307,8 @@ def main():
             nchk = a.check_queries
             qh = queries[:nchk].cpu().numpy()
             gi, gs, gc = ix.search_batch_brute_force(qh, K)
-            ci, cs = po.scan_topk(om, host_full, qh, K, po.MODE_C, nthreads=ncores)
+            ci, cs = po.scan_topk(om, host_full, qh, K, po.MODE_M if ix.sweep_arith_mode(K) == "M" else po.MODE_C,
+                                  nthreads=ncores)
             ri, rs = po.scan_topk(om, host_full, qh, K, po.MODE_R, nthreads=ncores)
             check = {"queries": nchk, "ids_equal_oracle_canonical": bool(np.array_equal(gi, ci)),
                      "scores_bit_equal_oracle_canonical": bool(np.array_equal(gs.view(np.uint32), cs.view(np.uint32))),

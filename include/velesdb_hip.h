@@ -176,10 +176,14 @@ int32_t vdb_hip_set_kernel_timing(int32_t on);
 /* tuning knob of the exact sweep: largest number of queries served by one corpus pass
  * (1,2,4,8 register-resident tiles; 16,32 LDS-resident tiles).  Default 32.  Results do not depend on it. */
 int32_t vdb_hip_set_max_query_tile(uint32_t b);
-/* arithmetic engine of the exact sweep for Cosine / DotProduct: 0 = vector-ALU kernels (canonical lane-chain
- * order, oracle mode C), 1 = matrix-core kernel (v_mfma_f32_16x16x4_f32, exact f32, k-ordered chain, oracle
- * mode M).  Both are exact f32 arithmetic; scores differ in the last bits because the summation order does. */
+/* arithmetic engine of the exact sweep for Cosine / DotProduct: 1 (default) = matrix-core kernel
+ * (v_mfma_f32_16x16x4_f32: exact f32, one k-ordered fmaf chain per pair, oracle mode M); 0 = vector-ALU kernels
+ * (canonical lane-chain order, oracle mode C — what Euclidean, the graph kernels and batch_distance always use).
+ * Both are exact f32 arithmetic; scores differ in the last bits because the summation order does.  The choice
+ * never depends on the batch size. */
 int32_t vdb_hip_set_sweep_engine(int32_t engine);
+/* *mode = 1 if searches in VDB_SEARCH_BRUTE mode with this k run on the matrix-core kernel (mode M), else 0 */
+int32_t vdb_hip_index_sweep_arith_mode(vdb_hip_index* idx, uint32_t k, int32_t* mode);
 int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* idx, float* ms, uint32_t* launches);
 
 const char* vdb_hip_last_error(void); /* thread-local, never NULL */

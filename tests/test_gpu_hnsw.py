@@ -132,7 +132,8 @@ def test_auto_mode_and_quality_presets(tmp_path):
         assert [x[0] for x in r] == oid.tolist()
         assert all(0.0 <= s <= 1.0 for _, s in r)  # clamp(1-d, 0, 1)
     r = ix.search_with_quality(q, 10, SQ.Perfect)   # brute force: raw similarity, may be negative
-    gt, gs = po.scan_topk(po.COSINE, rows, q.reshape(1, -1), 10, po.MODE_C)
+    gt, gs = po.scan_topk(po.COSINE, rows, q.reshape(1, -1), 10,
+                          po.MODE_M if ix.sweep_arith_mode(10) == "M" else po.MODE_C)
     assert [x[0] for x in r] == gt[0].tolist()
     assert np.array_equal(bits([s for _, s in r]), bits(gs[0]))
     assert ix.search(q, 10) == ix.search_with_quality(q, 10, SQ.Balanced)  # trait_impl.rs:38-42

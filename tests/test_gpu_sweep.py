@@ -19,6 +19,15 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
+def sweep_mode(metric, dim, k=10):
+    """oracle mode the exact sweep must match bit for bit: M (matrix-core order) for Cosine / Dot when the engine
+    is on (default), C (canonical lane-chain order) otherwise — asked from the library, not assumed"""
+    ix = va.HnswIndex(dim, metric)
+    m = ix.sweep_arith_mode(k)
+    ix.close()
+    return po.MODE_M if m == "M" else po.MODE_C
+
+
 def rand_rows(rng, n, d, metric):
     if metric in (DM.Hamming, DM.Jaccard):
         return (rng.random((n, d)) > 0.6915).astype(np.float32)  # P(bit)=0.3085 like N(0,1)>0.5
@@ -80,7 +89,8 @@ def test_batch_distance_edge_cases(gpu_required):
 # ------------------------------------------------------------------ brute-force search
 def oracle_brute(metric, rows, ids, queries, k, live=None):
     sel = np.arange(rows.shape[0]) if live is None else np.nonzero(live)[0]
-    r, s = po.scan_topk(int(metric), rows[sel], queries, min(k, len(sel)) if len(sel) else 1, po.MODE_C)
+    r, s = po.scan_topk(int(metric), rows[sel], queries, min(k, len(sel)) if len(sel) else 1,
+                        sweep_mode(metric, rows.shape[1], k))
     out = []
     for qi in range(queries.shape[0]):
         n = min(k, len(sel))
@@ -126,8 +136,38 @@ def test_query_tile_size_does_not_change_results(gpu_required):
                 assert np.array_equal(out[0], ref[0]) and np.array_equal(bits(out[1]), bits(ref[1]))
     finally:
         va.set_max_query_tile(32)
-    eid, esc = po.scan_topk(po.COSINE, rows, Q, 10, po.MODE_C, nthreads=4)
+    eid, esc = po.scan_topk(po.COSINE, rows, Q, 10, sweep_mode(DM.Cosine, 768), nthreads=4)
     assert np.array_equal(ref[0], eid) and np.array_equal(bits(ref[1]), bits(esc))
+
+
+@pytest.mark.parametrize("metric", [DM.Cosine, DM.DotProduct])
+def test_both_sweep_engines_bit_exact_against_their_oracle_mode(gpu_required, metric):
+    # engine 1: matrix cores, oracle mode M; engine 0: vector ALUs, oracle mode C.  Same ids (up to sub-ulp
+    # near-ties), scores within a few ulps of each other, each bit-identical to its own restatement.
+    rng = np.random.default_rng(123)
+    pm = int(metric)
+    for n, dim in [(6000, 768), (3000, 200), (1000, 17), (2048, 128), (500, 2500)]:
+        rows = rng.standard_normal((n, dim)).astype(np.float32)
+        Q = rng.standard_normal((37, dim)).astype(np.float32)
+        ix = va.HnswIndex(dim, metric)
+        ix.upload(np.arange(n), rows)
+        try:
+            va.set_sweep_engine(1)
+            assert ix.sweep_arith_mode(10) == ("M" if dim <= 2400 else "C")
+            mode1 = po.MODE_M if ix.sweep_arith_mode(10) == "M" else po.MODE_C
+            g1 = ix.search_batch_brute_force(Q, 10)
+            va.set_sweep_engine(0)
+            assert ix.sweep_arith_mode(10) == "C"
+            g0 = ix.search_batch_brute_force(Q, 10)
+        finally:
+            va.set_sweep_engine(1)
+        e1 = po.scan_topk(pm, rows, Q, 10, mode1, nthreads=4)
+        e0 = po.scan_topk(pm, rows, Q, 10, po.MODE_C, nthreads=4)
+        assert np.array_equal(g1[0], e1[0]) and np.array_equal(bits(g1[1]), bits(e1[1]))
+        assert np.array_equal(g0[0], e0[0]) and np.array_equal(bits(g0[1]), bits(e0[1]))
+        scale = np.maximum(np.abs(g0[1]), 1e-3) if metric == DM.Cosine else np.sqrt(dim) * 4
+        assert np.all(np.abs(g1[1] - g0[1]) <= 2e-6 * scale)
+        ix.close()
 
 
 def test_brute_force_single_query_api_and_order(gpu_required):
@@ -161,7 +201,7 @@ def test_reference_gpu_template_stricter(gpu_required):
     for i in range(100):
         ix.upload(np.array([i], dtype=np.uint64), rows[i:i + 1])
     res = ix.search_brute_force(q, 10)
-    c_ids, c_sc = po.scan_topk(po.COSINE, rows, q, 10, po.MODE_C)
+    c_ids, c_sc = po.scan_topk(po.COSINE, rows, q, 10, sweep_mode(DM.Cosine, 128))
     r_ids, r_sc = po.scan_topk(po.COSINE, rows, q, 10, po.MODE_R)
     assert [i for i, _ in res] == c_ids[0].tolist() == r_ids[0].tolist()
     assert np.array_equal(bits(np.float32([s for _, s in res])), bits(c_sc[0]))
@@ -239,6 +279,6 @@ def test_large_planted_neighbours_200k(gpu_required, metric):
     ix.upload(np.arange(n), rows)
     got = ix.search_brute_force(q, 10)
     assert [i for i, _ in got] == pos.tolist()
-    eid, esc = po.scan_topk(int(metric), rows, q, 10, po.MODE_C, nthreads=8)
+    eid, esc = po.scan_topk(int(metric), rows, q, 10, sweep_mode(metric, d), nthreads=8)
     assert [i for i, _ in got] == eid[0].tolist()
     assert np.array_equal(bits(np.float32([s for _, s in got])), bits(esc[0]))

@@ -14,7 +14,7 @@ namespace vdb {
 
 static thread_local std::string g_last_error;
 static int g_timing = 0;
-static int g_sweep_engine = 0;  // 0: VALU kernels (mode C); 1: MFMA for cosine / dot (mode M)
+static int g_sweep_engine = 1;  // 1 (default): MFMA kernel for cosine / dot (oracle mode M); 0: VALU kernels (mode C)
 static uint32_t g_max_tile = 32;  // largest query tile of the exact sweep (tuning knob, vdb_hip_set_max_query_tile)
 
 void set_last_error(const std::string& s) { g_last_error = s; }
@@ -313,6 +313,8 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
         }
       }
     }
+    // generic dims keep the query tile in LDS: shrink the tile until it fits the default 64 KiB window
+    while (!qlds && B > 1 && sweep_lds_bytes((int)B, k, ix->dim, cpl) > 60 * 1024) B /= 2;
     const uint32_t tile = std::min<uint32_t>(B, nq - q0);
     if (!qlds && sweep_lds_bytes((int)B, k, ix->dim, cpl) > 60 * 1024)
       return fail(VDB_ERR_UNSUPPORTED, "k (x dim) too large for the fused top-k path");
@@ -722,6 +724,15 @@ int32_t vdb_hip_index_search_rerank(vdb_hip_index* ix, const float* queries, uin
                                     uint32_t ef, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
   if (rerank_k == 0) return fail(VDB_ERR_INVALID_ARG, "rerank_k must be > 0");
   return search_batch_host(ix, queries, nq, k, ef, VDB_SEARCH_AUTO, rerank_k, out_ids, out_scores, out_n);
+}
+
+// which summation order the exact sweep uses for this index and k (tests / bench pick the oracle mode by it)
+int32_t vdb_hip_index_sweep_arith_mode(vdb_hip_index* ix, uint32_t k, int32_t* mode) {
+  if (!ix || !mode) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  const bool mfma = g_sweep_engine == 1 && (ix->metric == VDB_COSINE || ix->metric == VDB_DOT) &&
+                    sweep_mfma_lds_bytes(1, k, ix->dim) <= 160 * 1024;
+  *mode = mfma ? 1 : 0;
+  return VDB_OK;
 }
 
 // VectorIndex::search — index/mod.rs:58; trait_impl.rs:38-42

@@ -261,6 +261,12 @@ class HnswIndex:
     def load_reference_files(self, directory: str, basename: str = "native_hnsw") -> None:
         check(lib().vdb_hip_index_load_reference_files(self._h, directory.encode(), basename.encode()))
 
+    def sweep_arith_mode(self, k: int) -> str:
+        """'M' if exact searches with this k run on the matrix-core kernel (oracle mode M), else 'C'."""
+        m = C.c_int32(0)
+        check(lib().vdb_hip_index_sweep_arith_mode(self._h, k, C.byref(m)))
+        return "M" if m.value else "C"
+
     # ---- introspection ------------------------------------------------------------------
     def node_count(self) -> int:
         n = C.c_uint64(0)
