@@ -43,9 +43,10 @@ def parse():
     p.add_argument("--rows", type=int, default=1_000_000)
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--k", type=int, default=10)
-    p.add_argument("--batch", type=int, default=64, help="queries per step (exact sweep)")
+    p.add_argument("--batch", type=int, default=192, help="queries per step (exact sweep)")
     p.add_argument("--metric", default="cosine")
-    p.add_argument("--tile", type=int, default=32, help="largest query tile of the sweep (1,2,4,8,16,32)")
+    p.add_argument("--tile", type=int, default=48, help="largest query tile of the sweep (1,2,4,8,16,32,48)")
+    p.add_argument("--engine", type=int, default=1, help="1 = matrix-core sweep for cosine/dot (default), 0 = VALU")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=int, default=262_144)
     p.add_argument("--cpu-sample-queries", type=int, default=32)
@@ -96,6 +97,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     torch.cuda.synchronize()
     va.set_max_query_tile(a.tile)
+    va.set_sweep_engine(a.engine)
     ix.upload_dev(0, corpus.data_ptr(), N, stream)
     sample_rows = min(a.cpu_sample_rows, N)
     host_sample = corpus[:sample_rows].cpu().numpy() if rank == 0 else None
@@ -142,7 +144,11 @@ def main():
     qps = world * Q * a.steps / dt
 
     # ---- roofline of the dominant kernel (the sweep): algorithmic bytes / measured duration ----
-    def tile_for(nq, max_tile):  # the library's tile choice (index.hip brute_dev)
+    mfma = a.engine == 1 and a.metric in ("cosine", "dot")
+
+    def tile_for(nq, max_tile, use_mfma):  # the library's tile choice (index.hip brute_dev)
+        if use_mfma:
+            return 48 if (nq > 32 and max_tile >= 48) else (32 if (nq > 16 and max_tile >= 32) else 16)
         lds_tiles = D % 256 == 0 and D <= 1024
         if lds_tiles and nq >= 24 and max_tile >= 32:
             return 32
@@ -150,7 +156,9 @@ def main():
             return 16
         return min(8 if nq >= 8 else (4 if nq >= 4 else (2 if nq >= 2 else 1)), max_tile, 8)
 
-    def kernel_name(t):
+    def kernel_name(t, use_mfma):
+        if use_mfma:
+            return f"sweep_topk_mfma_f32<{a.metric},NQT={t // 16}>"
         cpl = D // 256 if D % 256 == 0 and D <= 1024 else 0
         return (f"sweep_topk_f32_qlds<{a.metric},B={t},CPL={cpl}>" if t >= 16
                 else f"sweep_topk_f32<{a.metric},B={t},CPL={cpl}>")
@@ -158,28 +166,34 @@ def main():
     def alg_bytes_for(t):  # N*D*4 (+ N*4 precomputed norms) per corpus pass + the query tile
         return N * D * 4 + (N * 4 if a.metric == "cosine" else 0) + t * D * 4
 
-    tile = tile_for(Q, a.tile)
+    tile = tile_for(Q, a.tile, mfma)
     alg_bytes = alg_bytes_for(tile)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     flops = 2.0 * N * D * tile
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": kernel_name(tile),
+                "kernel": kernel_name(tile, mfma),
                 "kernel_ms": round(kernel_ms, 4), "launches_timed": kernel_launches,
                 "alg_bytes_per_launch": alg_bytes, "queries_per_launch": tile,
-                "valu_tflops": round(flops / (kernel_ms * 1e-3) / 1e12, 1) if kernel_ms > 0 else 0.0,
-                "note": "one corpus pass serves `queries_per_launch` queries; at 32 per pass the f32 VALU FMA rate "
-                        "(peak 157 TFLOP/s) bounds the kernel before HBM does; see `tiles` for the per-tile figures"}
+                "f32_tflops": round(flops / (kernel_ms * 1e-3) / 1e12, 1) if kernel_ms > 0 else 0.0,
+                "note": "one corpus pass serves `queries_per_launch` queries, so HBM bytes per QUERY are "
+                        "alg_bytes/queries_per_launch; with 48 queries per pass the exact-f32 matrix pipe (157 TFLOP/s "
+                        "peak, f32_tflops achieved) shares the bound with HBM; `tiles` lists every tile size"}
 
-    # ---- the same sweep at every tile size (queries per corpus pass): kernel time, HBM rate, throughput ----
+    # ---- the same sweep at every tile size (queries per corpus pass), both engines ----
     tiles = []
     if rank == 0:
-        for t in (1, 8, 16, 32):
-            if t > a.tile:
+        plans = [(1, t) for t in (16, 32, 48)] if a.metric in ("cosine", "dot") else []
+        plans = [(1, 1)] + plans if plans else plans
+        plans += [(0, t) for t in (1, 8, 16, 32)]
+        for eng, t in plans:
+            if t > a.tile and not (eng == 1 and t == 1):
                 continue
-            va.set_max_query_tile(t)
-            nq_t = max(t, 8) if t > 1 else 1
-            eff = tile_for(nq_t, t)
+            use_m = eng == 1
+            va.set_sweep_engine(eng)
+            va.set_max_query_tile(max(t, 16) if use_m else t)
+            nq_t = 1 if t == 1 else t
+            eff = tile_for(nq_t, max(t, 16) if use_m else t, use_m)
             for _ in range(2):
                 ix.search_batch_dev(queries.data_ptr(), nq_t, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
                                     out_sc.data_ptr(), out_n.data_ptr(), stream)
@@ -195,9 +209,10 @@ def main():
             kms, nl = ix.last_kernel_ms()
             va.set_kernel_timing(False)
             gbs = alg_bytes_for(eff) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-            tiles.append({"queries_per_pass": eff, "kernel": kernel_name(eff), "kernel_ms": round(kms, 4),
-                          "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
-                          "qps": round(nq_t / t_dt, 1)})
+            tiles.append({"engine": "mfma" if use_m else "valu", "queries": nq_t, "kernel": kernel_name(eff, use_m),
+                          "kernel_ms": round(kms, 4), "hbm_gbs": round(gbs, 1),
+                          "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "qps": round(nq_t / t_dt, 1)})
+        va.set_sweep_engine(a.engine)
         va.set_max_query_tile(a.tile)
 
     # ---- single-query latency mode (one corpus pass per query) ----
@@ -214,7 +229,7 @@ def main():
         l_dt = (time.perf_counter() - t1) / reps
         kms, _ = ix.last_kernel_ms()
         va.set_kernel_timing(False)
-        b1 = N * D * 4 + (N * 4 if a.metric == "cosine" else 0) + D * 4
+        b1 = alg_bytes_for(16 if mfma else 1)
         lat = {"ms_per_query": round(l_dt * 1e3, 4), "qps": round(1.0 / l_dt, 1), "sweep_kernel_ms": round(kms, 4),
                "hbm_gbs": round(b1 / (kms * 1e-3) / 1e9, 1) if kms > 0 else 0.0,
                "hbm_frac": round(b1 / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else 0.0}

@@ -15,7 +15,7 @@ p.add_argument("--rows", type=int, default=1_000_000)
 p.add_argument("--dim", type=int, default=768)
 p.add_argument("--k", type=int, default=10)
 p.add_argument("--metric", default="cosine")
-p.add_argument("--nqs", default="1,8,16,32,64,256")
+p.add_argument("--nqs", default="1,8,16,32,48,96,192")
 p.add_argument("--tile", type=int, default=32)
 p.add_argument("--engine", type=int, default=0)
 a = p.parse_args()

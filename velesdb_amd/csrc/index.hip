@@ -15,7 +15,7 @@ namespace vdb {
 static thread_local std::string g_last_error;
 static int g_timing = 0;
 static int g_sweep_engine = 1;  // 1 (default): MFMA kernel for cosine / dot (oracle mode M); 0: VALU kernels (mode C)
-static uint32_t g_max_tile = 32;  // largest query tile of the exact sweep (tuning knob, vdb_hip_set_max_query_tile)
+static uint32_t g_max_tile = 48;  // largest query tile of the exact sweep (tuning knob, vdb_hip_set_max_query_tile)
 
 void set_last_error(const std::string& s) { g_last_error = s; }
 int32_t fail(int32_t code, const std::string& msg) {
@@ -253,7 +253,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     // matrix-core engine (cosine / dot): one or two 16-query tiles per corpus pass
     int mfma_nqt = 0;
     if (g_sweep_engine == 1 && (ix->metric == VDB_COSINE || ix->metric == VDB_DOT)) {
-      int want = (nq - q0 > 16 && g_max_tile >= 32) ? 2 : 1;
+      int want = (nq - q0 > 32 && g_max_tile >= 48) ? 3 : ((nq - q0 > 16 && g_max_tile >= 32) ? 2 : 1);
       for (; want >= 1; want--)
         if (sweep_mfma_lds_bytes(want, k, ix->dim) <= 160 * 1024) break;
       mfma_nqt = want;  // 0: does not fit the LDS (very large dim or k): VALU kernels
@@ -261,7 +261,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     if (mfma_nqt) {
       const uint32_t Bm = (uint32_t)mfma_nqt * 16;
       const uint32_t tile_m = std::min<uint32_t>(Bm, nq - q0);
-      const int waves = mfma_nqt == 2 ? kMfmaWaves2 : kMfmaWaves1;
+      const int waves = mfma_nqt >= 2 ? kMfmaWaves2 : kMfmaWaves1;
       const size_t lds = sweep_mfma_lds_bytes(mfma_nqt, k, ix->dim);
       const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, (size_t)(16 / waves)));
       const uint32_t ntiles = (uint32_t)((ix->n_rows + 15) / 16);
@@ -412,7 +412,8 @@ const char* vdb_hip_last_error(void) { return g_last_error.c_str(); }
 const char* vdb_hip_version(void) { return "velesdb-hip 0.1.0 (gfx950)"; }
 
 int32_t vdb_hip_set_max_query_tile(uint32_t b) {
-  if (b != 1 && b != 2 && b != 4 && b != 8 && b != 16 && b != 32) return fail(VDB_ERR_INVALID_ARG, "tile must be 1..32, power of 2");
+  if (b != 1 && b != 2 && b != 4 && b != 8 && b != 16 && b != 32 && b != 48)
+    return fail(VDB_ERR_INVALID_ARG, "tile must be 1, 2, 4, 8, 16, 32 or 48");
   g_max_tile = b;
   return VDB_OK;
 }

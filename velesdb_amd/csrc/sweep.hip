@@ -467,12 +467,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sweep_topk_mfma_f32(SweepArgs a
 
     auto compute = [&](uint32_t U, const float4(&av)[8]) {
       const float* qb = qs + ((size_t)U * NQT * 8 * 64 + lane) * 4;
+      constexpr bool DBUF = NQT <= 2;  // three tiles: no register room for the look-ahead copy of the B fragments
       float4 bq[NQT], bn[NQT];
 #pragma unroll
       for (int t = 0; t < NQT; t++) bq[t] = ld4(qb + (size_t)(t * 8) * 256);
 #pragma unroll
       for (int m = 0; m < 8; m++) {
-        if (m + 1 < 8) {
+        if (DBUF && m + 1 < 8) {
 #pragma unroll
           for (int t = 0; t < NQT; t++) bn[t] = ld4(qb + (size_t)(t * 8 + m + 1) * 256);
         }
@@ -485,8 +486,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sweep_topk_mfma_f32(SweepArgs a
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[c], bx, acc[t], 0, 0, 0);
           }
         }
+        if (DBUF) {
 #pragma unroll
-        for (int t = 0; t < NQT; t++) bq[t] = bn[t];
+          for (int t = 0; t < NQT; t++) bq[t] = bn[t];
+        } else if (m + 1 < 8) {
+#pragma unroll
+          for (int t = 0; t < NQT; t++) bq[t] = ld4(qb + (size_t)(t * 8 + m + 1) * 256);
+        }
       }
     };
     // macro steps, two at a time so the ring roles are static; the next tile's first chunk is requested
@@ -931,9 +937,11 @@ static hipError_t launch_mfma_t(const SweepArgs& a, int blocks, size_t lds, hipS
 hipError_t launch_sweep_mfma(int metric, int nqt, const SweepArgs& a, int blocks, hipStream_t st) {
   const size_t lds = sweep_mfma_lds_bytes(nqt, a.k, a.dim);
   if (metric == kCosine) {
+    if (nqt == 3) return launch_mfma_t<kCosine, 3, kMfmaWaves2>(a, blocks, lds, st);
     if (nqt == 2) return launch_mfma_t<kCosine, 2, kMfmaWaves2>(a, blocks, lds, st);
     return launch_mfma_t<kCosine, 1, kMfmaWaves1>(a, blocks, lds, st);
   }
+  if (nqt == 3) return launch_mfma_t<kDot, 3, kMfmaWaves2>(a, blocks, lds, st);
   if (nqt == 2) return launch_mfma_t<kDot, 2, kMfmaWaves2>(a, blocks, lds, st);
   return launch_mfma_t<kDot, 1, kMfmaWaves1>(a, blocks, lds, st);
 }
