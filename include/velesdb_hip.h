@@ -64,7 +64,11 @@ enum vdb_search_mode {
                            len<=100, else HNSW with `ef`; scores = transform_score           */
   VDB_SEARCH_BRUTE = 1, /* HnswIndex::search_brute_force (search.rs:176-219): exact scan, raw
                            similarity/distance scores, metric.sort_results order             */
-  VDB_SEARCH_HNSW = 2   /* always the graph (search_batch_parallel, batch.rs:180-194)        */
+  VDB_SEARCH_HNSW = 2,  /* always the graph (search_batch_parallel, batch.rs:180-194)        */
+  VDB_SEARCH_BRUTE_BF16 = 3 /* exact scan over the bf16 copy of the rows with bf16-rounded queries and f32
+                           accumulation on the matrix cores: half_precision::dot_product / cosine_similarity on
+                           VectorData::BF16 (half_precision.rs:199-255).  Cosine / DotProduct only; needs
+                           vdb_hip_index_enable_bf16.  Raw scores, best first.                       */
 };
 
 /* score convention of vdb_hip_batch_distance */
@@ -101,6 +105,9 @@ int32_t vdb_hip_index_insert_batch(vdb_hip_index* idx, const uint64_t* ids, cons
  * default 2048; 1 = identical to insert_batch). */
 int32_t vdb_hip_index_insert_batch_parallel(vdb_hip_index* idx, const uint64_t* ids, const float* vecs_rowmajor,
                                             uint64_t n, uint32_t max_batch, uint64_t* inserted);
+/* keeps a bf16 copy (round to nearest even, VectorData::from_f32_slice(.., BF16), half_precision.rs:94-101) of every
+ * row next to the f32 rows, for VDB_SEARCH_BRUTE_BF16; +2 bytes per element of HBM */
+int32_t vdb_hip_index_enable_bf16(vdb_hip_index* idx);
 /* links every row that is not in the graph yet (rows that arrived through upload/upload_dev), same
  * schedule as insert_batch_parallel; afterwards the HNSW search modes are available. */
 int32_t vdb_hip_index_build_graph(vdb_hip_index* idx, uint32_t max_batch);

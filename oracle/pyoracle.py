@@ -128,6 +128,10 @@ def _declare(L):
     L.vo_scan_topk.restype = None
     L.vo_scan_topk.argtypes = [C.c_int, C.c_int, _f32p, C.c_uint64, C.c_uint32, _f32p, C.c_uint32, C.c_uint32,
                                C.c_uint32, _u64p, _f32p]
+    L.vo_round_bf16.restype, L.vo_round_bf16.argtypes = None, [_f32p, _f32p, C.c_uint64]
+    L.vo_scan_topk_bf16.restype = None
+    L.vo_scan_topk_bf16.argtypes = [C.c_int, _f32p, C.c_uint64, C.c_uint32, _f32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    _u64p, _f32p]
     L.vo_cpu_has_avx512f.restype = C.c_int
     L.vo_build_info.restype = C.c_char_p
 
@@ -268,6 +272,26 @@ def scan_topk(metric, rows, queries, k, mode=MODE_R, nthreads=1):
     ids = np.empty((nq, k), dtype=np.uint64)
     sc = np.empty((nq, k), dtype=np.float32)
     lib().vo_scan_topk(metric, mode, rows, rows.shape[0], rows.shape[1], queries, nq, k, nthreads, ids, sc)
+    return ids, sc
+
+
+def round_bf16(a):
+    """f32 -> bf16 (round to nearest even) -> f32, like half::bf16::from_f32(x).to_f32()"""
+    a = _f(a)
+    out = np.empty_like(a)
+    lib().vo_round_bf16(a.reshape(-1), out.reshape(-1), a.size)
+    return out
+
+
+def scan_topk_bf16(metric, rows, queries, k, nthreads=1):
+    """half_precision.rs BF16 semantics: exact top-k over bf16-rounded rows and queries, f32 sequential sums"""
+    rows, queries = _f(rows), _f(queries)
+    if queries.ndim == 1:
+        queries = queries.reshape(1, -1)
+    nq = queries.shape[0]
+    ids = np.zeros((nq, k), dtype=np.uint64)
+    sc = np.zeros((nq, k), dtype=np.float32)
+    lib().vo_scan_topk_bf16(metric, rows, rows.shape[0], rows.shape[1], queries, nq, k, nthreads, ids, sc)
     return ids, sc
 
 

@@ -1587,6 +1587,79 @@ void vo_scan_topk(int metric, int mode, const float* rows, uint64_t nrows, uint3
   }
 }
 
+// ---------------------------------------------------------------------------
+// half_precision.rs — VectorData::BF16: `half::bf16::from_f32` (round to nearest even; NaN stays NaN),
+// dot_product (:199-233) = sequential f32 sum of x.to_f32() * y.to_f32(); cosine_similarity (:237-254) =
+// dot / (sqrt(norm_squared(a)) * sqrt(norm_squared(b))), 0.0 when a norm is below f32::EPSILON;
+// norm_squared (:290-311) sequential.  Exact scan + top-k (score descending, row ascending among equals).
+// ---------------------------------------------------------------------------
+static inline uint16_t bf16_from_f32(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x0040u);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+void vo_round_bf16(const float* in, float* out, uint64_t n) {
+  for (uint64_t i = 0; i < n; i++) out[i] = bf16_to_f32(bf16_from_f32(in[i]));
+}
+void vo_scan_topk_bf16(int metric, const float* rows, uint64_t nrows, uint32_t dim, const float* queries,
+                       uint32_t nq, uint32_t k, uint32_t nthreads, uint64_t* out_rows, float* out_scores) {
+  std::vector<float> rr((size_t)nrows * dim), qq((size_t)nq * dim), rn(nrows);
+  vo_round_bf16(rows, rr.data(), (uint64_t)nrows * dim);
+  vo_round_bf16(queries, qq.data(), (uint64_t)nq * dim);
+  auto nsq = [&](const float* v) {
+    float s = 0.f;
+    for (uint32_t i = 0; i < dim; i++) s += v[i] * v[i];
+    return s;
+  };
+  for (uint64_t r = 0; r < nrows; r++) rn[r] = std::sqrt(nsq(rr.data() + (size_t)r * dim));
+  if (nthreads < 1) nthreads = 1;
+  std::atomic<uint32_t> next(0);
+  auto worker = [&]() {
+    std::vector<std::pair<float, uint64_t>> sc(nrows);
+    for (;;) {
+      uint32_t qi = next.fetch_add(1);
+      if (qi >= nq) break;
+      const float* q = qq.data() + (size_t)qi * dim;
+      const float qn = std::sqrt(nsq(q));
+      for (uint64_t r = 0; r < nrows; r++) {
+        const float* v = rr.data() + (size_t)r * dim;
+        float dot = 0.f;
+        for (uint32_t i = 0; i < dim; i++) dot += q[i] * v[i];
+        float s = dot;
+        if (metric == VO_COSINE) {
+          const float eps = std::numeric_limits<float>::epsilon();
+          s = (qn < eps || rn[r] < eps) ? 0.0f : dot / (qn * rn[r]);
+        }
+        sc[r] = {s, r};
+      }
+      const size_t kk = std::min<size_t>(k, nrows);
+      std::partial_sort(sc.begin(), sc.begin() + kk, sc.end(), [](const auto& a, const auto& b) {
+        int c = total_cmp(b.first, a.first);
+        return c ? c < 0 : a.second < b.second;
+      });
+      for (size_t i = 0; i < kk; i++) {
+        out_rows[(size_t)qi * k + i] = sc[i].second;
+        out_scores[(size_t)qi * k + i] = sc[i].first;
+      }
+    }
+  };
+  if (nthreads == 1) {
+    worker();
+  } else {
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nthreads; t++) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+  }
+}
+
 int vo_cpu_has_avx512f(void) { return __builtin_cpu_supports("avx512f") ? 1 : 0; }
 const char* vo_build_info(void) {
 #if VO_HAVE_AVX2

@@ -167,6 +167,12 @@ void vo_scan_topk(int metric, int mode, const float* rows, uint64_t nrows, uint3
                   const float* queries, uint32_t nq, uint32_t k, uint32_t nthreads,
                   uint64_t* out_rows, float* out_scores);
 
+/* half_precision.rs BF16 path: exact scan over bf16-rounded rows/queries, f32 sequential accumulation
+ * (metric: VO_COSINE or VO_DOT); canonical tie order; out arrays are [nq][k] */
+void vo_round_bf16(const float* in, float* out, uint64_t n);
+void vo_scan_topk_bf16(int metric, const float* rows, uint64_t nrows, uint32_t dim, const float* queries,
+                       uint32_t nq, uint32_t k, uint32_t nthreads, uint64_t* out_rows, float* out_scores);
+
 int vo_cpu_has_avx512f(void);
 const char* vo_build_info(void);
 

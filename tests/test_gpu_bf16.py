@@ -1,0 +1,81 @@
+"""GPU parity test of the bf16 GEMM-distance sweep (BASELINE configs[3]; reference semantics: half_precision.rs:199-255 —
+bf16-rounded vectors, f32 accumulation).  The matrix-core instruction adds its 32 exact products in an undocumented
+order, so the bar is the tolerance the north star states for f32 (1e-5 relative; here absolute on the cosine, and
+relative to |q||v| for the dot product), with the tie-aware id rule of SURVEY.md §8(c): ids and ranks must agree with
+the oracle wherever neighbouring oracle scores are further apart than the tolerance."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+va = pytest.importorskip("velesdb_amd")
+DM = va.DistanceMetric
+
+
+def check(metric, pm, rows, qs, k, gids, gsc, gcnt):
+    eid, esc = po.scan_topk_bf16(pm, rows, qs, k, nthreads=4)
+    rr, qq = po.round_bf16(rows).astype(np.float64), po.round_bf16(qs).astype(np.float64)
+    full = qq @ rr.T
+    scale = np.ones_like(full)
+    if metric == DM.Cosine:
+        full = full / (np.linalg.norm(qq, axis=1)[:, None] * np.linalg.norm(rr, axis=1)[None, :])
+    else:
+        scale = np.linalg.norm(qq, axis=1)[:, None] * np.linalg.norm(rr, axis=1)[None, :]
+    tol = 1e-5
+    for qi in range(qs.shape[0]):
+        kk = min(k, rows.shape[0])
+        assert gcnt[qi] == kk
+        g_i, g_s = gids[qi, :kk].astype(np.int64), gsc[qi, :kk].astype(np.float64)
+        # every returned score is the true (f64) score of that row within tolerance, and close to the f32 oracle's
+        assert np.all(np.abs(g_s - full[qi, g_i]) <= tol * scale[qi, g_i])
+        # best first
+        assert np.all(np.diff(g_s) <= 1e-12)
+        # nothing better was missed: k-th returned >= k-th true - tol
+        kth_true = np.sort(full[qi])[::-1][kk - 1]
+        assert g_s[-1] >= kth_true - tol * scale[qi].max()
+        # tie-aware rank agreement with the f32 oracle
+        e_i, e_s = eid[qi, :kk].astype(np.int64), esc[qi, :kk].astype(np.float64)
+        for r in range(kk):
+            if g_i[r] != e_i[r]:
+                assert abs(e_s[r] - full[qi, g_i[r]]) <= 2 * tol * scale[qi, g_i[r]], (qi, r)
+
+
+@pytest.mark.parametrize("metric,pm", [(DM.Cosine, po.COSINE), (DM.DotProduct, po.DOT)])
+@pytest.mark.parametrize("n,dim", [(6000, 768), (3000, 256), (2000, 100), (500, 40), (40, 8)])
+def test_bf16_sweep_matches_half_precision_semantics(metric, pm, n, dim):
+    rng = np.random.default_rng(n + dim)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ix = va.HnswIndex(dim, metric)
+    ix.upload(np.arange(n), rows[: n // 2])
+    ix.enable_bf16()                       # converts what is there ...
+    ix.upload(np.arange(n // 2, n), rows[n // 2:])  # ... and what arrives later
+    for nq, k in [(1, 10), (20, 10), (70, 5), (100, 10), (3, 64)]:
+        qs = rng.standard_normal((nq, dim)).astype(np.float32)
+        gi, gs, gc = ix.search_batch_brute_force_bf16(qs, k)
+        check(metric, pm, rows, qs, k, gi, gs, gc)
+    ix.close()
+
+
+def test_bf16_needs_enable_and_metric():
+    ix = va.HnswIndex(16, DM.Cosine)
+    ix.upload(np.arange(10), np.ones((10, 16), np.float32))
+    with pytest.raises(va.VelesHipError):
+        ix.search_batch_brute_force_bf16(np.ones((1, 16), np.float32), 3)
+    e = va.HnswIndex(16, DM.Euclidean)
+    with pytest.raises(va.VelesHipError):
+        e.enable_bf16()
+
+
+def test_bf16_exact_values_are_exact():
+    # values representable in bf16 with small integer products: every partial sum is exact, so the scores must be too
+    rng = np.random.default_rng(5)
+    rows = rng.integers(-4, 5, size=(1000, 64)).astype(np.float32)
+    qs = rng.integers(-4, 5, size=(33, 64)).astype(np.float32)
+    ix = va.HnswIndex(64, DM.DotProduct)
+    ix.upload(np.arange(1000), rows)
+    ix.enable_bf16()
+    gi, gs, gc = ix.search_batch_brute_force_bf16(qs, 10)
+    eid, esc = po.scan_topk_bf16(po.DOT, rows, qs, 10)
+    assert np.array_equal(gi, eid) and np.array_equal(gs, esc)

@@ -81,6 +81,9 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
     return fail(VDB_ERR_OOM, std::string("grow norms: ") + hipGetErrorString(e));
   if (is_bits_metric(ix->metric) && (e = ix->bits.reserve(ncap * ix->words * 4, true, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("grow bits: ") + hipGetErrorString(e));
+  if (ix->bf16_enabled && ((e = ix->rows_bf16.reserve(ncap * ix->bf16_stride * 2, true, st)) != hipSuccess ||
+                           (e = ix->norms_bf16.reserve(ncap * 4, true, st)) != hipSuccess))
+    return fail(VDB_ERR_OOM, std::string("grow bf16 rows: ") + hipGetErrorString(e));
   for (auto& L : ix->layers) {
     if ((e = L.nbr.reserve(ncap * L.stride * 4, true, st)) != hipSuccess ||
         (e = L.cnt.reserve(ncap * 4, true, st)) != hipSuccess ||
@@ -106,6 +109,63 @@ static int32_t finish_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
   pa.dim = ix->dim;
   pa.words = ix->words;
   if (pa.norms || pa.bits) launch_prep_rows(pa, ix->stream);
+  if (ix->bf16_enabled) {
+    launch_prep_bf16(ix->rows.as<float>(), ix->row_stride, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride,
+                     ix->norms_bf16.as<float>(), (uint32_t)first, (uint32_t)n, ix->dim, ix->stream);
+    ix->bf16_rows = first + n;
+  }
+  VDB_HIP(hipGetLastError());
+  return VDB_OK;
+}
+
+// exact sweep over the bf16 copy of the rows: half_precision::dot_product / cosine_similarity semantics
+// (half_precision.rs:199-255) for nq device-resident f32 queries (rounded to bf16 by the kernel)
+static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k,
+                              uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st) {
+  if (!ix->bf16_enabled) return fail(VDB_ERR_STATE, "bf16 sweep: call vdb_hip_index_enable_bf16 first");
+  if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT)
+    return fail(VDB_ERR_UNSUPPORTED, "bf16 sweep: Cosine and DotProduct only");
+  if (nq == 0) return VDB_OK;
+  if (k == 0 || ix->n_rows == 0) {
+    VDB_HIP(hipMemsetAsync(d_n, 0, (size_t)nq * 4, st));
+    return VDB_OK;
+  }
+  const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
+  for (uint32_t q0 = 0; q0 < nq;) {
+    const uint32_t rem = nq - q0;
+    int nqt = rem > 64 ? 6 : (rem > 32 ? 4 : (rem > 16 ? 2 : 1));
+    while (nqt > 1 && sweep_bf16_lds_bytes(nqt, k, ix->dim) > 160 * 1024) nqt = nqt == 6 ? 4 : nqt / 2;
+    if (sweep_bf16_lds_bytes(nqt, k, ix->dim) > 160 * 1024)
+      return fail(VDB_ERR_UNSUPPORTED, "bf16 sweep: dim / k too large for the LDS query tile");
+    const uint32_t Bq = (uint32_t)nqt * 16;
+    const uint32_t tile = std::min<uint32_t>(Bq, rem);
+    const int waves = nqt >= 4 ? kBf16WavesBig : kBf16WavesSmall;
+    const size_t lds = sweep_bf16_lds_bytes(nqt, k, ix->dim);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, (size_t)(16 / waves)));
+    const uint32_t ntiles = (uint32_t)((ix->n_rows + 15) / 16);
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ntiles + waves - 1) / waves,
+                                                                 (int64_t)ix->n_cus * per_cu));
+    hipError_t e;
+    if ((e = ix->s_part_keys.reserve((size_t)Bq * blocks * k * 8, false, st)) != hipSuccess)
+      return fail(VDB_ERR_OOM, "top-k scratch");
+    EventPair* ev = next_events(ix);
+    if (ev) (void)hipEventRecord(ev->a, st);
+    e = launch_sweep_bf16(ix->metric, nqt, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride, ix->norms_bf16.as<float>(),
+                          alive, d_q + (size_t)q0 * q_stride, q_stride, ix->s_part_keys.as<uint64_t>(),
+                          (uint32_t)ix->n_rows, ix->dim, tile, k, blocks, st);
+    if (ev) (void)hipEventRecord(ev->b, st);
+    if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("bf16 sweep launch: ") + hipGetErrorString(e));
+    MergeArgs m{};
+    m.part_keys = ix->s_part_keys.as<uint64_t>();
+    m.ext_ids = ix->ext_ids.as<uint64_t>();
+    m.out_ids = d_ids + (size_t)q0 * k;
+    m.out_scores = d_scores + (size_t)q0 * k;
+    m.out_n = d_n + q0;
+    m.n_lists = (uint32_t)blocks;
+    m.k = k;
+    launch_merge(true, m, tile, st);
+    q0 += tile;
+  }
   VDB_HIP(hipGetLastError());
   return VDB_OK;
 }
@@ -386,6 +446,7 @@ static int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride
     return VDB_OK;
   }
   if (mode == VDB_SEARCH_BRUTE) return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
+  if (mode == VDB_SEARCH_BRUTE_BF16) return brute_bf16_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
   if (mode == VDB_SEARCH_AUTO && ix->live <= 100 && ix->n_rows > 0)  // search.rs:75-77
     return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
   if (mode != VDB_SEARCH_AUTO && mode != VDB_SEARCH_HNSW) return fail(VDB_ERR_INVALID_ARG, "bad search mode");
@@ -482,7 +543,7 @@ void vdb_hip_index_destroy(vdb_hip_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   (void)hipStreamSynchronize(ix->stream);
-  for (DevBuf* b : {&ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids, &ix->s_queries, &ix->s_part_keys,
+  for (DevBuf* b : {&ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids, &ix->rows_bf16, &ix->norms_bf16, &ix->s_queries, &ix->s_part_keys,
                     &ix->s_part_cnt, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels,
                     &ix->s_req_keys, &ix->s_req_vals, &ix->s_sort_tmp})
     b->release();
@@ -545,6 +606,31 @@ int32_t vdb_hip_index_insert_batch_parallel(vdb_hip_index* ix, const uint64_t* i
   if (rc != VDB_OK) return rc;
   if (ins && ix->graph_valid) rc = graph_insert_rows(ix, first, ins, max_batch);
   return rc;
+}
+
+// keeps a bf16 copy of the rows (round to nearest even) for VDB_SEARCH_BRUTE_BF16; existing rows are converted now,
+// later inserts / uploads as they arrive
+int32_t vdb_hip_index_enable_bf16(vdb_hip_index* ix) {
+  if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  if (ix->bf16_enabled) return VDB_OK;
+  if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT)
+    return fail(VDB_ERR_UNSUPPORTED, "bf16 sweep: Cosine and DotProduct only");
+  VDB_HIP(hipSetDevice(ix->device));
+  ix->bf16_stride = ((uint64_t)ix->dim + 7) / 8 * 8;
+  hipError_t e;
+  if ((e = ix->rows_bf16.reserve(std::max<uint64_t>(ix->capacity, 1) * ix->bf16_stride * 2, false, ix->stream)) != hipSuccess ||
+      (e = ix->norms_bf16.reserve(std::max<uint64_t>(ix->capacity, 1) * 4, false, ix->stream)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("bf16 rows: ") + hipGetErrorString(e));
+  ix->bf16_enabled = true;
+  if (ix->n_rows) {
+    launch_prep_bf16(ix->rows.as<float>(), ix->row_stride, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride,
+                     ix->norms_bf16.as<float>(), 0, (uint32_t)ix->n_rows, ix->dim, ix->stream);
+    VDB_HIP(hipGetLastError());
+    VDB_HIP(hipStreamSynchronize(ix->stream));
+  }
+  ix->bf16_rows = ix->n_rows;
+  return VDB_OK;
 }
 
 // links every row that is not in the graph yet (rows that arrived through upload / upload_dev)

@@ -15,6 +15,8 @@
 //   * the 4 waves of a block fold their lists in LDS; one k-list per block goes to HBM and a
 //     one-block-per-query merge kernel finishes (same threshold + insert scheme).
 // Algorithmic HBM bytes per launch: n_rows * dim * 4 (+ 4 B/row of norms for cosine).
+#include <algorithm>
+
 #include "vdb_device.hpp"
 #include "vdb_kernels.hpp"
 
@@ -560,6 +562,226 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sweep_topk_mfma_f32(SweepArgs a
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 GEMM-distance sweep (BASELINE configs[3]: 10 M x 768 bf16, 1024 queries per batch): the corpus is kept as
+// bf16 (round-to-nearest-even of the f32 rows, half the HBM bytes), the query tile is rounded the same way, and
+// rows x queries is a true bf16 contraction on the matrix cores with f32 accumulation
+// (v_mfma_f32_16x16x32_bf16) — the semantics of the reference's half_precision::dot_product /
+// cosine_similarity on VectorData::BF16 (half_precision.rs:199-255: f32 accumulate over the bf16 values).
+// Same structure as sweep_topk_mfma_f32: a wave owns 16 rows x NQT*16 queries; lane (i = l&15, kk = l>>4)
+// reads 8 bf16 = 16 B per load, the four kk lanes 64 contiguous bytes of row i, eight loads 512 B (a macro
+// step of 256 k-values); query fragments in LDS in operand order.  One MFMA retires 32 k-values, so the kernel
+// is HBM-bound up to ~100 queries per pass: NQT = 6 (96 queries, 144 KiB of LDS) is the large tile.
+// Products of bf16 values are exact in f32; the order in which one instruction adds its 32 products is not
+// documented, so parity with the oracle is by tolerance (tests), not bit for bit.
+// LDS: q fragments KU*NQT*8 KiB | lists[B][k] u64 | cnt[B] | lock[B] | qnorm[B].
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x0040u);  // NaN stays NaN (quiet)
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// rows f32 -> bf16 copy + norm of the ROUNDED row (canonical lane-chain order over the rounded values)
+__global__ __launch_bounds__(256) void prep_bf16_rows(const float* rows, uint64_t row_stride, uint16_t* out,
+                                                      uint64_t out_stride, float* norms, uint32_t row0, uint32_t n_rows,
+                                                      uint32_t dim) {
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4;
+  for (uint32_t r = wave; r < n_rows; r += nwaves) {
+    const uint32_t row = row0 + r;
+    const float* p = rows + (size_t)row * row_stride;
+    uint16_t* o = out + (size_t)row * out_stride;
+    float acc = 0.0f;
+    for (uint32_t c = lane; c * 4 < out_stride; c += 64) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const uint32_t i = c * 4 + e;
+        if (i < out_stride) {
+          const uint16_t h = i < dim ? f32_to_bf16_rne(p[i]) : (uint16_t)0;
+          o[i] = h;
+          if (i < dim) {
+            const float x = bf16_to_f32(h);
+            acc = __builtin_fmaf(x, x, acc);
+          }
+        }
+      }
+    }
+    const float n = sqrtf(butterfly_all(acc));
+    if (lane == 0 && norms) norms[row] = n;
+  }
+}
+
+struct Bf16SweepArgs {
+  const uint16_t* rows;   // [n_rows][row_stride] bf16, row_stride % 8 == 0
+  const float* norms;     // norm of the rounded rows (cosine)
+  const uint8_t* alive;
+  const float* queries;   // f32, rounded to bf16 while staging
+  uint64_t* part_keys;
+  uint64_t row_stride, q_stride;
+  uint32_t n_rows, dim, nq, k, KU;
+};
+
+template <int METRIC, int NQT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 16 ? 4 : 2)) void sweep_topk_mfma_bf16(Bf16SweepArgs a) {
+  constexpr int B = NQT * 16;
+  constexpr bool HIB = true;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t wave = blockIdx.x * WAVES + wib;
+  const uint32_t nwaves = gridDim.x * WAVES;
+  const uint32_t k = a.k, KU = a.KU;
+  uint16_t* qs = reinterpret_cast<uint16_t*>(smem);
+  const size_t qbytes = (size_t)KU * NQT * 8192;
+  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(smem + qbytes);
+  volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(smem + qbytes + (size_t)B * k * 8);
+  uint32_t* locks = reinterpret_cast<uint32_t*>(smem + qbytes + (size_t)B * k * 8 + (size_t)B * 4);
+  float* qn = reinterpret_cast<float*>(smem + qbytes + (size_t)B * k * 8 + (size_t)B * 8);
+
+  for (uint32_t i = threadIdx.x; i < KU * NQT * 2048; i += WAVES * 64) reinterpret_cast<uint32_t*>(qs)[i] = 0u;
+  if (threadIdx.x < B) {
+    cnts[threadIdx.x] = 0;
+    locks[threadIdx.x] = 0;
+    qn[threadIdx.x] = 0.0f;
+  }
+  __syncthreads();
+  // fragment order: slot ((U*NQT + t)*8 + m)*64 + (kk*16 + j) holds q[j][256U + 32m + 8kk + 0..7]
+  for (uint32_t idx = threadIdx.x; idx < (uint32_t)B * a.dim; idx += WAVES * 64) {
+    const uint32_t b = idx / a.dim, kx = idx % a.dim;
+    if (b < a.nq) {
+      const uint32_t t = b >> 4, j = b & 15, U = kx >> 8, m = (kx >> 5) & 7, kk = (kx >> 3) & 3, e = kx & 7;
+      qs[((((size_t)U * NQT + t) * 8 + m) * 64 + kk * 16 + j) * 8 + e] = f32_to_bf16_rne(a.queries[(size_t)b * a.q_stride + kx]);
+    }
+  }
+  if (METRIC == kCosine) {  // norm of the ROUNDED query, canonical lane-chain order
+    for (uint32_t b = wib; b < (uint32_t)B && b < a.nq; b += WAVES) {
+      const float* qp = a.queries + (size_t)b * a.q_stride;
+      float nacc = 0.0f;
+      for (uint32_t c = lane; c * 4 < a.dim; c += 64)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const uint32_t i = c * 4 + e;
+          if (i < a.dim) {
+            const float x = bf16_to_f32(f32_to_bf16_rne(qp[i]));
+            nacc = __builtin_fmaf(x, x, nacc);
+          }
+        }
+      const float n = sqrtf(butterfly_all(nacc));
+      if (lane == 0) qn[b] = n;
+    }
+  }
+  __syncthreads();
+  float qn_t[NQT];
+#pragma unroll
+  for (int t = 0; t < NQT; t++) qn_t[t] = qn[t * 16 + (lane & 15)];
+
+  const uint32_t kk8 = (uint32_t)(lane >> 4) * 8;  // element offset of this lane inside every 32-element load group
+  const uint32_t ntiles = (a.n_rows + 15) / 16;
+  auto row_ptr = [&](uint32_t g) -> const uint16_t* {
+    uint32_t row = g * 16 + (lane & 15);
+    row = row < a.n_rows ? row : a.n_rows - 1;
+    return a.rows + (size_t)row * a.row_stride + kk8;
+  };
+  auto load_a = [&](const uint16_t* rp, uint32_t U, uint4(&dst)[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const uint32_t k0 = U * 256 + m * 32 + kk8;
+      if (k0 < (uint32_t)a.row_stride)
+        dst[m] = *reinterpret_cast<const uint4*>(rp + (size_t)U * 256 + m * 32);
+      else
+        dst[m] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  uint4 A0[8], A1[8];
+  if (wave < ntiles) load_a(row_ptr(wave), 0, A0);
+  for (uint32_t g = wave; g < ntiles; g += nwaves) {
+    const uint16_t* rp = row_ptr(g);
+    const uint32_t gnext = g + nwaves < ntiles ? g + nwaves : g;
+    const uint16_t* rpn = row_ptr(gnext);
+    float vn[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t row = g * 16 + 4 * (lane >> 4) + r;
+      vn[r] = (METRIC == kCosine) ? a.norms[row < a.n_rows ? row : a.n_rows - 1] : 1.0f;
+    }
+    f32x4 acc[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](uint32_t U, const uint4(&av)[8]) {
+      const uint16_t* qb = qs + ((size_t)U * NQT * 8 * 64 + lane) * 8;
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const bf16x8 afrag = __builtin_bit_cast(bf16x8, av[m]);
+#pragma unroll
+        for (int t = 0; t < NQT; t++) {
+          const uint4 bu = *reinterpret_cast<const uint4*>(qb + (size_t)(t * 8 + m) * 512);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag, __builtin_bit_cast(bf16x8, bu), acc[t], 0, 0, 0);
+        }
+      }
+    };
+    for (uint32_t U = 0; U < KU; U += 2) {
+      if (U + 1 < KU) load_a(rp, U + 1, A1); else load_a(rpn, 0, A1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(U, A0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (U + 1 < KU) {
+        if (U + 2 < KU) load_a(rp, U + 2, A0); else load_a(rpn, 0, A0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(U + 1, A1);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+#pragma unroll
+        for (int m = 0; m < 8; m++) A0[m] = A1[m];
+      }
+    }
+    float tau_f[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; t++) {
+      const uint32_t b = t * 16 + (lane & 15);
+      tau_f[t] = (cnts[b] == k) ? key_score<HIB>(lists[(size_t)b * k + (k - 1)]) : __uint_as_float(0xFF800000u);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t row = g * 16 + 4 * (lane >> 4) + r;
+#pragma unroll
+      for (int t = 0; t < NQT; t++) {
+        const uint32_t b = t * 16 + (lane & 15);
+        const float dotv = acc[t][r];
+        const float rq = (METRIC == kCosine) ? __builtin_amdgcn_rcpf(qn_t[t] * vn[r]) : 1.0f;
+        const float approx = dotv * rq;
+        const float margin = fabsf(tau_f[t]) * 1.9073486e-6f + 1e-37f;
+        const bool maybe = !(approx < tau_f[t] - margin) && row < a.n_rows && b < a.nq;
+        uint64_t mask = __ballot(maybe);
+        if (mask == 0) continue;
+        const float score = finish_score<METRIC>(dotv, qn_t[t], vn[r]);
+        const uint64_t key = maybe ? make_key<HIB>(score, row) : kKeyInvalid;
+        const uint64_t tau = (cnts[b] == k) ? lists[(size_t)b * k + (k - 1)] : kKeyInvalid;
+        mask = __ballot(key < tau);
+        while (mask) {
+          const int src = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const uint64_t kk = readlane64(key, src);
+          if (a.alive && a.alive[key_row(kk)] == 0) continue;
+          const int bb = t * 16 + (src & 15);
+          shared_list_offer(lists + (size_t)bb * k, cnts + bb, locks + bb, k, kk, lane);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int b = wib; b < (int)a.nq && b < B; b += WAVES) {
+    const uint32_t c = cnts[b];
+    uint64_t* out = a.part_keys + ((size_t)b * gridDim.x + blockIdx.x) * k;
+    for (uint32_t e = lane; e < k; e += 64) out[e] = e < c ? lists[(size_t)b * k + e] : kKeyInvalid;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // merge: one wave per query scans the per-wave lists with the same threshold + insert scheme
 // and writes ids / scores best-first.
 // ------------------------------------------------------------------------------------------
@@ -944,6 +1166,51 @@ hipError_t launch_sweep_mfma(int metric, int nqt, const SweepArgs& a, int blocks
   if (nqt == 3) return launch_mfma_t<kDot, 3, kMfmaWaves2>(a, blocks, lds, st);
   if (nqt == 2) return launch_mfma_t<kDot, 2, kMfmaWaves2>(a, blocks, lds, st);
   return launch_mfma_t<kDot, 1, kMfmaWaves1>(a, blocks, lds, st);
+}
+
+// ---- bf16 launchers --------------------------------------------------------------------------
+size_t sweep_bf16_lds_bytes(int nqt, uint32_t k, uint32_t dim) {
+  const size_t KU = (dim + 255) / 256, B = (size_t)nqt * 16;
+  return ((KU * nqt * 8192 + B * k * 8 + B * 12) + 15) & ~(size_t)15;
+}
+void launch_prep_bf16(const float* rows, uint64_t row_stride, uint16_t* out, uint64_t out_stride, float* norms,
+                      uint32_t row0, uint32_t n_rows, uint32_t dim, hipStream_t st) {
+  if (n_rows == 0) return;
+  const int blocks = (int)std::min<uint64_t>(((uint64_t)n_rows + 3) / 4, 4096);
+  hipLaunchKernelGGL(prep_bf16_rows, dim3(blocks), dim3(256), 0, st, rows, row_stride, out, out_stride, norms, row0,
+                     n_rows, dim);
+}
+template <int METRIC, int NQT, int WAVES>
+static hipError_t launch_bf16_t(const Bf16SweepArgs& a, int blocks, size_t lds, hipStream_t st) {
+  static bool done = false;
+  if (lds > 64 * 1024 && !done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_mfma_bf16<METRIC, NQT, WAVES>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  hipLaunchKernelGGL((sweep_topk_mfma_bf16<METRIC, NQT, WAVES>), dim3(blocks), dim3(WAVES * 64), lds, st, a);
+  return hipGetLastError();
+}
+hipError_t launch_sweep_bf16(int metric, int nqt, const uint16_t* rows, uint64_t row_stride, const float* norms,
+                             const uint8_t* alive, const float* queries, uint64_t q_stride, uint64_t* part_keys,
+                             uint32_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int blocks, hipStream_t st) {
+  Bf16SweepArgs a{rows, norms, alive, queries, part_keys, row_stride, q_stride, n_rows, dim, nq, k, (dim + 255) / 256};
+  const size_t lds = sweep_bf16_lds_bytes(nqt, k, dim);
+  if (metric == kCosine) {
+    switch (nqt) {
+      case 6: return launch_bf16_t<kCosine, 6, kBf16WavesBig>(a, blocks, lds, st);
+      case 4: return launch_bf16_t<kCosine, 4, kBf16WavesBig>(a, blocks, lds, st);
+      case 2: return launch_bf16_t<kCosine, 2, kBf16WavesSmall>(a, blocks, lds, st);
+      default: return launch_bf16_t<kCosine, 1, kBf16WavesSmall>(a, blocks, lds, st);
+    }
+  }
+  switch (nqt) {
+    case 6: return launch_bf16_t<kDot, 6, kBf16WavesBig>(a, blocks, lds, st);
+    case 4: return launch_bf16_t<kDot, 4, kBf16WavesBig>(a, blocks, lds, st);
+    case 2: return launch_bf16_t<kDot, 2, kBf16WavesSmall>(a, blocks, lds, st);
+    default: return launch_bf16_t<kDot, 1, kBf16WavesSmall>(a, blocks, lds, st);
+  }
 }
 
 void launch_merge(bool hib, const MergeArgs& m, uint32_t nq, hipStream_t st) {

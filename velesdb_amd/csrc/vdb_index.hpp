@@ -66,6 +66,11 @@ struct vdb_hip_index {
   hipStream_t stream = nullptr;
 
   vdb::DevBuf rows, norms, bits, alive, ext_ids;
+  // optional bf16 copy of the rows for the GEMM-distance sweep (vdb_hip_index_enable_bf16)
+  vdb::DevBuf rows_bf16, norms_bf16;
+  bool bf16_enabled = false;
+  uint64_t bf16_stride = 0;  // bf16 elements per row (multiple of 8)
+  uint64_t bf16_rows = 0;    // rows converted so far
   // graph
   std::vector<vdb::GraphLayer> layers;
   bool graph_valid = true;   // false once rows exist that are not linked into the graph

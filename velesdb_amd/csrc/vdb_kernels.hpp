@@ -115,6 +115,15 @@ constexpr int kMfmaWaves1 = 8;   // waves per block for one 16-query tile
 constexpr int kMfmaWaves2 = 16;  // ... for two tiles (the 96 KiB query fragments fill most of the LDS)
 size_t sweep_mfma_lds_bytes(int nqt, uint32_t k, uint32_t dim);
 hipError_t launch_sweep_mfma(int metric, int nqt, const SweepArgs& a, int blocks, hipStream_t st);
+// bf16 GEMM-distance sweep (cosine / dot over a bf16 copy of the rows): nqt in {1, 2, 4, 6} 16-query tiles
+constexpr int kBf16WavesBig = 8;     // waves per block for nqt >= 4 (<= 256 VGPRs each, one block per CU)
+constexpr int kBf16WavesSmall = 8;   // ... for nqt <= 2
+size_t sweep_bf16_lds_bytes(int nqt, uint32_t k, uint32_t dim);
+void launch_prep_bf16(const float* rows, uint64_t row_stride, uint16_t* out, uint64_t out_stride, float* norms,
+                      uint32_t row0, uint32_t n_rows, uint32_t dim, hipStream_t st);
+hipError_t launch_sweep_bf16(int metric, int nqt, const uint16_t* rows, uint64_t row_stride, const float* norms,
+                             const uint8_t* alive, const float* queries, uint64_t q_stride, uint64_t* part_keys,
+                             uint32_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int blocks, hipStream_t st);
 void launch_merge(bool higher_is_better, const MergeArgs& m, uint32_t nq, hipStream_t st);
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st);
 void launch_prep_rows(const PrepArgs& a, hipStream_t st);

@@ -19,7 +19,7 @@ from . import _ffi
 from ._ffi import check, lib
 from .params import DistanceMetric, HnswParams, SearchQuality
 
-MODE_AUTO, MODE_BRUTE, MODE_HNSW = 0, 1, 2
+MODE_AUTO, MODE_BRUTE, MODE_HNSW, MODE_BRUTE_BF16 = 0, 1, 2, 3
 KIND_ENGINE, KIND_RAW = 0, 1
 
 
@@ -199,6 +199,19 @@ class HnswIndex:
         cnt = np.zeros(1, dtype=np.uint32)
         check(lib().vdb_hip_index_search_rerank(self._h, _ptr(q), 1, k, rerank_k, ef, _ptr(ids), _ptr(sc), _ptr(cnt)))
         return self._tuples(ids[0], sc[0], cnt[0])
+
+    def enable_bf16(self) -> None:
+        """Keeps a bf16 (round-to-nearest-even) copy of the rows for search_batch_brute_force_bf16."""
+        check(lib().vdb_hip_index_enable_bf16(self._h))
+
+    def search_batch_brute_force_bf16(self, queries, k: int):
+        """Exact scan with bf16 rows and queries, f32 accumulation on the matrix cores
+        (half_precision.rs:199-255 semantics); numpy outputs like search_batch_brute_force."""
+        qs = _f32(queries)
+        if qs.ndim == 1:
+            qs = qs.reshape(1, -1)
+        self._validate(qs)
+        return self._search_raw(qs, k, 0, MODE_BRUTE_BF16)
 
     def search_batch_brute_force(self, queries, k: int):
         """Batched exact search (one corpus pass per tile of queries); numpy outputs."""
