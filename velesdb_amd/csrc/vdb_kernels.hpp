@@ -116,7 +116,7 @@ constexpr int kMfmaWaves2 = 16;  // ... for two tiles (the 96 KiB query fragment
 size_t sweep_mfma_lds_bytes(int nqt, uint32_t k, uint32_t dim);
 hipError_t launch_sweep_mfma(int metric, int nqt, const SweepArgs& a, int blocks, hipStream_t st);
 // bf16 GEMM-distance sweep (cosine / dot over a bf16 copy of the rows): nqt in {1, 2, 4, 6} 16-query tiles
-constexpr int kBf16WavesBig = 8;     // waves per block for nqt >= 4 (<= 256 VGPRs each, one block per CU)
+constexpr int kBf16WavesBig = 16;    // waves per block for nqt >= 4 (one block per CU)
 constexpr int kBf16WavesSmall = 8;   // ... for nqt <= 2
 size_t sweep_bf16_lds_bytes(int nqt, uint32_t k, uint32_t dim);
 void launch_prep_bf16(const float* rows, uint64_t row_stride, uint16_t* out, uint64_t out_stride, float* norms,
