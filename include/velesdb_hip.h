@@ -65,6 +65,10 @@ enum vdb_search_mode {
   VDB_SEARCH_BRUTE = 1, /* HnswIndex::search_brute_force (search.rs:176-219): exact scan, raw
                            similarity/distance scores, metric.sort_results order             */
   VDB_SEARCH_HNSW = 2,  /* always the graph (search_batch_parallel, batch.rs:180-194)        */
+  VDB_SEARCH_HNSW_INT8 = 4, /* DualPrecisionHnsw::search_with_config(use_int8_traversal) (native/dual_precision.rs:
+                           223-441): the graph is walked with integer L2^2 distances between u8 codes (4x fewer bytes
+                           per visited node), the k * oversampling best are re-scored with the exact f32 distance.
+                           `ef` = ef_search; needs vdb_hip_index_train_quantizer.  Scores as in VDB_SEARCH_HNSW. */
   VDB_SEARCH_BRUTE_BF16 = 3 /* exact scan over the bf16 copy of the rows with bf16-rounded queries and f32
                            accumulation on the matrix cores: half_precision::dot_product / cosine_similarity on
                            VectorData::BF16 (half_precision.rs:199-255).  Cosine / DotProduct only; needs
@@ -105,6 +109,11 @@ int32_t vdb_hip_index_insert_batch(vdb_hip_index* idx, const uint64_t* ids, cons
  * default 2048; 1 = identical to insert_batch). */
 int32_t vdb_hip_index_insert_batch_parallel(vdb_hip_index* idx, const uint64_t* ids, const float* vecs_rowmajor,
                                             uint64_t n, uint32_t max_batch, uint64_t* inserted);
+/* ScalarQuantizer::train (native/quantization.rs:191-233) on the first sample_rows rows (0 = min(1000, rows), what
+ * DualPrecisionHnsw uses) + u8 codes for every present and future row (+1 byte per element of HBM). */
+int32_t vdb_hip_index_train_quantizer(vdb_hip_index* idx, uint32_t sample_rows);
+/* DualPrecisionConfig::oversampling_ratio (default 4) of VDB_SEARCH_HNSW_INT8, process-wide */
+int32_t vdb_hip_set_int8_oversampling(uint32_t ratio);
 /* keeps a bf16 copy (round to nearest even, VectorData::from_f32_slice(.., BF16), half_precision.rs:94-101) of every
  * row next to the f32 rows, for VDB_SEARCH_BRUTE_BF16; +2 bytes per element of HBM */
 int32_t vdb_hip_index_enable_bf16(vdb_hip_index* idx);

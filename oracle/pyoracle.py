@@ -128,6 +128,12 @@ def _declare(L):
     L.vo_scan_topk.restype = None
     L.vo_scan_topk.argtypes = [C.c_int, C.c_int, _f32p, C.c_uint64, C.c_uint32, _f32p, C.c_uint32, C.c_uint32,
                                C.c_uint32, _u64p, _f32p]
+    _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+    L.vo_sq_train.restype, L.vo_sq_train.argtypes = None, [_f32p, C.c_uint64, C.c_uint32, _f32p, _f32p, _f32p]
+    L.vo_sq_quantize.restype, L.vo_sq_quantize.argtypes = None, [_f32p, C.c_uint64, C.c_uint32, _f32p, _f32p, _u8p]
+    L.vo_dual_search_int8.restype = C.c_uint32
+    L.vo_dual_search_int8.argtypes = [vp, _u8p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _u64p,
+                                      _f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.vo_round_bf16.restype, L.vo_round_bf16.argtypes = None, [_f32p, _f32p, C.c_uint64]
     L.vo_scan_topk_bf16.restype = None
     L.vo_scan_topk_bf16.argtypes = [C.c_int, _f32p, C.c_uint64, C.c_uint32, _f32p, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -273,6 +279,35 @@ def scan_topk(metric, rows, queries, k, mode=MODE_R, nthreads=1):
     sc = np.empty((nq, k), dtype=np.float32)
     lib().vo_scan_topk(metric, mode, rows, rows.shape[0], rows.shape[1], queries, nq, k, nthreads, ids, sc)
     return ids, sc
+
+
+class ScalarQuantizer:
+    """quantization.rs:191-260 — trained on `train_rows`, then used to encode any rows"""
+
+    def __init__(self, train_rows):
+        t = _f(train_rows)
+        self.dim = t.shape[1]
+        self.min_vals = np.empty(self.dim, np.float32)
+        self.scales = np.empty(self.dim, np.float32)
+        self.inv_scales = np.empty(self.dim, np.float32)
+        lib().vo_sq_train(t, t.shape[0], self.dim, self.min_vals, self.scales, self.inv_scales)
+
+    def quantize(self, rows):
+        r = _f(rows).reshape(-1, self.dim)
+        out = np.empty(r.shape, dtype=np.uint8)
+        lib().vo_sq_quantize(r, r.shape[0], self.dim, self.min_vals, self.scales, out)
+        return out
+
+
+def dual_search_int8(graph, sq, codes, q, k, ef, oversampling=4, tie=TIE_CANONICAL):
+    """DualPrecisionHnsw::search_with_config(use_int8_traversal=true) on `graph` (a NativeHnsw) ->
+    (nodes, exact engine distances, n_dist_int8, n_expand)"""
+    ids = np.empty(max(k, 1), dtype=np.uint64)
+    ds = np.empty(max(k, 1), dtype=np.float32)
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    n = lib().vo_dual_search_int8(graph._h, np.ascontiguousarray(codes, dtype=np.uint8), sq.min_vals, sq.scales, _f(q), k,
+                                  ef, oversampling, tie, ids, ds, C.byref(a), C.byref(b))
+    return ids[:n].copy(), ds[:n].copy(), int(a.value), int(b.value)
 
 
 def round_bf16(a):

@@ -1588,6 +1588,131 @@ void vo_scan_topk(int metric, int mode, const float* rows, uint64_t nrows, uint3
 }
 
 // ---------------------------------------------------------------------------
+// DualPrecisionHnsw — native/dual_precision.rs + native/quantization.rs: per-dimension scalar quantiser trained
+// on the first min(1000, n) inserted vectors (quantization.rs:191-233), u8 codes (:236-252, f32::round = half away
+// from zero), integer L2^2 between codes (:42-91), int8 graph traversal (dual_precision.rs:284-441) and exact f32
+// re-ranking of k * oversampling candidates (:253-282).
+// ---------------------------------------------------------------------------
+void vo_sq_train(const float* vecs, uint64_t n, uint32_t dim, float* min_vals, float* scales, float* inv_scales) {
+  std::vector<float> mx(dim, std::numeric_limits<float>::lowest());
+  for (uint32_t i = 0; i < dim; i++) min_vals[i] = std::numeric_limits<float>::max();
+  for (uint64_t r = 0; r < n; r++)
+    for (uint32_t i = 0; i < dim; i++) {
+      const float v = vecs[(size_t)r * dim + i];
+      min_vals[i] = std::fmin(min_vals[i], v);  // f32::min / f32::max: the non-NaN operand wins
+      mx[i] = std::fmax(mx[i], v);
+    }
+  for (uint32_t i = 0; i < dim; i++) {
+    const float range = mx[i] - min_vals[i];
+    scales[i] = std::fabs(range) < 1e-10f ? 1.0f : 255.0f / range;
+    inv_scales[i] = 1.0f / scales[i];
+  }
+}
+void vo_sq_quantize(const float* vecs, uint64_t n, uint32_t dim, const float* min_vals, const float* scales,
+                    uint8_t* codes) {
+  for (uint64_t r = 0; r < n; r++)
+    for (uint32_t i = 0; i < dim; i++) {
+      float q = std::round((vecs[(size_t)r * dim + i] - min_vals[i]) * scales[i]);
+      q = q < 0.0f ? 0.0f : (q > 255.0f ? 255.0f : q);  // clamp; NaN -> `as u8` saturating cast = 0
+      codes[(size_t)r * dim + i] = std::isnan(q) ? 0 : (uint8_t)q;
+    }
+}
+uint32_t vo_sq_l2(const uint8_t* a, const uint8_t* b, uint32_t dim) {
+  uint32_t s = 0;
+  for (uint32_t i = 0; i < dim; i++) {
+    const int32_t d = (int32_t)a[i] - (int32_t)b[i];
+    s += (uint32_t)(d * d);
+  }
+  return s;
+}
+// search_int8_traversal (dual_precision.rs:253-282) on graph g with the code store `codes` ([count][dim]).
+// Output: node ids + EXACT engine distances (inner.compute_distance), best first.
+uint32_t vo_dual_search_int8(const vo_hnsw* gp, const uint8_t* codes, const float* min_vals, const float* scales,
+                             const float* q, uint32_t k, uint32_t ef_search, uint32_t oversampling, int tie,
+                             uint64_t* out_nodes, float* out_dist, uint64_t* n_dist_int8, uint64_t* n_expand) {
+  const vo_hnsw& g = *gp;
+  const uint32_t dim = g.dim;
+  uint64_t nd = 0, ne = 0;
+  if (g.entry_point < 0) return 0;
+  std::vector<uint8_t> qc(dim);
+  vo_sq_quantize(q, 1, dim, min_vals, scales, qc.data());
+  auto dist = [&](uint64_t node) {
+    nd++;
+    return vo_sq_l2(qc.data(), codes + (size_t)node * dim, dim);
+  };
+  const size_t cand_k = (size_t)k * oversampling;
+  // greedy descent with int8 distances (:407-441)
+  uint64_t cur = (uint64_t)g.entry_point;
+  for (size_t l = g.max_layer; l >= 1; l--) {
+    uint64_t current = cur;
+    uint32_t current_dist = dist(current);
+    for (;;) {
+      const std::vector<uint64_t> nbs = g.nbrs(l, current);
+      bool improved = false;
+      for (uint64_t nb : nbs) {
+        const uint32_t d = dist(nb);
+        if (d < current_dist) {
+          current = nb;
+          current_dist = d;
+          improved = true;
+        }
+      }
+      if (!improved) break;
+    }
+    cur = current;
+  }
+  // layer 0 beam (:316-384)
+  struct IKey {
+    uint32_t d;
+    uint64_t node;
+    bool operator<(const IKey& o) const { return d != o.d ? d < o.d : node < o.node; }
+  };
+  std::vector<uint8_t> visited(g.vectors.size() / dim, 0);
+  std::vector<IKey> candidates, results;  // kept as sorted vectors: pops follow the (dist, node) total order
+  auto push_sorted = [](std::vector<IKey>& v, IKey x) { v.insert(std::upper_bound(v.begin(), v.end(), x), x); };
+  {
+    const uint32_t d = dist(cur);
+    push_sorted(candidates, {d, cur});
+    push_sorted(results, {d, cur});
+    visited[cur] = 1;
+  }
+  const size_t ef = std::max<size_t>(ef_search, cand_k);
+  while (!candidates.empty()) {
+    const IKey c = candidates.front();
+    candidates.erase(candidates.begin());
+    const uint32_t furthest = results.empty() ? UINT32_MAX : results.back().d;
+    if (c.d > furthest && results.size() >= ef) break;
+    ne++;
+    for (uint64_t nb : g.nbrs(0, c.node)) {
+      if (visited[nb]) continue;
+      visited[nb] = 1;
+      const uint32_t d = dist(nb);
+      const uint32_t far = results.empty() ? UINT32_MAX : results.back().d;
+      if (d < far || results.size() < ef) {
+        push_sorted(candidates, {d, nb});
+        push_sorted(results, {d, nb});
+        if (results.size() > ef) results.pop_back();
+      }
+    }
+  }
+  (void)tie;  // results is already in canonical (dist, node) order; the reference's order among equal integer
+              // distances is the heap artefact (into_iter + stable sort_by_key), not reproduced
+  if (results.size() > cand_k) results.resize(cand_k);
+  // exact re-ranking (:267-281): inner.compute_distance = DistanceEngine::distance, stable sort by total_cmp
+  std::vector<std::pair<uint64_t, float>> rr;
+  for (const IKey& c : results) rr.emplace_back(c.node, engine_distance(g.metric, g.mode, q, g.vec(c.node), dim));
+  std::stable_sort(rr.begin(), rr.end(), [](const auto& a, const auto& b) { return total_cmp(a.second, b.second) < 0; });
+  if (rr.size() > k) rr.resize(k);
+  for (size_t i = 0; i < rr.size(); i++) {
+    out_nodes[i] = rr[i].first;
+    out_dist[i] = rr[i].second;
+  }
+  if (n_dist_int8) *n_dist_int8 = nd;
+  if (n_expand) *n_expand = ne;
+  return (uint32_t)rr.size();
+}
+
+// ---------------------------------------------------------------------------
 // half_precision.rs — VectorData::BF16: `half::bf16::from_f32` (round to nearest even; NaN stays NaN),
 // dot_product (:199-233) = sequential f32 sum of x.to_f32() * y.to_f32(); cosine_similarity (:237-254) =
 // dot / (sqrt(norm_squared(a)) * sqrt(norm_squared(b))), 0.0 when a norm is below f32::EPSILON;

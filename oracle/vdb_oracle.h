@@ -167,6 +167,19 @@ void vo_scan_topk(int metric, int mode, const float* rows, uint64_t nrows, uint3
                   const float* queries, uint32_t nq, uint32_t k, uint32_t nthreads,
                   uint64_t* out_rows, float* out_scores);
 
+/* DualPrecisionHnsw (native/dual_precision.rs, native/quantization.rs): scalar quantiser, u8 codes, integer L2^2,
+ * int8 graph traversal + exact f32 re-rank.  vo_sq_train: per-dimension min / scale = 255/range / inv_scale over n
+ * vectors (the reference trains on the first min(1000, max_elements) inserts). */
+void vo_sq_train(const float* vecs, uint64_t n, uint32_t dim, float* min_vals, float* scales, float* inv_scales);
+void vo_sq_quantize(const float* vecs, uint64_t n, uint32_t dim, const float* min_vals, const float* scales,
+                    uint8_t* codes);
+uint32_t vo_sq_l2(const uint8_t* a, const uint8_t* b, uint32_t dim);
+/* search_with_config(use_int8_traversal) -> search_int8_traversal: returns count; out = node ids + exact engine
+ * distances, best first; counters = int8 distance evaluations / layer-0 expansions */
+uint32_t vo_dual_search_int8(const vo_hnsw*, const uint8_t* codes, const float* min_vals, const float* scales,
+                             const float* q, uint32_t k, uint32_t ef_search, uint32_t oversampling, int tie,
+                             uint64_t* out_nodes, float* out_dist, uint64_t* n_dist_int8, uint64_t* n_expand);
+
 /* half_precision.rs BF16 path: exact scan over bf16-rounded rows/queries, f32 sequential accumulation
  * (metric: VO_COSINE or VO_DOT); canonical tie order; out arrays are [nq][k] */
 void vo_round_bf16(const float* in, float* out, uint64_t n);

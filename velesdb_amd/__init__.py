@@ -5,7 +5,7 @@ include/velesdb_hip.h; this package is the host-side mirror of the reference's
 VectorIndex / HnswIndex / DistanceEngine / GpuAccelerator interfaces over that ABI.
 """
 from ._ffi import LIB_PATH, VelesHipError, lib  # noqa: F401
-from .index import (GpuAccelerator, HipDistance, HnswIndex, MODE_AUTO, MODE_BRUTE, MODE_BRUTE_BF16, MODE_HNSW,  # noqa: F401
+from .index import (GpuAccelerator, HipDistance, HnswIndex, MODE_AUTO, MODE_BRUTE, MODE_BRUTE_BF16, MODE_HNSW, MODE_HNSW_INT8,  # noqa: F401
                     device_count, device_name, set_kernel_timing, set_max_query_tile, set_sweep_engine)
 from .params import DistanceMetric, HnswParams, SearchQuality  # noqa: F401
 

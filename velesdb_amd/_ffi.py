@@ -35,6 +35,8 @@ SIGNATURES = {
     "vdb_hip_index_insert_batch_parallel": (_i32, [_vp, _vp, _vp, _u64, _u32, _pu64]),
     "vdb_hip_index_build_graph": (_i32, [_vp, _u32]),
     "vdb_hip_index_enable_bf16": (_i32, [_vp]),
+    "vdb_hip_index_train_quantizer": (_i32, [_vp, _u32]),
+    "vdb_hip_set_int8_oversampling": (_i32, [_u32]),
     "vdb_hip_index_upload": (_i32, [_vp, _vp, _vp, _u64, _pu64]),
     "vdb_hip_index_upload_dev": (_i32, [_vp, _u64, _vp, _u64, _vp]),
     "vdb_hip_index_remove": (_i32, [_vp, _u64, _pi32]),

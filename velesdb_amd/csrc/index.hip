@@ -15,7 +15,8 @@ namespace vdb {
 static thread_local std::string g_last_error;
 static int g_timing = 0;
 static int g_sweep_engine = 1;  // 1 (default): MFMA kernel for cosine / dot (oracle mode M); 0: VALU kernels (mode C)
-static uint32_t g_max_tile = 48;  // largest query tile of the exact sweep (tuning knob, vdb_hip_set_max_query_tile)
+static uint32_t g_max_tile = 48;
+static uint32_t g_int8_oversampling = 4;  // DualPrecisionConfig::default().oversampling_ratio (dual_precision.rs:57)  // largest query tile of the exact sweep (tuning knob, vdb_hip_set_max_query_tile)
 
 void set_last_error(const std::string& s) { g_last_error = s; }
 int32_t fail(int32_t code, const std::string& msg) {
@@ -81,6 +82,9 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
     return fail(VDB_ERR_OOM, std::string("grow norms: ") + hipGetErrorString(e));
   if (is_bits_metric(ix->metric) && (e = ix->bits.reserve(ncap * ix->words * 4, true, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("grow bits: ") + hipGetErrorString(e));
+  if (ix->quantizer_trained && ((e = ix->codes.reserve(ncap * ix->code_words * 4, true, st)) != hipSuccess ||
+                                (e = ix->codes_sq.reserve(ncap * 4, true, st)) != hipSuccess))
+    return fail(VDB_ERR_OOM, std::string("grow codes: ") + hipGetErrorString(e));
   if (ix->bf16_enabled && ((e = ix->rows_bf16.reserve(ncap * ix->bf16_stride * 2, true, st)) != hipSuccess ||
                            (e = ix->norms_bf16.reserve(ncap * 4, true, st)) != hipSuccess))
     return fail(VDB_ERR_OOM, std::string("grow bf16 rows: ") + hipGetErrorString(e));
@@ -109,6 +113,10 @@ static int32_t finish_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
   pa.dim = ix->dim;
   pa.words = ix->words;
   if (pa.norms || pa.bits) launch_prep_rows(pa, ix->stream);
+  if (ix->quantizer_trained) {
+    int32_t rq = quantize_rows(ix, first, n);
+    if (rq != VDB_OK) return rq;
+  }
   if (ix->bf16_enabled) {
     launch_prep_bf16(ix->rows.as<float>(), ix->row_stride, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride,
                      ix->norms_bf16.as<float>(), (uint32_t)first, (uint32_t)n, ix->dim, ix->stream);
@@ -449,6 +457,11 @@ static int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride
   if (mode == VDB_SEARCH_BRUTE_BF16) return brute_bf16_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
   if (mode == VDB_SEARCH_AUTO && ix->live <= 100 && ix->n_rows > 0)  // search.rs:75-77
     return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
+  if (mode == VDB_SEARCH_HNSW_INT8) {
+    if (used_hnsw) *used_hnsw = true;
+    return hnsw_search_int8_dev(ix, d_q, q_stride, nq, k, ef == 0 ? balanced_ef(k) : ef, g_int8_oversampling, cap_mult,
+                                d_ids, d_scores, d_n, st);
+  }
   if (mode != VDB_SEARCH_AUTO && mode != VDB_SEARCH_HNSW) return fail(VDB_ERR_INVALID_ARG, "bad search mode");
   if (rerank_k) {
     // search_with_rerank(_quality): the candidate search runs with k = rerank_k (search.rs:124,310)
@@ -543,7 +556,7 @@ void vdb_hip_index_destroy(vdb_hip_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   (void)hipStreamSynchronize(ix->stream);
-  for (DevBuf* b : {&ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids, &ix->rows_bf16, &ix->norms_bf16, &ix->s_queries, &ix->s_part_keys,
+  for (DevBuf* b : {&ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids, &ix->rows_bf16, &ix->norms_bf16, &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq, &ix->s_queries, &ix->s_part_keys,
                     &ix->s_part_cnt, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels,
                     &ix->s_req_keys, &ix->s_req_vals, &ix->s_sort_tmp})
     b->release();
@@ -606,6 +619,22 @@ int32_t vdb_hip_index_insert_batch_parallel(vdb_hip_index* ix, const uint64_t* i
   if (rc != VDB_OK) return rc;
   if (ins && ix->graph_valid) rc = graph_insert_rows(ix, first, ins, max_batch);
   return rc;
+}
+
+// ScalarQuantizer::train + quantisation of every row (native/quantization.rs:191-252; DualPrecisionHnsw trains on its
+// first min(1000, max_elements) inserts, dual_precision.rs:95,134-157)
+int32_t vdb_hip_index_train_quantizer(vdb_hip_index* ix, uint32_t sample_rows) {
+  if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  VDB_HIP(hipSetDevice(ix->device));
+  int32_t rc = quantizer_train(ix, sample_rows);
+  if (rc == VDB_OK) VDB_HIP(hipStreamSynchronize(ix->stream));
+  return rc;
+}
+int32_t vdb_hip_set_int8_oversampling(uint32_t ratio) {
+  if (ratio == 0 || ratio > 64) return fail(VDB_ERR_INVALID_ARG, "oversampling ratio must be 1..64");
+  g_int8_oversampling = ratio;
+  return VDB_OK;
 }
 
 // keeps a bf16 copy of the rows (round to nearest even) for VDB_SEARCH_BRUTE_BF16; existing rows are converted now,

@@ -83,18 +83,89 @@ __device__ __forceinline__ void list_insert(volatile uint64_t* keys, volatile ui
   cnt = newcnt;
 }
 
+// distance domain of a key: f32 (total-order bits, compared as raw floats like the reference does) or u32 (the
+// integer L2^2 of the int8 traversal, dual_precision.rs:336)
+template <bool UD>
+__device__ __forceinline__ bool key_dist_gt(uint64_t a, uint64_t b) {
+  if (UD) return (uint32_t)(a >> 32) > (uint32_t)(b >> 32);
+  return key_dist(a) > key_dist(b);
+}
+
 // entries past ef stay only up to the last one the termination test could still expand
+template <bool UD = false>
 __device__ __forceinline__ void list_truncate(volatile uint64_t* keys, uint32_t& cnt, uint32_t ef, int lane) {
   if (cnt <= ef) return;
-  const float wd = key_dist(keys[ef - 1]);
+  const uint64_t wk = keys[ef - 1];
   uint32_t last = ef - 1;
   for (uint32_t c = ef; c < cnt; c += 64) {
     const uint32_t e = c + lane;
-    const bool alive = e < cnt && !(key_dist(keys[e]) > wd);  // negation of graph.rs:474's raw compare
+    const bool alive = e < cnt && !key_dist_gt<UD>(keys[e], wk);  // negation of graph.rs:474's raw compare
     const uint64_t mask = __ballot(alive);
     if (mask) last = c + 63u - (uint32_t)__clzll((long long)mask);
   }
   cnt = last + 1;
+}
+
+// ---- int8 traversal distances (DualPrecisionHnsw, native/quantization.rs:42-91): integer L2^2 between u8 codes
+// = qsq + rsq[row] - 2 * sum(q_i * r_i), every term an exact integer (v_dot4_u32_u8), so the result is the
+// reference's u32 bit for bit whatever the summation order.
+template <int S>
+__device__ __forceinline__ uint32_t add_xor_u32(uint32_t v) {
+  if (S == 32) {
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return r[0] + r[1];
+  } else if (S == 16) {
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return r[0] + r[1];
+  } else {
+    return v + __float_as_uint(lane_xor<S>(__uint_as_float(v)));
+  }
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+  v = add_xor_u32<32>(v);
+  v = add_xor_u32<16>(v);
+  v = add_xor_u32<8>(v);
+  v = add_xor_u32<4>(v);
+  v = add_xor_u32<2>(v);
+  v = add_xor_u32<1>(v);
+  return v;
+}
+struct CodeCtx {
+  const uint32_t* codes;  // [n_rows][code_words] packed u8 codes, zero padded
+  const uint32_t* rsq;    // [n_rows] sum of squared codes
+  uint32_t code_words;    // words per row (multiple of 4)
+};
+// nb_id[0..m) -> nb_d[0..m) as u32 bit patterns.  qw: this lane's query words (word w = lane + 64*j), QW of them.
+template <int QW>
+__device__ __forceinline__ void dist_phase_int8(const CodeCtx& c, const uint32_t (&qw)[QW], uint32_t qsq, uint32_t m,
+                                                volatile uint32_t* nb_id, volatile float* nb_d, int lane, int wib) {
+  constexpr int R = 8;
+  for (uint32_t j0 = (uint32_t)wib * R; j0 < m; j0 += 4 * R) {
+    uint32_t dot[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const uint32_t j = j0 + r < m ? j0 + r : m - 1;
+      const uint32_t* p = c.codes + (size_t)nb_id[j] * c.code_words + lane;
+      uint32_t w[QW];
+#pragma unroll
+      for (int t = 0; t < QW; t++) w[t] = ((uint32_t)lane + 64u * t < c.code_words) ? p[64 * t] : 0u;
+      uint32_t acc = 0;
+#pragma unroll
+      for (int t = 0; t < QW; t++) acc = __builtin_amdgcn_udot4(qw[t], w[t], acc, false);
+      dot[r] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) dot[r] = wave_sum_u32(dot[r]);
+    // lane r finishes row j0 + r
+    uint32_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) mine = (lane == r) ? dot[r] : mine;
+    const uint32_t j = j0 + (uint32_t)lane;
+    if (lane < R && j < m) {
+      const uint32_t d = qsq + c.rsq[nb_id[j]] - 2u * mine;
+      nb_d[j] = __uint_as_float(d);
+    }
+  }
 }
 
 // ---- the candidate/result list behind one interface ---------------------------------------------
@@ -109,7 +180,7 @@ __device__ __forceinline__ void list_truncate(volatile uint64_t* keys, uint32_t&
 // the "expanded" flag in bit 0 (node ids < 2^31).
 constexpr uint32_t kNoIndex = 0xFFFFFFFFu;
 
-template <int NS>
+template <int NS, bool UD = false>
 struct CandList {
   uint64_t k[NS];
   uint32_t cnt;
@@ -180,12 +251,12 @@ struct CandList {
   }
   __device__ __forceinline__ void truncate(uint32_t ef, int lane) {
     if (cnt <= ef) return;
-    const float wd = key_dist(key_at(ef - 1, lane));
+    const uint64_t wk = enc(key_at(ef - 1, lane));
     uint32_t last = ef - 1;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
       const uint32_t e = (uint32_t)s * 64 + lane;
-      const bool alive = e >= ef && e < cnt && !(key_dist(k[s]) > wd);  // negation of graph.rs:474's raw compare
+      const bool alive = e >= ef && e < cnt && !key_dist_gt<UD>(k[s], wk);  // negation of graph.rs:474's raw compare
       const uint64_t mask = __ballot(alive);
       if (mask) last = (uint32_t)s * 64 + 63u - (uint32_t)__clzll((long long)mask);
     }
@@ -212,8 +283,8 @@ struct CandList {
   }
 };
 
-template <>
-struct CandList<0> {
+template <bool UD>
+struct CandList<0, UD> {
   volatile uint64_t* keys;
   volatile uint8_t* flags;
   uint32_t cnt, cap;
@@ -243,7 +314,7 @@ struct CandList<0> {
   __device__ __forceinline__ void mark_expanded(uint32_t idx, int lane) {
     if (lane == 0) flags[idx] = 1;
   }
-  __device__ __forceinline__ void truncate(uint32_t ef, int lane) { list_truncate(keys, cnt, ef, lane); }
+  __device__ __forceinline__ void truncate(uint32_t ef, int lane) { list_truncate<UD>(keys, cnt, ef, lane); }
   __device__ __forceinline__ uint64_t chunk_key(uint32_t base, int lane) const { return keys[base + lane]; }
   __device__ __forceinline__ void dump(volatile uint64_t*, uint32_t, int) const {}
 };

@@ -68,6 +68,10 @@ struct vdb_hip_index {
   vdb::DevBuf rows, norms, bits, alive, ext_ids;
   // optional bf16 copy of the rows for the GEMM-distance sweep (vdb_hip_index_enable_bf16)
   vdb::DevBuf rows_bf16, norms_bf16;
+  // optional scalar quantiser + u8 codes for the int8 traversal (hnsw_int8.hip)
+  vdb::DevBuf sq_min, sq_scale, codes, codes_sq;
+  uint32_t code_words = 0;
+  bool quantizer_trained = false;
   bool bf16_enabled = false;
   uint64_t bf16_stride = 0;  // bf16 elements per row (multiple of 8)
   uint64_t bf16_rows = 0;    // rows converted so far
@@ -114,6 +118,12 @@ int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
                         uint32_t rerank_k = 0);
 // hnsw_build.hip; max_batch 1 = the reference's sequential insert, 0 = default batched schedule
 int32_t graph_insert_rows(vdb_hip_index* ix, uint64_t first, uint64_t n, uint32_t max_batch);
-int32_t ensure_traversal_scratch(vdb_hip_index* ix, hipStream_t st);  // visited bitmaps + logs + stats
+int32_t ensure_traversal_scratch(vdb_hip_index* ix, hipStream_t st);
+// hnsw_int8.hip
+int32_t quantizer_train(vdb_hip_index* ix, uint32_t sample_rows);
+int32_t quantize_rows(vdb_hip_index* ix, uint64_t first, uint64_t n);
+int32_t hnsw_search_int8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k,
+                             uint32_t ef_search, uint32_t oversampling, uint32_t cap_mult, uint64_t* d_ids,
+                             float* d_scores, uint32_t* d_n, hipStream_t st);  // visited bitmaps + logs + stats
 constexpr uint32_t kVlogCap = 16384;
 }  // namespace vdb

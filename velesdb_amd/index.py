@@ -19,7 +19,7 @@ from . import _ffi
 from ._ffi import check, lib
 from .params import DistanceMetric, HnswParams, SearchQuality
 
-MODE_AUTO, MODE_BRUTE, MODE_HNSW, MODE_BRUTE_BF16 = 0, 1, 2, 3
+MODE_AUTO, MODE_BRUTE, MODE_HNSW, MODE_BRUTE_BF16, MODE_HNSW_INT8 = 0, 1, 2, 3, 4
 KIND_ENGINE, KIND_RAW = 0, 1
 
 
@@ -199,6 +199,19 @@ class HnswIndex:
         cnt = np.zeros(1, dtype=np.uint32)
         check(lib().vdb_hip_index_search_rerank(self._h, _ptr(q), 1, k, rerank_k, ef, _ptr(ids), _ptr(sc), _ptr(cnt)))
         return self._tuples(ids[0], sc[0], cnt[0])
+
+    def train_quantizer(self, sample_rows: int = 0) -> None:
+        """ScalarQuantizer::train on the first sample_rows rows (0 = min(1000, rows)) + u8 codes of every row."""
+        check(lib().vdb_hip_index_train_quantizer(self._h, sample_rows))
+
+    def search_batch_int8(self, queries, k: int, ef_search: int):
+        """DualPrecisionHnsw::search_with_config(use_int8_traversal): int8 graph walk + exact f32 re-rank."""
+        qs = _f32(queries)
+        if qs.ndim == 1:
+            qs = qs.reshape(1, -1)
+        self._validate(qs)
+        ids, sc, cnt = self._search_raw(qs, k, ef_search, MODE_HNSW_INT8)
+        return [self._tuples(ids[i], sc[i], cnt[i]) for i in range(qs.shape[0])]
 
     def enable_bf16(self) -> None:
         """Keeps a bf16 (round-to-nearest-even) copy of the rows for search_batch_brute_force_bf16."""
