@@ -45,7 +45,8 @@ def parse():
     p.add_argument("--k", type=int, default=10)
     p.add_argument("--batch", type=int, default=192, help="queries per step (exact sweep)")
     p.add_argument("--metric", default="cosine")
-    p.add_argument("--tile", type=int, default=48, help="largest query tile of the sweep (1,2,4,8,16,32,48)")
+    p.add_argument("--tile", type=int, default=128, help="largest query tile of the sweep (1,2,4,8,16,32,48; 128 = "
+                   "batches of >= 64 queries go to the GEMM-structured matrix-core kernel)")
     p.add_argument("--engine", type=int, default=1, help="1 = matrix-core sweep for cosine/dot (default), 0 = VALU")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=int, default=262_144)
@@ -146,8 +147,17 @@ def main():
     # ---- roofline of the dominant kernel (the sweep): algorithmic bytes / measured duration ----
     mfma = a.engine == 1 and a.metric in ("cosine", "dot")
 
+    F32_MFMA_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak of MI355X (cdna_hip_programming.md section 3)
+
+    def gemm_plan(nq):  # sweep_gemm_plan (sweep_gemm.hip): query tiles of <= 128, 16*nqf queries per wave
+        nqt = (nq + 127) // 128
+        qper = (nq + nqt - 1) // nqt
+        return nqt, qper, max(2, (qper + 31) // 32)
+
     def tile_for(nq, max_tile, use_mfma):  # the library's tile choice (index.hip brute_dev)
         if use_mfma:
+            if nq >= 64 and max_tile >= 128:
+                return nq  # GEMM kernel: the whole batch in one launch
             return 48 if (nq > 32 and max_tile >= 48) else (32 if (nq > 16 and max_tile >= 32) else 16)
         lds_tiles = D % 256 == 0 and D <= 1024
         if lds_tiles and nq >= 24 and max_tile >= 32:
@@ -158,6 +168,8 @@ def main():
 
     def kernel_name(t, use_mfma):
         if use_mfma:
+            if t >= 64:
+                return f"sweep_topk_gemm_f32<{a.metric},NQF={gemm_plan(t)[2]}>"
             return f"sweep_topk_mfma_f32<{a.metric},NQT={t // 16}>"
         cpl = D // 256 if D % 256 == 0 and D <= 1024 else 0
         return (f"sweep_topk_f32_qlds<{a.metric},B={t},CPL={cpl}>" if t >= 16
@@ -169,49 +181,70 @@ def main():
     tile = tile_for(Q, a.tile, mfma)
     alg_bytes = alg_bytes_for(tile)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    flops = 2.0 * N * D * tile
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": kernel_name(tile, mfma),
-                "kernel_ms": round(kernel_ms, 4), "launches_timed": kernel_launches,
-                "alg_bytes_per_launch": alg_bytes, "queries_per_launch": tile,
-                "f32_tflops": round(flops / (kernel_ms * 1e-3) / 1e12, 1) if kernel_ms > 0 else 0.0,
-                "note": "one corpus pass serves `queries_per_launch` queries, so HBM bytes per QUERY are "
-                        "alg_bytes/queries_per_launch; with 48 queries per pass the exact-f32 matrix pipe (157 TFLOP/s "
-                        "peak, f32_tflops achieved) shares the bound with HBM; `tiles` lists every tile size"}
+    flops = 2.0 * N * D * tile  # algorithmic: one multiply-add per (row, query, dimension)
+    tflops = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    if mfma and tile >= 64:
+        # the GEMM-structured kernel serves the whole batch with one corpus pass: bound by the exact-f32 matrix pipe
+        roofline = {"bound": "mfma", "achieved": round(tflops, 1), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": kernel_name(tile, mfma), "kernel_ms": round(kernel_ms, 4),
+                    "launches_timed": kernel_launches, "alg_flops_per_launch": flops,
+                    "queries_per_launch": tile, "alg_bytes_per_launch": alg_bytes,
+                    "hbm_gbs": round(achieved, 1), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "note": "exact f32 contraction on v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: 157.3 TFLOP/s "
+                            "dense peak, 1/16 of the bf16 rate); algorithmic flop = 2*rows*dim*queries; the corpus "
+                            "is read once per launch (hbm_gbs = algorithmic bytes / kernel time); `tiles` lists the "
+                            "HBM-bound small-batch kernels"}
+    else:
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": kernel_name(tile, mfma),
+                    "kernel_ms": round(kernel_ms, 4), "launches_timed": kernel_launches,
+                    "alg_bytes_per_launch": alg_bytes, "queries_per_launch": tile,
+                    "f32_tflops": round(tflops, 1),
+                    "note": "one corpus pass serves `queries_per_launch` queries, so HBM bytes per QUERY are "
+                            "alg_bytes/queries_per_launch; `tiles` lists every tile size"}
 
     # ---- the same sweep at every tile size (queries per corpus pass), both engines ----
     tiles = []
     if rank == 0:
-        plans = [(1, t) for t in (16, 32, 48)] if a.metric in ("cosine", "dot") else []
+        plans = [(1, t) for t in (16, 32, 48, 64, 96, 128, 192, 256)] if a.metric in ("cosine", "dot") else []
         plans = [(1, 1)] + plans if plans else plans
         plans += [(0, t) for t in (1, 8, 16, 32)]
         for eng, t in plans:
-            if t > a.tile and not (eng == 1 and t == 1):
+            if t > a.tile and not (eng == 1 and (t == 1 or (t >= 64 and a.tile >= 128))):
+                continue
+            if t > n_query_pool:
                 continue
             use_m = eng == 1
             va.set_sweep_engine(eng)
-            va.set_max_query_tile(max(t, 16) if use_m else t)
-            nq_t = 1 if t == 1 else t
-            eff = tile_for(nq_t, max(t, 16) if use_m else t, use_m)
+            mt = (128 if t >= 64 else max(t, 16)) if use_m else t
+            va.set_max_query_tile(mt if mt in (1, 2, 4, 8, 16, 32, 48, 128) else 48)
+            nq_t = t
+            eff = tile_for(nq_t, mt, use_m)
+            t_ids = torch.empty((nq_t, K), dtype=torch.int64, device=dev)
+            t_sc = torch.empty((nq_t, K), dtype=torch.float32, device=dev)
+            t_n = torch.empty((nq_t,), dtype=torch.int32, device=dev)
             for _ in range(2):
-                ix.search_batch_dev(queries.data_ptr(), nq_t, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
-                                    out_sc.data_ptr(), out_n.data_ptr(), stream)
+                ix.search_batch_dev(queries.data_ptr(), nq_t, K, 0, va.MODE_BRUTE, t_ids.data_ptr(),
+                                    t_sc.data_ptr(), t_n.data_ptr(), stream)
             torch.cuda.synchronize()
             va.set_kernel_timing(True)
             reps = 10
             tt = time.perf_counter()
             for _ in range(reps):
-                ix.search_batch_dev(queries.data_ptr(), nq_t, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
-                                    out_sc.data_ptr(), out_n.data_ptr(), stream)
+                ix.search_batch_dev(queries.data_ptr(), nq_t, K, 0, va.MODE_BRUTE, t_ids.data_ptr(),
+                                    t_sc.data_ptr(), t_n.data_ptr(), stream)
             torch.cuda.synchronize()
             t_dt = (time.perf_counter() - tt) / reps
             kms, nl = ix.last_kernel_ms()
             va.set_kernel_timing(False)
             gbs = alg_bytes_for(eff) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+            tf = 2.0 * N * D * min(eff, nq_t) / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
             tiles.append({"engine": "mfma" if use_m else "valu", "queries": nq_t, "kernel": kernel_name(eff, use_m),
                           "kernel_ms": round(kms, 4), "hbm_gbs": round(gbs, 1),
-                          "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "qps": round(nq_t / t_dt, 1)})
+                          "hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "f32_tflops": round(tf, 1),
+                          "qps": round(nq_t / t_dt, 1)})
         va.set_sweep_engine(a.engine)
         va.set_max_query_tile(a.tile)
 
@@ -229,7 +262,7 @@ def main():
         l_dt = (time.perf_counter() - t1) / reps
         kms, _ = ix.last_kernel_ms()
         va.set_kernel_timing(False)
-        b1 = alg_bytes_for(16 if mfma else 1)
+        b1 = alg_bytes_for(16 if mfma else 1)  # the matrix-core streaming kernel stages a 16-query tile
         lat = {"ms_per_query": round(l_dt * 1e3, 4), "qps": round(1.0 / l_dt, 1), "sweep_kernel_ms": round(kms, 4),
                "hbm_gbs": round(b1 / (kms * 1e-3) / 1e9, 1) if kms > 0 else 0.0,
                "hbm_frac": round(b1 / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else 0.0}
@@ -385,7 +418,8 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{N}x{D} f32 {a.metric}, k={K}, exact distance sweep + fused GPU top-k "
-                                   f"(BASELINE configs[1]); {Q} queries/step, {tile} queries per corpus pass",
+                                   f"(BASELINE configs[1]); {Q} queries/step, {tile} queries per corpus pass "
+                                   f"({roofline['kernel']})",
                        "rows": N, "dim": D, "k": K, "queries_per_step": Q,
                        "parallelism": "replicas x%d (query stream split, no collective)" % world},
             "recall_at_10": recall, "parity_check": check,

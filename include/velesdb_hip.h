@@ -190,8 +190,9 @@ int32_t vdb_hip_index_last_search_stats(vdb_hip_index* idx, uint64_t* n_dist, ui
  * events on the launch stream; 0 if timing is off.  Enable with vdb_hip_set_kernel_timing(1). */
 int32_t vdb_hip_set_kernel_timing(int32_t on);
 /* tuning knob of the exact sweep: largest number of queries served by one corpus pass
- * (vector-ALU kernels: 1,2,4,8 register-resident tiles, 16,32 LDS-resident tiles; matrix-core kernel: 16, 32 or
- * 48 queries).  Default 48.  Results do not depend on it. */
+ * (vector-ALU kernels: 1,2,4,8 register-resident tiles, 16,32 LDS-resident tiles; matrix-core streaming kernel:
+ * 16, 32 or 48 queries; 128 = batches of >= 64 queries go to the GEMM-structured matrix-core kernel, up to 128
+ * queries per block tile).  Default 128.  Results do not depend on it. */
 int32_t vdb_hip_set_max_query_tile(uint32_t b);
 /* arithmetic engine of the exact sweep for Cosine / DotProduct: 1 (default) = matrix-core kernel
  * (v_mfma_f32_16x16x4_f32: exact f32, one k-ordered fmaf chain per pair, oracle mode M); 0 = vector-ALU kernels

@@ -127,7 +127,7 @@ def test_query_tile_size_does_not_change_results(gpu_required):
     ix.upload(np.arange(20000), rows)
     ref = None
     try:
-        for tile in (1, 8, 16, 32):
+        for tile in (1, 8, 16, 32, 48, 128):
             va.set_max_query_tile(tile)
             out = ix.search_batch_brute_force(Q, 10)
             if ref is None:
@@ -135,9 +135,66 @@ def test_query_tile_size_does_not_change_results(gpu_required):
             else:
                 assert np.array_equal(out[0], ref[0]) and np.array_equal(bits(out[1]), bits(ref[1]))
     finally:
-        va.set_max_query_tile(32)
+        va.set_max_query_tile(128)
     eid, esc = po.scan_topk(po.COSINE, rows, Q, 10, sweep_mode(DM.Cosine, 768), nthreads=4)
     assert np.array_equal(ref[0], eid) and np.array_equal(bits(ref[1]), bits(esc))
+
+
+@pytest.mark.parametrize("metric", [DM.Cosine, DM.DotProduct])
+@pytest.mark.parametrize("n,dim", [(10007, 768), (4000, 100), (3000, 17), (50, 64), (129, 128), (2500, 1001)])
+def test_gemm_sweep_large_batches_bit_exact(gpu_required, metric, n, dim):
+    # batches of >= 64 queries take the GEMM-structured matrix-core kernel (sweep_gemm.hip): one launch for the
+    # whole batch, 128-row x <=128-query block tiles.  Same mode-M chain as the streaming kernel => same bits.
+    rng = np.random.default_rng(n * 31 + dim)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64) * 7 + 3
+    ix = va.HnswIndex(dim, metric)
+    assert ix.upload(ids, rows) == n
+    assert ix.sweep_arith_mode(10) == "M"
+    for nq, k in [(64, 10), (65, 1), (100, 10), (128, 10), (129, 7), (192, 10), (200, 64), (300, 10)]:
+        Q = rng.standard_normal((nq, dim)).astype(np.float32)
+        gid, gsc, gcnt = ix.search_batch_brute_force(Q, k)
+        eid, esc = po.scan_topk(int(metric), rows, Q, min(k, n), po.MODE_M, nthreads=8)
+        kk = min(k, n)
+        assert np.all(gcnt == kk)
+        assert np.array_equal(gid[:, :kk], ids[eid.astype(np.int64)]), (nq, k)
+        assert np.array_equal(bits(gsc[:, :kk]), bits(esc)), (nq, k)
+    # soft-deleted rows are filtered inside the kernel's offer path
+    dead = rng.choice(n, max(1, n // 10), replace=False)
+    for d in dead:
+        assert ix.remove(int(ids[d]))
+    live = np.ones(n, bool)
+    live[dead] = False
+    Q = rng.standard_normal((96, dim)).astype(np.float32)
+    gid, gsc, gcnt = ix.search_batch_brute_force(Q, 10)
+    exp = oracle_brute(metric, rows, ids, Q, 10, live)
+    for qi in range(96):
+        eid, esc = exp[qi]
+        assert gcnt[qi] == len(eid)
+        assert np.array_equal(gid[qi, :gcnt[qi]], eid) and np.array_equal(bits(gsc[qi, :gcnt[qi]]), bits(esc))
+    ix.close()
+
+
+def test_gemm_sweep_special_values(gpu_required):
+    # zero rows / zero queries (cosine 0.0), NaN and inf rows: same bits and order as the oracle's total order
+    rng = np.random.default_rng(77)
+    n, dim = 1000, 64
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[5] = 0.0
+    rows[17, 3] = np.nan
+    rows[29, 0] = np.inf
+    rows[41] = rows[40]  # exact duplicate: tie broken by row index
+    Q = rng.standard_normal((80, dim)).astype(np.float32)
+    Q[3] = 0.0
+    Q[9] = rows[40]
+    for metric in (DM.Cosine, DM.DotProduct):
+        ix = va.HnswIndex(dim, metric)
+        ix.upload(np.arange(n), rows)
+        gid, gsc, gcnt = ix.search_batch_brute_force(Q, 20)
+        eid, esc = po.scan_topk(int(metric), rows, Q, 20, po.MODE_M, nthreads=4)
+        assert np.array_equal(gid, eid), metric
+        assert np.array_equal(bits(gsc), bits(esc)), metric
+        ix.close()
 
 
 @pytest.mark.parametrize("metric", [DM.Cosine, DM.DotProduct])

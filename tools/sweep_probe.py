@@ -15,9 +15,9 @@ p.add_argument("--rows", type=int, default=1_000_000)
 p.add_argument("--dim", type=int, default=768)
 p.add_argument("--k", type=int, default=10)
 p.add_argument("--metric", default="cosine")
-p.add_argument("--nqs", default="1,8,16,32,48,96,192")
-p.add_argument("--tile", type=int, default=32)
-p.add_argument("--engine", type=int, default=0)
+p.add_argument("--nqs", default="16,32,48,64,96,128,192,256,512")
+p.add_argument("--tile", type=int, default=128)
+p.add_argument("--engine", type=int, default=1)
 a = p.parse_args()
 va.set_max_query_tile(a.tile)
 va.set_sweep_engine(a.engine)
@@ -25,7 +25,7 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(42)
 corpus = torch.randn((a.rows, a.dim), generator=g, device=dev)
-queries = torch.randn((256, a.dim), generator=g, device=dev)
+queries = torch.randn((1024, a.dim), generator=g, device=dev)
 metric = {"cosine": va.DistanceMetric.Cosine, "euclidean": va.DistanceMetric.Euclidean, "dot": va.DistanceMetric.DotProduct}[a.metric]
 ix = va.HnswIndex(a.dim, metric, va.HnswParams(32, 400, a.rows))
 torch.cuda.synchronize()
@@ -50,4 +50,5 @@ for nq in [int(x) for x in a.nqs.split(",")]:
     kms, nl = ix.last_kernel_ms()
     va.set_kernel_timing(False)
     print(f"nq={nq:3d}: call {dt*1e3:8.3f} ms  ({nq/dt:9.1f} qps)  sweep kernel {kms:7.4f} ms x{nl}  "
-          f"{alg/(kms*1e-3)/1e9:7.1f} GB/s ({alg/(kms*1e-3)/1e9/8000:.3f} of 8 TB/s)")
+          f"{alg/(kms*1e-3)/1e9:7.1f} GB/s ({alg/(kms*1e-3)/1e9/8000:.3f} of 8 TB/s)  "
+          f"{2.0*a.rows*a.dim*nq/nl/(kms*1e-3)/1e12:6.1f} TFLOP/s", flush=True)

@@ -15,7 +15,7 @@ namespace vdb {
 static thread_local std::string g_last_error;
 static int g_timing = 0;
 static int g_sweep_engine = 1;  // 1 (default): MFMA kernel for cosine / dot (oracle mode M); 0: VALU kernels (mode C)
-static uint32_t g_max_tile = 48;
+static uint32_t g_max_tile = 128;
 static uint32_t g_int8_oversampling = 4;  // DualPrecisionConfig::default().oversampling_ratio (dual_precision.rs:57)  // largest query tile of the exact sweep (tuning knob, vdb_hip_set_max_query_tile)
 
 void set_last_error(const std::string& s) { g_last_error = s; }
@@ -326,6 +326,45 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
         if (sweep_mfma_lds_bytes(want, k, ix->dim) <= 160 * 1024) break;
       mfma_nqt = want;  // 0: does not fit the LDS (very large dim or k): VALU kernels
     }
+    // large batches: GEMM-structured matrix-core kernel, the whole batch in one launch (sweep_gemm.hip)
+    if (mfma_nqt && g_max_tile >= 128 && nq - q0 >= kGemmMinQueries && k <= kGemmMaxK) {
+      const uint32_t nqg = std::min<uint32_t>(nq - q0, kGemmMaxQueries);
+      GemmPlan gp;
+      sweep_gemm_plan(nqg, (uint32_t)ix->n_rows, ix->n_cus, k, &gp);
+      if (gp.lds <= 160 * 1024) {
+        hipError_t e3;
+        if ((e3 = ix->s_part_keys.reserve((size_t)nqg * gp.G * k * 8, false, st)) != hipSuccess)
+          return fail(VDB_ERR_OOM, "top-k scratch");
+        SweepArgs ag{};
+        ag.rows = ix->rows.as<float>();
+        ag.norms = ix->norms.as<float>();
+        ag.alive = alive;
+        ag.queries = d_q + (size_t)q0 * q_stride;
+        ag.part_keys = ix->s_part_keys.as<uint64_t>();
+        ag.row_stride = ix->row_stride;
+        ag.q_stride = q_stride;
+        ag.n_rows = (uint32_t)ix->n_rows;
+        ag.dim = ix->dim;
+        ag.nq = nqg;
+        ag.k = k;
+        EventPair* evg = next_events(ix);
+        if (evg) (void)hipEventRecord(evg->a, st);
+        e3 = launch_sweep_gemm(ix->metric, gp, ag, st);
+        if (evg) (void)hipEventRecord(evg->b, st);
+        if (e3 != hipSuccess) return fail(VDB_ERR_HIP, std::string("gemm sweep launch: ") + hipGetErrorString(e3));
+        MergeArgs mg{};
+        mg.part_keys = ag.part_keys;
+        mg.ext_ids = ix->ext_ids.as<uint64_t>();
+        mg.out_ids = d_ids + (size_t)q0 * k;
+        mg.out_scores = d_scores + (size_t)q0 * k;
+        mg.out_n = d_n + q0;
+        mg.n_lists = gp.G;
+        mg.k = k;
+        launch_merge(hib, mg, nqg, st);
+        q0 += nqg;
+        continue;
+      }
+    }
     if (mfma_nqt) {
       const uint32_t Bm = (uint32_t)mfma_nqt * 16;
       const uint32_t tile_m = std::min<uint32_t>(Bm, nq - q0);
@@ -486,8 +525,8 @@ const char* vdb_hip_last_error(void) { return g_last_error.c_str(); }
 const char* vdb_hip_version(void) { return "velesdb-hip 0.1.0 (gfx950)"; }
 
 int32_t vdb_hip_set_max_query_tile(uint32_t b) {
-  if (b != 1 && b != 2 && b != 4 && b != 8 && b != 16 && b != 32 && b != 48)
-    return fail(VDB_ERR_INVALID_ARG, "tile must be 1, 2, 4, 8, 16, 32 or 48");
+  if (b != 1 && b != 2 && b != 4 && b != 8 && b != 16 && b != 32 && b != 48 && b != 128)
+    return fail(VDB_ERR_INVALID_ARG, "tile must be 1, 2, 4, 8, 16, 32, 48 or 128");
   g_max_tile = b;
   return VDB_OK;
 }

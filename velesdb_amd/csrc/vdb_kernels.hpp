@@ -115,6 +115,21 @@ constexpr int kMfmaWaves1 = 8;   // waves per block for one 16-query tile
 constexpr int kMfmaWaves2 = 16;  // ... for two tiles (the 96 KiB query fragments fill most of the LDS)
 size_t sweep_mfma_lds_bytes(int nqt, uint32_t k, uint32_t dim);
 hipError_t launch_sweep_mfma(int metric, int nqt, const SweepArgs& a, int blocks, hipStream_t st);
+// GEMM-structured f32 sweep for large query batches (sweep_gemm.hip): 128-row x 32*nqf-query block tiles
+struct GemmPlan {
+  uint32_t nqt;   // query tiles
+  uint32_t qper;  // queries per tile
+  uint32_t G;     // row groups = partial top-k lists per query
+  int nqf;        // 16-query accumulator tiles per wave (block tile = 32 * nqf queries)
+  int blocks;
+  size_t lds;
+};
+constexpr uint32_t kGemmMinQueries = 64;    // below this the streaming kernels (HBM-bound) are faster
+constexpr uint32_t kGemmMaxK = 48;          // candidate buffers hold <= 64 keys per query (one per lane when compacted)
+constexpr uint32_t kGemmMaxQueries = 1024;  // per launch (bounds the partial-list scratch)
+size_t sweep_gemm_lds_bytes(int nqf, uint32_t k);
+void sweep_gemm_plan(uint32_t nq, uint32_t n_rows, int n_cus, uint32_t k, GemmPlan* p);
+hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, hipStream_t st);
 // bf16 GEMM-distance sweep (cosine / dot over a bf16 copy of the rows): nqt in {1, 2, 4, 6} 16-query tiles
 constexpr int kBf16WavesBig = 16;    // waves per block for nqt >= 4 (one block per CU)
 constexpr int kBf16WavesSmall = 8;   // ... for nqt <= 2
