@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvelesdb_hip.so")
+# VELESDB_HIP_LIB selects another build of the same ABI (kernel-variant probes); the default is the in-tree library
+LIB_PATH = os.environ.get("VELESDB_HIP_LIB") or os.path.join(_HERE, "lib", "libvelesdb_hip.so")
 
 VDB_OK = 0
 VDB_DUPLICATE_IGNORED = 1

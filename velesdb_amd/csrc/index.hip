@@ -74,7 +74,8 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
   ncap = std::max<uint64_t>(ncap, 1024);
   hipStream_t st = ix->stream;
   hipError_t e;
-  if ((e = ix->rows.reserve(ncap * ix->row_stride * 4, true, st)) != hipSuccess ||
+  // + kRowSlack rows: tiled kernels read whole 128-row tiles (rows past n_rows are never reported)
+  if ((e = ix->rows.reserve((ncap + kRowSlack) * ix->row_stride * 4, true, st)) != hipSuccess ||
       (e = ix->alive.reserve(ncap, true, st)) != hipSuccess ||
       (e = ix->ext_ids.reserve(ncap * 8, true, st)) != hipSuccess)
     return fail(e == hipErrorOutOfMemory ? VDB_ERR_OOM : VDB_ERR_HIP, std::string("grow: ") + hipGetErrorString(e));

@@ -36,16 +36,24 @@
 //     slots, so a row tile needed by several query tiles comes out of that XCD's L2 the second time.
 // Bound: the f32 matrix pipe (157.3 TFLOP/s dense); algorithmic flop per launch = 2 * n_rows * dim * nq.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "vdb_device.hpp"
 #include "vdb_kernels.hpp"
 
+// Ablation hooks for tools/probes/gemm_variants.sh (never defined in the product build):
+//   VDB_GEMM_ABL_NOEPI   skip filter/append/compaction (accumulators kept live)
+//   VDB_GEMM_ABL_NOMFMA  skip the multiply (staging + barriers only)
+//   VDB_GEMM_ABL_NOLOAD  skip the global loads (multiply + barriers only)
+//   VDB_GEMM_STATS       count epilogue rounds / appends / compactions / overflow failures (printed per launch)
 namespace vdb {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kGemmBM = 128;  // rows per block tile
 constexpr int kGemmBK = 32;   // floats per k-tile (one 128-B line per row)
+constexpr int kGemmQueue = 256;  // per-wave queue of filter survivors (entries)
 
 struct GemmSweepArgs {
   SweepArgs s;
@@ -54,9 +62,40 @@ struct GemmSweepArgs {
   uint32_t nqt;    // query tiles
   uint32_t qper;   // queries per tile (<= 32 * NQF)
   uint32_t cap;    // candidate buffer entries per query (k < cap <= 64)
+  uint32_t stagger_mode;  // probe knob: which blocks are delayed (0: second half of the grid)
+  uint32_t stagger;  // start delay of the second half of the grid, in units of 8128 cycles (0: none)
+#ifdef VDB_GEMM_STATS
+  unsigned long long* stats;  // [4] rounds, appends, compactions, failures
+#endif
 };
 
-template <int METRIC, int NQF, bool QVEC>
+// acc[rf][t][r] for a per-lane element index e = (rf*NQF + t)*4 + r, without dynamic register indexing: a binary
+// select tree (one v_cndmask per inner node, the six bit tests shared by a level).
+template <int NQF, int LO, int N>
+struct AccSelect {
+  static __device__ __forceinline__ float get(const f32x4 (&acc)[4][NQF], uint32_t e) {
+    if (LO >= 16 * NQF) return 0.0f;  // past the last element (NQF = 3: 48 of 64)
+    const float lo = AccSelect<NQF, LO, N / 2>::get(acc, e);
+    if (LO + N / 2 >= 16 * NQF) return lo;
+    const float hi = AccSelect<NQF, LO + N / 2, N / 2>::get(acc, e);
+    return (e & (uint32_t)(N / 2)) ? hi : lo;
+  }
+};
+template <int NQF, int LO>
+struct AccSelect<NQF, LO, 1> {
+  static __device__ __forceinline__ float get(const f32x4 (&acc)[4][NQF], uint32_t) {
+    if (LO >= 16 * NQF) return 0.0f;
+    return acc[(LO / 4) / NQF][(LO / 4) % NQF][LO % 4];
+  }
+};
+template <int NQF>
+__device__ __forceinline__ float select_acc(const f32x4 (&acc)[4][NQF], uint32_t e) {
+  return AccSelect<NQF, 0, 64>::get(acc, e);
+}
+
+// FULL: dim % 128 == 0 and the queries are readable as aligned float4 — no zero-fill, and the tile loads are
+// `uniform base (SGPR) + loop-invariant per-thread offset`: no vector ALU work at all for addressing.
+template <int METRIC, int NQF, bool QVEC, bool FULL>
 __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) {
   constexpr int BM = kGemmBM, BK = kGemmBK, BN = 32 * NQF;
   constexpr bool HIB = true;  // cosine and dot: higher is better
@@ -71,11 +110,14 @@ __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) 
   uint32_t* cnts = reinterpret_cast<uint32_t*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 8);
   float* qn = reinterpret_cast<float*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 12);
   volatile uint32_t* ovf = reinterpret_cast<volatile uint32_t*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 16);  // overflow token
+  float* vns = reinterpret_cast<float*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 16 + 16);  // [BM] norms of the row tile
+  uint64_t* wqueue_all = reinterpret_cast<uint64_t*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 16 + 16 + BM * 4);  // [4][kGemmQueue]
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wib >> 1, wq = wib & 1;
+  uint64_t* wqueue = wqueue_all + wib * kGemmQueue;  // this wave's survivors of the filter: (dot bits, row in tile, query)
 
   // block -> (query tile, row group): the nqt query tiles of a row group sit on one XCD (blockIdx % 8)
   const uint32_t bid = blockIdx.x;
@@ -129,205 +171,439 @@ __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) 
   uint32_t pend_kf = 0;           // k offset of the loads currently held in ra / rb
   // Branch-free: every load is issued unconditionally from a clamped (valid) address and zeroed by a select —
   // a conditional load makes hipcc branch around it and wait vmcnt(0) per element (serialised round trips).
-  auto gload = [&]() __attribute__((always_inline)) {
-    const uint32_t kf = ld_kt * BK + st_slot * 4;
-    const bool kin = kf < (uint32_t)a.row_stride;
-    const uint32_t kfa = kin ? kf : 0u;
+  // FULL path: per-thread byte offsets inside a row tile / the query tile (loop-invariant)
+  const uint32_t voff_a = (uint32_t)st_row * (uint32_t)a.row_stride * 4u + (uint32_t)st_slot * 16u;
+  uint32_t voff_b[NQF];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      uint32_t row = ld_rt * BM + st_row + 32 * j;
-      row = row < a.n_rows ? row : a.n_rows - 1;  // tail rows: re-read the last row, masked in the epilogue
-      ra[j] = ld4(a.rows + (size_t)row * a.row_stride + kfa);
-    }
-#pragma unroll
-    for (int j = 0; j < NQF; j++) {
-      const uint32_t q = st_row + 32 * j;
-      const float* qp = queries + (size_t)(q < nq_t ? q : 0u) * a.q_stride;
-      if (QVEC) {
-        rb[j] = ld4(qp + (kf < a.dim ? kf : 0u));
-      } else {
-        const uint32_t dl = a.dim - 1;
-        rb[j] = make_float4(qp[min(kf, dl)], qp[min(kf + 1, dl)], qp[min(kf + 2, dl)], qp[min(kf + 3, dl)]);
-      }
-    }
-    pend_kf = kf;  // the zero-fill selects run in lds_store, after the multiply, so nothing waits on the loads here
-    if (++ld_kt == ga.KT) {
-      ld_kt = 0;
-      ld_rt += ga.G;
-    }
-  };
-  auto lds_store = [&]() __attribute__((always_inline)) {
-    float* Ab = As;
-    float* Bb = Bs;
-    const bool kin = pend_kf < (uint32_t)a.row_stride;
-    const bool k0 = pend_kf < a.dim, k1 = pend_kf + 1 < a.dim, k2 = pend_kf + 2 < a.dim, k3 = pend_kf + 3 < a.dim;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int row = st_row + 32 * j;
-      float4 v = ra[j];
-      v.x = kin ? v.x : 0.f;
-      v.y = kin ? v.y : 0.f;
-      v.z = kin ? v.z : 0.f;
-      v.w = kin ? v.w : 0.f;
-      *reinterpret_cast<float4*>(Ab + row * BK + ((st_slot ^ ((row >> 1) & 7)) << 2)) = v;
-    }
-#pragma unroll
-    for (int j = 0; j < NQF; j++) {
-      const int q = st_row + 32 * j;
-      const bool qin = (uint32_t)q < nq_t;
-      float4 v = rb[j];
-      v.x = (qin && k0) ? v.x : 0.f;
-      v.y = (qin && k1) ? v.y : 0.f;
-      v.z = (qin && k2) ? v.z : 0.f;
-      v.w = (qin && k3) ? v.w : 0.f;
-      *reinterpret_cast<float4*>(Bb + q * BK + ((st_slot ^ ((q >> 1) & 7)) << 2)) = v;
-    }
-  };
+  for (int j = 0; j < NQF; j++) {
+    const uint32_t q = st_row + 32 * j;
+    voff_b[j] = (q < nq_t ? q : nq_t - 1) * (uint32_t)a.q_stride * 4u + (uint32_t)st_slot * 16u;  // padded slots repeat a query
+  }
+  // (macros, not lambdas: hipcc does not always promote arrays captured by a lambda to registers)
+#define VDB_GEMM_GLOAD() do { \
+    if (FULL) { \
+ \
+      const unsigned char* base_a = reinterpret_cast<const unsigned char*>(a.rows) + \
+                                    ((size_t)ld_rt * BM * a.row_stride + (size_t)ld_kt * BK) * 4; \
+      const unsigned char* base_b = reinterpret_cast<const unsigned char*>(queries) + (size_t)ld_kt * BK * 4; \
+_Pragma("unroll") \
+      for (int j = 0; j < 4; j++) \
+        ra[j] = ld4(reinterpret_cast<const float*>(base_a + (size_t)(32 * j) * a.row_stride * 4 + voff_a)); \
+_Pragma("unroll") \
+      for (int j = 0; j < NQF; j++) rb[j] = ld4(reinterpret_cast<const float*>(base_b + voff_b[j])); \
+    } else { \
+      const uint32_t kf = ld_kt * BK + st_slot * 4; \
+      const bool kin = kf < (uint32_t)a.row_stride; \
+      const uint32_t kfa = kin ? kf : 0u; \
+_Pragma("unroll") \
+      for (int j = 0; j < 4; j++) { \
+        uint32_t row = ld_rt * BM + st_row + 32 * j; \
+        row = row < a.n_rows ? row : a.n_rows - 1; \
+        ra[j] = ld4(a.rows + (size_t)row * a.row_stride + kfa); \
+      } \
+_Pragma("unroll") \
+      for (int j = 0; j < NQF; j++) { \
+        const uint32_t q = st_row + 32 * j; \
+        const float* qp = queries + (size_t)(q < nq_t ? q : 0u) * a.q_stride; \
+        if (QVEC) { \
+          rb[j] = ld4(qp + (kf < a.dim ? kf : 0u)); \
+        } else { \
+          const uint32_t dl = a.dim - 1; \
+          rb[j] = make_float4(qp[min(kf, dl)], qp[min(kf + 1, dl)], qp[min(kf + 2, dl)], qp[min(kf + 3, dl)]); \
+        } \
+      } \
+      pend_kf = kf; \
+    } \
+    if (++ld_kt == ga.KT) { \
+      ld_kt = 0; \
+      ld_rt += ga.G; \
+    } \
+  } while (0)
+  // staging writes: rows 32 apart share the swizzle term: one address + immediate offsets
+  unsigned char* const st_wr_a = reinterpret_cast<unsigned char*>(As) + st_row * (BK * 4) + ((st_slot ^ ((st_row >> 1) & 7)) << 4);
+  unsigned char* const st_wr_b = reinterpret_cast<unsigned char*>(Bs) + st_row * (BK * 4) + ((st_slot ^ ((st_row >> 1) & 7)) << 4);
+#define VDB_GEMM_LDS_STORE() do { \
+    if (FULL) { \
+_Pragma("unroll") \
+      for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4*>(st_wr_a + j * (32 * BK * 4)) = f32x4{ra[j].x, ra[j].y, ra[j].z, ra[j].w}; \
+_Pragma("unroll") \
+      for (int j = 0; j < NQF; j++) *reinterpret_cast<f32x4*>(st_wr_b + j * (32 * BK * 4)) = f32x4{rb[j].x, rb[j].y, rb[j].z, rb[j].w}; \
+    } else { \
+    const bool kin = pend_kf < (uint32_t)a.row_stride; \
+    const bool k0 = pend_kf < a.dim, k1 = pend_kf + 1 < a.dim, k2 = pend_kf + 2 < a.dim, k3 = pend_kf + 3 < a.dim; \
+_Pragma("unroll") \
+    for (int j = 0; j < 4; j++) { \
+      float4 v = ra[j]; \
+      v.x = kin ? v.x : 0.f; \
+      v.y = kin ? v.y : 0.f; \
+      v.z = kin ? v.z : 0.f; \
+      v.w = kin ? v.w : 0.f; \
+      *reinterpret_cast<float4*>(st_wr_a + j * (32 * BK * 4)) = v; \
+    } \
+_Pragma("unroll") \
+    for (int j = 0; j < NQF; j++) { \
+      const int q = st_row + 32 * j; \
+      const bool qin = (uint32_t)q < nq_t; \
+      float4 v = rb[j]; \
+      v.x = (qin && k0) ? v.x : 0.f; \
+      v.y = (qin && k1) ? v.y : 0.f; \
+      v.z = (qin && k2) ? v.z : 0.f; \
+      v.w = (qin && k3) ? v.w : 0.f; \
+      *reinterpret_cast<float4*>(st_wr_b + j * (32 * BK * 4)) = v; \
+    } \
+    } \
+  } while (0)
 
   f32x4 acc[4][NQF];
+#ifdef VDB_GEMM_V_32X32
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  f32x16 acc32[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc32[j][e] = 0.f;
+#endif
 #pragma unroll
   for (int rf = 0; rf < 4; rf++)
 #pragma unroll
     for (int t = 0; t < NQF; t++) acc[rf][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- compaction of the candidate buffers this wave owns (queries wib, wib+4, ...) ----
-  auto compact = [&]() __attribute__((always_inline)) {
+  // `force`: every buffer holding more than k keys (overflow rounds, end of the sweep); otherwise only the
+  // buffers past the watermark — a query's k-th best then lags behind, which costs a few more (cheap) appends
+  // and saves most of the (expensive) compactions: ~4 per query and block instead of one per row tile.
+#ifdef VDB_GEMM_STATS
+  unsigned long long st_comp = 0, st_app = 0, st_fail = 0, st_rounds = 0;
+#endif
+  const uint32_t watermark = (k + CAP) / 2;
+  auto compact = [&](bool force) __attribute__((always_inline)) {
     // lane l looks at query wib + 4*l
     const uint32_t bq = (uint32_t)wib + 4u * (uint32_t)lane;
-    uint64_t need = __ballot(bq < nq_t && cnts[bq < (uint32_t)BN ? bq : 0] > k);
+    const uint32_t cq = bq < nq_t ? cnts[bq] : 0u;
+    uint64_t need = __ballot(cq > k && (force || cq >= watermark));
+    // 64 / CAP buffers per pass (CAP = 32: the two halves of the wave rank one buffer each): a lane holds one key
+    // and counts the smaller ones — the other keys come as LDS broadcast reads, four in flight (keys are unique)
+    const uint32_t per = 64u / CAP, li = (uint32_t)lane & (CAP - 1u), half = (uint32_t)lane / CAP;
     while (need) {
-      const int src = __ffsll((long long)need) - 1;
+      const int src0 = __ffsll((long long)need) - 1;
       need &= need - 1;
-      const uint32_t b = (uint32_t)wib + 4u * (uint32_t)src;
+      int src1 = src0;
+      if (per == 2 && need) {
+        src1 = __ffsll((long long)need) - 1;
+        need &= need - 1;
+      }
+      const bool active = half == 0 || src1 != src0;  // odd count: the second half idles
+      const uint32_t b = (uint32_t)wib + 4u * (uint32_t)(half ? src1 : src0);
+#ifdef VDB_GEMM_STATS
+      if (li == 0 && active) st_comp++;
+#endif
       const uint32_t n = min(cnts[b], CAP);
       uint64_t* cb = cand + (size_t)b * CAP;
-      const uint64_t key = (uint32_t)lane < n ? cb[lane] : kKeyInvalid;
+      const uint64_t key = (active && li < n) ? cb[li] : kKeyInvalid;
       uint32_t rank = 0;
-      for (uint32_t j = 0; j < n; j++) rank += (readlane64(key, (int)j) < key) ? 1u : 0u;  // keys are unique
-      if ((uint32_t)lane < n && rank < k) cb[rank] = key;
-      if ((uint32_t)lane < n && rank == k - 1) tauk[b] = key;
-      if (lane == 0) cnts[b] = k;
+      for (uint32_t j = 0; j < CAP; j += 4) {
+        uint64_t kj[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) kj[u] = cb[j + u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) rank += (j + u < n && kj[u] < key) ? 1u : 0u;
+      }
+      const bool mine = active && li < n;
+      if (mine && rank < k) cb[rank] = key;
+      if (mine && rank == k - 1) tauk[b] = key;
+      if (active && li == 0) cnts[b] = k;
     }
   };
 
+  // fragment read addresses: lane (i = l&15, kk = l>>4) reads slot (4m + kk) ^ ((i>>1)&7) of row i (+16 per fragment)
+  const int sw_i = ((lane & 15) >> 1) & 7;
+  const int rd_off = (lane & 15) * (BK * 4) + ((((lane >> 4) ^ sw_i) & 3) << 4);  // bits 0-1 of the slot
+  const int rd_x = (sw_i & 4) << 4;                                                // bit 2 of the slot, as byte 64
+  const unsigned char* a_rd = reinterpret_cast<const unsigned char*>(As) + wr * 64 * (BK * 4) + rd_off;
+  const unsigned char* b_rd = reinterpret_cast<const unsigned char*>(Bs) + wq * 16 * NQF * (BK * 4) + rd_off;
+  const int a_rd_x = rd_x, b_rd_x = rd_x;
+
+  // Two blocks share a CU (and each SIMD's matrix pipe).  Started together they stay in lockstep — identical work,
+  // round-robin MFMA issue — so their barrier / staging phases and their epilogues coincide and the pipe idles
+  // (66 % busy measured).  The phase offset between two such blocks is preserved from step to step, so the
+  // second half of the grid (dispatched behind the first, one block per CU each) starts about half a row tile
+  // late: its staging and epilogue phases then fall into the other block's multiply phases.  Speed only — no
+  // correctness depends on which blocks share a CU.
+  if (ga.stagger && ((ga.stagger_mode == 0 && bid >= gridDim.x / 2) || (ga.stagger_mode == 1 && (slot_id & 1u)) || (ga.stagger_mode == 2 && (bid & 1u)))) {
+    for (uint32_t i = 0; i < ga.stagger; i++) __builtin_amdgcn_s_sleep(127);
+  }
   if (total) {
-    gload();
-    lds_store();
+    VDB_GEMM_GLOAD();
+    VDB_GEMM_LDS_STORE();
   }
   __syncthreads();
   uint32_t kt = 0, rt = g;
+#ifdef VDB_GEMM_STATS
+  const long long t_start = clock64();
+  long long t_comp_s = 0, t_bar1_s = 0, t_store_s = 0, t_bar2_s = 0, n_steps = 0;
+  long long t_epi = 0, t_epi_first = 0, t_b1 = 0, t_filter = 0, t_finish = 0, t_compact = 0;
+#endif
   uint32_t token = 0;  // ++ per epilogue round, block-uniform: a value written to *ovf is never reused
   for (uint32_t it = 0; it < total; it++) {
     const bool more = it + 1 < total;
-    if (more) gload();
+#ifdef VDB_GEMM_STATS
+    const long long t_it0 = clock64();
+#endif
+#ifndef VDB_GEMM_ABL_NOLOAD
+    if (more) VDB_GEMM_GLOAD();
+#endif
+    // the row tile's norms travel one step ahead of its epilogue: register now, LDS in that step's staging phase.
+    // Loaded unconditionally every step (clamped address, L2 hit): a conditional load would make hipcc wait
+    // vmcnt(0) in front of the branch, i.e. for the tile loads just issued.
+    float vn_reg = 0.0f;
+    if (METRIC == kCosine) {
+      const uint32_t row = rt * BM + (uint32_t)(tid & (BM - 1));
+      vn_reg = a.norms[row < a.n_rows ? row : a.n_rows - 1];
+    }
+    const bool vn_step = METRIC == kCosine && kt + 2 == ga.KT;
+#ifndef VDB_GEMM_ABL_NOMFMA
     {  // ---- multiply k-tile `it` out of LDS ----
+      // rows 16 apart share the swizzle term, so the 4 / NQF fragment reads of a 16-deep group are one base +
+      // immediate offsets; the second group flips bit 2 of the slot = byte 64 of the (swizzled) address.
+      // Both groups are requested up front: the second one's LDS latency hides behind the first one's MFMAs.
+      float4 av[2][4], bv[2][NQF];
 #pragma unroll
       for (int m = 0; m < 2; m++) {
-        const int slot = m * 4 + (lane >> 4);
-        float4 av[4], bv[NQF];
 #pragma unroll
-        for (int rf = 0; rf < 4; rf++) {
-          const int row = wr * 64 + rf * 16 + (lane & 15);
-          av[rf] = ld4(As + row * BK + ((slot ^ ((row >> 1) & 7)) << 2));
-        }
+        for (int rf = 0; rf < 4; rf++) av[m][rf] = *reinterpret_cast<const float4*>(a_rd + ((m * 64) ^ a_rd_x) + rf * (16 * BK * 4));
 #pragma unroll
-        for (int t = 0; t < NQF; t++) {
-          const int q = wq * 16 * NQF + t * 16 + (lane & 15);
-          bv[t] = ld4(Bs + q * BK + ((slot ^ ((q >> 1) & 7)) << 2));
-        }
+        for (int t = 0; t < NQF; t++) bv[m][t] = *reinterpret_cast<const float4*>(b_rd + ((m * 64) ^ b_rd_x) + t * (16 * BK * 4));
+      }
+#ifdef VDB_GEMM_V_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef VDB_GEMM_V_32X32  // timing probe only (wrong numerics): same flops on v_mfma_f32_32x32x2_f32
+#pragma unroll
+      for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const float4 a4 = av[m][j & 3], b4 = bv[m][(j >> 1) % NQF];
+            const float ax = c == 0 ? a4.x : (c == 1 ? a4.y : (c == 2 ? a4.z : a4.w));
+            const float bx = c == 0 ? b4.x : (c == 1 ? b4.y : (c == 2 ? b4.z : b4.w));
+            acc32[j & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, acc32[j & 3], 0, 0, 0);
+          }
+#else
+#pragma unroll
+      for (int m = 0; m < 2; m++) {
 #pragma unroll
         for (int c = 0; c < 4; c++) {
 #pragma unroll
           for (int rf = 0; rf < 4; rf++) {
-            const float ax = c == 0 ? av[rf].x : (c == 1 ? av[rf].y : (c == 2 ? av[rf].z : av[rf].w));
+            const float ax = c == 0 ? av[m][rf].x : (c == 1 ? av[m][rf].y : (c == 2 ? av[m][rf].z : av[m][rf].w));
 #pragma unroll
             for (int t = 0; t < NQF; t++) {
-              const float bx = c == 0 ? bv[t].x : (c == 1 ? bv[t].y : (c == 2 ? bv[t].z : bv[t].w));
+              const float bx = c == 0 ? bv[m][t].x : (c == 1 ? bv[m][t].y : (c == 2 ? bv[m][t].z : bv[m][t].w));
               acc[rf][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bx, acc[rf][t], 0, 0, 0);
             }
           }
         }
       }
+#endif
+#ifdef VDB_GEMM_V_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
-    if (++kt < ga.KT) {
-      __syncthreads();  // every wave is done reading the tile
-      if (more) lds_store();
+#endif
+#ifdef VDB_GEMM_ABL_NOEPI
+    if (++kt == ga.KT) {
+#pragma unroll
+      for (int rf = 0; rf < 4; rf++)
+#pragma unroll
+        for (int t = 0; t < NQF; t++) asm volatile("" ::"v"(acc[rf][t]));
+#ifdef VDB_GEMM_V_32X32
+#pragma unroll
+      for (int j = 0; j < 4; j++) asm volatile("" ::"v"(acc32[j]));
+#endif
+      kt = 0;
+      rt += ga.G;
+    }
+    {
+      __syncthreads();
+      if (more) VDB_GEMM_LDS_STORE();
       __syncthreads();
       continue;
     }
+#endif
+    if (++kt < ga.KT) {
+#ifdef VDB_GEMM_STATS
+      {  // drain the matrix pipe first: the timestamp then marks the END of the multiply, not the end of its issue
+        float drain;
+        asm volatile("v_mov_b32 %0, %1\n\ts_nop 4" : "=v"(drain) : "v"(acc[3][NQF - 1][3]));
+        asm volatile("" ::"v"(drain));
+      }
+      const long long t_s0 = clock64();
+      t_comp_s += t_s0 - t_it0;
+#endif
+      __syncthreads();  // every wave is done reading the tile
+#ifdef VDB_GEMM_STATS
+      const long long t_s1 = clock64();
+#endif
+      if (more) VDB_GEMM_LDS_STORE();
+      if (vn_step && tid < BM) vns[tid] = vn_reg;
+#ifdef VDB_GEMM_STATS
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const long long t_s2 = clock64();
+#endif
+      __syncthreads();
+#ifdef VDB_GEMM_STATS
+      const long long t_s3 = clock64();
+      t_bar1_s += t_s1 - t_s0; t_store_s += t_s2 - t_s1; t_bar2_s += t_s3 - t_s2; n_steps++;
+#endif
+      continue;
+    }
     // ---- last k-tile of a row tile: epilogue = filter, exact finish, append; compaction between the barriers ----
-    uint64_t done = 0;  // bit (rf*NQF + t)*4 + r: element already appended (overflow rounds must not append twice)
-    for (bool first = true;; first = false) {
-      bool failed = false;
-      ++token;
-      float cut[NQF];
-      uint64_t tk[NQF];
+#ifdef VDB_GEMM_STATS
+    const long long t_e0 = clock64();
+#endif
+    __syncthreads();  // every wave is done reading the tile
+    if (more) VDB_GEMM_LDS_STORE();  // staging registers are dead from here on: the epilogue gets their 32 VGPRs
+#ifdef VDB_GEMM_STATS
+    long long t_p = clock64();
+    t_b1 += t_p - t_e0;
+#endif
+    // (1a) filter, branch-free: one bit per accumulator element in a per-lane 64-bit mask, element e = (rf*NQF + t)*4
+    //      + r shifted in at the bottom (so e = 63 - bit index ... see clz below).  Pass unless clearly below the
+    //      query's k-th best (16-ulp margin); cosine compares dot * (1/|v|) with cut * |q|: NaN / inf / zero-norm
+    //      cases compare false and go to the exact path; padded query slots get +inf (nothing passes).  Rows past
+    //      n_rows are weeded out by the dense pass (2).
+    uint32_t pm[2] = {0u, 0u};  // pm[0]: elements 0..31 (element e at bit 31 - e), pm[1]: elements 32..63
+    {
+      float cutq[NQF];
 #pragma unroll
       for (int t = 0; t < NQF; t++) {
         const uint32_t b = wq * 16 * NQF + t * 16 + (lane & 15);
-        tk[t] = tauk[b];
-        const float tf = tk[t] == kKeyInvalid ? __uint_as_float(0xFF800000u) : key_score<HIB>(tk[t]);
-        cut[t] = tf - (fabsf(tf) * 1.9073486e-6f + 1e-37f);
+        const uint64_t tkb = tauk[b];
+        const float tf = tkb == kKeyInvalid ? __uint_as_float(0xFF800000u) : key_score<HIB>(tkb);
+        const float cut = tf - (fabsf(tf) * 1.9073486e-6f + 1e-37f);
+        cutq[t] = b < nq_t ? (METRIC == kCosine ? cut * qn_t[t] : cut) : __uint_as_float(0x7F800000u);
       }
 #pragma unroll
       for (int rf = 0; rf < 4; rf++) {
-        __builtin_amdgcn_sched_barrier(0);  // one 16-row slab at a time: keeps the epilogue's live set small
-        const uint32_t rbase = rt * BM + wr * 64 + rf * 16 + 4 * (lane >> 4);
-        f32x4 vn;
+        f32x4 rvn = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (METRIC == kCosine) {
+          const f32x4 vn = *reinterpret_cast<const f32x4*>(vns + wr * 64 + rf * 16 + 4 * (lane >> 4));
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const uint32_t row = rbase + r;
-          vn[r] = (METRIC == kCosine) ? a.norms[row < a.n_rows ? row : a.n_rows - 1] : 1.0f;
+          for (int r = 0; r < 4; r++) rvn[r] = __builtin_amdgcn_rcpf(vn[r]);
         }
 #pragma unroll
         for (int t = 0; t < NQF; t++) {
-          const uint32_t b = wq * 16 * NQF + t * 16 + (lane & 15);
-          const f32x4 d = acc[rf][t];
-          // pass unless clearly below the k-th best; NaN / inf / zero-norm cases always pass to the exact path
-          bool pass[4];
-          bool any = false;
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const float rq = (METRIC == kCosine) ? __builtin_amdgcn_rcpf(qn_t[t] * vn[r]) : 1.0f;
-            pass[r] = !(d[r] * rq < cut[t]) && rbase + r < a.n_rows && b < nq_t &&
-                      !((done >> ((rf * NQF + t) * 4 + r)) & 1ull);
-            any |= pass[r];
-          }
-          if (__ballot(any) == 0) continue;
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            if (pass[r]) {
-              const uint32_t row = rbase + r;
-              float dv = d[r];
-              asm volatile("" : "+v"(dv));  // pins the exact finish + key packing inside the (rare) branch: hipcc
-                                            // otherwise speculates all 64 keys up front (128 VGPRs, spills)
-              const float score = finish_score<METRIC>(dv, qn_t[t], vn[r]);
-              const uint64_t key = make_key<HIB>(score, row);
-              bool take = key < tk[t];
-              if (take && a.alive) take = a.alive[row] != 0;  // soft-deleted rows are filtered where it is rare
-              if (take) {
-                const uint32_t idx = atomicAdd(&cnts[b], 1u);
-                if (idx < CAP) {
-                  cand[(size_t)b * CAP + idx] = key;
-                  done |= 1ull << ((rf * NQF + t) * 4 + r);
-                } else {
-                  failed = true;  // buffer full: compact, then offer again
-                }
-              } else {
-                done |= 1ull << ((rf * NQF + t) * 4 + r);
-              }
-            }
+            constexpr int kHalf = 32;
+            const int e = (rf * NQF + t) * 4 + r;
+            const bool pass = !((METRIC == kCosine ? acc[rf][t][r] * rvn[r] : acc[rf][t][r]) < cutq[t]);
+            pm[e / kHalf] = (pm[e / kHalf] << 1) | (pass ? 1u : 0u);
           }
         }
       }
+      // left-align both words: element e of a word sits at bit 31 - (e % 32)
+      constexpr int kElems = 16 * NQF;
+      if (kElems < 32) pm[0] <<= (32 - kElems);
+      if (kElems > 32 && kElems < 64) pm[1] <<= (64 - kElems);
+    }
+    uint32_t qcarry = 0;  // queue entries carried into the next round (their candidate buffer was full)
+    // per-lane part of a queue entry's low word: (row in tile) << 8 | query in tile, for rf = t = r = 0
+    const uint32_t lane_word = ((uint32_t)(wr * 64 + 4 * (lane >> 4)) << 8) | (uint32_t)(wq * 16 * NQF + (lane & 15));
+    for (;;) {
+      bool failed = false;
+      ++token;
+      // (1b) drain the masks into the wave's queue as raw (dot, row, query): every pass takes each lane's lowest
+      //      pending element (a 6-level select tree over the accumulators — no dynamic register indexing), slots
+      //      from ballot/mbcnt, plain LDS stores.  Passes = the largest number of survivors in one lane (3-4).
+      uint32_t qn_ent = qcarry;  // wave-uniform
+      for (;;) {
+        const bool has = (pm[0] | pm[1]) != 0u;
+        const uint64_t mh = __ballot(has);
+        if (mh == 0) break;
+        const uint32_t nh = (uint32_t)__popcll(mh);
+        if (qn_ent + nh > (uint32_t)kGemmQueue) {
+          failed = true;  // queue full: finish what is queued, then continue draining
+          break;
+        }
+        const bool lo = pm[0] != 0u;
+        const uint32_t word = lo ? pm[0] : pm[1];
+        const uint32_t lz = (uint32_t)__builtin_clz(word | 1u);  // element inside the word
+        const uint32_t e = lz + (lo ? 0u : 32u);
+        const uint32_t cleared = word & ~(0x80000000u >> lz);
+        if (has) {
+          if (lo) pm[0] = cleared; else pm[1] = cleared;
+        }
+        const float dv = select_acc<NQF>(acc, e);
+        // e = (rf*NQF + t)*4 + r
+        const uint32_t r = e & 3u, ft = e >> 2;
+        const uint32_t rf = NQF == 4 ? ft >> 2 : (NQF == 2 ? ft >> 1 : (ft * 11u) >> 5);  // ft / NQF for ft < 16
+        const uint32_t t = ft - rf * NQF;
+        const uint32_t slot = qn_ent + __builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u));
+        if (has) wqueue[slot] = ((uint64_t)__float_as_uint(dv) << 32) | (lane_word + (((rf * 16u + r) << 8) + t * 16u));
+        qn_ent += nh;
+      }
+#ifdef VDB_GEMM_STATS
+      { const long long t_n = clock64(); t_filter += t_n - t_p; t_p = t_n; }
+#endif
+      // (2) finish the queue densely, one entry per lane: exact score, key, candidate buffer of the entry's query
+      qcarry = 0;
+#pragma unroll 1
+      for (uint32_t c = 0; c * 64 < qn_ent; c++) {
+        // entries whose candidate buffer is full are re-queued at slot <= c*64 + lane: never ahead of the read position
+        const uint64_t ent1 = (c * 64 + lane) < qn_ent ? wqueue[c * 64 + lane] : kKeyInvalid;
+        const bool valid = ent1 != kKeyInvalid;
+        const uint32_t b = valid ? (uint32_t)ent1 & 0xFFu : 0u;
+        const uint32_t rl = valid ? ((uint32_t)ent1 >> 8) & 0xFFu : 0u;
+        const uint32_t row = rt * BM + rl;
+        const float dotv = __uint_as_float((uint32_t)(ent1 >> 32));
+        const float score = finish_score<METRIC>(dotv, qn[b], METRIC == kCosine ? vns[rl] : 1.0f);
+        const uint64_t key = make_key<HIB>(score, row);
+        bool take = valid & (b < nq_t) & (row < a.n_rows) & (key < tauk[b]);
+        if (take && a.alive) take = a.alive[row] != 0;  // soft-deleted rows are filtered where it is rare
+        bool full = false;
+        if (take) {
+          const uint32_t idx = atomicAdd(&cnts[b], 1u);
+          if (idx < CAP)
+            cand[(size_t)b * CAP + idx] = key;
+          else
+            full = true;  // candidate buffer full: keep the entry queued for the round after the compaction
+#ifdef VDB_GEMM_STATS
+          if (idx < CAP) st_app++; else st_fail++;
+#endif
+        }
+        const uint64_t mf = __ballot(full);
+        if (mf) {
+          const uint32_t slot = qcarry + __builtin_amdgcn_mbcnt_hi((uint32_t)(mf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mf, 0u));
+          if (full) wqueue[slot] = ent1;
+          qcarry += (uint32_t)__popcll(mf);
+          failed = true;
+        }
+      }
+#ifdef VDB_GEMM_STATS
+      { const long long t_n = clock64(); t_finish += t_n - t_p; t_p = t_n; }
+#endif
       if (failed) *ovf = token;
-      __syncthreads();  // barrier 1: tile reads done, appends visible
+#ifdef VDB_GEMM_STATS
+      if (tid == 0) st_rounds++;
+#endif
+      __syncthreads();  // appends visible
       const bool again = *ovf == token;
-      if (first && more) lds_store();
-      compact();
-      __syncthreads();  // barrier 2: next tile and the compacted lists visible
+      compact(again || !more);
+      __syncthreads();  // the compacted lists (and, first round, the next tile) visible
+#ifdef VDB_GEMM_STATS
+      { const long long t_n = clock64(); t_compact += t_n - t_p; t_p = t_n; }
+#endif
       if (!again) break;
     }
+#ifdef VDB_GEMM_STATS
+    {
+      const long long dt = clock64() - t_e0;
+      t_epi += dt;
+      if (rt == g) t_epi_first = dt;
+    }
+#endif
 #pragma unroll
     for (int rf = 0; rf < 4; rf++)
 #pragma unroll
@@ -335,6 +611,32 @@ __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) 
     kt = 0;
     rt += ga.G;
   }
+#ifdef VDB_GEMM_STATS
+  if (st_rounds) atomicAdd(&ga.stats[0], st_rounds);
+  if (st_app) atomicAdd(&ga.stats[1], st_app);
+  if (st_comp) atomicAdd(&ga.stats[2], st_comp);
+  if (st_fail) atomicAdd(&ga.stats[3], st_fail);
+  if (tid == 0) {
+    atomicAdd(&ga.stats[4], (unsigned long long)t_epi);
+    atomicAdd(&ga.stats[5], (unsigned long long)(clock64() - t_start));
+    atomicAdd(&ga.stats[6], (unsigned long long)t_epi_first);
+    atomicAdd(&ga.stats[7], (unsigned long long)t_b1);
+    atomicAdd(&ga.stats[8], (unsigned long long)t_filter);
+    atomicAdd(&ga.stats[9], (unsigned long long)t_finish);
+    atomicAdd(&ga.stats[10], (unsigned long long)t_compact);
+    atomicAdd(&ga.stats[11], (unsigned long long)t_comp_s);
+    atomicAdd(&ga.stats[12], (unsigned long long)t_bar1_s);
+    atomicAdd(&ga.stats[13], (unsigned long long)t_store_s);
+    atomicAdd(&ga.stats[14], (unsigned long long)t_bar2_s);
+    atomicAdd(&ga.stats[15], (unsigned long long)n_steps);
+  }
+  if (lane == 0) {
+    atomicAdd(&ga.stats[16 + wib * 4 + 0], (unsigned long long)t_comp_s);
+    atomicAdd(&ga.stats[16 + wib * 4 + 1], (unsigned long long)t_bar1_s);
+    atomicAdd(&ga.stats[16 + wib * 4 + 2], (unsigned long long)t_store_s);
+    atomicAdd(&ga.stats[16 + wib * 4 + 3], (unsigned long long)t_bar2_s);
+  }
+#endif
   __syncthreads();
   for (uint32_t b = wib; b < nq_t; b += 4) {
     const uint32_t c = min(cnts[b], k);  // <= k entries: whatever order (the merge kernel scans them all)
@@ -343,11 +645,14 @@ __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) 
   }
 }
 
+#undef VDB_GEMM_GLOAD
+#undef VDB_GEMM_LDS_STORE
+
 // ---- host side ---------------------------------------------------------------------------------
 uint32_t sweep_gemm_cap(uint32_t k) { return k <= 16 ? 32u : 64u; }  // candidate buffer entries per query
 size_t sweep_gemm_lds_bytes(int nqf, uint32_t k) {
   const size_t BN = (size_t)32 * nqf;
-  return ((size_t)kGemmBM * kGemmBK * 4 + BN * kGemmBK * 4 + BN * sweep_gemm_cap(k) * 8 + BN * 16 + 16 + 15) & ~(size_t)15;
+  return ((size_t)kGemmBM * kGemmBK * 4 + BN * kGemmBK * 4 + BN * sweep_gemm_cap(k) * 8 + BN * 16 + 16 + kGemmBM * 4 + (size_t)4 * kGemmQueue * 8 + 15) & ~(size_t)15;
 }
 
 void sweep_gemm_plan(uint32_t nq, uint32_t n_rows, int n_cus, uint32_t k, GemmPlan* p) {
@@ -356,7 +661,8 @@ void sweep_gemm_plan(uint32_t nq, uint32_t n_rows, int n_cus, uint32_t k, GemmPl
   p->nqf = (int)((p->qper + 31) / 32);
   if (p->nqf < 2) p->nqf = 2;
   p->lds = sweep_gemm_lds_bytes(p->nqf, k);
-  const int per_cu = p->lds * 2 <= 160 * 1024 ? 2 : 1;
+  int per_cu = p->lds * 2 <= 160 * 1024 ? 2 : 1;
+  if (const char* e = getenv("VDB_GEMM_PERCU")) per_cu = atoi(e);  // probe knob
   const uint32_t ntiles = (n_rows + kGemmBM - 1) / kGemmBM;
   uint32_t G = (uint32_t)std::max(1, n_cus * per_cu / (int)p->nqt);
   G = std::min(G, ntiles);
@@ -365,24 +671,24 @@ void sweep_gemm_plan(uint32_t nq, uint32_t n_rows, int n_cus, uint32_t k, GemmPl
   p->blocks = (int)(G * p->nqt);
 }
 
-template <int METRIC, int NQF, bool QVEC>
+template <int METRIC, int NQF, bool QVEC, bool FULL>
 static hipError_t launch_gemm_v(const GemmSweepArgs& ga, int blocks, size_t lds, hipStream_t st) {
   static bool done = false;
   if (lds > 64 * 1024 && !done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_gemm_f32<METRIC, NQF, QVEC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_gemm_f32<METRIC, NQF, QVEC, FULL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     done = true;
   }
-  hipLaunchKernelGGL((sweep_topk_gemm_f32<METRIC, NQF, QVEC>), dim3(blocks), dim3(256), lds, st, ga);
+  hipLaunchKernelGGL((sweep_topk_gemm_f32<METRIC, NQF, QVEC, FULL>), dim3(blocks), dim3(256), lds, st, ga);
   return hipGetLastError();
 }
 template <int METRIC, int NQF>
 static hipError_t launch_gemm_t(const GemmSweepArgs& ga, bool qvec, int blocks, size_t lds, hipStream_t st) {
-  return qvec ? launch_gemm_v<METRIC, NQF, true>(ga, blocks, lds, st)
-              : launch_gemm_v<METRIC, NQF, false>(ga, blocks, lds, st);
+  if (qvec && ga.s.dim % 128 == 0) return launch_gemm_v<METRIC, NQF, true, true>(ga, blocks, lds, st);
+  return qvec ? launch_gemm_v<METRIC, NQF, true, false>(ga, blocks, lds, st)
+              : launch_gemm_v<METRIC, NQF, false, false>(ga, blocks, lds, st);
 }
-
 hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, hipStream_t st) {
   GemmSweepArgs ga;
   ga.s = a;
@@ -391,6 +697,35 @@ hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, 
   ga.nqt = p.nqt;
   ga.qper = p.qper;
   ga.cap = sweep_gemm_cap(a.k);
+  {
+    const char* e = getenv("VDB_GEMM_STAGGER");  // probe knob; default: about half a row tile of one block running alone
+    const char* m = getenv("VDB_GEMM_STAGGER_MODE");
+    ga.stagger_mode = m ? (uint32_t)atoi(m) : 0u;
+    ga.stagger = e ? (uint32_t)atoi(e) : (p.lds * 2 <= 160 * 1024 ? ga.KT / 3 : 0u);
+  }
+#ifdef VDB_GEMM_STATS
+  static unsigned long long* d_stats = nullptr;
+  if (!d_stats) (void)hipMalloc(&d_stats, 256);
+  (void)hipMemsetAsync(d_stats, 0, 256, st);
+  ga.stats = d_stats;
+  struct Printer {
+    unsigned long long* d; hipStream_t st; uint32_t nq, blocks;
+    ~Printer() {
+      unsigned long long h[32];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h, d, 256, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[gemm stats] nq=%u blocks=%u rounds=%llu appends=%llu compactions=%llu failures=%llu | per block: "
+              "cycles=%.0f epilogue=%.0f (first tile %.0f) = barrier+store %.0f + filter %.0f + finish %.0f + sync/compact %.0f\n",
+              nq, blocks, h[0], h[1], h[2], h[3], (double)h[5] / blocks, (double)h[4] / blocks, (double)h[6] / blocks,
+              (double)h[7] / blocks, (double)h[8] / blocks, (double)h[9] / blocks, (double)h[10] / blocks);
+      fprintf(stderr, "[gemm stats] per regular step (wave 0): loads+multiply %.0f, barrier1 %.0f, wait+store %.0f, barrier2 %.0f cycles\n",
+              (double)h[11] / h[15], (double)h[12] / h[15], (double)h[13] / h[15], (double)h[14] / h[15]);
+      for (int w = 0; w < 4; w++)
+        fprintf(stderr, "[gemm stats]   wave %d: loads+multiply %.0f, barrier1 %.0f, wait+store %.0f, barrier2 %.0f\n", w,
+                (double)h[16 + w * 4] / h[15], (double)h[17 + w * 4] / h[15], (double)h[18 + w * 4] / h[15], (double)h[19 + w * 4] / h[15]);
+    }
+  } printer{d_stats, st, a.nq, (uint32_t)p.blocks};
+#endif
   // queries readable as aligned float4?
   const bool qvec = a.dim % 4 == 0 && a.q_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.queries) & 15) == 0;
   if (metric == kCosine) {

@@ -124,6 +124,7 @@ struct GemmPlan {
   int blocks;
   size_t lds;
 };
+constexpr uint64_t kRowSlack = 128;         // rows allocated past the capacity of the f32 row array (whole-tile reads)
 constexpr uint32_t kGemmMinQueries = 64;    // below this the streaming kernels (HBM-bound) are faster
 constexpr uint32_t kGemmMaxK = 48;          // candidate buffers hold <= 64 keys per query (one per lane when compacted)
 constexpr uint32_t kGemmMaxQueries = 1024;  // per launch (bounds the partial-list scratch)
