@@ -43,14 +43,15 @@ def parse():
     p.add_argument("--rows", type=int, default=1_000_000)
     p.add_argument("--dim", type=int, default=768)
     p.add_argument("--k", type=int, default=10)
-    p.add_argument("--batch", type=int, default=192, help="queries per step (exact sweep)")
+    p.add_argument("--batch", type=int, default=1024, help="queries per step (exact sweep)")
     p.add_argument("--metric", default="cosine")
     p.add_argument("--tile", type=int, default=128, help="largest query tile of the sweep (1,2,4,8,16,32,48; 128 = "
                    "batches of >= 64 queries go to the GEMM-structured matrix-core kernel)")
     p.add_argument("--engine", type=int, default=1, help="1 = matrix-core sweep for cosine/dot (default), 0 = VALU")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-rows", type=int, default=262_144)
-    p.add_argument("--cpu-sample-queries", type=int, default=32)
+    p.add_argument("--no-tiles", action="store_true", help="skip the per-tile-size table (profiling passes)")
+    p.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
     p.add_argument("--check-queries", type=int, default=2)
     # graph leg (configs[2])
     p.add_argument("--no-hnsw", action="store_true")
@@ -104,7 +105,7 @@ def main():
     host_sample = corpus[:sample_rows].cpu().numpy() if rank == 0 else None
     host_full = None
     if rank == 0 and a.check_queries > 0:
-        host_full = corpus.cpu().numpy()
+        host_full = host_sample if sample_rows == N else corpus.cpu().numpy()
     del corpus
     torch.cuda.empty_cache()
 
@@ -205,9 +206,21 @@ def main():
                     "note": "one corpus pass serves `queries_per_launch` queries, so HBM bytes per QUERY are "
                             "alg_bytes/queries_per_launch; `tiles` lists every tile size"}
 
+    # HBM traffic of the dominant kernel: FETCH_SIZE from the separate rocprofv3 --pmc pass of THIS command
+    # (tools/gpu_round_check.sh; corrected per MI355X_MICROARCH.md), committed as profiles/pmc_traffic.json
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pt = json.load(f)
+        ent = pt.get("kernels", {}).get(roofline["kernel"] + f"@{Q}")
+        if ent:
+            roofline["traffic"] = ent["fetch_bytes_per_launch"]
+            roofline["traffic_source"] = pt.get("source", "profiles/pmc_traffic.json")
+    except (OSError, ValueError):
+        pass
+
     # ---- the same sweep at every tile size (queries per corpus pass), both engines ----
     tiles = []
-    if rank == 0:
+    if rank == 0 and not a.no_tiles:
         plans = [(1, t) for t in (16, 32, 48, 64, 96, 128, 192, 256)] if a.metric in ("cosine", "dot") else []
         plans = [(1, 1)] + plans if plans else plans
         plans += [(0, t) for t in (1, 8, 16, 32)]
@@ -339,6 +352,15 @@ def main():
                              "kernel_ms": round(hk_ms, 4), "launches_timed": hk_n,
                              "alg_bytes_per_launch": hbytes,
                              "alg_bytes_rule": "n_dist*dim*4 + n_expand*M0*4, counters from the kernel"}}
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            ent = pt.get("kernels", {}).get(hnsw["roofline"]["kernel"] + "@hnsw")
+            if ent:
+                hnsw["roofline"]["traffic"] = ent["fetch_bytes_per_launch"]
+                hnsw["roofline"]["traffic_source"] = pt.get("source", "profiles/pmc_traffic.json")
+        except (OSError, ValueError):
+            pass
         if rank == 0 and not a.no_cpu_baseline:
             graph_dir = tempfile.mkdtemp(prefix="vdb_bench_")
             ix.save(graph_dir, "native_hnsw")
@@ -363,9 +385,16 @@ def main():
                      "ids_equal_reference_order": bool(np.array_equal(gi, ri)),
                      "max_rel_diff_vs_reference_order": float(np.max(np.abs(gs - rs) / np.abs(rs)))}
             recall = float(np.mean([len(set(gi[i].tolist()) & set(ri[i].tolist())) / K for i in range(nchk)]))
-            del host_full
+            host_full = None
         if not a.no_cpu_baseline:
-            sq = min(a.cpu_sample_queries, n_query_pool)
+            # bounded sample of the SAME workload: every host core, the first `sample_rows` rows (default: all of
+            # them), as many queries as fit ~cpu_seconds (calibrated on 2 queries per thread-chunk first)
+            cal = min(max(8, ncores // 8), n_query_pool)
+            qh = queries[:cal].cpu().numpy()
+            t3 = time.perf_counter()
+            po.scan_topk(om, host_sample, qh, K, po.MODE_R, nthreads=ncores)
+            cal_dt = time.perf_counter() - t3
+            sq = int(max(cal, min(n_query_pool, a.cpu_seconds / max(cal_dt / cal, 1e-6))))
             qh = queries[:sq].cpu().numpy()
             t3 = time.perf_counter()
             po.scan_topk(om, host_sample, qh, K, po.MODE_R, nthreads=ncores)
@@ -374,8 +403,8 @@ def main():
             cpu = {"value": round(cpu_qps_sample * sample_rows / N, 3), "unit": "queries/s", "cores": ncores,
                    "kind": "port",
                    "sample": f"oracle mode R (wide16 AVX2+FMA restatement of brute_force_search_parallel) on the first "
-                             f"{sample_rows} rows x {sq} queries, {ncores} threads, {cdt:.2f} s; value = measured "
-                             f"{cpu_qps_sample:.1f} q/s scaled by {sample_rows}/{N} to the full corpus",
+                             f"{sample_rows} of {N} rows x {sq} queries, {ncores} threads, {cdt:.2f} s; value = measured "
+                             f"{cpu_qps_sample:.1f} q/s x {sample_rows}/{N}",
                    "measured_qps_on_sample": round(cpu_qps_sample, 2)}
             if graph_dir is not None:
                 # the reference's graph search on the host cores, over the SAME graph (loaded from the files the

@@ -1,12 +1,13 @@
 set -x
 export TMPDIR=/tmp
+TAG=${TAG:-r01}
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r01c
-timeout 1500 python -m pytest tests -m gpu -x -q > $R/gpurun_out/r01c/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/gpurun_out/r01c/pytest_gpu.log
-tail -5 $R/gpurun_out/r01c/pytest_gpu.log
-timeout 900 python bench.py > $R/gpurun_out/r01c/bench_line.json 2> $R/gpurun_out/r01c/bench.err; echo "bench rc=$?"
-tail -c 3000 $R/gpurun_out/r01c/bench_line.json
+mkdir -p $R/gpurun_out/${TAG:-r01}
+timeout 1500 python -m pytest tests -m gpu -x -q > $R/gpurun_out/${TAG:-r01}/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/gpurun_out/${TAG:-r01}/pytest_gpu.log
+tail -5 $R/gpurun_out/${TAG:-r01}/pytest_gpu.log
+timeout 900 python bench.py > $R/gpurun_out/${TAG:-r01}/bench_line.json 2> $R/gpurun_out/${TAG:-r01}/bench.err; echo "bench rc=$?"
+tail -c 3000 $R/gpurun_out/${TAG:-r01}/bench_line.json
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r01c/prof -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --check-queries 0 > $R/gpurun_out/r01c/bench_under_rocprof.json 2> $R/gpurun_out/r01c/rocprof.err; echo "rocprof rc=$?"
-timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r01c/pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --check-queries 0 --hnsw-steps 1 > $R/gpurun_out/r01c/bench_under_pmc.json 2> $R/gpurun_out/r01c/pmc.err; echo "pmc rc=$?"
-find $R/gpurun_out/r01c -name "*.csv" | head -20
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG:-r01}/prof -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --check-queries 0 > $R/gpurun_out/${TAG:-r01}/bench_under_rocprof.json 2> $R/gpurun_out/${TAG:-r01}/rocprof.err; echo "rocprof rc=$?"
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG:-r01}/pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --check-queries 0 --hnsw-steps 1 --no-tiles > $R/gpurun_out/${TAG:-r01}/bench_under_pmc.json 2> $R/gpurun_out/${TAG:-r01}/pmc.err; echo "pmc rc=$?"
+find $R/gpurun_out/${TAG:-r01} -name "*.csv" | head -20
