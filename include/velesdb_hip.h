@@ -178,6 +178,14 @@ int32_t vdb_hip_batch_distance_dev(int32_t metric, int32_t kind, const float* d_
 int32_t vdb_hip_index_load_reference_files(vdb_hip_index* idx, const char* dir, const char* basename);
 int32_t vdb_hip_index_save_reference_files(vdb_hip_index* idx, const char* dir, const char* basename);
 
+/* HnswIndex::save / HnswIndex::load (index/hnsw/index/constructors.rs:190-287): a directory holding
+ * native_hnsw.{vectors,graph} (above), native_mappings.bin (bincode 1.3.3: id_to_idx map, idx_to_id map, next_idx) and
+ * native_meta.bin (bincode: dimension, metric, enable_vector_storage) — what a VelesDB collection keeps on disk for its
+ * HNSW index.  load_dir creates the index (dimension / metric from the meta file, M / ef_construction from the graph
+ * file, ids from the mappings; ids the reference removed are absent from the mappings and come back soft-deleted). */
+int32_t vdb_hip_index_save_dir(vdb_hip_index* idx, const char* dir);
+int32_t vdb_hip_index_load_dir(const char* dir, int32_t device, vdb_hip_index** out);
+
 /* ---- introspection used by tests and the bench ---- */
 /* neighbours of `node` on `layer`; returns count in *n, writes up to cap ids */
 int32_t vdb_hip_index_get_neighbors(vdb_hip_index* idx, uint32_t layer, uint64_t node, uint32_t* out,

@@ -525,3 +525,66 @@ def build_info():
 
 def cpu_has_avx512f():
     return bool(lib().vo_cpu_has_avx512f())
+
+
+# ---- HnswIndex::save / ::load directory (hnsw/index/constructors.rs:190-287) ---------------------------------
+# native_hnsw.{vectors,graph} come from NativeHnsw.file_dump above; the two small files beside them are bincode
+# 1.3.3 (Cargo.lock:393-396) with its default options: fixed-width little-endian integers, u64 lengths, usize as u64,
+# bool as one byte.  Pure-Python struct code: these files are tiny.
+def write_index_meta(directory, dim, metric, enable_vector_storage=True):
+    """(usize dimension, u8 metric, bool enable_vector_storage) — constructors.rs:273-283"""
+    import struct
+    with open(os.path.join(directory, "native_meta.bin"), "wb") as f:
+        f.write(struct.pack("<QBB", dim, metric, 1 if enable_vector_storage else 0))
+
+
+def read_index_meta(directory):
+    import struct
+    raw = open(os.path.join(directory, "native_meta.bin"), "rb").read()
+    dim, metric, storage = struct.unpack("<QBB", raw[:10])
+    if metric > 4:
+        raise OSError("Unknown distance metric")  # constructors.rs:211-216
+    return dim, metric, bool(storage)
+
+
+def write_index_mappings(directory, idx_to_id, next_idx=None):
+    """(HashMap<u64,usize> id_to_idx, HashMap<usize,u64> idx_to_id, usize next_idx) — constructors.rs:262-271.
+    `idx_to_id`: dict internal index -> external id of the LIVE entries (removed ids are absent from both maps,
+    sharded_mappings.rs:115-122); entries are written in dict order (any order is valid: hash-iteration order)."""
+    import struct
+    items = list(idx_to_id.items())
+    if next_idx is None:
+        next_idx = (max(idx_to_id) + 1) if idx_to_id else 0
+    with open(os.path.join(directory, "native_mappings.bin"), "wb") as f:
+        f.write(struct.pack("<Q", len(items)))
+        for idx, id_ in items:
+            f.write(struct.pack("<QQ", id_, idx))
+        f.write(struct.pack("<Q", len(items)))
+        for idx, id_ in items:
+            f.write(struct.pack("<QQ", idx, id_))
+        f.write(struct.pack("<Q", next_idx))
+
+
+def read_index_mappings(directory):
+    import struct
+    raw = open(os.path.join(directory, "native_mappings.bin"), "rb").read()
+    off = 0
+
+    def u64():
+        nonlocal off
+        v = struct.unpack_from("<Q", raw, off)[0]
+        off += 8
+        return v
+
+    id_to_idx = {}
+    for _ in range(u64()):
+        id_ = u64()
+        id_to_idx[id_] = u64()
+    idx_to_id = {}
+    for _ in range(u64()):
+        idx = u64()
+        idx_to_id[idx] = u64()
+    next_idx = u64()
+    if off != len(raw):
+        raise OSError("trailing bytes in native_mappings.bin")
+    return id_to_idx, idx_to_id, next_idx

@@ -156,3 +156,64 @@ def test_save_load_roundtrip_and_insert_after_load(tmp_path):
         g.insert(v)
         ix2.insert(400 + i, v)
     assert_same_graph(g, ix2, 550)
+
+
+@pytest.mark.parametrize("metric,pm", [(DM.Cosine, po.COSINE), (DM.Euclidean, po.EUCLIDEAN)])
+def test_index_directory_save_load_with_id_mappings(tmp_path, metric, pm):
+    # HnswIndex::save / ::load (constructors.rs:190-287): graph + vectors + bincode id mappings + bincode meta.
+    # (1) oracle-written directory (arbitrary external ids, some removed, shuffled map order) -> GPU load: same
+    #     results as the oracle index; (2) GPU save -> oracle reader: same maps / meta / graph; (3) GPU save ->
+    #     GPU load: same results.
+    rng = np.random.default_rng(33)
+    n, dim = 300, 32
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ext = (np.arange(n, dtype=np.uint64) * 7 + 1000)
+    oi = po.HnswIndex(dim, pm, po.MODE_C, M=8, ef_construction=60)
+    for i in range(n):
+        assert oi.insert(int(ext[i]), rows[i])
+    removed = [int(ext[i]) for i in (3, 77, 150, 299)]
+    for r in removed:
+        assert oi.remove(r)
+    d1 = tmp_path / "from_oracle"
+    d1.mkdir()
+    oi.graph.file_dump(str(d1), "native_hnsw")
+    live = {i: int(ext[i]) for i in range(n) if int(ext[i]) not in removed}
+    items = list(live.items())
+    rng.shuffle(items)
+    po.write_index_mappings(str(d1), dict(items), next_idx=n)
+    po.write_index_meta(str(d1), dim, pm, True)
+    gi = va.HnswIndex.load(str(d1), dim, metric)
+    assert gi.dimension() == dim and gi.metric() == metric
+    assert gi.len() == n - len(removed) and gi.node_count() == n
+    Q = rng.standard_normal((20, dim)).astype(np.float32)
+    for q in Q:
+        oid, osc = oi.search_with_quality(q, 10, po.Q_CUSTOM, 64, po.TIE_CANONICAL)
+        got = gi.search_with_quality(q, 10, SQ.Custom(64))
+        assert [g for g, _ in got] == oid.tolist()
+        assert np.array_equal(np.float32([s for _, s in got]).view(np.uint32), osc.view(np.uint32))
+        assert not ({g for g, _ in got} & set(removed))
+    # a removed id can be inserted again (it is simply unknown after the load), an existing one is ignored
+    assert not gi.remove(removed[0])
+    gi.insert(removed[0], rows[3])
+    gi.insert(int(ext[5]), rows[5])
+    assert gi.len() == n - len(removed) + 1
+    # (2) GPU save -> oracle reader
+    d2 = tmp_path / "from_gpu"
+    gi.save(str(d2))
+    assert po.read_index_meta(str(d2)) == (dim, pm, True)
+    a, b, nxt = po.read_index_mappings(str(d2))
+    want = dict(live)
+    want[n] = removed[0]
+    assert b == want and a == {v: k for k, v in want.items()} and nxt == n + 1
+    g2 = po.NativeHnsw.file_load(str(d2), "native_hnsw", pm, po.MODE_C)
+    g2.dim = dim
+    assert_same_graph(g2, gi, n + 1)
+    # (3) GPU save -> GPU load
+    gj = va.HnswIndex.load(str(d2))
+    assert gj.len() == gi.len()
+    for q in Q[:5]:
+        assert gj.search_with_quality(q, 10, SQ.Custom(64)) == gi.search_with_quality(q, 10, SQ.Custom(64))
+        assert gj.search_brute_force(q, 10) == gi.search_brute_force(q, 10)
+    # errors: missing files are an I/O status, not a crash
+    with pytest.raises(va.VelesHipError):
+        va.HnswIndex.load(str(tmp_path / "nowhere"))

@@ -228,4 +228,120 @@ int32_t vdb_hip_index_save_reference_files(vdb_hip_index* ix, const char* dir, c
   return VDB_OK;
 }
 
+
+// ---- HnswIndex::save / HnswIndex::load (index/hnsw/index/constructors.rs:190-287) --------------------------
+// A directory with
+//   native_hnsw.vectors / native_hnsw.graph   NativeHnsw::file_dump, format v1 (above)
+//   native_mappings.bin   bincode 1.3.3 (Cargo.lock:393-396), default options = fixed-width little-endian integers,
+//                         u64 sequence lengths: (HashMap<u64, usize> id_to_idx, HashMap<usize, u64> idx_to_id,
+//                         usize next_idx) -> len u64, (key u64, value u64)*, len u64, (key u64, value u64)*, u64.
+//                         Entry order is the writer's hash-iteration order and carries no meaning; removed ids are
+//                         simply absent from both maps (sharded_mappings.rs:115-122).
+//   native_meta.bin       (usize dimension, u8 metric, bool enable_vector_storage) -> u64, u8, u8
+// The loaded index keeps the vectors the .vectors file carries, so exact search stays exact after a load (the
+// reference comes back with an empty ShardedVectors and falls back to HNSW there, SURVEY 8a note 9).
+namespace {
+bool put_u64(FILE* f, uint64_t v) { return std::fwrite(&v, 8, 1, f) == 1; }
+bool get_u64(FILE* f, uint64_t* v) { return std::fread(v, 8, 1, f) == 1; }
+}  // namespace
+
+int32_t vdb_hip_index_save_dir(vdb_hip_index* ix, const char* dir) {
+  if (!ix || !dir) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  int32_t rc = vdb_hip_index_save_reference_files(ix, dir, "native_hnsw");
+  if (rc != VDB_OK) return rc;
+  std::lock_guard<std::mutex> g(ix->mu);
+  const std::string mp = std::string(dir) + "/native_mappings.bin";
+  FILE* f = std::fopen(mp.c_str(), "wb");
+  if (!f) return fail(VDB_ERR_IO, "cannot create " + mp);
+  bool ok = put_u64(f, ix->id_to_idx.size());
+  for (uint64_t idx = 0; idx < ix->n_rows && ok; idx++)  // ascending internal index: any order is valid bincode
+    if (ix->idx_live[idx]) ok = put_u64(f, ix->idx_to_id[idx]) && put_u64(f, idx);
+  ok = ok && put_u64(f, ix->id_to_idx.size());
+  for (uint64_t idx = 0; idx < ix->n_rows && ok; idx++)
+    if (ix->idx_live[idx]) ok = put_u64(f, idx) && put_u64(f, ix->idx_to_id[idx]);
+  ok = ok && put_u64(f, ix->n_rows);  // next_idx: one index per node ever inserted
+  std::fclose(f);
+  if (!ok) return fail(VDB_ERR_IO, "short write to " + mp);
+  const std::string tp = std::string(dir) + "/native_meta.bin";
+  f = std::fopen(tp.c_str(), "wb");
+  if (!f) return fail(VDB_ERR_IO, "cannot create " + tp);
+  const uint8_t metric = (uint8_t)ix->metric, storage = 1;
+  ok = put_u64(f, ix->dim) && std::fwrite(&metric, 1, 1, f) == 1 && std::fwrite(&storage, 1, 1, f) == 1;
+  std::fclose(f);
+  return ok ? VDB_OK : fail(VDB_ERR_IO, "short write to " + tp);
+}
+
+int32_t vdb_hip_index_load_dir(const char* dir, int32_t device, vdb_hip_index** out) {
+  if (!dir || !out) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  const std::string tp = std::string(dir) + "/native_meta.bin";
+  FILE* f = std::fopen(tp.c_str(), "rb");
+  if (!f) return fail(VDB_ERR_IO, "cannot open " + tp);
+  uint64_t dim = 0;
+  uint8_t metric = 0, storage = 0;
+  bool ok = get_u64(f, &dim) && std::fread(&metric, 1, 1, f) == 1 && std::fread(&storage, 1, 1, f) == 1;
+  std::fclose(f);
+  if (!ok || dim == 0 || dim > 0xFFFFFFFFull) return fail(VDB_ERR_IO, "bad " + tp);
+  if (metric > 4) return fail(VDB_ERR_IO, "Unknown distance metric");  // constructors.rs:211-216
+  vdb_hip_index* ix = nullptr;
+  int32_t rc = vdb_hip_index_create((uint32_t)dim, (int32_t)metric, 16, 200, 1024, device, &ix);  // M / efc: from the graph file
+  if (rc != VDB_OK) return rc;
+  rc = vdb_hip_index_load_reference_files(ix, dir, "native_hnsw");
+  if (rc != VDB_OK) {
+    vdb_hip_index_destroy(ix);
+    return rc;
+  }
+  const std::string mp = std::string(dir) + "/native_mappings.bin";
+  f = std::fopen(mp.c_str(), "rb");
+  if (!f) {
+    vdb_hip_index_destroy(ix);
+    return fail(VDB_ERR_IO, "cannot open " + mp);
+  }
+  uint64_t count = 0;
+  (void)vdb_hip_index_node_count(ix, &count);
+  std::vector<uint64_t> ids(count, 0);
+  std::vector<uint8_t> live(count, 0);
+  std::unordered_map<uint64_t, uint64_t> id_to_idx;
+  uint64_t n1 = 0, n2 = 0, next_idx = 0;
+  ok = get_u64(f, &n1) && n1 <= count;
+  for (uint64_t i = 0; i < n1 && ok; i++) {
+    uint64_t id = 0, idx = 0;
+    ok = get_u64(f, &id) && get_u64(f, &idx) && idx < count;
+    if (ok) id_to_idx[id] = idx;
+  }
+  ok = ok && get_u64(f, &n2) && n2 <= count;
+  for (uint64_t i = 0; i < n2 && ok; i++) {
+    uint64_t id = 0, idx = 0;
+    ok = get_u64(f, &idx) && get_u64(f, &id) && idx < count;
+    if (ok) {
+      ids[idx] = id;
+      live[idx] = 1;
+    }
+  }
+  ok = ok && get_u64(f, &next_idx);
+  std::fclose(f);
+  // the two maps must be inverse of each other (they are written from one registry)
+  if (ok) ok = id_to_idx.size() == n1 && n1 == n2;
+  for (auto it = id_to_idx.begin(); ok && it != id_to_idx.end(); ++it) ok = live[it->second] && ids[it->second] == it->first;
+  if (!ok) {
+    vdb_hip_index_destroy(ix);
+    return fail(VDB_ERR_IO, "bad " + mp);
+  }
+  std::lock_guard<std::mutex> g(ix->mu);
+  ix->id_to_idx.swap(id_to_idx);
+  ix->idx_to_id = ids;
+  ix->idx_live = live;
+  ix->live = n1;
+  ix->any_dead = n1 != count;
+  hipError_t e = hipSuccess;
+  if (count) {
+    e = hipMemcpyAsync(ix->ext_ids.p, ids.data(), count * 8, hipMemcpyHostToDevice, ix->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ix->alive.p, live.data(), count, hipMemcpyHostToDevice, ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+  }
+  if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("mappings upload: ") + hipGetErrorString(e));  // (index leaked on a device error)
+  *out = ix;
+  return VDB_OK;
+}
+
 }  // extern "C"

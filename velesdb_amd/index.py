@@ -11,6 +11,7 @@ All compute happens in libvelesdb_hip.so; this file only marshals numpy buffers.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -280,9 +281,30 @@ class HnswIndex:
     def set_searching_mode(self) -> None:  # search.rs:380-384: no-op for the native engine
         pass
 
-    def save(self, directory: str, basename: str = "native_hnsw") -> None:
-        """Graph + vectors in the reference's format v1 (backend_adapter.rs:184-261)."""
-        check(lib().vdb_hip_index_save_reference_files(self._h, directory.encode(), basename.encode()))
+    def save(self, directory: str, basename: Optional[str] = None) -> None:
+        """HnswIndex::save (constructors.rs:255-287): native_hnsw.{vectors,graph} + native_mappings.bin +
+        native_meta.bin in `directory`.  With a `basename`: only the graph + vector files under that name
+        (NativeHnsw::file_dump, backend_adapter.rs:184-261)."""
+        os.makedirs(directory, exist_ok=True)
+        if basename is None:
+            check(lib().vdb_hip_index_save_dir(self._h, directory.encode()))
+        else:
+            check(lib().vdb_hip_index_save_reference_files(self._h, directory.encode(), basename.encode()))
+
+    @classmethod
+    def load(cls, directory: str, dimension: int = 0, metric: Optional[DistanceMetric] = None, device: int = 0):
+        """HnswIndex::load (constructors.rs:190-253); dimension / metric are read from the metadata file, the
+        arguments exist for API compatibility like the reference's."""
+        h = C.c_void_p()
+        check(lib().vdb_hip_index_load_dir(directory.encode(), device, C.byref(h)))
+        self = cls.__new__(cls)
+        self._h = h
+        d, m = C.c_uint32(0), C.c_int32(0)
+        check(lib().vdb_hip_index_dimension(h, C.byref(d)))
+        check(lib().vdb_hip_index_metric(h, C.byref(m)))
+        self._dimension, self._metric = int(d.value), DistanceMetric(m.value)
+        self.params = HnswParams.auto(self._dimension)
+        return self
 
     def load_reference_files(self, directory: str, basename: str = "native_hnsw") -> None:
         check(lib().vdb_hip_index_load_reference_files(self._h, directory.encode(), basename.encode()))
