@@ -135,6 +135,22 @@ def _declare(L):
     L.vo_dual_search_int8.argtypes = [vp, _u8p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _u64p,
                                       _f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.vo_round_bf16.restype, L.vo_round_bf16.argtypes = None, [_f32p, _f32p, C.c_uint64]
+    _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+    L.vo_binary_quantize.restype, L.vo_binary_quantize.argtypes = None, [_f32p, C.c_uint32, _u8p]
+    L.vo_binary_hamming.restype, L.vo_binary_hamming.argtypes = C.c_uint32, [_u8p, _u8p, C.c_uint32]
+    L.vo_sq8_quantize.restype = None
+    L.vo_sq8_quantize.argtypes = [_f32p, C.c_uint32, _u8p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.vo_sq8_dequantize.restype, L.vo_sq8_dequantize.argtypes = None, [_u8p, C.c_float, C.c_float, C.c_uint32, _f32p]
+    L.vo_sq8_dot.restype, L.vo_sq8_dot.argtypes = C.c_float, [_f32p, _u8p, C.c_float, C.c_float, C.c_uint32]
+    L.vo_sq8_l2sq.restype, L.vo_sq8_l2sq.argtypes = C.c_float, [_f32p, _u8p, C.c_float, C.c_float, C.c_uint32, C.c_int]
+    L.vo_sq8_cosine.restype, L.vo_sq8_cosine.argtypes = C.c_float, [_f32p, _u8p, C.c_float, C.c_float, C.c_uint32, C.c_int]
+    L.vo_sq8_norm_sq.restype, L.vo_sq8_norm_sq.argtypes = C.c_float, [_u8p, C.c_float, C.c_float, C.c_uint32]
+    L.vo_scan_topk_sq8.restype = None
+    L.vo_scan_topk_sq8.argtypes = [C.c_int, _f32p, C.c_uint64, C.c_uint32, _f32p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                   np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS"), _f32p]
+    L.vo_scan_topk_binary.restype = None
+    L.vo_scan_topk_binary.argtypes = [_f32p, C.c_uint64, C.c_uint32, _f32p, C.c_uint32, C.c_uint32,
+                                      np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS"), _f32p]
     L.vo_scan_topk_bf16.restype = None
     L.vo_scan_topk_bf16.argtypes = [C.c_int, _f32p, C.c_uint64, C.c_uint32, _f32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                     _u64p, _f32p]
@@ -588,3 +604,122 @@ def read_index_mappings(directory):
     if off != len(raw):
         raise OSError("trailing bytes in native_mappings.bin")
     return id_to_idx, idx_to_id, next_idx
+
+
+# ---- storage modes (core/quantization.rs) ---------------------------------------------------------------------
+class BinaryQuantizedVector:
+    """quantization.rs:48-202 — sign bits (x >= 0.0), LSB-first in bytes"""
+
+    def __init__(self, data: np.ndarray, dimension: int):
+        self.data, self.dimension = np.ascontiguousarray(data, dtype=np.uint8), int(dimension)
+
+    @classmethod
+    def from_f32(cls, vector):
+        v = _f(vector).reshape(-1)
+        assert v.size > 0, "Cannot quantize empty vector"
+        out = np.empty((v.size + 7) // 8, dtype=np.uint8)
+        lib().vo_binary_quantize(v, v.size, out)
+        return cls(out, v.size)
+
+    def memory_size(self):
+        return int(self.data.size)
+
+    def get_bits(self):
+        return [bool((self.data[i // 8] >> (i % 8)) & 1) for i in range(self.dimension)]
+
+    def hamming_distance(self, other):
+        return int(lib().vo_binary_hamming(self.data, other.data, self.data.size))
+
+    def hamming_similarity(self, other):
+        return float(np.float32(1.0) - np.float32(self.hamming_distance(other)) / np.float32(self.dimension))
+
+    def to_bytes(self):  # u32 LE dimension + data (:155-169)
+        return int(self.dimension).to_bytes(4, "little") + self.data.tobytes()
+
+    @classmethod
+    def from_bytes(cls, raw):
+        if len(raw) < 4:
+            raise OSError("Not enough bytes for BinaryQuantizedVector header")
+        dim = int.from_bytes(raw[:4], "little")
+        n = (dim + 7) // 8
+        if len(raw) < 4 + n:
+            raise OSError("Not enough bytes for BinaryQuantizedVector data")
+        return cls(np.frombuffer(raw[4:4 + n], dtype=np.uint8).copy(), dim)
+
+
+class QuantizedVector:
+    """quantization.rs:204-316 — SQ8 with per-vector min / max"""
+
+    def __init__(self, data, mn, mx):
+        self.data = np.ascontiguousarray(data, dtype=np.uint8)
+        self.min, self.max = np.float32(mn), np.float32(mx)
+
+    @classmethod
+    def from_f32(cls, vector):
+        v = _f(vector).reshape(-1)
+        assert v.size > 0, "Cannot quantize empty vector"
+        data = np.empty(v.size, dtype=np.uint8)
+        mn, mx = C.c_float(0), C.c_float(0)
+        lib().vo_sq8_quantize(v, v.size, data, C.byref(mn), C.byref(mx))
+        return cls(data, mn.value, mx.value)
+
+    def dimension(self):
+        return int(self.data.size)
+
+    def memory_size(self):
+        return int(self.data.size) + 8
+
+    def to_f32(self):
+        out = np.empty(self.data.size, dtype=np.float32)
+        lib().vo_sq8_dequantize(self.data, self.min, self.max, self.data.size, out)
+        return out
+
+    def to_bytes(self):  # min, max f32 LE + data (:289-295)
+        return np.float32(self.min).tobytes() + np.float32(self.max).tobytes() + self.data.tobytes()
+
+    @classmethod
+    def from_bytes(cls, raw):
+        if len(raw) < 8:
+            raise OSError("Not enough bytes for QuantizedVector header")
+        mn, mx = np.frombuffer(raw[:8], dtype=np.float32)
+        return cls(np.frombuffer(raw[8:], dtype=np.uint8).copy(), mn, mx)
+
+
+def dot_product_quantized(q, qv, simd=False):  # :322-345 / :410-469 (one summation order)
+    return float(lib().vo_sq8_dot(_f(q), qv.data, qv.min, qv.max, qv.data.size))
+
+
+def euclidean_squared_quantized(q, qv, simd=False):  # :349-374 / :473-518
+    return float(lib().vo_sq8_l2sq(_f(q), qv.data, qv.min, qv.max, qv.data.size, 1 if simd else 0))
+
+
+def cosine_similarity_quantized(q, qv, simd=False):  # :380-395 / :524-554
+    return float(lib().vo_sq8_cosine(_f(q), qv.data, qv.min, qv.max, qv.data.size, 1 if simd else 0))
+
+
+def sq8_norm_sq(qv):
+    return float(lib().vo_sq8_norm_sq(qv.data, qv.min, qv.max, qv.data.size))
+
+
+def scan_topk_sq8(metric, rows, queries, k, nthreads=1):
+    """exact top-k of f32 queries over the SQ8 codes of `rows` with the *_simd distance functions"""
+    rows, queries = _f(rows), _f(queries)
+    if queries.ndim == 1:
+        queries = queries.reshape(1, -1)
+    nq = queries.shape[0]
+    ids = np.zeros((nq, k), dtype=np.uint64)
+    sc = np.zeros((nq, k), dtype=np.float32)
+    lib().vo_scan_topk_sq8(metric, rows, rows.shape[0], rows.shape[1], queries, nq, k, nthreads, ids, sc)
+    return ids, sc
+
+
+def scan_topk_binary(rows, queries, k):
+    """exact top-k by Hamming distance between the sign-bit codes"""
+    rows, queries = _f(rows), _f(queries)
+    if queries.ndim == 1:
+        queries = queries.reshape(1, -1)
+    nq = queries.shape[0]
+    ids = np.zeros((nq, k), dtype=np.uint64)
+    sc = np.zeros((nq, k), dtype=np.float32)
+    lib().vo_scan_topk_binary(rows, rows.shape[0], rows.shape[1], queries, nq, k, ids, sc)
+    return ids, sc

@@ -1786,6 +1786,217 @@ void vo_scan_topk_bf16(int metric, const float* rows, uint64_t nrows, uint32_t d
 }
 
 int vo_cpu_has_avx512f(void) { return __builtin_cpu_supports("avx512f") ? 1 : 0; }
+// =============================================================================================
+// Storage modes (core/quantization.rs): BinaryQuantizedVector (sign bits) and QuantizedVector (SQ8, per-vector
+// min/max) + the asymmetric f32-query x SQ8 distances.  Rust never contracts a*b+c, and this file is built with
+// -ffp-contract=off: every operation below is one IEEE rounding, in the order the Rust code performs it.
+// (f32 `Iterator::sum` folds left to right; it is restated from +0.0 — a start of -0.0, as newer std versions use,
+// differs only for an all-negative-zero sequence.)
+// =============================================================================================
+// BinaryQuantizedVector::from_f32 — quantization.rs:68-86: bit i = (v[i] >= 0.0), byte i/8, bit i%8
+void vo_binary_quantize(const float* v, uint32_t dim, uint8_t* out) {
+  const uint32_t nb = (dim + 7) / 8;
+  for (uint32_t b = 0; b < nb; b++) out[b] = 0;
+  for (uint32_t i = 0; i < dim; i++)
+    if (v[i] >= 0.0f) out[i / 8] |= (uint8_t)(1u << (i % 8));
+}
+// BinaryQuantizedVector::hamming_distance — quantization.rs:123-135
+uint32_t vo_binary_hamming(const uint8_t* a, const uint8_t* b, uint32_t nbytes) {
+  uint32_t d = 0;
+  for (uint32_t i = 0; i < nbytes; i++) d += (uint32_t)__builtin_popcount((unsigned)(a[i] ^ b[i]));
+  return d;
+}
+// QuantizedVector::from_f32 — quantization.rs:229-255
+void vo_sq8_quantize(const float* v, uint32_t dim, uint8_t* data, float* out_min, float* out_max) {
+  float mn = std::numeric_limits<float>::infinity(), mx = -std::numeric_limits<float>::infinity();
+  for (uint32_t i = 0; i < dim; i++) {  // f32::min / f32::max: a NaN operand yields the other one
+    mn = std::fmin(mn, v[i]);
+    mx = std::fmax(mx, v[i]);
+  }
+  const float range = mx - mn;
+  if (range < std::numeric_limits<float>::epsilon()) {
+    for (uint32_t i = 0; i < dim; i++) data[i] = 128;
+  } else {
+    const float scale = 255.0f / range;
+    for (uint32_t i = 0; i < dim; i++) {
+      const float normalized = (v[i] - mn) * scale;
+      float r = std::round(normalized);  // f32::round: half away from zero
+      r = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);  // clamp(0.0, 255.0); NaN `as u8` saturates to 0
+      data[i] = std::isnan(r) ? 0 : (uint8_t)r;
+    }
+  }
+  *out_min = mn;
+  *out_max = mx;
+}
+// QuantizedVector::to_f32 — quantization.rs:261-273
+void vo_sq8_dequantize(const uint8_t* data, float mn, float mx, uint32_t dim, float* out) {
+  const float range = mx - mn;
+  if (range < std::numeric_limits<float>::epsilon()) {
+    for (uint32_t i = 0; i < dim; i++) out[i] = mn;
+  } else {
+    const float scale = range / 255.0f;
+    for (uint32_t i = 0; i < dim; i++) out[i] = (float)data[i] * scale + mn;
+  }
+}
+// dot_product_quantized (:322-345) and dot_product_quantized_simd (:410-469): the same left-to-right sum
+float vo_sq8_dot(const float* q, const uint8_t* data, float mn, float mx, uint32_t dim) {
+  const float range = mx - mn;
+  if (range < std::numeric_limits<float>::epsilon()) {
+    float s = 0.0f;
+    for (uint32_t i = 0; i < dim; i++) s += q[i];
+    return s * mn;
+  }
+  const float scale = range / 255.0f, offset = mn;
+  float sum = 0.0f;
+  for (uint32_t i = 0; i < dim; i++) {
+    const float dequant = (float)data[i] * scale + offset;
+    sum += q[i] * dequant;
+  }
+  return sum;
+}
+// euclidean_squared_quantized (:349-374, simd = 0) / euclidean_squared_quantized_simd (:473-518, simd = 1)
+float vo_sq8_l2sq(const float* q, const uint8_t* data, float mn, float mx, uint32_t dim, int simd) {
+  const float range = mx - mn;
+  if (range < std::numeric_limits<float>::epsilon()) {
+    float s = 0.0f;
+    for (uint32_t i = 0; i < dim; i++) {
+      const float d = q[i] - mn;
+      s += d * d;  // powi(2)
+    }
+    return s;
+  }
+  const float scale = range / 255.0f, offset = mn;
+  float sum = 0.0f;
+  if (!simd) {
+    for (uint32_t i = 0; i < dim; i++) {
+      const float dequantized = (float)data[i] * scale + offset;
+      const float d = q[i] - dequantized;
+      sum += d * d;
+    }
+    return sum;
+  }
+  const uint32_t chunks = dim / 4;
+  for (uint32_t c = 0; c < chunks; c++) {
+    const uint32_t b = c * 4;
+    const float d0 = (float)data[b] * scale + offset, d1 = (float)data[b + 1] * scale + offset;
+    const float d2 = (float)data[b + 2] * scale + offset, d3 = (float)data[b + 3] * scale + offset;
+    const float f0 = q[b] - d0, f1 = q[b + 1] - d1, f2 = q[b + 2] - d2, f3 = q[b + 3] - d3;
+    sum += f0 * f0 + f1 * f1 + f2 * f2 + f3 * f3;  // ((f0^2 + f1^2) + f2^2) + f3^2, then += (:507)
+  }
+  for (uint32_t i = chunks * 4; i < dim; i++) {
+    const float dequant = (float)data[i] * scale + offset;
+    const float d = q[i] - dequant;
+    sum += d * d;
+  }
+  return sum;
+}
+// cosine_similarity_quantized (:380-395, simd = 0) / cosine_similarity_quantized_simd (:524-554, simd = 1)
+float vo_sq8_cosine(const float* q, const uint8_t* data, float mn, float mx, uint32_t dim, int simd) {
+  const float dot = vo_sq8_dot(q, data, mn, mx, dim);
+  const float eps = std::numeric_limits<float>::epsilon();
+  if (!simd) {
+    float qs = 0.0f;
+    for (uint32_t i = 0; i < dim; i++) qs += q[i] * q[i];
+    const float query_norm = std::sqrt(qs);
+    std::vector<float> rec(dim);
+    vo_sq8_dequantize(data, mn, mx, dim, rec.data());
+    float vs = 0.0f;
+    for (uint32_t i = 0; i < dim; i++) vs += rec[i] * rec[i];
+    const float quantized_norm = std::sqrt(vs);
+    if (query_norm < eps || quantized_norm < eps) return 0.0f;
+    return dot / (query_norm * quantized_norm);
+  }
+  float query_norm_sq = 0.0f;
+  for (uint32_t i = 0; i < dim; i++) query_norm_sq += q[i] * q[i];
+  const float range = mx - mn;
+  const float scale = range < eps ? 0.0f : range / 255.0f;
+  float quantized_norm_sq = 0.0f;
+  for (uint32_t i = 0; i < dim; i++) {
+    const float dequant = (float)data[i] * scale + mn;
+    quantized_norm_sq += dequant * dequant;
+  }
+  const float denom = std::sqrt(query_norm_sq * quantized_norm_sq);
+  if (denom < eps) return 0.0f;
+  return dot / denom;
+}
+// quantized_norm_sq of cosine_similarity_quantized_simd alone (what the GPU keeps per row)
+float vo_sq8_norm_sq(const uint8_t* data, float mn, float mx, uint32_t dim) {
+  const float eps = std::numeric_limits<float>::epsilon();
+  const float range = mx - mn;
+  const float scale = range < eps ? 0.0f : range / 255.0f;
+  float s = 0.0f;
+  for (uint32_t i = 0; i < dim; i++) {
+    const float dequant = (float)data[i] * scale + mn;
+    s += dequant * dequant;
+  }
+  return s;
+}
+// exact top-k of f32 queries over SQ8 rows with the *_simd functions (cosine / dot: best = largest; Euclidean:
+// squared distance, best = smallest); ties by row index.  `rows` are quantised here with vo_sq8_quantize.
+void vo_scan_topk_sq8(int metric, const float* rows, uint64_t nrows, uint32_t dim, const float* queries, uint32_t nq,
+                      uint32_t k, uint32_t nthreads, uint64_t* out_rows, float* out_scores) {
+  std::vector<uint8_t> codes((size_t)nrows * dim);
+  std::vector<float> mn(nrows), mx(nrows);
+  for (uint64_t r = 0; r < nrows; r++)
+    vo_sq8_quantize(rows + (size_t)r * dim, dim, codes.data() + (size_t)r * dim, &mn[r], &mx[r]);
+  const bool hib = metric != VO_EUCLIDEAN;
+  if (nthreads < 1) nthreads = 1;
+  std::atomic<uint32_t> next(0);
+  auto worker = [&]() {
+    std::vector<std::pair<float, uint64_t>> sc(nrows);
+    for (;;) {
+      const uint32_t qi = next.fetch_add(1);
+      if (qi >= nq) break;
+      const float* q = queries + (size_t)qi * dim;
+      for (uint64_t r = 0; r < nrows; r++) {
+        const uint8_t* d = codes.data() + (size_t)r * dim;
+        float s;
+        if (metric == VO_COSINE)
+          s = vo_sq8_cosine(q, d, mn[r], mx[r], dim, 1);
+        else if (metric == VO_EUCLIDEAN)
+          s = vo_sq8_l2sq(q, d, mn[r], mx[r], dim, 1);
+        else
+          s = vo_sq8_dot(q, d, mn[r], mx[r], dim);
+        sc[r] = {s, r};
+      }
+      const size_t kk = std::min<size_t>(k, nrows);
+      std::partial_sort(sc.begin(), sc.begin() + kk, sc.end(), [hib](const auto& a, const auto& b) {
+        int c = hib ? total_cmp(b.first, a.first) : total_cmp(a.first, b.first);
+        return c ? c < 0 : a.second < b.second;
+      });
+      for (size_t i = 0; i < kk; i++) {
+        out_rows[(size_t)qi * k + i] = sc[i].second;
+        out_scores[(size_t)qi * k + i] = sc[i].first;
+      }
+    }
+  };
+  if (nthreads == 1) {
+    worker();
+  } else {
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < nthreads; t++) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+  }
+}
+// exact top-k by BinaryQuantizedVector::hamming_distance between the sign-bit codes (smallest first, ties by row)
+void vo_scan_topk_binary(const float* rows, uint64_t nrows, uint32_t dim, const float* queries, uint32_t nq, uint32_t k,
+                         uint64_t* out_rows, float* out_scores) {
+  const uint32_t nb = (dim + 7) / 8;
+  std::vector<uint8_t> codes((size_t)nrows * nb), qc(nb);
+  for (uint64_t r = 0; r < nrows; r++) vo_binary_quantize(rows + (size_t)r * dim, dim, codes.data() + (size_t)r * nb);
+  std::vector<std::pair<uint32_t, uint64_t>> sc(nrows);
+  for (uint32_t qi = 0; qi < nq; qi++) {
+    vo_binary_quantize(queries + (size_t)qi * dim, dim, qc.data());
+    for (uint64_t r = 0; r < nrows; r++) sc[r] = {vo_binary_hamming(qc.data(), codes.data() + (size_t)r * nb, nb), r};
+    const size_t kk = std::min<size_t>(k, nrows);
+    std::partial_sort(sc.begin(), sc.begin() + kk, sc.end());
+    for (size_t i = 0; i < kk; i++) {
+      out_rows[(size_t)qi * k + i] = sc[i].second;
+      out_scores[(size_t)qi * k + i] = (float)sc[i].first;
+    }
+  }
+}
+
 const char* vo_build_info(void) {
 #if VO_HAVE_AVX2
   return "vdb_oracle: g++ " __VERSION__ " avx2+fma intrinsics, -ffp-contract=off";

@@ -187,6 +187,19 @@ void vo_scan_topk_bf16(int metric, const float* rows, uint64_t nrows, uint32_t d
                        uint32_t nq, uint32_t k, uint32_t nthreads, uint64_t* out_rows, float* out_scores);
 
 int vo_cpu_has_avx512f(void);
+/* ---- storage modes (core/quantization.rs): sign-bit and SQ8 (per-vector min/max) codes, asymmetric distances ---- */
+void vo_binary_quantize(const float* v, uint32_t dim, uint8_t* out /* ceil(dim/8) */);
+uint32_t vo_binary_hamming(const uint8_t* a, const uint8_t* b, uint32_t nbytes);
+void vo_sq8_quantize(const float* v, uint32_t dim, uint8_t* data, float* out_min, float* out_max);
+void vo_sq8_dequantize(const uint8_t* data, float mn, float mx, uint32_t dim, float* out);
+float vo_sq8_dot(const float* q, const uint8_t* data, float mn, float mx, uint32_t dim);
+float vo_sq8_l2sq(const float* q, const uint8_t* data, float mn, float mx, uint32_t dim, int simd);
+float vo_sq8_cosine(const float* q, const uint8_t* data, float mn, float mx, uint32_t dim, int simd);
+float vo_sq8_norm_sq(const uint8_t* data, float mn, float mx, uint32_t dim);
+void vo_scan_topk_sq8(int metric, const float* rows, uint64_t nrows, uint32_t dim, const float* queries, uint32_t nq,
+                      uint32_t k, uint32_t nthreads, uint64_t* out_rows, float* out_scores);
+void vo_scan_topk_binary(const float* rows, uint64_t nrows, uint32_t dim, const float* queries, uint32_t nq, uint32_t k,
+                         uint64_t* out_rows, float* out_scores);
 const char* vo_build_info(void);
 
 #ifdef __cplusplus
