@@ -69,10 +69,24 @@ enum vdb_search_mode {
                            223-441): the graph is walked with integer L2^2 distances between u8 codes (4x fewer bytes
                            per visited node), the k * oversampling best are re-scored with the exact f32 distance.
                            `ef` = ef_search; needs vdb_hip_index_train_quantizer.  Scores as in VDB_SEARCH_HNSW. */
+  VDB_SEARCH_BRUTE_SQ8 = 5, /* exact scan of the f32 queries over the SQ8 codes of the rows with the reference's asymmetric
+                           distances (core/quantization.rs:410-554): Cosine -> cosine_similarity_quantized_simd, DotProduct
+                           -> dot_product_quantized_simd (best = largest), Euclidean -> euclidean_squared_quantized_simd (the
+                           SQUARED distance, best = smallest).  Needs vdb_hip_index_set_storage_mode(VDB_STORAGE_SQ8).  */
+  VDB_SEARCH_BRUTE_BINARY = 6, /* exact scan by BinaryQuantizedVector::hamming_distance (quantization.rs:123-135) between
+                           the sign bits of the query and of every row; scores = the distance as f32, smallest first.
+                           Needs VDB_STORAGE_BINARY; any metric.                                              */
   VDB_SEARCH_BRUTE_BF16 = 3 /* exact scan over the bf16 copy of the rows with bf16-rounded queries and f32
                            accumulation on the matrix cores: half_precision::dot_product / cosine_similarity on
                            VectorData::BF16 (half_precision.rs:199-255).  Cosine / DotProduct only; needs
                            vdb_hip_index_enable_bf16.  Raw scores, best first.                       */
+};
+
+/* StorageMode (core/quantization.rs:17-29): which quantised copy of the rows the index keeps next to the f32 rows */
+enum vdb_storage_mode {
+  VDB_STORAGE_FULL = 0,  /* f32 only (default)                                                                  */
+  VDB_STORAGE_SQ8 = 1,   /* QuantizedVector: one byte per dimension, per-vector min / max (quantization.rs:204-255) */
+  VDB_STORAGE_BINARY = 2 /* BinaryQuantizedVector: bit = (x >= 0.0), LSB first (quantization.rs:48-86)           */
 };
 
 /* score convention of vdb_hip_batch_distance */
@@ -114,6 +128,14 @@ int32_t vdb_hip_index_insert_batch_parallel(vdb_hip_index* idx, const uint64_t* 
 int32_t vdb_hip_index_train_quantizer(vdb_hip_index* idx, uint32_t sample_rows);
 /* DualPrecisionConfig::oversampling_ratio (default 4) of VDB_SEARCH_HNSW_INT8, process-wide */
 int32_t vdb_hip_set_int8_oversampling(uint32_t ratio);
+/* Collection StorageMode (quantization.rs:17-29; collection/core/crud.rs:66-82 quantises every upserted vector):
+ * encodes every present and future row on the device (SQ8: +dim+12 bytes per row, Binary: +dim/8) for the
+ * VDB_SEARCH_BRUTE_SQ8 / VDB_SEARCH_BRUTE_BINARY scans.  Switching modes drops the previous codes. */
+int32_t vdb_hip_index_set_storage_mode(vdb_hip_index* idx, int32_t mode);
+/* the stored code of one vector in the reference's serialisation: QuantizedVector::to_bytes (min f32, max f32, dim
+ * bytes; quantization.rs:289-295) or BinaryQuantizedVector::to_bytes (dimension u32, ceil(dim/8) bytes; :155-169).
+ * *len = bytes needed / written. */
+int32_t vdb_hip_index_get_quantized(vdb_hip_index* idx, uint64_t id, uint8_t* out, size_t cap, size_t* len);
 /* keeps a bf16 copy (round to nearest even, VectorData::from_f32_slice(.., BF16), half_precision.rs:94-101) of every
  * row next to the f32 rows, for VDB_SEARCH_BRUTE_BF16; +2 bytes per element of HBM */
 int32_t vdb_hip_index_enable_bf16(vdb_hip_index* idx);

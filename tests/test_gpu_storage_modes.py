@@ -1,0 +1,132 @@
+"""GPU parity for the storage modes of core/quantization.rs (SQ8 and Binary): the codes the index keeps are
+byte-identical to the oracle's QuantizedVector / BinaryQuantizedVector serialisations, and the exact scans over
+them return the oracle's ids, ranks and scores BIT FOR BIT (the reference's asymmetric distances are scalar
+left-to-right sums: one lane per row reproduces them exactly)."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+va = pytest.importorskip("velesdb_amd")
+DM = va.DistanceMetric
+SM = va.StorageMode
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def special_rows(rng, n, dim):
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[3] = 0.25                      # constant vector: range < EPSILON branch
+    rows[7] = 0.0                       # all zeros (cosine denominator 0)
+    rows[11] = rows[10]                 # duplicate: tie broken by row
+    rows[13, 0] = -0.0
+    return rows
+
+
+@pytest.mark.parametrize("n,dim", [(3000, 768), (1000, 100), (700, 17), (300, 3), (2048, 64)])
+def test_sq8_codes_byte_identical(gpu_required, n, dim):
+    rng = np.random.default_rng(n + dim)
+    rows = special_rows(rng, n, dim)
+    ids = np.arange(n, dtype=np.uint64) * 5 + 9
+    ix = va.HnswIndex(dim, DM.Cosine)
+    ix.upload(ids[: n // 2], rows[: n // 2])
+    ix.set_storage_mode(SM.SQ8)          # encodes what is there ...
+    ix.upload(ids[n // 2:], rows[n // 2:])  # ... and every later row
+    for r in list(range(0, n, max(1, n // 40))) + [3, 7, 13, n - 1]:
+        assert ix.get_quantized_bytes(int(ids[r])) == po.QuantizedVector.from_f32(rows[r]).to_bytes(), r
+    ix.close()
+
+
+@pytest.mark.parametrize("metric,pm", [(DM.Cosine, po.COSINE), (DM.Euclidean, po.EUCLIDEAN), (DM.DotProduct, po.DOT)])
+@pytest.mark.parametrize("n,dim", [(5000, 768), (2000, 100), (900, 17), (1500, 66)])
+def test_sq8_scan_bit_exact(gpu_required, metric, pm, n, dim):
+    rng = np.random.default_rng(n * 3 + dim + int(metric))
+    rows = special_rows(rng, n, dim)
+    ids = np.arange(n, dtype=np.uint64) + 100
+    ix = va.HnswIndex(dim, metric)
+    ix.set_storage_mode(SM.SQ8)
+    ix.upload(ids, rows)
+    for nq, k in [(1, 10), (4, 10), (7, 3), (9, 25)]:
+        Q = rng.standard_normal((nq, dim)).astype(np.float32)
+        Q[0] = rows[10]
+        gid, gsc, gcnt = ix.search_batch_sq8(Q, k)
+        eid, esc = po.scan_topk_sq8(pm, rows, Q, k, nthreads=4)
+        assert np.all(gcnt == k)
+        assert np.array_equal(gid, ids[eid.astype(np.int64)]), (metric, nq, k)
+        assert np.array_equal(bits(gsc), bits(esc)), (metric, nq, k)
+    # soft delete + fewer rows than k
+    assert ix.remove(int(ids[10]))
+    gid, gsc, gcnt = ix.search_batch_sq8(rows[10], 5)
+    assert int(ids[10]) not in gid[0].tolist()
+    ix.close()
+    small = va.HnswIndex(dim, metric)
+    small.set_storage_mode(SM.SQ8)
+    small.upload(np.arange(3), rows[:3])
+    gid, gsc, gcnt = small.search_batch_sq8(rows[1], 10)
+    assert gcnt[0] == 3
+    small.close()
+
+
+def test_sq8_scan_tracks_the_f32_scan(gpu_required):
+    # quantization_tests.rs:296-355 style: top-10 of the SQ8 scan overlaps the exact f32 top-10 (>= 0.8 recall on
+    # embedding-like data), and scores stay within the quantisation error
+    rng = np.random.default_rng(12)
+    n, dim = 20000, 768
+    proj = rng.standard_normal((24, dim)).astype(np.float32)
+    rows = (rng.standard_normal((n, 24)).astype(np.float32) @ proj + 0.3 * rng.standard_normal((n, dim)).astype(np.float32))
+    Q = (rng.standard_normal((16, 24)).astype(np.float32) @ proj + 0.3 * rng.standard_normal((16, dim)).astype(np.float32))
+    ix = va.HnswIndex(dim, DM.Cosine)
+    ix.upload(np.arange(n), rows)
+    ix.set_storage_mode(SM.SQ8)
+    a, sa, _ = ix.search_batch_sq8(Q, 10)
+    b, sb, _ = ix.search_batch_brute_force(Q, 10)
+    rec = np.mean([len(set(a[i].tolist()) & set(b[i].tolist())) / 10 for i in range(16)])
+    assert rec >= 0.8, rec
+    assert np.max(np.abs(sa[:, 0] - sb[:, 0])) < 0.02
+    ix.close()
+
+
+@pytest.mark.parametrize("n,dim", [(4000, 768), (1000, 100), (600, 17), (300, 33)])
+def test_binary_codes_and_scan_exact(gpu_required, n, dim):
+    rng = np.random.default_rng(n + 7 * dim)
+    rows = special_rows(rng, n, dim)
+    rows[5, 1] = np.nan
+    ids = np.arange(n, dtype=np.uint64) * 2 + 1
+    ix = va.HnswIndex(dim, DM.Euclidean)
+    ix.upload(ids, rows)
+    ix.set_storage_mode(SM.Binary)
+    for r in (0, 3, 5, 7, 13, n - 1):
+        assert ix.get_quantized_bytes(int(ids[r])) == po.BinaryQuantizedVector.from_f32(rows[r]).to_bytes(), r
+    Q = rng.standard_normal((6, dim)).astype(np.float32)
+    Q[1] = rows[20]
+    gid, gsc, gcnt = ix.search_batch_binary(Q, 12)
+    eid, esc = po.scan_topk_binary(rows, Q, 12)
+    assert np.array_equal(gid, ids[eid.astype(np.int64)])
+    assert np.array_equal(gsc, esc)           # integer distances: exact
+    assert gid[1, 0] == ids[20] and gsc[1, 0] == 0.0
+    ix.close()
+
+
+def test_storage_mode_state_errors(gpu_required):
+    ix = va.HnswIndex(8, DM.Cosine)
+    ix.upload(np.arange(4), np.eye(4, 8, dtype=np.float32))
+    with pytest.raises(va.VelesHipError):
+        ix.search_batch_sq8(np.ones(8, np.float32), 2)      # storage mode is Full
+    ix.set_storage_mode(SM.Binary)
+    with pytest.raises(va.VelesHipError):
+        ix.search_batch_sq8(np.ones(8, np.float32), 2)      # wrong mode
+    ix.set_storage_mode(SM.SQ8)
+    ix.search_batch_sq8(np.ones(8, np.float32), 2)
+    with pytest.raises(va.VelesHipError):
+        ix.set_storage_mode(7)
+    ix.close()
+    h = va.HnswIndex(8, DM.Hamming)
+    h.upload(np.arange(4), np.eye(4, 8, dtype=np.float32))
+    h.set_storage_mode(SM.SQ8)
+    with pytest.raises(va.VelesHipError):
+        h.search_batch_sq8(np.ones(8, np.float32), 2)       # SQ8 distances exist for cosine / euclidean / dot only
+    h.close()

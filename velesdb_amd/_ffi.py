@@ -38,6 +38,8 @@ SIGNATURES = {
     "vdb_hip_index_insert_batch_parallel": (_i32, [_vp, _vp, _vp, _u64, _u32, _pu64]),
     "vdb_hip_index_build_graph": (_i32, [_vp, _u32]),
     "vdb_hip_index_enable_bf16": (_i32, [_vp]),
+    "vdb_hip_index_set_storage_mode": (_i32, [_vp, _i32]),
+    "vdb_hip_index_get_quantized": (_i32, [_vp, _u64, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "vdb_hip_index_train_quantizer": (_i32, [_vp, _u32]),
     "vdb_hip_set_int8_oversampling": (_i32, [_u32]),
     "vdb_hip_index_upload": (_i32, [_vp, _vp, _vp, _u64, _pu64]),

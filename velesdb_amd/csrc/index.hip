@@ -123,6 +123,10 @@ static int32_t finish_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
                      ix->norms_bf16.as<float>(), (uint32_t)first, (uint32_t)n, ix->dim, ix->stream);
     ix->bf16_rows = first + n;
   }
+  if (ix->storage_mode != VDB_STORAGE_FULL) {  // crud.rs:66-82: the quantised code is built with every upsert
+    int32_t rs = storage_mode_append(ix, first, n);
+    if (rs != VDB_OK) return rs;
+  }
   VDB_HIP(hipGetLastError());
   return VDB_OK;
 }
@@ -495,6 +499,8 @@ static int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride
   }
   if (mode == VDB_SEARCH_BRUTE) return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
   if (mode == VDB_SEARCH_BRUTE_BF16) return brute_bf16_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
+  if (mode == VDB_SEARCH_BRUTE_SQ8) return brute_sq8_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
+  if (mode == VDB_SEARCH_BRUTE_BINARY) return brute_binary_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
   if (mode == VDB_SEARCH_AUTO && ix->live <= 100 && ix->n_rows > 0)  // search.rs:75-77
     return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
   if (mode == VDB_SEARCH_HNSW_INT8) {
@@ -596,7 +602,7 @@ void vdb_hip_index_destroy(vdb_hip_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   (void)hipStreamSynchronize(ix->stream);
-  for (DevBuf* b : {&ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids, &ix->rows_bf16, &ix->norms_bf16, &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq, &ix->s_queries, &ix->s_part_keys,
+  for (DevBuf* b : {&ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids, &ix->rows_bf16, &ix->norms_bf16, &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits, &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq, &ix->s_queries, &ix->s_part_keys,
                     &ix->s_part_cnt, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels,
                     &ix->s_req_keys, &ix->s_req_vals, &ix->s_sort_tmp})
     b->release();

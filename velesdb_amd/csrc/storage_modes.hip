@@ -1,0 +1,518 @@
+// storage_modes.hip — the storage modes of core/quantization.rs on the GPU: SQ8 (QuantizedVector: one byte per
+// dimension + per-vector min/max, :204-316) and Binary (BinaryQuantizedVector: one sign bit per dimension, :48-202),
+// the quantisers, and exact top-k searches of f32 queries over the quantised corpus with the reference's asymmetric
+// distances dot_product_quantized_simd / euclidean_squared_quantized_simd / cosine_similarity_quantized_simd
+// (:410-554) and BinaryQuantizedVector::hamming_distance (:123-135).  crud.rs:66-82 builds exactly these codes on
+// upsert when a collection's StorageMode is SQ8 / Binary.
+//
+// Arithmetic: the reference's functions are plain scalar Rust — every sum is one left-to-right chain over the
+// dimensions, nothing is fused (Rust never contracts a*b+c).  That order is reproduced exactly: ONE LANE OWNS ONE
+// ROW and walks its dimensions in order with separately rounded multiplies and adds (__fmul_rn / __fadd_rn = plain
+// * and + under -ffp-contract=off; sqrtf and / are correctly rounded; NOT __fsqrt_rn, which is the native
+// approximation in this toolchain), so
+// scores are bit-identical to the oracle's restatement (oracle/vdb_oracle.cpp vo_sq8_*), and — the reference's
+// functions being deterministic scalar code — to the reference itself.
+//
+// sweep_topk_sq8<METRIC,B>: a wave takes 64 rows; their codes arrive through an LDS tile (16 rows x 64 B per load
+// instruction, coalesced; each lane then reads its own row's 64 bytes with 4 conflict-free ds_read_b128), the B
+// queries sit in LDS dimension-major so one broadcast ds_read_b128 feeds 4 queries; per element 3 VALU ops of
+// dequantisation shared by the B queries + 2 per query.  Bound: HBM for B <= 4 (N*(dim+16) bytes per pass: 784 MB
+// at 1 M x 768), the vector ALUs beyond.  Top-k: block-shared locked lists (vdb_device.hpp) + merge_topk.
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+#include "vdb_device.hpp"
+#include "vdb_index.hpp"
+#include "vdb_kernels.hpp"
+
+namespace vdb {
+
+constexpr float kF32Eps = 1.1920929e-07f;  // f32::EPSILON
+
+// ---- quantisers ---------------------------------------------------------------------------------------------
+// QuantizedVector::from_f32 (:229-255), one wave per row: min / max are order-independent, the codes elementwise.
+// Also keeps quantized_norm_sq of cosine_similarity_quantized_simd (:531-546) — a left-to-right chain, so it is
+// computed by sq8_norms below, one lane per row.
+__global__ __launch_bounds__(256) void sq8_quantize_rows(const float* rows, uint64_t row_stride, uint8_t* codes,
+                                                         uint64_t code_stride, float* vmin, float* vmax, uint32_t row0,
+                                                         uint32_t n_rows, uint32_t dim) {
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4;
+  for (uint32_t r = wave; r < n_rows; r += nwaves) {
+    const uint32_t row = row0 + r;
+    const float* p = rows + (size_t)row * row_stride;
+    float mn = __uint_as_float(0x7F800000u), mx = __uint_as_float(0xFF800000u);
+    for (uint32_t i = lane; i < dim; i += 64) {
+      mn = fminf(mn, p[i]);  // f32::min / f32::max semantics: a NaN operand yields the other one
+      mx = fmaxf(mx, p[i]);
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+      mn = fminf(mn, __shfl_xor(mn, s, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, s, 64));
+    }
+    const float range = __fsub_rn(mx, mn);
+    uint8_t* c = codes + (size_t)row * code_stride;
+    if (range < kF32Eps) {
+      for (uint32_t i = lane; i < code_stride; i += 64) c[i] = i < dim ? 128 : 0;
+    } else {
+      const float scale = __fdiv_rn(255.0f, range);
+      for (uint32_t i = lane; i < code_stride; i += 64) {
+        uint8_t q = 0;
+        if (i < dim) {
+          const float normalized = __fmul_rn(__fsub_rn(p[i], mn), scale);
+          float rr = roundf(normalized);  // half away from zero, like f32::round
+          rr = rr < 0.0f ? 0.0f : (rr > 255.0f ? 255.0f : rr);
+          q = (rr != rr) ? (uint8_t)0 : (uint8_t)rr;  // NaN `as u8` saturates to 0
+        }
+        c[i] = q;
+      }
+    }
+    if (lane == 0) {
+      vmin[row] = mn;
+      vmax[row] = mx;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sq8_norms(const uint8_t* codes, uint64_t code_stride, const float* vmin,
+                                                 const float* vmax, float* nsq, uint32_t row0, uint32_t n_rows,
+                                                 uint32_t dim) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  const uint32_t row = row0 + r;
+  const float mn = vmin[row], range = __fsub_rn(vmax[row], mn);
+  const float scale = range < kF32Eps ? 0.0f : __fdiv_rn(range, 255.0f);
+  const uint32_t* c = reinterpret_cast<const uint32_t*>(codes + (size_t)row * code_stride);
+  float s = 0.0f;
+  for (uint32_t i = 0; i < dim; i += 4) {
+    const uint32_t w = c[i / 4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (i + e < dim) {
+        const float dq = __fadd_rn(__fmul_rn((float)((w >> (8 * e)) & 0xFFu), scale), mn);
+        s = __fadd_rn(s, __fmul_rn(dq, dq));
+      }
+    }
+  }
+  nsq[row] = s;
+}
+
+// BinaryQuantizedVector::from_f32 (:68-86): bit i = (v[i] >= 0.0), LSB-first in bytes = bit i%32 of word i/32.
+// One wave per row: a ballot over 64 consecutive dimensions IS eight of the reference's bytes.
+__global__ __launch_bounds__(256) void sign_bits_rows(const float* rows, uint64_t row_stride, uint32_t* bits, uint32_t words,
+                                                      uint32_t row0, uint32_t n_rows, uint32_t dim) {
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4;
+  for (uint32_t r = wave; r < n_rows; r += nwaves) {
+    const uint32_t row = row0 + r;
+    const float* p = rows + (size_t)row * row_stride;
+    uint32_t* dst = bits + (size_t)row * words;
+    for (uint32_t e0 = 0; e0 < words * 32; e0 += 64) {
+      const uint32_t e = e0 + lane;
+      const bool bit = e < dim && p[e] >= 0.0f;  // NaN >= 0 is false, -0.0 >= 0 is true, as on the CPU
+      const uint64_t m = __ballot(bit);
+      if (lane == 0) {
+        dst[e0 / 32] = (uint32_t)m;
+        if (e0 / 32 + 1 < words) dst[e0 / 32 + 1] = (uint32_t)(m >> 32);
+      }
+    }
+  }
+}
+
+// ---- SQ8 sweep ------------------------------------------------------------------------------------------------
+struct Sq8Args {
+  const uint8_t* codes;   // [n_rows][code_stride], code_stride % 16 == 0, padding bytes 0
+  const float* vmin;
+  const float* vmax;
+  const float* nsq;       // quantized_norm_sq per row (cosine)
+  const uint8_t* alive;
+  const float* queries;   // [nq][q_stride] f32
+  uint64_t* part_keys;    // [nq][n_blocks][k]
+  uint64_t code_stride, q_stride;
+  uint32_t n_rows, dim, nq, k;
+};
+
+constexpr int kSq8TileStride = 80;  // bytes per row of the staging tile: 64 + 16 padding (conflict-free b128 reads)
+
+template <int METRIC, int B>
+__global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
+  constexpr bool HIB = METRIC != kEuclidean;  // cosine / dot similarity: larger is better; squared L2: smaller
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t k = a.k, dim = a.dim;
+  const uint32_t dpad = (dim + 3u) & ~3u;
+  // LDS: queries [dpad][B] f32 | per-wave tiles [4][64][80] | lists [B][k] | cnt[B] | lock[B] | qsum[B] | qnsq[B]
+  float* qs = reinterpret_cast<float*>(smem);
+  unsigned char* tiles = smem + (size_t)dpad * B * 4;
+  unsigned char* tile = tiles + (size_t)wib * 64 * kSq8TileStride;
+  unsigned char* tail = tiles + (size_t)4 * 64 * kSq8TileStride;
+  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(tail);
+  volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(tail + (size_t)B * k * 8);
+  uint32_t* locks = reinterpret_cast<uint32_t*>(tail + (size_t)B * k * 8 + B * 4);
+  float* qsum = reinterpret_cast<float*>(tail + (size_t)B * k * 8 + B * 8);
+  float* qnsq = reinterpret_cast<float*>(tail + (size_t)B * k * 8 + B * 12);
+
+  for (uint32_t i = tid; i < dpad * B; i += 256) {
+    const uint32_t d = i / B, b = i % B;
+    qs[i] = (d < dim && b < a.nq) ? a.queries[(size_t)b * a.q_stride + d] : 0.0f;
+  }
+  if (tid < B) {
+    cnts[tid] = 0;
+    locks[tid] = 0;
+  }
+  __syncthreads();
+  if (tid < B) {  // per query: sum(q) (constant-vector branch, :332-334) and sum(q*q) (:528), left to right
+    float s = 0.0f, n2 = 0.0f;
+    for (uint32_t d = 0; d < dim; d++) {
+      const float x = qs[d * B + tid];
+      s = __fadd_rn(s, x);
+      n2 = __fadd_rn(n2, __fmul_rn(x, x));
+    }
+    qsum[tid] = s;
+    qnsq[tid] = n2;
+  }
+  __syncthreads();
+
+  const uint32_t ngroups = (a.n_rows + 63) / 64;
+  for (uint32_t g = blockIdx.x * 4 + wib; g < ngroups; g += gridDim.x * 4) {
+    const uint32_t row = g * 64 + lane;
+    const bool valid = row < a.n_rows;
+    const uint32_t rowc = valid ? row : a.n_rows - 1;
+    const float mn = a.vmin[rowc];
+    const float range = __fsub_rn(a.vmax[rowc], mn);
+    const bool flat = range < kF32Eps;
+    const float scale = __fdiv_rn(range, 255.0f);
+    float acc[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) acc[b] = 0.0f;
+    for (uint32_t c0 = 0; c0 < dim; c0 += 64) {
+      // stage 64 rows x 64 B: lane l moves 16 B of row 16 j + l/4, part l%4
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t rr = g * 64 + 16 * j + (lane >> 2);
+        const uint32_t off = c0 + (lane & 3) * 16;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (rr < a.n_rows && off < a.code_stride) v = *reinterpret_cast<const uint4*>(a.codes + (size_t)rr * a.code_stride + off);
+        *reinterpret_cast<uint4*>(tile + (16 * j + (lane >> 2)) * kSq8TileStride + (lane & 3) * 16) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      uint4 w4[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) w4[j] = *reinterpret_cast<const uint4*>(tile + lane * kSq8TileStride + j * 16);
+      __builtin_amdgcn_wave_barrier();  // tile reads done before the next chunk overwrites it
+      const uint32_t wds[16] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w,
+                                w4[2].x, w4[2].y, w4[2].z, w4[2].w, w4[3].x, w4[3].y, w4[3].z, w4[3].w};
+#pragma unroll
+      for (int wi = 0; wi < 16; wi++) {
+        const uint32_t i0 = c0 + wi * 4;
+        if (i0 >= dim) break;  // uniform
+        const uint32_t w = wds[wi];
+        float dq[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) dq[e] = __fadd_rn(__fmul_rn((float)((w >> (8 * e)) & 0xFFu), scale), mn);
+        if (METRIC == kEuclidean) {
+          if (i0 + 3 < dim) {  // a full group of four: sum += ((f0^2 + f1^2) + f2^2) + f3^2 (:495-507)
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+              const float f0 = __fsub_rn(qs[(i0 + 0) * B + b], dq[0]), f1 = __fsub_rn(qs[(i0 + 1) * B + b], dq[1]);
+              const float f2 = __fsub_rn(qs[(i0 + 2) * B + b], dq[2]), f3 = __fsub_rn(qs[(i0 + 3) * B + b], dq[3]);
+              const float t = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(f0, f0), __fmul_rn(f1, f1)), __fmul_rn(f2, f2)),
+                                        __fmul_rn(f3, f3));
+              acc[b] = __fadd_rn(acc[b], t);
+            }
+          } else {  // remainder: one element at a time (:510-515)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              if (i0 + e < dim) {
+#pragma unroll
+                for (int b = 0; b < B; b++) {
+                  const float f = __fsub_rn(qs[(i0 + e) * B + b], dq[e]);
+                  acc[b] = __fadd_rn(acc[b], __fmul_rn(f, f));
+                }
+              }
+            }
+          }
+        } else {  // dot chain (:452-466), also the numerator of the cosine
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            if (i0 + e < dim) {
+#pragma unroll
+              for (int b = 0; b < B; b++) acc[b] = __fadd_rn(acc[b], __fmul_rn(qs[(i0 + e) * B + b], dq[e]));
+            }
+          }
+        }
+      }
+    }
+    // constant-vector rows (range < EPSILON) take the reference's other branch; rare, so a divergent redo
+    if (__ballot(valid && flat)) {
+      if (valid && flat) {
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          if (METRIC == kEuclidean) {  // sum((q - value)^2), left to right (:357-361)
+            float s = 0.0f;
+            for (uint32_t d = 0; d < dim; d++) {
+              const float f = __fsub_rn(qs[d * B + b], mn);
+              s = __fadd_rn(s, __fmul_rn(f, f));
+            }
+            acc[b] = s;
+          } else {
+            acc[b] = __fmul_rn(qsum[b], mn);  // sum(q) * value (:330-334)
+          }
+        }
+      }
+    }
+    const float vn2 = (METRIC == kCosine) ? a.nsq[rowc] : 0.0f;
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      float score = acc[b];
+      if (METRIC == kCosine) {  // :548-553
+        const float denom = sqrtf(__fmul_rn(qnsq[b], vn2));
+        score = denom < kF32Eps ? 0.0f : __fdiv_rn(acc[b], denom);
+      }
+      const bool ok = valid && (uint32_t)b < a.nq;
+      const uint64_t key = ok ? make_key<HIB>(score, row) : kKeyInvalid;
+      const uint64_t tau = (cnts[b] == k) ? lists[(size_t)b * k + (k - 1)] : kKeyInvalid;
+      uint64_t mask = __ballot(key < tau);
+      while (mask) {
+        const int src = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const uint64_t kk = readlane64(key, src);
+        if (a.alive && a.alive[key_row(kk)] == 0) continue;
+        shared_list_offer(lists + (size_t)b * k, cnts + b, locks + b, k, kk, lane);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = wib; b < a.nq && b < (uint32_t)B; b += 4) {
+    const uint32_t c = cnts[b];
+    uint64_t* out = a.part_keys + ((size_t)b * gridDim.x + blockIdx.x) * k;
+    for (uint32_t e = lane; e < k; e += 64) out[e] = e < c ? lists[(size_t)b * k + e] : kKeyInvalid;
+  }
+}
+
+static size_t sq8_lds_bytes(int B, uint32_t k, uint32_t dim) {
+  const size_t dpad = (dim + 3u) & ~3u;
+  return (dpad * B * 4 + (size_t)4 * 64 * kSq8TileStride + (size_t)B * k * 8 + (size_t)B * 16 + 15) & ~(size_t)15;
+}
+
+template <int METRIC, int B>
+static hipError_t launch_sq8_t(const Sq8Args& a, int blocks, size_t lds, hipStream_t st) {
+  static bool done = false;
+  if (lds > 64 * 1024 && !done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_sq8<METRIC, B>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  hipLaunchKernelGGL((sweep_topk_sq8<METRIC, B>), dim3(blocks), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+template <int B>
+static hipError_t launch_sq8_m(int metric, const Sq8Args& a, int blocks, size_t lds, hipStream_t st) {
+  if (metric == kCosine) return launch_sq8_t<kCosine, B>(a, blocks, lds, st);
+  if (metric == kEuclidean) return launch_sq8_t<kEuclidean, B>(a, blocks, lds, st);
+  return launch_sq8_t<kDot, B>(a, blocks, lds, st);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+static void quantize_range(vdb_hip_index* ix, uint64_t first, uint64_t n) {
+  if (n == 0) return;
+  const int blocks = (int)std::min<uint64_t>((n + 3) / 4, 4096);
+  if (ix->storage_mode == VDB_STORAGE_SQ8) {
+    hipLaunchKernelGGL(sq8_quantize_rows, dim3(blocks), dim3(256), 0, ix->stream, ix->rows.as<float>(), ix->row_stride,
+                       ix->sq8_codes.as<uint8_t>(), ix->sq8_stride, ix->sq8_min.as<float>(), ix->sq8_max.as<float>(),
+                       (uint32_t)first, (uint32_t)n, ix->dim);
+    hipLaunchKernelGGL(sq8_norms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ix->stream, ix->sq8_codes.as<uint8_t>(),
+                       ix->sq8_stride, ix->sq8_min.as<float>(), ix->sq8_max.as<float>(), ix->sq8_nsq.as<float>(),
+                       (uint32_t)first, (uint32_t)n, ix->dim);
+  } else if (ix->storage_mode == VDB_STORAGE_BINARY) {
+    hipLaunchKernelGGL(sign_bits_rows, dim3(blocks), dim3(256), 0, ix->stream, ix->rows.as<float>(), ix->row_stride,
+                       ix->sign_bits.as<uint32_t>(), ix->words, (uint32_t)first, (uint32_t)n, ix->dim);
+  }
+}
+
+// grows the quantised arrays with the index and encodes rows [first, first + n)
+int32_t storage_mode_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
+  if (ix->storage_mode == VDB_STORAGE_FULL) return VDB_OK;
+  const uint64_t cap = std::max<uint64_t>(ix->capacity, 1);
+  hipError_t e = hipSuccess;
+  if (ix->storage_mode == VDB_STORAGE_SQ8) {
+    if ((e = ix->sq8_codes.reserve(cap * ix->sq8_stride, true, ix->stream)) != hipSuccess ||
+        (e = ix->sq8_min.reserve(cap * 4, true, ix->stream)) != hipSuccess ||
+        (e = ix->sq8_max.reserve(cap * 4, true, ix->stream)) != hipSuccess ||
+        (e = ix->sq8_nsq.reserve(cap * 4, true, ix->stream)) != hipSuccess)
+      return fail(VDB_ERR_OOM, std::string("SQ8 codes: ") + hipGetErrorString(e));
+  } else {
+    if ((e = ix->sign_bits.reserve(cap * ix->words * 4, true, ix->stream)) != hipSuccess)
+      return fail(VDB_ERR_OOM, std::string("sign bits: ") + hipGetErrorString(e));
+  }
+  quantize_range(ix, first, n);
+  VDB_HIP(hipGetLastError());
+  return VDB_OK;
+}
+
+int32_t brute_sq8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint64_t* d_ids,
+                      float* d_scores, uint32_t* d_n, hipStream_t st) {
+  if (ix->storage_mode != VDB_STORAGE_SQ8) return fail(VDB_ERR_STATE, "SQ8 search: set the storage mode to SQ8 first");
+  if (ix->metric != VDB_COSINE && ix->metric != VDB_EUCLIDEAN && ix->metric != VDB_DOT)
+    return fail(VDB_ERR_UNSUPPORTED, "SQ8 search: Cosine, Euclidean and DotProduct only");
+  if (nq == 0) return VDB_OK;
+  if (k == 0 || ix->n_rows == 0) {
+    VDB_HIP(hipMemsetAsync(d_n, 0, (size_t)nq * 4, st));
+    return VDB_OK;
+  }
+  const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
+  for (uint32_t q0 = 0; q0 < nq;) {
+    int B = nq - q0 >= 4 ? 4 : 1;
+    if (B == 4 && sq8_lds_bytes(4, k, ix->dim) > 160 * 1024) B = 1;
+    const size_t lds = sq8_lds_bytes(B, k, ix->dim);
+    if (lds > 160 * 1024) return fail(VDB_ERR_UNSUPPORTED, "SQ8 search: dim / k too large for the LDS query tile");
+    const uint32_t tile = std::min<uint32_t>((uint32_t)B, nq - q0);
+    const uint32_t ngroups = (uint32_t)((ix->n_rows + 63) / 64);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 4));
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ngroups + 3) / 4, (int64_t)ix->n_cus * per_cu));
+    hipError_t e;
+    if ((e = ix->s_part_keys.reserve((size_t)B * blocks * k * 8, false, st)) != hipSuccess)
+      return fail(VDB_ERR_OOM, "top-k scratch");
+    Sq8Args a{};
+    a.codes = ix->sq8_codes.as<uint8_t>();
+    a.vmin = ix->sq8_min.as<float>();
+    a.vmax = ix->sq8_max.as<float>();
+    a.nsq = ix->sq8_nsq.as<float>();
+    a.alive = alive;
+    a.queries = d_q + (size_t)q0 * q_stride;
+    a.part_keys = ix->s_part_keys.as<uint64_t>();
+    a.code_stride = ix->sq8_stride;
+    a.q_stride = q_stride;
+    a.n_rows = (uint32_t)ix->n_rows;
+    a.dim = ix->dim;
+    a.nq = tile;
+    a.k = k;
+    EventPair* ev = next_events(ix);
+    if (ev) (void)hipEventRecord(ev->a, st);
+    e = B == 4 ? launch_sq8_m<4>(ix->metric, a, blocks, lds, st) : launch_sq8_m<1>(ix->metric, a, blocks, lds, st);
+    if (ev) (void)hipEventRecord(ev->b, st);
+    if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("SQ8 sweep launch: ") + hipGetErrorString(e));
+    MergeArgs m{};
+    m.part_keys = a.part_keys;
+    m.ext_ids = ix->ext_ids.as<uint64_t>();
+    m.out_ids = d_ids + (size_t)q0 * k;
+    m.out_scores = d_scores + (size_t)q0 * k;
+    m.out_n = d_n + q0;
+    m.n_lists = (uint32_t)blocks;
+    m.k = k;
+    launch_merge(ix->metric != VDB_EUCLIDEAN, m, tile, st);
+    q0 += tile;
+  }
+  VDB_HIP(hipGetLastError());
+  return VDB_OK;
+}
+
+// BinaryQuantizedVector::hamming_distance between the sign bits of the queries and of every row: the packed-bit
+// sweep of sweep.hip over the sign-bit array (scores = distance as f32, smallest first)
+int32_t brute_binary_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint64_t* d_ids,
+                         float* d_scores, uint32_t* d_n, hipStream_t st) {
+  if (ix->storage_mode != VDB_STORAGE_BINARY) return fail(VDB_ERR_STATE, "Binary search: set the storage mode to Binary first");
+  if (nq == 0) return VDB_OK;
+  if (k == 0 || ix->n_rows == 0) {
+    VDB_HIP(hipMemsetAsync(d_n, 0, (size_t)nq * 4, st));
+    return VDB_OK;
+  }
+  if ((size_t)4 * k * 8 + (size_t)ix->words * 4 + 32 > 60 * 1024)
+    return fail(VDB_ERR_UNSUPPORTED, "k too large for the fused top-k path");
+  hipError_t e = ix->s_qbits.reserve((size_t)nq * ix->words * 4, false, st);
+  if (e != hipSuccess) return fail(VDB_ERR_OOM, "qbits scratch");
+  hipLaunchKernelGGL(sign_bits_rows, dim3((unsigned)std::min<uint32_t>((nq + 3) / 4, 4096)), dim3(256), 0, st, d_q, q_stride,
+                     ix->s_qbits.as<uint32_t>(), ix->words, 0u, nq, ix->dim);
+  const uint32_t nchunks = (uint32_t)((ix->n_rows + 63) / 64);
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + 3) / 4, (int64_t)ix->n_cus * 4));
+  if ((e = ix->s_part_keys.reserve((size_t)nq * blocks * k * 8, false, st)) != hipSuccess ||
+      (e = ix->s_part_cnt.reserve((size_t)nq * blocks * 4, false, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, "top-k scratch");
+  BitsArgs ba{};
+  ba.bits = ix->sign_bits.as<uint32_t>();
+  ba.qbits = ix->s_qbits.as<uint32_t>();
+  ba.alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
+  ba.part_keys = ix->s_part_keys.as<uint64_t>();
+  ba.part_cnt = ix->s_part_cnt.as<uint32_t>();
+  ba.n_rows = (uint32_t)ix->n_rows;
+  ba.words = ix->words;
+  ba.k = k;
+  EventPair* ev = next_events(ix);
+  if (ev) (void)hipEventRecord(ev->a, st);
+  launch_sweep_bits(VDB_HAMMING, ba, blocks, nq, st);
+  if (ev) (void)hipEventRecord(ev->b, st);
+  MergeArgs m{};
+  m.part_keys = ba.part_keys;
+  m.part_cnt = ba.part_cnt;
+  m.ext_ids = ix->ext_ids.as<uint64_t>();
+  m.out_ids = d_ids;
+  m.out_scores = d_scores;
+  m.out_n = d_n;
+  m.n_lists = (uint32_t)blocks;
+  m.k = k;
+  launch_merge(false, m, nq, st);
+  VDB_HIP(hipGetLastError());
+  return VDB_OK;
+}
+
+}  // namespace vdb
+
+using namespace vdb;
+
+extern "C" {
+
+// StorageMode of a collection (quantization.rs:17-29; crud.rs:66-82 encodes every upserted vector accordingly)
+int32_t vdb_hip_index_set_storage_mode(vdb_hip_index* ix, int32_t mode) {
+  if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (mode != VDB_STORAGE_FULL && mode != VDB_STORAGE_SQ8 && mode != VDB_STORAGE_BINARY)
+    return fail(VDB_ERR_INVALID_ARG, "bad storage mode");
+  std::lock_guard<std::mutex> g(ix->mu);
+  if (ix->storage_mode == mode) return VDB_OK;
+  VDB_HIP(hipSetDevice(ix->device));
+  for (DevBuf* b : {&ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits}) b->release();
+  ix->storage_mode = mode;
+  ix->sq8_stride = ((uint64_t)ix->dim + 15) / 16 * 16;
+  int32_t rc = storage_mode_append(ix, 0, ix->n_rows);
+  if (rc != VDB_OK) {
+    ix->storage_mode = VDB_STORAGE_FULL;
+    return rc;
+  }
+  VDB_HIP(hipStreamSynchronize(ix->stream));
+  return VDB_OK;
+}
+
+// The stored code of one vector in the reference's byte format: QuantizedVector::to_bytes (min f32, max f32, dim
+// bytes; quantization.rs:289-295) or BinaryQuantizedVector::to_bytes (dimension u32, ceil(dim/8) bytes; :155-169).
+int32_t vdb_hip_index_get_quantized(vdb_hip_index* ix, uint64_t id, uint8_t* out, size_t cap, size_t* len) {
+  if (!ix || !len) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  if (ix->storage_mode == VDB_STORAGE_FULL) return fail(VDB_ERR_STATE, "storage mode is Full: nothing is quantised");
+  auto it = ix->id_to_idx.find(id);
+  if (it == ix->id_to_idx.end()) return fail(VDB_ERR_INVALID_ARG, "unknown id");
+  const uint64_t row = it->second;
+  const size_t need = ix->storage_mode == VDB_STORAGE_SQ8 ? 8 + (size_t)ix->dim : 4 + ((size_t)ix->dim + 7) / 8;
+  *len = need;
+  if (!out || cap < need) return fail(VDB_ERR_INVALID_ARG, "buffer too small");
+  VDB_HIP(hipSetDevice(ix->device));
+  if (ix->storage_mode == VDB_STORAGE_SQ8) {
+    VDB_HIP(hipMemcpyAsync(out, ix->sq8_min.as<float>() + row, 4, hipMemcpyDeviceToHost, ix->stream));
+    VDB_HIP(hipMemcpyAsync(out + 4, ix->sq8_max.as<float>() + row, 4, hipMemcpyDeviceToHost, ix->stream));
+    VDB_HIP(hipMemcpyAsync(out + 8, ix->sq8_codes.as<uint8_t>() + row * ix->sq8_stride, ix->dim, hipMemcpyDeviceToHost, ix->stream));
+  } else {
+    const uint32_t d = ix->dim;
+    std::memcpy(out, &d, 4);
+    VDB_HIP(hipMemcpyAsync(out + 4, ix->sign_bits.as<uint32_t>() + row * ix->words, need - 4, hipMemcpyDeviceToHost, ix->stream));
+  }
+  VDB_HIP(hipStreamSynchronize(ix->stream));
+  return VDB_OK;
+}
+
+}  // extern "C"

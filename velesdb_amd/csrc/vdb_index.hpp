@@ -75,6 +75,10 @@ struct vdb_hip_index {
   bool bf16_enabled = false;
   uint64_t bf16_stride = 0;  // bf16 elements per row (multiple of 8)
   uint64_t bf16_rows = 0;    // rows converted so far
+  // optional quantised copy of the rows per StorageMode (storage_modes.hip; core/quantization.rs)
+  int32_t storage_mode = 0;      // VDB_STORAGE_FULL
+  uint64_t sq8_stride = 0;       // bytes per SQ8 row (multiple of 16)
+  vdb::DevBuf sq8_codes, sq8_min, sq8_max, sq8_nsq, sign_bits;
   // graph
   std::vector<vdb::GraphLayer> layers;
   bool graph_valid = true;   // false once rows exist that are not linked into the graph
@@ -126,4 +130,10 @@ int32_t hnsw_search_int8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_str
                              uint32_t ef_search, uint32_t oversampling, uint32_t cap_mult, uint64_t* d_ids,
                              float* d_scores, uint32_t* d_n, hipStream_t st);  // visited bitmaps + logs + stats
 constexpr uint32_t kVlogCap = 16384;
+// storage_modes.hip
+int32_t storage_mode_append(vdb_hip_index* ix, uint64_t first, uint64_t n);
+int32_t brute_sq8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint64_t* d_ids,
+                      float* d_scores, uint32_t* d_n, hipStream_t st);
+int32_t brute_binary_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint64_t* d_ids,
+                         float* d_scores, uint32_t* d_n, hipStream_t st);
 }  // namespace vdb

@@ -20,7 +20,7 @@ from . import _ffi
 from ._ffi import check, lib
 from .params import DistanceMetric, HnswParams, SearchQuality
 
-MODE_AUTO, MODE_BRUTE, MODE_HNSW, MODE_BRUTE_BF16, MODE_HNSW_INT8 = 0, 1, 2, 3, 4
+MODE_AUTO, MODE_BRUTE, MODE_HNSW, MODE_BRUTE_BF16, MODE_HNSW_INT8, MODE_BRUTE_SQ8, MODE_BRUTE_BINARY = 0, 1, 2, 3, 4, 5, 6
 KIND_ENGINE, KIND_RAW = 0, 1
 
 
@@ -226,6 +226,36 @@ class HnswIndex:
             qs = qs.reshape(1, -1)
         self._validate(qs)
         return self._search_raw(qs, k, 0, MODE_BRUTE_BF16)
+
+    # ---- storage modes (core/quantization.rs) -----------------------------------------------
+    def set_storage_mode(self, mode) -> None:
+        """StorageMode of the owning collection (quantization.rs:17-29): the index keeps the SQ8 / binary code of every
+        vector, as collection/core/crud.rs:66-82 does on upsert."""
+        check(lib().vdb_hip_index_set_storage_mode(self._h, int(mode)))
+
+    def get_quantized_bytes(self, id: int) -> bytes:
+        """QuantizedVector::to_bytes / BinaryQuantizedVector::to_bytes of the stored code of `id`."""
+        n = C.c_size_t(0)
+        buf = (C.c_uint8 * (self._dimension + 16))()
+        check(lib().vdb_hip_index_get_quantized(self._h, id, buf, len(buf), C.byref(n)))
+        return bytes(buf[:n.value])
+
+    def search_batch_sq8(self, queries, k: int):
+        """Exact scan over the SQ8 codes with the reference's asymmetric `_simd` distances (quantization.rs:410-554):
+        cosine / dot similarity (best = largest) or SQUARED Euclidean distance (best = smallest)."""
+        qs = _f32(queries)
+        if qs.ndim == 1:
+            qs = qs.reshape(1, -1)
+        self._validate(qs)
+        return self._search_raw(qs, k, 0, MODE_BRUTE_SQ8)
+
+    def search_batch_binary(self, queries, k: int):
+        """Exact scan by Hamming distance between sign-bit codes (BinaryQuantizedVector::hamming_distance)."""
+        qs = _f32(queries)
+        if qs.ndim == 1:
+            qs = qs.reshape(1, -1)
+        self._validate(qs)
+        return self._search_raw(qs, k, 0, MODE_BRUTE_BINARY)
 
     def search_batch_brute_force(self, queries, k: int):
         """Batched exact search (one corpus pass per tile of queries); numpy outputs."""

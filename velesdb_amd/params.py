@@ -79,3 +79,10 @@ SearchQuality.Fast = SearchQuality("fast")
 SearchQuality.Balanced = SearchQuality("balanced")
 SearchQuality.Accurate = SearchQuality("accurate")
 SearchQuality.Perfect = SearchQuality("perfect")
+
+
+class StorageMode(enum.IntEnum):
+    """core/quantization.rs:17-29"""
+    Full = 0
+    SQ8 = 1
+    Binary = 2
