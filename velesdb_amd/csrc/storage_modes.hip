@@ -190,16 +190,36 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
     float acc[B];
 #pragma unroll
     for (int b = 0; b < B; b++) acc[b] = 0.0f;
-    for (uint32_t c0 = 0; c0 < dim; c0 += 64) {
-      // stage 64 rows x 64 B: lane l moves 16 B of row 16 j + l/4, part l%4
+    // query elements are wave-uniform: read straight from global memory with a uniform address, i.e. scalar loads into
+    // SGPRs that the multiplies take as operands (LDS broadcast reads of the same data made the LDS pipe the bound)
+    // (constant address space: the queries are read-only for the whole launch, which is what lets hipcc use s_load)
+    typedef const __attribute__((address_space(4))) float* cfloat_p;
+    cfloat_p qg[B];
+#pragma unroll
+    for (int b = 0; b < B; b++)
+      qg[b] = (cfloat_p)(uintptr_t)(a.queries + (size_t)((uint32_t)b < a.nq ? b : 0) * a.q_stride);
+    // staging loads run one 64-byte column chunk ahead of the arithmetic (registers), so their latency hides
+    // behind the previous chunk's ~700 VALU instructions
+    uint4 stg[4];
+    auto stage_load = [&](uint32_t c0) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const uint32_t rr = g * 64 + 16 * j + (lane >> 2);
         const uint32_t off = c0 + (lane & 3) * 16;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (rr < a.n_rows && off < a.code_stride) v = *reinterpret_cast<const uint4*>(a.codes + (size_t)rr * a.code_stride + off);
-        *reinterpret_cast<uint4*>(tile + (16 * j + (lane >> 2)) * kSq8TileStride + (lane & 3) * 16) = v;
+        const uint32_t rc = rr < a.n_rows ? rr : a.n_rows - 1;          // branch-free: clamped address, selected below
+        const uint32_t oc = off < a.code_stride ? off : 0u;
+        const uint4 v = *reinterpret_cast<const uint4*>(a.codes + (size_t)rc * a.code_stride + oc);
+        const bool ok = rr < a.n_rows && off < a.code_stride;
+        stg[j] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
       }
+    };
+    stage_load(0);
+    for (uint32_t c0 = 0; c0 < dim; c0 += 64) {
+      // stage 64 rows x 64 B: lane l moves 16 B of row 16 j + l/4, part l%4
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        *reinterpret_cast<uint4*>(tile + (16 * j + (lane >> 2)) * kSq8TileStride + (lane & 3) * 16) = stg[j];
+      if (c0 + 64 < dim) stage_load(c0 + 64);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -217,12 +237,26 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
         float dq[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) dq[e] = __fadd_rn(__fmul_rn((float)((w >> (8 * e)) & 0xFFu), scale), mn);
+        // Two queries per instruction where B is even (v_pk_mul_f32 / v_pk_add_f32: each half is the same IEEE
+        // operation as the scalar form, so the bits do not change; a plain f32 VALU op runs at half the packed rate).
+        constexpr int P = B / 2;  // query pairs
         if (METRIC == kEuclidean) {
           if (i0 + 3 < dim) {  // a full group of four: sum += ((f0^2 + f1^2) + f2^2) + f3^2 (:495-507)
 #pragma unroll
-            for (int b = 0; b < B; b++) {
-              const float f0 = __fsub_rn(qs[(i0 + 0) * B + b], dq[0]), f1 = __fsub_rn(qs[(i0 + 1) * B + b], dq[1]);
-              const float f2 = __fsub_rn(qs[(i0 + 2) * B + b], dq[2]), f3 = __fsub_rn(qs[(i0 + 3) * B + b], dq[3]);
+            for (int p = 0; p < P; p++) {
+              f32x2 t = {0.f, 0.f};
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const f32x2 f = f32x2{qg[2 * p][i0 + e], qg[2 * p + 1][i0 + e]} - f32x2{dq[e], dq[e]};
+                t = e == 0 ? f * f : t + f * f;
+              }
+              acc[2 * p] = __fadd_rn(acc[2 * p], t.x);
+              acc[2 * p + 1] = __fadd_rn(acc[2 * p + 1], t.y);
+            }
+            if (B & 1) {
+              const int b = B - 1;
+              const float f0 = __fsub_rn(qg[b][i0 + 0], dq[0]), f1 = __fsub_rn(qg[b][i0 + 1], dq[1]);
+              const float f2 = __fsub_rn(qg[b][i0 + 2], dq[2]), f3 = __fsub_rn(qg[b][i0 + 3], dq[3]);
               const float t = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(f0, f0), __fmul_rn(f1, f1)), __fmul_rn(f2, f2)),
                                         __fmul_rn(f3, f3));
               acc[b] = __fadd_rn(acc[b], t);
@@ -233,7 +267,7 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
               if (i0 + e < dim) {
 #pragma unroll
                 for (int b = 0; b < B; b++) {
-                  const float f = __fsub_rn(qs[(i0 + e) * B + b], dq[e]);
+                  const float f = __fsub_rn(qg[b][i0 + e], dq[e]);
                   acc[b] = __fadd_rn(acc[b], __fmul_rn(f, f));
                 }
               }
@@ -244,7 +278,13 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
           for (int e = 0; e < 4; e++) {
             if (i0 + e < dim) {
 #pragma unroll
-              for (int b = 0; b < B; b++) acc[b] = __fadd_rn(acc[b], __fmul_rn(qs[(i0 + e) * B + b], dq[e]));
+              for (int p = 0; p < P; p++) {
+                const f32x2 r = f32x2{acc[2 * p], acc[2 * p + 1]} +
+                                f32x2{qg[2 * p][i0 + e], qg[2 * p + 1][i0 + e]} * f32x2{dq[e], dq[e]};
+                acc[2 * p] = r.x;
+                acc[2 * p + 1] = r.y;
+              }
+              if (B & 1) acc[B - 1] = __fadd_rn(acc[B - 1], __fmul_rn(qg[B - 1][i0 + e], dq[e]));
             }
           }
         }
