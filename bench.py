@@ -55,6 +55,7 @@ def parse():
     p.add_argument("--check-queries", type=int, default=2)
     # graph leg (configs[2])
     p.add_argument("--no-hnsw", action="store_true")
+    p.add_argument("--no-int8", action="store_true", help="skip the dual-precision (int8 traversal) leg")
     p.add_argument("--hnsw-batch", type=int, default=8192, help="queries per step (graph traversal)")
     p.add_argument("--hnsw-steps", type=int, default=5)
     p.add_argument("--ef", type=int, default=128)
@@ -352,6 +353,39 @@ def main():
                              "kernel_ms": round(hk_ms, 4), "launches_timed": hk_n,
                              "alg_bytes_per_launch": hbytes,
                              "alg_bytes_rule": "n_dist*dim*4 + n_expand*M0*4, counters from the kernel"}}
+        # dual-precision leg: int8 graph walk (integer L2^2 between u8 codes) + exact f32 re-rank of
+        # the k * 4 best, same graph, same queries, same ef
+        if not a.no_int8:
+            ix.train_quantizer(0)
+            torch.cuda.synchronize()
+
+            def istep():
+                ix.search_batch_dev(queries.data_ptr(), HQ, K, a.ef, va.MODE_HNSW_INT8, h_ids.data_ptr(), h_sc.data_ptr(),
+                                    h_n.data_ptr(), stream)
+
+            istep()
+            barrier()
+            va.set_kernel_timing(True)
+            ti = time.perf_counter()
+            for _ in range(a.hnsw_steps):
+                istep()
+            barrier()
+            idt = max_over_ranks(time.perf_counter() - ti)
+            ik_ms, _ = ix.last_kernel_ms()
+            va.set_kernel_timing(False)
+            i_nd, i_ne = ix.last_search_stats()
+            ibytes = i_nd * (D + 4) + i_ne * 2 * a.M * 4 + HQ * K * 4 * D * 4
+            ii = h_ids[:RQ].cpu().numpy()
+            rec_i = float(np.mean([len(set(ii[i].tolist()) & set(gt[i].tolist())) / K for i in range(RQ)]))
+            hnsw["int8"] = {"qps": round(world * HQ * a.hnsw_steps / idt, 1), "ms_per_step": round(idt / a.hnsw_steps * 1e3, 3),
+                            "recall_at_10": round(rec_i, 4), "n_dist_per_query": round(i_nd / HQ, 1),
+                            "n_expand_per_query": round(i_ne / HQ, 1), "kernel_ms": round(ik_ms, 4),
+                            "alg_bytes_per_launch": ibytes,
+                            "alg_bytes_rule": "n_dist*(dim+4) + n_expand*M0*4 + k*oversampling(4)*dim*4 per query",
+                            "hbm_gbs": round(ibytes / (ik_ms * 1e-3) / 1e9, 1) if ik_ms > 0 else 0.0,
+                            "hbm_frac": round(ibytes / (ik_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ik_ms > 0 else 0.0}
+            hstep()  # leave the f32 results in h_ids for the parity check below
+            torch.cuda.synchronize()
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pt = json.load(f)
