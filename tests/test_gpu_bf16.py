@@ -79,3 +79,35 @@ def test_bf16_exact_values_are_exact():
     gi, gs, gc = ix.search_batch_brute_force_bf16(qs, 10)
     eid, esc = po.scan_topk_bf16(po.DOT, rows, qs, 10)
     assert np.array_equal(gi, eid) and np.array_equal(gs, esc)
+
+
+@pytest.mark.parametrize("metric,pm", [(DM.Cosine, po.COSINE), (DM.DotProduct, po.DOT)])
+@pytest.mark.parametrize("n,dim", [(10007, 768), (3000, 192), (50, 64), (129, 128)])
+def test_bf16_gemm_sweep_large_batches(metric, pm, n, dim):
+    # >= 64 queries and dim % 64 == 0: the GEMM-structured kernel over the bf16 rows (sweep_gemm.hip, BF16 variant)
+    rng = np.random.default_rng(n * 7 + dim)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ix = va.HnswIndex(dim, metric)
+    ix.upload(np.arange(n), rows)
+    ix.enable_bf16()
+    for nq, k in [(64, 10), (129, 5), (300, 10)]:
+        qs = rng.standard_normal((nq, dim)).astype(np.float32)
+        gi, gs, gc = ix.search_batch_brute_force_bf16(qs, k)
+        check(metric, pm, rows, qs, k, gi, gs, gc)
+    ix.close()
+
+
+def test_bf16_gemm_exact_values_are_exact():
+    rng = np.random.default_rng(6)
+    rows = rng.integers(-4, 5, size=(5000, 128)).astype(np.float32)
+    qs = rng.integers(-4, 5, size=(200, 128)).astype(np.float32)
+    ix = va.HnswIndex(128, DM.DotProduct)
+    ix.upload(np.arange(5000), rows)
+    ix.enable_bf16()
+    gi, gs, gc = ix.search_batch_brute_force_bf16(qs, 10)
+    eid, esc = po.scan_topk_bf16(po.DOT, rows, qs, 10, nthreads=4)
+    assert np.array_equal(gi, eid) and np.array_equal(gs, esc)
+    # soft delete is honoured by the GEMM epilogue too
+    assert ix.remove(int(gi[0, 0]))
+    gi2, _, _ = ix.search_batch_brute_force_bf16(qs, 10)
+    assert int(gi[0, 0]) not in gi2[0].tolist()

@@ -86,7 +86,7 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
   if (ix->quantizer_trained && ((e = ix->codes.reserve(ncap * ix->code_words * 4, true, st)) != hipSuccess ||
                                 (e = ix->codes_sq.reserve(ncap * 4, true, st)) != hipSuccess))
     return fail(VDB_ERR_OOM, std::string("grow codes: ") + hipGetErrorString(e));
-  if (ix->bf16_enabled && ((e = ix->rows_bf16.reserve(ncap * ix->bf16_stride * 2, true, st)) != hipSuccess ||
+  if (ix->bf16_enabled && ((e = ix->rows_bf16.reserve((ncap + kRowSlack) * ix->bf16_stride * 2, true, st)) != hipSuccess ||
                            (e = ix->norms_bf16.reserve(ncap * 4, true, st)) != hipSuccess))
     return fail(VDB_ERR_OOM, std::string("grow bf16 rows: ") + hipGetErrorString(e));
   for (auto& L : ix->layers) {
@@ -146,6 +146,39 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
   for (uint32_t q0 = 0; q0 < nq;) {
     const uint32_t rem = nq - q0;
+    // large batches: the GEMM-structured kernel over the bf16 rows (sweep_gemm.hip, BF16 variant): the corpus is read
+    // once per <= 128 queries instead of once per 96, both operands through LDS, lock-free top-k epilogue
+    if (g_max_tile >= 128 && rem >= kGemmMinQueries && k <= kGemmMaxK && ix->dim % 64 == 0) {
+      const uint32_t nqg = std::min<uint32_t>(rem, kGemmMaxQueries);
+      GemmPlan gp;
+      sweep_gemm_plan(nqg, (uint32_t)ix->n_rows, ix->n_cus, k, &gp);
+      if (gp.lds <= 160 * 1024) {
+        hipError_t e3;
+        if ((e3 = ix->s_part_keys.reserve((size_t)nqg * gp.G * k * 8, false, st)) != hipSuccess ||
+            (e3 = ix->s_misc.reserve((size_t)nqg * ix->bf16_stride * 2, false, st)) != hipSuccess)
+          return fail(VDB_ERR_OOM, "bf16 GEMM scratch");
+        launch_round_queries_bf16(d_q + (size_t)q0 * q_stride, q_stride, ix->s_misc.as<uint16_t>(), ix->bf16_stride, nqg,
+                                  ix->dim, st);
+        EventPair* evg = next_events(ix);
+        if (evg) (void)hipEventRecord(evg->a, st);
+        e3 = launch_sweep_gemm_bf16(ix->metric, gp, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride, ix->norms_bf16.as<float>(),
+                                    alive, ix->s_misc.as<uint16_t>(), ix->bf16_stride, ix->s_part_keys.as<uint64_t>(),
+                                    (uint32_t)ix->n_rows, ix->dim, nqg, k, st);
+        if (evg) (void)hipEventRecord(evg->b, st);
+        if (e3 != hipSuccess) return fail(VDB_ERR_HIP, std::string("bf16 gemm sweep launch: ") + hipGetErrorString(e3));
+        MergeArgs mg{};
+        mg.part_keys = ix->s_part_keys.as<uint64_t>();
+        mg.ext_ids = ix->ext_ids.as<uint64_t>();
+        mg.out_ids = d_ids + (size_t)q0 * k;
+        mg.out_scores = d_scores + (size_t)q0 * k;
+        mg.out_n = d_n + q0;
+        mg.n_lists = gp.G;
+        mg.k = k;
+        launch_merge(true, mg, nqg, st);
+        q0 += nqg;
+        continue;
+      }
+    }
     int nqt = rem > 64 ? 6 : (rem > 32 ? 4 : (rem > 16 ? 2 : 1));
     while (nqt > 1 && sweep_bf16_lds_bytes(nqt, k, ix->dim) > 160 * 1024) nqt = nqt == 6 ? 4 : nqt / 2;
     if (sweep_bf16_lds_bytes(nqt, k, ix->dim) > 160 * 1024)
@@ -694,7 +727,7 @@ int32_t vdb_hip_index_enable_bf16(vdb_hip_index* ix) {
   VDB_HIP(hipSetDevice(ix->device));
   ix->bf16_stride = ((uint64_t)ix->dim + 7) / 8 * 8;
   hipError_t e;
-  if ((e = ix->rows_bf16.reserve(std::max<uint64_t>(ix->capacity, 1) * ix->bf16_stride * 2, false, ix->stream)) != hipSuccess ||
+  if ((e = ix->rows_bf16.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * ix->bf16_stride * 2, false, ix->stream)) != hipSuccess ||
       (e = ix->norms_bf16.reserve(std::max<uint64_t>(ix->capacity, 1) * 4, false, ix->stream)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("bf16 rows: ") + hipGetErrorString(e));
   ix->bf16_enabled = true;

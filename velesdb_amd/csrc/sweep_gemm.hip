@@ -98,8 +98,15 @@ __device__ __forceinline__ float select_acc(const f32x4 (&acc)[4][NQF], uint32_t
 
 // FULL: dim % 128 == 0 and the queries are readable as aligned float4 — no zero-fill, and the tile loads are
 // `uniform base (SGPR) + loop-invariant per-thread offset`: no vector ALU work at all for addressing.
-template <int METRIC, int NQF, bool QVEC, bool FULL>
+// BF16: the same kernel over the bf16 copy of the rows and bf16-rounded queries (a.rows / a.queries then point at
+// uint16 data, strides in elements): k-tiles of 64 bf16 = the same 128 bytes per row, so the LDS geometry, staging and
+// epilogue are byte-for-byte the f32 kernel's; one 16-B fragment feeds ONE v_mfma_f32_16x16x32_bf16 (f32 accumulate:
+// half_precision.rs:199-255 semantics) instead of four f32 MFMAs.  FULL only (dim % 64 == 0).
+template <int METRIC, int NQF, bool QVEC, bool FULL, bool BF16>
 __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) {
+  static_assert(!BF16 || FULL, "the bf16 variant has no zero-fill path");
+  constexpr int ES = BF16 ? 2 : 4;        // bytes per element in HBM
+  constexpr int BKE = 128 / ES;           // elements per k-tile (one 128-B line per row)
   constexpr int BM = kGemmBM, BK = kGemmBK, BN = 32 * NQF;
   constexpr bool HIB = true;  // cosine and dot: higher is better
   const SweepArgs& a = ga.s;
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) 
   const uint32_t g = (slot_id / ga.nqt) * 8u + xcd;
   const uint32_t q0 = qt * ga.qper;
   const uint32_t nq_t = min(ga.qper, a.nq - q0);
-  const float* queries = a.queries + (size_t)q0 * a.q_stride;
+  const float* queries = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.queries) + (size_t)q0 * a.q_stride * ES);
 
   if (tid < BN) {
     cnts[tid] = 0;
@@ -139,7 +146,23 @@ __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) 
   }
   if (tid == 0) *ovf = 0u;
   __syncthreads();
-  if (METRIC == kCosine) {  // canonical query norms (same as every other kernel)
+  if (METRIC == kCosine && BF16) {  // norm of the ROUNDED query, canonical lane-chain order (as sweep_topk_mfma_bf16)
+    for (uint32_t b = wib; b < nq_t; b += 4) {
+      const uint16_t* qp = reinterpret_cast<const uint16_t*>(queries) + (size_t)b * a.q_stride;
+      float nacc = 0.0f;
+      for (uint32_t c = lane; c * 4 < a.dim; c += 64)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const uint32_t i = c * 4 + e;
+          if (i < a.dim) {
+            const float x = __uint_as_float((uint32_t)qp[i] << 16);
+            nacc = __builtin_fmaf(x, x, nacc);
+          }
+        }
+      const float n = sqrtf(butterfly_all(nacc));
+      if (lane == 0) qn[b] = n;
+    }
+  } else if (METRIC == kCosine) {  // canonical query norms (same as every other kernel)
     const int d4 = (int)((a.dim + 3) / 4);
     for (uint32_t b = wib; b < nq_t; b += 4) {
       const float* qp = queries + (size_t)b * a.q_stride;
@@ -176,23 +199,23 @@ __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) 
   // Branch-free: every load is issued unconditionally from a clamped (valid) address and zeroed by a select —
   // a conditional load makes hipcc branch around it and wait vmcnt(0) per element (serialised round trips).
   // FULL path: per-thread byte offsets inside a row tile / the query tile (loop-invariant)
-  const uint32_t voff_a = (uint32_t)st_row * (uint32_t)a.row_stride * 4u + (uint32_t)st_slot * 16u;
+  const uint32_t voff_a = (uint32_t)st_row * (uint32_t)a.row_stride * (uint32_t)ES + (uint32_t)st_slot * 16u;
   uint32_t voff_b[NQF];
 #pragma unroll
   for (int j = 0; j < NQF; j++) {
     const uint32_t q = st_row + 32 * j;
-    voff_b[j] = (q < nq_t ? q : nq_t - 1) * (uint32_t)a.q_stride * 4u + (uint32_t)st_slot * 16u;  // padded slots repeat a query
+    voff_b[j] = (q < nq_t ? q : nq_t - 1) * (uint32_t)a.q_stride * (uint32_t)ES + (uint32_t)st_slot * 16u;  // padded slots repeat a query
   }
   // (macros, not lambdas: hipcc does not always promote arrays captured by a lambda to registers)
 #define VDB_GEMM_GLOAD() do { \
     if (FULL) { \
  \
       const unsigned char* base_a = reinterpret_cast<const unsigned char*>(a.rows) + \
-                                    ((size_t)ld_rt * BM * a.row_stride + (size_t)ld_kt * BK) * 4; \
-      const unsigned char* base_b = reinterpret_cast<const unsigned char*>(queries) + (size_t)ld_kt * BK * 4; \
+                                    ((size_t)ld_rt * BM * a.row_stride + (size_t)ld_kt * BKE) * ES; \
+      const unsigned char* base_b = reinterpret_cast<const unsigned char*>(queries) + (size_t)ld_kt * BKE * ES; \
 _Pragma("unroll") \
       for (int j = 0; j < 4; j++) \
-        ra[j] = ld4(reinterpret_cast<const float*>(base_a + (size_t)(32 * j) * a.row_stride * 4 + voff_a)); \
+        ra[j] = ld4(reinterpret_cast<const float*>(base_a + (size_t)(32 * j) * a.row_stride * ES + voff_a)); \
 _Pragma("unroll") \
       for (int j = 0; j < NQF; j++) rb[j] = ld4(reinterpret_cast<const float*>(base_b + voff_b[j])); \
     } else { \
@@ -356,7 +379,7 @@ _Pragma("unroll") \
 #ifndef VDB_GEMM_ABL_NOLOAD
     if (more) VDB_GEMM_GLOAD();
 #endif
-    // the row tile's norms travel one step ahead of its epilogue: register now, LDS in that step's staging phase.
+    // the row tile's norms: loaded here every step, written to LDS by the epilogue step in front of its first barrier.
     // Loaded unconditionally every step (clamped address, L2 hit): a conditional load would make hipcc wait
     // vmcnt(0) in front of the branch, i.e. for the tile loads just issued.
     float vn_reg = 0.0f;
@@ -364,7 +387,6 @@ _Pragma("unroll") \
       const uint32_t row = rt * BM + (uint32_t)(tid & (BM - 1));
       vn_reg = a.norms[row < a.n_rows ? row : a.n_rows - 1];
     }
-    const bool vn_step = METRIC == kCosine && kt + 2 == ga.KT;
 #ifndef VDB_GEMM_ABL_NOMFMA
     {  // ---- multiply k-tile `it` out of LDS ----
       // rows 16 apart share the swizzle term, so the 4 / NQF fragment reads of a 16-deep group are one base +
@@ -383,6 +405,17 @@ _Pragma("unroll") \
       // dense MFMA stream (8 ds_writes took ~1900 cycles).  With priority they slip through at once, the wave gets
       // back to feeding the matrix pipe sooner, and the partner's MFMAs fill the gaps anyway: +8 % (110 -> 118 TF).
       __builtin_amdgcn_s_setprio(0);
+      if (BF16) {
+        typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+          for (int rf = 0; rf < 4; rf++)
+#pragma unroll
+            for (int t = 0; t < NQF; t++)
+              acc[rf][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[m][rf]),
+                                                                  __builtin_bit_cast(bf16x8, bv[m][t]), acc[rf][t], 0, 0, 0);
+      } else {
 #ifdef VDB_GEMM_V_32X32  // timing probe only (wrong numerics): same flops on v_mfma_f32_32x32x2_f32
 #pragma unroll
       for (int m = 0; m < 2; m++)
@@ -412,6 +445,7 @@ _Pragma("unroll") \
         }
       }
 #endif
+      }
       __builtin_amdgcn_s_setprio(VDB_GEMM_PRIO);
     }
 #endif
@@ -435,6 +469,7 @@ _Pragma("unroll") \
       continue;
     }
 #endif
+    const bool vn_step = METRIC == kCosine && kt + 2 == ga.KT;  // the step before the epilogue step stages the norms
     if (++kt < ga.KT) {
 #ifdef VDB_GEMM_STATS
       {  // drain the matrix pipe first: the timestamp then marks the END of the multiply, not the end of its issue
@@ -466,7 +501,8 @@ _Pragma("unroll") \
 #ifdef VDB_GEMM_STATS
     const long long t_e0 = clock64();
 #endif
-    __syncthreads();  // every wave is done reading the tile
+    if (METRIC == kCosine && ga.KT < 2 && tid < BM) vns[tid] = vn_reg;  // single-k-tile rows: no earlier step to do it in
+    __syncthreads();  // every wave is done reading the tile; norms visible
     if (more) VDB_GEMM_LDS_STORE();  // staging registers are dead from here on: the epilogue gets their 32 VGPRs
 #ifdef VDB_GEMM_STATS
     long long t_p = clock64();
@@ -675,23 +711,23 @@ void sweep_gemm_plan(uint32_t nq, uint32_t n_rows, int n_cus, uint32_t k, GemmPl
   p->blocks = (int)(G * p->nqt);
 }
 
-template <int METRIC, int NQF, bool QVEC, bool FULL>
+template <int METRIC, int NQF, bool QVEC, bool FULL, bool BF16>
 static hipError_t launch_gemm_v(const GemmSweepArgs& ga, int blocks, size_t lds, hipStream_t st) {
   static bool done = false;
   if (lds > 64 * 1024 && !done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_gemm_f32<METRIC, NQF, QVEC, FULL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_gemm_f32<METRIC, NQF, QVEC, FULL, BF16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     done = true;
   }
-  hipLaunchKernelGGL((sweep_topk_gemm_f32<METRIC, NQF, QVEC, FULL>), dim3(blocks), dim3(256), lds, st, ga);
+  hipLaunchKernelGGL((sweep_topk_gemm_f32<METRIC, NQF, QVEC, FULL, BF16>), dim3(blocks), dim3(256), lds, st, ga);
   return hipGetLastError();
 }
 template <int METRIC, int NQF>
 static hipError_t launch_gemm_t(const GemmSweepArgs& ga, bool qvec, int blocks, size_t lds, hipStream_t st) {
-  if (qvec && ga.s.dim % 128 == 0) return launch_gemm_v<METRIC, NQF, true, true>(ga, blocks, lds, st);
-  return qvec ? launch_gemm_v<METRIC, NQF, true, false>(ga, blocks, lds, st)
-              : launch_gemm_v<METRIC, NQF, false, false>(ga, blocks, lds, st);
+  if (qvec && ga.s.dim % 128 == 0) return launch_gemm_v<METRIC, NQF, true, true, false>(ga, blocks, lds, st);
+  return qvec ? launch_gemm_v<METRIC, NQF, true, false, false>(ga, blocks, lds, st)
+              : launch_gemm_v<METRIC, NQF, false, false, false>(ga, blocks, lds, st);
 }
 hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, hipStream_t st) {
   GemmSweepArgs ga;
@@ -705,7 +741,7 @@ hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, 
     const char* e = getenv("VDB_GEMM_STAGGER");  // probe knob; default: about half a row tile of one block running alone
     const char* m = getenv("VDB_GEMM_STAGGER_MODE");
     ga.stagger_mode = m ? (uint32_t)atoi(m) : 0u;
-    ga.stagger = e ? (uint32_t)atoi(e) : (p.lds * 2 <= 160 * 1024 ? ga.KT / 3 : 0u);
+    ga.stagger = e ? (uint32_t)atoi(e) : 0u;  // measured: no effect once the wave priorities are set
   }
 #ifdef VDB_GEMM_STATS
   static unsigned long long* d_stats = nullptr;
@@ -743,6 +779,78 @@ hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, 
     case 2: return launch_gemm_t<kDot, 2>(ga, qvec, p.blocks, p.lds, st);
     case 3: return launch_gemm_t<kDot, 3>(ga, qvec, p.blocks, p.lds, st);
     default: return launch_gemm_t<kDot, 4>(ga, qvec, p.blocks, p.lds, st);
+  }
+}
+
+// ---- bf16 variant: rows16 / queries16 are bf16 (uint16), strides in elements, dim % 64 == 0 ----
+// round-to-nearest-even copy of the query batch (VectorData::from_f32_slice(.., BF16), half_precision.rs:94-101)
+__global__ __launch_bounds__(256) void round_queries_bf16(const float* q, uint64_t q_stride, uint16_t* out, uint64_t out_stride,
+                                                          uint32_t nq, uint32_t dim) {
+  const uint64_t n = (uint64_t)nq * out_stride;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const uint32_t b = (uint32_t)(i / out_stride), d = (uint32_t)(i % out_stride);
+    uint16_t h = 0;
+    if (d < dim) {
+      uint32_t u = __float_as_uint(q[(size_t)b * q_stride + d]);
+      if ((u & 0x7FFFFFFFu) > 0x7F800000u) {
+        h = (uint16_t)((u >> 16) | 0x0040u);  // NaN stays NaN (quiet)
+      } else {
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        h = (uint16_t)(u >> 16);
+      }
+    }
+    out[i] = h;
+  }
+}
+void launch_round_queries_bf16(const float* q, uint64_t q_stride, uint16_t* out, uint64_t out_stride, uint32_t nq,
+                               uint32_t dim, hipStream_t st) {
+  const uint64_t n = (uint64_t)nq * out_stride;
+  hipLaunchKernelGGL(round_queries_bf16, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, q,
+                     q_stride, out, out_stride, nq, dim);
+}
+
+hipError_t launch_sweep_gemm_bf16(int metric, const GemmPlan& p, const uint16_t* rows16, uint64_t row_stride,
+                                  const float* norms, const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride,
+                                  uint64_t* part_keys, uint32_t n_rows, uint32_t dim, uint32_t nq, uint32_t k,
+                                  hipStream_t st) {
+  GemmSweepArgs ga;
+  ga.s = SweepArgs{};
+  ga.s.rows = reinterpret_cast<const float*>(rows16);        // bytes; the kernel addresses them as ES = 2
+  ga.s.norms = norms;
+  ga.s.alive = alive;
+  ga.s.queries = reinterpret_cast<const float*>(queries16);
+  ga.s.part_keys = part_keys;
+  ga.s.row_stride = row_stride;
+  ga.s.q_stride = q_stride;
+  ga.s.n_rows = n_rows;
+  ga.s.dim = dim;
+  ga.s.nq = nq;
+  ga.s.k = k;
+  ga.KT = dim / 64;
+  ga.G = p.G;
+  ga.nqt = p.nqt;
+  ga.qper = p.qper;
+  ga.cap = sweep_gemm_cap(k);
+  {
+    const char* e = getenv("VDB_GEMM_STAGGER");
+    const char* m = getenv("VDB_GEMM_STAGGER_MODE");
+    ga.stagger_mode = m ? (uint32_t)atoi(m) : 0u;
+    ga.stagger = e ? (uint32_t)atoi(e) : 0u;
+  }
+#ifdef VDB_GEMM_STATS
+  ga.stats = nullptr;
+#endif
+  if (metric == kCosine) {
+    switch (p.nqf) {
+      case 2: return launch_gemm_v<kCosine, 2, true, true, true>(ga, p.blocks, p.lds, st);
+      case 3: return launch_gemm_v<kCosine, 3, true, true, true>(ga, p.blocks, p.lds, st);
+      default: return launch_gemm_v<kCosine, 4, true, true, true>(ga, p.blocks, p.lds, st);
+    }
+  }
+  switch (p.nqf) {
+    case 2: return launch_gemm_v<kDot, 2, true, true, true>(ga, p.blocks, p.lds, st);
+    case 3: return launch_gemm_v<kDot, 3, true, true, true>(ga, p.blocks, p.lds, st);
+    default: return launch_gemm_v<kDot, 4, true, true, true>(ga, p.blocks, p.lds, st);
   }
 }
 

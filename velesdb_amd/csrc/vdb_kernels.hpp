@@ -131,6 +131,13 @@ constexpr uint32_t kGemmMaxQueries = 1024;  // per launch (bounds the partial-li
 size_t sweep_gemm_lds_bytes(int nqf, uint32_t k);
 void sweep_gemm_plan(uint32_t nq, uint32_t n_rows, int n_cus, uint32_t k, GemmPlan* p);
 hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, hipStream_t st);
+// bf16 variant of the same kernel (dim % 64 == 0): rows16 = the bf16 row copy, queries16 = launch_round_queries_bf16 output
+void launch_round_queries_bf16(const float* q, uint64_t q_stride, uint16_t* out, uint64_t out_stride, uint32_t nq,
+                               uint32_t dim, hipStream_t st);
+hipError_t launch_sweep_gemm_bf16(int metric, const GemmPlan& p, const uint16_t* rows16, uint64_t row_stride,
+                                  const float* norms, const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride,
+                                  uint64_t* part_keys, uint32_t n_rows, uint32_t dim, uint32_t nq, uint32_t k,
+                                  hipStream_t st);
 // bf16 GEMM-distance sweep (cosine / dot over a bf16 copy of the rows): nqt in {1, 2, 4, 6} 16-query tiles
 constexpr int kBf16WavesBig = 16;    // waves per block for nqt >= 4 (one block per CU)
 constexpr int kBf16WavesSmall = 8;   // ... for nqt <= 2
