@@ -37,7 +37,6 @@
 // Bound: the f32 matrix pipe (157.3 TFLOP/s dense); algorithmic flop per launch = 2 * n_rows * dim * nq.
 #include <algorithm>
 #include <cstdio>
-#include <cstdlib>
 
 #include "vdb_device.hpp"
 #include "vdb_kernels.hpp"
@@ -65,8 +64,6 @@ struct GemmSweepArgs {
   uint32_t nqt;    // query tiles
   uint32_t qper;   // queries per tile (<= 32 * NQF)
   uint32_t cap;    // candidate buffer entries per query (k < cap <= 64)
-  uint32_t stagger_mode;  // probe knob: which blocks are delayed (0: second half of the grid)
-  uint32_t stagger;  // start delay of the second half of the grid, in units of 8128 cycles (0: none)
 #ifdef VDB_GEMM_STATS
   unsigned long long* stats;  // [4] rounds, appends, compactions, failures
 #endif
@@ -282,14 +279,6 @@ _Pragma("unroll") \
   } while (0)
 
   f32x4 acc[4][NQF];
-#ifdef VDB_GEMM_V_32X32
-  typedef float f32x16 __attribute__((ext_vector_type(16)));
-  f32x16 acc32[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++)
-#pragma unroll
-    for (int e = 0; e < 16; e++) acc32[j][e] = 0.f;
-#endif
 #pragma unroll
   for (int rf = 0; rf < 4; rf++)
 #pragma unroll
@@ -350,15 +339,6 @@ _Pragma("unroll") \
   const unsigned char* b_rd = reinterpret_cast<const unsigned char*>(Bs) + wq * 16 * NQF * (BK * 4) + rd_off;
   const int a_rd_x = rd_x, b_rd_x = rd_x;
 
-  // Two blocks share a CU (and each SIMD's matrix pipe).  Started together they stay in lockstep — identical work,
-  // round-robin MFMA issue — so their barrier / staging phases and their epilogues coincide and the pipe idles
-  // (66 % busy measured).  The phase offset between two such blocks is preserved from step to step, so the
-  // second half of the grid (dispatched behind the first, one block per CU each) starts about half a row tile
-  // late: its staging and epilogue phases then fall into the other block's multiply phases.  Speed only — no
-  // correctness depends on which blocks share a CU.
-  if (ga.stagger && ((ga.stagger_mode == 0 && bid >= gridDim.x / 2) || (ga.stagger_mode == 1 && (slot_id & 1u)) || (ga.stagger_mode == 2 && (bid & 1u)))) {
-    for (uint32_t i = 0; i < ga.stagger; i++) __builtin_amdgcn_s_sleep(127);
-  }
   if (total) {
     VDB_GEMM_GLOAD();
     VDB_GEMM_LDS_STORE();
@@ -416,19 +396,6 @@ _Pragma("unroll") \
               acc[rf][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[m][rf]),
                                                                   __builtin_bit_cast(bf16x8, bv[m][t]), acc[rf][t], 0, 0, 0);
       } else {
-#ifdef VDB_GEMM_V_32X32  // timing probe only (wrong numerics): same flops on v_mfma_f32_32x32x2_f32
-#pragma unroll
-      for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const float4 a4 = av[m][j & 3], b4 = bv[m][(j >> 1) % NQF];
-            const float ax = c == 0 ? a4.x : (c == 1 ? a4.y : (c == 2 ? a4.z : a4.w));
-            const float bx = c == 0 ? b4.x : (c == 1 ? b4.y : (c == 2 ? b4.z : b4.w));
-            acc32[j & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx, acc32[j & 3], 0, 0, 0);
-          }
-#else
 #pragma unroll
       for (int m = 0; m < 2; m++) {
 #pragma unroll
@@ -444,7 +411,6 @@ _Pragma("unroll") \
           }
         }
       }
-#endif
       }
       __builtin_amdgcn_s_setprio(VDB_GEMM_PRIO);
     }
@@ -455,10 +421,6 @@ _Pragma("unroll") \
       for (int rf = 0; rf < 4; rf++)
 #pragma unroll
         for (int t = 0; t < NQF; t++) asm volatile("" ::"v"(acc[rf][t]));
-#ifdef VDB_GEMM_V_32X32
-#pragma unroll
-      for (int j = 0; j < 4; j++) asm volatile("" ::"v"(acc32[j]));
-#endif
       kt = 0;
       rt += ga.G;
     }
@@ -701,8 +663,7 @@ void sweep_gemm_plan(uint32_t nq, uint32_t n_rows, int n_cus, uint32_t k, GemmPl
   p->nqf = (int)((p->qper + 31) / 32);
   if (p->nqf < 2) p->nqf = 2;
   p->lds = sweep_gemm_lds_bytes(p->nqf, k);
-  int per_cu = p->lds * 2 <= 160 * 1024 ? 2 : 1;
-  if (const char* e = getenv("VDB_GEMM_PERCU")) per_cu = atoi(e);  // probe knob
+  const int per_cu = p->lds * 2 <= 160 * 1024 ? 2 : 1;
   const uint32_t ntiles = (n_rows + kGemmBM - 1) / kGemmBM;
   uint32_t G = (uint32_t)std::max(1, n_cus * per_cu / (int)p->nqt);
   G = std::min(G, ntiles);
@@ -737,12 +698,6 @@ hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, 
   ga.nqt = p.nqt;
   ga.qper = p.qper;
   ga.cap = sweep_gemm_cap(a.k);
-  {
-    const char* e = getenv("VDB_GEMM_STAGGER");  // probe knob; default: about half a row tile of one block running alone
-    const char* m = getenv("VDB_GEMM_STAGGER_MODE");
-    ga.stagger_mode = m ? (uint32_t)atoi(m) : 0u;
-    ga.stagger = e ? (uint32_t)atoi(e) : 0u;  // measured: no effect once the wave priorities are set
-  }
 #ifdef VDB_GEMM_STATS
   static unsigned long long* d_stats = nullptr;
   if (!d_stats) (void)hipMalloc(&d_stats, 256);
@@ -831,12 +786,6 @@ hipError_t launch_sweep_gemm_bf16(int metric, const GemmPlan& p, const uint16_t*
   ga.nqt = p.nqt;
   ga.qper = p.qper;
   ga.cap = sweep_gemm_cap(k);
-  {
-    const char* e = getenv("VDB_GEMM_STAGGER");
-    const char* m = getenv("VDB_GEMM_STAGGER_MODE");
-    ga.stagger_mode = m ? (uint32_t)atoi(m) : 0u;
-    ga.stagger = e ? (uint32_t)atoi(e) : 0u;
-  }
 #ifdef VDB_GEMM_STATS
   ga.stats = nullptr;
 #endif
