@@ -8,6 +8,6 @@ tail -5 $R/gpurun_out/${TAG:-r01}/pytest_gpu.log
 timeout 900 python bench.py > $R/gpurun_out/${TAG:-r01}/bench_line.json 2> $R/gpurun_out/${TAG:-r01}/bench.err; echo "bench rc=$?"
 tail -c 3000 $R/gpurun_out/${TAG:-r01}/bench_line.json
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG:-r01}/prof -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --check-queries 0 > $R/gpurun_out/${TAG:-r01}/bench_under_rocprof.json 2> $R/gpurun_out/${TAG:-r01}/rocprof.err; echo "rocprof rc=$?"
-timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG:-r01}/pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --check-queries 0 --hnsw-steps 1 --no-tiles > $R/gpurun_out/${TAG:-r01}/bench_under_pmc.json 2> $R/gpurun_out/${TAG:-r01}/pmc.err; echo "pmc rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG:-r01}/prof -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --check-queries 0 --no-embedding-leg > $R/gpurun_out/${TAG:-r01}/bench_under_rocprof.json 2> $R/gpurun_out/${TAG:-r01}/rocprof.err; echo "rocprof rc=$?"
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG:-r01}/pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --check-queries 0 --hnsw-steps 1 --no-tiles --no-embedding-leg > $R/gpurun_out/${TAG:-r01}/bench_under_pmc.json 2> $R/gpurun_out/${TAG:-r01}/pmc.err; echo "pmc rc=$?"
 find $R/gpurun_out/${TAG:-r01} -name "*.csv" | head -20
