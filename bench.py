@@ -48,6 +48,8 @@ def parse():
     p.add_argument("--tile", type=int, default=128, help="largest query tile of the sweep (1,2,4,8,16,32,48; 128 = "
                    "batches of >= 64 queries go to the GEMM-structured matrix-core kernel)")
     p.add_argument("--engine", type=int, default=1, help="1 = matrix-core sweep for cosine/dot (default), 0 = VALU")
+    p.add_argument("--shard-rows", type=int, default=0, help="rows per GPU in the range-sharded leg (0 = --rows; BASELINE "
+                   "configs[4] at 8 GPUs: 6250000)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-tiles", action="store_true", help="skip the per-tile-size table (profiling passes)")
     p.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
@@ -285,27 +287,55 @@ def main():
                "hbm_frac": round(b1 / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else 0.0}
 
     # ---- range-sharded mode: per-shard top-k + one RCCL all-gather + merge ----
+    # Default: every rank treats its copy as a different N-row shard (corpus = world * N rows).  BASELINE configs[4]
+    # (50 M rows over 8 GPUs) is `--shard-rows 6250000`: every rank generates its own shard on the device.
     sharded = None
     if world > 1:
         from velesdb_amd.sharded import merge_shard_topk
+        SR = a.shard_rows if a.shard_rows > 0 else N
+        ix_sh = ix
+        ok = 1
+        if SR != N:
+            try:
+                gs = torch.Generator(device=dev)
+                gs.manual_seed(4242 + rank)
+                ix_sh = va.HnswIndex(D, metric, va.HnswParams(a.M, a.efc, SR), device=local)
+                chunk = 1_000_000
+                for base in range(0, SR, chunk):  # bounded staging: 3 GB at a time
+                    n_c = min(chunk, SR - base)
+                    c = torch.randn((n_c, D), generator=gs, device=dev, dtype=torch.float32)
+                    torch.cuda.synchronize()
+                    ix_sh.upload_dev(base, c.data_ptr(), n_c, stream)
+                    del c
+            except Exception as e:  # noqa: BLE001 - a shard that cannot be set up must not hang the collective
+                print(f"[rank {rank}] shard setup failed: {e}", file=sys.stderr)
+                ok = 0
+        t_ok = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)  # every rank agrees before the first data-path collective
+        if int(t_ok.item()) == 1:
+            def sharded_step(i):
+                off = (i * Q) % (n_query_pool - Q + 1)  # every rank searches the SAME queries against ITS shard
+                ix_sh.search_batch_dev(queries[off:off + Q].data_ptr(), Q, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
+                                       out_sc.data_ptr(), out_n.data_ptr(), stream)
+                # global row id = shard offset + local row; one all-gather of k (id, score) pairs per query, merge
+                return merge_shard_topk(out_ids, out_sc, out_n, rank * SR, K, metric.higher_is_better())
 
-        def sharded_step(i):
-            off = (i * Q) % (n_query_pool - Q + 1)  # every rank searches the SAME queries against ITS shard
-            ix.search_batch_dev(queries[off:off + Q].data_ptr(), Q, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
-                                out_sc.data_ptr(), out_n.data_ptr(), stream)
-            # global row id = shard offset + local row; one all-gather of k (id, score) pairs per query, merge
-            return merge_shard_topk(out_ids, out_sc, out_n, rank * N, K, metric.higher_is_better())
-
-        for i in range(a.warmup):
-            sharded_step(i)
-        barrier()
-        t2 = time.perf_counter()
-        for i in range(a.steps):
-            sharded_step(a.warmup + i)
-        barrier()
-        sdt = max_over_ranks(time.perf_counter() - t2)
-        sharded = {"qps": round(Q * a.steps / sdt, 1), "corpus_rows": world * N, "ms_per_step": round(sdt / a.steps * 1e3, 4),
-                   "collective": "all_gather_into_tensor(ids u64, scores f32), %d B/query/GPU" % (K * 12)}
+            for i in range(a.warmup):
+                sharded_step(i)
+            barrier()
+            t2 = time.perf_counter()
+            for i in range(a.steps):
+                sharded_step(a.warmup + i)
+            barrier()
+            sdt = max_over_ranks(time.perf_counter() - t2)
+            sharded = {"qps": round(Q * a.steps / sdt, 1), "corpus_rows": world * SR, "rows_per_shard": SR,
+                       "ms_per_step": round(sdt / a.steps * 1e3, 4),
+                       "collective": "all_gather_into_tensor(ids u64, scores f32), %d B/query/GPU" % (K * 12)}
+        else:
+            sharded = {"error": "shard setup failed on at least one rank (see stderr)"}
+        if ix_sh is not ix:
+            ix_sh.close()
+            torch.cuda.empty_cache()
 
     # ---- graph leg (configs[2]): GPU construction + traversal kernel ----
     hnsw = None
