@@ -175,6 +175,20 @@ def test_gemm_sweep_large_batches_bit_exact(gpu_required, metric, n, dim):
     ix.close()
 
 
+def test_gemm_sweep_more_queries_than_one_launch(gpu_required):
+    # > 1024 queries: several GEMM launches (kGemmMaxQueries), the tail through whatever kernel its size selects
+    rng = np.random.default_rng(31)
+    n, dim = 3000, 64
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    Q = rng.standard_normal((1100, dim)).astype(np.float32)
+    ix = va.HnswIndex(dim, DM.DotProduct)
+    ix.upload(np.arange(n), rows)
+    gid, gsc, gcnt = ix.search_batch_brute_force(Q, 10)
+    eid, esc = po.scan_topk(po.DOT, rows, Q, 10, po.MODE_M, nthreads=8)
+    assert np.all(gcnt == 10) and np.array_equal(gid, eid) and np.array_equal(bits(gsc), bits(esc))
+    ix.close()
+
+
 def test_gemm_sweep_special_values(gpu_required):
     # zero rows / zero queries (cosine 0.0), NaN and inf rows: same bits and order as the oracle's total order
     rng = np.random.default_rng(77)
