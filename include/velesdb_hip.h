@@ -93,8 +93,11 @@ enum vdb_storage_mode {
 enum vdb_distance_kind {
   VDB_KIND_ENGINE = 0, /* DistanceEngine::distance (native/distance.rs:75-85): 1-cos, sqrt(l2),
                           -dot, hamming, 1-jaccard                                          */
-  VDB_KIND_RAW = 1     /* HnswIndex::compute_distance / GpuAccelerator::batch_* (search.rs:30-38;
-                          gpu_backend.rs:157,355,397): cos, sqrt(l2), dot, hamming, jaccard */
+  VDB_KIND_RAW = 1,    /* HnswIndex::compute_distance / GpuAccelerator::batch_* (search.rs:30-38;
+                          gpu_backend.rs:157,355,397): cos, sqrt(l2), dot, hamming, jaccard.  With VDB_DOT this is also
+                          simd::cosine_similarity_normalized / batch_cosine_normalized (simd_avx512.rs:390-422: the
+                          cosine of pre-normalised vectors IS their dot product)                     */
+  VDB_KIND_SQUARED = 2 /* simd::squared_l2_distance (simd.rs:207-211): VDB_EUCLIDEAN without the sqrt */
 };
 
 /* ---- device discovery: GpuAccelerator::new()/is_available() (gpu_backend.rs:33,136) ---- */
@@ -194,6 +197,23 @@ int32_t vdb_hip_batch_distance(int32_t device, int32_t metric, int32_t kind, con
 int32_t vdb_hip_batch_distance_dev(int32_t metric, int32_t kind, const float* d_query,
                                    const float* d_vecs_rowmajor, uint64_t n, uint32_t dim, float* d_out,
                                    void* stream);
+
+/* ---- the other free functions of the reference's SIMD module on the path, n vectors per call
+ * (host pointers, row-major; vec_utils.hip) ---- */
+/* simd::norm / simd_explicit::norm_simd (simd.rs:240-242; simd_explicit.rs:194-215): out[i] = |vecs[i]| */
+int32_t vdb_hip_batch_norm(int32_t device, const float* vecs_rowmajor, uint64_t n, uint32_t dim, float* out);
+/* simd::normalize_inplace (simd.rs:217-219; simd_explicit.rs:638-664): rows scaled to unit length in place; a zero
+ * vector stays as it is */
+int32_t vdb_hip_normalize_rows(int32_t device, float* vecs_rowmajor, uint64_t n, uint32_t dim);
+/* simd_explicit::batch_dot_product (simd_explicit.rs:519-560): out[i * n + j] = dot(queries[i], vecs[j]) */
+int32_t vdb_hip_batch_dot_product(int32_t device, const float* queries_rowmajor, uint32_t nq, const float* vecs_rowmajor,
+                                  uint64_t n, uint32_t dim, float* out);
+/* hamming_distance_binary(_fast) / jaccard_similarity_binary over packed u64 words (simd_explicit.rs:308-360,457-500):
+ * one query of `words` u64 against n rows of `words` u64 */
+int32_t vdb_hip_batch_hamming_binary(int32_t device, const uint64_t* query_words, const uint64_t* rows_words, uint64_t n,
+                                     uint32_t words, uint32_t* out);
+int32_t vdb_hip_batch_jaccard_binary(int32_t device, const uint64_t* query_words, const uint64_t* rows_words, uint64_t n,
+                                     uint32_t words, float* out);
 
 /* ---- persistence hand-off: NativeHnsw::file_dump / file_load, format v1
  * (native/backend_adapter.rs:184-381): <dir>/<basename>.vectors and .graph ---- */

@@ -31,6 +31,11 @@ SIGNATURES = {
     "vdb_hip_device_name": (_i32, [_i32, C.c_char_p, C.c_size_t]),
     "vdb_hip_index_create": (_i32, [_u32, _i32, _u32, _u32, _u64, _i32, C.POINTER(_vp)]),
     "vdb_hip_index_destroy": (None, [_vp]),
+    "vdb_hip_batch_norm": (_i32, [_i32, _vp, _u64, _u32, _vp]),
+    "vdb_hip_normalize_rows": (_i32, [_i32, _vp, _u64, _u32]),
+    "vdb_hip_batch_dot_product": (_i32, [_i32, _vp, _u32, _vp, _u64, _u32, _vp]),
+    "vdb_hip_batch_hamming_binary": (_i32, [_i32, _vp, _vp, _u64, _u32, _vp]),
+    "vdb_hip_batch_jaccard_binary": (_i32, [_i32, _vp, _vp, _u64, _u32, _vp]),
     "vdb_hip_index_save_dir": (_i32, [_vp, C.c_char_p]),
     "vdb_hip_index_load_dir": (_i32, [C.c_char_p, _i32, C.POINTER(_vp)]),
     "vdb_hip_index_insert": (_i32, [_vp, _u64, _vp, _u32]),

@@ -945,7 +945,8 @@ int32_t vdb_hip_index_search(vdb_hip_index* ix, const float* query, uint32_t que
 // (gpu/gpu_backend.rs:157,355,397)
 int32_t vdb_hip_batch_distance_dev(int32_t metric, int32_t kind, const float* d_query, const float* d_vecs,
                                    uint64_t n, uint32_t dim, float* d_out, void* stream) {
-  if (metric < 0 || metric > 4 || (kind != 0 && kind != 1)) return fail(VDB_ERR_INVALID_ARG, "bad metric/kind");
+  if (metric < 0 || metric > 4 || kind < 0 || kind > 2 || (kind == VDB_KIND_SQUARED && metric != VDB_EUCLIDEAN))
+    return fail(VDB_ERR_INVALID_ARG, "bad metric/kind");
   if (n == 0 || dim == 0) return VDB_OK;  // gpu_backend.rs:163-169: empty in, empty out
   if (!d_query || !d_vecs || !d_out) return fail(VDB_ERR_INVALID_ARG, "null argument");
   ScoreArgs a{};
@@ -963,7 +964,8 @@ int32_t vdb_hip_batch_distance_dev(int32_t metric, int32_t kind, const float* d_
 
 int32_t vdb_hip_batch_distance(int32_t device, int32_t metric, int32_t kind, const float* query, const float* vecs,
                                uint64_t n, uint32_t dim, float* out) {
-  if (metric < 0 || metric > 4 || (kind != 0 && kind != 1)) return fail(VDB_ERR_INVALID_ARG, "bad metric/kind");
+  if (metric < 0 || metric > 4 || kind < 0 || kind > 2 || (kind == VDB_KIND_SQUARED && metric != VDB_EUCLIDEAN))
+    return fail(VDB_ERR_INVALID_ARG, "bad metric/kind");
   int32_t ndev = 0;
   int32_t rc = check_device(&ndev);
   if (rc != VDB_OK) return rc;

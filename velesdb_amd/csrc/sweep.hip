@@ -1027,6 +1027,7 @@ __global__ __launch_bounds__(256) void score_rows(ScoreArgs a) {
       float vn = 1.0f;
       if (METRIC == kCosine) vn = sqrtf(butterfly_all(nacc));
       float s = finish_score<METRIC>(sum, qn, vn);
+      if (METRIC == kEuclidean && a.kind == 2) s = sum;  // simd::squared_l2_distance (simd.rs:207-211): no sqrt
       if (a.kind == 0) {  // DistanceEngine::distance (native/distance.rs:78-80)
         if (METRIC == kCosine) s = 1.0f - s;
         if (METRIC == kDot) s = -s;
