@@ -159,6 +159,11 @@ int32_t vdb_hip_index_remove(vdb_hip_index* idx, uint64_t id, int32_t* removed);
 int32_t vdb_hip_index_len(const vdb_hip_index* idx, uint64_t* n);
 int32_t vdb_hip_index_dimension(const vdb_hip_index* idx, uint32_t* dim);
 int32_t vdb_hip_index_metric(const vdb_hip_index* idx, int32_t* metric);
+/* HnswIndex::tombstone_count / vacuum (index/hnsw/index/vacuum.rs:45-52,110-184).  tombstone_ratio = count / node_count,
+ * needs_vacuum = ratio > 0.2 (:60-76).  vacuum rebuilds the graph over the active vectors with HnswParams::auto(dim);
+ * *count = vectors in the rebuilt index. */
+int32_t vdb_hip_index_tombstone_count(const vdb_hip_index* idx, uint64_t* n);
+int32_t vdb_hip_index_vacuum(vdb_hip_index* idx, uint64_t* count);
 /* number of graph nodes (NativeHnsw::len, native/graph.rs:130-132; includes soft-deleted) */
 int32_t vdb_hip_index_node_count(const vdb_hip_index* idx, uint64_t* n);
 

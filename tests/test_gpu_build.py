@@ -217,3 +217,41 @@ def test_index_directory_save_load_with_id_mappings(tmp_path, metric, pm):
     # errors: missing files are an I/O status, not a crash
     with pytest.raises(va.VelesHipError):
         va.HnswIndex.load(str(tmp_path / "nowhere"))
+
+
+def test_vacuum_rebuilds_without_tombstones():
+    # index/hnsw/index/vacuum.rs: tombstone_count / ratio / needs_vacuum, vacuum = rebuild over the active vectors with
+    # HnswParams::auto.  Deterministic here: ascending old index, batch-synchronous build => equal, link for link, to
+    # the oracle's batched build of the same rows.
+    rng = np.random.default_rng(55)
+    n, dim = 900, 48
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64) * 3 + 7
+    ix = va.HnswIndex(dim, DM.Cosine, va.HnswParams(8, 60, n))
+    ix.insert_batch_parallel([(int(ids[i]), rows[i]) for i in range(n)])
+    assert ix.tombstone_count() == 0 and ix.tombstone_ratio() == 0.0 and not ix.needs_vacuum()
+    dead = rng.choice(n, 250, replace=False)
+    for d in dead:
+        assert ix.remove(int(ids[d]))
+    assert ix.tombstone_count() == 250 and abs(ix.tombstone_ratio() - 250 / 900) < 1e-12 and ix.needs_vacuum()
+    live = np.ones(n, bool)
+    live[dead] = False
+    q = rng.standard_normal((6, dim)).astype(np.float32)
+    before = [ix.search_brute_force(x, 10) for x in q]
+    assert ix.vacuum() == n - 250
+    assert ix.len() == n - 250 and ix.node_count() == n - 250 and ix.tombstone_count() == 0 and not ix.needs_vacuum()
+    assert [ix.search_brute_force(x, 10) for x in q] == before          # exact search unchanged
+    M, efc = 24, 300                                                     # HnswParams::auto(48) (params.rs:41-57)
+    g = oracle_graph(rows[live], DM.Cosine, M, efc, max_batch=2048)
+    assert_same_graph(g, ix, n - 250)
+    res = ix.search_batch_parallel(q, 10, SQ.Custom(64))
+    lid = ids[live]
+    for x, r in zip(q, res):
+        oid, _ = g.search(x, 10, 64, po.TIE_CANONICAL)
+        assert [a for a, _ in r] == lid[oid.astype(np.int64)].tolist()
+    # removed ids are gone for good, inserts continue
+    assert not ix.remove(int(ids[dead[0]]))
+    ix.insert(int(ids[dead[0]]), rows[dead[0]])
+    assert ix.len() == n - 249
+    empty = va.HnswIndex(dim, DM.Cosine)
+    assert empty.vacuum() == 0 and empty.tombstone_ratio() == 0.0

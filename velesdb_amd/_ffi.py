@@ -36,6 +36,8 @@ SIGNATURES = {
     "vdb_hip_batch_dot_product": (_i32, [_i32, _vp, _u32, _vp, _u64, _u32, _vp]),
     "vdb_hip_batch_hamming_binary": (_i32, [_i32, _vp, _vp, _u64, _u32, _vp]),
     "vdb_hip_batch_jaccard_binary": (_i32, [_i32, _vp, _vp, _u64, _u32, _vp]),
+    "vdb_hip_index_tombstone_count": (_i32, [_vp, _pu64]),
+    "vdb_hip_index_vacuum": (_i32, [_vp, _pu64]),
     "vdb_hip_index_save_dir": (_i32, [_vp, C.c_char_p]),
     "vdb_hip_index_load_dir": (_i32, [C.c_char_p, _i32, C.POINTER(_vp)]),
     "vdb_hip_index_insert": (_i32, [_vp, _u64, _vp, _u32]),

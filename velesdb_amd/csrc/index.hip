@@ -829,6 +829,82 @@ int32_t vdb_hip_index_len(const vdb_hip_index* ix, uint64_t* n) {  // trait_impl
   *n = ix->live;
   return VDB_OK;
 }
+// HnswIndex::tombstone_count (index/hnsw/index/vacuum.rs:45-52): entries removed from the mappings but still in the
+// graph = next_idx - len.  tombstone_ratio / needs_vacuum (:60-76) follow from it and vdb_hip_index_node_count.
+int32_t vdb_hip_index_tombstone_count(const vdb_hip_index* ix, uint64_t* n) {
+  if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  *n = ix->n_rows - ix->live;
+  return VDB_OK;
+}
+
+// HnswIndex::vacuum (vacuum.rs:110-184): rebuild the graph over the active vectors only, with HnswParams::auto of the
+// dimension (params.rs:41-57), new internal indices 0..count-1.  The reference collects the active vectors in
+// hash-map order and inserts them with rayon (non-deterministic); here: ascending old internal index, the
+// deterministic batch-synchronous construction (vdb_hip_index_insert_batch_parallel).  Quantised / bf16 copies are
+// re-encoded with the rows.
+int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
+  if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::mutex> g(ix->mu);
+  VDB_HIP(hipSetDevice(ix->device));
+  const uint64_t n_old = ix->n_rows, n_live = ix->live;
+  if (count) *count = n_live;
+  if (n_live == 0) return VDB_OK;  // vacuum.rs:123-125: nothing to rebuild
+  // 1. snapshot of the active vectors (vacuum.rs:115-121)
+  std::vector<float> all((size_t)n_old * ix->dim);
+  VDB_HIP(hipMemcpy2DAsync(all.data(), (size_t)ix->dim * 4, ix->rows.p, ix->row_stride * 4, (size_t)ix->dim * 4, n_old,
+                           hipMemcpyDeviceToHost, ix->stream));
+  VDB_HIP(hipStreamSynchronize(ix->stream));
+  std::vector<float> vecs((size_t)n_live * ix->dim);
+  std::vector<uint64_t> ids(n_live);
+  uint64_t w = 0;
+  for (uint64_t i = 0; i < n_old; i++)
+    if (ix->idx_live[i]) {
+      std::memcpy(vecs.data() + (size_t)w * ix->dim, all.data() + (size_t)i * ix->dim, (size_t)ix->dim * 4);
+      ids[w++] = ix->idx_to_id[i];
+    }
+  all.clear();
+  all.shrink_to_fit();
+  // 2. fresh graph state with auto parameters (vacuum.rs:127-134)
+  ix->M = ix->dim <= 256 ? 24 : 32;
+  ix->M0 = ix->M * 2;
+  ix->efc = ix->dim <= 256 ? 300 : 400;
+  for (auto& L : ix->layers) {
+    L.nbr.release();
+    L.cnt.release();
+    L.ndist.release();
+  }
+  ix->layers.clear();
+  GraphLayer l0;
+  l0.stride = ix->M0;
+  ix->layers.push_back(l0);
+  ix->entry_point = -1;
+  ix->max_layer = 0;
+  ix->graph_nodes = 0;
+  ix->graph_valid = true;
+  ix->ndist_valid = true;
+  ix->rng_state = 0x5DEECE66D1A4B5B5ull;
+  ix->id_to_idx.clear();
+  ix->idx_to_id.clear();
+  ix->idx_live.clear();
+  ix->live = 0;
+  ix->any_dead = false;
+  ix->n_rows = 0;
+  ix->bf16_rows = 0;
+  const uint64_t cap = ix->capacity;
+  ix->capacity = 0;  // re-reserve the per-row arrays (rows keep their buffer; the new layer arrays are allocated)
+  int32_t rc = ensure_capacity(ix, std::max<uint64_t>(cap, 1));
+  if (rc != VDB_OK) return rc;
+  // 3./4./5. re-register, re-store, link (vacuum.rs:136-154)
+  uint64_t ins = 0, first = 0;
+  rc = append_host_rows(ix, ids.data(), vecs.data(), n_live, &ins, &first);
+  if (rc != VDB_OK) return rc;
+  rc = graph_insert_rows(ix, 0, n_live, 0);
+  if (rc != VDB_OK) return rc;
+  VDB_HIP(hipStreamSynchronize(ix->stream));
+  return VDB_OK;
+}
+
 int32_t vdb_hip_index_node_count(const vdb_hip_index* ix, uint64_t* n) {
   if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
   std::lock_guard<std::mutex> g(ix->mu);

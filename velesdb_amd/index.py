@@ -308,6 +308,26 @@ class HnswIndex:
         check(lib().vdb_hip_index_upload(self._h, _ptr(ids), _ptr(vecs), vecs.shape[0], C.byref(n)))
         return int(n.value)
 
+    # ---- maintenance (index/hnsw/index/vacuum.rs) ------------------------------------------
+    def tombstone_count(self) -> int:
+        n = C.c_uint64(0)
+        check(lib().vdb_hip_index_tombstone_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def tombstone_ratio(self) -> float:  # vacuum.rs:60-67
+        total = self.node_count()
+        return 0.0 if total == 0 else self.tombstone_count() / total
+
+    def needs_vacuum(self) -> bool:  # vacuum.rs:74-76
+        return self.tombstone_ratio() > 0.2
+
+    def vacuum(self) -> int:
+        """Rebuild without tombstones (vacuum.rs:110-184); returns the number of vectors in the rebuilt index."""
+        n = C.c_uint64(0)
+        check(lib().vdb_hip_index_vacuum(self._h, C.byref(n)))
+        self.params = HnswParams.auto(self._dimension)
+        return int(n.value)
+
     def set_searching_mode(self) -> None:  # search.rs:380-384: no-op for the native engine
         pass
 
