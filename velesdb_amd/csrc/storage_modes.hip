@@ -190,14 +190,8 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
     float acc[B];
 #pragma unroll
     for (int b = 0; b < B; b++) acc[b] = 0.0f;
-    // query elements are wave-uniform: read straight from global memory with a uniform address, i.e. scalar loads into
-    // SGPRs that the multiplies take as operands (LDS broadcast reads of the same data made the LDS pipe the bound)
-    // (constant address space: the queries are read-only for the whole launch, which is what lets hipcc use s_load)
-    typedef const __attribute__((address_space(4))) float* cfloat_p;
-    cfloat_p qg[B];
-#pragma unroll
-    for (int b = 0; b < B; b++)
-      qg[b] = (cfloat_p)(uintptr_t)(a.queries + (size_t)((uint32_t)b < a.nq ? b : 0) * a.q_stride);
+    // query elements: LDS, dimension-major [dim][B] — one broadcast ds_read_b128 brings element i of all 4 queries as two
+    // adjacent pairs, the operands of the packed multiplies below
     // staging loads run one 64-byte column chunk ahead of the arithmetic (registers), so their latency hides
     // behind the previous chunk's ~700 VALU instructions
     uint4 stg[4];
@@ -229,62 +223,125 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
       __builtin_amdgcn_wave_barrier();  // tile reads done before the next chunk overwrites it
       const uint32_t wds[16] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w,
                                 w4[2].x, w4[2].y, w4[2].z, w4[2].w, w4[3].x, w4[3].y, w4[3].z, w4[3].w};
-#pragma unroll
-      for (int wi = 0; wi < 16; wi++) {
-        const uint32_t i0 = c0 + wi * 4;
-        if (i0 >= dim) break;  // uniform
-        const uint32_t w = wds[wi];
-        float dq[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) dq[e] = __fadd_rn(__fmul_rn((float)((w >> (8 * e)) & 0xFFu), scale), mn);
-        // Two queries per instruction where B is even (v_pk_mul_f32 / v_pk_add_f32: each half is the same IEEE
-        // operation as the scalar form, so the bits do not change; a plain f32 VALU op runs at half the packed rate).
-        constexpr int P = B / 2;  // query pairs
-        if (METRIC == kEuclidean) {
-          if (i0 + 3 < dim) {  // a full group of four: sum += ((f0^2 + f1^2) + f2^2) + f3^2 (:495-507)
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-              f32x2 t = {0.f, 0.f};
-#pragma unroll
-              for (int e = 0; e < 4; e++) {
-                const f32x2 f = f32x2{qg[2 * p][i0 + e], qg[2 * p + 1][i0 + e]} - f32x2{dq[e], dq[e]};
-                t = e == 0 ? f * f : t + f * f;
+      if (c0 + 64 <= dim) {  // full chunk: no bounds tests => ONE basic block, the scheduler overlaps the LDS reads of
+                             // later groups with the arithmetic of earlier ones (per-group branches pinned them)
+  #pragma unroll
+        for (int wi = 0; wi < 16; wi++) {
+          const uint32_t i0 = c0 + wi * 4;
+          const uint32_t w = wds[wi];
+          float dq[4];
+  #pragma unroll
+          for (int e = 0; e < 4; e++) dq[e] = __fadd_rn(__fmul_rn((float)((w >> (8 * e)) & 0xFFu), scale), mn);
+          // Two queries per instruction where B is even (v_pk_mul_f32 / v_pk_add_f32: each half is the same IEEE
+          // operation as the scalar form, so the bits do not change; a plain f32 VALU op runs at half the packed rate).
+          constexpr int P = B / 2;  // query pairs
+          if (METRIC == kEuclidean) {
+            if (true) {  // a full group of four: sum += ((f0^2 + f1^2) + f2^2) + f3^2 (:495-507)
+  #pragma unroll
+              for (int p = 0; p < P; p++) {
+                f32x2 t = {0.f, 0.f};
+  #pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  const f32x2 f = f32x2{qs[(size_t)(i0 + e) * B + (2 * p)], qs[(size_t)(i0 + e) * B + (2 * p + 1)]} - f32x2{dq[e], dq[e]};
+                  t = e == 0 ? f * f : t + f * f;
+                }
+                acc[2 * p] = __fadd_rn(acc[2 * p], t.x);
+                acc[2 * p + 1] = __fadd_rn(acc[2 * p + 1], t.y);
               }
-              acc[2 * p] = __fadd_rn(acc[2 * p], t.x);
-              acc[2 * p + 1] = __fadd_rn(acc[2 * p + 1], t.y);
-            }
-            if (B & 1) {
-              const int b = B - 1;
-              const float f0 = __fsub_rn(qg[b][i0 + 0], dq[0]), f1 = __fsub_rn(qg[b][i0 + 1], dq[1]);
-              const float f2 = __fsub_rn(qg[b][i0 + 2], dq[2]), f3 = __fsub_rn(qg[b][i0 + 3], dq[3]);
-              const float t = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(f0, f0), __fmul_rn(f1, f1)), __fmul_rn(f2, f2)),
-                                        __fmul_rn(f3, f3));
-              acc[b] = __fadd_rn(acc[b], t);
-            }
-          } else {  // remainder: one element at a time (:510-515)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-              if (i0 + e < dim) {
-#pragma unroll
-                for (int b = 0; b < B; b++) {
-                  const float f = __fsub_rn(qg[b][i0 + e], dq[e]);
-                  acc[b] = __fadd_rn(acc[b], __fmul_rn(f, f));
+              if (B & 1) {
+                const int b = B - 1;
+                const float f0 = __fsub_rn(qs[(size_t)(i0 + 0) * B + (b)], dq[0]), f1 = __fsub_rn(qs[(size_t)(i0 + 1) * B + (b)], dq[1]);
+                const float f2 = __fsub_rn(qs[(size_t)(i0 + 2) * B + (b)], dq[2]), f3 = __fsub_rn(qs[(size_t)(i0 + 3) * B + (b)], dq[3]);
+                const float t = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(f0, f0), __fmul_rn(f1, f1)), __fmul_rn(f2, f2)),
+                                          __fmul_rn(f3, f3));
+                acc[b] = __fadd_rn(acc[b], t);
+              }
+            } else {  // remainder: one element at a time (:510-515)
+  #pragma unroll
+              for (int e = 0; e < 4; e++) {
+                if (true) {
+  #pragma unroll
+                  for (int b = 0; b < B; b++) {
+                    const float f = __fsub_rn(qs[(size_t)(i0 + e) * B + (b)], dq[e]);
+                    acc[b] = __fadd_rn(acc[b], __fmul_rn(f, f));
+                  }
                 }
               }
             }
-          }
-        } else {  // dot chain (:452-466), also the numerator of the cosine
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            if (i0 + e < dim) {
-#pragma unroll
-              for (int p = 0; p < P; p++) {
-                const f32x2 r = f32x2{acc[2 * p], acc[2 * p + 1]} +
-                                f32x2{qg[2 * p][i0 + e], qg[2 * p + 1][i0 + e]} * f32x2{dq[e], dq[e]};
-                acc[2 * p] = r.x;
-                acc[2 * p + 1] = r.y;
+          } else {  // dot chain (:452-466), also the numerator of the cosine
+  #pragma unroll
+            for (int e = 0; e < 4; e++) {
+              if (true) {
+  #pragma unroll
+                for (int p = 0; p < P; p++) {
+                  const f32x2 r = f32x2{acc[2 * p], acc[2 * p + 1]} +
+                                  f32x2{qs[(size_t)(i0 + e) * B + (2 * p)], qs[(size_t)(i0 + e) * B + (2 * p + 1)]} * f32x2{dq[e], dq[e]};
+                  acc[2 * p] = r.x;
+                  acc[2 * p + 1] = r.y;
+                }
+                if (B & 1) acc[B - 1] = __fadd_rn(acc[B - 1], __fmul_rn(qs[(size_t)(i0 + e) * B + (B - 1)], dq[e]));
               }
-              if (B & 1) acc[B - 1] = __fadd_rn(acc[B - 1], __fmul_rn(qg[B - 1][i0 + e], dq[e]));
+            }
+          }
+        }
+      } else {
+  #pragma unroll
+        for (int wi = 0; wi < 16; wi++) {
+          const uint32_t i0 = c0 + wi * 4;
+          if (i0 >= dim) break;  // uniform
+          const uint32_t w = wds[wi];
+          float dq[4];
+  #pragma unroll
+          for (int e = 0; e < 4; e++) dq[e] = __fadd_rn(__fmul_rn((float)((w >> (8 * e)) & 0xFFu), scale), mn);
+          // Two queries per instruction where B is even (v_pk_mul_f32 / v_pk_add_f32: each half is the same IEEE
+          // operation as the scalar form, so the bits do not change; a plain f32 VALU op runs at half the packed rate).
+          constexpr int P = B / 2;  // query pairs
+          if (METRIC == kEuclidean) {
+            if (i0 + 3 < dim) {  // a full group of four: sum += ((f0^2 + f1^2) + f2^2) + f3^2 (:495-507)
+  #pragma unroll
+              for (int p = 0; p < P; p++) {
+                f32x2 t = {0.f, 0.f};
+  #pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  const f32x2 f = f32x2{qs[(size_t)(i0 + e) * B + (2 * p)], qs[(size_t)(i0 + e) * B + (2 * p + 1)]} - f32x2{dq[e], dq[e]};
+                  t = e == 0 ? f * f : t + f * f;
+                }
+                acc[2 * p] = __fadd_rn(acc[2 * p], t.x);
+                acc[2 * p + 1] = __fadd_rn(acc[2 * p + 1], t.y);
+              }
+              if (B & 1) {
+                const int b = B - 1;
+                const float f0 = __fsub_rn(qs[(size_t)(i0 + 0) * B + (b)], dq[0]), f1 = __fsub_rn(qs[(size_t)(i0 + 1) * B + (b)], dq[1]);
+                const float f2 = __fsub_rn(qs[(size_t)(i0 + 2) * B + (b)], dq[2]), f3 = __fsub_rn(qs[(size_t)(i0 + 3) * B + (b)], dq[3]);
+                const float t = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(f0, f0), __fmul_rn(f1, f1)), __fmul_rn(f2, f2)),
+                                          __fmul_rn(f3, f3));
+                acc[b] = __fadd_rn(acc[b], t);
+              }
+            } else {  // remainder: one element at a time (:510-515)
+  #pragma unroll
+              for (int e = 0; e < 4; e++) {
+                if (i0 + e < dim) {
+  #pragma unroll
+                  for (int b = 0; b < B; b++) {
+                    const float f = __fsub_rn(qs[(size_t)(i0 + e) * B + (b)], dq[e]);
+                    acc[b] = __fadd_rn(acc[b], __fmul_rn(f, f));
+                  }
+                }
+              }
+            }
+          } else {  // dot chain (:452-466), also the numerator of the cosine
+  #pragma unroll
+            for (int e = 0; e < 4; e++) {
+              if (i0 + e < dim) {
+  #pragma unroll
+                for (int p = 0; p < P; p++) {
+                  const f32x2 r = f32x2{acc[2 * p], acc[2 * p + 1]} +
+                                  f32x2{qs[(size_t)(i0 + e) * B + (2 * p)], qs[(size_t)(i0 + e) * B + (2 * p + 1)]} * f32x2{dq[e], dq[e]};
+                  acc[2 * p] = r.x;
+                  acc[2 * p + 1] = r.y;
+                }
+                if (B & 1) acc[B - 1] = __fadd_rn(acc[B - 1], __fmul_rn(qs[(size_t)(i0 + e) * B + (B - 1)], dq[e]));
+              }
             }
           }
         }
