@@ -111,3 +111,39 @@ def test_bf16_gemm_exact_values_are_exact():
     assert ix.remove(int(gi[0, 0]))
     gi2, _, _ = ix.search_batch_brute_force_bf16(qs, 10)
     assert int(gi[0, 0]) not in gi2[0].tolist()
+
+
+@pytest.mark.parametrize("metric,pm", [(DM.Cosine, po.COSINE), (DM.DotProduct, po.DOT)])
+@pytest.mark.parametrize("n,dim", [(10007, 768), (700, 64), (300, 192)])
+def test_bf16_gemm_big_tile(metric, pm, n, dim):
+    # batches that fill 256-query tiles to >= 7/8 and k <= 16: the 256-row x 256-query tile (8 waves, one block per CU);
+    # ragged query / row tiles
+    rng = np.random.default_rng(n * 3 + dim)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ix = va.HnswIndex(dim, metric)
+    ix.upload(np.arange(n), rows)
+    ix.enable_bf16()
+    for nq, k in [(230, 10), (480, 16), (700, 16), (1024, 1)]:
+        qs = rng.standard_normal((nq, dim)).astype(np.float32)
+        gi, gs, gc = ix.search_batch_brute_force_bf16(qs, k)
+        check(metric, pm, rows, qs, k, gi, gs, gc)
+    # k > 16 needs 64-entry candidate buffers, which do not fit beside the big tile: the 128 x 128 tile takes over
+    qs = rng.standard_normal((500, dim)).astype(np.float32)
+    gi, gs, gc = ix.search_batch_brute_force_bf16(qs, 20)
+    check(metric, pm, rows, qs, 20, gi, gs, gc)
+    ix.close()
+
+
+def test_bf16_gemm_big_tile_exact_and_deleted_rows():
+    rng = np.random.default_rng(16)
+    rows = rng.integers(-4, 5, size=(9000, 128)).astype(np.float32)
+    qs = rng.integers(-4, 5, size=(520, 128)).astype(np.float32)
+    ix = va.HnswIndex(128, DM.DotProduct)
+    ix.upload(np.arange(9000), rows)
+    ix.enable_bf16()
+    gi, gs, gc = ix.search_batch_brute_force_bf16(qs, 10)
+    eid, esc = po.scan_topk_bf16(po.DOT, rows, qs, 10, nthreads=4)
+    assert np.array_equal(gi, eid) and np.array_equal(gs, esc)   # exact products: ties resolved by row like the oracle
+    assert ix.remove(int(gi[7, 0]))
+    gi2, _, _ = ix.search_batch_brute_force_bf16(qs, 10)
+    assert int(gi[7, 0]) not in gi2[7].tolist()

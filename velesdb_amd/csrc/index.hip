@@ -151,7 +151,7 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
     if (g_max_tile >= 128 && rem >= kGemmMinQueries && k <= kGemmMaxK && ix->dim % 64 == 0) {
       const uint32_t nqg = std::min<uint32_t>(rem, kGemmMaxQueries);
       GemmPlan gp;
-      sweep_gemm_plan(nqg, (uint32_t)ix->n_rows, ix->n_cus, k, &gp);
+      sweep_gemm_plan(nqg, (uint32_t)ix->n_rows, ix->n_cus, k, &gp, /*allow_big=*/true);
       if (gp.lds <= 160 * 1024) {
         hipError_t e3;
         if ((e3 = ix->s_part_keys.reserve((size_t)nqg * gp.G * k * 8, false, st)) != hipSuccess ||

@@ -37,6 +37,7 @@
 // Bound: the f32 matrix pipe (157.3 TFLOP/s dense); algorithmic flop per launch = 2 * n_rows * dim * nq.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 #include "vdb_device.hpp"
 #include "vdb_kernels.hpp"
@@ -71,26 +72,26 @@ struct GemmSweepArgs {
 
 // acc[rf][t][r] for a per-lane element index e = (rf*NQF + t)*4 + r, without dynamic register indexing: a binary
 // select tree (one v_cndmask per inner node, the six bit tests shared by a level).
-template <int NQF, int LO, int N>
+template <int RF, int NQF, int LO, int N>
 struct AccSelect {
-  static __device__ __forceinline__ float get(const f32x4 (&acc)[4][NQF], uint32_t e) {
-    if (LO >= 16 * NQF) return 0.0f;  // past the last element (NQF = 3: 48 of 64)
-    const float lo = AccSelect<NQF, LO, N / 2>::get(acc, e);
-    if (LO + N / 2 >= 16 * NQF) return lo;
-    const float hi = AccSelect<NQF, LO + N / 2, N / 2>::get(acc, e);
+  static __device__ __forceinline__ float get(const f32x4 (&acc)[RF][NQF], uint32_t e) {
+    if (LO >= 4 * RF * NQF) return 0.0f;  // past the last element (NQF = 3: 48 of 64)
+    const float lo = AccSelect<RF, NQF, LO, N / 2>::get(acc, e);
+    if (LO + N / 2 >= 4 * RF * NQF) return lo;
+    const float hi = AccSelect<RF, NQF, LO + N / 2, N / 2>::get(acc, e);
     return (e & (uint32_t)(N / 2)) ? hi : lo;
   }
 };
-template <int NQF, int LO>
-struct AccSelect<NQF, LO, 1> {
-  static __device__ __forceinline__ float get(const f32x4 (&acc)[4][NQF], uint32_t) {
-    if (LO >= 16 * NQF) return 0.0f;
+template <int RF, int NQF, int LO>
+struct AccSelect<RF, NQF, LO, 1> {
+  static __device__ __forceinline__ float get(const f32x4 (&acc)[RF][NQF], uint32_t) {
+    if (LO >= 4 * RF * NQF) return 0.0f;
     return acc[(LO / 4) / NQF][(LO / 4) % NQF][LO % 4];
   }
 };
-template <int NQF>
-__device__ __forceinline__ float select_acc(const f32x4 (&acc)[4][NQF], uint32_t e) {
-  return AccSelect<NQF, 0, 64>::get(acc, e);
+template <int RF, int NQF>
+__device__ __forceinline__ float select_acc(const f32x4 (&acc)[RF][NQF], uint32_t e) {
+  return AccSelect<RF, NQF, 0, (RF == 8 ? 128 : 64)>::get(acc, e);
 }
 
 // FULL: dim % 128 == 0 and the queries are readable as aligned float4 — no zero-fill, and the tile loads are
@@ -99,12 +100,21 @@ __device__ __forceinline__ float select_acc(const f32x4 (&acc)[4][NQF], uint32_t
 // uint16 data, strides in elements): k-tiles of 64 bf16 = the same 128 bytes per row, so the LDS geometry, staging and
 // epilogue are byte-for-byte the f32 kernel's; one 16-B fragment feeds ONE v_mfma_f32_16x16x32_bf16 (f32 accumulate:
 // half_precision.rs:199-255 semantics) instead of four f32 MFMAs.  FULL only (dim % 64 == 0).
-template <int METRIC, int NQF, bool QVEC, bool FULL, bool BF16>
-__global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) {
+// RF / WAVES: accumulator fragments per wave along the rows (wave tile = 16 RF rows x 16 NQF queries) and waves per
+// block (2 along the rows x WAVES/2 along the queries).  (4, 4) = the 128 x 32 NQF tile at two blocks per CU described
+// above; (8, 8) = a 256 x 256 tile, ONE block of eight waves per CU (bf16 only): twice the MFMAs per LDS fragment
+// read / staging instruction / barrier, half the row re-reads — the bf16 multiply is 16x cheaper per element than the
+// exact-f32 one, so there the per-step instruction overhead is what bounds the kernel.
+template <int METRIC, int NQF, bool QVEC, bool FULL, bool BF16, int RF = 4, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) {
   static_assert(!BF16 || FULL, "the bf16 variant has no zero-fill path");
+  static_assert((RF == 4 && WAVES == 4) || (RF == 8 && WAVES == 8 && NQF == 4 && BF16), "supported tile shapes");
   constexpr int ES = BF16 ? 2 : 4;        // bytes per element in HBM
   constexpr int BKE = 128 / ES;           // elements per k-tile (one 128-B line per row)
-  constexpr int BM = kGemmBM, BK = kGemmBK, BN = 32 * NQF;
+  constexpr int NT = WAVES * 64, WCOLS = WAVES / 2, WROWS = 16 * RF, SR = NT / 8;  // SR: rows staged per pass
+  constexpr int BM = 2 * WROWS, BK = kGemmBK, BN = WCOLS * 16 * NQF;
+  static_assert(BM == 4 * SR && BN == NQF * SR, "staging passes: 4 for the rows, NQF for the queries");
+  constexpr int NW = RF * NQF * 4 / 32 > 2 ? RF * NQF * 4 / 32 : 2;  // 32-bit words of the per-lane pass mask
   constexpr bool HIB = true;  // cosine and dot: higher is better
   const SweepArgs& a = ga.s;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -118,13 +128,13 @@ __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) 
   float* qn = reinterpret_cast<float*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 12);
   volatile uint32_t* ovf = reinterpret_cast<volatile uint32_t*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 16);  // overflow token
   float* vns = reinterpret_cast<float*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 16 + 16);  // [BM] norms of the row tile
-  uint64_t* wqueue_all = reinterpret_cast<uint64_t*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 16 + 16 + BM * 4);  // [4][kGemmQueue]
+  uint64_t* wqueue_all = reinterpret_cast<uint64_t*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 16 + 16 + BM * 4);  // [WAVES][kGemmQueue]
 
   __builtin_amdgcn_s_setprio(VDB_GEMM_PRIO);
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wib >> 1, wq = wib & 1;
+  const int wr = wib / WCOLS, wq = wib % WCOLS;
   uint64_t* wqueue = wqueue_all + wib * kGemmQueue;  // this wave's survivors of the filter: (dot bits, row in tile, query)
 
   // block -> (query tile, row group): the nqt query tiles of a row group sit on one XCD (blockIdx % 8)
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) 
   if (tid == 0) *ovf = 0u;
   __syncthreads();
   if (METRIC == kCosine && BF16) {  // norm of the ROUNDED query, canonical lane-chain order (as sweep_topk_mfma_bf16)
-    for (uint32_t b = wib; b < nq_t; b += 4) {
+    for (uint32_t b = wib; b < nq_t; b += WAVES) {
       const uint16_t* qp = reinterpret_cast<const uint16_t*>(queries) + (size_t)b * a.q_stride;
       float nacc = 0.0f;
       for (uint32_t c = lane; c * 4 < a.dim; c += 64)
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) 
     }
   } else if (METRIC == kCosine) {  // canonical query norms (same as every other kernel)
     const int d4 = (int)((a.dim + 3) / 4);
-    for (uint32_t b = wib; b < nq_t; b += 4) {
+    for (uint32_t b = wib; b < nq_t; b += WAVES) {
       const float* qp = queries + (size_t)b * a.q_stride;
       float nacc = 0.0f;
       for (int c = lane; c < d4; c += 64) {
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) 
   const uint32_t my_tiles = g < ntiles ? (ntiles - g + ga.G - 1) / ga.G : 0;
   const uint32_t total = my_tiles * ga.KT;
 
-  // ---- staging: thread t moves the 16-B slot (t & 7) of rows (t >> 3) + 32 j ----
+  // ---- staging: thread t moves the 16-B slot (t & 7) of rows (t >> 3) + SR j ----
   const int st_slot = tid & 7, st_row = tid >> 3;
   float4 ra[4], rb[NQF];
   uint32_t ld_rt = g, ld_kt = 0;  // (row tile, k-tile) of the NEXT step to load
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) 
   uint32_t voff_b[NQF];
 #pragma unroll
   for (int j = 0; j < NQF; j++) {
-    const uint32_t q = st_row + 32 * j;
+    const uint32_t q = st_row + SR * j;
     voff_b[j] = (q < nq_t ? q : nq_t - 1) * (uint32_t)a.q_stride * (uint32_t)ES + (uint32_t)st_slot * 16u;  // padded slots repeat a query
   }
   // (macros, not lambdas: hipcc does not always promote arrays captured by a lambda to registers)
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) 
       const unsigned char* base_b = reinterpret_cast<const unsigned char*>(queries) + (size_t)ld_kt * BKE * ES; \
 _Pragma("unroll") \
       for (int j = 0; j < 4; j++) \
-        ra[j] = ld4(reinterpret_cast<const float*>(base_a + (size_t)(32 * j) * a.row_stride * ES + voff_a)); \
+        ra[j] = ld4(reinterpret_cast<const float*>(base_a + (size_t)(SR * j) * a.row_stride * ES + voff_a)); \
 _Pragma("unroll") \
       for (int j = 0; j < NQF; j++) rb[j] = ld4(reinterpret_cast<const float*>(base_b + voff_b[j])); \
     } else { \
@@ -221,13 +231,13 @@ _Pragma("unroll") \
       const uint32_t kfa = kin ? kf : 0u; \
 _Pragma("unroll") \
       for (int j = 0; j < 4; j++) { \
-        uint32_t row = ld_rt * BM + st_row + 32 * j; \
+        uint32_t row = ld_rt * BM + st_row + SR * j; \
         row = row < a.n_rows ? row : a.n_rows - 1; \
         ra[j] = ld4(a.rows + (size_t)row * a.row_stride + kfa); \
       } \
 _Pragma("unroll") \
       for (int j = 0; j < NQF; j++) { \
-        const uint32_t q = st_row + 32 * j; \
+        const uint32_t q = st_row + SR * j; \
         const float* qp = queries + (size_t)(q < nq_t ? q : 0u) * a.q_stride; \
         if (QVEC) { \
           rb[j] = ld4(qp + (kf < a.dim ? kf : 0u)); \
@@ -243,15 +253,15 @@ _Pragma("unroll") \
       ld_rt += ga.G; \
     } \
   } while (0)
-  // staging writes: rows 32 apart share the swizzle term: one address + immediate offsets
+  // staging writes: rows SR (32 / 64) apart share the swizzle term: one address + immediate offsets
   unsigned char* const st_wr_a = reinterpret_cast<unsigned char*>(As) + st_row * (BK * 4) + ((st_slot ^ ((st_row >> 1) & 7)) << 4);
   unsigned char* const st_wr_b = reinterpret_cast<unsigned char*>(Bs) + st_row * (BK * 4) + ((st_slot ^ ((st_row >> 1) & 7)) << 4);
 #define VDB_GEMM_LDS_STORE() do { \
     if (FULL) { \
 _Pragma("unroll") \
-      for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4*>(st_wr_a + j * (32 * BK * 4)) = f32x4{ra[j].x, ra[j].y, ra[j].z, ra[j].w}; \
+      for (int j = 0; j < 4; j++) *reinterpret_cast<f32x4*>(st_wr_a + j * (SR * BK * 4)) = f32x4{ra[j].x, ra[j].y, ra[j].z, ra[j].w}; \
 _Pragma("unroll") \
-      for (int j = 0; j < NQF; j++) *reinterpret_cast<f32x4*>(st_wr_b + j * (32 * BK * 4)) = f32x4{rb[j].x, rb[j].y, rb[j].z, rb[j].w}; \
+      for (int j = 0; j < NQF; j++) *reinterpret_cast<f32x4*>(st_wr_b + j * (SR * BK * 4)) = f32x4{rb[j].x, rb[j].y, rb[j].z, rb[j].w}; \
     } else { \
     const bool kin = pend_kf < (uint32_t)a.row_stride; \
     const bool k0 = pend_kf < a.dim, k1 = pend_kf + 1 < a.dim, k2 = pend_kf + 2 < a.dim, k3 = pend_kf + 3 < a.dim; \
@@ -262,29 +272,29 @@ _Pragma("unroll") \
       v.y = kin ? v.y : 0.f; \
       v.z = kin ? v.z : 0.f; \
       v.w = kin ? v.w : 0.f; \
-      *reinterpret_cast<float4*>(st_wr_a + j * (32 * BK * 4)) = v; \
+      *reinterpret_cast<float4*>(st_wr_a + j * (SR * BK * 4)) = v; \
     } \
 _Pragma("unroll") \
     for (int j = 0; j < NQF; j++) { \
-      const int q = st_row + 32 * j; \
+      const int q = st_row + SR * j; \
       const bool qin = (uint32_t)q < nq_t; \
       float4 v = rb[j]; \
       v.x = (qin && k0) ? v.x : 0.f; \
       v.y = (qin && k1) ? v.y : 0.f; \
       v.z = (qin && k2) ? v.z : 0.f; \
       v.w = (qin && k3) ? v.w : 0.f; \
-      *reinterpret_cast<float4*>(st_wr_b + j * (32 * BK * 4)) = v; \
+      *reinterpret_cast<float4*>(st_wr_b + j * (SR * BK * 4)) = v; \
     } \
     } \
   } while (0)
 
-  f32x4 acc[4][NQF];
+  f32x4 acc[RF][NQF];
 #pragma unroll
-  for (int rf = 0; rf < 4; rf++)
+  for (int rf = 0; rf < RF; rf++)
 #pragma unroll
     for (int t = 0; t < NQF; t++) acc[rf][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- compaction of the candidate buffers this wave owns (queries wib, wib+4, ...) ----
+  // ---- compaction of the candidate buffers this wave owns (queries wib, wib+WAVES, ...) ----
   // `force`: every buffer holding more than k keys (overflow rounds, end of the sweep); otherwise only the
   // buffers past the watermark — a query's k-th best then lags behind, which costs a few more (cheap) appends
   // and saves most of the (expensive) compactions: ~4 per query and block instead of one per row tile.
@@ -293,8 +303,8 @@ _Pragma("unroll") \
 #endif
   const uint32_t watermark = (k + CAP) / 2;
   auto compact = [&](bool force) __attribute__((always_inline)) {
-    // lane l looks at query wib + 4*l
-    const uint32_t bq = (uint32_t)wib + 4u * (uint32_t)lane;
+    // lane l looks at query wib + WAVES*l
+    const uint32_t bq = (uint32_t)wib + (uint32_t)WAVES * (uint32_t)lane;
     const uint32_t cq = bq < nq_t ? cnts[bq] : 0u;
     uint64_t need = __ballot(cq > k && (force || cq >= watermark));
     // 64 / CAP buffers per pass (CAP = 32: the two halves of the wave rank one buffer each): a lane holds one key
@@ -309,7 +319,7 @@ _Pragma("unroll") \
         need &= need - 1;
       }
       const bool active = half == 0 || src1 != src0;  // odd count: the second half idles
-      const uint32_t b = (uint32_t)wib + 4u * (uint32_t)(half ? src1 : src0);
+      const uint32_t b = (uint32_t)wib + (uint32_t)WAVES * (uint32_t)(half ? src1 : src0);
 #ifdef VDB_GEMM_STATS
       if (li == 0 && active) st_comp++;
 #endif
@@ -335,7 +345,7 @@ _Pragma("unroll") \
   const int sw_i = ((lane & 15) >> 1) & 7;
   const int rd_off = (lane & 15) * (BK * 4) + ((((lane >> 4) ^ sw_i) & 3) << 4);  // bits 0-1 of the slot
   const int rd_x = (sw_i & 4) << 4;                                                // bit 2 of the slot, as byte 64
-  const unsigned char* a_rd = reinterpret_cast<const unsigned char*>(As) + wr * 64 * (BK * 4) + rd_off;
+  const unsigned char* a_rd = reinterpret_cast<const unsigned char*>(As) + wr * WROWS * (BK * 4) + rd_off;
   const unsigned char* b_rd = reinterpret_cast<const unsigned char*>(Bs) + wq * 16 * NQF * (BK * 4) + rd_off;
   const int a_rd_x = rd_x, b_rd_x = rd_x;
 
@@ -372,13 +382,17 @@ _Pragma("unroll") \
       // rows 16 apart share the swizzle term, so the 4 / NQF fragment reads of a 16-deep group are one base +
       // immediate offsets; the second group flips bit 2 of the slot = byte 64 of the (swizzled) address.
       // Both groups are requested up front: the second one's LDS latency hides behind the first one's MFMAs.
-      float4 av[2][4], bv[2][NQF];
+      // (the 256 x 256 variant holds ONE 16-deep group at a time: 128 accumulator registers leave no room for two)
+      constexpr int MB = RF == 8 ? 1 : 2;
 #pragma unroll
-      for (int m = 0; m < 2; m++) {
+      for (int m0 = 0; m0 < 2; m0 += MB) {
+      float4 av[MB][RF], bv[MB][NQF];
 #pragma unroll
-        for (int rf = 0; rf < 4; rf++) av[m][rf] = *reinterpret_cast<const float4*>(a_rd + ((m * 64) ^ a_rd_x) + rf * (16 * BK * 4));
+      for (int m = 0; m < MB; m++) {
 #pragma unroll
-        for (int t = 0; t < NQF; t++) bv[m][t] = *reinterpret_cast<const float4*>(b_rd + ((m * 64) ^ b_rd_x) + t * (16 * BK * 4));
+        for (int rf = 0; rf < RF; rf++) av[m][rf] = *reinterpret_cast<const float4*>(a_rd + (((m0 + m) * 64) ^ a_rd_x) + rf * (16 * BK * 4));
+#pragma unroll
+        for (int t = 0; t < NQF; t++) bv[m][t] = *reinterpret_cast<const float4*>(b_rd + (((m0 + m) * 64) ^ b_rd_x) + t * (16 * BK * 4));
       }
       // Wave priority: LOW while streaming MFMAs, HIGH for everything else.  The two blocks of a CU share each SIMD's
       // issue port; at equal priority the staging / epilogue instructions of one block queue behind the partner's
@@ -388,20 +402,20 @@ _Pragma("unroll") \
       if (BF16) {
         typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+        for (int m = 0; m < MB; m++)
 #pragma unroll
-          for (int rf = 0; rf < 4; rf++)
+          for (int rf = 0; rf < RF; rf++)
 #pragma unroll
             for (int t = 0; t < NQF; t++)
               acc[rf][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[m][rf]),
                                                                   __builtin_bit_cast(bf16x8, bv[m][t]), acc[rf][t], 0, 0, 0);
       } else {
 #pragma unroll
-      for (int m = 0; m < 2; m++) {
+      for (int m = 0; m < MB; m++) {
 #pragma unroll
         for (int c = 0; c < 4; c++) {
 #pragma unroll
-          for (int rf = 0; rf < 4; rf++) {
+          for (int rf = 0; rf < RF; rf++) {
             const float ax = c == 0 ? av[m][rf].x : (c == 1 ? av[m][rf].y : (c == 2 ? av[m][rf].z : av[m][rf].w));
 #pragma unroll
             for (int t = 0; t < NQF; t++) {
@@ -413,12 +427,13 @@ _Pragma("unroll") \
       }
       }
       __builtin_amdgcn_s_setprio(VDB_GEMM_PRIO);
+      }
     }
 #endif
 #ifdef VDB_GEMM_ABL_NOEPI
     if (++kt == ga.KT) {
 #pragma unroll
-      for (int rf = 0; rf < 4; rf++)
+      for (int rf = 0; rf < RF; rf++)
 #pragma unroll
         for (int t = 0; t < NQF; t++) asm volatile("" ::"v"(acc[rf][t]));
       kt = 0;
@@ -436,7 +451,7 @@ _Pragma("unroll") \
 #ifdef VDB_GEMM_STATS
       {  // drain the matrix pipe first: the timestamp then marks the END of the multiply, not the end of its issue
         float drain;
-        asm volatile("v_mov_b32 %0, %1\n\ts_nop 4" : "=v"(drain) : "v"(acc[3][NQF - 1][3]));
+        asm volatile("v_mov_b32 %0, %1\n\ts_nop 4" : "=v"(drain) : "v"(acc[RF - 1][NQF - 1][3]));
         asm volatile("" ::"v"(drain));
       }
       const long long t_s0 = clock64();
@@ -475,7 +490,9 @@ _Pragma("unroll") \
     //      query's k-th best (16-ulp margin); cosine compares dot * (1/|v|) with cut * |q|: NaN / inf / zero-norm
     //      cases compare false and go to the exact path; padded query slots get +inf (nothing passes).  Rows past
     //      n_rows are weeded out by the dense pass (2).
-    uint32_t pm[2] = {0u, 0u};  // pm[0]: elements 0..31 (element e at bit 31 - e), pm[1]: elements 32..63
+    uint32_t pm[NW];  // pm[w]: elements 32w .. 32w+31 (element e at bit 31 - e % 32)
+#pragma unroll
+    for (int w = 0; w < NW; w++) pm[w] = 0u;
     {
       float cutq[NQF];
 #pragma unroll
@@ -487,10 +504,10 @@ _Pragma("unroll") \
         cutq[t] = b < nq_t ? (METRIC == kCosine ? cut * qn_t[t] : cut) : __uint_as_float(0x7F800000u);
       }
 #pragma unroll
-      for (int rf = 0; rf < 4; rf++) {
+      for (int rf = 0; rf < RF; rf++) {
         f32x4 rvn = f32x4{1.f, 1.f, 1.f, 1.f};
         if (METRIC == kCosine) {
-          const f32x4 vn = *reinterpret_cast<const f32x4*>(vns + wr * 64 + rf * 16 + 4 * (lane >> 4));
+          const f32x4 vn = *reinterpret_cast<const f32x4*>(vns + wr * WROWS + rf * 16 + 4 * (lane >> 4));
 #pragma unroll
           for (int r = 0; r < 4; r++) rvn[r] = __builtin_amdgcn_rcpf(vn[r]);
         }
@@ -506,13 +523,13 @@ _Pragma("unroll") \
         }
       }
       // left-align both words: element e of a word sits at bit 31 - (e % 32)
-      constexpr int kElems = 16 * NQF;
+      constexpr int kElems = 4 * RF * NQF;
       if (kElems < 32) pm[0] <<= (32 - kElems);
       if (kElems > 32 && kElems < 64) pm[1] <<= (64 - kElems);
     }
     uint32_t qcarry = 0;  // queue entries carried into the next round (their candidate buffer was full)
     // per-lane part of a queue entry's low word: (row in tile) << 8 | query in tile, for rf = t = r = 0
-    const uint32_t lane_word = ((uint32_t)(wr * 64 + 4 * (lane >> 4)) << 8) | (uint32_t)(wq * 16 * NQF + (lane & 15));
+    const uint32_t lane_word = ((uint32_t)(wr * WROWS + 4 * (lane >> 4)) << 8) | (uint32_t)(wq * 16 * NQF + (lane & 15));
     for (;;) {
       bool failed = false;
       ++token;
@@ -521,7 +538,10 @@ _Pragma("unroll") \
       //      from ballot/mbcnt, plain LDS stores.  Passes = the largest number of survivors in one lane (3-4).
       uint32_t qn_ent = qcarry;  // wave-uniform
       for (;;) {
-        const bool has = (pm[0] | pm[1]) != 0u;
+        uint32_t pm_any = pm[0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) pm_any |= pm[w];
+        const bool has = pm_any != 0u;
         const uint64_t mh = __ballot(has);
         if (mh == 0) break;
         const uint32_t nh = (uint32_t)__popcll(mh);
@@ -529,18 +549,35 @@ _Pragma("unroll") \
           failed = true;  // queue full: finish what is queued, then continue draining
           break;
         }
-        const bool lo = pm[0] != 0u;
-        const uint32_t word = lo ? pm[0] : pm[1];
-        const uint32_t lz = (uint32_t)__builtin_clz(word | 1u);  // element inside the word
-        const uint32_t e = lz + (lo ? 0u : 32u);
-        const uint32_t cleared = word & ~(0x80000000u >> lz);
-        if (has) {
-          if (lo) pm[0] = cleared; else pm[1] = cleared;
+        uint32_t word, e;
+        if (NW == 2) {
+          const bool lo = pm[0] != 0u;
+          word = lo ? pm[0] : pm[1];
+          const uint32_t lz = (uint32_t)__builtin_clz(word | 1u);  // element inside the word
+          e = lz + (lo ? 0u : 32u);
+          const uint32_t cleared = word & ~(0x80000000u >> lz);
+          if (has) {
+            if (lo) pm[0] = cleared; else pm[1] = cleared;
+          }
+        } else {
+          uint32_t wi = NW - 1;  // first non-empty word
+          word = pm[NW - 1];
+#pragma unroll
+          for (int w = NW - 2; w >= 0; w--) {
+            const bool nz = pm[w] != 0u;
+            word = nz ? pm[w] : word;
+            wi = nz ? (uint32_t)w : wi;
+          }
+          const uint32_t lz = (uint32_t)__builtin_clz(word | 1u);
+          e = lz + 32u * wi;
+          const uint32_t cleared = word & ~(0x80000000u >> lz);
+#pragma unroll
+          for (int w = 0; w < NW; w++) pm[w] = (has && wi == (uint32_t)w) ? cleared : pm[w];
         }
-        const float dv = select_acc<NQF>(acc, e);
+        const float dv = select_acc<RF, NQF>(acc, e);
         // e = (rf*NQF + t)*4 + r
         const uint32_t r = e & 3u, ft = e >> 2;
-        const uint32_t rf = NQF == 4 ? ft >> 2 : (NQF == 2 ? ft >> 1 : (ft * 11u) >> 5);  // ft / NQF for ft < 16
+        const uint32_t rf = NQF == 4 ? ft >> 2 : (NQF == 2 ? ft >> 1 : (ft * 11u) >> 5);  // ft / NQF (NQF = 3: ft < 16)
         const uint32_t t = ft - rf * NQF;
         const uint32_t slot = qn_ent + __builtin_amdgcn_mbcnt_hi((uint32_t)(mh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mh, 0u));
         if (has) wqueue[slot] = ((uint64_t)__float_as_uint(dv) << 32) | (lane_word + (((rf * 16u + r) << 8) + t * 16u));
@@ -607,7 +644,7 @@ _Pragma("unroll") \
     }
 #endif
 #pragma unroll
-    for (int rf = 0; rf < 4; rf++)
+    for (int rf = 0; rf < RF; rf++)
 #pragma unroll
       for (int t = 0; t < NQF; t++) acc[rf][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     kt = 0;
@@ -640,7 +677,7 @@ _Pragma("unroll") \
   }
 #endif
   __syncthreads();
-  for (uint32_t b = wib; b < nq_t; b += 4) {
+  for (uint32_t b = wib; b < nq_t; b += WAVES) {
     const uint32_t c = min(cnts[b], k);  // <= k entries: whatever order (the merge kernel scans them all)
     uint64_t* out = a.part_keys + ((size_t)(q0 + b) * ga.G + g) * k;
     for (uint32_t e = lane; e < k; e += 64) out[e] = e < c ? cand[(size_t)b * CAP + e] : kKeyInvalid;
@@ -652,36 +689,46 @@ _Pragma("unroll") \
 
 // ---- host side ---------------------------------------------------------------------------------
 uint32_t sweep_gemm_cap(uint32_t k) { return k <= 16 ? 32u : 64u; }  // candidate buffer entries per query
-size_t sweep_gemm_lds_bytes(int nqf, uint32_t k) {
-  const size_t BN = (size_t)32 * nqf;
-  return ((size_t)kGemmBM * kGemmBK * 4 + BN * kGemmBK * 4 + BN * sweep_gemm_cap(k) * 8 + BN * 16 + 16 + kGemmBM * 4 + (size_t)4 * kGemmQueue * 8 + 15) & ~(size_t)15;
+size_t sweep_gemm_lds_bytes(int nqf, uint32_t k, bool big) {
+  const size_t BM = big ? 256 : kGemmBM, BN = big ? 256 : (size_t)32 * nqf, waves = big ? 8 : 4;
+  return (BM * kGemmBK * 4 + BN * kGemmBK * 4 + BN * sweep_gemm_cap(k) * 8 + BN * 16 + 16 + BM * 4 + waves * kGemmQueue * 8 + 15) & ~(size_t)15;
 }
 
-void sweep_gemm_plan(uint32_t nq, uint32_t n_rows, int n_cus, uint32_t k, GemmPlan* p) {
-  p->nqt = (nq + 127) / 128;
+void sweep_gemm_plan(uint32_t nq, uint32_t n_rows, int n_cus, uint32_t k, GemmPlan* p, bool allow_big) {
+  static const bool env_big = [] {  // VELESDB_GEMM_BIG=0: never pick the 256 x 256 tile (A/B probes)
+    const char* e = getenv("VELESDB_GEMM_BIG");
+    return !(e && e[0] == '0');
+  }();
+  // the 256 x 256 tile wins by ~20 % per (padded) query slot: taken when the batch fills its query tiles to >= 7/8
+  const uint32_t nqt_big = (nq + 255) / 256;
+  p->big = allow_big && env_big && nq >= kGemmBigMinQueries && (uint64_t)nq * 8 >= (uint64_t)nqt_big * 256 * 7 &&
+           sweep_gemm_lds_bytes(4, k, true) <= 160 * 1024;
+  const uint32_t bn = p->big ? 256 : 128, bm = p->big ? 256 : kGemmBM;
+  p->nqt = (nq + bn - 1) / bn;
   p->qper = (nq + p->nqt - 1) / p->nqt;
-  p->nqf = (int)((p->qper + 31) / 32);
+  p->nqf = p->big ? 4 : (int)((p->qper + 31) / 32);
   if (p->nqf < 2) p->nqf = 2;
-  p->lds = sweep_gemm_lds_bytes(p->nqf, k);
-  const int per_cu = p->lds * 2 <= 160 * 1024 ? 2 : 1;
-  const uint32_t ntiles = (n_rows + kGemmBM - 1) / kGemmBM;
-  uint32_t G = (uint32_t)std::max(1, n_cus * per_cu / (int)p->nqt);
-  G = std::min(G, ntiles);
-  G = (G + 7) / 8 * 8;  // whole XCD rounds (groups beyond the last row tile emit empty lists)
+  p->lds = sweep_gemm_lds_bytes(p->nqf, k, p->big);
+  const int per_cu = (!p->big && p->lds * 2 <= 160 * 1024) ? 2 : 1;
+  const uint32_t ntiles = (n_rows + bm - 1) / bm;
+  // row groups: whole XCD rounds (multiples of 8; groups beyond the last row tile emit empty lists), and never more
+  // blocks than the chip holds at once — a few blocks left over for a second round would double the launch's time
+  uint32_t G = (uint32_t)std::max(8, n_cus * per_cu / (int)p->nqt / 8 * 8);
+  G = std::min(G, (ntiles + 7) / 8 * 8);
   p->G = G;
   p->blocks = (int)(G * p->nqt);
 }
 
-template <int METRIC, int NQF, bool QVEC, bool FULL, bool BF16>
+template <int METRIC, int NQF, bool QVEC, bool FULL, bool BF16, int RF = 4, int WAVES = 4>
 static hipError_t launch_gemm_v(const GemmSweepArgs& ga, int blocks, size_t lds, hipStream_t st) {
   static bool done = false;
   if (lds > 64 * 1024 && !done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_gemm_f32<METRIC, NQF, QVEC, FULL, BF16>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_gemm_f32<METRIC, NQF, QVEC, FULL, BF16, RF, WAVES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     done = true;
   }
-  hipLaunchKernelGGL((sweep_topk_gemm_f32<METRIC, NQF, QVEC, FULL, BF16>), dim3(blocks), dim3(256), lds, st, ga);
+  hipLaunchKernelGGL((sweep_topk_gemm_f32<METRIC, NQF, QVEC, FULL, BF16, RF, WAVES>), dim3(blocks), dim3(WAVES * 64), lds, st, ga);
   return hipGetLastError();
 }
 template <int METRIC, int NQF>
@@ -789,6 +836,9 @@ hipError_t launch_sweep_gemm_bf16(int metric, const GemmPlan& p, const uint16_t*
 #ifdef VDB_GEMM_STATS
   ga.stats = nullptr;
 #endif
+  if (p.big)
+    return metric == kCosine ? launch_gemm_v<kCosine, 4, true, true, true, 8, 8>(ga, p.blocks, p.lds, st)
+                             : launch_gemm_v<kDot, 4, true, true, true, 8, 8>(ga, p.blocks, p.lds, st);
   if (metric == kCosine) {
     switch (p.nqf) {
       case 2: return launch_gemm_v<kCosine, 2, true, true, true>(ga, p.blocks, p.lds, st);

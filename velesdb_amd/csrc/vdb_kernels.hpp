@@ -120,16 +120,18 @@ struct GemmPlan {
   uint32_t nqt;   // query tiles
   uint32_t qper;  // queries per tile
   uint32_t G;     // row groups = partial top-k lists per query
-  int nqf;        // 16-query accumulator tiles per wave (block tile = 32 * nqf queries)
+  int nqf;        // 16-query accumulator tiles per wave (block tile = 32 * nqf queries; big: 256)
   int blocks;
   size_t lds;
+  bool big;       // the 256-row x 256-query tile, one 8-wave block per CU (bf16 batches that fill 256-query tiles, k <= 16)
 };
-constexpr uint64_t kRowSlack = 128;         // rows allocated past the capacity of the f32 row array (whole-tile reads)
+constexpr uint64_t kRowSlack = 256;         // rows allocated past the capacity of the row arrays (whole-tile reads)
+constexpr uint32_t kGemmBigMinQueries = 224;
 constexpr uint32_t kGemmMinQueries = 64;    // below this the streaming kernels (HBM-bound) are faster
 constexpr uint32_t kGemmMaxK = 48;          // candidate buffers hold <= 64 keys per query (one per lane when compacted)
 constexpr uint32_t kGemmMaxQueries = 1024;  // per launch (bounds the partial-list scratch)
-size_t sweep_gemm_lds_bytes(int nqf, uint32_t k);
-void sweep_gemm_plan(uint32_t nq, uint32_t n_rows, int n_cus, uint32_t k, GemmPlan* p);
+size_t sweep_gemm_lds_bytes(int nqf, uint32_t k, bool big = false);
+void sweep_gemm_plan(uint32_t nq, uint32_t n_rows, int n_cus, uint32_t k, GemmPlan* p, bool allow_big = false);
 hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, hipStream_t st);
 // bf16 variant of the same kernel (dim % 64 == 0): rows16 = the bf16 row copy, queries16 = launch_round_queries_bf16 output
 void launch_round_queries_bf16(const float* q, uint64_t q_stride, uint16_t* out, uint64_t out_stride, uint32_t nq,
