@@ -175,6 +175,30 @@ def test_gemm_sweep_large_batches_bit_exact(gpu_required, metric, n, dim):
     ix.close()
 
 
+@pytest.mark.parametrize("metric", [DM.Cosine, DM.DotProduct])
+@pytest.mark.parametrize("n,dim", [(10007, 768), (700, 128), (300, 256)])
+def test_gemm_sweep_many_query_tiles_bit_exact(gpu_required, metric, n, dim):
+    # 2 .. 8 query tiles per launch (row groups = resident block slots / query tiles, whole XCD rounds), ragged last
+    # tiles, an exact tie inside a row tile.
+    rng = np.random.default_rng(n * 13 + dim)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows[n // 2] = rows[n // 2 - 1]  # an exact tie inside a tile
+    ix = va.HnswIndex(dim, metric)
+    ix.upload(np.arange(n), rows)
+    for nq, k in [(230, 10), (480, 16), (700, 3), (1024, 10)]:
+        Q = rng.standard_normal((nq, dim)).astype(np.float32)
+        Q[5] = rows[n // 2]
+        gid, gsc, gcnt = ix.search_batch_brute_force(Q, k)
+        eid, esc = po.scan_topk(int(metric), rows, Q, k, po.MODE_M, nthreads=8)
+        assert np.all(gcnt == k)
+        assert np.array_equal(gid, eid), (nq, k)
+        assert np.array_equal(bits(gsc), bits(esc)), (nq, k)
+    assert ix.remove(int(gid[0, 0]))
+    g2, _, _ = ix.search_batch_brute_force(Q, 10)
+    assert int(gid[0, 0]) not in g2[0].tolist()
+    ix.close()
+
+
 def test_gemm_sweep_more_queries_than_one_launch(gpu_required):
     # > 1024 queries: several GEMM launches (kGemmMaxQueries), the tail through whatever kernel its size selects
     rng = np.random.default_rng(31)

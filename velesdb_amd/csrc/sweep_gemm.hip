@@ -104,7 +104,8 @@ __device__ __forceinline__ float select_acc(const f32x4 (&acc)[RF][NQF], uint32_
 // block (2 along the rows x WAVES/2 along the queries).  (4, 4) = the 128 x 32 NQF tile at two blocks per CU described
 // above; (8, 8) = a 256 x 256 tile, ONE block of eight waves per CU (bf16 only): twice the MFMAs per LDS fragment
 // read / staging instruction / barrier, half the row re-reads — the bf16 multiply is 16x cheaper per element than the
-// exact-f32 one, so there the per-step instruction overhead is what bounds the kernel.
+// exact-f32 one, so there the per-step instruction overhead is what bounds the kernel.  (The f32 instance of the big
+// tile was measured too: bit-identical, 120.6 vs 122.8 TFLOP/s at 1 024 queries — not kept.)
 template <int METRIC, int NQF, bool QVEC, bool FULL, bool BF16, int RF = 4, int WAVES = 4>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void sweep_topk_gemm_f32(GemmSweepArgs ga) {
   static_assert(!BF16 || FULL, "the bf16 variant has no zero-fill path");
@@ -770,6 +771,7 @@ hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, 
 #endif
   // queries readable as aligned float4?
   const bool qvec = a.dim % 4 == 0 && a.q_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.queries) & 15) == 0;
+  if (p.big) return hipErrorInvalidValue;  // the 256 x 256 tile is a bf16 instance only (f32: measured no gain)
   if (metric == kCosine) {
     switch (p.nqf) {
       case 2: return launch_gemm_t<kCosine, 2>(ga, qvec, p.blocks, p.lds, st);
