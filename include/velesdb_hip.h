@@ -232,6 +232,12 @@ int32_t vdb_hip_index_save_reference_files(vdb_hip_index* idx, const char* dir, 
  * file, ids from the mappings; ids the reference removed are absent from the mappings and come back soft-deleted). */
 int32_t vdb_hip_index_save_dir(vdb_hip_index* idx, const char* dir);
 int32_t vdb_hip_index_load_dir(const char* dir, int32_t device, vdb_hip_index** out);
+/* A flushed MmapStorage directory (core/storage/mmap.rs:96-160,402-455,602-626: vectors.idx = bincode
+ * FxHashMap<u64 id, usize byte offset>, vectors.dat = raw f32 at those offsets) as an upload source: every vector
+ * the store's index names is uploaded (no graph, as vdb_hip_index_upload) in ascending byte offset, i.e. in the order
+ * the store first saw the ids.  The index's dimension must be the store's.  Ids already present are skipped.
+ * VDB_ERR_IO: missing / truncated files, an offset past the end of vectors.dat ("Offset out of bounds", :563-568). */
+int32_t vdb_hip_index_upload_vector_store(vdb_hip_index* idx, const char* dir, uint64_t* inserted);
 
 /* ---- introspection used by tests and the bench ---- */
 /* neighbours of `node` on `layer`; returns count in *n, writes up to cap ids */

@@ -723,3 +723,114 @@ def scan_topk_binary(rows, queries, k):
     sc = np.zeros((nq, k), dtype=np.float32)
     lib().vo_scan_topk_binary(rows, rows.shape[0], rows.shape[1], queries, nq, k, ids, sc)
     return ids, sc
+
+
+# ---- MmapStorage directory (core/storage/mmap.rs), restated for the upload-source hand-off ----
+# Byte layout: read off the code (no reference test pins bytes, only behaviour — storage/tests.rs:18-166 — which the
+# tests of this restatement repeat): vectors.dat = raw LE f32 at byte offsets handed out by a monotonic counter,
+# pre-sized to 16 MiB and grown by ensure_capacity; vectors.idx = bincode 1.3.3 FxHashMap<u64, usize>
+# (u64 count, count x (u64 id, u64 offset), hash-iteration order = unspecified); vectors.wal = append-only op log
+# (1 | id | len u32 | bytes for a store, 2 | id for a delete) that MmapStorage::new does not replay.
+class MmapVectorStore:
+    INITIAL_SIZE = 16 * 1024 * 1024   # mmap.rs:76
+    MIN_GROWTH = 64 * 1024 * 1024     # :80
+    GROWTH_FACTOR = 2                 # :84
+
+    def __init__(self, path, dimension):
+        """MmapStorage::new (mmap.rs:96-160): create / open the three files, load the index if it was flushed."""
+        import struct
+        self.path, self.dimension = path, dimension
+        os.makedirs(path, exist_ok=True)
+        self._dat = os.path.join(path, "vectors.dat")
+        if not os.path.exists(self._dat) or os.path.getsize(self._dat) == 0:
+            with open(self._dat, "wb") as f:
+                f.truncate(self.INITIAL_SIZE)
+        self._wal = open(os.path.join(path, "vectors.wal"), "ab")
+        self.index = {}
+        ip = os.path.join(path, "vectors.idx")
+        if os.path.exists(ip):
+            raw = open(ip, "rb").read()
+            if len(raw) < 8:
+                raise OSError("invalid data: vectors.idx")
+            (n,) = struct.unpack_from("<Q", raw, 0)
+            if len(raw) != 8 + 16 * n:
+                raise OSError("invalid data: vectors.idx")
+            for i in range(n):
+                id_, off = struct.unpack_from("<QQ", raw, 8 + 16 * i)
+                self.index[id_] = off
+        # next_offset = max offset + one vector (:137-143)
+        self.next_offset = (max(self.index.values()) + dimension * 4) if self.index else 0
+
+    def _ensure_capacity(self, required):  # :175-221
+        cur = os.path.getsize(self._dat)
+        if cur < required:
+            new_len = max(cur * self.GROWTH_FACTOR, required + self.MIN_GROWTH, cur + self.MIN_GROWTH, required)
+            with open(self._dat, "r+b") as f:
+                f.truncate(new_len)
+
+    def store(self, id_, vector):  # :402-455
+        import struct
+        v = np.ascontiguousarray(vector, dtype="<f4")
+        if v.size != self.dimension:
+            raise OSError(f"Vector dimension mismatch: expected {self.dimension}, got {v.size}")
+        b = v.tobytes()
+        self._wal.write(b"\x01" + struct.pack("<QI", id_, len(b)) + b)
+        if id_ in self.index:
+            off = self.index[id_]           # an update rewrites its slot in place
+        else:
+            off = self.next_offset
+            self.next_offset += len(b)
+        self._ensure_capacity(off + len(b))
+        with open(self._dat, "r+b") as f:
+            f.seek(off)
+            f.write(b)
+        self.index.setdefault(id_, off)
+
+    def delete(self, id_):  # :575-599: WAL record, index entry removed, slot hole-punched (reads back as zeros)
+        import struct
+        self._wal.write(b"\x02" + struct.pack("<Q", id_))
+        off = self.index.pop(id_, None)
+        if off is not None:
+            with open(self._dat, "r+b") as f:
+                f.seek(off)
+                f.write(bytes(self.dimension * 4))
+
+    def retrieve(self, id_):  # :554-573
+        off = self.index.get(id_)
+        if off is None:
+            return None
+        n = self.dimension * 4
+        if off + n > os.path.getsize(self._dat):
+            raise OSError("Offset out of bounds")
+        with open(self._dat, "rb") as f:
+            f.seek(off)
+            return np.frombuffer(f.read(n), dtype="<f4").copy()
+
+    def __len__(self):
+        return len(self.index)
+
+    def ids(self):
+        return list(self.index)
+
+    def flush(self):  # :602-626
+        import struct
+        self._wal.flush()
+        with open(os.path.join(self.path, "vectors.idx"), "wb") as f:
+            f.write(struct.pack("<Q", len(self.index)))
+            for id_, off in self.index.items():
+                f.write(struct.pack("<QQ", id_, off))
+
+    def close(self):
+        self._wal.close()
+
+
+def read_vector_store(directory, dimension):
+    """(ids, vectors) of a flushed store in ascending byte offset — the order vdb_hip_index_upload_vector_store uses."""
+    st = MmapVectorStore(directory, dimension)
+    items = sorted(st.index.items(), key=lambda kv: kv[1])
+    ids = np.array([k for k, _ in items], dtype=np.uint64)
+    vecs = np.zeros((len(items), dimension), dtype=np.float32)
+    for i, (k, _) in enumerate(items):
+        vecs[i] = st.retrieve(k)
+    st.close()
+    return ids, vecs

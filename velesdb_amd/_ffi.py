@@ -40,6 +40,7 @@ SIGNATURES = {
     "vdb_hip_index_vacuum": (_i32, [_vp, _pu64]),
     "vdb_hip_index_save_dir": (_i32, [_vp, C.c_char_p]),
     "vdb_hip_index_load_dir": (_i32, [C.c_char_p, _i32, C.POINTER(_vp)]),
+    "vdb_hip_index_upload_vector_store": (_i32, [_vp, C.c_char_p, _pu64]),
     "vdb_hip_index_insert": (_i32, [_vp, _u64, _vp, _u32]),
     "vdb_hip_index_insert_batch": (_i32, [_vp, _vp, _vp, _u64, _pu64]),
     "vdb_hip_index_insert_batch_parallel": (_i32, [_vp, _vp, _vp, _u64, _u32, _pu64]),

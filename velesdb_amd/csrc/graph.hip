@@ -5,6 +5,9 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <string>
+#include <utility>
+#include <vector>
 
 #include "vdb_index.hpp"
 #include "vdb_kernels.hpp"
@@ -342,6 +345,75 @@ int32_t vdb_hip_index_load_dir(const char* dir, int32_t device, vdb_hip_index** 
   if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("mappings upload: ") + hipGetErrorString(e));  // (index leaked on a device error)
   *out = ix;
   return VDB_OK;
+}
+
+// ---- MmapStorage directory as an upload source (core/storage/mmap.rs:96-160 open, :402-455 store, :602-626 flush) ----
+//   vectors.idx   bincode FxHashMap<u64, usize>: u64 count, then count x (u64 id, u64 byte offset into vectors.dat)
+//   vectors.dat   raw little-endian f32, `dimension` values at each offset (pre-sized: 16 MiB, then grown)
+//   vectors.wal   append-only log; MmapStorage::new does not replay it, so a flushed store = idx + dat
+// Rows are uploaded in ascending byte offset = the order in which the store first saw each id (offsets are handed
+// out by a monotonic counter, :434-436; an update rewrites its slot in place), which makes the internal row order —
+// the tie-break of the exact search — a function of the files alone, not of hash-map iteration order.
+int32_t vdb_hip_index_upload_vector_store(vdb_hip_index* ix, const char* dir, uint64_t* inserted) {
+  if (inserted) *inserted = 0;
+  if (!ix || !dir) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  const std::string ip = std::string(dir) + "/vectors.idx", dp = std::string(dir) + "/vectors.dat";
+  FILE* f = std::fopen(ip.c_str(), "rb");
+  if (!f) return fail(VDB_ERR_IO, "cannot open " + ip);
+  std::fseek(f, 0, SEEK_END);
+  const long idx_bytes = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  uint64_t count = 0;
+  bool ok = get_u64(f, &count) && idx_bytes >= 8 && count == (uint64_t)(idx_bytes - 8) / 16 && (idx_bytes - 8) % 16 == 0;
+  std::vector<std::pair<uint64_t, uint64_t>> ent;  // (offset, id)
+  if (ok) ent.reserve(count);
+  for (uint64_t i = 0; i < count && ok; i++) {
+    uint64_t id = 0, off = 0;
+    ok = get_u64(f, &id) && get_u64(f, &off);
+    if (ok) ent.emplace_back(off, id);
+  }
+  std::fclose(f);
+  if (!ok) return fail(VDB_ERR_IO, "bad " + ip);
+  FILE* d = std::fopen(dp.c_str(), "rb");
+  if (!d) return fail(VDB_ERR_IO, "cannot open " + dp);
+  std::fseek(d, 0, SEEK_END);
+  const uint64_t dat_bytes = (uint64_t)std::ftell(d);
+  const uint64_t vbytes = (uint64_t)ix->dim * 4;
+  std::sort(ent.begin(), ent.end());
+  for (size_t i = 0; i < ent.size() && ok; i++) {
+    ok = ent[i].first % 4 == 0 && ent[i].first + vbytes <= dat_bytes;            // "Offset out of bounds" (mmap.rs:563-568)
+    if (ok && i) ok = ent[i].first >= ent[i - 1].first + vbytes && ent[i].second != ent[i - 1].second;  // slots never overlap
+  }
+  if (!ok) {
+    std::fclose(d);
+    return fail(VDB_ERR_IO, "vectors.idx does not describe vectors.dat (offset out of bounds / overlapping slots)");
+  }
+  // chunks of <= 64 MiB through the ordinary upload path (duplicate ids already in the index are skipped there)
+  const size_t chunk = std::max<size_t>(1, (size_t)((64u << 20) / vbytes));
+  std::vector<float> rows;
+  std::vector<uint64_t> ids;
+  uint64_t total = 0;
+  int32_t rc = VDB_OK;
+  for (size_t base = 0; base < ent.size() && rc == VDB_OK; base += chunk) {
+    const size_t n = std::min(chunk, ent.size() - base);
+    rows.resize(n * ix->dim);
+    ids.resize(n);
+    for (size_t i = 0; i < n && ok; i++) {
+      ids[i] = ent[base + i].second;
+      ok = std::fseek(d, (long)ent[base + i].first, SEEK_SET) == 0 &&
+           std::fread(rows.data() + i * ix->dim, 4, ix->dim, d) == ix->dim;
+    }
+    if (!ok) {
+      rc = fail(VDB_ERR_IO, "short read from " + dp);
+      break;
+    }
+    uint64_t ins = 0;
+    rc = vdb_hip_index_upload(ix, ids.data(), rows.data(), n, &ins);
+    total += ins;
+  }
+  std::fclose(d);
+  if (inserted) *inserted = total;
+  return rc;
 }
 
 }  // extern "C"

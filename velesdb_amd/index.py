@@ -308,6 +308,13 @@ class HnswIndex:
         check(lib().vdb_hip_index_upload(self._h, _ptr(ids), _ptr(vecs), vecs.shape[0], C.byref(n)))
         return int(n.value)
 
+    def upload_vector_store(self, directory: str) -> int:
+        """Upload every vector of a flushed MmapStorage directory (core/storage/mmap.rs: vectors.idx + vectors.dat),
+        in the order the store first saw the ids; no graph (as `upload`).  Returns the number of rows added."""
+        n = C.c_uint64(0)
+        check(lib().vdb_hip_index_upload_vector_store(self._h, directory.encode(), C.byref(n)))
+        return int(n.value)
+
     # ---- maintenance (index/hnsw/index/vacuum.rs) ------------------------------------------
     def tombstone_count(self) -> int:
         n = C.c_uint64(0)
