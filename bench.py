@@ -59,6 +59,10 @@ def parse():
     p.add_argument("--no-hnsw", action="store_true")
     p.add_argument("--no-int8", action="store_true", help="skip the dual-precision (int8 traversal) leg")
     p.add_argument("--no-embedding-leg", action="store_true", help="skip the graph leg on embedding-like data")
+    p.add_argument("--no-bf16-leg", action="store_true", help="skip the bf16 GEMM-distance leg (BASELINE configs[3])")
+    p.add_argument("--bf16-rows", type=int, default=10_000_000)
+    p.add_argument("--bf16-steps", type=int, default=5)
+    p.add_argument("--bf16-cpu-rows", type=int, default=1_000_000, help="rows of the slice the CPU restatement scans")
     p.add_argument("--latent", type=int, default=32, help="latent factors of the embedding-like corpus")
     p.add_argument("--latent-noise", type=float, default=0.25)
     p.add_argument("--hnsw-batch", type=int, default=8192, help="queries per step (graph traversal)")
@@ -591,6 +595,84 @@ def main():
                 shutil.rmtree(gd, ignore_errors=True)
         ix2.close()
 
+    # ---- bf16 GEMM distance (BASELINE configs[3], N = 1 only): 10 M x 768 bf16 rows, 1 024 queries per batch contracted
+    # on the bf16 matrix cores with f32 accumulation (half_precision.rs:199-255 semantics), fused top-k.  Bound: MFMA.
+    bf16_leg = None
+    if world == 1 and not a.no_bf16_leg and a.metric in ("cosine", "dot") and D % 64 == 0:
+        BR, BQ = a.bf16_rows, 1024
+        ix3 = va.HnswIndex(D, metric, va.HnswParams(a.M, a.efc, BR), device=local)
+        ix3.enable_bf16()
+        g.manual_seed(45)
+        first_chunk = None
+        chunk = 1_000_000
+        for base in range(0, BR, chunk):
+            n_c = min(chunk, BR - base)
+            c = torch.randn((n_c, D), generator=g, device=dev)
+            torch.cuda.synchronize()
+            ix3.upload_dev(base, c.data_ptr(), n_c, stream)
+            if base == 0 and not a.no_cpu_baseline:
+                first_chunk = c[:min(a.bf16_cpu_rows, n_c)].cpu().numpy()
+            del c
+        bq = torch.randn((BQ, D), generator=g, device=dev)
+        b_ids = torch.empty((BQ, K), dtype=torch.int64, device=dev)
+        b_sc = torch.empty((BQ, K), dtype=torch.float32, device=dev)
+        b_n = torch.empty((BQ,), dtype=torch.int32, device=dev)
+
+        def bstep(mode=va.MODE_BRUTE_BF16):
+            ix3.search_batch_dev(bq.data_ptr(), BQ, K, 0, mode, b_ids.data_ptr(), b_sc.data_ptr(), b_n.data_ptr(), stream)
+
+        bstep()
+        torch.cuda.synchronize()
+        va.set_kernel_timing(True)
+        tb0 = time.perf_counter()
+        for _ in range(a.bf16_steps):
+            bstep()
+        torch.cuda.synchronize()
+        bdt = (time.perf_counter() - tb0) / a.bf16_steps
+        bk_ms, b_nl = ix3.last_kernel_ms()
+        va.set_kernel_timing(False)
+        bf_ids = b_ids.cpu().numpy().copy()
+        bstep(va.MODE_BRUTE)  # exact f32 sweep over the same rows: ground truth of the recall figure
+        torch.cuda.synchronize()
+        ex_ids = b_ids.cpu().numpy()
+        rec_b = float(np.mean([len(set(bf_ids[i].tolist()) & set(ex_ids[i].tolist())) / K for i in range(BQ)]))
+        bflop = 2.0 * BR * D * BQ
+        b_tf = bflop / (bk_ms * 1e-3) / 1e12 if bk_ms > 0 else 0.0
+        bf16_leg = {"workload": f"{BR}x{D} bf16 {a.metric} (rows and queries rounded to nearest even, f32 accumulate), "
+                                f"{BQ} queries per batch as one MFMA GEMM distance with fused top-k, k={K} (BASELINE configs[3])",
+                    "qps": round(BQ / bdt, 1), "ms_per_batch": round(bdt * 1e3, 3), "recall_at_10_vs_exact_f32": round(rec_b, 4),
+                    "roofline": {"bound": "mfma", "achieved": round(b_tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                 "frac": round(b_tf / 2500.0, 4), "traffic": None, "kernel_ms": round(bk_ms, 4),
+                                 "launches_timed": b_nl, "alg_flops_per_launch": bflop,
+                                 "alg_bytes_per_launch": BR * D * 2 + BR * 4 + BQ * D * 2,
+                                 "kernel": "sweep_topk_gemm_f32<%s,NQF=4,BF16,256x256 tile>" % a.metric,
+                                 "note": "dense bf16 MFMA peak 2.5 PFLOP/s (v_mfma_f32_16x16x32_bf16); algorithmic flop = 2*rows*dim*queries"}}
+        if first_chunk is not None:
+            from oracle import pyoracle as po
+            om = {"cosine": po.COSINE, "dot": po.DOT}[a.metric]
+            ncores = os.cpu_count() or 1
+            qh = bq.cpu().numpy()
+            nqc = min(ncores, BQ)
+            t6 = time.perf_counter()
+            oi, _ = po.scan_topk_bf16(om, first_chunk, qh[:nqc], K, nthreads=ncores)   # calibration pass (also the parity check)
+            t_c = time.perf_counter() - t6
+            nq2, t_c2 = nqc, t_c
+            if t_c < 0.5 * a.cpu_seconds:  # one query per thread was short: a second, longer pass sized to the target
+                nq2 = int(max(nqc, min(BQ, nqc * (a.cpu_seconds / max(t_c, 1e-3)))))
+                t7 = time.perf_counter()
+                po.scan_topk_bf16(om, first_chunk, qh[:nq2], K, nthreads=ncores)
+                t_c2 = time.perf_counter() - t7
+            slice_qps = nq2 / t_c2
+            bf16_leg["cpu_baseline"] = {"value": round(slice_qps * first_chunk.shape[0] / BR, 2), "unit": "queries/s", "cores": ncores,
+                                        "kind": "port",
+                                        "sample": f"oracle scan_topk_bf16 (half_precision.rs semantics: bf16-rounded inputs, f32 "
+                                                  f"accumulate) on a {first_chunk.shape[0]}-row slice x {nq2} queries, {ncores} threads, "
+                                                  f"{t_c2:.2f} s = {slice_qps:.1f} q/s on the slice; value = that x "
+                                                  f"{first_chunk.shape[0]}/{BR} (extrapolated to the full corpus)"}
+            bf16_leg["gpu_over_cpu"] = round(bf16_leg["qps"] / max(bf16_leg["cpu_baseline"]["value"], 1e-9), 1)
+        ix3.close()
+        torch.cuda.empty_cache()
+
     if rank == 0:
         line = {
             "metric": "qps_at_recall10_1Mx768_k10", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
@@ -603,7 +685,7 @@ def main():
                        "parallelism": "replicas x%d (query stream split, no collective)" % world},
             "recall_at_10": recall, "parity_check": check,
             "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "tiles": tiles, "sharded": sharded,
-            "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb,
+            "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb, "bf16_gemm": bf16_leg,
             "device": va.device_name(local),
         }
         print(json.dumps(line))
