@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""GPU fuzz of the exact-sweep kernels against the oracle (not part of the test-suite: random shapes and adversarial
+data for a fixed wall-clock budget).  f32: ids and score bits must equal the oracle's (mode M / C as the library
+reports); bf16: the tolerance check of tests/test_gpu_bf16.py.
+
+    python tools/fuzz_sweep.py --seconds 240 --seed 1
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import velesdb_amd as va  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument("--seconds", type=float, default=240)
+p.add_argument("--seed", type=int, default=1)
+a = p.parse_args()
+rng = np.random.default_rng(a.seed)
+DM = va.DistanceMetric
+
+
+def make_rows(kind, n, dim, q0):
+    if kind == "normal":
+        return rng.standard_normal((n, dim)).astype(np.float32)
+    if kind == "dups":       # few distinct rows: massive exact ties, candidate buffers overflow with equal keys
+        base = rng.standard_normal((max(1, n // 50), dim)).astype(np.float32)
+        return base[rng.integers(0, base.shape[0], n)]
+    if kind == "ascending":  # every later row is better than all before it: every row tile floods the epilogue
+        t = np.linspace(0.0, 1.0, n, dtype=np.float32)[:, None]
+        noise = rng.standard_normal((n, dim)).astype(np.float32)
+        return (t * 4.0) * q0[None, :] + noise * 0.05 + q0[None, :] * 0.01
+    if kind == "small_ints":
+        return rng.integers(-3, 4, size=(n, dim)).astype(np.float32)
+    if kind == "zeros_mixed":
+        r = rng.standard_normal((n, dim)).astype(np.float32)
+        r[rng.random(n) < 0.2] = 0.0
+        return r
+    raise ValueError(kind)
+
+
+def bits(x):
+    return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+
+
+from test_gpu_bf16 import check as bf16_check  # noqa: E402
+
+t_end = time.time() + a.seconds
+it = 0
+stats = {"f32": 0, "bf16": 0}
+while time.time() < t_end:
+    it += 1
+    bf16 = rng.random() < 0.4
+    metric = [DM.Cosine, DM.DotProduct][int(rng.integers(0, 2))]
+    dim = int(rng.choice([64, 128, 192, 256, 768])) if bf16 else int(rng.choice([8, 17, 64, 100, 128, 256, 300, 768]))
+    n = int(rng.choice([1, 7, 100, 129, 1000, 4097, 12000, 30000]))
+    nq = int(rng.choice([1, 5, 63, 64, 100, 128, 129, 230, 256, 300, 480, 512, 700, 1024, 1100]))
+    k = int(rng.choice([1, 3, 10, 16, 17, 32, 48, 64]))
+    kind = str(rng.choice(["normal", "dups", "ascending", "small_ints", "zeros_mixed"]))
+    q0 = rng.standard_normal(dim).astype(np.float32)
+    rows = make_rows(kind, n, dim, q0)
+    Q = rng.standard_normal((nq, dim)).astype(np.float32)
+    if kind == "ascending":
+        Q = (Q * 0.05 + q0[None, :]).astype(np.float32)
+    if kind == "small_ints":
+        Q = rng.integers(-3, 4, size=(nq, dim)).astype(np.float32)
+    ix = va.HnswIndex(dim, metric)
+    ix.upload(np.arange(n), rows)
+    tag = f"it={it} bf16={bf16} {metric.name} n={n} dim={dim} nq={nq} k={k} {kind}"
+    kk = min(k, n)
+    if bf16:
+        ix.enable_bf16()
+        gi, gs, gc = ix.search_batch_brute_force_bf16(Q, k)
+        pm = po.COSINE if metric == DM.Cosine else po.DOT
+        if kind in ("small_ints",) and metric == DM.DotProduct:
+            eid, esc = po.scan_topk_bf16(pm, rows, Q, kk, nthreads=8)
+            assert np.array_equal(gi[:, :kk], eid) and np.array_equal(gs[:, :kk], esc), tag
+        else:
+            # the tolerance check needs separated scores to compare ids; duplicates make every rank a tie group: values only
+            if kind == "dups" or kind == "zeros_mixed":
+                rr, qq = po.round_bf16(rows).astype(np.float64), po.round_bf16(Q).astype(np.float64)
+                full = qq @ rr.T
+                scale = np.linalg.norm(qq, axis=1)[:, None] * np.linalg.norm(rr, axis=1)[None, :]
+                if metric == DM.Cosine:
+                    with np.errstate(invalid="ignore", divide="ignore"):
+                        full = np.where(scale > 0, full / scale, 0.0)
+                    scale = np.ones_like(full)
+                for qi in range(nq):
+                    g_i, g_s = gi[qi, :kk].astype(np.int64), gs[qi, :kk].astype(np.float64)
+                    assert np.all(np.abs(g_s - full[qi, g_i]) <= 1e-5 * np.maximum(scale[qi, g_i], 1e-30) + 1e-12), tag
+                    kth = np.sort(full[qi])[::-1][kk - 1]
+                    assert g_s[-1] >= kth - 1e-5 * max(scale[qi].max(), 1e-30) - 1e-12, tag
+                    assert len(set(g_i.tolist())) == kk, tag
+            else:
+                bf16_check(metric, pm, rows, Q, k, gi, gs, gc)
+        stats["bf16"] += 1
+    else:
+        gi, gs, gc = ix.search_batch_brute_force(Q, k)
+        mode = po.MODE_M if ix.sweep_arith_mode(k) == "M" else po.MODE_C
+        eid, esc = po.scan_topk(int(metric), rows, Q, kk, mode, nthreads=8)
+        assert np.all(gc == kk), tag
+        assert np.array_equal(gi[:, :kk], eid), tag
+        assert np.array_equal(bits(gs[:, :kk]), bits(esc)), tag
+        stats["f32"] += 1
+    ix.close()
+    if it % 20 == 0:
+        print(f"[fuzz] {it} cases ok ({stats})", flush=True)
+print(f"[fuzz] done: {it} cases, all equal to the oracle ({stats})")
