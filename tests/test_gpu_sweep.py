@@ -359,6 +359,42 @@ def test_hamming_ties_canonical_order(gpu_required):
     assert [s for _, s in got] == d[order].tolist()
 
 
+@pytest.mark.parametrize("metric", [DM.Hamming, DM.Jaccard])
+@pytest.mark.parametrize("n,dim", [(20000, 768), (5000, 48), (1300, 200), (700, 1)])
+def test_packed_bit_sweep_batches_exact(gpu_required, metric, n, dim):
+    # >= 3 queries: 8 or 32 queries per corpus pass (sweep_topk_bits_batch); integer work, canonical (score, row) order:
+    # identical to the oracle and to the per-query kernel, ties at rank k included (dim 48 / 1: almost everything ties)
+    rng = np.random.default_rng(n + dim + int(metric))
+    rows = rand_rows(rng, n, dim, metric)
+    rows[7] = 0.0                                           # empty bit set: Jaccard union can be 0 (score 1.0 vs an empty query)
+    ids = np.arange(n, dtype=np.uint64) * 5 + 1
+    ix = va.HnswIndex(dim, metric)
+    assert ix.upload(ids, rows) == n
+    for nq, k in [(30, 10), (64, 10), (100, 1), (300, 17), (32, 200), (9, 64)]:
+        Q = rand_rows(rng, nq, dim, metric)
+        Q[1] = 0.0
+        gid, gsc, gcnt = ix.search_batch_brute_force(Q, k)
+        exp = oracle_brute(metric, rows, ids, Q, k)
+        for qi in range(nq):
+            eid, esc = exp[qi]
+            assert gcnt[qi] == len(eid)
+            assert np.array_equal(gid[qi, :gcnt[qi]], eid), (metric, nq, k, qi)
+            assert np.array_equal(bits(gsc[qi, :gcnt[qi]]), bits(esc))
+        one = ix.search_batch_brute_force(Q[:1], k)         # the per-query kernel agrees
+        assert np.array_equal(one[0][0, :one[2][0]], gid[0, :gcnt[0]])
+    dead = rng.choice(n, n // 7, replace=False)
+    for d in dead:
+        assert ix.remove(int(ids[d]))
+    live = np.ones(n, bool)
+    live[dead] = False
+    Q = rand_rows(rng, 40, dim, metric)
+    gid, gsc, gcnt = ix.search_batch_brute_force(Q, 10)
+    exp = oracle_brute(metric, rows, ids, Q, 10, live)
+    for qi in range(40):
+        assert np.array_equal(gid[qi, :gcnt[qi]], exp[qi][0]) and np.array_equal(bits(gsc[qi, :gcnt[qi]]), bits(exp[qi][1]))
+    ix.close()
+
+
 @pytest.mark.parametrize("metric", [DM.Cosine, DM.Euclidean])
 def test_large_planted_neighbours_200k(gpu_required, metric):
     # size-independent property at a larger size: planted near-duplicates of the query must come

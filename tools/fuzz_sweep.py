@@ -20,6 +20,7 @@ from oracle import pyoracle as po  # noqa: E402
 p = argparse.ArgumentParser()
 p.add_argument("--seconds", type=float, default=240)
 p.add_argument("--seed", type=int, default=1)
+p.add_argument("--bits", action="store_true", help="Hamming / Jaccard (packed-bit kernels) instead of cosine / dot")
 a = p.parse_args()
 rng = np.random.default_rng(a.seed)
 DM = va.DistanceMetric
@@ -57,6 +58,9 @@ while time.time() < t_end:
     it += 1
     bf16 = rng.random() < 0.4
     metric = [DM.Cosine, DM.DotProduct][int(rng.integers(0, 2))]
+    if a.bits:
+        bf16 = False
+        metric = [DM.Hamming, DM.Jaccard][int(rng.integers(0, 2))]
     dim = int(rng.choice([64, 128, 192, 256, 768])) if bf16 else int(rng.choice([8, 17, 64, 100, 128, 256, 300, 768]))
     n = int(rng.choice([1, 7, 100, 129, 1000, 4097, 12000, 30000]))
     nq = int(rng.choice([1, 5, 63, 64, 100, 128, 129, 230, 256, 300, 480, 512, 700, 1024, 1100]))
@@ -65,9 +69,18 @@ while time.time() < t_end:
     q0 = rng.standard_normal(dim).astype(np.float32)
     rows = make_rows(kind, n, dim, q0)
     Q = rng.standard_normal((nq, dim)).astype(np.float32)
-    if kind == "ascending":
+    if a.bits:  # 0/1 data with a random density (sparse rows: empty unions; dense rows: everything ties)
+        dens = float(rng.choice([0.02, 0.3085, 0.5, 0.97]))
+        rows = (rng.random((n, dim)) < dens).astype(np.float32)
+        Q = (rng.random((nq, dim)) < dens).astype(np.float32)
+        if kind == "dups":
+            rows = rows[rng.integers(0, max(1, n // 50), n)]
+        if kind == "zeros_mixed":
+            rows[rng.random(n) < 0.2] = 0.0
+            Q[rng.random(nq) < 0.2] = 0.0
+    if kind == "ascending" and not a.bits:
         Q = (Q * 0.05 + q0[None, :]).astype(np.float32)
-    if kind == "small_ints":
+    if kind == "small_ints" and not a.bits:
         Q = rng.integers(-3, 4, size=(nq, dim)).astype(np.float32)
     ix = va.HnswIndex(dim, metric)
     ix.upload(np.arange(n), rows)

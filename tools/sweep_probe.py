@@ -26,13 +26,19 @@ g = torch.Generator(device=dev)
 g.manual_seed(42)
 corpus = torch.randn((a.rows, a.dim), generator=g, device=dev)
 queries = torch.randn((1024, a.dim), generator=g, device=dev)
-metric = {"cosine": va.DistanceMetric.Cosine, "euclidean": va.DistanceMetric.Euclidean, "dot": va.DistanceMetric.DotProduct}[a.metric]
+metric = {"cosine": va.DistanceMetric.Cosine, "euclidean": va.DistanceMetric.Euclidean, "dot": va.DistanceMetric.DotProduct,
+          "hamming": va.DistanceMetric.Hamming, "jaccard": va.DistanceMetric.Jaccard}[a.metric]
+if a.metric in ("hamming", "jaccard"):  # N(0,1) thresholded at 0.5 (the kernels sweep the packed bits: 96 B/row at 768-D)
+    corpus = (corpus > 0.5).float()
+    queries = (queries > 0.5).float()
 ix = va.HnswIndex(a.dim, metric, va.HnswParams(32, 400, a.rows))
 torch.cuda.synchronize()
 st = torch.cuda.current_stream().cuda_stream
 ix.upload_dev(0, corpus.data_ptr(), a.rows, st)
 del corpus
 alg = a.rows * a.dim * 4 + (a.rows * 4 if a.metric == "cosine" else 0)
+if a.metric in ("hamming", "jaccard"):
+    alg = a.rows * ((a.dim + 127) // 128 * 16)  # packed rows, words rounded to 4
 for nq in [int(x) for x in a.nqs.split(",")]:
     ids = torch.empty((nq, a.k), dtype=torch.int64, device=dev)
     sc = torch.empty((nq, a.k), dtype=torch.float32, device=dev)

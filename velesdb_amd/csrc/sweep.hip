@@ -918,6 +918,355 @@ __global__ __launch_bounds__(256) void sweep_topk_bits(BitsArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Batched packed-bit sweep: B queries per corpus pass (grid.y = query tile).  The kernel above reads the whole corpus
+// once per query — fine for one query (HBM / latency bound, 96 B per row), wasteful for a batch: 1 024 queries at
+// 1 M x 768 cost 1 024 passes (28 ms).  Here a lane holds TWO rows' words in registers and walks the B queries of the
+// tile out of LDS (one broadcast ds_read_b128 = 4 words of one query, used for both rows):
+//   inter[r][b] += popc(x_r & q_b)   — one v_and + one v_bcnt (popcount-accumulate) per word,
+// and both metrics finish from the same counts: |x ^ q| = |x| + |q| - 2 inter, |x | q| = |x| + |q| - inter
+// (|x| once per row, |q| once per query).  Bound: the vector ALUs — 2 instructions per 32 bits and query.
+// Top-k: per query a block-shared sorted list (shared_list_offer); the filter in front of it is a conservative
+// integer / float threshold per query in LDS (Hamming: distance <= the k-th best's; Jaccard: inter >= tau * union with
+// tau a hair below the k-th best's score), refreshed by whoever inserts; survivors (rare) go through the exact
+// 64-bit key compare.  Integer work: results are bit-identical to the per-query kernel and to the oracle.
+// ------------------------------------------------------------------------------------------
+// the rare path of sweep_topk_bits_batch: lanes in `mask` passed the conservative filter of one query; exact keys,
+// offers to the query's block-shared list, threshold refresh.  Not inlined: it runs for a few rows per thousand, and
+// keeping it out of line keeps the (R x B)-fold unrolled filter loop small enough to stay fully unrolled.
+template <int METRIC>
+__device__ __noinline__ void bits_offer(volatile uint64_t* list, volatile uint32_t* cnt, uint32_t* lock, uint32_t* thr,
+                                        uint32_t k, uint32_t pqb, uint32_t px, uint32_t inter, uint32_t row, uint64_t mask,
+                                        const uint8_t* alive, int lane) {
+  constexpr bool HIB = higher_is_better(METRIC);
+  float score;
+  if (METRIC == kHamming) {
+    score = (float)(px + pqb - 2u * inter);
+  } else {
+    const uint32_t uni = px + pqb - inter;
+    score = (uni == 0) ? 1.0f : (float)inter / (float)uni;  // simd_explicit.rs:431-442
+  }
+  const uint64_t key = make_key<HIB>(score, row);
+  bool inserted = false;
+  while (mask) {
+    const int src = __ffsll((long long)mask) - 1;
+    mask &= mask - 1;
+    const uint64_t kk = readlane64(key, src);
+    if (*cnt == k && kk >= list[k - 1]) continue;
+    if (alive && alive[key_row(kk)] == 0) continue;  // soft-deleted rows are filtered where it is rare
+    shared_list_offer(list, cnt, lock, k, kk, lane);
+    inserted = true;
+    if (*cnt == k) mask &= __ballot(key < list[k - 1]);  // drop every pending lane the (new) k-th best already beats
+  }
+  if (inserted && *cnt == k && lane == 0) {
+    // publish a threshold from the current k-th best (a stale, looser value written by a racing wave is still
+    // conservative: the exact compare above decides)
+    const float sk = key_score<HIB>(list[k - 1]);
+    if (METRIC == kHamming)
+      *thr = (uint32_t)((int32_t)sk + 1 - (int32_t)pqb);
+    else
+      *thr = __float_as_uint(sk > 0.0f ? sk * 0.999999f : -1.0f);
+  }
+}
+
+template <int METRIC, int B>
+__global__ __launch_bounds__(256) void sweep_topk_bits_batch(BitsArgs a, uint32_t nq) {
+  constexpr int R = 2;  // rows per lane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = (int)threadIdx.x;
+  const int lane = lane_id();
+  const uint32_t k = a.k, W = a.words, W4 = W / 4;
+  const uint32_t q0 = blockIdx.y * B;
+  const uint32_t nb = min((uint32_t)B, nq - q0);
+  // LDS: qw [W4][B][4] u32 | pq[B] | thr[B] (Hamming: int32 "d_k + 1 - |q|", Jaccard: float tau) | cnt[B] | lock[B] | lists [B][k] u64
+  uint32_t* qw = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* pq = qw + (size_t)W * B;
+  uint32_t* thr = pq + B;
+  volatile uint32_t* cnt = thr + B;
+  uint32_t* lock = const_cast<uint32_t*>(cnt) + B;
+  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(lock + B);
+  for (uint32_t i = tid; i < W * B; i += 256) {
+    const uint32_t b = i / W, w = i % W;
+    const uint32_t src = min(q0 + b, nq - 1);  // padded slots repeat the last query (their lists are never written out)
+    qw[((size_t)(w >> 2) * B + b) * 4 + (w & 3)] = a.qbits[(size_t)src * W + w];
+  }
+  __syncthreads();
+  if (tid < B) {
+    uint32_t c = 0;
+    for (uint32_t w = 0; w < W; w++) c += __popc(qw[((size_t)(w >> 2) * B + tid) * 4 + (w & 3)]);
+    pq[tid] = c;
+    // nothing selected yet: everything passes (Hamming: px - 2 inter < INT_MAX; Jaccard: inter >= -1 * union)
+    thr[tid] = METRIC == kHamming ? 0x7FFFFFFFu : __float_as_uint(-1.0f);
+    cnt[tid] = 0;
+    lock[tid] = 0;
+  }
+  __syncthreads();
+  const uint32_t* bits = a.bits;
+  for (uint64_t base = (uint64_t)blockIdx.x * (256 * R); base < a.n_rows; base += (uint64_t)gridDim.x * (256 * R)) {
+    uint32_t row[R];
+    bool valid[R];
+    const uint4* rp[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      row[r] = (uint32_t)base + r * 256 + tid;
+      valid[r] = row[r] < a.n_rows;
+      rp[r] = reinterpret_cast<const uint4*>(bits + (size_t)(valid[r] ? row[r] : a.n_rows - 1) * W);
+    }
+    uint32_t inter[R][B];
+    uint32_t px[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      px[r] = 0;
+#pragma unroll
+      for (int b = 0; b < B; b++) inter[r][b] = 0;
+    }
+    for (uint32_t c = 0; c < W4; c++) {
+      uint4 x[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        x[r] = rp[r][c];
+        px[r] += __popc(x[r].x) + __popc(x[r].y) + __popc(x[r].z) + __popc(x[r].w);
+      }
+      const uint4* qc = reinterpret_cast<const uint4*>(qw) + (size_t)c * B;
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        const uint4 q = qc[b];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          inter[r][b] += __popc(x[r].x & q.x) + __popc(x[r].y & q.y) + __popc(x[r].z & q.z) + __popc(x[r].w & q.w);
+      }
+    }
+    // ---- filter + (rare) exact offers ----
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      const uint32_t pqb = pq[b];
+      const uint32_t tb = thr[b];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        bool pass;
+        if (METRIC == kHamming) {
+          // ham = px + pq - 2 inter <= d_k  <=>  px - 2 inter < thr (= d_k + 1 - pq, signed)
+          pass = (int32_t)(px[r] - 2u * inter[r][b]) < (int32_t)tb;
+        } else {
+          const uint32_t uni = px[r] + pqb - inter[r][b];
+          pass = !((float)inter[r][b] < __uint_as_float(tb) * (float)uni);  // union 0 (score 1.0): 0 >= 0 passes
+        }
+#ifdef VDB_BITS_ABL_NOOFFER  // ablation (tools/probes): popcount + filter only
+        const uint64_t mask = __ballot(pass && valid[r] && inter[r][b] == 0xFFFFFFFFu);
+#else
+        const uint64_t mask = __ballot(pass && valid[r]);
+#endif
+        if (mask) bits_offer<METRIC>(lists + (size_t)b * k, &cnt[b], &lock[b], &thr[b], k, pqb, px[r], inter[r][b], row[r], mask, a.alive, lane);
+      }
+    }
+  }
+  __syncthreads();
+  const int wib = tid >> 6;
+  for (uint32_t b = wib; b < nb; b += 4) {
+    const uint32_t c = cnt[b];
+    uint64_t* dst = a.part_keys + ((size_t)(q0 + b) * gridDim.x + blockIdx.x) * k;
+    for (uint32_t e = lane; e < k; e += 64) dst[e] = e < c ? lists[(size_t)b * k + e] : kKeyInvalid;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched packed-bit sweep, k <= 48: same popcount core as sweep_topk_bits_batch, lock-free selection.  Measured
+// on the locked variant above (1 M x 768 bits, 32 queries): popcounts + filter 0.09 ms, the selection 1.6 ms — every
+// block starts with empty lists, so its first rows all qualify and queue up one locked sorted insertion at a time.
+// Here (the scheme of the GEMM sweep's epilogue, sweep_gemm.hip): per query a candidate buffer cand[64] + counter in
+// LDS; a row that passes the cheap per-query filter APPENDS its exact 64-bit key (one LDS atomic add + one store, all
+// lanes at once).  After the appends of a row step: barrier, wave w compacts the buffers of queries w, w+4, ... that
+// are past the watermark (one key per lane, rank = number of smaller keys, the k best written back in order, k-th
+// best and the filter threshold published), barrier.  Keys that found their buffer full stay pending in a per-lane
+// bit mask (one bit per (query, row slot)) and the block repeats append / compact for them against the tightened
+// k-th best — only the first row step of a block does.  The final lists hold the k smallest keys offered whatever
+// the interleaving (keys are unique; a key is only ever dropped against a k-th best that never gets worse).
+// ------------------------------------------------------------------------------------------
+constexpr int kBitsCap = 64;   // candidate buffer entries per query (= one key per lane when compacted)
+template <int METRIC, int B>
+__global__ __launch_bounds__(256) void sweep_topk_bits_tile(BitsArgs a, uint32_t nq) {
+  constexpr bool HIB = higher_is_better(METRIC);
+  constexpr int R = 2, CAP = kBitsCap;
+  static_assert(B * R <= 64, "one pending bit per (query, row slot)");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = (int)threadIdx.x;
+  const int lane = lane_id();
+  const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t k = a.k, W = a.words, W4 = W / 4;
+  const uint32_t q0 = blockIdx.y * B;
+  const uint32_t nb = min((uint32_t)B, nq - q0);
+  // LDS: qw [W4][B][4] u32 | pq[B] | thr[B] | cnts[B] | ovf (+pad) | tauk[B] u64 | cand[B][CAP] u64
+  uint32_t* qw = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* pq = qw + (size_t)W * B;
+  uint32_t* thr = pq + B;
+  uint32_t* cnts = thr + B;
+  volatile uint32_t* ovf = cnts + B;
+  uint64_t* tauk = reinterpret_cast<uint64_t*>(cnts + B + 4);
+  uint64_t* cand = tauk + B;
+  for (uint32_t i = tid; i < W * B; i += 256) {
+    const uint32_t b = i / W, w = i % W;
+    const uint32_t src = min(q0 + b, nq - 1);  // padded slots repeat the last query (their lists are never written out)
+    qw[((size_t)(w >> 2) * B + b) * 4 + (w & 3)] = a.qbits[(size_t)src * W + w];
+  }
+  __syncthreads();
+  if (tid < B) {
+    uint32_t c = 0;
+    for (uint32_t w = 0; w < W; w++) c += __popc(qw[((size_t)(w >> 2) * B + tid) * 4 + (w & 3)]);
+    pq[tid] = c;
+    thr[tid] = METRIC == kHamming ? 0x7FFFFFFFu : __float_as_uint(-1.0f);  // nothing selected yet: everything passes
+    cnts[tid] = 0;
+    tauk[tid] = kKeyInvalid;
+  }
+  if (tid == 0) *ovf = 0u;
+  __syncthreads();
+
+  const uint32_t watermark = (k + CAP) / 2;
+  auto compact = [&](bool force) __attribute__((always_inline)) {
+    const uint32_t bq = (uint32_t)wib + 4u * (uint32_t)lane;  // lane l looks at query wib + 4 l
+    const uint32_t cq = bq < (uint32_t)B ? cnts[bq] : 0u;
+    uint64_t need = __ballot(cq > k && (force || cq >= watermark));
+    while (need) {
+      const int src = __ffsll((long long)need) - 1;
+      need &= need - 1;
+      const uint32_t b = (uint32_t)wib + 4u * (uint32_t)src;
+      const uint32_t n = min(cnts[b], (uint32_t)CAP);
+      uint64_t* cb = cand + (size_t)b * CAP;
+      const bool mine = (uint32_t)lane < n;
+      const uint64_t key = mine ? cb[lane] : kKeyInvalid;
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < (uint32_t)CAP; j += 4) {
+        uint64_t kj[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) kj[u] = cb[j + u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) rank += (j + u < n && kj[u] < key) ? 1u : 0u;
+      }
+      if (mine && rank < k) cb[rank] = key;
+      if (mine && rank == k - 1) {
+        tauk[b] = key;
+        // the cheap filter in front of the exact compare: conservative (ties with the k-th best pass)
+        const float sk = key_score<HIB>(key);
+        if (METRIC == kHamming)
+          thr[b] = (uint32_t)((int32_t)sk + 1 - (int32_t)pq[b]);
+        else
+          thr[b] = __float_as_uint(sk > 0.0f ? sk * 0.999999f : -1.0f);
+      }
+      if (lane == 0) cnts[b] = k;
+    }
+  };
+
+  const uint32_t* bits = a.bits;
+  uint32_t token = 0;
+  for (uint64_t base = (uint64_t)blockIdx.x * (256 * R); base < a.n_rows; base += (uint64_t)gridDim.x * (256 * R)) {
+    uint32_t row[R];
+    bool valid[R];
+    const uint4* rp[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      row[r] = (uint32_t)base + r * 256 + tid;
+      valid[r] = row[r] < a.n_rows;
+      rp[r] = reinterpret_cast<const uint4*>(bits + (size_t)(valid[r] ? row[r] : a.n_rows - 1) * W);
+    }
+    uint32_t inter[R][B];
+    uint32_t px[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      px[r] = 0;
+#pragma unroll
+      for (int b = 0; b < B; b++) inter[r][b] = 0;
+    }
+    for (uint32_t c = 0; c < W4; c++) {
+      uint4 x[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        x[r] = rp[r][c];
+        px[r] += __popc(x[r].x) + __popc(x[r].y) + __popc(x[r].z) + __popc(x[r].w);
+      }
+      const uint4* qc = reinterpret_cast<const uint4*>(qw) + (size_t)c * B;
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        const uint4 q = qc[b];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+          inter[r][b] += __popc(x[r].x & q.x) + __popc(x[r].y & q.y) + __popc(x[r].z & q.z) + __popc(x[r].w & q.w);
+      }
+    }
+    // ---- cheap filter: one pending bit per (query, row slot) ----
+    uint32_t pend[2] = {0u, 0u};
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      const uint32_t pqb = pq[b];
+      const uint32_t tb = thr[b];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        bool pass;
+        if (METRIC == kHamming) {
+          pass = (int32_t)(px[r] - 2u * inter[r][b]) < (int32_t)tb;  // ham <= d_k  <=>  px - 2 inter < d_k + 1 - pq
+        } else {
+          const uint32_t uni = px[r] + pqb - inter[r][b];
+          pass = !((float)inter[r][b] < __uint_as_float(tb) * (float)uni);  // union 0 (score 1.0): 0 >= 0 passes
+        }
+        const int bit = b * R + r;
+        pend[bit >> 5] |= (pass && valid[r]) ? (1u << (bit & 31)) : 0u;
+      }
+    }
+#ifdef VDB_BITS_ABL_NOOFFER  // ablation (tools/probes): popcount + filter only
+    pend[0] = pend[1] = 0u;
+#endif
+    // ---- append / compact rounds ----
+    for (;;) {
+      ++token;
+      bool failed = false;
+      if (__ballot((pend[0] | pend[1]) != 0u)) {
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+#pragma unroll
+          for (int r = 0; r < R; r++) {
+            const int bit = b * R + r;
+            const uint32_t bm = 1u << (bit & 31);
+            const bool want = (pend[bit >> 5] & bm) != 0u;
+            if (__ballot(want) == 0) continue;
+            const uint32_t pqb = pq[b];
+            float score;
+            if (METRIC == kHamming) {
+              score = (float)(px[r] + pqb - 2u * inter[r][b]);
+            } else {
+              const uint32_t uni = px[r] + pqb - inter[r][b];
+              score = (uni == 0) ? 1.0f : (float)inter[r][b] / (float)uni;  // simd_explicit.rs:431-442
+            }
+            const uint64_t key = make_key<HIB>(score, row[r]);
+            bool ok = want && key < tauk[b];
+            if (ok && a.alive) ok = a.alive[row[r]] != 0;  // soft-deleted rows are filtered where it is rare
+            bool full = false;
+            if (ok) {
+              const uint32_t idx = atomicAdd(&cnts[b], 1u);
+              if (idx < (uint32_t)CAP)
+                cand[(size_t)b * CAP + idx] = key;
+              else
+                full = true;  // buffer full: stays pending for the round after the compaction
+            }
+            if (!full) pend[bit >> 5] &= ~bm;
+            failed |= full;
+          }
+        }
+      }
+      if (failed) *ovf = token;
+      __syncthreads();  // appends visible
+      const bool again = *ovf == token;
+      compact(again);
+      __syncthreads();  // compacted lists, k-th bests and thresholds visible
+      if (!again) break;
+    }
+  }
+  compact(true);
+  __syncthreads();
+  for (uint32_t b = wib; b < nb; b += 4) {
+    const uint32_t c = min(cnts[b], k);  // <= k entries; unsorted if never compacted (the merge kernel scans them all)
+    uint64_t* dst = a.part_keys + ((size_t)(q0 + b) * gridDim.x + blockIdx.x) * k;
+    for (uint32_t e = lane; e < k; e += 64) dst[e] = e < c ? cand[(size_t)b * CAP + e] : kKeyInvalid;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Insert-time row preparation: canonical norms (cosine) and packed threshold bits.
 // One wave per row.
 // ------------------------------------------------------------------------------------------
@@ -1220,6 +1569,50 @@ void launch_merge(bool hib, const MergeArgs& m, uint32_t nq, hipStream_t st) {
     hipLaunchKernelGGL((merge_topk<true>), dim3(nq), dim3(256), lds, st, m);
   else
     hipLaunchKernelGGL((merge_topk<false>), dim3(nq), dim3(256), lds, st, m);
+}
+
+size_t sweep_bits_batch_lds_bytes(int B, uint32_t words, uint32_t k) {
+  return (((size_t)words * B * 4 + (size_t)B * 16 + (size_t)B * k * 8) + 15) & ~(size_t)15;
+}
+template <int METRIC, int B>
+static hipError_t launch_bits_batch_t(const BitsArgs& a, int blocks, uint32_t nq, size_t lds, hipStream_t st) {
+  static bool done = false;
+  if (lds > 64 * 1024 && !done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_bits_batch<METRIC, B>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  hipLaunchKernelGGL((sweep_topk_bits_batch<METRIC, B>), dim3(blocks, (nq + B - 1) / B), dim3(256), lds, st, a, nq);
+  return hipGetLastError();
+}
+size_t sweep_bits_tile_lds_bytes(int B, uint32_t words) {
+  return (((size_t)words * B * 4 + (size_t)B * 12 + 16 + (size_t)B * 8 + (size_t)B * kBitsCap * 8) + 15) & ~(size_t)15;
+}
+template <int METRIC, int B>
+static hipError_t launch_bits_tile_t(const BitsArgs& a, int blocks, uint32_t nq, size_t lds, hipStream_t st) {
+  static bool done = false;
+  if (lds > 64 * 1024 && !done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_bits_tile<METRIC, B>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  hipLaunchKernelGGL((sweep_topk_bits_tile<METRIC, B>), dim3(blocks, (nq + B - 1) / B), dim3(256), lds, st, a, nq);
+  return hipGetLastError();
+}
+hipError_t launch_sweep_bits_tile(int metric, int B, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st) {
+  const size_t lds = sweep_bits_tile_lds_bytes(B, a.words);
+  if (metric == kHamming)
+    return B == 32 ? launch_bits_tile_t<kHamming, 32>(a, blocks, nq, lds, st) : launch_bits_tile_t<kHamming, 8>(a, blocks, nq, lds, st);
+  return B == 32 ? launch_bits_tile_t<kJaccard, 32>(a, blocks, nq, lds, st) : launch_bits_tile_t<kJaccard, 8>(a, blocks, nq, lds, st);
+}
+
+hipError_t launch_sweep_bits_batch(int metric, int B, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st) {
+  const size_t lds = sweep_bits_batch_lds_bytes(B, a.words, a.k);
+  if (metric == kHamming)
+    return B == 32 ? launch_bits_batch_t<kHamming, 32>(a, blocks, nq, lds, st) : launch_bits_batch_t<kHamming, 8>(a, blocks, nq, lds, st);
+  return B == 32 ? launch_bits_batch_t<kJaccard, 32>(a, blocks, nq, lds, st) : launch_bits_batch_t<kJaccard, 8>(a, blocks, nq, lds, st);
 }
 
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st) {

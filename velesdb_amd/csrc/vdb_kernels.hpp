@@ -151,6 +151,13 @@ hipError_t launch_sweep_bf16(int metric, int nqt, const uint16_t* rows, uint64_t
                              uint32_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int blocks, hipStream_t st);
 void launch_merge(bool higher_is_better, const MergeArgs& m, uint32_t nq, hipStream_t st);
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st);
+// B (8 or 32) queries per corpus pass; blocks = row blocks (= partial lists per query), grid.y = ceil(nq / B)
+size_t sweep_bits_batch_lds_bytes(int B, uint32_t words, uint32_t k);
+hipError_t launch_sweep_bits_batch(int metric, int B, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st);
+// same popcount core, lock-free selection (candidate buffers + compaction); k <= kBitsTileMaxK
+constexpr uint32_t kBitsTileMaxK = 48;
+size_t sweep_bits_tile_lds_bytes(int B, uint32_t words);
+hipError_t launch_sweep_bits_tile(int metric, int B, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st);
 void launch_prep_rows(const PrepArgs& a, hipStream_t st);
 void launch_score_rows(int metric, const ScoreArgs& a, hipStream_t st);
 
