@@ -321,27 +321,8 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     pa.dim = ix->dim;
     pa.words = ix->words;
     launch_prep_rows(pa, st);
-    const uint32_t nchunks = (uint32_t)((ix->n_rows + 63) / 64);
-    int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + 3) / 4, (int64_t)ix->n_cus * 4));
-    // >= 3 queries: B queries per corpus pass; B = 8 or 32, whichever pads the batch less.  k <= 48: lock-free selection
-    // (sweep_topk_bits_tile); larger k: block-shared locked lists (sweep_topk_bits_batch), worth it from ~96 queries
-    int bits_B = 0;
-    bool bits_tile = false;
-    if (nq >= 3) {
-      const uint32_t pad8 = (nq + 7) / 8 * 8, pad32 = (nq + 31) / 32 * 32;
-      bits_B = (nq >= 64 || pad32 <= pad8) ? 32 : 8;
-      if (k <= kBitsTileMaxK && sweep_bits_tile_lds_bytes(bits_B, ix->words) <= 64 * 1024) {
-        bits_tile = true;
-      } else {
-        if (nq < 96) bits_B = 0;
-        if (bits_B && sweep_bits_batch_lds_bytes(bits_B, ix->words, k) > 64 * 1024) bits_B = 8;
-        if (bits_B && sweep_bits_batch_lds_bytes(bits_B, ix->words, k) > 64 * 1024) bits_B = 0;
-      }
-    }
-    if (bits_B) {
-      const int64_t nqt = (nq + bits_B - 1) / bits_B;
-      blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ix->n_rows + 511) / 512, (int64_t)ix->n_cus * 4 / nqt));
-    }
+    const BitsPlan bp = plan_bits_sweep(ix->n_rows, ix->n_cus, ix->words, nq, k);
+    const int blocks = bp.blocks;
     const uint32_t nw = (uint32_t)blocks;  // one list per block
     if ((e = ix->s_part_keys.reserve((size_t)nq * nw * k * 8, false, st)) != hipSuccess ||
         (e = ix->s_part_cnt.reserve((size_t)nq * nw * 4, false, st)) != hipSuccess)
@@ -357,12 +338,9 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     ba.k = k;
     EventPair* ev = next_events(ix);
     if (ev) (void)hipEventRecord(ev->a, st);
-    if (bits_B) {
-      hipError_t eb = bits_tile ? launch_sweep_bits_tile(ix->metric, bits_B, ba, blocks, nq, st)
-                                : launch_sweep_bits_batch(ix->metric, bits_B, ba, blocks, nq, st);
+    {
+      hipError_t eb = launch_bits_plan(ix->metric, bp, ba, nq, st);
       if (eb != hipSuccess) return fail(VDB_ERR_HIP, std::string("packed-bit sweep launch: ") + hipGetErrorString(eb));
-    } else {
-      launch_sweep_bits(ix->metric, ba, blocks, nq, st);
     }
     if (ev) (void)hipEventRecord(ev->b, st);
     MergeArgs m{};

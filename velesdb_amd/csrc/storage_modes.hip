@@ -528,8 +528,8 @@ int32_t brute_binary_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
   if (e != hipSuccess) return fail(VDB_ERR_OOM, "qbits scratch");
   hipLaunchKernelGGL(sign_bits_rows, dim3((unsigned)std::min<uint32_t>((nq + 3) / 4, 4096)), dim3(256), 0, st, d_q, q_stride,
                      ix->s_qbits.as<uint32_t>(), ix->words, 0u, nq, ix->dim);
-  const uint32_t nchunks = (uint32_t)((ix->n_rows + 63) / 64);
-  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nchunks + 3) / 4, (int64_t)ix->n_cus * 4));
+  const BitsPlan bp = plan_bits_sweep(ix->n_rows, ix->n_cus, ix->words, nq, k);  // batches: 8 / 32 queries per corpus pass
+  const int blocks = bp.blocks;
   if ((e = ix->s_part_keys.reserve((size_t)nq * blocks * k * 8, false, st)) != hipSuccess ||
       (e = ix->s_part_cnt.reserve((size_t)nq * blocks * 4, false, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, "top-k scratch");
@@ -544,7 +544,8 @@ int32_t brute_binary_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
   ba.k = k;
   EventPair* ev = next_events(ix);
   if (ev) (void)hipEventRecord(ev->a, st);
-  launch_sweep_bits(VDB_HAMMING, ba, blocks, nq, st);
+  if ((e = launch_bits_plan(VDB_HAMMING, bp, ba, nq, st)) != hipSuccess)
+    return fail(VDB_ERR_HIP, std::string("sign-bit sweep launch: ") + hipGetErrorString(e));
   if (ev) (void)hipEventRecord(ev->b, st);
   MergeArgs m{};
   m.part_keys = ba.part_keys;

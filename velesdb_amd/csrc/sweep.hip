@@ -1615,6 +1615,39 @@ hipError_t launch_sweep_bits_batch(int metric, int B, const BitsArgs& a, int blo
   return B == 32 ? launch_bits_batch_t<kJaccard, 32>(a, blocks, nq, lds, st) : launch_bits_batch_t<kJaccard, 8>(a, blocks, nq, lds, st);
 }
 
+// Which packed-bit kernel serves a batch, and with how many row blocks (= partial lists per query):
+//   1-2 queries: per-query kernel; >= 3 queries: B queries per corpus pass, B = 8 or 32, whichever pads the batch
+//   less; k <= 48: lock-free selection (sweep_topk_bits_tile); larger k: block-shared locked lists
+//   (sweep_topk_bits_batch), worth it from ~96 queries.
+BitsPlan plan_bits_sweep(uint64_t n_rows, int n_cus, uint32_t words, uint32_t nq, uint32_t k) {
+  BitsPlan p{};
+  const uint64_t nchunks = (n_rows + 63) / 64;
+  p.blocks = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)(nchunks + 3) / 4, (int64_t)n_cus * 4));
+  if (nq >= 3) {
+    const uint32_t pad8 = (nq + 7) / 8 * 8, pad32 = (nq + 31) / 32 * 32;
+    p.B = (nq >= 64 || pad32 <= pad8) ? 32 : 8;
+    if (k <= kBitsTileMaxK && sweep_bits_tile_lds_bytes(p.B, words) <= 64 * 1024) {
+      p.tile = true;
+    } else {
+      if (nq < 96) p.B = 0;
+      if (p.B && sweep_bits_batch_lds_bytes(p.B, words, k) > 64 * 1024) p.B = 8;
+      if (p.B && sweep_bits_batch_lds_bytes(p.B, words, k) > 64 * 1024) p.B = 0;
+    }
+  }
+  if (p.B) {
+    const int64_t nqt = (nq + p.B - 1) / p.B;
+    p.blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)n_rows + 511) / 512, (int64_t)n_cus * 4 / nqt));
+  }
+  return p;
+}
+hipError_t launch_bits_plan(int metric, const BitsPlan& p, const BitsArgs& a, uint32_t nq, hipStream_t st) {
+  if (p.B == 0) {
+    launch_sweep_bits(metric, a, p.blocks, nq, st);
+    return hipGetLastError();
+  }
+  return p.tile ? launch_sweep_bits_tile(metric, p.B, a, p.blocks, nq, st) : launch_sweep_bits_batch(metric, p.B, a, p.blocks, nq, st);
+}
+
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st) {
   const size_t lds = ((((size_t)a.k * 8 + 8 + 15) & ~(size_t)15) + (size_t)a.words * 4 + 15) & ~(size_t)15;
   if (metric == kHamming)

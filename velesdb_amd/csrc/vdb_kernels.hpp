@@ -158,6 +158,13 @@ hipError_t launch_sweep_bits_batch(int metric, int B, const BitsArgs& a, int blo
 constexpr uint32_t kBitsTileMaxK = 48;
 size_t sweep_bits_tile_lds_bytes(int B, uint32_t words);
 hipError_t launch_sweep_bits_tile(int metric, int B, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st);
+struct BitsPlan {
+  int blocks;  // row blocks = partial top-k lists per query
+  int B;       // queries per corpus pass (0: the per-query kernel)
+  bool tile;   // lock-free selection (k <= kBitsTileMaxK)
+};
+BitsPlan plan_bits_sweep(uint64_t n_rows, int n_cus, uint32_t words, uint32_t nq, uint32_t k);
+hipError_t launch_bits_plan(int metric, const BitsPlan& p, const BitsArgs& a, uint32_t nq, hipStream_t st);
 void launch_prep_rows(const PrepArgs& a, hipStream_t st);
 void launch_score_rows(int metric, const ScoreArgs& a, hipStream_t st);
 
