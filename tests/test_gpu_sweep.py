@@ -199,6 +199,91 @@ def test_gemm_sweep_many_query_tiles_bit_exact(gpu_required, metric, n, dim):
     ix.close()
 
 
+@pytest.mark.parametrize("n,dim", [(10007, 768), (4000, 100), (3000, 17), (50, 64), (2500, 1001)])
+def test_euclidean_large_batches_bit_exact(gpu_required, n, dim):
+    # >= 64 Euclidean queries: approximate selection of k + 16 candidates on the matrix cores (|v|^2 + |q|^2 - 2 q.v),
+    # canonical (q - v)^2 re-scoring, per-query proof of exactness, exact vector-ALU sweep for the unproven ones.
+    # Whatever the route, ids and score bits equal the oracle's mode C — the same bits a single query returns.
+    rng = np.random.default_rng(n * 17 + dim)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64) * 7 + 3
+    ix = va.HnswIndex(dim, DM.Euclidean)
+    assert ix.upload(ids, rows) == n
+    for nq, k in [(64, 10), (129, 1), (300, 32), (200, 40)]:        # k = 40: beyond the candidate slack, VALU route
+        Q = rng.standard_normal((nq, dim)).astype(np.float32)
+        Q[3] = rows[n // 3]                                           # an exact hit (distance 0)
+        gid, gsc, gcnt = ix.search_batch_brute_force(Q, k)
+        kk = min(k, n)
+        eid, esc = po.scan_topk(po.EUCLIDEAN, rows, Q, kk, po.MODE_C, nthreads=8)
+        assert np.all(gcnt == kk)
+        assert np.array_equal(gid[:, :kk], ids[eid.astype(np.int64)]), (nq, k)
+        assert np.array_equal(bits(gsc[:, :kk]), bits(esc)), (nq, k)
+        one = ix.search_batch_brute_force(Q[:2], k)                   # small batch: same bits
+        assert np.array_equal(one[0][:, :kk], gid[:2, :kk]) and np.array_equal(bits(one[1][:, :kk]), bits(gsc[:2, :kk]))
+    dead = rng.choice(n, max(1, n // 10), replace=False)
+    for d in dead:
+        assert ix.remove(int(ids[d]))
+    live = np.ones(n, bool)
+    live[dead] = False
+    Q = rng.standard_normal((96, dim)).astype(np.float32)
+    gid, gsc, gcnt = ix.search_batch_brute_force(Q, 10)
+    exp = oracle_brute(DM.Euclidean, rows, ids, Q, 10, live)
+    for qi in range(96):
+        assert np.array_equal(gid[qi, :gcnt[qi]], exp[qi][0]) and np.array_equal(bits(gsc[qi, :gcnt[qi]]), bits(exp[qi][1]))
+    ix.close()
+
+
+def test_euclidean_large_batches_near_duplicates_and_specials(gpu_required):
+    # near-duplicate clouds: hundreds of rows within 1e-4 of the query, far more than the candidate slack — the
+    # approximate values cannot separate them (cancellation), the per-query verdict must send those queries to the exact
+    # sweep; NaN / inf rows; duplicates (tie by row)
+    rng = np.random.default_rng(41)
+    n, dim = 6000, 256
+    rows = rng.standard_normal((n, dim)).astype(np.float32) * 3
+    centre = rng.standard_normal(dim).astype(np.float32) * 3
+    rows[1000:1400] = centre + rng.standard_normal((400, dim)).astype(np.float32) * 1e-4
+    rows[2000] = rows[1999]
+    rows[17, 3] = np.nan
+    rows[29, 0] = np.inf
+    Q = rng.standard_normal((80, dim)).astype(np.float32) * 3
+    Q[:40] = centre + rng.standard_normal((40, dim)).astype(np.float32) * 1e-4
+    Q[50] = rows[1999]
+    ix = va.HnswIndex(dim, DM.Euclidean)
+    ix.upload(np.arange(n), rows)
+    gid, gsc, gcnt = ix.search_batch_brute_force(Q, 10)
+    eid, esc = po.scan_topk(po.EUCLIDEAN, rows, Q, 10, po.MODE_C, nthreads=8)
+    assert np.array_equal(gid, eid)
+    assert np.array_equal(bits(gsc), bits(esc))
+    ix.close()
+
+
+@pytest.mark.parametrize("dim", [256, 512, 1024])
+def test_lds_query_tile_kernel_many_row_groups_per_wave(gpu_required, dim):
+    # regression (found by tools/fuzz_sweep.py --euclid): sweep_topk_f32_qlds prefetches row chunks two steps ahead; with
+    # ONE 256-float chunk per row (dim 256) "two steps ahead" is the group after the next, and it used to read the
+    # neighbouring row instead — wrong results once a wave owned three or more row groups (tens of thousands of rows;
+    # the other tests of this kernel are smaller).  16 and 32 queries per pass, Euclidean and the vector-ALU engine of
+    # cosine / dot.
+    rng = np.random.default_rng(dim)
+    n = 70000 if dim == 256 else 40000
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    for metric in (DM.Euclidean, DM.Cosine, DM.DotProduct):
+        ix = va.HnswIndex(dim, metric)
+        ix.upload(np.arange(n), rows)
+        try:
+            if metric != DM.Euclidean:
+                va.set_sweep_engine(0)
+            for nq, k in [(16, 10), (40, 10), (32, 48)]:
+                Q = rng.standard_normal((nq, dim)).astype(np.float32)
+                gid, gsc, gcnt = ix.search_batch_brute_force(Q, k)
+                eid, esc = po.scan_topk(int(metric), rows, Q, k, po.MODE_C, nthreads=8)
+                assert np.array_equal(gid, eid), (metric, nq, k)
+                assert np.array_equal(bits(gsc), bits(esc)), (metric, nq, k)
+        finally:
+            va.set_sweep_engine(1)
+        ix.close()
+
+
 def test_gemm_sweep_more_queries_than_one_launch(gpu_required):
     # > 1024 queries: several GEMM launches (kGemmMaxQueries), the tail through whatever kernel its size selects
     rng = np.random.default_rng(31)

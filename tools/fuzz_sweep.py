@@ -20,6 +20,8 @@ from oracle import pyoracle as po  # noqa: E402
 p = argparse.ArgumentParser()
 p.add_argument("--seconds", type=float, default=240)
 p.add_argument("--seed", type=int, default=1)
+p.add_argument("--only-it", type=int, default=0, help="replay: generate every case, run only this one (verbose)")
+p.add_argument("--euclid", action="store_true", help="Euclidean only (matrix-core batches + exact re-scoring)")
 p.add_argument("--bits", action="store_true", help="Hamming / Jaccard (packed-bit kernels) instead of cosine / dot")
 a = p.parse_args()
 rng = np.random.default_rng(a.seed)
@@ -61,6 +63,9 @@ while time.time() < t_end:
     if a.bits:
         bf16 = False
         metric = [DM.Hamming, DM.Jaccard][int(rng.integers(0, 2))]
+    if a.euclid:
+        bf16 = False
+        metric = DM.Euclidean
     dim = int(rng.choice([64, 128, 192, 256, 768])) if bf16 else int(rng.choice([8, 17, 64, 100, 128, 256, 300, 768]))
     n = int(rng.choice([1, 7, 100, 129, 1000, 4097, 12000, 30000]))
     nq = int(rng.choice([1, 5, 63, 64, 100, 128, 129, 230, 256, 300, 480, 512, 700, 1024, 1100]))
@@ -82,10 +87,26 @@ while time.time() < t_end:
         Q = (Q * 0.05 + q0[None, :]).astype(np.float32)
     if kind == "small_ints" and not a.bits:
         Q = rng.integers(-3, 4, size=(nq, dim)).astype(np.float32)
+    if a.only_it and it != a.only_it:
+        if it > a.only_it:
+            break
+        continue
     ix = va.HnswIndex(dim, metric)
     ix.upload(np.arange(n), rows)
     tag = f"it={it} bf16={bf16} {metric.name} n={n} dim={dim} nq={nq} k={k} {kind}"
     kk = min(k, n)
+    if a.only_it:
+        gi, gs, gc = ix.search_batch_brute_force(Q, k)
+        mode = po.MODE_M if ix.sweep_arith_mode(k) == "M" else po.MODE_C
+        eid, esc = po.scan_topk(int(metric), rows, Q, kk, mode, nthreads=8)
+        bad = np.nonzero(np.any(gi[:, :kk] != eid, axis=1) | np.any(bits(gs[:, :kk]) != bits(esc), axis=1))[0]
+        print(tag, "mode", mode, "bad queries", bad.tolist()[:20], "of", nq)
+        for qi in bad[:3]:
+            d = np.nonzero(gi[qi, :kk] != eid[qi])[0]
+            print(" q", qi, "first diff rank", d[:5], "gpu", gi[qi, d[:5]], gs[qi, d[:5]], "oracle", eid[qi, d[:5]], esc[qi, d[:5]])
+            one = ix.search_batch_brute_force(Q[qi:qi + 1], k)
+            print("   alone equal to oracle:", np.array_equal(one[0][0, :kk], eid[qi]), " count", gc[qi], one[2][0])
+        sys.exit(0)
     if bf16:
         ix.enable_bf16()
         gi, gs, gc = ix.search_batch_brute_force_bf16(Q, k)

@@ -79,7 +79,7 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
       (e = ix->alive.reserve(ncap, true, st)) != hipSuccess ||
       (e = ix->ext_ids.reserve(ncap * 8, true, st)) != hipSuccess)
     return fail(e == hipErrorOutOfMemory ? VDB_ERR_OOM : VDB_ERR_HIP, std::string("grow: ") + hipGetErrorString(e));
-  if (ix->metric == VDB_COSINE && (e = ix->norms.reserve(ncap * 4, true, st)) != hipSuccess)
+  if ((ix->metric == VDB_COSINE || ix->metric == VDB_EUCLIDEAN) && (e = ix->norms.reserve(ncap * 4, true, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("grow norms: ") + hipGetErrorString(e));
   if (is_bits_metric(ix->metric) && (e = ix->bits.reserve(ncap * ix->words * 4, true, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("grow bits: ") + hipGetErrorString(e));
@@ -106,7 +106,8 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
 static int32_t finish_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
   PrepArgs pa{};
   pa.rows = ix->rows.as<float>();
-  pa.norms = ix->metric == VDB_COSINE ? ix->norms.as<float>() : nullptr;
+  // cosine: the kernels divide by them; Euclidean: |v|^2 of the matrix-core batch path (sweep_topk_gemm_f32<kEuclidean>)
+  pa.norms = (ix->metric == VDB_COSINE || ix->metric == VDB_EUCLIDEAN) ? ix->norms.as<float>() : nullptr;
   pa.bits = is_bits_metric(ix->metric) ? ix->bits.as<uint32_t>() : nullptr;
   pa.row_stride = ix->row_stride;
   pa.row0 = (uint32_t)first;
@@ -366,6 +367,84 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
       for (; want >= 1; want--)
         if (sweep_mfma_lds_bytes(want, k, ix->dim) <= 160 * 1024) break;
       mfma_nqt = want;  // 0: does not fit the LDS (very large dim or k): VALU kernels
+    }
+    // Euclidean batches: approximate selection of k + slack candidates on the matrix cores, canonical re-scoring, proof
+    // of exactness per query; the (rare) unproven queries go through the exact vector-ALU sweep below
+    if (ix->metric == VDB_EUCLIDEAN && g_sweep_engine == 1 && g_max_tile >= 128 && nq - q0 >= kGemmMinQueries &&
+        k + kEuclidSlack <= kGemmMaxK) {
+      const uint32_t nqg = std::min<uint32_t>(nq - q0, kGemmMaxQueries);
+      // k <= 10: 16 candidates — the 32-entry candidate buffers then leave room for two blocks per CU; the per-query
+      // verdict catches the (rare) query whose near-ties are wider than the slack
+      const uint32_t kp = k + 6 <= 16 ? 16 : k + kEuclidSlack;
+      GemmPlan gp;
+      sweep_gemm_plan(nqg, (uint32_t)ix->n_rows, ix->n_cus, kp, &gp);
+      if (gp.lds <= 160 * 1024) {
+        hipError_t e3;
+        // scratch: norm max (16 B) | flags [nqg] | cand n [nqg] | cand approx [nqg][kp] | cand rows [nqg][kp] (8-B aligned)
+        const size_t off_flags = 16, off_n = off_flags + (size_t)nqg * 4, off_ap = off_n + (size_t)nqg * 4;
+        const size_t off_rows = (off_ap + (size_t)nqg * kp * 4 + 15) & ~(size_t)15;
+        if ((e3 = ix->s_part_keys.reserve((size_t)nqg * gp.G * kp * 8, false, st)) != hipSuccess ||
+            (e3 = ix->s_misc.reserve(off_rows + (size_t)nqg * kp * 8, false, st)) != hipSuccess)
+          return fail(VDB_ERR_OOM, "top-k scratch");
+        unsigned char* sc = ix->s_misc.as<unsigned char>();
+        SweepArgs ag{};
+        ag.rows = ix->rows.as<float>();
+        ag.norms = ix->norms.as<float>();
+        ag.alive = alive;
+        ag.queries = d_q + (size_t)q0 * q_stride;
+        ag.part_keys = ix->s_part_keys.as<uint64_t>();
+        ag.row_stride = ix->row_stride;
+        ag.q_stride = q_stride;
+        ag.n_rows = (uint32_t)ix->n_rows;
+        ag.dim = ix->dim;
+        ag.nq = nqg;
+        ag.k = kp;
+        EventPair* evg = next_events(ix);
+        if (evg) (void)hipEventRecord(evg->a, st);
+        e3 = launch_sweep_gemm(VDB_EUCLIDEAN, gp, ag, st);
+        if (evg) (void)hipEventRecord(evg->b, st);
+        if (e3 != hipSuccess) return fail(VDB_ERR_HIP, std::string("gemm sweep launch: ") + hipGetErrorString(e3));
+        MergeArgs mg{};
+        mg.part_keys = ag.part_keys;
+        mg.ext_ids = nullptr;  // internal rows
+        mg.out_ids = reinterpret_cast<uint64_t*>(sc + off_rows);
+        mg.out_scores = reinterpret_cast<float*>(sc + off_ap);
+        mg.out_n = reinterpret_cast<uint32_t*>(sc + off_n);
+        mg.n_lists = gp.G;
+        mg.k = kp;
+        launch_merge(false, mg, nqg, st);
+        EuclidRerankArgs ra{};
+        ra.rows = ag.rows;
+        ra.queries = ag.queries;
+        ra.cand_rows = mg.out_ids;
+        ra.cand_approx = mg.out_scores;
+        ra.cand_n = mg.out_n;
+        ra.ext_ids = ix->ext_ids.as<uint64_t>();
+        ra.norm_max_bits = reinterpret_cast<const uint32_t*>(sc);
+        ra.out_ids = d_ids + (size_t)q0 * k;
+        ra.out_scores = d_scores + (size_t)q0 * k;
+        ra.out_n = d_n + q0;
+        ra.flags = reinterpret_cast<uint32_t*>(sc + off_flags);
+        ra.row_stride = ix->row_stride;
+        ra.q_stride = q_stride;
+        ra.dim = ix->dim;
+        ra.k = k;
+        ra.kp = kp;
+        launch_euclid_rerank(ra, ag.norms, ag.n_rows, nqg, st);
+        VDB_HIP(hipGetLastError());
+        std::vector<uint32_t> flags(nqg);
+        VDB_HIP(hipMemcpyAsync(flags.data(), ra.flags, (size_t)nqg * 4, hipMemcpyDeviceToHost, st));
+        VDB_HIP(hipStreamSynchronize(st));
+        for (uint32_t i = 0; i < nqg; i++) {
+          if (!flags[i]) continue;
+          const int32_t rc1 = brute_dev(ix, d_q + (size_t)(q0 + i) * q_stride, q_stride, 1, k, d_ids + (size_t)(q0 + i) * k,
+                                        d_scores + (size_t)(q0 + i) * k, d_n + q0 + i, st);
+          if (rc1 != VDB_OK) return rc1;
+          ix->euclid_fallbacks++;
+        }
+        q0 += nqg;
+        continue;
+      }
     }
     // large batches: GEMM-structured matrix-core kernel, the whole batch in one launch (sweep_gemm.hip)
     if (mfma_nqt && g_max_tile >= 128 && nq - q0 >= kGemmMinQueries && k <= kGemmMaxK) {

@@ -268,6 +268,7 @@ __global__ __launch_bounds__(WAVES * 64, (B == 32 ? 4 : 3)) void sweep_topk_f32_
     for (int i = 0; i < 32; i++) acc2[i] = f32x2{0.0f, 0.0f};
     const uint32_t row0 = g * RPG;
     const uint32_t gn = g + nwaves < ngroups ? g + nwaves : g;  // last group: harmless re-read
+    const uint32_t gn2 = g + 2 * nwaves < ngroups ? g + 2 * nwaves : g;
     const uint32_t row = row0 + lane / B;
     const bool valid = row < a.n_rows && myb < (int)a.nq;
     float vnorm = 1.0f;
@@ -314,8 +315,16 @@ __global__ __launch_bounds__(WAVES * 64, (B == 32 ? 4 : 3)) void sweep_topk_f32_
           // The row norm is requested first so that waiting for it later does not wait for the prefetches.
           if (j == 0 && METRIC == kCosine) vnorm = a.norms[row < a.n_rows ? row : a.n_rows - 1];
 #pragma unroll
-          for (int r = 0; r < RPG; r++)
-            n2[r] = (j + 2 < CPL) ? ld4(row_ptr(g, r) + (j + 2) * 256) : ld4(row_ptr(gn, r) + (j + 2 - CPL) * 256);
+          for (int r = 0; r < RPG; r++) {
+            // step s+2: chunk j+2 of this group, or of the next group; with ONE chunk per row (CPL = 1) it is
+            // chunk 0 of the group after the next
+            if (j + 2 < CPL)
+              n2[r] = ld4(row_ptr(g, r) + (j + 2) * 256);
+            else if (j + 2 - CPL < CPL)
+              n2[r] = ld4(row_ptr(gn, r) + (j + 2 - CPL) * 256);
+            else
+              n2[r] = ld4(row_ptr(gn2, r) + (j + 2 - 2 * CPL) * 256);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -1267,6 +1276,101 @@ __global__ __launch_bounds__(256) void sweep_topk_bits_tile(BitsArgs a, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------
+// Euclidean batches on the matrix cores, second half (first half: sweep_topk_gemm_f32<kEuclidean>, which keeps the
+// k' = k + slack rows with the smallest APPROXIMATE squared distance |v|^2 + |q|^2 - 2 q.v per query).  One block per
+// query: (1) every candidate is re-scored with the canonical (q - v)^2 lane chain + butterfly + sqrt — the very
+// arithmetic of the small-batch kernels, so a query's result does not depend on the batch it came in;
+// (2) the candidates are ranked by (exact score, row); (3) the verdict: a row OUTSIDE the candidates has an
+// approximate value >= A (the worst one kept), hence a canonical squared sum >= A - delta, where delta bounds
+// |approx - canonical| for any row: both deviate from the true |q - v|^2 by at most ~2 n eps (|q|^2 + |v|^2), the
+// bound used is 8 n eps (|q|^2 + max|v|^2).  If A - delta > the k-th best canonical sum, nothing outside can reach
+// the top k and the answer is exact; otherwise (near-ties wider than the slack, NaN) the query is FLAGGED and the
+// caller re-runs it through the exact vector-ALU sweep.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void max_norm_kernel(const float* norms, uint32_t n, uint32_t* out_bits) {
+  float m = 0.0f;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float v = norms[i];
+    m = (v > m || v != v) ? v : m;  // NaN propagates: the verdict then flags every query
+  }
+  // norms are >= 0 (or NaN, whose bit pattern is above every finite value): unsigned order = float order
+  atomicMax(out_bits, __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void euclid_rerank_verify(EuclidRerankArgs a) {
+  __shared__ uint64_t keys[64];
+  __shared__ float sums[64];
+  const int lane = lane_id();
+  const int wib = (int)(threadIdx.x >> 6);
+  const uint32_t qi = blockIdx.x;
+  const uint32_t n = min(a.cand_n[qi], a.kp);
+  const float* q = a.queries + (size_t)qi * a.q_stride;
+  const int d4 = (int)((a.dim + 3) / 4);
+  for (uint32_t c = wib; c < n; c += 4) {
+    const uint32_t row = (uint32_t)a.cand_rows[(size_t)qi * a.kp + c];
+    const float* p = a.rows + (size_t)row * a.row_stride;  // 16-B aligned, zero-padded to the stride
+    float acc = 0.0f;
+    for (int ch = lane; ch < d4; ch += 64) {
+      const int nv = (int)a.dim - ch * 4;
+      const float4 x = ld4(p + ch * 4);
+      float4 qq;
+      if (nv >= 4) {
+        qq = make_float4(q[ch * 4], q[ch * 4 + 1], q[ch * 4 + 2], q[ch * 4 + 3]);
+        acc = chain4<kOpL2>(acc, qq, x);
+      } else {
+        qq = make_float4(q[ch * 4], nv > 1 ? q[ch * 4 + 1] : 0.f, nv > 2 ? q[ch * 4 + 2] : 0.f, 0.f);
+        acc = chain4_tail<kOpL2>(acc, qq, x, nv);
+      }
+    }
+    const float sum = butterfly_all(acc);
+    if (lane == 0) {
+      sums[c] = sum;
+      keys[c] = make_key<false>(finish_score<kEuclidean>(sum, 0.f, 0.f), row);
+    }
+  }
+  __syncthreads();
+  if (wib != 0) return;
+  // rank by (exact score, row)
+  const uint64_t key = (uint32_t)lane < n ? keys[lane] : kKeyInvalid;
+  uint32_t rank = 0;
+  for (uint32_t j = 0; j < n; j++) rank += keys[j] < key ? 1u : 0u;
+  // lane e picks up the candidate of rank e (ranks are a permutation of 0..n-1: keys are unique)
+  uint32_t mine = 0;
+  for (uint32_t j = 0; j < n; j++) {
+    const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)rank, (int)j);
+    if (rj == (uint32_t)lane) mine = j;
+  }
+  // |q|^2 for the error bound (any accurate value will do)
+  float qacc = 0.0f;
+  for (uint32_t i = lane; i < a.dim; i += 64) qacc = __builtin_fmaf(q[i], q[i], qacc);
+  const float qn2 = butterfly_all(qacc);
+  const uint32_t kk = min(a.k, n);
+  bool ok = true;
+  if (n == a.kp && kk > 0) {  // the candidate buffer is full: rows were left out
+    const float A = a.cand_approx[(size_t)qi * a.kp + a.kp - 1];
+    const float nmax = __uint_as_float(*a.norm_max_bits);
+    const float delta = 8.0f * (float)a.dim * 5.9604645e-8f * (qn2 + nmax * nmax) + fabsf(A) * 1e-6f;
+    const float Ek = sums[__builtin_amdgcn_readlane((int)mine, (int)(kk - 1))];
+    ok = (A - delta) > Ek;  // false for NaN anywhere
+  }
+  if (lane == 0) {
+    a.flags[qi] = ok ? 0u : 1u;
+    a.out_n[qi] = kk;
+  }
+  for (uint32_t e = lane; e < a.k; e += 64) {
+    if (e < kk) {
+      const uint64_t ke = keys[mine];
+      const uint32_t row = key_row(ke);
+      a.out_ids[(size_t)qi * a.k + e] = a.ext_ids ? a.ext_ids[row] : (uint64_t)row;
+      a.out_scores[(size_t)qi * a.k + e] = key_score<false>(ke);
+    } else {
+      a.out_ids[(size_t)qi * a.k + e] = ~0ull;
+      a.out_scores[(size_t)qi * a.k + e] = __uint_as_float(0x7FC00000u);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Insert-time row preparation: canonical norms (cosine) and packed threshold bits.
 // One wave per row.
 // ------------------------------------------------------------------------------------------
@@ -1344,7 +1448,7 @@ __global__ __launch_bounds__(256) void score_rows(ScoreArgs a) {
         out = (float)ham;
       } else {
         float sim = (uni == 0) ? 1.0f : (float)inter / (float)uni;
-        out = (a.kind == 0) ? 1.0f - sim : sim;  // native/distance.rs:83
+        out = (a.kind == 0) ? canon_nan(1.0f - sim) : sim;  // native/distance.rs:83
       }
     } else {
       constexpr int OP = (METRIC == kEuclidean) ? kOpL2 : kOpDot;
@@ -1376,9 +1480,9 @@ __global__ __launch_bounds__(256) void score_rows(ScoreArgs a) {
       float vn = 1.0f;
       if (METRIC == kCosine) vn = sqrtf(butterfly_all(nacc));
       float s = finish_score<METRIC>(sum, qn, vn);
-      if (METRIC == kEuclidean && a.kind == 2) s = sum;  // simd::squared_l2_distance (simd.rs:207-211): no sqrt
+      if (METRIC == kEuclidean && a.kind == 2) s = canon_nan(sum);  // simd::squared_l2_distance (simd.rs:207-211): no sqrt
       if (a.kind == 0) {  // DistanceEngine::distance (native/distance.rs:78-80)
-        if (METRIC == kCosine) s = 1.0f - s;
+        if (METRIC == kCosine) s = canon_nan(1.0f - s);
         if (METRIC == kDot) s = -s;
       }
       out = s;
@@ -1561,6 +1665,13 @@ hipError_t launch_sweep_bf16(int metric, int nqt, const uint16_t* rows, uint64_t
     case 2: return launch_bf16_t<kDot, 2, kBf16WavesSmall>(a, blocks, lds, st);
     default: return launch_bf16_t<kDot, 1, kBf16WavesSmall>(a, blocks, lds, st);
   }
+}
+
+void launch_euclid_rerank(const EuclidRerankArgs& a, const float* norms, uint32_t n_rows, uint32_t nq, hipStream_t st) {
+  (void)hipMemsetAsync(const_cast<uint32_t*>(a.norm_max_bits), 0, 4, st);
+  hipLaunchKernelGGL(max_norm_kernel, dim3(std::min<uint32_t>((n_rows + 255) / 256, 1024)), dim3(256), 0, st, norms, n_rows,
+                     const_cast<uint32_t*>(a.norm_max_bits));
+  hipLaunchKernelGGL(euclid_rerank_verify, dim3(nq), dim3(256), 0, st, a);
 }
 
 void launch_merge(bool hib, const MergeArgs& m, uint32_t nq, hipStream_t st) {

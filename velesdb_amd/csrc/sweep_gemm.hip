@@ -116,7 +116,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void sweep_topk_gem
   constexpr int BM = 2 * WROWS, BK = kGemmBK, BN = WCOLS * 16 * NQF;
   static_assert(BM == 4 * SR && BN == NQF * SR, "staging passes: 4 for the rows, NQF for the queries");
   constexpr int NW = RF * NQF * 4 / 32 > 2 ? RF * NQF * 4 / 32 : 2;  // 32-bit words of the per-lane pass mask
-  constexpr bool HIB = true;  // cosine and dot: higher is better
+  // Euclidean instance: the accumulators are still q.v; the kernel selects by the APPROXIMATE squared distance
+  // |v|^2 + |q|^2 - 2 q.v (lower is better) and keeps k' = k + slack candidates per query; the caller re-scores them
+  // with the canonical (q - v)^2 chain and verifies that nothing outside the candidates can reach the top k
+  // (euclid_rerank_verify, index.hip) — the identity alone loses all relative accuracy for near-duplicates.
+  constexpr bool HIB = METRIC != kEuclidean;
+  constexpr bool NORMS = METRIC == kCosine || METRIC == kEuclidean;  // per-row / per-query norms are needed
   const SweepArgs& a = ga.s;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* As = reinterpret_cast<float*>(smem);  // [BM][BK]
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void sweep_topk_gem
       const float n = sqrtf(butterfly_all(nacc));
       if (lane == 0) qn[b] = n;
     }
-  } else if (METRIC == kCosine) {  // canonical query norms (same as every other kernel)
+  } else if (NORMS) {  // canonical query norms (same as every other kernel); Euclidean keeps the squared norm
     const int d4 = (int)((a.dim + 3) / 4);
     for (uint32_t b = wib; b < nq_t; b += WAVES) {
       const float* qp = queries + (size_t)b * a.q_stride;
@@ -186,7 +191,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void sweep_topk_gem
           nacc = chain4_tail<kOpDot>(nacc, x, x, nv);
         }
       }
-      const float n = sqrtf(butterfly_all(nacc));
+      const float nsq = butterfly_all(nacc);
+      const float n = METRIC == kEuclidean ? nsq : sqrtf(nsq);
       if (lane == 0) qn[b] = n;
     }
   }
@@ -374,9 +380,10 @@ _Pragma("unroll") \
     // Loaded unconditionally every step (clamped address, L2 hit): a conditional load would make hipcc wait
     // vmcnt(0) in front of the branch, i.e. for the tile loads just issued.
     float vn_reg = 0.0f;
-    if (METRIC == kCosine) {
+    if (NORMS) {
       const uint32_t row = rt * BM + (uint32_t)(tid & (BM - 1));
       vn_reg = a.norms[row < a.n_rows ? row : a.n_rows - 1];
+      if (METRIC == kEuclidean) vn_reg *= vn_reg;  // |v|^2
     }
 #ifndef VDB_GEMM_ABL_NOMFMA
     {  // ---- multiply k-tile `it` out of LDS ----
@@ -447,7 +454,7 @@ _Pragma("unroll") \
       continue;
     }
 #endif
-    const bool vn_step = METRIC == kCosine && kt + 2 == ga.KT;  // the step before the epilogue step stages the norms
+    const bool vn_step = NORMS && kt + 2 == ga.KT;  // the step before the epilogue step stages the norms
     if (++kt < ga.KT) {
 #ifdef VDB_GEMM_STATS
       {  // drain the matrix pipe first: the timestamp then marks the END of the multiply, not the end of its issue
@@ -479,7 +486,7 @@ _Pragma("unroll") \
 #ifdef VDB_GEMM_STATS
     const long long t_e0 = clock64();
 #endif
-    if (METRIC == kCosine && ga.KT < 2 && tid < BM) vns[tid] = vn_reg;  // single-k-tile rows: no earlier step to do it in
+    if (NORMS && ga.KT < 2 && tid < BM) vns[tid] = vn_reg;  // single-k-tile rows: no earlier step to do it in
     __syncthreads();  // every wave is done reading the tile; norms visible
     if (more) VDB_GEMM_LDS_STORE();  // staging registers are dead from here on: the epilogue gets their 32 VGPRs
 #ifdef VDB_GEMM_STATS
@@ -500,17 +507,25 @@ _Pragma("unroll") \
       for (int t = 0; t < NQF; t++) {
         const uint32_t b = wq * 16 * NQF + t * 16 + (lane & 15);
         const uint64_t tkb = tauk[b];
+        if (METRIC == kEuclidean) {
+          // pass iff |v|^2 + |q|^2 - 2 acc <= tau (+ margin)  <=>  !(acc < 0.5 |v|^2 (1 - 2^-18) + hq), with
+          // hq = 0.5 (|q|^2 (1 - 2^-18) - tau'); the 2^-18 slack covers the rounding of both forms ~10x over
+          const float tf = tkb == kKeyInvalid ? __uint_as_float(0x7F800000u) : key_score<HIB>(tkb);
+          const float tfm = tf + (fabsf(tf) * 3.8146973e-6f + 1e-37f);
+          cutq[t] = b < nq_t ? 0.5f * (qn_t[t] * 0.99999619f - tfm) : __uint_as_float(0x7F800000u);
+        } else {
         const float tf = tkb == kKeyInvalid ? __uint_as_float(0xFF800000u) : key_score<HIB>(tkb);
         const float cut = tf - (fabsf(tf) * 1.9073486e-6f + 1e-37f);
         cutq[t] = b < nq_t ? (METRIC == kCosine ? cut * qn_t[t] : cut) : __uint_as_float(0x7F800000u);
+        }
       }
 #pragma unroll
       for (int rf = 0; rf < RF; rf++) {
         f32x4 rvn = f32x4{1.f, 1.f, 1.f, 1.f};
-        if (METRIC == kCosine) {
+        if (NORMS) {
           const f32x4 vn = *reinterpret_cast<const f32x4*>(vns + wr * WROWS + rf * 16 + 4 * (lane >> 4));
 #pragma unroll
-          for (int r = 0; r < 4; r++) rvn[r] = __builtin_amdgcn_rcpf(vn[r]);
+          for (int r = 0; r < 4; r++) rvn[r] = METRIC == kEuclidean ? vn[r] * 0.49999809f : __builtin_amdgcn_rcpf(vn[r]);
         }
 #pragma unroll
         for (int t = 0; t < NQF; t++) {
@@ -518,7 +533,8 @@ _Pragma("unroll") \
           for (int r = 0; r < 4; r++) {
             constexpr int kHalf = 32;
             const int e = (rf * NQF + t) * 4 + r;
-            const bool pass = !((METRIC == kCosine ? acc[rf][t][r] * rvn[r] : acc[rf][t][r]) < cutq[t]);
+            const bool pass = METRIC == kEuclidean ? !(acc[rf][t][r] < rvn[r] + cutq[t])
+                                                   : !((METRIC == kCosine ? acc[rf][t][r] * rvn[r] : acc[rf][t][r]) < cutq[t]);
             pm[e / kHalf] = (pm[e / kHalf] << 1) | (pass ? 1u : 0u);
           }
         }
@@ -598,7 +614,8 @@ _Pragma("unroll") \
         const uint32_t rl = valid ? ((uint32_t)ent1 >> 8) & 0xFFu : 0u;
         const uint32_t row = rt * BM + rl;
         const float dotv = __uint_as_float((uint32_t)(ent1 >> 32));
-        const float score = finish_score<METRIC>(dotv, qn[b], METRIC == kCosine ? vns[rl] : 1.0f);
+        const float score = METRIC == kEuclidean ? __builtin_fmaf(-2.0f, dotv, qn[b] + vns[rl])  // approximate |q - v|^2
+                                                 : finish_score<METRIC>(dotv, qn[b], METRIC == kCosine ? vns[rl] : 1.0f);
         const uint64_t key = make_key<HIB>(score, row);
         bool take = valid & (b < nq_t) & (row < a.n_rows) & (key < tauk[b]);
         if (take && a.alive) take = a.alive[row] != 0;  // soft-deleted rows are filtered where it is rare
@@ -777,6 +794,13 @@ hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, 
       case 2: return launch_gemm_t<kCosine, 2>(ga, qvec, p.blocks, p.lds, st);
       case 3: return launch_gemm_t<kCosine, 3>(ga, qvec, p.blocks, p.lds, st);
       default: return launch_gemm_t<kCosine, 4>(ga, qvec, p.blocks, p.lds, st);
+    }
+  }
+  if (metric == kEuclidean) {
+    switch (p.nqf) {
+      case 2: return launch_gemm_t<kEuclidean, 2>(ga, qvec, p.blocks, p.lds, st);
+      case 3: return launch_gemm_t<kEuclidean, 3>(ga, qvec, p.blocks, p.lds, st);
+      default: return launch_gemm_t<kEuclidean, 4>(ga, qvec, p.blocks, p.lds, st);
     }
   }
   switch (p.nqf) {

@@ -243,6 +243,13 @@ __device__ __forceinline__ float chain4_tail(float acc, const float4& q, const f
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// a - b on this hardware is a + (-b): a NaN in b comes out with its sign flipped (x86 returns the operand's NaN as it
+// is).  In the IEEE total order that moves a row with a NaN component from the very end of an ascending ranking to its
+// very front.  Scores that went through a subtraction are therefore canonicalised: any NaN -> +qNaN, which is what
+// the reference computes for the standard NaN (f32::NAN, 0x7FC00000).  (A negative NaN in the INPUT keeps its sign on
+// x86 and does not here: documented deviation)
+__device__ __forceinline__ float canon_nan(float x) { return x != x ? __uint_as_float(0x7FC00000u) : x; }
+
 // final score of one (row, query) pair from the canonical sums
 template <int METRIC>
 __device__ __forceinline__ float finish_score(float sum, float qnorm, float vnorm) {
@@ -251,7 +258,8 @@ __device__ __forceinline__ float finish_score(float sum, float qnorm, float vnor
     if (qnorm == 0.0f || vnorm == 0.0f) return 0.0f;
     return sum / (qnorm * vnorm);
   } else if (METRIC == kEuclidean) {
-    return sqrtf(sum);  // simd_avx512.rs:119-121
+    // canonicalised BEFORE the root: hipcc drops an isnan test on sqrtf's result, and the root returns a NaN operand as it is
+    return sqrtf(canon_nan(sum));  // simd_avx512.rs:119-121
   } else {
     return sum;
   }

@@ -33,6 +33,23 @@ struct MergeArgs {
   uint32_t k;
 };
 
+struct EuclidRerankArgs {
+  const float* rows;            // f32 rows of the index
+  const float* queries;
+  const uint64_t* cand_rows;    // [nq][kp] internal rows, best approximate value first (merge_topk output)
+  const float* cand_approx;     // [nq][kp] approximate squared distances
+  const uint32_t* cand_n;       // [nq]
+  const uint64_t* ext_ids;
+  const uint32_t* norm_max_bits;  // device scalar: bits of max |v| over the rows (filled by launch_euclid_rerank)
+  uint64_t* out_ids;            // [nq][k]
+  float* out_scores;            // [nq][k] canonical Euclidean distances
+  uint32_t* out_n;              // [nq]
+  uint32_t* flags;              // [nq] 1 = not proven exact: re-run through the exact sweep
+  uint64_t row_stride, q_stride;
+  uint32_t dim, k, kp;
+};
+constexpr uint32_t kEuclidSlack = 16;  // extra candidates per query kept by the approximate selection
+
 struct BitsArgs {
   const uint32_t* bits;     // [n_rows][words]
   const uint32_t* qbits;    // [nq][words]
@@ -150,6 +167,7 @@ hipError_t launch_sweep_bf16(int metric, int nqt, const uint16_t* rows, uint64_t
                              const uint8_t* alive, const float* queries, uint64_t q_stride, uint64_t* part_keys,
                              uint32_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int blocks, hipStream_t st);
 void launch_merge(bool higher_is_better, const MergeArgs& m, uint32_t nq, hipStream_t st);
+void launch_euclid_rerank(const EuclidRerankArgs& a, const float* norms, uint32_t n_rows, uint32_t nq, hipStream_t st);
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st);
 // B (8 or 32) queries per corpus pass; blocks = row blocks (= partial lists per query), grid.y = ceil(nq / B)
 size_t sweep_bits_batch_lds_bytes(int B, uint32_t words, uint32_t k);
