@@ -20,11 +20,13 @@ from oracle import pyoracle as po  # noqa: E402
 p = argparse.ArgumentParser()
 p.add_argument("--seconds", type=float, default=240)
 p.add_argument("--seed", type=int, default=1)
+p.add_argument("--engine", type=int, default=1, help="0 = vector-ALU kernels for cosine / dot too")
 p.add_argument("--only-it", type=int, default=0, help="replay: generate every case, run only this one (verbose)")
 p.add_argument("--euclid", action="store_true", help="Euclidean only (matrix-core batches + exact re-scoring)")
 p.add_argument("--bits", action="store_true", help="Hamming / Jaccard (packed-bit kernels) instead of cosine / dot")
 a = p.parse_args()
 rng = np.random.default_rng(a.seed)
+va.set_sweep_engine(a.engine)
 DM = va.DistanceMetric
 
 
