@@ -20,12 +20,14 @@ from oracle import pyoracle as po  # noqa: E402
 p = argparse.ArgumentParser()
 p.add_argument("--seconds", type=float, default=240)
 p.add_argument("--seed", type=int, default=1)
+p.add_argument("--big", action="store_true", help="few cases over 100K-400K rows (many row tiles / groups per wave and block)")
 p.add_argument("--engine", type=int, default=1, help="0 = vector-ALU kernels for cosine / dot too")
 p.add_argument("--only-it", type=int, default=0, help="replay: generate every case, run only this one (verbose)")
 p.add_argument("--euclid", action="store_true", help="Euclidean only (matrix-core batches + exact re-scoring)")
 p.add_argument("--bits", action="store_true", help="Hamming / Jaccard (packed-bit kernels) instead of cosine / dot")
 a = p.parse_args()
 rng = np.random.default_rng(a.seed)
+NT = min(64, os.cpu_count() or 8)
 va.set_sweep_engine(a.engine)
 DM = va.DistanceMetric
 
@@ -73,6 +75,12 @@ while time.time() < t_end:
     nq = int(rng.choice([1, 5, 63, 64, 100, 128, 129, 230, 256, 300, 480, 512, 700, 1024, 1100]))
     k = int(rng.choice([1, 3, 10, 16, 17, 32, 48, 64]))
     kind = str(rng.choice(["normal", "dups", "ascending", "small_ints", "zeros_mixed"]))
+    if a.big:
+        n = int(rng.choice([100_000, 250_000, 400_000]))
+        dim = int(rng.choice([64, 256, 512, 768])) if not a.bits else int(rng.choice([64, 256, 768, 1000]))
+        nq = int(rng.choice([1, 8, 24, 40, 64, 130, 300]))
+        k = int(rng.choice([1, 10, 32]))
+        kind = str(rng.choice(["normal", "normal", "dups", "small_ints"]))
     q0 = rng.standard_normal(dim).astype(np.float32)
     rows = make_rows(kind, n, dim, q0)
     Q = rng.standard_normal((nq, dim)).astype(np.float32)
@@ -100,7 +108,7 @@ while time.time() < t_end:
     if a.only_it:
         gi, gs, gc = ix.search_batch_brute_force(Q, k)
         mode = po.MODE_M if ix.sweep_arith_mode(k) == "M" else po.MODE_C
-        eid, esc = po.scan_topk(int(metric), rows, Q, kk, mode, nthreads=8)
+        eid, esc = po.scan_topk(int(metric), rows, Q, kk, mode, nthreads=NT)
         bad = np.nonzero(np.any(gi[:, :kk] != eid, axis=1) | np.any(bits(gs[:, :kk]) != bits(esc), axis=1))[0]
         print(tag, "mode", mode, "bad queries", bad.tolist()[:20], "of", nq)
         for qi in bad[:3]:
@@ -114,7 +122,7 @@ while time.time() < t_end:
         gi, gs, gc = ix.search_batch_brute_force_bf16(Q, k)
         pm = po.COSINE if metric == DM.Cosine else po.DOT
         if kind in ("small_ints",) and metric == DM.DotProduct:
-            eid, esc = po.scan_topk_bf16(pm, rows, Q, kk, nthreads=8)
+            eid, esc = po.scan_topk_bf16(pm, rows, Q, kk, nthreads=NT)
             assert np.array_equal(gi[:, :kk], eid) and np.array_equal(gs[:, :kk], esc), tag
         else:
             # the tolerance check needs separated scores to compare ids; duplicates make every rank a tie group: values only
@@ -138,7 +146,7 @@ while time.time() < t_end:
     else:
         gi, gs, gc = ix.search_batch_brute_force(Q, k)
         mode = po.MODE_M if ix.sweep_arith_mode(k) == "M" else po.MODE_C
-        eid, esc = po.scan_topk(int(metric), rows, Q, kk, mode, nthreads=8)
+        eid, esc = po.scan_topk(int(metric), rows, Q, kk, mode, nthreads=NT)
         assert np.all(gc == kk), tag
         assert np.array_equal(gi[:, :kk], eid), tag
         assert np.array_equal(bits(gs[:, :kk]), bits(esc)), tag
