@@ -19,6 +19,7 @@ from oracle import pyoracle as po  # noqa: E402
 p = argparse.ArgumentParser()
 p.add_argument("--seconds", type=float, default=240)
 p.add_argument("--seed", type=int, default=1)
+p.add_argument("--big", action="store_true", help="graphs of 5K-20K nodes, batched GPU builds, bigger beams")
 a = p.parse_args()
 rng = np.random.default_rng(a.seed)
 DM = va.DistanceMetric
@@ -53,6 +54,13 @@ while time.time() < t_end:
     efc = int(rng.choice([10, 40, 100]))
     kind = str(rng.choice(["normal", "dups", "ints", "sparse"]))
     mb = [None, 1, 7, 64][int(rng.integers(0, 4))]
+    if a.big:
+        n = int(rng.choice([5000, 20000]))
+        d = int(rng.choice([32, 128, 256]))
+        M = int(rng.choice([8, 16]))
+        efc = int(rng.choice([40, 100]))
+        mb = [64, 256, 1024][int(rng.integers(0, 3))]
+        kind = str(rng.choice(["normal", "normal", "dups"]))
     rows = make(kind, n, d, metric)
     tag = f"it={it} {metric.name} n={n} d={d} M={M} efc={efc} {kind} batch={mb}"
     g = po.NativeHnsw(d, PO[metric], M, efc, po.MODE_C)
@@ -71,15 +79,15 @@ while time.time() < t_end:
     for layer in range(g.num_layers):
         for node in range(n):
             assert ix.neighbors(layer, node) == g.neighbors(layer, node), f"{tag} layer {layer} node {node}"
-    nq = int(rng.integers(1, 6))
+    nq = int(rng.integers(1, 6)) if not a.big else 40
     qs = make(kind, nq, d, metric)
     k = int(rng.choice([1, 5, 10, 30]))
-    ef = int(rng.choice([1, 10, 64, 200, 300]))
+    ef = int(rng.choice([1, 10, 64, 200, 300])) if not a.big else int(rng.choice([64, 128, 200, 400]))
     res = ix.search_batch_parallel(qs, k, SQ.Custom(ef))
     for q, r in zip(qs, res):
         oid, od = g.search(q, k, max(ef, k), po.TIE_CANONICAL)
         assert [x[0] for x in r] == oid.tolist(), tag + f" k={k} ef={ef}"
     ix.close()
-    if it % 20 == 0:
+    if it % (20 if not a.big else 2) == 0:
         print(f"[fuzz-hnsw] {it} cases ok", flush=True)
 print(f"[fuzz-hnsw] done: {it} cases, every graph link for link equal to the oracle, traversal ids equal")
