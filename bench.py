@@ -59,6 +59,7 @@ def parse():
     p.add_argument("--no-hnsw", action="store_true")
     p.add_argument("--no-int8", action="store_true", help="skip the dual-precision (int8 traversal) leg")
     p.add_argument("--no-embedding-leg", action="store_true", help="skip the graph leg on embedding-like data")
+    p.add_argument("--no-metrics-leg", action="store_true", help="skip the per-metric table (Euclidean / dot / Hamming / Jaccard sweeps)")
     p.add_argument("--no-bf16-leg", action="store_true", help="skip the bf16 GEMM-distance leg (BASELINE configs[3])")
     p.add_argument("--bf16-rows", type=int, default=10_000_000)
     p.add_argument("--bf16-steps", type=int, default=5)
@@ -673,6 +674,58 @@ def main():
         ix3.close()
         torch.cuda.empty_cache()
 
+    # ---- the exact sweep for the other metrics of the path (N = 1 only): same N x D corpus (Hamming / Jaccard: the
+    # reference's x > 0.5 threshold of it, swept as packed bits), one query per launch and --batch queries per launch
+    metrics_leg = None
+    if world == 1 and not a.no_metrics_leg:
+        metrics_leg = []
+        g.manual_seed(42)
+        base = torch.randn((N, D), generator=g, device=dev, dtype=torch.float32)
+        for mname, mm in (("euclidean", va.DistanceMetric.Euclidean), ("dot", va.DistanceMetric.DotProduct),
+                          ("hamming", va.DistanceMetric.Hamming), ("jaccard", va.DistanceMetric.Jaccard)):
+            if mname == a.metric:
+                continue
+            bits_metric = mname in ("hamming", "jaccard")
+            src = (base > 0.5).float() if bits_metric else base
+            qsrc = (queries[:Q] > 0.5).float() if bits_metric else queries[:Q].contiguous()
+            ixm = va.HnswIndex(D, mm, va.HnswParams(a.M, a.efc, N), device=local)
+            torch.cuda.synchronize()
+            ixm.upload_dev(0, src.data_ptr(), N, stream)
+            torch.cuda.synchronize()
+            row = {"metric": mname}
+            for nq_m, reps in ((1, 20), (Q, 5)):
+                for _ in range(2):
+                    ixm.search_batch_dev(qsrc.data_ptr(), nq_m, K, 0, va.MODE_BRUTE, out_ids.data_ptr(), out_sc.data_ptr(),
+                                         out_n.data_ptr(), stream)
+                torch.cuda.synchronize()
+                va.set_kernel_timing(True)
+                tm = time.perf_counter()
+                for _ in range(reps):
+                    ixm.search_batch_dev(qsrc.data_ptr(), nq_m, K, 0, va.MODE_BRUTE, out_ids.data_ptr(), out_sc.data_ptr(),
+                                         out_n.data_ptr(), stream)
+                torch.cuda.synchronize()
+                mdt = (time.perf_counter() - tm) / reps
+                kms_m, nl_m = ixm.last_kernel_ms()
+                va.set_kernel_timing(False)
+                key = "single_query" if nq_m == 1 else "batch"
+                row[key] = {"queries": nq_m, "ms_per_call": round(mdt * 1e3, 4), "qps": round(nq_m / mdt, 1),
+                            "sweep_kernel_ms": round(kms_m, 4), "launches": nl_m}
+            pass_bytes = N * ((D + 127) // 128 * 16) if bits_metric else N * D * 4
+            sk = row["single_query"]["sweep_kernel_ms"]
+            row["single_query"]["hbm_gbs"] = round(pass_bytes / (sk * 1e-3) / 1e9, 1) if sk > 0 else 0.0
+            row["single_query"]["hbm_frac"] = round(pass_bytes / (sk * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sk > 0 else 0.0
+            row["alg_bytes_per_pass"] = pass_bytes
+            row["note"] = {"euclidean": "batch: candidates on the matrix cores (|v|^2+|q|^2-2q.v), canonical re-scoring, per-query proof of exactness",
+                           "dot": "batch: GEMM-structured matrix-core kernel (as the headline)",
+                           "hamming": "packed bits (x > 0.5), 96 B/row; batch: 32 queries per corpus pass, AND+popcount, lock-free top-k",
+                           "jaccard": "packed bits (x > 0.5), 96 B/row; batch: 32 queries per corpus pass, AND+popcount, lock-free top-k"}[mname]
+            metrics_leg.append(row)
+            ixm.close()
+            del src
+            torch.cuda.empty_cache()
+        del base
+        torch.cuda.empty_cache()
+
     if rank == 0:
         line = {
             "metric": "qps_at_recall10_1Mx768_k10", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
@@ -685,7 +738,7 @@ def main():
                        "parallelism": "replicas x%d (query stream split, no collective)" % world},
             "recall_at_10": recall, "parity_check": check,
             "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "tiles": tiles, "sharded": sharded,
-            "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb, "bf16_gemm": bf16_leg,
+            "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb, "bf16_gemm": bf16_leg, "other_metrics": metrics_leg,
             "device": va.device_name(local),
         }
         print(json.dumps(line))
