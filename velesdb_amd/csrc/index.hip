@@ -357,6 +357,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     VDB_HIP(hipGetLastError());
     return VDB_OK;
   }
+  uint32_t euclid_skip_until = 0;  // Euclidean chunk without proofs: [q0, this) goes through the exact tiles
   for (uint32_t q0 = 0; q0 < nq;) {
     uint32_t B = pick_B(nq - q0);
     const int cpl = sweep_cpl_for_dim(ix->dim);
@@ -371,7 +372,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     // Euclidean batches: approximate selection of k + slack candidates on the matrix cores, canonical re-scoring, proof
     // of exactness per query; the (rare) unproven queries go through the exact vector-ALU sweep below
     if (ix->metric == VDB_EUCLIDEAN && g_sweep_engine == 1 && g_max_tile >= 128 && nq - q0 >= kGemmMinQueries &&
-        k + kEuclidSlack <= kGemmMaxK) {
+        k + kEuclidSlack <= kGemmMaxK && q0 >= euclid_skip_until) {
       const uint32_t nqg = std::min<uint32_t>(nq - q0, kGemmMaxQueries);
       // k <= 10: 16 candidates — the 32-entry candidate buffers then leave room for two blocks per CU; the per-query
       // verdict catches the (rare) query whose near-ties are wider than the slack
@@ -435,6 +436,15 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
         std::vector<uint32_t> flags(nqg);
         VDB_HIP(hipMemcpyAsync(flags.data(), ra.flags, (size_t)nqg * 4, hipMemcpyDeviceToHost, st));
         VDB_HIP(hipStreamSynchronize(st));
+        uint32_t n_flagged = 0;
+        for (uint32_t i = 0; i < nqg; i++) n_flagged += flags[i] ? 1u : 0u;
+        if (n_flagged > nqg / 8) {
+          // tie-heavy data (duplicates, low-cardinality values): most queries lack a proof — the whole chunk goes through
+          // the exact vector-ALU tiles below instead of one sweep per query
+          ix->euclid_fallbacks += nqg;
+          euclid_skip_until = q0 + nqg;
+          continue;
+        }
         for (uint32_t i = 0; i < nqg; i++) {
           if (!flags[i]) continue;
           const int32_t rc1 = brute_dev(ix, d_q + (size_t)(q0 + i) * q_stride, q_stride, 1, k, d_ids + (size_t)(q0 + i) * k,
