@@ -101,6 +101,20 @@ while time.time() < t_end:
         r = ix.search_brute_force(q, k)
         eid, esc = exact(q, k)
         assert [x[0] for x in r] == eid and np.array_equal(bits([x[1] for x in r]), bits(esc)), tag + " brute force"
+    if rng.random() < 0.35:  # HnswIndex::save / ::load round trip (external ids, soft deletes, graph): same answers
+        import shutil
+        import tempfile
+        dd = tempfile.mkdtemp(prefix="vdb_fuzz_")
+        try:
+            ix.save(dd)
+            ix2 = va.HnswIndex.load(dd)
+            assert len(ix2) == len(ix) and ix2.graph_info() == ix.graph_info(), tag + " load"
+            for q in qs:
+                assert ix2.search_with_quality(q, 10, SQ.Custom(80)) == ix.search_with_quality(q, 10, SQ.Custom(80)), tag + " load search"
+                assert ix2.search_brute_force(q, 7) == ix.search_brute_force(q, 7), tag + " load brute"
+            ix2.close()
+        finally:
+            shutil.rmtree(dd, ignore_errors=True)
     res = ix.search_batch_parallel(qs, 10, SQ.Custom(64))
     bi, bs, bc = oix.search_batch(qs, 10, po.Q_CUSTOM, 64, po.TIE_CANONICAL)
     for qi in range(qs.shape[0]):
