@@ -59,6 +59,8 @@ def parse():
     p.add_argument("--no-hnsw", action="store_true")
     p.add_argument("--no-int8", action="store_true", help="skip the dual-precision (int8 traversal) leg")
     p.add_argument("--no-embedding-leg", action="store_true", help="skip the graph leg on embedding-like data")
+    p.add_argument("--dist-single", action="store_true", help="self-test: initialise the RCCL process group and run the "
+                   "range-sharded leg (all_reduce, all_gather_into_tensor, merge) even with one rank")
     p.add_argument("--no-metrics-leg", action="store_true", help="skip the per-metric table (Euclidean / dot / Hamming / Jaccard sweeps)")
     p.add_argument("--no-bf16-leg", action="store_true", help="skip the bf16 GEMM-distance leg (BASELINE configs[3])")
     p.add_argument("--bf16-rows", type=int, default=10_000_000)
@@ -91,8 +93,14 @@ def main():
     assert torch.cuda.is_available() and va.device_count() > 0, "bench.py needs a GPU"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or a.dist_single
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     metric = {"cosine": va.DistanceMetric.Cosine, "euclidean": va.DistanceMetric.Euclidean,
@@ -131,12 +139,12 @@ def main():
                             out_sc.data_ptr(), out_n.data_ptr(), stream)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world > 1:
+        if use_dist:
             t = torch.tensor([x], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
@@ -145,6 +153,12 @@ def main():
     for i in range(a.warmup):
         step(i)
     barrier()
+    if use_dist:  # RCCL's version banner sits in the C stdout buffer of every rank: push it out now, not after the JSON line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
     va.set_kernel_timing(True)
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -295,7 +309,7 @@ def main():
     # Default: every rank treats its copy as a different N-row shard (corpus = world * N rows).  BASELINE configs[4]
     # (50 M rows over 8 GPUs) is `--shard-rows 6250000`: every rank generates its own shard on the device.
     sharded = None
-    if world > 1:
+    if use_dist:
         from velesdb_amd.sharded import merge_shard_topk
         SR = a.shard_rows if a.shard_rows > 0 else N
         ix_sh = ix
@@ -741,9 +755,17 @@ def main():
             "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb, "bf16_gemm": bf16_leg, "other_metrics": metrics_leg,
             "device": va.device_name(local),
         }
-        print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to the C stdout buffer: flush it first so that the JSON line is the LAST line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
