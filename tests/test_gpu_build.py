@@ -255,3 +255,27 @@ def test_vacuum_rebuilds_without_tombstones():
     assert ix.len() == n - 249
     empty = va.HnswIndex(dim, DM.Cosine)
     assert empty.vacuum() == 0 and empty.tombstone_ratio() == 0.0
+
+
+def test_build_with_massive_exact_ties_grows_the_candidate_list():
+    # regression (found by tools/fuzz_index.py): sparse Jaccard data — most pairs sit at distance exactly 1.0, and every
+    # candidate tied with the worst result has to stay in the list unexpanded (the reference's candidates heap is
+    # unbounded, graph.rs:449-510).  The LDS list used to overflow (VDB_ERR_UNSUPPORTED); now the batch is repeated
+    # with twice the room until it fits, and the graph equals the oracle's link for link.
+    rng = np.random.default_rng(45)
+    n, dim, M, efc = 1200, 32, 8, 120
+    rows = (rng.random((n, dim)) > 0.93).astype(np.float32)
+    g = oracle_graph(rows, DM.Jaccard, M, efc)
+    ix = va.HnswIndex(dim, DM.Jaccard, va.HnswParams(M, efc, n))
+    assert ix.insert_batch_sequential([(i, rows[i]) for i in range(n)]) == n
+    assert_same_graph(g, ix, n)
+    gb = oracle_graph(rows, DM.Jaccard, M, efc, max_batch=64)
+    ib = va.HnswIndex(dim, DM.Jaccard, va.HnswParams(M, efc, n))
+    ib.upload(np.arange(n), rows)
+    ib.build_graph(64)
+    assert_same_graph(gb, ib, n)
+    qs = (rng.random((5, dim)) > 0.93).astype(np.float32)
+    res = ix.search_batch_parallel(qs, 10, SQ.Custom(100))
+    for q, r in zip(qs, res):
+        oid, _ = g.search(q, 10, 100, po.TIE_CANONICAL)
+        assert [x[0] for x in r] == oid.tolist()

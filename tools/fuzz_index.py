@@ -60,7 +60,11 @@ while time.time() < t_end:
     ix = va.HnswIndex(d, metric, va.HnswParams(M, efc, n))
     for i in range(n):
         assert oix.insert(int(ids[i]), rows[i])
-    assert ix.insert_batch_sequential([(int(ids[i]), rows[i]) for i in range(n)]) == n
+    try:
+        assert ix.insert_batch_sequential([(int(ids[i]), rows[i]) for i in range(n)]) == n
+    except Exception:
+        print("FAILED BUILD:", tag, flush=True)
+        raise
     # duplicate ids are ignored by both
     assert ix.insert_batch_sequential([(int(ids[0]), rows[-1])]) == 0 and not oix.insert(int(ids[0]), rows[-1])
     live = np.ones(n, bool)

@@ -715,9 +715,9 @@ int32_t graph_insert_rows(vdb_hip_index* ix, uint64_t first, uint64_t n, uint32_
   a.cap = (uint32_t)cap;
   a.nbmax = (std::max(max_stride, ef) + 63) / 64 * 64;
   a.alpha = 1.0f;  // graph.rs:77
-  const size_t lds = insert_lds_bytes(a.cap, a.nbmax, ix->dim, ix->words, ix->metric);
+  size_t lds = insert_lds_bytes(a.cap, a.nbmax, ix->dim, ix->words, ix->metric);
   if (lds > 160 * 1024) return fail(VDB_ERR_UNSUPPORTED, "ef_construction too large for the LDS-resident candidate list");
-  const int per_cu = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / lds));
+  int per_cu = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / lds));
   rc = ensure_traversal_scratch(ix, st);
   if (rc != VDB_OK) return rc;
   const uint64_t vis_words = ix->vis_words;
@@ -769,11 +769,33 @@ int32_t graph_insert_rows(vdb_hip_index* ix, uint64_t first, uint64_t n, uint32_
       a.entry_point = (uint32_t)ix->entry_point;
       const uint32_t nreq = (uint32_t)(b * per_node);
       a.req_cap = nreq;
-      VDB_HIP(hipMemsetAsync(d_req_n, 0, 4, st));
-      VDB_HIP(hipMemsetAsync(keys_in, 0xFF, (size_t)nreq * 8, st));
-      const int slots = (int)std::min<uint64_t>(b, (uint64_t)ix->n_cus * per_cu);
-      e = VDB_DISPATCH_METRIC_CPL(launch_insert_t, ix->metric, ix->dim, a, slots, lds, st);
-      if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("insert launch: ") + hipGetErrorString(e));
+      for (;;) {
+        VDB_HIP(hipMemsetAsync(d_req_n, 0, 8, st));  // request counter + overflow flags
+        VDB_HIP(hipMemsetAsync(keys_in, 0xFF, (size_t)nreq * 8, st));
+        const int slots = (int)std::min<uint64_t>(b, (uint64_t)ix->n_cus * per_cu);
+        e = VDB_DISPATCH_METRIC_CPL(launch_insert_t, ix->metric, ix->dim, a, slots, lds, st);
+        if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("insert launch: ") + hipGetErrorString(e));
+        // The insert kernel only writes the NEW nodes' own lists and the request buffer (back-links are applied by the
+        // link kernel below), so a batch can be repeated.  Candidates tied with the worst result stay in the list
+        // unexpanded (the reference's candidates heap is unbounded, graph.rs:449-510): with very many exact ties
+        // (sparse Jaccard: most pairs at distance 1.0) the list outgrows ef + slack — repeat with twice the room.
+        uint32_t h_batch_over = 0;
+        VDB_HIP(hipMemcpyAsync(&h_batch_over, d_overflow, 4, hipMemcpyDeviceToHost, st));
+        VDB_HIP(hipStreamSynchronize(st));
+        if (!(h_batch_over & 1u)) {
+          if (h_batch_over)
+            return fail(VDB_ERR_UNSUPPORTED, "graph construction: link-request buffer overflow, code " + std::to_string(h_batch_over));
+          break;
+        }
+        const uint64_t ncap = (uint64_t)a.cap * 2;
+        const size_t nlds = insert_lds_bytes((uint32_t)ncap, a.nbmax, ix->dim, ix->words, ix->metric);
+        if (nlds > 160 * 1024)
+          return fail(VDB_ERR_UNSUPPORTED,
+                      "graph construction: candidate list overflow (more exact distance ties than the LDS list can hold)");
+        a.cap = (uint32_t)ncap;
+        lds = nlds;
+        per_cu = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / lds));
+      }
       HnswLinkArgs la{};
       fill_layers(ix, la.layers, nullptr);
       la.n = nreq;
