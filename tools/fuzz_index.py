@@ -24,7 +24,7 @@ rng = np.random.default_rng(a.seed)
 DM, SQ = va.DistanceMetric, va.SearchQuality
 PO = {DM.Cosine: po.COSINE, DM.Euclidean: po.EUCLIDEAN, DM.DotProduct: po.DOT, DM.Hamming: po.HAMMING, DM.Jaccard: po.JACCARD}
 QUAL = [(SQ.Fast, po.Q_FAST, 0), (SQ.Balanced, po.Q_BALANCED, 0), (SQ.Accurate, po.Q_ACCURATE, 0), (SQ.Perfect, po.Q_PERFECT, 0),
-        (SQ.Custom(37), po.Q_CUSTOM, 37), (SQ.Custom(250), po.Q_CUSTOM, 250)]
+        (SQ.Custom(37), po.Q_CUSTOM, 37), (SQ.Custom(250), po.Q_CUSTOM, 250), (SQ.Custom(700), po.Q_CUSTOM, 700)]
 
 
 def bits(x):
@@ -47,8 +47,8 @@ it = 0
 while time.time() < t_end:
     it += 1
     metric = [DM.Cosine, DM.Euclidean, DM.DotProduct, DM.Hamming, DM.Jaccard][int(rng.integers(0, 5))]
-    n = int(rng.choice([3, 60, 100, 101, 400, 1200]))
-    d = int(rng.choice([4, 32, 96, 256]))
+    n = int(rng.choice([3, 60, 100, 101, 400, 1200, 2500]))
+    d = int(rng.choice([4, 32, 96, 256, 768]))
     M = int(rng.choice([4, 8, 16]))
     efc = int(rng.choice([20, 60, 120]))
     kind = str(rng.choice(["normal", "dups", "ints", "sparse"]))
@@ -82,7 +82,7 @@ while time.time() < t_end:
         return ids[sel[ei[0, :kk].astype(np.int64)]].tolist(), es[0, :kk]
     qs = make(kind, int(rng.integers(1, 5)), d, metric)
     for q in qs:
-        k = int(rng.choice([1, 5, 10, 40]))
+        k = int(rng.choice([1, 5, 10, 40, 120, 250]))
         gq, oq, oef = QUAL[int(rng.integers(0, len(QUAL)))]
         r = ix.search_with_quality(q, k, gq)
         if oq == po.Q_PERFECT or len(sel) <= 100:  # search.rs:68-77: the exact path
