@@ -87,6 +87,19 @@ while time.time() < t_end:
     for q, r in zip(qs, res):
         oid, od = g.search(q, k, max(ef, k), po.TIE_CANONICAL)
         assert [x[0] for x in r] == oid.tolist(), tag + f" k={k} ef={ef}"
+    # dual-precision traversal (int8 graph walk + exact f32 re-rank) on the same graph: integer distances, bit-exact
+    if metric in (DM.Cosine, DM.Euclidean, DM.DotProduct) and n >= 2 and rng.random() < 0.5:
+        ix.train_quantizer()
+        sq = po.ScalarQuantizer(rows[:1000])
+        codes = sq.quantize(rows)
+        k8 = int(rng.choice([1, 5, 10, 30]))
+        ef8 = int(rng.choice([8, 64, 200, 300]))
+        r8 = ix.search_batch_int8(qs, k8, ef8)
+        for qi, q in enumerate(qs):
+            oid, od, _, _ = po.dual_search_int8(g, sq, codes, q, k8, ef8, 4, po.TIE_CANONICAL)
+            osc = np.array([po.transform_score(PO[metric], float(x)) for x in od], dtype=np.float32)
+            assert [x[0] for x in r8[qi]] == oid.tolist(), tag + f" int8 k={k8} ef={ef8}"
+            assert np.array_equal(bits([x[1] for x in r8[qi]]), bits(osc)), tag + " int8 scores"
     ix.close()
     if it % (20 if not a.big else 2) == 0:
         print(f"[fuzz-hnsw] {it} cases ok", flush=True)
