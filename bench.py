@@ -733,6 +733,22 @@ def main():
                            "dot": "batch: GEMM-structured matrix-core kernel (as the headline)",
                            "hamming": "packed bits (x > 0.5), 96 B/row; batch: 32 queries per corpus pass, AND+popcount, lock-free top-k",
                            "jaccard": "packed bits (x > 0.5), 96 B/row; batch: 32 queries per corpus pass, AND+popcount, lock-free top-k"}[mname]
+            if not a.no_cpu_baseline:
+                # the reference's exact path for this metric restated on the host cores (mode R: wide16 kernels; Hamming /
+                # Jaccard: the f32-threshold kernels of simd_explicit.rs), one query per thread, bounded sample
+                from oracle import pyoracle as po
+                pm = {"euclidean": po.EUCLIDEAN, "dot": po.DOT, "hamming": po.HAMMING, "jaccard": po.JACCARD}[mname]
+                ncores = os.cpu_count() or 1
+                host_rows = src.cpu().numpy()
+                nq_c = min(ncores, Q)
+                qh = qsrc[:nq_c].cpu().numpy()
+                tc = time.perf_counter()
+                po.scan_topk(pm, host_rows, qh, K, po.MODE_R, nthreads=ncores)
+                cdt = time.perf_counter() - tc
+                row["cpu_baseline"] = {"value": round(nq_c / cdt, 2), "unit": "queries/s", "cores": ncores, "kind": "port",
+                                       "sample": f"oracle mode R exact scan of {N} rows x {nq_c} queries, {ncores} threads, {cdt:.2f} s"}
+                row["gpu_over_cpu_batch"] = round(row["batch"]["qps"] / max(nq_c / cdt, 1e-9), 1)
+                del host_rows
             metrics_leg.append(row)
             ixm.close()
             del src
