@@ -467,7 +467,8 @@ int32_t brute_sq8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, ui
   }
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
   for (uint32_t q0 = 0; q0 < nq;) {
-    int B = nq - q0 >= 4 ? 4 : 1;
+    int B = nq - q0 >= 8 ? 8 : (nq - q0 >= 4 ? 4 : 1);
+    if (B == 8 && sq8_lds_bytes(8, k, ix->dim) > 160 * 1024) B = 4;
     if (B == 4 && sq8_lds_bytes(4, k, ix->dim) > 160 * 1024) B = 1;
     const size_t lds = sq8_lds_bytes(B, k, ix->dim);
     if (lds > 160 * 1024) return fail(VDB_ERR_UNSUPPORTED, "SQ8 search: dim / k too large for the LDS query tile");
@@ -494,7 +495,8 @@ int32_t brute_sq8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, ui
     a.k = k;
     EventPair* ev = next_events(ix);
     if (ev) (void)hipEventRecord(ev->a, st);
-    e = B == 4 ? launch_sq8_m<4>(ix->metric, a, blocks, lds, st) : launch_sq8_m<1>(ix->metric, a, blocks, lds, st);
+    e = B == 8 ? launch_sq8_m<8>(ix->metric, a, blocks, lds, st)
+               : (B == 4 ? launch_sq8_m<4>(ix->metric, a, blocks, lds, st) : launch_sq8_m<1>(ix->metric, a, blocks, lds, st));
     if (ev) (void)hipEventRecord(ev->b, st);
     if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("SQ8 sweep launch: ") + hipGetErrorString(e));
     MergeArgs m{};
