@@ -54,13 +54,13 @@ def parse():
     p.add_argument("--no-tiles", action="store_true", help="skip the per-tile-size table (profiling passes)")
     p.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
-    p.add_argument("--check-queries", type=int, default=2)
+    p.add_argument("--check-queries", type=int, default=64, help="queries of the headline batch compared with the oracle in the run")
     # graph leg (configs[2])
     p.add_argument("--no-hnsw", action="store_true")
     p.add_argument("--no-int8", action="store_true", help="skip the dual-precision (int8 traversal) leg")
     p.add_argument("--no-embedding-leg", action="store_true", help="skip the graph leg on embedding-like data")
-    p.add_argument("--dist-single", action="store_true", help="self-test: initialise the RCCL process group and run the "
-                   "range-sharded leg (all_reduce, all_gather_into_tensor, merge) even with one rank")
+    p.add_argument("--dist-single", action="store_true", help="self-test: initialise torch's RCCL process group even with one rank")
+    p.add_argument("--no-sharded-leg", action="store_true", help="skip the range-sharded leg (profiling passes)")
     p.add_argument("--no-metrics-leg", action="store_true", help="skip the per-metric table (Euclidean / dot / Hamming / Jaccard sweeps)")
     p.add_argument("--no-bf16-leg", action="store_true", help="skip the bf16 GEMM-distance leg (BASELINE configs[3])")
     p.add_argument("--bf16-rows", type=int, default=10_000_000)
@@ -305,57 +305,6 @@ def main():
                "hbm_gbs": round(b1 / (kms * 1e-3) / 1e9, 1) if kms > 0 else 0.0,
                "hbm_frac": round(b1 / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kms > 0 else 0.0}
 
-    # ---- range-sharded mode: per-shard top-k + one RCCL all-gather + merge ----
-    # Default: every rank treats its copy as a different N-row shard (corpus = world * N rows).  BASELINE configs[4]
-    # (50 M rows over 8 GPUs) is `--shard-rows 6250000`: every rank generates its own shard on the device.
-    sharded = None
-    if use_dist:
-        from velesdb_amd.sharded import merge_shard_topk
-        SR = a.shard_rows if a.shard_rows > 0 else N
-        ix_sh = ix
-        ok = 1
-        if SR != N:
-            try:
-                gs = torch.Generator(device=dev)
-                gs.manual_seed(4242 + rank)
-                ix_sh = va.HnswIndex(D, metric, va.HnswParams(a.M, a.efc, SR), device=local)
-                chunk = 1_000_000
-                for base in range(0, SR, chunk):  # bounded staging: 3 GB at a time
-                    n_c = min(chunk, SR - base)
-                    c = torch.randn((n_c, D), generator=gs, device=dev, dtype=torch.float32)
-                    torch.cuda.synchronize()
-                    ix_sh.upload_dev(base, c.data_ptr(), n_c, stream)
-                    del c
-            except Exception as e:  # noqa: BLE001 - a shard that cannot be set up must not hang the collective
-                print(f"[rank {rank}] shard setup failed: {e}", file=sys.stderr)
-                ok = 0
-        t_ok = torch.tensor([ok], device=dev, dtype=torch.int32)
-        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)  # every rank agrees before the first data-path collective
-        if int(t_ok.item()) == 1:
-            def sharded_step(i):
-                off = (i * Q) % (n_query_pool - Q + 1)  # every rank searches the SAME queries against ITS shard
-                ix_sh.search_batch_dev(queries[off:off + Q].data_ptr(), Q, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
-                                       out_sc.data_ptr(), out_n.data_ptr(), stream)
-                # global row id = shard offset + local row; one all-gather of k (id, score) pairs per query, merge
-                return merge_shard_topk(out_ids, out_sc, out_n, rank * SR, K, metric.higher_is_better())
-
-            for i in range(a.warmup):
-                sharded_step(i)
-            barrier()
-            t2 = time.perf_counter()
-            for i in range(a.steps):
-                sharded_step(a.warmup + i)
-            barrier()
-            sdt = max_over_ranks(time.perf_counter() - t2)
-            sharded = {"qps": round(Q * a.steps / sdt, 1), "corpus_rows": world * SR, "rows_per_shard": SR,
-                       "ms_per_step": round(sdt / a.steps * 1e3, 4),
-                       "collective": "all_gather_into_tensor(ids u64, scores f32), %d B/query/GPU" % (K * 12)}
-        else:
-            sharded = {"error": "shard setup failed on at least one rank (see stderr)"}
-        if ix_sh is not ix:
-            ix_sh.close()
-            torch.cuda.empty_cache()
-
     # ---- graph leg (configs[2]): GPU construction + traversal kernel ----
     hnsw = None
     graph_dir = None
@@ -460,17 +409,22 @@ def main():
         om = {"cosine": po.COSINE, "euclidean": po.EUCLIDEAN, "dot": po.DOT}[a.metric]
         ncores = os.cpu_count() or 1
         if host_full is not None:
-            nchk = a.check_queries
-            qh = queries[:nchk].cpu().numpy()
-            gi, gs, gc = ix.search_batch_brute_force(qh, K)
+            # the headline launch itself (Q queries in ONE call = the GEMM kernel, every query tile), of which
+            # `--check-queries` spread over the whole batch are compared with the oracle (ids + score bits)
+            nchk = min(a.check_queries, Q)
+            qall = queries[:Q].cpu().numpy()
+            gi_all, gs_all, _ = ix.search_batch_brute_force(qall, K)
+            sel = np.unique(np.linspace(0, Q - 1, nchk).astype(np.int64))
+            qh, gi, gs = qall[sel], gi_all[sel], gs_all[sel]
             ci, cs = po.scan_topk(om, host_full, qh, K, po.MODE_M if ix.sweep_arith_mode(K) == "M" else po.MODE_C,
                                   nthreads=ncores)
             ri, rs = po.scan_topk(om, host_full, qh, K, po.MODE_R, nthreads=ncores)
-            check = {"queries": nchk, "ids_equal_oracle_canonical": bool(np.array_equal(gi, ci)),
+            check = {"queries": int(sel.size), "of_a_batch_of": Q, "kernel": roofline["kernel"],
+                     "ids_equal_oracle_canonical": bool(np.array_equal(gi, ci)),
                      "scores_bit_equal_oracle_canonical": bool(np.array_equal(gs.view(np.uint32), cs.view(np.uint32))),
                      "ids_equal_reference_order": bool(np.array_equal(gi, ri)),
                      "max_rel_diff_vs_reference_order": float(np.max(np.abs(gs - rs) / np.abs(rs)))}
-            recall = float(np.mean([len(set(gi[i].tolist()) & set(ri[i].tolist())) / K for i in range(nchk)]))
+            recall = float(np.mean([len(set(gi[i].tolist()) & set(ri[i].tolist())) / K for i in range(sel.size)]))
             host_full = None
         if not a.no_cpu_baseline:
             # bounded sample of the SAME workload: every host core, the first `sample_rows` rows (default: all of
@@ -755,6 +709,101 @@ def main():
             torch.cuda.empty_cache()
         del base
         torch.cuda.empty_cache()
+
+    # ---- range-sharded mode (BASELINE configs[4]), every run: per-shard top-k + ONE all-gather of k 12-byte (id, score)
+    # records per query and shard + merge kernel, all behind the C ABI (csrc/shard_group.hip).
+    #   * one process per GPU (torchrun, also the 1-rank default run): every rank's index joins the RCCL group
+    #     (vdb_hip_index_join_group); default: rank r's N rows are shard r of a world*N-row corpus; `--shard-rows
+    #     6250000` at 8 GPUs = configs[4] (50 M rows, every rank generates its own shard on the device).
+    #   * at one GPU additionally: ONE handle over two co-located range shards of the same corpus
+    #     (vdb_hip_index_create(devices=[0, 0], VDB_SHARD_RANGE)): the merged result must equal the unsharded one bit for bit.
+    sharded = None
+    if not a.no_sharded_leg:
+        from velesdb_amd.sharded import join_process_group
+        sharded = {}
+        ref_ids = ref_sc = None
+        if world == 1:
+            step(0)
+            torch.cuda.synchronize()
+            ref_ids, ref_sc = out_ids.cpu().numpy().copy(), out_sc.cpu().numpy().copy()
+            if host_sample is not None and sample_rows == N:
+                gx = va.HnswIndex(D, metric, va.HnswParams(a.M, a.efc, N), devices=[local, local], shard_mode=va.SHARD_RANGE)
+                gx.upload(np.arange(N, dtype=np.uint64), host_sample)
+                off0 = (0 * world + rank) * Q % (n_query_pool - Q + 1)
+
+                def gstep():
+                    gx.search_batch_dev(queries[off0:off0 + Q].data_ptr(), Q, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
+                                        out_sc.data_ptr(), out_n.data_ptr(), stream)
+
+                gstep()
+                torch.cuda.synchronize()
+                same = bool(np.array_equal(out_ids.cpu().numpy(), ref_ids) and
+                            np.array_equal(out_sc.cpu().numpy().view(np.uint32), ref_sc.view(np.uint32)))
+                tg = time.perf_counter()
+                for _ in range(a.steps):
+                    gstep()
+                torch.cuda.synchronize()
+                gdt = (time.perf_counter() - tg) / a.steps
+                sharded["one_handle_two_range_shards"] = {
+                    "qps": round(Q / gdt, 1), "ms_per_step": round(gdt * 1e3, 4), "shards": 2, "rows_per_shard": N // 2,
+                    "transport": gx.shard_info()["transport"], "equals_unsharded_bitwise": same,
+                    "note": "co-located on one GPU: the two shard sweeps run one after the other"}
+                gx.close()
+                torch.cuda.empty_cache()
+        SR = a.shard_rows if a.shard_rows > 0 else N
+        ix_sh = ix
+        ok = 1
+        try:
+            if SR != N or world > 1:  # every rank generates its own shard (ids = global rows rank * SR ...)
+                gs = torch.Generator(device=dev)
+                gs.manual_seed(4242 + rank)
+                ix_sh = va.HnswIndex(D, metric, va.HnswParams(a.M, a.efc, SR), device=local)
+                chunk = 1_000_000
+                for base in range(0, SR, chunk):  # bounded staging: 3 GB at a time
+                    n_c = min(chunk, SR - base)
+                    c = torch.randn((n_c, D), generator=gs, device=dev, dtype=torch.float32)
+                    torch.cuda.synchronize()
+                    ix_sh.upload_dev(rank * SR + base, c.data_ptr(), n_c, stream)
+                    del c
+        except Exception as e:  # noqa: BLE001 - a shard that cannot be set up must not hang the collective
+            print(f"[rank {rank}] shard setup failed: {e}", file=sys.stderr)
+            ok = 0
+        if use_dist:
+            t_ok = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)  # every rank agrees before the first data-path collective
+            ok = int(t_ok.item())
+        if ok == 1:
+            join_process_group(ix_sh, rank, world, dev)
+
+            def sharded_step(i):
+                off = (i * Q) % (n_query_pool - Q + 1)  # every rank searches the SAME queries against ITS shard
+                ix_sh.search_batch_dev(queries[off:off + Q].data_ptr(), Q, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
+                                       out_sc.data_ptr(), out_n.data_ptr(), stream)
+
+            for i in range(a.warmup):
+                sharded_step(i)
+            barrier()
+            t2 = time.perf_counter()
+            for i in range(a.steps):
+                sharded_step(a.warmup + i)
+            barrier()
+            sdt = max_over_ranks(time.perf_counter() - t2)
+            sharded.update({"qps": round(Q * a.steps / sdt, 1), "corpus_rows": world * SR, "rows_per_shard": SR,
+                            "ranks": world, "ms_per_step": round(sdt / a.steps * 1e3, 4),
+                            "transport": ix_sh.shard_info()["transport"],
+                            "collective": "one ncclAllGather of %d B/query/GPU (12-byte (u64 id, f32 score) records) + "
+                                          "merge_shards_topk, inside libvelesdb_hip.so" % (K * 12)})
+            if world == 1 and SR == N and ref_ids is not None:
+                sharded_step(0)
+                torch.cuda.synchronize()
+                sharded["equals_unsharded_bitwise"] = bool(
+                    np.array_equal(out_ids.cpu().numpy(), ref_ids) and
+                    np.array_equal(out_sc.cpu().numpy().view(np.uint32), ref_sc.view(np.uint32)))
+        else:
+            sharded["error"] = "shard setup failed on at least one rank (see stderr)"
+        if ix_sh is not ix:
+            ix_sh.close()
+            torch.cuda.empty_cache()
 
     if rank == 0:
         line = {

@@ -104,13 +104,38 @@ enum vdb_distance_kind {
 int32_t vdb_hip_device_count(int32_t* n);
 int32_t vdb_hip_device_name(int32_t device, char* buf, size_t cap);
 
+/* how a handle spreads over several GPUs of one node */
+enum vdb_shard_mode {
+  VDB_SHARD_REPLICA = 0, /* every device holds every row (and the graph); a query batch is split between the devices,
+                            no collective — the mode of the graph path                                           */
+  VDB_SHARD_RANGE = 1    /* contiguous ranges of the internal rows: row r lives on device min(r / C, n - 1),
+                            C = ceil(max_elements / n); exact searches = per-shard top-k, ONE RCCL all-gather of
+                            k (id, score) records per query and device, merge — BASELINE configs[4]              */
+};
+
 /* ---- lifecycle: HnswIndex::with_params (constructors.rs:117-160) ----
- * M = max_connections, M0 = 2M (native/graph.rs:62); max_elements is a capacity hint
- * (storage grows); `device` is a HIP device ordinal.  row_id_base is added to internal row
- * numbers nowhere visible to the caller; it exists so a range-shard can be created with
- * the same ids as the unsharded index. */
+ * M = max_connections, M0 = 2M (native/graph.rs:62); max_elements is a capacity hint (storage grows; with
+ * VDB_SHARD_RANGE it also fixes the rows per shard).  `devices` = n_devices HIP device ordinals (NULL / 0 = device 0).
+ * One VectorIndex object whatever is behind it (index/mod.rs:30-83): with n_devices > 1 the handle owns one shard per
+ * device and every entry point below works on the whole; results (ids, ranks, score bits, tie order) of the exact
+ * search modes are those of the single-device index over the same rows.  The same device may be named more than once
+ * (co-located shards: the exchange is then a device-to-device copy instead of RCCL — a test configuration).
+ * HNSW modes on a VDB_SHARD_RANGE handle search one graph per shard and merge (recall differs from one big graph). */
 int32_t vdb_hip_index_create(uint32_t dim, int32_t metric, uint32_t M, uint32_t ef_construction,
-                             uint64_t max_elements, int32_t device, vdb_hip_index** out);
+                             uint64_t max_elements, const int32_t* devices, int32_t n_devices, int32_t shard_mode,
+                             vdb_hip_index** out);
+/* One process per GPU (torchrun, MPI): every rank creates its own single-device index = ONE shard of a range-sharded
+ * corpus (rank order = row order) and joins the group with the 128-byte id rank 0 generated and distributed out of
+ * band.  From then on the exact search modes of this handle return the GLOBAL top-k on every rank: local top-k, one
+ * ncclAllGather of nq * k 12-byte (u64 id, f32 score) records per rank, merge kernel.  Collective: every rank must
+ * call search with the same queries, k and mode.  world == 1 is allowed (the collective degenerates). */
+#define VDB_COMM_ID_BYTES 128
+int32_t vdb_hip_comm_unique_id(uint8_t* id /* VDB_COMM_ID_BYTES */);
+int32_t vdb_hip_index_join_group(vdb_hip_index* idx, const uint8_t* id, int32_t rank, int32_t world);
+/* n_shards = devices behind the handle (1 for a plain index), shard_mode as created, rank / world of the process
+ * group (0 / 1 without one), transport of the exchange: 0 none, 1 RCCL, 2 device-to-device copies */
+int32_t vdb_hip_index_shard_info(vdb_hip_index* idx, int32_t* n_shards, int32_t* shard_mode, int32_t* rank,
+                                 int32_t* world, int32_t* transport);
 void vdb_hip_index_destroy(vdb_hip_index* idx);
 
 /* ---- VectorIndex::insert (index/mod.rs:46, trait_impl.rs:10-36) ---- */

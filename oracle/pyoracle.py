@@ -155,6 +155,10 @@ def _declare(L):
     L.vo_scan_topk_bf16.argtypes = [C.c_int, _f32p, C.c_uint64, C.c_uint32, _f32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                     _u64p, _f32p]
     L.vo_cpu_has_avx512f.restype = C.c_int
+    L.vo_merge_shard_records.restype = None
+    L.vo_merge_shard_records.argtypes = [np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS"), C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_int, _u64p, _f32p,
+                                         np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")]
     L.vo_build_info.restype = C.c_char_p
 
 
@@ -723,6 +727,17 @@ def scan_topk_binary(rows, queries, k):
     sc = np.zeros((nq, k), dtype=np.float32)
     lib().vo_scan_topk_binary(rows, rows.shape[0], rows.shape[1], queries, nq, k, ids, sc)
     return ids, sc
+
+
+def merge_shard_records(rec, k, higher_is_better):
+    """rec: uint32 [S][nq][k][3] wire records of the per-shard top-k lists -> (ids [nq,k], scores [nq,k], counts [nq])"""
+    rec = np.ascontiguousarray(rec, dtype=np.uint32)
+    S, nq = rec.shape[0], rec.shape[1]
+    ids = np.zeros((nq, k), dtype=np.uint64)
+    sc = np.zeros((nq, k), dtype=np.float32)
+    cnt = np.zeros(nq, dtype=np.uint32)
+    lib().vo_merge_shard_records(rec.reshape(-1), S, nq, k, 1 if higher_is_better else 0, ids, sc, cnt)
+    return ids, sc, cnt
 
 
 # ---- MmapStorage directory (core/storage/mmap.rs), restated for the upload-source hand-off (SURVEY 8f-4) ----

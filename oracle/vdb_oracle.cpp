@@ -1587,6 +1587,33 @@ void vo_scan_topk(int metric, int mode, const float* rows, uint64_t nrows, uint3
   }
 }
 
+// Range-sharded exact search: merge of per-shard top-k record lists.  The unsharded result is the stable sort of ALL rows
+// by score (core/distance.rs:95-103) in row order; shards are contiguous row ranges and every shard's list is already in
+// that order, so a stable sort of the shard-major concatenation by score alone reproduces it.
+void vo_merge_shard_records(const uint32_t* rec, uint32_t S, uint32_t nq, uint32_t k, int hib, uint64_t* out_ids,
+                            float* out_scores, uint32_t* out_n) {
+  for (uint32_t q = 0; q < nq; q++) {
+    std::vector<std::pair<uint64_t, float>> all;
+    for (uint32_t s = 0; s < S; s++)
+      for (uint32_t p = 0; p < k; p++) {
+        const uint32_t* r = rec + (((size_t)s * nq + q) * k + p) * 3;
+        if (r[0] == 0xFFFFFFFFu && r[1] == 0xFFFFFFFFu && r[2] == 0xFFFFFFFFu) continue;
+        float f;
+        std::memcpy(&f, &r[2], 4);
+        all.emplace_back(((uint64_t)r[1] << 32) | r[0], f);
+      }
+    std::stable_sort(all.begin(), all.end(), [hib](const auto& a, const auto& b) {
+      return hib ? total_cmp(b.second, a.second) < 0 : total_cmp(a.second, b.second) < 0;
+    });
+    const uint32_t n = (uint32_t)std::min<size_t>(all.size(), k);
+    out_n[q] = n;
+    for (uint32_t i = 0; i < k; i++) {
+      out_ids[(size_t)q * k + i] = i < n ? all[i].first : UINT64_MAX;
+      out_scores[(size_t)q * k + i] = i < n ? all[i].second : std::numeric_limits<float>::quiet_NaN();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // DualPrecisionHnsw — native/dual_precision.rs + native/quantization.rs: per-dimension scalar quantiser trained
 // on the first min(1000, n) inserted vectors (quantization.rs:191-233), u8 codes (:236-252, f32::round = half away

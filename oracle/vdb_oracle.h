@@ -200,6 +200,12 @@ void vo_scan_topk_sq8(int metric, const float* rows, uint64_t nrows, uint32_t di
                       uint32_t k, uint32_t nthreads, uint64_t* out_rows, float* out_scores);
 void vo_scan_topk_binary(const float* rows, uint64_t nrows, uint32_t dim, const float* queries, uint32_t nq, uint32_t k,
                          uint64_t* out_rows, float* out_scores);
+/* Range-sharded exact search: merge of per-shard top-k lists = DistanceMetric::sort_results
+ * (core/distance.rs:95-103: stable sort by total_cmp, descending for higher-is-better metrics) over the shard-major
+ * concatenation, cut to k.  rec = [S][nq][k] wire records (id low, id high, score bits; a slot past a shard's count
+ * carries id = ~0 and score bits 0xFFFFFFFF) — the checker of merge_shards_topk (csrc/shard_group.hip). */
+void vo_merge_shard_records(const uint32_t* rec, uint32_t S, uint32_t nq, uint32_t k, int higher_is_better,
+                            uint64_t* out_ids, float* out_scores, uint32_t* out_n);
 const char* vo_build_info(void);
 
 #ifdef __cplusplus

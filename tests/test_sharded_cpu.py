@@ -1,7 +1,9 @@
-"""world_size-2 gloo tests (CPU) of the multi-GPU composition in velesdb_amd/sharded.py: range-sharded exact
-search = per-shard top-k + one all-gather + merge must equal the exact top-k over the whole corpus, ties
-included; replica mode must split a query batch without loss or overlap.  The per-shard top-k (the GPU sweep in
-production) is supplied here by the oracle, so the test exercises exactly the N>1 logic that has no GPU."""
+"""world_size-2 gloo tests (CPU) of the one-process-per-GPU composition: what the launcher side owns
+(velesdb_amd/sharded.py: the wire record of the all-gather, the query split of replica mode) plus the merge rule the HIP
+kernel implements (restated in the oracle, vo_merge_shard_records).  Range-sharded exact search = per-shard top-k + ONE
+all-gather of packed 12-byte records + merge must equal the exact top-k over the whole corpus, ties included.  The
+per-shard top-k (the GPU sweep in production) is supplied here by the oracle and the collective is gloo's, so the test
+exercises exactly the N>1 logic that needs no GPU; tests/test_gpu_sharded.py runs the real thing (RCCL + merge kernel)."""
 import os
 import socket
 
@@ -12,7 +14,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import pyoracle as po
-from velesdb_amd.sharded import merge_shard_topk, query_slice
+from velesdb_amd.sharded import RECORD_DTYPE, pack_records, query_slice
 
 
 def _free_port():
@@ -40,16 +42,22 @@ def _worker(rank, world, port, metric, hib, n, dim, nq, k, seed, out):
         lo, hi = cuts[rank], cuts[rank + 1]
         kk = min(k, hi - lo)
         lid, lsc = po.scan_topk(metric, rows[lo:hi], qs, kk, po.MODE_C)
-        ids = np.zeros((nq, k), dtype=np.int64)
+        ids = np.zeros((nq, k), dtype=np.uint64)
         sc = np.zeros((nq, k), dtype=np.float32)
-        ids[:, :kk] = lid
+        ids[:, :kk] = lid + np.uint64(lo)   # external id = global row
         sc[:, :kk] = lsc
-        cnt = torch.full((nq,), kk, dtype=torch.int32)
-        gi, gs, gc = merge_shard_topk(torch.from_numpy(ids), torch.from_numpy(sc), cnt, lo, k, hib)
+        rec = pack_records(ids, sc, np.full(nq, kk, dtype=np.uint32))
+        assert rec.dtype == RECORD_DTYPE and rec.nbytes == nq * k * 12
+        # ONE all-gather of nq * k * 12 bytes per rank
+        mine = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        allrec = np.stack([g.numpy().view(np.uint32).reshape(nq, k, 3) for g in gathered])
+        gi, gs, gc = po.merge_shard_records(allrec, k, hib)
         eid, esc = po.scan_topk(metric, rows, qs, min(k, n), po.MODE_C)
-        ok = bool(np.array_equal(gi.numpy()[:, :eid.shape[1]].astype(np.uint64), eid)
-                  and np.array_equal(gs.numpy()[:, :esc.shape[1]].view(np.uint32), esc.view(np.uint32))
-                  and int(gc.min()) == min(k, n))
+        ok = bool(np.array_equal(gi[:, :eid.shape[1]], eid)
+                  and np.array_equal(gs[:, :esc.shape[1]].view(np.uint32), esc.view(np.uint32))
+                  and int(gc.min()) == min(k, n) and int(gc.max()) == min(k, n))
         # replica mode: the slices of all ranks tile [0, nq)
         sl = torch.tensor(list(query_slice(nq, rank, world)), dtype=torch.int64)
         allsl = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
@@ -64,8 +72,8 @@ def _worker(rank, world, port, metric, hib, n, dim, nq, k, seed, out):
 @pytest.mark.parametrize("metric,hib,n,dim,k", [
     (po.COSINE, True, 3000, 64, 10),
     (po.EUCLIDEAN, False, 2000, 48, 10),
-    (po.HAMMING, False, 4000, 64, 10),   # ties across shards must come out in global-id order
-    (po.DOT, True, 25, 16, 10),          # second shard smaller than... first shard has 8 rows < k
+    (po.HAMMING, False, 4000, 64, 10),   # ties across shards must come out in global-row order
+    (po.DOT, True, 25, 16, 10),          # the first shard has 8 rows < k
 ])
 def test_range_sharded_topk_world2(metric, hib, n, dim, k):
     world = 2
@@ -74,6 +82,24 @@ def test_range_sharded_topk_world2(metric, hib, n, dim, k):
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, metric, hib, n, dim, 17, k, 1234, out), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def test_merge_rule_ties_and_short_lists():
+    # equal scores: shard order, then position; empty slots skipped; fewer than k records in total
+    def rec(entries, k):
+        ids = np.zeros((1, k), dtype=np.uint64)
+        sc = np.zeros((1, k), dtype=np.float32)
+        for i, (a, b) in enumerate(entries):
+            ids[0, i], sc[0, i] = a, b
+        return pack_records(ids, sc, np.array([len(entries)], dtype=np.uint32)).view(np.uint32).reshape(1, k, 3)
+    k = 4
+    allrec = np.stack([rec([(10, 1.0), (11, 2.0)], k), rec([(20, 1.0), (21, 1.0), (22, 3.0)], k), rec([], k)])
+    ids, sc, cnt = po.merge_shard_records(allrec, k, False)
+    assert ids[0].tolist() == [10, 20, 21, 11] and cnt[0] == 4
+    ids, sc, cnt = po.merge_shard_records(allrec, k, True)
+    assert ids[0].tolist() == [22, 11, 10, 20]
+    ids, sc, cnt = po.merge_shard_records(allrec[[0, 2]], k, False)
+    assert cnt[0] == 2 and ids[0, :2].tolist() == [10, 11] and ids[0, 2] == np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
 def test_query_slice_properties():

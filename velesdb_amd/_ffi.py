@@ -29,7 +29,10 @@ _pi32, _pu32, _pu64, _pf32 = C.POINTER(_i32), C.POINTER(_u32), C.POINTER(_u64), 
 SIGNATURES = {
     "vdb_hip_device_count": (_i32, [_pi32]),
     "vdb_hip_device_name": (_i32, [_i32, C.c_char_p, C.c_size_t]),
-    "vdb_hip_index_create": (_i32, [_u32, _i32, _u32, _u32, _u64, _i32, C.POINTER(_vp)]),
+    "vdb_hip_index_create": (_i32, [_u32, _i32, _u32, _u32, _u64, _pi32, _i32, _i32, C.POINTER(_vp)]),
+    "vdb_hip_comm_unique_id": (_i32, [_vp]),
+    "vdb_hip_index_join_group": (_i32, [_vp, _vp, _i32, _i32]),
+    "vdb_hip_index_shard_info": (_i32, [_vp, _pi32, _pi32, _pi32, _pi32, _pi32]),
     "vdb_hip_index_destroy": (None, [_vp]),
     "vdb_hip_batch_norm": (_i32, [_i32, _vp, _u64, _u32, _vp]),
     "vdb_hip_normalize_rows": (_i32, [_i32, _vp, _u64, _u32]),

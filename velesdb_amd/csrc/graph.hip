@@ -36,17 +36,28 @@ extern "C" {
 
 int32_t vdb_hip_index_graph_info(vdb_hip_index* ix, uint32_t* num_layers, uint32_t* max_layer,
                                  int64_t* entry_point) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) {  // replicas hold identical graphs; a range-sharded handle has one graph per shard
+    if (group_mode(ix) != VDB_SHARD_REPLICA) return fail(VDB_ERR_UNSUPPORTED, "graph_info: one graph per shard on a range-sharded handle");
+    return vdb_hip_index_graph_info(group_shard(ix, 0), num_layers, max_layer, entry_point);
+  }
   std::lock_guard<std::mutex> g(ix->mu);
   if (num_layers) *num_layers = (uint32_t)ix->layers.size();
   if (max_layer) *max_layer = ix->max_layer;
   if (entry_point) *entry_point = ix->graph_valid ? ix->entry_point : -1;
   return VDB_OK;
+  });
 }
 
 int32_t vdb_hip_index_get_neighbors(vdb_hip_index* ix, uint32_t layer, uint64_t node, uint32_t* out, uint32_t cap,
                                     uint32_t* n) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) {
+    if (group_mode(ix) != VDB_SHARD_REPLICA) return fail(VDB_ERR_UNSUPPORTED, "get_neighbors: one graph per shard on a range-sharded handle");
+    return vdb_hip_index_get_neighbors(group_shard(ix, 0), layer, node, out, cap, n);
+  }
   std::lock_guard<std::mutex> g(ix->mu);
   *n = 0;
   if (layer >= ix->layers.size() || node >= ix->n_rows) return VDB_OK;  // layer.rs:33-39: empty
@@ -63,6 +74,7 @@ int32_t vdb_hip_index_get_neighbors(vdb_hip_index* ix, uint32_t layer, uint64_t 
     VDB_HIP(hipStreamSynchronize(ix->stream));
   }
   return VDB_OK;
+  });
 }
 
 // NativeHnsw::file_load — native/backend_adapter.rs:273-381.  The index must be empty; dim must
@@ -70,7 +82,9 @@ int32_t vdb_hip_index_get_neighbors(vdb_hip_index* ix, uint32_t layer, uint64_t 
 // the node ids (the reference keeps its id mappings in a separate bincode file that is out of
 // scope; HnswIndex::load re-associates them, constructors.rs:190-253).
 int32_t vdb_hip_index_load_reference_files(vdb_hip_index* ix, const char* dir, const char* basename) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || !dir || !basename) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  VDB_NO_GROUP(ix, "load_reference_files");
   std::lock_guard<std::mutex> g(ix->mu);
   if (ix->n_rows != 0) return fail(VDB_ERR_STATE, "load_reference_files needs an empty index");
   VDB_HIP(hipSetDevice(ix->device));
@@ -176,11 +190,14 @@ int32_t vdb_hip_index_load_reference_files(vdb_hip_index* ix, const char* dir, c
   ix->graph_valid = true;
   ix->rng_state = 0x5DEECE66D1A4B5B5ull;  // backend_adapter.rs:373
   return VDB_OK;
+  });
 }
 
 // NativeHnsw::file_dump — native/backend_adapter.rs:184-261
 int32_t vdb_hip_index_save_reference_files(vdb_hip_index* ix, const char* dir, const char* basename) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || !dir || !basename) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  VDB_NO_GROUP(ix, "save_reference_files");
   std::lock_guard<std::mutex> g(ix->mu);
   if (!ix->graph_valid) return fail(VDB_ERR_STATE, "graph not built for all rows");
   VDB_HIP(hipSetDevice(ix->device));
@@ -229,6 +246,7 @@ int32_t vdb_hip_index_save_reference_files(vdb_hip_index* ix, const char* dir, c
   }
   std::fclose(f);
   return VDB_OK;
+  });
 }
 
 
@@ -249,7 +267,9 @@ bool get_u64(FILE* f, uint64_t* v) { return std::fread(v, 8, 1, f) == 1; }
 }  // namespace
 
 int32_t vdb_hip_index_save_dir(vdb_hip_index* ix, const char* dir) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || !dir) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  VDB_NO_GROUP(ix, "save_dir");
   int32_t rc = vdb_hip_index_save_reference_files(ix, dir, "native_hnsw");
   if (rc != VDB_OK) return rc;
   std::lock_guard<std::mutex> g(ix->mu);
@@ -272,9 +292,11 @@ int32_t vdb_hip_index_save_dir(vdb_hip_index* ix, const char* dir) {
   ok = put_u64(f, ix->dim) && std::fwrite(&metric, 1, 1, f) == 1 && std::fwrite(&storage, 1, 1, f) == 1;
   std::fclose(f);
   return ok ? VDB_OK : fail(VDB_ERR_IO, "short write to " + tp);
+  });
 }
 
 int32_t vdb_hip_index_load_dir(const char* dir, int32_t device, vdb_hip_index** out) {
+  return vdb::guarded([&]() -> int32_t {
   if (!dir || !out) return fail(VDB_ERR_INVALID_ARG, "null argument");
   *out = nullptr;
   const std::string tp = std::string(dir) + "/native_meta.bin";
@@ -287,7 +309,7 @@ int32_t vdb_hip_index_load_dir(const char* dir, int32_t device, vdb_hip_index** 
   if (!ok || dim == 0 || dim > 0xFFFFFFFFull) return fail(VDB_ERR_IO, "bad " + tp);
   if (metric > 4) return fail(VDB_ERR_IO, "Unknown distance metric");  // constructors.rs:211-216
   vdb_hip_index* ix = nullptr;
-  int32_t rc = vdb_hip_index_create((uint32_t)dim, (int32_t)metric, 16, 200, 1024, device, &ix);  // M / efc: from the graph file
+  int32_t rc = create_single((uint32_t)dim, (int32_t)metric, 16, 200, 1024, device, &ix);  // M / efc: from the graph file
   if (rc != VDB_OK) return rc;
   rc = vdb_hip_index_load_reference_files(ix, dir, "native_hnsw");
   if (rc != VDB_OK) {
@@ -345,6 +367,7 @@ int32_t vdb_hip_index_load_dir(const char* dir, int32_t device, vdb_hip_index** 
   if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("mappings upload: ") + hipGetErrorString(e));  // (index leaked on a device error)
   *out = ix;
   return VDB_OK;
+  });
 }
 
 // ---- MmapStorage directory as an upload source (core/storage/mmap.rs:96-160 open, :402-455 store, :602-626 flush) ----
@@ -355,8 +378,10 @@ int32_t vdb_hip_index_load_dir(const char* dir, int32_t device, vdb_hip_index** 
 // out by a monotonic counter, :434-436; an update rewrites its slot in place), which makes the internal row order —
 // the tie-break of the exact search — a function of the files alone, not of hash-map iteration order.
 int32_t vdb_hip_index_upload_vector_store(vdb_hip_index* ix, const char* dir, uint64_t* inserted) {
+  return vdb::guarded([&]() -> int32_t {
   if (inserted) *inserted = 0;
   if (!ix || !dir) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  VDB_NO_GROUP(ix, "upload_vector_store");
   const std::string ip = std::string(dir) + "/vectors.idx", dp = std::string(dir) + "/vectors.dat";
   FILE* f = std::fopen(ip.c_str(), "rb");
   if (!f) return fail(VDB_ERR_IO, "cannot open " + ip);
@@ -414,6 +439,7 @@ int32_t vdb_hip_index_upload_vector_store(vdb_hip_index* ix, const char* dir, ui
   std::fclose(d);
   if (inserted) *inserted = total;
   return rc;
+  });
 }
 
 }  // extern "C"

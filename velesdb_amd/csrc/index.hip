@@ -613,9 +613,9 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
 static uint32_t balanced_ef(uint32_t k) { return std::max<uint32_t>(128, k * 4); }  // params.rs:313
 
 // dispatch of search_with_quality (search.rs:59-94) for device-resident queries
-static int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k,
-                          uint32_t ef, int32_t mode, uint64_t* d_ids, float* d_scores, uint32_t* d_n,
-                          hipStream_t st, uint32_t cap_mult = 1, bool* used_hnsw = nullptr, uint32_t rerank_k = 0) {
+int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint32_t ef,
+                   int32_t mode, uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st, uint32_t cap_mult,
+                   bool* used_hnsw, uint32_t rerank_k) {
   if (used_hnsw) *used_hnsw = false;
   ix->ev_used = 0;
   if (ix->n_rows == 0) {  // empty index: no entry point => empty result (native/graph.rs:252-255)
@@ -646,54 +646,9 @@ static int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride
   return hnsw_search_dev(ix, d_q, q_stride, nq, k, ef, cap_mult, d_ids, d_scores, d_n, st, rerank_k);
 }
 
-}  // namespace vdb
-
-using namespace vdb;
-
-// =============================================================================================
-extern "C" {
-
-const char* vdb_hip_last_error(void) { return g_last_error.c_str(); }
-const char* vdb_hip_version(void) { return "velesdb-hip 0.1.0 (gfx950)"; }
-
-int32_t vdb_hip_set_max_query_tile(uint32_t b) {
-  if (b != 1 && b != 2 && b != 4 && b != 8 && b != 16 && b != 32 && b != 48 && b != 128)
-    return fail(VDB_ERR_INVALID_ARG, "tile must be 1, 2, 4, 8, 16, 32, 48 or 128");
-  g_max_tile = b;
-  return VDB_OK;
-}
-
-int32_t vdb_hip_set_sweep_engine(int32_t engine) {
-  if (engine != 0 && engine != 1) return fail(VDB_ERR_INVALID_ARG, "engine must be 0 (VALU) or 1 (MFMA)");
-  g_sweep_engine = engine;
-  return VDB_OK;
-}
-
-int32_t vdb_hip_set_kernel_timing(int32_t on) {
-  g_timing = on ? 1 : 0;
-  return VDB_OK;
-}
-
-// GpuAccelerator::new() / is_available() — gpu/gpu_backend.rs:33,136
-int32_t vdb_hip_device_count(int32_t* n) {
-  if (!n) return fail(VDB_ERR_INVALID_ARG, "n is null");
-  int32_t rc = check_device(n);
-  return rc == VDB_ERR_NO_DEVICE ? VDB_OK : rc;  // 0 devices is an answer, not an error
-}
-int32_t vdb_hip_device_name(int32_t device, char* buf, size_t cap) {
-  if (!buf || cap == 0) return fail(VDB_ERR_INVALID_ARG, "buf is null");
-  int32_t rc = check_device(nullptr);
-  if (rc != VDB_OK) return rc;
-  hipDeviceProp_t p;
-  VDB_HIP(hipGetDeviceProperties(&p, device));
-  std::snprintf(buf, cap, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
-  return VDB_OK;
-}
-
-// HnswIndex::with_params — index/hnsw/index/constructors.rs:117-160
-int32_t vdb_hip_index_create(uint32_t dim, int32_t metric, uint32_t M, uint32_t ef_construction,
-                             uint64_t max_elements, int32_t device, vdb_hip_index** out) {
-  if (!out) return fail(VDB_ERR_INVALID_ARG, "out is null");
+// one single-device index: HnswIndex::with_params — index/hnsw/index/constructors.rs:117-160
+int32_t create_single(uint32_t dim, int32_t metric, uint32_t M, uint32_t ef_construction, uint64_t max_elements,
+                      int32_t device, vdb_hip_index** out) {
   *out = nullptr;
   if (dim == 0 || metric < 0 || metric > 4 || M < 2) return fail(VDB_ERR_INVALID_ARG, "bad dim/metric/M");
   int32_t ndev = 0;
@@ -701,7 +656,7 @@ int32_t vdb_hip_index_create(uint32_t dim, int32_t metric, uint32_t M, uint32_t 
   if (rc != VDB_OK) return rc;
   if (device < 0 || device >= ndev) return fail(VDB_ERR_INVALID_ARG, "bad device ordinal");
   VDB_HIP(hipSetDevice(device));
-  std::unique_ptr<vdb_hip_index> ix(new vdb_hip_index());
+  std::unique_ptr<vdb_hip_index, void (*)(vdb_hip_index*)> ix(new vdb_hip_index(), destroy_single);
   ix->device = device;
   hipDeviceProp_t p;
   VDB_HIP(hipGetDeviceProperties(&p, device));
@@ -723,10 +678,11 @@ int32_t vdb_hip_index_create(uint32_t dim, int32_t metric, uint32_t M, uint32_t 
   return VDB_OK;
 }
 
-void vdb_hip_index_destroy(vdb_hip_index* ix) {
+void destroy_single(vdb_hip_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
-  (void)hipStreamSynchronize(ix->stream);
+  if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+  proc_comm_free(ix->pcomm);
   for (DevBuf* b : {&ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids, &ix->rows_bf16, &ix->norms_bf16, &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits, &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq, &ix->s_queries, &ix->s_part_keys,
                     &ix->s_part_cnt, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels,
                     &ix->s_req_keys, &ix->s_req_vals, &ix->s_sort_tmp})
@@ -740,16 +696,174 @@ void vdb_hip_index_destroy(vdb_hip_index* ix) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
-  (void)hipStreamDestroy(ix->stream);
+  if (ix->stream) (void)hipStreamDestroy(ix->stream);
   delete ix;
+}
+
+// direction of the scores a search mode reports (the merge of per-shard results needs it): the metric's own
+// (core/distance.rs:76-82) except the sign-bit scan, which reports Hamming distances whatever the metric
+bool mode_higher_is_better(int metric, int32_t mode) {
+  if (mode == VDB_SEARCH_BRUTE_BINARY) return false;
+  return higher_is_better_host(metric);
+}
+
+// HnswIndex::search_batch_parallel (batch.rs:159-197) / search_with_quality / search_brute_force for host queries;
+// results stay in ix->s_out_* on the device.  queries == nullptr: they already sit in ix->s_queries (row_stride layout).
+int32_t search_to_device(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode,
+                         uint32_t rerank_k, uint32_t* out_n) {
+  hipStream_t st = ix->stream;
+  const size_t kk = std::max<uint32_t>(k, 1);
+  hipError_t e;
+  if ((e = ix->s_queries.reserve((size_t)nq * ix->row_stride * 4, false, st)) != hipSuccess ||
+      (e = ix->s_out_ids.reserve((size_t)nq * kk * 8, false, st)) != hipSuccess ||
+      (e = ix->s_out_scores.reserve((size_t)nq * kk * 4, false, st)) != hipSuccess ||
+      (e = ix->s_out_n.reserve((size_t)nq * 4, false, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("search scratch: ") + hipGetErrorString(e));
+  float* dq = ix->s_queries.as<float>();
+  if (queries) {
+    if (ix->row_stride != ix->dim) VDB_HIP(hipMemsetAsync(dq, 0, (size_t)nq * ix->row_stride * 4, st));
+    VDB_HIP(hipMemcpy2DAsync(dq, ix->row_stride * 4, queries, (size_t)ix->dim * 4, (size_t)ix->dim * 4, nq,
+                             hipMemcpyHostToDevice, st));
+  }
+  // The traversal kernel reports (out_n = 0xFFFFFFFF) a query whose candidate list overflowed its LDS
+  // capacity (only possible with many exact distance ties); such a batch is re-run with more room.
+  for (uint32_t cap_mult = 1;; cap_mult *= 4) {
+    bool used_hnsw = false;
+    int32_t rc = search_dev(ix, dq, ix->row_stride, nq, k, ef, mode, ix->s_out_ids.as<uint64_t>(),
+                            ix->s_out_scores.as<float>(), ix->s_out_n.as<uint32_t>(), st, cap_mult, &used_hnsw,
+                            rerank_k);
+    if (rc != VDB_OK) {
+      (void)hipStreamSynchronize(st);
+      return rc;
+    }
+    VDB_HIP(hipMemcpyAsync(out_n, ix->s_out_n.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    VDB_HIP(hipStreamSynchronize(st));
+    bool overflow = false;
+    if (used_hnsw)
+      for (uint32_t i = 0; i < nq; i++) overflow |= out_n[i] == 0xFFFFFFFFu;
+    if (!overflow) {
+      // rerank over the <=100-vector exact shortcut: at most rerank_k candidates exist (search.rs:124)
+      if (rerank_k && !used_hnsw) {
+        bool cut = false;
+        for (uint32_t i = 0; i < nq; i++) {
+          cut |= out_n[i] > rerank_k;
+          out_n[i] = std::min(out_n[i], rerank_k);
+        }
+        if (cut) VDB_HIP(hipMemcpyAsync(ix->s_out_n.p, out_n, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+      }
+      break;
+    }
+  }
+  return VDB_OK;
+}
+
+}  // namespace vdb
+
+using namespace vdb;
+
+// =============================================================================================
+extern "C" {
+
+const char* vdb_hip_last_error(void) { return g_last_error.c_str(); }
+const char* vdb_hip_version(void) { return "velesdb-hip 0.1.0 (gfx950)"; }
+
+int32_t vdb_hip_set_max_query_tile(uint32_t b) {
+  return vdb::guarded([&]() -> int32_t {
+  if (b != 1 && b != 2 && b != 4 && b != 8 && b != 16 && b != 32 && b != 48 && b != 128)
+    return fail(VDB_ERR_INVALID_ARG, "tile must be 1, 2, 4, 8, 16, 32, 48 or 128");
+  g_max_tile = b;
+  return VDB_OK;
+  });
+}
+
+int32_t vdb_hip_set_sweep_engine(int32_t engine) {
+  return vdb::guarded([&]() -> int32_t {
+  if (engine != 0 && engine != 1) return fail(VDB_ERR_INVALID_ARG, "engine must be 0 (VALU) or 1 (MFMA)");
+  g_sweep_engine = engine;
+  return VDB_OK;
+  });
+}
+
+int32_t vdb_hip_set_kernel_timing(int32_t on) {
+  return vdb::guarded([&]() -> int32_t {
+  g_timing = on ? 1 : 0;
+  return VDB_OK;
+  });
+}
+
+// GpuAccelerator::new() / is_available() — gpu/gpu_backend.rs:33,136
+int32_t vdb_hip_device_count(int32_t* n) {
+  return vdb::guarded([&]() -> int32_t {
+  if (!n) return fail(VDB_ERR_INVALID_ARG, "n is null");
+  int32_t rc = check_device(n);
+  return rc == VDB_ERR_NO_DEVICE ? VDB_OK : rc;  // 0 devices is an answer, not an error
+  });
+}
+int32_t vdb_hip_device_name(int32_t device, char* buf, size_t cap) {
+  return vdb::guarded([&]() -> int32_t {
+  if (!buf || cap == 0) return fail(VDB_ERR_INVALID_ARG, "buf is null");
+  int32_t rc = check_device(nullptr);
+  if (rc != VDB_OK) return rc;
+  hipDeviceProp_t p;
+  VDB_HIP(hipGetDeviceProperties(&p, device));
+  std::snprintf(buf, cap, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  return VDB_OK;
+  });
+}
+
+// HnswIndex::with_params — index/hnsw/index/constructors.rs:117-160
+int32_t vdb_hip_index_create(uint32_t dim, int32_t metric, uint32_t M, uint32_t ef_construction,
+                             uint64_t max_elements, const int32_t* devices, int32_t n_devices, int32_t shard_mode,
+                             vdb_hip_index** out) {
+  return vdb::guarded([&]() -> int32_t {
+  if (!out) return fail(VDB_ERR_INVALID_ARG, "out is null");
+  *out = nullptr;
+  if (n_devices < 0 || n_devices > 64 || (n_devices > 0 && !devices)) return fail(VDB_ERR_INVALID_ARG, "bad device list");
+  if (shard_mode != VDB_SHARD_REPLICA && shard_mode != VDB_SHARD_RANGE) return fail(VDB_ERR_INVALID_ARG, "bad shard mode");
+  const int32_t dev0 = n_devices > 0 ? devices[0] : 0;
+  if (n_devices <= 1) return create_single(dim, metric, M, ef_construction, max_elements, dev0, out);
+  if (dim == 0 || metric < 0 || metric > 4 || M < 2) return fail(VDB_ERR_INVALID_ARG, "bad dim/metric/M");
+  int32_t ndev = 0;
+  int32_t rc = check_device(&ndev);
+  if (rc != VDB_OK) return rc;
+  for (int32_t i = 0; i < n_devices; i++)
+    if (devices[i] < 0 || devices[i] >= ndev) return fail(VDB_ERR_INVALID_ARG, "bad device ordinal");
+  std::unique_ptr<vdb_hip_index, void (*)(vdb_hip_index*)> ix(new vdb_hip_index(), vdb_hip_index_destroy);
+  ix->dim = dim;
+  ix->metric = metric;
+  ix->M = M;
+  ix->M0 = M * 2;
+  ix->efc = ef_construction;
+  ix->row_stride = ((uint64_t)dim + 3) / 4 * 4;
+  rc = group_create(ix.get(), devices, n_devices, shard_mode, max_elements);
+  if (rc != VDB_OK) return rc;
+  *out = ix.release();
+  return VDB_OK;
+  });
+}
+
+void vdb_hip_index_destroy(vdb_hip_index* ix) {
+  if (!ix) return;
+  if (ix->group) {
+    shard_group_free(ix->group);
+    delete ix;
+    return;
+  }
+  destroy_single(ix);
 }
 
 // VectorIndex::insert — index/mod.rs:46; trait_impl.rs:10-36
 int32_t vdb_hip_index_insert(vdb_hip_index* ix, uint64_t id, const float* vec, uint32_t vec_len) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || !vec) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (vec_len != ix->dim)
     return fail(VDB_ERR_DIM_MISMATCH, "Vector dimension mismatch: expected " + std::to_string(ix->dim) + ", got " +
                                           std::to_string(vec_len));
+  if (ix->group) {
+    uint64_t gi = 0;
+    int32_t grc = group_insert(ix, &id, vec, 1, 0, 1, &gi);
+    return grc != VDB_OK ? grc : (gi ? VDB_OK : VDB_DUPLICATE_IGNORED);
+  }
   std::lock_guard<std::mutex> g(ix->mu);
   VDB_HIP(hipSetDevice(ix->device));
   uint64_t ins = 0, first = 0;
@@ -761,12 +875,15 @@ int32_t vdb_hip_index_insert(vdb_hip_index* ix, uint64_t id, const float* vec, u
     if (rc != VDB_OK) return rc;
   }
   return VDB_OK;
+  });
 }
 
 // HnswIndex::insert_batch_sequential — batch.rs:128-149 (deterministic order)
 int32_t vdb_hip_index_insert_batch(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, uint64_t n,
                                    uint64_t* inserted) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) return group_insert(ix, ids, vecs, n, 0, 1, inserted);
   std::lock_guard<std::mutex> g(ix->mu);
   VDB_HIP(hipSetDevice(ix->device));
   uint64_t ins = 0, first = 0;
@@ -775,13 +892,16 @@ int32_t vdb_hip_index_insert_batch(vdb_hip_index* ix, const uint64_t* ids, const
   if (rc != VDB_OK) return rc;
   if (ins && ix->graph_valid) rc = graph_insert_rows(ix, first, ins, 1);
   return rc;
+  });
 }
 
 // HnswIndex::insert_batch_parallel — batch.rs:83-108 (rayon in the reference, non-deterministic there;
 // here batch-synchronous and deterministic, hnsw_build.hip)
 int32_t vdb_hip_index_insert_batch_parallel(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, uint64_t n,
                                             uint32_t max_batch, uint64_t* inserted) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) return group_insert(ix, ids, vecs, n, 1, max_batch, inserted);
   std::lock_guard<std::mutex> g(ix->mu);
   VDB_HIP(hipSetDevice(ix->device));
   uint64_t ins = 0, first = 0;
@@ -790,28 +910,36 @@ int32_t vdb_hip_index_insert_batch_parallel(vdb_hip_index* ix, const uint64_t* i
   if (rc != VDB_OK) return rc;
   if (ins && ix->graph_valid) rc = graph_insert_rows(ix, first, ins, max_batch);
   return rc;
+  });
 }
 
 // ScalarQuantizer::train + quantisation of every row (native/quantization.rs:191-252; DualPrecisionHnsw trains on its
 // first min(1000, max_elements) inserts, dual_precision.rs:95,134-157)
 int32_t vdb_hip_index_train_quantizer(vdb_hip_index* ix, uint32_t sample_rows) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) return group_for_all(ix, 3, sample_rows);
   std::lock_guard<std::mutex> g(ix->mu);
   VDB_HIP(hipSetDevice(ix->device));
   int32_t rc = quantizer_train(ix, sample_rows);
   if (rc == VDB_OK) VDB_HIP(hipStreamSynchronize(ix->stream));
   return rc;
+  });
 }
 int32_t vdb_hip_set_int8_oversampling(uint32_t ratio) {
+  return vdb::guarded([&]() -> int32_t {
   if (ratio == 0 || ratio > 64) return fail(VDB_ERR_INVALID_ARG, "oversampling ratio must be 1..64");
   g_int8_oversampling = ratio;
   return VDB_OK;
+  });
 }
 
 // keeps a bf16 copy of the rows (round to nearest even) for VDB_SEARCH_BRUTE_BF16; existing rows are converted now,
 // later inserts / uploads as they arrive
 int32_t vdb_hip_index_enable_bf16(vdb_hip_index* ix) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) return group_for_all(ix, 1, 0);
   std::lock_guard<std::mutex> g(ix->mu);
   if (ix->bf16_enabled) return VDB_OK;
   if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT)
@@ -831,22 +959,28 @@ int32_t vdb_hip_index_enable_bf16(vdb_hip_index* ix) {
   }
   ix->bf16_rows = ix->n_rows;
   return VDB_OK;
+  });
 }
 
 // links every row that is not in the graph yet (rows that arrived through upload / upload_dev)
 int32_t vdb_hip_index_build_graph(vdb_hip_index* ix, uint32_t max_batch) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) return group_for_all(ix, 0, max_batch);
   std::lock_guard<std::mutex> g(ix->mu);
   VDB_HIP(hipSetDevice(ix->device));
   int32_t rc = VDB_OK;
   if (ix->graph_nodes < ix->n_rows) rc = graph_insert_rows(ix, ix->graph_nodes, ix->n_rows - ix->graph_nodes, max_batch);
   if (rc == VDB_OK) ix->graph_valid = true;
   return rc;
+  });
 }
 
 int32_t vdb_hip_index_upload(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, uint64_t n,
                              uint64_t* inserted) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) return group_insert(ix, ids, vecs, n, 2, 0, inserted);
   std::lock_guard<std::mutex> g(ix->mu);
   VDB_HIP(hipSetDevice(ix->device));
   uint64_t ins = 0, first = 0;
@@ -855,10 +989,13 @@ int32_t vdb_hip_index_upload(vdb_hip_index* ix, const uint64_t* ids, const float
   if (ins) ix->graph_valid = false;
   if (rc == VDB_OK) VDB_HIP(hipStreamSynchronize(ix->stream));
   return rc;
+  });
 }
 
 int32_t vdb_hip_index_upload_dev(vdb_hip_index* ix, uint64_t id_base, const float* d_vecs, uint64_t n, void* stream) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || (n && !d_vecs)) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  VDB_NO_GROUP(ix, "upload_dev (rows resident on one device)");
   std::lock_guard<std::mutex> g(ix->mu);
   VDB_HIP(hipSetDevice(ix->device));
   if (n == 0) return VDB_OK;
@@ -892,11 +1029,14 @@ int32_t vdb_hip_index_upload_dev(vdb_hip_index* ix, uint64_t id_base, const floa
   if (rc != VDB_OK) return rc;
   VDB_HIP(hipStreamSynchronize(ix->stream));
   return VDB_OK;
+  });
 }
 
 // VectorIndex::remove — soft delete (trait_impl.rs:54-58)
 int32_t vdb_hip_index_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) return group_remove(ix, id, removed);
   std::lock_guard<std::mutex> g(ix->mu);
   auto it = ix->id_to_idx.find(id);
   if (it == ix->id_to_idx.end()) {
@@ -913,6 +1053,7 @@ int32_t vdb_hip_index_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed) {
   ix->any_dead = true;
   if (removed) *removed = 1;
   return VDB_OK;
+  });
 }
 
 int32_t vdb_hip_index_len(const vdb_hip_index* ix, uint64_t* n) {  // trait_impl.rs:60-62 mappings.len()
@@ -924,10 +1065,12 @@ int32_t vdb_hip_index_len(const vdb_hip_index* ix, uint64_t* n) {  // trait_impl
 // HnswIndex::tombstone_count (index/hnsw/index/vacuum.rs:45-52): entries removed from the mappings but still in the
 // graph = next_idx - len.  tombstone_ratio / needs_vacuum (:60-76) follow from it and vdb_hip_index_node_count.
 int32_t vdb_hip_index_tombstone_count(const vdb_hip_index* ix, uint64_t* n) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
   std::lock_guard<std::mutex> g(ix->mu);
   *n = ix->n_rows - ix->live;
   return VDB_OK;
+  });
 }
 
 // HnswIndex::vacuum (vacuum.rs:110-184): rebuild the graph over the active vectors only, with HnswParams::auto of the
@@ -936,7 +1079,9 @@ int32_t vdb_hip_index_tombstone_count(const vdb_hip_index* ix, uint64_t* n) {
 // deterministic batch-synchronous construction (vdb_hip_index_insert_batch_parallel).  Quantised / bf16 copies are
 // re-encoded with the rows.
 int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  VDB_NO_GROUP(ix, "vacuum");
   std::lock_guard<std::mutex> g(ix->mu);
   VDB_HIP(hipSetDevice(ix->device));
   const uint64_t n_old = ix->n_rows, n_live = ix->live;
@@ -995,34 +1140,51 @@ int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
   if (rc != VDB_OK) return rc;
   VDB_HIP(hipStreamSynchronize(ix->stream));
   return VDB_OK;
+  });
 }
 
 int32_t vdb_hip_index_node_count(const vdb_hip_index* ix, uint64_t* n) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
   std::lock_guard<std::mutex> g(ix->mu);
   *n = ix->n_rows;
   return VDB_OK;
+  });
 }
 int32_t vdb_hip_index_dimension(const vdb_hip_index* ix, uint32_t* dim) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || !dim) return fail(VDB_ERR_INVALID_ARG, "null argument");
   *dim = ix->dim;
   return VDB_OK;
+  });
 }
 int32_t vdb_hip_index_metric(const vdb_hip_index* ix, int32_t* metric) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || !metric) return fail(VDB_ERR_INVALID_ARG, "null argument");
   *metric = ix->metric;
   return VDB_OK;
+  });
 }
 
 int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* ix, const float* d_queries, uint32_t nq, uint32_t k,
                                        uint32_t ef, int32_t mode, uint64_t* d_out_ids, float* d_out_scores,
                                        uint32_t* d_out_n, void* stream) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || (nq && (!d_queries || !d_out_ids || !d_out_scores || !d_out_n)))
     return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group)
+    return group_search_dev(ix, d_queries, nq, k, ef, mode, d_out_ids, d_out_scores, d_out_n,
+                            reinterpret_cast<hipStream_t>(stream));
   std::lock_guard<std::mutex> g(ix->mu);
   VDB_HIP(hipSetDevice(ix->device));
-  return search_dev(ix, d_queries, ix->dim, nq, k, ef, mode, d_out_ids, d_out_scores, d_out_n,
-                    reinterpret_cast<hipStream_t>(stream));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int32_t rc = search_dev(ix, d_queries, ix->dim, nq, k, ef, mode, d_out_ids, d_out_scores, d_out_n, st);
+  if (rc == VDB_OK && ix->pcomm && nq && k) {
+    const int32_t m = (mode == VDB_SEARCH_AUTO) ? (ix->live <= 100 ? VDB_SEARCH_BRUTE : VDB_SEARCH_HNSW) : mode;
+    rc = pcomm_exchange_merge(ix, nq, k, mode_higher_is_better(ix->metric, m), d_out_ids, d_out_scores, d_out_n, st);
+  }
+  return rc;
+  });
 }
 
 // HnswIndex::search_batch_parallel (batch.rs:159-197) / search_with_quality / search_brute_force
@@ -1032,42 +1194,18 @@ static int32_t search_batch_host(vdb_hip_index* ix, const float* queries, uint32
   if (!ix || (nq && (!queries || !out_n)) || (nq && k && (!out_ids || !out_scores)))
     return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (nq == 0) return VDB_OK;
+  if (ix->group) return group_search_host(ix, queries, nq, k, ef, mode, rerank_k, out_ids, out_scores, out_n);
   std::lock_guard<std::mutex> g(ix->mu);
   VDB_HIP(hipSetDevice(ix->device));
   hipStream_t st = ix->stream;
-  const size_t kk = std::max<uint32_t>(k, 1);
-  hipError_t e;
-  if ((e = ix->s_queries.reserve((size_t)nq * ix->row_stride * 4, false, st)) != hipSuccess ||
-      (e = ix->s_out_ids.reserve((size_t)nq * kk * 8, false, st)) != hipSuccess ||
-      (e = ix->s_out_scores.reserve((size_t)nq * kk * 4, false, st)) != hipSuccess ||
-      (e = ix->s_out_n.reserve((size_t)nq * 4, false, st)) != hipSuccess)
-    return fail(VDB_ERR_OOM, std::string("search scratch: ") + hipGetErrorString(e));
-  float* dq = ix->s_queries.as<float>();
-  if (ix->row_stride != ix->dim) VDB_HIP(hipMemsetAsync(dq, 0, (size_t)nq * ix->row_stride * 4, st));
-  VDB_HIP(hipMemcpy2DAsync(dq, ix->row_stride * 4, queries, (size_t)ix->dim * 4, (size_t)ix->dim * 4, nq,
-                           hipMemcpyHostToDevice, st));
-  // The traversal kernel reports (out_n = 0xFFFFFFFF) a query whose candidate list overflowed its LDS
-  // capacity (only possible with many exact distance ties); such a batch is re-run with more room.
-  for (uint32_t cap_mult = 1;; cap_mult *= 4) {
-    bool used_hnsw = false;
-    int32_t rc = search_dev(ix, dq, ix->row_stride, nq, k, ef, mode, ix->s_out_ids.as<uint64_t>(),
-                            ix->s_out_scores.as<float>(), ix->s_out_n.as<uint32_t>(), st, cap_mult, &used_hnsw,
-                            rerank_k);
-    if (rc != VDB_OK) {
-      (void)hipStreamSynchronize(st);
-      return rc;
-    }
+  int32_t rc = search_to_device(ix, queries, nq, k, ef, mode, rerank_k, out_n);
+  if (rc != VDB_OK) return rc;
+  if (ix->pcomm && k) {  // member of a process group: every rank ends with the global top-k
+    const int32_t m = (mode == VDB_SEARCH_AUTO) ? (ix->live <= 100 ? VDB_SEARCH_BRUTE : VDB_SEARCH_HNSW) : mode;
+    rc = pcomm_exchange_merge(ix, nq, k, mode_higher_is_better(ix->metric, rerank_k ? VDB_SEARCH_BRUTE : m),
+                              ix->s_out_ids.as<uint64_t>(), ix->s_out_scores.as<float>(), ix->s_out_n.as<uint32_t>(), st);
+    if (rc != VDB_OK) return rc;
     VDB_HIP(hipMemcpyAsync(out_n, ix->s_out_n.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    VDB_HIP(hipStreamSynchronize(st));
-    bool overflow = false;
-    if (used_hnsw)
-      for (uint32_t i = 0; i < nq; i++) overflow |= out_n[i] == 0xFFFFFFFFu;
-    if (!overflow) {
-      // rerank over the <=100-vector exact shortcut: at most rerank_k candidates exist (search.rs:124)
-      if (rerank_k && !used_hnsw)
-        for (uint32_t i = 0; i < nq; i++) out_n[i] = std::min(out_n[i], rerank_k);
-      break;
-    }
   }
   if (k) {
     VDB_HIP(hipMemcpyAsync(out_ids, ix->s_out_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
@@ -1079,33 +1217,42 @@ static int32_t search_batch_host(vdb_hip_index* ix, const float* queries, uint32
 
 int32_t vdb_hip_index_search_batch(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef,
                                    int32_t mode, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
+  return vdb::guarded([&]() -> int32_t {
   return search_batch_host(ix, queries, nq, k, ef, mode, 0, out_ids, out_scores, out_n);
+  });
 }
 
 // HnswIndex::search_with_rerank / search_with_rerank_quality — search.rs:118-160,297-350
 int32_t vdb_hip_index_search_rerank(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t rerank_k,
                                     uint32_t ef, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
+  return vdb::guarded([&]() -> int32_t {
   if (rerank_k == 0) return fail(VDB_ERR_INVALID_ARG, "rerank_k must be > 0");
   return search_batch_host(ix, queries, nq, k, ef, VDB_SEARCH_AUTO, rerank_k, out_ids, out_scores, out_n);
+  });
 }
 
 // which summation order the exact sweep uses for this index and k (tests / bench pick the oracle mode by it)
 int32_t vdb_hip_index_sweep_arith_mode(vdb_hip_index* ix, uint32_t k, int32_t* mode) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || !mode) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) return vdb_hip_index_sweep_arith_mode(group_shard(ix, 0), k, mode);
   const bool mfma = g_sweep_engine == 1 && (ix->metric == VDB_COSINE || ix->metric == VDB_DOT) &&
                     sweep_mfma_lds_bytes(1, k, ix->dim) <= 160 * 1024;
   *mode = mfma ? 1 : 0;
   return VDB_OK;
+  });
 }
 
 // VectorIndex::search — index/mod.rs:58; trait_impl.rs:38-42
 int32_t vdb_hip_index_search(vdb_hip_index* ix, const float* query, uint32_t query_len, uint32_t k, uint32_t ef,
                              int32_t mode, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || !query) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (query_len != ix->dim)
     return fail(VDB_ERR_DIM_MISMATCH, "Query dimension mismatch: expected " + std::to_string(ix->dim) + ", got " +
                                           std::to_string(query_len));
   return vdb_hip_index_search_batch(ix, query, 1, k, ef, mode, out_ids, out_scores, out_n);
+  });
 }
 
 // DistanceEngine::batch_distance (native/distance.rs:21-24) /
@@ -1113,6 +1260,7 @@ int32_t vdb_hip_index_search(vdb_hip_index* ix, const float* query, uint32_t que
 // (gpu/gpu_backend.rs:157,355,397)
 int32_t vdb_hip_batch_distance_dev(int32_t metric, int32_t kind, const float* d_query, const float* d_vecs,
                                    uint64_t n, uint32_t dim, float* d_out, void* stream) {
+  return vdb::guarded([&]() -> int32_t {
   if (metric < 0 || metric > 4 || kind < 0 || kind > 2 || (kind == VDB_KIND_SQUARED && metric != VDB_EUCLIDEAN))
     return fail(VDB_ERR_INVALID_ARG, "bad metric/kind");
   if (n == 0 || dim == 0) return VDB_OK;  // gpu_backend.rs:163-169: empty in, empty out
@@ -1128,10 +1276,12 @@ int32_t vdb_hip_batch_distance_dev(int32_t metric, int32_t kind, const float* d_
   launch_score_rows(metric, a, reinterpret_cast<hipStream_t>(stream));
   VDB_HIP(hipGetLastError());
   return VDB_OK;
+  });
 }
 
 int32_t vdb_hip_batch_distance(int32_t device, int32_t metric, int32_t kind, const float* query, const float* vecs,
                                uint64_t n, uint32_t dim, float* out) {
+  return vdb::guarded([&]() -> int32_t {
   if (metric < 0 || metric > 4 || kind < 0 || kind > 2 || (kind == VDB_KIND_SQUARED && metric != VDB_EUCLIDEAN))
     return fail(VDB_ERR_INVALID_ARG, "bad metric/kind");
   int32_t ndev = 0;
@@ -1156,10 +1306,13 @@ int32_t vdb_hip_batch_distance(int32_t device, int32_t metric, int32_t kind, con
   if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? VDB_ERR_OOM : VDB_ERR_HIP,
                                    std::string("batch_distance: ") + hipGetErrorString(e));
   return rc;
+  });
 }
 
 int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* ix, float* ms, uint32_t* launches) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || !ms) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) return vdb_hip_index_last_kernel_ms(group_shard(ix, 0), ms, launches);
   std::lock_guard<std::mutex> g(ix->mu);
   double total = 0.0;
   uint32_t cnt = 0;
@@ -1174,10 +1327,25 @@ int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* ix, float* ms, uint32_t* lau
   *ms = cnt ? (float)(total / cnt) : 0.0f;
   if (launches) *launches = cnt;
   return VDB_OK;
+  });
 }
 
 int32_t vdb_hip_index_last_search_stats(vdb_hip_index* ix, uint64_t* n_dist, uint64_t* n_expand) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) {  // sum over the shards (replicas: each searched its slice of the batch)
+    uint64_t a = 0, b = 0;
+    for (size_t s = 0; s < group_size(ix); s++) {
+      uint64_t x = 0, y = 0;
+      int32_t rc = vdb_hip_index_last_search_stats(group_shard(ix, s), &x, &y);
+      if (rc != VDB_OK) return rc;
+      a += x;
+      b += y;
+    }
+    if (n_dist) *n_dist = a;
+    if (n_expand) *n_expand = b;
+    return VDB_OK;
+  }
   std::lock_guard<std::mutex> g(ix->mu);
   if (ix->stats_pending) {
     unsigned long long h[2] = {0, 0};
@@ -1191,6 +1359,7 @@ int32_t vdb_hip_index_last_search_stats(vdb_hip_index* ix, uint64_t* n_dist, uin
   if (n_dist) *n_dist = ix->last_n_dist;
   if (n_expand) *n_expand = ix->last_n_expand;
   return VDB_OK;
+  });
 }
 
 }  // extern "C"

@@ -571,9 +571,11 @@ extern "C" {
 
 // StorageMode of a collection (quantization.rs:17-29; crud.rs:66-82 encodes every upserted vector accordingly)
 int32_t vdb_hip_index_set_storage_mode(vdb_hip_index* ix, int32_t mode) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (mode != VDB_STORAGE_FULL && mode != VDB_STORAGE_SQ8 && mode != VDB_STORAGE_BINARY)
     return fail(VDB_ERR_INVALID_ARG, "bad storage mode");
+  if (ix->group) return group_for_all(ix, 2, (uint32_t)mode);
   std::lock_guard<std::mutex> g(ix->mu);
   if (ix->storage_mode == mode) return VDB_OK;
   VDB_HIP(hipSetDevice(ix->device));
@@ -587,12 +589,20 @@ int32_t vdb_hip_index_set_storage_mode(vdb_hip_index* ix, int32_t mode) {
   }
   VDB_HIP(hipStreamSynchronize(ix->stream));
   return VDB_OK;
+  });
 }
 
 // The stored code of one vector in the reference's byte format: QuantizedVector::to_bytes (min f32, max f32, dim
 // bytes; quantization.rs:289-295) or BinaryQuantizedVector::to_bytes (dimension u32, ceil(dim/8) bytes; :155-169).
 int32_t vdb_hip_index_get_quantized(vdb_hip_index* ix, uint64_t id, uint8_t* out, size_t cap, size_t* len) {
+  return vdb::guarded([&]() -> int32_t {
   if (!ix || !len) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) {  // every shard that holds the id holds the same code
+    for (size_t s = 0; s < group_size(ix); s++) {
+      int32_t rc = vdb_hip_index_get_quantized(group_shard(ix, s), id, out, cap, len);
+      if (rc == VDB_OK || s + 1 == group_size(ix)) return rc;
+    }
+  }
   std::lock_guard<std::mutex> g(ix->mu);
   if (ix->storage_mode == VDB_STORAGE_FULL) return fail(VDB_ERR_STATE, "storage mode is Full: nothing is quantised");
   auto it = ix->id_to_idx.find(id);
@@ -613,6 +623,7 @@ int32_t vdb_hip_index_get_quantized(vdb_hip_index* ix, uint64_t id, uint8_t* out
   }
   VDB_HIP(hipStreamSynchronize(ix->stream));
   return VDB_OK;
+  });
 }
 
 }  // extern "C"

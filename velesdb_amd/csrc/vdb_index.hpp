@@ -7,7 +7,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -50,6 +53,30 @@ struct GraphLayer {
 struct EventPair {
   hipEvent_t a = nullptr, b = nullptr;
 };
+
+struct ShardGroup;  // shard_group.hip: the children of a multi-device handle
+struct ProcComm;    // shard_group.hip: this process's membership of a one-process-per-GPU shard group (RCCL)
+void shard_group_free(ShardGroup*);
+void proc_comm_free(ProcComm*);
+
+// nothing unwinds across the C ABI: every extern "C" body runs inside guarded()
+template <class F>
+static inline int32_t guarded(F&& f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return fail(VDB_ERR_OOM, "out of host memory");
+  } catch (const std::exception& e) {
+    return fail(VDB_ERR_INVALID_ARG, std::string("internal exception: ") + e.what());
+  } catch (...) {
+    return fail(VDB_ERR_INVALID_ARG, "internal exception");
+  }
+}
+
+#define VDB_NO_GROUP(ix, what)                                                                     \
+  do {                                                                                             \
+    if ((ix)->group) return ::vdb::fail(VDB_ERR_UNSUPPORTED, what ": not available on a multi-device handle"); \
+  } while (0)
 
 }  // namespace vdb
 
@@ -107,10 +134,47 @@ struct vdb_hip_index {
   uint64_t last_n_dist = 0, last_n_expand = 0;
 
   mutable std::mutex mu;
+
+  // multi-device handle (vdb_hip_index_create with n_devices > 1): this object then owns no device memory, only the
+  // id mappings / counters above and the children; every entry point dispatches through the group (shard_group.hip)
+  vdb::ShardGroup* group = nullptr;
+  // one-process-per-GPU shard group joined with vdb_hip_index_join_group: exact searches end with ONE RCCL all-gather
+  // of the per-shard top-k records and the merge kernel
+  vdb::ProcComm* pcomm = nullptr;
 };
 
 namespace vdb {
 // index.hip
+int32_t create_single(uint32_t dim, int32_t metric, uint32_t M, uint32_t ef_construction, uint64_t max_elements,
+                      int32_t device, vdb_hip_index** out);
+void destroy_single(vdb_hip_index* ix);
+// search_with_quality dispatch for device-resident queries (enqueue only; see index.hip)
+int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint32_t ef,
+                   int32_t mode, uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st, uint32_t cap_mult = 1,
+                   bool* used_hnsw = nullptr, uint32_t rerank_k = 0);
+// host queries -> results in ix->s_out_ids / s_out_scores / s_out_n on the device (out_n also on the host); the caller
+// holds ix->mu.  Re-runs HNSW batches whose candidate list overflowed.
+int32_t search_to_device(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode,
+                         uint32_t rerank_k, uint32_t* out_n);
+bool mode_higher_is_better(int metric, int32_t mode);
+// shard_group.hip
+int32_t group_create(vdb_hip_index* parent, const int32_t* devices, int32_t n_devices, int32_t shard_mode,
+                     uint64_t max_elements);
+int32_t group_insert(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, uint64_t n, int kind, uint32_t max_batch,
+                     uint64_t* inserted);  // kind 0 insert_batch, 1 insert_batch_parallel, 2 upload
+int32_t group_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed);
+vdb_hip_index* group_shard(const vdb_hip_index* ix, size_t s);  // child s of a multi-device handle
+size_t group_size(const vdb_hip_index* ix);
+int group_mode(const vdb_hip_index* ix);
+int32_t group_for_all(vdb_hip_index* ix, int op, uint32_t arg);  // op: 0 build_graph, 1 enable_bf16, 2 storage mode, 3 quantizer
+int32_t group_search_host(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode,
+                          uint32_t rerank_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n);
+int32_t group_search_dev(vdb_hip_index* ix, const float* d_q, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode,
+                         uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st);
+// after a local search whose results sit in (d_ids, d_scores, d_n) on `st`: all-gather the per-shard records over the
+// process group and merge them into the same buffers (every rank ends with the global top-k)
+int32_t pcomm_exchange_merge(vdb_hip_index* ix, uint32_t nq, uint32_t k, bool hib, uint64_t* d_ids, float* d_scores,
+                             uint32_t* d_n, hipStream_t st);
 int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want);
 int32_t append_host_rows(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, uint64_t n, uint64_t* inserted,
                          uint64_t* first_row);

@@ -95,6 +95,7 @@ using namespace vdb;
 extern "C" {
 
 int32_t vdb_hip_batch_norm(int32_t device, const float* vecs_rowmajor, uint64_t n, uint32_t dim, float* out) {
+  return vdb::guarded([&]() -> int32_t {
   if (n == 0) return VDB_OK;
   if (!vecs_rowmajor || !out || dim == 0) return fail(VDB_ERR_INVALID_ARG, "null argument");
   int32_t rc = device_ready(device);
@@ -108,9 +109,11 @@ int32_t vdb_hip_batch_norm(int32_t device, const float* vecs_rowmajor, uint64_t 
   VDB_HIP(hipGetLastError());
   VDB_HIP(hipMemcpy(out, d_out.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   return VDB_OK;
+  });
 }
 
 int32_t vdb_hip_normalize_rows(int32_t device, float* vecs_rowmajor, uint64_t n, uint32_t dim) {
+  return vdb::guarded([&]() -> int32_t {
   if (n == 0) return VDB_OK;
   if (!vecs_rowmajor || dim == 0) return fail(VDB_ERR_INVALID_ARG, "null argument");
   int32_t rc = device_ready(device);
@@ -123,6 +126,7 @@ int32_t vdb_hip_normalize_rows(int32_t device, float* vecs_rowmajor, uint64_t n,
   VDB_HIP(hipGetLastError());
   VDB_HIP(hipMemcpy(vecs_rowmajor, d_rows.p, (size_t)n * dim * 4, hipMemcpyDeviceToHost));
   return VDB_OK;
+  });
 }
 
 static int32_t binary_words(int32_t device, const uint64_t* query_words, const uint64_t* rows_words, uint64_t n,
@@ -151,17 +155,22 @@ static int32_t binary_words(int32_t device, const uint64_t* query_words, const u
 
 int32_t vdb_hip_batch_hamming_binary(int32_t device, const uint64_t* query_words, const uint64_t* rows_words, uint64_t n,
                                      uint32_t words, uint32_t* out) {
+  return vdb::guarded([&]() -> int32_t {
   return binary_words(device, query_words, rows_words, n, words, out, nullptr);
+  });
 }
 
 int32_t vdb_hip_batch_jaccard_binary(int32_t device, const uint64_t* query_words, const uint64_t* rows_words, uint64_t n,
                                      uint32_t words, float* out) {
+  return vdb::guarded([&]() -> int32_t {
   return binary_words(device, query_words, rows_words, n, words, nullptr, out);
+  });
 }
 
 // batch_dot_product(queries, vectors) -> out[i * n + j] = dot(queries[i], vectors[j]) (simd_explicit.rs:519-560)
 int32_t vdb_hip_batch_dot_product(int32_t device, const float* queries_rowmajor, uint32_t nq, const float* vecs_rowmajor,
                                   uint64_t n, uint32_t dim, float* out) {
+  return vdb::guarded([&]() -> int32_t {
   if (nq == 0 || n == 0) return VDB_OK;
   if (!queries_rowmajor || !vecs_rowmajor || !out || dim == 0) return fail(VDB_ERR_INVALID_ARG, "null argument");
   int32_t rc = device_ready(device);
@@ -186,6 +195,7 @@ int32_t vdb_hip_batch_dot_product(int32_t device, const float* queries_rowmajor,
   VDB_HIP(hipGetLastError());
   VDB_HIP(hipMemcpy(out, d_out.p, (size_t)nq * n * 4, hipMemcpyDeviceToHost));
   return VDB_OK;
+  });
 }
 
 }  // extern "C"

@@ -22,6 +22,8 @@ from .params import DistanceMetric, HnswParams, SearchQuality
 
 MODE_AUTO, MODE_BRUTE, MODE_HNSW, MODE_BRUTE_BF16, MODE_HNSW_INT8, MODE_BRUTE_SQ8, MODE_BRUTE_BINARY = 0, 1, 2, 3, 4, 5, 6
 KIND_ENGINE, KIND_RAW = 0, 1
+SHARD_REPLICA, SHARD_RANGE = 0, 1
+COMM_ID_BYTES = 128
 
 
 def _f32(a) -> np.ndarray:
@@ -44,6 +46,13 @@ def device_name(device: int = 0) -> str:
     return buf.value.decode()
 
 
+def comm_unique_id() -> bytes:
+    """The 128-byte id of a new one-process-per-GPU shard group (rank 0 makes it, every rank passes it to join_group)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    check(lib().vdb_hip_comm_unique_id(buf))
+    return bytes(buf)
+
+
 def set_kernel_timing(on: bool) -> None:
     check(lib().vdb_hip_set_kernel_timing(1 if on else 0))
 
@@ -62,15 +71,31 @@ class HnswIndex:
     """HNSW index whose vectors, graph and search run on one MI355X."""
 
     def __init__(self, dimension: int, metric: DistanceMetric, params: Optional[HnswParams] = None,
-                 device: int = 0):
-        # HnswIndex::new / with_params — constructors.rs:28-32,117-160
+                 device: int = 0, devices: Optional[Sequence[int]] = None, shard_mode: int = SHARD_REPLICA):
+        # HnswIndex::new / with_params — constructors.rs:28-32,117-160.  `devices` (more than one) = one handle over
+        # several GPUs: SHARD_RANGE (contiguous row ranges, exact searches merged) or SHARD_REPLICA (query stream split)
         self._h = C.c_void_p()
         self._dimension = int(dimension)
         self._metric = DistanceMetric(metric)
         self.params = params or HnswParams.auto(dimension)
+        devs = list(devices) if devices is not None else [int(device)]
+        arr = (C.c_int32 * len(devs))(*devs)
         check(lib().vdb_hip_index_create(dimension, int(self._metric), self.params.max_connections,
-                                         self.params.ef_construction, self.params.max_elements, device,
-                                         C.byref(self._h)))
+                                         self.params.ef_construction, self.params.max_elements, arr, len(devs),
+                                         int(shard_mode), C.byref(self._h)))
+
+    def join_group(self, unique_id: bytes, rank: int, world: int) -> None:
+        """One process per GPU: this index becomes shard `rank` of `world` (rank order = row order); exact searches
+        then return the global top-k on every rank (one RCCL all-gather per batch)."""
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        check(lib().vdb_hip_index_join_group(self._h, buf, rank, world))
+
+    def shard_info(self) -> dict:
+        v = [C.c_int32(0) for _ in range(5)]
+        check(lib().vdb_hip_index_shard_info(self._h, *[C.byref(x) for x in v]))
+        return {"n_shards": v[0].value, "shard_mode": v[1].value, "rank": v[2].value, "world": v[3].value,
+                "transport": {0: "none", 1: "rccl", 2: "d2d-copy"}[v[4].value]}
 
     @classmethod
     def with_params(cls, dimension, metric, params, device=0):
@@ -131,6 +156,7 @@ class HnswIndex:
             f"{what} dimension mismatch: expected {self._dimension}, got {q.shape[-1]}"  # search.rs:16-23
 
     def _search_raw(self, queries: np.ndarray, k: int, ef: int, mode: int):
+        assert queries.ndim == 2 and queries.shape[1] == self._dimension and queries.flags.c_contiguous
         nq = queries.shape[0]
         kk = max(k, 1)
         ids = np.empty((nq, kk), dtype=np.uint64)
@@ -300,10 +326,11 @@ class HnswIndex:
 
     def upload(self, ids, vectors) -> int:
         """Bulk upload without graph construction (exact search only until a graph exists)."""
-        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        ids = np.ascontiguousarray(ids, dtype=np.uint64).reshape(-1)
         vecs = _f32(vectors)
         assert vecs.ndim == 2 and vecs.shape[1] == self._dimension, \
             f"Vector dimension mismatch: expected {self._dimension}, got {vecs.shape[-1]}"
+        assert ids.shape[0] == vecs.shape[0], f"{ids.shape[0]} ids for {vecs.shape[0]} vectors"
         n = C.c_uint64(0)
         check(lib().vdb_hip_index_upload(self._h, _ptr(ids), _ptr(vecs), vecs.shape[0], C.byref(n)))
         return int(n.value)
@@ -454,6 +481,7 @@ class GpuAccelerator:
         q = _f32(query).reshape(-1)
         if dimension == 0 or v.size == 0:
             return np.empty(0, dtype=np.float32)  # gpu_backend.rs:163-169
+        assert q.size == dimension, f"Query dimension mismatch: expected {dimension}, got {q.size}"
         n = v.size // dimension
         if n == 0:
             return np.empty(0, dtype=np.float32)
