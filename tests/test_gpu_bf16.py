@@ -48,7 +48,7 @@ def test_bf16_sweep_matches_half_precision_semantics(metric, pm, n, dim):
     rng = np.random.default_rng(n + dim)
     rows = rng.standard_normal((n, dim)).astype(np.float32)
     ix = va.HnswIndex(dim, metric)
-    ix.upload(np.arange(n), rows[: n // 2])
+    ix.upload(np.arange(n // 2), rows[: n // 2])
     ix.enable_bf16()                       # converts what is there ...
     ix.upload(np.arange(n // 2, n), rows[n // 2:])  # ... and what arrives later
     for nq, k in [(1, 10), (20, 10), (70, 5), (100, 10), (3, 64)]:

@@ -1,0 +1,207 @@
+"""Robustness of the boundary (round-1 advisor findings + the reference's concurrency contract):
+
+  * a failed graph insertion leaves the rows registered and the handle in a state that says so: HNSW modes answer
+    VDB_ERR_STATE (never silently omit rows), exact search keeps working, later inserts append, build_graph reports
+    the cause again instead of "rows must be linked in order";
+  * corrupt native_hnsw.{vectors,graph} files are rejected with VDB_ERR_IO before anything is committed (entry point /
+    max layer out of range, count mismatch, sizes beyond the file), and the index stays usable;
+  * `VectorIndex: Send + Sync` (index/mod.rs:30): concurrent `search` from many threads while another thread inserts
+    (the reference's stress tests, index/hnsw/native/tests.rs:264-416);
+  * device-resident searches enqueued on different streams do not race on the index's scratch.
+"""
+import os
+import struct
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+va = pytest.importorskip("velesdb_amd")
+DM = va.DistanceMetric
+SQ = va.SearchQuality
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_failed_graph_insert_is_visible_in_the_state(gpu_required):
+    rng = np.random.default_rng(1)
+    rows = rng.standard_normal((40, 32)).astype(np.float32)
+    ix = va.HnswIndex(32, DM.Cosine, va.HnswParams(200, 100, 64))  # max_connections > 128: the link kernel refuses
+    with pytest.raises(va.VelesHipError) as e:
+        ix.insert_batch_sequential([(i, rows[i]) for i in range(10)])
+    assert e.value.code == -7
+    assert ix.len() == 10 and ix.node_count() == 10  # the rows ARE registered ...
+    ids, sc, cnt = ix.search_batch_brute_force(rows[:2], 3)  # ... and exact search serves them
+    assert ids[0, 0] == 0 and ids[1, 0] == 1 and np.all(cnt == 3)
+    ix.upload(np.arange(100, 200), np.tile(rows, (3, 1))[:100])  # > 100 vectors: AUTO no longer takes the exact shortcut
+    for mode_call in (lambda: ix.search_batch_parallel(rows[:2], 3, SQ.Fast), lambda: ix.search(rows[0], 3)):
+        with pytest.raises(va.VelesHipError) as e2:  # never VDB_OK with rows missing
+            mode_call()
+        assert e2.value.code == -8
+    ix.insert(999, rows[11])  # appends (exact search sees it); no "rows must be linked in order"
+    assert ix.len() == 111
+    with pytest.raises(va.VelesHipError) as e3:
+        ix.build_graph()
+    assert e3.value.code == -7 and "max_connections" in str(e3.value)
+    ix.close()
+
+
+def _write_files(d, rows, graph_header, layers):
+    n, dim = rows.shape
+    with open(os.path.join(d, "native_hnsw.vectors"), "wb") as f:
+        f.write(struct.pack("<IQI", 1, n, dim))
+        f.write(rows.astype("<f4").tobytes())
+    with open(os.path.join(d, "native_hnsw.graph"), "wb") as f:
+        f.write(struct.pack("<IIIIIQIQ", *graph_header))
+        for lay in layers:
+            f.write(struct.pack("<Q", len(lay)))
+            for nb in lay:
+                f.write(struct.pack("<I", len(nb)))
+                f.write(np.asarray(nb, dtype="<u4").tobytes())
+
+
+def test_corrupt_reference_files_are_rejected_before_commit(gpu_required, tmp_path):
+    rng = np.random.default_rng(2)
+    n, dim, M = 6, 8, 4
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ring = [[(i + 1) % n, (i + n - 1) % n] for i in range(n)]
+    good = (1, 1, M, 2 * M, 50, 0, 0, n)  # version, layers, M, M0, efc, entry point, max layer, count
+    bad_headers = {
+        "entry point >= count": (1, 1, M, 2 * M, 50, n, 0, n),
+        "max layer >= layers": (1, 1, M, 2 * M, 50, 0, 3, n),
+        "count mismatch": (1, 1, M, 2 * M, 50, 0, 0, n + 1),
+        "too many layers": (1, 4000, M, 2 * M, 50, 0, 0, n),
+        "M0 < M": (1, 1, M, 2, 50, 0, 0, n),
+        "version": (2, 1, M, 2 * M, 50, 0, 0, n),
+    }
+    for name, hdr in bad_headers.items():
+        d = tmp_path / name.replace(" ", "_").replace(">", "g").replace("<", "l").replace("=", "e")
+        d.mkdir()
+        _write_files(str(d), rows, hdr, [ring])
+        ix = va.HnswIndex(dim, DM.Euclidean, va.HnswParams(16, 100, 32))
+        with pytest.raises(va.VelesHipError) as e:
+            ix.load_reference_files(str(d))
+        assert e.value.code == -5, name
+        # nothing was committed: the index is empty, keeps ITS parameters, and builds a sound graph afterwards
+        assert ix.len() == 0 and ix.graph_info()[0] == 1
+        for i in range(n):
+            ix.insert(i, rows[i])
+        assert [r[0] for r in ix.search_batch_parallel(rows[:1], 3, SQ.Fast)[0]][0] == 0
+        assert len(ix.neighbors(0, 0)) == n - 1  # layer 0 still has stride M0 = 32: room for all five links
+        ix.close()
+    # sizes beyond the file: a 2^40-vector header in a 200-byte file must not allocate 2^40 * dim floats
+    d = tmp_path / "huge"
+    d.mkdir()
+    _write_files(str(d), rows, good, [ring])
+    raw = bytearray(open(d / "native_hnsw.vectors", "rb").read())
+    raw[4:12] = struct.pack("<Q", 1 << 40)
+    open(d / "native_hnsw.vectors", "wb").write(raw)
+    ix = va.HnswIndex(dim, DM.Euclidean, va.HnswParams(16, 100, 32))
+    with pytest.raises(va.VelesHipError) as e:
+        ix.load_reference_files(str(d))
+    assert e.value.code == -5
+    # a layer that claims 2^50 nodes, a node with more links than the stride, a neighbour id out of range
+    for name, lay in (("nodes", None), ("links", [[1] * 9] + ring[1:]), ("range", [[77]] + ring[1:])):
+        d = tmp_path / ("bad_" + name)
+        d.mkdir()
+        _write_files(str(d), rows, good, [lay if lay is not None else ring])
+        if lay is None:
+            raw = bytearray(open(d / "native_hnsw.graph", "rb").read())
+            raw[40:48] = struct.pack("<Q", 1 << 50)
+            open(d / "native_hnsw.graph", "wb").write(raw)
+        with pytest.raises(va.VelesHipError) as e:
+            ix.load_reference_files(str(d))
+        assert e.value.code == -5, name
+        assert ix.len() == 0
+    # and the intact files load
+    d = tmp_path / "good"
+    d.mkdir()
+    _write_files(str(d), rows, good, [ring])
+    ix.load_reference_files(str(d))
+    assert ix.len() == n and ix.neighbors(0, 2) == [3, 1]
+    ix.close()
+
+
+def test_concurrent_search_and_insert(gpu_required):
+    # Send + Sync: 8 threads search (host entry points; ctypes releases the GIL) while one thread inserts
+    rng = np.random.default_rng(3)
+    n0, n_add, dim, k = 3000, 400, 64, 10
+    rows = rng.standard_normal((n0 + n_add, dim)).astype(np.float32)
+    qs = rng.standard_normal((64, dim)).astype(np.float32)
+    ix = va.HnswIndex(dim, DM.Euclidean, va.HnswParams(8, 60, n0 + n_add))
+    ix.insert_batch_parallel([(i, rows[i]) for i in range(n0)], 512)
+    errors, done = [], threading.Event()
+
+    def searcher(t):
+        try:
+            it = 0
+            while not done.is_set() or it < 3:
+                q = qs[(t * 8 + it) % 56:(t * 8 + it) % 56 + 8]
+                if it % 2:
+                    res = ix.search_batch_parallel(q, k, SQ.Custom(64))
+                    for r in res:
+                        d = [s for _, s in r]
+                        assert len(r) == k and d == sorted(d) and all(0 <= i < n0 + n_add for i, _ in r)
+                else:
+                    ids, sc, cnt = ix.search_batch_brute_force(q, k)
+                    assert np.all(cnt == k) and np.all(np.diff(sc, axis=1) >= 0) and ids.max() < n0 + n_add
+                it += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def inserter():
+        try:
+            for i in range(n0, n0 + n_add):
+                ix.insert(i, rows[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+        finally:
+            done.set()
+
+    th = [threading.Thread(target=searcher, args=(t,)) for t in range(8)] + [threading.Thread(target=inserter)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+    assert ix.len() == n0 + n_add
+    # after the dust settles: exact search equals the oracle over everything that was inserted
+    ids, sc, _ = ix.search_batch_brute_force(qs[:8], k)
+    eid, esc = po.scan_topk(po.EUCLIDEAN, rows, qs[:8], k, po.MODE_C)
+    assert np.array_equal(ids, eid) and np.array_equal(bits(sc), bits(esc))
+    ix.close()
+
+
+def test_device_searches_on_two_streams_do_not_race(gpu_required):
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(4)
+    n, dim, k, nq = 60000, 256, 10, 24
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ix = va.HnswIndex(dim, DM.Cosine, va.HnswParams(8, 60, n))
+    ix.upload(np.arange(n), rows)
+    qa = torch.from_numpy(rng.standard_normal((nq, dim)).astype(np.float32)).cuda()
+    qb = torch.from_numpy(rng.standard_normal((nq, dim)).astype(np.float32)).cuda()
+    ref = [ix.search_batch_brute_force(q.cpu().numpy(), k) for q in (qa, qb)]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [[torch.empty((nq, k), dtype=torch.int64, device="cuda"), torch.empty((nq, k), dtype=torch.float32, device="cuda"),
+             torch.empty((nq,), dtype=torch.int32, device="cuda")] for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(20):  # back to back on alternating streams, no host synchronisation in between
+        for j, (q, st) in enumerate(((qa, s1), (qb, s2))):
+            o = outs[j]
+            ix.search_batch_dev(q.data_ptr(), nq, k, 0, va.MODE_BRUTE, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+                                st.cuda_stream)
+    # a host call right behind them must also wait for the caller streams
+    hid, hsc, _ = ix.search_batch_brute_force(qa.cpu().numpy()[:4], k)
+    torch.cuda.synchronize()
+    for j in range(2):
+        assert np.array_equal(outs[j][0].cpu().numpy().astype(np.uint64), ref[j][0])
+        assert np.array_equal(bits(outs[j][1].cpu().numpy()), bits(ref[j][1]))
+    assert np.array_equal(hid, ref[0][0][:4]) and np.array_equal(bits(hsc), bits(ref[0][1][:4]))
+    ix.close()

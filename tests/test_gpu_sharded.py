@@ -79,7 +79,8 @@ def test_range_handle_equals_oracle_and_single_device(gpu_required, metric, n, d
         assert np.array_equal(bits(g[1][:, :esc.shape[1]]), bits(esc))
         assert np.all(g[2] == min(k, n))
     # soft delete on the handle: gone from the results, like the single-device index (search.rs:86-91)
-    victims = [int(got[0][0, 0]), int(got[0][0, min(k, n) - 1]), int(ids[n - 1])]
+    victims = [int(got[0][0, 0]), int(got[0][0, min(k, n) - 1])]
+    victims.append(int(next(i for i in ids[::-1] if int(i) not in victims)))
     for v in victims:
         assert sh.remove(v) and one.remove(v)
     assert not sh.remove(victims[0])

@@ -61,7 +61,7 @@ int32_t vdb_hip_index_get_neighbors(vdb_hip_index* ix, uint32_t layer, uint64_t 
   std::lock_guard<std::mutex> g(ix->mu);
   *n = 0;
   if (layer >= ix->layers.size() || node >= ix->n_rows) return VDB_OK;  // layer.rs:33-39: empty
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   GraphLayer& L = ix->layers[layer];
   uint32_t c = 0;
   VDB_HIP(hipMemcpyAsync(&c, L.cnt.as<uint32_t>() + node, 4, hipMemcpyDeviceToHost, ix->stream));
@@ -87,82 +87,81 @@ int32_t vdb_hip_index_load_reference_files(vdb_hip_index* ix, const char* dir, c
   VDB_NO_GROUP(ix, "load_reference_files");
   std::lock_guard<std::mutex> g(ix->mu);
   if (ix->n_rows != 0) return fail(VDB_ERR_STATE, "load_reference_files needs an empty index");
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   const std::string vp = std::string(dir) + "/" + basename + ".vectors";
   const std::string gp = std::string(dir) + "/" + basename + ".graph";
-  FILE* f = std::fopen(vp.c_str(), "rb");
-  if (!f) return fail(VDB_ERR_IO, "cannot open " + vp);
+  // Everything is parsed and validated into locals first; the index is only touched once both files are known to be
+  // consistent (a corrupt header must neither size a host buffer beyond the file nor leave a half-loaded index).
+  struct Closer {
+    FILE* f;
+    ~Closer() {
+      if (f) std::fclose(f);
+    }
+  };
+  auto file_size = [](FILE* f) -> uint64_t {
+    const long cur = std::ftell(f);
+    std::fseek(f, 0, SEEK_END);
+    const long end = std::ftell(f);
+    std::fseek(f, cur, SEEK_SET);
+    return end < 0 ? 0 : (uint64_t)end;
+  };
   uint32_t version = 0, dim = 0;
   uint64_t count = 0;
-  bool ok = std::fread(&version, 4, 1, f) == 1 && std::fread(&count, 8, 1, f) == 1 && std::fread(&dim, 4, 1, f) == 1;
-  if (!ok || version != 1) {
-    std::fclose(f);
-    return fail(VDB_ERR_IO, "Unsupported version: " + std::to_string(version));  // backend_adapter.rs:285-290
+  std::vector<float> vecs;
+  {
+    Closer c{std::fopen(vp.c_str(), "rb")};
+    if (!c.f) return fail(VDB_ERR_IO, "cannot open " + vp);
+    bool ok = std::fread(&version, 4, 1, c.f) == 1 && std::fread(&count, 8, 1, c.f) == 1 && std::fread(&dim, 4, 1, c.f) == 1;
+    if (!ok || version != 1)
+      return fail(VDB_ERR_IO, "Unsupported version: " + std::to_string(version));  // backend_adapter.rs:285-290
+    if (count && dim != ix->dim)
+      return fail(VDB_ERR_DIM_MISMATCH, "file dimension " + std::to_string(dim) + " != index dimension " +
+                                            std::to_string(ix->dim));
+    const uint64_t payload = file_size(c.f) - 16;
+    if (count > 0xFFFFFFF0ull || (dim && count > payload / ((uint64_t)dim * 4))) return fail(VDB_ERR_IO, "truncated " + vp);
+    vecs.resize((size_t)count * dim);
+    if (std::fread(vecs.data(), 4, vecs.size(), c.f) != vecs.size()) return fail(VDB_ERR_IO, "truncated " + vp);
   }
-  if (count && dim != ix->dim) {
-    std::fclose(f);
-    return fail(VDB_ERR_DIM_MISMATCH, "file dimension " + std::to_string(dim) + " != index dimension " +
-                                          std::to_string(ix->dim));
-  }
-  std::vector<float> vecs((size_t)count * dim);
-  ok = std::fread(vecs.data(), 4, vecs.size(), f) == vecs.size();
-  std::fclose(f);
-  if (!ok) return fail(VDB_ERR_IO, "truncated " + vp);
-  f = std::fopen(gp.c_str(), "rb");
-  if (!f) return fail(VDB_ERR_IO, "cannot open " + gp);
   uint32_t num_layers = 0, M = 0, M0 = 0, efc = 0, max_layer = 0;
   uint64_t ep = 0, count2 = 0;
-  ok = std::fread(&version, 4, 1, f) == 1 && version == 1 && std::fread(&num_layers, 4, 1, f) == 1 &&
-       std::fread(&M, 4, 1, f) == 1 && std::fread(&M0, 4, 1, f) == 1 && std::fread(&efc, 4, 1, f) == 1 &&
-       std::fread(&ep, 8, 1, f) == 1 && std::fread(&max_layer, 4, 1, f) == 1 && std::fread(&count2, 8, 1, f) == 1;
-  if (!ok || num_layers == 0 || num_layers > 64 || M < 1) {
-    std::fclose(f);
-    return fail(VDB_ERR_IO, "bad graph header in " + gp);
-  }
-  // adopt the file's parameters (backend_adapter.rs:368-379)
-  ix->M = M;
-  ix->M0 = M0;
-  ix->efc = efc;
-  for (auto& L : ix->layers) {
-    L.nbr.release();
-    L.cnt.release();
-    L.ndist.release();
-  }
-  ix->layers.clear();
-  ix->ndist_valid = false;  // the files carry no distances; recomputed before the first insert
-  std::vector<std::vector<uint32_t>> h_nbr(num_layers), h_cnt(num_layers);
-  for (uint32_t l = 0; l < num_layers && ok; l++) {
-    const uint32_t stride = l == 0 ? M0 : M;
-    uint64_t nn = 0;
-    ok = std::fread(&nn, 8, 1, f) == 1;
-    if (!ok) break;
-    h_nbr[l].assign((size_t)count * stride, 0);
-    h_cnt[l].assign((size_t)count, 0);
+  std::vector<std::vector<uint32_t>> h_nbr, h_cnt;
+  {
+    Closer c{std::fopen(gp.c_str(), "rb")};
+    if (!c.f) return fail(VDB_ERR_IO, "cannot open " + gp);
+    bool ok = std::fread(&version, 4, 1, c.f) == 1 && version == 1 && std::fread(&num_layers, 4, 1, c.f) == 1 &&
+              std::fread(&M, 4, 1, c.f) == 1 && std::fread(&M0, 4, 1, c.f) == 1 && std::fread(&efc, 4, 1, c.f) == 1 &&
+              std::fread(&ep, 8, 1, c.f) == 1 && std::fread(&max_layer, 4, 1, c.f) == 1 && std::fread(&count2, 8, 1, c.f) == 1;
+    // the traversal and construction kernels index rows[entry_point] and layers[max_layer] without further checks
+    if (!ok || num_layers == 0 || num_layers > (uint32_t)kMaxLayers || M < 2 || M > 4096 || M0 < M || M0 > 8192 ||
+        max_layer >= num_layers || count2 != count || (count && ep >= count))
+      return fail(VDB_ERR_IO, "bad graph header in " + gp);
+    const uint64_t fsz = file_size(c.f);
+    h_nbr.resize(num_layers);
+    h_cnt.resize(num_layers);
     std::vector<uint32_t> tmp;
-    for (uint64_t i = 0; i < nn && ok; i++) {
-      uint32_t kk = 0;
-      ok = std::fread(&kk, 4, 1, f) == 1;
-      tmp.resize(kk);
-      if (ok && kk) ok = std::fread(tmp.data(), 4, kk, f) == kk;
-      if (!ok) break;
-      if (i >= count) continue;
-      if (kk > stride) {
-        std::fclose(f);
-        return fail(VDB_ERR_IO, "node with more neighbours than the layer's max_connections");
-      }
-      for (uint32_t j = 0; j < kk; j++) {
-        if (tmp[j] >= count) {
-          std::fclose(f);
-          return fail(VDB_ERR_IO, "neighbour id out of range");
+    for (uint32_t l = 0; l < num_layers; l++) {
+      const uint32_t stride = l == 0 ? M0 : M;
+      uint64_t nn = 0;
+      if (std::fread(&nn, 8, 1, c.f) != 1) return fail(VDB_ERR_IO, "truncated " + gp);
+      if (nn > fsz / 4) return fail(VDB_ERR_IO, "bad layer size in " + gp);  // every node costs >= 4 bytes
+      h_nbr[l].assign((size_t)count * stride, 0);
+      h_cnt[l].assign((size_t)count, 0);
+      for (uint64_t i = 0; i < nn; i++) {
+        uint32_t kk = 0;
+        if (std::fread(&kk, 4, 1, c.f) != 1) return fail(VDB_ERR_IO, "truncated " + gp);
+        if (kk > stride) return fail(VDB_ERR_IO, "node with more neighbours than the layer's max_connections");
+        tmp.resize(kk);
+        if (kk && std::fread(tmp.data(), 4, kk, c.f) != kk) return fail(VDB_ERR_IO, "truncated " + gp);
+        if (i >= count) continue;
+        for (uint32_t j = 0; j < kk; j++) {
+          if (tmp[j] >= count) return fail(VDB_ERR_IO, "neighbour id out of range");
+          h_nbr[l][(size_t)i * stride + j] = tmp[j];
         }
-        h_nbr[l][(size_t)i * stride + j] = tmp[j];
+        h_cnt[l][i] = kk;
       }
-      h_cnt[l][i] = kk;
     }
   }
-  std::fclose(f);
-  if (!ok) return fail(VDB_ERR_IO, "truncated " + gp);
-  // vectors + ids
+  // ---- commit: vectors + ids, then the layers (adopting the file's parameters, backend_adapter.rs:368-379) ----
   std::vector<uint64_t> ids(count);
   for (uint64_t i = 0; i < count; i++) ids[i] = i;
   int32_t rc = ensure_capacity(ix, std::max<uint64_t>(count, 1));
@@ -170,6 +169,13 @@ int32_t vdb_hip_index_load_reference_files(vdb_hip_index* ix, const char* dir, c
   uint64_t ins = 0, first = 0;
   rc = append_host_rows(ix, ids.data(), vecs.data(), count, &ins, &first);
   if (rc != VDB_OK) return rc;
+  std::vector<GraphLayer> layers;
+  auto drop = [&]() {
+    for (auto& L : layers) {
+      L.nbr.release();
+      L.cnt.release();
+    }
+  };
   for (uint32_t l = 0; l < num_layers; l++) {
     GraphLayer L;
     L.stride = l == 0 ? M0 : M;
@@ -181,9 +187,23 @@ int32_t vdb_hip_index_load_reference_files(vdb_hip_index* ix, const char* dir, c
     if (e == hipSuccess && count)
       e = hipMemcpyAsync(L.cnt.p, h_cnt[l].data(), h_cnt[l].size() * 4, hipMemcpyHostToDevice, ix->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
-    if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("graph upload: ") + hipGetErrorString(e));
-    ix->layers.push_back(L);
+    layers.push_back(L);
+    if (e != hipSuccess) {
+      drop();
+      ix->graph_valid = false;  // the rows are in; the graph is not
+      return fail(e == hipErrorOutOfMemory ? VDB_ERR_OOM : VDB_ERR_HIP, std::string("graph upload: ") + hipGetErrorString(e));
+    }
   }
+  for (auto& L : ix->layers) {
+    L.nbr.release();
+    L.cnt.release();
+    L.ndist.release();
+  }
+  ix->layers = std::move(layers);
+  ix->M = M;
+  ix->M0 = M0;
+  ix->efc = efc;
+  ix->ndist_valid = false;  // the files carry no distances; recomputed before the first insert
   ix->entry_point = count ? (int64_t)ep : -1;
   ix->max_layer = max_layer;
   ix->graph_nodes = count;
@@ -200,7 +220,7 @@ int32_t vdb_hip_index_save_reference_files(vdb_hip_index* ix, const char* dir, c
   VDB_NO_GROUP(ix, "save_reference_files");
   std::lock_guard<std::mutex> g(ix->mu);
   if (!ix->graph_valid) return fail(VDB_ERR_STATE, "graph not built for all rows");
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   const uint64_t count = ix->n_rows;
   std::vector<float> vecs((size_t)count * ix->dim);
   if (count) {

@@ -678,7 +678,7 @@ int32_t graph_fill_ndist(vdb_hip_index* ix) {
 
 // Links rows [first, first+n) into the graph.  max_batch == 1: the reference's sequential insert;
 // otherwise batch-synchronous insertion with the schedule build_batch_size().
-int32_t graph_insert_rows(vdb_hip_index* ix, uint64_t first, uint64_t n, uint32_t max_batch) {
+static int32_t graph_insert_rows_impl(vdb_hip_index* ix, uint64_t first, uint64_t n, uint32_t max_batch) {
   if (n == 0) return VDB_OK;
   if (first != ix->graph_nodes) return fail(VDB_ERR_STATE, "graph_insert_rows: rows must be linked in order");
   if (max_batch == 0) max_batch = 2048;
@@ -838,6 +838,24 @@ int32_t graph_insert_rows(vdb_hip_index* ix, uint64_t first, uint64_t n, uint32_
                 "graph construction: candidate list overflow (too many exact distance ties for the LDS list), code " +
                     std::to_string(h_over));
   return VDB_OK;
+}
+
+// A failure (candidate-list overflow on exact ties, max_connections > 128, LDS limit, out of memory) can strike after
+// some sub-batches are linked.  The rows stay registered (exact search keeps serving them) but the graph no longer
+// covers them: graph_valid = false makes every HNSW mode answer VDB_ERR_STATE instead of silently omitting rows, later
+// inserts only append, and vdb_hip_index_build_graph resumes from graph_nodes — with the level stream (graph.rs:368-403)
+// rewound to the last linked node, so the finished graph is the one an undisturbed run builds.
+int32_t graph_insert_rows(vdb_hip_index* ix, uint64_t first, uint64_t n, uint32_t max_batch) {
+  const uint64_t rng0 = ix->rng_state, nodes0 = ix->graph_nodes;
+  const int32_t rc = graph_insert_rows_impl(ix, first, n, max_batch);
+  if (rc != VDB_OK) {
+    ix->graph_valid = false;
+    const double level_mult = 1.0 / std::log((double)ix->M);
+    ix->rng_state = rng0;
+    for (uint64_t i = nodes0; i < ix->graph_nodes; i++) (void)next_level(ix->rng_state, level_mult);
+    (void)hipStreamSynchronize(ix->stream);
+  }
+  return rc;
 }
 
 }  // namespace vdb

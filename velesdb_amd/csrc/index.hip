@@ -13,10 +13,12 @@
 namespace vdb {
 
 static thread_local std::string g_last_error;
-static int g_timing = 0;
-static int g_sweep_engine = 1;  // 1 (default): MFMA kernel for cosine / dot (oracle mode M); 0: VALU kernels (mode C)
-static uint32_t g_max_tile = 128;
-static uint32_t g_int8_oversampling = 4;  // DualPrecisionConfig::default().oversampling_ratio (dual_precision.rs:57)  // largest query tile of the exact sweep (tuning knob, vdb_hip_set_max_query_tile)
+// process-wide tuning / diagnostic knobs (results never depend on them): atomics, so that setting one while other
+// threads search is a data-race-free read of either value
+static std::atomic<int> g_timing{0};
+static std::atomic<int> g_sweep_engine{1};  // 1 (default): MFMA kernel for cosine / dot (oracle mode M); 0: VALU kernels (mode C)
+static std::atomic<uint32_t> g_max_tile{128};  // largest query tile of the exact sweep (vdb_hip_set_max_query_tile)
+static std::atomic<uint32_t> g_int8_oversampling{4};  // DualPrecisionConfig::default().oversampling_ratio (dual_precision.rs:57)
 
 void set_last_error(const std::string& s) { g_last_error = s; }
 int32_t fail(int32_t code, const std::string& msg) {
@@ -64,6 +66,15 @@ static int32_t check_device(int32_t* n_out) {
     return fail(VDB_ERR_NO_DEVICE, "no HIP device visible (hipGetDeviceCount)");
   }
   if (n_out) *n_out = n;
+  return VDB_OK;
+}
+
+int32_t enter_index(vdb_hip_index* ix) {
+  VDB_HIP(hipSetDevice(ix->device));
+  if (ix->foreign_pending) {
+    VDB_HIP(hipStreamWaitEvent(ix->stream, ix->ev_foreign, 0));
+    ix->foreign_pending = false;
+  }
   return VDB_OK;
 }
 
@@ -288,7 +299,7 @@ EventPair* next_events(vdb_hip_index* ix) {
 
 static uint32_t pick_B(uint32_t nq) {
   uint32_t b = nq >= 8 ? 8 : (nq >= 4 ? 4 : (nq >= 2 ? 2 : 1));
-  return std::min(b, std::min<uint32_t>(g_max_tile, 8));
+  return std::min(b, std::min<uint32_t>(g_max_tile.load(), 8));
 }
 static int blocks_for(const vdb_hip_index* ix, int B, uint32_t ngroups) {
   const int occ = (B == 1) ? 4 : (B == 8 ? 2 : 3);  // resident 256-thread blocks per CU (VGPR-limited)
@@ -669,6 +680,8 @@ int32_t create_single(uint32_t dim, int32_t metric, uint32_t M, uint32_t ef_cons
   ix->row_stride = ((uint64_t)dim + 3) / 4 * 4;
   ix->words = ((dim + 31) / 32 + 3) / 4 * 4;
   VDB_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+  VDB_HIP(hipEventCreateWithFlags(&ix->ev_foreign, hipEventDisableTiming));
+  VDB_HIP(hipEventCreateWithFlags(&ix->ev_own, hipEventDisableTiming));
   GraphLayer l0;
   l0.stride = ix->M0;
   ix->layers.push_back(l0);  // graph.rs:68 vec![Layer::new(max_elements)]
@@ -696,6 +709,8 @@ void destroy_single(vdb_hip_index* ix) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
+  if (ix->ev_foreign) (void)hipEventDestroy(ix->ev_foreign);
+  if (ix->ev_own) (void)hipEventDestroy(ix->ev_own);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
   delete ix;
 }
@@ -865,7 +880,7 @@ int32_t vdb_hip_index_insert(vdb_hip_index* ix, uint64_t id, const float* vec, u
     return grc != VDB_OK ? grc : (gi ? VDB_OK : VDB_DUPLICATE_IGNORED);
   }
   std::lock_guard<std::mutex> g(ix->mu);
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   uint64_t ins = 0, first = 0;
   int32_t rc = append_host_rows(ix, &id, vec, 1, &ins, &first);
   if (rc != VDB_OK) return rc;
@@ -885,7 +900,7 @@ int32_t vdb_hip_index_insert_batch(vdb_hip_index* ix, const uint64_t* ids, const
   if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_insert(ix, ids, vecs, n, 0, 1, inserted);
   std::lock_guard<std::mutex> g(ix->mu);
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   uint64_t ins = 0, first = 0;
   int32_t rc = append_host_rows(ix, ids, vecs, n, &ins, &first);
   if (inserted) *inserted = ins;
@@ -903,7 +918,7 @@ int32_t vdb_hip_index_insert_batch_parallel(vdb_hip_index* ix, const uint64_t* i
   if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_insert(ix, ids, vecs, n, 1, max_batch, inserted);
   std::lock_guard<std::mutex> g(ix->mu);
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   uint64_t ins = 0, first = 0;
   int32_t rc = append_host_rows(ix, ids, vecs, n, &ins, &first);
   if (inserted) *inserted = ins;
@@ -920,7 +935,7 @@ int32_t vdb_hip_index_train_quantizer(vdb_hip_index* ix, uint32_t sample_rows) {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_for_all(ix, 3, sample_rows);
   std::lock_guard<std::mutex> g(ix->mu);
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   int32_t rc = quantizer_train(ix, sample_rows);
   if (rc == VDB_OK) VDB_HIP(hipStreamSynchronize(ix->stream));
   return rc;
@@ -944,7 +959,7 @@ int32_t vdb_hip_index_enable_bf16(vdb_hip_index* ix) {
   if (ix->bf16_enabled) return VDB_OK;
   if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT)
     return fail(VDB_ERR_UNSUPPORTED, "bf16 sweep: Cosine and DotProduct only");
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   ix->bf16_stride = ((uint64_t)ix->dim + 7) / 8 * 8;
   hipError_t e;
   if ((e = ix->rows_bf16.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * ix->bf16_stride * 2, false, ix->stream)) != hipSuccess ||
@@ -968,7 +983,7 @@ int32_t vdb_hip_index_build_graph(vdb_hip_index* ix, uint32_t max_batch) {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_for_all(ix, 0, max_batch);
   std::lock_guard<std::mutex> g(ix->mu);
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   int32_t rc = VDB_OK;
   if (ix->graph_nodes < ix->n_rows) rc = graph_insert_rows(ix, ix->graph_nodes, ix->n_rows - ix->graph_nodes, max_batch);
   if (rc == VDB_OK) ix->graph_valid = true;
@@ -982,7 +997,7 @@ int32_t vdb_hip_index_upload(vdb_hip_index* ix, const uint64_t* ids, const float
   if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_insert(ix, ids, vecs, n, 2, 0, inserted);
   std::lock_guard<std::mutex> g(ix->mu);
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   uint64_t ins = 0, first = 0;
   int32_t rc = append_host_rows(ix, ids, vecs, n, &ins, &first);
   if (inserted) *inserted = ins;
@@ -997,7 +1012,7 @@ int32_t vdb_hip_index_upload_dev(vdb_hip_index* ix, uint64_t id_base, const floa
   if (!ix || (n && !d_vecs)) return fail(VDB_ERR_INVALID_ARG, "null argument");
   VDB_NO_GROUP(ix, "upload_dev (rows resident on one device)");
   std::lock_guard<std::mutex> g(ix->mu);
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   if (n == 0) return VDB_OK;
   for (uint64_t i = 0; i < n; i++)
     if (ix->id_to_idx.count(id_base + i)) return fail(VDB_ERR_INVALID_ARG, "upload_dev: id range overlaps existing ids");
@@ -1044,7 +1059,7 @@ int32_t vdb_hip_index_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed) {
     return VDB_OK;
   }
   const uint64_t idx = it->second;
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   VDB_HIP(hipMemsetAsync(ix->alive.as<uint8_t>() + idx, 0, 1, ix->stream));
   VDB_HIP(hipStreamSynchronize(ix->stream));
   ix->idx_live[idx] = 0;
@@ -1083,7 +1098,7 @@ int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   VDB_NO_GROUP(ix, "vacuum");
   std::lock_guard<std::mutex> g(ix->mu);
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   const uint64_t n_old = ix->n_rows, n_live = ix->live;
   if (count) *count = n_live;
   if (n_live == 0) return VDB_OK;  // vacuum.rs:123-125: nothing to rebuild
@@ -1178,10 +1193,24 @@ int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* ix, const float* d_queries
   std::lock_guard<std::mutex> g(ix->mu);
   VDB_HIP(hipSetDevice(ix->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (st != ix->stream) {
+    // the kernels below share this index's scratch, rows and graph with everything enqueued before: order the caller's
+    // stream behind the work pending on ix->stream and behind an earlier device-resident search on ANOTHER stream
+    VDB_HIP(hipEventRecord(ix->ev_own, ix->stream));
+    VDB_HIP(hipStreamWaitEvent(st, ix->ev_own, 0));
+    if (ix->foreign_pending && ix->last_foreign != st) VDB_HIP(hipStreamWaitEvent(st, ix->ev_foreign, 0));
+  } else {
+    VDB_ENTER(ix);
+  }
   int32_t rc = search_dev(ix, d_queries, ix->dim, nq, k, ef, mode, d_out_ids, d_out_scores, d_out_n, st);
   if (rc == VDB_OK && ix->pcomm && nq && k) {
     const int32_t m = (mode == VDB_SEARCH_AUTO) ? (ix->live <= 100 ? VDB_SEARCH_BRUTE : VDB_SEARCH_HNSW) : mode;
     rc = pcomm_exchange_merge(ix, nq, k, mode_higher_is_better(ix->metric, m), d_out_ids, d_out_scores, d_out_n, st);
+  }
+  if (st != ix->stream) {
+    VDB_HIP(hipEventRecord(ix->ev_foreign, st));
+    ix->last_foreign = st;
+    ix->foreign_pending = true;
   }
   return rc;
   });
@@ -1196,7 +1225,7 @@ static int32_t search_batch_host(vdb_hip_index* ix, const float* queries, uint32
   if (nq == 0) return VDB_OK;
   if (ix->group) return group_search_host(ix, queries, nq, k, ef, mode, rerank_k, out_ids, out_scores, out_n);
   std::lock_guard<std::mutex> g(ix->mu);
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   hipStream_t st = ix->stream;
   int32_t rc = search_to_device(ix, queries, nq, k, ef, mode, rerank_k, out_n);
   if (rc != VDB_OK) return rc;
@@ -1291,18 +1320,28 @@ int32_t vdb_hip_batch_distance(int32_t device, int32_t metric, int32_t kind, con
   if (!query || !vecs || !out) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (device < 0 || device >= ndev) return fail(VDB_ERR_INVALID_ARG, "bad device ordinal");
   VDB_HIP(hipSetDevice(device));
-  float *dq = nullptr, *dv = nullptr, *dout = nullptr;
-  hipError_t e = hipMalloc(&dq, (size_t)dim * 4);
-  if (e == hipSuccess) e = hipMalloc(&dv, (size_t)n * dim * 4);
-  if (e == hipSuccess) e = hipMalloc(&dout, (size_t)n * 4);
-  if (e == hipSuccess) e = hipMemcpy(dq, query, (size_t)dim * 4, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dv, vecs, (size_t)n * dim * 4, hipMemcpyHostToDevice);
+  // persistent, growing staging buffers per device (the reference's wgpu path allocates and frees three buffers per
+  // call, gpu/gpu_backend.rs:157-296 — the pattern SURVEY 2.3 says not to reproduce); one call per device at a time
+  struct Staging {
+    std::mutex mu;
+    DevBuf q, v, out;
+    hipStream_t st = nullptr;
+  };
+  static Staging staging[64];
+  if (device >= 64) return fail(VDB_ERR_INVALID_ARG, "bad device ordinal");
+  Staging& sg = staging[device];
+  std::lock_guard<std::mutex> lk(sg.mu);
+  if (!sg.st) VDB_HIP(hipStreamCreateWithFlags(&sg.st, hipStreamNonBlocking));
+  hipError_t e = sg.q.reserve((size_t)dim * 4, false, sg.st);
+  if (e == hipSuccess) e = sg.v.reserve((size_t)n * dim * 4, false, sg.st);
+  if (e == hipSuccess) e = sg.out.reserve((size_t)n * 4, false, sg.st);
+  if (e == hipSuccess) e = hipMemcpyAsync(sg.q.p, query, (size_t)dim * 4, hipMemcpyHostToDevice, sg.st);
+  if (e == hipSuccess) e = hipMemcpyAsync(sg.v.p, vecs, (size_t)n * dim * 4, hipMemcpyHostToDevice, sg.st);
   rc = VDB_OK;
-  if (e == hipSuccess) rc = vdb_hip_batch_distance_dev(metric, kind, dq, dv, n, dim, dout, nullptr);
-  if (e == hipSuccess && rc == VDB_OK) e = hipMemcpy(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost);
-  (void)hipFree(dq);
-  (void)hipFree(dv);
-  (void)hipFree(dout);
+  if (e == hipSuccess)
+    rc = vdb_hip_batch_distance_dev(metric, kind, sg.q.as<float>(), sg.v.as<float>(), n, dim, sg.out.as<float>(), sg.st);
+  if (e == hipSuccess && rc == VDB_OK) e = hipMemcpyAsync(out, sg.out.p, (size_t)n * 4, hipMemcpyDeviceToHost, sg.st);
+  if (e == hipSuccess) e = hipStreamSynchronize(sg.st);
   if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? VDB_ERR_OOM : VDB_ERR_HIP,
                                    std::string("batch_distance: ") + hipGetErrorString(e));
   return rc;
@@ -1349,7 +1388,7 @@ int32_t vdb_hip_index_last_search_stats(vdb_hip_index* ix, uint64_t* n_dist, uin
   std::lock_guard<std::mutex> g(ix->mu);
   if (ix->stats_pending) {
     unsigned long long h[2] = {0, 0};
-    VDB_HIP(hipSetDevice(ix->device));
+    VDB_ENTER(ix);
     VDB_HIP(hipDeviceSynchronize());
     VDB_HIP(hipMemcpy(h, ix->s_stats.p, 16, hipMemcpyDeviceToHost));
     ix->last_n_dist = h[0];

@@ -578,7 +578,7 @@ int32_t vdb_hip_index_set_storage_mode(vdb_hip_index* ix, int32_t mode) {
   if (ix->group) return group_for_all(ix, 2, (uint32_t)mode);
   std::lock_guard<std::mutex> g(ix->mu);
   if (ix->storage_mode == mode) return VDB_OK;
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   for (DevBuf* b : {&ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits}) b->release();
   ix->storage_mode = mode;
   ix->sq8_stride = ((uint64_t)ix->dim + 15) / 16 * 16;
@@ -611,7 +611,7 @@ int32_t vdb_hip_index_get_quantized(vdb_hip_index* ix, uint64_t id, uint8_t* out
   const size_t need = ix->storage_mode == VDB_STORAGE_SQ8 ? 8 + (size_t)ix->dim : 4 + ((size_t)ix->dim + 7) / 8;
   *len = need;
   if (!out || cap < need) return fail(VDB_ERR_INVALID_ARG, "buffer too small");
-  VDB_HIP(hipSetDevice(ix->device));
+  VDB_ENTER(ix);
   if (ix->storage_mode == VDB_STORAGE_SQ8) {
     VDB_HIP(hipMemcpyAsync(out, ix->sq8_min.as<float>() + row, 4, hipMemcpyDeviceToHost, ix->stream));
     VDB_HIP(hipMemcpyAsync(out + 4, ix->sq8_max.as<float>() + row, 4, hipMemcpyDeviceToHost, ix->stream));

@@ -73,6 +73,15 @@ static inline int32_t guarded(F&& f) noexcept {
   }
 }
 
+// after taking ix->mu: select the device and order ix->stream behind a device-resident search still in flight on a
+// caller's stream
+int32_t enter_index(vdb_hip_index* ix);
+#define VDB_ENTER(ix)                        \
+  do {                                       \
+    int32_t _erc = ::vdb::enter_index(ix);   \
+    if (_erc != VDB_OK) return _erc;         \
+  } while (0)
+
 #define VDB_NO_GROUP(ix, what)                                                                     \
   do {                                                                                             \
     if ((ix)->group) return ::vdb::fail(VDB_ERR_UNSUPPORTED, what ": not available on a multi-device handle"); \
@@ -134,6 +143,13 @@ struct vdb_hip_index {
   uint64_t last_n_dist = 0, last_n_expand = 0;
 
   mutable std::mutex mu;
+  // Device-side ordering between streams (the scratch buffers, the rows and the graph are shared by every search of this
+  // index): a device-resident search enqueued on a caller's stream records ev_foreign; whatever touches the index next on
+  // another stream — ix->stream for every host entry point, another caller stream — waits for it first (VDB_ENTER /
+  // vdb_hip_index_search_batch_dev), and a caller stream waits for the work pending on ix->stream (ev_own).
+  hipEvent_t ev_foreign = nullptr, ev_own = nullptr;
+  hipStream_t last_foreign = nullptr;
+  bool foreign_pending = false;
 
   // multi-device handle (vdb_hip_index_create with n_devices > 1): this object then owns no device memory, only the
   // id mappings / counters above and the children; every entry point dispatches through the group (shard_group.hip)
