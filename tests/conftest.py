@@ -3,6 +3,16 @@ import sys
 
 import pytest
 
+# torch first (as bench.py does): PyTorch-ROCm bundles its own HIP runtime, and a process that loaded ROCm's copy through
+# libvelesdb_hip.so before torch initialised reports "No HIP GPUs are available" from torch afterwards.  Tests that hand
+# torch device pointers to the C ABI need both in one process.
+try:
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+except Exception:  # noqa: BLE001 - torch is optional for everything but the device-pointer tests
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -52,6 +52,15 @@ void DevBuf::release() {
   cap = 0;
 }
 
+// VELESDB_BF16_GLDS=0: big bf16 batches stay on the register-staged kernel of sweep_gemm.hip (A/B probes)
+static bool gemm_bf16_glds_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("VELESDB_BF16_GLDS");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 static bool higher_is_better_host(int metric) {  // core/distance.rs:76-82
   return metric == VDB_COSINE || metric == VDB_DOT || metric == VDB_JACCARD;
 }
@@ -98,7 +107,7 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
                                 (e = ix->codes_sq.reserve(ncap * 4, true, st)) != hipSuccess))
     return fail(VDB_ERR_OOM, std::string("grow codes: ") + hipGetErrorString(e));
   if (ix->bf16_enabled && ((e = ix->rows_bf16.reserve((ncap + kRowSlack) * ix->bf16_stride * 2, true, st)) != hipSuccess ||
-                           (e = ix->norms_bf16.reserve(ncap * 4, true, st)) != hipSuccess))
+                           (e = ix->norms_bf16.reserve((ncap + kRowSlack) * 4, true, st)) != hipSuccess))
     return fail(VDB_ERR_OOM, std::string("grow bf16 rows: ") + hipGetErrorString(e));
   for (auto& L : ix->layers) {
     if ((e = L.nbr.reserve(ncap * L.stride * 4, true, st)) != hipSuccess ||
@@ -158,6 +167,89 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
   for (uint32_t q0 = 0; q0 < nq;) {
     const uint32_t rem = nq - q0;
+    // large batches over a large corpus: the 256 x 256 LDS-DMA kernel (sweep_gemm_bf16.hip).  Its thresholds are seeded:
+    // the 128 x 128 kernel first sweeps the first kGemmBf16SeedRows rows, the k-th best key found there (+ 1) is every
+    // block's starting bound — without it the first row tile of every block floods the 12-key candidate buffers.
+    if (g_max_tile >= 128 && rem >= kGemmBigMinQueries && k <= kGemmBf16MaxK && ix->dim % 64 == 0 && ix->dim >= 128 &&
+        ix->n_rows >= kGemmBf16MinRows && ix->n_rows < 0xFFFFFF00ull && gemm_bf16_glds_enabled()) {
+      const uint32_t nqg = std::min<uint32_t>(rem, kGemmMaxQueries);
+      const uint32_t nqt_big = (nqg + 255) / 256;
+      if ((uint64_t)nqg * 8 >= (uint64_t)nqt_big * 256 * 7) {  // the batch fills its 256-query tiles to >= 7/8
+        // Launch schedule: rows [0, R0) by the 128 x 128 kernel (seed), then the LDS-DMA kernel over [R0, R1) and [R1, n).
+        // Every launch starts from the k-th best key over ALL rows swept before it: the number of candidates a wave has
+        // to look at per row tile falls as k / rows seen (5 per wave tile behind 16 K rows, 0.1 behind 640 K).  All
+        // launches write their partial lists into one [nq][lists][k] array that the final merge scans once.
+        const uint32_t n = (uint32_t)ix->n_rows;
+        const uint32_t R0 = kGemmBf16SeedRows;
+        uint32_t R1 = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(R0 + (1u << 18), R0 + (n / 16 + 255) / 256 * 256));
+        if (n - R1 < (1u << 18)) R1 = n;  // a short tail is not worth a launch of its own
+        Bf16GemmPlan bp[2];
+        int n_launch = 0;
+        sweep_gemm_bf16_plan(nqg, R0, R1, ix->n_cus, &bp[n_launch++]);
+        if (R1 < n) sweep_gemm_bf16_plan(nqg, R1, n, ix->n_cus, &bp[n_launch++]);
+        uint32_t lists = 1;
+        for (int j = 0; j < n_launch; j++) lists += bp[j].G;
+        GemmPlan sp;  // seeding sweep over the first rows
+        sweep_gemm_plan(nqg, R0, ix->n_cus, k, &sp, /*allow_big=*/false);
+        const size_t off_ids = ((size_t)nqg * sp.G * k * 8 + 15) & ~(size_t)15, off_sc = off_ids + (size_t)nqg * k * 8,
+                     off_n = off_sc + (size_t)nqg * k * 4, off_tau = (off_n + (size_t)nqg * 4 + 15) & ~(size_t)15;
+        hipError_t e3;
+        if ((e3 = ix->s_part_keys.reserve((size_t)nqg * lists * k * 8, false, st)) != hipSuccess ||
+            (e3 = ix->s_seed.reserve(off_tau + (size_t)nqg * 8, false, st)) != hipSuccess ||
+            (e3 = ix->s_misc.reserve(((size_t)nqg + 256) * ix->bf16_stride * 2, false, st)) != hipSuccess)
+          return fail(VDB_ERR_OOM, "bf16 GEMM scratch");
+        unsigned char* sd = ix->s_seed.as<unsigned char>();
+        uint64_t* parts = ix->s_part_keys.as<uint64_t>();
+        uint64_t* tau0 = reinterpret_cast<uint64_t*>(sd + off_tau);
+        const uint16_t* q16 = ix->s_misc.as<uint16_t>();
+        launch_round_queries_bf16(d_q + (size_t)q0 * q_stride, q_stride, ix->s_misc.as<uint16_t>(), ix->bf16_stride, nqg,
+                                  ix->dim, st);
+        // the 256 x 256 kernel stages whole 256-query tiles: zero rows behind the batch
+        VDB_HIP(hipMemsetAsync(ix->s_misc.as<uint16_t>() + (size_t)nqg * ix->bf16_stride, 0, (size_t)256 * ix->bf16_stride * 2, st));
+        VDB_HIP(hipMemsetAsync(parts, 0xFF, (size_t)nqg * lists * k * 8, st));  // every slot: kKeyInvalid
+        EventPair* evg = next_events(ix);
+        if (evg) (void)hipEventRecord(evg->a, st);
+        e3 = launch_sweep_gemm_bf16(ix->metric, sp, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride, ix->norms_bf16.as<float>(),
+                                    alive, q16, ix->bf16_stride, reinterpret_cast<uint64_t*>(sd), R0, ix->dim, nqg, k, st);
+        if (e3 != hipSuccess) return fail(VDB_ERR_HIP, std::string("bf16 seed sweep launch: ") + hipGetErrorString(e3));
+        MergeArgs ms{};
+        ms.part_keys = reinterpret_cast<const uint64_t*>(sd);
+        ms.ext_ids = nullptr;  // internal rows
+        ms.out_ids = reinterpret_cast<uint64_t*>(sd + off_ids);
+        ms.out_scores = reinterpret_cast<float*>(sd + off_sc);
+        ms.out_n = reinterpret_cast<uint32_t*>(sd + off_n);
+        ms.n_lists = sp.G;
+        ms.k = k;
+        launch_merge(true, ms, nqg, st);
+        launch_seed_tau(ms.out_ids, ms.out_scores, ms.out_n, tau0, parts, lists, nqg, k, st);  // list 0 = the seed's top-k
+        uint32_t list_off = 1;
+        for (int j = 0; j < n_launch; j++) {
+          e3 = launch_sweep_gemm_bf16_glds(ix->metric, bp[j], ix->rows_bf16.as<uint16_t>(), ix->bf16_stride,
+                                           ix->norms_bf16.as<float>(), alive, q16, ix->bf16_stride, tau0, parts, lists,
+                                           list_off, ix->dim, nqg, k, st);
+          if (e3 != hipSuccess) return fail(VDB_ERR_HIP, std::string("bf16 gemm sweep launch: ") + hipGetErrorString(e3));
+          list_off += bp[j].G;
+          if (j + 1 < n_launch) {  // bound for the next launch: k-th best key over everything swept so far
+            ms.part_keys = parts;
+            ms.n_lists = lists;
+            launch_merge(true, ms, nqg, st);
+            launch_seed_tau(ms.out_ids, ms.out_scores, ms.out_n, tau0, nullptr, 0, nqg, k, st);
+          }
+        }
+        if (evg) (void)hipEventRecord(evg->b, st);
+        MergeArgs mg{};
+        mg.part_keys = parts;
+        mg.ext_ids = ix->ext_ids.as<uint64_t>();
+        mg.out_ids = d_ids + (size_t)q0 * k;
+        mg.out_scores = d_scores + (size_t)q0 * k;
+        mg.out_n = d_n + q0;
+        mg.n_lists = lists;
+        mg.k = k;
+        launch_merge(true, mg, nqg, st);
+        q0 += nqg;
+        continue;
+      }
+    }
     // large batches: the GEMM-structured kernel over the bf16 rows (sweep_gemm.hip, BF16 variant): the corpus is read
     // once per <= 128 queries instead of once per 96, both operands through LDS, lock-free top-k epilogue
     if (g_max_tile >= 128 && rem >= kGemmMinQueries && k <= kGemmMaxK && ix->dim % 64 == 0) {
@@ -697,7 +789,7 @@ void destroy_single(vdb_hip_index* ix) {
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   proc_comm_free(ix->pcomm);
   for (DevBuf* b : {&ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids, &ix->rows_bf16, &ix->norms_bf16, &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits, &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq, &ix->s_queries, &ix->s_part_keys,
-                    &ix->s_part_cnt, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels,
+                    &ix->s_part_cnt, &ix->s_seed, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels,
                     &ix->s_req_keys, &ix->s_req_vals, &ix->s_sort_tmp})
     b->release();
   for (auto& L : ix->layers) {
@@ -963,7 +1055,7 @@ int32_t vdb_hip_index_enable_bf16(vdb_hip_index* ix) {
   ix->bf16_stride = ((uint64_t)ix->dim + 7) / 8 * 8;
   hipError_t e;
   if ((e = ix->rows_bf16.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * ix->bf16_stride * 2, false, ix->stream)) != hipSuccess ||
-      (e = ix->norms_bf16.reserve(std::max<uint64_t>(ix->capacity, 1) * 4, false, ix->stream)) != hipSuccess)
+      (e = ix->norms_bf16.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * 4, false, ix->stream)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("bf16 rows: ") + hipGetErrorString(e));
   ix->bf16_enabled = true;
   if (ix->n_rows) {

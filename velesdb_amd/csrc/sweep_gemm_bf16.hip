@@ -37,7 +37,6 @@ namespace vdb {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 constexpr int kG16BM = 256, kG16BN = 256, kG16Waves = 8;
 constexpr int kG16Cap = 12;     // candidate buffer entries per query (k <= kGemmBf16MaxK = 10)
@@ -56,25 +55,54 @@ struct Bf16GemmArgs {
   const uint8_t* alive;     // nullable
   const uint16_t* queries;  // [nq][q_stride] bf16 (round_queries_bf16)
   const uint64_t* tau0;     // [nq] seed: (k-th best key over a prefix of the rows) + 1, or kKeyInvalid
-  uint64_t* part_keys;      // [nq][G][k]
+  uint64_t* part_keys;      // [nq][list_stride][k]: this launch fills lists list_off .. list_off + G - 1
   uint64_t row_stride, q_stride;  // elements
-  uint32_t n_rows, dim, nq, k;
+  uint32_t n_rows, dim, nq, k;    // n_rows: end of the row range of this launch
   uint32_t KT, G, nqt, qper;
+  uint32_t row_tile0;       // first 256-row tile of the row range
+  uint32_t list_stride, list_off;
 };
 
-// acc[rf][t][r] for a per-lane element index e = (rf * 4 + t) * 4 + r without dynamic register indexing
-template <int LO, int N>
-struct Acc128 {
-  static __device__ __forceinline__ float get(const f32x4 (&acc)[8][4], uint32_t e) {
-    const float lo = Acc128<LO, N / 2>::get(acc, e);
-    const float hi = Acc128<LO + N / 2, N / 2>::get(acc, e);
-    return (e & (uint32_t)(N / 2)) ? hi : lo;
-  }
-};
-template <int LO>
-struct Acc128<LO, 1> {
-  static __device__ __forceinline__ float get(const f32x4 (&acc)[8][4], uint32_t) { return acc[LO / 16][(LO / 4) % 4][LO % 4]; }
-};
+// The lane id, re-derived where it is needed: a value computed from threadIdx before the main loop stays live across it,
+// and with 128 accumulators + 48 fragment registers the allocator answers every such value with a scratch spill — whose
+// reload is a VMEM operation that queues behind the LDS-DMA loads of the next k-tile (measured: it serialises the
+// pipeline).  `asm volatile` keeps the two v_mbcnt inside the block that uses them.
+__device__ __forceinline__ uint32_t lane_now() {
+  uint32_t l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+// acc += A x B on the matrix cores, IN PLACE.  Through the builtin hipcc (ROCm 7.2) writes every product of this
+// kernel to a second register set (vdst != srcC, the two sets swapping roles every half k-tile): 128 accumulators then
+// occupy ~240 registers and the rest of the kernel lives in scratch.  The tied "+v" operand pins vdst = srcC.
+// Hazards the compiler no longer sees (cdna_hip_programming.md 5.7): the accumulators are read by vector-ALU code only
+// in the epilogue, behind mfma_drain(); two MFMAs on one accumulator are always >= 31 MFMAs apart.
+// `asm volatile`: the MFMAs keep their program order among themselves and against mfma_drain() / lane_now(); fragment
+// reads (plain LDS loads) still move freely around them.
+__device__ __forceinline__ void mfma_bf16_inplace(f32x4& c, const f32x4& a, const f32x4& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// first product of a row tile: srcC = 0, no zeroing pass over the 128 accumulators
+__device__ __forceinline__ void mfma_bf16_first(f32x4& c, const f32x4& a, const f32x4& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
+// One LDS-DMA instruction (`buffer_load_dwordx4 ... offen lds`: 64 lanes x 16 B land at M0 + 16 lane), pinned in the
+// instruction stream (`asm volatile` keeps its place among the MFMAs).  The compiler does not count these on vmcnt: every k-tile step ends with an explicit `s_waitcnt vmcnt(0)` in front of its barrier.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void glds_b128(const i32x4& rsrc, uint32_t voff, uint32_t soff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               :
+               : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+               : "m0");  // no "memory" clobber: fragment reads of the OTHER buffer may move across a request
+}
+__device__ __forceinline__ i32x4 make_rsrc(const void* base) {  // raw buffer, byte-addressed, no bounds in reach
+  const uint64_t b = reinterpret_cast<uint64_t>(base);
+  return i32x4{(int)(uint32_t)b, (int)((uint32_t)(b >> 32) & 0xFFFFu), 0x7FFFFFFF, 0x00020000};
+}
+__device__ __forceinline__ void wait_glds() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int METRIC>
 __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs a) {
@@ -132,61 +160,50 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs
     }
   }
   __syncthreads();
-  float qn_t[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++) qn_t[t] = qn[wq * 64 + t * 16 + (lane & 15)];
-
-  const uint32_t ntiles = (a.n_rows + BM - 1) / BM;
-  const uint32_t my_tiles = g < ntiles ? (ntiles - g + a.G - 1) / a.G : 0;
+  const uint32_t ntiles = (a.n_rows + BM - 1) / BM;  // tiles row_tile0 .. ntiles - 1 belong to this launch
+  const uint32_t rt_first = a.row_tile0 + g;
+  const uint32_t my_tiles = rt_first < ntiles ? (ntiles - rt_first + a.G - 1) / a.G : 0;
   const uint32_t total = my_tiles * a.KT;
 
   // ---- LDS-DMA staging: wave w, instruction j fills the 1 KiB row block rb = 8 j + w (rows 8 rb .. 8 rb + 7) ----
   // lane (r = l >> 3, p = l & 7) lands at row 8 rb + r, physical slot p, and fetches logical slot p ^ ((row >> 1) & 7);
-  // (row >> 1) & 7 does not depend on j (64 j >> 1 is a multiple of 8): one per-lane offset, four uniform bases
-  const uint32_t st_row = (uint32_t)wib * 8u + ((uint32_t)lane >> 3);
-  const uint32_t st_slot = ((uint32_t)lane & 7u) ^ ((st_row >> 1) & 7u);
-  const uint32_t voff_a = st_row * (uint32_t)a.row_stride * 2u + st_slot * 16u;
-  uint32_t voff_b[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const uint32_t q = st_row + 64u * (uint32_t)j;
-    voff_b[j] = (q < nq_t ? q : nq_t - 1) * (uint32_t)a.q_stride * 2u + st_slot * 16u;  // padded slots repeat a query
-  }
+  // (row >> 1) & 7 does not depend on j (64 j >> 1 is a multiple of 8).  The tile's base address sits in a buffer
+  // descriptor (4 SGPRs, rebuilt per step with scalar adds), the per-lane offset is one VGPR per operand (rebuilt from the
+  // lane id, see lane_now), the row block of instruction j a scalar offset.
+  // (The query buffer is zero-padded to whole 256-query tiles by the host, so B needs no clamping.)
+  const uint32_t soff_a = 64u * (uint32_t)a.row_stride * 2u, soff_b = 64u * (uint32_t)a.q_stride * 2u;
   const unsigned char* rows_b = reinterpret_cast<const unsigned char*>(a.rows);
   const unsigned char* queries_b = reinterpret_cast<const unsigned char*>(queries);
-  uint32_t ld_rt = g, ld_kt = 0;  // (row tile, k-tile) of the NEXT step to request
-#define VDB_G16_ISSUE(BUF) do { \
-    const unsigned char* base_a = rows_b + ((size_t)ld_rt * BM * a.row_stride + (size_t)ld_kt * 64) * 2; \
-    const unsigned char* base_b = queries_b + (size_t)ld_kt * 128; \
-    unsigned char* la = smem + (size_t)(BUF) * 65536 + (size_t)wib * 1024; \
-_Pragma("unroll") \
-    for (int j = 0; j < 4; j++) \
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base_a + (size_t)j * 64 * a.row_stride * 2 + voff_a), \
-                                       (lds_ptr_t)(la + j * 8192), 16, 0, 0); \
-_Pragma("unroll") \
-    for (int j = 0; j < 4; j++) \
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base_b + voff_b[j]), (lds_ptr_t)(la + 32768 + j * 8192), 16, 0, 0); \
-    if (++ld_kt == a.KT) { \
+  uint32_t ld_rt = rt_first, ld_kt = 0;  // (row tile, k-tile) of the NEXT step to request
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr_t)smem;  // LDS byte address of the dynamic block (0)
+  // operands of the eight requests of one step, for buffer BUF
+#define VDB_G16_REQ(BUF) \
+    const uint32_t ln_ = lane_now(); \
+    const uint32_t st_row = (uint32_t)wib * 8u + (ln_ >> 3); \
+    const uint32_t st_slot = (ln_ & 7u) ^ ((st_row >> 1) & 7u); \
+    const uint32_t voff_a = st_row * (uint32_t)a.row_stride * 2u + st_slot * 16u; \
+    const uint32_t voff_b = st_row * (uint32_t)a.q_stride * 2u + st_slot * 16u; \
+    const i32x4 ra = make_rsrc(rows_b + ((size_t)ld_rt * BM * a.row_stride + (size_t)ld_kt * 64) * 2); \
+    const i32x4 rb = make_rsrc(queries_b + (size_t)ld_kt * 128); \
+    const uint32_t la = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)wib * 1024u;
+  // request J (0..3: row tile, 4..7: query tile)
+#define VDB_G16_GLDS(J) do { \
+    if ((J) < 4) glds_b128(ra, voff_a, (uint32_t)(J) * soff_a, la + (uint32_t)(J) * 8192u); \
+    else glds_b128(rb, voff_b, (uint32_t)((J) - 4) * soff_b, la + 32768u + (uint32_t)((J) - 4) * 8192u); \
+  } while (0)
+  // after a step's requests: the step after it, unless there is none (the last step is then simply requested again)
+#define VDB_G16_ADVANCE() do { \
+    if (it + 2 < total && ++ld_kt == a.KT) { \
       ld_kt = 0; \
       ld_rt += a.G; \
     } \
   } while (0)
 
   f32x4 acc[8][4];
-#pragma unroll
-  for (int rf = 0; rf < 8; rf++)
-#pragma unroll
-    for (int t = 0; t < 4; t++) acc[rf][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment reads: lane (i = l & 15, kk = l >> 4) reads slot (4 m + kk) ^ ((i >> 1) & 7) of row i (+ 16 rows per fragment)
-  const int sw_i = ((lane & 15) >> 1) & 7;
-  const int rd_off = (lane & 15) * 128 + ((((lane >> 4) ^ sw_i) & 3) << 4);
-  const int rd_x = (sw_i & 4) << 4;
-  const int a_rd0 = wr * 128 * 128 + rd_off;           // + buffer base
-  const int b_rd0 = 32768 + wq * 64 * 128 + rd_off;
 
   // ---- compaction of the candidate buffers this wave owns (queries wib, wib + 8, ...): one buffer per 16 lanes ----
   auto compact = [&]() __attribute__((always_inline)) {
+    const int lane = (int)lane_now();
     const uint32_t bq = (uint32_t)wib + (uint32_t)WAVES * (uint32_t)lane;  // lane l looks at query wib + 8 l (l < 32)
     const uint32_t cq = (lane < 32 && bq < nq_t) ? cnts[bq] : 0u;
     uint64_t need = __ballot(cq > k);
@@ -224,144 +241,157 @@ _Pragma("unroll") \
   uint32_t qcnt = 0;   // entries in this wave's queue (carried over while their candidate buffer is full)
   uint32_t epoch = 0;  // block-uniform: ++ per synchronisation point of the epilogue protocol
 
-  if (total) VDB_G16_ISSUE(0);
-  __syncthreads();  // (drains the LDS-DMA: the compiler puts vmcnt(0) in front of a barrier while one is in flight)
-  uint32_t kt = 0, rt = g;
-  for (uint32_t it = 0; it < total; it++) {
-    const int buf = (int)(it & 1u);
-    const bool more = it + 1 < total;
-    if (more) VDB_G16_ISSUE(buf ^ 1);
-    if (kt == 0 && wib == 0)  // the row tile's norms: 1 KiB = one instruction; vns was last read before the previous barrier
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(reinterpret_cast<const unsigned char*>(a.norms) + (size_t)rt * BM * 4 + lane * 16),
-                                       (lds_ptr_t)(smem + kOffVns), 16, 0, 0);
-    {  // ---- multiply k-tile `it` out of LDS: two 32-deep halves, 12 fragment reads + 32 MFMAs each ----
-      const unsigned char* tb = smem + (size_t)buf * 65536;
+  // One k-tile step: the current buffer is multiplied — two 32-deep halves, 12 fragment reads + 32 MFMAs each — with the
+  // eight LDS-DMA requests of the NEXT step (the other buffer) spread over the FIRST half, one per 4 MFMAs.  The eight
+  // waves' 64 requests of a step are 64 KiB through the CU's 64 B/clk vector-memory path = 1 024 cycles during which a
+  // wave that has a request pending issues nothing else: sent as one burst at the head of the step they stall every
+  // wave at once (measured 0.5 us per step); sent between MFMA groups they hide behind the other wave's MFMAs; sent over
+  // the WHOLE step the last ones have no time left to land before the step's barrier (measured 5 % slower than the burst).
+  // The row tile's norms travel with its first step.  Fragment reads: lane (i = l & 15, kk = l >> 4) reads slot
+  // (4 m + kk) ^ ((i >> 1) & 7) of row i (+ 16 rows per fragment); the address terms are rebuilt from the lane id every step.
+#define VDB_G16_STEP(KT_NOW, FIRST) do { \
+    const int buf = (int)(it & 1u); \
+    VDB_G16_REQ(buf ^ 1) \
+    if ((KT_NOW) == 0 && wib == 0) /* vns was last read before the previous barrier */ \
+      glds_b128(make_rsrc(reinterpret_cast<const unsigned char*>(a.norms) + (size_t)rt * BM * 4), ln_ * 16u, 0u, lds0 + (uint32_t)kOffVns); \
+    const int sw_i = (int)((ln_ & 15u) >> 1) & 7; \
+    const int rd_off = (int)(ln_ & 15u) * 128 + (((int)(ln_ >> 4) ^ sw_i) & 3) * 16; \
+    const int rd_x = (sw_i & 4) << 4; \
+    const int a_rd0 = wr * 128 * 128 + rd_off; \
+    const int b_rd0 = 32768 + wq * 64 * 128 + rd_off; \
+    const unsigned char* tb = smem + (size_t)buf * 65536; \
+_Pragma("unroll") \
+    for (int m = 0; m < 2; m++) { \
+      f32x4 av[8], bv[4]; \
+_Pragma("unroll") \
+      for (int t = 0; t < 4; t++) bv[t] = *reinterpret_cast<const f32x4*>(tb + b_rd0 + ((m * 64) ^ rd_x) + t * 2048); \
+_Pragma("unroll") \
+      for (int rf = 0; rf < 8; rf++) av[rf] = *reinterpret_cast<const f32x4*>(tb + a_rd0 + ((m * 64) ^ rd_x) + rf * 2048); \
+_Pragma("unroll") \
+      for (int rf = 0; rf < 8; rf++) { \
+_Pragma("unroll") \
+        for (int t = 0; t < 4; t++) { \
+          if ((FIRST) && m == 0) mfma_bf16_first(acc[rf][t], av[rf], bv[t]); \
+          else mfma_bf16_inplace(acc[rf][t], av[rf], bv[t]); \
+        } \
+        if (m == 0) VDB_G16_GLDS(rf); \
+      } \
+    } \
+    VDB_G16_ADVANCE(); \
+    it++; \
+    wait_glds(); /* this wave's requests have landed; the barrier that follows makes that true for every wave */ \
+  } while (0)
+
+  uint32_t it = 0;
+  if (total) {  // prologue: the first step's tiles
+    VDB_G16_REQ(0)
 #pragma unroll
-      for (int m = 0; m < 2; m++) {
-        float4 av[8], bv[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) bv[t] = *reinterpret_cast<const float4*>(tb + b_rd0 + ((m * 64) ^ rd_x) + t * 2048);
-#pragma unroll
-        for (int rf = 0; rf < 8; rf++) av[rf] = *reinterpret_cast<const float4*>(tb + a_rd0 + ((m * 64) ^ rd_x) + rf * 2048);
-#pragma unroll
-        for (int rf = 0; rf < 8; rf++)
-#pragma unroll
-          for (int t = 0; t < 4; t++)
-            acc[rf][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[rf]),
-                                                                __builtin_bit_cast(bf16x8, bv[t]), acc[rf][t], 0, 0, 0);
-      }
+    for (int j = 0; j < 8; j++) VDB_G16_GLDS(j);
+    if (total > 1 && ++ld_kt == a.KT) {
+      ld_kt = 0;
+      ld_rt += a.G;
     }
-    if (++kt < a.KT) {
-      __syncthreads();  // every wave is done with this buffer; the next one has landed
-      continue;
+    wait_glds();
+  }
+  __syncthreads();
+  // Row tiles outside, k-tiles inside: the accumulators are a loop-carried value of the INNER loop only, updated in place
+  // on its single back edge.  (One flat loop with a `continue` made hipcc copy all 128 of them on every back edge.)
+  for (uint32_t rt = rt_first; rt < ntiles; rt += a.G) {
+    VDB_G16_STEP(0, true);  // KT >= 2 (host)
+    __syncthreads();        // every wave is done with this buffer; the next one has landed
+    for (uint32_t kt = 1; kt + 1 < a.KT; kt++) {
+      VDB_G16_STEP(kt, false);
+      __syncthreads();
     }
+    VDB_G16_STEP(a.KT - 1, false);  // the last k-tile: its closing barrier is the first sync point of the epilogue
+    const bool more = it < total;
     // =====================================================================================================
     // last k-tile of a row tile: the accumulators hold 128 rows x 64 queries of dot products per wave
     // =====================================================================================================
     const bool last = !more;
-    uint32_t pm[4] = {0u, 0u, 0u, 0u};  // per-lane mask of pending elements, element e at bit 31 - e % 32 of word e / 32
+    mfma_drain();  // the matrix pipe has written every accumulator before the vector ALU reads one
+    const int lane = (int)lane_now();  // (shadows the kernel-scope lane: see lane_now)
+    // Quick test: per query column t a lane reduces its 32 accumulators (rows 16 rf + 4 (l >> 4) + r of the wave's 128)
+    // with max and compares with a bound no element that matters can miss.  hm[t] = the lanes that MAY hold a survivor
+    // (wave-uniform masks: they are also the state carried through the rounds of the protocol below).
+    uint64_t hm[4];
     {
-      float cutq[4];
-      bool hot = false;
+      const float* vnl = vns + wr * 128 + 4 * (lane >> 4);
+      float vmin = vnl[0], vmax = vmin, vsum = 0.0f;
+#pragma unroll
+      for (int rf = 0; rf < 8; rf++) {
+        const f32x4 vn = *reinterpret_cast<const f32x4*>(vnl + rf * 16);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          vmin = fminf(vmin, vn[r]);
+          vmax = fmaxf(vmax, vn[r]);
+          vsum += vn[r];  // NaN / inf / overflow-prone norms show up in the sum (min / max drop NaNs)
+        }
+      }
+      const bool force = !(vsum < 1e18f);
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         const uint32_t b = wq * 64 + t * 16 + (lane & 15);
         const uint64_t tkb = tauk[b];
         const float tf = tkb == kKeyInvalid ? __uint_as_float(0xFF800000u) : key_score<HIB>(tkb);
         const float cut = tf - (fabsf(tf) * 1.9073486e-6f + 1e-37f);  // 16-ulp margin
-        cutq[t] = b < nq_t ? (METRIC == kCosine ? cut * qn_t[t] : cut) : __uint_as_float(0x7F800000u);
-        hot |= !(qn_t[t] < 1e18f);  // a query norm that is NaN / inf / huge: no bound holds
-      }
-      // norms of the lane's 32 rows (rows 16 rf + 4 (l >> 4) + r of the wave's 128)
-      f32x4 vn[8];
-#pragma unroll
-      for (int rf = 0; rf < 8; rf++) vn[rf] = *reinterpret_cast<const f32x4*>(vns + wr * 128 + rf * 16 + 4 * (lane >> 4));
-      float vmin = vn[0][0], vmax = vn[0][0], vsum = 0.0f;
-#pragma unroll
-      for (int rf = 0; rf < 8; rf++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          vmin = fminf(vmin, vn[rf][r]);
-          vmax = fmaxf(vmax, vn[rf][r]);
-          vsum += vn[rf][r];  // NaN / inf / overflow-prone norms show up in the sum (min / max drop NaNs)
-        }
-      hot |= !(vsum < 1e18f);
-      // quick test: can ANY of the lane's 32 elements of column t reach the query's k-th best?
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
+        const float qnb = qn[b];
+        const float cutq = METRIC == kCosine ? cut * qnb : cut;
         float mx = acc[0][t][0];
 #pragma unroll
         for (int rf = 0; rf < 8; rf++)
 #pragma unroll
           for (int r = 0; r < 4; r++) mx = fmaxf(mx, acc[rf][t][r]);
         // cosine: score = acc / (|q| |v|) >= cut  <=>  acc >= cutq |v|: the smallest |v| of the lane bounds it for cutq > 0,
-        // the largest for cutq <= 0 (rounding slack: the 16-ulp margin of cut)
-        const float thr = METRIC == kCosine ? (cutq[t] > 0.0f ? cutq[t] * vmin : cutq[t] * vmax) : cutq[t];
-        hot |= !(mx < thr);
-      }
-      if (__ballot(hot)) {
-        // exact per-element filter (one bit per accumulator element); NaN / inf / zero-norm cases compare false = pass
-#pragma unroll
-        for (int rf = 0; rf < 8; rf++) {
-          f32x4 rvn = f32x4{1.f, 1.f, 1.f, 1.f};
-          if (METRIC == kCosine)
-#pragma unroll
-            for (int r = 0; r < 4; r++) rvn[r] = __builtin_amdgcn_rcpf(vn[rf][r]);
-#pragma unroll
-          for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-              const int e = (rf * 4 + t) * 4 + r;
-              const bool pass = !((METRIC == kCosine ? acc[rf][t][r] * rvn[r] : acc[rf][t][r]) < cutq[t]);
-              pm[e / 32] = (pm[e / 32] << 1) | (pass ? 1u : 0u);
-            }
-        }
+        // the largest for cutq <= 0 (rounding slack: the 16-ulp margin of cut).  A norm that is NaN / inf / huge (query
+        // or row): no bound holds, the lane is looked at.  fmaxf drops NaN accumulators: they only arise from such norms.
+        const float thr = METRIC == kCosine ? (cutq > 0.0f ? cutq * vmin : cutq * vmax) : cutq;
+        const bool hot = (b < nq_t) & (force | !(qnb < 1e18f) | !(mx < thr));
+        hm[t] = __ballot(hot);
       }
     }
-    const uint32_t lane_rl = (uint32_t)(wr * 128 + 4 * (lane >> 4));  // row in tile for rf = r = 0
-    const uint32_t lane_b = (uint32_t)(wq * 64 + (lane & 15));         // query in tile for t = 0
     for (;;) {
       ++epoch;
-      // ---- (1) drain the masks: every pass finishes each lane's lowest pending element exactly and parks the ones that
-      //      beat their query's k-th best key in the wave's queue; stops when the queue is full ----
+      // ---- (1) look at the hot lanes, one at a time: its 32 elements of the column are spread over lanes 0..31
+      //      (v_readlane with a uniform source lane) and finished densely — exact score, key, test against the query's
+      //      k-th best key — and the survivors are parked in the wave's queue.  Cost per hot lane ~100 instructions,
+      //      whatever the number of survivors; a lane whose survivors do not fit the queue waits for the next round. ----
       bool pend = false;
-      for (;;) {
-        const uint32_t any = pm[0] | pm[1] | pm[2] | pm[3];
-        if (__ballot(any != 0u) == 0) break;
-        uint32_t wi = 3, word = pm[3];
-#pragma unroll
-        for (int w = 2; w >= 0; w--) {
-          const bool nz = pm[w] != 0u;
-          word = nz ? pm[w] : word;
-          wi = nz ? (uint32_t)w : wi;
-        }
-        const bool has = any != 0u;
-        const uint32_t lz = (uint32_t)__builtin_clz(word | 1u);
-        const uint32_t e = lz + 32u * wi;
-        const float dv = Acc128<0, 128>::get(acc, e);
-        const uint32_t r = e & 3u, t = (e >> 2) & 3u, rf = e >> 4;
-        const uint32_t rl = lane_rl + rf * 16u + r, b = lane_b + t * 16u;
-        const uint32_t row = rt * BM + rl;
-        const float score = finish_score<METRIC>(dv, qn[b], METRIC == kCosine ? vns[rl] : 1.0f);
-        const uint64_t key = make_key<HIB>(score, row);
-        bool take = has & (b < nq_t) & (row < a.n_rows) & (key < tauk[b]);
-        if (take && a.alive) take = a.alive[row] != 0;  // soft-deleted rows are filtered where it is rare
-        const uint64_t mt = __ballot(take);
-        const uint32_t nt = (uint32_t)__popcll(mt);
-        if (qcnt + nt > (uint32_t)QCAP) {  // does not fit: nothing of this pass is committed
-          pend = true;
-          break;
-        }
-        const uint32_t cleared = word & ~(0x80000000u >> lz);
-#pragma unroll
-        for (int w = 0; w < 4; w++) pm[w] = (has && wi == (uint32_t)w) ? cleared : pm[w];
-        if (take) {
-          const uint32_t slot = qcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mt, 0u));
-          wq_keys[slot] = key;
-          wq_qs[slot] = (uint8_t)b;
-        }
-        qcnt += nt;
+#define VDB_G16_LOOK(T) \
+      while (hm[T] && !pend) { \
+        const int src = __ffsll((long long)hm[T]) - 1; \
+        float x = 0.0f; \
+_Pragma("unroll") \
+        for (int i = 0; i < 32; i++) { \
+          const float v = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(acc[i / 4][T][i % 4]), src)); \
+          x = lane == i ? v : x; \
+        } \
+        const uint32_t rl = (uint32_t)(wr * 128) + ((uint32_t)lane >> 2) * 16u + 4u * ((uint32_t)src >> 4) + ((uint32_t)lane & 3u); \
+        const uint32_t b = (uint32_t)(wq * 64 + (T) * 16) + ((uint32_t)src & 15u); \
+        const uint32_t row = rt * BM + (rl & 255u); \
+        const float score = finish_score<METRIC>(x, qn[b], METRIC == kCosine ? vns[rl & 255u] : 1.0f); \
+        const uint64_t key = make_key<HIB>(score, row); \
+        bool take = (lane < 32) & (row < a.n_rows) & (key < tauk[b]); \
+        if (take && a.alive) take = a.alive[row] != 0; /* soft-deleted rows are filtered where it is rare */ \
+        const uint64_t mt = __ballot(take); \
+        const uint32_t nt = (uint32_t)__popcll(mt); \
+        if (qcnt + nt > (uint32_t)QCAP) { /* does not fit: the lane stays hot for the next round */ \
+          pend = true; \
+          break; \
+        } \
+        hm[T] &= hm[T] - 1; \
+        if (take) { \
+          const uint32_t slot = qcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mt, 0u)); \
+          wq_keys[slot] = key; \
+          wq_qs[slot] = (uint8_t)b; \
+        } \
+        qcnt += nt; \
       }
+      VDB_G16_LOOK(0)
+      VDB_G16_LOOK(1)
+      VDB_G16_LOOK(2)
+      VDB_G16_LOOK(3)
+#undef VDB_G16_LOOK
       if (pend || (last && qcnt)) flags[0] = epoch;
       __syncthreads();  // sync point `epoch` (first round: also the k-tile's closing barrier)
       // ---- (2) buffers past k since the last sync point: compact them (everybody, between two barriers) ----
@@ -402,43 +432,49 @@ _Pragma("unroll") \
       }
       if (!again) break;
     }
-#pragma unroll
-    for (int rf = 0; rf < 8; rf++)
-#pragma unroll
-      for (int t = 0; t < 4; t++) acc[rf][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    kt = 0;
-    rt += a.G;
   }
-#undef VDB_G16_ISSUE
+#undef VDB_G16_STEP
+#undef VDB_G16_ADVANCE
+#undef VDB_G16_GLDS
+#undef VDB_G16_REQ
   __syncthreads();
   compact();  // every buffer still holding more than k keys
   __syncthreads();
+  const uint32_t lane_o = lane_now();
   for (uint32_t b = wib; b < nq_t; b += WAVES) {
     const uint32_t c = min(cnts[b], k);  // <= k entries, whatever order (the merge kernel scans them all)
-    uint64_t* out = a.part_keys + ((size_t)(q0 + b) * a.G + g) * k;
-    for (uint32_t e = lane; e < k; e += 64) out[e] = e < c ? cand[(size_t)b * CAP + e] : kKeyInvalid;
+    uint64_t* out = a.part_keys + ((size_t)(q0 + b) * a.list_stride + a.list_off + g) * k;
+    for (uint32_t e = lane_o; e < k; e += 64) out[e] = e < c ? cand[(size_t)b * CAP + e] : kKeyInvalid;
   }
 }
 
-// k-th best key of a query over the seed rows (+ 1: the key itself must still pass `key < tauk`)
+// From a merged prefix top-k (internal rows + raw scores, merge_topk with ext_ids = nullptr): the query's bound for the
+// next launch = k-th best key + 1 (the key itself must still pass `key < tauk`), and — list != nullptr — the top-k as a
+// key list in slot 0 of the launch-spanning list array (the seed rows are swept by a different kernel).
 __global__ __launch_bounds__(256) void seed_tau_kernel(const uint64_t* ids, const float* scores, const uint32_t* n, uint64_t* tau0,
-                                                       uint32_t nq, uint32_t k) {
+                                                       uint64_t* list, uint32_t list_stride, uint32_t nq, uint32_t k) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
+  const uint32_t c = min(n[q], k);
   uint64_t t = kKeyInvalid;
-  if (n[q] >= k && k > 0) t = make_key<true>(scores[(size_t)q * k + k - 1], (uint32_t)ids[(size_t)q * k + k - 1]) + 1ull;
+  if (c >= k && k > 0) t = make_key<true>(scores[(size_t)q * k + k - 1], (uint32_t)ids[(size_t)q * k + k - 1]) + 1ull;
   tau0[q] = t;
+  if (list)
+    for (uint32_t e = 0; e < k; e++)
+      list[(size_t)q * list_stride * k + e] = e < c ? make_key<true>(scores[(size_t)q * k + e], (uint32_t)ids[(size_t)q * k + e]) : kKeyInvalid;
 }
-void launch_seed_tau(const uint64_t* ids, const float* scores, const uint32_t* n, uint64_t* tau0, uint32_t nq, uint32_t k,
-                     hipStream_t st) {
-  hipLaunchKernelGGL(seed_tau_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, tau0, nq, k);
+void launch_seed_tau(const uint64_t* ids, const float* scores, const uint32_t* n, uint64_t* tau0, uint64_t* list,
+                     uint32_t list_stride, uint32_t nq, uint32_t k, hipStream_t st) {
+  hipLaunchKernelGGL(seed_tau_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, tau0, list, list_stride, nq, k);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------
-void sweep_gemm_bf16_plan(uint32_t nq, uint32_t n_rows, int n_cus, Bf16GemmPlan* p) {
+void sweep_gemm_bf16_plan(uint32_t nq, uint32_t row_lo, uint32_t row_hi, int n_cus, Bf16GemmPlan* p) {
   p->nqt = (nq + kG16BN - 1) / kG16BN;
   p->qper = (nq + p->nqt - 1) / p->nqt;
-  const uint32_t ntiles = (n_rows + kG16BM - 1) / kG16BM;
+  p->row_lo = row_lo;
+  p->row_hi = row_hi;
+  const uint32_t ntiles = (row_hi - row_lo + kG16BM - 1) / kG16BM;
   // row groups: whole XCD rounds, never more blocks than the chip holds at once (one block per CU)
   uint32_t G = (uint32_t)std::max(8, n_cus / (int)p->nqt / 8 * 8);
   G = std::min(G, (ntiles + 7) / 8 * 8);
@@ -448,8 +484,8 @@ void sweep_gemm_bf16_plan(uint32_t nq, uint32_t n_rows, int n_cus, Bf16GemmPlan*
 
 hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const uint16_t* rows16, uint64_t row_stride,
                                        const float* norms, const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride,
-                                       const uint64_t* tau0, uint64_t* part_keys, uint32_t n_rows, uint32_t dim, uint32_t nq,
-                                       uint32_t k, hipStream_t st) {
+                                       const uint64_t* tau0, uint64_t* part_keys, uint32_t list_stride, uint32_t list_off,
+                                       uint32_t dim, uint32_t nq, uint32_t k, hipStream_t st) {
   Bf16GemmArgs a{};
   a.rows = rows16;
   a.norms = norms;
@@ -459,7 +495,10 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
   a.part_keys = part_keys;
   a.row_stride = row_stride;
   a.q_stride = q_stride;
-  a.n_rows = n_rows;
+  a.n_rows = p.row_hi;
+  a.row_tile0 = p.row_lo / kG16BM;  // row_lo is a multiple of the tile height (host)
+  a.list_stride = list_stride;
+  a.list_off = list_off;
   a.dim = dim;
   a.nq = nq;
   a.k = k;

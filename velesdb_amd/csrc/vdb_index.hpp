@@ -132,6 +132,7 @@ struct vdb_hip_index {
 
   // scratch
   vdb::DevBuf s_queries, s_part_keys, s_part_cnt, s_out_ids, s_out_scores, s_out_n, s_qbits, s_misc;
+  vdb::DevBuf s_seed;  // seeding pre-pass of the bf16 GEMM sweep: partial lists, merged prefix top-k, seed keys
   uint64_t euclid_fallbacks = 0;  // queries of Euclidean matrix-core batches re-run through the exact sweep (diagnostic)
   vdb::DevBuf s_visited, s_vlog, s_stats;  // HNSW traversal scratch (hnsw_kernels.hip)
   vdb::DevBuf s_levels, s_req_keys, s_req_vals, s_sort_tmp;  // construction scratch (hnsw_build.hip)

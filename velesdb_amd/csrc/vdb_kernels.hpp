@@ -157,6 +157,22 @@ hipError_t launch_sweep_gemm_bf16(int metric, const GemmPlan& p, const uint16_t*
                                   const float* norms, const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride,
                                   uint64_t* part_keys, uint32_t n_rows, uint32_t dim, uint32_t nq, uint32_t k,
                                   hipStream_t st);
+// bf16 GEMM-distance sweep for big batches (sweep_gemm_bf16.hip): 256 x 256 block tile, LDS-DMA staging, seeded thresholds
+struct Bf16GemmPlan {
+  uint32_t nqt, qper, G;
+  uint32_t row_lo, row_hi;  // row range of the launch (row_lo a multiple of 256)
+  int blocks;
+};
+constexpr uint32_t kGemmBf16MaxK = 10;          // candidate buffers of 12 keys per query
+constexpr uint32_t kGemmBf16MinRows = 1u << 16; // below this the 128 x 128 kernel serves the batch alone
+constexpr uint32_t kGemmBf16SeedRows = 1u << 14; // rows of the seeding pre-pass (k-th best key over a prefix of the corpus)
+void sweep_gemm_bf16_plan(uint32_t nq, uint32_t row_lo, uint32_t row_hi, int n_cus, Bf16GemmPlan* p);
+hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const uint16_t* rows16, uint64_t row_stride,
+                                       const float* norms, const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride,
+                                       const uint64_t* tau0, uint64_t* part_keys, uint32_t list_stride, uint32_t list_off,
+                                       uint32_t dim, uint32_t nq, uint32_t k, hipStream_t st);
+void launch_seed_tau(const uint64_t* ids, const float* scores, const uint32_t* n, uint64_t* tau0, uint64_t* list,
+                     uint32_t list_stride, uint32_t nq, uint32_t k, hipStream_t st);
 // bf16 GEMM-distance sweep (cosine / dot over a bf16 copy of the rows): nqt in {1, 2, 4, 6} 16-query tiles
 constexpr int kBf16WavesBig = 16;    // waves per block for nqt >= 4 (one block per CU)
 constexpr int kBf16WavesSmall = 8;   // ... for nqt <= 2
