@@ -1,0 +1,127 @@
+"""GPU parity tests of the split-bf16 selector behind large exact Cosine / DotProduct batches (sweep_split.hip): the
+matrix cores select on hi + lo bf16 images, the candidates are re-scored with the exact chain, every answer is proven
+or recomputed by the exact kernel.  Bar: ids, ranks and score BITS equal to the oracle's mode M (= the exact matrix-core
+kernel) — on random data (everything proven) and on data built to defeat the selection (near-duplicates closer than the
+error bound, massive exact ties, rows sorted by score, zero / huge / non-finite values, soft deletes)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+va = pytest.importorskip("velesdb_amd")
+DM = va.DistanceMetric
+NT = min(64, os.cpu_count() or 8)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def run_case(metric, rows, qs, k, expect_unproven=None, remove=()):
+    n, dim = rows.shape
+    pm = po.COSINE if metric == DM.Cosine else po.DOT
+    ids_ext = np.arange(n, dtype=np.uint64) * np.uint64(3) + np.uint64(11)
+    ix = va.HnswIndex(dim, metric, va.HnswParams(8, 50, n))
+    ix.upload(ids_ext, rows)
+    keep = np.ones(n, dtype=bool)
+    for r in remove:
+        assert ix.remove(int(ids_ext[r]))
+        keep[r] = False
+    assert ix.sweep_arith_mode(k) == "M"
+    va.set_split_selector(True)
+    ids, sc, cnt = ix.search_batch_brute_force(qs, k)
+    nq_last, unproven = ix.last_split_stats()
+    assert nq_last > 0, "the split selector did not run"
+    eid, esc = po.scan_topk(pm, rows[keep], qs, k, po.MODE_M, nthreads=NT)
+    emap = ids_ext[keep]
+    assert np.array_equal(ids, emap[eid.astype(np.int64)]), "ids / ranks differ from the oracle (mode M)"
+    assert np.array_equal(bits(sc), bits(esc)), "score bits differ from the oracle (mode M)"
+    assert np.all(cnt == k)
+    va.set_split_selector(False)
+    ids0, sc0, cnt0 = ix.search_batch_brute_force(qs, k)
+    va.set_split_selector(True)
+    assert np.array_equal(ids0, ids) and np.array_equal(bits(sc0), bits(sc)), "selector on / off disagree"
+    if expect_unproven == "none":
+        assert unproven == 0, f"{unproven} of {nq_last} queries fell back on well-separated data"
+    elif expect_unproven == "some":
+        assert unproven > 0, "the data was built to defeat the proof, yet every query was proven"
+    ix.close()
+    return unproven
+
+
+@pytest.mark.parametrize("metric", [DM.Cosine, DM.DotProduct])
+@pytest.mark.parametrize("n,dim,nq,k", [(70_000, 768, 256, 10), (150_001, 128, 1000, 10), (66_000, 64, 300, 1), (300_000, 96, 450, 7)])
+def test_random_data_proven_and_bit_exact(gpu_required, metric, n, dim, nq, k):
+    rng = np.random.default_rng(n + dim + int(metric))
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    run_case(metric, rows, qs, k, expect_unproven="none")
+
+
+@pytest.mark.parametrize("metric", [DM.Cosine, DM.DotProduct])
+def test_near_duplicates_fall_back_to_the_exact_kernel(gpu_required, metric):
+    # clouds of rows that differ from a query by 1e-6 relative: their scores sit far inside the selector's error bound
+    rng = np.random.default_rng(5)
+    n, dim, nq, k = 80_000, 256, 256, 10
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    for j in range(40):  # 40 queries get a cloud of 60 near-copies scattered over the corpus
+        where = rng.choice(n, 60, replace=False)
+        rows[where] = qs[j] * (1.0 + 1e-6 * rng.standard_normal((60, 1)).astype(np.float32)) + \
+            1e-6 * rng.standard_normal((60, dim)).astype(np.float32)
+    unproven = run_case(metric, rows, qs, k, expect_unproven="some")
+    assert unproven <= 60  # the other queries keep their proofs
+
+
+def test_massive_exact_ties_and_duplicates(gpu_required):
+    # 2 000 distinct rows repeated 40 times: every score is shared by 40 rows; the answer is the lowest row numbers
+    rng = np.random.default_rng(6)
+    dim, nq, k = 128, 256, 10
+    base = rng.standard_normal((2000, dim)).astype(np.float32)
+    rows = base[rng.integers(0, 2000, 80_000)]
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    run_case(DM.Cosine, rows, qs, k)
+    run_case(DM.DotProduct, rows, qs, k)
+
+
+def test_rows_sorted_by_score(gpu_required):
+    # every later row beats all earlier ones for query 0: every row tile floods the selection
+    rng = np.random.default_rng(7)
+    n, dim, nq, k = 70_000, 128, 256, 10
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    t = np.linspace(0.0, 1.0, n, dtype=np.float32)[:, None]
+    rows = (t * 4.0) * qs[0][None, :] + rng.standard_normal((n, dim)).astype(np.float32) * 0.05 + qs[0][None, :] * 0.01
+    run_case(DM.DotProduct, rows.astype(np.float32), qs, k)
+    run_case(DM.Cosine, rows.astype(np.float32), qs, k)
+
+
+def test_zero_huge_and_nonfinite_values(gpu_required):
+    rng = np.random.default_rng(8)
+    n, dim, nq, k = 70_000, 64, 256, 10
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    rows[rng.random(n) < 0.1] = 0.0                     # zero rows: cosine 0.0 by definition
+    rows[100] *= 1e18
+    rows[70_000 - 5] *= 1e-30                           # lo underflows
+    rows[200, 3] = np.inf
+    rows[300, 5] = np.nan
+    rows[20_000, 1] = -np.inf
+    qs[3] = 0.0
+    qs[4] *= 1e15
+    for metric in (DM.Cosine, DM.DotProduct):
+        run_case(metric, rows, qs, k)
+
+
+def test_soft_deleted_rows(gpu_required):
+    rng = np.random.default_rng(9)
+    n, dim, nq, k = 90_000, 96, 256, 10
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    # remove the best row of every 4th query and a stride of others
+    best = np.argmax(qs[::4] @ rows.T, axis=1)
+    remove = sorted(set(best.tolist()) | set(range(0, n, 997)))
+    run_case(DM.DotProduct, rows, qs, k, remove=remove)

@@ -18,6 +18,7 @@ static thread_local std::string g_last_error;
 static std::atomic<int> g_timing{0};
 static std::atomic<int> g_sweep_engine{1};  // 1 (default): MFMA kernel for cosine / dot (oracle mode M); 0: VALU kernels (mode C)
 static std::atomic<uint32_t> g_max_tile{128};  // largest query tile of the exact sweep (vdb_hip_set_max_query_tile)
+static std::atomic<int> g_split_selector{1};  // large exact Cosine / Dot batches: split-bf16 selection + exact re-scoring + proof
 static std::atomic<uint32_t> g_int8_oversampling{4};  // DualPrecisionConfig::default().oversampling_ratio (dual_precision.rs:57)
 
 void set_last_error(const std::string& s) { g_last_error = s; }
@@ -99,8 +100,11 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
       (e = ix->alive.reserve(ncap, true, st)) != hipSuccess ||
       (e = ix->ext_ids.reserve(ncap * 8, true, st)) != hipSuccess)
     return fail(e == hipErrorOutOfMemory ? VDB_ERR_OOM : VDB_ERR_HIP, std::string("grow: ") + hipGetErrorString(e));
-  if ((ix->metric == VDB_COSINE || ix->metric == VDB_EUCLIDEAN) && (e = ix->norms.reserve(ncap * 4, true, st)) != hipSuccess)
+  if ((ix->metric == VDB_COSINE || ix->metric == VDB_EUCLIDEAN || ix->split_enabled) &&
+      (e = ix->norms.reserve((ncap + kRowSlack) * 4, true, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("grow norms: ") + hipGetErrorString(e));
+  if (ix->split_enabled && (e = ix->rows_split.reserve((ncap + kRowSlack) * (size_t)ix->dim * 4, true, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("grow split rows: ") + hipGetErrorString(e));
   if (is_bits_metric(ix->metric) && (e = ix->bits.reserve(ncap * ix->words * 4, true, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("grow bits: ") + hipGetErrorString(e));
   if (ix->quantizer_trained && ((e = ix->codes.reserve(ncap * ix->code_words * 4, true, st)) != hipSuccess ||
@@ -127,7 +131,7 @@ static int32_t finish_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
   PrepArgs pa{};
   pa.rows = ix->rows.as<float>();
   // cosine: the kernels divide by them; Euclidean: |v|^2 of the matrix-core batch path (sweep_topk_gemm_f32<kEuclidean>)
-  pa.norms = (ix->metric == VDB_COSINE || ix->metric == VDB_EUCLIDEAN) ? ix->norms.as<float>() : nullptr;
+  pa.norms = (ix->metric == VDB_COSINE || ix->metric == VDB_EUCLIDEAN || ix->split_enabled) ? ix->norms.as<float>() : nullptr;
   pa.bits = is_bits_metric(ix->metric) ? ix->bits.as<uint32_t>() : nullptr;
   pa.row_stride = ix->row_stride;
   pa.row0 = (uint32_t)first;
@@ -143,6 +147,11 @@ static int32_t finish_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
     launch_prep_bf16(ix->rows.as<float>(), ix->row_stride, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride,
                      ix->norms_bf16.as<float>(), (uint32_t)first, (uint32_t)n, ix->dim, ix->stream);
     ix->bf16_rows = first + n;
+  }
+  if (ix->split_enabled) {
+    launch_split_vectors(ix->rows.as<float>(), ix->row_stride, ix->rows_split.as<uint16_t>(), nullptr, (uint32_t)first,
+                         (uint32_t)n, ix->dim, ix->stream);
+    ix->split_rows = first + n;
   }
   if (ix->storage_mode != VDB_STORAGE_FULL) {  // crud.rs:66-82: the quantised code is built with every upsert
     int32_t rs = storage_mode_append(ix, first, n);
@@ -400,6 +409,190 @@ static int blocks_for(const vdb_hip_index* ix, int B, uint32_t ngroups) {
   return (int)std::max<int64_t>(1, std::min(want, cap));
 }
 
+// ---- exact Cosine / DotProduct batches: split-bf16 selection + exact re-scoring + proof (sweep_split.hip) ----------------
+// first use: build the split image of every row (and the canonical norms a DotProduct index did not need so far)
+static int32_t ensure_split(vdb_hip_index* ix, hipStream_t st) {
+  if (!ix->split_enabled) {
+    hipError_t e = ix->rows_split.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * (size_t)ix->dim * 4, false, st);
+    if (e == hipSuccess) e = ix->norms.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * 4, ix->metric != VDB_DOT, st);
+    if (e != hipSuccess) return fail(VDB_ERR_OOM, std::string("split rows: ") + hipGetErrorString(e));
+    ix->split_enabled = true;
+    ix->split_rows = 0;
+  }
+  if (ix->split_rows < ix->n_rows) {
+    launch_split_vectors(ix->rows.as<float>(), ix->row_stride, ix->rows_split.as<uint16_t>(),
+                         ix->metric == VDB_DOT ? ix->norms.as<float>() : nullptr, (uint32_t)ix->split_rows,
+                         (uint32_t)(ix->n_rows - ix->split_rows), ix->dim, st);
+    ix->split_rows = ix->n_rows;
+    VDB_HIP(hipGetLastError());
+  }
+  return VDB_OK;
+}
+
+static bool split_path_ok(const vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
+  if (!g_split_selector || g_sweep_engine != 1 || g_max_tile < 128) return false;
+  if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT) return false;
+  if (ix->dim % 32 != 0 || ix->dim < 64 || ix->row_stride != ix->dim) return false;
+  if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return false;
+  const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
+  const uint32_t nqt_big = (nqg + 255) / 256;
+  return nqg >= kGemmBigMinQueries && (uint64_t)nqg * 8 >= (uint64_t)nqt_big * 256 * 7;  // fills its 256-query tiles to >= 7/8
+}
+
+static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, uint64_t* d_ids,
+                               float* d_scores, uint32_t* d_n, hipStream_t st) {
+  int32_t rc = ensure_split(ix, st);
+  if (rc != VDB_OK) return rc;
+  const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
+  const uint32_t n = (uint32_t)ix->n_rows, dim = ix->dim, K2 = kSplitPool;
+  // launch schedule (as the bf16 sweep): exact seed over [0, R0), selection over [R0, R1) and [R1, n)
+  const uint32_t R0 = kGemmBf16SeedRows;
+  uint32_t R1 = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(R0 + (1u << 18), R0 + (n / 16 + 255) / 256 * 256));
+  if (n - R1 < (1u << 18)) R1 = n;
+  Bf16GemmPlan bp[2];
+  int n_launch = 0;
+  sweep_gemm_bf16_plan(nqg, R0, R1, ix->n_cus, &bp[n_launch++]);
+  if (R1 < n) sweep_gemm_bf16_plan(nqg, R1, n, ix->n_cus, &bp[n_launch++]);
+  uint32_t lists = 1;
+  for (int j = 0; j < n_launch; j++) lists += bp[j].G;
+  GemmPlan sp, fp;  // exact kernel: seed sweep over the first rows; fallback over everything
+  sweep_gemm_plan(nqg, R0, ix->n_cus, k, &sp);
+  sweep_gemm_plan(nqg, n, ix->n_cus, k, &fp);
+  if (sp.lds > 160 * 1024 || fp.lds > 160 * 1024) return fail(VDB_ERR_UNSUPPORTED, "k too large for the fused top-k path");
+  // scratch map (s_seed)
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = (off + bytes + 15) & ~(size_t)15;
+    return o;
+  };
+  const size_t o_seedp = take((size_t)nqg * sp.G * k * 8), o_ids = take((size_t)nqg * K2 * 8), o_sc = take((size_t)nqg * K2 * 4),
+               o_n = take((size_t)nqg * 4), o_tau = take((size_t)nqg * 8), o_delta = take((size_t)nqg * 4),
+               o_qn = take((size_t)nqg * 4), o_flags = take((size_t)nqg * 4 + 64 * 4 + 16), o_btau = take((size_t)nqg * lists * 8),
+               o_fid = take((size_t)nqg * k * 8), o_fsc = take((size_t)nqg * k * 4), o_fn = take((size_t)nqg * 4);
+  hipError_t e;
+  if ((e = ix->s_seed.reserve(off, false, st)) != hipSuccess ||
+      (e = ix->s_part_keys.reserve((size_t)nqg * lists * k * 8, false, st)) != hipSuccess ||
+      (e = ix->s_fb_keys.reserve((size_t)nqg * fp.G * k * 8, false, st)) != hipSuccess ||
+      (e = ix->s_misc.reserve(((size_t)nqg + 256) * dim * 4, false, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, "split sweep scratch");
+  unsigned char* sd = ix->s_seed.as<unsigned char>();
+  uint64_t* pool = ix->s_part_keys.as<uint64_t>();
+  uint64_t* m_ids = reinterpret_cast<uint64_t*>(sd + o_ids);
+  float* m_sc = reinterpret_cast<float*>(sd + o_sc);
+  uint32_t* m_n = reinterpret_cast<uint32_t*>(sd + o_n);
+  uint64_t* tau0 = reinterpret_cast<uint64_t*>(sd + o_tau);
+  float* delta = reinterpret_cast<float*>(sd + o_delta);
+  float* qnorms = reinterpret_cast<float*>(sd + o_qn);
+  uint32_t* flags = reinterpret_cast<uint32_t*>(sd + o_flags);
+  uint32_t* tile_needed = flags + nqg;          // [<= 64]
+  uint32_t* norm_max = tile_needed + 64;
+  uint64_t* blk_tau = reinterpret_cast<uint64_t*>(sd + o_btau);
+  uint16_t* q16 = ix->s_misc.as<uint16_t>();
+
+  EventPair* ev = next_events(ix);
+  if (ev) (void)hipEventRecord(ev->a, st);
+  // queries: split image (+ canonical norms), zero rows behind the batch (the kernel stages whole 256-query tiles)
+  launch_split_vectors(d_q, q_stride, q16, qnorms, 0, nqg, dim, st);
+  VDB_HIP(hipMemsetAsync(q16 + (size_t)nqg * dim * 2, 0, (size_t)256 * dim * 4, st));
+  VDB_HIP(hipMemsetAsync(pool, 0xFF, (size_t)nqg * lists * k * 8, st));
+  VDB_HIP(hipMemsetAsync(blk_tau, 0xFF, (size_t)nqg * lists * 8, st));
+  VDB_HIP(hipMemsetAsync(flags, 0, (size_t)nqg * 4 + 64 * 4 + 16, st));
+  VDB_HIP(hipMemsetAsync(ix->s_fb_keys.p, 0xFF, (size_t)nqg * fp.G * k * 8, st));
+  if (ix->metric == VDB_DOT) launch_max_norm(ix->norms.as<float>(), n, norm_max, st);
+  // exact seed sweep over the first rows
+  SweepArgs ag{};
+  ag.rows = ix->rows.as<float>();
+  ag.norms = ix->norms.as<float>();
+  ag.alive = alive;
+  ag.queries = d_q;
+  ag.part_keys = reinterpret_cast<uint64_t*>(sd + o_seedp);
+  ag.row_stride = ix->row_stride;
+  ag.q_stride = q_stride;
+  ag.n_rows = R0;
+  ag.dim = dim;
+  ag.nq = nqg;
+  ag.k = k;
+  e = launch_sweep_gemm(ix->metric, sp, ag, st);
+  if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split seed sweep launch: ") + hipGetErrorString(e));
+  MergeArgs ms{};
+  ms.part_keys = ag.part_keys;
+  ms.ext_ids = nullptr;  // internal rows
+  ms.out_ids = m_ids;
+  ms.out_scores = m_sc;
+  ms.out_n = m_n;
+  ms.n_lists = sp.G;
+  ms.k = k;
+  launch_merge(true, ms, nqg, st);
+  launch_split_seed(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, dim, st);
+  // selection launches over the split images
+  uint32_t list_off = 1;
+  for (int j = 0; j < n_launch; j++) {
+    e = launch_sweep_gemm_bf16_glds(ix->metric, bp[j], ix->rows_split.as<uint16_t>(), (uint64_t)dim * 2, ix->norms.as<float>(), alive,
+                                    q16, (uint64_t)dim * 2, tau0, pool, lists, list_off, dim, nqg, k, st, /*split=*/true, qnorms,
+                                    blk_tau);
+    if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split selection launch: ") + hipGetErrorString(e));
+    list_off += bp[j].G;
+    if (j + 1 < n_launch) {  // bound of the next launch: k-th best pool score so far
+      ms.part_keys = pool;
+      ms.n_lists = lists;
+      launch_merge(true, ms, nqg, st);
+      launch_split_reseed(m_ids, m_sc, m_n, delta, tau0, nqg, k, k, st);
+    }
+  }
+  // pool -> K2 best by pool score -> exact re-scoring, ranking, proof
+  ms.part_keys = pool;
+  ms.n_lists = lists;
+  ms.k_out = K2;
+  launch_merge(true, ms, nqg, st);
+  SplitRerankArgs ra{};
+  ra.rows = ix->rows.as<float>();
+  ra.norms = ix->norms.as<float>();
+  ra.queries = d_q;
+  ra.qnorms = qnorms;
+  ra.cand_rows = m_ids;
+  ra.cand_scores = m_sc;
+  ra.cand_n = m_n;
+  ra.blk_tau = blk_tau;
+  ra.delta = delta;
+  ra.ext_ids = ix->ext_ids.as<uint64_t>();
+  ra.out_ids = d_ids;
+  ra.out_scores = d_scores;
+  ra.out_n = d_n;
+  ra.flags = flags;
+  ra.tile_needed = tile_needed;
+  ra.row_stride = ix->row_stride;
+  ra.q_stride = q_stride;
+  ra.dim = dim;
+  ra.dim_pad = (dim + 127) / 128 * 128;
+  ra.k = k;
+  ra.k2 = K2;
+  ra.lists = lists;
+  ra.fb_qper = fp.qper;
+  launch_split_rerank(ix->metric, ra, nqg, st);
+  // exact kernel for the query tiles that hold an unproven query (decided on the device), its result for those queries
+  ag.part_keys = ix->s_fb_keys.as<uint64_t>();
+  ag.n_rows = n;
+  e = launch_sweep_gemm(ix->metric, fp, ag, st, tile_needed);
+  if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("exact fallback launch: ") + hipGetErrorString(e));
+  MergeArgs mf{};
+  mf.part_keys = ag.part_keys;
+  mf.ext_ids = ix->ext_ids.as<uint64_t>();
+  mf.out_ids = reinterpret_cast<uint64_t*>(sd + o_fid);
+  mf.out_scores = reinterpret_cast<float*>(sd + o_fsc);
+  mf.out_n = reinterpret_cast<uint32_t*>(sd + o_fn);
+  mf.n_lists = fp.G;
+  mf.k = k;
+  launch_merge(true, mf, nqg, st);
+  launch_select_fallback(flags, mf.out_ids, mf.out_scores, mf.out_n, d_ids, d_scores, d_n, nqg, k, st);
+  ix->split_flags_off = o_flags;
+  ix->split_flags_n = nqg;
+  ix->split_flags_stream = st;
+  if (ev) (void)hipEventRecord(ev->b, st);
+  VDB_HIP(hipGetLastError());
+  return VDB_OK;
+}
+
 // HnswIndex::search_brute_force (search.rs:176-219) for nq device-resident queries.
 // Outputs are device buffers; nothing synchronises.
 static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k,
@@ -471,6 +664,16 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
       for (; want >= 1; want--)
         if (sweep_mfma_lds_bytes(want, k, ix->dim) <= 160 * 1024) break;
       mfma_nqt = want;  // 0: does not fit the LDS (very large dim or k): VALU kernels
+    }
+    // large Cosine / DotProduct batches over a large corpus: split-bf16 selection + exact re-scoring + proof (same bits
+    // as the exact matrix-core kernel below, which remains the fallback for unproven queries and every other shape)
+    if (mfma_nqt && split_path_ok(ix, nq - q0, k)) {
+      const uint32_t nqg = std::min<uint32_t>(nq - q0, kGemmMaxQueries);
+      const int32_t rcs = brute_split_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nqg, k, d_ids + (size_t)q0 * k,
+                                          d_scores + (size_t)q0 * k, d_n + q0, st);
+      if (rcs != VDB_OK) return rcs;
+      q0 += nqg;
+      continue;
     }
     // Euclidean batches: approximate selection of k + slack candidates on the matrix cores, canonical re-scoring, proof
     // of exactness per query; the (rare) unproven queries go through the exact vector-ALU sweep below
@@ -789,7 +992,7 @@ void destroy_single(vdb_hip_index* ix) {
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   proc_comm_free(ix->pcomm);
   for (DevBuf* b : {&ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids, &ix->rows_bf16, &ix->norms_bf16, &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits, &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq, &ix->s_queries, &ix->s_part_keys,
-                    &ix->s_part_cnt, &ix->s_seed, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels,
+                    &ix->s_part_cnt, &ix->s_seed, &ix->s_fb_keys, &ix->rows_split, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels,
                     &ix->s_req_keys, &ix->s_req_vals, &ix->s_sort_tmp})
     b->release();
   for (auto& L : ix->layers) {
@@ -889,6 +1092,32 @@ int32_t vdb_hip_set_sweep_engine(int32_t engine) {
   g_sweep_engine = engine;
   return VDB_OK;
   });
+}
+
+// diagnostic: how many queries of the last split-selector batch (its last <= 1024-query chunk) were answered by the exact
+// fallback kernel because their selection could not be proven
+int32_t vdb_hip_index_last_split_stats(vdb_hip_index* ix, uint32_t* queries, uint32_t* unproven) {
+  return vdb::guarded([&]() -> int32_t {
+    if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+    VDB_NO_GROUP(ix, "last_split_stats");
+    std::lock_guard<std::mutex> g(ix->mu);
+    VDB_HIP(hipSetDevice(ix->device));
+    uint32_t nq = ix->split_flags_n, bad = 0;
+    if (nq) {
+      std::vector<uint32_t> h(nq);
+      VDB_HIP(hipStreamSynchronize(ix->split_flags_stream));
+      VDB_HIP(hipMemcpy(h.data(), ix->s_seed.as<unsigned char>() + ix->split_flags_off, (size_t)nq * 4, hipMemcpyDeviceToHost));
+      for (uint32_t f : h) bad += f ? 1u : 0u;
+    }
+    if (queries) *queries = nq;
+    if (unproven) *unproven = bad;
+    return VDB_OK;
+  });
+}
+
+int32_t vdb_hip_set_split_selector(int32_t on) {
+  g_split_selector = on ? 1 : 0;
+  return VDB_OK;
 }
 
 int32_t vdb_hip_set_kernel_timing(int32_t on) {
@@ -1235,6 +1464,7 @@ int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
   ix->any_dead = false;
   ix->n_rows = 0;
   ix->bf16_rows = 0;
+  ix->split_rows = 0;
   const uint64_t cap = ix->capacity;
   ix->capacity = 0;  // re-reserve the per-row arrays (rows keep their buffer; the new layer arrays are allocated)
   int32_t rc = ensure_capacity(ix, std::max<uint64_t>(cap, 1));

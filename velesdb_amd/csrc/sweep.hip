@@ -800,12 +800,13 @@ __global__ __launch_bounds__(256) void merge_topk(MergeArgs m) {
   const int lane = lane_id();
   const int wib = (int)(threadIdx.x >> 6);
   const uint32_t qi = blockIdx.x;
-  const uint32_t k = m.k;
+  const uint32_t kin = m.k;                     // entries per partial list
+  const uint32_t k = m.k_out ? m.k_out : m.k;   // entries kept (k_out > k: a candidate pool for a re-scoring stage)
   volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k;
   volatile uint32_t* wcnt = reinterpret_cast<volatile uint32_t*>(smem + (size_t)4 * k * 8);
   uint32_t cnt = 0;
-  const uint64_t* keys = m.part_keys + (size_t)qi * m.n_lists * k;
-  const uint32_t total = m.n_lists * k;  // slots beyond a list's count hold kKeyInvalid
+  const uint64_t* keys = m.part_keys + (size_t)qi * m.n_lists * kin;
+  const uint32_t total = m.n_lists * kin;  // slots beyond a list's count hold kKeyInvalid
   // wave w scans the slice [lo, hi); 4 independent loads in flight per lane
   const uint32_t per = ((total + 3) / 4 + 255) / 256 * 256;
   const uint32_t lo = wib * per, hi = min(total, lo + per);
@@ -1059,11 +1060,7 @@ __global__ __launch_bounds__(256) void sweep_topk_bits_batch(BitsArgs a, uint32_
           const uint32_t uni = px[r] + pqb - inter[r][b];
           pass = !((float)inter[r][b] < __uint_as_float(tb) * (float)uni);  // union 0 (score 1.0): 0 >= 0 passes
         }
-#ifdef VDB_BITS_ABL_NOOFFER  // ablation (tools/probes): popcount + filter only
-        const uint64_t mask = __ballot(pass && valid[r] && inter[r][b] == 0xFFFFFFFFu);
-#else
         const uint64_t mask = __ballot(pass && valid[r]);
-#endif
         if (mask) bits_offer<METRIC>(lists + (size_t)b * k, &cnt[b], &lock[b], &thr[b], k, pqb, px[r], inter[r][b], row[r], mask, a.alive, lane);
       }
     }
@@ -1218,9 +1215,6 @@ __global__ __launch_bounds__(256) void sweep_topk_bits_tile(BitsArgs a, uint32_t
         pend[bit >> 5] |= (pass && valid[r]) ? (1u << (bit & 31)) : 0u;
       }
     }
-#ifdef VDB_BITS_ABL_NOOFFER  // ablation (tools/probes): popcount + filter only
-    pend[0] = pend[1] = 0u;
-#endif
     // ---- append / compact rounds ----
     for (;;) {
       ++token;
@@ -1674,8 +1668,13 @@ void launch_euclid_rerank(const EuclidRerankArgs& a, const float* norms, uint32_
   hipLaunchKernelGGL(euclid_rerank_verify, dim3(nq), dim3(256), 0, st, a);
 }
 
+void launch_max_norm(const float* norms, uint32_t n_rows, uint32_t* out_bits, hipStream_t st) {
+  (void)hipMemsetAsync(out_bits, 0, 4, st);
+  hipLaunchKernelGGL(max_norm_kernel, dim3(std::min<uint32_t>((n_rows + 255) / 256, 1024)), dim3(256), 0, st, norms, n_rows, out_bits);
+}
+
 void launch_merge(bool hib, const MergeArgs& m, uint32_t nq, hipStream_t st) {
-  const size_t lds = ((size_t)4 * m.k * 8 + 16 + 15) & ~(size_t)15;
+  const size_t lds = ((size_t)4 * (m.k_out ? m.k_out : m.k) * 8 + 16 + 15) & ~(size_t)15;
   if (hib)
     hipLaunchKernelGGL((merge_topk<true>), dim3(nq), dim3(256), lds, st, m);
   else

@@ -42,14 +42,8 @@
 #include "vdb_device.hpp"
 #include "vdb_kernels.hpp"
 
-// Ablation hooks for tools/probes/gemm_variants.sh (never defined in the product build):
-//   VDB_GEMM_ABL_NOEPI   skip filter/append/compaction (accumulators kept live)
-//   VDB_GEMM_ABL_NOMFMA  skip the multiply (staging + barriers only)
-//   VDB_GEMM_ABL_NOLOAD  skip the global loads (multiply + barriers only)
-//   VDB_GEMM_STATS       count epilogue rounds / appends / compactions / overflow failures (printed per launch)
-#ifndef VDB_GEMM_PRIO
+// wave priority outside the MFMA stream (see the s_setprio note in the main loop)
 #define VDB_GEMM_PRIO 2
-#endif
 namespace vdb {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -65,9 +59,7 @@ struct GemmSweepArgs {
   uint32_t nqt;    // query tiles
   uint32_t qper;   // queries per tile (<= 32 * NQF)
   uint32_t cap;    // candidate buffer entries per query (k < cap <= 64)
-#ifdef VDB_GEMM_STATS
-  unsigned long long* stats;  // [4] rounds, appends, compactions, failures
-#endif
+  const uint32_t* tile_needed;  // nullable: [nqt] a query tile with 0 here is skipped (device-driven fallback, sweep_split.hip)
 };
 
 // acc[rf][t][r] for a per-lane element index e = (rf*NQF + t)*4 + r, without dynamic register indexing: a binary
@@ -148,6 +140,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void sweep_topk_gem
   const uint32_t xcd = bid & 7u, slot_id = bid >> 3;
   const uint32_t qt = slot_id % ga.nqt;
   const uint32_t g = (slot_id / ga.nqt) * 8u + xcd;
+  if (ga.tile_needed && ga.tile_needed[qt] == 0u) return;  // block-uniform, before the first barrier
   const uint32_t q0 = qt * ga.qper;
   const uint32_t nq_t = min(ga.qper, a.nq - q0);
   const float* queries = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.queries) + (size_t)q0 * a.q_stride * ES);
@@ -305,9 +298,6 @@ _Pragma("unroll") \
   // `force`: every buffer holding more than k keys (overflow rounds, end of the sweep); otherwise only the
   // buffers past the watermark — a query's k-th best then lags behind, which costs a few more (cheap) appends
   // and saves most of the (expensive) compactions: ~4 per query and block instead of one per row tile.
-#ifdef VDB_GEMM_STATS
-  unsigned long long st_comp = 0, st_app = 0, st_fail = 0, st_rounds = 0;
-#endif
   const uint32_t watermark = (k + CAP) / 2;
   auto compact = [&](bool force) __attribute__((always_inline)) {
     // lane l looks at query wib + WAVES*l
@@ -327,9 +317,6 @@ _Pragma("unroll") \
       }
       const bool active = half == 0 || src1 != src0;  // odd count: the second half idles
       const uint32_t b = (uint32_t)wib + (uint32_t)WAVES * (uint32_t)(half ? src1 : src0);
-#ifdef VDB_GEMM_STATS
-      if (li == 0 && active) st_comp++;
-#endif
       const uint32_t n = min(cnts[b], CAP);
       uint64_t* cb = cand + (size_t)b * CAP;
       const uint64_t key = (active && li < n) ? cb[li] : kKeyInvalid;
@@ -362,20 +349,10 @@ _Pragma("unroll") \
   }
   __syncthreads();
   uint32_t kt = 0, rt = g;
-#ifdef VDB_GEMM_STATS
-  const long long t_start = clock64();
-  long long t_comp_s = 0, t_bar1_s = 0, t_store_s = 0, t_bar2_s = 0, n_steps = 0;
-  long long t_epi = 0, t_epi_first = 0, t_b1 = 0, t_filter = 0, t_finish = 0, t_compact = 0;
-#endif
   uint32_t token = 0;  // ++ per epilogue round, block-uniform: a value written to *ovf is never reused
   for (uint32_t it = 0; it < total; it++) {
     const bool more = it + 1 < total;
-#ifdef VDB_GEMM_STATS
-    const long long t_it0 = clock64();
-#endif
-#ifndef VDB_GEMM_ABL_NOLOAD
     if (more) VDB_GEMM_GLOAD();
-#endif
     // the row tile's norms: loaded here every step, written to LDS by the epilogue step in front of its first barrier.
     // Loaded unconditionally every step (clamped address, L2 hit): a conditional load would make hipcc wait
     // vmcnt(0) in front of the branch, i.e. for the tile loads just issued.
@@ -385,7 +362,6 @@ _Pragma("unroll") \
       vn_reg = a.norms[row < a.n_rows ? row : a.n_rows - 1];
       if (METRIC == kEuclidean) vn_reg *= vn_reg;  // |v|^2
     }
-#ifndef VDB_GEMM_ABL_NOMFMA
     {  // ---- multiply k-tile `it` out of LDS ----
       // rows 16 apart share the swizzle term, so the 4 / NQF fragment reads of a 16-deep group are one base +
       // immediate offsets; the second group flips bit 2 of the slot = byte 64 of the (swizzled) address.
@@ -437,62 +413,18 @@ _Pragma("unroll") \
       __builtin_amdgcn_s_setprio(VDB_GEMM_PRIO);
       }
     }
-#endif
-#ifdef VDB_GEMM_ABL_NOEPI
-    if (++kt == ga.KT) {
-#pragma unroll
-      for (int rf = 0; rf < RF; rf++)
-#pragma unroll
-        for (int t = 0; t < NQF; t++) asm volatile("" ::"v"(acc[rf][t]));
-      kt = 0;
-      rt += ga.G;
-    }
-    {
-      __syncthreads();
-      if (more) VDB_GEMM_LDS_STORE();
-      __syncthreads();
-      continue;
-    }
-#endif
     const bool vn_step = NORMS && kt + 2 == ga.KT;  // the step before the epilogue step stages the norms
     if (++kt < ga.KT) {
-#ifdef VDB_GEMM_STATS
-      {  // drain the matrix pipe first: the timestamp then marks the END of the multiply, not the end of its issue
-        float drain;
-        asm volatile("v_mov_b32 %0, %1\n\ts_nop 4" : "=v"(drain) : "v"(acc[RF - 1][NQF - 1][3]));
-        asm volatile("" ::"v"(drain));
-      }
-      const long long t_s0 = clock64();
-      t_comp_s += t_s0 - t_it0;
-#endif
       __syncthreads();  // every wave is done reading the tile
-#ifdef VDB_GEMM_STATS
-      const long long t_s1 = clock64();
-#endif
       if (more) VDB_GEMM_LDS_STORE();
       if (vn_step && tid < BM) vns[tid] = vn_reg;
-#ifdef VDB_GEMM_STATS
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      const long long t_s2 = clock64();
-#endif
       __syncthreads();
-#ifdef VDB_GEMM_STATS
-      const long long t_s3 = clock64();
-      t_bar1_s += t_s1 - t_s0; t_store_s += t_s2 - t_s1; t_bar2_s += t_s3 - t_s2; n_steps++;
-#endif
       continue;
     }
     // ---- last k-tile of a row tile: epilogue = filter, exact finish, append; compaction between the barriers ----
-#ifdef VDB_GEMM_STATS
-    const long long t_e0 = clock64();
-#endif
     if (NORMS && ga.KT < 2 && tid < BM) vns[tid] = vn_reg;  // single-k-tile rows: no earlier step to do it in
     __syncthreads();  // every wave is done reading the tile; norms visible
     if (more) VDB_GEMM_LDS_STORE();  // staging registers are dead from here on: the epilogue gets their 32 VGPRs
-#ifdef VDB_GEMM_STATS
-    long long t_p = clock64();
-    t_b1 += t_p - t_e0;
-#endif
     // (1a) filter, branch-free: one bit per accumulator element in a per-lane 64-bit mask, element e = (rf*NQF + t)*4
     //      + r shifted in at the bottom (so e = 63 - bit index ... see clz below).  Pass unless clearly below the
     //      query's k-th best (16-ulp margin); cosine compares dot * (1/|v|) with cut * |q|: NaN / inf / zero-norm
@@ -600,9 +532,6 @@ _Pragma("unroll") \
         if (has) wqueue[slot] = ((uint64_t)__float_as_uint(dv) << 32) | (lane_word + (((rf * 16u + r) << 8) + t * 16u));
         qn_ent += nh;
       }
-#ifdef VDB_GEMM_STATS
-      { const long long t_n = clock64(); t_filter += t_n - t_p; t_p = t_n; }
-#endif
       // (2) finish the queue densely, one entry per lane: exact score, key, candidate buffer of the entry's query
       qcarry = 0;
 #pragma unroll 1
@@ -626,9 +555,6 @@ _Pragma("unroll") \
             cand[(size_t)b * CAP + idx] = key;
           else
             full = true;  // candidate buffer full: keep the entry queued for the round after the compaction
-#ifdef VDB_GEMM_STATS
-          if (idx < CAP) st_app++; else st_fail++;
-#endif
         }
         const uint64_t mf = __ballot(full);
         if (mf) {
@@ -638,29 +564,13 @@ _Pragma("unroll") \
           failed = true;
         }
       }
-#ifdef VDB_GEMM_STATS
-      { const long long t_n = clock64(); t_finish += t_n - t_p; t_p = t_n; }
-#endif
       if (failed) *ovf = token;
-#ifdef VDB_GEMM_STATS
-      if (tid == 0) st_rounds++;
-#endif
       __syncthreads();  // appends visible
       const bool again = *ovf == token;
       compact(again || !more);
       __syncthreads();  // the compacted lists (and, first round, the next tile) visible
-#ifdef VDB_GEMM_STATS
-      { const long long t_n = clock64(); t_compact += t_n - t_p; t_p = t_n; }
-#endif
       if (!again) break;
     }
-#ifdef VDB_GEMM_STATS
-    {
-      const long long dt = clock64() - t_e0;
-      t_epi += dt;
-      if (rt == g) t_epi_first = dt;
-    }
-#endif
 #pragma unroll
     for (int rf = 0; rf < RF; rf++)
 #pragma unroll
@@ -668,32 +578,6 @@ _Pragma("unroll") \
     kt = 0;
     rt += ga.G;
   }
-#ifdef VDB_GEMM_STATS
-  if (st_rounds) atomicAdd(&ga.stats[0], st_rounds);
-  if (st_app) atomicAdd(&ga.stats[1], st_app);
-  if (st_comp) atomicAdd(&ga.stats[2], st_comp);
-  if (st_fail) atomicAdd(&ga.stats[3], st_fail);
-  if (tid == 0) {
-    atomicAdd(&ga.stats[4], (unsigned long long)t_epi);
-    atomicAdd(&ga.stats[5], (unsigned long long)(clock64() - t_start));
-    atomicAdd(&ga.stats[6], (unsigned long long)t_epi_first);
-    atomicAdd(&ga.stats[7], (unsigned long long)t_b1);
-    atomicAdd(&ga.stats[8], (unsigned long long)t_filter);
-    atomicAdd(&ga.stats[9], (unsigned long long)t_finish);
-    atomicAdd(&ga.stats[10], (unsigned long long)t_compact);
-    atomicAdd(&ga.stats[11], (unsigned long long)t_comp_s);
-    atomicAdd(&ga.stats[12], (unsigned long long)t_bar1_s);
-    atomicAdd(&ga.stats[13], (unsigned long long)t_store_s);
-    atomicAdd(&ga.stats[14], (unsigned long long)t_bar2_s);
-    atomicAdd(&ga.stats[15], (unsigned long long)n_steps);
-  }
-  if (lane == 0) {
-    atomicAdd(&ga.stats[16 + wib * 4 + 0], (unsigned long long)t_comp_s);
-    atomicAdd(&ga.stats[16 + wib * 4 + 1], (unsigned long long)t_bar1_s);
-    atomicAdd(&ga.stats[16 + wib * 4 + 2], (unsigned long long)t_store_s);
-    atomicAdd(&ga.stats[16 + wib * 4 + 3], (unsigned long long)t_bar2_s);
-  }
-#endif
   __syncthreads();
   for (uint32_t b = wib; b < nq_t; b += WAVES) {
     const uint32_t c = min(cnts[b], k);  // <= k entries: whatever order (the merge kernel scans them all)
@@ -755,37 +639,15 @@ static hipError_t launch_gemm_t(const GemmSweepArgs& ga, bool qvec, int blocks, 
   return qvec ? launch_gemm_v<METRIC, NQF, true, false, false>(ga, blocks, lds, st)
               : launch_gemm_v<METRIC, NQF, false, false, false>(ga, blocks, lds, st);
 }
-hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, hipStream_t st) {
+hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, hipStream_t st, const uint32_t* tile_needed) {
   GemmSweepArgs ga;
   ga.s = a;
+  ga.tile_needed = tile_needed;
   ga.KT = (a.dim + 127) / 128 * 4;
   ga.G = p.G;
   ga.nqt = p.nqt;
   ga.qper = p.qper;
   ga.cap = sweep_gemm_cap(a.k);
-#ifdef VDB_GEMM_STATS
-  static unsigned long long* d_stats = nullptr;
-  if (!d_stats) (void)hipMalloc(&d_stats, 256);
-  (void)hipMemsetAsync(d_stats, 0, 256, st);
-  ga.stats = d_stats;
-  struct Printer {
-    unsigned long long* d; hipStream_t st; uint32_t nq, blocks;
-    ~Printer() {
-      unsigned long long h[32];
-      (void)hipStreamSynchronize(st);
-      (void)hipMemcpy(h, d, 256, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[gemm stats] nq=%u blocks=%u rounds=%llu appends=%llu compactions=%llu failures=%llu | per block: "
-              "cycles=%.0f epilogue=%.0f (first tile %.0f) = barrier+store %.0f + filter %.0f + finish %.0f + sync/compact %.0f\n",
-              nq, blocks, h[0], h[1], h[2], h[3], (double)h[5] / blocks, (double)h[4] / blocks, (double)h[6] / blocks,
-              (double)h[7] / blocks, (double)h[8] / blocks, (double)h[9] / blocks, (double)h[10] / blocks);
-      fprintf(stderr, "[gemm stats] per regular step (wave 0): loads+multiply %.0f, barrier1 %.0f, wait+store %.0f, barrier2 %.0f cycles\n",
-              (double)h[11] / h[15], (double)h[12] / h[15], (double)h[13] / h[15], (double)h[14] / h[15]);
-      for (int w = 0; w < 4; w++)
-        fprintf(stderr, "[gemm stats]   wave %d: loads+multiply %.0f, barrier1 %.0f, wait+store %.0f, barrier2 %.0f\n", w,
-                (double)h[16 + w * 4] / h[15], (double)h[17 + w * 4] / h[15], (double)h[18 + w * 4] / h[15], (double)h[19 + w * 4] / h[15]);
-    }
-  } printer{d_stats, st, a.nq, (uint32_t)p.blocks};
-#endif
   // queries readable as aligned float4?
   const bool qvec = a.dim % 4 == 0 && a.q_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.queries) & 15) == 0;
   if (p.big) return hipErrorInvalidValue;  // the 256 x 256 tile is a bf16 instance only (f32: measured no gain)
@@ -859,9 +721,7 @@ hipError_t launch_sweep_gemm_bf16(int metric, const GemmPlan& p, const uint16_t*
   ga.nqt = p.nqt;
   ga.qper = p.qper;
   ga.cap = sweep_gemm_cap(k);
-#ifdef VDB_GEMM_STATS
-  ga.stats = nullptr;
-#endif
+  ga.tile_needed = nullptr;
   if (p.big)
     return metric == kCosine ? launch_gemm_v<kCosine, 4, true, true, true, 8, 8>(ga, p.blocks, p.lds, st)
                              : launch_gemm_v<kDot, 4, true, true, true, 8, 8>(ga, p.blocks, p.lds, st);

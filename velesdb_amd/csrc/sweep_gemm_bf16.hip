@@ -61,6 +61,9 @@ struct Bf16GemmArgs {
   uint32_t KT, G, nqt, qper;
   uint32_t row_tile0;       // first 256-row tile of the row range
   uint32_t list_stride, list_off;
+  // SPLIT instance only (exact-f32 selection, see sweep_split.hip)
+  const float* qnorms;      // [nq] canonical f32 norms of the ORIGINAL queries (cosine)
+  uint64_t* blk_tau;        // [nq][list_stride]: the bound this block ends with per query (kKeyInvalid: it excluded nothing)
 };
 
 // The lane id, re-derived where it is needed: a value computed from threadIdx before the main loop stays live across it,
@@ -104,7 +107,12 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base) {  // raw buffer, b
 }
 __device__ __forceinline__ void wait_glds() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int METRIC>
+// SPLIT: the same kernel as the SELECTION stage of the exact f32 sweep.  Rows and queries arrive as split bf16 — per 32
+// elements 64 B of `hi` (the value rounded to bf16) followed by 64 B of `lo` (the remainder rounded to bf16), i.e. the same
+// 128 B per row and k-tile — and a k-tile contributes hi.hi + hi.lo + lo.hi (three MFMAs per accumulator tile instead of
+// two halves of one): x.q to ~2^-16 relative to |x||q| at 3/16 of the f32 matrix pipe's cost.  Scores are approximate;
+// sweep_split.hip re-scores the survivors exactly and proves the selection (or sends the query to the exact kernel).
+template <int METRIC, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs a) {
   constexpr bool HIB = true;  // Cosine / DotProduct
   constexpr int BM = kG16BM, BN = kG16BN, WAVES = kG16Waves, CAP = kG16Cap, QCAP = kG16Queue;
@@ -141,8 +149,10 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs
   }
   if (tid < 4) flags[tid] = 0u;
   __syncthreads();
-  {  // norm of the ROUNDED query, canonical lane-chain order (as sweep_topk_mfma_bf16); DotProduct keeps it for the
-     // overflow guard of the quick test only
+  if (SPLIT) {  // the caller computed the canonical norms of the f32 queries (what the exact score divides by)
+    if ((uint32_t)tid < nq_t && a.qnorms) qn[tid] = a.qnorms[q0 + tid];
+  } else {  // norm of the ROUNDED query, canonical lane-chain order (as sweep_topk_mfma_bf16); DotProduct keeps it for the
+            // overflow guard of the quick test only
     for (uint32_t b = wib; b < nq_t; b += WAVES) {
       const uint16_t* qp = queries + (size_t)b * a.q_stride;
       float nacc = 0.0f;
@@ -260,21 +270,56 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs
     const int a_rd0 = wr * 128 * 128 + rd_off; \
     const int b_rd0 = 32768 + wq * 64 * 128 + rd_off; \
     const unsigned char* tb = smem + (size_t)buf * 65536; \
+    if (!SPLIT) { \
 _Pragma("unroll") \
-    for (int m = 0; m < 2; m++) { \
-      f32x4 av[8], bv[4]; \
+      for (int m = 0; m < 2; m++) { \
+        f32x4 av[8], bv[4]; \
 _Pragma("unroll") \
-      for (int t = 0; t < 4; t++) bv[t] = *reinterpret_cast<const f32x4*>(tb + b_rd0 + ((m * 64) ^ rd_x) + t * 2048); \
+        for (int t = 0; t < 4; t++) bv[t] = *reinterpret_cast<const f32x4*>(tb + b_rd0 + ((m * 64) ^ rd_x) + t * 2048); \
 _Pragma("unroll") \
-      for (int rf = 0; rf < 8; rf++) av[rf] = *reinterpret_cast<const f32x4*>(tb + a_rd0 + ((m * 64) ^ rd_x) + rf * 2048); \
+        for (int rf = 0; rf < 8; rf++) av[rf] = *reinterpret_cast<const f32x4*>(tb + a_rd0 + ((m * 64) ^ rd_x) + rf * 2048); \
 _Pragma("unroll") \
-      for (int rf = 0; rf < 8; rf++) { \
+        for (int rf = 0; rf < 8; rf++) { \
 _Pragma("unroll") \
-        for (int t = 0; t < 4; t++) { \
-          if ((FIRST) && m == 0) mfma_bf16_first(acc[rf][t], av[rf], bv[t]); \
-          else mfma_bf16_inplace(acc[rf][t], av[rf], bv[t]); \
+          for (int t = 0; t < 4; t++) { \
+            if ((FIRST) && m == 0) mfma_bf16_first(acc[rf][t], av[rf], bv[t]); \
+            else mfma_bf16_inplace(acc[rf][t], av[rf], bv[t]); \
+          } \
+          if (m == 0) VDB_G16_GLDS(rf); \
         } \
-        if (m == 0) VDB_G16_GLDS(rf); \
+      } \
+    } else { /* half 0 of the line = hi, half 1 = lo; per pair of row fragments: hi.hi, hi.lo, lo.hi (8 MFMAs each) */ \
+      f32x4 bh[4], bl[4]; \
+_Pragma("unroll") \
+      for (int t = 0; t < 4; t++) { \
+        bh[t] = *reinterpret_cast<const f32x4*>(tb + b_rd0 + (0 ^ rd_x) + t * 2048); \
+        bl[t] = *reinterpret_cast<const f32x4*>(tb + b_rd0 + (64 ^ rd_x) + t * 2048); \
+      } \
+_Pragma("unroll") \
+      for (int rp = 0; rp < 4; rp++) { \
+        f32x4 ah[2], al[2]; \
+_Pragma("unroll") \
+        for (int i = 0; i < 2; i++) { \
+          ah[i] = *reinterpret_cast<const f32x4*>(tb + a_rd0 + (0 ^ rd_x) + (rp * 2 + i) * 2048); \
+          al[i] = *reinterpret_cast<const f32x4*>(tb + a_rd0 + (64 ^ rd_x) + (rp * 2 + i) * 2048); \
+        } \
+_Pragma("unroll") \
+        for (int i = 0; i < 2; i++) \
+_Pragma("unroll") \
+          for (int t = 0; t < 4; t++) { \
+            if (FIRST) mfma_bf16_first(acc[rp * 2 + i][t], ah[i], bh[t]); \
+            else mfma_bf16_inplace(acc[rp * 2 + i][t], ah[i], bh[t]); \
+          } \
+        VDB_G16_GLDS(rp * 2); \
+_Pragma("unroll") \
+        for (int i = 0; i < 2; i++) \
+_Pragma("unroll") \
+          for (int t = 0; t < 4; t++) mfma_bf16_inplace(acc[rp * 2 + i][t], ah[i], bl[t]); \
+        VDB_G16_GLDS(rp * 2 + 1); \
+_Pragma("unroll") \
+        for (int i = 0; i < 2; i++) \
+_Pragma("unroll") \
+          for (int t = 0; t < 4; t++) mfma_bf16_inplace(acc[rp * 2 + i][t], al[i], bh[t]); \
       } \
     } \
     VDB_G16_ADVANCE(); \
@@ -445,6 +490,7 @@ _Pragma("unroll") \
     const uint32_t c = min(cnts[b], k);  // <= k entries, whatever order (the merge kernel scans them all)
     uint64_t* out = a.part_keys + ((size_t)(q0 + b) * a.list_stride + a.list_off + g) * k;
     for (uint32_t e = lane_o; e < k; e += 64) out[e] = e < c ? cand[(size_t)b * CAP + e] : kKeyInvalid;
+    if (SPLIT && lane_o == 0) a.blk_tau[(size_t)(q0 + b) * a.list_stride + a.list_off + g] = tauk[b];
   }
 }
 
@@ -482,10 +528,26 @@ void sweep_gemm_bf16_plan(uint32_t nq, uint32_t row_lo, uint32_t row_hi, int n_c
   p->blocks = (int)(G * p->nqt);
 }
 
+template <int METRIC, bool SPLIT>
+static hipError_t launch_g16(const Bf16GemmArgs& a, int blocks, hipStream_t st) {
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_gemm_bf16_glds<METRIC, SPLIT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  hipLaunchKernelGGL((sweep_topk_gemm_bf16_glds<METRIC, SPLIT>), dim3(blocks), dim3(512), kG16Lds, st, a);
+  return hipGetLastError();
+}
+
+// split == false: rows16 / queries16 are bf16, strides in elements, k-tiles of 64 (dim % 64 == 0, dim >= 128).
+// split == true: split-bf16 images (sweep_split.hip), strides = 2 dim, k-tiles of 32 elements (dim % 32 == 0, dim >= 64).
 hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const uint16_t* rows16, uint64_t row_stride,
                                        const float* norms, const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride,
                                        const uint64_t* tau0, uint64_t* part_keys, uint32_t list_stride, uint32_t list_off,
-                                       uint32_t dim, uint32_t nq, uint32_t k, hipStream_t st) {
+                                       uint32_t dim, uint32_t nq, uint32_t k, hipStream_t st, bool split, const float* qnorms,
+                                       uint64_t* blk_tau) {
   Bf16GemmArgs a{};
   a.rows = rows16;
   a.norms = norms;
@@ -502,26 +564,15 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
   a.dim = dim;
   a.nq = nq;
   a.k = k;
-  a.KT = dim / 64;
+  a.KT = split ? dim / 32 : dim / 64;
   a.G = p.G;
   a.nqt = p.nqt;
   a.qper = p.qper;
-  static bool done[2] = {false, false};
-  const int mi = metric == kCosine ? 0 : 1;
-  if (!done[mi]) {
-    hipError_t e = metric == kCosine
-                       ? hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_gemm_bf16_glds<kCosine>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                       : hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_gemm_bf16_glds<kDot>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    done[mi] = true;
-  }
-  if (metric == kCosine)
-    hipLaunchKernelGGL((sweep_topk_gemm_bf16_glds<kCosine>), dim3(p.blocks), dim3(512), kG16Lds, st, a);
-  else
-    hipLaunchKernelGGL((sweep_topk_gemm_bf16_glds<kDot>), dim3(p.blocks), dim3(512), kG16Lds, st, a);
-  return hipGetLastError();
+  a.qnorms = qnorms;
+  a.blk_tau = blk_tau;
+  if (split)
+    return metric == kCosine ? launch_g16<kCosine, true>(a, p.blocks, st) : launch_g16<kDot, true>(a, p.blocks, st);
+  return metric == kCosine ? launch_g16<kCosine, false>(a, p.blocks, st) : launch_g16<kDot, false>(a, p.blocks, st);
 }
 
 }  // namespace vdb

@@ -1,0 +1,247 @@
+// sweep_split.hip — exact f32 Cosine / DotProduct search for LARGE query batches at bf16 matrix-core speed
+// (HnswIndex::search_brute_force over a batch, index/hnsw/index/search.rs:176-219; BASELINE configs[1]).
+//
+// The exact f32 contraction runs on v_mfma_f32_16x16x4_f32 at 1/16 of the bf16 matrix rate (sweep_gemm.hip: 0.77 of that
+// pipe = 79 K queries/s at 1 M x 768).  Here the matrix cores only SELECT:
+//   1. every row (once, at insert) and every query (per batch) is split x = hi + lo + e, hi = bf16(x), lo = bf16(x - hi),
+//      |e| <= 2^-18 |x|; the selection kernel (sweep_gemm_bf16.hip, SPLIT instance) accumulates hi.hi + hi.lo + lo.hi in
+//      f32: an approximation A(x, q) of x.q with |A - x.q| <= eps |x| |q|, eps = 3.1 * 2^-18 + 16 dim 2^-24 (the split
+//      remainder + a 4x padded worst case for the f32 accumulation inside and between the MFMAs, whose internal order is
+//      not documented).  It keeps, per block, the k best rows by approximate score under thresholds seeded by an EXACT
+//      sweep of the first rows (threshold lowered by the error bound).
+//   2. the per-block lists are merged to the K2 = 32 best by approximate score; split_rerank_verify re-scores those with
+//      the canonical chain of the exact kernels (oracle mode M: one fmaf chain per pair in the matrix-core order
+//      k = 128 U + 16 m + 4 kk + c) — the reported ids, ranks and score bits are the exact kernel's, bit for bit;
+//   3. and PROVES the answer per query: every row that was left out — by a block's threshold or by the cut at K2 — has
+//      an approximate score <= B, hence an exact score <= B + delta; if the k-th best exact score is above that, nothing
+//      outside can belong to the top k.  A query without proof (near-ties closer than the bound, non-finite data) is
+//      flagged; the exact matrix-core kernel then runs for the 128-query tiles that contain a flagged query — decided on
+//      the device (tile_needed), no host synchronisation — and select_fallback keeps its result for the flagged queries.
+#include <algorithm>
+
+#include "vdb_device.hpp"
+#include "vdb_kernels.hpp"
+
+namespace vdb {
+
+__device__ __forceinline__ uint16_t bf16_rne(float x) {  // round to nearest even; NaN stays (quiet) NaN
+  uint32_t u = __float_as_uint(x);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((u >> 16) | 0x0040u);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// One wave per vector: the split image (per 32 elements: 32 x hi then 32 x lo, 128 bytes) and, optionally, the canonical
+// norm (the chain of prep_rows: the value the exact kernels divide by).  dim % 32 == 0.
+__global__ __launch_bounds__(256) void split_vectors_kernel(const float* src, uint64_t src_stride, uint16_t* out, float* norms,
+                                                            uint32_t row0, uint32_t n, uint32_t dim) {
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4;
+  for (uint32_t r = wave; r < n; r += nwaves) {
+    const uint32_t row = row0 + r;
+    const float* p = src + (size_t)row * src_stride;
+    uint16_t* o = out + (size_t)row * dim * 2;
+    float acc = 0.0f;
+    for (uint32_t c = lane; c * 4 < dim; c += 64) {  // chunk c = elements 4c .. 4c + 3 (canonical lane assignment)
+      const float4 x = ld4(p + c * 4);
+      acc = chain4<kOpDot>(acc, x, x);
+      const float xs[4] = {x.x, x.y, x.z, x.w};
+      uint16_t hi[4], lo[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        hi[e] = bf16_rne(xs[e]);
+        lo[e] = bf16_rne(xs[e] - __uint_as_float((uint32_t)hi[e] << 16));  // the difference is exact in f32
+      }
+      const uint32_t k0 = c * 4, u = k0 >> 5, j = k0 & 31u;
+      uint16_t* oh = o + u * 64 + j;
+      *reinterpret_cast<uint2*>(oh) = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+      *reinterpret_cast<uint2*>(oh + 32) = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+    }
+    if (norms) {
+      const float nn = sqrtf(butterfly_all(acc));
+      if (lane == 0) norms[row] = nn;
+    }
+  }
+}
+void launch_split_vectors(const float* src, uint64_t src_stride, uint16_t* out, float* norms, uint32_t row0, uint32_t n,
+                          uint32_t dim, hipStream_t st) {
+  if (n == 0) return;
+  const int blocks = (int)std::min<uint64_t>(((uint64_t)n + 3) / 4, 4096);
+  hipLaunchKernelGGL(split_vectors_kernel, dim3(blocks), dim3(256), 0, st, src, src_stride, out, norms, row0, n, dim);
+}
+
+__host__ __device__ inline float split_eps(uint32_t dim) { return 3.1f * 3.8146973e-6f + 16.0f * (float)dim * 5.9604645e-8f; }
+
+// Seed from the EXACT sweep of the first rows (merged to rows + raw scores, best first): list slot 0 of the candidate pool
+// = its top k as keys (they are exact scores: re-scoring them later reproduces them), the query's error bound
+// delta (cosine: eps; dot: eps |q| max|v|), and the selection kernel's starting bound = k-th best exact score lowered by
+// delta (a row whose APPROXIMATE score is below that has an exact score below k rows of the prefix).
+template <int METRIC>
+__global__ __launch_bounds__(256) void split_seed_kernel(const uint64_t* ids, const float* scores, const uint32_t* n,
+                                                         const float* qnorms, const uint32_t* norm_max_bits, uint64_t* tau0,
+                                                         float* delta, uint64_t* list, uint64_t* blk_tau, uint32_t list_stride,
+                                                         uint32_t nq, uint32_t k, uint32_t dim) {
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  const float eps = split_eps(dim);
+  const float d = METRIC == kCosine ? eps * 1.001f + 4e-7f : eps * 1.001f * qnorms[q] * __uint_as_float(*norm_max_bits) + 1e-30f;
+  delta[q] = d;
+  const uint32_t c = min(n[q], k);
+  uint64_t t = kKeyInvalid;
+  if (c >= k && k > 0) {
+    const float s = scores[(size_t)q * k + k - 1];
+    const float lowered = s - d * 1.01f - fabsf(s) * 1e-6f;
+    t = lowered == lowered ? make_key<true>(lowered, 0u) : kKeyInvalid;  // NaN: no bound
+  }
+  tau0[q] = t;
+  for (uint32_t e = 0; e < k; e++)
+    list[(size_t)q * list_stride * k + e] = e < c ? make_key<true>(scores[(size_t)q * k + e], (uint32_t)ids[(size_t)q * k + e]) : kKeyInvalid;
+  blk_tau[(size_t)q * list_stride] = kKeyInvalid;  // slot 0 = the seed rows: excluded exactly, no bound needed
+}
+void launch_split_seed(int metric, const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
+                       const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
+                       uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t dim, hipStream_t st) {
+  if (metric == kCosine)
+    hipLaunchKernelGGL((split_seed_kernel<kCosine>), dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits,
+                       tau0, delta, list, blk_tau, list_stride, nq, k, dim);
+  else
+    hipLaunchKernelGGL((split_seed_kernel<kDot>), dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits,
+                       tau0, delta, list, blk_tau, list_stride, nq, k, dim);
+}
+
+// Between two selection launches: the next launch's bound = k-th best POOL score so far (approximate scores, exact ones for
+// slot 0), lowered by delta when it is an exact score's turn to bound approximate ones — simply always (it costs a sliver
+// of tightness).
+__global__ __launch_bounds__(256) void split_reseed_kernel(const uint64_t* ids, const float* scores, const uint32_t* n,
+                                                           const float* delta, uint64_t* tau0, uint32_t nq, uint32_t k, uint32_t kout) {
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  uint64_t t = kKeyInvalid;
+  if (n[q] >= k && k > 0) {
+    const float s = scores[(size_t)q * kout + k - 1];
+    const float lowered = s - 2.0f * delta[q] * 1.01f - fabsf(s) * 1e-6f;  // pool scores may err by delta either way
+    t = lowered == lowered ? make_key<true>(lowered, 0u) : kKeyInvalid;
+  }
+  tau0[q] = t;
+}
+void launch_split_reseed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* delta, uint64_t* tau0,
+                         uint32_t nq, uint32_t k, uint32_t kout, hipStream_t st) {
+  hipLaunchKernelGGL(split_reseed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, delta, tau0, nq, k, kout);
+}
+
+// One block per query: exact re-scoring of the K2 best of the pool, ranking, proof.  See the file header.
+template <int METRIC>
+__global__ __launch_bounds__(256) void split_rerank_verify(SplitRerankArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* qs = reinterpret_cast<float*>(smem);                    // [dim padded to 128]
+  uint64_t* keys = reinterpret_cast<uint64_t*>(qs + a.dim_pad);  // [K2]
+  unsigned long long* bmin = reinterpret_cast<unsigned long long*>(keys + a.k2);
+  const uint32_t tid = threadIdx.x, qi = blockIdx.x;
+  const uint32_t n = min(a.cand_n[qi], a.k2);
+  const float* q = a.queries + (size_t)qi * a.q_stride;
+  for (uint32_t i = tid; i < a.dim_pad; i += 256) qs[i] = i < a.dim ? q[i] : 0.0f;
+  if (tid == 0) *bmin = ~0ull;
+  __syncthreads();
+  // the bound the blocks ended with: the best (smallest key) of them; slot 0 (exact seed rows) holds kKeyInvalid
+  {
+    unsigned long long m = ~0ull;
+    for (uint32_t g = tid; g < a.lists; g += 256) m = min(m, (unsigned long long)a.blk_tau[(size_t)qi * a.lists + g]);
+    if (m != ~0ull) atomicMin(bmin, m);
+  }
+  const float qn = METRIC == kCosine ? a.qnorms[qi] : 0.0f;
+  if (tid < n) {
+    const uint32_t row = (uint32_t)a.cand_rows[(size_t)qi * a.k2 + tid];
+    const float* p = a.rows + (size_t)row * a.row_stride;
+    // oracle mode M (vdb_oracle.cpp dotM; sweep_topk_gemm_f32): ONE fmaf chain over k = 128 U + 16 m + 4 kk + c in the
+    // order U, m, c, kk, the vector zero-padded to a multiple of 128 (the padding steps are part of the chain)
+    float acc = 0.0f;
+    for (uint32_t U = 0; U < a.dim_pad; U += 128)
+      for (uint32_t m = 0; m < 8; m++) {
+        const uint32_t base = U + 16 * m;
+        float x[16];
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+          if (base + e < a.dim) {  // dim % 4 == 0 (split path: dim % 32 == 0): whole float4 in range
+            const float4 v = ld4(p + base + e);
+            x[e] = v.x; x[e + 1] = v.y; x[e + 2] = v.z; x[e + 3] = v.w;
+          } else {
+            x[e] = x[e + 1] = x[e + 2] = x[e + 3] = 0.0f;
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) acc = __builtin_fmaf(x[4 * kk + c], qs[base + 4 * kk + c], acc);
+      }
+    const float score = finish_score<METRIC>(acc, qn, METRIC == kCosine ? a.norms[row] : 1.0f);
+    keys[tid] = make_key<true>(score, row);
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  const int lane = (int)tid;
+  const uint64_t key = (uint32_t)lane < n ? keys[lane] : kKeyInvalid;
+  uint32_t rank = 0;
+  for (uint32_t j = 0; j < n; j++) rank += keys[j] < key ? 1u : 0u;
+  // lane e picks up the candidate of rank e (ranks are a permutation of 0..n-1: keys are unique)
+  uint32_t mine = 0;
+  for (uint32_t j = 0; j < n; j++) {
+    const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)rank, (int)j);
+    if (rj == (uint32_t)lane) mine = j;
+  }
+  const uint32_t kk = min(a.k, n);
+  bool ok = n >= a.k && a.k > 0;
+  if (ok) {
+    const float neg_inf = __uint_as_float(0xFF800000u);
+    const unsigned long long bm = *bmin;
+    const float a_blocks = bm == ~0ull ? neg_inf : key_score<true>((uint64_t)bm);
+    const float a_cut = n == a.k2 ? a.cand_scores[(size_t)qi * a.k2 + a.k2 - 1] : neg_inf;  // pool score of the last one kept
+    const float A = fmaxf(a_blocks, a_cut) == fmaxf(a_blocks, a_cut) ? fmaxf(a_blocks, a_cut) : __uint_as_float(0x7FC00000u);
+    const bool anan = a_blocks != a_blocks || a_cut != a_cut;
+    const uint64_t kth = keys[__builtin_amdgcn_readlane((int)mine, (int)(a.k - 1))];
+    const double Ek = (double)key_score<true>(kth);
+    ok = !anan && Ek > (double)A + (double)a.delta[qi];  // false for NaN anywhere
+  }
+  if (lane == 0) {
+    a.flags[qi] = ok ? 0u : 1u;
+    if (!ok) a.tile_needed[qi / a.fb_qper] = 1u;
+    a.out_n[qi] = kk;
+  }
+  for (uint32_t e = lane; e < a.k; e += 64) {
+    if (e < kk) {
+      const uint64_t ke = keys[mine];
+      const uint32_t row = key_row(ke);
+      a.out_ids[(size_t)qi * a.k + e] = a.ext_ids ? a.ext_ids[row] : (uint64_t)row;
+      a.out_scores[(size_t)qi * a.k + e] = key_score<true>(ke);
+    } else {
+      a.out_ids[(size_t)qi * a.k + e] = ~0ull;
+      a.out_scores[(size_t)qi * a.k + e] = __uint_as_float(0x7FC00000u);
+    }
+  }
+}
+void launch_split_rerank(int metric, const SplitRerankArgs& a, uint32_t nq, hipStream_t st) {
+  const size_t lds = ((size_t)a.dim_pad * 4 + (size_t)a.k2 * 8 + 16 + 15) & ~(size_t)15;
+  if (metric == kCosine)
+    hipLaunchKernelGGL((split_rerank_verify<kCosine>), dim3(nq), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL((split_rerank_verify<kDot>), dim3(nq), dim3(256), lds, st, a);
+}
+
+// flagged queries take the exact kernel's result
+__global__ __launch_bounds__(256) void select_fallback_kernel(const uint32_t* flags, const uint64_t* fb_ids, const float* fb_scores,
+                                                              const uint32_t* fb_n, uint64_t* out_ids, float* out_scores,
+                                                              uint32_t* out_n, uint32_t nq, uint32_t k) {
+  const uint32_t q = blockIdx.x;
+  if (q >= nq || !flags[q]) return;
+  for (uint32_t e = threadIdx.x; e < k; e += 256) {
+    out_ids[(size_t)q * k + e] = fb_ids[(size_t)q * k + e];
+    out_scores[(size_t)q * k + e] = fb_scores[(size_t)q * k + e];
+  }
+  if (threadIdx.x == 0) out_n[q] = fb_n[q];
+}
+void launch_select_fallback(const uint32_t* flags, const uint64_t* fb_ids, const float* fb_scores, const uint32_t* fb_n,
+                            uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint32_t nq, uint32_t k, hipStream_t st) {
+  hipLaunchKernelGGL(select_fallback_kernel, dim3(nq), dim3(256), 0, st, flags, fb_ids, fb_scores, fb_n, out_ids, out_scores, out_n, nq, k);
+}
+
+}  // namespace vdb

@@ -111,6 +111,14 @@ struct vdb_hip_index {
   bool bf16_enabled = false;
   uint64_t bf16_stride = 0;  // bf16 elements per row (multiple of 8)
   uint64_t bf16_rows = 0;    // rows converted so far
+  // split-bf16 image of the f32 rows (hi + lo per element, 4 bytes like the f32 row: sweep_split.hip), built at the first
+  // large exact Cosine / DotProduct batch and kept up to date from then on
+  vdb::DevBuf rows_split;
+  bool split_enabled = false;
+  uint64_t split_rows = 0;   // rows converted so far
+  size_t split_flags_off = 0;     // where the last split batch left its per-query verdicts in s_seed
+  uint32_t split_flags_n = 0;
+  hipStream_t split_flags_stream = nullptr;
   // optional quantised copy of the rows per StorageMode (storage_modes.hip; core/quantization.rs)
   int32_t storage_mode = 0;      // VDB_STORAGE_FULL
   uint64_t sq8_stride = 0;       // bytes per SQ8 row (multiple of 16)
@@ -132,6 +140,7 @@ struct vdb_hip_index {
 
   // scratch
   vdb::DevBuf s_queries, s_part_keys, s_part_cnt, s_out_ids, s_out_scores, s_out_n, s_qbits, s_misc;
+  vdb::DevBuf s_fb_keys;  // partial lists of the exact fallback launch behind the split-bf16 selection
   vdb::DevBuf s_seed;  // seeding pre-pass of the bf16 GEMM sweep: partial lists, merged prefix top-k, seed keys
   uint64_t euclid_fallbacks = 0;  // queries of Euclidean matrix-core batches re-run through the exact sweep (diagnostic)
   vdb::DevBuf s_visited, s_vlog, s_stats;  // HNSW traversal scratch (hnsw_kernels.hip)

@@ -30,7 +30,8 @@ struct MergeArgs {
   uint32_t* out_n;            // [nq]
   uint64_t row_base;
   uint32_t n_lists;
-  uint32_t k;
+  uint32_t k;                 // entries per partial list
+  uint32_t k_out;             // 0 = k; otherwise the number of entries kept per query (out_* are [nq][k_out])
 };
 
 struct EuclidRerankArgs {
@@ -149,7 +150,8 @@ constexpr uint32_t kGemmMaxK = 48;          // candidate buffers hold <= 64 keys
 constexpr uint32_t kGemmMaxQueries = 1024;  // per launch (bounds the partial-list scratch)
 size_t sweep_gemm_lds_bytes(int nqf, uint32_t k, bool big = false);
 void sweep_gemm_plan(uint32_t nq, uint32_t n_rows, int n_cus, uint32_t k, GemmPlan* p, bool allow_big = false);
-hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, hipStream_t st);
+hipError_t launch_sweep_gemm(int metric, const GemmPlan& p, const SweepArgs& a, hipStream_t st,
+                             const uint32_t* tile_needed = nullptr);
 // bf16 variant of the same kernel (dim % 64 == 0): rows16 = the bf16 row copy, queries16 = launch_round_queries_bf16 output
 void launch_round_queries_bf16(const float* q, uint64_t q_stride, uint16_t* out, uint64_t out_stride, uint32_t nq,
                                uint32_t dim, hipStream_t st);
@@ -170,7 +172,8 @@ void sweep_gemm_bf16_plan(uint32_t nq, uint32_t row_lo, uint32_t row_hi, int n_c
 hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const uint16_t* rows16, uint64_t row_stride,
                                        const float* norms, const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride,
                                        const uint64_t* tau0, uint64_t* part_keys, uint32_t list_stride, uint32_t list_off,
-                                       uint32_t dim, uint32_t nq, uint32_t k, hipStream_t st);
+                                       uint32_t dim, uint32_t nq, uint32_t k, hipStream_t st, bool split = false,
+                                       const float* qnorms = nullptr, uint64_t* blk_tau = nullptr);
 void launch_seed_tau(const uint64_t* ids, const float* scores, const uint32_t* n, uint64_t* tau0, uint64_t* list,
                      uint32_t list_stride, uint32_t nq, uint32_t k, hipStream_t st);
 // bf16 GEMM-distance sweep (cosine / dot over a bf16 copy of the rows): nqt in {1, 2, 4, 6} 16-query tiles
@@ -183,6 +186,38 @@ hipError_t launch_sweep_bf16(int metric, int nqt, const uint16_t* rows, uint64_t
                              const uint8_t* alive, const float* queries, uint64_t q_stride, uint64_t* part_keys,
                              uint32_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int blocks, hipStream_t st);
 void launch_merge(bool higher_is_better, const MergeArgs& m, uint32_t nq, hipStream_t st);
+void launch_max_norm(const float* norms, uint32_t n_rows, uint32_t* out_bits, hipStream_t st);  // bits of max |v| (NaN propagates)
+// ---- exact f32 Cosine / Dot batches through split-bf16 selection + exact re-scoring + proof (sweep_split.hip) ----
+constexpr uint32_t kSplitPool = 32;  // candidates per query that are re-scored exactly
+struct SplitRerankArgs {
+  const float* rows;            // f32 rows of the index
+  const float* norms;           // canonical row norms (cosine)
+  const float* queries;         // original f32 queries
+  const float* qnorms;          // canonical query norms
+  const uint64_t* cand_rows;    // [nq][k2] internal rows, best pool score first
+  const float* cand_scores;     // [nq][k2] pool scores
+  const uint32_t* cand_n;       // [nq]
+  const uint64_t* blk_tau;      // [nq][lists] the bound every selection block ended with
+  const float* delta;           // [nq] error bound of an approximate score
+  const uint64_t* ext_ids;
+  uint64_t* out_ids;            // [nq][k]
+  float* out_scores;            // [nq][k] exact scores (the exact kernel's bits)
+  uint32_t* out_n;              // [nq]
+  uint32_t* flags;              // [nq] 1 = not proven
+  uint32_t* tile_needed;        // [ceil(nq / fb_qper)] query tiles of the exact fallback launch that hold a flagged query
+  uint64_t row_stride, q_stride;
+  uint32_t dim, dim_pad, k, k2, lists, fb_qper;
+};
+void launch_split_vectors(const float* src, uint64_t src_stride, uint16_t* out, float* norms, uint32_t row0, uint32_t n,
+                          uint32_t dim, hipStream_t st);
+void launch_split_seed(int metric, const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
+                       const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
+                       uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t dim, hipStream_t st);
+void launch_split_reseed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* delta, uint64_t* tau0,
+                         uint32_t nq, uint32_t k, uint32_t kout, hipStream_t st);
+void launch_split_rerank(int metric, const SplitRerankArgs& a, uint32_t nq, hipStream_t st);
+void launch_select_fallback(const uint32_t* flags, const uint64_t* fb_ids, const float* fb_scores, const uint32_t* fb_n,
+                            uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint32_t nq, uint32_t k, hipStream_t st);
 void launch_euclid_rerank(const EuclidRerankArgs& a, const float* norms, uint32_t n_rows, uint32_t nq, hipStream_t st);
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st);
 // B (8 or 32) queries per corpus pass; blocks = row blocks (= partial lists per query), grid.y = ceil(nq / B)

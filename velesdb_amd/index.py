@@ -67,6 +67,12 @@ def set_sweep_engine(engine: int) -> None:
     check(lib().vdb_hip_set_sweep_engine(engine))
 
 
+def set_split_selector(on: bool) -> None:
+    """Large exact cosine / dot batches: True (default) = split-bf16 selection + exact re-scoring + proof, False = the exact
+    f32 matrix-core kernel for the whole batch.  Results are identical."""
+    check(lib().vdb_hip_set_split_selector(1 if on else 0))
+
+
 class HnswIndex:
     """HNSW index whose vectors, graph and search run on one MI355X."""
 
@@ -419,6 +425,12 @@ class HnswIndex:
     def last_search_stats(self):
         a, b = C.c_uint64(0), C.c_uint64(0)
         check(lib().vdb_hip_index_last_search_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def last_split_stats(self):
+        """(queries, unproven) of the last split-selector batch: unproven ones were answered by the exact fallback kernel."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        check(lib().vdb_hip_index_last_split_stats(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
     def last_kernel_ms(self):
