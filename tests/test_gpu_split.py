@@ -54,7 +54,7 @@ def run_case(metric, rows, qs, k, expect_unproven=None, remove=()):
 
 
 @pytest.mark.parametrize("metric", [DM.Cosine, DM.DotProduct])
-@pytest.mark.parametrize("n,dim,nq,k", [(70_000, 768, 256, 10), (150_001, 128, 1000, 10), (66_000, 64, 300, 1), (300_000, 96, 450, 7)])
+@pytest.mark.parametrize("n,dim,nq,k", [(70_000, 768, 256, 10), (150_001, 128, 1000, 10), (66_000, 64, 256, 1), (300_000, 96, 450, 7)])
 def test_random_data_proven_and_bit_exact(gpu_required, metric, n, dim, nq, k):
     rng = np.random.default_rng(n + dim + int(metric))
     rows = rng.standard_normal((n, dim)).astype(np.float32)

@@ -445,10 +445,16 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
   if (rc != VDB_OK) return rc;
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
   const uint32_t n = (uint32_t)ix->n_rows, dim = ix->dim, K2 = kSplitPool;
-  // launch schedule (as the bf16 sweep): exact seed over [0, R0), selection over [R0, R1) and [R1, n)
-  const uint32_t R0 = kGemmBf16SeedRows;
-  uint32_t R1 = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(R0 + (1u << 18), R0 + (n / 16 + 255) / 256 * 256));
-  if (n - R1 < (1u << 18)) R1 = n;
+  const uint32_t ks = std::min<uint32_t>(kGemmBf16MaxK, k + 3);  // rows a selection block keeps per query (sweep_split.hip)
+  // launch schedule: exact seed sweep over [0, R0) (at 1/16 of the selection's rate: kept short), selection over [R0, R1)
+  // and [R1, n); the second, long launch gets a whole number of row tiles per row group (no straggler blocks)
+  const uint32_t R0 = kSplitSeedRows;
+  const uint32_t tiles_all = (n - R0 + 255) / 256;
+  const uint32_t G2 = (uint32_t)std::max(8, ix->n_cus / (int)((nqg + 255) / 256) / 8 * 8);
+  uint32_t tiles1 = std::max<uint32_t>(1024, tiles_all / 16);          // >= 256 K rows behind the seed
+  if (tiles_all > tiles1) tiles1 += (tiles_all - tiles1) % G2;          // launch 2: tiles_all - tiles1 = a multiple of G2
+  uint32_t R1 = tiles1 >= tiles_all ? n : R0 + tiles1 * 256;
+  if (R1 >= n || n - R1 < (1u << 18)) R1 = n;                           // a short tail is not worth a launch of its own
   Bf16GemmPlan bp[2];
   int n_launch = 0;
   sweep_gemm_bf16_plan(nqg, R0, R1, ix->n_cus, &bp[n_launch++]);
@@ -472,7 +478,7 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
                o_fid = take((size_t)nqg * k * 8), o_fsc = take((size_t)nqg * k * 4), o_fn = take((size_t)nqg * 4);
   hipError_t e;
   if ((e = ix->s_seed.reserve(off, false, st)) != hipSuccess ||
-      (e = ix->s_part_keys.reserve((size_t)nqg * lists * k * 8, false, st)) != hipSuccess ||
+      (e = ix->s_part_keys.reserve((size_t)nqg * lists * ks * 8, false, st)) != hipSuccess ||
       (e = ix->s_fb_keys.reserve((size_t)nqg * fp.G * k * 8, false, st)) != hipSuccess ||
       (e = ix->s_misc.reserve(((size_t)nqg + 256) * dim * 4, false, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, "split sweep scratch");
@@ -495,7 +501,7 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
   // queries: split image (+ canonical norms), zero rows behind the batch (the kernel stages whole 256-query tiles)
   launch_split_vectors(d_q, q_stride, q16, qnorms, 0, nqg, dim, st);
   VDB_HIP(hipMemsetAsync(q16 + (size_t)nqg * dim * 2, 0, (size_t)256 * dim * 4, st));
-  VDB_HIP(hipMemsetAsync(pool, 0xFF, (size_t)nqg * lists * k * 8, st));
+  VDB_HIP(hipMemsetAsync(pool, 0xFF, (size_t)nqg * lists * ks * 8, st));
   VDB_HIP(hipMemsetAsync(blk_tau, 0xFF, (size_t)nqg * lists * 8, st));
   VDB_HIP(hipMemsetAsync(flags, 0, (size_t)nqg * 4 + 64 * 4 + 16, st));
   VDB_HIP(hipMemsetAsync(ix->s_fb_keys.p, 0xFF, (size_t)nqg * fp.G * k * 8, st));
@@ -524,18 +530,20 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
   ms.n_lists = sp.G;
   ms.k = k;
   launch_merge(true, ms, nqg, st);
-  launch_split_seed(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, dim, st);
+  launch_split_seed(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim, st);
   // selection launches over the split images
   uint32_t list_off = 1;
   for (int j = 0; j < n_launch; j++) {
     e = launch_sweep_gemm_bf16_glds(ix->metric, bp[j], ix->rows_split.as<uint16_t>(), (uint64_t)dim * 2, ix->norms.as<float>(), alive,
-                                    q16, (uint64_t)dim * 2, tau0, pool, lists, list_off, dim, nqg, k, st, /*split=*/true, qnorms,
+                                    q16, (uint64_t)dim * 2, tau0, pool, lists, list_off, dim, nqg, ks, st, /*split=*/true, qnorms,
                                     blk_tau);
     if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split selection launch: ") + hipGetErrorString(e));
     list_off += bp[j].G;
     if (j + 1 < n_launch) {  // bound of the next launch: k-th best pool score so far
       ms.part_keys = pool;
       ms.n_lists = lists;
+      ms.k = ks;
+      ms.k_out = k;
       launch_merge(true, ms, nqg, st);
       launch_split_reseed(m_ids, m_sc, m_n, delta, tau0, nqg, k, k, st);
     }
@@ -543,6 +551,7 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
   // pool -> K2 best by pool score -> exact re-scoring, ranking, proof
   ms.part_keys = pool;
   ms.n_lists = lists;
+  ms.k = ks;
   ms.k_out = K2;
   launch_merge(true, ms, nqg, st);
   SplitRerankArgs ra{};

@@ -7,8 +7,10 @@
 //      |e| <= 2^-18 |x|; the selection kernel (sweep_gemm_bf16.hip, SPLIT instance) accumulates hi.hi + hi.lo + lo.hi in
 //      f32: an approximation A(x, q) of x.q with |A - x.q| <= eps |x| |q|, eps = 3.1 * 2^-18 + 16 dim 2^-24 (the split
 //      remainder + a 4x padded worst case for the f32 accumulation inside and between the MFMAs, whose internal order is
-//      not documented).  It keeps, per block, the k best rows by approximate score under thresholds seeded by an EXACT
-//      sweep of the first rows (threshold lowered by the error bound).
+//      not documented).  It keeps, per block, the k' = min(10, k + 3) best rows by approximate score under thresholds
+//      seeded by an EXACT sweep of the first rows (threshold lowered by the error bound).  (k' > k: the bound a block ends
+//      with is the score of its k'-th best row; with k' = k the block that holds the best row of a k = 1 search would
+//      report that very score as the bound of what it left out, and no proof could succeed.)
 //   2. the per-block lists are merged to the K2 = 32 best by approximate score; split_rerank_verify re-scores those with
 //      the canonical chain of the exact kernels (oracle mode M: one fmaf chain per pair in the matrix-core order
 //      k = 128 U + 16 m + 4 kk + c) — the reported ids, ranks and score bits are the exact kernel's, bit for bit;
@@ -81,7 +83,7 @@ template <int METRIC>
 __global__ __launch_bounds__(256) void split_seed_kernel(const uint64_t* ids, const float* scores, const uint32_t* n,
                                                          const float* qnorms, const uint32_t* norm_max_bits, uint64_t* tau0,
                                                          float* delta, uint64_t* list, uint64_t* blk_tau, uint32_t list_stride,
-                                                         uint32_t nq, uint32_t k, uint32_t dim) {
+                                                         uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
   const float eps = split_eps(dim);
@@ -95,19 +97,19 @@ __global__ __launch_bounds__(256) void split_seed_kernel(const uint64_t* ids, co
     t = lowered == lowered ? make_key<true>(lowered, 0u) : kKeyInvalid;  // NaN: no bound
   }
   tau0[q] = t;
-  for (uint32_t e = 0; e < k; e++)
-    list[(size_t)q * list_stride * k + e] = e < c ? make_key<true>(scores[(size_t)q * k + e], (uint32_t)ids[(size_t)q * k + e]) : kKeyInvalid;
+  for (uint32_t e = 0; e < klist; e++)  // pool lists hold klist >= k entries
+    list[(size_t)q * list_stride * klist + e] = e < c ? make_key<true>(scores[(size_t)q * k + e], (uint32_t)ids[(size_t)q * k + e]) : kKeyInvalid;
   blk_tau[(size_t)q * list_stride] = kKeyInvalid;  // slot 0 = the seed rows: excluded exactly, no bound needed
 }
 void launch_split_seed(int metric, const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
                        const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
-                       uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t dim, hipStream_t st) {
+                       uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim, hipStream_t st) {
   if (metric == kCosine)
     hipLaunchKernelGGL((split_seed_kernel<kCosine>), dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits,
-                       tau0, delta, list, blk_tau, list_stride, nq, k, dim);
+                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, dim);
   else
     hipLaunchKernelGGL((split_seed_kernel<kDot>), dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits,
-                       tau0, delta, list, blk_tau, list_stride, nq, k, dim);
+                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, dim);
 }
 
 // Between two selection launches: the next launch's bound = k-th best POOL score so far (approximate scores, exact ones for
