@@ -155,6 +155,12 @@ def _declare(L):
     L.vo_scan_topk_bf16.argtypes = [C.c_int, _f32p, C.c_uint64, C.c_uint32, _f32p, C.c_uint32, C.c_uint32, C.c_uint32,
                                     _u64p, _f32p]
     L.vo_cpu_has_avx512f.restype = C.c_int
+    L.vo_alloc_spread.restype = C.c_void_p
+    L.vo_alloc_spread.argtypes = [_f32p, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.vo_free_spread.restype = None
+    L.vo_free_spread.argtypes = [C.c_void_p]
+    L.vo_hnsw_spread.restype = None
+    L.vo_hnsw_spread.argtypes = [C.c_void_p, C.c_uint32]
     L.vo_merge_shard_records.restype = None
     L.vo_merge_shard_records.argtypes = [np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS"), C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_int, _u64p, _f32p,
@@ -301,6 +307,27 @@ def scan_topk(metric, rows, queries, k, mode=MODE_R, nthreads=1):
     return ids, sc
 
 
+class SpreadRows:
+    """A copy of a row-major f32 corpus whose pages were first touched by the pool threads that scan_topk(…, nthreads)
+    reads them with (NUMA placement of the CPU baseline); `.array` is a numpy view, freed with the object."""
+
+    def __init__(self, rows, nthreads):
+        rows = _f(rows)
+        self.shape = rows.shape
+        self._p = lib().vo_alloc_spread(rows, rows.shape[0], rows.shape[1], nthreads)
+        buf = (C.c_float * (rows.shape[0] * rows.shape[1])).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=np.float32).reshape(rows.shape)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_p", None):
+                self.array = None
+                lib().vo_free_spread(self._p)
+                self._p = None
+        except Exception:
+            pass
+
+
 class ScalarQuantizer:
     """quantization.rs:191-260 — trained on `train_rows`, then used to encode any rows"""
 
@@ -413,6 +440,10 @@ class NativeHnsw:
         ds = np.empty(max(k, 1), dtype=np.float32)
         n = lib().vo_hnsw_search(self._h, q, k, ef, tie, ids, ds)
         return ids[:n].copy(), ds[:n].copy()
+
+    def spread(self, nthreads):
+        """re-place the vectors round-robin over the pool's threads (many-thread baselines on NUMA hosts)"""
+        lib().vo_hnsw_spread(self._h, nthreads)
 
     def search_batch(self, queries, k, ef, tie=TIE_REFERENCE, nthreads=1):
         """-> (nodes [nq,k], dist [nq,k], count [nq], total n_dist, total n_expand)"""

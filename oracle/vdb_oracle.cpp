@@ -28,6 +28,106 @@
 
 #if defined(__AVX2__) && defined(__FMA__)
 #include <immintrin.h>
+
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+
+// ---------------------------------------------------------------------------
+// Host-side execution helpers of the CPU baseline (the reference runs its batch paths on a rayon pool,
+// index/hnsw/index/batch.rs:159-244): one persistent pool instead of a thread spawn per call, and page placement by the
+// threads that will read the pages (a 3 GB corpus first-touched by one thread lives on ONE NUMA node of the host, and 256
+// threads scanning it are then bound by that node's memory controllers and the socket link).
+// ---------------------------------------------------------------------------
+namespace {
+class Pool {
+ public:
+  static Pool& get() {
+    static Pool p;
+    return p;
+  }
+  // runs fn(t) for t in [0, n) on n pool threads (n <= 1: inline); returns when all are done
+  void run(uint32_t n, const std::function<void(uint32_t)>& fn) {
+    if (n <= 1) {
+      fn(0);
+      return;
+    }
+    std::unique_lock<std::mutex> call(call_mu_);  // one parallel region at a time
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      while (workers_.size() < n) {
+        const uint32_t id = (uint32_t)workers_.size();
+        workers_.emplace_back([this, id] { loop(id); });
+      }
+      fn_ = &fn;
+      n_ = n;
+      pending_ = n;
+      gen_++;
+    }
+    cv_.notify_all();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  Pool() = default;
+  ~Pool() {
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      stop_ = true;
+      gen_++;
+    }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  void loop(uint32_t id) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(uint32_t)>* fn = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+        if (id < n_) fn = fn_;
+      }
+      if (fn) {
+        (*fn)(id);
+        std::unique_lock<std::mutex> lk(mu_);
+        if (--pending_ == 0) done_.notify_all();
+      }
+    }
+  }
+  std::mutex mu_, call_mu_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> workers_;
+  const std::function<void(uint32_t)>* fn_ = nullptr;
+  uint32_t n_ = 0, pending_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+// allocator that leaves floats uninitialised: resize() does not touch the pages, the first writer does
+template <class T>
+struct NoInitAlloc {
+  typedef T value_type;
+  NoInitAlloc() = default;
+  template <class U>
+  NoInitAlloc(const NoInitAlloc<U>&) {}
+  T* allocate(size_t n) { return static_cast<T*>(::operator new(n * sizeof(T))); }
+  void deallocate(T* p, size_t) { ::operator delete(p); }
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if (sizeof...(A)) ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+  template <class U>
+  bool operator==(const NoInitAlloc<U>&) const { return true; }
+  template <class U>
+  bool operator!=(const NoInitAlloc<U>&) const { return false; }
+};
+}  // namespace
+
 #define VO_HAVE_AVX2 1
 #else
 #define VO_HAVE_AVX2 0
@@ -382,6 +482,41 @@ inline float reduce16(const float* l) {
   for (int i = 0; i < 4; i++) h4[i] = h8[i] + h8[i + 4];
   return (h4[0] + h4[2]) + (h4[1] + h4[3]);
 }
+// the intrinsic sequence itself (simd_native.rs:40-77,86-119): compiled for avx512f whatever the flags of this file are,
+// called only when the host has it (vo_cpu_has_avx512f); bit-identical to the lane-wise restatement below
+template <int OP>
+__attribute__((target("avx512f"))) float native16_avx512(const float* a, const float* b, size_t n) {
+  __m512 acc = _mm512_setzero_ps();
+  const size_t blocks = n / 16, rem = n % 16;
+  for (size_t k = 0; k < blocks; k++) {
+    const __m512 x = _mm512_loadu_ps(a + k * 16), y = _mm512_loadu_ps(b + k * 16);
+    if (OP == OP_SQL2) {
+      const __m512 d = _mm512_sub_ps(x, y);
+      acc = _mm512_fmadd_ps(d, d, acc);
+    } else {
+      acc = _mm512_fmadd_ps(x, y, acc);
+    }
+  }
+  if (rem) {
+    const __mmask16 m = (__mmask16)((1u << rem) - 1u);
+    const __m512 x = _mm512_maskz_loadu_ps(m, a + blocks * 16), y = _mm512_maskz_loadu_ps(m, b + blocks * 16);
+    if (OP == OP_SQL2) {
+      const __m512 d = _mm512_sub_ps(x, y);
+      acc = _mm512_fmadd_ps(d, d, acc);
+    } else {
+      acc = _mm512_fmadd_ps(x, y, acc);
+    }
+  }
+  // _mm512_reduce_add_ps: 512 -> 256 -> 128 -> 64 -> 32 halving, as reduce16
+  alignas(64) float l[16];
+  _mm512_store_ps(l, acc);
+  float h8[8], h4[4];
+  for (int i = 0; i < 8; i++) h8[i] = l[i] + l[i + 8];
+  for (int i = 0; i < 4; i++) h4[i] = h8[i] + h8[i + 4];
+  return (h4[0] + h4[2]) + (h4[1] + h4[3]);
+}
+static const bool g_has_avx512f = __builtin_cpu_supports("avx512f");
+
 template <int OP>
 float native16(const float* a, const float* b, size_t n) {
   if (n < 16) {  // scalar fallback arms of *_native (simd_native.rs:399,417-424)
@@ -396,6 +531,7 @@ float native16(const float* a, const float* b, size_t n) {
     }
     return s;
   }
+  if (g_has_avx512f) return native16_avx512<OP>(a, b, n);
   float acc[16];
   for (int i = 0; i < 16; i++) acc[i] = 0.0f;
   size_t blocks = n / 16, rem = n % 16;
@@ -674,7 +810,7 @@ thread_local uint64_t tl_n_dist = 0, tl_n_expand = 0;
 struct vo_hnsw {
   uint32_t dim = 0;
   int metric = 0, mode = 0;
-  std::vector<float> vectors;                                // graph.rs:22 (flattened)
+  std::vector<float, NoInitAlloc<float>> vectors;            // graph.rs:22 (flattened; pages placed by their first writer)
   std::vector<std::vector<std::vector<uint64_t>>> layers;    // graph.rs:24, layer.rs:12-15
   int64_t entry_point = -1;                                  // graph.rs:26
   size_t max_layer = 0, count = 0;                           // graph.rs:28-30
@@ -1230,6 +1366,25 @@ int vo_hnsw_file_dump(const vo_hnsw* g, const char* dir, const char* basename) {
   std::fclose(f);
   return 0;
 }
+// Re-places the vector storage: 2 MiB chunks copied (= first touched) round-robin by the pool's threads, so that the
+// random 3 KB reads of a many-thread search batch spread over every memory controller of the host instead of hitting the
+// one NUMA node of the thread that loaded the file.
+void vo_hnsw_spread(vo_hnsw* g, uint32_t nthreads) {
+  if (!g || nthreads <= 1 || g->vectors.empty()) return;
+  std::vector<float, NoInitAlloc<float>> fresh;
+  fresh.resize(g->vectors.size());
+  const size_t chunk = (size_t)512 * 1024, n = g->vectors.size(), nchunks = (n + chunk - 1) / chunk;
+  const float* src = g->vectors.data();
+  float* dst = fresh.data();
+  Pool::get().run(nthreads, [&](uint32_t t) {
+    for (size_t c = t; c < nchunks; c += nthreads) {
+      const size_t lo = c * chunk, hi = std::min(n, lo + chunk);
+      std::memcpy(dst + lo, src + lo, (hi - lo) * sizeof(float));
+    }
+  });
+  g->vectors.swap(fresh);
+}
+
 // native/backend_adapter.rs:273-381 — file_load (alpha reset to 1.0, rng reseeded)
 vo_hnsw* vo_hnsw_file_load(const char* dir, const char* basename, int metric, int mode) {
   std::string vp = std::string(dir) + "/" + basename + ".vectors";
@@ -1439,13 +1594,7 @@ void vo_index_search_batch(const vo_index* ix, const float* queries, uint32_t nq
       out_n[qi] = n;
     }
   };
-  if (nthreads == 1) {
-    worker();
-  } else {
-    std::vector<std::thread> th;
-    for (uint32_t t = 0; t < nthreads; t++) th.emplace_back(worker);
-    for (auto& t : th) t.join();
-  }
+  Pool::get().run(nthreads, [&](uint32_t) { worker(); });
 }
 
 // NativeHnsw::search over a batch of queries with nthreads host threads (one search per thread at a
@@ -1530,13 +1679,7 @@ void vo_hnsw_search_batch(const vo_hnsw* gp, const float* queries, uint32_t nq, 
     nd_total += tl_n_dist;
     ne_total += n_expand;
   };
-  if (nthreads == 1) {
-    worker();
-  } else {
-    std::vector<std::thread> th;
-    for (uint32_t t = 0; t < nthreads; t++) th.emplace_back(worker);
-    for (auto& t : th) t.join();
-  }
+  Pool::get().run(nthreads, [&](uint32_t) { worker(); });
   if (total_n_dist) *total_n_dist = nd_total.load();
   if (total_n_expand) *total_n_expand = ne_total.load();
 }
@@ -1552,12 +1695,16 @@ void vo_scan_topk(int metric, int mode, const float* rows, uint64_t nrows, uint3
     int c = hib ? total_cmp(b.second, a.second) : total_cmp(a.second, b.second);
     return c ? c < 0 : a.first < b.first;
   };
+  // brute_force_search_parallel (batch.rs:223-244): the rows of ONE query are split over the pool's threads (rayon in the
+  // reference); the partition is static, so thread t always reads the same rows (and finds them on its own NUMA node
+  // when the caller placed them with vo_alloc_spread)
+  std::vector<std::vector<std::pair<uint64_t, float>>> part(nthreads);
   for (uint32_t qi = 0; qi < nq; qi++) {
     const float* q = queries + (size_t)qi * dim;
-    std::vector<std::vector<std::pair<uint64_t, float>>> part(nthreads);
     auto work = [&](uint32_t t) {
       uint64_t lo = nrows * t / nthreads, hi = nrows * (t + 1) / nthreads;
       auto& v = part[t];
+      v.clear();
       v.reserve((size_t)(hi - lo));
       for (uint64_t r = lo; r < hi; r++)
         v.emplace_back(r, index_compute_distance(metric, mode, q, rows + (size_t)r * dim, dim));
@@ -1565,13 +1712,7 @@ void vo_scan_topk(int metric, int mode, const float* rows, uint64_t nrows, uint3
       std::partial_sort(v.begin(), v.begin() + kk, v.end(), better);
       v.resize(kk);
     };
-    if (nthreads == 1) {
-      work(0);
-    } else {
-      std::vector<std::thread> th;
-      for (uint32_t t = 0; t < nthreads; t++) th.emplace_back(work, t);
-      for (auto& t : th) t.join();
-    }
+    Pool::get().run(nthreads, work);
     std::vector<std::pair<uint64_t, float>> all;
     for (auto& v : part) all.insert(all.end(), v.begin(), v.end());
     std::sort(all.begin(), all.end(), better);
@@ -1586,6 +1727,19 @@ void vo_scan_topk(int metric, int mode, const float* rows, uint64_t nrows, uint3
     }
   }
 }
+
+// A copy of `rows` whose pages are first touched by the pool thread that vo_scan_topk(…, nthreads) will read them with
+// (same static partition); freed with vo_free_spread.
+float* vo_alloc_spread(const float* rows, uint64_t nrows, uint32_t dim, uint32_t nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  float* p = static_cast<float*>(::operator new((size_t)nrows * dim * sizeof(float) + 64));
+  Pool::get().run(nthreads, [&](uint32_t t) {
+    const uint64_t lo = nrows * t / nthreads, hi = nrows * (t + 1) / nthreads;
+    std::memcpy(p + (size_t)lo * dim, rows + (size_t)lo * dim, (size_t)(hi - lo) * dim * sizeof(float));
+  });
+  return p;
+}
+void vo_free_spread(float* p) { ::operator delete(p); }
 
 // Range-sharded exact search: merge of per-shard top-k record lists.  The unsharded result is the stable sort of ALL rows
 // by score (core/distance.rs:95-103) in row order; shards are contiguous row ranges and every shard's list is already in
@@ -1803,13 +1957,7 @@ void vo_scan_topk_bf16(int metric, const float* rows, uint64_t nrows, uint32_t d
       }
     }
   };
-  if (nthreads == 1) {
-    worker();
-  } else {
-    std::vector<std::thread> th;
-    for (uint32_t t = 0; t < nthreads; t++) th.emplace_back(worker);
-    for (auto& t : th) t.join();
-  }
+  Pool::get().run(nthreads, [&](uint32_t) { worker(); });
 }
 
 int vo_cpu_has_avx512f(void) { return __builtin_cpu_supports("avx512f") ? 1 : 0; }
@@ -1997,13 +2145,7 @@ void vo_scan_topk_sq8(int metric, const float* rows, uint64_t nrows, uint32_t di
       }
     }
   };
-  if (nthreads == 1) {
-    worker();
-  } else {
-    std::vector<std::thread> th;
-    for (uint32_t t = 0; t < nthreads; t++) th.emplace_back(worker);
-    for (auto& t : th) t.join();
-  }
+  Pool::get().run(nthreads, [&](uint32_t) { worker(); });
 }
 // exact top-k by BinaryQuantizedVector::hamming_distance between the sign-bit codes (smallest first, ties by row)
 void vo_scan_topk_binary(const float* rows, uint64_t nrows, uint32_t dim, const float* queries, uint32_t nq, uint32_t k,

@@ -187,6 +187,11 @@ void vo_scan_topk_bf16(int metric, const float* rows, uint64_t nrows, uint32_t d
                        uint32_t nq, uint32_t k, uint32_t nthreads, uint64_t* out_rows, float* out_scores);
 
 int vo_cpu_has_avx512f(void);
+/* page placement for many-thread runs (see the Pool notes in vdb_oracle.cpp): a copy of the corpus first-touched by the
+ * threads vo_scan_topk will read it with; re-placement of a loaded graph's vectors in 2 MiB round-robin chunks */
+float* vo_alloc_spread(const float* rows, uint64_t nrows, uint32_t dim, uint32_t nthreads);
+void vo_free_spread(float* p);
+void vo_hnsw_spread(vo_hnsw*, uint32_t nthreads);
 /* ---- storage modes (core/quantization.rs): sign-bit and SQ8 (per-vector min/max) codes, asymmetric distances ---- */
 void vo_binary_quantize(const float* v, uint32_t dim, uint8_t* out /* ceil(dim/8) */);
 uint32_t vo_binary_hamming(const uint8_t* a, const uint8_t* b, uint32_t nbytes);
