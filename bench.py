@@ -551,7 +551,7 @@ def main():
     if rank == 0:
         from oracle import pyoracle as po
         om = {"cosine": po.COSINE, "euclidean": po.EUCLIDEAN, "dot": po.DOT}[a.metric]
-        ncores = os.cpu_count() or 1
+        ncores = po.host_threads()
         if host_full is not None:
             # the headline launch itself (Q queries in ONE call = the GEMM kernel, every query tile), of which
             # `--check-queries` spread over the whole batch are compared with the oracle (ids + score bits)
@@ -607,7 +607,9 @@ def main():
                 po.scan_topk(om, hs, queries[i:i + 1].cpu().numpy(), K, po.MODE_R, nthreads=1)
                 st_samples.append(time.perf_counter() - t3)
             cpu = {"value": shapes["shape_a"]["qps"], "unit": "queries/s", "cores": ncores, "kind": "port",
-                   "cpu_model": cpu_model, "shape_a": shapes["shape_a"], "shape_b": shapes["shape_b"],
+                   "cpu_model": cpu_model, "host_hardware_threads": os.cpu_count(),
+                   "cores_note": "cores = CPUs this process may use (affinity mask capped by the cgroup cpu.max quota); "
+                                 "one pool thread per CPU", "shape_a": shapes["shape_a"], "shape_b": shapes["shape_b"],
                    "single_thread_us": round(float(np.median(st_samples)) * 1e6 * N / sample_rows, 1),
                    "sample": f"oracle restatement of brute_force_search_parallel (batch.rs:223-244) on the first {sample_rows} of "
                              f"{N} rows, {ncores} pool threads, pages first-touched by the scanning threads; value = shape A "
@@ -739,7 +741,7 @@ def main():
             try:
                 ix2.save(gd, "native_hnsw")
                 og = po.NativeHnsw.file_load(gd, "native_hnsw", om, po.MODE_R)
-                ncores = os.cpu_count() or 1
+                ncores = po.host_threads()
                 og.spread(ncores)
                 cq = min(a.cpu_hnsw_queries, HQ)
                 qh2 = q2[:cq].cpu().numpy()
@@ -866,7 +868,7 @@ def main():
         if first_chunk is not None:
             from oracle import pyoracle as po
             om = {"cosine": po.COSINE, "dot": po.DOT}[a.metric]
-            ncores = os.cpu_count() or 1
+            ncores = po.host_threads()
             qh = bq.cpu().numpy()
             nqc = min(ncores, BQ)
             t6 = time.perf_counter()
@@ -939,7 +941,7 @@ def main():
                 # Jaccard: the f32-threshold kernels of simd_explicit.rs), one query per thread, bounded sample
                 from oracle import pyoracle as po
                 pm = {"euclidean": po.EUCLIDEAN, "dot": po.DOT, "hamming": po.HAMMING, "jaccard": po.JACCARD}[mname]
-                ncores = os.cpu_count() or 1
+                ncores = po.host_threads()
                 host_rows = src.cpu().numpy()
                 nq_c = min(ncores, Q)
                 qh = qsrc[:nq_c].cpu().numpy()

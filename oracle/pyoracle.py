@@ -570,6 +570,33 @@ class HnswIndex:
         return ids, sc, cnt
 
 
+def host_threads() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (cpu.max).  The GPU boxes of
+    this project expose 256 hardware threads to a container that is allowed 16 CPUs: 256 threads then time-slice through
+    16, and every fork-join of the baseline pays for it."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts and parts[0] != "max":
+                    n = min(n, max(1, -(-int(parts[0]) // int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, -(-q // int(f2.read().split()[0]))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def build_info():
     return lib().vo_build_info().decode()
 

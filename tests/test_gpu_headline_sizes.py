@@ -56,7 +56,7 @@ def test_headline_1m_gemm_vs_oracle(corpus, index):
     over 1 M rows (>= 15 row tiles per block); then the bench's 1 024-query launch shape (8 query tiles), of which 96
     spread over every tile are compared."""
     rows, qs = corpus
-    ncores = os.cpu_count() or 1
+    ncores = po.host_threads()
     assert index.sweep_arith_mode(K) == "M"
     nq = 320
     ids, sc, cnt = index.search_batch_brute_force(qs[:nq], K)
@@ -84,7 +84,7 @@ def test_hnsw_1m_vs_oracle(corpus, index, tmp_path, record_property):
     """configs[2] at full size: batched GPU build of the 1 M-node graph (M 32, ef_construction 400), 1 024 queries at
     ef = 128 through the traversal kernel, compared with the oracle searching the SAME graph."""
     rows, qs = corpus
-    ncores = os.cpu_count() or 1
+    ncores = po.host_threads()
     index.build_graph(0)
     nl, ml, ep = index.graph_info()
     assert index.node_count() == N and 0 <= ep < N and ml < nl

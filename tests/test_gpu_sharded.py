@@ -262,7 +262,7 @@ def _rccl_worker(rank, world, port, cfg, out):
                 rows = np.concatenate([_corpus_chunk(seed, c, chunk_rows, dim, hamming) for c in range(nchunks)])
                 pm = {0: po_.COSINE, 1: po_.EUCLIDEAN, 2: po_.DOT, 3: po_.HAMMING, 4: po_.JACCARD}[metric]
                 mode = po_.MODE_M if ix.sweep_arith_mode(k) == "M" else po_.MODE_C
-                eid, esc = po_.scan_topk(pm, rows, qs, k, mode, nthreads=os.cpu_count() or 1)
+                eid, esc = po_.scan_topk(pm, rows, qs, k, mode, nthreads=po_.host_threads())
                 ok &= bool(np.array_equal(gi, eid) and np.array_equal(gs.view(np.uint32), esc.view(np.uint32)))
                 ok &= bool(np.all(d_n.cpu().numpy() == k))
             # every rank holds the same merged result

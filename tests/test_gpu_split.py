@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 va = pytest.importorskip("velesdb_amd")
 DM = va.DistanceMetric
-NT = min(64, os.cpu_count() or 8)
+NT = po.host_threads()
 
 
 def bits(a):

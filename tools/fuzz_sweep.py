@@ -27,7 +27,7 @@ p.add_argument("--euclid", action="store_true", help="Euclidean only (matrix-cor
 p.add_argument("--bits", action="store_true", help="Hamming / Jaccard (packed-bit kernels) instead of cosine / dot")
 a = p.parse_args()
 rng = np.random.default_rng(a.seed)
-NT = min(64, os.cpu_count() or 8)
+NT = po.host_threads()
 va.set_sweep_engine(a.engine)
 DM = va.DistanceMetric
 
