@@ -85,6 +85,11 @@ def parse():
 
 def main():
     a = parse()
+    # stdout carries ONE JSON line and nothing else: native libraries (RCCL prints a version banner to the C stdout at
+    # communicator creation) are pointed at stderr for the life of the process; the line is written to the saved fd
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch  # first: the HIP runtime it loads is the one libvelesdb_hip.so binds to
     import torch.distributed as dist
     import numpy as np
@@ -1072,14 +1077,8 @@ def main():
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
-        # RCCL writes its version banner to the C stdout buffer: flush it first so that the JSON line is the LAST line
-        import ctypes
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
         sys.stdout.flush()
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
 
 
 if __name__ == "__main__":

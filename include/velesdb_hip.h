@@ -286,7 +286,6 @@ int32_t vdb_hip_set_max_query_tile(uint32_t b);
  * Both are exact f32 arithmetic; scores differ in the last bits because the summation order does.  The choice
  * never depends on the batch size. */
 int32_t vdb_hip_set_sweep_engine(int32_t engine);
-/* *mode = 1 if searches in VDB_SEARCH_BRUTE mode with this k run on the matrix-core kernel (mode M), else 0 */
 /* Large exact Cosine / DotProduct batches (>= 224 queries that fill 256-query tiles, k <= 10, >= 65 536 rows, dim % 32 == 0):
  * 1 (default) = the matrix cores SELECT on a split-bf16 image of rows and queries (x = hi + lo, three bf16 MFMAs per
  * product), the 32 best candidates per query are re-scored with the exact chain (oracle mode M), every query's answer is
@@ -296,6 +295,7 @@ int32_t vdb_hip_set_split_selector(int32_t on);
 /* diagnostic: queries in the last split-selector batch (its last chunk of <= 1024) and how many of them the exact
  * fallback kernel answered because the selection could not be proven (near-ties inside the error bound, non-finite data) */
 int32_t vdb_hip_index_last_split_stats(vdb_hip_index* idx, uint32_t* queries, uint32_t* unproven);
+/* *mode = 1 if searches in VDB_SEARCH_BRUTE mode with this k run on the matrix-core kernel (mode M), else 0 */
 int32_t vdb_hip_index_sweep_arith_mode(vdb_hip_index* idx, uint32_t k, int32_t* mode);
 int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* idx, float* ms, uint32_t* launches);
 

@@ -88,3 +88,88 @@ def test_params_mirror_reference_presets():
     assert SearchQuality.Fast.ef_search(10) == 64 and SearchQuality.Balanced.ef_search(10) == 128
     assert SearchQuality.Accurate.ef_search(50) == 800 and SearchQuality.Perfect.ef_search(10) == 4096
     assert SearchQuality.Custom(30).ef_search(50) == 50
+
+
+# ---- the Rust binding crate (velesdb-hip/) is source for the reference's toolchain; it is kept identical to the header ----
+
+RUST_SYS = os.path.join(ROOT, "velesdb-hip", "src", "sys.rs")
+RUST_LIB = os.path.join(ROOT, "velesdb-hip", "src", "lib.rs")
+_SCALARS = {"int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "size_t": "usize", "float": "f32",
+            "uint8_t": "u8", "char": "c_char", "void": "c_void", "vdb_hip_index": "VdbHipIndex"}
+
+
+def _c_type_to_rust(t):
+    t = t.strip()
+    stars = t.count("*")
+    const = t.startswith("const ")
+    base = t.replace("const ", "").replace("*", "").strip()
+    r = _SCALARS[base]
+    if stars == 0:
+        return r
+    if stars == 2:  # vdb_hip_index** out
+        return f"*mut *mut {r}"
+    return f"*const {r}" if const else f"*mut {r}"
+
+
+def header_prototypes():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_0-9 ]+?[\s\*]+)(vdb_hip_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        params = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.*?)([A-Za-z_][A-Za-z_0-9]*)$", a)
+                params.append((mm.group(2), _c_type_to_rust(mm.group(1))))
+        protos[name] = (params, None if ret == "void" else _c_type_to_rust(ret))
+    return protos
+
+
+def rust_prototypes():
+    src = open(RUST_SYS).read()
+    block = re.search(r'extern "C" \{(.*?)\n\}', src, flags=re.S).group(1)
+    protos = {}
+    for m in re.finditer(r"pub fn (vdb_hip_[a-z0-9_]+)\(([^)]*)\)(?:\s*->\s*([^;]+))?;", block):
+        name, args, ret = m.group(1), m.group(2).strip(), m.group(3)
+        params = []
+        if args:
+            for a in args.split(","):
+                pn, pt = a.split(":", 1)
+                params.append((pn.strip(), " ".join(pt.split())))
+        protos[name] = (params, ret.strip() if ret else None)
+    return protos
+
+
+def test_rust_sys_matches_header():
+    h, r = header_prototypes(), rust_prototypes()
+    assert sorted(h) == declared_functions(), "the prototype parser misses a declaration"
+    assert sorted(r) == sorted(h), (sorted(set(h) - set(r)), sorted(set(r) - set(h)))
+    for name in h:
+        assert r[name] == h[name], f"{name}: header {h[name]} != sys.rs {r[name]}"
+
+
+def test_rust_sys_constants_match_header_enums():
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    enums = dict((k, int(v)) for k, v in re.findall(r"\b(VDB_[A-Z0-9_]+)\s*=\s*(-?\d+)", src))
+    enums.update((k, int(v)) for k, v in re.findall(r"#define\s+(VDB_[A-Z0-9_]+)\s+(\d+)", src))
+    rs = dict((k, int(v)) for k, v in re.findall(r"pub const (VDB_[A-Z0-9_]+): (?:i32|usize) = (-?\d+);", open(RUST_SYS).read()))
+    assert rs == enums
+
+
+def test_rust_wrapper_has_complete_bodies_and_binds_only_declared_symbols():
+    lib = open(RUST_LIB).read()
+    assert not re.search(r"todo!|unimplemented!|/\*\s*…|\{\s*/\*", lib), "stub bodies in velesdb-hip/src/lib.rs"
+    used = set(re.findall(r"sys::(vdb_hip_[a-z0-9_]+)", lib))
+    assert used <= set(header_prototypes()), used - set(header_prototypes())
+    # the three seams of SURVEY 8b and the reference's inherent methods the collection layer calls
+    for item in ("impl VectorIndex for HipHnswIndex", "impl DistanceEngine for HipDistance", "impl Drop for HipHnswIndex",
+                 "unsafe impl Send for HipHnswIndex", "unsafe impl Sync for HipHnswIndex", "pub fn search_with_quality",
+                 "pub fn search_brute_force", "pub fn search_batch_parallel", "pub fn insert_batch_parallel",
+                 "pub fn insert_batch_sequential", "pub fn search_with_rerank", "pub fn search_with_rerank_quality",
+                 "pub fn vacuum", "pub fn tombstone_count", "pub fn needs_vacuum", "pub fn save", "pub fn load",
+                 "pub fn set_searching_mode", "pub fn batch_cosine_similarity", "pub fn batch_euclidean_distance",
+                 "pub fn batch_dot_product"):
+        assert item in lib, item
+    assert lib.count("{") == lib.count("}") and lib.count("(") == lib.count(")")

@@ -1,0 +1,759 @@
+//! `velesdb-hip` — velesdb-core's HNSW / exact-search hot path on an AMD MI355X through `libvelesdb_hip.so`.
+//!
+//! What the crate provides, each over the C ABI of `include/velesdb_hip.h` (bound in [`sys`]):
+//!
+//! | here | replaces in velesdb-core |
+//! |---|---|
+//! | [`HipHnswIndex`] + `impl VectorIndex` | `HnswIndex` (`index/hnsw/index/*.rs`), `impl VectorIndex for HnswIndex` (`trait_impl.rs:8-71`) |
+//! | [`HipDistance`] + `impl DistanceEngine` | `SimdDistance` / `NativeSimdDistance` (`index/hnsw/native/distance.rs:14-28,60-160`) |
+//! | [`HipAccelerator`] | `GpuAccelerator` (`gpu/gpu_backend.rs:33,136,157,355,397`) |
+//!
+//! Error behaviour follows the reference: dimension mismatches panic with the reference's messages
+//! (`index/hnsw/index/search.rs:16-27`, `trait_impl.rs:12-18`), a duplicate id is silently skipped (`trait_impl.rs:23-25`),
+//! persistence returns `io::Result`, `vacuum` returns `Result<usize, VacuumError>`; everything else the library reports
+//! (no device, out of memory, a HIP error) panics with the library's message, as a failing allocation or a poisoned lock
+//! does in the CPU index.  There is no CPU fallback in this crate: constructors return `None` without a HIP device and the
+//! caller keeps `velesdb_core::HnswIndex`.
+
+pub mod sys;
+
+use std::ffi::{CStr, CString};
+use std::io;
+use std::os::raw::c_void;
+use std::path::Path;
+use std::ptr;
+
+use velesdb_core::index::hnsw::native::DistanceEngine;
+use velesdb_core::{DistanceMetric, HnswParams, SearchQuality, VectorIndex};
+
+/// The thread-local message of the last failing call (`vdb_hip_last_error`, never NULL).
+#[must_use]
+pub fn last_error() -> String {
+    // SAFETY: the library returns a pointer to a NUL-terminated thread-local buffer that stays valid until the next call
+    // on this thread; it is copied before anything else is called.
+    unsafe { CStr::from_ptr(sys::vdb_hip_last_error()) }.to_string_lossy().into_owned()
+}
+
+/// Library version string (`vdb_hip_version`).
+#[must_use]
+pub fn version() -> String {
+    // SAFETY: static NUL-terminated string.
+    unsafe { CStr::from_ptr(sys::vdb_hip_version()) }.to_string_lossy().into_owned()
+}
+
+/// Number of HIP devices the library sees (0 without a GPU or without the driver).
+#[must_use]
+pub fn device_count() -> usize {
+    let mut n: i32 = 0;
+    // SAFETY: `n` is a valid out pointer.
+    let rc = unsafe { sys::vdb_hip_device_count(&mut n) };
+    if rc < 0 || n < 0 {
+        0
+    } else {
+        n as usize
+    }
+}
+
+/// Name of a device ("AMD Instinct MI355X").
+#[must_use]
+pub fn device_name(device: usize) -> Option<String> {
+    let mut buf = [0 as std::os::raw::c_char; 256];
+    // SAFETY: `buf` holds `cap` bytes; the library NUL-terminates within `cap`.
+    let rc = unsafe { sys::vdb_hip_device_name(device as i32, buf.as_mut_ptr(), buf.len()) };
+    if rc < 0 {
+        return None;
+    }
+    // SAFETY: NUL-terminated by the callee.
+    Some(unsafe { CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned())
+}
+
+fn metric_code(m: DistanceMetric) -> i32 {
+    // the reference's on-disk order (index/hnsw/index/constructors.rs:204-210)
+    match m {
+        DistanceMetric::Cosine => sys::VDB_COSINE,
+        DistanceMetric::Euclidean => sys::VDB_EUCLIDEAN,
+        DistanceMetric::DotProduct => sys::VDB_DOT,
+        DistanceMetric::Hamming => sys::VDB_HAMMING,
+        DistanceMetric::Jaccard => sys::VDB_JACCARD,
+    }
+}
+
+fn metric_from_code(c: i32) -> DistanceMetric {
+    match c {
+        sys::VDB_EUCLIDEAN => DistanceMetric::Euclidean,
+        sys::VDB_DOT => DistanceMetric::DotProduct,
+        sys::VDB_HAMMING => DistanceMetric::Hamming,
+        sys::VDB_JACCARD => DistanceMetric::Jaccard,
+        _ => DistanceMetric::Cosine,
+    }
+}
+
+/// Panics with the library's message on an error status; returns the (non-negative) status otherwise.
+fn check(rc: i32) -> i32 {
+    assert!(rc >= 0, "velesdb-hip: {} (status {})", last_error(), rc);
+    rc
+}
+
+fn io_check(rc: i32) -> io::Result<()> {
+    if rc >= 0 {
+        Ok(())
+    } else {
+        let kind = if rc == sys::VDB_ERR_IO { io::ErrorKind::InvalidData } else { io::ErrorKind::Other };
+        Err(io::Error::new(kind, last_error()))
+    }
+}
+
+fn c_path<P: AsRef<Path>>(p: P) -> io::Result<CString> {
+    CString::new(p.as_ref().to_string_lossy().as_bytes())
+        .map_err(|_| io::Error::new(io::ErrorKind::InvalidInput, "path contains a NUL byte"))
+}
+
+/// How a multi-GPU handle spreads its rows (`enum vdb_shard_mode`).
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum ShardMode {
+    /// Every device holds every row and the graph; a query batch is split between the devices.
+    Replica,
+    /// Contiguous row ranges per device; exact searches merge per-shard top-k after one RCCL all-gather.
+    Range,
+}
+
+/// `HnswIndex::vacuum`'s error type (`index/hnsw/index/vacuum.rs:11-14`).  The GPU index always stores its vectors, so
+/// the only variant the reference has can not occur here; it exists so that call sites compile unchanged.
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum VacuumError {
+    /// Vector storage is disabled, cannot rebuild index
+    VectorStorageDisabled,
+}
+
+impl std::fmt::Display for VacuumError {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        write!(f, "Cannot vacuum index: vector storage is disabled")
+    }
+}
+
+impl std::error::Error for VacuumError {}
+
+/// An HNSW index resident in the HBM of one or more MI355X GPUs.  Same inherent methods as `velesdb_core::HnswIndex`.
+pub struct HipHnswIndex {
+    h: *mut sys::VdbHipIndex,
+    dimension: usize,
+    metric: DistanceMetric,
+}
+
+// SAFETY: the handle is internally synchronised (one mutex per index, thread-local error strings); the C ABI documents
+// "a handle may be used from any thread" (include/velesdb_hip.h conventions) and tests/test_gpu_hardening.py drives
+// concurrent searches against a concurrent inserter.
+unsafe impl Send for HipHnswIndex {}
+// SAFETY: as above.
+unsafe impl Sync for HipHnswIndex {}
+
+impl HipHnswIndex {
+    /// `HnswIndex::new` (`constructors.rs:29-32`): `HnswParams::auto(dimension)`.
+    #[must_use]
+    pub fn new(dimension: usize, metric: DistanceMetric) -> Option<Self> {
+        Self::with_params(dimension, metric, HnswParams::auto(dimension))
+    }
+
+    /// `HnswIndex::with_params` (`constructors.rs:116-160`) on device 0.  `None` when no HIP device is present, like
+    /// `GpuAccelerator::new()` (`gpu/gpu_backend.rs:33`).
+    #[must_use]
+    pub fn with_params(dimension: usize, metric: DistanceMetric, params: HnswParams) -> Option<Self> {
+        Self::with_params_on(dimension, metric, params, &[0], ShardMode::Replica)
+    }
+
+    /// One index over several GPUs of a node (`devices` = HIP ordinals).  Still ONE `VectorIndex`.
+    #[must_use]
+    pub fn with_params_on(
+        dimension: usize,
+        metric: DistanceMetric,
+        params: HnswParams,
+        devices: &[i32],
+        shard_mode: ShardMode,
+    ) -> Option<Self> {
+        if device_count() == 0 || devices.is_empty() {
+            return None;
+        }
+        let mode = match shard_mode {
+            ShardMode::Replica => sys::VDB_SHARD_REPLICA,
+            ShardMode::Range => sys::VDB_SHARD_RANGE,
+        };
+        let mut h: *mut sys::VdbHipIndex = ptr::null_mut();
+        // SAFETY: `devices` outlives the call; `h` is a valid out pointer.
+        let rc = unsafe {
+            sys::vdb_hip_index_create(
+                dimension as u32,
+                metric_code(metric),
+                params.max_connections as u32,
+                params.ef_construction as u32,
+                params.max_elements as u64,
+                devices.as_ptr(),
+                devices.len() as i32,
+                mode,
+                &mut h,
+            )
+        };
+        if rc != sys::VDB_OK || h.is_null() {
+            return None;
+        }
+        let me = Self { h, dimension, metric };
+        // HnswParams::storage_mode (params.rs:24-27): SQ8 / Binary collections quantise every stored vector
+        let sm = match params.storage_mode {
+            velesdb_core::quantization::StorageMode::Full => sys::VDB_STORAGE_FULL,
+            velesdb_core::quantization::StorageMode::SQ8 => sys::VDB_STORAGE_SQ8,
+            velesdb_core::quantization::StorageMode::Binary => sys::VDB_STORAGE_BINARY,
+        };
+        if sm != sys::VDB_STORAGE_FULL {
+            // SAFETY: live handle.
+            check(unsafe { sys::vdb_hip_index_set_storage_mode(me.h, sm) });
+        }
+        Some(me)
+    }
+
+    /// One process per GPU: joins the RCCL group of `world` ranks (`id` from [`comm_unique_id`] on rank 0, distributed
+    /// out of band).  Afterwards the exact search modes return the global top-k on every rank.
+    pub fn join_group(&self, id: &[u8; sys::VDB_COMM_ID_BYTES], rank: usize, world: usize) {
+        // SAFETY: live handle, `id` has VDB_COMM_ID_BYTES bytes.
+        check(unsafe { sys::vdb_hip_index_join_group(self.h, id.as_ptr(), rank as i32, world as i32) });
+    }
+
+    fn validate_dimension(&self, data: &[f32], data_type: &str) {
+        // index/hnsw/index/search.rs:16-27
+        assert_eq!(
+            data.len(),
+            self.dimension,
+            "{data_type} dimension mismatch: expected {}, got {}",
+            self.dimension,
+            data.len()
+        );
+    }
+
+    fn search_one(&self, query: &[f32], k: usize, ef: usize, mode: i32) -> Vec<(u64, f32)> {
+        if k == 0 {
+            return Vec::new();
+        }
+        let mut ids = vec![0u64; k];
+        let mut scores = vec![0f32; k];
+        let mut n: u32 = 0;
+        // SAFETY: `ids` / `scores` hold k entries as the ABI requires; the query has `dimension` floats (validated by callers).
+        check(unsafe {
+            sys::vdb_hip_index_search(
+                self.h,
+                query.as_ptr(),
+                query.len() as u32,
+                k as u32,
+                ef as u32,
+                mode,
+                ids.as_mut_ptr(),
+                scores.as_mut_ptr(),
+                &mut n,
+            )
+        });
+        ids.truncate(n as usize);
+        scores.truncate(n as usize);
+        ids.into_iter().zip(scores).collect()
+    }
+
+    fn search_many(&self, queries: &[&[f32]], k: usize, ef: usize, mode: i32) -> Vec<Vec<(u64, f32)>> {
+        if queries.is_empty() {
+            return Vec::new();
+        }
+        if k == 0 {
+            return vec![Vec::new(); queries.len()];
+        }
+        let nq = queries.len();
+        let mut flat = Vec::with_capacity(nq * self.dimension);
+        for q in queries {
+            flat.extend_from_slice(q);
+        }
+        let mut ids = vec![0u64; nq * k];
+        let mut scores = vec![0f32; nq * k];
+        let mut counts = vec![0u32; nq];
+        // SAFETY: buffer sizes are nq*dim / nq*k / nq as the ABI requires.
+        check(unsafe {
+            sys::vdb_hip_index_search_batch(
+                self.h,
+                flat.as_ptr(),
+                nq as u32,
+                k as u32,
+                ef as u32,
+                mode,
+                ids.as_mut_ptr(),
+                scores.as_mut_ptr(),
+                counts.as_mut_ptr(),
+            )
+        });
+        (0..nq)
+            .map(|i| {
+                let c = counts[i] as usize;
+                (0..c).map(|j| (ids[i * k + j], scores[i * k + j])).collect()
+            })
+            .collect()
+    }
+
+    /// `HnswIndex::search_with_quality` (`search.rs:59-94`): `Perfect` = exact scan; otherwise mode AUTO (exact scan when
+    /// `len() <= 100`, else the graph with `quality.ef_search(k)`; scores through `transform_score`).
+    #[must_use]
+    pub fn search_with_quality(&self, query: &[f32], k: usize, quality: SearchQuality) -> Vec<(u64, f32)> {
+        self.validate_dimension(query, "Query");
+        if matches!(quality, SearchQuality::Perfect) {
+            return self.search_brute_force(query, k);
+        }
+        self.search_one(query, k, quality.ef_search(k), sys::VDB_SEARCH_AUTO)
+    }
+
+    /// `HnswIndex::search_brute_force` (`search.rs:176-219`): exact scan, raw scores, `metric.sort_results` order.
+    #[must_use]
+    pub fn search_brute_force(&self, query: &[f32], k: usize) -> Vec<(u64, f32)> {
+        self.validate_dimension(query, "Query");
+        self.search_one(query, k, 0, sys::VDB_SEARCH_BRUTE)
+    }
+
+    /// `search_brute_force_buffered` (`search.rs:366-369`), `brute_force_search_parallel` (`batch.rs:223-240`) and
+    /// `search_brute_force_gpu` (`search.rs:229-290`) are the same exact scan here.
+    #[must_use]
+    pub fn search_brute_force_buffered(&self, query: &[f32], k: usize) -> Vec<(u64, f32)> {
+        self.search_brute_force(query, k)
+    }
+
+    /// See [`Self::search_brute_force_buffered`].
+    #[must_use]
+    pub fn brute_force_search_parallel(&self, query: &[f32], k: usize) -> Vec<(u64, f32)> {
+        self.search_brute_force(query, k)
+    }
+
+    /// See [`Self::search_brute_force_buffered`]; always `Some` (the reference returns `None` without its `gpu` feature).
+    #[must_use]
+    pub fn search_brute_force_gpu(&self, query: &[f32], k: usize) -> Option<Vec<(u64, f32)>> {
+        Some(self.search_brute_force(query, k))
+    }
+
+    /// The exact scan for a whole batch of queries in one call: the library's headline path (one corpus pass serves up
+    /// to 1 024 queries on the matrix cores).  Equal, query by query, to [`Self::search_brute_force`].
+    #[must_use]
+    pub fn search_batch_brute_force(&self, queries: &[&[f32]], k: usize) -> Vec<Vec<(u64, f32)>> {
+        for q in queries {
+            self.validate_dimension(q, "Query");
+        }
+        self.search_many(queries, k, 0, sys::VDB_SEARCH_BRUTE)
+    }
+
+    /// `HnswIndex::search_batch_parallel` (`batch.rs:159-197`): always the graph, one launch for all queries.
+    #[must_use]
+    pub fn search_batch_parallel(&self, queries: &[&[f32]], k: usize, quality: SearchQuality) -> Vec<Vec<(u64, f32)>> {
+        for (i, query) in queries.iter().enumerate() {
+            assert_eq!(
+                query.len(),
+                self.dimension,
+                "Query {} dimension mismatch: expected {}, got {}",
+                i,
+                self.dimension,
+                query.len()
+            );
+        }
+        self.search_many(queries, k, quality.ef_search(k), sys::VDB_SEARCH_HNSW)
+    }
+
+    /// `HnswIndex::search_with_rerank` (`search.rs:118-160`): `rerank_k` candidates at `SearchQuality::Accurate`, re-scored
+    /// with the raw distance, cut to `k`.
+    #[must_use]
+    pub fn search_with_rerank(&self, query: &[f32], k: usize, rerank_k: usize) -> Vec<(u64, f32)> {
+        self.rerank(query, k, rerank_k, 0)
+    }
+
+    /// `HnswIndex::search_with_rerank_quality` (`search.rs:297-350`).
+    #[must_use]
+    pub fn search_with_rerank_quality(
+        &self,
+        query: &[f32],
+        k: usize,
+        rerank_k: usize,
+        initial_quality: SearchQuality,
+    ) -> Vec<(u64, f32)> {
+        if matches!(initial_quality, SearchQuality::Perfect) {
+            // the candidates of the Perfect profile are the exact scan's; its raw scores are what the re-ranking computes
+            return self.search_brute_force(query, k);
+        }
+        self.rerank(query, k, rerank_k, initial_quality.ef_search(rerank_k))
+    }
+
+    fn rerank(&self, query: &[f32], k: usize, rerank_k: usize, ef: usize) -> Vec<(u64, f32)> {
+        self.validate_dimension(query, "Query");
+        if k == 0 {
+            return Vec::new();
+        }
+        let mut ids = vec![0u64; k];
+        let mut scores = vec![0f32; k];
+        let mut n: u32 = 0;
+        // SAFETY: one query, k outputs.
+        check(unsafe {
+            sys::vdb_hip_index_search_rerank(
+                self.h,
+                query.as_ptr(),
+                1,
+                k as u32,
+                rerank_k.max(k) as u32,
+                ef as u32,
+                ids.as_mut_ptr(),
+                scores.as_mut_ptr(),
+                &mut n,
+            )
+        });
+        ids.truncate(n as usize);
+        scores.truncate(n as usize);
+        ids.into_iter().zip(scores).collect()
+    }
+
+    fn flatten<I>(&self, vectors: I) -> (Vec<u64>, Vec<f32>)
+    where
+        I: IntoIterator<Item = (u64, Vec<f32>)>,
+    {
+        let mut ids = Vec::new();
+        let mut flat = Vec::new();
+        for (id, v) in vectors {
+            self.validate_dimension(&v, "Vector"); // batch.rs:26-34
+            ids.push(id);
+            flat.extend_from_slice(&v);
+        }
+        (ids, flat)
+    }
+
+    /// `HnswIndex::insert_batch_parallel` (`batch.rs:82-108`).  Returns the number of vectors inserted (duplicates are
+    /// skipped).  The reference inserts with rayon in a non-deterministic order; the library inserts batch-synchronously
+    /// and deterministically (header, `vdb_hip_index_insert_batch_parallel`).
+    pub fn insert_batch_parallel<I>(&self, vectors: I) -> usize
+    where
+        I: IntoIterator<Item = (u64, Vec<f32>)>,
+    {
+        let (ids, flat) = self.flatten(vectors);
+        if ids.is_empty() {
+            return 0;
+        }
+        let mut inserted: u64 = 0;
+        // SAFETY: `flat` holds ids.len() * dimension floats.
+        check(unsafe {
+            sys::vdb_hip_index_insert_batch_parallel(self.h, ids.as_ptr(), flat.as_ptr(), ids.len() as u64, 0, &mut inserted)
+        });
+        inserted as usize
+    }
+
+    /// `HnswIndex::insert_batch_sequential` (`batch.rs:120-149`): one vector after the other, the reference's own
+    /// deterministic order.
+    pub fn insert_batch_sequential<I>(&self, vectors: I) -> usize
+    where
+        I: IntoIterator<Item = (u64, Vec<f32>)>,
+    {
+        let (ids, flat) = self.flatten(vectors);
+        if ids.is_empty() {
+            return 0;
+        }
+        let mut inserted: u64 = 0;
+        // SAFETY: as above.
+        check(unsafe { sys::vdb_hip_index_insert_batch(self.h, ids.as_ptr(), flat.as_ptr(), ids.len() as u64, &mut inserted) });
+        inserted as usize
+    }
+
+    /// Bulk load without graph construction: rows are searchable by the exact modes at once; [`Self::build_graph`] links
+    /// them later.  (No counterpart in the reference: its `Collection::open` rebuilds the index by inserting.)
+    pub fn upload(&self, ids: &[u64], vectors_rowmajor: &[f32]) -> usize {
+        assert_eq!(
+            vectors_rowmajor.len(),
+            ids.len() * self.dimension,
+            "Vector dimension mismatch: expected {} floats, got {}",
+            ids.len() * self.dimension,
+            vectors_rowmajor.len()
+        );
+        if ids.is_empty() {
+            return 0;
+        }
+        let mut inserted: u64 = 0;
+        // SAFETY: sizes checked above.
+        check(unsafe { sys::vdb_hip_index_upload(self.h, ids.as_ptr(), vectors_rowmajor.as_ptr(), ids.len() as u64, &mut inserted) });
+        inserted as usize
+    }
+
+    /// Links every row that is not in the graph yet.
+    pub fn build_graph(&self) {
+        // SAFETY: live handle.
+        check(unsafe { sys::vdb_hip_index_build_graph(self.h, 0) });
+    }
+
+    /// `HnswIndex::set_searching_mode` (`search.rs:379-384`): a no-op kept for API compatibility, there as here.
+    pub fn set_searching_mode(&self) {}
+
+    /// `HnswIndex::has_vector_storage` (`constructors.rs:320-322`): the GPU index always keeps its vectors.
+    #[must_use]
+    pub fn has_vector_storage(&self) -> bool {
+        true
+    }
+
+    /// `HnswIndex::tombstone_count` (`vacuum.rs:45-52`).
+    #[must_use]
+    pub fn tombstone_count(&self) -> usize {
+        let mut n: u64 = 0;
+        // SAFETY: live handle, valid out pointer.
+        check(unsafe { sys::vdb_hip_index_tombstone_count(self.h, &mut n) });
+        n as usize
+    }
+
+    /// `HnswIndex::tombstone_ratio` (`vacuum.rs:60-68`): tombstones / graph nodes.
+    #[must_use]
+    pub fn tombstone_ratio(&self) -> f64 {
+        let mut nodes: u64 = 0;
+        // SAFETY: live handle, valid out pointer.
+        check(unsafe { sys::vdb_hip_index_node_count(self.h, &mut nodes) });
+        if nodes == 0 {
+            return 0.0;
+        }
+        self.tombstone_count() as f64 / nodes as f64
+    }
+
+    /// `HnswIndex::needs_vacuum` (`vacuum.rs:74-76`): ratio above 20 %.
+    #[must_use]
+    pub fn needs_vacuum(&self) -> bool {
+        self.tombstone_ratio() > 0.2
+    }
+
+    /// `HnswIndex::vacuum` (`vacuum.rs:110-184`): rebuilds the graph over the active vectors.
+    pub fn vacuum(&self) -> Result<usize, VacuumError> {
+        let mut count: u64 = 0;
+        // SAFETY: live handle, valid out pointer.
+        check(unsafe { sys::vdb_hip_index_vacuum(self.h, &mut count) });
+        Ok(count as usize)
+    }
+
+    /// `HnswIndex::save` (`constructors.rs:255-287`): `native_hnsw.{vectors,graph}`, `native_mappings.bin`, `native_meta.bin`.
+    pub fn save<P: AsRef<Path>>(&self, path: P) -> Result<(), io::Error> {
+        std::fs::create_dir_all(path.as_ref())?;
+        let dir = c_path(path)?;
+        // SAFETY: NUL-terminated path, live handle.
+        io_check(unsafe { sys::vdb_hip_index_save_dir(self.h, dir.as_ptr()) })
+    }
+
+    /// `HnswIndex::load` (`constructors.rs:190-253`).  Dimension and metric are read from `native_meta.bin`; the
+    /// arguments are checked against the files like the reference trusts them.
+    pub fn load<P: AsRef<Path>>(path: P, dimension: usize, metric: DistanceMetric) -> io::Result<Self> {
+        if device_count() == 0 {
+            return Err(io::Error::new(io::ErrorKind::NotFound, "no HIP device"));
+        }
+        let dir = c_path(path)?;
+        let mut h: *mut sys::VdbHipIndex = ptr::null_mut();
+        // SAFETY: NUL-terminated path, valid out pointer.
+        io_check(unsafe { sys::vdb_hip_index_load_dir(dir.as_ptr(), 0, &mut h) })?;
+        let mut dim: u32 = 0;
+        let mut mc: i32 = 0;
+        // SAFETY: `h` was just created.
+        unsafe {
+            sys::vdb_hip_index_dimension(h, &mut dim);
+            sys::vdb_hip_index_metric(h, &mut mc);
+        }
+        let me = Self { h, dimension: dim as usize, metric: metric_from_code(mc) };
+        if me.dimension != dimension || me.metric != metric {
+            return Err(io::Error::new(
+                io::ErrorKind::InvalidData,
+                format!(
+                    "index files hold dimension {} / {:?}, caller expects {} / {:?}",
+                    me.dimension, me.metric, dimension, metric
+                ),
+            ));
+        }
+        Ok(me)
+    }
+
+    /// Imports a flushed `MmapStorage` directory (`core/storage/mmap.rs`) with the store's ids; no graph is built.
+    pub fn upload_vector_store<P: AsRef<Path>>(&self, path: P) -> io::Result<usize> {
+        let dir = c_path(path)?;
+        let mut inserted: u64 = 0;
+        // SAFETY: NUL-terminated path, live handle, valid out pointer.
+        io_check(unsafe { sys::vdb_hip_index_upload_vector_store(self.h, dir.as_ptr(), &mut inserted) })?;
+        Ok(inserted as usize)
+    }
+
+    /// Device-resident search: `d_queries` / outputs are HIP device pointers, the call enqueues on `stream` and returns.
+    ///
+    /// # Safety
+    /// The pointers must be device allocations of `nq * dimension` f32, `nq * k` u64, `nq * k` f32 and `nq` u32 that
+    /// stay alive until `stream` has run the work; `stream` must be a live `hipStream_t` of the index's device.
+    #[allow(clippy::too_many_arguments)]
+    pub unsafe fn search_batch_dev(
+        &self,
+        d_queries: *const f32,
+        nq: usize,
+        k: usize,
+        ef: usize,
+        mode: i32,
+        d_out_ids: *mut u64,
+        d_out_scores: *mut f32,
+        d_out_n: *mut u32,
+        stream: *mut c_void,
+    ) {
+        check(sys::vdb_hip_index_search_batch_dev(
+            self.h,
+            d_queries,
+            nq as u32,
+            k as u32,
+            ef as u32,
+            mode,
+            d_out_ids,
+            d_out_scores,
+            d_out_n,
+            stream,
+        ));
+    }
+
+    /// The raw handle, for the entry points this wrapper does not cover (`sys::*`).
+    #[must_use]
+    pub fn as_raw(&self) -> *mut sys::VdbHipIndex {
+        self.h
+    }
+}
+
+impl VectorIndex for HipHnswIndex {
+    fn insert(&self, id: u64, vector: &[f32]) {
+        // trait_impl.rs:12-18
+        assert_eq!(
+            vector.len(),
+            self.dimension,
+            "Vector dimension mismatch: expected {}, got {}",
+            self.dimension,
+            vector.len()
+        );
+        // SAFETY: live handle, `vector` has `dimension` floats.  Status 1 = duplicate id, silently skipped (trait_impl.rs:23-25).
+        check(unsafe { sys::vdb_hip_index_insert(self.h, id, vector.as_ptr(), vector.len() as u32) });
+    }
+
+    fn search(&self, query: &[f32], k: usize) -> Vec<(u64, f32)> {
+        // trait_impl.rs:38-41
+        self.search_with_quality(query, k, SearchQuality::Balanced)
+    }
+
+    fn remove(&self, id: u64) -> bool {
+        let mut removed: i32 = 0;
+        // SAFETY: live handle, valid out pointer.
+        check(unsafe { sys::vdb_hip_index_remove(self.h, id, &mut removed) });
+        removed != 0
+    }
+
+    fn len(&self) -> usize {
+        let mut n: u64 = 0;
+        // SAFETY: live handle, valid out pointer.
+        check(unsafe { sys::vdb_hip_index_len(self.h, &mut n) });
+        n as usize
+    }
+
+    fn dimension(&self) -> usize {
+        self.dimension
+    }
+
+    fn metric(&self) -> DistanceMetric {
+        self.metric
+    }
+}
+
+impl Drop for HipHnswIndex {
+    fn drop(&mut self) {
+        // SAFETY: the handle was created by the library and is destroyed exactly once.
+        unsafe { sys::vdb_hip_index_destroy(self.h) }
+    }
+}
+
+/// 128-byte RCCL id for [`HipHnswIndex::join_group`]; rank 0 generates it and hands it to the other ranks.
+#[must_use]
+pub fn comm_unique_id() -> [u8; sys::VDB_COMM_ID_BYTES] {
+    let mut id = [0u8; sys::VDB_COMM_ID_BYTES];
+    // SAFETY: the buffer has VDB_COMM_ID_BYTES bytes.
+    check(unsafe { sys::vdb_hip_comm_unique_id(id.as_mut_ptr()) });
+    id
+}
+
+fn batch_distance_flat(device: i32, metric: DistanceMetric, kind: i32, query: &[f32], flat: &[f32], n: usize) -> Vec<f32> {
+    let mut out = vec![0f32; n];
+    if n == 0 {
+        return out;
+    }
+    // SAFETY: `flat` holds n * query.len() floats (callers build it that way), `out` holds n.
+    check(unsafe {
+        sys::vdb_hip_batch_distance(device, metric_code(metric), kind, query.as_ptr(), flat.as_ptr(), n as u64, query.len() as u32, out.as_mut_ptr())
+    });
+    out
+}
+
+/// `DistanceEngine` over the GPU (`index/hnsw/native/distance.rs:14-28`): `distance` conventions of `SimdDistance`
+/// (1 - cos, sqrt(l2), -dot, hamming, 1 - jaccard; `distance.rs:75-85`).
+pub struct HipDistance {
+    metric: DistanceMetric,
+    device: i32,
+}
+
+impl HipDistance {
+    /// `None` without a HIP device.
+    #[must_use]
+    pub fn new(metric: DistanceMetric) -> Option<Self> {
+        (device_count() > 0).then_some(Self { metric, device: 0 })
+    }
+}
+
+impl DistanceEngine for HipDistance {
+    fn distance(&self, a: &[f32], b: &[f32]) -> f32 {
+        assert_eq!(a.len(), b.len(), "Vector dimensions must match");
+        batch_distance_flat(self.device, self.metric, sys::VDB_KIND_ENGINE, a, b, 1)[0]
+    }
+
+    fn batch_distance(&self, query: &[f32], candidates: &[&[f32]]) -> Vec<f32> {
+        let mut flat = Vec::with_capacity(candidates.len() * query.len());
+        for c in candidates {
+            assert_eq!(c.len(), query.len(), "Vector dimensions must match");
+            flat.extend_from_slice(c);
+        }
+        batch_distance_flat(self.device, self.metric, sys::VDB_KIND_ENGINE, query, &flat, candidates.len())
+    }
+
+    fn metric(&self) -> DistanceMetric {
+        self.metric
+    }
+}
+
+/// `GpuAccelerator` (`gpu/gpu_backend.rs`): batch kernels over a flat row-major matrix, raw scores.
+pub struct HipAccelerator {
+    device: i32,
+}
+
+impl HipAccelerator {
+    /// `GpuAccelerator::new` (`gpu_backend.rs:33`).
+    #[must_use]
+    pub fn new() -> Option<Self> {
+        (device_count() > 0).then_some(Self { device: 0 })
+    }
+
+    /// `GpuAccelerator::is_available` (`gpu_backend.rs:136`).
+    #[must_use]
+    pub fn is_available() -> bool {
+        device_count() > 0
+    }
+
+    fn batch(&self, metric: DistanceMetric, vectors: &[f32], query: &[f32], dimension: usize) -> Vec<f32> {
+        if dimension == 0 || vectors.is_empty() {
+            return Vec::new(); // gpu_backend.rs:163-166
+        }
+        assert_eq!(query.len(), dimension, "Query dimension mismatch: expected {}, got {}", dimension, query.len());
+        let n = vectors.len() / dimension;
+        batch_distance_flat(self.device, metric, sys::VDB_KIND_RAW, query, &vectors[..n * dimension], n)
+    }
+
+    /// `GpuAccelerator::batch_cosine_similarity` (`gpu_backend.rs:157`).
+    #[must_use]
+    pub fn batch_cosine_similarity(&self, vectors: &[f32], query: &[f32], dimension: usize) -> Vec<f32> {
+        self.batch(DistanceMetric::Cosine, vectors, query, dimension)
+    }
+
+    /// `GpuAccelerator::batch_euclidean_distance` (`gpu_backend.rs:355`).
+    #[must_use]
+    pub fn batch_euclidean_distance(&self, vectors: &[f32], query: &[f32], dimension: usize) -> Vec<f32> {
+        self.batch(DistanceMetric::Euclidean, vectors, query, dimension)
+    }
+
+    /// `GpuAccelerator::batch_dot_product` (`gpu_backend.rs:397`).
+    #[must_use]
+    pub fn batch_dot_product(&self, vectors: &[f32], query: &[f32], dimension: usize) -> Vec<f32> {
+        self.batch(DistanceMetric::DotProduct, vectors, query, dimension)
+    }
+}
