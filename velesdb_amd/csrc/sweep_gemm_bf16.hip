@@ -92,11 +92,14 @@ __device__ __forceinline__ void mfma_bf16_first(f32x4& c, const f32x4& a, const 
 }
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
-// One LDS-DMA instruction (`buffer_load_dwordx4 ... offen lds`: 64 lanes x 16 B land at M0 + 16 lane), pinned in the
+// One LDS-DMA instruction (`buffer_load_dwordx4 ... offen lds`: 64 lanes x 16 B land at M0 + 16 lane).  s_nop 3: with the
+// s_mov that is 5 wait states between a vector-ALU write of one of the SGPR operands (v_readlane restoring a spilled SGPR)
+// and the load — "VALU writes SGPR -> VMEM reads that SGPR" is a hazard the compiler's recogniser cannot see inside inline
+// asm (an experiment with asm global loads next to a v_readlane faulted on exactly this).  Pinned in the
 // instruction stream (`asm volatile` keeps its place among the MFMAs).  The compiler does not count these on vmcnt: every k-tile step ends with an explicit `s_waitcnt vmcnt(0)` in front of its barrier.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void glds_b128(const i32x4& rsrc, uint32_t voff, uint32_t soff, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 3\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                :
                : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
                : "m0");  // no "memory" clobber: fragment reads of the OTHER buffer may move across a request
