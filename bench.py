@@ -61,7 +61,9 @@ def parse():
     p.add_argument("--no-embedding-leg", action="store_true", help="skip the graph leg on embedding-like data")
     p.add_argument("--dist-single", action="store_true", help="self-test: initialise torch's RCCL process group even with one rank")
     p.add_argument("--no-sharded-leg", action="store_true", help="skip the range-sharded leg (profiling passes)")
-    p.add_argument("--no-split", action="store_true", help="headline on the exact f32 matrix-core kernel (split-bf16 selector off)")
+    p.add_argument("--no-split", action="store_true", help="headline on the exact f32 matrix-core kernel (no selection stage)")
+    p.add_argument("--select-level", type=int, default=2, choices=[0, 1, 2],
+                   help="selection stage of large exact batches: 0 exact kernel, 1 split-bf16, 2 plain bf16 first (library default)")
     p.add_argument("--no-traffic-pass", action="store_true", help="skip the rocprofv3 FETCH_SIZE child pass that fills roofline.traffic")
     p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the child of the traffic pass: headline steps only
     p.add_argument("--no-latency-legs", action="store_true", help="skip the graph-path latency legs and the configs[0] leg")
@@ -129,7 +131,7 @@ def main():
     torch.cuda.synchronize()
     va.set_max_query_tile(a.tile)
     va.set_sweep_engine(a.engine)
-    va.set_split_selector(not a.no_split)
+    va.set_split_selector(0 if a.no_split else a.select_level)
     ix.upload_dev(0, corpus.data_ptr(), N, stream)
     sample_rows = min(a.cpu_sample_rows, N)
     host_sample = corpus[:sample_rows].cpu().numpy() if rank == 0 else None
@@ -227,7 +229,7 @@ def main():
     tflops = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
     # index.hip split_path_ok: large exact cosine / dot batches select on the bf16 matrix cores (sweep_split.hip)
-    split_active = (mfma and not a.no_split and a.tile >= 128 and Q >= 224 and Q * 8 >= ((Q + 255) // 256) * 256 * 7
+    split_active = (mfma and not a.no_split and a.select_level > 0 and a.tile >= 128 and Q >= 224 and Q * 8 >= ((Q + 255) // 256) * 256 * 7
                     and K <= 10 and N >= 65536 and D % 32 == 0 and D >= 64)
 
     def exact_roofline(kms, nl):
@@ -249,18 +251,24 @@ def main():
         # device-driven fallback launch.  achieved = ALGORITHMIC flop (2*rows*dim*queries) / that time against the bf16
         # dense peak; the selection issues 3 bf16 MFMAs per algorithmic product (hi.hi + hi.lo + lo.hi).
         nq_last, unproven = ix.last_split_stats()
+        level = ix.last_select_level()
+        mfmas_per_product = 3.0 if level == 1 else 1.0
+        sel_kernel = (f"sweep_topk_gemm_bf16_glds<{a.metric},SPLIT>" if level == 1 else f"sweep_topk_gemm_bf16_glds<{a.metric}> (plain bf16 selection)")
         roofline = {"bound": "mfma", "achieved": round(tflops, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "kernel": f"sweep_topk_gemm_bf16_glds<{a.metric},SPLIT> (+ exact seed, merges, split_rerank_verify, fallback check)",
+                    "kernel": sel_kernel + " (+ exact seed, merges, split_rerank_verify, fallback check)",
+                    "select_level": level,
                     "kernel_ms": round(kernel_ms, 4), "launches_timed": kernel_launches,
                     "alg_flops_per_launch": flops, "queries_per_launch": tile, "alg_bytes_per_launch": alg_bytes,
-                    "issued_bf16_tflops": round(3.0 * tflops, 1),
-                    "matrix_pipe_utilisation": round(3.0 * tflops / BF16_MFMA_PEAK_TFLOPS, 4),
+                    "issued_bf16_tflops": round(mfmas_per_product * tflops, 1),
+                    "matrix_pipe_utilisation": round(mfmas_per_product * tflops / BF16_MFMA_PEAK_TFLOPS, 4),
                     "unproven_queries_last_batch": unproven, "queries_last_batch": nq_last,
                     "hbm_gbs": round(achieved, 1), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "note": "frac = algorithmic flop / time / 2.5 PFLOP/s (bf16 dense); matrix_pipe_utilisation counts the "
-                            "3 MFMAs issued per product; exact_f32_kernel = the same batch on the exact f32 matrix-core "
-                            "kernel (split selector off), the kernel the results are bit-identical to"}
+                    "note": "exact f32 RESULTS (bit-identical to exact_f32_kernel) from a selection on the bf16 matrix cores "
+                            "(level 2: one MFMA per product over the bf16 copy of the rows; level 1: split-bf16, three) + "
+                            "exact re-scoring + per-query proof; kernel_ms = the whole batch (seed sweep, selection "
+                            "launches, merges, re-scoring, fallback check); frac = algorithmic flop (2*rows*dim*queries) / "
+                            "time / 2.5 PFLOP/s (bf16 dense)"}
         va.set_split_selector(False)
         for i in range(2):
             step(i)
@@ -274,7 +282,7 @@ def main():
         e_dt = (time.perf_counter() - te) / ne
         e_kms, e_nl = ix.last_kernel_ms()
         va.set_kernel_timing(False)
-        va.set_split_selector(True)
+        va.set_split_selector(a.select_level)
         exact_leg = {"qps": round(Q / e_dt, 1), "ms_per_step": round(e_dt * 1e3, 4), "roofline": exact_roofline(e_kms, e_nl)}
         roofline["exact_f32_kernel"] = exact_leg
     elif mfma and tile >= 64:
@@ -304,7 +312,7 @@ def main():
             cmd = ["rocprofv3", "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tdir, "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", str(child_steps), "--warmup", str(child_warm),
                    "--rows", str(N), "--dim", str(D), "--k", str(K), "--batch", str(Q), "--metric", a.metric,
-                   "--tile", str(a.tile), "--engine", str(a.engine)] + (["--no-split"] if a.no_split else [])
+                   "--tile", str(a.tile), "--engine", str(a.engine), "--select-level", str(a.select_level)] + (["--no-split"] if a.no_split else [])
             env = dict(os.environ, TMPDIR="/tmp")
             pr = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
             files = glob.glob(os.path.join(tdir, "**", "*counter_collection.csv"), recursive=True)
@@ -375,7 +383,7 @@ def main():
                           "qps": round(nq_t / t_dt, 1)})
         va.set_sweep_engine(a.engine)
         va.set_max_query_tile(a.tile)
-        va.set_split_selector(not a.no_split)
+        va.set_split_selector(0 if a.no_split else a.select_level)
 
     # ---- single-query latency mode (one corpus pass per query) ----
     lat = {}

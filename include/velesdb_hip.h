@@ -287,14 +287,22 @@ int32_t vdb_hip_set_max_query_tile(uint32_t b);
  * never depends on the batch size. */
 int32_t vdb_hip_set_sweep_engine(int32_t engine);
 /* Large exact Cosine / DotProduct batches (>= 224 queries that fill 256-query tiles, k <= 10, >= 65 536 rows, dim % 32 == 0):
- * 1 (default) = the matrix cores SELECT on a split-bf16 image of rows and queries (x = hi + lo, three bf16 MFMAs per
- * product), the 32 best candidates per query are re-scored with the exact chain (oracle mode M), every query's answer is
- * proven from an error bound or recomputed by the exact kernel — same ids, ranks and score bits as 0 = the exact f32
- * matrix-core kernel for the whole batch.  Costs +4 bytes per element of HBM (the split image, built at first use). */
-int32_t vdb_hip_set_split_selector(int32_t on);
+ * the matrix cores SELECT candidates on a reduced-precision image of rows and queries, the best candidates per query are
+ * re-scored with the exact chain (oracle mode M), and every query's answer is PROVEN from an error bound or recomputed by
+ * the exact kernel — same ids, ranks and score bits as the exact f32 matrix-core kernel for the whole batch.
+ *   0 = no selection stage: the exact f32 matrix-core kernel;
+ *   1 = split-bf16 selection (x = hi + lo, three bf16 MFMAs per product, error ~2^-15 + accumulation; 32 candidates);
+ *       costs +4 bytes per element of HBM (the split image, built at first use);
+ *   2 (default) = plain bf16 selection first (one MFMA per product over the bf16 copy of the rows, error ~2^-7; 64
+ *       candidates; +2 bytes per element, dim % 64 == 0), level 1 where that does not apply; a handle whose data defeats
+ *       the wider bound (> 1/16 of a batch unproven: near-duplicate clusters) moves itself to level 1 for the next 64
+ *       batches and then tries again. */
+int32_t vdb_hip_set_split_selector(int32_t level);
 /* diagnostic: queries in the last split-selector batch (its last chunk of <= 1024) and how many of them the exact
  * fallback kernel answered because the selection could not be proven (near-ties inside the error bound, non-finite data) */
 int32_t vdb_hip_index_last_split_stats(vdb_hip_index* idx, uint32_t* queries, uint32_t* unproven);
+/* selection level (0 / 1 / 2, see vdb_hip_set_split_selector) the last exact batch of this handle actually ran at */
+int32_t vdb_hip_index_last_select_level(vdb_hip_index* idx, int32_t* level);
 /* *mode = 1 if searches in VDB_SEARCH_BRUTE mode with this k run on the matrix-core kernel (mode M), else 0 */
 int32_t vdb_hip_index_sweep_arith_mode(vdb_hip_index* idx, uint32_t k, int32_t* mode);
 int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* idx, float* ms, uint32_t* launches);

@@ -1,6 +1,6 @@
-"""GPU parity tests of the split-bf16 selector behind large exact Cosine / DotProduct batches (sweep_split.hip): the
-matrix cores select on hi + lo bf16 images, the candidates are re-scored with the exact chain, every answer is proven
-or recomputed by the exact kernel.  Bar: ids, ranks and score BITS equal to the oracle's mode M (= the exact matrix-core
+"""GPU parity tests of the selection stage behind large exact Cosine / DotProduct batches (sweep_split.hip): the
+matrix cores select on hi + lo bf16 images (level 1) or on the plain bf16 copy (level 2, where dim % 64 == 0), the
+candidates are re-scored with the exact chain, every answer is proven or recomputed by the exact kernel.  Bar: ids, ranks and score BITS equal to the oracle's mode M (= the exact matrix-core
 kernel) — on random data (everything proven) and on data built to defeat the selection (near-duplicates closer than the
 error bound, massive exact ties, rows sorted by score, zero / huge / non-finite values, soft deletes)."""
 import os
@@ -22,6 +22,15 @@ def bits(a):
 
 
 def run_case(metric, rows, qs, k, expect_unproven=None, remove=()):
+    out = None
+    for level in (1, 2):
+        u = _run_case(metric, rows, qs, k, level, expect_unproven, remove)
+        out = u if out is None else out  # callers look at level 1's count
+    va.set_split_selector(2)  # the library default
+    return out
+
+
+def _run_case(metric, rows, qs, k, level, expect_unproven, remove):
     n, dim = rows.shape
     pm = po.COSINE if metric == DM.Cosine else po.DOT
     ids_ext = np.arange(n, dtype=np.uint64) * np.uint64(3) + np.uint64(11)
@@ -32,18 +41,19 @@ def run_case(metric, rows, qs, k, expect_unproven=None, remove=()):
         assert ix.remove(int(ids_ext[r]))
         keep[r] = False
     assert ix.sweep_arith_mode(k) == "M"
-    va.set_split_selector(True)
+    va.set_split_selector(level)
     ids, sc, cnt = ix.search_batch_brute_force(qs, k)
     nq_last, unproven = ix.last_split_stats()
-    assert nq_last > 0, "the split selector did not run"
+    assert nq_last > 0, "the selection stage did not run"
+    assert ix.last_select_level() == (2 if level == 2 and dim % 64 == 0 and dim >= 128 else 1)
     eid, esc = po.scan_topk(pm, rows[keep], qs, k, po.MODE_M, nthreads=NT)
     emap = ids_ext[keep]
     assert np.array_equal(ids, emap[eid.astype(np.int64)]), "ids / ranks differ from the oracle (mode M)"
     assert np.array_equal(bits(sc), bits(esc)), "score bits differ from the oracle (mode M)"
     assert np.all(cnt == k)
-    va.set_split_selector(False)
+    va.set_split_selector(0)
     ids0, sc0, cnt0 = ix.search_batch_brute_force(qs, k)
-    va.set_split_selector(True)
+    va.set_split_selector(level)
     assert np.array_equal(ids0, ids) and np.array_equal(bits(sc0), bits(sc)), "selector on / off disagree"
     if expect_unproven == "none":
         assert unproven == 0, f"{unproven} of {nq_last} queries fell back on well-separated data"
@@ -125,3 +135,32 @@ def test_soft_deleted_rows(gpu_required):
     best = np.argmax(qs[::4] @ rows.T, axis=1)
     remove = sorted(set(best.tolist()) | set(range(0, n, 997)))
     run_case(DM.DotProduct, rows, qs, k, remove=remove)
+
+
+def test_level2_parks_itself_at_level1_when_the_data_defeats_it(gpu_required):
+    # every query has 200 noisy copies whose cosines are ~5e-5 apart: the k-th and the 64th best are closer than level 2's
+    # ~2^-7 bound, the k-th and the 32nd further apart than level 1's ~3e-4.  The
+    # handle notices (> 1/16 of a batch unproven, read from pinned memory without synchronising) and answers the following
+    # batches at level 1 — with the same bits throughout.
+    rng = np.random.default_rng(10)
+    n, dim, nq, k = 80_000, 256, 256, 10
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    for j in range(nq):
+        where = rng.choice(n, 200, replace=False)
+        spread = np.linspace(0.05, 0.15, 200, dtype=np.float32)[:, None]
+        rows[where] = qs[j] + spread * rng.standard_normal((200, dim)).astype(np.float32)
+    ix = va.HnswIndex(dim, DM.Cosine, va.HnswParams(8, 50, n))
+    ix.upload(np.arange(n, dtype=np.uint64), rows)
+    va.set_split_selector(2)
+    eid, esc = po.scan_topk(po.COSINE, rows, qs, k, po.MODE_M, nthreads=NT)
+    levels, unproven = [], []
+    for rep in range(4):
+        ids, sc, cnt = ix.search_batch_brute_force(qs, k)  # a host call: the batch has finished when it returns
+        assert np.array_equal(ids, eid.astype(np.uint64)) and np.array_equal(bits(sc), bits(esc))
+        levels.append(ix.last_select_level())
+        unproven.append(ix.last_split_stats()[1])
+    assert levels[0] == 2 and unproven[0] > nq // 16, (levels, unproven)
+    assert levels[1:] == [1, 1, 1], levels
+    assert max(unproven[1:]) <= nq // 16, unproven
+    ix.close()

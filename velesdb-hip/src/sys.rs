@@ -104,8 +104,9 @@ extern "C" {
     pub fn vdb_hip_set_kernel_timing(on: i32) -> i32;
     pub fn vdb_hip_set_max_query_tile(b: u32) -> i32;
     pub fn vdb_hip_set_sweep_engine(engine: i32) -> i32;
-    pub fn vdb_hip_set_split_selector(on: i32) -> i32;
+    pub fn vdb_hip_set_split_selector(level: i32) -> i32;
     pub fn vdb_hip_index_last_split_stats(idx: *mut VdbHipIndex, queries: *mut u32, unproven: *mut u32) -> i32;
+    pub fn vdb_hip_index_last_select_level(idx: *mut VdbHipIndex, level: *mut i32) -> i32;
     pub fn vdb_hip_index_sweep_arith_mode(idx: *mut VdbHipIndex, k: u32, mode: *mut i32) -> i32;
     pub fn vdb_hip_index_last_kernel_ms(idx: *mut VdbHipIndex, ms: *mut f32, launches: *mut u32) -> i32;
     pub fn vdb_hip_last_error() -> *const c_char;

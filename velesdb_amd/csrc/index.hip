@@ -18,7 +18,8 @@ static thread_local std::string g_last_error;
 static std::atomic<int> g_timing{0};
 static std::atomic<int> g_sweep_engine{1};  // 1 (default): MFMA kernel for cosine / dot (oracle mode M); 0: VALU kernels (mode C)
 static std::atomic<uint32_t> g_max_tile{128};  // largest query tile of the exact sweep (vdb_hip_set_max_query_tile)
-static std::atomic<int> g_split_selector{1};  // large exact Cosine / Dot batches: split-bf16 selection + exact re-scoring + proof
+static std::atomic<int> g_split_selector{2};  // large exact Cosine / Dot batches: 0 exact kernel, 1 split-bf16 selection + exact re-scoring + proof,
+                                              // 2 plain bf16 selection first (same proof, wider bound), level 1 when a handle's data defeats it
 static std::atomic<uint32_t> g_int8_oversampling{4};  // DualPrecisionConfig::default().oversampling_ratio (dual_precision.rs:57)
 
 void set_last_error(const std::string& s) { g_last_error = s; }
@@ -100,7 +101,7 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
       (e = ix->alive.reserve(ncap, true, st)) != hipSuccess ||
       (e = ix->ext_ids.reserve(ncap * 8, true, st)) != hipSuccess)
     return fail(e == hipErrorOutOfMemory ? VDB_ERR_OOM : VDB_ERR_HIP, std::string("grow: ") + hipGetErrorString(e));
-  if ((ix->metric == VDB_COSINE || ix->metric == VDB_EUCLIDEAN || ix->split_enabled) &&
+  if ((ix->metric == VDB_COSINE || ix->metric == VDB_EUCLIDEAN || ix->split_enabled || ix->sel_norms) &&
       (e = ix->norms.reserve((ncap + kRowSlack) * 4, true, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("grow norms: ") + hipGetErrorString(e));
   if (ix->split_enabled && (e = ix->rows_split.reserve((ncap + kRowSlack) * (size_t)ix->dim * 4, true, st)) != hipSuccess)
@@ -131,7 +132,7 @@ static int32_t finish_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
   PrepArgs pa{};
   pa.rows = ix->rows.as<float>();
   // cosine: the kernels divide by them; Euclidean: |v|^2 of the matrix-core batch path (sweep_topk_gemm_f32<kEuclidean>)
-  pa.norms = (ix->metric == VDB_COSINE || ix->metric == VDB_EUCLIDEAN || ix->split_enabled) ? ix->norms.as<float>() : nullptr;
+  pa.norms = (ix->metric == VDB_COSINE || ix->metric == VDB_EUCLIDEAN || ix->split_enabled || ix->sel_norms) ? ix->norms.as<float>() : nullptr;
   pa.bits = is_bits_metric(ix->metric) ? ix->bits.as<uint32_t>() : nullptr;
   pa.row_stride = ix->row_stride;
   pa.row0 = (uint32_t)first;
@@ -429,22 +430,77 @@ static int32_t ensure_split(vdb_hip_index* ix, hipStream_t st) {
   return VDB_OK;
 }
 
-static bool split_path_ok(const vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
-  if (!g_split_selector || g_sweep_engine != 1 || g_max_tile < 128) return false;
-  if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT) return false;
-  if (ix->dim % 32 != 0 || ix->dim < 64 || ix->row_stride != ix->dim) return false;
-  if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return false;
+// level 2: the bf16 copy of the rows (what vdb_hip_index_enable_bf16 keeps) + canonical f32 norms for every metric
+static int32_t ensure_sel16(vdb_hip_index* ix, hipStream_t st) {
+  hipError_t e;
+  if (!ix->bf16_enabled) {
+    ix->bf16_stride = ((uint64_t)ix->dim + 7) / 8 * 8;
+    if ((e = ix->rows_bf16.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * ix->bf16_stride * 2, false, st)) != hipSuccess ||
+        (e = ix->norms_bf16.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * 4, false, st)) != hipSuccess)
+      return fail(VDB_ERR_OOM, std::string("bf16 rows: ") + hipGetErrorString(e));
+    ix->bf16_enabled = true;
+    ix->bf16_rows = 0;
+  }
+  if (ix->bf16_rows < ix->n_rows) {
+    launch_prep_bf16(ix->rows.as<float>(), ix->row_stride, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride, ix->norms_bf16.as<float>(),
+                     (uint32_t)ix->bf16_rows, (uint32_t)(ix->n_rows - ix->bf16_rows), ix->dim, st);
+    ix->bf16_rows = ix->n_rows;
+  }
+  if (!ix->sel_norms) {
+    if (ix->metric == VDB_DOT && !ix->split_enabled) {  // a DotProduct index did not need norms so far
+      if ((e = ix->norms.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * 4, false, st)) != hipSuccess)
+        return fail(VDB_ERR_OOM, std::string("norms: ") + hipGetErrorString(e));
+      PrepArgs pa{};
+      pa.rows = ix->rows.as<float>();
+      pa.norms = ix->norms.as<float>();
+      pa.row_stride = ix->row_stride;
+      pa.n_rows = (uint32_t)ix->n_rows;
+      pa.dim = ix->dim;
+      pa.words = ix->words;
+      if (pa.n_rows) launch_prep_rows(pa, st);
+    }
+    ix->sel_norms = true;
+  }
+  if (!ix->sel_stats) {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess) return fail(VDB_ERR_OOM, "pinned selection statistics");
+    memset(h, 0, 64);
+    ix->sel_stats = static_cast<volatile uint32_t*>(h);
+  }
+  VDB_HIP(hipGetLastError());
+  return VDB_OK;
+}
+
+// 0: no selection stage (exact kernel); 1: split-bf16 selection; 2: plain bf16 selection
+static int select_level(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
+  const int want = g_split_selector.load();
+  if (!want || g_sweep_engine != 1 || g_max_tile < 128) return 0;
+  if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT) return 0;
+  if (ix->dim % 32 != 0 || ix->dim < 64 || ix->row_stride != ix->dim) return 0;
+  if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
   const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
   const uint32_t nqt_big = (nqg + 255) / 256;
-  return nqg >= kGemmBigMinQueries && (uint64_t)nqg * 8 >= (uint64_t)nqt_big * 256 * 7;  // fills its 256-query tiles to >= 7/8
+  if (!(nqg >= kGemmBigMinQueries && (uint64_t)nqg * 8 >= (uint64_t)nqt_big * 256 * 7)) return 0;  // fills its 256-query tiles to >= 7/8
+  if (want < 2 || ix->dim % 64 != 0 || ix->dim < 128) return 1;
+  // what did the finished level-2 batches of this handle look like?  (pinned host memory, written by select_stats_kernel)
+  if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
+    ix->sel_seq_seen = ix->sel_stats[2];
+    if (ix->sel_stats[3] == 2u && (uint64_t)ix->sel_stats[0] * 16 > ix->sel_stats[1]) ix->sel16_hold = 64;  // > 1/16 unproven
+  }
+  if (ix->sel16_hold) {
+    ix->sel16_hold--;
+    return 1;
+  }
+  return 2;
 }
 
 static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, uint64_t* d_ids,
-                               float* d_scores, uint32_t* d_n, hipStream_t st) {
-  int32_t rc = ensure_split(ix, st);
+                               float* d_scores, uint32_t* d_n, hipStream_t st, int level) {
+  int32_t rc = level >= 2 ? ensure_sel16(ix, st) : ensure_split(ix, st);
   if (rc != VDB_OK) return rc;
+  ix->last_select_level = level;
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
-  const uint32_t n = (uint32_t)ix->n_rows, dim = ix->dim, K2 = kSplitPool;
+  const uint32_t n = (uint32_t)ix->n_rows, dim = ix->dim, K2 = level >= 2 ? kSelect16Pool : kSplitPool;
   const uint32_t ks = std::min<uint32_t>(kGemmBf16MaxK, k + 3);  // rows a selection block keeps per query (sweep_split.hip)
   // launch schedule: exact seed sweep over [0, R0) (at 1/16 of the selection's rate: kept short), selection over [R0, R1)
   // and [R1, n); the second, long launch gets a whole number of row tiles per row group (no straggler blocks)
@@ -498,9 +554,22 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
 
   EventPair* ev = next_events(ix);
   if (ev) (void)hipEventRecord(ev->a, st);
-  // queries: split image (+ canonical norms), zero rows behind the batch (the kernel stages whole 256-query tiles)
-  launch_split_vectors(d_q, q_stride, q16, qnorms, 0, nqg, dim, st);
-  VDB_HIP(hipMemsetAsync(q16 + (size_t)nqg * dim * 2, 0, (size_t)256 * dim * 4, st));
+  // queries: split image / bf16 image (+ canonical norms), zero rows behind the batch (the kernel stages whole 256-query tiles)
+  const uint64_t img_stride = level >= 2 ? ix->bf16_stride : (uint64_t)dim * 2;  // elements per row of either image
+  if (level >= 2) {
+    launch_round_queries_bf16(d_q, q_stride, q16, img_stride, nqg, dim, st);
+    PrepArgs pq{};
+    pq.rows = d_q;
+    pq.norms = qnorms;
+    pq.row_stride = q_stride;
+    pq.n_rows = nqg;
+    pq.dim = dim;
+    pq.words = ix->words;
+    launch_prep_rows(pq, st);
+  } else {
+    launch_split_vectors(d_q, q_stride, q16, qnorms, 0, nqg, dim, st);
+  }
+  VDB_HIP(hipMemsetAsync(q16 + (size_t)nqg * img_stride, 0, (size_t)256 * img_stride * 2, st));
   VDB_HIP(hipMemsetAsync(pool, 0xFF, (size_t)nqg * lists * ks * 8, st));
   VDB_HIP(hipMemsetAsync(blk_tau, 0xFF, (size_t)nqg * lists * 8, st));
   VDB_HIP(hipMemsetAsync(flags, 0, (size_t)nqg * 4 + 64 * 4 + 16, st));
@@ -530,13 +599,13 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
   ms.n_lists = sp.G;
   ms.k = k;
   launch_merge(true, ms, nqg, st);
-  launch_split_seed(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim, st);
+  launch_split_seed(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim, level, st);
   // selection launches over the split images
   uint32_t list_off = 1;
   for (int j = 0; j < n_launch; j++) {
-    e = launch_sweep_gemm_bf16_glds(ix->metric, bp[j], ix->rows_split.as<uint16_t>(), (uint64_t)dim * 2, ix->norms.as<float>(), alive,
-                                    q16, (uint64_t)dim * 2, tau0, pool, lists, list_off, dim, nqg, ks, st, /*split=*/true, qnorms,
-                                    blk_tau);
+    e = launch_sweep_gemm_bf16_glds(ix->metric, bp[j], level >= 2 ? ix->rows_bf16.as<uint16_t>() : ix->rows_split.as<uint16_t>(),
+                                    img_stride, ix->norms.as<float>(), alive, q16, img_stride, tau0, pool, lists, list_off, dim,
+                                    nqg, ks, st, /*split=*/level < 2, qnorms, blk_tau);
     if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split selection launch: ") + hipGetErrorString(e));
     list_off += bp[j].G;
     if (j + 1 < n_launch) {  // bound of the next launch: k-th best pool score so far
@@ -597,6 +666,7 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
   ix->split_flags_off = o_flags;
   ix->split_flags_n = nqg;
   ix->split_flags_stream = st;
+  if (ix->sel_stats) launch_select_stats(flags, nqg, ++ix->sel_seq, (uint32_t)level, ix->sel_stats, st);
   if (ev) (void)hipEventRecord(ev->b, st);
   VDB_HIP(hipGetLastError());
   return VDB_OK;
@@ -676,10 +746,11 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     }
     // large Cosine / DotProduct batches over a large corpus: split-bf16 selection + exact re-scoring + proof (same bits
     // as the exact matrix-core kernel below, which remains the fallback for unproven queries and every other shape)
-    if (mfma_nqt && split_path_ok(ix, nq - q0, k)) {
+    const int sel_level = mfma_nqt ? select_level(ix, nq - q0, k) : 0;
+    if (sel_level) {
       const uint32_t nqg = std::min<uint32_t>(nq - q0, kGemmMaxQueries);
       const int32_t rcs = brute_split_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nqg, k, d_ids + (size_t)q0 * k,
-                                          d_scores + (size_t)q0 * k, d_n + q0, st);
+                                          d_scores + (size_t)q0 * k, d_n + q0, st, sel_level);
       if (rcs != VDB_OK) return rcs;
       q0 += nqg;
       continue;
@@ -1013,6 +1084,7 @@ void destroy_single(vdb_hip_index* ix) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
+  if (ix->sel_stats) (void)hipHostFree(const_cast<uint32_t*>(ix->sel_stats));
   if (ix->ev_foreign) (void)hipEventDestroy(ix->ev_foreign);
   if (ix->ev_own) (void)hipEventDestroy(ix->ev_own);
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -1124,8 +1196,18 @@ int32_t vdb_hip_index_last_split_stats(vdb_hip_index* ix, uint32_t* queries, uin
   });
 }
 
-int32_t vdb_hip_set_split_selector(int32_t on) {
-  g_split_selector = on ? 1 : 0;
+int32_t vdb_hip_index_last_select_level(vdb_hip_index* ix, int32_t* level) {
+  return vdb::guarded([&]() -> int32_t {
+    if (!ix || !level) return fail(VDB_ERR_INVALID_ARG, "null argument");
+    VDB_NO_GROUP(ix, "last_select_level");
+    std::lock_guard<std::mutex> g(ix->mu);
+    *level = ix->last_select_level;
+    return VDB_OK;
+  });
+}
+
+int32_t vdb_hip_set_split_selector(int32_t level) {
+  g_split_selector = level <= 0 ? 0 : (level >= 2 ? 2 : 1);
   return VDB_OK;
 }
 

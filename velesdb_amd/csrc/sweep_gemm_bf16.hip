@@ -61,8 +61,8 @@ struct Bf16GemmArgs {
   uint32_t KT, G, nqt, qper;
   uint32_t row_tile0;       // first 256-row tile of the row range
   uint32_t list_stride, list_off;
-  // SPLIT instance only (exact-f32 selection, see sweep_split.hip)
-  const float* qnorms;      // [nq] canonical f32 norms of the ORIGINAL queries (cosine)
+  // selection stage of the exact f32 search only (sweep_split.hip; SPLIT instance, or the bf16 instance as its first level)
+  const float* qnorms;      // [nq] canonical f32 norms of the ORIGINAL queries (cosine); norms = those of the f32 rows
   uint64_t* blk_tau;        // [nq][list_stride]: the bound this block ends with per query (kKeyInvalid: it excluded nothing)
 };
 
@@ -152,8 +152,9 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs
   }
   if (tid < 4) flags[tid] = 0u;
   __syncthreads();
-  if (SPLIT) {  // the caller computed the canonical norms of the f32 queries (what the exact score divides by)
-    if ((uint32_t)tid < nq_t && a.qnorms) qn[tid] = a.qnorms[q0 + tid];
+  if (a.qnorms) {  // selection for the exact f32 search (SPLIT, or plain bf16 as its first level): the caller computed the
+                   // canonical norms of the f32 queries — what the exact score divides by
+    if ((uint32_t)tid < nq_t) qn[tid] = a.qnorms[q0 + tid];
   } else {  // norm of the ROUNDED query, canonical lane-chain order (as sweep_topk_mfma_bf16); DotProduct keeps it for the
             // overflow guard of the quick test only
     for (uint32_t b = wib; b < nq_t; b += WAVES) {
@@ -493,7 +494,7 @@ _Pragma("unroll") \
     const uint32_t c = min(cnts[b], k);  // <= k entries, whatever order (the merge kernel scans them all)
     uint64_t* out = a.part_keys + ((size_t)(q0 + b) * a.list_stride + a.list_off + g) * k;
     for (uint32_t e = lane_o; e < k; e += 64) out[e] = e < c ? cand[(size_t)b * CAP + e] : kKeyInvalid;
-    if (SPLIT && lane_o == 0) a.blk_tau[(size_t)(q0 + b) * a.list_stride + a.list_off + g] = tauk[b];
+    if (a.blk_tau && lane_o == 0) a.blk_tau[(size_t)(q0 + b) * a.list_stride + a.list_off + g] = tauk[b];
   }
 }
 

@@ -4,10 +4,12 @@
 // The exact f32 contraction runs on v_mfma_f32_16x16x4_f32 at 1/16 of the bf16 matrix rate (sweep_gemm.hip: 0.77 of that
 // pipe = 79 K queries/s at 1 M x 768).  Here the matrix cores only SELECT:
 //   1. every row (once, at insert) and every query (per batch) is split x = hi + lo + e, hi = bf16(x), lo = bf16(x - hi),
-//      |e| <= 2^-18 |x|; the selection kernel (sweep_gemm_bf16.hip, SPLIT instance) accumulates hi.hi + hi.lo + lo.hi in
-//      f32: an approximation A(x, q) of x.q with |A - x.q| <= eps |x| |q|, eps = 3.1 * 2^-18 + 16 dim 2^-24 (the split
-//      remainder + a 4x padded worst case for the f32 accumulation inside and between the MFMAs, whose internal order is
-//      not documented).  It keeps, per block, the k' = min(10, k + 3) best rows by approximate score under thresholds
+//      |e| <= 2^-17 |x|; the selection kernel (sweep_gemm_bf16.hip, SPLIT instance) accumulates hi.hi + hi.lo + lo.hi in
+//      f32: an approximation A(x, q) of x.q with |A - x.q| <= eps |x| |q| (select_eps: the split remainders, the dropped
+//      lo.lo term, a 4x padded worst case for the f32 accumulation inside and between the MFMAs, whose internal order is
+//      not documented).  LEVEL 2 selects on hi.hi alone — the plain bf16 instance over the bf16 copy of the rows, a third of
+//      the matrix work and half the bytes, eps ~ 2^-7: enough whenever the k-th best score stands clear of the pool's last
+//      by that much (it does on the benchmark data and on typical embeddings; near-duplicate clusters go to level 1).  It keeps, per block, the k' = min(10, k + 3) best rows by approximate score under thresholds
 //      seeded by an EXACT sweep of the first rows (threshold lowered by the error bound).  (k' > k: the bound a block ends
 //      with is the score of its k'-th best row; with k' = k the block that holds the best row of a k = 1 search would
 //      report that very score as the bound of what it left out, and no proof could succeed.)
@@ -73,7 +75,17 @@ void launch_split_vectors(const float* src, uint64_t src_stride, uint16_t* out, 
   hipLaunchKernelGGL(split_vectors_kernel, dim3(blocks), dim3(256), 0, st, src, src_stride, out, norms, row0, n, dim);
 }
 
-__host__ __device__ inline float split_eps(uint32_t dim) { return 3.1f * 3.8146973e-6f + 16.0f * (float)dim * 5.9604645e-8f; }
+// Error bound of a selection score, relative to |x| |q|.  bf16 keeps 8 significant bits: |x - hi| <= 2^-8 |x| (round to
+// nearest even), and the remainder's own rounding |x - hi - lo| <= 2^-17 |x|.
+//   level 1 (split: hi.hi + hi.lo + lo.hi): the dropped lo.lo term <= 2^-16, the two remainders 2 * 2^-17  => 2^-15 (8.2 * 2^-18
+//            with slack);
+//   level 2 (plain bf16: hi.hi only): hi.lo + lo.hi + lo.lo <= 2 * 2^-8 + 2^-16;
+// plus 16 dim 2^-24 for the f32 accumulation inside and between the MFMAs (order undocumented; 4x padded worst case).
+// (Cauchy-Schwarz over the per-element errors: sum |e_i q_i| <= |e| |q|.)
+__host__ __device__ inline float select_eps(uint32_t dim, int level) {
+  const float acc = 16.0f * (float)dim * 5.9604645e-8f;
+  return (level >= 2 ? 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f : 8.2f * 3.8146973e-6f) + acc;
+}
 
 // Seed from the EXACT sweep of the first rows (merged to rows + raw scores, best first): list slot 0 of the candidate pool
 // = its top k as keys (they are exact scores: re-scoring them later reproduces them), the query's error bound
@@ -83,10 +95,10 @@ template <int METRIC>
 __global__ __launch_bounds__(256) void split_seed_kernel(const uint64_t* ids, const float* scores, const uint32_t* n,
                                                          const float* qnorms, const uint32_t* norm_max_bits, uint64_t* tau0,
                                                          float* delta, uint64_t* list, uint64_t* blk_tau, uint32_t list_stride,
-                                                         uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim) {
+                                                         uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim, int level) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
-  const float eps = split_eps(dim);
+  const float eps = select_eps(dim, level);
   const float d = METRIC == kCosine ? eps * 1.001f + 4e-7f : eps * 1.001f * qnorms[q] * __uint_as_float(*norm_max_bits) + 1e-30f;
   delta[q] = d;
   const uint32_t c = min(n[q], k);
@@ -103,13 +115,13 @@ __global__ __launch_bounds__(256) void split_seed_kernel(const uint64_t* ids, co
 }
 void launch_split_seed(int metric, const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
                        const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
-                       uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim, hipStream_t st) {
+                       uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim, int level, hipStream_t st) {
   if (metric == kCosine)
     hipLaunchKernelGGL((split_seed_kernel<kCosine>), dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits,
-                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, dim);
+                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, dim, level);
   else
     hipLaunchKernelGGL((split_seed_kernel<kDot>), dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits,
-                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, dim);
+                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, dim, level);
 }
 
 // Between two selection launches: the next launch's bound = k-th best POOL score so far (approximate scores, exact ones for
@@ -227,6 +239,27 @@ void launch_split_rerank(int metric, const SplitRerankArgs& a, uint32_t nq, hipS
     hipLaunchKernelGGL((split_rerank_verify<kCosine>), dim3(nq), dim3(256), lds, st, a);
   else
     hipLaunchKernelGGL((split_rerank_verify<kDot>), dim3(nq), dim3(256), lds, st, a);
+}
+
+__global__ __launch_bounds__(256) void select_stats_kernel(const uint32_t* flags, uint32_t nq, uint32_t seq, uint32_t level,
+                                                           volatile uint32_t* host) {
+  __shared__ uint32_t cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  uint32_t c = 0;
+  for (uint32_t q = threadIdx.x; q < nq; q += 256) c += flags[q] ? 1u : 0u;
+  if (c) atomicAdd(&cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    host[0] = cnt;
+    host[1] = nq;
+    host[3] = level;
+    __threadfence_system();
+    host[2] = seq;  // last: a reader that sees the new sequence number sees the counts
+  }
+}
+void launch_select_stats(const uint32_t* flags, uint32_t nq, uint32_t seq, uint32_t level, volatile uint32_t* host, hipStream_t st) {
+  hipLaunchKernelGGL(select_stats_kernel, dim3(1), dim3(256), 0, st, flags, nq, seq, level, host);
 }
 
 // flagged queries take the exact kernel's result

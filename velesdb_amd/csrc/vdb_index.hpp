@@ -115,6 +115,12 @@ struct vdb_hip_index {
   // large exact Cosine / DotProduct batch and kept up to date from then on
   vdb::DevBuf rows_split;
   bool split_enabled = false;
+  bool sel_norms = false;    // canonical f32 norms are kept for every row whatever the metric (selection levels 1 / 2)
+  // level 2 (plain bf16 selection) adaptivity: the verdict counts of finished batches arrive in pinned host memory
+  // ({unproven, queries, sequence, level}); too many unproven queries park the handle at level 1 for a while
+  volatile uint32_t* sel_stats = nullptr;
+  uint32_t sel_seq = 0, sel_seq_seen = 0, sel16_hold = 0;
+  int last_select_level = 0;
   uint64_t split_rows = 0;   // rows converted so far
   size_t split_flags_off = 0;     // where the last split batch left its per-query verdicts in s_seed
   uint32_t split_flags_n = 0;

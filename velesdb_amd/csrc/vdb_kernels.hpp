@@ -188,7 +188,8 @@ hipError_t launch_sweep_bf16(int metric, int nqt, const uint16_t* rows, uint64_t
 void launch_merge(bool higher_is_better, const MergeArgs& m, uint32_t nq, hipStream_t st);
 void launch_max_norm(const float* norms, uint32_t n_rows, uint32_t* out_bits, hipStream_t st);  // bits of max |v| (NaN propagates)
 // ---- exact f32 Cosine / Dot batches through split-bf16 selection + exact re-scoring + proof (sweep_split.hip) ----
-constexpr uint32_t kSplitPool = 32;  // candidates per query that are re-scored exactly
+constexpr uint32_t kSplitPool = 32;  // candidates per query that are re-scored exactly (level 1: split selection)
+constexpr uint32_t kSelect16Pool = 64;  // the same for level 2 (plain bf16 selection: a wider error band to cover)
 constexpr uint32_t kSplitSeedRows = 4096;  // rows of the exact seed sweep
 struct SplitRerankArgs {
   const float* rows;            // f32 rows of the index
@@ -213,7 +214,9 @@ void launch_split_vectors(const float* src, uint64_t src_stride, uint16_t* out, 
                           uint32_t dim, hipStream_t st);
 void launch_split_seed(int metric, const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
                        const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
-                       uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim, hipStream_t st);
+                       uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim, int level, hipStream_t st);
+// {unproven, queries, seq, level} of a finished selection batch -> pinned host memory (no synchronisation)
+void launch_select_stats(const uint32_t* flags, uint32_t nq, uint32_t seq, uint32_t level, volatile uint32_t* host, hipStream_t st);
 void launch_split_reseed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* delta, uint64_t* tau0,
                          uint32_t nq, uint32_t k, uint32_t kout, hipStream_t st);
 void launch_split_rerank(int metric, const SplitRerankArgs& a, uint32_t nq, hipStream_t st);

@@ -67,10 +67,11 @@ def set_sweep_engine(engine: int) -> None:
     check(lib().vdb_hip_set_sweep_engine(engine))
 
 
-def set_split_selector(on: bool) -> None:
-    """Large exact cosine / dot batches: True (default) = split-bf16 selection + exact re-scoring + proof, False = the exact
-    f32 matrix-core kernel for the whole batch.  Results are identical."""
-    check(lib().vdb_hip_set_split_selector(1 if on else 0))
+def set_split_selector(level) -> None:
+    """Large exact cosine / dot batches: 0 / False = the exact f32 matrix-core kernel for the whole batch; 1 / True =
+    split-bf16 selection + exact re-scoring + proof; 2 (the library's default) = plain bf16 selection first, level 1 as the
+    fallback level.  Results are identical at every level."""
+    check(lib().vdb_hip_set_split_selector(int(level)))
 
 
 class HnswIndex:
@@ -432,6 +433,12 @@ class HnswIndex:
         a, b = C.c_uint32(0), C.c_uint32(0)
         check(lib().vdb_hip_index_last_split_stats(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def last_select_level(self) -> int:
+        """Selection level (0 / 1 / 2) the last exact batch of this handle ran at."""
+        v = C.c_int32(0)
+        check(lib().vdb_hip_index_last_select_level(self._h, C.byref(v)))
+        return int(v.value)
 
     def last_kernel_ms(self):
         ms, n = C.c_float(0), C.c_uint32(0)
