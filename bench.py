@@ -70,6 +70,7 @@ def parse():
     p.add_argument("--ef-curve", default="64,128,256,512", help="ef_search values of the recall / QPS curve of the graph legs")
     p.add_argument("--no-metrics-leg", action="store_true", help="skip the per-metric table (Euclidean / dot / Hamming / Jaccard sweeps)")
     p.add_argument("--no-bf16-leg", action="store_true", help="skip the bf16 GEMM-distance leg (BASELINE configs[3])")
+    p.add_argument("--no-sq8-leg", action="store_true", help="skip the SQ8 storage-mode leg")
     p.add_argument("--bf16-rows", type=int, default=10_000_000)
     p.add_argument("--bf16-steps", type=int, default=5)
     p.add_argument("--bf16-cpu-rows", type=int, default=1_000_000, help="rows of the slice the CPU restatement scans")
@@ -688,6 +689,61 @@ def main():
         if graph_dir is not None:
             shutil.rmtree(graph_dir, ignore_errors=True)
 
+    # ---- SQ8 storage mode (N = 1 only): exact top-k of f32 queries over the one-byte codes with the reference's
+    # asymmetric distances (quantization.rs:410-554).  Large batches select on the bf16 matrix cores over the dequantised
+    # rows and re-score the candidates with the reference's chain (bit-exact); small batches sweep the codes.
+    sq8_leg = None
+    if world == 1 and not a.no_sq8_leg and a.metric in ("cosine", "dot"):
+        ix.set_storage_mode(va.StorageMode.SQ8)
+
+        def sq8_run(nq, reps):
+            for _ in range(2):
+                ix.search_batch_dev(queries[:nq].data_ptr(), nq, K, 0, va.MODE_BRUTE_SQ8, out_ids.data_ptr(), out_sc.data_ptr(),
+                                    out_n.data_ptr(), stream)
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
+            for _ in range(reps):
+                ix.search_batch_dev(queries[:nq].data_ptr(), nq, K, 0, va.MODE_BRUTE_SQ8, out_ids.data_ptr(), out_sc.data_ptr(),
+                                    out_n.data_ptr(), stream)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_s) / reps
+
+        nq_big = min(Q, 1024)
+        dt_sel = sq8_run(nq_big, 5)
+        lvl = ix.last_select_level() if nq_big >= 224 else 0
+        nq_l, unp = ix.last_split_stats()
+        sel_ids = out_ids[:nq_big].cpu().numpy().astype(np.uint64)
+        sel_sc = out_sc[:nq_big].cpu().numpy().copy()
+        va.set_split_selector(0)
+        dt_exact = sq8_run(min(nq_big, 64), 2) / min(nq_big, 64) * nq_big  # the exact sweep serves 8 queries per pass: linear in the batch
+        ex_ids = out_ids[:min(nq_big, 64)].cpu().numpy().astype(np.uint64)
+        ex_sc = out_sc[:min(nq_big, 64)].cpu().numpy().copy()
+        dt_8 = sq8_run(8, 5)
+        va.set_split_selector(0 if a.no_split else a.select_level)
+        code_bytes = N * (D + 12 + (4 if a.metric == "cosine" else 0))
+        sq8_leg = {"workload": f"{N}x{D} SQ8 codes ({a.metric}, asymmetric f32-query distances), k={K}",
+                   "batch": {"queries": nq_big, "qps": round(nq_big / dt_sel, 1), "ms_per_batch": round(dt_sel * 1e3, 3),
+                             "select_level": lvl, "unproven_queries_last_batch": unp,
+                             "kernel": "sweep_topk_gemm_bf16_glds over the dequantised bf16 image + split_rerank_verify<SQ8> + "
+                                       "gathered sweep_topk_sq8 for unproven queries"},
+                   "exact_sweep_same_batch": {"qps": round(nq_big / dt_exact, 1), "ms_per_batch": round(dt_exact * 1e3, 3),
+                                              "note": "sweep_topk_sq8<B=8> for every query (selection off), extrapolated from 64 queries"},
+                   "batch_equals_exact_sweep_bitwise": bool(np.array_equal(sel_ids[:len(ex_ids)], ex_ids) and
+                                                            np.array_equal(sel_sc[:len(ex_sc)].view(np.uint32), ex_sc.view(np.uint32))),
+                   "eight_queries": {"qps": round(8 / dt_8, 1), "ms_per_call": round(dt_8 * 1e3, 4),
+                                     "hbm_gbs": round(code_bytes / dt_8 / 1e9, 1), "hbm_frac": round(code_bytes / dt_8 / 1e9 / HBM_PEAK_GBS, 4)},
+                   "alg_bytes_per_pass": code_bytes}
+        if rank == 0 and host_full is not None and a.check_queries > 0:
+            from oracle import pyoracle as po_s
+            nchk = min(16, nq_big)
+            pick = np.unique(np.linspace(0, nq_big - 1, nchk).astype(np.int64))
+            eid_s, esc_s = po_s.scan_topk_sq8({"cosine": po_s.COSINE, "dot": po_s.DOT}[a.metric], host_full, queries[:nq_big].cpu().numpy()[pick],
+                                              K, nthreads=po_s.host_threads())
+            sq8_leg["parity_check"] = {"queries": int(len(pick)), "of_a_batch_of": nq_big,
+                                       "ids_equal_oracle": bool(np.array_equal(sel_ids[pick], eid_s.astype(np.uint64))),
+                                       "scores_bit_equal_oracle": bool(np.array_equal(sel_sc[pick].view(np.uint32), esc_s.view(np.uint32)))}
+        ix.set_storage_mode(va.StorageMode.Full)
+
     # ---- graph leg on embedding-like data (N = 1 only): iid N(0,1) in 768-D has no neighbourhood structure, so HNSW
     # recall there is ~0.04 for the reference and the GPU alike.  Real embeddings have low intrinsic
     # dimension: `--latent` Gaussian factors through a random projection + noise.  Same build, same traversal kernel,
@@ -1079,7 +1135,7 @@ def main():
                        "parallelism": "replicas x%d (query stream split, no collective)" % world},
             "recall_at_10": recall, "parity_check": check,
             "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "tiles": tiles, "sharded": sharded,
-            "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb, "config0_10k": config0, "bf16_gemm": bf16_leg, "other_metrics": metrics_leg,
+            "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb, "config0_10k": config0, "bf16_gemm": bf16_leg, "sq8_storage_mode": sq8_leg, "other_metrics": metrics_leg,
             "device": va.device_name(local),
         }
     if use_dist:

@@ -130,3 +130,47 @@ def test_storage_mode_state_errors(gpu_required):
     with pytest.raises(va.VelesHipError):
         h.search_batch_sq8(np.ones(8, np.float32), 2)       # SQ8 distances exist for cosine / euclidean / dot only
     h.close()
+
+
+@pytest.mark.parametrize("metric,pm", [(DM.Cosine, po.COSINE), (DM.DotProduct, po.DOT)])
+@pytest.mark.parametrize("n,dim,nq,k", [(70_000, 128, 256, 10), (66_000, 256, 480, 3)])
+def test_sq8_big_batches_select_on_the_matrix_cores_bit_exact(gpu_required, metric, pm, n, dim, nq, k):
+    """Batches of >= 224 queries over >= 65 536 SQ8 rows (dim % 64 == 0): bf16 selection over the dequantised rows, the
+    reference's left-to-right chain for the 64 candidates, per-query proof, the exact SQ8 sweep for what is unproven (listed
+    on the device) — ids, ranks and score bits of the exact scan, whatever the path."""
+    rng = np.random.default_rng(n + dim + int(metric))
+    rows = special_rows(rng, n, dim)
+    rows[rng.integers(0, n, 50)] *= 30.0          # a few long rows (DotProduct winners)
+    ids = np.arange(n, dtype=np.uint64) * 3 + 1
+    ix = va.HnswIndex(dim, metric, va.HnswParams(8, 50, n))
+    ix.set_storage_mode(SM.SQ8)
+    ix.upload(ids, rows)
+    Q = rng.standard_normal((nq, dim)).astype(np.float32)
+    Q[0] = rows[10]                                # rows 10 / 11 are duplicates: an exact tie at the top (unprovable)
+    Q[1] = 0.0
+    va.set_split_selector(2)
+    gid, gsc, gcnt = ix.search_batch_sq8(Q, k)
+    assert ix.last_select_level() == 3, "the selection stage did not run"
+    nq_last, unproven = ix.last_split_stats()
+    eid, esc = po.scan_topk_sq8(pm, rows, Q, k, nthreads=po.host_threads())
+    assert np.all(gcnt == k)
+    assert np.array_equal(gid, ids[eid.astype(np.int64)]), "ids / ranks differ from the oracle's SQ8 scan"
+    assert np.array_equal(bits(gsc), bits(esc)), "score bits differ from the oracle's SQ8 scan"
+    assert 1 <= unproven <= nq // 8, f"{unproven} of {nq_last} unproven"  # the tie and the zero query, not the random ones
+    va.set_split_selector(0)                       # the exact sweep for the whole batch: the same bits
+    gid0, gsc0, _ = ix.search_batch_sq8(Q, k)
+    va.set_split_selector(2)
+    assert np.array_equal(gid0, gid) and np.array_equal(bits(gsc0), bits(gsc))
+    # rows appended later and soft deletes reach the selection image too
+    extra = rng.standard_normal((300, dim)).astype(np.float32)
+    extra[:50] = Q[5:55] * 1.5                     # new best rows for 50 queries
+    ix.upload(np.arange(300, dtype=np.uint64) + 10_000_000, extra)
+    assert ix.remove(int(ids[int(eid[7, 0])]))
+    rows2 = np.concatenate([rows, extra])
+    ids2 = np.concatenate([ids, np.arange(300, dtype=np.uint64) + 10_000_000])
+    keep = np.ones(len(rows2), dtype=bool)
+    keep[int(eid[7, 0])] = False
+    gid2, gsc2, _ = ix.search_batch_sq8(Q, k)
+    eid2, esc2 = po.scan_topk_sq8(pm, rows2[keep], Q, k, nthreads=po.host_threads())
+    assert np.array_equal(gid2, ids2[keep][eid2.astype(np.int64)]) and np.array_equal(bits(gsc2), bits(esc2))
+    ix.close()

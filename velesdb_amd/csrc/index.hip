@@ -494,9 +494,30 @@ static int select_level(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   return 2;
 }
 
-static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, uint64_t* d_ids,
-                               float* d_scores, uint32_t* d_n, hipStream_t st, int level) {
-  int32_t rc = level >= 2 ? ensure_sel16(ix, st) : ensure_split(ix, st);
+// the SQ8 storage mode's batches (VDB_SEARCH_BRUTE_SQ8): the same eligibility on the shapes the bf16 selection kernel takes
+int select_level_sq8(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
+  if (!g_split_selector.load() || g_max_tile < 128) return 0;
+  if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT) return 0;  // Euclidean keeps the exact sweep
+  if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
+  if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
+  const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
+  const uint32_t nqt_big = (nqg + 255) / 256;
+  if (!(nqg >= kGemmBigMinQueries && (uint64_t)nqg * 8 >= (uint64_t)nqt_big * 256 * 7)) return 0;
+  if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
+    ix->sel_seq_seen = ix->sel_stats[2];
+    if (ix->sel_stats[3] == 3u && (uint64_t)ix->sel_stats[0] * 16 > ix->sel_stats[1]) ix->sq8_hold = 64;
+  }
+  if (ix->sq8_hold) {
+    ix->sq8_hold--;
+    return 0;
+  }
+  return 3;
+}
+
+int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, uint64_t* d_ids,
+                        float* d_scores, uint32_t* d_n, hipStream_t st, int level) {
+  const bool sq8 = level >= 3;
+  int32_t rc = sq8 ? ensure_sq8_select(ix, st) : (level >= 2 ? ensure_sel16(ix, st) : ensure_split(ix, st));
   if (rc != VDB_OK) return rc;
   ix->last_select_level = level;
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
@@ -531,11 +552,13 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
   const size_t o_seedp = take((size_t)nqg * sp.G * k * 8), o_ids = take((size_t)nqg * K2 * 8), o_sc = take((size_t)nqg * K2 * 4),
                o_n = take((size_t)nqg * 4), o_tau = take((size_t)nqg * 8), o_delta = take((size_t)nqg * 4),
                o_qn = take((size_t)nqg * 4), o_flags = take((size_t)nqg * 4 + 64 * 4 + 16), o_btau = take((size_t)nqg * lists * 8),
-               o_fid = take((size_t)nqg * k * 8), o_fsc = take((size_t)nqg * k * 4), o_fn = take((size_t)nqg * 4);
+               o_fid = take((size_t)nqg * k * 8), o_fsc = take((size_t)nqg * k * 4), o_fn = take((size_t)nqg * 4),
+               o_qmap = take((size_t)nqg * 4 + 16), o_gid = take((size_t)96 * k * 8), o_gsc = take((size_t)96 * k * 4),
+               o_gn = take((size_t)96 * 4);
   hipError_t e;
   if ((e = ix->s_seed.reserve(off, false, st)) != hipSuccess ||
       (e = ix->s_part_keys.reserve((size_t)nqg * lists * ks * 8, false, st)) != hipSuccess ||
-      (e = ix->s_fb_keys.reserve((size_t)nqg * fp.G * k * 8, false, st)) != hipSuccess ||
+      (!sq8 && (e = ix->s_fb_keys.reserve((size_t)nqg * fp.G * k * 8, false, st)) != hipSuccess) ||
       (e = ix->s_misc.reserve(((size_t)nqg + 256) * dim * 4, false, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, "split sweep scratch");
   unsigned char* sd = ix->s_seed.as<unsigned char>();
@@ -555,7 +578,9 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
   EventPair* ev = next_events(ix);
   if (ev) (void)hipEventRecord(ev->a, st);
   // queries: split image / bf16 image (+ canonical norms), zero rows behind the batch (the kernel stages whole 256-query tiles)
-  const uint64_t img_stride = level >= 2 ? ix->bf16_stride : (uint64_t)dim * 2;  // elements per row of either image
+  const uint64_t img_stride = sq8 ? (uint64_t)dim : (level >= 2 ? ix->bf16_stride : (uint64_t)dim * 2);  // elements per image row
+  const uint16_t* img_rows = sq8 ? ix->sq8_img.as<uint16_t>() : (level >= 2 ? ix->rows_bf16.as<uint16_t>() : ix->rows_split.as<uint16_t>());
+  const float* sel_norms = sq8 ? ix->sq8_nrm.as<float>() : ix->norms.as<float>();
   if (level >= 2) {
     launch_round_queries_bf16(d_q, q_stride, q16, img_stride, nqg, dim, st);
     PrepArgs pq{};
@@ -573,12 +598,12 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
   VDB_HIP(hipMemsetAsync(pool, 0xFF, (size_t)nqg * lists * ks * 8, st));
   VDB_HIP(hipMemsetAsync(blk_tau, 0xFF, (size_t)nqg * lists * 8, st));
   VDB_HIP(hipMemsetAsync(flags, 0, (size_t)nqg * 4 + 64 * 4 + 16, st));
-  VDB_HIP(hipMemsetAsync(ix->s_fb_keys.p, 0xFF, (size_t)nqg * fp.G * k * 8, st));
-  if (ix->metric == VDB_DOT) launch_max_norm(ix->norms.as<float>(), n, norm_max, st);
+  if (!sq8) VDB_HIP(hipMemsetAsync(ix->s_fb_keys.p, 0xFF, (size_t)nqg * fp.G * k * 8, st));
+  if (ix->metric == VDB_DOT) launch_max_norm(sel_norms, n, norm_max, st);
   // exact seed sweep over the first rows
   SweepArgs ag{};
-  ag.rows = ix->rows.as<float>();
-  ag.norms = ix->norms.as<float>();
+  ag.rows = sq8 ? ix->sq8_seed.as<float>() : ix->rows.as<float>();  // SQ8: the dequantised prefix (f32)
+  ag.norms = sel_norms;
   ag.alive = alive;
   ag.queries = d_q;
   ag.part_keys = reinterpret_cast<uint64_t*>(sd + o_seedp);
@@ -603,8 +628,7 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
   // selection launches over the split images
   uint32_t list_off = 1;
   for (int j = 0; j < n_launch; j++) {
-    e = launch_sweep_gemm_bf16_glds(ix->metric, bp[j], level >= 2 ? ix->rows_bf16.as<uint16_t>() : ix->rows_split.as<uint16_t>(),
-                                    img_stride, ix->norms.as<float>(), alive, q16, img_stride, tau0, pool, lists, list_off, dim,
+    e = launch_sweep_gemm_bf16_glds(ix->metric, bp[j], img_rows, img_stride, sel_norms, alive, q16, img_stride, tau0, pool, lists, list_off, dim,
                                     nqg, ks, st, /*split=*/level < 2, qnorms, blk_tau);
     if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split selection launch: ") + hipGetErrorString(e));
     list_off += bp[j].G;
@@ -638,7 +662,14 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
   ra.out_scores = d_scores;
   ra.out_n = d_n;
   ra.flags = flags;
-  ra.tile_needed = tile_needed;
+  ra.tile_needed = sq8 ? nullptr : tile_needed;
+  if (sq8) {
+    ra.sq8_codes = ix->sq8_codes.as<uint8_t>();
+    ra.sq8_min = ix->sq8_min.as<float>();
+    ra.sq8_max = ix->sq8_max.as<float>();
+    ra.sq8_nsq = ix->sq8_nsq.as<float>();
+    ra.sq8_stride = ix->sq8_stride;
+  }
   ra.row_stride = ix->row_stride;
   ra.q_stride = q_stride;
   ra.dim = dim;
@@ -648,21 +679,78 @@ static int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_s
   ra.lists = lists;
   ra.fb_qper = fp.qper;
   launch_split_rerank(ix->metric, ra, nqg, st);
-  // exact kernel for the query tiles that hold an unproven query (decided on the device), its result for those queries
-  ag.part_keys = ix->s_fb_keys.as<uint64_t>();
-  ag.n_rows = n;
-  e = launch_sweep_gemm(ix->metric, fp, ag, st, tile_needed);
-  if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("exact fallback launch: ") + hipGetErrorString(e));
-  MergeArgs mf{};
-  mf.part_keys = ag.part_keys;
-  mf.ext_ids = ix->ext_ids.as<uint64_t>();
-  mf.out_ids = reinterpret_cast<uint64_t*>(sd + o_fid);
-  mf.out_scores = reinterpret_cast<float*>(sd + o_fsc);
-  mf.out_n = reinterpret_cast<uint32_t*>(sd + o_fn);
-  mf.n_lists = fp.G;
-  mf.k = k;
-  launch_merge(true, mf, nqg, st);
-  launch_select_fallback(flags, mf.out_ids, mf.out_scores, mf.out_n, d_ids, d_scores, d_n, nqg, k, st);
+  if (sq8) {  // the reference chain for the unproven queries only, decided on the device
+    const int32_t rf = sq8_fallback_flagged(ix, d_q, q_stride, nqg, k, flags, d_ids, d_scores, d_n, st);
+    if (rf != VDB_OK) return rf;
+  } else {
+    // Unproven queries, decided on the device.  A few (<= kFallbackGatherMax): listed, and the streaming matrix-core kernel
+    // makes ONE gathered corpus pass per 48 of them (0.9 ms; same mode-M bits).  More: the GEMM-structured kernel for the
+    // query tiles that hold one (a tile costs the whole launch's duration: its row groups are all it parallelises over).
+    // Both are launched; the one whose turn it is not exits at once.
+    constexpr uint32_t kFallbackGatherMax = 96;
+    const int g_nqt = 3, g_waves = kMfmaWaves2;
+    const uint32_t g_B = (uint32_t)g_nqt * 16;
+    const size_t g_lds = sweep_mfma_lds_bytes(g_nqt, k, dim);
+    const bool gather_ok = g_lds <= 160 * 1024;
+    uint32_t* qmap = reinterpret_cast<uint32_t*>(sd + o_qmap);
+    uint32_t* qcount = qmap + nqg;
+    if (gather_ok) {
+      const uint32_t ntiles16 = (n + 15) / 16;
+      const int g_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ntiles16 + g_waves - 1) / g_waves, (int64_t)ix->n_cus));
+      const size_t gk = (size_t)kFallbackGatherMax * g_blocks * k * 8;
+      if ((e = ix->s_part_cnt.reserve(gk, false, st)) != hipSuccess) return fail(VDB_ERR_OOM, "gathered fallback scratch");
+      launch_collect_flagged(flags, nqg, qmap, qcount, st);
+      SweepArgs am{};
+      am.rows = ix->rows.as<float>();
+      am.norms = ix->norms.as<float>();
+      am.alive = alive;
+      am.queries = d_q;
+      am.part_keys = ix->s_part_cnt.as<uint64_t>();
+      am.row_stride = ix->row_stride;
+      am.q_stride = q_stride;
+      am.n_rows = n;
+      am.dim = dim;
+      am.nq = g_B;
+      am.k = k;
+      am.qmap = qmap;
+      am.qcount = qcount;
+      am.qcount_max = kFallbackGatherMax;
+      e = launch_sweep_mfma(ix->metric, g_nqt, am, g_blocks, st, (int)(kFallbackGatherMax / g_B));
+      if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("gathered fallback launch: ") + hipGetErrorString(e));
+      MergeArgs mg{};
+      mg.part_keys = am.part_keys;
+      mg.ext_ids = ix->ext_ids.as<uint64_t>();
+      mg.out_ids = reinterpret_cast<uint64_t*>(sd + o_gid);
+      mg.out_scores = reinterpret_cast<float*>(sd + o_gsc);
+      mg.out_n = reinterpret_cast<uint32_t*>(sd + o_gn);
+      mg.n_lists = (uint32_t)g_blocks;
+      mg.k = k;
+      mg.active = qcount;
+      mg.active_max = kFallbackGatherMax;
+      launch_merge(true, mg, kFallbackGatherMax, st);
+      launch_scatter_flagged(qmap, qcount, kFallbackGatherMax, mg.out_ids, mg.out_scores, mg.out_n, d_ids, d_scores, d_n, nqg, k, st);
+      ag.qcount = qcount;
+      ag.qcount_max = kFallbackGatherMax;
+    }
+    ag.part_keys = ix->s_fb_keys.as<uint64_t>();
+    ag.n_rows = n;
+    ag.rows = ix->rows.as<float>();
+    e = launch_sweep_gemm(ix->metric, fp, ag, st, tile_needed);
+    if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("exact fallback launch: ") + hipGetErrorString(e));
+    MergeArgs mf{};
+    mf.part_keys = ag.part_keys;
+    mf.ext_ids = ix->ext_ids.as<uint64_t>();
+    mf.out_ids = reinterpret_cast<uint64_t*>(sd + o_fid);
+    mf.out_scores = reinterpret_cast<float*>(sd + o_fsc);
+    mf.out_n = reinterpret_cast<uint32_t*>(sd + o_fn);
+    mf.n_lists = fp.G;
+    mf.k = k;
+    launch_merge(true, mf, nqg, st);
+    if (gather_ok)
+      launch_select_fallback(flags, mf.out_ids, mf.out_scores, mf.out_n, d_ids, d_scores, d_n, nqg, k, st, qcount, kFallbackGatherMax);
+    else
+      launch_select_fallback(flags, mf.out_ids, mf.out_scores, mf.out_n, d_ids, d_scores, d_n, nqg, k, st);
+  }
   ix->split_flags_off = o_flags;
   ix->split_flags_n = nqg;
   ix->split_flags_stream = st;
@@ -1010,7 +1098,23 @@ int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint3
   }
   if (mode == VDB_SEARCH_BRUTE) return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
   if (mode == VDB_SEARCH_BRUTE_BF16) return brute_bf16_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
-  if (mode == VDB_SEARCH_BRUTE_SQ8) return brute_sq8_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
+  if (mode == VDB_SEARCH_BRUTE_SQ8) {
+    // large Cosine / DotProduct batches: bf16 selection over the dequantised rows + the reference chain for the candidates +
+    // proof (level 3); everything else, and what a handle's data defeats, on the exact SQ8 sweep
+    if (ix->storage_mode != VDB_STORAGE_SQ8) return fail(VDB_ERR_STATE, "SQ8 search: set the storage mode to SQ8 first");
+    uint32_t q0 = 0;
+    while (q0 < nq && k > 0 && ix->n_rows > 0) {
+      if (select_level_sq8(ix, nq - q0, k) != 3) break;
+      const uint32_t nqg = std::min<uint32_t>(nq - q0, kGemmMaxQueries);
+      const int32_t rcs = brute_split_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nqg, k, d_ids + (size_t)q0 * k,
+                                          d_scores + (size_t)q0 * k, d_n + q0, st, 3);
+      if (rcs != VDB_OK) return rcs;
+      q0 += nqg;
+    }
+    if (q0 == nq) return VDB_OK;
+    return brute_sq8_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nq - q0, k, d_ids + (size_t)q0 * k, d_scores + (size_t)q0 * k,
+                         d_n + q0, st);
+  }
   if (mode == VDB_SEARCH_BRUTE_BINARY) return brute_binary_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
   if (mode == VDB_SEARCH_AUTO && ix->live <= 100 && ix->n_rows > 0)  // search.rs:75-77
     return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);

@@ -134,6 +134,10 @@ struct Sq8Args {
   uint64_t* part_keys;    // [nq][n_blocks][k]
   uint64_t code_stride, q_stride;
   uint32_t n_rows, dim, nq, k;
+  // gathered variant (the exact pass over the queries a selection stage could not prove): block row blockIdx.y serves the
+  // queries qmap[B y .. B y + B - 1] of the *qcount listed ones and exits when there are none; part_keys slots follow the list
+  const uint32_t* qmap;
+  const uint32_t* qcount;
 };
 
 constexpr int kSq8TileStride = 80;  // bytes per row of the staging tile: 64 + 16 padding (conflict-free b128 reads)
@@ -157,9 +161,17 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
   float* qsum = reinterpret_cast<float*>(tail + (size_t)B * k * 8 + B * 8);
   float* qnsq = reinterpret_cast<float*>(tail + (size_t)B * k * 8 + B * 12);
 
+  uint32_t nq_here = a.nq, slot0 = 0;
+  if (a.qmap) {
+    const uint32_t listed = *a.qcount;
+    slot0 = blockIdx.y * (uint32_t)B;
+    if (slot0 >= listed) return;  // (uniform per block)
+    nq_here = min((uint32_t)B, listed - slot0);
+  }
   for (uint32_t i = tid; i < dpad * B; i += 256) {
     const uint32_t d = i / B, b = i % B;
-    qs[i] = (d < dim && b < a.nq) ? a.queries[(size_t)b * a.q_stride + d] : 0.0f;
+    const uint32_t qrow = (a.qmap && b < nq_here) ? a.qmap[slot0 + b] : b;
+    qs[i] = (d < dim && b < nq_here) ? a.queries[(size_t)qrow * a.q_stride + d] : 0.0f;
   }
   if (tid < B) {
     cnts[tid] = 0;
@@ -373,7 +385,7 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
         const float denom = sqrtf(__fmul_rn(qnsq[b], vn2));
         score = denom < kF32Eps ? 0.0f : __fdiv_rn(acc[b], denom);
       }
-      const bool ok = valid && (uint32_t)b < a.nq;
+      const bool ok = valid && (uint32_t)b < nq_here;
       const uint64_t key = ok ? make_key<HIB>(score, row) : kKeyInvalid;
       const uint64_t tau = (cnts[b] == k) ? lists[(size_t)b * k + (k - 1)] : kKeyInvalid;
       uint64_t mask = __ballot(key < tau);
@@ -387,9 +399,9 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
     }
   }
   __syncthreads();
-  for (uint32_t b = wib; b < a.nq && b < (uint32_t)B; b += 4) {
+  for (uint32_t b = wib; b < nq_here && b < (uint32_t)B; b += 4) {
     const uint32_t c = cnts[b];
-    uint64_t* out = a.part_keys + ((size_t)b * gridDim.x + blockIdx.x) * k;
+    uint64_t* out = a.part_keys + ((size_t)(slot0 + b) * gridDim.x + blockIdx.x) * k;
     for (uint32_t e = lane; e < k; e += 64) out[e] = e < c ? lists[(size_t)b * k + e] : kKeyInvalid;
   }
 }
@@ -400,7 +412,7 @@ static size_t sq8_lds_bytes(int B, uint32_t k, uint32_t dim) {
 }
 
 template <int METRIC, int B>
-static hipError_t launch_sq8_t(const Sq8Args& a, int blocks, size_t lds, hipStream_t st) {
+static hipError_t launch_sq8_t(const Sq8Args& a, int blocks, size_t lds, hipStream_t st, int groups = 1) {
   static bool done = false;
   if (lds > 64 * 1024 && !done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_sq8<METRIC, B>),
@@ -408,14 +420,47 @@ static hipError_t launch_sq8_t(const Sq8Args& a, int blocks, size_t lds, hipStre
     if (e != hipSuccess) return e;
     done = true;
   }
-  hipLaunchKernelGGL((sweep_topk_sq8<METRIC, B>), dim3(blocks), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((sweep_topk_sq8<METRIC, B>), dim3(blocks, groups), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 template <int B>
-static hipError_t launch_sq8_m(int metric, const Sq8Args& a, int blocks, size_t lds, hipStream_t st) {
-  if (metric == kCosine) return launch_sq8_t<kCosine, B>(a, blocks, lds, st);
-  if (metric == kEuclidean) return launch_sq8_t<kEuclidean, B>(a, blocks, lds, st);
-  return launch_sq8_t<kDot, B>(a, blocks, lds, st);
+static hipError_t launch_sq8_m(int metric, const Sq8Args& a, int blocks, size_t lds, hipStream_t st, int groups = 1) {
+  if (metric == kCosine) return launch_sq8_t<kCosine, B>(a, blocks, lds, st, groups);
+  if (metric == kEuclidean) return launch_sq8_t<kEuclidean, B>(a, blocks, lds, st, groups);
+  return launch_sq8_t<kDot, B>(a, blocks, lds, st, groups);
+}
+
+// ---- selection stage over the SQ8 storage mode (index.hip brute_split_dev, level 3) -------------------------------------
+// The dequantised rows d = code * scale + min as a bf16 image (what the matrix cores select on), their norms sqrt(nsq), and
+// the first kSplitSeedRows dequantised rows in f32 (what the exact matrix-core kernel seeds the thresholds from).
+__global__ __launch_bounds__(256) void sq8_dequant_rows(const uint8_t* codes, uint64_t code_stride, const float* vmin, const float* vmax,
+                                                        const float* nsq, uint16_t* img, float* nrm, float* seed, uint32_t seed_rows,
+                                                        uint32_t row0, uint32_t n_rows, uint32_t dim) {
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4;
+  for (uint32_t r = wave; r < n_rows; r += nwaves) {
+    const uint32_t row = row0 + r;
+    const float mn = vmin[row], range = __fsub_rn(vmax[row], mn);
+    const bool flat = range < kF32Eps;
+    const float scale = __fdiv_rn(range, 255.0f);
+    const uint8_t* c = codes + (size_t)row * code_stride;
+    for (uint32_t i = lane * 4; i < dim; i += 256) {  // dim % 4 == 0 (selection needs dim % 64 == 0)
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(c + i);
+      float d[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) d[e] = flat ? mn : __fadd_rn(__fmul_rn((float)((w >> (8 * e)) & 0xFFu), scale), mn);
+      uint32_t h[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {  // round to nearest even; NaN stays NaN
+        uint32_t u = __float_as_uint(d[e]);
+        h[e] = (u & 0x7FFFFFFFu) > 0x7F800000u ? ((u >> 16) | 0x0040u) : ((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+      }
+      *reinterpret_cast<uint2*>(img + (size_t)row * dim + i) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+      if (row < seed_rows) *reinterpret_cast<float4*>(seed + (size_t)row * dim + i) = make_float4(d[0], d[1], d[2], d[3]);
+    }
+    if (lane == 0) nrm[row] = sqrtf(nsq[row]);
+  }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
@@ -451,6 +496,96 @@ int32_t storage_mode_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
       return fail(VDB_ERR_OOM, std::string("sign bits: ") + hipGetErrorString(e));
   }
   quantize_range(ix, first, n);
+  if (first < ix->sq8_img_rows) ix->sq8_img_rows = first;  // codes rebuilt from `first`: the selection image follows at next use
+  VDB_HIP(hipGetLastError());
+  return VDB_OK;
+}
+
+// selection stage (level 3): bf16 image of the dequantised rows, their norms, the f32 seed prefix — built at first use,
+// kept current by storage_mode_append
+int32_t ensure_sq8_select(vdb_hip_index* ix, hipStream_t st) {
+  const uint64_t cap = std::max<uint64_t>(ix->capacity, 1) + kRowSlack;
+  hipError_t e;
+  if ((e = ix->sq8_img.reserve(cap * (size_t)ix->dim * 2, true, st)) != hipSuccess ||
+      (e = ix->sq8_nrm.reserve(cap * 4, true, st)) != hipSuccess ||
+      (e = ix->sq8_seed.reserve((size_t)kSplitSeedRows * ix->dim * 4, true, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("SQ8 selection image: ") + hipGetErrorString(e));
+  if (ix->sq8_img_rows < ix->n_rows) {
+    const uint64_t first = ix->sq8_img_rows, n = ix->n_rows - first;
+    const int blocks = (int)std::min<uint64_t>((n + 3) / 4, 4096);
+    hipLaunchKernelGGL(sq8_dequant_rows, dim3(blocks), dim3(256), 0, st, ix->sq8_codes.as<uint8_t>(), ix->sq8_stride,
+                       ix->sq8_min.as<float>(), ix->sq8_max.as<float>(), ix->sq8_nsq.as<float>(), ix->sq8_img.as<uint16_t>(),
+                       ix->sq8_nrm.as<float>(), ix->sq8_seed.as<float>(), kSplitSeedRows, (uint32_t)first, (uint32_t)n, ix->dim);
+    ix->sq8_img_rows = ix->n_rows;
+    VDB_HIP(hipGetLastError());
+  }
+  if (!ix->sel_stats) {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess) return fail(VDB_ERR_OOM, "pinned selection statistics");
+    memset(h, 0, 64);
+    ix->sel_stats = static_cast<volatile uint32_t*>(h);
+  }
+  return VDB_OK;
+}
+
+// the reference chain for the queries flagged by a selection batch, decided on the device: list them, one gathered launch of
+// the exact SQ8 sweep (block rows without a listed query exit at once), merge per listed query, scatter
+int32_t sq8_fallback_flagged(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, const uint32_t* flags,
+                             uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st) {
+  const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
+  int B = 8;
+  if (sq8_lds_bytes(8, k, ix->dim) > 160 * 1024) B = 4;
+  if (B == 4 && sq8_lds_bytes(4, k, ix->dim) > 160 * 1024) B = 1;
+  const size_t lds = sq8_lds_bytes(B, k, ix->dim);
+  if (lds > 160 * 1024) return fail(VDB_ERR_UNSUPPORTED, "SQ8 search: dim / k too large for the LDS query tile");
+  const uint32_t ngroups = (uint32_t)((ix->n_rows + 63) / 64);
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, 4));
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ngroups + 3) / 4, (int64_t)ix->n_cus * per_cu));
+  const int qgroups = (int)((nqg + (uint32_t)B - 1) / (uint32_t)B);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = (off + bytes + 15) & ~(size_t)15;
+    return o;
+  };
+  const size_t o_keys = take((size_t)nqg * blocks * k * 8), o_ids = take((size_t)nqg * k * 8), o_sc = take((size_t)nqg * k * 4),
+               o_n = take((size_t)nqg * 4), o_map = take((size_t)nqg * 4), o_cnt = take(16);
+  hipError_t e;
+  if ((e = ix->s_fb_keys.reserve(off, false, st)) != hipSuccess) return fail(VDB_ERR_OOM, "SQ8 fallback scratch");
+  unsigned char* sd = ix->s_fb_keys.as<unsigned char>();
+  uint32_t* qmap = reinterpret_cast<uint32_t*>(sd + o_map);
+  uint32_t* qcount = reinterpret_cast<uint32_t*>(sd + o_cnt);
+  launch_collect_flagged(flags, nqg, qmap, qcount, st);
+  Sq8Args a{};
+  a.codes = ix->sq8_codes.as<uint8_t>();
+  a.vmin = ix->sq8_min.as<float>();
+  a.vmax = ix->sq8_max.as<float>();
+  a.nsq = ix->sq8_nsq.as<float>();
+  a.alive = alive;
+  a.queries = d_q;
+  a.part_keys = reinterpret_cast<uint64_t*>(sd + o_keys);
+  a.code_stride = ix->sq8_stride;
+  a.q_stride = q_stride;
+  a.n_rows = (uint32_t)ix->n_rows;
+  a.dim = ix->dim;
+  a.nq = (uint32_t)B;
+  a.k = k;
+  a.qmap = qmap;
+  a.qcount = qcount;
+  e = B == 8 ? launch_sq8_m<8>(ix->metric, a, blocks, lds, st, qgroups)
+             : (B == 4 ? launch_sq8_m<4>(ix->metric, a, blocks, lds, st, qgroups) : launch_sq8_m<1>(ix->metric, a, blocks, lds, st, qgroups));
+  if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("SQ8 fallback sweep launch: ") + hipGetErrorString(e));
+  MergeArgs m{};
+  m.part_keys = a.part_keys;
+  m.ext_ids = ix->ext_ids.as<uint64_t>();
+  m.out_ids = reinterpret_cast<uint64_t*>(sd + o_ids);
+  m.out_scores = reinterpret_cast<float*>(sd + o_sc);
+  m.out_n = reinterpret_cast<uint32_t*>(sd + o_n);
+  m.n_lists = (uint32_t)blocks;
+  m.k = k;
+  m.active = qcount;
+  launch_merge(true, m, nqg, st);
+  launch_scatter_flagged(qmap, qcount, 0, m.out_ids, m.out_scores, m.out_n, d_ids, d_scores, d_n, nqg, k, st);
   VDB_HIP(hipGetLastError());
   return VDB_OK;
 }
@@ -579,7 +714,9 @@ int32_t vdb_hip_index_set_storage_mode(vdb_hip_index* ix, int32_t mode) {
   std::lock_guard<std::mutex> g(ix->mu);
   if (ix->storage_mode == mode) return VDB_OK;
   VDB_ENTER(ix);
-  for (DevBuf* b : {&ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits}) b->release();
+  for (DevBuf* b : {&ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits, &ix->sq8_img, &ix->sq8_nrm, &ix->sq8_seed})
+    b->release();
+  ix->sq8_img_rows = 0;
   ix->storage_mode = mode;
   ix->sq8_stride = ((uint64_t)ix->dim + 15) / 16 * 16;
   int32_t rc = storage_mode_append(ix, 0, ix->n_rows);

@@ -402,6 +402,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sweep_topk_mfma_f32(SweepArgs a
   uint32_t* locks = reinterpret_cast<uint32_t*>(smem + qbytes + (size_t)B * k * 8 + (size_t)B * 4);
   float* qn = reinterpret_cast<float*>(smem + qbytes + (size_t)B * k * 8 + (size_t)B * 8);
   const int d4 = (int)((a.dim + 3) / 4);
+  uint32_t nq_here = a.nq, slot0 = 0;
+  if (a.qmap) {  // gathered mode: this block row's share of the listed queries
+    const uint32_t listed = *a.qcount;
+    slot0 = blockIdx.y * (uint32_t)B;
+    if (listed > a.qcount_max || slot0 >= listed) return;  // (uniform per block, before the first barrier)
+    nq_here = min((uint32_t)B, listed - slot0);
+  }
 
   for (uint32_t i = threadIdx.x; i < KU * NQT * 2048; i += WAVES * 64) qs[i] = 0.0f;
   if (threadIdx.x < B) {
@@ -412,14 +419,15 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sweep_topk_mfma_f32(SweepArgs a
   __syncthreads();
   for (uint32_t idx = threadIdx.x; idx < (uint32_t)B * a.dim; idx += WAVES * 64) {
     const uint32_t b = idx / a.dim, kx = idx % a.dim;
-    if (b < a.nq) {
+    if (b < nq_here) {
       const uint32_t t = b >> 4, j = b & 15, U = kx >> 7, m = (kx >> 4) & 7, kk = (kx >> 2) & 3, c = kx & 3;
-      qs[((((size_t)U * NQT + t) * 8 + m) * 64 + kk * 16 + j) * 4 + c] = a.queries[(size_t)b * a.q_stride + kx];
+      const uint32_t qrow = a.qmap ? a.qmap[slot0 + b] : b;
+      qs[((((size_t)U * NQT + t) * 8 + m) * 64 + kk * 16 + j) * 4 + c] = a.queries[(size_t)qrow * a.q_stride + kx];
     }
   }
   if (METRIC == kCosine) {  // canonical query norms (same as every other kernel)
-    for (uint32_t b = wib; b < (uint32_t)B && b < a.nq; b += WAVES) {
-      const float* qp = a.queries + (size_t)b * a.q_stride;
+    for (uint32_t b = wib; b < (uint32_t)B && b < nq_here; b += WAVES) {
+      const float* qp = a.queries + (size_t)(a.qmap ? a.qmap[slot0 + b] : b) * a.q_stride;
       float nacc = 0.0f;
       for (int c = lane; c < d4; c += 64) {
         const int nv = (int)a.dim - c * 4;
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sweep_topk_mfma_f32(SweepArgs a
         const float approx = dotv * rq;
         // pass unless clearly below the threshold; NaN / inf / zero-norm cases always pass to the exact path
         const float margin = fabsf(tau_f[t]) * 1.9073486e-6f + 1e-37f;
-        const bool maybe = !(approx < tau_f[t] - margin) && row < a.n_rows && b < a.nq;
+        const bool maybe = !(approx < tau_f[t] - margin) && row < a.n_rows && b < nq_here;
         uint64_t mask = __ballot(maybe);
         if (mask == 0) continue;
         const float score = finish_score<METRIC>(dotv, qn_t[t], vn[r]);
@@ -563,9 +571,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sweep_topk_mfma_f32(SweepArgs a
     }
   }
   __syncthreads();
-  for (int b = wib; b < (int)a.nq && b < B; b += WAVES) {
+  for (int b = wib; b < (int)nq_here && b < B; b += WAVES) {
     const uint32_t c = cnts[b];
-    uint64_t* out = a.part_keys + ((size_t)b * gridDim.x + blockIdx.x) * k;
+    uint64_t* out = a.part_keys + ((size_t)(slot0 + b) * gridDim.x + blockIdx.x) * k;
     for (uint32_t e = lane; e < k; e += 64) out[e] = e < c ? lists[(size_t)b * k + e] : kKeyInvalid;
   }
 }
@@ -800,6 +808,7 @@ __global__ __launch_bounds__(256) void merge_topk(MergeArgs m) {
   const int lane = lane_id();
   const int wib = (int)(threadIdx.x >> 6);
   const uint32_t qi = blockIdx.x;
+  if (m.active && (qi >= *m.active || (m.active_max && *m.active > m.active_max))) return;  // (uniform per block)
   const uint32_t kin = m.k;                     // entries per partial list
   const uint32_t k = m.k_out ? m.k_out : m.k;   // entries kept (k_out > k: a candidate pool for a re-scoring stage)
   volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k;
@@ -1580,7 +1589,7 @@ size_t sweep_mfma_lds_bytes(int nqt, uint32_t k, uint32_t dim) {
   return ((KU * nqt * 8192 + B * k * 8 + B * 12) + 15) & ~(size_t)15;
 }
 template <int METRIC, int NQT, int WAVES>
-static hipError_t launch_mfma_t(const SweepArgs& a, int blocks, size_t lds, hipStream_t st) {
+static hipError_t launch_mfma_t(const SweepArgs& a, int blocks, size_t lds, hipStream_t st, int groups) {
   const uint32_t KT = (a.dim + 127) / 128;
   const bool full32 = (a.dim % 128) == 0;
   if (full32) {
@@ -1591,7 +1600,7 @@ static hipError_t launch_mfma_t(const SweepArgs& a, int blocks, size_t lds, hipS
       if (e != hipSuccess) return e;
       done = true;
     }
-    hipLaunchKernelGGL((sweep_topk_mfma_f32<METRIC, NQT, WAVES, true>), dim3(blocks), dim3(WAVES * 64), lds, st, a, KT);
+    hipLaunchKernelGGL((sweep_topk_mfma_f32<METRIC, NQT, WAVES, true>), dim3(blocks, groups), dim3(WAVES * 64), lds, st, a, KT);
   } else {
     static bool done = false;
     if (lds > 64 * 1024 && !done) {
@@ -1600,20 +1609,20 @@ static hipError_t launch_mfma_t(const SweepArgs& a, int blocks, size_t lds, hipS
       if (e != hipSuccess) return e;
       done = true;
     }
-    hipLaunchKernelGGL((sweep_topk_mfma_f32<METRIC, NQT, WAVES, false>), dim3(blocks), dim3(WAVES * 64), lds, st, a, KT);
+    hipLaunchKernelGGL((sweep_topk_mfma_f32<METRIC, NQT, WAVES, false>), dim3(blocks, groups), dim3(WAVES * 64), lds, st, a, KT);
   }
   return hipGetLastError();
 }
-hipError_t launch_sweep_mfma(int metric, int nqt, const SweepArgs& a, int blocks, hipStream_t st) {
+hipError_t launch_sweep_mfma(int metric, int nqt, const SweepArgs& a, int blocks, hipStream_t st, int groups) {
   const size_t lds = sweep_mfma_lds_bytes(nqt, a.k, a.dim);
   if (metric == kCosine) {
-    if (nqt == 3) return launch_mfma_t<kCosine, 3, kMfmaWaves2>(a, blocks, lds, st);
-    if (nqt == 2) return launch_mfma_t<kCosine, 2, kMfmaWaves2>(a, blocks, lds, st);
-    return launch_mfma_t<kCosine, 1, kMfmaWaves1>(a, blocks, lds, st);
+    if (nqt == 3) return launch_mfma_t<kCosine, 3, kMfmaWaves2>(a, blocks, lds, st, groups);
+    if (nqt == 2) return launch_mfma_t<kCosine, 2, kMfmaWaves2>(a, blocks, lds, st, groups);
+    return launch_mfma_t<kCosine, 1, kMfmaWaves1>(a, blocks, lds, st, groups);
   }
-  if (nqt == 3) return launch_mfma_t<kDot, 3, kMfmaWaves2>(a, blocks, lds, st);
-  if (nqt == 2) return launch_mfma_t<kDot, 2, kMfmaWaves2>(a, blocks, lds, st);
-  return launch_mfma_t<kDot, 1, kMfmaWaves1>(a, blocks, lds, st);
+  if (nqt == 3) return launch_mfma_t<kDot, 3, kMfmaWaves2>(a, blocks, lds, st, groups);
+  if (nqt == 2) return launch_mfma_t<kDot, 2, kMfmaWaves2>(a, blocks, lds, st, groups);
+  return launch_mfma_t<kDot, 1, kMfmaWaves1>(a, blocks, lds, st, groups);
 }
 
 // ---- bf16 launchers --------------------------------------------------------------------------

@@ -140,7 +140,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void sweep_topk_gem
   const uint32_t xcd = bid & 7u, slot_id = bid >> 3;
   const uint32_t qt = slot_id % ga.nqt;
   const uint32_t g = (slot_id / ga.nqt) * 8u + xcd;
-  if (ga.tile_needed && ga.tile_needed[qt] == 0u) return;  // block-uniform, before the first barrier
+  // device-driven fallback (sweep_split.hip): only the query tiles that hold an unproven query — and nothing at all when
+  // the unproven queries are few enough for the gathered pass of the streaming kernel (a.qcount / a.qcount_max)
+  if (ga.tile_needed && (ga.tile_needed[qt] == 0u || (a.qcount && *a.qcount <= a.qcount_max))) return;  // block-uniform, before the first barrier
   const uint32_t q0 = qt * ga.qper;
   const uint32_t nq_t = min(ga.qper, a.nq - q0);
   const float* queries = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.queries) + (size_t)q0 * a.q_stride * ES);

@@ -84,7 +84,9 @@ void launch_split_vectors(const float* src, uint64_t src_stride, uint16_t* out, 
 // (Cauchy-Schwarz over the per-element errors: sum |e_i q_i| <= |e| |q|.)
 __host__ __device__ inline float select_eps(uint32_t dim, int level) {
   const float acc = 16.0f * (float)dim * 5.9604645e-8f;
-  return (level >= 2 ? 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f : 8.2f * 3.8146973e-6f) + acc;
+  // level 3 = level 2 over the SQ8 storage mode's dequantised rows: + the distance between the matrix-core seed scores and
+  // the reference's left-to-right chain (dim 2^-24 each way, padded)
+  return (level >= 2 ? 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f : 8.2f * 3.8146973e-6f) + acc + (level >= 3 ? 1.5e-4f : 0.0f);
 }
 
 // Seed from the EXACT sweep of the first rows (merged to rows + raw scores, best first): list slot 0 of the candidate pool
@@ -145,12 +147,16 @@ void launch_split_reseed(const uint64_t* ids, const float* scores, const uint32_
 }
 
 // One block per query: exact re-scoring of the K2 best of the pool, ranking, proof.  See the file header.
-template <int METRIC>
+// SQ8: the exact score is the reference's asymmetric distance over the row's SQ8 code (core/quantization.rs:410-554) — one
+// left-to-right chain per (query, row), multiplies and adds rounded separately (storage_modes.hip sweep_topk_sq8 computes
+// the same bits for the whole corpus; here only for the candidates).
+template <int METRIC, bool SQ8>
 __global__ __launch_bounds__(256) void split_rerank_verify(SplitRerankArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* qs = reinterpret_cast<float*>(smem);                    // [dim padded to 128]
   uint64_t* keys = reinterpret_cast<uint64_t*>(qs + a.dim_pad);  // [K2]
   unsigned long long* bmin = reinterpret_cast<unsigned long long*>(keys + a.k2);
+  float* qred = reinterpret_cast<float*>(bmin + 1);              // SQ8: sum(q), sum(q*q), left to right
   const uint32_t tid = threadIdx.x, qi = blockIdx.x;
   const uint32_t n = min(a.cand_n[qi], a.k2);
   const float* q = a.queries + (size_t)qi * a.q_stride;
@@ -163,6 +169,45 @@ __global__ __launch_bounds__(256) void split_rerank_verify(SplitRerankArgs a) {
     for (uint32_t g = tid; g < a.lists; g += 256) m = min(m, (unsigned long long)a.blk_tau[(size_t)qi * a.lists + g]);
     if (m != ~0ull) atomicMin(bmin, m);
   }
+  if (SQ8) {
+    if (tid == 64) {  // :330-334 sum(q); :528 sum(q*q) — two chains, two waves
+      float s1 = 0.0f;
+      for (uint32_t d = 0; d < a.dim; d++) s1 = __fadd_rn(s1, qs[d]);
+      qred[0] = s1;
+    }
+    if (tid == 128) {
+      float s2 = 0.0f;
+      for (uint32_t d = 0; d < a.dim; d++) s2 = __fadd_rn(s2, __fmul_rn(qs[d], qs[d]));
+      qred[1] = s2;
+    }
+    __syncthreads();
+    if (tid < n) {
+      const uint32_t row = (uint32_t)a.cand_rows[(size_t)qi * a.k2 + tid];
+      const float mn = a.sq8_min[row], range = __fsub_rn(a.sq8_max[row], mn);
+      const uint32_t* c = reinterpret_cast<const uint32_t*>(a.sq8_codes + (size_t)row * a.sq8_stride);
+      float acc = 0.0f;
+      if (range < 1.1920929e-07f) {
+        acc = __fmul_rn(qred[0], mn);
+      } else {
+        const float scale = __fdiv_rn(range, 255.0f);
+        for (uint32_t i = 0; i < a.dim; i += 4) {
+          const uint32_t w = c[i >> 2];
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if (i + e < a.dim) {
+              const float dq = __fadd_rn(__fmul_rn((float)((w >> (8 * e)) & 0xFFu), scale), mn);
+              acc = __fadd_rn(acc, __fmul_rn(qs[i + e], dq));
+            }
+        }
+      }
+      float score = acc;
+      if (METRIC == kCosine) {
+        const float denom = sqrtf(__fmul_rn(qred[1], a.sq8_nsq[row]));
+        score = denom < 1.1920929e-07f ? 0.0f : __fdiv_rn(acc, denom);
+      }
+      keys[tid] = make_key<true>(score, row);
+    }
+  } else {
   const float qn = METRIC == kCosine ? a.qnorms[qi] : 0.0f;
   if (tid < n) {
     const uint32_t row = (uint32_t)a.cand_rows[(size_t)qi * a.k2 + tid];
@@ -191,6 +236,7 @@ __global__ __launch_bounds__(256) void split_rerank_verify(SplitRerankArgs a) {
     const float score = finish_score<METRIC>(acc, qn, METRIC == kCosine ? a.norms[row] : 1.0f);
     keys[tid] = make_key<true>(score, row);
   }
+  }
   __syncthreads();
   if (tid >= 64) return;
   const int lane = (int)tid;
@@ -218,7 +264,7 @@ __global__ __launch_bounds__(256) void split_rerank_verify(SplitRerankArgs a) {
   }
   if (lane == 0) {
     a.flags[qi] = ok ? 0u : 1u;
-    if (!ok) a.tile_needed[qi / a.fb_qper] = 1u;
+    if (!ok && a.tile_needed) a.tile_needed[qi / a.fb_qper] = 1u;
     a.out_n[qi] = kk;
   }
   for (uint32_t e = lane; e < a.k; e += 64) {
@@ -234,12 +280,19 @@ __global__ __launch_bounds__(256) void split_rerank_verify(SplitRerankArgs a) {
   }
 }
 void launch_split_rerank(int metric, const SplitRerankArgs& a, uint32_t nq, hipStream_t st) {
-  const size_t lds = ((size_t)a.dim_pad * 4 + (size_t)a.k2 * 8 + 16 + 15) & ~(size_t)15;
-  if (metric == kCosine)
-    hipLaunchKernelGGL((split_rerank_verify<kCosine>), dim3(nq), dim3(256), lds, st, a);
-  else
-    hipLaunchKernelGGL((split_rerank_verify<kDot>), dim3(nq), dim3(256), lds, st, a);
+  const size_t lds = ((size_t)a.dim_pad * 4 + (size_t)a.k2 * 8 + 16 + 16 + 15) & ~(size_t)15;
+  if (a.sq8_codes) {
+    if (metric == kCosine)
+      hipLaunchKernelGGL((split_rerank_verify<kCosine, true>), dim3(nq), dim3(256), lds, st, a);
+    else
+      hipLaunchKernelGGL((split_rerank_verify<kDot, true>), dim3(nq), dim3(256), lds, st, a);
+  } else if (metric == kCosine) {
+    hipLaunchKernelGGL((split_rerank_verify<kCosine, false>), dim3(nq), dim3(256), lds, st, a);
+  } else {
+    hipLaunchKernelGGL((split_rerank_verify<kDot, false>), dim3(nq), dim3(256), lds, st, a);
+  }
 }
+
 
 __global__ __launch_bounds__(256) void select_stats_kernel(const uint32_t* flags, uint32_t nq, uint32_t seq, uint32_t level,
                                                            volatile uint32_t* host) {
@@ -262,12 +315,65 @@ void launch_select_stats(const uint32_t* flags, uint32_t nq, uint32_t seq, uint3
   hipLaunchKernelGGL(select_stats_kernel, dim3(1), dim3(256), 0, st, flags, nq, seq, level, host);
 }
 
+// the queries a selection batch could not prove, in ascending order: qmap[0 .. *qcount)
+__global__ __launch_bounds__(1024) void collect_flagged_kernel(const uint32_t* flags, uint32_t nq, uint32_t* qmap, uint32_t* qcount) {
+  __shared__ uint32_t base;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (uint32_t q0 = 0; q0 < nq; q0 += 1024) {  // nq <= 1024 per chunk: one round
+    const uint32_t q = q0 + threadIdx.x;
+    const bool f = q < nq && flags[q] != 0;
+    const uint64_t m = __ballot(f);
+    __shared__ uint32_t wsum[16];
+    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) wsum[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t off = base;
+    for (uint32_t i = 0; i < w; i++) off += wsum[i];
+    if (f) qmap[off + (uint32_t)__popcll(m & ((1ull << l) - 1ull))] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int i = 0; i < 16; i++) t += wsum[i];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *qcount = base;
+}
+// listed query j takes the gathered exact pass's result (slot j)
+__global__ __launch_bounds__(64) void scatter_flagged_kernel(const uint32_t* qmap, const uint32_t* qcount, uint32_t max_listed,
+                                                             const uint64_t* fb_ids, const float* fb_scores, const uint32_t* fb_n,
+                                                             uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint32_t k) {
+  const uint32_t j = blockIdx.x;
+  if (j >= *qcount || (max_listed && *qcount > max_listed)) return;
+  const uint32_t q = qmap[j];
+  for (uint32_t e = threadIdx.x; e < k; e += 64) {
+    out_ids[(size_t)q * k + e] = fb_ids[(size_t)j * k + e];
+    out_scores[(size_t)q * k + e] = fb_scores[(size_t)j * k + e];
+  }
+  if (threadIdx.x == 0) out_n[q] = fb_n[j];
+}
+
+void launch_collect_flagged(const uint32_t* flags, uint32_t nq, uint32_t* qmap, uint32_t* qcount, hipStream_t st) {
+  hipLaunchKernelGGL(collect_flagged_kernel, dim3(1), dim3(1024), 0, st, flags, nq, qmap, qcount);
+}
+void launch_scatter_flagged(const uint32_t* qmap, const uint32_t* qcount, uint32_t max_listed, const uint64_t* fb_ids,
+                            const float* fb_scores, const uint32_t* fb_n, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
+                            uint32_t nq, uint32_t k, hipStream_t st) {
+  const uint32_t blocks = max_listed ? std::min(nq, max_listed) : nq;
+  hipLaunchKernelGGL(scatter_flagged_kernel, dim3(blocks), dim3(64), 0, st, qmap, qcount, max_listed, fb_ids, fb_scores, fb_n, out_ids,
+                     out_scores, out_n, k);
+}
+
 // flagged queries take the exact kernel's result
 __global__ __launch_bounds__(256) void select_fallback_kernel(const uint32_t* flags, const uint64_t* fb_ids, const float* fb_scores,
                                                               const uint32_t* fb_n, uint64_t* out_ids, float* out_scores,
-                                                              uint32_t* out_n, uint32_t nq, uint32_t k) {
+                                                              uint32_t* out_n, uint32_t nq, uint32_t k, const uint32_t* qcount,
+                                                              uint32_t skip_le) {
   const uint32_t q = blockIdx.x;
   if (q >= nq || !flags[q]) return;
+  if (qcount && *qcount <= skip_le) return;  // the gathered pass answered this batch's flagged queries
   for (uint32_t e = threadIdx.x; e < k; e += 256) {
     out_ids[(size_t)q * k + e] = fb_ids[(size_t)q * k + e];
     out_scores[(size_t)q * k + e] = fb_scores[(size_t)q * k + e];
@@ -275,8 +381,10 @@ __global__ __launch_bounds__(256) void select_fallback_kernel(const uint32_t* fl
   if (threadIdx.x == 0) out_n[q] = fb_n[q];
 }
 void launch_select_fallback(const uint32_t* flags, const uint64_t* fb_ids, const float* fb_scores, const uint32_t* fb_n,
-                            uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint32_t nq, uint32_t k, hipStream_t st) {
-  hipLaunchKernelGGL(select_fallback_kernel, dim3(nq), dim3(256), 0, st, flags, fb_ids, fb_scores, fb_n, out_ids, out_scores, out_n, nq, k);
+                            uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint32_t nq, uint32_t k, hipStream_t st,
+                            const uint32_t* qcount, uint32_t skip_le) {
+  hipLaunchKernelGGL(select_fallback_kernel, dim3(nq), dim3(256), 0, st, flags, fb_ids, fb_scores, fb_n, out_ids, out_scores, out_n, nq, k,
+                     qcount, skip_le);
 }
 
 }  // namespace vdb

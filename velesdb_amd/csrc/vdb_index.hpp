@@ -129,6 +129,10 @@ struct vdb_hip_index {
   int32_t storage_mode = 0;      // VDB_STORAGE_FULL
   uint64_t sq8_stride = 0;       // bytes per SQ8 row (multiple of 16)
   vdb::DevBuf sq8_codes, sq8_min, sq8_max, sq8_nsq, sign_bits;
+  // selection stage over SQ8 (level 3): bf16 image of the dequantised rows, their norms, f32 seed prefix
+  vdb::DevBuf sq8_img, sq8_nrm, sq8_seed;
+  uint64_t sq8_img_rows = 0;
+  uint32_t sq8_hold = 0;   // batches to answer with the exact SQ8 sweep after a batch the selection could not prove
   // graph
   std::vector<vdb::GraphLayer> layers;
   bool graph_valid = true;   // false once rows exist that are not linked into the graph
@@ -231,6 +235,13 @@ constexpr uint32_t kVlogCap = 16384;
 int32_t storage_mode_append(vdb_hip_index* ix, uint64_t first, uint64_t n);
 int32_t brute_sq8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint64_t* d_ids,
                       float* d_scores, uint32_t* d_n, hipStream_t st);
+int32_t ensure_sq8_select(vdb_hip_index* ix, hipStream_t st);
+int32_t sq8_fallback_flagged(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, const uint32_t* flags,
+                             uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st);
+// index.hip: selection + exact re-scoring + proof for a chunk of <= 1024 queries (level 1 / 2: f32 rows, 3: SQ8 storage mode)
+int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, uint64_t* d_ids,
+                        float* d_scores, uint32_t* d_n, hipStream_t st, int level);
+int select_level_sq8(vdb_hip_index* ix, uint32_t nq_left, uint32_t k);
 int32_t brute_binary_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint64_t* d_ids,
                          float* d_scores, uint32_t* d_n, hipStream_t st);
 }  // namespace vdb

@@ -19,6 +19,13 @@ struct SweepArgs {
   uint32_t dim;
   uint32_t nq;             // queries in this pass (<= B)
   uint32_t k;
+  // gathered mode (sweep_topk_mfma_f32; the exact pass over the few queries a selection batch could not prove): block row
+  // blockIdx.y serves the listed queries qmap[B y .. B y + B - 1] of `queries`, part_keys slots follow the list; the launch
+  // does nothing when more than qcount_max queries are listed (the GEMM-structured fallback takes those batches) and the
+  // GEMM-structured kernel does nothing when qcount is set and *qcount <= qcount_max
+  const uint32_t* qmap;
+  const uint32_t* qcount;
+  uint32_t qcount_max;
 };
 
 struct MergeArgs {
@@ -32,6 +39,8 @@ struct MergeArgs {
   uint32_t n_lists;
   uint32_t k;                 // entries per partial list
   uint32_t k_out;             // 0 = k; otherwise the number of entries kept per query (out_* are [nq][k_out])
+  const uint32_t* active;     // nullable: *active = number of leading queries that hold data (the other blocks exit)
+  uint32_t active_max;        // with `active`: nothing to do at all when *active > active_max (0 = no such limit)
 };
 
 struct EuclidRerankArgs {
@@ -132,7 +141,7 @@ hipError_t launch_sweep_f32_qlds(int metric, int B, const SweepArgs& a, int bloc
 constexpr int kMfmaWaves1 = 8;   // waves per block for one 16-query tile
 constexpr int kMfmaWaves2 = 16;  // ... for two tiles (the 96 KiB query fragments fill most of the LDS)
 size_t sweep_mfma_lds_bytes(int nqt, uint32_t k, uint32_t dim);
-hipError_t launch_sweep_mfma(int metric, int nqt, const SweepArgs& a, int blocks, hipStream_t st);
+hipError_t launch_sweep_mfma(int metric, int nqt, const SweepArgs& a, int blocks, hipStream_t st, int groups = 1);
 // GEMM-structured f32 sweep for large query batches (sweep_gemm.hip): 128-row x 32*nqf-query block tiles
 struct GemmPlan {
   uint32_t nqt;   // query tiles
@@ -209,6 +218,13 @@ struct SplitRerankArgs {
   uint32_t* tile_needed;        // [ceil(nq / fb_qper)] query tiles of the exact fallback launch that hold a flagged query
   uint64_t row_stride, q_stride;
   uint32_t dim, dim_pad, k, k2, lists, fb_qper;
+  // SQ8 storage mode (storage_modes.hip): candidates are re-scored with the reference's asymmetric distances over the
+  // codes (dot_product_quantized_simd / cosine_similarity_quantized_simd, core/quantization.rs:410-554) instead of `rows`
+  const uint8_t* sq8_codes;     // nullptr = f32 rows
+  const float* sq8_min;
+  const float* sq8_max;
+  const float* sq8_nsq;
+  uint64_t sq8_stride;
 };
 void launch_split_vectors(const float* src, uint64_t src_stride, uint16_t* out, float* norms, uint32_t row0, uint32_t n,
                           uint32_t dim, hipStream_t st);
@@ -220,8 +236,15 @@ void launch_select_stats(const uint32_t* flags, uint32_t nq, uint32_t seq, uint3
 void launch_split_reseed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* delta, uint64_t* tau0,
                          uint32_t nq, uint32_t k, uint32_t kout, hipStream_t st);
 void launch_split_rerank(int metric, const SplitRerankArgs& a, uint32_t nq, hipStream_t st);
+// the flagged queries of a batch in ascending order: qmap[0 .. *qcount) (one block; nq <= 1024 per round)
+void launch_collect_flagged(const uint32_t* flags, uint32_t nq, uint32_t* qmap, uint32_t* qcount, hipStream_t st);
+// listed query j takes slot j of a gathered exact pass; nothing happens when more than `max_listed` are listed (0 = no limit)
+void launch_scatter_flagged(const uint32_t* qmap, const uint32_t* qcount, uint32_t max_listed, const uint64_t* fb_ids,
+                            const float* fb_scores, const uint32_t* fb_n, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
+                            uint32_t nq, uint32_t k, hipStream_t st);  // a.sq8_codes selects the SQ8 chain
 void launch_select_fallback(const uint32_t* flags, const uint64_t* fb_ids, const float* fb_scores, const uint32_t* fb_n,
-                            uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint32_t nq, uint32_t k, hipStream_t st);
+                            uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint32_t nq, uint32_t k, hipStream_t st, const uint32_t* qcount = nullptr,
+                            uint32_t skip_le = 0);
 void launch_euclid_rerank(const EuclidRerankArgs& a, const float* norms, uint32_t n_rows, uint32_t nq, hipStream_t st);
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st);
 // B (8 or 32) queries per corpus pass; blocks = row blocks (= partial lists per query), grid.y = ceil(nq / B)
