@@ -583,7 +583,8 @@ def main():
                      "ids_equal_reference_order": bool(np.array_equal(gi, ri)),
                      "max_rel_diff_vs_reference_order": float(np.max(np.abs(gs - rs) / np.abs(rs)))}
             recall = float(np.mean([len(set(gi[i].tolist()) & set(ri[i].tolist())) / K for i in range(sel.size)]))
-            host_full = None
+            if a.no_sq8_leg or world != 1:
+                host_full = None  # (the SQ8 leg checks its batch against the oracle over the same rows)
         if not a.no_cpu_baseline:
             # bounded sample of the SAME workload on every host core through a persistent thread pool (rayon in the
             # reference), the corpus pages placed by the threads that scan them (NUMA); shape A = the production engine
@@ -743,6 +744,7 @@ def main():
                                        "ids_equal_oracle": bool(np.array_equal(sel_ids[pick], eid_s.astype(np.uint64))),
                                        "scores_bit_equal_oracle": bool(np.array_equal(sel_sc[pick].view(np.uint32), esc_s.view(np.uint32)))}
         ix.set_storage_mode(va.StorageMode.Full)
+    host_full = None
 
     # ---- graph leg on embedding-like data (N = 1 only): iid N(0,1) in 768-D has no neighbourhood structure, so HNSW
     # recall there is ~0.04 for the reference and the GPU alike.  Real embeddings have low intrinsic

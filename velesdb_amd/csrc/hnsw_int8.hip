@@ -13,11 +13,19 @@
 //     (canonical arithmetic), stable-sorted (total_cmp), cut to k (dual_precision.rs:267-281).
 // Algorithmic HBM bytes per query: n_dist * (dim + 4) + n_expand * M0 * 4 + k * oversampling * dim * 4.
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 
 #include "vdb_hnsw_device.hpp"
 #include "vdb_index.hpp"
 
 namespace vdb {
+
+// VELESDB_I8_WAVES2=0 keeps four-wave blocks for every batch (A / B measurements)
+static std::atomic<bool> g_i8_waves2{[] {
+  const char* e = getenv("VELESDB_I8_WAVES2");
+  return !(e && e[0] == '0');
+}()};
 
 namespace {
 
@@ -82,8 +90,11 @@ struct HnswInt8Args {
 
 // LDS: keys[cap] u64 | nb_id[nbmax] | nb_d[nbmax] | ctl[4] | flags[cap] (pad 16) | f32 query scratch (generic dims)
 //      | qcode words [code_words] | re-rank output (node, dist) [nbmax] u64
-template <int METRIC, int CPL, int NS>
-__global__ __launch_bounds__(256) void hnsw_search_int8_kernel(HnswInt8Args A) {
+// WAVES: 4 (a 256-thread block per query in flight) or 2: the traversal reads 772 bytes per visited node instead of 3 KB, so
+// a step's distance phase is short and the leader's serial part (pop, visited test-and-set, admission) dominates — at 142
+// registers a CU holds 12 waves: 3 queries in flight with four-wave blocks, 6 with two-wave blocks.
+template <int METRIC, int CPL, int NS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void hnsw_search_int8_kernel(HnswInt8Args A) {
   const HnswSearchArgs& a = A.s;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id();
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(256) void hnsw_search_int8_kernel(HnswInt8Args A) {
       }
       if (METRIC == kCosine) qnorm = sqrtf(butterfly_all(nacc));
     } else {
-      for (int i = threadIdx.x; i < d4 * 4; i += 256) qgen[i] = i < (int)a.dim ? qp[i] : 0.0f;
+      for (int i = threadIdx.x; i < d4 * 4; i += WAVES * 64) qgen[i] = i < (int)a.dim ? qp[i] : 0.0f;
       __syncthreads();
       if (METRIC == kCosine) {
         float nacc = 0.0f;
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(256) void hnsw_search_int8_kernel(HnswInt8Args A) {
       }
     }
     // quantised query (quantizer.quantize(query), dual_precision.rs:235)
-    for (uint32_t w = threadIdx.x; w < CW; w += 256) {
+    for (uint32_t w = threadIdx.x; w < CW; w += WAVES * 64) {
       uint32_t word = 0;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -332,9 +343,9 @@ __global__ __launch_bounds__(256) void hnsw_search_int8_kernel(HnswInt8Args A) {
       const uint32_t m = ctl[0];
       if (ctl[1]) break;
       if (ctl[3])
-        dist_phase_f32<METRIC, CPL>(dc, q, qnorm, qgen, m, nb_id, nb_d, lane, wib, false);  // exact engine distance
+        dist_phase_f32<METRIC, CPL, WAVES>(dc, q, qnorm, qgen, m, nb_id, nb_d, lane, wib, false);  // exact engine distance
       else
-        dist_phase_int8<QW>(A.codes, qw, qsq, m, nb_id, nb_d, lane, wib);
+        dist_phase_int8<QW, WAVES>(A.codes, qw, qsq, m, nb_id, nb_d, lane, wib);
       __syncthreads();
     }
 
@@ -381,29 +392,36 @@ __global__ __launch_bounds__(256) void hnsw_search_int8_kernel(HnswInt8Args A) {
     }
     const uint32_t nlog = ctl[2];
     if (nlog <= a.vlog_cap) {
-      for (uint32_t i = threadIdx.x; i < nlog; i += 256) vis[vlog[i] >> 5] = 0;
+      for (uint32_t i = threadIdx.x; i < nlog; i += WAVES * 64) vis[vlog[i] >> 5] = 0;
     } else {
-      for (uint64_t i = threadIdx.x; i < a.vis_words; i += 256) vis[i] = 0;
+      for (uint64_t i = threadIdx.x; i < a.vis_words; i += WAVES * 64) vis[i] = 0;
     }
     __syncthreads();
   }
 }
 
 // ---- host side -----------------------------------------------------------------------------
-template <int METRIC, int CPL, int NS>
-static hipError_t launch_i8_ns(const HnswInt8Args& A, int slots, size_t lds, hipStream_t st) {
+template <int METRIC, int CPL, int NS, int WAVES>
+static hipError_t launch_i8_w(const HnswInt8Args& A, int slots, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_search_int8_kernel<METRIC, CPL, NS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_search_int8_kernel<METRIC, CPL, NS, WAVES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   int occ = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, hnsw_search_int8_kernel<METRIC, CPL, NS>, 256, lds);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, hnsw_search_int8_kernel<METRIC, CPL, NS, WAVES>, WAVES * 64, lds);
   if (e != hipSuccess) return e;
-  occ = std::max(1, std::min(occ, 4));
+  occ = std::max(1, std::min(occ, kTraversalSlotsPerCu));
   const int grid = (int)std::min<int64_t>((int64_t)slots, (int64_t)A.s.n_cus * occ);
-  hipLaunchKernelGGL((hnsw_search_int8_kernel<METRIC, CPL, NS>), dim3(grid), dim3(256), lds, st, A);
+  hipLaunchKernelGGL((hnsw_search_int8_kernel<METRIC, CPL, NS, WAVES>), dim3(grid), dim3(WAVES * 64), lds, st, A);
   return hipGetLastError();
+}
+template <int METRIC, int CPL, int NS>
+static hipError_t launch_i8_ns(const HnswInt8Args& A, int slots, size_t lds, hipStream_t st) {
+  // batches that can fill more than four-wave blocks' worth of slots run two-wave blocks (twice the queries in flight)
+  if (g_i8_waves2.load(std::memory_order_relaxed) && (int64_t)slots > (int64_t)A.s.n_cus * 3)
+    return launch_i8_w<METRIC, CPL, NS, 2>(A, slots, lds, st);
+  return launch_i8_w<METRIC, CPL, NS, 4>(A, slots, lds, st);
 }
 template <int METRIC, int CPL>
 static hipError_t launch_i8_t(const HnswInt8Args& A, int slots, size_t lds, hipStream_t st) {
@@ -528,7 +546,7 @@ int32_t hnsw_search_int8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_str
   A.min_vals = ix->sq_min.as<float>();
   A.scales = ix->sq_scale.as<float>();
   A.cand_k = (uint32_t)cand_k;
-  const int slots = (int)std::min<int64_t>((int64_t)nq, (int64_t)ix->n_cus * 4);
+  const int slots = (int)std::min<int64_t>((int64_t)nq, (int64_t)ix->n_cus * kTraversalSlotsPerCu);
   EventPair* ev = next_events(ix);
   if (ev) (void)hipEventRecord(ev->a, st);
   hipError_t e;

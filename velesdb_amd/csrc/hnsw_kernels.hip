@@ -441,7 +441,7 @@ hipError_t launch_hnsw_search(const HnswSearchArgs& a, int slots, hipStream_t st
 // one visited bitmap (capacity bits) + one id log per resident block, zero between launches
 int32_t ensure_traversal_scratch(vdb_hip_index* ix, hipStream_t st) {
   const uint64_t vis_words = (ix->capacity + 31) / 32;
-  const int max_slots = ix->n_cus * 4;
+  const int max_slots = ix->n_cus * kTraversalSlotsPerCu;
   if (ix->vis_words != vis_words || ix->s_visited.cap < (size_t)max_slots * vis_words * 4) {
     hipError_t e = ix->s_visited.reserve((size_t)max_slots * vis_words * 4, false, st);
     if (e == hipSuccess) e = ix->s_vlog.reserve((size_t)max_slots * kVlogCap * 4, false, st);

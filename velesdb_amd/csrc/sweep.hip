@@ -918,9 +918,25 @@ __global__ __launch_bounds__(256) void sweep_topk_bits(BitsArgs a) {
     } else {
       score = (uni == 0) ? 1.0f : (float)inter / (float)uni;  // simd_explicit.rs:431-442
     }
-    const uint64_t key = valid ? make_key<HIB>(score, row) : kKeyInvalid;
+    uint64_t key = valid ? make_key<HIB>(score, row) : kKeyInvalid;
     const uint64_t tau = (*cnt == k) ? list[k - 1] : kKeyInvalid;
     uint64_t mask = __ballot(key < tau);
+    if ((uint32_t)__popcll(mask) > k) {
+      // Many lanes pass (always in a block's first steps, while its list is still filling): only the wave's own k best can
+      // end up in the list, so rank the passing keys among themselves first — one readlane + compare per passing lane
+      // instead of one locked list insertion (~20x the instructions) per passing lane.  Soft-deleted rows must not take
+      // a rank: they are dropped here (a rare, divergent load).
+      if (a.alive && (mask >> lane & 1ull) && a.alive[row] == 0) key = kKeyInvalid;
+      mask = __ballot(key < tau);
+      uint32_t rank = 0;
+      uint64_t rest = mask;
+      while (rest) {
+        const int src = __ffsll((long long)rest) - 1;
+        rest &= rest - 1;
+        rank += readlane64(key, src) < key ? 1u : 0u;
+      }
+      mask = __ballot((mask >> lane & 1ull) && rank < k);
+    }
     while (mask) {
       const int src = __ffsll((long long)mask) - 1;
       mask &= mask - 1;

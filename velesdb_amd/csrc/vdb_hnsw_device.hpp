@@ -136,11 +136,11 @@ struct CodeCtx {
   uint32_t code_words;    // words per row (multiple of 4)
 };
 // nb_id[0..m) -> nb_d[0..m) as u32 bit patterns.  qw: this lane's query words (word w = lane + 64*j), QW of them.
-template <int QW>
+template <int QW, int WAVES = 4>
 __device__ __forceinline__ void dist_phase_int8(const CodeCtx& c, const uint32_t (&qw)[QW], uint32_t qsq, uint32_t m,
                                                 volatile uint32_t* nb_id, volatile float* nb_d, int lane, int wib) {
   constexpr int R = 8;
-  for (uint32_t j0 = (uint32_t)wib * R; j0 < m; j0 += 4 * R) {
+  for (uint32_t j0 = (uint32_t)wib * R; j0 < m; j0 += WAVES * R) {
     uint32_t dot[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -331,14 +331,14 @@ __device__ __forceinline__ float transform_score_dev(int metric, float d) {  // 
 }
 
 // ---- distance evaluation of nb_id[0..m) -> nb_d[0..m): DistanceEngine::distance (native/distance.rs:75-85)
-template <int METRIC, int CPL>
+template <int METRIC, int CPL, int WAVES = 4>
 __device__ __forceinline__ void dist_phase_f32(const DistCtx& a, const float4* q, float qnorm,
                                                const float* qgen, uint32_t m, volatile uint32_t* nb_id,
                                                volatile float* nb_d, int lane, int wib, bool raw = false) {
   constexpr int OP = (METRIC == kEuclidean) ? kOpL2 : kOpDot;
   constexpr int R = 8;
   const int d4 = (int)((a.dim + 3) / 4);
-  for (uint32_t j0 = (uint32_t)wib * R; j0 < m; j0 += 4 * R) {
+  for (uint32_t j0 = (uint32_t)wib * R; j0 < m; j0 += WAVES * R) {
     float acc[R];
     if (CPL > 0) {
       float4 v[R][CPL > 0 ? CPL : 1];
