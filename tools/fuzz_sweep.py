@@ -21,6 +21,8 @@ p = argparse.ArgumentParser()
 p.add_argument("--seconds", type=float, default=240)
 p.add_argument("--seed", type=int, default=1)
 p.add_argument("--big", action="store_true", help="few cases over 100K-400K rows (many row tiles / groups per wave and block)")
+p.add_argument("--select", action="store_true", help="batches that take the selection stage (>= 224 queries, >= 65 536 rows, "
+               "k <= 10; levels 1 and 2 at random) incl. data built to defeat the proofs (gathered / GEMM fallbacks, level parking)")
 p.add_argument("--engine", type=int, default=1, help="0 = vector-ALU kernels for cosine / dot too")
 p.add_argument("--only-it", type=int, default=0, help="replay: generate every case, run only this one (verbose)")
 p.add_argument("--euclid", action="store_true", help="Euclidean only (matrix-core batches + exact re-scoring)")
@@ -81,9 +83,24 @@ while time.time() < t_end:
         nq = int(rng.choice([1, 8, 24, 40, 64, 130, 300]))
         k = int(rng.choice([1, 10, 32]))
         kind = str(rng.choice(["normal", "normal", "dups", "small_ints"]))
+    if a.select:
+        bf16 = False
+        n = int(rng.choice([66_000, 150_000, 300_000]))
+        dim = int(rng.choice([64, 128, 256, 768]))
+        nq = int(rng.choice([230, 256, 480, 1000]))
+        k = int(rng.choice([1, 3, 10]))
+        kind = str(rng.choice(["normal", "normal", "dups", "small_ints", "ascending", "zeros_mixed", "clusters"]))
+        va.set_split_selector(int(rng.choice([1, 2])))
     q0 = rng.standard_normal(dim).astype(np.float32)
-    rows = make_rows(kind, n, dim, q0)
+    rows = make_rows("normal" if kind == "clusters" else kind, n, dim, q0)
     Q = rng.standard_normal((nq, dim)).astype(np.float32)
+    if kind == "clusters":  # noisy copies of some queries, spreads from "inside every bound" to "inside level 2's only"
+        spread_hi = float(rng.choice([1e-6, 1e-3, 0.15]))
+        for j in rng.choice(nq, min(nq, 60), replace=False):
+            m = int(rng.choice([12, 60, 200]))
+            where = rng.choice(n, m, replace=False)
+            sp = np.linspace(spread_hi / 3, spread_hi, m, dtype=np.float32)[:, None]
+            rows[where] = Q[j] + sp * rng.standard_normal((m, dim)).astype(np.float32)
     if a.bits:  # 0/1 data with a random density (sparse rows: empty unions; dense rows: everything ties)
         dens = float(rng.choice([0.02, 0.3085, 0.5, 0.97]))
         rows = (rng.random((n, dim)) < dens).astype(np.float32)
@@ -150,6 +167,13 @@ while time.time() < t_end:
         assert np.all(gc == kk), tag
         assert np.array_equal(gi[:, :kk], eid), tag
         assert np.array_equal(bits(gs[:, :kk]), bits(esc)), tag
+        if a.select:  # again (a parked handle answers at the other level) and with a tail chunk that is no selection batch
+            lv, st2 = ix.last_select_level(), ix.last_split_stats()
+            stats.setdefault(f"level{lv}", 0)
+            stats[f"level{lv}"] += 1
+            stats["unproven"] = stats.get("unproven", 0) + st2[1]
+            gi2, gs2, _ = ix.search_batch_brute_force(Q, k)
+            assert np.array_equal(gi2, gi) and np.array_equal(bits(gs2), bits(gs)), tag + " (second call)"
         stats["f32"] += 1
     ix.close()
     if it % 20 == 0:
