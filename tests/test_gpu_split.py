@@ -164,3 +164,48 @@ def test_level2_parks_itself_at_level1_when_the_data_defeats_it(gpu_required):
     assert levels[1:] == [1, 1, 1], levels
     assert max(unproven[1:]) <= nq // 16, unproven
     ix.close()
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(70_000, 128, 256, 10), (90_000, 256, 480, 3), (66_000, 768, 256, 1)])
+def test_euclidean_batches_through_the_selection_stage(gpu_required, n, dim, nq, k):
+    """Euclidean batches select on the bf16 matrix cores over the augmented form s = q.v - |v|^2 / 2, re-score 64 candidates
+    with the canonical (q - v)^2 chain and prove the answer; unproven queries (here: duplicated rows = exact ties, a cluster of
+    near-copies) are listed and swept by the canonical vector-ALU kernel on the device.  Bar: the oracle's mode-C ids, ranks
+    and score bits, whatever the path."""
+    rng = np.random.default_rng(n + dim)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    rows[500] = rows[100]                              # an exact tie for whoever finds row 100
+    qs[0] = rows[100] + 0.01 * rng.standard_normal(dim).astype(np.float32)
+    where = rng.choice(n, 80, replace=False)           # 80 near-copies of query 1: closer together than the bound
+    rows[where] = qs[1] + 1e-4 * rng.standard_normal((80, dim)).astype(np.float32)
+    rows[rng.integers(0, n, 20)] *= 1.3                # a few longer rows (the max norm enters the bound)
+    ids_ext = np.arange(n, dtype=np.uint64) * np.uint64(7) + np.uint64(3)
+    ix = va.HnswIndex(dim, DM.Euclidean, va.HnswParams(8, 50, n))
+    ix.upload(ids_ext, rows)
+    va.set_split_selector(2)
+    ids, sc, cnt = ix.search_batch_brute_force(qs, k)
+    assert ix.last_select_level() == 2, "the selection stage did not run"
+    nq_last, unproven = ix.last_split_stats()
+    eid, esc = po.scan_topk(po.EUCLIDEAN, rows, qs, k, po.MODE_C, nthreads=NT)
+    assert np.all(cnt == k)
+    assert np.array_equal(ids, ids_ext[eid.astype(np.int64)]), "ids / ranks differ from the oracle (mode C)"
+    assert np.array_equal(bits(sc), bits(esc)), "score bits differ from the oracle (mode C)"
+    # (k = 1 over 66 K rows: the best and the 64th best are often closer than the bf16 bound — those queries take the gathered pass)
+    assert 1 <= unproven <= (nq // 8 if k > 1 else nq // 4), f"{unproven} of {nq_last} unproven"
+    va.set_split_selector(0)                           # the f32 matrix-core path: the same bits
+    ids0, sc0, _ = ix.search_batch_brute_force(qs, k)
+    va.set_split_selector(2)
+    assert np.array_equal(ids0, ids) and np.array_equal(bits(sc0), bits(sc))
+    # rows added later and soft deletes reach the augmented image
+    extra = (qs[5:45] * 1.01).astype(np.float32)
+    ix.upload(np.arange(40, dtype=np.uint64) + np.uint64(10_000_000), extra)
+    assert ix.remove(int(ids_ext[int(eid[9, 0])]))
+    rows2 = np.concatenate([rows, extra])
+    ids2 = np.concatenate([ids_ext, np.arange(40, dtype=np.uint64) + np.uint64(10_000_000)])
+    keep = np.ones(len(rows2), dtype=bool)
+    keep[int(eid[9, 0])] = False
+    ids3, sc3, _ = ix.search_batch_brute_force(qs, k)
+    eid3, esc3 = po.scan_topk(po.EUCLIDEAN, rows2[keep], qs, k, po.MODE_C, nthreads=NT)
+    assert np.array_equal(ids3, ids2[keep][eid3.astype(np.int64)]) and np.array_equal(bits(sc3), bits(esc3))
+    ix.close()

@@ -91,6 +91,8 @@ while time.time() < t_end:
         k = int(rng.choice([1, 3, 10]))
         kind = str(rng.choice(["normal", "normal", "dups", "small_ints", "ascending", "zeros_mixed", "clusters"]))
         va.set_split_selector(int(rng.choice([1, 2])))
+        if rng.random() < 0.3:
+            metric = DM.Euclidean
     q0 = rng.standard_normal(dim).astype(np.float32)
     rows = make_rows("normal" if kind == "clusters" else kind, n, dim, q0)
     Q = rng.standard_normal((nq, dim)).astype(np.float32)

@@ -494,6 +494,48 @@ static int select_level(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   return 2;
 }
 
+// Euclidean batches: augmented bf16 image + augmented f32 seed prefix (sweep_split.hip), built at first use, extended lazily
+static int32_t ensure_l2_select(vdb_hip_index* ix, hipStream_t st) {
+  const uint64_t cap = std::max<uint64_t>(ix->capacity, 1) + kRowSlack;
+  const uint32_t dim_a = ix->dim + 64, dim_s = ix->dim + 4;
+  hipError_t e;
+  if ((e = ix->l2_img.reserve(cap * (size_t)dim_a * 2, true, st)) != hipSuccess ||
+      (e = ix->l2_seed.reserve((size_t)kSplitSeedRows * dim_s * 4, true, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("Euclidean selection image: ") + hipGetErrorString(e));
+  if (ix->l2_rows < ix->n_rows) {
+    launch_l2_augment_rows(ix->rows.as<float>(), ix->row_stride, ix->norms.as<float>(), ix->l2_img.as<uint16_t>(), dim_a,
+                           ix->l2_seed.as<float>(), dim_s, kSplitSeedRows, (uint32_t)ix->l2_rows, (uint32_t)(ix->n_rows - ix->l2_rows),
+                           ix->dim, st);
+    ix->l2_rows = ix->n_rows;
+    VDB_HIP(hipGetLastError());
+  }
+  if (!ix->sel_stats) {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess) return fail(VDB_ERR_OOM, "pinned selection statistics");
+    memset(h, 0, 64);
+    ix->sel_stats = static_cast<volatile uint32_t*>(h);
+  }
+  return VDB_OK;
+}
+static int select_level_l2(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
+  if (!g_split_selector.load() || g_sweep_engine != 1 || g_max_tile < 128) return 0;
+  if (ix->metric != VDB_EUCLIDEAN) return 0;
+  if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
+  if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
+  const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
+  const uint32_t nqt_big = (nqg + 255) / 256;
+  if (!(nqg >= kGemmBigMinQueries && (uint64_t)nqg * 8 >= (uint64_t)nqt_big * 256 * 7)) return 0;
+  if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
+    ix->sel_seq_seen = ix->sel_stats[2];
+    if (ix->sel_stats[3] == 5u && (uint64_t)ix->sel_stats[0] * 16 > ix->sel_stats[1]) ix->l2_hold = 64;
+  }
+  if (ix->l2_hold) {
+    ix->l2_hold--;
+    return 0;
+  }
+  return 2;
+}
+
 // the SQ8 storage mode's batches (VDB_SEARCH_BRUTE_SQ8): the same eligibility on the shapes the bf16 selection kernel takes
 int select_level_sq8(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (!g_split_selector.load() || g_max_tile < 128) return 0;
@@ -517,11 +559,14 @@ int select_level_sq8(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
 int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, uint64_t* d_ids,
                         float* d_scores, uint32_t* d_n, hipStream_t st, int level) {
   const bool sq8 = level >= 3;
-  int32_t rc = sq8 ? ensure_sq8_select(ix, st) : (level >= 2 ? ensure_sel16(ix, st) : ensure_split(ix, st));
+  const bool l2 = ix->metric == VDB_EUCLIDEAN;  // (level 2) the augmented DotProduct form of |q - v|^2, sweep_split.hip
+  const int sel_metric = l2 ? VDB_DOT : ix->metric;
+  int32_t rc = l2 ? ensure_l2_select(ix, st) : (sq8 ? ensure_sq8_select(ix, st) : (level >= 2 ? ensure_sel16(ix, st) : ensure_split(ix, st)));
   if (rc != VDB_OK) return rc;
   ix->last_select_level = level;
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
   const uint32_t n = (uint32_t)ix->n_rows, dim = ix->dim, K2 = level >= 2 ? kSelect16Pool : kSplitPool;
+  const uint32_t dim_a = l2 ? dim + 64 : dim, dim_s = dim + 4;  // augmented image / f32 seed widths (Euclidean)
   const uint32_t ks = std::min<uint32_t>(kGemmBf16MaxK, k + 3);  // rows a selection block keeps per query (sweep_split.hip)
   // Launch schedule: exact seed sweep over [0, R0) (at 1/16 of the selection's rate: kept short), then selection launches
   // of GROWING size — G, 4 G, 16 G row tiles (G = row groups the chip holds at once: one tile per block first), then the
@@ -569,8 +614,8 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   hipError_t e;
   if ((e = ix->s_seed.reserve(off, false, st)) != hipSuccess ||
       (e = ix->s_part_keys.reserve((size_t)nqg * lists * ks * 8, false, st)) != hipSuccess ||
-      (!sq8 && (e = ix->s_fb_keys.reserve((size_t)nqg * fp.G * k * 8, false, st)) != hipSuccess) ||
-      (e = ix->s_misc.reserve(((size_t)nqg + 256) * dim * 4, false, st)) != hipSuccess)
+      (!sq8 && !l2 && (e = ix->s_fb_keys.reserve((size_t)nqg * fp.G * k * 8, false, st)) != hipSuccess) ||
+      (e = ix->s_misc.reserve(((size_t)nqg + 256) * (dim + 64) * 4 + (size_t)nqg * dim_s * 4, false, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, "split sweep scratch");
   unsigned char* sd = ix->s_seed.as<unsigned char>();
   uint64_t* pool = ix->s_part_keys.as<uint64_t>();
@@ -589,10 +634,22 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   EventPair* ev = next_events(ix);
   if (ev) (void)hipEventRecord(ev->a, st);
   // queries: split image / bf16 image (+ canonical norms), zero rows behind the batch (the kernel stages whole 256-query tiles)
-  const uint64_t img_stride = sq8 ? (uint64_t)dim : (level >= 2 ? ix->bf16_stride : (uint64_t)dim * 2);  // elements per image row
-  const uint16_t* img_rows = sq8 ? ix->sq8_img.as<uint16_t>() : (level >= 2 ? ix->rows_bf16.as<uint16_t>() : ix->rows_split.as<uint16_t>());
+  const uint64_t img_stride = l2 ? (uint64_t)dim_a : (sq8 ? (uint64_t)dim : (level >= 2 ? ix->bf16_stride : (uint64_t)dim * 2));  // elements per image row
+  const uint16_t* img_rows = l2 ? ix->l2_img.as<uint16_t>()
+                                : (sq8 ? ix->sq8_img.as<uint16_t>() : (level >= 2 ? ix->rows_bf16.as<uint16_t>() : ix->rows_split.as<uint16_t>()));
   const float* sel_norms = sq8 ? ix->sq8_nrm.as<float>() : ix->norms.as<float>();
-  if (level >= 2) {
+  float* qaug = reinterpret_cast<float*>(ix->s_misc.as<unsigned char>() + ((size_t)nqg + 256) * (dim + 64) * 4);  // Euclidean: (q, 1, 0, 0, 0) f32
+  if (l2) {
+    launch_l2_augment_queries(d_q, q_stride, q16, dim_a, qaug, dim_s, nqg, dim, st);
+    PrepArgs pq{};
+    pq.rows = d_q;
+    pq.norms = qnorms;
+    pq.row_stride = q_stride;
+    pq.n_rows = nqg;
+    pq.dim = dim;
+    pq.words = ix->words;
+    launch_prep_rows(pq, st);
+  } else if (level >= 2) {
     launch_round_queries_bf16(d_q, q_stride, q16, img_stride, nqg, dim, st);
     PrepArgs pq{};
     pq.rows = d_q;
@@ -609,22 +666,22 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   VDB_HIP(hipMemsetAsync(pool, 0xFF, (size_t)nqg * lists * ks * 8, st));
   VDB_HIP(hipMemsetAsync(blk_tau, 0xFF, (size_t)nqg * lists * 8, st));
   VDB_HIP(hipMemsetAsync(flags, 0, (size_t)nqg * 4 + 64 * 4 + 16, st));
-  if (!sq8) VDB_HIP(hipMemsetAsync(ix->s_fb_keys.p, 0xFF, (size_t)nqg * fp.G * k * 8, st));
-  if (ix->metric == VDB_DOT) launch_max_norm(sel_norms, n, norm_max, st);
+  if (!sq8 && !l2) VDB_HIP(hipMemsetAsync(ix->s_fb_keys.p, 0xFF, (size_t)nqg * fp.G * k * 8, st));
+  if (sel_metric == VDB_DOT) launch_max_norm(sel_norms, n, norm_max, st);
   // exact seed sweep over the first rows
   SweepArgs ag{};
-  ag.rows = sq8 ? ix->sq8_seed.as<float>() : ix->rows.as<float>();  // SQ8: the dequantised prefix (f32)
+  ag.rows = l2 ? ix->l2_seed.as<float>() : (sq8 ? ix->sq8_seed.as<float>() : ix->rows.as<float>());  // SQ8: the dequantised prefix (f32)
   ag.norms = sel_norms;
   ag.alive = alive;
-  ag.queries = d_q;
+  ag.queries = l2 ? qaug : d_q;
   ag.part_keys = reinterpret_cast<uint64_t*>(sd + o_seedp);
-  ag.row_stride = ix->row_stride;
-  ag.q_stride = q_stride;
+  ag.row_stride = l2 ? (uint64_t)dim_s : ix->row_stride;
+  ag.q_stride = l2 ? (uint64_t)dim_s : q_stride;
   ag.n_rows = R0;
-  ag.dim = dim;
+  ag.dim = l2 ? dim_s : dim;
   ag.nq = nqg;
   ag.k = k;
-  e = launch_sweep_gemm(ix->metric, sp, ag, st);
+  e = launch_sweep_gemm(sel_metric, sp, ag, st);
   if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split seed sweep launch: ") + hipGetErrorString(e));
   MergeArgs ms{};
   ms.part_keys = ag.part_keys;
@@ -635,12 +692,15 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   ms.n_lists = sp.G;
   ms.k = k;
   launch_merge(true, ms, nqg, st);
-  launch_split_seed(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim, level, st);
+  if (l2)
+    launch_l2_seed(m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim_a, st);
+  else
+    launch_split_seed(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim, level, st);
   // selection launches over the split images
   uint32_t list_off = 1;
   for (int j = 0; j < n_launch; j++) {
-    e = launch_sweep_gemm_bf16_glds(ix->metric, bp[j], img_rows, img_stride, sel_norms, alive, q16, img_stride, tau0, pool, lists, list_off, dim,
-                                    nqg, ks, st, /*split=*/level < 2, qnorms, blk_tau);
+    e = launch_sweep_gemm_bf16_glds(sel_metric, bp[j], img_rows, img_stride, sel_norms, alive, q16, img_stride, tau0, pool, lists, list_off,
+                                    l2 ? dim_a : dim, nqg, ks, st, /*split=*/level < 2, qnorms, blk_tau);
     if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split selection launch: ") + hipGetErrorString(e));
     list_off += bp[j].G;
     if (j + 1 < n_launch) {  // bound of the next launch: k-th best pool score so far
@@ -689,8 +749,43 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   ra.k2 = K2;
   ra.lists = lists;
   ra.fb_qper = fp.qper;
-  launch_split_rerank(ix->metric, ra, nqg, st);
-  if (sq8) {  // the reference chain for the unproven queries only, decided on the device
+  ra.norm_max_bits = norm_max;
+  if (l2) launch_l2_rerank(ra, nqg, st);
+  else launch_split_rerank(ix->metric, ra, nqg, st);
+  if (l2) {  // the canonical vector-ALU sweep for the unproven queries only, listed and gathered on the device
+    uint32_t* qmap = reinterpret_cast<uint32_t*>(sd + o_qmap);
+    uint32_t* qcount = qmap + nqg;
+    const uint32_t ngroups8 = (n + 7) / 8;
+    const int f_blocks = blocks_for(ix, 8, ngroups8);
+    if ((e = ix->s_part_cnt.reserve((size_t)nqg * f_blocks * k * 8, false, st)) != hipSuccess) return fail(VDB_ERR_OOM, "gathered fallback scratch");
+    launch_collect_flagged(flags, nqg, qmap, qcount, st);
+    SweepArgs af{};
+    af.rows = ix->rows.as<float>();
+    af.norms = ix->norms.as<float>();
+    af.alive = alive;
+    af.queries = d_q;
+    af.part_keys = ix->s_part_cnt.as<uint64_t>();
+    af.row_stride = ix->row_stride;
+    af.q_stride = q_stride;
+    af.n_rows = n;
+    af.dim = dim;
+    af.nq = 8;
+    af.k = k;
+    af.qmap = qmap;
+    af.qcount = qcount;
+    launch_sweep_f32(VDB_EUCLIDEAN, 8, af, f_blocks, st, (int)((nqg + 7) / 8));
+    MergeArgs mg{};
+    mg.part_keys = af.part_keys;
+    mg.ext_ids = ix->ext_ids.as<uint64_t>();
+    mg.out_ids = reinterpret_cast<uint64_t*>(sd + o_fid);
+    mg.out_scores = reinterpret_cast<float*>(sd + o_fsc);
+    mg.out_n = reinterpret_cast<uint32_t*>(sd + o_fn);
+    mg.n_lists = (uint32_t)f_blocks;
+    mg.k = k;
+    mg.active = qcount;
+    launch_merge(false, mg, nqg, st);
+    launch_scatter_flagged(qmap, qcount, 0, mg.out_ids, mg.out_scores, mg.out_n, d_ids, d_scores, d_n, nqg, k, st);
+  } else if (sq8) {  // the reference chain for the unproven queries only, decided on the device
     const int32_t rf = sq8_fallback_flagged(ix, d_q, q_stride, nqg, k, flags, d_ids, d_scores, d_n, st);
     if (rf != VDB_OK) return rf;
   } else {
@@ -765,7 +860,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   ix->split_flags_off = o_flags;
   ix->split_flags_n = nqg;
   ix->split_flags_stream = st;
-  if (ix->sel_stats) launch_select_stats(flags, nqg, ++ix->sel_seq, (uint32_t)level, ix->sel_stats, st);
+  if (ix->sel_stats) launch_select_stats(flags, nqg, ++ix->sel_seq, l2 ? 5u : (uint32_t)level, ix->sel_stats, st);
   if (ev) (void)hipEventRecord(ev->b, st);
   VDB_HIP(hipGetLastError());
   return VDB_OK;
@@ -850,6 +945,17 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
       const uint32_t nqg = std::min<uint32_t>(nq - q0, kGemmMaxQueries);
       const int32_t rcs = brute_split_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nqg, k, d_ids + (size_t)q0 * k,
                                           d_scores + (size_t)q0 * k, d_n + q0, st, sel_level);
+      if (rcs != VDB_OK) return rcs;
+      q0 += nqg;
+      continue;
+    }
+    // Euclidean batches, first choice: the selection stage of the Cosine / DotProduct batches over the augmented form
+    // s = q.v - |v|^2 / 2 (bf16 matrix pipe, canonical re-scoring, proof, unproven queries gathered on the device — no host
+    // synchronisation); the f32 matrix-core path below remains for the shapes it does not take and for handles it parks
+    if (ix->metric == VDB_EUCLIDEAN && q0 >= euclid_skip_until && select_level_l2(ix, nq - q0, k)) {
+      const uint32_t nqg = std::min<uint32_t>(nq - q0, kGemmMaxQueries);
+      const int32_t rcs = brute_split_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nqg, k, d_ids + (size_t)q0 * k,
+                                          d_scores + (size_t)q0 * k, d_n + q0, st, 2);
       if (rcs != VDB_OK) return rcs;
       q0 += nqg;
       continue;
@@ -1671,6 +1777,7 @@ int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
   ix->n_rows = 0;
   ix->bf16_rows = 0;
   ix->split_rows = 0;
+  ix->l2_rows = 0;
   const uint64_t cap = ix->capacity;
   ix->capacity = 0;  // re-reserve the per-row arrays (rows keep their buffer; the new layer arrays are allocated)
   int32_t rc = ensure_capacity(ix, std::max<uint64_t>(cap, 1));

@@ -43,6 +43,13 @@ __global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
   volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(smem + (size_t)B * k * 8);
   uint32_t* locks = reinterpret_cast<uint32_t*>(smem + (size_t)B * k * 8 + (size_t)B * 4);
   float* qgen = reinterpret_cast<float*>(smem + ((((size_t)B * k * 8 + (size_t)B * 8) + 15) & ~(size_t)15));  // generic path only
+  uint32_t nq_here = a.nq, slot0 = 0;
+  if (a.qmap) {  // gathered mode (SweepArgs): this block row's share of the listed queries
+    const uint32_t listed = *a.qcount;
+    slot0 = blockIdx.y * (uint32_t)B;
+    if ((a.qcount_max && listed > a.qcount_max) || slot0 >= listed) return;  // (uniform per block, before the first barrier)
+    nq_here = min((uint32_t)B, listed - slot0);
+  }
   if (threadIdx.x < B) {
     cnts[threadIdx.x] = 0;
     locks[threadIdx.x] = 0;
@@ -59,8 +66,9 @@ __global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
       float nacc = 0.0f;
 #pragma unroll
       for (int j = 0; j < CPL; j++) {
-        q[b][j] = (b < (int)a.nq) ? ld4(a.queries + (size_t)b * a.q_stride + (size_t)(j * 64 + lane) * 4)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        q[b][j] = (b < (int)nq_here) ? ld4(a.queries + (size_t)(a.qmap ? a.qmap[slot0 + b] : (uint32_t)b) * a.q_stride +
+                                           (size_t)(j * 64 + lane) * 4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
         nacc = chain4<kOpDot>(nacc, q[b][j], q[b][j]);
       }
       if (METRIC == kCosine) {
@@ -73,7 +81,7 @@ __global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
     const int qlen = d4 * 4;
     for (int i = threadIdx.x; i < B * qlen; i += 256) {
       int b = i / qlen, e = i % qlen;
-      qgen[i] = (b < (int)a.nq && e < (int)a.dim) ? a.queries[(size_t)b * a.q_stride + e] : 0.0f;
+      qgen[i] = (b < (int)nq_here && e < (int)a.dim) ? a.queries[(size_t)(a.qmap ? a.qmap[slot0 + b] : (uint32_t)b) * a.q_stride + e] : 0.0f;
     }
     __syncthreads();
     if (METRIC == kCosine) {
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
     // lane l now owns pair idx = l: row r = l / B, query b = l % B
     const int b = lane % B;
     const uint32_t row = row0 + lane / B;
-    const bool valid = row < a.n_rows && b < (int)a.nq;
+    const bool valid = row < a.n_rows && b < (int)nq_here;
     float vnorm = 1.0f;
     if (METRIC == kCosine && valid) vnorm = a.norms[row];
     const float score = finish_score<METRIC>(acc[0], qnorm_mine, vnorm);
@@ -160,9 +168,9 @@ __global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
   }
   // ---- one list per query per block goes to HBM, padded with invalid keys ----
   __syncthreads();
-  for (int b = wib; b < (int)a.nq && b < B; b += 4) {
+  for (int b = wib; b < (int)nq_here && b < B; b += 4) {
     const uint32_t c = cnts[b];
-    uint64_t* out = a.part_keys + ((size_t)b * gridDim.x + blockIdx.x) * k;
+    uint64_t* out = a.part_keys + ((size_t)(slot0 + b) * gridDim.x + blockIdx.x) * k;
     for (uint32_t e = lane; e < k; e += 64) out[e] = e < c ? lists[(size_t)b * k + e] : kKeyInvalid;
   }
 }
@@ -1512,26 +1520,26 @@ __global__ __launch_bounds__(256) void score_rows(ScoreArgs a) {
 
 // ---- host-callable launchers ------------------------------------------------------------
 template <int METRIC, int B, int CPL>
-static void launch_sweep_t(const SweepArgs& a, int blocks, size_t lds, hipStream_t st) {
-  hipLaunchKernelGGL((sweep_topk_f32<METRIC, B, CPL>), dim3(blocks), dim3(256), lds, st, a);
+static void launch_sweep_t(const SweepArgs& a, int blocks, size_t lds, hipStream_t st, int groups) {
+  hipLaunchKernelGGL((sweep_topk_f32<METRIC, B, CPL>), dim3(blocks, groups), dim3(256), lds, st, a);
 }
 template <int METRIC, int B>
-static void launch_sweep_cpl(const SweepArgs& a, int cpl, int blocks, size_t lds, hipStream_t st) {
+static void launch_sweep_cpl(const SweepArgs& a, int cpl, int blocks, size_t lds, hipStream_t st, int groups) {
   switch (cpl) {
-    case 1: launch_sweep_t<METRIC, B, 1>(a, blocks, lds, st); break;
-    case 2: launch_sweep_t<METRIC, B, 2>(a, blocks, lds, st); break;
-    case 3: launch_sweep_t<METRIC, B, 3>(a, blocks, lds, st); break;
-    case 4: launch_sweep_t<METRIC, B, 4>(a, blocks, lds, st); break;
-    default: launch_sweep_t<METRIC, B, 0>(a, blocks, lds, st); break;
+    case 1: launch_sweep_t<METRIC, B, 1>(a, blocks, lds, st, groups); break;
+    case 2: launch_sweep_t<METRIC, B, 2>(a, blocks, lds, st, groups); break;
+    case 3: launch_sweep_t<METRIC, B, 3>(a, blocks, lds, st, groups); break;
+    case 4: launch_sweep_t<METRIC, B, 4>(a, blocks, lds, st, groups); break;
+    default: launch_sweep_t<METRIC, B, 0>(a, blocks, lds, st, groups); break;
   }
 }
 template <int METRIC>
-static void launch_sweep_b(const SweepArgs& a, int B, int cpl, int blocks, size_t lds, hipStream_t st) {
+static void launch_sweep_b(const SweepArgs& a, int B, int cpl, int blocks, size_t lds, hipStream_t st, int groups) {
   switch (B) {
-    case 1: launch_sweep_cpl<METRIC, 1>(a, cpl, blocks, lds, st); break;
-    case 2: launch_sweep_cpl<METRIC, 2>(a, cpl, blocks, lds, st); break;
-    case 4: launch_sweep_cpl<METRIC, 4>(a, cpl, blocks, lds, st); break;
-    default: launch_sweep_cpl<METRIC, 8>(a, cpl, blocks, lds, st); break;
+    case 1: launch_sweep_cpl<METRIC, 1>(a, cpl, blocks, lds, st, groups); break;
+    case 2: launch_sweep_cpl<METRIC, 2>(a, cpl, blocks, lds, st, groups); break;
+    case 4: launch_sweep_cpl<METRIC, 4>(a, cpl, blocks, lds, st, groups); break;
+    default: launch_sweep_cpl<METRIC, 8>(a, cpl, blocks, lds, st, groups); break;
   }
 }
 
@@ -1547,13 +1555,13 @@ int sweep_cpl_for_dim(uint32_t dim) {
   return (c >= 1 && c <= 4) ? c : 0;
 }
 
-void launch_sweep_f32(int metric, int B, const SweepArgs& a, int blocks, hipStream_t st) {
+void launch_sweep_f32(int metric, int B, const SweepArgs& a, int blocks, hipStream_t st, int groups) {
   const int cpl = sweep_cpl_for_dim(a.dim);
   const size_t lds = sweep_lds_bytes(B, a.k, a.dim, cpl);
   switch (metric) {
-    case kCosine: launch_sweep_b<kCosine>(a, B, cpl, blocks, lds, st); break;
-    case kEuclidean: launch_sweep_b<kEuclidean>(a, B, cpl, blocks, lds, st); break;
-    default: launch_sweep_b<kDot>(a, B, cpl, blocks, lds, st); break;
+    case kCosine: launch_sweep_b<kCosine>(a, B, cpl, blocks, lds, st, groups); break;
+    case kEuclidean: launch_sweep_b<kEuclidean>(a, B, cpl, blocks, lds, st, groups); break;
+    default: launch_sweep_b<kDot>(a, B, cpl, blocks, lds, st, groups); break;
   }
 }
 

@@ -366,6 +366,190 @@ void launch_scatter_flagged(const uint32_t* qmap, const uint32_t* qcount, uint32
                      out_scores, out_n, k);
 }
 
+// ---- Euclidean batches through the same selection stage ----------------------------------------------------------------
+// |q - v|^2 = |q|^2 - 2 (q.v - |v|^2 / 2): the nearest rows are the rows with the largest s = q.v - h, h = |v|^2 / 2, and s is a
+// DOT PRODUCT of augmented vectors v' = (v, -h_hi, -h_lo, 0...), q' = (q, 1, 1, 0...) (h split into two bf16 so that the extra
+// term is exact to 2^-17 h).  The bf16 selection kernel (DotProduct instance) runs unchanged over the augmented images; the
+// thresholds come from the exact f32 matrix-core kernel (DotProduct) over an augmented f32 prefix; the candidates are re-scored
+// with the canonical (q - v)^2 lane chain of the small-batch kernels (l2_rerank_verify) and proven in the squared-distance
+// domain.  Error of a selection score: eps2 |q| max|v| for the q.v part (the bf16 roundings) + (2^-16 + acc) max h for the
+// augmentation and the f32 accumulation over it.
+__global__ __launch_bounds__(256) void l2_augment_rows_kernel(const float* rows, uint64_t row_stride, const float* norms, uint16_t* img,
+                                                              uint32_t dim_a, float* seed, uint32_t dim_s, uint32_t seed_rows,
+                                                              uint32_t row0, uint32_t n, uint32_t dim) {
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4;
+  for (uint32_t r = wave; r < n; r += nwaves) {
+    const uint32_t row = row0 + r;
+    const float* p = rows + (size_t)row * row_stride;
+    uint16_t* o = img + (size_t)row * dim_a;
+    for (uint32_t i = lane * 4; i < dim; i += 256) {  // dim % 64 == 0
+      const float4 x = ld4(p + i);
+      *reinterpret_cast<uint2*>(o + i) = make_uint2((uint32_t)bf16_rne(x.x) | ((uint32_t)bf16_rne(x.y) << 16),
+                                                    (uint32_t)bf16_rne(x.z) | ((uint32_t)bf16_rne(x.w) << 16));
+      if (row < seed_rows) *reinterpret_cast<float4*>(seed + (size_t)row * dim_s + i) = x;
+    }
+    const float nn = norms[row];
+    const float h = -0.5f * nn * nn;
+    const uint16_t hi = bf16_rne(h);
+    const uint16_t lo = bf16_rne(h - __uint_as_float((uint32_t)hi << 16));
+    if (lane < 64u && dim + lane < dim_a) o[dim + lane] = lane == 0 ? hi : (lane == 1 ? lo : (uint16_t)0);
+    if (row < seed_rows && lane < 4) seed[(size_t)row * dim_s + dim + lane] = lane == 0 ? h : 0.0f;
+  }
+}
+void launch_l2_augment_rows(const float* rows, uint64_t row_stride, const float* norms, uint16_t* img, uint32_t dim_a, float* seed,
+                            uint32_t dim_s, uint32_t seed_rows, uint32_t row0, uint32_t n, uint32_t dim, hipStream_t st) {
+  if (n == 0) return;
+  const int blocks = (int)std::min<uint64_t>(((uint64_t)n + 3) / 4, 4096);
+  hipLaunchKernelGGL(l2_augment_rows_kernel, dim3(blocks), dim3(256), 0, st, rows, row_stride, norms, img, dim_a, seed, dim_s, seed_rows,
+                     row0, n, dim);
+}
+__global__ __launch_bounds__(256) void l2_augment_queries_kernel(const float* q, uint64_t q_stride, uint16_t* img, uint32_t dim_a,
+                                                                 float* qaug, uint32_t dim_s, uint32_t nq, uint32_t dim) {
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= nq) return;
+  const float* p = q + (size_t)wave * q_stride;
+  uint16_t* o = img + (size_t)wave * dim_a;
+  for (uint32_t i = lane * 4; i < dim; i += 256) {
+    const float4 x = ld4(p + i);
+    *reinterpret_cast<uint2*>(o + i) = make_uint2((uint32_t)bf16_rne(x.x) | ((uint32_t)bf16_rne(x.y) << 16),
+                                                  (uint32_t)bf16_rne(x.z) | ((uint32_t)bf16_rne(x.w) << 16));
+    *reinterpret_cast<float4*>(qaug + (size_t)wave * dim_s + i) = x;
+  }
+  if (dim + lane < dim_a) o[dim + lane] = lane < 2 ? (uint16_t)0x3F80 : (uint16_t)0;  // bf16(1.0)
+  if (lane < 4) qaug[(size_t)wave * dim_s + dim + lane] = lane == 0 ? 1.0f : 0.0f;
+}
+void launch_l2_augment_queries(const float* q, uint64_t q_stride, uint16_t* img, uint32_t dim_a, float* qaug, uint32_t dim_s, uint32_t nq,
+                               uint32_t dim, hipStream_t st) {
+  hipLaunchKernelGGL(l2_augment_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, q, q_stride, img, dim_a, qaug, dim_s, nq, dim);
+}
+
+// seed from the exact DotProduct sweep of the augmented prefix (merged: rows + s values, best first): delta, starting bound,
+// pool slot 0, and the bound of what the seed's cut left out (its k-th s: those rows were excluded by a NEARLY exact value,
+// d_seed wide instead of delta)
+__global__ __launch_bounds__(256) void l2_seed_kernel(const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
+                                                      const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list,
+                                                      uint64_t* blk_tau, uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist,
+                                                      uint32_t dim_a) {
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  const float nmax = __uint_as_float(*norm_max_bits), hmax = 0.5f * nmax * nmax;
+  const float acc = 16.0f * (float)dim_a * 5.9604645e-8f;
+  const float eps_r = 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f + acc;                      // select_eps(dim_a, 2)
+  const float d = eps_r * 1.001f * qnorms[q] * nmax + (1.6e-5f + acc) * hmax + 1e-30f;  // bf16 roundings of q.v + the augmentation
+  const float d_seed = 4.0f * acc * (qnorms[q] * nmax + hmax) + 1e-30f;                 // f32 matrix-core s against the true s
+  delta[q] = d;
+  const uint32_t c = min(n[q], k);
+  uint64_t t = kKeyInvalid, bt = kKeyInvalid;
+  if (c >= k && k > 0) {
+    const float s = scores[(size_t)q * k + k - 1];
+    const float lowered = s - d * 1.01f - fabsf(s) * 1e-6f;
+    t = lowered == lowered ? make_key<true>(lowered, 0u) : kKeyInvalid;
+    const float b = s - d + d_seed;  // A + delta then reads s + d_seed
+    bt = b == b ? make_key<true>(b, 0u) : make_key<true>(__uint_as_float(0x7F800000u), 0u);
+  }
+  tau0[q] = t;
+  for (uint32_t e = 0; e < klist; e++)
+    list[(size_t)q * list_stride * klist + e] = e < c ? make_key<true>(scores[(size_t)q * k + e], (uint32_t)ids[(size_t)q * k + e]) : kKeyInvalid;
+  blk_tau[(size_t)q * list_stride] = bt;
+}
+void launch_l2_seed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms, const uint32_t* norm_max_bits,
+                    uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau, uint32_t list_stride, uint32_t nq, uint32_t k,
+                    uint32_t klist, uint32_t dim_a, hipStream_t st) {
+  hipLaunchKernelGGL(l2_seed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits, tau0, delta, list,
+                     blk_tau, list_stride, nq, k, klist, dim_a);
+}
+
+// One block per query (the Euclidean sibling of split_rerank_verify): every candidate is re-scored with the canonical
+// (q - v)^2 lane chain + butterfly + sqrt (the arithmetic of the small-batch kernels: euclid_rerank_verify, sweep.hip), ranked by
+// (distance, row), and the answer is proven: a row outside the pool has a selection score s <= A, a true s <= A + delta, a true
+// squared distance >= |q|^2 - 2 (A + delta); if that is above the k-th best canonical squared sum (plus the canonical chain's own
+// distance from the truth), nothing outside belongs to the top k.
+__global__ __launch_bounds__(256) void l2_rerank_verify(SplitRerankArgs a) {
+  __shared__ uint64_t keys[64];
+  __shared__ float sums[64];
+  __shared__ unsigned long long bmin;
+  const int lane = lane_id();
+  const int wib = (int)(threadIdx.x >> 6);
+  const uint32_t qi = blockIdx.x;
+  const uint32_t n = min(a.cand_n[qi], a.k2);  // k2 <= 64
+  const float* q = a.queries + (size_t)qi * a.q_stride;
+  const int d4 = (int)((a.dim + 3) / 4);
+  if (threadIdx.x == 0) bmin = ~0ull;
+  __syncthreads();
+  {
+    unsigned long long m = ~0ull;
+    for (uint32_t g = threadIdx.x; g < a.lists; g += 256) m = min(m, (unsigned long long)a.blk_tau[(size_t)qi * a.lists + g]);
+    if (m != ~0ull) atomicMin(&bmin, m);
+  }
+  for (uint32_t c = wib; c < n; c += 4) {
+    const uint32_t row = (uint32_t)a.cand_rows[(size_t)qi * a.k2 + c];
+    const float* p = a.rows + (size_t)row * a.row_stride;
+    float acc = 0.0f;
+    for (int ch = lane; ch < d4; ch += 64) {
+      const int nv = (int)a.dim - ch * 4;
+      const float4 x = ld4(p + ch * 4);
+      float4 qq;
+      if (nv >= 4) {
+        qq = make_float4(q[ch * 4], q[ch * 4 + 1], q[ch * 4 + 2], q[ch * 4 + 3]);
+        acc = chain4<kOpL2>(acc, qq, x);
+      } else {
+        qq = make_float4(q[ch * 4], nv > 1 ? q[ch * 4 + 1] : 0.f, nv > 2 ? q[ch * 4 + 2] : 0.f, 0.f);
+        acc = chain4_tail<kOpL2>(acc, qq, x, nv);
+      }
+    }
+    const float sum = butterfly_all(acc);
+    if (lane == 0) {
+      sums[c] = sum;
+      keys[c] = make_key<false>(finish_score<kEuclidean>(sum, 0.f, 0.f), row);
+    }
+  }
+  __syncthreads();
+  if (wib != 0) return;
+  const uint64_t key = (uint32_t)lane < n ? keys[lane] : kKeyInvalid;
+  uint32_t rank = 0;
+  for (uint32_t j = 0; j < n; j++) rank += keys[j] < key ? 1u : 0u;
+  uint32_t mine = 0;
+  for (uint32_t j = 0; j < n; j++) {
+    const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)rank, (int)j);
+    if (rj == (uint32_t)lane) mine = j;
+  }
+  const uint32_t kk = min(a.k, n);
+  bool ok = n >= a.k && a.k > 0;
+  if (ok) {
+    const float neg_inf = __uint_as_float(0xFF800000u);
+    const float a_blocks = bmin == ~0ull ? neg_inf : key_score<true>((uint64_t)bmin);
+    const float a_cut = n == a.k2 ? a.cand_scores[(size_t)qi * a.k2 + a.k2 - 1] : neg_inf;
+    const bool anan = a_blocks != a_blocks || a_cut != a_cut;
+    const double A = (double)fmaxf(a_blocks, a_cut);
+    const double qn = (double)a.qnorms[qi], nmax = (double)__uint_as_float(*a.norm_max_bits);
+    const double Ek = (double)sums[__builtin_amdgcn_readlane((int)mine, (int)(a.k - 1))];
+    // the canonical chain and |q|^2 against the truth: 8 n eps (|q|^2 + max|v|^2), as in euclid_rerank_verify
+    const double slack = 8.0 * (double)a.dim * 5.9604645e-8 * (qn * qn + nmax * nmax) + 1e-6 * Ek;
+    ok = !anan && (Ek + slack) < qn * qn - 2.0 * (A + (double)a.delta[qi]);  // false for NaN anywhere
+  }
+  if (lane == 0) {
+    a.flags[qi] = ok ? 0u : 1u;
+    a.out_n[qi] = kk;
+  }
+  for (uint32_t e = lane; e < a.k; e += 64) {
+    if (e < kk) {
+      const uint64_t ke = keys[mine];
+      const uint32_t row = key_row(ke);
+      a.out_ids[(size_t)qi * a.k + e] = a.ext_ids ? a.ext_ids[row] : (uint64_t)row;
+      a.out_scores[(size_t)qi * a.k + e] = key_score<false>(ke);
+    } else {
+      a.out_ids[(size_t)qi * a.k + e] = ~0ull;
+      a.out_scores[(size_t)qi * a.k + e] = __uint_as_float(0x7FC00000u);
+    }
+  }
+}
+void launch_l2_rerank(const SplitRerankArgs& a, uint32_t nq, hipStream_t st) {
+  hipLaunchKernelGGL(l2_rerank_verify, dim3(nq), dim3(256), 0, st, a);
+}
+
 // flagged queries take the exact kernel's result
 __global__ __launch_bounds__(256) void select_fallback_kernel(const uint32_t* flags, const uint64_t* fb_ids, const float* fb_scores,
                                                               const uint32_t* fb_n, uint64_t* out_ids, float* out_scores,

@@ -121,6 +121,10 @@ struct vdb_hip_index {
   volatile uint32_t* sel_stats = nullptr;
   uint32_t sel_seq = 0, sel_seq_seen = 0, sel16_hold = 0;
   int last_select_level = 0;
+  // Euclidean batches through the selection stage: augmented bf16 image [capacity][dim + 64], augmented f32 seed prefix
+  vdb::DevBuf l2_img, l2_seed;
+  uint64_t l2_rows = 0;     // rows converted so far
+  uint32_t l2_hold = 0;     // batches to answer on the f32 matrix-core path after a batch the selection could not prove
   uint64_t split_rows = 0;   // rows converted so far
   size_t split_flags_off = 0;     // where the last split batch left its per-query verdicts in s_seed
   uint32_t split_flags_n = 0;

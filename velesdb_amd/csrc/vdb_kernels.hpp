@@ -131,7 +131,7 @@ hipError_t launch_hnsw_search(const HnswSearchArgs& a, int slots, hipStream_t st
 
 size_t sweep_lds_bytes(int B, uint32_t k, uint32_t dim, int cpl);
 int sweep_cpl_for_dim(uint32_t dim);
-void launch_sweep_f32(int metric, int B, const SweepArgs& a, int blocks, hipStream_t st);
+void launch_sweep_f32(int metric, int B, const SweepArgs& a, int blocks, hipStream_t st, int groups = 1);
 // large query tiles (B = 16 / 32) with the queries in LDS; dim % 256 == 0 and dim <= 1024 only
 constexpr int kQldsWaves16 = 4;   // waves per block for B = 16 (3 blocks per CU)
 constexpr int kQldsWaves32 = 16;  // waves per block for B = 32
@@ -220,6 +220,7 @@ struct SplitRerankArgs {
   uint32_t dim, dim_pad, k, k2, lists, fb_qper;
   // SQ8 storage mode (storage_modes.hip): candidates are re-scored with the reference's asymmetric distances over the
   // codes (dot_product_quantized_simd / cosine_similarity_quantized_simd, core/quantization.rs:410-554) instead of `rows`
+  const uint32_t* norm_max_bits; // Euclidean instance (l2_rerank_verify): max row norm (launch_max_norm)
   const uint8_t* sq8_codes;     // nullptr = f32 rows
   const float* sq8_min;
   const float* sq8_max;
@@ -236,6 +237,15 @@ void launch_select_stats(const uint32_t* flags, uint32_t nq, uint32_t seq, uint3
 void launch_split_reseed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* delta, uint64_t* tau0,
                          uint32_t nq, uint32_t k, uint32_t kout, hipStream_t st);
 void launch_split_rerank(int metric, const SplitRerankArgs& a, uint32_t nq, hipStream_t st);
+// Euclidean batches through the selection stage (sweep_split.hip): augmented images, seed, re-scoring + proof
+void launch_l2_augment_rows(const float* rows, uint64_t row_stride, const float* norms, uint16_t* img, uint32_t dim_a, float* seed,
+                            uint32_t dim_s, uint32_t seed_rows, uint32_t row0, uint32_t n, uint32_t dim, hipStream_t st);
+void launch_l2_augment_queries(const float* q, uint64_t q_stride, uint16_t* img, uint32_t dim_a, float* qaug, uint32_t dim_s, uint32_t nq,
+                               uint32_t dim, hipStream_t st);
+void launch_l2_seed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms, const uint32_t* norm_max_bits,
+                    uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau, uint32_t list_stride, uint32_t nq, uint32_t k,
+                    uint32_t klist, uint32_t dim_a, hipStream_t st);
+void launch_l2_rerank(const SplitRerankArgs& a, uint32_t nq, hipStream_t st);
 // the flagged queries of a batch in ascending order: qmap[0 .. *qcount) (one block; nq <= 1024 per round)
 void launch_collect_flagged(const uint32_t* flags, uint32_t nq, uint32_t* qmap, uint32_t* qcount, hipStream_t st);
 // listed query j takes slot j of a gathered exact pass; nothing happens when more than `max_listed` are listed (0 = no limit)
