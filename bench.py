@@ -1003,8 +1003,9 @@ def main():
             row["single_query"]["hbm_gbs"] = round(pass_bytes / (sk * 1e-3) / 1e9, 1) if sk > 0 else 0.0
             row["single_query"]["hbm_frac"] = round(pass_bytes / (sk * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sk > 0 else 0.0
             row["alg_bytes_per_pass"] = pass_bytes
-            row["note"] = {"euclidean": "batch: candidates on the matrix cores (|v|^2+|q|^2-2q.v), canonical re-scoring, per-query proof of exactness",
-                           "dot": "batch: GEMM-structured matrix-core kernel (as the headline)",
+            row["note"] = {"euclidean": "batch: selection on the bf16 matrix cores over s = q.v - |v|^2/2 (augmented DotProduct form), canonical "
+                                        "(q - v)^2 re-scoring of 64 candidates, per-query proof, gathered exact pass for unproven queries",
+                           "dot": "batch: the headline's selection stage (plain bf16 selection + exact re-scoring + proof)",
                            "hamming": "packed bits (x > 0.5), 96 B/row; batch: 32 queries per corpus pass, AND+popcount, lock-free top-k",
                            "jaccard": "packed bits (x > 0.5), 96 B/row; batch: 32 queries per corpus pass, AND+popcount, lock-free top-k"}[mname]
             if not a.no_cpu_baseline:
