@@ -264,6 +264,20 @@ int32_t vdb_hip_index_load_dir(const char* dir, int32_t device, vdb_hip_index** 
  * VDB_ERR_IO: missing / truncated files, an offset past the end of vectors.dat ("Offset out of bounds", :563-568). */
 int32_t vdb_hip_index_upload_vector_store(vdb_hip_index* idx, const char* dir, uint64_t* inserted);
 
+/* ---- tuning options ----
+ * Every option has a process-wide default (vdb_hip_set_* below) and a per-handle value: a handle follows the default until
+ * vdb_hip_index_set_option gives it its own (value < 0: follow the default again).  A multi-device handle passes the option to
+ * every shard.  Results never depend on an option. */
+enum vdb_option {
+  VDB_OPT_MAX_QUERY_TILE = 0,   /* vdb_hip_set_max_query_tile    */
+  VDB_OPT_SWEEP_ENGINE = 1,     /* vdb_hip_set_sweep_engine      */
+  VDB_OPT_SELECTOR_LEVEL = 2,   /* vdb_hip_set_split_selector    */
+  VDB_OPT_INT8_OVERSAMPLING = 3,/* vdb_hip_set_int8_oversampling */
+  VDB_OPT_KERNEL_TIMING = 4     /* vdb_hip_set_kernel_timing     */
+};
+int32_t vdb_hip_index_set_option(vdb_hip_index* idx, int32_t option, int64_t value);
+int32_t vdb_hip_index_get_option(vdb_hip_index* idx, int32_t option, int64_t* value); /* the effective value */
+
 /* ---- introspection used by tests and the bench ---- */
 /* neighbours of `node` on `layer`; returns count in *n, writes up to cap ids */
 int32_t vdb_hip_index_get_neighbors(vdb_hip_index* idx, uint32_t layer, uint64_t node, uint32_t* out,

@@ -205,3 +205,41 @@ def test_device_searches_on_two_streams_do_not_race(gpu_required):
         assert np.array_equal(bits(outs[j][1].cpu().numpy()), bits(ref[j][1]))
     assert np.array_equal(hid, ref[0][0][:4]) and np.array_equal(bits(hsc), bits(ref[0][1][:4]))
     ix.close()
+
+
+def test_per_handle_options_override_the_process_defaults(gpu_required):
+    # two handles over the same rows: one pinned to the vector-ALU engine and small tiles, one left on the defaults — the
+    # arithmetic mode each reports, and the oracle mode its results match, follow the HANDLE; flipping the process default
+    # moves only the handle that follows it
+    rng = np.random.default_rng(5)
+    n, dim, k = 5000, 128, 10
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    qs = rng.standard_normal((70, dim)).astype(np.float32)
+    a = va.HnswIndex(dim, DM.Cosine, va.HnswParams(8, 50, n))
+    b = va.HnswIndex(dim, DM.Cosine, va.HnswParams(8, 50, n))
+    for ix in (a, b):
+        ix.upload(np.arange(n), rows)
+    a.set_option(va.OPT_SWEEP_ENGINE, 0)
+    a.set_option(va.OPT_MAX_QUERY_TILE, 8)
+    assert a.get_option(va.OPT_SWEEP_ENGINE) == 0 and a.get_option(va.OPT_MAX_QUERY_TILE) == 8
+    assert b.get_option(va.OPT_SWEEP_ENGINE) == 1 and b.get_option(va.OPT_MAX_QUERY_TILE) == 128
+    assert a.sweep_arith_mode(k) == "C" and b.sweep_arith_mode(k) == "M"
+    for ix, mode in ((a, po.MODE_C), (b, po.MODE_M)):
+        ids, sc, _ = ix.search_batch_brute_force(qs, k)
+        eid, esc = po.scan_topk(po.COSINE, rows, qs, k, mode)
+        assert np.array_equal(ids, eid) and np.array_equal(bits(sc), bits(esc))
+    va.set_sweep_engine(0)  # the process default: b follows, a keeps its own value either way
+    try:
+        assert b.sweep_arith_mode(k) == "C" and a.sweep_arith_mode(k) == "C"
+        a.set_option(va.OPT_SWEEP_ENGINE, 1)
+        assert a.sweep_arith_mode(k) == "M" and b.sweep_arith_mode(k) == "C"
+    finally:
+        va.set_sweep_engine(1)
+    a.set_option(va.OPT_SWEEP_ENGINE, -1)  # back to the default
+    assert a.get_option(va.OPT_SWEEP_ENGINE) == 1
+    with pytest.raises(va.VelesHipError):
+        a.set_option(va.OPT_MAX_QUERY_TILE, 7)
+    with pytest.raises(va.VelesHipError):
+        a.set_option(99, 1)
+    a.close()
+    b.close()

@@ -600,6 +600,22 @@ impl HipHnswIndex {
         ));
     }
 
+    /// Per-handle tuning option (`sys::VDB_OPT_*`); a negative value returns the handle to the process-wide default.
+    /// Results never depend on an option.
+    pub fn set_option(&self, option: i32, value: i64) {
+        // SAFETY: live handle.
+        check(unsafe { sys::vdb_hip_index_set_option(self.h, option, value) });
+    }
+
+    /// The effective value of a tuning option.
+    #[must_use]
+    pub fn option(&self, option: i32) -> i64 {
+        let mut v: i64 = 0;
+        // SAFETY: live handle, valid out pointer.
+        check(unsafe { sys::vdb_hip_index_get_option(self.h, option, &mut v) });
+        v
+    }
+
     /// The raw handle, for the entry points this wrapper does not cover (`sys::*`).
     #[must_use]
     pub fn as_raw(&self) -> *mut sys::VdbHipIndex {

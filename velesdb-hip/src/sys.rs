@@ -54,6 +54,13 @@ pub const VDB_KIND_SQUARED: i32 = 2;
 pub const VDB_SHARD_REPLICA: i32 = 0;
 pub const VDB_SHARD_RANGE: i32 = 1;
 
+// enum vdb_option
+pub const VDB_OPT_MAX_QUERY_TILE: i32 = 0;
+pub const VDB_OPT_SWEEP_ENGINE: i32 = 1;
+pub const VDB_OPT_SELECTOR_LEVEL: i32 = 2;
+pub const VDB_OPT_INT8_OVERSAMPLING: i32 = 3;
+pub const VDB_OPT_KERNEL_TIMING: i32 = 4;
+
 pub const VDB_COMM_ID_BYTES: usize = 128;
 
 extern "C" {
@@ -98,6 +105,8 @@ extern "C" {
     pub fn vdb_hip_index_save_dir(idx: *mut VdbHipIndex, dir: *const c_char) -> i32;
     pub fn vdb_hip_index_load_dir(dir: *const c_char, device: i32, out: *mut *mut VdbHipIndex) -> i32;
     pub fn vdb_hip_index_upload_vector_store(idx: *mut VdbHipIndex, dir: *const c_char, inserted: *mut u64) -> i32;
+    pub fn vdb_hip_index_set_option(idx: *mut VdbHipIndex, option: i32, value: i64) -> i32;
+    pub fn vdb_hip_index_get_option(idx: *mut VdbHipIndex, option: i32, value: *mut i64) -> i32;
     pub fn vdb_hip_index_get_neighbors(idx: *mut VdbHipIndex, layer: u32, node: u64, out: *mut u32, cap: u32, n: *mut u32) -> i32;
     pub fn vdb_hip_index_graph_info(idx: *mut VdbHipIndex, num_layers: *mut u32, max_layer: *mut u32, entry_point: *mut i64) -> i32;
     pub fn vdb_hip_index_last_search_stats(idx: *mut VdbHipIndex, n_dist: *mut u64, n_expand: *mut u64) -> i32;

@@ -6,7 +6,8 @@ VectorIndex / HnswIndex / DistanceEngine / GpuAccelerator interfaces over that A
 """
 from ._ffi import LIB_PATH, VelesHipError, lib  # noqa: F401
 from .index import (GpuAccelerator, HipDistance, HnswIndex, MODE_AUTO, MODE_BRUTE, MODE_BRUTE_BF16, MODE_HNSW, MODE_HNSW_INT8,  # noqa: F401
-                    MODE_BRUTE_SQ8, MODE_BRUTE_BINARY, SHARD_RANGE, SHARD_REPLICA, comm_unique_id,
+                    MODE_BRUTE_SQ8, MODE_BRUTE_BINARY, OPT_INT8_OVERSAMPLING, OPT_KERNEL_TIMING, OPT_MAX_QUERY_TILE,
+                    OPT_SELECTOR_LEVEL, OPT_SWEEP_ENGINE, SHARD_RANGE, SHARD_REPLICA, comm_unique_id,
                     device_count, device_name, set_kernel_timing, set_max_query_tile, set_split_selector, set_sweep_engine)
 from .params import DistanceMetric, HnswParams, SearchQuality, StorageMode  # noqa: F401
 

@@ -22,6 +22,14 @@ static std::atomic<int> g_split_selector{2};  // large exact Cosine / Dot batche
                                               // 2 plain bf16 selection first (same proof, wider bound), level 1 when a handle's data defeats it
 static std::atomic<uint32_t> g_int8_oversampling{4};  // DualPrecisionConfig::default().oversampling_ratio (dual_precision.rs:57)
 
+// effective option values of a handle: its own (vdb_hip_index_set_option) or the process-wide default
+static inline uint32_t opt_max_tile(const vdb_hip_index* ix) { return ix->opt[VDB_OPT_MAX_QUERY_TILE] >= 0 ? (uint32_t)ix->opt[VDB_OPT_MAX_QUERY_TILE] : (uint32_t)g_max_tile.load(); }
+static inline int opt_engine(const vdb_hip_index* ix) { return ix->opt[VDB_OPT_SWEEP_ENGINE] >= 0 ? ix->opt[VDB_OPT_SWEEP_ENGINE] : g_sweep_engine.load(); }
+static inline int opt_selector(const vdb_hip_index* ix) { return ix->opt[VDB_OPT_SELECTOR_LEVEL] >= 0 ? ix->opt[VDB_OPT_SELECTOR_LEVEL] : g_split_selector.load(); }
+static inline uint32_t opt_oversampling(const vdb_hip_index* ix) { return ix->opt[VDB_OPT_INT8_OVERSAMPLING] >= 0 ? (uint32_t)ix->opt[VDB_OPT_INT8_OVERSAMPLING] : (uint32_t)g_int8_oversampling.load(); }
+static inline bool opt_timing(const vdb_hip_index* ix) { return (ix->opt[VDB_OPT_KERNEL_TIMING] >= 0 ? ix->opt[VDB_OPT_KERNEL_TIMING] : g_timing.load()) != 0; }
+
+
 void set_last_error(const std::string& s) { g_last_error = s; }
 int32_t fail(int32_t code, const std::string& msg) {
   g_last_error = msg;
@@ -180,7 +188,7 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
     // large batches over a large corpus: the 256 x 256 LDS-DMA kernel (sweep_gemm_bf16.hip).  Its thresholds are seeded:
     // the 128 x 128 kernel first sweeps the first kGemmBf16SeedRows rows, the k-th best key found there (+ 1) is every
     // block's starting bound — without it the first row tile of every block floods the 12-key candidate buffers.
-    if (g_max_tile >= 128 && rem >= kGemmBigMinQueries && k <= kGemmBf16MaxK && ix->dim % 64 == 0 && ix->dim >= 128 &&
+    if (opt_max_tile(ix) >= 128 && rem >= kGemmBigMinQueries && k <= kGemmBf16MaxK && ix->dim % 64 == 0 && ix->dim >= 128 &&
         ix->n_rows >= kGemmBf16MinRows && ix->n_rows < 0xFFFFFF00ull && gemm_bf16_glds_enabled()) {
       const uint32_t nqg = std::min<uint32_t>(rem, kGemmMaxQueries);
       const uint32_t nqt_big = (nqg + 255) / 256;
@@ -262,7 +270,7 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
     }
     // large batches: the GEMM-structured kernel over the bf16 rows (sweep_gemm.hip, BF16 variant): the corpus is read
     // once per <= 128 queries instead of once per 96, both operands through LDS, lock-free top-k epilogue
-    if (g_max_tile >= 128 && rem >= kGemmMinQueries && k <= kGemmMaxK && ix->dim % 64 == 0) {
+    if (opt_max_tile(ix) >= 128 && rem >= kGemmMinQueries && k <= kGemmMaxK && ix->dim % 64 == 0) {
       const uint32_t nqg = std::min<uint32_t>(rem, kGemmMaxQueries);
       GemmPlan gp;
       sweep_gemm_plan(nqg, (uint32_t)ix->n_rows, ix->n_cus, k, &gp, /*allow_big=*/true);
@@ -389,7 +397,7 @@ int32_t append_host_rows(vdb_hip_index* ix, const uint64_t* ids, const float* ve
 }
 
 EventPair* next_events(vdb_hip_index* ix) {
-  if (!g_timing) return nullptr;
+  if (!opt_timing(ix)) return nullptr;
   if (ix->ev_used == ix->ev_pool.size()) {
     if (ix->ev_pool.size() >= 8192) return nullptr;
     EventPair p;
@@ -399,9 +407,9 @@ EventPair* next_events(vdb_hip_index* ix) {
   return &ix->ev_pool[ix->ev_used++];
 }
 
-static uint32_t pick_B(uint32_t nq) {
+static uint32_t pick_B(const vdb_hip_index* ix, uint32_t nq) {
   uint32_t b = nq >= 8 ? 8 : (nq >= 4 ? 4 : (nq >= 2 ? 2 : 1));
-  return std::min(b, std::min<uint32_t>(g_max_tile.load(), 8));
+  return std::min(b, std::min<uint32_t>(opt_max_tile(ix), 8));
 }
 static int blocks_for(const vdb_hip_index* ix, int B, uint32_t ngroups) {
   const int occ = (B == 1) ? 4 : (B == 8 ? 2 : 3);  // resident 256-thread blocks per CU (VGPR-limited)
@@ -473,8 +481,8 @@ static int32_t ensure_sel16(vdb_hip_index* ix, hipStream_t st) {
 
 // 0: no selection stage (exact kernel); 1: split-bf16 selection; 2: plain bf16 selection
 static int select_level(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
-  const int want = g_split_selector.load();
-  if (!want || g_sweep_engine != 1 || g_max_tile < 128) return 0;
+  const int want = opt_selector(ix);
+  if (!want || opt_engine(ix) != 1 || opt_max_tile(ix) < 128) return 0;
   if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT) return 0;
   if (ix->dim % 32 != 0 || ix->dim < 64 || ix->row_stride != ix->dim) return 0;
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
@@ -518,7 +526,7 @@ static int32_t ensure_l2_select(vdb_hip_index* ix, hipStream_t st) {
   return VDB_OK;
 }
 static int select_level_l2(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
-  if (!g_split_selector.load() || g_sweep_engine != 1 || g_max_tile < 128) return 0;
+  if (!opt_selector(ix) || opt_engine(ix) != 1 || opt_max_tile(ix) < 128) return 0;
   if (ix->metric != VDB_EUCLIDEAN) return 0;
   if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
@@ -538,7 +546,7 @@ static int select_level_l2(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
 
 // the SQ8 storage mode's batches (VDB_SEARCH_BRUTE_SQ8): the same eligibility on the shapes the bf16 selection kernel takes
 int select_level_sq8(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
-  if (!g_split_selector.load() || g_max_tile < 128) return 0;
+  if (!opt_selector(ix) || opt_max_tile(ix) < 128) return 0;
   if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT) return 0;  // Euclidean keeps the exact sweep
   if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
@@ -928,12 +936,12 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
   }
   uint32_t euclid_skip_until = 0;  // Euclidean chunk without proofs: [q0, this) goes through the exact tiles
   for (uint32_t q0 = 0; q0 < nq;) {
-    uint32_t B = pick_B(nq - q0);
+    uint32_t B = pick_B(ix, nq - q0);
     const int cpl = sweep_cpl_for_dim(ix->dim);
     // matrix-core engine (cosine / dot): one or two 16-query tiles per corpus pass
     int mfma_nqt = 0;
-    if (g_sweep_engine == 1 && (ix->metric == VDB_COSINE || ix->metric == VDB_DOT)) {
-      int want = (nq - q0 > 32 && g_max_tile >= 48) ? 3 : ((nq - q0 > 16 && g_max_tile >= 32) ? 2 : 1);
+    if (opt_engine(ix) == 1 && (ix->metric == VDB_COSINE || ix->metric == VDB_DOT)) {
+      int want = (nq - q0 > 32 && opt_max_tile(ix) >= 48) ? 3 : ((nq - q0 > 16 && opt_max_tile(ix) >= 32) ? 2 : 1);
       for (; want >= 1; want--)
         if (sweep_mfma_lds_bytes(want, k, ix->dim) <= 160 * 1024) break;
       mfma_nqt = want;  // 0: does not fit the LDS (very large dim or k): VALU kernels
@@ -962,7 +970,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     }
     // Euclidean batches: approximate selection of k + slack candidates on the matrix cores, canonical re-scoring, proof
     // of exactness per query; the (rare) unproven queries go through the exact vector-ALU sweep below
-    if (ix->metric == VDB_EUCLIDEAN && g_sweep_engine == 1 && g_max_tile >= 128 && nq - q0 >= kGemmMinQueries &&
+    if (ix->metric == VDB_EUCLIDEAN && opt_engine(ix) == 1 && opt_max_tile(ix) >= 128 && nq - q0 >= kGemmMinQueries &&
         k + kEuclidSlack <= kGemmMaxK && q0 >= euclid_skip_until) {
       const uint32_t nqg = std::min<uint32_t>(nq - q0, kGemmMaxQueries);
       // k <= 10: 16 candidates — the 32-entry candidate buffers then leave room for two blocks per CU; the per-query
@@ -1048,7 +1056,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
       }
     }
     // large batches: GEMM-structured matrix-core kernel, the whole batch in one launch (sweep_gemm.hip)
-    if (mfma_nqt && g_max_tile >= 128 && nq - q0 >= kGemmMinQueries && k <= kGemmMaxK) {
+    if (mfma_nqt && opt_max_tile(ix) >= 128 && nq - q0 >= kGemmMinQueries && k <= kGemmMaxK) {
       const uint32_t nqg = std::min<uint32_t>(nq - q0, kGemmMaxQueries);
       GemmPlan gp;
       sweep_gemm_plan(nqg, (uint32_t)ix->n_rows, ix->n_cus, k, &gp);
@@ -1129,7 +1137,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     }
     // large tiles: queries in LDS, 16 or 32 per corpus pass (dims that are a multiple of 256, <= 1024)
     bool qlds = false;
-    const uint32_t max_tile = g_max_tile;
+    const uint32_t max_tile = opt_max_tile(ix);
     if (cpl > 0 && nq - q0 >= 12 && max_tile >= 16) {
       const uint32_t want = (nq - q0 >= 24 && max_tile >= 32) ? 32 : 16;
       for (uint32_t b = want; b >= 16; b /= 2) {
@@ -1237,7 +1245,7 @@ int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint3
     return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
   if (mode == VDB_SEARCH_HNSW_INT8) {
     if (used_hnsw) *used_hnsw = true;
-    return hnsw_search_int8_dev(ix, d_q, q_stride, nq, k, ef == 0 ? balanced_ef(k) : ef, g_int8_oversampling, cap_mult,
+    return hnsw_search_int8_dev(ix, d_q, q_stride, nq, k, ef == 0 ? balanced_ef(k) : ef, opt_oversampling(ix), cap_mult,
                                 d_ids, d_scores, d_n, st);
   }
   if (mode != VDB_SEARCH_AUTO && mode != VDB_SEARCH_HNSW) return fail(VDB_ERR_INVALID_ARG, "bad search mode");
@@ -1423,6 +1431,54 @@ int32_t vdb_hip_index_last_select_level(vdb_hip_index* ix, int32_t* level) {
     VDB_NO_GROUP(ix, "last_select_level");
     std::lock_guard<std::mutex> g(ix->mu);
     *level = ix->last_select_level;
+    return VDB_OK;
+  });
+}
+
+int32_t vdb_hip_index_set_option(vdb_hip_index* ix, int32_t option, int64_t value) {
+  return vdb::guarded([&]() -> int32_t {
+    if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+    if (option < 0 || option > VDB_OPT_KERNEL_TIMING) return fail(VDB_ERR_INVALID_ARG, "unknown option");
+    if (ix->group) return group_set_option(ix, option, value);
+    std::lock_guard<std::mutex> g(ix->mu);
+    int32_t v = -1;  // negative: back to the process-wide default
+    if (value >= 0) {
+      switch (option) {
+        case VDB_OPT_MAX_QUERY_TILE:
+          if (!(value == 1 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 48 || value == 128))
+            return fail(VDB_ERR_INVALID_ARG, "query tile: 1, 2, 4, 8, 16, 32, 48 or 128");
+          v = (int32_t)value;
+          break;
+        case VDB_OPT_SWEEP_ENGINE:
+          if (value > 1) return fail(VDB_ERR_INVALID_ARG, "sweep engine: 0 or 1");
+          v = (int32_t)value;
+          break;
+        case VDB_OPT_SELECTOR_LEVEL: v = value >= 2 ? 2 : (int32_t)value; break;
+        case VDB_OPT_INT8_OVERSAMPLING:
+          if (value < 1 || value > 64) return fail(VDB_ERR_INVALID_ARG, "oversampling ratio: 1..64");
+          v = (int32_t)value;
+          break;
+        default: v = value ? 1 : 0; break;
+      }
+    }
+    ix->opt[option] = v;
+    return VDB_OK;
+  });
+}
+
+int32_t vdb_hip_index_get_option(vdb_hip_index* ix, int32_t option, int64_t* value) {
+  return vdb::guarded([&]() -> int32_t {
+    if (!ix || !value) return fail(VDB_ERR_INVALID_ARG, "null argument");
+    if (option < 0 || option > VDB_OPT_KERNEL_TIMING) return fail(VDB_ERR_INVALID_ARG, "unknown option");
+    vdb_hip_index* c = ix->group ? group_first_shard(ix) : ix;
+    std::lock_guard<std::mutex> g(c->mu);
+    switch (option) {
+      case VDB_OPT_MAX_QUERY_TILE: *value = opt_max_tile(c); break;
+      case VDB_OPT_SWEEP_ENGINE: *value = opt_engine(c); break;
+      case VDB_OPT_SELECTOR_LEVEL: *value = opt_selector(c); break;
+      case VDB_OPT_INT8_OVERSAMPLING: *value = opt_oversampling(c); break;
+      default: *value = opt_timing(c) ? 1 : 0; break;
+    }
     return VDB_OK;
   });
 }
@@ -1900,7 +1956,7 @@ int32_t vdb_hip_index_sweep_arith_mode(vdb_hip_index* ix, uint32_t k, int32_t* m
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !mode) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return vdb_hip_index_sweep_arith_mode(group_shard(ix, 0), k, mode);
-  const bool mfma = g_sweep_engine == 1 && (ix->metric == VDB_COSINE || ix->metric == VDB_DOT) &&
+  const bool mfma = opt_engine(ix) == 1 && (ix->metric == VDB_COSINE || ix->metric == VDB_DOT) &&
                     sweep_mfma_lds_bytes(1, k, ix->dim) <= 160 * 1024;
   *mode = mfma ? 1 : 0;
   return VDB_OK;

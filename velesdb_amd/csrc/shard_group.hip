@@ -404,6 +404,13 @@ int32_t group_for_all(vdb_hip_index* ix, int op, uint32_t arg) {
   });
 }
 
+int32_t group_set_option(vdb_hip_index* ix, int32_t option, int64_t value) {
+  ShardGroup* g = ix->group;
+  std::lock_guard<std::mutex> lk(ix->mu);
+  return for_each_shard(g, [&](size_t s) -> int32_t { return vdb_hip_index_set_option(g->shards[s], option, value); });
+}
+vdb_hip_index* group_first_shard(vdb_hip_index* ix) { return ix->group->shards[0]; }
+
 // ---- sharded search ---------------------------------------------------------------------------------
 static int32_t ensure_group_comms(ShardGroup* g) {
   if (!g->distinct || !g->comms.empty()) return VDB_OK;

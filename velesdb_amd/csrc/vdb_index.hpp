@@ -114,6 +114,8 @@ struct vdb_hip_index {
   // split-bf16 image of the f32 rows (hi + lo per element, 4 bytes like the f32 row: sweep_split.hip), built at the first
   // large exact Cosine / DotProduct batch and kept up to date from then on
   vdb::DevBuf rows_split;
+  // per-handle options (vdb_hip_index_set_option): -1 = follow the process-wide default (vdb_hip_set_*)
+  int32_t opt[5] = {-1, -1, -1, -1, -1};
   bool split_enabled = false;
   bool sel_norms = false;    // canonical f32 norms are kept for every row whatever the metric (selection levels 1 / 2)
   // level 2 (plain bf16 selection) adaptivity: the verdict counts of finished batches arrive in pinned host memory
@@ -206,7 +208,9 @@ int32_t group_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed);
 vdb_hip_index* group_shard(const vdb_hip_index* ix, size_t s);  // child s of a multi-device handle
 size_t group_size(const vdb_hip_index* ix);
 int group_mode(const vdb_hip_index* ix);
-int32_t group_for_all(vdb_hip_index* ix, int op, uint32_t arg);  // op: 0 build_graph, 1 enable_bf16, 2 storage mode, 3 quantizer
+int32_t group_for_all(vdb_hip_index* ix, int op, uint32_t arg);
+int32_t group_set_option(vdb_hip_index* ix, int32_t option, int64_t value);
+vdb_hip_index* group_first_shard(vdb_hip_index* ix);  // op: 0 build_graph, 1 enable_bf16, 2 storage mode, 3 quantizer
 int32_t group_search_host(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode,
                           uint32_t rerank_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n);
 int32_t group_search_dev(vdb_hip_index* ix, const float* d_q, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode,

@@ -21,6 +21,7 @@ from ._ffi import check, lib
 from .params import DistanceMetric, HnswParams, SearchQuality
 
 MODE_AUTO, MODE_BRUTE, MODE_HNSW, MODE_BRUTE_BF16, MODE_HNSW_INT8, MODE_BRUTE_SQ8, MODE_BRUTE_BINARY = 0, 1, 2, 3, 4, 5, 6
+OPT_MAX_QUERY_TILE, OPT_SWEEP_ENGINE, OPT_SELECTOR_LEVEL, OPT_INT8_OVERSAMPLING, OPT_KERNEL_TIMING = 0, 1, 2, 3, 4
 KIND_ENGINE, KIND_RAW = 0, 1
 SHARD_REPLICA, SHARD_RANGE = 0, 1
 COMM_ID_BYTES = 128
@@ -433,6 +434,15 @@ class HnswIndex:
         a, b = C.c_uint32(0), C.c_uint32(0)
         check(lib().vdb_hip_index_last_split_stats(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def set_option(self, option: int, value: int) -> None:
+        """Per-handle tuning option (OPT_*); value < 0 = follow the process-wide default again.  Results never depend on it."""
+        check(lib().vdb_hip_index_set_option(self._h, int(option), int(value)))
+
+    def get_option(self, option: int) -> int:
+        v = C.c_int64(0)
+        check(lib().vdb_hip_index_get_option(self._h, int(option), C.byref(v)))
+        return int(v.value)
 
     def last_select_level(self) -> int:
         """Selection level (0 / 1 / 2) the last exact batch of this handle ran at."""
