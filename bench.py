@@ -1126,6 +1126,18 @@ def main():
             ix_sh.close()
             torch.cuda.empty_cache()
 
+    device_state = None
+    if rank == 0:
+        # which box is this?  The HBM-bound traversal leg differs by up to 15 % between boxes of the pool and by < 1 % within one
+        # (profiles/r02ag_hnsw_spread.log): memory / fabric clock levels and the partition modes are recorded with the line
+        try:
+            import subprocess as sp_
+            out = sp_.run(["rocm-smi", "--showclocks", "--showmemorypartition", "--showcomputepartition", "--showpower"],
+                          capture_output=True, text=True, timeout=30).stdout
+            device_state = [ln.split(":", 1)[1].strip() if ln.startswith("GPU[0]") else ln.strip()
+                            for ln in out.splitlines() if ln.startswith("GPU[0]")]
+        except Exception as ex:  # noqa: BLE001
+            device_state = [f"rocm-smi unavailable: {ex}"]
     if rank == 0:
         line = {
             "metric": "qps_at_recall10_1Mx768_k10", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
@@ -1139,7 +1151,7 @@ def main():
             "recall_at_10": recall, "parity_check": check,
             "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "tiles": tiles, "sharded": sharded,
             "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb, "config0_10k": config0, "bf16_gemm": bf16_leg, "sq8_storage_mode": sq8_leg, "other_metrics": metrics_leg,
-            "device": va.device_name(local),
+            "device": va.device_name(local), "device_state": device_state,
         }
     if use_dist:
         dist.destroy_process_group()
