@@ -300,7 +300,8 @@ int32_t vdb_hip_set_max_query_tile(uint32_t b);
  * Both are exact f32 arithmetic; scores differ in the last bits because the summation order does.  The choice
  * never depends on the batch size. */
 int32_t vdb_hip_set_sweep_engine(int32_t engine);
-/* Large exact Cosine / DotProduct batches (>= 224 queries that fill 256-query tiles, k <= 10, >= 65 536 rows, dim % 32 == 0):
+/* Exact Cosine / DotProduct (and Euclidean, SQ8) batches of 80 .. 256 queries, or more that fill 256-query tiles to 7/8
+ * (k <= 10, >= 65 536 rows, dim % 32 == 0):
  * the matrix cores SELECT candidates on a reduced-precision image of rows and queries, the best candidates per query are
  * re-scored with the exact chain (oracle mode M), and every query's answer is PROVEN from an error bound or recomputed by
  * the exact kernel — same ids, ranks and score bits as the exact f32 matrix-core kernel for the whole batch.

@@ -479,6 +479,22 @@ static int32_t ensure_sel16(vdb_hip_index* ix, hipStream_t st) {
   return VDB_OK;
 }
 
+// does a chunk of nqg queries take the selection stage?  Whole 256-query tiles filled to >= 7/8 — or ONE partly filled tile
+// from kSelectMinQueries up: a single-tile launch spreads its row groups over the whole chip, and a half-empty tile on the
+// bf16 pipe still beats the f32 pipe's exact kernels (measured: see DESIGN 4.1b)
+static uint32_t select_min_queries() {
+  static const uint32_t v = [] {
+    const char* e = getenv("VELESDB_SELECT_MIN_QUERIES");
+    return e ? (uint32_t)atoi(e) : kSelectMinQueries;
+  }();
+  return v;
+}
+static bool select_shape_ok(uint32_t nqg) {
+  const uint32_t nqt_big = (nqg + 255) / 256;
+  if (nqt_big == 1) return nqg >= select_min_queries();
+  return nqg >= kGemmBigMinQueries && (uint64_t)nqg * 8 >= (uint64_t)nqt_big * 256 * 7;
+}
+
 // 0: no selection stage (exact kernel); 1: split-bf16 selection; 2: plain bf16 selection
 static int select_level(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   const int want = opt_selector(ix);
@@ -487,8 +503,7 @@ static int select_level(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (ix->dim % 32 != 0 || ix->dim < 64 || ix->row_stride != ix->dim) return 0;
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
   const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
-  const uint32_t nqt_big = (nqg + 255) / 256;
-  if (!(nqg >= kGemmBigMinQueries && (uint64_t)nqg * 8 >= (uint64_t)nqt_big * 256 * 7)) return 0;  // fills its 256-query tiles to >= 7/8
+  if (!select_shape_ok(nqg)) return 0;
   if (want < 2 || ix->dim % 64 != 0 || ix->dim < 128) return 1;
   // what did the finished level-2 batches of this handle look like?  (pinned host memory, written by select_stats_kernel)
   if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
@@ -531,8 +546,7 @@ static int select_level_l2(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
   const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
-  const uint32_t nqt_big = (nqg + 255) / 256;
-  if (!(nqg >= kGemmBigMinQueries && (uint64_t)nqg * 8 >= (uint64_t)nqt_big * 256 * 7)) return 0;
+  if (!select_shape_ok(nqg)) return 0;
   if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
     ix->sel_seq_seen = ix->sel_stats[2];
     if (ix->sel_stats[3] == 5u && (uint64_t)ix->sel_stats[0] * 16 > ix->sel_stats[1]) ix->l2_hold = 64;
@@ -551,8 +565,7 @@ int select_level_sq8(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
   const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
-  const uint32_t nqt_big = (nqg + 255) / 256;
-  if (!(nqg >= kGemmBigMinQueries && (uint64_t)nqg * 8 >= (uint64_t)nqt_big * 256 * 7)) return 0;
+  if (!select_shape_ok(nqg)) return 0;
   if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
     ix->sel_seq_seen = ix->sel_stats[2];
     if (ix->sel_stats[3] == 3u && (uint64_t)ix->sel_stats[0] * 16 > ix->sel_stats[1]) ix->sq8_hold = 64;
@@ -590,9 +603,9 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   {
     uint32_t lo = R0, left = tiles_all;
     const uint32_t steps[3] = {G2, 4 * G2, 16 * G2};
-    for (int j = 0; j < 3 && left > steps[j] + 32 * G2; j++) {  // (a short tail is not worth a launch of its own)
+    for (int j = 0; j < 3 && left >= 2 * steps[j]; j++) {  // (the rest must be worth at least as much again)
       uint32_t t = steps[j];
-      if (j == 2) t += (left - t) % G2;  // the last, long launch gets a whole number of row tiles per row group
+      if (j == 2 || left < 2 * steps[j + 1 < 3 ? j + 1 : 2]) t += (left - t) % G2;  // the launch behind this one is the last: whole row tiles per row group
       const uint32_t hi = lo + t * 256;
       sweep_gemm_bf16_plan(nqg, lo, hi, ix->n_cus, &bp[n_launch++]);
       lo = hi;

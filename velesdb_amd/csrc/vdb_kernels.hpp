@@ -154,6 +154,7 @@ struct GemmPlan {
 };
 constexpr uint64_t kRowSlack = 256;         // rows allocated past the capacity of the row arrays (whole-tile reads)
 constexpr uint32_t kGemmBigMinQueries = 224;
+constexpr uint32_t kSelectMinQueries = 80;     // selection stage: smallest single-tile batch (VELESDB_SELECT_MIN_QUERIES overrides)
 constexpr uint32_t kGemmMinQueries = 64;    // below this the streaming kernels (HBM-bound) are faster
 constexpr uint32_t kGemmMaxK = 48;          // candidate buffers hold <= 64 keys per query (one per lane when compacted)
 constexpr uint32_t kGemmMaxQueries = 1024;  // per launch (bounds the partial-list scratch)
