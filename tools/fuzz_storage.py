@@ -18,6 +18,7 @@ from oracle import pyoracle as po  # noqa: E402
 p = argparse.ArgumentParser()
 p.add_argument("--seconds", type=float, default=240)
 p.add_argument("--seed", type=int, default=1)
+p.add_argument("--select", action="store_true", help="SQ8 batches that take the selection stage (>= 80 queries, >= 65 536 rows, dim % 64 == 0, k <= 10)")
 a = p.parse_args()
 rng = np.random.default_rng(a.seed)
 DM, SM = va.DistanceMetric, va.StorageMode
@@ -55,6 +56,13 @@ while time.time() < t_end:
     nq = int(rng.choice([1, 2, 3, 4, 5, 9, 33, 70, 200]))
     k = int(rng.choice([1, 5, 10, 31, 64]))
     kind = str(rng.choice(["normal", "dups", "const", "zeros", "ints", "wide"]))
+    if a.select:
+        mode = "sq8"
+        metric = [DM.Cosine, DM.DotProduct][int(rng.integers(0, 2))]
+        n = int(rng.choice([66_000, 120_000]))
+        dim = int(rng.choice([128, 256, 768]))
+        nq = int(rng.choice([80, 150, 256, 480]))
+        k = int(rng.choice([1, 5, 10]))
     rows = make(kind, n, dim)
     Q = make(kind if kind != "dups" else "normal", nq, dim)
     ids = rng.permutation(n).astype(np.uint64) * 3 + 1
@@ -75,7 +83,10 @@ while time.time() < t_end:
     if mode == "sq8":
         pm = {DM.Cosine: po.COSINE, DM.Euclidean: po.EUCLIDEAN, DM.DotProduct: po.DOT}[metric]
         gi, gs, gc = ix.search_batch_sq8(Q, k)
-        ei, es = po.scan_topk_sq8(pm, rows[sel], Q, max(kk, 1), nthreads=8)
+        ei, es = po.scan_topk_sq8(pm, rows[sel], Q, max(kk, 1), nthreads=po.host_threads())
+        if a.select:
+            stats["selected"] = stats.get("selected", 0) + (1 if ix.last_select_level() == 3 else 0)
+            stats["unproven"] = stats.get("unproven", 0) + ix.last_split_stats()[1]
     else:
         gi, gs, gc = ix.search_batch_binary(Q, k)
         ei, es = po.scan_topk_binary(rows[sel], Q, max(kk, 1))
