@@ -24,6 +24,7 @@
 // Algorithmic HBM bytes per query: n_dist * dim * 4 + n_expand * M0 * 4, with n_dist / n_expand
 // counted by the kernel (stats), SURVEY.md §8(d).
 #include <algorithm>
+#include <cstdlib>
 
 #include "vdb_hnsw_device.hpp"
 #include "vdb_index.hpp"
@@ -51,9 +52,17 @@ enum Phase : int {
 // LDS: keys[cap] u64 | nb_id[nbmax] u32 | nb_d[nbmax] f32 | ctl[4] u32 | flags[cap] u8 (padded to 16)
 //      | query scratch: generic f32 dims: d4*4 floats; bit metrics: `words` u32
 // ------------------------------------------------------------------------------------------
-template <int METRIC, int CPL, int NS>
-__global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
+// LAT (latency mode: a handful of queries per call, f32 metrics, layer-0 lists of <= 64 neighbours): a 1 024-thread block per
+// query and a speculative layer-0 step.  A walk is a chain of dependent memory round trips — neighbour ids, visited
+// test-and-set, rows — and a single query cannot hide them behind other queries: here all (<= 64) neighbours' rows are fetched
+// at once by 16 waves (4 rows each) WITHOUT waiting for the visited test, which the leader wave issues alongside; the
+// verdicts select, in list order, which of the evaluated distances are admitted.  Same ids, scores and counters (n_dist counts
+// the unvisited neighbours, as the reference's loop evaluates them); the rows of visited neighbours are wasted bandwidth that a
+// single query has to spare.
+template <int METRIC, int CPL, int NS, bool LAT = false>
+__global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearchArgs a) {
   constexpr bool BITS = (METRIC == kHamming || METRIC == kJaccard);
+  constexpr int WAVES = LAT ? 16 : 4, TPB = WAVES * 64, RR = LAT ? 4 : 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id();
   const int wib = (int)rfl(threadIdx.x >> 6);
@@ -77,7 +86,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
     float4 q[CPL > 0 ? CPL : 1];
     float qnorm = 0.0f;
     if (BITS) {
-      for (uint32_t w = threadIdx.x; w < a.words; w += 256) {
+      for (uint32_t w = threadIdx.x; w < a.words; w += TPB) {
         uint32_t bitsw = 0;
         for (uint32_t e = 0; e < 32; e++) {
           const uint32_t i = w * 32 + e;
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
       if (METRIC == kCosine) qnorm = sqrtf(butterfly_all(nacc));
     } else {
       const int qlen = d4 * 4;
-      for (int i = threadIdx.x; i < qlen; i += 256) qgen[i] = i < (int)a.dim ? qp[i] : 0.0f;
+      for (int i = threadIdx.x; i < qlen; i += TPB) qgen[i] = i < (int)a.dim ? qp[i] : 0.0f;
       __syncthreads();
       if (METRIC == kCosine) {
         float nacc = 0.0f;
@@ -113,6 +122,8 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
     CandList<NS> list;
     list.init(keys, flags, cap);
     uint32_t n_dist = 0, n_expand = 0, logn = 0, overflow = 0, m_prev = 0, rr_m = 0;
+    bool spec = false;        // LAT: the distance phase in flight evaluates ALL neighbours of the expanded node ...
+    uint64_t spec_mask = 0;   // ... and these lanes' neighbours were unvisited (known behind that phase)
     int phase = P_START;
     int layer = (int)a.max_layer;
     uint32_t cur = a.entry_point;
@@ -210,24 +221,30 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
                 if ((uint32_t)lane < lim) nb0 = L.nbr[(size_t)cnode * L.stride + lane];
                 uint32_t nc = rfl(L.cnt[cnode]);
                 nc = min(nc, lim);
+                if (LAT) {  // (nc <= 64, host) every neighbour is evaluated; the visited verdicts follow with the distances
+                  if ((uint32_t)lane < nc) nb_id[lane] = nb0;
+                  m = nc;
+                  spec = nc != 0;
+                } else {
                 for (uint32_t base = 0; base < nc; base += 64) {
-                  const uint32_t t = base + lane;
-                  const bool valid = t < nc;
-                  uint32_t nb = nb0;
-                  bool newly = false;
-                  if (valid) {
-                    if (base != 0) nb = L.nbr[(size_t)cnode * L.stride + t];
-                    const uint32_t bit = 1u << (nb & 31);
-                    newly = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;  // visited.insert (graph.rs:499)
+                    const uint32_t t = base + lane;
+                    const bool valid = t < nc;
+                    uint32_t nb = nb0;
+                    bool newly = false;
+                    if (valid) {
+                      if (base != 0) nb = L.nbr[(size_t)cnode * L.stride + t];
+                      const uint32_t bit = 1u << (nb & 31);
+                      newly = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;  // visited.insert (graph.rs:499)
+                    }
+                    const uint64_t mask = __ballot(newly);
+                    const uint32_t before = (uint32_t)__popcll(mask & lt_mask(lane));
+                    if (newly) {
+                      nb_id[m + before] = nb;
+                      if (logn + before < a.vlog_cap) vlog[logn + before] = nb;
+                    }
+                    m += (uint32_t)__popcll(mask);
+                    logn += (uint32_t)__popcll(mask);
                   }
-                  const uint64_t mask = __ballot(newly);
-                  const uint32_t before = (uint32_t)__popcll(mask & lt_mask(lane));
-                  if (newly) {
-                    nb_id[m + before] = nb;
-                    if (logn + before < a.vlog_cap) vlog[logn + before] = nb;
-                  }
-                  m += (uint32_t)__popcll(mask);
-                  logn += (uint32_t)__popcll(mask);
                 }
                 if (m != 0) {
                   ready = true;
@@ -236,7 +253,16 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
               }
             }
           } else if (phase == P_Z_ADMIT) {
-            n_dist += m_prev;
+            if (LAT) {  // the unvisited ones of the evaluated neighbours, in list order: counters and the undo log
+              n_dist += (uint32_t)__popcll(spec_mask);
+              if (spec_mask >> lane & 1ull) {
+                const uint32_t pos = logn + (uint32_t)__popcll(spec_mask & lt_mask(lane));
+                if (pos < a.vlog_cap) vlog[pos] = nb_id[lane];
+              }
+              logn += (uint32_t)__popcll(spec_mask);
+            } else {
+              n_dist += m_prev;
+            }
             for (uint32_t base = 0; base < m_prev; base += 64) {
               const uint32_t t = base + lane;
               const float d = t < m_prev ? nb_d[t] : 0.0f;
@@ -245,6 +271,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
               // pre-filter against the furthest distance at chunk start: it only decreases while the
               // result set is full, so a neighbour rejected now would be rejected at its turn too
               uint64_t mask = __ballot(t < m_prev && (d < far || size < ef));
+              if (LAT) mask &= spec_mask;
               while (mask) {
                 const int src = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
@@ -301,10 +328,21 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
       const uint32_t m = ctl[0];
       if (ctl[1]) break;
       const bool raw = ctl[3] != 0;
+      uint32_t spec_old = 0, spec_bit = 0;
+      const bool spec_lane = LAT && wib == 0 && spec && (uint32_t)lane < m;
+      if (spec_lane) {  // visited.insert (graph.rs:499) for every neighbour, in flight beside the row fetches below
+        const uint32_t nb = nb_id[lane];
+        spec_bit = 1u << (nb & 31);
+        spec_old = atomicOr(&vis[nb >> 5], spec_bit);
+      }
       if (BITS)
         dist_phase_bits<METRIC>(dc, qbits, m, nb_id, nb_d, raw);
       else
-        dist_phase_f32<METRIC, CPL>(dc, q, qnorm, qgen, m, nb_id, nb_d, lane, wib, raw);
+        dist_phase_f32<METRIC, CPL, WAVES, RR>(dc, q, qnorm, qgen, m, nb_id, nb_d, lane, wib, raw);
+      if (LAT && wib == 0) {
+        spec_mask = spec ? __ballot(spec_lane && (spec_old & spec_bit) == 0) : 0ull;
+        spec = false;
+      }
       __syncthreads();
     }
 
@@ -375,9 +413,9 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(HnswSearchArgs a) {
     // ---- undo the visited bits of this query ----
     const uint32_t nlog = ctl[2];
     if (nlog <= a.vlog_cap) {
-      for (uint32_t i = threadIdx.x; i < nlog; i += 256) vis[vlog[i] >> 5] = 0;
+      for (uint32_t i = threadIdx.x; i < nlog; i += TPB) vis[vlog[i] >> 5] = 0;
     } else {
-      for (uint64_t i = threadIdx.x; i < a.vis_words; i += 256) vis[i] = 0;
+      for (uint64_t i = threadIdx.x; i < a.vis_words; i += TPB) vis[i] = 0;
     }
     __syncthreads();
   }
@@ -393,6 +431,17 @@ size_t hnsw_lds_bytes(uint32_t cap, uint32_t nbmax, uint32_t dim, uint32_t words
   return (s + 15) & ~(size_t)15;
 }
 
+// latency mode: one 1 024-thread block per query (<= kLatencyMaxQueries queries per call)
+template <int METRIC, int CPL>
+static hipError_t launch_lat(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_search_kernel<METRIC, CPL, kSearchRegSlots, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((hnsw_search_kernel<METRIC, CPL, kSearchRegSlots, true>), dim3(slots), dim3(1024), lds, st, a);
+  return hipGetLastError();
+}
 template <int METRIC, int CPL, int NS>
 static hipError_t launch_ns(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
@@ -427,8 +476,33 @@ static hipError_t launch_cpl(const HnswSearchArgs& a, int slots, size_t lds, hip
   }
 }
 
+template <int METRIC>
+static hipError_t launch_lat_cpl(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
+  switch (sweep_cpl_for_dim(a.dim)) {
+    case 1: return launch_lat<METRIC, 1>(a, slots, lds, st);
+    case 2: return launch_lat<METRIC, 2>(a, slots, lds, st);
+    case 3: return launch_lat<METRIC, 3>(a, slots, lds, st);
+    case 4: return launch_lat<METRIC, 4>(a, slots, lds, st);
+    default: return launch_lat<METRIC, 0>(a, slots, lds, st);
+  }
+}
+// VELESDB_HNSW_LATENCY_MODE=0 keeps the throughput kernel for every call (A / B measurements)
+static const bool g_hnsw_lat = [] {
+  const char* e = getenv("VELESDB_HNSW_LATENCY_MODE");
+  return !(e && e[0] == '0');
+}();
+
 hipError_t launch_hnsw_search(const HnswSearchArgs& a, int slots, hipStream_t st) {
   const size_t lds = hnsw_lds_bytes(a.cap, a.nbmax, a.dim, a.words, a.metric);
+  // a handful of queries: the latency-mode kernel (f32 metrics, register list, layer-0 lists of <= 64 neighbours)
+  if (g_hnsw_lat && a.nq <= kLatencyMaxQueries && a.list_slots == kSearchRegSlots && a.rerank_k == 0 && a.layers[0].stride <= 64 &&
+      a.nbmax >= 64 && (a.metric == kCosine || a.metric == kEuclidean || a.metric == kDot)) {
+    switch (a.metric) {
+      case kCosine: return launch_lat_cpl<kCosine>(a, (int)a.nq, lds, st);
+      case kEuclidean: return launch_lat_cpl<kEuclidean>(a, (int)a.nq, lds, st);
+      default: return launch_lat_cpl<kDot>(a, (int)a.nq, lds, st);
+    }
+  }
   switch (a.metric) {
     case kCosine: return launch_cpl<kCosine>(a, slots, lds, st);
     case kEuclidean: return launch_cpl<kEuclidean>(a, slots, lds, st);

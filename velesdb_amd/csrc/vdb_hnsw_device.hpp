@@ -331,12 +331,11 @@ __device__ __forceinline__ float transform_score_dev(int metric, float d) {  // 
 }
 
 // ---- distance evaluation of nb_id[0..m) -> nb_d[0..m): DistanceEngine::distance (native/distance.rs:75-85)
-template <int METRIC, int CPL, int WAVES = 4>
+template <int METRIC, int CPL, int WAVES = 4, int R = 8>
 __device__ __forceinline__ void dist_phase_f32(const DistCtx& a, const float4* q, float qnorm,
                                                const float* qgen, uint32_t m, volatile uint32_t* nb_id,
                                                volatile float* nb_d, int lane, int wib, bool raw = false) {
   constexpr int OP = (METRIC == kEuclidean) ? kOpL2 : kOpDot;
-  constexpr int R = 8;
   const int d4 = (int)((a.dim + 3) / 4);
   for (uint32_t j0 = (uint32_t)wib * R; j0 < m; j0 += WAVES * R) {
     float acc[R];
