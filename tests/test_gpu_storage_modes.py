@@ -132,7 +132,7 @@ def test_storage_mode_state_errors(gpu_required):
     h.close()
 
 
-@pytest.mark.parametrize("metric,pm", [(DM.Cosine, po.COSINE), (DM.DotProduct, po.DOT)])
+@pytest.mark.parametrize("metric,pm", [(DM.Cosine, po.COSINE), (DM.DotProduct, po.DOT), (DM.Euclidean, po.EUCLIDEAN)])
 @pytest.mark.parametrize("n,dim,nq,k", [(70_000, 128, 256, 10), (66_000, 256, 480, 3)])
 def test_sq8_big_batches_select_on_the_matrix_cores_bit_exact(gpu_required, metric, pm, n, dim, nq, k):
     """Batches of >= 224 queries over >= 65 536 SQ8 rows (dim % 64 == 0): bf16 selection over the dequantised rows, the
@@ -156,7 +156,10 @@ def test_sq8_big_batches_select_on_the_matrix_cores_bit_exact(gpu_required, metr
     assert np.all(gcnt == k)
     assert np.array_equal(gid, ids[eid.astype(np.int64)]), "ids / ranks differ from the oracle's SQ8 scan"
     assert np.array_equal(bits(gsc), bits(esc)), "score bits differ from the oracle's SQ8 scan"
-    assert 1 <= unproven <= nq // 8, f"{unproven} of {nq_last} unproven"  # the tie and the zero query, not the random ones
+    # the tie and the zero query, not the random ones.  (Euclidean: its bound scales with the LONGEST row, and this corpus holds
+    # rows 30x the typical length — most queries take the gathered exact pass; the bits are what is checked.)
+    if metric != DM.Euclidean:
+        assert 1 <= unproven <= nq // 8, f"{unproven} of {nq_last} unproven"
     va.set_split_selector(0)                       # the exact sweep for the whole batch: the same bits
     gid0, gsc0, _ = ix.search_batch_sq8(Q, k)
     va.set_split_selector(2)

@@ -58,7 +58,7 @@ while time.time() < t_end:
     kind = str(rng.choice(["normal", "dups", "const", "zeros", "ints", "wide"]))
     if a.select:
         mode = "sq8"
-        metric = [DM.Cosine, DM.DotProduct][int(rng.integers(0, 2))]
+        metric = [DM.Cosine, DM.DotProduct, DM.Euclidean][int(rng.integers(0, 3))]
         n = int(rng.choice([66_000, 120_000]))
         dim = int(rng.choice([128, 256, 768]))
         nq = int(rng.choice([80, 150, 256, 480]))

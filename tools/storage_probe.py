@@ -20,7 +20,7 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(42)
 corpus = torch.randn((a.rows, a.dim), generator=g, device=dev)
-queries = torch.randn((256, a.dim), generator=g, device=dev)
+queries = torch.randn((1024, a.dim), generator=g, device=dev)
 metric = {"cosine": va.DistanceMetric.Cosine, "euclidean": va.DistanceMetric.Euclidean, "dot": va.DistanceMetric.DotProduct}[a.metric]
 ix = va.HnswIndex(a.dim, metric, va.HnswParams(32, 400, a.rows))
 torch.cuda.synchronize()

@@ -561,7 +561,7 @@ static int select_level_l2(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
 // the SQ8 storage mode's batches (VDB_SEARCH_BRUTE_SQ8): the same eligibility on the shapes the bf16 selection kernel takes
 int select_level_sq8(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (!opt_selector(ix) || opt_max_tile(ix) < 128) return 0;
-  if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT) return 0;  // Euclidean keeps the exact sweep
+  if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT && ix->metric != VDB_EUCLIDEAN) return 0;
   if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
   const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
@@ -582,7 +582,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   const bool sq8 = level >= 3;
   const bool l2 = ix->metric == VDB_EUCLIDEAN;  // (level 2) the augmented DotProduct form of |q - v|^2, sweep_split.hip
   const int sel_metric = l2 ? VDB_DOT : ix->metric;
-  int32_t rc = l2 ? ensure_l2_select(ix, st) : (sq8 ? ensure_sq8_select(ix, st) : (level >= 2 ? ensure_sel16(ix, st) : ensure_split(ix, st)));
+  int32_t rc = sq8 ? ensure_sq8_select(ix, st) : (l2 ? ensure_l2_select(ix, st) : (level >= 2 ? ensure_sel16(ix, st) : ensure_split(ix, st)));
   if (rc != VDB_OK) return rc;
   ix->last_select_level = level;
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
@@ -656,8 +656,8 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   if (ev) (void)hipEventRecord(ev->a, st);
   // queries: split image / bf16 image (+ canonical norms), zero rows behind the batch (the kernel stages whole 256-query tiles)
   const uint64_t img_stride = l2 ? (uint64_t)dim_a : (sq8 ? (uint64_t)dim : (level >= 2 ? ix->bf16_stride : (uint64_t)dim * 2));  // elements per image row
-  const uint16_t* img_rows = l2 ? ix->l2_img.as<uint16_t>()
-                                : (sq8 ? ix->sq8_img.as<uint16_t>() : (level >= 2 ? ix->rows_bf16.as<uint16_t>() : ix->rows_split.as<uint16_t>()));
+  const uint16_t* img_rows = sq8 ? ix->sq8_img.as<uint16_t>()
+                                 : (l2 ? ix->l2_img.as<uint16_t>() : (level >= 2 ? ix->rows_bf16.as<uint16_t>() : ix->rows_split.as<uint16_t>()));
   const float* sel_norms = sq8 ? ix->sq8_nrm.as<float>() : ix->norms.as<float>();
   float* qaug = reinterpret_cast<float*>(ix->s_misc.as<unsigned char>() + ((size_t)nqg + 256) * (dim + 64) * 4);  // Euclidean: (q, 1, 0, 0, 0) f32
   if (l2) {
@@ -691,7 +691,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   if (sel_metric == VDB_DOT) launch_max_norm(sel_norms, n, norm_max, st);
   // exact seed sweep over the first rows
   SweepArgs ag{};
-  ag.rows = l2 ? ix->l2_seed.as<float>() : (sq8 ? ix->sq8_seed.as<float>() : ix->rows.as<float>());  // SQ8: the dequantised prefix (f32)
+  ag.rows = sq8 ? ix->sq8_seed.as<float>() : (l2 ? ix->l2_seed.as<float>() : ix->rows.as<float>());  // SQ8: the dequantised prefix (f32)
   ag.norms = sel_norms;
   ag.alive = alive;
   ag.queries = l2 ? qaug : d_q;
@@ -714,7 +714,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   ms.k = k;
   launch_merge(true, ms, nqg, st);
   if (l2)
-    launch_l2_seed(m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim_a, st);
+    launch_l2_seed(m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim_a, sq8 ? 1.5e-4f : 0.0f, st);
   else
     launch_split_seed(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim, level, st);
   // selection launches over the split images
@@ -773,7 +773,10 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   ra.norm_max_bits = norm_max;
   if (l2) launch_l2_rerank(ra, nqg, st);
   else launch_split_rerank(ix->metric, ra, nqg, st);
-  if (l2) {  // the canonical vector-ALU sweep for the unproven queries only, listed and gathered on the device
+  if (sq8) {  // the reference chain for the unproven queries only, decided on the device
+    const int32_t rf = sq8_fallback_flagged(ix, d_q, q_stride, nqg, k, flags, d_ids, d_scores, d_n, st);
+    if (rf != VDB_OK) return rf;
+  } else if (l2) {  // the canonical vector-ALU sweep for the unproven queries only, listed and gathered on the device
     uint32_t* qmap = reinterpret_cast<uint32_t*>(sd + o_qmap);
     uint32_t* qcount = qmap + nqg;
     const uint32_t ngroups8 = (n + 7) / 8;
@@ -806,9 +809,6 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     mg.active = qcount;
     launch_merge(false, mg, nqg, st);
     launch_scatter_flagged(qmap, qcount, 0, mg.out_ids, mg.out_scores, mg.out_n, d_ids, d_scores, d_n, nqg, k, st);
-  } else if (sq8) {  // the reference chain for the unproven queries only, decided on the device
-    const int32_t rf = sq8_fallback_flagged(ix, d_q, q_stride, nqg, k, flags, d_ids, d_scores, d_n, st);
-    if (rf != VDB_OK) return rf;
   } else {
     // Unproven queries, decided on the device.  A few (<= kFallbackGatherMax): listed, and the streaming matrix-core kernel
     // makes ONE gathered corpus pass per 48 of them (0.9 ms; same mode-M bits).  More: the GEMM-structured kernel for the
@@ -881,7 +881,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   ix->split_flags_off = o_flags;
   ix->split_flags_n = nqg;
   ix->split_flags_stream = st;
-  if (ix->sel_stats) launch_select_stats(flags, nqg, ++ix->sel_seq, l2 ? 5u : (uint32_t)level, ix->sel_stats, st);
+  if (ix->sel_stats) launch_select_stats(flags, nqg, ++ix->sel_seq, sq8 ? 3u : (l2 ? 5u : (uint32_t)level), ix->sel_stats, st);
   if (ev) (void)hipEventRecord(ev->b, st);
   VDB_HIP(hipGetLastError());
   return VDB_OK;

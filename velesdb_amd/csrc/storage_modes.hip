@@ -433,9 +433,11 @@ static hipError_t launch_sq8_m(int metric, const Sq8Args& a, int blocks, size_t 
 // ---- selection stage over the SQ8 storage mode (index.hip brute_split_dev, level 3) -------------------------------------
 // The dequantised rows d = code * scale + min as a bf16 image (what the matrix cores select on), their norms sqrt(nsq), and
 // the first kSplitSeedRows dequantised rows in f32 (what the exact matrix-core kernel seeds the thresholds from).
+// Euclidean (aug): the augmented form of sweep_split.hip — image rows of dim + 64 (slots dim, dim + 1 = hi / lo of -nsq / 2), seed
+// rows of dim + 4 (slot dim = -nsq / 2)
 __global__ __launch_bounds__(256) void sq8_dequant_rows(const uint8_t* codes, uint64_t code_stride, const float* vmin, const float* vmax,
                                                         const float* nsq, uint16_t* img, float* nrm, float* seed, uint32_t seed_rows,
-                                                        uint32_t row0, uint32_t n_rows, uint32_t dim) {
+                                                        uint32_t row0, uint32_t n_rows, uint32_t dim, uint32_t dim_a, uint32_t dim_s) {
   const int lane = lane_id();
   const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t nwaves = gridDim.x * 4;
@@ -456,8 +458,17 @@ __global__ __launch_bounds__(256) void sq8_dequant_rows(const uint8_t* codes, ui
         uint32_t u = __float_as_uint(d[e]);
         h[e] = (u & 0x7FFFFFFFu) > 0x7F800000u ? ((u >> 16) | 0x0040u) : ((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
       }
-      *reinterpret_cast<uint2*>(img + (size_t)row * dim + i) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-      if (row < seed_rows) *reinterpret_cast<float4*>(seed + (size_t)row * dim + i) = make_float4(d[0], d[1], d[2], d[3]);
+      *reinterpret_cast<uint2*>(img + (size_t)row * dim_a + i) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+      if (row < seed_rows) *reinterpret_cast<float4*>(seed + (size_t)row * dim_s + i) = make_float4(d[0], d[1], d[2], d[3]);
+    }
+    if (dim_a > dim) {
+      const float hh = -0.5f * nsq[row];
+      uint32_t u = __float_as_uint(hh);
+      const uint32_t hi = (u & 0x7FFFFFFFu) > 0x7F800000u ? ((u >> 16) | 0x0040u) : ((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+      u = __float_as_uint(hh - __uint_as_float(hi << 16));
+      const uint32_t lo = (u & 0x7FFFFFFFu) > 0x7F800000u ? ((u >> 16) | 0x0040u) : ((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+      if (dim + lane < dim_a) img[(size_t)row * dim_a + dim + lane] = lane == 0 ? (uint16_t)hi : (lane == 1 ? (uint16_t)lo : (uint16_t)0);
+      if (row < seed_rows && lane < 4 && dim + lane < dim_s) seed[(size_t)row * dim_s + dim + lane] = lane == 0 ? hh : 0.0f;
     }
     if (lane == 0) nrm[row] = sqrtf(nsq[row]);
   }
@@ -505,17 +516,19 @@ int32_t storage_mode_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
 // kept current by storage_mode_append
 int32_t ensure_sq8_select(vdb_hip_index* ix, hipStream_t st) {
   const uint64_t cap = std::max<uint64_t>(ix->capacity, 1) + kRowSlack;
+  const bool aug = ix->metric == VDB_EUCLIDEAN;
+  const uint32_t dim_a = aug ? ix->dim + 64 : ix->dim, dim_s = aug ? ix->dim + 4 : ix->dim;
   hipError_t e;
-  if ((e = ix->sq8_img.reserve(cap * (size_t)ix->dim * 2, true, st)) != hipSuccess ||
+  if ((e = ix->sq8_img.reserve(cap * (size_t)dim_a * 2, true, st)) != hipSuccess ||
       (e = ix->sq8_nrm.reserve(cap * 4, true, st)) != hipSuccess ||
-      (e = ix->sq8_seed.reserve((size_t)kSplitSeedRows * ix->dim * 4, true, st)) != hipSuccess)
+      (e = ix->sq8_seed.reserve((size_t)kSplitSeedRows * dim_s * 4, true, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("SQ8 selection image: ") + hipGetErrorString(e));
   if (ix->sq8_img_rows < ix->n_rows) {
     const uint64_t first = ix->sq8_img_rows, n = ix->n_rows - first;
     const int blocks = (int)std::min<uint64_t>((n + 3) / 4, 4096);
     hipLaunchKernelGGL(sq8_dequant_rows, dim3(blocks), dim3(256), 0, st, ix->sq8_codes.as<uint8_t>(), ix->sq8_stride,
                        ix->sq8_min.as<float>(), ix->sq8_max.as<float>(), ix->sq8_nsq.as<float>(), ix->sq8_img.as<uint16_t>(),
-                       ix->sq8_nrm.as<float>(), ix->sq8_seed.as<float>(), kSplitSeedRows, (uint32_t)first, (uint32_t)n, ix->dim);
+                       ix->sq8_nrm.as<float>(), ix->sq8_seed.as<float>(), kSplitSeedRows, (uint32_t)first, (uint32_t)n, ix->dim, dim_a, dim_s);
     ix->sq8_img_rows = ix->n_rows;
     VDB_HIP(hipGetLastError());
   }
@@ -584,7 +597,7 @@ int32_t sq8_fallback_flagged(vdb_hip_index* ix, const float* d_q, uint64_t q_str
   m.n_lists = (uint32_t)blocks;
   m.k = k;
   m.active = qcount;
-  launch_merge(true, m, nqg, st);
+  launch_merge(ix->metric != VDB_EUCLIDEAN, m, nqg, st);
   launch_scatter_flagged(qmap, qcount, 0, m.out_ids, m.out_scores, m.out_n, d_ids, d_scores, d_n, nqg, k, st);
   VDB_HIP(hipGetLastError());
   return VDB_OK;

@@ -432,13 +432,13 @@ void launch_l2_augment_queries(const float* q, uint64_t q_stride, uint16_t* img,
 __global__ __launch_bounds__(256) void l2_seed_kernel(const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
                                                       const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list,
                                                       uint64_t* blk_tau, uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist,
-                                                      uint32_t dim_a) {
+                                                      uint32_t dim_a, float extra_rel) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
   const float nmax = __uint_as_float(*norm_max_bits), hmax = 0.5f * nmax * nmax;
   const float acc = 16.0f * (float)dim_a * 5.9604645e-8f;
-  const float eps_r = 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f + acc;                      // select_eps(dim_a, 2)
-  const float d = eps_r * 1.001f * qnorms[q] * nmax + (1.6e-5f + acc) * hmax + 1e-30f;  // bf16 roundings of q.v + the augmentation
+  const float eps_r = 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f + acc + extra_rel;          // select_eps(dim_a, 2) (+ SQ8: level 3's extra)
+  const float d = eps_r * 1.001f * qnorms[q] * nmax + (1.6e-5f + acc + extra_rel) * hmax + 1e-30f;  // bf16 roundings of q.v + the augmentation
   const float d_seed = 4.0f * acc * (qnorms[q] * nmax + hmax) + 1e-30f;                 // f32 matrix-core s against the true s
   delta[q] = d;
   const uint32_t c = min(n[q], k);
@@ -457,9 +457,9 @@ __global__ __launch_bounds__(256) void l2_seed_kernel(const uint64_t* ids, const
 }
 void launch_l2_seed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms, const uint32_t* norm_max_bits,
                     uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau, uint32_t list_stride, uint32_t nq, uint32_t k,
-                    uint32_t klist, uint32_t dim_a, hipStream_t st) {
+                    uint32_t klist, uint32_t dim_a, float extra_rel, hipStream_t st) {
   hipLaunchKernelGGL(l2_seed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits, tau0, delta, list,
-                     blk_tau, list_stride, nq, k, klist, dim_a);
+                     blk_tau, list_stride, nq, k, klist, dim_a, extra_rel);
 }
 
 // One block per query (the Euclidean sibling of split_rerank_verify): every candidate is re-scored with the canonical
@@ -484,6 +484,41 @@ __global__ __launch_bounds__(256) void l2_rerank_verify(SplitRerankArgs a) {
     for (uint32_t g = threadIdx.x; g < a.lists; g += 256) m = min(m, (unsigned long long)a.blk_tau[(size_t)qi * a.lists + g]);
     if (m != ~0ull) atomicMin(&bmin, m);
   }
+  if (a.sq8_codes) {
+    // SQ8 storage mode: euclidean_squared_quantized_simd (core/quantization.rs:469-516) over the candidate's code, one thread per
+    // candidate — groups of four: sum += ((f0^2 + f1^2) + f2^2) + f3^2, the remainder one by one; the SQUARED distance is the score
+    if (threadIdx.x < n) {
+      const uint32_t c = threadIdx.x;
+      const uint32_t row = (uint32_t)a.cand_rows[(size_t)qi * a.k2 + c];
+      const float mn = a.sq8_min[row], range = __fsub_rn(a.sq8_max[row], mn);
+      const uint32_t* cw = reinterpret_cast<const uint32_t*>(a.sq8_codes + (size_t)row * a.sq8_stride);
+      float sum = 0.0f;
+      if (range < 1.1920929e-07f) {  // constant vector (:478-481): sum((q - value)^2), left to right
+        for (uint32_t d = 0; d < a.dim; d++) {
+          const float f = __fsub_rn(q[d], mn);
+          sum = __fadd_rn(sum, __fmul_rn(f, f));
+        }
+      } else {
+        const float scale = __fdiv_rn(range, 255.0f);
+        const uint32_t full = a.dim & ~3u;
+        for (uint32_t i = 0; i < full; i += 4) {
+          const uint32_t w = cw[i >> 2];
+          float f[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) f[e] = __fsub_rn(q[i + e], __fadd_rn(__fmul_rn((float)((w >> (8 * e)) & 0xFFu), scale), mn));
+          const float t = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(f[0], f[0]), __fmul_rn(f[1], f[1])), __fmul_rn(f[2], f[2])), __fmul_rn(f[3], f[3]));
+          sum = __fadd_rn(sum, t);
+        }
+        for (uint32_t i = full; i < a.dim; i++) {
+          const float dq = __fadd_rn(__fmul_rn((float)((cw[i >> 2] >> (8 * (i & 3u))) & 0xFFu), scale), mn);
+          const float f = __fsub_rn(q[i], dq);
+          sum = __fadd_rn(sum, __fmul_rn(f, f));
+        }
+      }
+      sums[c] = sum;
+      keys[c] = make_key<false>(sum, row);
+    }
+  } else
   for (uint32_t c = wib; c < n; c += 4) {
     const uint32_t row = (uint32_t)a.cand_rows[(size_t)qi * a.k2 + c];
     const float* p = a.rows + (size_t)row * a.row_stride;

@@ -245,7 +245,7 @@ void launch_l2_augment_queries(const float* q, uint64_t q_stride, uint16_t* img,
                                uint32_t dim, hipStream_t st);
 void launch_l2_seed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms, const uint32_t* norm_max_bits,
                     uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau, uint32_t list_stride, uint32_t nq, uint32_t k,
-                    uint32_t klist, uint32_t dim_a, hipStream_t st);
+                    uint32_t klist, uint32_t dim_a, float extra_rel, hipStream_t st);
 void launch_l2_rerank(const SplitRerankArgs& a, uint32_t nq, hipStream_t st);
 // the flagged queries of a batch in ascending order: qmap[0 .. *qcount) (one block; nq <= 1024 per round)
 void launch_collect_flagged(const uint32_t* flags, uint32_t nq, uint32_t* qmap, uint32_t* qcount, hipStream_t st);
