@@ -64,7 +64,7 @@ def _run_case(metric, rows, qs, k, level, expect_unproven, remove):
 
 
 @pytest.mark.parametrize("metric", [DM.Cosine, DM.DotProduct])
-@pytest.mark.parametrize("n,dim,nq,k", [(70_000, 768, 256, 10), (150_001, 128, 1000, 10), (66_000, 64, 256, 1), (300_000, 96, 450, 7)])
+@pytest.mark.parametrize("n,dim,nq,k", [(70_000, 768, 256, 10), (150_001, 128, 1000, 10), (66_000, 64, 256, 1), (300_000, 96, 450, 7), (70_000, 128, 300, 5), (70_000, 128, 100, 10), (70_000, 128, 620, 10)])
 def test_random_data_proven_and_bit_exact(gpu_required, metric, n, dim, nq, k):
     rng = np.random.default_rng(n + dim + int(metric))
     rows = rng.standard_normal((n, dim)).astype(np.float32)

@@ -87,7 +87,7 @@ while time.time() < t_end:
         bf16 = False
         n = int(rng.choice([66_000, 150_000, 300_000]))
         dim = int(rng.choice([64, 128, 256, 768]))
-        nq = int(rng.choice([80, 100, 150, 230, 256, 480, 1000]))
+        nq = int(rng.choice([80, 100, 150, 230, 256, 300, 480, 620, 1000]))
         k = int(rng.choice([1, 3, 10]))
         kind = str(rng.choice(["normal", "normal", "dups", "small_ints", "ascending", "zeros_mixed", "clusters"]))
         va.set_split_selector(int(rng.choice([1, 2])))

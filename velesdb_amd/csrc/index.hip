@@ -494,6 +494,13 @@ static bool select_shape_ok(uint32_t nqg) {
   if (nqt_big == 1) return nqg >= select_min_queries();
   return nqg >= kGemmBigMinQueries && (uint64_t)nqg * 8 >= (uint64_t)nqt_big * 256 * 7;
 }
+// the chunk of the remaining nq_left queries the selection stage takes next (0: none): up to 1 024, and when that leaves the
+// last 256-query tile too empty, the whole tiles in front of it (the rest is the next chunk: a single tile, or the exact kernels)
+static uint32_t select_chunk(uint32_t nq_left) {
+  const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
+  if (select_shape_ok(nqg)) return nqg;
+  return nqg >= 256 ? nqg / 256 * 256 : 0;
+}
 
 // 0: no selection stage (exact kernel); 1: split-bf16 selection; 2: plain bf16 selection
 static int select_level(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
@@ -502,8 +509,7 @@ static int select_level(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT) return 0;
   if (ix->dim % 32 != 0 || ix->dim < 64 || ix->row_stride != ix->dim) return 0;
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
-  const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
-  if (!select_shape_ok(nqg)) return 0;
+  if (!select_chunk(nq_left)) return 0;
   if (want < 2 || ix->dim % 64 != 0 || ix->dim < 128) return 1;
   // what did the finished level-2 batches of this handle look like?  (pinned host memory, written by select_stats_kernel)
   if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
@@ -545,8 +551,7 @@ static int select_level_l2(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (ix->metric != VDB_EUCLIDEAN) return 0;
   if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
-  const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
-  if (!select_shape_ok(nqg)) return 0;
+  if (!select_chunk(nq_left)) return 0;
   if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
     ix->sel_seq_seen = ix->sel_stats[2];
     if (ix->sel_stats[3] == 5u && (uint64_t)ix->sel_stats[0] * 16 > ix->sel_stats[1]) ix->l2_hold = 64;
@@ -564,8 +569,7 @@ int select_level_sq8(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT && ix->metric != VDB_EUCLIDEAN) return 0;
   if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
-  const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
-  if (!select_shape_ok(nqg)) return 0;
+  if (!select_chunk(nq_left)) return 0;
   if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
     ix->sel_seq_seen = ix->sel_stats[2];
     if (ix->sel_stats[3] == 3u && (uint64_t)ix->sel_stats[0] * 16 > ix->sel_stats[1]) ix->sq8_hold = 64;
@@ -963,7 +967,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     // as the exact matrix-core kernel below, which remains the fallback for unproven queries and every other shape)
     const int sel_level = mfma_nqt ? select_level(ix, nq - q0, k) : 0;
     if (sel_level) {
-      const uint32_t nqg = std::min<uint32_t>(nq - q0, kGemmMaxQueries);
+      const uint32_t nqg = select_chunk(nq - q0);
       const int32_t rcs = brute_split_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nqg, k, d_ids + (size_t)q0 * k,
                                           d_scores + (size_t)q0 * k, d_n + q0, st, sel_level);
       if (rcs != VDB_OK) return rcs;
@@ -974,7 +978,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     // s = q.v - |v|^2 / 2 (bf16 matrix pipe, canonical re-scoring, proof, unproven queries gathered on the device — no host
     // synchronisation); the f32 matrix-core path below remains for the shapes it does not take and for handles it parks
     if (ix->metric == VDB_EUCLIDEAN && q0 >= euclid_skip_until && select_level_l2(ix, nq - q0, k)) {
-      const uint32_t nqg = std::min<uint32_t>(nq - q0, kGemmMaxQueries);
+      const uint32_t nqg = select_chunk(nq - q0);
       const int32_t rcs = brute_split_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nqg, k, d_ids + (size_t)q0 * k,
                                           d_scores + (size_t)q0 * k, d_n + q0, st, 2);
       if (rcs != VDB_OK) return rcs;
@@ -1243,7 +1247,7 @@ int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint3
     uint32_t q0 = 0;
     while (q0 < nq && k > 0 && ix->n_rows > 0) {
       if (select_level_sq8(ix, nq - q0, k) != 3) break;
-      const uint32_t nqg = std::min<uint32_t>(nq - q0, kGemmMaxQueries);
+      const uint32_t nqg = select_chunk(nq - q0);
       const int32_t rcs = brute_split_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nqg, k, d_ids + (size_t)q0 * k,
                                           d_scores + (size_t)q0 * k, d_n + q0, st, 3);
       if (rcs != VDB_OK) return rcs;
