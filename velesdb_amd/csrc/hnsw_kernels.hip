@@ -494,8 +494,10 @@ static const bool g_hnsw_lat = [] {
 
 hipError_t launch_hnsw_search(const HnswSearchArgs& a, int slots, hipStream_t st) {
   const size_t lds = hnsw_lds_bytes(a.cap, a.nbmax, a.dim, a.words, a.metric);
-  // a handful of queries: the latency-mode kernel (f32 metrics, register list, layer-0 lists of <= 64 neighbours)
-  if (g_hnsw_lat && a.nq <= kLatencyMaxQueries && a.list_slots == kSearchRegSlots && a.rerank_k == 0 && a.layers[0].stride <= 64 &&
+  // a handful of queries over a corpus that does not sit in the 256 MB Infinity Cache: the latency-mode kernel (f32 metrics,
+  // register list, layer-0 lists of <= 64 neighbours).  Over a cache-resident corpus the walk is not latency-bound the same way
+  // (10 K x 768: 408 us per query on the throughput kernel, 599 us in latency mode, whose speculation fetches visited rows too)
+  if (g_hnsw_lat && a.nq <= kLatencyMaxQueries && (uint64_t)a.n_rows * a.row_stride * 4 >= (256ull << 20) && a.list_slots == kSearchRegSlots && a.rerank_k == 0 && a.layers[0].stride <= 64 &&
       a.nbmax >= 64 && (a.metric == kCosine || a.metric == kEuclidean || a.metric == kDot)) {
     switch (a.metric) {
       case kCosine: return launch_lat_cpl<kCosine>(a, (int)a.nq, lds, st);
