@@ -94,7 +94,6 @@ def test_hnsw_1m_vs_oracle(corpus, index, tmp_path, record_property):
     index.save(str(tmp_path), "native_hnsw")
     og = po.NativeHnsw.file_load(str(tmp_path), "native_hnsw", po.COSINE, po.MODE_C)
     oi, od, oc, nd, ne = og.search_batch(qs[:nq], K, ef, po.TIE_CANONICAL, nthreads=ncores)
-    del og
     assert (nd_gpu, ne_gpu) == (nd, ne), "distance-evaluation / expansion counters differ from the oracle at 1M"
     gid = np.array([[r[0] for r in q] for q in res], dtype=np.uint64)
     gsc = np.array([[r[1] for r in q] for q in res], dtype=np.float32)
@@ -103,6 +102,17 @@ def test_hnsw_1m_vs_oracle(corpus, index, tmp_path, record_property):
     one_minus = np.float32(1.0) - od  # transform_score for Cosine: clamp(1 - d, 0, 1) (backend_adapter.rs:160-168)
     osim = np.minimum(np.maximum(one_minus, np.float32(0.0)), np.float32(1.0)).astype(np.float32)
     assert np.array_equal(bits(gsc), bits(osim)), "traversal score bits differ from the oracle (mode C) at 1M"
+    # calls of <= 16 queries over a corpus beyond the Infinity Cache take the latency-mode kernel (speculative row fetch beside
+    # the visited test, 1 024-thread blocks): the same ids, score bits and counters, query by query
+    for lo, cnt in ((0, 1), (1, 5), (6, 16)):
+        small = index.search_batch_parallel(qs[lo:lo + cnt], K, SQ.Custom(ef))
+        nd_s, ne_s = index.last_search_stats()
+        sid = np.array([[r[0] for r in q] for q in small], dtype=np.uint64)
+        ssc = np.array([[r[1] for r in q] for q in small], dtype=np.float32)
+        assert np.array_equal(sid, gid[lo:lo + cnt]) and np.array_equal(bits(ssc), bits(gsc[lo:lo + cnt])), (lo, cnt)
+        _, _, _, nd_o, ne_o = og.search_batch(qs[lo:lo + cnt], K, ef, po.TIE_CANONICAL, nthreads=ncores)
+        assert (nd_s, ne_s) == (nd_o, ne_o), "latency-mode counters differ from the oracle"
+    del og
     # the reference's own arithmetic (mode R, reference heap / tie order) over the same graph: how often does a sub-ulp
     # difference in a distance change the id list?  
     ogr = po.NativeHnsw.file_load(str(tmp_path), "native_hnsw", po.COSINE, po.MODE_R)

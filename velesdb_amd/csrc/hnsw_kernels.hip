@@ -486,10 +486,11 @@ static hipError_t launch_lat_cpl(const HnswSearchArgs& a, int slots, size_t lds,
     default: return launch_lat<METRIC, 0>(a, slots, lds, st);
   }
 }
-// VELESDB_HNSW_LATENCY_MODE=0 keeps the throughput kernel for every call (A / B measurements)
-static const bool g_hnsw_lat = [] {
+// VELESDB_HNSW_LATENCY_MODE=0 keeps the throughput kernel for every call (A / B measurements), =2 takes the latency-mode kernel
+// whatever the corpus size (fuzzing it over small graphs: tools/fuzz_hnsw.py)
+static const int g_hnsw_lat = [] {
   const char* e = getenv("VELESDB_HNSW_LATENCY_MODE");
-  return !(e && e[0] == '0');
+  return e ? atoi(e) : 1;
 }();
 
 hipError_t launch_hnsw_search(const HnswSearchArgs& a, int slots, hipStream_t st) {
@@ -497,7 +498,7 @@ hipError_t launch_hnsw_search(const HnswSearchArgs& a, int slots, hipStream_t st
   // a handful of queries over a corpus that does not sit in the 256 MB Infinity Cache: the latency-mode kernel (f32 metrics,
   // register list, layer-0 lists of <= 64 neighbours).  Over a cache-resident corpus the walk is not latency-bound the same way
   // (10 K x 768: 408 us per query on the throughput kernel, 599 us in latency mode, whose speculation fetches visited rows too)
-  if (g_hnsw_lat && a.nq <= kLatencyMaxQueries && (uint64_t)a.n_rows * a.row_stride * 4 >= (256ull << 20) && a.list_slots == kSearchRegSlots && a.rerank_k == 0 && a.layers[0].stride <= 64 &&
+  if (g_hnsw_lat && a.nq <= kLatencyMaxQueries && (g_hnsw_lat >= 2 || (uint64_t)a.n_rows * a.row_stride * 4 >= (256ull << 20)) && a.list_slots == kSearchRegSlots && a.rerank_k == 0 && a.layers[0].stride <= 64 &&
       a.nbmax >= 64 && (a.metric == kCosine || a.metric == kEuclidean || a.metric == kDot)) {
     switch (a.metric) {
       case kCosine: return launch_lat_cpl<kCosine>(a, (int)a.nq, lds, st);
