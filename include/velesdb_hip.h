@@ -321,6 +321,9 @@ int32_t vdb_hip_index_last_select_level(vdb_hip_index* idx, int32_t* level);
 /* *mode = 1 if searches in VDB_SEARCH_BRUTE mode with this k run on the matrix-core kernel (mode M), else 0 */
 int32_t vdb_hip_index_sweep_arith_mode(vdb_hip_index* idx, uint32_t k, int32_t* mode);
 int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* idx, float* ms, uint32_t* launches);
+/* with kernel timing on: the launches of the selection kernel (sweep_topk_gemm_bf16_glds) in the last search call — their
+ * number and the SUM of their durations in ms (HIP events around each launch); 0 / 0 when the call had no selection stage */
+int32_t vdb_hip_index_last_selection_ms(vdb_hip_index* idx, float* total_ms, uint32_t* launches);
 
 const char* vdb_hip_last_error(void); /* thread-local, never NULL */
 const char* vdb_hip_version(void);

@@ -118,6 +118,7 @@ extern "C" {
     pub fn vdb_hip_index_last_select_level(idx: *mut VdbHipIndex, level: *mut i32) -> i32;
     pub fn vdb_hip_index_sweep_arith_mode(idx: *mut VdbHipIndex, k: u32, mode: *mut i32) -> i32;
     pub fn vdb_hip_index_last_kernel_ms(idx: *mut VdbHipIndex, ms: *mut f32, launches: *mut u32) -> i32;
+    pub fn vdb_hip_index_last_selection_ms(idx: *mut VdbHipIndex, total_ms: *mut f32, launches: *mut u32) -> i32;
     pub fn vdb_hip_last_error() -> *const c_char;
     pub fn vdb_hip_version() -> *const c_char;
 }

@@ -396,8 +396,21 @@ int32_t append_host_rows(vdb_hip_index* ix, const uint64_t* ids, const float* ve
   return finish_append(ix, first, m);
 }
 
+// (pointers into the pools stay valid: their capacity is reserved once)
+static EventPair* next_sel_events(vdb_hip_index* ix) {
+  if (!opt_timing(ix)) return nullptr;
+  if (ix->sel_ev.capacity() < 64) ix->sel_ev.reserve(64);
+  if (ix->sel_ev_used == ix->sel_ev.size()) {
+    if (ix->sel_ev.size() >= 64) return nullptr;
+    EventPair p;
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+    ix->sel_ev.push_back(p);
+  }
+  return &ix->sel_ev[ix->sel_ev_used++];
+}
 EventPair* next_events(vdb_hip_index* ix) {
   if (!opt_timing(ix)) return nullptr;
+  if (ix->ev_pool.capacity() < 8192) ix->ev_pool.reserve(8192);
   if (ix->ev_used == ix->ev_pool.size()) {
     if (ix->ev_pool.size() >= 8192) return nullptr;
     EventPair p;
@@ -724,8 +737,11 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   // selection launches over the split images
   uint32_t list_off = 1;
   for (int j = 0; j < n_launch; j++) {
+    EventPair* evs = next_sel_events(ix);
+    if (evs) (void)hipEventRecord(evs->a, st);
     e = launch_sweep_gemm_bf16_glds(sel_metric, bp[j], img_rows, img_stride, sel_norms, alive, q16, img_stride, tau0, pool, lists, list_off,
                                     l2 ? dim_a : dim, nqg, ks, st, /*split=*/level < 2, qnorms, blk_tau);
+    if (evs) (void)hipEventRecord(evs->b, st);
     if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split selection launch: ") + hipGetErrorString(e));
     list_off += bp[j].G;
     if (j + 1 < n_launch) {  // bound of the next launch: k-th best pool score so far
@@ -1234,6 +1250,7 @@ int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint3
                    bool* used_hnsw, uint32_t rerank_k) {
   if (used_hnsw) *used_hnsw = false;
   ix->ev_used = 0;
+  ix->sel_ev_used = 0;
   if (ix->n_rows == 0) {  // empty index: no entry point => empty result (native/graph.rs:252-255)
     if (nq) VDB_HIP(hipMemsetAsync(d_n, 0, (size_t)nq * 4, st));
     return VDB_OK;
@@ -1326,10 +1343,11 @@ void destroy_single(vdb_hip_index* ix) {
     L.cnt.release();
     L.ndist.release();
   }
-  for (auto& e : ix->ev_pool) {
-    (void)hipEventDestroy(e.a);
-    (void)hipEventDestroy(e.b);
-  }
+  for (auto* pool : {&ix->ev_pool, &ix->sel_ev})
+    for (auto& e : *pool) {
+      (void)hipEventDestroy(e.a);
+      (void)hipEventDestroy(e.b);
+    }
   if (ix->sel_stats) (void)hipHostFree(const_cast<uint32_t*>(ix->sel_stats));
   if (ix->ev_foreign) (void)hipEventDestroy(ix->ev_foreign);
   if (ix->ev_own) (void)hipEventDestroy(ix->ev_own);
@@ -2072,6 +2090,26 @@ int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* ix, float* ms, uint32_t* lau
     }
   }
   *ms = cnt ? (float)(total / cnt) : 0.0f;
+  if (launches) *launches = cnt;
+  return VDB_OK;
+  });
+}
+
+int32_t vdb_hip_index_last_selection_ms(vdb_hip_index* ix, float* total_ms, uint32_t* launches) {
+  return vdb::guarded([&]() -> int32_t {
+  if (!ix || !total_ms) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) return vdb_hip_index_last_selection_ms(group_shard(ix, 0), total_ms, launches);
+  std::lock_guard<std::mutex> g(ix->mu);
+  double total = 0.0;
+  uint32_t cnt = 0;
+  for (size_t i = 0; i < ix->sel_ev_used; i++) {
+    float t = 0.f;
+    if (hipEventSynchronize(ix->sel_ev[i].b) == hipSuccess && hipEventElapsedTime(&t, ix->sel_ev[i].a, ix->sel_ev[i].b) == hipSuccess) {
+      total += t;
+      cnt++;
+    }
+  }
+  *total_ms = (float)total;
   if (launches) *launches = cnt;
   return VDB_OK;
   });

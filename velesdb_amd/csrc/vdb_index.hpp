@@ -166,6 +166,8 @@ struct vdb_hip_index {
   bool stats_pending = false;
   std::vector<vdb::EventPair> ev_pool;
   size_t ev_used = 0;
+  std::vector<vdb::EventPair> sel_ev;  // kernel timing: one pair per launch of the selection kernel in the last search call
+  size_t sel_ev_used = 0;
   uint64_t last_n_dist = 0, last_n_expand = 0;
 
   mutable std::mutex mu;

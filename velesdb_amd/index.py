@@ -450,6 +450,12 @@ class HnswIndex:
         check(lib().vdb_hip_index_last_select_level(self._h, C.byref(v)))
         return int(v.value)
 
+    def last_selection_ms(self):
+        """(total ms, launches) of the selection kernel in the last search call (kernel timing on)."""
+        ms, n = C.c_float(0), C.c_uint32(0)
+        check(lib().vdb_hip_index_last_selection_ms(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
     def last_kernel_ms(self):
         ms, n = C.c_float(0), C.c_uint32(0)
         check(lib().vdb_hip_index_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
