@@ -1841,9 +1841,26 @@ int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
     }
   all.clear();
   all.shrink_to_fit();
-  // 2. fresh graph state with auto parameters (vacuum.rs:127-134)
-  ix->M = ix->dim <= 256 ? 24 : 32;
-  ix->M0 = ix->M * 2;
+  // 2. fresh graph state with auto parameters (vacuum.rs:127-134).  The one large allocation of the rebuild — the new layer-0
+  // arrays at the index's capacity — is made BEFORE anything is torn down: when the device is out of memory the call fails
+  // here with the index untouched (the rows keep their buffer, the id maps are host memory, upper layers are small).
+  const uint32_t M_new = ix->dim <= 256 ? 24 : 32, M0_new = M_new * 2;
+  GraphLayer l0;
+  l0.stride = M0_new;
+  {
+    const uint64_t cap0 = std::max<uint64_t>(ix->capacity, 1);
+    hipError_t ea;
+    if ((ea = l0.nbr.reserve(cap0 * M0_new * 4, false, ix->stream)) != hipSuccess ||
+        (ea = l0.cnt.reserve(cap0 * 4, false, ix->stream)) != hipSuccess ||
+        (ea = l0.ndist.reserve(cap0 * M0_new * 4, false, ix->stream)) != hipSuccess) {
+      l0.nbr.release();
+      l0.cnt.release();
+      l0.ndist.release();
+      return fail(VDB_ERR_OOM, std::string("vacuum: the rebuilt graph does not fit (index unchanged): ") + hipGetErrorString(ea));
+    }
+  }
+  ix->M = M_new;
+  ix->M0 = M0_new;
   ix->efc = ix->dim <= 256 ? 300 : 400;
   for (auto& L : ix->layers) {
     L.nbr.release();
@@ -1851,8 +1868,6 @@ int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
     L.ndist.release();
   }
   ix->layers.clear();
-  GraphLayer l0;
-  l0.stride = ix->M0;
   ix->layers.push_back(l0);
   ix->entry_point = -1;
   ix->max_layer = 0;
