@@ -744,9 +744,10 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     if (evs) (void)hipEventRecord(evs->b, st);
     if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split selection launch: ") + hipGetErrorString(e));
     list_off += bp[j].G;
-    if (j + 1 < n_launch) {  // bound of the next launch: k-th best pool score so far
+    if (j + 1 < n_launch) {  // bound of the next launch: k-th best pool score so far (the lists written so far)
       ms.part_keys = pool;
-      ms.n_lists = lists;
+      ms.n_lists = list_off;
+      ms.list_stride = lists;
       ms.k = ks;
       ms.k_out = k;
       launch_merge(true, ms, nqg, st);
@@ -756,6 +757,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   // pool -> K2 best by pool score -> exact re-scoring, ranking, proof
   ms.part_keys = pool;
   ms.n_lists = lists;
+  ms.list_stride = 0;
   ms.k = ks;
   ms.k_out = K2;
   launch_merge(true, ms, nqg, st);
@@ -892,6 +894,10 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     mf.out_n = reinterpret_cast<uint32_t*>(sd + o_fn);
     mf.n_lists = fp.G;
     mf.k = k;
+    if (gather_ok) {  // (the GEMM pass did not run for a batch the gathered pass answered: nothing to merge)
+      mf.skip_cnt = qcount;
+      mf.skip_le = kFallbackGatherMax;
+    }
     launch_merge(true, mf, nqg, st);
     if (gather_ok)
       launch_select_fallback(flags, mf.out_ids, mf.out_scores, mf.out_n, d_ids, d_scores, d_n, nqg, k, st, qcount, kFallbackGatherMax);

@@ -817,12 +817,13 @@ __global__ __launch_bounds__(256) void merge_topk(MergeArgs m) {
   const int wib = (int)(threadIdx.x >> 6);
   const uint32_t qi = blockIdx.x;
   if (m.active && (qi >= *m.active || (m.active_max && *m.active > m.active_max))) return;  // (uniform per block)
+  if (m.skip_cnt && *m.skip_cnt <= m.skip_le) return;
   const uint32_t kin = m.k;                     // entries per partial list
   const uint32_t k = m.k_out ? m.k_out : m.k;   // entries kept (k_out > k: a candidate pool for a re-scoring stage)
   volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k;
   volatile uint32_t* wcnt = reinterpret_cast<volatile uint32_t*>(smem + (size_t)4 * k * 8);
   uint32_t cnt = 0;
-  const uint64_t* keys = m.part_keys + (size_t)qi * m.n_lists * kin;
+  const uint64_t* keys = m.part_keys + (size_t)qi * (m.list_stride ? m.list_stride : m.n_lists) * kin;
   const uint32_t total = m.n_lists * kin;  // slots beyond a list's count hold kKeyInvalid
   // wave w scans the slice [lo, hi); 4 independent loads in flight per lane
   const uint32_t per = ((total + 3) / 4 + 255) / 256 * 256;

@@ -41,6 +41,9 @@ struct MergeArgs {
   uint32_t k_out;             // 0 = k; otherwise the number of entries kept per query (out_* are [nq][k_out])
   const uint32_t* active;     // nullable: *active = number of leading queries that hold data (the other blocks exit)
   uint32_t active_max;        // with `active`: nothing to do at all when *active > active_max (0 = no such limit)
+  uint32_t list_stride;       // lists per query in part_keys (0 = n_lists): merge only the first n_lists of them
+  const uint32_t* skip_cnt;   // nullable: nothing to do when *skip_cnt <= skip_le (the pass that would have filled the lists did not run)
+  uint32_t skip_le;
 };
 
 struct EuclidRerankArgs {
