@@ -1,0 +1,86 @@
+"""The error bounds behind the selection stage (sweep_split.hip `select_eps`, `l2_seed_kernel`), checked on the CPU in float64:
+whatever order the matrix cores add the products in, a selection score differs from the exact dot product by the roundings of
+the operands — bf16 keeps 8 significant bits (|x - hi| <= 2^-8 |x|, round to nearest even), the split remainder
+|x - hi - lo| <= 2^-17 |x| — and the bounds the proofs use must cover that for any data, including values that sit exactly
+on rounding boundaries.  (The f32 accumulation term 16 dim 2^-24 is on top of these and is not exercised here: the sums below
+are exact.)"""
+import numpy as np
+
+from oracle import pyoracle as po
+
+EPS1 = 8.2 * 2.0 ** -18                      # level 1: hi.hi + hi.lo + lo.hi
+EPS2 = 2.0 * 2.0 ** -8 * 1.002 + 1.6e-5      # level 2: hi.hi
+
+
+def split(x):
+    hi = po.round_bf16(x).astype(np.float32)
+    lo = po.round_bf16((x - hi).astype(np.float32)).astype(np.float32)
+    return hi.astype(np.float64), lo.astype(np.float64)
+
+
+def cases(rng):
+    for dim in (64, 128, 768):
+        yield rng.standard_normal(dim).astype(np.float32), rng.standard_normal(dim).astype(np.float32)
+        yield (rng.standard_normal(dim) * 1e-3).astype(np.float32), (rng.standard_normal(dim) * 1e4).astype(np.float32)
+        # values just below a rounding boundary: the largest |x - hi| a binade allows, same sign everywhere (errors add up)
+        worst = np.float32(1.0 + 2.0 ** -8 - 2.0 ** -20)
+        yield np.full(dim, worst, np.float32), np.full(dim, worst, np.float32)
+        yield np.full(dim, worst, np.float32), -np.full(dim, np.float32(1.0 + 2.0 ** -8 + 2.0 ** -9 - 2.0 ** -20), np.float32)
+        # remainders that are themselves on a boundary of the second rounding
+        v = np.float32(1.0 + 2.0 ** -9 + 2.0 ** -17 - 2.0 ** -23)
+        yield np.full(dim, v, np.float32), np.full(dim, v, np.float32)
+        yield rng.integers(-3, 4, dim).astype(np.float32), rng.integers(-3, 4, dim).astype(np.float32)  # exactly representable
+
+
+def test_bf16_and_split_rounding_facts():
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(200_000) * np.exp(rng.uniform(-20, 20, 200_000))).astype(np.float32)
+    hi, lo = split(x)
+    x64 = x.astype(np.float64)
+    assert np.all(np.abs(x64 - hi) <= 2.0 ** -8 * np.abs(x64))           # 8 significant bits, nearest
+    assert np.all(np.abs(x64 - hi - lo) <= 2.0 ** -17 * np.abs(x64))     # the remainder's own rounding
+    # 2^-9 (the unit roundoff one might assume for "bfloat16") is NOT a bound: values exist beyond it
+    assert np.max(np.abs(x64 - hi) / np.abs(x64)) > 2.0 ** -9
+
+
+def test_selection_scores_stay_inside_the_bounds_the_proofs_use():
+    rng = np.random.default_rng(1)
+    worst1 = worst2 = 0.0
+    for x, q in cases(rng):
+        xh, xl = split(x)
+        qh, ql = split(q)
+        exact = float(np.dot(x.astype(np.float64), q.astype(np.float64)))
+        scale = float(np.linalg.norm(x.astype(np.float64)) * np.linalg.norm(q.astype(np.float64)))
+        if scale == 0.0:
+            continue
+        a1 = float(np.dot(xh, qh) + np.dot(xh, ql) + np.dot(xl, qh))     # level 1 (the lo.lo term is dropped)
+        a2 = float(np.dot(xh, qh))                                        # level 2
+        worst1 = max(worst1, abs(a1 - exact) / scale)
+        worst2 = max(worst2, abs(a2 - exact) / scale)
+        assert abs(a1 - exact) <= EPS1 * scale, (abs(a1 - exact) / scale, EPS1)
+        assert abs(a2 - exact) <= EPS2 * scale, (abs(a2 - exact) / scale, EPS2)
+    # the adversarial cases come close to the bounds — and beyond what a 2^-9-per-rounding analysis (3.1 * 2^-18) would allow
+    assert worst1 > 3.1 * 2.0 ** -18, worst1
+    assert worst2 > 0.5 * EPS2, worst2
+
+
+def test_euclidean_augmentation_bound():
+    # s = q.v - |v|^2 / 2 as the dot product of (v, -h_hi, -h_lo) and (q, 1, 1): error <= eps2 |q| |v| + 2^-16 h
+    rng = np.random.default_rng(2)
+    for dim in (128, 768):
+        for scale_v in (1.0, 7.5, 1e-2):
+            v = (rng.standard_normal(dim) * scale_v).astype(np.float32)
+            q = rng.standard_normal(dim).astype(np.float32)
+            vh, _ = split(v)
+            qh, _ = split(q)
+            nn = np.float32(np.sqrt(np.float32(np.dot(v.astype(np.float64), v.astype(np.float64)))))
+            h = np.float32(-0.5) * nn * nn
+            hh, hl = split(np.array([h], np.float32))
+            approx = float(np.dot(vh, qh) + hh[0] + hl[0])
+            v64, q64 = v.astype(np.float64), q.astype(np.float64)
+            exact = float(np.dot(q64, v64) - 0.5 * np.dot(v64, v64))
+            bound = EPS2 * np.linalg.norm(q64) * np.linalg.norm(v64) + (2.0 ** -16 + 1e-6) * 0.5 * float(np.dot(v64, v64))
+            assert abs(approx - exact) <= bound, (dim, scale_v, abs(approx - exact), bound)
+            # and the identity the proof turns back into a distance
+            d2 = float(np.dot(q64 - v64, q64 - v64))
+            assert abs(d2 - (float(np.dot(q64, q64)) - 2.0 * exact)) <= 1e-9 * max(d2, 1.0)
