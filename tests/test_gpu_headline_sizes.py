@@ -102,9 +102,9 @@ def test_hnsw_1m_vs_oracle(corpus, index, tmp_path, record_property):
     one_minus = np.float32(1.0) - od  # transform_score for Cosine: clamp(1 - d, 0, 1) (backend_adapter.rs:160-168)
     osim = np.minimum(np.maximum(one_minus, np.float32(0.0)), np.float32(1.0)).astype(np.float32)
     assert np.array_equal(bits(gsc), bits(osim)), "traversal score bits differ from the oracle (mode C) at 1M"
-    # calls of <= 16 queries over a corpus beyond the Infinity Cache take the latency-mode kernel (speculative row fetch beside
-    # the visited test, 1 024-thread blocks): the same ids, score bits and counters, query by query
-    for lo, cnt in ((0, 1), (1, 5), (6, 16)):
+    # calls of at most one query per CU over a corpus beyond the Infinity Cache take the latency-mode kernel (speculative row
+    # fetch beside the visited test, 1 024-thread blocks): the same ids, score bits and counters, query by query
+    for lo, cnt in ((0, 1), (1, 5), (6, 16), (22, 200)):
         small = index.search_batch_parallel(qs[lo:lo + cnt], K, SQ.Custom(ef))
         nd_s, ne_s = index.last_search_stats()
         sid = np.array([[r[0] for r in q] for q in small], dtype=np.uint64)

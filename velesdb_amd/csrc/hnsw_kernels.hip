@@ -52,7 +52,7 @@ enum Phase : int {
 // LDS: keys[cap] u64 | nb_id[nbmax] u32 | nb_d[nbmax] f32 | ctl[4] u32 | flags[cap] u8 (padded to 16)
 //      | query scratch: generic f32 dims: d4*4 floats; bit metrics: `words` u32
 // ------------------------------------------------------------------------------------------
-// LAT (latency mode: a handful of queries per call, f32 metrics, layer-0 lists of <= 64 neighbours): a 1 024-thread block per
+// LAT (latency mode: calls of at most one query per CU, f32 metrics, layer-0 lists of <= 64 neighbours): a 1 024-thread block per
 // query and a speculative layer-0 step.  A walk is a chain of dependent memory round trips — neighbour ids, visited
 // test-and-set, rows — and a single query cannot hide them behind other queries: here all (<= 64) neighbours' rows are fetched
 // at once by 16 waves (4 rows each) WITHOUT waiting for the visited test, which the leader wave issues alongside; the
@@ -431,7 +431,7 @@ size_t hnsw_lds_bytes(uint32_t cap, uint32_t nbmax, uint32_t dim, uint32_t words
   return (s + 15) & ~(size_t)15;
 }
 
-// latency mode: one 1 024-thread block per query (<= kLatencyMaxQueries queries per call)
+// latency mode: one 1 024-thread block per query (at most one query per CU per call)
 template <int METRIC, int CPL>
 static hipError_t launch_lat(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
@@ -492,13 +492,19 @@ static const int g_hnsw_lat = [] {
   const char* e = getenv("VELESDB_HNSW_LATENCY_MODE");
   return e ? atoi(e) : 1;
 }();
+static const uint32_t g_hnsw_lat_max = [] {  // 0: one query per CU (the default); VELESDB_HNSW_LATENCY_MAX_QUERIES overrides
+  const char* e = getenv("VELESDB_HNSW_LATENCY_MAX_QUERIES");
+  return e ? (uint32_t)atoi(e) : 0u;
+}();
 
 hipError_t launch_hnsw_search(const HnswSearchArgs& a, int slots, hipStream_t st) {
   const size_t lds = hnsw_lds_bytes(a.cap, a.nbmax, a.dim, a.words, a.metric);
-  // a handful of queries over a corpus that does not sit in the 256 MB Infinity Cache: the latency-mode kernel (f32 metrics,
+  // at most one query per CU (measured at 1 M x 768, ef 128: 64 queries 1.57 ms against 2.68 ms on the throughput kernel, 256
+  // queries 2.12 against 3.21 ms — a 1 024-thread block per CU is all the chip holds of this kernel) over a corpus that does not
+  // sit in the 256 MB Infinity Cache: the latency-mode kernel (f32 metrics,
   // register list, layer-0 lists of <= 64 neighbours).  Over a cache-resident corpus the walk is not latency-bound the same way
   // (10 K x 768: 408 us per query on the throughput kernel, 599 us in latency mode, whose speculation fetches visited rows too)
-  if (g_hnsw_lat && a.nq <= kLatencyMaxQueries && (g_hnsw_lat >= 2 || (uint64_t)a.n_rows * a.row_stride * 4 >= (256ull << 20)) && a.list_slots == kSearchRegSlots && a.rerank_k == 0 && a.layers[0].stride <= 64 &&
+  if (g_hnsw_lat && a.nq <= (g_hnsw_lat_max ? g_hnsw_lat_max : a.n_cus) && (g_hnsw_lat >= 2 || (uint64_t)a.n_rows * a.row_stride * 4 >= (256ull << 20)) && a.list_slots == kSearchRegSlots && a.rerank_k == 0 && a.layers[0].stride <= 64 &&
       a.nbmax >= 64 && (a.metric == kCosine || a.metric == kEuclidean || a.metric == kDot)) {
     switch (a.metric) {
       case kCosine: return launch_lat_cpl<kCosine>(a, (int)a.nq, lds, st);

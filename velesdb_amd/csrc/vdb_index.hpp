@@ -241,7 +241,6 @@ int32_t hnsw_search_int8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_str
                              uint32_t ef_search, uint32_t oversampling, uint32_t cap_mult, uint64_t* d_ids,
                              float* d_scores, uint32_t* d_n, hipStream_t st);  // visited bitmaps + logs + stats
 constexpr uint32_t kVlogCap = 16384;
-constexpr uint32_t kLatencyMaxQueries = 16;  // calls with at most this many queries take the latency-mode traversal kernel
 constexpr int kTraversalSlotsPerCu = 8;  // visited bitmaps / id logs are sized for this many queries in flight per CU
 // storage_modes.hip
 int32_t storage_mode_append(vdb_hip_index* ix, uint64_t first, uint64_t n);
