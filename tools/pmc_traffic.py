@@ -36,6 +36,9 @@ for key, kname in ((line["roofline"]["kernel"] + "@%d" % line["config"]["queries
     if not key:
         continue
     for pname, vals in acc.items():
+        # the traversal leg's launch is the register-list instantiation (NS = 4); ef > 192 (the ef curve) runs the LDS-list one
+        if kname.startswith("hnsw_search_kernel") and ", 4, false>" not in pname:
+            continue
         if match(kname, pname):
             out["kernels"][key] = {"fetch_bytes_per_launch": round(sum(vals) / len(vals)), "dispatches": len(vals),
                                    "profiler_kernel": pname[:120]}
