@@ -212,7 +212,9 @@ int32_t vdb_hip_index_search_rerank(vdb_hip_index* idx, const float* queries_row
                                     uint32_t rerank_k, uint32_t ef, uint64_t* out_ids, float* out_scores,
                                     uint32_t* out_n);
 /* device-resident variant: d_queries nq*dim f32 (16-byte aligned), outputs device buffers of
- * nq*k / nq; enqueued on `stream`, no host synchronisation.  In HNSW mode d_out_n[i] ==
+ * nq*k / nq; enqueued on `stream`, no host synchronisation (one exception: Euclidean VDB_SEARCH_BRUTE batches of >= 64 queries
+ * outside the selection stage's shapes — < 80 queries, dim % 64 != 0, k > 10, < 65 536 rows — read their per-query verdicts back
+ * once per <= 1 024-query chunk).  In HNSW mode d_out_n[i] ==
  * 0xFFFFFFFF marks a query whose LDS candidate list overflowed (needs very many exact distance
  * ties); the host variant above re-runs such batches with a larger list by itself. */
 int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* idx, const float* d_queries, uint32_t nq,
