@@ -950,8 +950,39 @@ def main():
             qh = bq.cpu().numpy()
             nqc = min(ncores, BQ)
             t6 = time.perf_counter()
-            oi, _ = po.scan_topk_bf16(om, first_chunk, qh[:nqc], K, nthreads=ncores)   # calibration pass (also the parity check)
+            oi, osc = po.scan_topk_bf16(om, first_chunk, qh[:nqc], K, nthreads=ncores)   # calibration pass + the parity check's oracle side
             t_c = time.perf_counter() - t6
+            # parity of configs[3]'s kernel IN this run: the same 1 024-query batch over an index of the slice the oracle just
+            # scanned (>= 65 536 rows: served by sweep_topk_gemm_bf16_glds, asserted), first nqc queries against the oracle by
+            # the rule of tests/test_gpu_bf16.py (scores within 1e-5 of the f64 value — relative to |q||v| for the dot product —
+            # and ids equal wherever neighbouring oracle scores are further apart than that)
+            ixp = va.HnswIndex(D, metric, va.HnswParams(a.M, a.efc, first_chunk.shape[0]), device=local)
+            ixp.upload(np.arange(first_chunk.shape[0]), first_chunk)
+            ixp.enable_bf16()
+            pi, ps, _ = ixp.search_batch_brute_force_bf16(qh, K)
+            glds = bool(ixp.last_kernels() & va.KERNEL_GEMM_BF16_GLDS)
+            ixp.close()
+            qq64 = po.round_bf16(qh[:nqc]).astype(np.float64)
+            ids_equal = bool(np.array_equal(pi[:nqc], oi))
+            ok_q, worst = 0, 0.0
+            for i in range(nqc):
+                r64 = po.round_bf16(first_chunk[pi[i].astype(np.int64)]).astype(np.float64)
+                tv = r64 @ qq64[i]
+                sc_ = np.linalg.norm(r64, axis=1) * np.linalg.norm(qq64[i])
+                if a.metric == "cosine":
+                    tv, sc_ = tv / sc_, np.ones_like(sc_)
+                err = float(np.max(np.abs(ps[i].astype(np.float64) - tv) / sc_))
+                worst = max(worst, err)
+                good = err <= 1e-5
+                for r in range(K):
+                    if pi[i, r] != oi[i, r]:  # a different row at this rank: only inside a near-tie of the oracle's scores
+                        good &= abs(float(osc[i, r]) - tv[r]) <= 2e-5 * sc_[r]
+                ok_q += int(good)
+            bf16_leg["parity_check"] = {"rows": int(first_chunk.shape[0]), "queries": int(nqc), "served_by_gemm_bf16_glds": glds,
+                                        "queries_within_rule": ok_q, "ids_identical_to_oracle": ids_equal,
+                                        "max_score_err_rel": worst, "ok": bool(glds and ok_q == nqc),
+                                        "rule": "scores within 1e-5 (cosine: absolute; dot: relative to |q||v|) of the f64 score of the "
+                                                "bf16-rounded inputs; ids equal to oracle scan_topk_bf16 except inside near-ties <= 2e-5"}
             nq2, t_c2 = nqc, t_c
             if t_c < 0.5 * a.cpu_seconds:  # one query per thread was short: a second, longer pass sized to the target
                 nq2 = int(max(nqc, min(BQ, nqc * (a.cpu_seconds / max(t_c, 1e-3)))))

@@ -320,6 +320,23 @@ int32_t vdb_hip_set_split_selector(int32_t level);
 int32_t vdb_hip_index_last_split_stats(vdb_hip_index* idx, uint32_t* queries, uint32_t* unproven);
 /* selection level (0 / 1 / 2, see vdb_hip_set_split_selector) the last exact batch of this handle actually ran at */
 int32_t vdb_hip_index_last_select_level(vdb_hip_index* idx, int32_t* level);
+/* which kernel families served the last search call of this handle (a bit set; what a test asserts when it claims to have
+ * driven a particular kernel — e.g. BASELINE configs[3] is VDB_KERNEL_GEMM_BF16_GLDS, which needs >= 65 536 rows) */
+enum vdb_kernel_bit {
+  VDB_KERNEL_SWEEP_VALU = 1,       /* sweep_topk_f32 / sweep_topk_f32_qlds (vector ALU, mode C)                       */
+  VDB_KERNEL_SWEEP_MFMA_F32 = 2,   /* sweep_topk_mfma_f32 (streaming, <= 48 queries per corpus pass, mode M)           */
+  VDB_KERNEL_GEMM_F32 = 4,         /* sweep_topk_gemm_f32 (GEMM-structured exact f32; also the selection stage's seed) */
+  VDB_KERNEL_SWEEP_MFMA_BF16 = 8,  /* sweep_topk_mfma_bf16 (streaming over the bf16 rows, <= 96 queries per pass)      */
+  VDB_KERNEL_GEMM_BF16 = 16,       /* register-staged bf16 GEMM kernels of sweep_gemm.hip (128 x 128 / 256 x 256)      */
+  VDB_KERNEL_GEMM_BF16_GLDS = 32,  /* sweep_topk_gemm_bf16_glds reporting bf16 RESULTS (VDB_SEARCH_BRUTE_BF16)         */
+  VDB_KERNEL_SELECT_BF16 = 64,     /* the same kernel as the selection stage of an exact / SQ8 batch (levels 2, 3)     */
+  VDB_KERNEL_SELECT_SPLIT = 128,   /* ... its split-bf16 instance (level 1)                                            */
+  VDB_KERNEL_BITS = 256,           /* packed-bit sweeps (Hamming / Jaccard / sign-bit codes)                           */
+  VDB_KERNEL_SQ8 = 512,            /* sweep_topk_sq8                                                                   */
+  VDB_KERNEL_HNSW = 1024,          /* hnsw_search_kernel                                                               */
+  VDB_KERNEL_HNSW_INT8 = 2048      /* hnsw_search_int8_kernel                                                          */
+};
+int32_t vdb_hip_index_last_kernels(vdb_hip_index* idx, uint32_t* mask);
 /* *mode = 1 if searches in VDB_SEARCH_BRUTE mode with this k run on the matrix-core kernel (mode M), else 0 */
 int32_t vdb_hip_index_sweep_arith_mode(vdb_hip_index* idx, uint32_t k, int32_t* mode);
 int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* idx, float* ms, uint32_t* launches);

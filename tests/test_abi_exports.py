@@ -173,3 +173,31 @@ def test_rust_wrapper_has_complete_bodies_and_binds_only_declared_symbols():
                  "pub fn batch_dot_product"):
         assert item in lib, item
     assert lib.count("{") == lib.count("}") and lib.count("(") == lib.count(")")
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    # the error path used to read the message out of the (null) binding object.  VELESDB_RCCL_LIB names the
+    # library to bind; a name that does not exist = a host without RCCL.  Needs no GPU.
+    import sys
+    script = ("import sys; sys.path.insert(0, %r)\n"
+              "import velesdb_amd as va\n"
+              "try:\n"
+              "    va.comm_unique_id(); print('NO-ERROR')\n"
+              "except va.VelesHipError as e:\n"
+              "    print('CODE', e.code, e)\n") % ROOT
+    env = dict(os.environ, VELESDB_RCCL_LIB="/nonexistent/librccl-missing.so")
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    assert "CODE -7" in r.stdout and "librccl-missing" in r.stdout, r.stdout
+
+
+def test_rccl_stub_exports_what_the_product_binds():
+    # the loop-back transport of tests/stub_rccl must offer exactly the entry points shard_group.hip resolves with dlsym
+    stub = os.path.join(ROOT, "tests", "stub_rccl", "libstub_rccl.so")
+    assert os.path.exists(stub), "run __graft_entry__.build()"
+    src = open(os.path.join(ROOT, "velesdb_amd", "csrc", "shard_group.hip")).read()
+    wanted = sorted(set(re.findall(r'sym\("(nccl[A-Za-z]+)"\)', src)))
+    assert len(wanted) == 8
+    L = C.CDLL(stub)
+    for name in wanted:
+        assert hasattr(L, name), name

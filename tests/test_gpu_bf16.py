@@ -147,3 +147,127 @@ def test_bf16_gemm_big_tile_exact_and_deleted_rows():
     assert ix.remove(int(gi[7, 0]))
     gi2, _, _ = ix.search_batch_brute_force_bf16(qs, 10)
     assert int(gi[7, 0]) not in gi2[7].tolist()
+
+
+# ---- BASELINE configs[3]'s own kernel: sweep_topk_gemm_bf16_glds in RESULT mode (>= 65 536 rows, batches that fill
+# ---- 256-query tiles, k <= 10) — seed sweep + 1-2 LDS-DMA launches + merges (index.hip brute_bf16_dev) -------------------
+def check_sampled(metric, pm, rows, qs, k, gids, gsc, gcnt, sample, tol=1e-5):
+    """The rule of check() for a SAMPLE of the batch's queries, with the f64 reference computed in row chunks (the whole
+    f64 score matrix of 1 M rows does not fit)."""
+    n = rows.shape[0]
+    qsel = qs[sample]
+    eid, esc = po.scan_topk_bf16(pm, rows, qsel, k, nthreads=po.host_threads())
+    qq = po.round_bf16(qsel).astype(np.float64)
+    qn = np.linalg.norm(qq, axis=1)
+    full = np.empty((len(sample), n), np.float64)
+    rnorm = np.empty(n, np.float64)
+    for lo in range(0, n, 65536):
+        rr = po.round_bf16(rows[lo:lo + 65536]).astype(np.float64)
+        full[:, lo:lo + rr.shape[0]] = qq @ rr.T
+        rnorm[lo:lo + rr.shape[0]] = np.linalg.norm(rr, axis=1)
+    if metric == DM.Cosine:
+        full /= qn[:, None] * rnorm[None, :]
+        scale = np.ones_like(full)
+    else:
+        scale = qn[:, None] * rnorm[None, :]
+    kk = min(k, n)
+    for j, qi in enumerate(sample):
+        assert gcnt[qi] == kk
+        g_i, g_s = gids[qi, :kk].astype(np.int64), gsc[qi, :kk].astype(np.float64)
+        assert len(set(g_i.tolist())) == kk
+        assert np.all(np.abs(g_s - full[j, g_i]) <= tol * scale[j, g_i]), (qi,)
+        assert np.all(np.diff(g_s) <= 1e-12)
+        kth_true = np.partition(full[j], n - kk)[n - kk]
+        assert g_s[-1] >= kth_true - tol * scale[j].max(), (qi,)
+        e_i, e_s = eid[j, :kk].astype(np.int64), esc[j, :kk].astype(np.float64)
+        for r in range(kk):
+            if g_i[r] != e_i[r]:
+                assert abs(e_s[r] - full[j, g_i[r]]) <= 2 * tol * scale[j, g_i[r]], (qi, r)
+
+
+def served_by_glds(ix):
+    assert ix.last_kernels() & va.KERNEL_GEMM_BF16_GLDS, "sweep_topk_gemm_bf16_glds did not serve the call (mask %#x)" % ix.last_kernels()
+
+
+@pytest.mark.parametrize("metric,pm,n,dim,cases", [
+    (DM.Cosine, po.COSINE, 70_000, 128, [(224, 10), (600, 1), (1024, 10)]),
+    (DM.DotProduct, po.DOT, 70_000, 768, [(230, 10), (1024, 1)]),
+    (DM.DotProduct, po.DOT, 300_001, 128, [(600, 10), (1024, 1)]),
+    (DM.Cosine, po.COSINE, 300_001, 768, [(600, 10), (224, 1)]),
+    (DM.Cosine, po.COSINE, 1_000_000, 768, [(1024, 10), (1024, 1)]),       # two LDS-DMA launches, re-seeded in between
+    (DM.DotProduct, po.DOT, 1_000_000, 128, [(1024, 10), (480, 3)]),
+])
+def test_bf16_glds_result_mode(metric, pm, n, dim, cases):
+    rng = np.random.default_rng(n * 13 + dim)
+    rows = rng.standard_normal((n, dim), dtype=np.float32)
+    ix = va.HnswIndex(dim, metric, va.HnswParams(16, 100, n))
+    ix.upload(np.arange(n), rows)
+    ix.enable_bf16()
+    for nq, k in cases:
+        qs = rng.standard_normal((nq, dim), dtype=np.float32)
+        gi, gs, gc = ix.search_batch_brute_force_bf16(qs, k)
+        served_by_glds(ix)
+        sample = np.unique(np.concatenate([[0, nq - 1, 255 % nq, 256 % nq], rng.integers(0, nq, 20)]))
+        check_sampled(metric, pm, rows, qs, k, gi, gs, gc, sample)
+    ix.close()
+
+
+@pytest.mark.parametrize("metric,pm", [(DM.DotProduct, po.DOT), (DM.Cosine, po.COSINE)])
+@pytest.mark.parametrize("n", [70_077, 600_077])   # one launch / two launches; ragged last row tile
+def test_bf16_glds_exact_products_bit_equal(metric, pm, n):
+    # small integers: every product and every partial sum is exact in f32 whatever the order, so ids, ranks (exact ties
+    # broken by row) and score BITS must equal the oracle's — with duplicates of good rows planted in other row tiles,
+    # row groups and launches (ties straddling tiles), zero rows, rows whose norm overflows / is below f32::EPSILON
+    # (half_precision.rs:247: the score is 0.0), and soft-deleted rows
+    dim, nq, k = 128, 300, 10
+    rng = np.random.default_rng(n)
+    rows = rng.integers(-4, 5, size=(n, dim)).astype(np.float32)
+    qs = rng.integers(-4, 5, size=(nq, dim)).astype(np.float32)
+    best = np.argsort(-(qs[:8] @ rows.T), axis=1)[:, :2].ravel()          # good rows for the first queries ...
+    spots = np.array([255, 256, 257, 16383, 16384, 16385, 65535, 65536, 70_000, n - 2, n - 1, n // 2, n // 2 + 255, 300, 4000, 9999])
+    rows[spots] = rows[best]                                            # ... duplicated across tile / launch boundaries
+    rows[[5, 20_000, n - 3]] = 0.0
+    rows[[7, 30_001]] = 3e19        # |v|^2 overflows: cosine = dot / inf = 0; the dot product itself stays finite and exact
+    rows[[9, 40_003]] = 1e-9        # norm 1.1e-8 < f32::EPSILON: cosine 0.0 by the reference's rule (the plain quotient: +-1)
+    qs[3] = 0.0                     # a zero query: every score 0, ties by row
+    ix = va.HnswIndex(dim, metric, va.HnswParams(16, 100, n))
+    ix.upload(np.arange(n), rows)
+    ix.enable_bf16()
+    gi, gs, gc = ix.search_batch_brute_force_bf16(qs, k)
+    served_by_glds(ix)
+    eid, esc = po.scan_topk_bf16(pm, rows, qs, k, nthreads=po.host_threads())
+    assert np.array_equal(gi, eid)
+    assert np.array_equal(gs.view(np.uint32), esc.view(np.uint32))
+    assert np.all(gc == k)
+    # soft deletes: the best row of some queries and one of the planted duplicates
+    dead = sorted({int(gi[0, 0]), int(gi[17, 0]), int(spots[1]), int(gi[299, 9])})
+    for d in dead:
+        assert ix.remove(d)
+    gi2, gs2, _ = ix.search_batch_brute_force_bf16(qs, k)
+    served_by_glds(ix)
+    keep = np.ones(n, bool)
+    keep[dead] = False
+    live = np.flatnonzero(keep)
+    eid2, esc2 = po.scan_topk_bf16(pm, rows[keep], qs, k, nthreads=po.host_threads())
+    assert np.array_equal(gi2, live[eid2.astype(np.int64)].astype(np.uint64))
+    assert np.array_equal(gs2.view(np.uint32), esc2.view(np.uint32))
+    ix.close()
+
+
+def test_bf16_small_batches_follow_the_epsilon_rule_too():
+    # the streaming kernel (<= 96 queries) and the register-staged GEMM kernels (< 65 536 rows): same half_precision.rs rule
+    dim, n = 128, 5000
+    rng = np.random.default_rng(77)
+    rows = rng.integers(-4, 5, size=(n, dim)).astype(np.float32)
+    rows[[9, 4003]] = 1e-9
+    rows[[11]] = 0.0
+    ix = va.HnswIndex(dim, DM.Cosine)
+    ix.upload(np.arange(n), rows)
+    ix.enable_bf16()
+    for nq in (3, 70, 300):
+        qs = -np.abs(rng.integers(-4, 5, size=(nq, dim))).astype(np.float32)   # mostly negative scores: the 0.0 rows rank high
+        qs[:, ::2] *= -1
+        gi, gs, _ = ix.search_batch_brute_force_bf16(qs, 10)
+        eid, esc = po.scan_topk_bf16(po.COSINE, rows, qs, 10, nthreads=4)
+        assert np.array_equal(gi, eid) and np.array_equal(gs.view(np.uint32), esc.view(np.uint32)), nq
+    ix.close()

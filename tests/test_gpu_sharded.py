@@ -289,3 +289,96 @@ def test_sharded_rccl(gpu_required):
     out = mgr.dict()
     mp.spawn(_rccl_worker, args=(world, _free_port(), cfg, out), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world)), dict(out)
+
+
+_LOOPBACK_SCRIPT = r'''
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["VDB_TEST_ROOT"])
+import velesdb_amd as va
+from oracle import pyoracle as po
+DM = va.DistanceMetric
+bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+stub = ctypes.CDLL(os.environ["VELESDB_RCCL_LIB"])   # the same object the product dlopen()s: shared counters
+for metric, pm, n, dim, shards, nq, k in [(DM.Cosine, po.COSINE, 5000, 96, 3, 70, 10), (DM.Hamming, po.HAMMING, 3000, 64, 4, 9, 25),
+                                          (DM.Euclidean, po.EUCLIDEAN, 23, 16, 4, 3, 10)]:
+    rng = np.random.default_rng(n)
+    if metric == DM.Hamming:
+        rows = ((rng.random((4, dim)) > 0.5).astype(np.float32))[rng.integers(0, 4, n)]   # ties in every shard
+        qs = (rng.random((nq, dim)) > 0.5).astype(np.float32)
+    else:
+        rows = rng.standard_normal((n, dim)).astype(np.float32)
+        qs = rng.standard_normal((nq, dim)).astype(np.float32)
+    sh = va.HnswIndex(dim, metric, va.HnswParams(8, 50, n), devices=[0] * shards, shard_mode=va.SHARD_RANGE)
+    one = va.HnswIndex(dim, metric, va.HnswParams(8, 50, n))
+    assert sh.shard_info()["transport"] == "rccl", sh.shard_info()      # forced: the collective branch
+    sh.upload(np.arange(n), rows)
+    one.upload(np.arange(n), rows)
+    before = stub.velesdb_stub_allgathers()
+    for rep in range(2):                                                # twice: gather buffers and communicators are reused
+        a, b = sh.search_batch_brute_force(qs, k), one.search_batch_brute_force(qs, k)
+        assert np.array_equal(a[2], b[2])
+        kk = min(k, n)
+        assert np.array_equal(a[0][:, :kk], b[0][:, :kk]) and np.array_equal(bits(a[1][:, :kk]), bits(b[1][:, :kk]))
+    mode = po.MODE_M if one.sweep_arith_mode(k) == "M" else po.MODE_C
+    eid, esc = po.scan_topk(pm, rows, qs, min(k, n), mode)
+    assert np.array_equal(a[0][:, :eid.shape[1]], eid) and np.array_equal(bits(a[1][:, :esc.shape[1]]), bits(esc))
+    assert stub.velesdb_stub_allgathers() - before == 2 * shards        # ONE grouped all-gather per shard and search
+    sh.close(); one.close()
+assert stub.velesdb_stub_init_all_calls() == 3                          # ncclCommInitAll once per handle
+# the one-process-per-GPU path over the same transport (world = 1)
+ix = va.HnswIndex(32, DM.Cosine)
+rows = np.random.default_rng(1).standard_normal((500, 32)).astype(np.float32)
+ix.upload(np.arange(500), rows)
+ref = ix.search_batch_brute_force(rows[:7], 5)
+ix.join_group(va.comm_unique_id(), 0, 1)
+got = ix.search_batch_brute_force(rows[:7], 5)
+assert np.array_equal(got[0], ref[0]) and np.array_equal(bits(got[1]), bits(ref[1]))
+print("LOOPBACK-OK")
+'''
+
+
+def test_collective_branch_over_a_loopback_transport(gpu_required):
+    """The in-process multi-device branch (ncclCommInitAll + one grouped ncclAllGather per shard + merge,
+    shard_group.hip ensure_group_comms / group_exchange_merge) needs shards on DISTINCT devices — which a one-GPU box
+    never has.  Here it runs anyway: VELESDB_SHARD_FORCE_COLLECTIVE=1 sends co-located shards down that branch and
+    VELESDB_RCCL_LIB binds tests/stub_rccl (a loop-back all-gather with RCCL's signatures) instead of librccl."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = os.path.join(root, "tests", "stub_rccl", "libstub_rccl.so")
+    assert os.path.exists(stub), "tests/stub_rccl/libstub_rccl.so is missing: __graft_entry__.build() compiles it"
+    env = dict(os.environ, VELESDB_RCCL_LIB=stub, VELESDB_SHARD_FORCE_COLLECTIVE="1", VDB_TEST_ROOT=root)
+    r = subprocess.run([sys.executable, "-c", _LOOPBACK_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "LOOPBACK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_distinct_devices_without_rccl_fail_loudly(gpu_required):
+    """>= 2 GPUs but no loadable RCCL: a range-sharded search must fail with VDB_ERR_UNSUPPORTED and name the library — not
+    crash, not silently fall back to copies.  (On a one-GPU box the same is forced through the collective hook.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["VDB_TEST_ROOT"])
+import velesdb_amd as va
+sh = va.HnswIndex(16, va.DistanceMetric.Cosine, va.HnswParams(8, 50, 100), devices=[0, 0], shard_mode=va.SHARD_RANGE)
+sh.upload(np.arange(100), np.random.default_rng(0).standard_normal((100, 16)).astype(np.float32))
+try:
+    sh.search_batch_brute_force(np.ones((2, 16), np.float32), 3)
+    print("NO-ERROR")
+except va.VelesHipError as e:
+    print("CODE", e.code, str(e))
+try:
+    va.comm_unique_id()
+    print("NO-ERROR")
+except va.VelesHipError as e:
+    print("CODE", e.code, str(e))
+'''
+    env = dict(os.environ, VELESDB_RCCL_LIB="/nonexistent/librccl-missing.so", VELESDB_SHARD_FORCE_COLLECTIVE="1", VDB_TEST_ROOT=root)
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("CODE", "NO-ERROR"))]
+    assert len(lines) == 2 and all(l.startswith("CODE -7") and "librccl-missing" in l for l in lines), r.stdout

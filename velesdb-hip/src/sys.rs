@@ -61,6 +61,20 @@ pub const VDB_OPT_SELECTOR_LEVEL: i32 = 2;
 pub const VDB_OPT_INT8_OVERSAMPLING: i32 = 3;
 pub const VDB_OPT_KERNEL_TIMING: i32 = 4;
 
+// enum vdb_kernel_bit (vdb_hip_index_last_kernels)
+pub const VDB_KERNEL_SWEEP_VALU: i32 = 1;
+pub const VDB_KERNEL_SWEEP_MFMA_F32: i32 = 2;
+pub const VDB_KERNEL_GEMM_F32: i32 = 4;
+pub const VDB_KERNEL_SWEEP_MFMA_BF16: i32 = 8;
+pub const VDB_KERNEL_GEMM_BF16: i32 = 16;
+pub const VDB_KERNEL_GEMM_BF16_GLDS: i32 = 32;
+pub const VDB_KERNEL_SELECT_BF16: i32 = 64;
+pub const VDB_KERNEL_SELECT_SPLIT: i32 = 128;
+pub const VDB_KERNEL_BITS: i32 = 256;
+pub const VDB_KERNEL_SQ8: i32 = 512;
+pub const VDB_KERNEL_HNSW: i32 = 1024;
+pub const VDB_KERNEL_HNSW_INT8: i32 = 2048;
+
 pub const VDB_COMM_ID_BYTES: usize = 128;
 
 extern "C" {
@@ -116,6 +130,7 @@ extern "C" {
     pub fn vdb_hip_set_split_selector(level: i32) -> i32;
     pub fn vdb_hip_index_last_split_stats(idx: *mut VdbHipIndex, queries: *mut u32, unproven: *mut u32) -> i32;
     pub fn vdb_hip_index_last_select_level(idx: *mut VdbHipIndex, level: *mut i32) -> i32;
+    pub fn vdb_hip_index_last_kernels(idx: *mut VdbHipIndex, mask: *mut u32) -> i32;
     pub fn vdb_hip_index_sweep_arith_mode(idx: *mut VdbHipIndex, k: u32, mode: *mut i32) -> i32;
     pub fn vdb_hip_index_last_kernel_ms(idx: *mut VdbHipIndex, ms: *mut f32, launches: *mut u32) -> i32;
     pub fn vdb_hip_index_last_selection_ms(idx: *mut VdbHipIndex, total_ms: *mut f32, launches: *mut u32) -> i32;

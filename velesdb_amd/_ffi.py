@@ -77,6 +77,7 @@ SIGNATURES = {
     "vdb_hip_set_split_selector": (_i32, [_i32]),
     "vdb_hip_index_last_split_stats": (_i32, [_vp, _pu32, _pu32]),
     "vdb_hip_index_last_select_level": (_i32, [_vp, C.POINTER(C.c_int32)]),
+    "vdb_hip_index_last_kernels": (_i32, [_vp, _pu32]),
     "vdb_hip_index_last_selection_ms": (_i32, [_vp, _pf32, _pu32]),
     "vdb_hip_index_set_option": (_i32, [_vp, _i32, C.c_int64]),
     "vdb_hip_index_get_option": (_i32, [_vp, _i32, C.POINTER(C.c_int64)]),

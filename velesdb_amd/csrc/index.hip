@@ -225,6 +225,7 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
         // the 256 x 256 kernel stages whole 256-query tiles: zero rows behind the batch
         VDB_HIP(hipMemsetAsync(ix->s_misc.as<uint16_t>() + (size_t)nqg * ix->bf16_stride, 0, (size_t)256 * ix->bf16_stride * 2, st));
         VDB_HIP(hipMemsetAsync(parts, 0xFF, (size_t)nqg * lists * k * 8, st));  // every slot: kKeyInvalid
+        ix->last_kernels |= VDB_KERNEL_GEMM_BF16_GLDS | VDB_KERNEL_GEMM_BF16;  // (the seed prefix: the 128 x 128 kernel)
         EventPair* evg = next_events(ix);
         if (evg) (void)hipEventRecord(evg->a, st);
         e3 = launch_sweep_gemm_bf16(ix->metric, sp, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride, ix->norms_bf16.as<float>(),
@@ -281,6 +282,7 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
           return fail(VDB_ERR_OOM, "bf16 GEMM scratch");
         launch_round_queries_bf16(d_q + (size_t)q0 * q_stride, q_stride, ix->s_misc.as<uint16_t>(), ix->bf16_stride, nqg,
                                   ix->dim, st);
+        ix->last_kernels |= VDB_KERNEL_GEMM_BF16;
         EventPair* evg = next_events(ix);
         if (evg) (void)hipEventRecord(evg->a, st);
         e3 = launch_sweep_gemm_bf16(ix->metric, gp, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride, ix->norms_bf16.as<float>(),
@@ -318,6 +320,7 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
       return fail(VDB_ERR_OOM, "top-k scratch");
     EventPair* ev = next_events(ix);
     if (ev) (void)hipEventRecord(ev->a, st);
+    ix->last_kernels |= VDB_KERNEL_SWEEP_MFMA_BF16;
     e = launch_sweep_bf16(ix->metric, nqt, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride, ix->norms_bf16.as<float>(),
                           alive, d_q + (size_t)q0 * q_stride, q_stride, ix->s_part_keys.as<uint64_t>(),
                           (uint32_t)ix->n_rows, ix->dim, tile, k, blocks, st);
@@ -602,6 +605,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   int32_t rc = sq8 ? ensure_sq8_select(ix, st) : (l2 ? ensure_l2_select(ix, st) : (level >= 2 ? ensure_sel16(ix, st) : ensure_split(ix, st)));
   if (rc != VDB_OK) return rc;
   ix->last_select_level = level;
+  ix->last_kernels |= (level < 2 ? VDB_KERNEL_SELECT_SPLIT : VDB_KERNEL_SELECT_BF16) | VDB_KERNEL_GEMM_F32;  // (exact seed sweep)
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
   const uint32_t n = (uint32_t)ix->n_rows, dim = ix->dim, K2 = level >= 2 ? kSelect16Pool : kSplitPool;
   const uint32_t dim_a = l2 ? dim + 64 : dim, dim_s = dim + 4;  // augmented image / f32 seed widths (Euclidean)
@@ -953,6 +957,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     ba.n_rows = (uint32_t)ix->n_rows;
     ba.words = ix->words;
     ba.k = k;
+    ix->last_kernels |= VDB_KERNEL_BITS;
     EventPair* ev = next_events(ix);
     if (ev) (void)hipEventRecord(ev->a, st);
     {
@@ -1040,6 +1045,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
         ag.k = kp;
         EventPair* evg = next_events(ix);
         if (evg) (void)hipEventRecord(evg->a, st);
+        ix->last_kernels |= VDB_KERNEL_GEMM_F32;
         e3 = launch_sweep_gemm(VDB_EUCLIDEAN, gp, ag, st);
         if (evg) (void)hipEventRecord(evg->b, st);
         if (e3 != hipSuccess) return fail(VDB_ERR_HIP, std::string("gemm sweep launch: ") + hipGetErrorString(e3));
@@ -1117,6 +1123,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
         ag.k = k;
         EventPair* evg = next_events(ix);
         if (evg) (void)hipEventRecord(evg->a, st);
+        ix->last_kernels |= VDB_KERNEL_GEMM_F32;
         e3 = launch_sweep_gemm(ix->metric, gp, ag, st);
         if (evg) (void)hipEventRecord(evg->b, st);
         if (e3 != hipSuccess) return fail(VDB_ERR_HIP, std::string("gemm sweep launch: ") + hipGetErrorString(e3));
@@ -1159,6 +1166,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
       am.k = k;
       EventPair* evm = next_events(ix);
       if (evm) (void)hipEventRecord(evm->a, st);
+      ix->last_kernels |= VDB_KERNEL_SWEEP_MFMA_F32;
       e2 = launch_sweep_mfma(ix->metric, mfma_nqt, am, blocks_m, st);
       if (evm) (void)hipEventRecord(evm->b, st);
       if (e2 != hipSuccess) return fail(VDB_ERR_HIP, std::string("mfma sweep launch: ") + hipGetErrorString(e2));
@@ -1223,6 +1231,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     a.dim = ix->dim;
     a.nq = tile;
     a.k = k;
+    ix->last_kernels |= VDB_KERNEL_SWEEP_VALU;
     EventPair* ev = next_events(ix);
     if (ev) (void)hipEventRecord(ev->a, st);
     if (qlds) {
@@ -1257,6 +1266,10 @@ int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint3
   if (used_hnsw) *used_hnsw = false;
   ix->ev_used = 0;
   ix->sel_ev_used = 0;
+  // diagnostics describe THIS call: brute_split_dev / the sweep paths overwrite them when they run
+  ix->last_select_level = 0;
+  ix->split_flags_n = 0;
+  ix->last_kernels = 0;
   if (ix->n_rows == 0) {  // empty index: no entry point => empty result (native/graph.rs:252-255)
     if (nq) VDB_HIP(hipMemsetAsync(d_n, 0, (size_t)nq * 4, st));
     return VDB_OK;
@@ -1277,14 +1290,17 @@ int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint3
       q0 += nqg;
     }
     if (q0 == nq) return VDB_OK;
+    ix->last_kernels |= VDB_KERNEL_SQ8;
     return brute_sq8_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nq - q0, k, d_ids + (size_t)q0 * k, d_scores + (size_t)q0 * k,
                          d_n + q0, st);
   }
+  if (mode == VDB_SEARCH_BRUTE_BINARY) ix->last_kernels |= VDB_KERNEL_BITS;
   if (mode == VDB_SEARCH_BRUTE_BINARY) return brute_binary_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
   if (mode == VDB_SEARCH_AUTO && ix->live <= 100 && ix->n_rows > 0)  // search.rs:75-77
     return brute_dev(ix, d_q, q_stride, nq, k, d_ids, d_scores, d_n, st);
   if (mode == VDB_SEARCH_HNSW_INT8) {
     if (used_hnsw) *used_hnsw = true;
+    ix->last_kernels |= VDB_KERNEL_HNSW_INT8;
     return hnsw_search_int8_dev(ix, d_q, q_stride, nq, k, ef == 0 ? balanced_ef(k) : ef, opt_oversampling(ix), cap_mult,
                                 d_ids, d_scores, d_n, st);
   }
@@ -1298,6 +1314,7 @@ int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint3
     ef = std::max(ef, k);  // SearchQuality::Custom(ef) = max(ef, k), params.rs:317
   }
   if (used_hnsw) *used_hnsw = true;
+  ix->last_kernels |= VDB_KERNEL_HNSW;
   return hnsw_search_dev(ix, d_q, q_stride, nq, k, ef, cap_mult, d_ids, d_scores, d_n, st, rerank_k);
 }
 
@@ -1335,20 +1352,33 @@ int32_t create_single(uint32_t dim, int32_t metric, uint32_t M, uint32_t ef_cons
   return VDB_OK;
 }
 
+// EVERY device buffer a single-device handle can own — the one list destroy_single frees (a buffer missing here leaks with
+// every destroyed handle; tests/test_gpu_hardening.py::test_destroy_returns_all_device_memory watches hipMemGetInfo)
+std::vector<DevBuf*> index_buffers(vdb_hip_index* ix) {
+  std::vector<DevBuf*> v = {
+      &ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids,           // rows
+      &ix->rows_bf16, &ix->norms_bf16, &ix->rows_split,                     // bf16 copy, split-bf16 image
+      &ix->l2_img, &ix->l2_seed,                                            // Euclidean selection images
+      &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq,                // int8 traversal
+      &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits,  // storage modes
+      &ix->sq8_img, &ix->sq8_nrm, &ix->sq8_seed,                            // SQ8 selection images
+      &ix->s_queries, &ix->s_part_keys, &ix->s_part_cnt, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits,
+      &ix->s_misc, &ix->s_fb_keys, &ix->s_seed, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels, &ix->s_req_keys,
+      &ix->s_req_vals, &ix->s_sort_tmp};
+  for (auto& L : ix->layers) {
+    v.push_back(&L.nbr);
+    v.push_back(&L.cnt);
+    v.push_back(&L.ndist);
+  }
+  return v;
+}
+
 void destroy_single(vdb_hip_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   proc_comm_free(ix->pcomm);
-  for (DevBuf* b : {&ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids, &ix->rows_bf16, &ix->norms_bf16, &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits, &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq, &ix->s_queries, &ix->s_part_keys,
-                    &ix->s_part_cnt, &ix->s_seed, &ix->s_fb_keys, &ix->rows_split, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits, &ix->s_misc, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels,
-                    &ix->s_req_keys, &ix->s_req_vals, &ix->s_sort_tmp})
-    b->release();
-  for (auto& L : ix->layers) {
-    L.nbr.release();
-    L.cnt.release();
-    L.ndist.release();
-  }
+  for (DevBuf* b : index_buffers(ix)) b->release();
   for (auto* pool : {&ix->ev_pool, &ix->sel_ev})
     for (auto& e : *pool) {
       (void)hipEventDestroy(e.a);
@@ -1472,6 +1502,19 @@ int32_t vdb_hip_index_last_select_level(vdb_hip_index* ix, int32_t* level) {
     VDB_NO_GROUP(ix, "last_select_level");
     std::lock_guard<std::mutex> g(ix->mu);
     *level = ix->last_select_level;
+    return VDB_OK;
+  });
+}
+
+int32_t vdb_hip_index_last_kernels(vdb_hip_index* ix, uint32_t* mask) {
+  return vdb::guarded([&]() -> int32_t {
+    if (!ix || !mask) return fail(VDB_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    // a multi-device handle: what any shard ran
+    uint32_t m = ix->last_kernels;
+    if (ix->group)
+      for (size_t s = 0; s < group_size(ix); s++) m |= group_shard(ix, s)->last_kernels;
+    *mask = m;
     return VDB_OK;
   });
 }

@@ -41,27 +41,46 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
-  std::string err;
 };
 
+// why rccl() returned nullptr — kept OUTSIDE the nullable object, so that the error paths can quote it
+static std::string& rccl_load_error() {
+  static std::string e;
+  return e;
+}
+
+// VELESDB_RCCL_LIB names the library to bind instead of the default search (a site-specific RCCL build; the loop-back
+// transport of tests/stub_rccl that drives the collective branch on one GPU; a name that does not exist = "no RCCL").
 static Rccl* rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (r.h) break;
-    }
-    if (!r.h) {
-      r.err = std::string("cannot load librccl.so.1: ") + dlerror();
-      return;
+    std::string& err = rccl_load_error();
+    const char* forced = getenv("VELESDB_RCCL_LIB");
+    if (forced && forced[0]) {
+      r.h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+      if (!r.h) {
+        const char* de = dlerror();
+        err = std::string("cannot load ") + forced + " (VELESDB_RCCL_LIB): " + (de ? de : "unknown error");
+        return;
+      }
+    } else {
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.h) break;
+      }
+      if (!r.h) {
+        const char* de = dlerror();
+        err = std::string("cannot load librccl.so.1: ") + (de ? de : "unknown error");
+        return;
+      }
     }
     bool ok = true;
     auto sym = [&](const char* n) {
       void* p = dlsym(r.h, n);
       if (!p) {
         ok = false;
-        r.err = std::string("librccl lacks ") + n;
+        err = std::string("the RCCL library lacks ") + n;
       }
       return p;
     };
@@ -205,6 +224,7 @@ struct ShardGroup {
   std::vector<vdb_hip_index*> shards;
   uint64_t rows_per_shard = 0;   // C of the range rule
   bool distinct = true;          // all shards on different devices -> RCCL; otherwise device-to-device copies
+  bool broken = false;           // a replica insert failed on some devices only: the replicas may differ, every later call fails
   std::vector<ncclComm_t> comms; // in-process communicators, created at the first sharded search
   std::vector<DevBuf> gath;      // per shard: [S][nq][k] records (every device receives everything)
   std::vector<hipEvent_t> ev;    // per shard: "records packed"
@@ -241,6 +261,10 @@ int32_t group_create(vdb_hip_index* parent, const int32_t* devices, int32_t n_de
   for (int32_t a = 0; a < n_devices; a++)
     for (int32_t b = a + 1; b < n_devices; b++)
       if (devices[a] == devices[b]) g->distinct = false;
+  // test hook: run the collective branch (ncclCommInitAll + grouped ncclAllGather) over co-located shards.  Real RCCL
+  // refuses duplicate devices; the loop-back transport of tests/stub_rccl (VELESDB_RCCL_LIB) does not.
+  if (const char* fc = getenv("VELESDB_SHARD_FORCE_COLLECTIVE"))
+    if (fc[0] == '1') g->distinct = true;
   g->gath.resize(S);
   g->ev.assign(S, nullptr);
   for (int32_t s = 0; s < n_devices; s++) {
@@ -275,7 +299,14 @@ static int32_t for_each_shard(ShardGroup* g, const std::function<int32_t(size_t)
     for (size_t s = 0; s < S; s++) run(s);
   } else {
     std::vector<std::thread> th;
-    for (size_t s = 0; s < S; s++) th.emplace_back(run, s);
+    th.reserve(S);
+    size_t started = 0;
+    try {
+      for (; started < S; started++) th.emplace_back(run, started);
+    } catch (...) {  // thread creation failed (EAGAIN): the shards without a thread run here; a joinable thread must never
+                     // be destroyed (std::terminate)
+      for (size_t s = started; s < S; s++) run(s);
+    }
     for (auto& t : th) t.join();
   }
   for (size_t s = 0; s < S; s++)
@@ -286,6 +317,9 @@ static int32_t for_each_shard(ShardGroup* g, const std::function<int32_t(size_t)
 static size_t shard_of_row(const ShardGroup* g, uint64_t row) {
   return (size_t)std::min<uint64_t>(row / g->rows_per_shard, g->shards.size() - 1);
 }
+
+static const char* const kBrokenMsg =
+    "replica group is inconsistent: an insert succeeded on some devices only; destroy the handle and rebuild it";
 
 // kind 0 insert_batch, 1 insert_batch_parallel, 2 upload
 static int32_t child_insert(vdb_hip_index* c, const uint64_t* ids, const float* vecs, uint64_t n, int kind,
@@ -308,6 +342,7 @@ int32_t group_insert(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, 
   ShardGroup* g = ix->group;
   std::lock_guard<std::mutex> lk(ix->mu);
   if (inserted) *inserted = 0;
+  if (g->broken) return fail(VDB_ERR_STATE, kBrokenMsg);
   // duplicates (against the index and inside the batch) are skipped once, here (trait_impl.rs:23-25)
   std::vector<uint64_t> src;
   src.reserve(n);
@@ -344,8 +379,17 @@ int32_t group_insert(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, 
     if (inserted) *inserted = upto;
   };
   if (g->mode == VDB_SHARD_REPLICA) {
+    // all replicas or none: rows a device took while another failed (out of memory, a lost device) cannot be taken back
+    // (node ids are insertion order), so a partial failure leaves replicas that differ — the handle refuses further work
+    // instead of answering from diverged copies
+    std::vector<uint64_t> before(g->shards.size());
+    for (size_t s = 0; s < g->shards.size(); s++) before[s] = g->shards[s]->n_rows;
     int32_t rc = for_each_shard(g, [&](size_t s) { return child_insert(g->shards[s], ids, vecs, m, kind, max_batch); });
-    if (rc != VDB_OK) return rc;
+    if (rc != VDB_OK) {
+      const std::string why = vdb_hip_last_error();
+      for (size_t s = 0; s < g->shards.size(); s++) g->broken |= g->shards[s]->n_rows != before[s];
+      return g->broken ? fail(rc, why + " — " + kBrokenMsg) : rc;
+    }
     commit(m);
     return VDB_OK;
   }
@@ -370,6 +414,7 @@ int32_t group_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed) {
   ShardGroup* g = ix->group;
   std::lock_guard<std::mutex> lk(ix->mu);
   if (removed) *removed = 0;
+  if (g->broken) return fail(VDB_ERR_STATE, kBrokenMsg);
   auto it = ix->id_to_idx.find(id);
   if (it == ix->id_to_idx.end()) return VDB_OK;
   const uint64_t row = it->second;
@@ -391,6 +436,7 @@ int32_t group_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed) {
 int32_t group_for_all(vdb_hip_index* ix, int op, uint32_t arg) {
   ShardGroup* g = ix->group;
   std::lock_guard<std::mutex> lk(ix->mu);
+  if (g->broken) return fail(VDB_ERR_STATE, kBrokenMsg);
   if (op == 3 && g->mode == VDB_SHARD_RANGE)
     return fail(VDB_ERR_UNSUPPORTED, "the int8 quantiser is trained on the first rows of ONE index: replicas only");
   return for_each_shard(g, [&](size_t s) -> int32_t {
@@ -415,7 +461,7 @@ vdb_hip_index* group_first_shard(vdb_hip_index* ix) { return ix->group->shards[0
 static int32_t ensure_group_comms(ShardGroup* g) {
   if (!g->distinct || !g->comms.empty()) return VDB_OK;
   Rccl* r = rccl();
-  if (!r) return fail(VDB_ERR_UNSUPPORTED, "range-sharded search needs RCCL: " + rccl()->err);
+  if (!r) return fail(VDB_ERR_UNSUPPORTED, "range-sharded search needs RCCL: " + rccl_load_error());
   std::vector<int> devs;
   for (auto* c : g->shards) devs.push_back(c->device);
   g->comms.assign(devs.size(), nullptr);
@@ -496,6 +542,7 @@ int32_t group_search_host(vdb_hip_index* ix, const float* queries, uint32_t nq, 
   ShardGroup* g = ix->group;
   if (nq == 0) return VDB_OK;
   std::lock_guard<std::mutex> lk(ix->mu);
+  if (g->broken) return fail(VDB_ERR_STATE, kBrokenMsg);
   const size_t S = g->shards.size();
   if (g->mode == VDB_SHARD_REPLICA) {
     return for_each_shard(g, [&](size_t s) -> int32_t {
@@ -555,6 +602,7 @@ int32_t group_search_dev(vdb_hip_index* ix, const float* d_q, uint32_t nq, uint3
   ShardGroup* g = ix->group;
   if (nq == 0) return VDB_OK;
   std::lock_guard<std::mutex> lk(ix->mu);
+  if (g->broken) return fail(VDB_ERR_STATE, kBrokenMsg);
   const size_t S = g->shards.size();
   VDB_HIP(hipSetDevice(g->shards[0]->device));
   VDB_HIP(hipStreamSynchronize(st));  // the queries are complete
@@ -635,7 +683,7 @@ int32_t pcomm_exchange_merge(vdb_hip_index* ix, uint32_t nq, uint32_t k, bool hi
   ProcComm* p = ix->pcomm;
   if (nq == 0 || k == 0) return VDB_OK;
   Rccl* r = rccl();
-  if (!r) return fail(VDB_ERR_UNSUPPORTED, "RCCL is not available");
+  if (!r) return fail(VDB_ERR_UNSUPPORTED, "RCCL is not available: " + rccl_load_error());
   const size_t chunk = (size_t)nq * k * 12;
   if (p->gath.cap < (size_t)p->world * chunk) {
     // growing frees the old buffer: an earlier collective enqueued on another stream must have left it
@@ -660,7 +708,7 @@ int32_t vdb_hip_comm_unique_id(uint8_t* id) {
     if (!id) return fail(VDB_ERR_INVALID_ARG, "null argument");
     static_assert(VDB_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
     Rccl* r = rccl();
-    if (!r) return fail(VDB_ERR_UNSUPPORTED, "RCCL is not available: " + rccl()->err);
+    if (!r) return fail(VDB_ERR_UNSUPPORTED, "RCCL is not available: " + rccl_load_error());
     ncclUniqueId u;
     VDB_NCCL(r->GetUniqueId(&u));
     std::memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
@@ -676,7 +724,7 @@ int32_t vdb_hip_index_join_group(vdb_hip_index* ix, const uint8_t* id, int32_t r
     std::lock_guard<std::mutex> lk(ix->mu);
     if (ix->pcomm) return fail(VDB_ERR_STATE, "already member of a process group");
     Rccl* r = rccl();
-    if (!r) return fail(VDB_ERR_UNSUPPORTED, "RCCL is not available: " + rccl()->err);
+    if (!r) return fail(VDB_ERR_UNSUPPORTED, "RCCL is not available: " + rccl_load_error());
     VDB_HIP(hipSetDevice(ix->device));
     std::unique_ptr<ProcComm, void (*)(ProcComm*)> p(new ProcComm(), proc_comm_free);
     p->rank = rank;

@@ -780,10 +780,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 16 ? 4 : 2)) void sweep_topk_
         const float rq = (METRIC == kCosine) ? __builtin_amdgcn_rcpf(qn_t[t] * vn[r]) : 1.0f;
         const float approx = dotv * rq;
         const float margin = fabsf(tau_f[t]) * 1.9073486e-6f + 1e-37f;
-        const bool maybe = !(approx < tau_f[t] - margin) && row < a.n_rows && b < a.nq;
+        // (a norm below f32::EPSILON makes the score 0.0 whatever the dot product: never filtered by the approximation)
+        const bool tiny = METRIC == kCosine && (qn_t[t] < kHalfNormEps || vn[r] < kHalfNormEps);
+        const bool maybe = (tiny || !(approx < tau_f[t] - margin)) && row < a.n_rows && b < a.nq;
         uint64_t mask = __ballot(maybe);
         if (mask == 0) continue;
-        const float score = finish_score<METRIC>(dotv, qn_t[t], vn[r]);
+        const float score = finish_score_half<METRIC>(dotv, qn_t[t], vn[r]);
         const uint64_t key = maybe ? make_key<HIB>(score, row) : kKeyInvalid;
         const uint64_t tau = (cnts[b] == k) ? lists[(size_t)b * k + (k - 1)] : kKeyInvalid;
         mask = __ballot(key < tau);

@@ -451,6 +451,9 @@ _Pragma("unroll") \
         const float tf = tkb == kKeyInvalid ? __uint_as_float(0xFF800000u) : key_score<HIB>(tkb);
         const float cut = tf - (fabsf(tf) * 1.9073486e-6f + 1e-37f);
         cutq[t] = b < nq_t ? (METRIC == kCosine ? cut * qn_t[t] : cut) : __uint_as_float(0x7F800000u);
+        // bf16 results follow half_precision.rs: a norm below f32::EPSILON makes every score of the query 0.0 — nothing
+        // may be filtered by the approximation (NaN compares false: everything passes to the exact finish)
+        if (BF16 && METRIC == kCosine && b < nq_t && qn_t[t] < kHalfNormEps) cutq[t] = __uint_as_float(0x7FC00000u);
         }
       }
 #pragma unroll
@@ -459,7 +462,10 @@ _Pragma("unroll") \
         if (NORMS) {
           const f32x4 vn = *reinterpret_cast<const f32x4*>(vns + wr * WROWS + rf * 16 + 4 * (lane >> 4));
 #pragma unroll
-          for (int r = 0; r < 4; r++) rvn[r] = METRIC == kEuclidean ? vn[r] * 0.49999809f : __builtin_amdgcn_rcpf(vn[r]);
+          for (int r = 0; r < 4; r++) {
+            rvn[r] = METRIC == kEuclidean ? vn[r] * 0.49999809f : __builtin_amdgcn_rcpf(vn[r]);
+            if (BF16 && METRIC == kCosine && vn[r] < kHalfNormEps) rvn[r] = __uint_as_float(0x7FC00000u);  // score 0.0: see above
+          }
         }
 #pragma unroll
         for (int t = 0; t < NQF; t++) {
@@ -546,7 +552,8 @@ _Pragma("unroll") \
         const uint32_t row = rt * BM + rl;
         const float dotv = __uint_as_float((uint32_t)(ent1 >> 32));
         const float score = METRIC == kEuclidean ? __builtin_fmaf(-2.0f, dotv, qn[b] + vns[rl])  // approximate |q - v|^2
-                                                 : finish_score<METRIC>(dotv, qn[b], METRIC == kCosine ? vns[rl] : 1.0f);
+                                                 : (BF16 ? finish_score_half<METRIC>(dotv, qn[b], METRIC == kCosine ? vns[rl] : 1.0f)
+                                                         : finish_score<METRIC>(dotv, qn[b], METRIC == kCosine ? vns[rl] : 1.0f));
         const uint64_t key = make_key<HIB>(score, row);
         bool take = valid & (b < nq_t) & (row < a.n_rows) & (key < tauk[b]);
         if (take && a.alive) take = a.alive[row] != 0;  // soft-deleted rows are filtered where it is rare

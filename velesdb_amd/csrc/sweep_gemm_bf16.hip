@@ -360,6 +360,9 @@ _Pragma("unroll") \
     const bool last = !more;
     mfma_drain();  // the matrix pipe has written every accumulator before the vector ALU reads one
     const int lane = (int)lane_now();  // (shadows the kernel-scope lane: see lane_now)
+    // result mode (VDB_SEARCH_BRUTE_BF16): half_precision.rs's cosine — 0.0 when a norm is below f32::EPSILON; selection
+    // mode approximates the exact f32 cosine (0.0 only for a zero norm)
+    const bool halfp = a.qnorms == nullptr;
     // Quick test: per query column t a lane reduces its 32 accumulators (rows 16 rf + 4 (l >> 4) + r of the wave's 128)
     // with max and compares with a bound no element that matters can miss.  hm[t] = the lanes that MAY hold a survivor
     // (wave-uniform masks: they are also the state carried through the rounds of the protocol below).
@@ -377,7 +380,8 @@ _Pragma("unroll") \
           vsum += vn[r];  // NaN / inf / overflow-prone norms show up in the sum (min / max drop NaNs)
         }
       }
-      const bool force = !(vsum < 1e18f);
+      // (result mode: a row norm below f32::EPSILON means score 0.0 whatever the accumulator — no bound holds for the lane)
+      const bool force = !(vsum < 1e18f) | (halfp & (METRIC == kCosine) & (vmin < kHalfNormEps));
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         const uint32_t b = wq * 64 + t * 16 + (lane & 15);
@@ -395,7 +399,7 @@ _Pragma("unroll") \
         // the largest for cutq <= 0 (rounding slack: the 16-ulp margin of cut).  A norm that is NaN / inf / huge (query
         // or row): no bound holds, the lane is looked at.  fmaxf drops NaN accumulators: they only arise from such norms.
         const float thr = METRIC == kCosine ? (cutq > 0.0f ? cutq * vmin : cutq * vmax) : cutq;
-        const bool hot = (b < nq_t) & (force | !(qnb < 1e18f) | !(mx < thr));
+        const bool hot = (b < nq_t) & (force | !(qnb < 1e18f) | (halfp & (METRIC == kCosine) & (qnb < kHalfNormEps)) | !(mx < thr));
         hm[t] = __ballot(hot);
       }
     }
@@ -418,7 +422,8 @@ _Pragma("unroll") \
         const uint32_t rl = (uint32_t)(wr * 128) + ((uint32_t)lane >> 2) * 16u + 4u * ((uint32_t)src >> 4) + ((uint32_t)lane & 3u); \
         const uint32_t b = (uint32_t)(wq * 64 + (T) * 16) + ((uint32_t)src & 15u); \
         const uint32_t row = rt * BM + (rl & 255u); \
-        const float score = finish_score<METRIC>(x, qn[b], METRIC == kCosine ? vns[rl & 255u] : 1.0f); \
+        const float score = halfp ? finish_score_half<METRIC>(x, qn[b], METRIC == kCosine ? vns[rl & 255u] : 1.0f) \
+                                  : finish_score<METRIC>(x, qn[b], METRIC == kCosine ? vns[rl & 255u] : 1.0f); \
         const uint64_t key = make_key<HIB>(score, row); \
         bool take = (lane < 32) & (row < a.n_rows) & (key < tauk[b]); \
         if (take && a.alive) take = a.alive[row] != 0; /* soft-deleted rows are filtered where it is rare */ \

@@ -265,6 +265,18 @@ __device__ __forceinline__ float finish_score(float sum, float qnorm, float vnor
   }
 }
 
+// the same for the bf16 result kernels: half_precision::cosine_similarity on VectorData::BF16 (half_precision.rs:237-254)
+// returns 0.0 when a norm is below f32::EPSILON (not only when it is zero); dot_product is the plain sum
+constexpr float kHalfNormEps = 1.1920929e-7f;
+template <int METRIC>
+__device__ __forceinline__ float finish_score_half(float sum, float qnorm, float vnorm) {
+  if (METRIC == kCosine) {
+    if (qnorm < kHalfNormEps || vnorm < kHalfNormEps) return 0.0f;
+    return sum / (qnorm * vnorm);
+  }
+  return sum;
+}
+
 constexpr bool higher_is_better(int metric) {  // core/distance.rs:76-82
   return metric == kCosine || metric == kDot || metric == kJaccard;
 }

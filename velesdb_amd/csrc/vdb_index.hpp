@@ -123,6 +123,7 @@ struct vdb_hip_index {
   volatile uint32_t* sel_stats = nullptr;
   uint32_t sel_seq = 0, sel_seq_seen = 0, sel16_hold = 0;
   int last_select_level = 0;
+  uint32_t last_kernels = 0;  // vdb_kernel_bit set of the last search call (vdb_hip_index_last_kernels)
   // Euclidean batches through the selection stage: augmented bf16 image [capacity][dim + 64], augmented f32 seed prefix
   vdb::DevBuf l2_img, l2_seed;
   uint64_t l2_rows = 0;     // rows converted so far

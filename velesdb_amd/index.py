@@ -23,6 +23,9 @@ from .params import DistanceMetric, HnswParams, SearchQuality
 MODE_AUTO, MODE_BRUTE, MODE_HNSW, MODE_BRUTE_BF16, MODE_HNSW_INT8, MODE_BRUTE_SQ8, MODE_BRUTE_BINARY = 0, 1, 2, 3, 4, 5, 6
 OPT_MAX_QUERY_TILE, OPT_SWEEP_ENGINE, OPT_SELECTOR_LEVEL, OPT_INT8_OVERSAMPLING, OPT_KERNEL_TIMING = 0, 1, 2, 3, 4
 KIND_ENGINE, KIND_RAW = 0, 1
+# enum vdb_kernel_bit (HnswIndex.last_kernels)
+(KERNEL_SWEEP_VALU, KERNEL_SWEEP_MFMA_F32, KERNEL_GEMM_F32, KERNEL_SWEEP_MFMA_BF16, KERNEL_GEMM_BF16, KERNEL_GEMM_BF16_GLDS,
+ KERNEL_SELECT_BF16, KERNEL_SELECT_SPLIT, KERNEL_BITS, KERNEL_SQ8, KERNEL_HNSW, KERNEL_HNSW_INT8) = (1 << i for i in range(12))
 SHARD_REPLICA, SHARD_RANGE = 0, 1
 COMM_ID_BYTES = 128
 
@@ -448,6 +451,12 @@ class HnswIndex:
         """Selection level (0 / 1 / 2) the last exact batch of this handle ran at."""
         v = C.c_int32(0)
         check(lib().vdb_hip_index_last_select_level(self._h, C.byref(v)))
+        return int(v.value)
+
+    def last_kernels(self) -> int:
+        """Bit set (KERNEL_*) of the kernel families that served the last search call."""
+        v = C.c_uint32(0)
+        check(lib().vdb_hip_index_last_kernels(self._h, C.byref(v)))
         return int(v.value)
 
     def last_selection_ms(self):
