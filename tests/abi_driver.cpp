@@ -115,6 +115,7 @@ int main(int argc, char** argv) {
   CHECK(vdb_hip_index_len(ix, &len));
   if (len != kRows - 1) return 17;
   if (search(ix, queries, VDB_SEARCH_BRUTE, 0, &after_remove)) return 1;
+  // the directory does not exist yet: HnswIndex::save creates it (constructors.rs:257 create_dir_all)
   CHECK(vdb_hip_index_save_dir(ix, dir.c_str()));
   vdb_hip_index_destroy(ix);
   ix = nullptr;

@@ -2,6 +2,7 @@
 // (NativeHnsw::file_dump / file_load, native/backend_adapter.rs:184-381), introspection, and the
 // launch paths of the traversal / construction kernels (hnsw_kernels.hip).
 #include <algorithm>
+#include <filesystem>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -290,6 +291,11 @@ int32_t vdb_hip_index_save_dir(vdb_hip_index* ix, const char* dir) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !dir) return fail(VDB_ERR_INVALID_ARG, "null argument");
   VDB_NO_GROUP(ix, "save_dir");
+  {  // HnswIndex::save starts with std::fs::create_dir_all(path) (constructors.rs:257)
+    std::error_code ec;
+    std::filesystem::create_directories(dir, ec);
+    if (ec) return fail(VDB_ERR_IO, std::string("cannot create directory ") + dir + ": " + ec.message());
+  }
   int32_t rc = vdb_hip_index_save_reference_files(ix, dir, "native_hnsw");
   if (rc != VDB_OK) return rc;
   std::lock_guard<std::mutex> g(ix->mu);

@@ -190,9 +190,11 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
     // block's starting bound — without it the first row tile of every block floods the 12-key candidate buffers.
     if (opt_max_tile(ix) >= 128 && rem >= kGemmBigMinQueries && k <= kGemmBf16MaxK && ix->dim % 64 == 0 && ix->dim >= 128 &&
         ix->n_rows >= kGemmBf16MinRows && ix->n_rows < 0xFFFFFF00ull && gemm_bf16_glds_enabled()) {
-      const uint32_t nqg = std::min<uint32_t>(rem, kGemmMaxQueries);
-      const uint32_t nqt_big = (nqg + 255) / 256;
-      if ((uint64_t)nqg * 8 >= (uint64_t)nqt_big * 256 * 7) {  // the batch fills its 256-query tiles to >= 7/8
+      // the chunk this kernel takes: up to 1 024 queries that fill their 256-query tiles to >= 7/8; when the last tile would
+      // be emptier than that, the whole tiles in front of it (the rest is the next chunk: the 128 x 128 / streaming kernels)
+      uint32_t nqg = std::min<uint32_t>(rem, kGemmMaxQueries);
+      if ((uint64_t)nqg * 8 < (uint64_t)((nqg + 255) / 256) * 256 * 7) nqg = nqg / 256 * 256;
+      if (nqg >= kGemmBigMinQueries) {
         // Launch schedule: rows [0, R0) by the 128 x 128 kernel (seed), then the LDS-DMA kernel over [R0, R1) and [R1, n).
         // Every launch starts from the k-th best key over ALL rows swept before it: the number of candidates a wave has
         // to look at per row tile falls as k / rows seen (5 per wave tile behind 16 K rows, 0.1 behind 640 K).  All
