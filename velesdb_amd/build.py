@@ -29,7 +29,7 @@ def sources():
 
 def _deps_mtime():
     return max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC)
-               if f.endswith((".hpp", ".h"))) if os.listdir(CSRC) else 0
+               if f.endswith((".hpp", ".h", ".inc"))) if os.listdir(CSRC) else 0
 
 
 def _compile(src: str, force: bool) -> str:

@@ -108,6 +108,14 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base) {  // raw buffer, b
   const uint64_t b = reinterpret_cast<uint64_t>(base);
   return i32x4{(int)(uint32_t)b, (int)((uint32_t)(b >> 32) & 0xFFFFu), 0x7FFFFFFF, 0x00020000};
 }
+// the same for a base the compiler may have parked in a vector register (loop-carried uniform values under scalar-register
+// pressure: an "s" operand fed from one came out as v[0:3] — not an encodable descriptor)
+__device__ __forceinline__ i32x4 make_rsrc_uniform(const void* base) {
+  const uint64_t b = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+  return i32x4{(int)lo, (int)(hi & 0xFFFFu), 0x7FFFFFFF, 0x00020000};
+}
 __device__ __forceinline__ void wait_glds() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // SPLIT: the same kernel as the SELECTION stage of the exact f32 sweep.  Rows and queries arrive as split bf16 — per 32
@@ -215,43 +223,7 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs
 
   f32x4 acc[8][4];
 
-  // ---- compaction of the candidate buffers this wave owns (queries wib, wib + 8, ...): one buffer per 16 lanes ----
-  auto compact = [&]() __attribute__((always_inline)) {
-    const int lane = (int)lane_now();
-    const uint32_t bq = (uint32_t)wib + (uint32_t)WAVES * (uint32_t)lane;  // lane l looks at query wib + 8 l (l < 32)
-    const uint32_t cq = (lane < 32 && bq < nq_t) ? cnts[bq] : 0u;
-    uint64_t need = __ballot(cq > k);
-    const uint32_t li = (uint32_t)lane & 15u, grp = (uint32_t)lane >> 4;
-    while (need) {
-      int src[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        src[u] = -1;
-        if (need) {
-          src[u] = __ffsll((long long)need) - 1;
-          need &= need - 1;
-        }
-      }
-      const int mysrc = grp == 0 ? src[0] : (grp == 1 ? src[1] : (grp == 2 ? src[2] : src[3]));
-      const bool active = mysrc >= 0;
-      const uint32_t b = (uint32_t)wib + (uint32_t)WAVES * (uint32_t)(active ? mysrc : 0);
-      const uint32_t n = min(cnts[b], (uint32_t)CAP);
-      uint64_t* cb = cand + (size_t)b * CAP;
-      const bool mine = active && li < n;
-      const uint64_t key = mine ? cb[li] : kKeyInvalid;
-      uint32_t rank = 0;
-#pragma unroll
-      for (int j = 0; j < CAP; j++) {
-        const uint64_t kj = cb[j];
-        rank += ((uint32_t)j < n && kj < key) ? 1u : 0u;
-      }
-      // all reads of the group precede its writes (same wave: program order; LDS ops complete in order)
-      if (mine && rank < k) cb[rank] = key;
-      if (mine && rank == k - 1) tauk[b] = key;
-      if (active && li == 0) cnts[b] = k;
-    }
-  };
-
+#include "g16_compact.inc"
   uint32_t qcnt = 0;   // entries in this wave's queue (carried over while their candidate buffer is full)
   uint32_t epoch = 0;  // block-uniform: ++ per synchronisation point of the epilogue protocol
 
@@ -354,153 +326,277 @@ _Pragma("unroll") \
     }
     VDB_G16_STEP(a.KT - 1, false);  // the last k-tile: its closing barrier is the first sync point of the epilogue
     const bool more = it < total;
-    // =====================================================================================================
-    // last k-tile of a row tile: the accumulators hold 128 rows x 64 queries of dot products per wave
-    // =====================================================================================================
-    const bool last = !more;
-    mfma_drain();  // the matrix pipe has written every accumulator before the vector ALU reads one
-    const int lane = (int)lane_now();  // (shadows the kernel-scope lane: see lane_now)
-    // result mode (VDB_SEARCH_BRUTE_BF16): half_precision.rs's cosine — 0.0 when a norm is below f32::EPSILON; selection
-    // mode approximates the exact f32 cosine (0.0 only for a zero norm)
-    const bool halfp = a.qnorms == nullptr;
-    // Quick test: per query column t a lane reduces its 32 accumulators (rows 16 rf + 4 (l >> 4) + r of the wave's 128)
-    // with max and compares with a bound no element that matters can miss.  hm[t] = the lanes that MAY hold a survivor
-    // (wave-uniform masks: they are also the state carried through the rounds of the protocol below).
-    uint64_t hm[4];
-    {
-      const float* vnl = vns + wr * 128 + 4 * (lane >> 4);
-      float vmin = vnl[0], vmax = vmin, vsum = 0.0f;
-#pragma unroll
-      for (int rf = 0; rf < 8; rf++) {
-        const f32x4 vn = *reinterpret_cast<const f32x4*>(vnl + rf * 16);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          vmin = fminf(vmin, vn[r]);
-          vmax = fmaxf(vmax, vn[r]);
-          vsum += vn[r];  // NaN / inf / overflow-prone norms show up in the sum (min / max drop NaNs)
-        }
-      }
-      // (result mode: a row norm below f32::EPSILON means score 0.0 whatever the accumulator — no bound holds for the lane)
-      const bool force = !(vsum < 1e18f) | (halfp & (METRIC == kCosine) & (vmin < kHalfNormEps));
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const uint32_t b = wq * 64 + t * 16 + (lane & 15);
-        const uint64_t tkb = tauk[b];
-        const float tf = tkb == kKeyInvalid ? __uint_as_float(0xFF800000u) : key_score<HIB>(tkb);
-        const float cut = tf - (fabsf(tf) * 1.9073486e-6f + 1e-37f);  // 16-ulp margin
-        const float qnb = qn[b];
-        const float cutq = METRIC == kCosine ? cut * qnb : cut;
-        float mx = acc[0][t][0];
-#pragma unroll
-        for (int rf = 0; rf < 8; rf++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) mx = fmaxf(mx, acc[rf][t][r]);
-        // cosine: score = acc / (|q| |v|) >= cut  <=>  acc >= cutq |v|: the smallest |v| of the lane bounds it for cutq > 0,
-        // the largest for cutq <= 0 (rounding slack: the 16-ulp margin of cut).  A norm that is NaN / inf / huge (query
-        // or row): no bound holds, the lane is looked at.  fmaxf drops NaN accumulators: they only arise from such norms.
-        const float thr = METRIC == kCosine ? (cutq > 0.0f ? cutq * vmin : cutq * vmax) : cutq;
-        const bool hot = (b < nq_t) & (force | !(qnb < 1e18f) | (halfp & (METRIC == kCosine) & (qnb < kHalfNormEps)) | !(mx < thr));
-        hm[t] = __ballot(hot);
-      }
-    }
-    for (;;) {
-      ++epoch;
-      // ---- (1) look at the hot lanes, one at a time: its 32 elements of the column are spread over lanes 0..31
-      //      (v_readlane with a uniform source lane) and finished densely — exact score, key, test against the query's
-      //      k-th best key — and the survivors are parked in the wave's queue.  Cost per hot lane ~100 instructions,
-      //      whatever the number of survivors; a lane whose survivors do not fit the queue waits for the next round. ----
-      bool pend = false;
-#define VDB_G16_LOOK(T) \
-      while (hm[T] && !pend) { \
-        const int src = __ffsll((long long)hm[T]) - 1; \
-        float x = 0.0f; \
-_Pragma("unroll") \
-        for (int i = 0; i < 32; i++) { \
-          const float v = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(acc[i / 4][T][i % 4]), src)); \
-          x = lane == i ? v : x; \
-        } \
-        const uint32_t rl = (uint32_t)(wr * 128) + ((uint32_t)lane >> 2) * 16u + 4u * ((uint32_t)src >> 4) + ((uint32_t)lane & 3u); \
-        const uint32_t b = (uint32_t)(wq * 64 + (T) * 16) + ((uint32_t)src & 15u); \
-        const uint32_t row = rt * BM + (rl & 255u); \
-        const float score = halfp ? finish_score_half<METRIC>(x, qn[b], METRIC == kCosine ? vns[rl & 255u] : 1.0f) \
-                                  : finish_score<METRIC>(x, qn[b], METRIC == kCosine ? vns[rl & 255u] : 1.0f); \
-        const uint64_t key = make_key<HIB>(score, row); \
-        bool take = (lane < 32) & (row < a.n_rows) & (key < tauk[b]); \
-        if (take && a.alive) take = a.alive[row] != 0; /* soft-deleted rows are filtered where it is rare */ \
-        const uint64_t mt = __ballot(take); \
-        const uint32_t nt = (uint32_t)__popcll(mt); \
-        if (qcnt + nt > (uint32_t)QCAP) { /* does not fit: the lane stays hot for the next round */ \
-          pend = true; \
-          break; \
-        } \
-        hm[T] &= hm[T] - 1; \
-        if (take) { \
-          const uint32_t slot = qcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(mt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mt, 0u)); \
-          wq_keys[slot] = key; \
-          wq_qs[slot] = (uint8_t)b; \
-        } \
-        qcnt += nt; \
-      }
-      VDB_G16_LOOK(0)
-      VDB_G16_LOOK(1)
-      VDB_G16_LOOK(2)
-      VDB_G16_LOOK(3)
-#undef VDB_G16_LOOK
-      if (pend || (last && qcnt)) flags[0] = epoch;
-      __syncthreads();  // sync point `epoch` (first round: also the k-tile's closing barrier)
-      // ---- (2) buffers past k since the last sync point: compact them (everybody, between two barriers) ----
-      if (flags[1] == epoch) {
-        compact();
-        __syncthreads();
-      }
-      // ---- (3) append the queue to the candidate buffers; an entry whose buffer is full stays queued ----
-      bool want = false;
-      {
-        const uint64_t key = (uint32_t)lane < qcnt ? wq_keys[lane] : kKeyInvalid;
-        const uint32_t b = (uint32_t)lane < qcnt ? wq_qs[lane] : 0u;
-        bool full = false;
-        if (key != kKeyInvalid && key < tauk[b]) {
-          const uint32_t idx = atomicAdd(&cnts[b], 1u);
-          if (idx < (uint32_t)CAP) {
-            cand[(size_t)b * CAP + idx] = key;
-            want = idx >= k;  // past k: the k-th best can be tightened
-          } else {
-            full = true;
-            want = true;
-          }
-        }
-        const uint64_t mf = __ballot(full);
-        qcnt = (uint32_t)__popcll(mf);
-        if (full) {
-          const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mf, 0u));
-          wq_keys[slot] = key;  // slot <= lane and every lane has read its entry: no entry is overwritten before it is read
-          wq_qs[slot] = (uint8_t)b;
-        }
-      }
-      if (__ballot(want)) flags[1] = epoch + 1;
-      bool again = flags[0] == epoch;
-      if (last) {  // the block's last row tile: everything still queued must get in before the lists are written out
-        if (qcnt) flags[2] = epoch;
-        __syncthreads();
-        again |= flags[2] == epoch;
-      }
-      if (!again) break;
-    }
+#include "g16_epilogue.inc"
   }
 #undef VDB_G16_STEP
 #undef VDB_G16_ADVANCE
 #undef VDB_G16_GLDS
 #undef VDB_G16_REQ
-  __syncthreads();
-  compact();  // every buffer still holding more than k keys
-  __syncthreads();
-  const uint32_t lane_o = lane_now();
-  for (uint32_t b = wib; b < nq_t; b += WAVES) {
-    const uint32_t c = min(cnts[b], k);  // <= k entries, whatever order (the merge kernel scans them all)
-    uint64_t* out = a.part_keys + ((size_t)(q0 + b) * a.list_stride + a.list_off + g) * k;
-    for (uint32_t e = lane_o; e < k; e += 64) out[e] = e < c ? cand[(size_t)b * CAP + e] : kKeyInvalid;
-    if (a.blk_tau && lane_o == 0) a.blk_tau[(size_t)(q0 + b) * a.list_stride + a.list_off + g] = tauk[b];
+#include "g16_writeout.inc"
+}
+
+// =====================================================================================================================
+// sweep_topk_gemm_bf16_pp — the plain-bf16 instance as a PING-PONG pipeline (round 3).  Same tile (256 rows x 256 queries,
+// eight waves as 2 x 4, wave tile 128 x 64), same LDS image (two 64-KiB stages of 128-B lines, swizzle on the DMA's source
+// address), same epilogue text (g16_epilogue.inc) and therefore the same results; what changes is WHEN things happen:
+//   * the accumulators live in the accumulation registers ("+a": 128 AGPRs), which leaves the wave's 128 vector registers
+//     to fragments: the B fragments of a whole k-tile (64 queries x 64 k = 32 registers) and BOTH halves of the A
+//     fragments (2 x 64 rows x 64 k = 2 x 32 registers) are resident, so fragment reads can be placed a phase or more ahead
+//     of the products that use them;
+//   * a k-tile is four PHASES of 16 products — one quadrant (64 rows x 32 queries x 64 k) of the wave tile each — and the
+//     two wave rows run one barrier apart: while waves 0-3 multiply, waves 4-7 read fragments and issue LDS-DMA requests,
+//     and vice versa.  A SIMD holds one wave of each row, so its matrix pipe is fed by one wave while the other does
+//     everything else (MI355X_MICROARCH.md "Two waves per SIMD"; cdna_hip_programming.md, the 256^2 8-phase template);
+//   * the stage buffers are recycled per HALF-TILE (A rows 0-127 / 128-255, B queries 0-127 / 128-255: 16 KiB = two
+//     requests per wave), each half-tile of k-tile c + 2 requested into the slot of k-tile c as soon as its last reader is
+//     done, 1.5 k-tiles ahead of its first reader; waves wait with vmcnt(6) — three half-tiles stay in flight across every
+//     barrier, nothing ever waits for vmcnt(0) in the loop.
+// Schedule of k-tile c (buffer c & 1), per wave, "read" = ds_read_b128 into fragment registers, "req" = 2 LDS-DMA requests:
+//   phase 1: read B(c)            req B1(c+1)   | products (rows 0-63,   queries 0-31)
+//   phase 2: read A rows 64-127(c) req B0(c+2)  | products (rows 0-63,   queries 32-63)
+//   phase 3:                      req A0(c+2), vmcnt(6): A(c+1) has landed        | products (rows 64-127, queries 32-63)
+//   phase 4: read A rows 0-63(c+1) req A1(c+2), vmcnt(6): B(c+1) has landed       | products (rows 64-127, queries 0-31)
+// Every phase is [reads, requests, lgkmcnt(0), barrier, 16 products, barrier]; waves 4-7 start one barrier late.  A buffer
+// is read one phase after the wait + barrier that retire its requests, and re-requested at least one barrier after the
+// lgkmcnt(0) that retired its last reads (lifetimes: B half-tiles are read in phase 1 only, A half-tile wr in phases 4 (of
+// the k-tile before) and 2).  At the end of a row tile the two wave rows re-align (one extra barrier for waves 0-3), run
+// the epilogue protocol together, and waves 4-7 fall one barrier behind again.
+// What it buys, measured (profiles/r03c_*, r03e_*; 4 M x 768 x 1 024 queries): the matrix pipe is busy 0.56 of the cycles
+// instead of 0.51, wave-cycles fall 12 % — and the kernel is 3-4 % faster, because the board sits at its power limit under
+// both kernels (1 205-1 230 W; rocm-smi beside a sustained run) and answers the busier pipe with a lower shader clock
+// (2.13 -> 1.95 GHz).  Ablations of this kernel (no epilogue 5.03 ms; + no requests 3.75; + no fragment reads 3.39 = 0.74
+// of the bf16 peak with the matrix pipe saturated) say the same: under the cap time follows ENERGY — products, bytes
+// through L2 -> LDS -> registers — not how well the two overlap.  A second version with two 32-product phases per k-tile
+// (half the barriers, requests 4-5 segments ahead) measured within 1 % of this one.  The vendor GEMM (hipBLASLt through
+// torch.matmul) on the same box: 1 121-1 230 TFLOP/s for K = 768 shapes, 1 666 for 8192^3 (profiles/r03d_gemm_ceiling.log).
+// =====================================================================================================================
+__device__ __forceinline__ void mfma_acc(f32x4& c, const f32x4& a, const f32x4& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_acc_first(f32x4& c, const f32x4& a, const f32x4& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));
+}
+// the barrier in front of a phase's products: this wave's fragment reads have completed (their stage slots may be
+// re-requested by anybody who has passed the barrier); "memory": no LDS access moves across
+__device__ __forceinline__ void pp_barrier_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
+__device__ __forceinline__ void pp_wait_dma6() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+
+template <int METRIC>
+__global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a) {
+  constexpr bool HIB = true;  // Cosine / DotProduct
+  constexpr int BM = kG16BM, BN = kG16BN, WAVES = kG16Waves, CAP = kG16Cap, QCAP = kG16Queue;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* cand = reinterpret_cast<uint64_t*>(smem + kOffCand);   // [BN][CAP]
+  uint64_t* tauk = reinterpret_cast<uint64_t*>(smem + kOffTauk);   // [BN] k-th best key (kKeyInvalid: none)
+  uint32_t* cnts = reinterpret_cast<uint32_t*>(smem + kOffCnts);   // [BN]
+  float* qn = reinterpret_cast<float*>(smem + kOffQn);             // [BN] query norms (cosine)
+  float* vns = reinterpret_cast<float*>(smem + kOffVns);           // [BM] norms of the current row tile
+  volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(smem + kOffFlags);  // [0] again, [1] need, [2] last-again
+
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wib >> 2, wq = wib & 3;
+  uint64_t* wq_keys = reinterpret_cast<uint64_t*>(smem + kOffQueue + (size_t)wib * kQueueBytes);
+  uint8_t* wq_qs = reinterpret_cast<uint8_t*>(wq_keys + QCAP);
+
+  // block -> (query tile, row group), as in the kernel above
+  const uint32_t bid = blockIdx.x;
+  const uint32_t xcd = bid & 7u, slot_id = bid >> 3;
+  const uint32_t qt = slot_id % a.nqt;
+  const uint32_t g = (slot_id / a.nqt) * 8u + xcd;
+  const uint32_t q0 = qt * a.qper;
+  const uint32_t nq_t = min(a.qper, a.nq - q0);
+  const uint32_t k = a.k;
+  const uint16_t* queries = a.queries + (size_t)q0 * a.q_stride;
+
+  if (tid < BN) {
+    cnts[tid] = 0;
+    tauk[tid] = ((uint32_t)tid < nq_t && a.tau0) ? a.tau0[q0 + tid] : kKeyInvalid;
+    qn[tid] = 0.0f;
   }
+  if (tid < 4) flags[tid] = 0u;
+  __syncthreads();
+  if (a.qnorms) {
+    if ((uint32_t)tid < nq_t) qn[tid] = a.qnorms[q0 + tid];
+  } else {
+    for (uint32_t b = wib; b < nq_t; b += WAVES) {
+      const uint16_t* qp = queries + (size_t)b * a.q_stride;
+      float nacc = 0.0f;
+      for (uint32_t c = lane; c * 4 < a.dim; c += 64)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const uint32_t i = c * 4 + e;
+          if (i < a.dim) {
+            const float x = __uint_as_float((uint32_t)qp[i] << 16);
+            nacc = __builtin_fmaf(x, x, nacc);
+          }
+        }
+      const float n = sqrtf(butterfly_all(nacc));
+      if (lane == 0) qn[b] = n;
+    }
+  }
+  __syncthreads();
+  const uint32_t ntiles = (a.n_rows + BM - 1) / BM;
+  const uint32_t rt_first = a.row_tile0 + g;
+  const uint32_t my_tiles = rt_first < ntiles ? (ntiles - rt_first + a.G - 1) / a.G : 0;
+  const uint32_t total = my_tiles * a.KT;  // k-tiles of this block's flat (row tile, k-tile) stream; KT >= 2 (host)
+
+  // ---- LDS-DMA requests: wave w, request J fills the 1 KiB row block 8 J + w of the A (J < 4) or B (J >= 4) image; a
+  // ---- half-tile is two consecutive J.  Lane (r = l >> 3, p = l & 7) lands at row 8 rb + r, physical slot p, and fetches
+  // ---- logical slot p ^ ((row >> 1) & 7) (see the kernel above).
+  const uint32_t st_row = (uint32_t)wib * 8u + ((uint32_t)lane >> 3);
+  const uint32_t st_slot = ((uint32_t)lane & 7u) ^ ((st_row >> 1) & 7u);
+  const uint32_t voff_a = st_row * (uint32_t)a.row_stride * 2u + st_slot * 16u;
+  const uint32_t voff_b = st_row * (uint32_t)a.q_stride * 2u + st_slot * 16u;
+  const uint32_t soff_a = 64u * (uint32_t)a.row_stride * 2u, soff_b = 64u * (uint32_t)a.q_stride * 2u;
+  const unsigned char* rows_b = reinterpret_cast<const unsigned char*>(a.rows);
+  const unsigned char* queries_b = reinterpret_cast<const unsigned char*>(queries);
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr_t)smem;
+  const uint32_t lds_w = lds0 + (uint32_t)wib * 1024u;
+  // half-tile HALF (0, 1) of the A image of k-tile (RT, KT_) -> stage BUF; the same for B
+#define VDB_PP_REQ_A(HALF, RT, KT_, BUF) do { \
+    const i32x4 ra_ = make_rsrc_uniform(rows_b + ((size_t)(RT) * BM * a.row_stride + (size_t)(KT_) * 64) * 2); \
+    glds_b128(ra_, voff_a, (uint32_t)(2 * (HALF)) * soff_a, lds_w + (uint32_t)(BUF) * 65536u + (uint32_t)(2 * (HALF)) * 8192u); \
+    glds_b128(ra_, voff_a, (uint32_t)(2 * (HALF) + 1) * soff_a, lds_w + (uint32_t)(BUF) * 65536u + (uint32_t)(2 * (HALF) + 1) * 8192u); \
+  } while (0)
+#define VDB_PP_REQ_B(HALF, KT_, BUF) do { \
+    const i32x4 rb_ = make_rsrc_uniform(queries_b + (size_t)(KT_) * 128); \
+    glds_b128(rb_, voff_b, (uint32_t)(2 * (HALF)) * soff_b, lds_w + (uint32_t)(BUF) * 65536u + 32768u + (uint32_t)(2 * (HALF)) * 8192u); \
+    glds_b128(rb_, voff_b, (uint32_t)(2 * (HALF) + 1) * soff_b, lds_w + (uint32_t)(BUF) * 65536u + 32768u + (uint32_t)(2 * (HALF) + 1) * 8192u); \
+  } while (0)
+
+  // ---- fragment reads: lane (i = l & 15, kk = l >> 4) reads slot (4 m + kk) ^ ((i >> 1) & 7) of row i (+ 16 rows per fragment)
+  const int sw_i = (int)(((uint32_t)lane & 15u) >> 1) & 7;
+  const int rd_off = (int)((uint32_t)lane & 15u) * 128 + (((int)((uint32_t)lane >> 4) ^ sw_i) & 3) * 16;
+  const int rd_x = (sw_i & 4) << 4;
+  const int a_rd0 = wr * 128 * 128 + rd_off;
+  const int b_rd0 = 32768 + wq * 64 * 128 + rd_off;
+#define VDB_PP_READ_A(DST, RF0, BUF) do { \
+    const unsigned char* tb_ = smem + (size_t)(BUF) * 65536; \
+_Pragma("unroll") \
+    for (int rf_ = 0; rf_ < 4; rf_++) \
+_Pragma("unroll") \
+      for (int m_ = 0; m_ < 2; m_++) \
+        DST[rf_][m_] = *reinterpret_cast<const f32x4*>(tb_ + a_rd0 + ((m_ * 64) ^ rd_x) + ((RF0) + rf_) * 2048); \
+  } while (0)
+#define VDB_PP_READ_B(BUF) do { \
+    const unsigned char* tb_ = smem + (size_t)(BUF) * 65536; \
+_Pragma("unroll") \
+    for (int t_ = 0; t_ < 4; t_++) \
+_Pragma("unroll") \
+      for (int m_ = 0; m_ < 2; m_++) \
+        bv[t_][m_] = *reinterpret_cast<const f32x4*>(tb_ + b_rd0 + ((m_ * 64) ^ rd_x) + t_ * 2048); \
+  } while (0)
+  // 16 products: rows RF0 .. RF0 + 3 (fragments of AV) x queries T0, T0 + 1 x both 32-deep halves
+#define VDB_PP_MFMA(AV, RF0, T0, FIRST) do { \
+_Pragma("unroll") \
+    for (int m_ = 0; m_ < 2; m_++) \
+_Pragma("unroll") \
+      for (int rf_ = 0; rf_ < 4; rf_++) \
+_Pragma("unroll") \
+        for (int t_ = 0; t_ < 2; t_++) { \
+          if ((FIRST) && m_ == 0) mfma_acc_first(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
+          else mfma_acc(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
+        } \
+  } while (0)
+
+  f32x4 acc[8][4];
+  f32x4 bv[4][2], a0v[4][2], a1v[4][2];
+
+#include "g16_compact.inc"
+
+  uint32_t qcnt = 0;   // entries in this wave's queue (carried over while their candidate buffer is full)
+  uint32_t epoch = 0;  // block-uniform: ++ per synchronisation point of the epilogue protocol
+
+  // positions in the flat stream: (rt1, kt1) = k-tile c + 1, (rt2, kt2) = k-tile c + 2, both clamped to the last k-tile (a
+  // request past the end re-fetches the last k-tile into a slot nobody reads again: the request count per phase stays
+  // uniform, which is what the vmcnt(6) waits count on)
+  uint32_t rt1 = rt_first, kt1 = 0, rt2 = rt_first, kt2 = 0, n2 = 0;
+#define VDB_PP_NEXT2() do { \
+    rt1 = rt2; \
+    kt1 = kt2; \
+    if (n2 + 1 < total) { \
+      n2++; \
+      if (++kt2 == a.KT) { \
+        kt2 = 0; \
+        rt2 += a.G; \
+      } \
+    } \
+  } while (0)
+  uint32_t c = 0;  // k-tiles done
+  if (total) {
+    // prologue: k-tile 0 complete (stage 0), of k-tile 1 (stage 1) everything but B1 — the request order of the loop
+    VDB_PP_REQ_A(0, rt_first, 0, 0);
+    VDB_PP_REQ_A(1, rt_first, 0, 0);
+    VDB_PP_REQ_B(0, 0, 0);
+    VDB_PP_REQ_B(1, 0, 0);
+    VDB_PP_NEXT2();  // (rt2, kt2) = k-tile 1
+    VDB_PP_REQ_B(0, kt2, 1);
+    VDB_PP_REQ_A(0, rt2, kt2, 1);
+    VDB_PP_REQ_A(1, rt2, kt2, 1);
+    VDB_PP_NEXT2();  // (rt1, kt1) = k-tile 1, (rt2, kt2) = k-tile 2 (or the last)
+    pp_wait_dma6();  // k-tile 0 has landed (this wave's share; the barrier: everybody's)
+  }
+  pp_barrier();
+  if (total) VDB_PP_READ_A(a0v, 0, 0);  // A rows 0-63 of k-tile 0 (in the loop: read in phase 4 of the k-tile before)
+  if (wr == 1) pp_barrier();  // waves 4-7 run one barrier behind
+  // one k-tile: four phases (see the schedule above)
+#define VDB_PP_KTILE(FIRST, LAST) do { \
+    const uint32_t buf = c & 1u; \
+    /* phase 1 */ \
+    VDB_PP_READ_B(buf); \
+    VDB_PP_REQ_B(1, kt1, buf ^ 1u); \
+    if ((FIRST) && wib == 0) /* the row tile's norms (vns was last read in the epilogue before) */ \
+      glds_b128(make_rsrc_uniform(reinterpret_cast<const unsigned char*>(a.norms) + (size_t)rt * BM * 4), (uint32_t)lane * 16u, 0u, lds0 + (uint32_t)kOffVns); \
+    pp_barrier_reads_done(); \
+    VDB_PP_MFMA(a0v, 0, 0, FIRST); \
+    pp_barrier(); \
+    /* phase 2 */ \
+    VDB_PP_READ_A(a1v, 4, buf); \
+    VDB_PP_REQ_B(0, kt2, buf); \
+    pp_barrier_reads_done(); \
+    VDB_PP_MFMA(a0v, 0, 2, FIRST); \
+    pp_barrier(); \
+    /* phase 3 */ \
+    VDB_PP_REQ_A(0, rt2, kt2, buf); \
+    pp_wait_dma6(); \
+    pp_barrier_reads_done(); \
+    VDB_PP_MFMA(a1v, 4, 2, FIRST); \
+    pp_barrier(); \
+    /* phase 4 */ \
+    if (!(LAST)) VDB_PP_READ_A(a0v, 0, buf ^ 1u); /* (the last k-tile of a row tile: read behind the epilogue, which gets the registers) */ \
+    VDB_PP_REQ_A(1, rt2, kt2, buf); \
+    pp_wait_dma6(); \
+    pp_barrier_reads_done(); \
+    VDB_PP_MFMA(a1v, 4, 0, FIRST); \
+    pp_barrier(); \
+    VDB_PP_NEXT2(); \
+    c++; \
+  } while (0)
+
+  for (uint32_t rt = rt_first; rt < ntiles; rt += a.G) {
+    VDB_PP_KTILE(true, false);
+    for (uint32_t kt = 1; kt + 1 < a.KT; kt++) VDB_PP_KTILE(false, false);
+    VDB_PP_KTILE(false, true);
+    if (wr == 0) pp_barrier();  // waves 0-3 wait for the last products of waves 4-7: the block is aligned again
+    const bool more = c < total;
+#include "g16_epilogue.inc"
+    // A rows 0-63 of the next row tile's first k-tile (landed: waited for in phase 3 above).  Unconditional — behind the last
+    // row tile it reads a stage nobody uses: a conditional read would keep the OLD fragments alive across the epilogue
+    VDB_PP_READ_A(a0v, 0, c & 1u);
+    if (more && wr == 1) pp_barrier();  // ... and waves 4-7 fall one barrier behind again
+  }
+#undef VDB_PP_KTILE
+#undef VDB_PP_NEXT2
+#undef VDB_PP_MFMA
+#undef VDB_PP_READ_B
+#undef VDB_PP_READ_A
+#undef VDB_PP_REQ_B
+#undef VDB_PP_REQ_A
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // requests past the end must not land in LDS that is no longer ours
+#include "g16_writeout.inc"
 }
 
 // From a merged prefix top-k (internal rows + raw scores, merge_topk with ext_ids = nullptr): the query's bound for the
@@ -535,6 +631,26 @@ void sweep_gemm_bf16_plan(uint32_t nq, uint32_t row_lo, uint32_t row_hi, int n_c
   G = std::min(G, (ntiles + 7) / 8 * 8);
   p->G = G;
   p->blocks = (int)(G * p->nqt);
+}
+
+static bool pingpong_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("VELESDB_BF16_PP");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+template <int METRIC>
+static hipError_t launch_g16_pp(const Bf16GemmArgs& a, int blocks, hipStream_t st) {
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_gemm_bf16_pp<METRIC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  hipLaunchKernelGGL((sweep_topk_gemm_bf16_pp<METRIC>), dim3(blocks), dim3(512), kG16Lds, st, a);
+  return hipGetLastError();
 }
 
 template <int METRIC, bool SPLIT>
@@ -581,6 +697,7 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
   a.blk_tau = blk_tau;
   if (split)
     return metric == kCosine ? launch_g16<kCosine, true>(a, p.blocks, st) : launch_g16<kDot, true>(a, p.blocks, st);
+  if (pingpong_enabled()) return metric == kCosine ? launch_g16_pp<kCosine>(a, p.blocks, st) : launch_g16_pp<kDot>(a, p.blocks, st);
   return metric == kCosine ? launch_g16<kCosine, false>(a, p.blocks, st) : launch_g16<kDot, false>(a, p.blocks, st);
 }
 
