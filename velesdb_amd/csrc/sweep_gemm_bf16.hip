@@ -37,6 +37,7 @@ namespace vdb {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 
 constexpr int kG16BM = 256, kG16BN = 256, kG16Waves = 8;
 constexpr int kG16Cap = 12;     // candidate buffer entries per query (k <= kGemmBf16MaxK = 10)
@@ -133,7 +134,9 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs
   uint32_t* cnts = reinterpret_cast<uint32_t*>(smem + kOffCnts);   // [BN]
   float* qn = reinterpret_cast<float*>(smem + kOffQn);             // [BN] query norms (cosine)
   float* vns = reinterpret_cast<float*>(smem + kOffVns);           // [BM] norms of the current row tile
-  volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(smem + kOffFlags);  // [0] again, [1] need, [2] last-again
+  // [0] again, [1] need, [2] last-again.  An LDS-typed pointer: a volatile access through a generic pointer is a FLAT instruction,
+  // which counts on vmcnt as well — its wait drained every LDS-DMA request in flight, once per flag read
+  volatile lds_u32_t* flags = (volatile lds_u32_t*)(lds_ptr_t)(smem + kOffFlags);
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
@@ -326,7 +329,8 @@ _Pragma("unroll") \
     }
     VDB_G16_STEP(a.KT - 1, false);  // the last k-tile: its closing barrier is the first sync point of the epilogue
     const bool more = it < total;
-#include "g16_epilogue.inc"
+#include "g16_quicktest.inc"
+#include "g16_protocol.inc"
   }
 #undef VDB_G16_STEP
 #undef VDB_G16_ADVANCE
@@ -338,7 +342,7 @@ _Pragma("unroll") \
 // =====================================================================================================================
 // sweep_topk_gemm_bf16_pp — the plain-bf16 instance as a PING-PONG pipeline (round 3).  Same tile (256 rows x 256 queries,
 // eight waves as 2 x 4, wave tile 128 x 64), same LDS image (two 64-KiB stages of 128-B lines, swizzle on the DMA's source
-// address), same epilogue text (g16_epilogue.inc) and therefore the same results; what changes is WHEN things happen:
+// address), same epilogue text (g16_quicktest.inc, g16_protocol.inc) and therefore the same results; what changes is WHEN things happen:
 //   * the accumulators live in the accumulation registers ("+a": 128 AGPRs), which leaves the wave's 128 vector registers
 //     to fragments: the B fragments of a whole k-tile (64 queries x 64 k = 32 registers) and BOTH halves of the A
 //     fragments (2 x 64 rows x 64 k = 2 x 32 registers) are resident, so fragment reads can be placed a phase or more ahead
@@ -369,6 +373,10 @@ _Pragma("unroll") \
 // through L2 -> LDS -> registers — not how well the two overlap.  A second version with two 32-product phases per k-tile
 // (half the barriers, requests 4-5 segments ahead) measured within 1 % of this one.  The vendor GEMM (hipBLASLt through
 // torch.matmul) on the same box: 1 121-1 230 TFLOP/s for K = 768 shapes, 1 666 for 8192^3 (profiles/r03d_gemm_ceiling.log).
+// Idle time is not what the clock governor charges for either: an artificial bubble of 8 x 1 024 cycles per row tile
+// (+40 % cycles) cost 9 % of time — the shader clock rose from 2.01 to 2.30 GHz (profiles/r03g_idle_bubble_experiment.log);
+// conversely removing real bubbles (the scratch reloads and FLAT flag reads that used to drain the DMA queue in every
+// epilogue, the quick test of waves 0-3 moved beside the last products of waves 4-7) changed nothing measurable.
 // =====================================================================================================================
 __device__ __forceinline__ void mfma_acc(f32x4& c, const f32x4& a, const f32x4& b) {
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
@@ -392,7 +400,9 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a
   uint32_t* cnts = reinterpret_cast<uint32_t*>(smem + kOffCnts);   // [BN]
   float* qn = reinterpret_cast<float*>(smem + kOffQn);             // [BN] query norms (cosine)
   float* vns = reinterpret_cast<float*>(smem + kOffVns);           // [BM] norms of the current row tile
-  volatile uint32_t* flags = reinterpret_cast<volatile uint32_t*>(smem + kOffFlags);  // [0] again, [1] need, [2] last-again
+  // [0] again, [1] need, [2] last-again.  An LDS-typed pointer: a volatile access through a generic pointer is a FLAT instruction,
+  // which counts on vmcnt as well — its wait drained every LDS-DMA request in flight, once per flag read
+  volatile lds_u32_t* flags = (volatile lds_u32_t*)(lds_ptr_t)(smem + kOffFlags);
 
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
@@ -446,10 +456,24 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a
   // ---- LDS-DMA requests: wave w, request J fills the 1 KiB row block 8 J + w of the A (J < 4) or B (J >= 4) image; a
   // ---- half-tile is two consecutive J.  Lane (r = l >> 3, p = l & 7) lands at row 8 rb + r, physical slot p, and fetches
   // ---- logical slot p ^ ((row >> 1) & 7) (see the kernel above).
-  const uint32_t st_row = (uint32_t)wib * 8u + ((uint32_t)lane >> 3);
-  const uint32_t st_slot = ((uint32_t)lane & 7u) ^ ((st_row >> 1) & 7u);
-  const uint32_t voff_a = st_row * (uint32_t)a.row_stride * 2u + st_slot * 16u;
-  const uint32_t voff_b = st_row * (uint32_t)a.q_stride * 2u + st_slot * 16u;
+  // (the per-lane offsets live in registers only while the k-loop runs: they are re-derived from the lane id behind every
+  // epilogue — VDB_PP_LANE — instead of being carried across it, where they ended in scratch memory whose reloads are VMEM
+  // operations: the wait for them drained the whole LDS-DMA queue once per row tile)
+  uint32_t voff_a, voff_b;
+  int a_rd0, b_rd0, rd_x;
+#define VDB_PP_LANE() do { \
+    const uint32_t ln_ = lane_now(); \
+    const uint32_t st_row_ = (uint32_t)wib * 8u + (ln_ >> 3); \
+    const uint32_t st_slot_ = (ln_ & 7u) ^ ((st_row_ >> 1) & 7u); \
+    voff_a = st_row_ * (uint32_t)a.row_stride * 2u + st_slot_ * 16u; \
+    voff_b = st_row_ * (uint32_t)a.q_stride * 2u + st_slot_ * 16u; \
+    const int sw_i_ = (int)((ln_ & 15u) >> 1) & 7; \
+    const int rd_off_ = (int)(ln_ & 15u) * 128 + (((int)(ln_ >> 4) ^ sw_i_) & 3) * 16; \
+    rd_x = (sw_i_ & 4) << 4; \
+    a_rd0 = wr * 128 * 128 + rd_off_; \
+    b_rd0 = 32768 + wq * 64 * 128 + rd_off_; \
+  } while (0)
+  VDB_PP_LANE();
   const uint32_t soff_a = 64u * (uint32_t)a.row_stride * 2u, soff_b = 64u * (uint32_t)a.q_stride * 2u;
   const unsigned char* rows_b = reinterpret_cast<const unsigned char*>(a.rows);
   const unsigned char* queries_b = reinterpret_cast<const unsigned char*>(queries);
@@ -468,11 +492,6 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a
   } while (0)
 
   // ---- fragment reads: lane (i = l & 15, kk = l >> 4) reads slot (4 m + kk) ^ ((i >> 1) & 7) of row i (+ 16 rows per fragment)
-  const int sw_i = (int)(((uint32_t)lane & 15u) >> 1) & 7;
-  const int rd_off = (int)((uint32_t)lane & 15u) * 128 + (((int)((uint32_t)lane >> 4) ^ sw_i) & 3) * 16;
-  const int rd_x = (sw_i & 4) << 4;
-  const int a_rd0 = wr * 128 * 128 + rd_off;
-  const int b_rd0 = 32768 + wq * 64 * 128 + rd_off;
 #define VDB_PP_READ_A(DST, RF0, BUF) do { \
     const unsigned char* tb_ = smem + (size_t)(BUF) * 65536; \
 _Pragma("unroll") \
@@ -549,7 +568,7 @@ _Pragma("unroll") \
     VDB_PP_READ_B(buf); \
     VDB_PP_REQ_B(1, kt1, buf ^ 1u); \
     if ((FIRST) && wib == 0) /* the row tile's norms (vns was last read in the epilogue before) */ \
-      glds_b128(make_rsrc_uniform(reinterpret_cast<const unsigned char*>(a.norms) + (size_t)rt * BM * 4), (uint32_t)lane * 16u, 0u, lds0 + (uint32_t)kOffVns); \
+      glds_b128(make_rsrc_uniform(reinterpret_cast<const unsigned char*>(a.norms) + (size_t)rt * BM * 4), lane_now() * 16u, 0u, lds0 + (uint32_t)kOffVns); \
     pp_barrier_reads_done(); \
     VDB_PP_MFMA(a0v, 0, 0, FIRST); \
     pp_barrier(); \
@@ -580,15 +599,18 @@ _Pragma("unroll") \
     VDB_PP_KTILE(true, false);
     for (uint32_t kt = 1; kt + 1 < a.KT; kt++) VDB_PP_KTILE(false, false);
     VDB_PP_KTILE(false, true);
-    if (wr == 0) pp_barrier();  // waves 0-3 wait for the last products of waves 4-7: the block is aligned again
     const bool more = c < total;
-#include "g16_epilogue.inc"
+#include "g16_quicktest.inc"  // (waves 0-3: beside the last products of waves 4-7)
+    if (wr == 0) pp_barrier();  // waves 0-3 wait for the last products of waves 4-7: the block is aligned again
+#include "g16_protocol.inc"
     // A rows 0-63 of the next row tile's first k-tile (landed: waited for in phase 3 above).  Unconditional — behind the last
     // row tile it reads a stage nobody uses: a conditional read would keep the OLD fragments alive across the epilogue
+    VDB_PP_LANE();
     VDB_PP_READ_A(a0v, 0, c & 1u);
     if (more && wr == 1) pp_barrier();  // ... and waves 4-7 fall one barrier behind again
   }
 #undef VDB_PP_KTILE
+#undef VDB_PP_LANE
 #undef VDB_PP_NEXT2
 #undef VDB_PP_MFMA
 #undef VDB_PP_READ_B
