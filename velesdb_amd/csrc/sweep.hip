@@ -876,6 +876,107 @@ __global__ __launch_bounds__(256) void merge_topk(MergeArgs m) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The same merge by SELECTION, for queries whose partial lists fit the LDS (<= kMergeSelectMaxKeys slots, k <= 256).
+// merge_topk inserts one key at a time into a sorted list — ~1 000 cycles per insertion into a 64-entry list: the
+// selection stage's final merge (a 64-candidate pool per query out of ~3 300 slots) took 200 us per 1 024 queries.  Here:
+//   1. the valid keys are compacted into LDS (ballot + one LDS atomic per wave and 256 slots);
+//   2. the k-th smallest key is built bit by bit from the top: with P the bits decided so far, c = #{keys <= P | low bits all
+//      ones}; c < k means the k-th smallest has the bit set.  One ballot-count per wave and 256 keys, one LDS atomic per wave,
+//      one barrier per bit; it stops at the first bound that holds exactly k keys (typically after the ~35 leading bits);
+//   3. the <= k keys under the bound are compacted and ranked among themselves (one key per thread), and written in order.
+// Keys are distinct (a row sits in exactly one partial list; equal keys would still get distinct places: ties by position).
+// Output identical to merge_topk.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kMergeSelectMaxKeys = 7900;  // x 8 B + counters + a 256-key selection buffer: inside the default 64-KiB window
+constexpr uint32_t kMergeSelectMaxK = 256;
+template <bool HIB>
+__global__ __launch_bounds__(256) void merge_topk_select(MergeArgs m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const uint32_t tid = threadIdx.x;
+  const uint32_t qi = blockIdx.x;
+  if (m.active && (qi >= *m.active || (m.active_max && *m.active > m.active_max))) return;  // (uniform per block)
+  if (m.skip_cnt && *m.skip_cnt <= m.skip_le) return;
+  const uint32_t kin = m.k;
+  const uint32_t k = m.k_out ? m.k_out : m.k;
+  const uint32_t total = m.n_lists * kin;
+  uint64_t* ks = reinterpret_cast<uint64_t*>(smem);                       // [total] compacted keys
+  uint64_t* sel = ks + total;                                              // [kMergeSelectMaxK] the keys under the bound
+  uint32_t* cnt_s = reinterpret_cast<uint32_t*>(sel + kMergeSelectMaxK);  // [64] one counter per bit + [64] n, n_sel
+  const uint64_t* keys = m.part_keys + (size_t)qi * (m.list_stride ? m.list_stride : m.n_lists) * kin;
+  if (tid < 66) cnt_s[tid] = 0;
+  __syncthreads();
+  auto mbcnt = [](uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); };
+  for (uint32_t base = 0; base < total; base += 256) {
+    const uint32_t i = base + tid;
+    const uint64_t key = i < total ? keys[i] : kKeyInvalid;
+    const bool valid = key != kKeyInvalid;
+    const uint64_t mask = __ballot(valid);
+    uint32_t off = 0;
+    if (lane == 0 && mask) off = atomicAdd(&cnt_s[64], (uint32_t)__popcll(mask));
+    off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+    if (valid) ks[off + mbcnt(mask)] = key;
+  }
+  __syncthreads();
+  const uint32_t n = cnt_s[64];
+  const uint32_t cnt = min(n, k);
+  uint64_t bound = kKeyInvalid;  // every key passes
+  if (n > k) {
+    uint64_t P = 0;
+    for (int bit = 63; bit >= 0; bit--) {
+      const uint64_t cand = P | ((1ull << bit) - 1ull);
+      uint32_t wc = 0;
+      for (uint32_t base = 0; base < n; base += 256) {
+        const uint32_t i = base + tid;
+        wc += (uint32_t)__popcll(__ballot(i < n && ks[i] <= cand));
+      }
+      if (lane == 0 && wc) atomicAdd(&cnt_s[bit], wc);
+      __syncthreads();
+      const uint32_t c = cnt_s[bit];
+      if (c == k) {  // (block-uniform)
+        bound = cand;
+        break;
+      }
+      if (c < k) P |= 1ull << bit;
+      bound = P;  // after the last bit: P is the k-th smallest key itself
+    }
+  }
+  for (uint32_t base = 0; base < n; base += 256) {
+    const uint32_t i = base + tid;
+    const uint64_t key = i < n ? ks[i] : kKeyInvalid;
+    const bool take = i < n && key <= bound;
+    const uint64_t mask = __ballot(take);
+    uint32_t off = 0;
+    if (lane == 0 && mask) off = atomicAdd(&cnt_s[65], (uint32_t)__popcll(mask));
+    off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+    if (take) {
+      const uint32_t slot = off + mbcnt(mask);
+      if (slot < kMergeSelectMaxK) sel[slot] = key;
+    }
+  }
+  __syncthreads();
+  const uint32_t ns = min(cnt_s[65], kMergeSelectMaxK);  // == cnt for distinct keys
+  if (tid < ns) {
+    const uint64_t key = sel[tid];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < ns; j++) {
+      const uint64_t kj = sel[j];
+      rank += (kj < key || (kj == key && j < tid)) ? 1u : 0u;
+    }
+    if (rank < k) {
+      const uint32_t row = key_row(key);
+      m.out_ids[(size_t)qi * k + rank] = m.ext_ids ? m.ext_ids[row] : (uint64_t)row + m.row_base;
+      m.out_scores[(size_t)qi * k + rank] = key_score<HIB>(key);  // raw compute_distance value (search.rs:209)
+    }
+  }
+  for (uint32_t e = cnt + tid; e < k; e += 256) {
+    m.out_ids[(size_t)qi * k + e] = ~0ull;
+    m.out_scores[(size_t)qi * k + e] = __uint_as_float(0x7FC00000u);
+  }
+  if (tid == 0) m.out_n[qi] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------
 // packed-bit sweep for Hamming / Jaccard (simd_explicit.rs:234-287,372-443 on the exact
 // re-encoding bit = (x > 0.5)).  Lane per row; grid.y = query.  Rows are W words (16-B
 // aligned), read as dwordx4.  Algorithmic bytes per launch: n_rows * W * 4 per query.
@@ -1710,6 +1811,15 @@ void launch_max_norm(const float* norms, uint32_t n_rows, uint32_t* out_bits, hi
 }
 
 void launch_merge(bool hib, const MergeArgs& m, uint32_t nq, hipStream_t st) {
+  const uint64_t total = (uint64_t)m.n_lists * m.k;
+  if (total <= kMergeSelectMaxKeys && (m.k_out ? m.k_out : m.k) <= kMergeSelectMaxK) {  // selection: the whole query in LDS
+    const size_t lds_r = (size_t)total * 8 + (size_t)kMergeSelectMaxK * 8 + 66 * 4 + 8;
+    if (hib)
+      hipLaunchKernelGGL((merge_topk_select<true>), dim3(nq), dim3(256), lds_r, st, m);
+    else
+      hipLaunchKernelGGL((merge_topk_select<false>), dim3(nq), dim3(256), lds_r, st, m);
+    return;
+  }
   const size_t lds = ((size_t)4 * (m.k_out ? m.k_out : m.k) * 8 + 16 + 15) & ~(size_t)15;
   if (hib)
     hipLaunchKernelGGL((merge_topk<true>), dim3(nq), dim3(256), lds, st, m);
