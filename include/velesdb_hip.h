@@ -216,7 +216,9 @@ int32_t vdb_hip_index_search_rerank(vdb_hip_index* idx, const float* queries_row
  * outside the selection stage's shapes — < 80 queries, dim % 64 != 0, k > 10, < 65 536 rows — read their per-query verdicts back
  * once per <= 1 024-query chunk).  In HNSW mode d_out_n[i] ==
  * 0xFFFFFFFF marks a query whose LDS candidate list overflowed (needs very many exact distance
- * ties); the host variant above re-runs such batches with a larger list by itself. */
+ * ties) or, in calls of at most one query per CU, whose walk visited more nodes than the LDS visited set
+ * holds (> ~24 000 at ef <= 270); the host variant above re-runs such batches with a larger list and
+ * the HBM visited bitmaps by itself. */
 int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* idx, const float* d_queries, uint32_t nq,
                                        uint32_t k, uint32_t ef, int32_t mode, uint64_t* d_out_ids,
                                        float* d_out_scores, uint32_t* d_out_n, void* stream);

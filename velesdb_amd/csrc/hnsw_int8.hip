@@ -93,7 +93,7 @@ struct HnswInt8Args {
 // WAVES: 4 (a 256-thread block per query in flight) or 2: the traversal reads 772 bytes per visited node instead of 3 KB, so
 // a step's distance phase is short and the leader's serial part (pop, visited test-and-set, admission) dominates — at 142
 // registers a CU holds 12 waves: 3 queries in flight with four-wave blocks, 6 with two-wave blocks.
-template <int METRIC, int CPL, int NS, int WAVES>
+template <int METRIC, int CPL, int NS, int WAVES, bool VIS = false>
 __global__ __launch_bounds__(WAVES * 64) void hnsw_search_int8_kernel(HnswInt8Args A) {
   const HnswSearchArgs& a = A.s;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -116,6 +116,13 @@ __global__ __launch_bounds__(WAVES * 64) void hnsw_search_int8_kernel(HnswInt8Ar
   uint32_t* vlog = a.vlog + (size_t)blockIdx.x * a.vlog_cap;
   const DistCtx dc{a.rows, a.norms, a.bits, a.row_stride, a.dim, a.words};
   const uint32_t CW = A.codes.code_words;
+  // VIS: the exact visited set in LDS (VisSet, vdb_hnsw_device.hpp) instead of the HBM bitmap
+  const VisSet vs{reinterpret_cast<uint32_t*>(smem + a.vis_off), (1u << a.vis_log2) - 1u, 32u - a.vis_log2};
+  const uint32_t vis_limit = VIS ? (3u << a.vis_log2) / 4u : 0xFFFFFFFFu;
+  if (VIS) {
+    vs.clear(threadIdx.x, WAVES * 64);
+    __syncthreads();
+  }
 
   for (uint32_t qi = blockIdx.x; qi < a.nq; qi += gridDim.x) {
     const float* qp = a.queries + (size_t)qi * a.q_stride;
@@ -240,8 +247,12 @@ __global__ __launch_bounds__(WAVES * 64) void hnsw_search_int8_kernel(HnswInt8Ar
             n_dist += 1;
             list.insert(((uint64_t)d << 32) | cur, lane, overflow);
             if (lane == 0) {
-              atomicOr(&vis[cur >> 5], 1u << (cur & 31));
-              if (a.vlog_cap) vlog[0] = cur;
+              if (VIS) {
+                (void)vs.test_and_set(cur);
+              } else {
+                atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+                if (a.vlog_cap) vlog[0] = cur;
+              }
             }
             logn = 1;
             phase = Q_Z_POP;
@@ -253,6 +264,10 @@ __global__ __launch_bounds__(WAVES * 64) void hnsw_search_int8_kernel(HnswInt8Ar
               const uint64_t ckey = list.key_at(idx, lane);
               bool stop = false;
               if (list.size() >= ef) stop = (uint32_t)(ckey >> 32) > (uint32_t)(list.key_at(ef - 1, lane) >> 32);  // :341
+              if (!stop && VIS && logn + nbmax > vis_limit) {  // the LDS set could pass 3/4: the caller re-runs on the bitmap
+                overflow = 1;
+                stop = true;
+              }
               if (stop) {
                 phase = Q_FINISH;
               } else {
@@ -273,13 +288,13 @@ __global__ __launch_bounds__(WAVES * 64) void hnsw_search_int8_kernel(HnswInt8Ar
                   if (valid) {
                     if (base != 0) nb = L.nbr[(size_t)cnode * L.stride + t];
                     const uint32_t bit = 1u << (nb & 31);
-                    newly = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;
+                    newly = VIS ? vs.test_and_set(nb) : (atomicOr(&vis[nb >> 5], bit) & bit) == 0;
                   }
                   const uint64_t mask = __ballot(newly);
                   const uint32_t before = (uint32_t)__popcll(mask & lt_mask(lane));
                   if (newly) {
                     nb_id[m + before] = nb;
-                    if (logn + before < a.vlog_cap) vlog[logn + before] = nb;
+                    if (!VIS && logn + before < a.vlog_cap) vlog[logn + before] = nb;
                   }
                   m += (uint32_t)__popcll(mask);
                   logn += (uint32_t)__popcll(mask);
@@ -391,7 +406,10 @@ __global__ __launch_bounds__(WAVES * 64) void hnsw_search_int8_kernel(HnswInt8Ar
       }
     }
     const uint32_t nlog = ctl[2];
-    if (nlog <= a.vlog_cap) {
+    if (VIS) {
+      __syncthreads();
+      vs.clear(threadIdx.x, WAVES * 64);
+    } else if (nlog <= a.vlog_cap) {
       for (uint32_t i = threadIdx.x; i < nlog; i += WAVES * 64) vis[vlog[i] >> 5] = 0;
     } else {
       for (uint64_t i = threadIdx.x; i < a.vis_words; i += WAVES * 64) vis[i] = 0;
@@ -401,20 +419,37 @@ __global__ __launch_bounds__(WAVES * 64) void hnsw_search_int8_kernel(HnswInt8Ar
 }
 
 // ---- host side -----------------------------------------------------------------------------
-template <int METRIC, int CPL, int NS, int WAVES>
-static hipError_t launch_i8_w(const HnswInt8Args& A, int slots, size_t lds, hipStream_t st) {
+template <int METRIC, int CPL, int NS, int WAVES, bool VIS>
+static hipError_t launch_i8_wv(const HnswInt8Args& A, int slots, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_search_int8_kernel<METRIC, CPL, NS, WAVES>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_search_int8_kernel<METRIC, CPL, NS, WAVES, VIS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   int occ = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, hnsw_search_int8_kernel<METRIC, CPL, NS, WAVES>, WAVES * 64, lds);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, hnsw_search_int8_kernel<METRIC, CPL, NS, WAVES, VIS>, WAVES * 64, lds);
   if (e != hipSuccess) return e;
   occ = std::max(1, std::min(occ, kTraversalSlotsPerCu));
   const int grid = (int)std::min<int64_t>((int64_t)slots, (int64_t)A.s.n_cus * occ);
-  hipLaunchKernelGGL((hnsw_search_int8_kernel<METRIC, CPL, NS, WAVES>), dim3(grid), dim3(WAVES * 64), lds, st, A);
+  hipLaunchKernelGGL((hnsw_search_int8_kernel<METRIC, CPL, NS, WAVES, VIS>), dim3(grid), dim3(WAVES * 64), lds, st, A);
   return hipGetLastError();
+}
+// VELESDB_INT8_VIS_LDS: 0 = HBM bitmaps, 1 = the exact LDS visited set (2^14 entries = 64 KiB: two queries in flight per CU);
+// unset = the measured default
+static const int g_i8_vis = [] {
+  const char* e = getenv("VELESDB_INT8_VIS_LDS");
+  return e ? atoi(e) : -1;
+}();
+template <int METRIC, int CPL, int NS, int WAVES>
+static hipError_t launch_i8_w(const HnswInt8Args& A0, int slots, size_t lds, hipStream_t st) {
+  HnswInt8Args A = A0;
+  const uint32_t lg = 14;
+  const bool use = A0.s.vis_log2 != 0 && g_i8_vis == 1 && (uint64_t)A0.s.ef * 90 + A0.s.nbmax <= (3ull << lg) / 4 &&
+                   lds + ((size_t)4 << lg) <= 160 * 1024;
+  A.s.vis_log2 = use ? lg : 0u;
+  A.s.vis_off = (uint32_t)lds;
+  if (use) return launch_i8_wv<METRIC, CPL, NS, WAVES, true>(A, slots, lds + ((size_t)4 << lg), st);
+  return launch_i8_wv<METRIC, CPL, NS, WAVES, false>(A, slots, lds, st);
 }
 template <int METRIC, int CPL, int NS>
 static hipError_t launch_i8_ns(const HnswInt8Args& A, int slots, size_t lds, hipStream_t st) {
@@ -542,6 +577,7 @@ int32_t hnsw_search_int8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_str
   a.metric = ix->metric;
   a.n_cus = (uint32_t)ix->n_cus;
   a.list_slots = reg_list ? kSearchRegSlots : 0;
+  a.vis_log2 = cap_mult == 1 ? 1u : 0u;  // "the LDS visited set is allowed" (a re-run after an overflow takes the bitmap)
   A.codes = CodeCtx{ix->codes.as<uint32_t>(), ix->codes_sq.as<uint32_t>(), ix->code_words};
   A.min_vals = ix->sq_min.as<float>();
   A.scales = ix->sq_scale.as<float>();

@@ -59,7 +59,7 @@ enum Phase : int {
 // verdicts select, in list order, which of the evaluated distances are admitted.  Same ids, scores and counters (n_dist counts
 // the unvisited neighbours, as the reference's loop evaluates them); the rows of visited neighbours are wasted bandwidth that a
 // single query has to spare.
-template <int METRIC, int CPL, int NS, bool LAT = false>
+template <int METRIC, int CPL, int NS, bool LAT = false, bool VIS = false>
 __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearchArgs a) {
   constexpr bool BITS = (METRIC == kHamming || METRIC == kJaccard);
   constexpr int WAVES = LAT ? 16 : 4, TPB = WAVES * 64, RR = LAT ? 4 : 8;
@@ -78,6 +78,13 @@ __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearc
 
   uint32_t* vis = a.visited + (size_t)blockIdx.x * a.vis_words;
   uint32_t* vlog = a.vlog + (size_t)blockIdx.x * a.vlog_cap;
+  // VIS: the exact visited set in LDS (zero between queries); a query stops with the overflow flag before it is 3/4 full
+  const VisSet vs{reinterpret_cast<uint32_t*>(smem + a.vis_off), (1u << a.vis_log2) - 1u, 32u - a.vis_log2};
+  const uint32_t vis_limit = VIS ? (3u << a.vis_log2) / 4u : 0xFFFFFFFFu;
+  if (VIS) {
+    vs.clear(threadIdx.x, TPB);
+    __syncthreads();
+  }
   const int d4 = (int)((a.dim + 3) / 4);
   const DistCtx dc{a.rows, a.norms, a.bits, a.row_stride, a.dim, a.words};
 
@@ -195,8 +202,12 @@ __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearc
             n_dist += 1;
             list.insert(make_key<false>(d, cur), lane, overflow);
             if (lane == 0) {
-              atomicOr(&vis[cur >> 5], 1u << (cur & 31));
-              if (a.vlog_cap) vlog[0] = cur;
+              if (VIS) {
+                (void)vs.test_and_set(cur);
+              } else {
+                atomicOr(&vis[cur >> 5], 1u << (cur & 31));
+                if (a.vlog_cap) vlog[0] = cur;
+              }
             }
             logn = 1;
             phase = P_Z_POP;
@@ -208,6 +219,10 @@ __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearc
               const uint64_t ckey = list.key_at(idx, lane);
               bool stop = false;
               if (list.size() >= ef) stop = key_dist(ckey) > key_dist(list.key_at(ef - 1, lane));  // graph.rs:474
+              if (!stop && VIS && logn + nbmax > vis_limit) {  // the LDS set could pass 3/4: the caller re-runs on the bitmap
+                overflow = 1;
+                stop = true;
+              }
               if (stop) {
                 phase = P_FINISH;
               } else {
@@ -234,13 +249,13 @@ __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearc
                     if (valid) {
                       if (base != 0) nb = L.nbr[(size_t)cnode * L.stride + t];
                       const uint32_t bit = 1u << (nb & 31);
-                      newly = (atomicOr(&vis[nb >> 5], bit) & bit) == 0;  // visited.insert (graph.rs:499)
+                      newly = VIS ? vs.test_and_set(nb) : (atomicOr(&vis[nb >> 5], bit) & bit) == 0;  // visited.insert (graph.rs:499)
                     }
                     const uint64_t mask = __ballot(newly);
                     const uint32_t before = (uint32_t)__popcll(mask & lt_mask(lane));
                     if (newly) {
                       nb_id[m + before] = nb;
-                      if (logn + before < a.vlog_cap) vlog[logn + before] = nb;
+                      if (!VIS && logn + before < a.vlog_cap) vlog[logn + before] = nb;
                     }
                     m += (uint32_t)__popcll(mask);
                     logn += (uint32_t)__popcll(mask);
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearc
           } else if (phase == P_Z_ADMIT) {
             if (LAT) {  // the unvisited ones of the evaluated neighbours, in list order: counters and the undo log
               n_dist += (uint32_t)__popcll(spec_mask);
-              if (spec_mask >> lane & 1ull) {
+              if (!VIS && (spec_mask >> lane & 1ull)) {
                 const uint32_t pos = logn + (uint32_t)__popcll(spec_mask & lt_mask(lane));
                 if (pos < a.vlog_cap) vlog[pos] = nb_id[lane];
               }
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearc
       if (spec_lane) {  // visited.insert (graph.rs:499) for every neighbour, in flight beside the row fetches below
         const uint32_t nb = nb_id[lane];
         spec_bit = 1u << (nb & 31);
-        spec_old = atomicOr(&vis[nb >> 5], spec_bit);
+        spec_old = VIS ? (vs.test_and_set(nb) ? 0u : spec_bit) : atomicOr(&vis[nb >> 5], spec_bit);
       }
       if (BITS)
         dist_phase_bits<METRIC>(dc, qbits, m, nb_id, nb_d, raw);
@@ -412,7 +427,10 @@ __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearc
     }
     // ---- undo the visited bits of this query ----
     const uint32_t nlog = ctl[2];
-    if (nlog <= a.vlog_cap) {
+    if (VIS) {
+      __syncthreads();  // (ctl[2] read by everybody before the next query's leader rewrites it)
+      vs.clear(threadIdx.x, TPB);
+    } else if (nlog <= a.vlog_cap) {
       for (uint32_t i = threadIdx.x; i < nlog; i += TPB) vis[vlog[i] >> 5] = 0;
     } else {
       for (uint64_t i = threadIdx.x; i < a.vis_words; i += TPB) vis[i] = 0;
@@ -432,32 +450,40 @@ size_t hnsw_lds_bytes(uint32_t cap, uint32_t nbmax, uint32_t dim, uint32_t words
 }
 
 // latency mode: one 1 024-thread block per query (at most one query per CU per call)
-template <int METRIC, int CPL>
-static hipError_t launch_lat(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
+template <int METRIC, int CPL, bool VIS>
+static hipError_t launch_lat_v(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_search_kernel<METRIC, CPL, kSearchRegSlots, true>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_search_kernel<METRIC, CPL, kSearchRegSlots, true, VIS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((hnsw_search_kernel<METRIC, CPL, kSearchRegSlots, true>), dim3(slots), dim3(1024), lds, st, a);
+  hipLaunchKernelGGL((hnsw_search_kernel<METRIC, CPL, kSearchRegSlots, true, VIS>), dim3(slots), dim3(1024), lds, st, a);
   return hipGetLastError();
 }
-template <int METRIC, int CPL, int NS>
-static hipError_t launch_ns(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
+template <int METRIC, int CPL>
+static hipError_t launch_lat(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
+  return a.vis_log2 ? launch_lat_v<METRIC, CPL, true>(a, slots, lds, st) : launch_lat_v<METRIC, CPL, false>(a, slots, lds, st);
+}
+template <int METRIC, int CPL, int NS, bool VIS>
+static hipError_t launch_ns_v(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_search_kernel<METRIC, CPL, NS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_search_kernel<METRIC, CPL, NS, false, VIS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   // resident blocks per CU of THIS instantiation (registers / LDS): a grid larger than what is resident would
   // queue whole blocks behind the persistent ones
   int occ = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, hnsw_search_kernel<METRIC, CPL, NS>, 256, lds);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, hnsw_search_kernel<METRIC, CPL, NS, false, VIS>, 256, lds);
   if (e != hipSuccess) return e;
   occ = std::max(1, std::min(occ, 4));
   const int grid = (int)std::min<int64_t>((int64_t)slots, (int64_t)a.n_cus * occ);
-  hipLaunchKernelGGL((hnsw_search_kernel<METRIC, CPL, NS>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((hnsw_search_kernel<METRIC, CPL, NS, false, VIS>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
+}
+template <int METRIC, int CPL, int NS>
+static hipError_t launch_ns(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
+  return a.vis_log2 ? launch_ns_v<METRIC, CPL, NS, true>(a, slots, lds, st) : launch_ns_v<METRIC, CPL, NS, false>(a, slots, lds, st);
 }
 // list_slots: 0 = LDS list (any ef), kSearchRegSlots = register list (ef + 64 <= kSearchRegSlots * 64)
 template <int METRIC, int CPL>
@@ -497,8 +523,28 @@ static const uint32_t g_hnsw_lat_max = [] {  // 0: one query per CU (the default
   return e ? (uint32_t)atoi(e) : 0u;
 }();
 
-hipError_t launch_hnsw_search(const HnswSearchArgs& a, int slots, hipStream_t st) {
-  const size_t lds = hnsw_lds_bytes(a.cap, a.nbmax, a.dim, a.words, a.metric);
+// VELESDB_HNSW_VIS_LDS: 0 = HBM bitmaps everywhere, 1 = the exact LDS set in the throughput kernel too (two blocks per CU
+// instead of four), unset = the measured default (see pick_vis)
+static const int g_hnsw_vis = [] {
+  const char* e = getenv("VELESDB_HNSW_VIS_LDS");
+  return e ? atoi(e) : -1;
+}();
+// the LDS visited set of a launch: 2^log2 entries behind the kernel's other LDS, or none.  A walk at ef visits ~75 ef nodes
+// (1 M x 768, M0 = 64: 9 570 at ef 128) and the kernel stops a query at 3/4 of the table (the caller re-runs it on the bitmap):
+// offered where that is unlikely.
+static uint32_t pick_vis(const HnswSearchArgs& a, size_t lds, bool lat) {
+  if (!a.vis_log2 || g_hnsw_vis == 0) return 0;  // (a.vis_log2 != 0 on entry: the caller allows it — not a re-run)
+  if (!lat && g_hnsw_vis != 1) return 0;
+  for (uint32_t lg = lat ? 15u : 14u; lg >= 14u; lg--) {
+    const uint64_t limit = (3ull << lg) / 4;
+    if ((uint64_t)a.ef * 90 + a.nbmax <= limit && lds + ((size_t)4 << lg) <= 160 * 1024) return lg;
+  }
+  return 0;
+}
+
+hipError_t launch_hnsw_search(const HnswSearchArgs& a0, int slots, hipStream_t st) {
+  HnswSearchArgs a = a0;
+  size_t lds = hnsw_lds_bytes(a.cap, a.nbmax, a.dim, a.words, a.metric);
   // at most one query per CU (measured at 1 M x 768, ef 128: 64 queries 1.57 ms against 2.68 ms on the throughput kernel, 256
   // queries 2.12 against 3.21 ms — a 1 024-thread block per CU is all the chip holds of this kernel) over a corpus that does not
   // sit in the 256 MB Infinity Cache: the latency-mode kernel (f32 metrics,
@@ -506,12 +552,18 @@ hipError_t launch_hnsw_search(const HnswSearchArgs& a, int slots, hipStream_t st
   // (10 K x 768: 408 us per query on the throughput kernel, 599 us in latency mode, whose speculation fetches visited rows too)
   if (g_hnsw_lat && a.nq <= (g_hnsw_lat_max ? g_hnsw_lat_max : a.n_cus) && (g_hnsw_lat >= 2 || (uint64_t)a.n_rows * a.row_stride * 4 >= (256ull << 20)) && a.list_slots == kSearchRegSlots && a.rerank_k == 0 && a.layers[0].stride <= 64 &&
       a.nbmax >= 64 && (a.metric == kCosine || a.metric == kEuclidean || a.metric == kDot)) {
+    a.vis_log2 = pick_vis(a0, lds, true);
+    a.vis_off = (uint32_t)lds;
+    if (a.vis_log2) lds += (size_t)4 << a.vis_log2;
     switch (a.metric) {
       case kCosine: return launch_lat_cpl<kCosine>(a, (int)a.nq, lds, st);
       case kEuclidean: return launch_lat_cpl<kEuclidean>(a, (int)a.nq, lds, st);
       default: return launch_lat_cpl<kDot>(a, (int)a.nq, lds, st);
     }
   }
+  a.vis_log2 = pick_vis(a0, lds, false);
+  a.vis_off = (uint32_t)lds;
+  if (a.vis_log2) lds += (size_t)4 << a.vis_log2;
   switch (a.metric) {
     case kCosine: return launch_cpl<kCosine>(a, slots, lds, st);
     case kEuclidean: return launch_cpl<kEuclidean>(a, slots, lds, st);
@@ -605,6 +657,7 @@ int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   a.metric = ix->metric;
   a.rerank_k = rerank_k;
   a.list_slots = reg_list ? kSearchRegSlots : 0;
+  a.vis_log2 = cap_mult == 1 ? 1u : 0u;  // "the LDS visited set is allowed" (a re-run after an overflow takes the bitmap)
   a.n_cus = (uint32_t)ix->n_cus;
   EventPair* ev = next_events(ix);
   if (ev) (void)hipEventRecord(ev->a, st);

@@ -83,6 +83,31 @@ __device__ __forceinline__ void list_insert(volatile uint64_t* keys, volatile ui
   cnt = newcnt;
 }
 
+// ---- exact visited set in LDS (round 3): open addressing over node id + 1 (0 = empty), linear probing, one LDS compare-
+// and-swap per probe.  The HBM bitmap costs a dependent memory round trip per expansion (atomicOr on a line that is rarely
+// in L2: 125 KB of bitmap per query in flight) between the neighbour ids and their rows; this costs ~100 cycles.  Exact: a
+// node is reported new exactly once.  The kernels stop a query (overflow flag -> the caller re-runs it on the bitmap) before
+// the table passes 3/4 of its entries, so a probe sequence always ends.
+struct VisSet {
+  uint32_t* tab;   // LDS, `mask + 1` entries
+  uint32_t mask;   // entries - 1 (a power of two)
+  uint32_t shift;  // 32 - log2(entries)
+  __device__ __forceinline__ bool test_and_set(uint32_t id) const {  // true: newly inserted (HashSet::insert, graph.rs:499)
+    const uint32_t key = id + 1u;
+    uint32_t h = (id * 0x9E3779B1u) >> shift;
+    for (;;) {
+      const uint32_t old = atomicCAS(&tab[h], 0u, key);
+      if (old == 0u) return true;
+      if (old == key) return false;
+      h = (h + 1u) & mask;
+    }
+  }
+  __device__ __forceinline__ void clear(uint32_t tid, uint32_t nthreads) const {  // every thread of the block
+    uint4* t4 = reinterpret_cast<uint4*>(tab);
+    for (uint32_t i = tid; i < (mask + 1u) / 4u; i += nthreads) t4[i] = uint4{0u, 0u, 0u, 0u};
+  }
+};
+
 // distance domain of a key: f32 (total-order bits, compared as raw floats like the reference does) or u32 (the
 // integer L2^2 of the int8 traversal, dual_precision.rs:336)
 template <bool UD>

@@ -125,10 +125,12 @@ struct HnswSearchArgs {
   int32_t metric;
   uint32_t n_cus;       // launch sizing only
   uint32_t list_slots;  // 0: candidate list in LDS; kSearchRegSlots: in registers (ef + 64 <= slots * 64)
+  uint32_t vis_log2;    // > 0: the visited set is an exact hash set of 2^vis_log2 entries in LDS at byte offset vis_off (VisSet,
+  uint32_t vis_off;     // vdb_hnsw_device.hpp) instead of the HBM bitmap; a query that would pass 3/4 of it reports overflow
   uint32_t rerank_k;  // > 0: search_with_rerank (search.rs:118-160): the first rerank_k results are re-scored with the
                       // raw compute_distance, stable-sorted in the metric's order and cut to k
 };
-size_t hnsw_lds_bytes(uint32_t cap, uint32_t nbmax, uint32_t dim, uint32_t words, int metric);
+size_t hnsw_lds_bytes(uint32_t cap, uint32_t nbmax, uint32_t dim, uint32_t words, int metric);  // without the visited set
 // returns hipSuccess or the launch error; grid = slots blocks of 256 threads
 hipError_t launch_hnsw_search(const HnswSearchArgs& a, int slots, hipStream_t st);
 
