@@ -65,7 +65,10 @@ def parse():
     p.add_argument("--select-level", type=int, default=2, choices=[0, 1, 2],
                    help="selection stage of large exact batches: 0 exact kernel, 1 split-bf16, 2 plain bf16 first (library default)")
     p.add_argument("--no-traffic-pass", action="store_true", help="skip the rocprofv3 FETCH_SIZE child pass that fills roofline.traffic")
-    p.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the child of the traffic pass: headline steps only
+    # the child of a traffic pass (run under rocprofv3 --pmc FETCH_SIZE by the parent): "headline" = the headline steps only,
+    # "hnsw" = the traversal leg over the graph files in --graph-dir, "bf16" = the configs[3] leg
+    p.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)
+    p.add_argument("--graph-dir", default="", help=argparse.SUPPRESS)
     p.add_argument("--no-latency-legs", action="store_true", help="skip the graph-path latency legs and the configs[0] leg")
     p.add_argument("--ef-curve", default="64,128,256,512", help="ef_search values of the recall / QPS curve of the graph legs")
     p.add_argument("--no-metrics-leg", action="store_true", help="skip the per-metric table (Euclidean / dot / Hamming / Jaccard sweeps)")
@@ -120,6 +123,36 @@ def main():
               "dot": va.DistanceMetric.DotProduct}[a.metric]
     N, D, K, Q = a.rows, a.dim, a.k, a.batch
 
+    if a.pmc_child in ("hnsw", "bf16"):  # traffic pass of another leg: the same launches, nothing else
+        stream_c = torch.cuda.current_stream().cuda_stream
+        gc_ = torch.Generator(device=dev)
+        if a.pmc_child == "hnsw":
+            ixc = va.HnswIndex(D, metric, va.HnswParams(a.M, a.efc, N), device=local)
+            ixc.load_reference_files(a.graph_dir, "native_hnsw")
+            nqc = a.hnsw_batch
+            mode_c, ef_c = va.MODE_HNSW, a.ef
+        else:
+            ixc = va.HnswIndex(D, metric, va.HnswParams(a.M, a.efc, a.bf16_rows), device=local)
+            ixc.enable_bf16()
+            gc_.manual_seed(45)
+            for base in range(0, a.bf16_rows, 1_000_000):
+                n_c = min(1_000_000, a.bf16_rows - base)
+                c = torch.randn((n_c, D), generator=gc_, device=dev)
+                torch.cuda.synchronize()
+                ixc.upload_dev(base, c.data_ptr(), n_c, stream_c)
+                del c
+            nqc = 1024
+            mode_c, ef_c = va.MODE_BRUTE_BF16, 0
+        gc_.manual_seed(43)
+        qc = torch.randn((nqc, D), generator=gc_, device=dev, dtype=torch.float32)
+        c_ids = torch.empty((nqc, K), dtype=torch.int64, device=dev)
+        c_sc = torch.empty((nqc, K), dtype=torch.float32, device=dev)
+        c_n = torch.empty((nqc,), dtype=torch.int32, device=dev)
+        for _ in range(a.warmup + a.steps):
+            ixc.search_batch_dev(qc.data_ptr(), nqc, K, ef_c, mode_c, c_ids.data_ptr(), c_sc.data_ptr(), c_n.data_ptr(), stream_c)
+        torch.cuda.synchronize()
+        return
+
     # ---- synthetic corpus, generated on the device (same seed on every rank = replica) ----
     g = torch.Generator(device=dev)
     g.manual_seed(42)
@@ -167,7 +200,7 @@ def main():
     for i in range(a.warmup):
         step(i)
     barrier()
-    if a.pmc_child:  # traffic pass (run under rocprofv3 --pmc FETCH_SIZE by the parent): the headline steps, nothing else
+    if a.pmc_child:  # "headline" traffic pass (run under rocprofv3 --pmc FETCH_SIZE by the parent): the headline steps, nothing else
         for i in range(a.steps):
             step(a.warmup + i)
         torch.cuda.synchronize()
@@ -307,48 +340,49 @@ def main():
                     "note": "one corpus pass serves `queries_per_launch` queries, so HBM bytes per QUERY are "
                             "alg_bytes/queries_per_launch; `tiles` lists every tile size"}
 
-    # HBM traffic of the headline step, measured in THIS run: rank 0 re-runs the headline steps in a child process under
-    # `rocprofv3 --pmc FETCH_SIZE` (its own pass, counters only + kernel trace; MI355X_MICROARCH.md HBM section: the counter
-    # is in KiB and reports half of the bytes of wide coalesced reads on gfx950 => x 1024 x 2) and sums the sweep's kernels.
-    if rank == 0 and world == 1 and not a.no_traffic_pass:
+    # HBM traffic, measured in THIS run: rank 0 re-runs a leg's launches in a child process under `rocprofv3 --pmc FETCH_SIZE`
+    # (its own pass, counters only + kernel trace; MI355X_MICROARCH.md HBM section: the counter is in KiB and reports half of
+    # the bytes of wide coalesced reads on gfx950 => x 1024 x 2) and sums the kernels named in `wanted`.
+    def traffic_pass(mode, wanted, extra, child_steps=3, child_warm=1, timeout=600):
+        """-> (bytes per step, {kernel: bytes per step}, source text); bytes is None when the pass failed"""
         import csv
         import glob
         import subprocess
         tdir = tempfile.mkdtemp(prefix="vdb_bench_pmc_")
         try:
-            child_steps, child_warm = 3, 1
             cmd = ["rocprofv3", "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", tdir, "--",
-                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", str(child_steps), "--warmup", str(child_warm),
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", mode, "--steps", str(child_steps), "--warmup", str(child_warm),
                    "--rows", str(N), "--dim", str(D), "--k", str(K), "--batch", str(Q), "--metric", a.metric,
-                   "--tile", str(a.tile), "--engine", str(a.engine), "--select-level", str(a.select_level)] + (["--no-split"] if a.no_split else [])
-            env = dict(os.environ, TMPDIR="/tmp")
-            pr = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+                   "--tile", str(a.tile), "--engine", str(a.engine), "--select-level", str(a.select_level)] + (["--no-split"] if a.no_split else []) + extra
+            pr = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
             files = glob.glob(os.path.join(tdir, "**", "*counter_collection.csv"), recursive=True)
-            if pr.returncode == 0 and files:
-                per_kernel = {}
-                for r in csv.DictReader(open(files[0])):
-                    if r.get("Counter_Name") != "FETCH_SIZE":
-                        continue
-                    name = r["Kernel_Name"]
-                    if not any(t in name for t in ("sweep_topk", "merge_topk", "split_rerank", "split_seed", "split_reseed",
-                                                   "select_fallback")):
-                        continue  # corpus upload / conversion, torch kernels
-                    short = name.split("(")[0].replace("void ", "")
-                    per_kernel[short] = per_kernel.get(short, 0.0) + float(r["Counter_Value"]) * 1024.0 * 2.0
-                nsteps = child_steps + child_warm
-                roofline["traffic"] = round(sum(per_kernel.values()) / nsteps)
-                roofline["traffic_by_kernel"] = {k2: round(v / nsteps) for k2, v in sorted(per_kernel.items(), key=lambda kv: -kv[1])[:4]}
-                roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / alg_bytes, 3)
-                roofline["traffic_source"] = (f"rocprofv3 --pmc FETCH_SIZE child pass of this run ({nsteps} headline steps), "
-                                              "bytes per step, x2 gfx950 correction applied")
-            else:
-                roofline["traffic_source"] = "traffic pass failed: " + (pr.stderr or "")[-200:]
+            if pr.returncode != 0 or not files:
+                return None, {}, "traffic pass failed: " + (pr.stderr or "")[-200:]
+            per_kernel = {}
+            for r in csv.DictReader(open(files[0])):
+                if r.get("Counter_Name") != "FETCH_SIZE":
+                    continue
+                name = r["Kernel_Name"]
+                if not any(t in name for t in wanted):
+                    continue  # corpus upload / conversion, torch kernels
+                short = name.split("(")[0].replace("void ", "")
+                per_kernel[short] = per_kernel.get(short, 0.0) + float(r["Counter_Value"]) * 1024.0 * 2.0
+            nsteps = child_steps + child_warm
+            return (round(sum(per_kernel.values()) / nsteps), {k2: round(v / nsteps) for k2, v in sorted(per_kernel.items(), key=lambda kv: -kv[1])[:4]},
+                    f"rocprofv3 --pmc FETCH_SIZE child pass of this run ({nsteps} steps of the leg), bytes per step, x2 gfx950 correction applied")
         except Exception as e:  # noqa: BLE001 - the traffic pass is diagnostic: never fail the bench line for it
-            roofline["traffic_source"] = f"traffic pass failed: {e!r}"[:300]
+            return None, {}, f"traffic pass failed: {e!r}"[:300]
         finally:
             shutil.rmtree(tdir, ignore_errors=True)
 
-    # ---- the same sweep at every tile size (queries per corpus pass), both engines ----
+    if rank == 0 and world == 1 and not a.no_traffic_pass:
+        tb_, tk_, tsrc_ = traffic_pass("headline", ("sweep_topk", "merge_topk", "split_rerank", "split_seed", "split_reseed", "select_fallback"), [])
+        roofline["traffic_source"] = tsrc_
+        if tb_ is not None:
+            roofline["traffic"] = tb_
+            roofline["traffic_by_kernel"] = tk_
+            roofline["traffic_over_algorithmic"] = round(tb_ / alg_bytes, 3)
+
     tiles = []
     if rank == 0 and not a.no_tiles:
         va.set_split_selector(False)  # the table shows the exact kernels at every batch size
@@ -552,18 +586,16 @@ def main():
                             "hbm_frac": round(ibytes / (ik_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ik_ms > 0 else 0.0}
             hstep()  # leave the f32 results in h_ids for the parity check below
             torch.cuda.synchronize()
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pt = json.load(f)
-            ent = pt.get("kernels", {}).get(hnsw["roofline"]["kernel"] + "@hnsw")
-            if ent:
-                hnsw["roofline"]["traffic"] = ent["fetch_bytes_per_launch"]
-                hnsw["roofline"]["traffic_source"] = pt.get("source", "profiles/pmc_traffic.json")
-        except (OSError, ValueError):
-            pass
-        if rank == 0 and not a.no_cpu_baseline:
+        if rank == 0 and (not a.no_cpu_baseline or (world == 1 and not a.no_traffic_pass)):
             graph_dir = tempfile.mkdtemp(prefix="vdb_bench_")
             ix.save(graph_dir, "native_hnsw")
+        if rank == 0 and world == 1 and not a.no_traffic_pass and graph_dir:
+            tb_, _, tsrc_ = traffic_pass("hnsw", ("hnsw_search_kernel",), ["--graph-dir", graph_dir, "--hnsw-batch", str(HQ), "--ef", str(a.ef),
+                                                                        "--M", str(a.M), "--efc", str(a.efc)], child_steps=2, child_warm=1)
+            hnsw["roofline"]["traffic"] = tb_
+            hnsw["roofline"]["traffic_source"] = tsrc_
+            if tb_ is not None:
+                hnsw["roofline"]["traffic_over_algorithmic"] = round(tb_ / hbytes, 3)
 
     # ---- exactness / recall check against the oracle on the full corpus (rank 0) ----
     recall = None
@@ -814,6 +846,18 @@ def main():
                                  "frac": round(ebytes / (ek_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ek_ms > 0 else 0.0,
                                  "traffic": None, "kernel_ms": round(ek_ms, 4), "alg_bytes_per_launch": ebytes}}
         hnsw_emb["ef_curve"] = gpu_ef_curve(ix2, q2, gt2, HQ, RQ)
+        if not a.no_traffic_pass:  # FETCH_SIZE of the same launch over the same graph, in a child pass of this run
+            gdt_ = tempfile.mkdtemp(prefix="vdb_bench_embt_")
+            try:
+                ix2.save(gdt_, "native_hnsw")
+                tb_, _, tsrc_ = traffic_pass("hnsw", ("hnsw_search_kernel",), ["--graph-dir", gdt_, "--hnsw-batch", str(HQ), "--ef", str(a.ef),
+                                                                            "--M", str(a.M), "--efc", str(a.efc)], child_steps=2, child_warm=1)
+                hnsw_emb["roofline"]["traffic"] = tb_
+                hnsw_emb["roofline"]["traffic_source"] = tsrc_
+                if tb_ is not None:
+                    hnsw_emb["roofline"]["traffic_over_algorithmic"] = round(tb_ / ebytes, 3)
+            finally:
+                shutil.rmtree(gdt_, ignore_errors=True)
         if not a.no_cpu_baseline:
             gd = tempfile.mkdtemp(prefix="vdb_bench_emb_")
             try:
@@ -999,6 +1043,14 @@ def main():
             bf16_leg["gpu_over_cpu"] = round(bf16_leg["qps"] / max(bf16_leg["cpu_baseline"]["value"], 1e-9), 1)
         ix3.close()
         torch.cuda.empty_cache()
+        if not a.no_traffic_pass:  # FETCH_SIZE of the timed region (seed sweep, LDS-DMA launches, merges) in a child pass of this run
+            tb_, tk_, tsrc_ = traffic_pass("bf16", ("sweep_topk_gemm", "merge_topk", "seed_tau", "round_queries_bf16"),
+                                           ["--bf16-rows", str(BR)], child_steps=2, child_warm=1)
+            bf16_leg["roofline"]["traffic"] = tb_
+            bf16_leg["roofline"]["traffic_source"] = tsrc_
+            if tb_ is not None:
+                bf16_leg["roofline"]["traffic_by_kernel"] = tk_
+                bf16_leg["roofline"]["traffic_over_algorithmic"] = round(tb_ / (BR * D * 2 + BR * 4 + BQ * D * 2), 3)
 
     # ---- the exact sweep for the other metrics of the path (N = 1 only): same N x D corpus (Hamming / Jaccard: the
     # reference's x > 0.5 threshold of it, swept as packed bits), one query per launch and --batch queries per launch
@@ -1133,6 +1185,20 @@ def main():
             ok = int(t_ok.item())
         if ok == 1:
             join_process_group(ix_sh, rank, world, dev)
+            # self-diagnosis of the first real multi-GPU run: what every rank's handle says about itself
+            inf = ix_sh.shard_info()
+            mine = torch.tensor([rank, inf["world"], inf["rank"], {"none": 0, "rccl": 1, "d2d-copy": 2}.get(inf["transport"], -1),
+                                 ix_sh.len()], device=dev, dtype=torch.int64)
+            allinf = [torch.zeros_like(mine) for _ in range(world)] if use_dist else [mine]
+            if use_dist:
+                dist.all_gather(allinf, mine)
+            per_rank = [{"rank": int(t[0]), "group_world": int(t[1]), "group_rank": int(t[2]),
+                         "transport": {0: "none", 1: "rccl", 2: "d2d-copy"}.get(int(t[3]), "?"), "rows": int(t[4])} for t in allinf]
+            sharded["per_rank"] = per_rank
+            sharded["group_ok"] = bool(all(r_["transport"] == "rccl" and r_["group_world"] == world and r_["group_rank"] == r_["rank"]
+                                           for r_ in per_rank))
+            if not sharded["group_ok"]:
+                sharded["error"] = "the shard group is not what --gpus asked for (see per_rank): every rank must report transport rccl, group_world == n_gpus"
 
             def sharded_step(i):
                 off = (i * Q) % (n_query_pool - Q + 1)  # every rank searches the SAME queries against ITS shard
@@ -1187,6 +1253,7 @@ def main():
                        "rows": N, "dim": D, "k": K, "queries_per_step": Q,
                        "parallelism": "replicas x%d (query stream split, no collective)" % world},
             "recall_at_10": recall, "parity_check": check,
+            "frac_step": (roofline.get("whole_batch") or {}).get("frac"),  # the headline's algorithmic flop over the WHOLE step's time / peak
             "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "tiles": tiles, "sharded": sharded,
             "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb, "config0_10k": config0, "bf16_gemm": bf16_leg, "sq8_storage_mode": sq8_leg, "other_metrics": metrics_leg,
             "device": va.device_name(local), "device_state": device_state,

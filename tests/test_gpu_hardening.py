@@ -342,3 +342,65 @@ def test_diagnostics_describe_the_last_call_only(gpu_required):
     assert ix.last_select_level() == 0 and ix.last_split_stats() == (0, 0)
     assert ix.last_kernels() == va.KERNEL_SWEEP_MFMA_F32
     ix.close()
+
+
+def test_concurrent_searches_on_one_handle_overlap(gpu_required):
+    """The reference takes a READ lock per search (index/hnsw/index/search.rs:80; stress tests native/tests.rs:264-416): many
+    threads search one index at once.  Here a search leases a context of the handle (scratch + stream; vdb_index.hpp) under a
+    shared lock, so single-query graph searches from several threads run side by side (each walk occupies one CU): 4 threads x
+    30 searches must finish in well under 4 x the time one thread needs for 30, with the sequential results bit for bit; the
+    per-thread diagnostics describe the calling thread's own search; an insert between two rounds is seen by every context."""
+    import time
+    rng = np.random.default_rng(8)
+    n, dim, k, per = 120_000, 768, 10, 30     # 368 MB of rows: the latency-mode traversal kernel (one 1 024-thread block per query)
+    rows = rng.standard_normal((n + 1, dim), dtype=np.float32)
+    qs = rng.standard_normal((4 * per, dim), dtype=np.float32)
+    ix = va.HnswIndex(dim, DM.Cosine, va.HnswParams(16, 100, n + 1))
+    ix.upload(np.arange(n), rows[:n])
+    ix.build_graph()
+    ref = [ix.search_with_quality(qs[i], k, SQ.Custom(128)) for i in range(4 * per)]
+    exact_ref = ix.search_batch_brute_force(qs[:8], k)
+    t0 = time.perf_counter()
+    for i in range(per):
+        ix.search_with_quality(qs[i], k, SQ.Custom(128))
+    t_one = time.perf_counter() - t0
+    out, errors, masks = [None] * (4 * per), [], [0] * 4
+
+    def worker(t):
+        try:
+            for i in range(t * per, (t + 1) * per):
+                out[i] = ix.search_with_quality(qs[i], k, SQ.Custom(128))
+            masks[t] = ix.last_kernels()
+            if t == 0:  # an exact sweep beside the walks of the other threads
+                e = ix.search_batch_brute_force(qs[:8], k)
+                assert np.array_equal(e[0], exact_ref[0]) and np.array_equal(bits(e[1]), bits(exact_ref[1]))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    t_four = time.perf_counter() - t0
+    assert not errors, errors[:3]
+    assert out == ref, "concurrent searches returned something else than the same searches one after the other"
+    assert all(m & va.KERNEL_HNSW for m in masks), masks
+    print(f"\n[concurrency] 30 searches on one thread: {t_one * 1e3:.1f} ms; 4 x 30 on four threads: {t_four * 1e3:.1f} ms "
+          f"({t_four / t_one:.2f} x)")
+    assert t_four < 2.6 * t_one, (t_one, t_four)   # serialised by one mutex this is >= 4 x
+    # a change of the index reaches every context: the new row is the nearest neighbour of itself from any thread
+    ix.insert(n, rows[n])
+    hits = []
+
+    def probe():
+        hits.append(ix.search_with_quality(rows[n], 1, SQ.Custom(64))[0][0])
+
+    th = [threading.Thread(target=probe) for _ in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert hits == [n] * 4, hits
+    ix.close()

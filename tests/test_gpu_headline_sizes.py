@@ -127,4 +127,66 @@ def test_hnsw_1m_vs_oracle(corpus, index, tmp_path, record_property):
     rsim = np.minimum(np.maximum(np.float32(1.0) - rd, np.float32(0.0)), np.float32(1.0))
     same = np.all(gid == ri, axis=1)
     assert np.all(np.abs(gsc[same] - rsim[same]) <= 1e-5 * np.maximum(np.abs(rsim[same]), 1e-3))
-    assert seq_diff <= nq // 20, "more than 5 % of the queries change their id list under the reference's summation order"
+    # measured: 0 of 1 024 (profiles/r02a_pytest_headline_sizes.log); pinned there with a small allowance — a drift of the GPU's
+    # arithmetic away from the reference's would show up here first
+    assert seq_diff <= 2, f"{seq_diff} of {nq} queries change their id list under the reference's summation order (measured: 0)"
+
+
+def test_configs3_full_size_10m_bf16_vs_oracle(gpu_required):
+    """BASELINE configs[3] at FULL size: 10 000 000 x 768 bf16, 1 024 queries per batch, k = 10 — the launch bench.py quotes
+    `bf16_gemm` on (seed sweep + two launches of sweep_topk_gemm_bf16_glds + merges, index.hip brute_bf16_dev).  The corpus is
+    generated chunk-wise on the device exactly as bench.py does and uploaded chunk by chunk; every chunk is also copied to the
+    host once, where the oracle (half_precision.rs:199-255 semantics) scans it for 32 sampled queries and the per-chunk lists are
+    merged — the same scan an index over all 10 M rows would get.  Compared by the rule of tests/test_gpu_bf16.py: same ids
+    wherever neighbouring oracle scores are further apart than the tolerance, scores within 2e-5 of the oracle's (two f32
+    summation orders), the k-th score not below the oracle's."""
+    torch = pytest.importorskip("torch")
+    BR, BQ, chunk, nsample = 10_000_000, 1024, 1_000_000, 32
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(45)
+    stream = torch.cuda.current_stream().cuda_stream
+    ix = va.HnswIndex(D, DM.Cosine, va.HnswParams(16, 100, BR))
+    ix.enable_bf16()
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(46)
+    qs = torch.randn((BQ, D), generator=gq, device=dev).cpu().numpy()
+    sample = np.unique(np.concatenate([[0, 255, 256, 1023], np.random.default_rng(7).integers(0, BQ, nsample)]))
+    best_i = np.empty((len(sample), 0), np.int64)
+    best_s = np.empty((len(sample), 0), np.float32)
+    nt = po.host_threads()
+    for base in range(0, BR, chunk):
+        c = torch.randn((chunk, D), generator=g, device=dev)
+        torch.cuda.synchronize()
+        ix.upload_dev(base, c.data_ptr(), chunk, stream)
+        torch.cuda.synchronize()
+        host = c.cpu().numpy()
+        del c
+        ei, es = po.scan_topk_bf16(po.COSINE, host, qs[sample], K, nthreads=nt)
+        del host
+        best_i = np.concatenate([best_i, ei.astype(np.int64) + base], axis=1)
+        best_s = np.concatenate([best_s, es], axis=1)
+        order = np.lexsort((best_i, -best_s.astype(np.float64)), axis=1)[:, :K]   # score descending, row ascending
+        best_i = np.take_along_axis(best_i, order, axis=1)
+        best_s = np.take_along_axis(best_s, order, axis=1)
+    gi, gs, gc = ix.search_batch_brute_force_bf16(qs, K)
+    assert ix.last_kernels() & va.KERNEL_GEMM_BF16_GLDS, "sweep_topk_gemm_bf16_glds did not serve the 10 M batch"
+    assert np.all(gc == K)
+    tol = 2e-5
+    differing = 0
+    for j, qi in enumerate(sample):
+        g_i, g_s = gi[qi].astype(np.int64), gs[qi].astype(np.float64)
+        e_i, e_s = best_i[j], best_s[j].astype(np.float64)
+        assert np.all(np.diff(g_s) <= 1e-12) and len(set(g_i.tolist())) == K
+        assert g_s[-1] >= e_s[-1] - tol, (qi,)
+        for r in range(K):
+            hit = np.nonzero(e_i == g_i[r])[0]
+            if len(hit):
+                assert abs(g_s[r] - e_s[hit[0]]) <= tol, (qi, r)      # the same row: the same score within two summation orders
+            else:
+                assert g_s[r] >= e_s[-1] - tol, (qi, r)                 # another row: only from inside a near-tie at the cut
+            if g_i[r] != e_i[r]:
+                differing += 1
+                assert abs(e_s[r] - g_s[r]) <= tol, (qi, r)             # a different row at this rank: a near-tie of scores
+    assert differing <= 2 * len(sample) // 10 + 2, differing               # (measured: 0)
+    ix.close()

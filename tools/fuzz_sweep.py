@@ -23,6 +23,8 @@ p.add_argument("--seed", type=int, default=1)
 p.add_argument("--big", action="store_true", help="few cases over 100K-400K rows (many row tiles / groups per wave and block)")
 p.add_argument("--select", action="store_true", help="batches that take the selection stage (>= 224 queries, >= 65 536 rows, "
                "k <= 10; levels 1 and 2 at random) incl. data built to defeat the proofs (gathered / GEMM fallbacks, level parking)")
+p.add_argument("--bf16-big", action="store_true", help="bf16 result batches that the 256 x 256 LDS-DMA kernel serves (>= 65 536 rows, "
+               ">= 224 queries, k <= 10 — BASELINE configs[3]'s kernel), asserted through last_kernels()")
 p.add_argument("--engine", type=int, default=1, help="0 = vector-ALU kernels for cosine / dot too")
 p.add_argument("--only-it", type=int, default=0, help="replay: generate every case, run only this one (verbose)")
 p.add_argument("--euclid", action="store_true", help="Euclidean only (matrix-core batches + exact re-scoring)")
@@ -57,7 +59,7 @@ def bits(x):
     return np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
 
 
-from test_gpu_bf16 import check as bf16_check  # noqa: E402
+from test_gpu_bf16 import check as bf16_check, check_sampled as bf16_check_sampled  # noqa: E402
 
 t_end = time.time() + a.seconds
 it = 0
@@ -93,6 +95,14 @@ while time.time() < t_end:
         va.set_split_selector(int(rng.choice([1, 2])))
         if rng.random() < 0.3:
             metric = DM.Euclidean
+    if a.bf16_big:
+        bf16 = True
+        metric = [DM.Cosine, DM.DotProduct][int(rng.integers(0, 2))]
+        n = int(rng.choice([66_000, 70_077, 150_000, 300_001, 600_000]))
+        dim = int(rng.choice([128, 192, 256, 768]))
+        nq = int(rng.choice([224, 256, 300, 480, 600, 700, 1024]))
+        k = int(rng.choice([1, 3, 10]))
+        kind = str(rng.choice(["normal", "normal", "dups", "small_ints", "zeros_mixed", "ascending"]))
     q0 = rng.standard_normal(dim).astype(np.float32)
     rows = make_rows("normal" if kind == "clusters" else kind, n, dim, q0)
     Q = rng.standard_normal((nq, dim)).astype(np.float32)
@@ -136,7 +146,37 @@ while time.time() < t_end:
             one = ix.search_batch_brute_force(Q[qi:qi + 1], k)
             print("   alone equal to oracle:", np.array_equal(one[0][0, :kk], eid[qi]), " count", gc[qi], one[2][0])
         sys.exit(0)
-    if bf16:
+    if bf16 and a.bf16_big:
+        ix.enable_bf16()
+        gi, gs, gc = ix.search_batch_brute_force_bf16(Q, k)
+        assert ix.last_kernels() & va.KERNEL_GEMM_BF16_GLDS, tag + " (not served by sweep_topk_gemm_bf16_glds)"
+        pm = po.COSINE if metric == DM.Cosine else po.DOT
+        sample = np.unique(np.concatenate([[0, nq - 1, 255 % nq, 256 % nq], rng.integers(0, nq, 12)]))
+        if kind == "small_ints":  # exact products: ids, ranks (ties by row) and score bits
+            eid, esc = po.scan_topk_bf16(pm, rows, Q[sample], kk, nthreads=NT)
+            assert np.array_equal(gi[sample][:, :kk], eid) and np.array_equal(bits(gs[sample][:, :kk]), bits(esc)), tag
+        elif kind in ("dups", "zeros_mixed", "ascending"):  # tie groups / near-ties everywhere: values only
+            rr64 = po.round_bf16(rows).astype(np.float64)
+            for qi in sample:
+                q64 = po.round_bf16(Q[qi]).astype(np.float64)
+                full = rr64 @ q64
+                scale = np.linalg.norm(rr64, axis=1) * np.linalg.norm(q64)
+                if metric == DM.Cosine:
+                    with np.errstate(invalid="ignore", divide="ignore"):
+                        full = np.where(scale >= 1.1920929e-7 ** 1, full / np.where(scale > 0, scale, 1.0), 0.0)
+                    tol = 1e-5 * np.ones_like(full)
+                else:
+                    tol = 1e-5 * np.maximum(scale, 1e-30)
+                g_i, g_s = gi[qi, :kk].astype(np.int64), gs[qi, :kk].astype(np.float64)
+                assert np.all(np.abs(g_s - full[g_i]) <= tol[g_i] + 1e-12), tag
+                kth = np.partition(full, n - kk)[n - kk]
+                assert g_s[-1] >= kth - tol.max() - 1e-12, tag
+                assert len(set(g_i.tolist())) == kk, tag
+            del rr64
+        else:
+            bf16_check_sampled(metric, pm, rows, Q, k, gi, gs, gc, sample)
+        stats["bf16"] += 1
+    elif bf16:
         ix.enable_bf16()
         gi, gs, gc = ix.search_batch_brute_force_bf16(Q, k)
         pm = po.COSINE if metric == DM.Cosine else po.DOT

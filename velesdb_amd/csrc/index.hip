@@ -88,13 +88,151 @@ static int32_t check_device(int32_t* n_out) {
   return VDB_OK;
 }
 
-int32_t enter_index(vdb_hip_index* ix) {
+int32_t enter_index(vdb_hip_index* ix, bool exclusive) {
   VDB_HIP(hipSetDevice(ix->device));
   if (ix->foreign_pending) {
     VDB_HIP(hipStreamWaitEvent(ix->stream, ix->ev_foreign, 0));
     ix->foreign_pending = false;
   }
+  if (exclusive) mark_changed(ix);  // (every exclusive entry point may change what searches read: contexts re-sync their views)
+  // (exclusive callers only touch a primary: its search contexts may have device-resident searches in flight on callers' streams
+  // or on their own; whatever changes the index waits for them — contexts are idle on the host side while mu is held exclusively)
+  if (exclusive && !ix->primary)
+    for (vdb_hip_index* c : ix->ctx_clones) {
+      if (c->foreign_pending) {
+        VDB_HIP(hipStreamWaitEvent(ix->stream, c->ev_foreign, 0));
+        c->foreign_pending = false;
+      }
+      VDB_HIP(hipEventRecord(c->ev_own, c->stream));
+      VDB_HIP(hipStreamWaitEvent(ix->stream, c->ev_own, 0));
+    }
   return VDB_OK;
+}
+
+// ---- search contexts (vdb_index.hpp) ----------------------------------------------------------------------------------
+void copy_image_fields(vdb_hip_index* c, const vdb_hip_index* p) {
+  c->norms = p->norms;
+  c->rows_split = p->rows_split;
+  c->split_enabled = p->split_enabled;
+  c->split_rows = p->split_rows;
+  c->sel_norms = p->sel_norms;
+  c->rows_bf16 = p->rows_bf16;
+  c->norms_bf16 = p->norms_bf16;
+  c->bf16_enabled = p->bf16_enabled;
+  c->bf16_stride = p->bf16_stride;
+  c->bf16_rows = p->bf16_rows;
+  c->l2_img = p->l2_img;
+  c->l2_seed = p->l2_seed;
+  c->l2_rows = p->l2_rows;
+  c->sq8_img = p->sq8_img;
+  c->sq8_nrm = p->sq8_nrm;
+  c->sq8_seed = p->sq8_seed;
+  c->sq8_img_rows = p->sq8_img_rows;
+}
+// every field a search READS about the index (non-owning views of the device buffers); scratch, stream, events, diagnostics and
+// the adaptive selection state stay the context's own
+static void copy_data_fields(vdb_hip_index* c, const vdb_hip_index* p) {
+  c->device = p->device;
+  c->n_cus = p->n_cus;
+  c->dim = p->dim;
+  c->metric = p->metric;
+  c->M = p->M;
+  c->M0 = p->M0;
+  c->efc = p->efc;
+  c->row_stride = p->row_stride;
+  c->words = p->words;
+  c->capacity = p->capacity;
+  c->n_rows = p->n_rows;
+  c->rows = p->rows;
+  c->bits = p->bits;
+  c->alive = p->alive;
+  c->ext_ids = p->ext_ids;
+  c->sq_min = p->sq_min;
+  c->sq_scale = p->sq_scale;
+  c->codes = p->codes;
+  c->codes_sq = p->codes_sq;
+  c->code_words = p->code_words;
+  c->quantizer_trained = p->quantizer_trained;
+  for (int i = 0; i < 5; i++) c->opt[i] = p->opt[i];
+  c->storage_mode = p->storage_mode;
+  c->sq8_stride = p->sq8_stride;
+  c->sq8_codes = p->sq8_codes;
+  c->sq8_min = p->sq8_min;
+  c->sq8_max = p->sq8_max;
+  c->sq8_nsq = p->sq8_nsq;
+  c->sign_bits = p->sign_bits;
+  c->layers = p->layers;
+  c->graph_valid = p->graph_valid;
+  c->entry_point = p->entry_point;
+  c->max_layer = p->max_layer;
+  c->graph_nodes = p->graph_nodes;
+  c->live = p->live;
+  c->any_dead = p->any_dead;
+  c->ndist_valid = p->ndist_valid;
+  copy_image_fields(c, p);
+}
+static thread_local vdb_hip_index* tl_ctx = nullptr;        // the context of this thread's last search ...
+static thread_local vdb_hip_index* tl_ctx_owner = nullptr;  // ... and the handle it belongs to
+vdb_hip_index* last_context(vdb_hip_index* ix) { return tl_ctx_owner == ix && tl_ctx ? tl_ctx : ix; }
+
+constexpr size_t kMaxSearchContexts = 4;  // the primary + up to three clones (each owns its scratch: ~0.3 GB at 1 M rows once it walked a graph)
+CtxLease::CtxLease(vdb_hip_index* ix) {
+  if (ix->ctx_mu.try_lock()) {
+    ctx = ix;
+  } else {
+    std::lock_guard<std::mutex> pl(ix->pool_mu);
+    for (vdb_hip_index* c : ix->ctx_clones)
+      if (c->ctx_mu.try_lock()) {
+        ctx = c;
+        break;
+      }
+    if (!ctx && ix->ctx_clones.size() + 1 < kMaxSearchContexts) {
+      std::unique_ptr<vdb_hip_index> c(new vdb_hip_index());
+      c->primary = ix;
+      c->device = ix->device;
+      hipError_t e = hipSetDevice(ix->device);
+      if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_foreign, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_own, hipEventDisableTiming);
+      if (e == hipSuccess) {
+        c->ctx_mu.lock();
+        ctx = c.get();
+        ix->ctx_clones.push_back(c.release());
+      } else {  // no second context: wait for the primary below
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        if (c->ev_foreign) (void)hipEventDestroy(c->ev_foreign);
+        if (c->ev_own) (void)hipEventDestroy(c->ev_own);
+        (void)hipGetLastError();
+      }
+    }
+  }
+  if (!ctx) {  // everything busy: queue for the primary
+    ix->ctx_mu.lock();
+    ctx = ix;
+  }
+  if (ctx != ix && ctx->synced_version != ix->version) {
+    // the index changed since this context last looked: the change's device work (on the primary's stream) is complete before
+    // a search on another stream reads it
+    hipError_t e = hipSetDevice(ix->device);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) rc = fail(VDB_ERR_HIP, std::string("search context: ") + hipGetErrorString(e));
+    copy_data_fields(ctx, ix);
+    ctx->synced_version = ix->version;
+  }
+  tl_ctx = ctx;
+  tl_ctx_owner = ix;
+}
+CtxLease::~CtxLease() {
+  if (ctx) ctx->ctx_mu.unlock();
+}
+// frees what a clone owns (scratch, stream, events); its views of the primary's buffers are dropped, not released
+static void destroy_clone(vdb_hip_index* c) {
+  const int dev = c->device;
+  vdb_hip_index blank;
+  copy_data_fields(c, &blank);  // every aliased DevBuf -> empty
+  c->device = dev;
+  c->primary = nullptr;
+  destroy_single(c);
 }
 
 // ---- capacity management: all per-row arrays grow together ---------------------------------
@@ -122,6 +260,12 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
   if (ix->bf16_enabled && ((e = ix->rows_bf16.reserve((ncap + kRowSlack) * ix->bf16_stride * 2, true, st)) != hipSuccess ||
                            (e = ix->norms_bf16.reserve((ncap + kRowSlack) * 4, true, st)) != hipSuccess))
     return fail(VDB_ERR_OOM, std::string("grow bf16 rows: ") + hipGetErrorString(e));
+  // the lazily built selection images grow HERE (exclusive lock), never inside a search (shared lock: other contexts hold views)
+  if (ix->l2_img.cap && (e = ix->l2_img.reserve((ncap + kRowSlack) * (size_t)(ix->dim + 64) * 2, true, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("grow Euclidean selection image: ") + hipGetErrorString(e));
+  if (ix->sq8_img.cap && ((e = ix->sq8_img.reserve((ncap + kRowSlack) * (size_t)(ix->dim + (ix->metric == VDB_EUCLIDEAN ? 64 : 0)) * 2, true, st)) != hipSuccess ||
+                          (e = ix->sq8_nrm.reserve((ncap + kRowSlack) * 4, true, st)) != hipSuccess))
+    return fail(VDB_ERR_OOM, std::string("grow SQ8 selection image: ") + hipGetErrorString(e));
   for (auto& L : ix->layers) {
     if ((e = L.nbr.reserve(ncap * L.stride * 4, true, st)) != hipSuccess ||
         (e = L.cnt.reserve(ncap * 4, true, st)) != hipSuccess ||
@@ -132,6 +276,7 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
       return fail(VDB_ERR_HIP, std::string("grow graph: ") + hipGetErrorString(e));
   }
   ix->capacity = ncap;
+  mark_changed(ix);
   return VDB_OK;
 }
 
@@ -438,7 +583,36 @@ static int blocks_for(const vdb_hip_index* ix, int B, uint32_t ngroups) {
 
 // ---- exact Cosine / DotProduct batches: split-bf16 selection + exact re-scoring + proof (sweep_split.hip) ----------------
 // first use: build the split image of every row (and the canonical norms a DotProduct index did not need so far)
+// (The three builders below run inside searches, i.e. under the SHARED lock: serialised by the primary's img_mu, always on the
+// primary's fields — a search context then takes over the views — and complete on the building search's stream before
+// another context may read the image.)
+static int32_t pinned_select_stats(vdb_hip_index* ix) {  // per context: the adaptive level state is the context's own
+  if (!ix->sel_stats) {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess) return fail(VDB_ERR_OOM, "pinned selection statistics");
+    memset(h, 0, 64);
+    ix->sel_stats = static_cast<volatile uint32_t*>(h);
+  }
+  return VDB_OK;
+}
+static int32_t ensure_split_impl(vdb_hip_index* ix, hipStream_t st);
+static int32_t ensure_sel16_impl(vdb_hip_index* ix, hipStream_t st);
+static int32_t ensure_l2_select_impl(vdb_hip_index* ix, hipStream_t st);
+template <class F>
+static int32_t build_image_on_primary(vdb_hip_index* ix, hipStream_t st, bool stale, F&& impl) {
+  vdb_hip_index* p = primary_of(ix);
+  std::lock_guard<std::mutex> il(p->img_mu);
+  const int32_t rc = impl(p, st);
+  if (rc != VDB_OK) return rc;
+  if (stale && !p->ctx_clones.empty()) VDB_HIP(hipStreamSynchronize(st));
+  if (ix != p) copy_image_fields(ix, p);
+  return VDB_OK;
+}
 static int32_t ensure_split(vdb_hip_index* ix, hipStream_t st) {
+  vdb_hip_index* p = primary_of(ix);
+  return build_image_on_primary(ix, st, !p->split_enabled || p->split_rows < p->n_rows, ensure_split_impl);
+}
+static int32_t ensure_split_impl(vdb_hip_index* ix, hipStream_t st) {
   if (!ix->split_enabled) {
     hipError_t e = ix->rows_split.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * (size_t)ix->dim * 4, false, st);
     if (e == hipSuccess) e = ix->norms.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * 4, ix->metric != VDB_DOT, st);
@@ -458,6 +632,11 @@ static int32_t ensure_split(vdb_hip_index* ix, hipStream_t st) {
 
 // level 2: the bf16 copy of the rows (what vdb_hip_index_enable_bf16 keeps) + canonical f32 norms for every metric
 static int32_t ensure_sel16(vdb_hip_index* ix, hipStream_t st) {
+  vdb_hip_index* p = primary_of(ix);
+  const int32_t rc = build_image_on_primary(ix, st, !p->bf16_enabled || p->bf16_rows < p->n_rows || !p->sel_norms, ensure_sel16_impl);
+  return rc != VDB_OK ? rc : pinned_select_stats(ix);
+}
+static int32_t ensure_sel16_impl(vdb_hip_index* ix, hipStream_t st) {
   hipError_t e;
   if (!ix->bf16_enabled) {
     ix->bf16_stride = ((uint64_t)ix->dim + 7) / 8 * 8;
@@ -486,12 +665,6 @@ static int32_t ensure_sel16(vdb_hip_index* ix, hipStream_t st) {
       if (pa.n_rows) launch_prep_rows(pa, st);
     }
     ix->sel_norms = true;
-  }
-  if (!ix->sel_stats) {
-    void* h = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess) return fail(VDB_ERR_OOM, "pinned selection statistics");
-    memset(h, 0, 64);
-    ix->sel_stats = static_cast<volatile uint32_t*>(h);
   }
   VDB_HIP(hipGetLastError());
   return VDB_OK;
@@ -543,6 +716,11 @@ static int select_level(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
 
 // Euclidean batches: augmented bf16 image + augmented f32 seed prefix (sweep_split.hip), built at first use, extended lazily
 static int32_t ensure_l2_select(vdb_hip_index* ix, hipStream_t st) {
+  vdb_hip_index* p = primary_of(ix);
+  const int32_t rc = build_image_on_primary(ix, st, p->l2_img.cap == 0 || p->l2_rows < p->n_rows, ensure_l2_select_impl);
+  return rc != VDB_OK ? rc : pinned_select_stats(ix);
+}
+static int32_t ensure_l2_select_impl(vdb_hip_index* ix, hipStream_t st) {
   const uint64_t cap = std::max<uint64_t>(ix->capacity, 1) + kRowSlack;
   const uint32_t dim_a = ix->dim + 64, dim_s = ix->dim + 4;
   hipError_t e;
@@ -555,12 +733,6 @@ static int32_t ensure_l2_select(vdb_hip_index* ix, hipStream_t st) {
                            ix->dim, st);
     ix->l2_rows = ix->n_rows;
     VDB_HIP(hipGetLastError());
-  }
-  if (!ix->sel_stats) {
-    void* h = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess) return fail(VDB_ERR_OOM, "pinned selection statistics");
-    memset(h, 0, 64);
-    ix->sel_stats = static_cast<volatile uint32_t*>(h);
   }
   return VDB_OK;
 }
@@ -1379,6 +1551,8 @@ void destroy_single(vdb_hip_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+  for (vdb_hip_index* c : ix->ctx_clones) destroy_clone(c);
+  ix->ctx_clones.clear();
   proc_comm_free(ix->pcomm);
   for (DevBuf* b : index_buffers(ix)) b->release();
   for (auto* pool : {&ix->ev_pool, &ix->sel_ev})
@@ -1483,7 +1657,9 @@ int32_t vdb_hip_index_last_split_stats(vdb_hip_index* ix, uint32_t* queries, uin
   return vdb::guarded([&]() -> int32_t {
     if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
     VDB_NO_GROUP(ix, "last_split_stats");
-    std::lock_guard<std::mutex> g(ix->mu);
+    std::shared_lock<std::shared_mutex> g(ix->mu);
+    ix = last_context(ix);  // the search context that served this thread's last search (the handle itself unless searches overlapped)
+    std::lock_guard<std::mutex> cg(ix->ctx_mu);
     VDB_HIP(hipSetDevice(ix->device));
     uint32_t nq = ix->split_flags_n, bad = 0;
     if (nq) {
@@ -1502,7 +1678,9 @@ int32_t vdb_hip_index_last_select_level(vdb_hip_index* ix, int32_t* level) {
   return vdb::guarded([&]() -> int32_t {
     if (!ix || !level) return fail(VDB_ERR_INVALID_ARG, "null argument");
     VDB_NO_GROUP(ix, "last_select_level");
-    std::lock_guard<std::mutex> g(ix->mu);
+    std::shared_lock<std::shared_mutex> g(ix->mu);
+    ix = last_context(ix);  // the search context that served this thread's last search (the handle itself unless searches overlapped)
+    std::lock_guard<std::mutex> cg(ix->ctx_mu);
     *level = ix->last_select_level;
     return VDB_OK;
   });
@@ -1511,9 +1689,9 @@ int32_t vdb_hip_index_last_select_level(vdb_hip_index* ix, int32_t* level) {
 int32_t vdb_hip_index_last_kernels(vdb_hip_index* ix, uint32_t* mask) {
   return vdb::guarded([&]() -> int32_t {
     if (!ix || !mask) return fail(VDB_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> g(ix->mu);
-    // a multi-device handle: what any shard ran
-    uint32_t m = ix->last_kernels;
+    std::shared_lock<std::shared_mutex> g(ix->mu);
+    // a multi-device handle: what any shard ran; a plain handle: the context of this thread's last search
+    uint32_t m = ix->group ? ix->last_kernels : last_context(ix)->last_kernels;
     if (ix->group)
       for (size_t s = 0; s < group_size(ix); s++) m |= group_shard(ix, s)->last_kernels;
     *mask = m;
@@ -1526,7 +1704,8 @@ int32_t vdb_hip_index_set_option(vdb_hip_index* ix, int32_t option, int64_t valu
     if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
     if (option < 0 || option > VDB_OPT_KERNEL_TIMING) return fail(VDB_ERR_INVALID_ARG, "unknown option");
     if (ix->group) return group_set_option(ix, option, value);
-    std::lock_guard<std::mutex> g(ix->mu);
+    std::lock_guard<std::shared_mutex> g(ix->mu);
+    mark_changed(ix);
     int32_t v = -1;  // negative: back to the process-wide default
     if (value >= 0) {
       switch (option) {
@@ -1557,7 +1736,7 @@ int32_t vdb_hip_index_get_option(vdb_hip_index* ix, int32_t option, int64_t* val
     if (!ix || !value) return fail(VDB_ERR_INVALID_ARG, "null argument");
     if (option < 0 || option > VDB_OPT_KERNEL_TIMING) return fail(VDB_ERR_INVALID_ARG, "unknown option");
     vdb_hip_index* c = ix->group ? group_first_shard(ix) : ix;
-    std::lock_guard<std::mutex> g(c->mu);
+    std::lock_guard<std::shared_mutex> g(c->mu);
     switch (option) {
       case VDB_OPT_MAX_QUERY_TILE: *value = opt_max_tile(c); break;
       case VDB_OPT_SWEEP_ENGINE: *value = opt_engine(c); break;
@@ -1654,7 +1833,7 @@ int32_t vdb_hip_index_insert(vdb_hip_index* ix, uint64_t id, const float* vec, u
     int32_t grc = group_insert(ix, &id, vec, 1, 0, 1, &gi);
     return grc != VDB_OK ? grc : (gi ? VDB_OK : VDB_DUPLICATE_IGNORED);
   }
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   VDB_ENTER(ix);
   uint64_t ins = 0, first = 0;
   int32_t rc = append_host_rows(ix, &id, vec, 1, &ins, &first);
@@ -1674,7 +1853,7 @@ int32_t vdb_hip_index_insert_batch(vdb_hip_index* ix, const uint64_t* ids, const
   return vdb::guarded([&]() -> int32_t {
   if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_insert(ix, ids, vecs, n, 0, 1, inserted);
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   VDB_ENTER(ix);
   uint64_t ins = 0, first = 0;
   int32_t rc = append_host_rows(ix, ids, vecs, n, &ins, &first);
@@ -1692,7 +1871,7 @@ int32_t vdb_hip_index_insert_batch_parallel(vdb_hip_index* ix, const uint64_t* i
   return vdb::guarded([&]() -> int32_t {
   if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_insert(ix, ids, vecs, n, 1, max_batch, inserted);
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   VDB_ENTER(ix);
   uint64_t ins = 0, first = 0;
   int32_t rc = append_host_rows(ix, ids, vecs, n, &ins, &first);
@@ -1709,7 +1888,7 @@ int32_t vdb_hip_index_train_quantizer(vdb_hip_index* ix, uint32_t sample_rows) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_for_all(ix, 3, sample_rows);
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   VDB_ENTER(ix);
   int32_t rc = quantizer_train(ix, sample_rows);
   if (rc == VDB_OK) VDB_HIP(hipStreamSynchronize(ix->stream));
@@ -1730,7 +1909,7 @@ int32_t vdb_hip_index_enable_bf16(vdb_hip_index* ix) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_for_all(ix, 1, 0);
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   if (ix->bf16_enabled) return VDB_OK;
   if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT)
     return fail(VDB_ERR_UNSUPPORTED, "bf16 sweep: Cosine and DotProduct only");
@@ -1757,7 +1936,7 @@ int32_t vdb_hip_index_build_graph(vdb_hip_index* ix, uint32_t max_batch) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_for_all(ix, 0, max_batch);
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   VDB_ENTER(ix);
   int32_t rc = VDB_OK;
   if (ix->graph_nodes < ix->n_rows) rc = graph_insert_rows(ix, ix->graph_nodes, ix->n_rows - ix->graph_nodes, max_batch);
@@ -1771,7 +1950,7 @@ int32_t vdb_hip_index_upload(vdb_hip_index* ix, const uint64_t* ids, const float
   return vdb::guarded([&]() -> int32_t {
   if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_insert(ix, ids, vecs, n, 2, 0, inserted);
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   VDB_ENTER(ix);
   uint64_t ins = 0, first = 0;
   int32_t rc = append_host_rows(ix, ids, vecs, n, &ins, &first);
@@ -1786,7 +1965,7 @@ int32_t vdb_hip_index_upload_dev(vdb_hip_index* ix, uint64_t id_base, const floa
   return vdb::guarded([&]() -> int32_t {
   if (!ix || (n && !d_vecs)) return fail(VDB_ERR_INVALID_ARG, "null argument");
   VDB_NO_GROUP(ix, "upload_dev (rows resident on one device)");
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   VDB_ENTER(ix);
   if (n == 0) return VDB_OK;
   for (uint64_t i = 0; i < n; i++)
@@ -1827,7 +2006,7 @@ int32_t vdb_hip_index_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_remove(ix, id, removed);
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   auto it = ix->id_to_idx.find(id);
   if (it == ix->id_to_idx.end()) {
     if (removed) *removed = 0;
@@ -1848,7 +2027,7 @@ int32_t vdb_hip_index_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed) {
 
 int32_t vdb_hip_index_len(const vdb_hip_index* ix, uint64_t* n) {  // trait_impl.rs:60-62 mappings.len()
   if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   *n = ix->live;
   return VDB_OK;
 }
@@ -1857,7 +2036,7 @@ int32_t vdb_hip_index_len(const vdb_hip_index* ix, uint64_t* n) {  // trait_impl
 int32_t vdb_hip_index_tombstone_count(const vdb_hip_index* ix, uint64_t* n) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   *n = ix->n_rows - ix->live;
   return VDB_OK;
   });
@@ -1872,7 +2051,7 @@ int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   VDB_NO_GROUP(ix, "vacuum");
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   VDB_ENTER(ix);
   const uint64_t n_old = ix->n_rows, n_live = ix->live;
   if (count) *count = n_live;
@@ -1953,7 +2132,7 @@ int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
 int32_t vdb_hip_index_node_count(const vdb_hip_index* ix, uint64_t* n) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   *n = ix->n_rows;
   return VDB_OK;
   });
@@ -1982,7 +2161,16 @@ int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* ix, const float* d_queries
   if (ix->group)
     return group_search_dev(ix, d_queries, nq, k, ef, mode, d_out_ids, d_out_scores, d_out_n,
                             reinterpret_cast<hipStream_t>(stream));
-  std::lock_guard<std::mutex> g(ix->mu);
+  // searches share the handle (search.rs:80 takes the read lock); a member of a process group searches collectively on one
+  // gather buffer: those calls stay exclusive
+  std::shared_lock<std::shared_mutex> rd(ix->mu, std::defer_lock);
+  std::unique_lock<std::shared_mutex> wr(ix->mu, std::defer_lock);
+  if (ix->pcomm) wr.lock(); else rd.lock();
+  CtxLease lease(ix);
+  if (lease.rc != VDB_OK) return lease.rc;
+  vdb_hip_index* const handle = ix;
+  ix = lease.ctx;
+  (void)handle;
   VDB_HIP(hipSetDevice(ix->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (st != ix->stream) {
@@ -1992,7 +2180,7 @@ int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* ix, const float* d_queries
     VDB_HIP(hipStreamWaitEvent(st, ix->ev_own, 0));
     if (ix->foreign_pending && ix->last_foreign != st) VDB_HIP(hipStreamWaitEvent(st, ix->ev_foreign, 0));
   } else {
-    VDB_ENTER(ix);
+    VDB_ENTER_SHARED(ix);
   }
   int32_t rc = search_dev(ix, d_queries, ix->dim, nq, k, ef, mode, d_out_ids, d_out_scores, d_out_n, st);
   if (rc == VDB_OK && ix->pcomm && nq && k) {
@@ -2016,8 +2204,13 @@ static int32_t search_batch_host(vdb_hip_index* ix, const float* queries, uint32
     return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (nq == 0) return VDB_OK;
   if (ix->group) return group_search_host(ix, queries, nq, k, ef, mode, rerank_k, out_ids, out_scores, out_n);
-  std::lock_guard<std::mutex> g(ix->mu);
-  VDB_ENTER(ix);
+  std::shared_lock<std::shared_mutex> rd(ix->mu, std::defer_lock);
+  std::unique_lock<std::shared_mutex> wr(ix->mu, std::defer_lock);
+  if (ix->pcomm) wr.lock(); else rd.lock();
+  CtxLease lease(ix);  // this search's scratch + stream: the handle itself, or one of its search contexts when it is busy
+  if (lease.rc != VDB_OK) return lease.rc;
+  ix = lease.ctx;
+  VDB_ENTER_SHARED(ix);
   hipStream_t st = ix->stream;
   int32_t rc = search_to_device(ix, queries, nq, k, ef, mode, rerank_k, out_n);
   if (rc != VDB_OK) return rc;
@@ -2144,7 +2337,9 @@ int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* ix, float* ms, uint32_t* lau
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !ms) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return vdb_hip_index_last_kernel_ms(group_shard(ix, 0), ms, launches);
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::shared_lock<std::shared_mutex> g(ix->mu);
+    ix = last_context(ix);  // the search context that served this thread's last search (the handle itself unless searches overlapped)
+    std::lock_guard<std::mutex> cg(ix->ctx_mu);
   double total = 0.0;
   uint32_t cnt = 0;
   for (size_t i = 0; i < ix->ev_used; i++) {
@@ -2165,7 +2360,9 @@ int32_t vdb_hip_index_last_selection_ms(vdb_hip_index* ix, float* total_ms, uint
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !total_ms) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return vdb_hip_index_last_selection_ms(group_shard(ix, 0), total_ms, launches);
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::shared_lock<std::shared_mutex> g(ix->mu);
+    ix = last_context(ix);  // the search context that served this thread's last search (the handle itself unless searches overlapped)
+    std::lock_guard<std::mutex> cg(ix->ctx_mu);
   double total = 0.0;
   uint32_t cnt = 0;
   for (size_t i = 0; i < ix->sel_ev_used; i++) {
@@ -2197,10 +2394,12 @@ int32_t vdb_hip_index_last_search_stats(vdb_hip_index* ix, uint64_t* n_dist, uin
     if (n_expand) *n_expand = b;
     return VDB_OK;
   }
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::shared_lock<std::shared_mutex> g(ix->mu);
+    ix = last_context(ix);  // the search context that served this thread's last search (the handle itself unless searches overlapped)
+    std::lock_guard<std::mutex> cg(ix->ctx_mu);
   if (ix->stats_pending) {
     unsigned long long h[2] = {0, 0};
-    VDB_ENTER(ix);
+    VDB_ENTER_SHARED(ix);
     VDB_HIP(hipDeviceSynchronize());
     VDB_HIP(hipMemcpy(h, ix->s_stats.p, 16, hipMemcpyDeviceToHost));
     ix->last_n_dist = h[0];

@@ -514,7 +514,26 @@ int32_t storage_mode_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
 
 // selection stage (level 3): bf16 image of the dequantised rows, their norms, the f32 seed prefix — built at first use,
 // kept current by storage_mode_append
-int32_t ensure_sq8_select(vdb_hip_index* ix, hipStream_t st) {
+static int32_t ensure_sq8_select_impl(vdb_hip_index* ix, hipStream_t st);
+int32_t ensure_sq8_select(vdb_hip_index* cx, hipStream_t st) {  // (inside a search: see index.hip build_image_on_primary)
+  vdb_hip_index* p = primary_of(cx);
+  {
+    std::lock_guard<std::mutex> il(p->img_mu);
+    const bool stale = p->sq8_img.cap == 0 || p->sq8_img_rows < p->n_rows;
+    const int32_t rc = ensure_sq8_select_impl(p, st);
+    if (rc != VDB_OK) return rc;
+    if (stale && !p->ctx_clones.empty()) VDB_HIP(hipStreamSynchronize(st));
+    if (cx != p) copy_image_fields(cx, p);
+  }
+  if (!cx->sel_stats) {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess) return fail(VDB_ERR_OOM, "pinned selection statistics");
+    memset(h, 0, 64);
+    cx->sel_stats = static_cast<volatile uint32_t*>(h);
+  }
+  return VDB_OK;
+}
+static int32_t ensure_sq8_select_impl(vdb_hip_index* ix, hipStream_t st) {
   const uint64_t cap = std::max<uint64_t>(ix->capacity, 1) + kRowSlack;
   const bool aug = ix->metric == VDB_EUCLIDEAN;
   const uint32_t dim_a = aug ? ix->dim + 64 : ix->dim, dim_s = aug ? ix->dim + 4 : ix->dim;
@@ -531,12 +550,6 @@ int32_t ensure_sq8_select(vdb_hip_index* ix, hipStream_t st) {
                        ix->sq8_nrm.as<float>(), ix->sq8_seed.as<float>(), kSplitSeedRows, (uint32_t)first, (uint32_t)n, ix->dim, dim_a, dim_s);
     ix->sq8_img_rows = ix->n_rows;
     VDB_HIP(hipGetLastError());
-  }
-  if (!ix->sel_stats) {
-    void* h = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocDefault) != hipSuccess) return fail(VDB_ERR_OOM, "pinned selection statistics");
-    memset(h, 0, 64);
-    ix->sel_stats = static_cast<volatile uint32_t*>(h);
   }
   return VDB_OK;
 }
@@ -724,7 +737,7 @@ int32_t vdb_hip_index_set_storage_mode(vdb_hip_index* ix, int32_t mode) {
   if (mode != VDB_STORAGE_FULL && mode != VDB_STORAGE_SQ8 && mode != VDB_STORAGE_BINARY)
     return fail(VDB_ERR_INVALID_ARG, "bad storage mode");
   if (ix->group) return group_for_all(ix, 2, (uint32_t)mode);
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   if (ix->storage_mode == mode) return VDB_OK;
   VDB_ENTER(ix);
   for (DevBuf* b : {&ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits, &ix->sq8_img, &ix->sq8_nrm, &ix->sq8_seed})
@@ -753,7 +766,7 @@ int32_t vdb_hip_index_get_quantized(vdb_hip_index* ix, uint64_t id, uint8_t* out
       if (rc == VDB_OK || s + 1 == group_size(ix)) return rc;
     }
   }
-  std::lock_guard<std::mutex> g(ix->mu);
+  std::lock_guard<std::shared_mutex> g(ix->mu);
   if (ix->storage_mode == VDB_STORAGE_FULL) return fail(VDB_ERR_STATE, "storage mode is Full: nothing is quantised");
   auto it = ix->id_to_idx.find(id);
   if (it == ix->id_to_idx.end()) return fail(VDB_ERR_INVALID_ARG, "unknown id");

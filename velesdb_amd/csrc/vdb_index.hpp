@@ -10,6 +10,7 @@
 #include <atomic>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -75,11 +76,21 @@ static inline int32_t guarded(F&& f) noexcept {
 
 // after taking ix->mu: select the device and order ix->stream behind a device-resident search still in flight on a
 // caller's stream
-int32_t enter_index(vdb_hip_index* ix);
+// exclusive = the caller holds ix->mu exclusively (it is about to change the index): the primary's stream is also ordered behind
+// whatever its search contexts still have in flight
+int32_t enter_index(vdb_hip_index* ix, bool exclusive = true);
+// the handle that owns the data a search context reads (itself unless it is a clone)
+static inline vdb_hip_index* primary_of(vdb_hip_index* ix);
 #define VDB_ENTER(ix)                        \
   do {                                       \
     int32_t _erc = ::vdb::enter_index(ix);   \
     if (_erc != VDB_OK) return _erc;         \
+  } while (0)
+
+#define VDB_ENTER_SHARED(ix)                        \
+  do {                                              \
+    int32_t _erc = ::vdb::enter_index(ix, false);   \
+    if (_erc != VDB_OK) return _erc;                \
   } while (0)
 
 #define VDB_NO_GROUP(ix, what)                                                                     \
@@ -171,7 +182,22 @@ struct vdb_hip_index {
   size_t sel_ev_used = 0;
   uint64_t last_n_dist = 0, last_n_expand = 0;
 
-  mutable std::mutex mu;
+  // Reader / writer lock of the handle (the reference's RwLock around the graph, index/hnsw/index/search.rs:80): searches
+  // hold it SHARED while they enqueue (and, host entry points, until their results are back), everything that changes the
+  // index holds it exclusively.
+  mutable std::shared_mutex mu;
+  // Search contexts.  A search needs scratch buffers, event pools and a stream of its own; concurrent searches on one handle
+  // each lease a CONTEXT: this object itself (context 0) or one of `ctx_clones` — handles that alias this one's data buffers
+  // (rows, norms, images, graph: non-owning copies of the DevBufs, refreshed when `version` moved) and own only their scratch
+  // and stream.  ctx_mu = "this context is in use"; pool_mu guards ctx_clones.  Clones are created on demand (a handle that
+  // is only ever searched by one thread at a time never makes one).
+  vdb_hip_index* primary = nullptr;            // set in a clone
+  std::vector<vdb_hip_index*> ctx_clones;      // (primary only)
+  std::mutex ctx_mu, pool_mu;
+  uint64_t version = 1, synced_version = 0;    // primary: bumped by every change; clone: the version its views were copied at
+  // first-use construction of the selection images (split / bf16 / augmented / SQ8-dequantised) happens inside searches, i.e.
+  // under the SHARED lock: serialised here, always on the primary's fields
+  std::mutex img_mu;
   // Device-side ordering between streams (the scratch buffers, the rows and the graph are shared by every search of this
   // index): a device-resident search enqueued on a caller's stream records ev_foreign; whatever touches the index next on
   // another stream — ix->stream for every host entry point, another caller stream — waits for it first (VDB_ENTER /
@@ -189,6 +215,22 @@ struct vdb_hip_index {
 };
 
 namespace vdb {
+static inline vdb_hip_index* primary_of(vdb_hip_index* ix) { return ix->primary ? ix->primary : ix; }
+// after a change to the index (exclusive lock held): search contexts refresh their views before their next search
+static inline void mark_changed(vdb_hip_index* ix) { primary_of(ix)->version++; }
+// copies the selection-image state (buffers + progress counters) of the primary into a search context
+void copy_image_fields(vdb_hip_index* dst, const vdb_hip_index* src);
+// a leased search context of `ix` (shared lock on ix->mu held by the caller): the primary if free, else a free / new clone
+struct CtxLease {
+  vdb_hip_index* ctx = nullptr;
+  int32_t rc = VDB_OK;
+  explicit CtxLease(vdb_hip_index* ix);
+  ~CtxLease();
+  CtxLease(const CtxLease&) = delete;
+  CtxLease& operator=(const CtxLease&) = delete;
+};
+// the context that served this thread's last search on `ix` (diagnostic getters read from it)
+vdb_hip_index* last_context(vdb_hip_index* ix);
 // index.hip
 int32_t create_single(uint32_t dim, int32_t metric, uint32_t M, uint32_t ef_construction, uint64_t max_elements,
                       int32_t device, vdb_hip_index** out);
