@@ -20,6 +20,11 @@ static std::atomic<int> g_sweep_engine{1};  // 1 (default): MFMA kernel for cosi
 static std::atomic<uint32_t> g_max_tile{128};  // largest query tile of the exact sweep (vdb_hip_set_max_query_tile)
 static std::atomic<int> g_split_selector{2};  // large exact Cosine / Dot batches: 0 exact kernel, 1 split-bf16 selection + exact re-scoring + proof,
                                               // 2 plain bf16 selection first (same proof, wider bound), level 1 when a handle's data defeats it
+// VELESDB_BF16_SEED=0: level 2 keeps the exact f32 seed sweep (A / B probes)
+static const bool g_bf16_seed = [] {
+  const char* e = getenv("VELESDB_BF16_SEED");
+  return !(e && e[0] == '0');
+}();
 static std::atomic<uint32_t> g_int8_oversampling{4};  // DualPrecisionConfig::default().oversampling_ratio (dual_precision.rs:57)
 
 // effective option values of a handle: its own (vdb_hip_index_set_option) or the process-wide default
@@ -348,10 +353,20 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
         const uint32_t R0 = kGemmBf16SeedRows;
         uint32_t R1 = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(R0 + (1u << 18), R0 + (n / 16 + 255) / 256 * 256));
         if (n - R1 < (1u << 18)) R1 = n;  // a short tail is not worth a launch of its own
-        Bf16GemmPlan bp[2];
+        // ... and no launch longer than kGemmBf16MaxLaunchRows: the query tiles of a row group share their row tiles through one
+        // XCD's L2 only while they run in step, and over hundreds of row tiles they drift apart (10 M rows in one launch:
+        // FETCH_SIZE 2.1 x the corpus; in launches of 2 M rows: see profiles/).  A boundary costs one merge + re-seed (~20 us).
+        constexpr uint32_t kGemmBf16MaxLaunchRows = 1u << 21;
+        constexpr int kMaxLaunches = 64;
+        Bf16GemmPlan bp[kMaxLaunches];
         int n_launch = 0;
         sweep_gemm_bf16_plan(nqg, R0, R1, ix->n_cus, &bp[n_launch++]);
-        if (R1 < n) sweep_gemm_bf16_plan(nqg, R1, n, ix->n_cus, &bp[n_launch++]);
+        for (uint32_t lo = R1; lo < n;) {
+            uint32_t hi = (uint32_t)std::min<uint64_t>(n, (uint64_t)lo + kGemmBf16MaxLaunchRows);
+            if (n - hi < (1u << 19) || n_launch == kMaxLaunches - 1) hi = n;  // (a short tail joins the launch in front of it)
+            sweep_gemm_bf16_plan(nqg, lo, hi, ix->n_cus, &bp[n_launch++]);
+            lo = hi;
+        }
         uint32_t lists = 1;
         for (int j = 0; j < n_launch; j++) lists += bp[j].G;
         GemmPlan sp;  // seeding sweep over the first rows
@@ -821,7 +836,9 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     off = (off + bytes + 15) & ~(size_t)15;
     return o;
   };
-  const size_t o_seedp = take((size_t)nqg * sp.G * k * 8), o_ids = take((size_t)nqg * K2 * 8), o_sc = take((size_t)nqg * K2 * 4),
+  // level 2 over the f32 rows: the seed runs on the bf16 pipe (sweep_split.hip seed_scores_bf16: every seed score as a key)
+  const bool bf16_seed = level == 2 && !l2 && !sq8 && g_bf16_seed;
+  const size_t o_seedp = take(std::max((size_t)nqg * sp.G * k * 8, bf16_seed ? (size_t)nqg * R0 * 8 : (size_t)0)), o_ids = take((size_t)nqg * K2 * 8), o_sc = take((size_t)nqg * K2 * 4),
                o_n = take((size_t)nqg * 4), o_tau = take((size_t)nqg * 8), o_delta = take((size_t)nqg * 4),
                o_qn = take((size_t)nqg * 4), o_flags = take((size_t)nqg * 4 + 64 * 4 + 16), o_btau = take((size_t)nqg * lists * 8),
                o_fid = take((size_t)nqg * k * 8), o_fsc = take((size_t)nqg * k * 4), o_fn = take((size_t)nqg * 4),
@@ -897,18 +914,28 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   ag.dim = l2 ? dim_s : dim;
   ag.nq = nqg;
   ag.k = k;
-  e = launch_sweep_gemm(sel_metric, sp, ag, st);
-  if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split seed sweep launch: ") + hipGetErrorString(e));
   MergeArgs ms{};
   ms.part_keys = ag.part_keys;
   ms.ext_ids = nullptr;  // internal rows
   ms.out_ids = m_ids;
   ms.out_scores = m_sc;
   ms.out_n = m_n;
+  if (bf16_seed) {
+    launch_seed_scores_bf16(sel_metric, img_rows, img_stride, sel_norms, alive, q16, img_stride, qnorms, ag.part_keys, R0, nqg, dim, st);
+    ms.n_lists = R0;  // one "list" of one key per seed row: the selection merge picks the ks best
+    ms.k = 1;
+    ms.k_out = ks;
+    launch_merge(true, ms, nqg, st);
+    launch_split_seed_approx(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, R0, dim, level, st);
+  } else {
+  e = launch_sweep_gemm(sel_metric, sp, ag, st);
+  if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split seed sweep launch: ") + hipGetErrorString(e));
   ms.n_lists = sp.G;
   ms.k = k;
   launch_merge(true, ms, nqg, st);
-  if (l2)
+  }
+  if (bf16_seed) {
+  } else if (l2)
     launch_l2_seed(m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim_a, sq8 ? 1.5e-4f : 0.0f, st);
   else
     launch_split_seed(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim, level, st);

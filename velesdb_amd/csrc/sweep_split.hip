@@ -126,6 +126,109 @@ void launch_split_seed(int metric, const uint64_t* ids, const float* scores, con
                        tau0, delta, list, blk_tau, list_stride, nq, k, klist, dim, level);
 }
 
+// ---- level 2's seed on the bf16 pipe (round 3) -----------------------------------------------------------------------------
+// The exact f32 seed sweep cost 235 us of a 2.5 ms batch: one 128 x 128 tile per block at 1/16 of the bf16 rate, and — no
+// threshold exists yet — every one of its 16 384 products a candidate for the fused top-k.  A bound does not need exact scores:
+// with A_k the k-th best APPROXIMATE score over any set of rows and delta the bound of |approximate - exact|, the k rows
+// behind it have exact scores >= A_k - delta, so the exact k-th best over the corpus is >= A_k - delta, and a row of the exact
+// top k has an approximate score >= A_k - 2 delta: tau = A_k - 2 delta (what split_reseed_kernel already uses between
+// launches).  So: seed_scores_bf16 = a plain bf16 GEMM of the first rows x the batch over the selection's own images, every
+// score stored as a key ([nq][seed_rows]; 32 MiB, L2 / MALL resident), merge_topk_select picks the ks best per query,
+// split_seed_approx_kernel turns them into list slot 0 of the pool (approximate keys like every other slot), the bound of
+// what slot 0 left out (its ks-th key: blk_tau, as a selection block reports it) and tau.
+// One wave = 16 rows x 64 queries; both operands straight from L2 in fragment shape (16 B per lane per fragment: lane (i = l &
+// 15, kk = l >> 4) holds elements 32 s + 8 kk .. + 7 of row / query i), four 32-deep steps in flight.
+typedef float f32x4_s __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
+template <int METRIC>
+__global__ __launch_bounds__(256) void seed_scores_bf16(const uint16_t* rows16, uint64_t row_stride, const float* norms, const uint8_t* alive,
+                                                        const uint16_t* q16, uint64_t q_stride, const float* qnorms, uint64_t* keys,
+                                                        uint32_t seed_rows, uint32_t nq, uint32_t dim) {
+  const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+  const uint32_t row0 = (blockIdx.x * 4u + wib) * 16u;  // this wave's 16 rows
+  const uint32_t qb = blockIdx.y * 64u;                  // ... and 64 queries
+  if (row0 >= seed_rows) return;
+  const uint32_t i = lane & 15u, kk = lane >> 4;
+  const uint16_t* ap = rows16 + (size_t)(row0 + i) * row_stride + kk * 8u;
+  const uint16_t* bp[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) bp[t] = q16 + (size_t)min(qb + (uint32_t)t * 16u + i, nq - 1u) * q_stride + kk * 8u;
+  f32x4_s acc[4] = {f32x4_s{0.f, 0.f, 0.f, 0.f}, f32x4_s{0.f, 0.f, 0.f, 0.f}, f32x4_s{0.f, 0.f, 0.f, 0.f}, f32x4_s{0.f, 0.f, 0.f, 0.f}};
+  for (uint32_t k0 = 0; k0 < dim; k0 += 128) {  // dim % 64 == 0 (level 2): steps past dim are skipped
+    bf16x8_s av[4], bv[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      const bool in = k0 + (uint32_t)s * 32u < dim;
+      av[s] = in ? *reinterpret_cast<const bf16x8_s*>(ap + k0 + s * 32) : bf16x8_s{};
+#pragma unroll
+      for (int t = 0; t < 4; t++) bv[s][t] = in ? *reinterpret_cast<const bf16x8_s*>(bp[t] + k0 + s * 32) : bf16x8_s{};
+    }
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s], bv[s][t], acc[t], 0, 0, 0);
+  }
+  // lane holds rows row0 + 4 kk + r (r = 0..3) of query column qb + 16 t + i
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const uint32_t q = qb + (uint32_t)t * 16u + i;
+    if (q >= nq) continue;
+    const float qn = METRIC == kCosine ? qnorms[q] : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t row = row0 + 4u * kk + (uint32_t)r;
+      const float sc = finish_score<METRIC>(acc[t][r], qn, METRIC == kCosine ? norms[row] : 1.0f);
+      const bool live = !alive || alive[row] != 0;
+      keys[(size_t)q * seed_rows + row] = live ? make_key<true>(sc, row) : kKeyInvalid;
+    }
+  }
+}
+void launch_seed_scores_bf16(int metric, const uint16_t* rows16, uint64_t row_stride, const float* norms, const uint8_t* alive,
+                             const uint16_t* q16, uint64_t q_stride, const float* qnorms, uint64_t* keys, uint32_t seed_rows,
+                             uint32_t nq, uint32_t dim, hipStream_t st) {
+  const dim3 grid((seed_rows + 63) / 64, (nq + 63) / 64);
+  if (metric == kCosine)
+    hipLaunchKernelGGL((seed_scores_bf16<kCosine>), grid, dim3(256), 0, st, rows16, row_stride, norms, alive, q16, q_stride, qnorms, keys, seed_rows, nq, dim);
+  else
+    hipLaunchKernelGGL((seed_scores_bf16<kDot>), grid, dim3(256), 0, st, rows16, row_stride, norms, alive, q16, q_stride, qnorms, keys, seed_rows, nq, dim);
+}
+// the ks best approximate seed scores of every query (merged, best first) -> pool slot 0, its bound, delta, tau
+template <int METRIC>
+__global__ __launch_bounds__(256) void split_seed_approx_kernel(const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
+                                                                const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list,
+                                                                uint64_t* blk_tau, uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist,
+                                                                uint32_t seed_rows, uint32_t dim, int level) {
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  const float eps = select_eps(dim, level);
+  const float d = METRIC == kCosine ? eps * 1.001f + 4e-7f : eps * 1.001f * qnorms[q] * __uint_as_float(*norm_max_bits) + 1e-30f;
+  delta[q] = d;
+  const uint32_t c = min(n[q], klist);
+  uint64_t t = kKeyInvalid;
+  if (c >= k && k > 0) {
+    const float s = scores[(size_t)q * klist + k - 1];
+    const float lowered = s - 2.0f * d * 1.01f - fabsf(s) * 1e-6f;  // approximate scores on both sides: 2 delta
+    t = lowered == lowered ? make_key<true>(lowered, 0u) : kKeyInvalid;  // NaN: no bound
+  }
+  tau0[q] = t;
+  for (uint32_t e = 0; e < klist; e++)
+    list[(size_t)q * list_stride * klist + e] = e < c ? make_key<true>(scores[(size_t)q * klist + e], (uint32_t)ids[(size_t)q * klist + e]) : kKeyInvalid;
+  // what slot 0 left out: every other seed row has a key >= its klist-th (nothing when the seed region had no more rows)
+  blk_tau[(size_t)q * list_stride] = (c == klist && seed_rows > klist) ? make_key<true>(scores[(size_t)q * klist + klist - 1], (uint32_t)ids[(size_t)q * klist + klist - 1])
+                                                                      : kKeyInvalid;
+}
+void launch_split_seed_approx(int metric, const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
+                              const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
+                              uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t seed_rows, uint32_t dim, int level,
+                              hipStream_t st) {
+  if (metric == kCosine)
+    hipLaunchKernelGGL((split_seed_approx_kernel<kCosine>), dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits,
+                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, seed_rows, dim, level);
+  else
+    hipLaunchKernelGGL((split_seed_approx_kernel<kDot>), dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits,
+                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, seed_rows, dim, level);
+}
+
 // Between two selection launches: the next launch's bound = k-th best POOL score so far (approximate scores, exact ones for
 // slot 0), lowered by delta when it is an exact score's turn to bound approximate ones — simply always (it costs a sliver
 // of tightness).

@@ -238,6 +238,15 @@ void launch_split_vectors(const float* src, uint64_t src_stride, uint16_t* out, 
 void launch_split_seed(int metric, const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
                        const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
                        uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim, int level, hipStream_t st);
+// level 2's seed on the bf16 pipe: a plain GEMM of the first rows x the batch into keys [nq][seed_rows], and the seed kernel for
+// approximate seed scores (tau = A_k - 2 delta; slot 0 of the pool with its bound)
+void launch_seed_scores_bf16(int metric, const uint16_t* rows16, uint64_t row_stride, const float* norms, const uint8_t* alive,
+                             const uint16_t* q16, uint64_t q_stride, const float* qnorms, uint64_t* keys, uint32_t seed_rows,
+                             uint32_t nq, uint32_t dim, hipStream_t st);
+void launch_split_seed_approx(int metric, const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
+                              const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
+                              uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t seed_rows, uint32_t dim, int level,
+                              hipStream_t st);
 // {unproven, queries, seq, level} of a finished selection batch -> pinned host memory (no synchronisation)
 void launch_select_stats(const uint32_t* flags, uint32_t nq, uint32_t seq, uint32_t level, volatile uint32_t* host, hipStream_t st);
 void launch_split_reseed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* delta, uint64_t* tau0,
