@@ -372,10 +372,11 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
         GemmPlan sp;  // seeding sweep over the first rows
         sweep_gemm_plan(nqg, R0, ix->n_cus, k, &sp, /*allow_big=*/false);
         const size_t off_ids = ((size_t)nqg * sp.G * k * 8 + 15) & ~(size_t)15, off_sc = off_ids + (size_t)nqg * k * 8,
-                     off_n = off_sc + (size_t)nqg * k * 4, off_tau = (off_n + (size_t)nqg * 4 + 15) & ~(size_t)15;
+                     off_n = off_sc + (size_t)nqg * k * 4, off_tau = (off_n + (size_t)nqg * 4 + 15) & ~(size_t)15,
+                     off_qn = off_tau + (size_t)nqg * 8;
         hipError_t e3;
         if ((e3 = ix->s_part_keys.reserve((size_t)nqg * lists * k * 8, false, st)) != hipSuccess ||
-            (e3 = ix->s_seed.reserve(off_tau + (size_t)nqg * 8, false, st)) != hipSuccess ||
+            (e3 = ix->s_seed.reserve(off_qn + (size_t)nqg * 4, false, st)) != hipSuccess ||
             (e3 = ix->s_misc.reserve(((size_t)nqg + 256) * ix->bf16_stride * 2, false, st)) != hipSuccess)
           return fail(VDB_ERR_OOM, "bf16 GEMM scratch");
         unsigned char* sd = ix->s_seed.as<unsigned char>();
@@ -384,6 +385,8 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
         const uint16_t* q16 = ix->s_misc.as<uint16_t>();
         launch_round_queries_bf16(d_q + (size_t)q0 * q_stride, q_stride, ix->s_misc.as<uint16_t>(), ix->bf16_stride, nqg,
                                   ix->dim, st);
+        float* qn_half = reinterpret_cast<float*>(sd + off_qn);  // norms of the rounded queries, once per batch
+        launch_query_norms_bf16(q16, ix->bf16_stride, qn_half, nqg, ix->dim, st);
         // the 256 x 256 kernel stages whole 256-query tiles: zero rows behind the batch
         VDB_HIP(hipMemsetAsync(ix->s_misc.as<uint16_t>() + (size_t)nqg * ix->bf16_stride, 0, (size_t)256 * ix->bf16_stride * 2, st));
         VDB_HIP(hipMemsetAsync(parts, 0xFF, (size_t)nqg * lists * k * 8, st));  // every slot: kKeyInvalid
@@ -407,7 +410,7 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
         for (int j = 0; j < n_launch; j++) {
           e3 = launch_sweep_gemm_bf16_glds(ix->metric, bp[j], ix->rows_bf16.as<uint16_t>(), ix->bf16_stride,
                                            ix->norms_bf16.as<float>(), alive, q16, ix->bf16_stride, tau0, parts, lists,
-                                           list_off, ix->dim, nqg, k, st);
+                                           list_off, ix->dim, nqg, k, st, /*split=*/false, nullptr, nullptr, qn_half);
           if (e3 != hipSuccess) return fail(VDB_ERR_HIP, std::string("bf16 gemm sweep launch: ") + hipGetErrorString(e3));
           list_off += bp[j].G;
           if (j + 1 < n_launch) {  // bound for the next launch: k-th best key over everything swept so far

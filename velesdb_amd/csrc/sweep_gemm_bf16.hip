@@ -41,14 +41,18 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 
 constexpr int kG16BM = 256, kG16BN = 256, kG16Waves = 8;
 constexpr int kG16Cap = 12;     // candidate buffer entries per query (k <= kGemmBf16MaxK = 10)
-constexpr int kG16Queue = 40;   // per-wave queue of finished survivors
+constexpr int kG16Queue = 39;   // per-wave queue of finished survivors (and, transiently, raw ones: g16_protocol.inc)
+static_assert(kG16Queue <= 64 && kG16Queue >= 32, "the finish pass takes one queue entry per lane; one hot lane's 32 elements fit");
 // LDS map (bytes): two tile buffers (A 32 KiB + B 32 KiB each), candidate buffers, k-th best keys, counters, query norms,
 // row-tile norms, flags, per-wave queues (keys + query slots)
 constexpr size_t kOffCand = 131072, kOffTauk = kOffCand + (size_t)kG16BN * kG16Cap * 8, kOffCnts = kOffTauk + kG16BN * 8,
                  kOffQn = kOffCnts + kG16BN * 4, kOffVns = kOffQn + kG16BN * 4, kOffFlags = kOffVns + kG16BM * 4,
-                 kOffQueue = kOffFlags + 16, kQueueBytes = (size_t)kG16Queue * 8 + 48,
+                 kOffQueue = kOffFlags + 16,
+                 kQueueBytes = 368,  // keys [kG16Queue] + one slot for pushes past the end, query columns [kG16Queue]
+                
                  kG16Lds = kOffQueue + kG16Waves * kQueueBytes;
 static_assert(kG16Lds <= 160 * 1024, "LDS budget");
+static_assert((size_t)(kG16Queue + 1) * 8 + kG16Queue + 4 <= 364 + 4 && (size_t)(kG16Queue + 1) * 8 + kG16Queue <= 364, "queue layout");
 
 struct Bf16GemmArgs {
   const uint16_t* rows;     // [n_rows + slack][row_stride] bf16
@@ -65,6 +69,8 @@ struct Bf16GemmArgs {
   // selection stage of the exact f32 search only (sweep_split.hip; SPLIT instance, or the bf16 instance as its first level)
   const float* qnorms;      // [nq] canonical f32 norms of the ORIGINAL queries (cosine); norms = those of the f32 rows
   uint64_t* blk_tau;        // [nq][list_stride]: the bound this block ends with per query (kKeyInvalid: it excluded nothing)
+  // result mode (VDB_SEARCH_BRUTE_BF16): [nq] norms of the ROUNDED queries (query_norms_bf16), or nullptr: computed by every block
+  const float* qnorms_half;
 };
 
 // The lane id, re-derived where it is needed: a value computed from threadIdx before the main loop stays live across it,
@@ -105,17 +111,29 @@ __device__ __forceinline__ void glds_b128(const i32x4& rsrc, uint32_t voff, uint
                : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
                : "m0");  // no "memory" clobber: fragment reads of the OTHER buffer may move across a request
 }
-__device__ __forceinline__ i32x4 make_rsrc(const void* base) {  // raw buffer, byte-addressed, no bounds in reach
+// Descriptor of a raw buffer, byte-addressed.  num_records = the bytes that EXIST behind base: a lane whose offset lies past
+// them gets zeros (the hardware's range check of raw buffers), which is how the corpus' ragged last tile is read — its rows past
+// the end come out as zero rows with zero norms instead of whatever the allocation holds (NaN patterns make every lane of the
+// tile hot; the quick test ignores zero norms, a zero product passes no positive bound).
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, uint32_t num_records = 0x7FFFFFFFu) {
   const uint64_t b = reinterpret_cast<uint64_t>(base);
-  return i32x4{(int)(uint32_t)b, (int)((uint32_t)(b >> 32) & 0xFFFFu), 0x7FFFFFFF, 0x00020000};
+  return i32x4{(int)(uint32_t)b, (int)((uint32_t)(b >> 32) & 0xFFFFu), (int)num_records, 0x00020000};
 }
 // the same for a base the compiler may have parked in a vector register (loop-carried uniform values under scalar-register
 // pressure: an "s" operand fed from one came out as v[0:3] — not an encodable descriptor)
-__device__ __forceinline__ i32x4 make_rsrc_uniform(const void* base) {
+__device__ __forceinline__ i32x4 make_rsrc_uniform(const void* base, uint32_t num_records = 0x7FFFFFFFu) {
   const uint64_t b = reinterpret_cast<uint64_t>(base);
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
-  return i32x4{(int)lo, (int)(hi & 0xFFFFu), 0x7FFFFFFF, 0x00020000};
+  return i32x4{(int)lo, (int)(hi & 0xFFFFu), __builtin_amdgcn_readfirstlane((int)num_records), 0x00020000};
+}
+// bytes of the row image that exist behind the first byte of k-tile kt of row tile rt (the launch's rows end at n_rows)
+__device__ __forceinline__ uint32_t a_tile_records(uint32_t n_rows, uint32_t rt, uint32_t kt, uint64_t row_stride) {
+  const uint64_t left = (uint64_t)(n_rows - rt * (uint32_t)kG16BM) * row_stride * 2u - (uint64_t)kt * 128u;
+  return (uint32_t)(left < 0x7FFFFFFFull ? left : 0x7FFFFFFFull);
+}
+__device__ __forceinline__ uint32_t norm_records(uint32_t n_rows, uint32_t rt) {
+  return min(n_rows - rt * (uint32_t)kG16BM, (uint32_t)kG16BM) * 4u;
 }
 __device__ __forceinline__ void wait_glds() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -143,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs
   const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wib >> 2, wq = wib & 3;
   uint64_t* wq_keys = reinterpret_cast<uint64_t*>(smem + kOffQueue + (size_t)wib * kQueueBytes);
-  uint8_t* wq_qs = reinterpret_cast<uint8_t*>(wq_keys + QCAP);
+  uint8_t* wq_qs = reinterpret_cast<uint8_t*>(wq_keys + QCAP + 1);
 
   // block -> (query tile, row group): the query tiles of a row group sit on one XCD in adjacent dispatch slots, run in
   // lock-step and share every row tile through that XCD's L2 (measured: HBM traffic = 1.04 x the corpus)
@@ -166,6 +184,8 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs
   if (a.qnorms) {  // selection for the exact f32 search (SPLIT, or plain bf16 as its first level): the caller computed the
                    // canonical norms of the f32 queries — what the exact score divides by
     if ((uint32_t)tid < nq_t) qn[tid] = a.qnorms[q0 + tid];
+  } else if (a.qnorms_half) {
+    if ((uint32_t)tid < nq_t) qn[tid] = a.qnorms_half[q0 + tid];
   } else {  // norm of the ROUNDED query, canonical lane-chain order (as sweep_topk_mfma_bf16); DotProduct keeps it for the
             // overflow guard of the quick test only
     for (uint32_t b = wib; b < nq_t; b += WAVES) {
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs
     const uint32_t st_slot = (ln_ & 7u) ^ ((st_row >> 1) & 7u); \
     const uint32_t voff_a = st_row * (uint32_t)a.row_stride * 2u + st_slot * 16u; \
     const uint32_t voff_b = st_row * (uint32_t)a.q_stride * 2u + st_slot * 16u; \
-    const i32x4 ra = make_rsrc(rows_b + ((size_t)ld_rt * BM * a.row_stride + (size_t)ld_kt * 64) * 2); \
+    const i32x4 ra = make_rsrc(rows_b + ((size_t)ld_rt * BM * a.row_stride + (size_t)ld_kt * 64) * 2, a_tile_records(a.n_rows, ld_rt, ld_kt, a.row_stride)); \
     const i32x4 rb = make_rsrc(queries_b + (size_t)ld_kt * 128); \
     const uint32_t la = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)wib * 1024u;
   // request J (0..3: row tile, 4..7: query tile)
@@ -242,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs
     const int buf = (int)(it & 1u); \
     VDB_G16_REQ(buf ^ 1) \
     if ((KT_NOW) == 0 && wib == 0) /* vns was last read before the previous barrier */ \
-      glds_b128(make_rsrc(reinterpret_cast<const unsigned char*>(a.norms) + (size_t)rt * BM * 4), ln_ * 16u, 0u, lds0 + (uint32_t)kOffVns); \
+      glds_b128(make_rsrc(reinterpret_cast<const unsigned char*>(a.norms) + (size_t)rt * BM * 4, norm_records(a.n_rows, rt)), ln_ * 16u, 0u, lds0 + (uint32_t)kOffVns); \
     const int sw_i = (int)((ln_ & 15u) >> 1) & 7; \
     const int rd_off = (int)(ln_ & 15u) * 128 + (((int)(ln_ >> 4) ^ sw_i) & 3) * 16; \
     const int rd_x = (sw_i & 4) << 4; \
@@ -330,7 +350,9 @@ _Pragma("unroll") \
     VDB_G16_STEP(a.KT - 1, false);  // the last k-tile: its closing barrier is the first sync point of the epilogue
     const bool more = it < total;
 #include "g16_quicktest.inc"
+#define VDB_G16_ACC_ELEM(X, A) asm volatile("v_mov_b32 %0, %1" : "=v"(X) : "v"(A))
 #include "g16_protocol.inc"
+#undef VDB_G16_ACC_ELEM
   }
 #undef VDB_G16_STEP
 #undef VDB_G16_ADVANCE
@@ -409,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a
   const int wib = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wib >> 2, wq = wib & 3;
   uint64_t* wq_keys = reinterpret_cast<uint64_t*>(smem + kOffQueue + (size_t)wib * kQueueBytes);
-  uint8_t* wq_qs = reinterpret_cast<uint8_t*>(wq_keys + QCAP);
+  uint8_t* wq_qs = reinterpret_cast<uint8_t*>(wq_keys + QCAP + 1);
 
   // block -> (query tile, row group), as in the kernel above
   const uint32_t bid = blockIdx.x;
@@ -430,6 +452,8 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a
   __syncthreads();
   if (a.qnorms) {
     if ((uint32_t)tid < nq_t) qn[tid] = a.qnorms[q0 + tid];
+  } else if (a.qnorms_half) {  // (32 dependent row reads per wave and launch otherwise: 50 us before the first product)
+    if ((uint32_t)tid < nq_t) qn[tid] = a.qnorms_half[q0 + tid];
   } else {
     for (uint32_t b = wib; b < nq_t; b += WAVES) {
       const uint16_t* qp = queries + (size_t)b * a.q_stride;
@@ -481,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a
   const uint32_t lds_w = lds0 + (uint32_t)wib * 1024u;
   // half-tile HALF (0, 1) of the A image of k-tile (RT, KT_) -> stage BUF; the same for B
 #define VDB_PP_REQ_A(HALF, RT, KT_, BUF) do { \
-    const i32x4 ra_ = make_rsrc_uniform(rows_b + ((size_t)(RT) * BM * a.row_stride + (size_t)(KT_) * 64) * 2); \
+    const i32x4 ra_ = make_rsrc_uniform(rows_b + ((size_t)(RT) * BM * a.row_stride + (size_t)(KT_) * 64) * 2, a_tile_records(a.n_rows, (RT), (KT_), a.row_stride)); \
     glds_b128(ra_, voff_a, (uint32_t)(2 * (HALF)) * soff_a, lds_w + (uint32_t)(BUF) * 65536u + (uint32_t)(2 * (HALF)) * 8192u); \
     glds_b128(ra_, voff_a, (uint32_t)(2 * (HALF) + 1) * soff_a, lds_w + (uint32_t)(BUF) * 65536u + (uint32_t)(2 * (HALF) + 1) * 8192u); \
   } while (0)
@@ -568,7 +592,7 @@ _Pragma("unroll") \
     VDB_PP_READ_B(buf); \
     VDB_PP_REQ_B(1, kt1, buf ^ 1u); \
     if ((FIRST) && wib == 0) /* the row tile's norms (vns was last read in the epilogue before) */ \
-      glds_b128(make_rsrc_uniform(reinterpret_cast<const unsigned char*>(a.norms) + (size_t)rt * BM * 4), lane_now() * 16u, 0u, lds0 + (uint32_t)kOffVns); \
+      glds_b128(make_rsrc_uniform(reinterpret_cast<const unsigned char*>(a.norms) + (size_t)rt * BM * 4, norm_records(a.n_rows, rt)), lane_now() * 16u, 0u, lds0 + (uint32_t)kOffVns); \
     pp_barrier_reads_done(); \
     VDB_PP_MFMA(a0v, 0, 0, FIRST); \
     pp_barrier(); \
@@ -602,7 +626,9 @@ _Pragma("unroll") \
     const bool more = c < total;
 #include "g16_quicktest.inc"  // (waves 0-3: beside the last products of waves 4-7)
     if (wr == 0) pp_barrier();  // waves 0-3 wait for the last products of waves 4-7: the block is aligned again
+#define VDB_G16_ACC_ELEM(X, A) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(X) : "a"(A))
 #include "g16_protocol.inc"
+#undef VDB_G16_ACC_ELEM
     // A rows 0-63 of the next row tile's first k-tile (landed: waited for in phase 3 above).  Unconditional — behind the last
     // row tile it reads a stage nobody uses: a conditional read would keep the OLD fragments alive across the epilogue
     VDB_PP_LANE();
@@ -619,6 +645,29 @@ _Pragma("unroll") \
 #undef VDB_PP_REQ_A
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // requests past the end must not land in LDS that is no longer ours
 #include "g16_writeout.inc"
+}
+
+// Norms of the rounded queries of a result-mode batch, once per batch instead of once per block: one wave per query, the
+// chain the kernels above run when qnorms_half is absent (canonical lane-chain order, as sweep_topk_mfma_bf16).
+__global__ __launch_bounds__(256) void query_norms_bf16_kernel(const uint16_t* q16, uint64_t q_stride, float* out, uint32_t nq, uint32_t dim) {
+  const uint32_t lane = threadIdx.x & 63u, b = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (b >= nq) return;
+  const uint16_t* qp = q16 + (size_t)b * q_stride;
+  float nacc = 0.0f;
+  for (uint32_t c = lane; c * 4 < dim; c += 64)
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint32_t i = c * 4 + e;
+      if (i < dim) {
+        const float x = __uint_as_float((uint32_t)qp[i] << 16);
+        nacc = __builtin_fmaf(x, x, nacc);
+      }
+    }
+  const float n = sqrtf(butterfly_all(nacc));
+  if (lane == 0) out[b] = n;
+}
+void launch_query_norms_bf16(const uint16_t* q16, uint64_t q_stride, float* out, uint32_t nq, uint32_t dim, hipStream_t st) {
+  hipLaunchKernelGGL(query_norms_bf16_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, q16, q_stride, out, nq, dim);
 }
 
 // From a merged prefix top-k (internal rows + raw scores, merge_topk with ext_ids = nullptr): the query's bound for the
@@ -694,7 +743,7 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
                                        const float* norms, const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride,
                                        const uint64_t* tau0, uint64_t* part_keys, uint32_t list_stride, uint32_t list_off,
                                        uint32_t dim, uint32_t nq, uint32_t k, hipStream_t st, bool split, const float* qnorms,
-                                       uint64_t* blk_tau) {
+                                       uint64_t* blk_tau, const float* qnorms_half) {
   Bf16GemmArgs a{};
   a.rows = rows16;
   a.norms = norms;
@@ -717,6 +766,7 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
   a.qper = p.qper;
   a.qnorms = qnorms;
   a.blk_tau = blk_tau;
+  a.qnorms_half = qnorms_half;
   if (split)
     return metric == kCosine ? launch_g16<kCosine, true>(a, p.blocks, st) : launch_g16<kDot, true>(a, p.blocks, st);
   if (pingpong_enabled()) return metric == kCosine ? launch_g16_pp<kCosine>(a, p.blocks, st) : launch_g16_pp<kDot>(a, p.blocks, st);

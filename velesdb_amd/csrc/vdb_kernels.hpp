@@ -188,7 +188,9 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
                                        const float* norms, const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride,
                                        const uint64_t* tau0, uint64_t* part_keys, uint32_t list_stride, uint32_t list_off,
                                        uint32_t dim, uint32_t nq, uint32_t k, hipStream_t st, bool split = false,
-                                       const float* qnorms = nullptr, uint64_t* blk_tau = nullptr);
+                                       const float* qnorms = nullptr, uint64_t* blk_tau = nullptr, const float* qnorms_half = nullptr);
+// norms of the rounded queries of a result-mode batch (qnorms_half above)
+void launch_query_norms_bf16(const uint16_t* q16, uint64_t q_stride, float* out, uint32_t nq, uint32_t dim, hipStream_t st);
 void launch_seed_tau(const uint64_t* ids, const float* scores, const uint32_t* n, uint64_t* tau0, uint64_t* list,
                      uint32_t list_stride, uint32_t nq, uint32_t k, hipStream_t st);
 // bf16 GEMM-distance sweep (cosine / dot over a bf16 copy of the rows): nqt in {1, 2, 4, 6} 16-query tiles
