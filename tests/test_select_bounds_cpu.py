@@ -84,3 +84,36 @@ def test_euclidean_augmentation_bound():
             # and the identity the proof turns back into a distance
             d2 = float(np.dot(q64 - v64, q64 - v64))
             assert abs(d2 - (float(np.dot(q64, q64)) - 2.0 * exact)) <= 1e-9 * max(d2, 1.0)
+
+
+def test_measured_residual_bound_of_level_2():
+    # sweep_split.hip select_eps_q: |x.q - hx.hq| <= (rho_x + rho_q + 3 rho_x rho_q) |x| |q| with the MEASURED residual ratios
+    # rho = |v - bf16(v)| / |v| — for any data (adversarial boundary values, denormal-range rows, mixed scales), and about
+    # half the constant bound on Gaussian data (what the benchmark and typical embeddings look like)
+    rng = np.random.default_rng(3)
+
+    def rho(v):
+        h, _ = split(v)
+        v64 = v.astype(np.float64)
+        n = float(np.linalg.norm(v64))
+        return (float(np.linalg.norm(v64 - h)) / n if n > 0.0 else 0.0), h
+
+    extra = [
+        (np.full(768, 1e-40, np.float32), rng.standard_normal(768).astype(np.float32)),           # denormal row: rho far above 2^-8
+        ((rng.standard_normal(768) * np.exp(rng.uniform(-30, 30, 768))).astype(np.float32), rng.standard_normal(768).astype(np.float32)),
+    ]
+    ratios = []
+    for x, q in list(cases(rng)) + extra:
+        rx, xh = rho(x)
+        rq, qh = rho(q)
+        x64, q64 = x.astype(np.float64), q.astype(np.float64)
+        scale = float(np.linalg.norm(x64) * np.linalg.norm(q64))
+        if scale == 0.0:
+            continue
+        err = abs(float(np.dot(xh, qh)) - float(np.dot(x64, q64)))
+        bound = (rx + rq + 3.0 * rx * rq) * scale
+        assert err <= bound * (1.0 + 1e-12), (err / scale, rx, rq)
+        ratios.append((rx, rq))
+    g = [rho(rng.standard_normal(768).astype(np.float32))[0] for _ in range(200)]
+    assert max(g) < 0.5 * 2.0 ** -8, max(g)       # Gaussian rows: ~0.41 x 2^-8
+    assert max(r for r, _ in ratios) > 0.05       # ... while the denormal row shows why the constant was not a bound for ALL data

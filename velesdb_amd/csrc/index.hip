@@ -123,6 +123,7 @@ void copy_image_fields(vdb_hip_index* c, const vdb_hip_index* p) {
   c->sel_norms = p->sel_norms;
   c->rows_bf16 = p->rows_bf16;
   c->norms_bf16 = p->norms_bf16;
+  c->bf16_rho = p->bf16_rho;
   c->bf16_enabled = p->bf16_enabled;
   c->bf16_stride = p->bf16_stride;
   c->bf16_rows = p->bf16_rows;
@@ -304,7 +305,7 @@ static int32_t finish_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
   }
   if (ix->bf16_enabled) {
     launch_prep_bf16(ix->rows.as<float>(), ix->row_stride, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride,
-                     ix->norms_bf16.as<float>(), (uint32_t)first, (uint32_t)n, ix->dim, ix->stream);
+                     ix->norms_bf16.as<float>(), (uint32_t)first, (uint32_t)n, ix->dim, ix->stream, ix->bf16_rho.as<uint32_t>());
     ix->bf16_rows = first + n;
   }
   if (ix->split_enabled) {
@@ -654,6 +655,12 @@ static int32_t ensure_sel16(vdb_hip_index* ix, hipStream_t st) {
   const int32_t rc = build_image_on_primary(ix, st, !p->bf16_enabled || p->bf16_rows < p->n_rows || !p->sel_norms, ensure_sel16_impl);
   return rc != VDB_OK ? rc : pinned_select_stats(ix);
 }
+// the residual-ratio scalar of a bf16 copy that is about to be (re)built from row 0
+static int32_t reset_bf16_rho(vdb_hip_index* ix, hipStream_t st) {
+  hipError_t e = ix->bf16_rho.reserve(256, false, st);
+  if (e == hipSuccess) e = hipMemsetAsync(ix->bf16_rho.p, 0, 256, st);
+  return e == hipSuccess ? VDB_OK : fail(VDB_ERR_OOM, std::string("bf16 residual bound: ") + hipGetErrorString(e));
+}
 static int32_t ensure_sel16_impl(vdb_hip_index* ix, hipStream_t st) {
   hipError_t e;
   if (!ix->bf16_enabled) {
@@ -661,12 +668,14 @@ static int32_t ensure_sel16_impl(vdb_hip_index* ix, hipStream_t st) {
     if ((e = ix->rows_bf16.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * ix->bf16_stride * 2, false, st)) != hipSuccess ||
         (e = ix->norms_bf16.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * 4, false, st)) != hipSuccess)
       return fail(VDB_ERR_OOM, std::string("bf16 rows: ") + hipGetErrorString(e));
+    const int32_t rr = reset_bf16_rho(ix, st);
+    if (rr != VDB_OK) return rr;
     ix->bf16_enabled = true;
     ix->bf16_rows = 0;
   }
   if (ix->bf16_rows < ix->n_rows) {
     launch_prep_bf16(ix->rows.as<float>(), ix->row_stride, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride, ix->norms_bf16.as<float>(),
-                     (uint32_t)ix->bf16_rows, (uint32_t)(ix->n_rows - ix->bf16_rows), ix->dim, st);
+                     (uint32_t)ix->bf16_rows, (uint32_t)(ix->n_rows - ix->bf16_rows), ix->dim, st, ix->bf16_rho.as<uint32_t>());
     ix->bf16_rows = ix->n_rows;
   }
   if (!ix->sel_norms) {
@@ -843,7 +852,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   const bool bf16_seed = level == 2 && !l2 && !sq8 && g_bf16_seed;
   const size_t o_seedp = take(std::max((size_t)nqg * sp.G * k * 8, bf16_seed ? (size_t)nqg * R0 * 8 : (size_t)0)), o_ids = take((size_t)nqg * K2 * 8), o_sc = take((size_t)nqg * K2 * 4),
                o_n = take((size_t)nqg * 4), o_tau = take((size_t)nqg * 8), o_delta = take((size_t)nqg * 4),
-               o_qn = take((size_t)nqg * 4), o_flags = take((size_t)nqg * 4 + 64 * 4 + 16), o_btau = take((size_t)nqg * lists * 8),
+               o_qn = take((size_t)nqg * 4), o_rho = take((size_t)nqg * 4), o_flags = take((size_t)nqg * 4 + 64 * 4 + 16), o_btau = take((size_t)nqg * lists * 8),
                o_fid = take((size_t)nqg * k * 8), o_fsc = take((size_t)nqg * k * 4), o_fn = take((size_t)nqg * 4),
                o_qmap = take((size_t)nqg * 4 + 16), o_gid = take((size_t)96 * k * 8), o_gsc = take((size_t)96 * k * 4),
                o_gn = take((size_t)96 * 4);
@@ -861,6 +870,9 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   uint64_t* tau0 = reinterpret_cast<uint64_t*>(sd + o_tau);
   float* delta = reinterpret_cast<float*>(sd + o_delta);
   float* qnorms = reinterpret_cast<float*>(sd + o_qn);
+  // level 2 over the f32 rows: the error bound from MEASURED rounding residuals (sweep_split.hip select_eps_q)
+  float* rho_q = (level == 2 && !l2 && !sq8 && ix->bf16_rho.p) ? reinterpret_cast<float*>(sd + o_rho) : nullptr;
+  const uint32_t* rho_max = rho_q ? ix->bf16_rho.as<uint32_t>() : nullptr;
   uint32_t* flags = reinterpret_cast<uint32_t*>(sd + o_flags);
   uint32_t* tile_needed = flags + nqg;          // [<= 64]
   uint32_t* norm_max = tile_needed + 64;
@@ -887,6 +899,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     launch_prep_rows(pq, st);
   } else if (level >= 2) {
     launch_round_queries_bf16(d_q, q_stride, q16, img_stride, nqg, dim, st);
+    if (rho_q) launch_query_round_error(d_q, q_stride, rho_q, nqg, dim, st);
     PrepArgs pq{};
     pq.rows = d_q;
     pq.norms = qnorms;
@@ -929,7 +942,8 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     ms.k = 1;
     ms.k_out = ks;
     launch_merge(true, ms, nqg, st);
-    launch_split_seed_approx(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, R0, dim, level, st);
+    launch_split_seed_approx(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, R0, dim, level, st,
+                             rho_q, rho_max);
   } else {
   e = launch_sweep_gemm(sel_metric, sp, ag, st);
   if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split seed sweep launch: ") + hipGetErrorString(e));
@@ -941,7 +955,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   } else if (l2)
     launch_l2_seed(m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim_a, sq8 ? 1.5e-4f : 0.0f, st);
   else
-    launch_split_seed(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim, level, st);
+    launch_split_seed(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim, level, st, rho_q, rho_max);
   // selection launches over the split images
   uint32_t list_off = 1;
   for (int j = 0; j < n_launch; j++) {
@@ -1561,7 +1575,7 @@ int32_t create_single(uint32_t dim, int32_t metric, uint32_t M, uint32_t ef_cons
 std::vector<DevBuf*> index_buffers(vdb_hip_index* ix) {
   std::vector<DevBuf*> v = {
       &ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids,           // rows
-      &ix->rows_bf16, &ix->norms_bf16, &ix->rows_split,                     // bf16 copy, split-bf16 image
+      &ix->rows_bf16, &ix->norms_bf16, &ix->bf16_rho, &ix->rows_split,      // bf16 copy, split-bf16 image
       &ix->l2_img, &ix->l2_seed,                                            // Euclidean selection images
       &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq,                // int8 traversal
       &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits,  // storage modes
@@ -1949,10 +1963,14 @@ int32_t vdb_hip_index_enable_bf16(vdb_hip_index* ix) {
   if ((e = ix->rows_bf16.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * ix->bf16_stride * 2, false, ix->stream)) != hipSuccess ||
       (e = ix->norms_bf16.reserve((std::max<uint64_t>(ix->capacity, 1) + kRowSlack) * 4, false, ix->stream)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("bf16 rows: ") + hipGetErrorString(e));
+  {
+    const int32_t rr = reset_bf16_rho(ix, ix->stream);
+    if (rr != VDB_OK) return rr;
+  }
   ix->bf16_enabled = true;
   if (ix->n_rows) {
     launch_prep_bf16(ix->rows.as<float>(), ix->row_stride, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride,
-                     ix->norms_bf16.as<float>(), 0, (uint32_t)ix->n_rows, ix->dim, ix->stream);
+                     ix->norms_bf16.as<float>(), 0, (uint32_t)ix->n_rows, ix->dim, ix->stream, ix->bf16_rho.as<uint32_t>());
     VDB_HIP(hipGetLastError());
     VDB_HIP(hipStreamSynchronize(ix->stream));
   }

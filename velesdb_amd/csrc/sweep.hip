@@ -610,10 +610,13 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
-// rows f32 -> bf16 copy + norm of the ROUNDED row (canonical lane-chain order over the rounded values)
+// rows f32 -> bf16 copy + norm of the ROUNDED row (canonical lane-chain order over the rounded values); rho_max_bits != nullptr:
+// the row's rounding residual ratio |x - bf16(x)| / |x| (f64 sums: no f32 row underflows them) raises a device scalar — the
+// measured error bound of the level-2 selection (sweep_split.hip select_eps_q).  Rows with non-finite elements contribute
+// nothing: their scores are non-finite too and never proven.
 __global__ __launch_bounds__(256) void prep_bf16_rows(const float* rows, uint64_t row_stride, uint16_t* out,
                                                       uint64_t out_stride, float* norms, uint32_t row0, uint32_t n_rows,
-                                                      uint32_t dim) {
+                                                      uint32_t dim, uint32_t* rho_max_bits) {
   const int lane = lane_id();
   const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t nwaves = gridDim.x * 4;
@@ -622,22 +625,40 @@ __global__ __launch_bounds__(256) void prep_bf16_rows(const float* rows, uint64_
     const float* p = rows + (size_t)row * row_stride;
     uint16_t* o = out + (size_t)row * out_stride;
     float acc = 0.0f;
+    double se = 0.0, sx = 0.0;
     for (uint32_t c = lane; c * 4 < out_stride; c += 64) {
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         const uint32_t i = c * 4 + e;
         if (i < out_stride) {
-          const uint16_t h = i < dim ? f32_to_bf16_rne(p[i]) : (uint16_t)0;
+          const float v = i < dim ? p[i] : 0.0f;
+          const uint16_t h = i < dim ? f32_to_bf16_rne(v) : (uint16_t)0;
           o[i] = h;
           if (i < dim) {
             const float x = bf16_to_f32(h);
             acc = __builtin_fmaf(x, x, acc);
+            if (rho_max_bits) {
+              const float d = v - x;  // exact in f32
+              se += (double)d * (double)d;
+              sx += (double)v * (double)v;
+            }
           }
         }
       }
     }
     const float n = sqrtf(butterfly_all(acc));
     if (lane == 0 && norms) norms[row] = n;
+    if (rho_max_bits) {
+#pragma unroll
+      for (int o2 = 32; o2 > 0; o2 >>= 1) {
+        se += __shfl_xor(se, o2, 64);
+        sx += __shfl_xor(sx, o2, 64);
+      }
+      if (lane == 0 && sx > 0.0) {
+        const float rho = (float)(sqrt(se / sx) * 1.0000002);  // (rounded to f32: the pad covers it)
+        if (rho == rho && rho < __uint_as_float(0x7F800000u)) atomicMax(rho_max_bits, __float_as_uint(rho));  // >= +0: bit order = value order
+      }
+    }
   }
 }
 
@@ -1759,11 +1780,11 @@ size_t sweep_bf16_lds_bytes(int nqt, uint32_t k, uint32_t dim) {
   return ((KU * nqt * 8192 + B * k * 8 + B * 12) + 15) & ~(size_t)15;
 }
 void launch_prep_bf16(const float* rows, uint64_t row_stride, uint16_t* out, uint64_t out_stride, float* norms,
-                      uint32_t row0, uint32_t n_rows, uint32_t dim, hipStream_t st) {
+                      uint32_t row0, uint32_t n_rows, uint32_t dim, hipStream_t st, uint32_t* rho_max_bits) {
   if (n_rows == 0) return;
   const int blocks = (int)std::min<uint64_t>(((uint64_t)n_rows + 3) / 4, 4096);
   hipLaunchKernelGGL(prep_bf16_rows, dim3(blocks), dim3(256), 0, st, rows, row_stride, out, out_stride, norms, row0,
-                     n_rows, dim);
+                     n_rows, dim, rho_max_bits);
 }
 template <int METRIC, int NQT, int WAVES>
 static hipError_t launch_bf16_t(const Bf16SweepArgs& a, int blocks, size_t lds, hipStream_t st) {

@@ -89,6 +89,41 @@ __host__ __device__ inline float select_eps(uint32_t dim, int level) {
   return (level >= 2 ? 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f : 8.2f * 3.8146973e-6f) + acc + (level >= 3 ? 1.5e-4f : 0.0f);
 }
 
+// Level 2 with MEASURED rounding residuals (round 3).  The constant above takes every element at bf16's worst case (2^-8 of its
+// magnitude); with ex = x - bf16(x), eq = q - bf16(q) the dropped terms are ex.hq + hx.eq + ex.eq, and by Cauchy-Schwarz
+//   |x.q - hx.hq| <= (rho_x + rho_q + 3 rho_x rho_q) |x| |q|,   rho_x = |ex| / |x|, rho_q = |eq| / |q|   (rho <= 1),
+// where rho_x is bounded by the largest residual ratio of any row of the image (prep_bf16_rows keeps it: a device scalar,
+// rows of typical data sit at 0.4 x 2^-8) and rho_q is the batch's own (query_round_error).  Residuals and norms are summed in
+// f64 (no underflow for any f32 row, rounding error far below the 1.002 pad).  Half the constant bound on the benchmark data:
+// a third of the candidates in front of the selection kernel's epilogue.
+__device__ __forceinline__ float select_eps_q(uint32_t dim, int level, const float* rho_q, const uint32_t* rho_max_bits, uint32_t q) {
+  if (level != 2 || !rho_q || !rho_max_bits) return select_eps(dim, level);
+  const float rm = __uint_as_float(*rho_max_bits), rq = rho_q[q];
+  return (rm + rq + 3.0f * rm * rq) * 1.002f + 16.0f * (float)dim * 5.9604645e-8f;  // (NaN query: NaN -> no bound, no proof)
+}
+// rho_q per query: one wave per query
+__global__ __launch_bounds__(256) void query_round_error_kernel(const float* q, uint64_t q_stride, float* rho_q, uint32_t nq, uint32_t dim) {
+  const uint32_t lane = threadIdx.x & 63u, b = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (b >= nq) return;
+  const float* p = q + (size_t)b * q_stride;
+  double se = 0.0, sx = 0.0;
+  for (uint32_t i = lane; i < dim; i += 64) {
+    const float x = p[i];
+    const float e = x - __uint_as_float((uint32_t)bf16_rne(x) << 16);  // exact in f32
+    se += (double)e * (double)e;
+    sx += (double)x * (double)x;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    se += __shfl_xor(se, o, 64);
+    sx += __shfl_xor(sx, o, 64);
+  }
+  if (lane == 0) rho_q[b] = sx > 0.0 ? (float)(sqrt(se / sx) * 1.0000002) : (sx == 0.0 ? 0.0f : __uint_as_float(0x7FC00000u));
+}
+void launch_query_round_error(const float* q, uint64_t q_stride, float* rho_q, uint32_t nq, uint32_t dim, hipStream_t st) {
+  hipLaunchKernelGGL(query_round_error_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, q, q_stride, rho_q, nq, dim);
+}
+
 // Seed from the EXACT sweep of the first rows (merged to rows + raw scores, best first): list slot 0 of the candidate pool
 // = its top k as keys (they are exact scores: re-scoring them later reproduces them), the query's error bound
 // delta (cosine: eps; dot: eps |q| max|v|), and the selection kernel's starting bound = k-th best exact score lowered by
@@ -97,10 +132,11 @@ template <int METRIC>
 __global__ __launch_bounds__(256) void split_seed_kernel(const uint64_t* ids, const float* scores, const uint32_t* n,
                                                          const float* qnorms, const uint32_t* norm_max_bits, uint64_t* tau0,
                                                          float* delta, uint64_t* list, uint64_t* blk_tau, uint32_t list_stride,
-                                                         uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim, int level) {
+                                                         uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim, int level,
+                                                         const float* rho_q, const uint32_t* rho_max_bits) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
-  const float eps = select_eps(dim, level);
+  const float eps = select_eps_q(dim, level, rho_q, rho_max_bits, q);
   const float d = METRIC == kCosine ? eps * 1.001f + 4e-7f : eps * 1.001f * qnorms[q] * __uint_as_float(*norm_max_bits) + 1e-30f;
   delta[q] = d;
   const uint32_t c = min(n[q], k);
@@ -117,13 +153,14 @@ __global__ __launch_bounds__(256) void split_seed_kernel(const uint64_t* ids, co
 }
 void launch_split_seed(int metric, const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
                        const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
-                       uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim, int level, hipStream_t st) {
+                       uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim, int level, hipStream_t st,
+                       const float* rho_q, const uint32_t* rho_max_bits) {
   if (metric == kCosine)
     hipLaunchKernelGGL((split_seed_kernel<kCosine>), dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits,
-                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, dim, level);
+                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, dim, level, rho_q, rho_max_bits);
   else
     hipLaunchKernelGGL((split_seed_kernel<kDot>), dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits,
-                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, dim, level);
+                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, dim, level, rho_q, rho_max_bits);
 }
 
 // ---- level 2's seed on the bf16 pipe (round 3) -----------------------------------------------------------------------------
@@ -197,10 +234,11 @@ template <int METRIC>
 __global__ __launch_bounds__(256) void split_seed_approx_kernel(const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
                                                                 const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list,
                                                                 uint64_t* blk_tau, uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist,
-                                                                uint32_t seed_rows, uint32_t dim, int level) {
+                                                                uint32_t seed_rows, uint32_t dim, int level, const float* rho_q,
+                                                                const uint32_t* rho_max_bits) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
-  const float eps = select_eps(dim, level);
+  const float eps = select_eps_q(dim, level, rho_q, rho_max_bits, q);
   const float d = METRIC == kCosine ? eps * 1.001f + 4e-7f : eps * 1.001f * qnorms[q] * __uint_as_float(*norm_max_bits) + 1e-30f;
   delta[q] = d;
   const uint32_t c = min(n[q], klist);
@@ -220,13 +258,13 @@ __global__ __launch_bounds__(256) void split_seed_approx_kernel(const uint64_t* 
 void launch_split_seed_approx(int metric, const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
                               const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
                               uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t seed_rows, uint32_t dim, int level,
-                              hipStream_t st) {
+                              hipStream_t st, const float* rho_q, const uint32_t* rho_max_bits) {
   if (metric == kCosine)
     hipLaunchKernelGGL((split_seed_approx_kernel<kCosine>), dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits,
-                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, seed_rows, dim, level);
+                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, seed_rows, dim, level, rho_q, rho_max_bits);
   else
     hipLaunchKernelGGL((split_seed_approx_kernel<kDot>), dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits,
-                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, seed_rows, dim, level);
+                       tau0, delta, list, blk_tau, list_stride, nq, k, klist, seed_rows, dim, level, rho_q, rho_max_bits);
 }
 
 // Between two selection launches: the next launch's bound = k-th best POOL score so far (approximate scores, exact ones for

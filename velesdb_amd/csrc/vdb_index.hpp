@@ -115,6 +115,9 @@ struct vdb_hip_index {
   vdb::DevBuf rows, norms, bits, alive, ext_ids;
   // optional bf16 copy of the rows for the GEMM-distance sweep (vdb_hip_index_enable_bf16)
   vdb::DevBuf rows_bf16, norms_bf16;
+  // one u32: the f32 bit pattern of the largest rounding residual ratio |x - bf16(x)| / |x| over every row the bf16 copy ever held
+  // (prep_bf16_rows raises it; never lowered: a bound) — the level-2 selection's measured error bound (sweep_split.hip)
+  vdb::DevBuf bf16_rho;
   // optional scalar quantiser + u8 codes for the int8 traversal (hnsw_int8.hip)
   vdb::DevBuf sq_min, sq_scale, codes, codes_sq;
   uint32_t code_words = 0;

@@ -197,8 +197,9 @@ void launch_seed_tau(const uint64_t* ids, const float* scores, const uint32_t* n
 constexpr int kBf16WavesBig = 16;    // waves per block for nqt >= 4 (one block per CU)
 constexpr int kBf16WavesSmall = 8;   // ... for nqt <= 2
 size_t sweep_bf16_lds_bytes(int nqt, uint32_t k, uint32_t dim);
+// rho_max_bits (nullable): device scalar, raised to the largest |x - bf16(x)| / |x| of the converted rows (select_eps_q)
 void launch_prep_bf16(const float* rows, uint64_t row_stride, uint16_t* out, uint64_t out_stride, float* norms,
-                      uint32_t row0, uint32_t n_rows, uint32_t dim, hipStream_t st);
+                      uint32_t row0, uint32_t n_rows, uint32_t dim, hipStream_t st, uint32_t* rho_max_bits = nullptr);
 hipError_t launch_sweep_bf16(int metric, int nqt, const uint16_t* rows, uint64_t row_stride, const float* norms,
                              const uint8_t* alive, const float* queries, uint64_t q_stride, uint64_t* part_keys,
                              uint32_t n_rows, uint32_t dim, uint32_t nq, uint32_t k, int blocks, hipStream_t st);
@@ -239,7 +240,10 @@ void launch_split_vectors(const float* src, uint64_t src_stride, uint16_t* out, 
                           uint32_t dim, hipStream_t st);
 void launch_split_seed(int metric, const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
                        const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
-                       uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim, int level, hipStream_t st);
+                       uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim, int level, hipStream_t st,
+                       const float* rho_q = nullptr, const uint32_t* rho_max_bits = nullptr);
+// level 2's measured rounding residuals (sweep_split.hip select_eps_q): rho_q[nq] = |q - bf16(q)| / |q| of a batch
+void launch_query_round_error(const float* q, uint64_t q_stride, float* rho_q, uint32_t nq, uint32_t dim, hipStream_t st);
 // level 2's seed on the bf16 pipe: a plain GEMM of the first rows x the batch into keys [nq][seed_rows], and the seed kernel for
 // approximate seed scores (tau = A_k - 2 delta; slot 0 of the pool with its bound)
 void launch_seed_scores_bf16(int metric, const uint16_t* rows16, uint64_t row_stride, const float* norms, const uint8_t* alive,
@@ -248,7 +252,7 @@ void launch_seed_scores_bf16(int metric, const uint16_t* rows16, uint64_t row_st
 void launch_split_seed_approx(int metric, const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
                               const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
                               uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t seed_rows, uint32_t dim, int level,
-                              hipStream_t st);
+                              hipStream_t st, const float* rho_q = nullptr, const uint32_t* rho_max_bits = nullptr);
 // {unproven, queries, seq, level} of a finished selection batch -> pinned host memory (no synchronisation)
 void launch_select_stats(const uint32_t* flags, uint32_t nq, uint32_t seq, uint32_t level, volatile uint32_t* host, hipStream_t st);
 void launch_split_reseed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* delta, uint64_t* tau0,
