@@ -2,6 +2,7 @@
 // Each entry point names the reference interface it replaces.  No CPU compute path exists
 // here: every score, norm, bit-pack, top-k and traversal runs in a HIP kernel.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -824,10 +825,22 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   int n_launch = 0;
   {
     uint32_t lo = R0, left = tiles_all;
-    const uint32_t steps[3] = {G2, 4 * G2, 16 * G2};
-    for (int j = 0; j < 3 && left >= 2 * steps[j]; j++) {  // (the rest must be worth at least as much again)
+    // (VELESDB_SEL_STEPS="a,b,c": tiles per row group of the first launches — schedule probes)
+    static const std::array<uint32_t, 3> mult = [] {
+      std::array<uint32_t, 3> m{1, 4, 16};
+      if (const char* e = getenv("VELESDB_SEL_STEPS")) {
+        unsigned a = 0, b = 0, c = 0;
+        const int got = sscanf(e, "%u,%u,%u", &a, &b, &c);
+        m = {got >= 1 ? a : 0u, got >= 2 ? b : 0u, got >= 3 ? c : 0u};
+      }
+      return m;
+    }();
+    const uint32_t steps[3] = {mult[0] * G2, mult[1] * G2, mult[2] * G2};
+    int ns = 0;
+    while (ns < 3 && steps[ns]) ns++;
+    for (int j = 0; j < ns && left >= 2 * steps[j]; j++) {  // (the rest must be worth at least as much again)
       uint32_t t = steps[j];
-      if (j == 2 || left < 2 * steps[j + 1 < 3 ? j + 1 : 2]) t += (left - t) % G2;  // the launch behind this one is the last: whole row tiles per row group
+      if (j == ns - 1 || left < 2 * steps[j + 1]) t += (left - t) % G2;  // the launch behind this one is the last: whole row tiles per row group
       const uint32_t hi = lo + t * 256;
       sweep_gemm_bf16_plan(nqg, lo, hi, ix->n_cus, &bp[n_launch++]);
       lo = hi;
@@ -911,9 +924,10 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   } else {
     launch_split_vectors(d_q, q_stride, q16, qnorms, 0, nqg, dim, st);
   }
-  VDB_HIP(hipMemsetAsync(q16 + (size_t)nqg * img_stride, 0, (size_t)256 * img_stride * 2, st));
-  VDB_HIP(hipMemsetAsync(pool, 0xFF, (size_t)nqg * lists * ks * 8, st));
-  VDB_HIP(hipMemsetAsync(blk_tau, 0xFF, (size_t)nqg * lists * 8, st));
+  if (nqg % 256u) VDB_HIP(hipMemsetAsync(q16 + (size_t)nqg * img_stride, 0, (size_t)256 * img_stride * 2, st));  // (whole tiles read nothing behind the batch)
+  // (pool and blk_tau need no fill: the seed kernel writes slot 0 of every query, every selection block writes its slot of
+  // every query of its tile — all ks keys, padded with invalid ones, and its bound — and every merge reads only the slots
+  // written so far)
   VDB_HIP(hipMemsetAsync(flags, 0, (size_t)nqg * 4 + 64 * 4 + 16, st));
   if (!sq8 && !l2) VDB_HIP(hipMemsetAsync(ix->s_fb_keys.p, 0xFF, (size_t)nqg * fp.G * k * 8, st));
   if (sel_metric == VDB_DOT) launch_max_norm(sel_norms, n, norm_max, st);
@@ -972,8 +986,11 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
       ms.list_stride = lists;
       ms.k = ks;
       ms.k_out = k;
+      ms.reseed_delta = delta;  // ... and the bound itself, in the merge's own pass (sweep_split.hip split_reseed_kernel's rule)
+      ms.reseed_tau = tau0;
+      ms.reseed_k = k;
       launch_merge(true, ms, nqg, st);
-      launch_split_reseed(m_ids, m_sc, m_n, delta, tau0, nqg, k, k, st);
+      ms.reseed_delta = nullptr;
     }
   }
   // pool -> K2 best by pool score -> exact re-scoring, ranking, proof

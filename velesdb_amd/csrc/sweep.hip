@@ -833,6 +833,11 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 16 ? 4 : 2)) void sweep_topk_
 // merge: one wave per query scans the per-wave lists with the same threshold + insert scheme
 // and writes ids / scores best-first.
 // ------------------------------------------------------------------------------------------
+// the lowered bound of the selection stage's next launch (pool scores may err by delta either way)
+__device__ __forceinline__ uint64_t reseed_key(float s, float delta) {
+  const float lowered = s - 2.0f * delta * 1.01f - fabsf(s) * 1e-6f;
+  return lowered == lowered ? make_key<true>(lowered, 0u) : kKeyInvalid;  // NaN: no bound
+}
 template <bool HIB>
 __global__ __launch_bounds__(256) void merge_topk(MergeArgs m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -888,12 +893,16 @@ __global__ __launch_bounds__(256) void merge_topk(MergeArgs m) {
       const float s = key_score<HIB>(key);  // raw compute_distance value (search.rs:209)
       m.out_ids[(size_t)qi * k + e] = m.ext_ids ? m.ext_ids[row] : (uint64_t)row + m.row_base;
       m.out_scores[(size_t)qi * k + e] = s;
+      if (m.reseed_delta && e + 1 == m.reseed_k) m.reseed_tau[qi] = reseed_key(s, m.reseed_delta[qi]);
     } else {
       m.out_ids[(size_t)qi * k + e] = ~0ull;
       m.out_scores[(size_t)qi * k + e] = __uint_as_float(0x7FC00000u);
     }
   }
-  if (lane == 0) m.out_n[qi] = cnt;
+  if (lane == 0) {
+    m.out_n[qi] = cnt;
+    if (m.reseed_delta && (cnt < m.reseed_k || m.reseed_k == 0)) m.reseed_tau[qi] = kKeyInvalid;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -988,13 +997,17 @@ __global__ __launch_bounds__(256) void merge_topk_select(MergeArgs m) {
       const uint32_t row = key_row(key);
       m.out_ids[(size_t)qi * k + rank] = m.ext_ids ? m.ext_ids[row] : (uint64_t)row + m.row_base;
       m.out_scores[(size_t)qi * k + rank] = key_score<HIB>(key);  // raw compute_distance value (search.rs:209)
+      if (m.reseed_delta && rank + 1 == m.reseed_k) m.reseed_tau[qi] = reseed_key(key_score<HIB>(key), m.reseed_delta[qi]);
     }
   }
   for (uint32_t e = cnt + tid; e < k; e += 256) {
     m.out_ids[(size_t)qi * k + e] = ~0ull;
     m.out_scores[(size_t)qi * k + e] = __uint_as_float(0x7FC00000u);
   }
-  if (tid == 0) m.out_n[qi] = cnt;
+  if (tid == 0) {
+    m.out_n[qi] = cnt;
+    if (m.reseed_delta && (cnt < m.reseed_k || m.reseed_k == 0)) m.reseed_tau[qi] = kKeyInvalid;
+  }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -349,33 +349,70 @@ __global__ __launch_bounds__(256) void split_rerank_verify(SplitRerankArgs a) {
       keys[tid] = make_key<true>(score, row);
     }
   } else {
+  // oracle mode M (vdb_oracle.cpp dotM; sweep_topk_gemm_f32): ONE fmaf chain per candidate over k = 128 U + 16 m + 4 kk + c in
+  // the order U, m, c, kk, the vector zero-padded to a multiple of 128 (the padding steps are part of the chain).  The chain is
+  // serial by definition and belongs to one lane; the MEMORY side is the block's: the candidates' rows travel through LDS in
+  // steps of 64 elements, every load instruction a run of whole rows' 256-byte pieces (a lane reading its own row 16 bytes at
+  // a time touched 64 lines per instruction and, with 8 blocks per CU, evicted them before their other 48 bytes were used:
+  // 2.1 x the rows' bytes from HBM, 124 us per 1 024-query batch), double-buffered: the next step's loads are in flight while
+  // the chains run.
   const float qn = METRIC == kCosine ? a.qnorms[qi] : 0.0f;
-  if (tid < n) {
-    const uint32_t row = (uint32_t)a.cand_rows[(size_t)qi * a.k2 + tid];
-    const float* p = a.rows + (size_t)row * a.row_stride;
-    // oracle mode M (vdb_oracle.cpp dotM; sweep_topk_gemm_f32): ONE fmaf chain over k = 128 U + 16 m + 4 kk + c in the
-    // order U, m, c, kk, the vector zero-padded to a multiple of 128 (the padding steps are part of the chain)
-    float acc = 0.0f;
-    for (uint32_t U = 0; U < a.dim_pad; U += 128)
-      for (uint32_t m = 0; m < 8; m++) {
-        const uint32_t base = U + 16 * m;
-        float x[16];
+  {
+    constexpr uint32_t kStep = 64, kStride = kStep + 4;  // floats per row and step; + 4: 16-B aligned, rows on distinct banks
+    float* stage = qred + 2;                             // [2][k2][kStride], 16-byte aligned (bmin + qred = 16 bytes)
+    uint32_t* crow = reinterpret_cast<uint32_t*>(stage + 2 * (size_t)a.k2 * kStride);  // [k2] candidate rows
+    if (tid < n) crow[tid] = (uint32_t)a.cand_rows[(size_t)qi * a.k2 + tid];
+    __syncthreads();
+    const uint32_t nf4 = n * (kStep / 4);  // float4 per step
+    float4 v[4];                           // k2 <= 64: <= 1 024 float4 per step, 4 per thread
+    auto fetch = [&](uint32_t U) {
 #pragma unroll
-        for (int e = 0; e < 16; e += 4) {
-          if (base + e < a.dim) {  // dim % 4 == 0 (split path: dim % 32 == 0): whole float4 in range
-            const float4 v = ld4(p + base + e);
-            x[e] = v.x; x[e + 1] = v.y; x[e + 2] = v.z; x[e + 3] = v.w;
-          } else {
-            x[e] = x[e + 1] = x[e + 2] = x[e + 3] = 0.0f;
-          }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-          for (int kk = 0; kk < 4; kk++) acc = __builtin_fmaf(x[4 * kk + c], qs[base + 4 * kk + c], acc);
+      for (int i = 0; i < 4; i++) {
+        const uint32_t f = tid + 256u * (uint32_t)i;
+        const uint32_t r = f / (kStep / 4), c4 = f % (kStep / 4);
+        v[i] = (f < nf4 && U + 4 * c4 < a.dim) ? ld4(a.rows + (size_t)crow[r] * a.row_stride + U + 4 * c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
-    const float score = finish_score<METRIC>(acc, qn, METRIC == kCosine ? a.norms[row] : 1.0f);
-    keys[tid] = make_key<true>(score, row);
+    };
+    auto park = [&](uint32_t buf) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t f = tid + 256u * (uint32_t)i;
+        const uint32_t r = f / (kStep / 4), c4 = f % (kStep / 4);
+        if (f < nf4) *reinterpret_cast<float4*>(stage + ((size_t)buf * a.k2 + r) * kStride + 4 * c4) = v[i];
+      }
+    };
+    fetch(0);
+    park(0);
+    __syncthreads();
+    float acc = 0.0f;
+    for (uint32_t U = 0, buf = 0; U < a.dim_pad; U += kStep, buf ^= 1u) {
+      const bool more = U + kStep < a.dim_pad;
+      if (more) fetch(U + kStep);
+      if (tid < n) {
+        const float* x = stage + ((size_t)buf * a.k2 + tid) * kStride;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          float xr[16];
+#pragma unroll
+          for (int e = 0; e < 16; e += 4) {
+            const float4 w = *reinterpret_cast<const float4*>(x + 16 * m + e);
+            xr[e] = w.x; xr[e + 1] = w.y; xr[e + 2] = w.z; xr[e + 3] = w.w;
+          }
+          const uint32_t base = U + 16 * m;
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) acc = __builtin_fmaf(xr[4 * kk + c], qs[base + 4 * kk + c], acc);
+        }
+      }
+      if (more) park(buf ^ 1u);
+      __syncthreads();
+    }
+    if (tid < n) {
+      const uint32_t row = crow[tid];
+      const float score = finish_score<METRIC>(acc, qn, METRIC == kCosine ? a.norms[row] : 1.0f);
+      keys[tid] = make_key<true>(score, row);
+    }
   }
   }
   __syncthreads();
@@ -421,7 +458,8 @@ __global__ __launch_bounds__(256) void split_rerank_verify(SplitRerankArgs a) {
   }
 }
 void launch_split_rerank(int metric, const SplitRerankArgs& a, uint32_t nq, hipStream_t st) {
-  const size_t lds = ((size_t)a.dim_pad * 4 + (size_t)a.k2 * 8 + 16 + 16 + 15) & ~(size_t)15;
+  // query | keys | bmin | qred (16 B) | row stage [2][k2][68] f32 | candidate rows [k2]   (k2 <= 64)
+  const size_t lds = ((size_t)a.dim_pad * 4 + (size_t)a.k2 * 8 + 16 + 16 + 2 * (size_t)a.k2 * 68 * 4 + (size_t)a.k2 * 4 + 15) & ~(size_t)15;
   if (a.sq8_codes) {
     if (metric == kCosine)
       hipLaunchKernelGGL((split_rerank_verify<kCosine, true>), dim3(nq), dim3(256), lds, st, a);

@@ -44,6 +44,11 @@ struct MergeArgs {
   uint32_t list_stride;       // lists per query in part_keys (0 = n_lists): merge only the first n_lists of them
   const uint32_t* skip_cnt;   // nullable: nothing to do when *skip_cnt <= skip_le (the pass that would have filled the lists did not run)
   uint32_t skip_le;
+  // selection stage, between two launches (sweep_split.hip): the next launch's bound in the same pass — reseed_tau[q] = key of
+  // (the reseed_k-th best merged score lowered by 2 reseed_delta[q]), kKeyInvalid while fewer than reseed_k keys exist
+  const float* reseed_delta;  // nullable
+  uint64_t* reseed_tau;
+  uint32_t reseed_k;
 };
 
 struct EuclidRerankArgs {
