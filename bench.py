@@ -288,7 +288,7 @@ def main():
         nq_last, unproven = ix.last_split_stats()
         level = ix.last_select_level()
         mfmas_per_product = 3.0 if level == 1 else 1.0
-        sel_kernel = (f"sweep_topk_gemm_bf16_glds<{a.metric},SPLIT>" if level == 1 else f"sweep_topk_gemm_bf16_glds<{a.metric}> (plain bf16 selection)")
+        sel_kernel = (f"sweep_topk_gemm_bf16_glds<{a.metric},SPLIT>" if level == 1 else f"sweep_topk_gemm_bf16_pp<{a.metric}> (plain bf16 selection, ping-pong pipeline)")
         # the dominant kernel = the selection kernel: its launches of one step sweep every row behind the seed prefix once
         # (algorithmic flop 2 * rows * dim * queries per step), their durations are summed from HIP events around each launch
         sel_tf = (2.0 * (N - 4096) * D * tile) / (sel_ms * 1e-3) / 1e12 if sel_ms > 0 else 0.0
@@ -764,7 +764,7 @@ def main():
         sq8_leg = {"workload": f"{N}x{D} SQ8 codes ({a.metric}, asymmetric f32-query distances), k={K}",
                    "batch": {"queries": nq_big, "qps": round(nq_big / dt_sel, 1), "ms_per_batch": round(dt_sel * 1e3, 3),
                              "select_level": lvl, "unproven_queries_last_batch": unp,
-                             "kernel": "sweep_topk_gemm_bf16_glds over the dequantised bf16 image + split_rerank_verify<SQ8> + "
+                             "kernel": "sweep_topk_gemm_bf16_pp over the dequantised bf16 image + split_rerank_verify<SQ8> + "
                                        "gathered sweep_topk_sq8 for unproven queries"},
                    "exact_sweep_same_batch": {"qps": round(nq_big / dt_exact, 1), "ms_per_batch": round(dt_exact * 1e3, 3),
                                               "note": "sweep_topk_sq8<B=8> for every query (selection off), extrapolated from 64 queries"},
@@ -985,7 +985,7 @@ def main():
                                  "frac": round(b_tf / 2500.0, 4), "traffic": None, "kernel_ms": round(bk_ms, 4),
                                  "launches_timed": b_nl, "alg_flops_per_launch": bflop,
                                  "alg_bytes_per_launch": BR * D * 2 + BR * 4 + BQ * D * 2,
-                                 "kernel": "sweep_topk_gemm_bf16_glds<%s> (256x256 LDS-DMA tile; timed region = seed sweep + 2 launches + merges)" % a.metric,
+                                 "kernel": "sweep_topk_gemm_bf16_pp<%s> (256x256 LDS-DMA tile, ping-pong pipeline; timed region = seed sweep + launches of <= 2 M rows + merges)" % a.metric,
                                  "note": "dense bf16 MFMA peak 2.5 PFLOP/s (v_mfma_f32_16x16x32_bf16); algorithmic flop = 2*rows*dim*queries"}}
         if first_chunk is not None:
             from oracle import pyoracle as po

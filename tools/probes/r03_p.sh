@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03p
 mkdir -p $O
-for v in base noscan nopush noappend; do
+for v in base noscan; do
   [ $v != base ] && export VELESDB_HIP_LIB=$R/tools/probes/out/libvelesdb_hip_$v.so
   VELESDB_TRACE_LEVELS=2 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_$v -- python $R/tools/probes/split_probe.py --reps 3 > $O/probe_$v.log 2>&1
   python3 - $v <<'PY'

@@ -665,6 +665,94 @@ impl VectorIndex for HipHnswIndex {
     }
 }
 
+impl HipHnswIndex {
+    /// The index side of `Collection::search_with_filter` (`collection/search/vector.rs:164-235`): post-filtering over an
+    /// over-fetched candidate list — `candidates_k = max(4 k, k + 10)` through `VectorIndex::search`, the ids `keep` rejects
+    /// dropped, the first `k` survivors kept, then a stable sort in the metric's order (`partial_cmp`, incomparable = Equal).
+    /// Payload storage and the `Filter` type stay the caller's: `keep(id)` stands for `filter.matches(payload(id))`.
+    #[must_use]
+    pub fn search_filtered<F: Fn(u64) -> bool>(&self, query: &[f32], k: usize, keep: F) -> Vec<(u64, f32)> {
+        let candidates_k = k.saturating_mul(4).max(k + 10); // vector.rs:182
+        let mut out: Vec<(u64, f32)> = VectorIndex::search(self, query, candidates_k).into_iter().filter(|(id, _)| keep(*id)).take(k).collect();
+        let higher_is_better = self.metric.higher_is_better();
+        out.sort_by(|a, b| {
+            let o = if higher_is_better { b.1.partial_cmp(&a.1) } else { a.1.partial_cmp(&b.1) };
+            o.unwrap_or(std::cmp::Ordering::Equal)
+        });
+        out
+    }
+
+    /// Boxed as the trait object `Collection` holds: what a downstream crate's `hip` feature registers with the index factory
+    /// hook of velesdb-core (see Cargo.toml: the dependency points from this crate to the core, never back).
+    #[must_use]
+    pub fn boxed(dimension: usize, metric: DistanceMetric, params: HnswParams) -> Option<Box<dyn VectorIndex>> {
+        Self::with_params(dimension, metric, params).map(|ix| Box::new(ix) as Box<dyn VectorIndex>)
+    }
+}
+
+/// The reference's second `impl VectorIndex` (`index/hnsw/native_index.rs:403-427`) over the same graph.  What differs from
+/// [`HipHnswIndex`] is the search entry point: `search_with_quality` ALWAYS walks the graph with `ef = quality.ef_search(k)`
+/// (`native_index.rs:230-249`) — no exact-scan shortcut for `Perfect` or for indexes of <= 100 vectors, scores always through
+/// `transform_score`; removed ids are dropped after the cut.  Deviation kept from `HnswIndex`: a duplicate id is skipped (the
+/// reference re-inserts the vector under the existing internal index, `native_index.rs:256-263`).
+pub struct HipNativeHnswIndex(HipHnswIndex);
+
+impl HipNativeHnswIndex {
+    #[must_use]
+    pub fn new(dimension: usize, metric: DistanceMetric) -> Option<Self> {
+        HipHnswIndex::new(dimension, metric).map(Self)
+    }
+
+    #[must_use]
+    pub fn with_params(dimension: usize, metric: DistanceMetric, params: HnswParams) -> Option<Self> {
+        HipHnswIndex::with_params(dimension, metric, params).map(Self)
+    }
+
+    /// `native_index.rs:230-249`: the graph walk, whatever the quality and the size of the index.
+    #[must_use]
+    pub fn search_with_quality(&self, query: &[f32], k: usize, quality: SearchQuality) -> Vec<(u64, f32)> {
+        let q = [query];
+        self.0.search_batch_parallel(&q, k, quality).pop().unwrap_or_default()
+    }
+
+    /// `native_index.rs:275-295`
+    pub fn insert_batch(&self, items: &[(u64, Vec<f32>)]) {
+        let _ = self.0.insert_batch_parallel(items.iter().map(|(id, v)| (*id, v.clone())));
+    }
+
+    #[must_use]
+    pub fn inner(&self) -> &HipHnswIndex {
+        &self.0
+    }
+}
+
+impl VectorIndex for HipNativeHnswIndex {
+    fn insert(&self, id: u64, vector: &[f32]) {
+        VectorIndex::insert(&self.0, id, vector);
+    }
+
+    fn search(&self, query: &[f32], k: usize) -> Vec<(u64, f32)> {
+        // native_index.rs:225-227
+        self.search_with_quality(query, k, SearchQuality::Balanced)
+    }
+
+    fn remove(&self, id: u64) -> bool {
+        VectorIndex::remove(&self.0, id)
+    }
+
+    fn len(&self) -> usize {
+        VectorIndex::len(&self.0)
+    }
+
+    fn dimension(&self) -> usize {
+        VectorIndex::dimension(&self.0)
+    }
+
+    fn metric(&self) -> DistanceMetric {
+        VectorIndex::metric(&self.0)
+    }
+}
+
 impl Drop for HipHnswIndex {
     fn drop(&mut self) {
         // SAFETY: the handle was created by the library and is destroyed exactly once.

@@ -5,7 +5,7 @@ include/velesdb_hip.h; this package is the host-side mirror of the reference's
 VectorIndex / HnswIndex / DistanceEngine / GpuAccelerator interfaces over that ABI.
 """
 from ._ffi import LIB_PATH, VelesHipError, lib  # noqa: F401
-from .index import (GpuAccelerator, HipDistance, HnswIndex, MODE_AUTO, MODE_BRUTE, MODE_BRUTE_BF16, MODE_HNSW, MODE_HNSW_INT8,  # noqa: F401
+from .index import (GpuAccelerator, HipDistance, HnswIndex, NativeHnswIndex, MODE_AUTO, MODE_BRUTE, MODE_BRUTE_BF16, MODE_HNSW, MODE_HNSW_INT8,  # noqa: F401
                     MODE_BRUTE_SQ8, MODE_BRUTE_BINARY, OPT_INT8_OVERSAMPLING, OPT_KERNEL_TIMING, OPT_MAX_QUERY_TILE,
                     OPT_SELECTOR_LEVEL, OPT_SWEEP_ENGINE, SHARD_RANGE, SHARD_REPLICA, comm_unique_id,
                     device_count, device_name, set_kernel_timing, set_max_query_tile, set_split_selector, set_sweep_engine)
@@ -14,5 +14,5 @@ from .index import (KERNEL_BITS, KERNEL_GEMM_BF16, KERNEL_GEMM_BF16_GLDS, KERNEL
                     KERNEL_SWEEP_VALU)
 from .params import DistanceMetric, HnswParams, SearchQuality, StorageMode  # noqa: F401
 
-__all__ = ["HnswIndex", "HipDistance", "GpuAccelerator", "DistanceMetric", "HnswParams", "SearchQuality", "StorageMode",
+__all__ = ["HnswIndex", "NativeHnswIndex", "HipDistance", "GpuAccelerator", "DistanceMetric", "HnswParams", "SearchQuality", "StorageMode",
            "device_count", "device_name", "comm_unique_id", "SHARD_RANGE", "SHARD_REPLICA", "set_kernel_timing", "set_max_query_tile", "set_sweep_engine", "set_split_selector", "lib", "VelesHipError"]

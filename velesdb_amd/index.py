@@ -191,6 +191,23 @@ class HnswIndex:
             ids, sc, cnt = self._search_raw(q, k, quality.ef_search(k), MODE_AUTO)
         return self._tuples(ids[0], sc[0], cnt[0])
 
+    def search_filtered(self, query, k: int, keep) -> List[Tuple[int, float]]:
+        """The index side of Collection::search_with_filter (collection/search/vector.rs:164-235): post-filtering over an
+        over-fetched candidate list — candidates_k = max(4 k, k + 10) through VectorIndex::search, the ids `keep(id)`
+        rejects dropped, the first k survivors kept, then ordered by the metric's rule (a stable sort, as the reference's
+        sort_by over partial_cmp).  Payload storage and the Filter type stay the caller's: `keep` stands for
+        `filter.matches(payload(id))`."""
+        candidates_k = max(k * 4, k + 10)  # vector.rs:182
+        out = [(i, s) for i, s in self.search(query, candidates_k) if keep(i)][:k]
+        hib = self._metric in (DistanceMetric.Cosine, DistanceMetric.DotProduct, DistanceMetric.Jaccard)  # higher_is_better
+        # vector.rs:219-233: stable sort by score (partial_cmp; incomparable pairs compare Equal and keep their order)
+        import functools
+
+        def cmp(a, b):
+            x, y = (b[1], a[1]) if hib else (a[1], b[1])
+            return -1 if x < y else (1 if x > y else 0)
+        return sorted(out, key=functools.cmp_to_key(cmp))
+
     def search_brute_force(self, query, k: int) -> List[Tuple[int, float]]:
         """search.rs:176-219: exact scan, raw scores, metric.sort_results order."""
         q = _f32(query).reshape(1, -1)
@@ -479,6 +496,24 @@ class HnswIndex:
         check(lib().vdb_hip_index_search_batch_dev(self._h, C.c_void_p(d_queries), nq, k, ef, mode,
                                                    C.c_void_p(d_ids), C.c_void_p(d_scores), C.c_void_p(d_n),
                                                    C.c_void_p(stream)))
+
+
+class NativeHnswIndex(HnswIndex):
+    """index/hnsw/native_index.rs: the reference's second `impl VectorIndex` (:403-427) over the same NativeHnsw graph.  What
+    differs from HnswIndex is the search entry point: `search_with_quality` ALWAYS walks the graph with
+    ef = quality.ef_search(k) (:230-249) — no exact-scan shortcut for Perfect or for indexes of <= 100 vectors, scores always
+    through transform_score; removed ids are dropped after the cut (:241-247, mappings.get_id).  Deviation kept from
+    HnswIndex: a duplicate id is skipped (the reference re-inserts the vector under the existing internal index, :256-263,
+    which links one node twice)."""
+
+    def search_with_quality(self, query, k: int, quality: SearchQuality) -> List[Tuple[int, float]]:
+        q = _f32(query).reshape(1, -1)
+        self._validate(q)
+        ids, sc, cnt = self._search_raw(q, k, quality.ef_search(k), MODE_HNSW)
+        return self._tuples(ids[0], sc[0], cnt[0])
+
+    def insert_batch(self, items) -> None:  # native_index.rs:275-295
+        self.insert_batch_parallel(items)
 
 
 class HipDistance:
