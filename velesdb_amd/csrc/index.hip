@@ -129,6 +129,7 @@ void copy_image_fields(vdb_hip_index* c, const vdb_hip_index* p) {
   c->bf16_stride = p->bf16_stride;
   c->bf16_rows = p->bf16_rows;
   c->l2_img = p->l2_img;
+  c->l2_rho = p->l2_rho;
   c->l2_seed = p->l2_seed;
   c->l2_rows = p->l2_rows;
   c->sq8_img = p->sq8_img;
@@ -755,10 +756,15 @@ static int32_t ensure_l2_select_impl(vdb_hip_index* ix, hipStream_t st) {
   if ((e = ix->l2_img.reserve(cap * (size_t)dim_a * 2, true, st)) != hipSuccess ||
       (e = ix->l2_seed.reserve((size_t)kSplitSeedRows * dim_s * 4, true, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("Euclidean selection image: ") + hipGetErrorString(e));
+  if (!ix->l2_rho.p) {  // (the image is built from row 0 behind this: every row contributes)
+    if ((e = ix->l2_rho.reserve(256, false, st)) != hipSuccess || (e = hipMemsetAsync(ix->l2_rho.p, 0, 256, st)) != hipSuccess)
+      return fail(VDB_ERR_OOM, std::string("Euclidean residual bound: ") + hipGetErrorString(e));
+    ix->l2_rows = 0;
+  }
   if (ix->l2_rows < ix->n_rows) {
     launch_l2_augment_rows(ix->rows.as<float>(), ix->row_stride, ix->norms.as<float>(), ix->l2_img.as<uint16_t>(), dim_a,
                            ix->l2_seed.as<float>(), dim_s, kSplitSeedRows, (uint32_t)ix->l2_rows, (uint32_t)(ix->n_rows - ix->l2_rows),
-                           ix->dim, st);
+                           ix->dim, st, ix->l2_rho.as<uint32_t>());
     ix->l2_rows = ix->n_rows;
     VDB_HIP(hipGetLastError());
   }
@@ -862,7 +868,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     return o;
   };
   // level 2 over the f32 rows: the seed runs on the bf16 pipe (sweep_split.hip seed_scores_bf16: every seed score as a key)
-  const bool bf16_seed = level == 2 && !l2 && !sq8 && g_bf16_seed;
+  const bool bf16_seed = level == 2 && !sq8 && g_bf16_seed;
   const size_t o_seedp = take(std::max((size_t)nqg * sp.G * k * 8, bf16_seed ? (size_t)nqg * R0 * 8 : (size_t)0)), o_ids = take((size_t)nqg * K2 * 8), o_sc = take((size_t)nqg * K2 * 4),
                o_n = take((size_t)nqg * 4), o_tau = take((size_t)nqg * 8), o_delta = take((size_t)nqg * 4),
                o_qn = take((size_t)nqg * 4), o_rho = take((size_t)nqg * 4), o_flags = take((size_t)nqg * 4 + 64 * 4 + 16), o_btau = take((size_t)nqg * lists * 8),
@@ -884,8 +890,9 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   float* delta = reinterpret_cast<float*>(sd + o_delta);
   float* qnorms = reinterpret_cast<float*>(sd + o_qn);
   // level 2 over the f32 rows: the error bound from MEASURED rounding residuals (sweep_split.hip select_eps_q)
-  float* rho_q = (level == 2 && !l2 && !sq8 && ix->bf16_rho.p) ? reinterpret_cast<float*>(sd + o_rho) : nullptr;
-  const uint32_t* rho_max = rho_q ? ix->bf16_rho.as<uint32_t>() : nullptr;
+  const DevBuf& rho_buf = l2 ? ix->l2_rho : ix->bf16_rho;
+  float* rho_q = (level == 2 && !sq8 && rho_buf.p) ? reinterpret_cast<float*>(sd + o_rho) : nullptr;
+  const uint32_t* rho_max = rho_q ? rho_buf.as<uint32_t>() : nullptr;
   uint32_t* flags = reinterpret_cast<uint32_t*>(sd + o_flags);
   uint32_t* tile_needed = flags + nqg;          // [<= 64]
   uint32_t* norm_max = tile_needed + 64;
@@ -900,18 +907,9 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
                                  : (l2 ? ix->l2_img.as<uint16_t>() : (level >= 2 ? ix->rows_bf16.as<uint16_t>() : ix->rows_split.as<uint16_t>()));
   const float* sel_norms = sq8 ? ix->sq8_nrm.as<float>() : ix->norms.as<float>();
   float* qaug = reinterpret_cast<float*>(ix->s_misc.as<unsigned char>() + ((size_t)nqg + 256) * (dim + 64) * 4);  // Euclidean: (q, 1, 0, 0, 0) f32
+  bool flags_cleared = false;
   if (l2) {
     launch_l2_augment_queries(d_q, q_stride, q16, dim_a, qaug, dim_s, nqg, dim, st);
-    PrepArgs pq{};
-    pq.rows = d_q;
-    pq.norms = qnorms;
-    pq.row_stride = q_stride;
-    pq.n_rows = nqg;
-    pq.dim = dim;
-    pq.words = ix->words;
-    launch_prep_rows(pq, st);
-  } else if (level >= 2) {
-    launch_round_queries_bf16(d_q, q_stride, q16, img_stride, nqg, dim, st);
     if (rho_q) launch_query_round_error(d_q, q_stride, rho_q, nqg, dim, st);
     PrepArgs pq{};
     pq.rows = d_q;
@@ -921,6 +919,10 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     pq.dim = dim;
     pq.words = ix->words;
     launch_prep_rows(pq, st);
+  } else if (level >= 2) {
+    // one launch: image rows, canonical norms, rounding residual ratios, the cleared flag words
+    launch_sel16_prep_queries(d_q, q_stride, q16, img_stride, qnorms, rho_q, flags, nqg + 64 + 4, nqg, dim, st);
+    flags_cleared = true;
   } else {
     launch_split_vectors(d_q, q_stride, q16, qnorms, 0, nqg, dim, st);
   }
@@ -928,7 +930,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   // (pool and blk_tau need no fill: the seed kernel writes slot 0 of every query, every selection block writes its slot of
   // every query of its tile — all ks keys, padded with invalid ones, and its bound — and every merge reads only the slots
   // written so far)
-  VDB_HIP(hipMemsetAsync(flags, 0, (size_t)nqg * 4 + 64 * 4 + 16, st));
+  if (!flags_cleared) VDB_HIP(hipMemsetAsync(flags, 0, (size_t)nqg * 4 + 64 * 4 + 16, st));
   if (!sq8 && !l2) VDB_HIP(hipMemsetAsync(ix->s_fb_keys.p, 0xFF, (size_t)nqg * fp.G * k * 8, st));
   if (sel_metric == VDB_DOT) launch_max_norm(sel_norms, n, norm_max, st);
   // exact seed sweep over the first rows
@@ -951,13 +953,17 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   ms.out_scores = m_sc;
   ms.out_n = m_n;
   if (bf16_seed) {
-    launch_seed_scores_bf16(sel_metric, img_rows, img_stride, sel_norms, alive, q16, img_stride, qnorms, ag.part_keys, R0, nqg, dim, st);
+    launch_seed_scores_bf16(sel_metric, img_rows, img_stride, sel_norms, alive, q16, img_stride, qnorms, ag.part_keys, R0, nqg,
+                            l2 ? dim_a : dim, st);
     ms.n_lists = R0;  // one "list" of one key per seed row: the selection merge picks the ks best
     ms.k = 1;
     ms.k_out = ks;
     launch_merge(true, ms, nqg, st);
-    launch_split_seed_approx(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, R0, dim, level, st,
-                             rho_q, rho_max);
+    if (l2)
+      launch_l2_seed(m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim_a, 0.0f, st, rho_q, rho_max, R0);
+    else
+      launch_split_seed_approx(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, R0, dim, level, st,
+                               rho_q, rho_max);
   } else {
   e = launch_sweep_gemm(sel_metric, sp, ag, st);
   if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split seed sweep launch: ") + hipGetErrorString(e));
@@ -967,7 +973,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   }
   if (bf16_seed) {
   } else if (l2)
-    launch_l2_seed(m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim_a, sq8 ? 1.5e-4f : 0.0f, st);
+    launch_l2_seed(m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim_a, sq8 ? 1.5e-4f : 0.0f, st, rho_q, rho_max);
   else
     launch_split_seed(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim, level, st, rho_q, rho_max);
   // selection launches over the split images
@@ -1593,7 +1599,7 @@ std::vector<DevBuf*> index_buffers(vdb_hip_index* ix) {
   std::vector<DevBuf*> v = {
       &ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids,           // rows
       &ix->rows_bf16, &ix->norms_bf16, &ix->bf16_rho, &ix->rows_split,      // bf16 copy, split-bf16 image
-      &ix->l2_img, &ix->l2_seed,                                            // Euclidean selection images
+      &ix->l2_img, &ix->l2_seed, &ix->l2_rho,                               // Euclidean selection images
       &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq,                // int8 traversal
       &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits,  // storage modes
       &ix->sq8_img, &ix->sq8_nrm, &ix->sq8_seed,                            // SQ8 selection images

@@ -120,6 +120,59 @@ __global__ __launch_bounds__(256) void query_round_error_kernel(const float* q, 
   }
   if (lane == 0) rho_q[b] = sx > 0.0 ? (float)(sqrt(se / sx) * 1.0000002) : (sx == 0.0 ? 0.0f : __uint_as_float(0x7FC00000u));
 }
+// The front of a level-2 / level-3 batch in ONE launch (it was four: round_queries_bf16, prep_rows for the canonical norms,
+// query_round_error, a fill of the flag words): per query — one wave — the bf16 image row (round to nearest even, zero-padded to
+// the image stride), the canonical f32 norm (prep_rows' chain: float4 chunk c in lane c mod 64, fmaf chains, xor butterfly, sqrt)
+// and, rho_q != nullptr, the rounding residual ratio; the first threads clear the batch's flag words.  dim % 4 == 0.
+__global__ __launch_bounds__(256) void sel16_prep_queries_kernel(const float* q, uint64_t q_stride, uint16_t* img, uint64_t img_stride,
+                                                                 float* qnorms, float* rho_q, uint32_t* zero_words, uint32_t n_zero,
+                                                                 uint32_t nq, uint32_t dim) {
+  const uint32_t lane = threadIdx.x & 63u, b = blockIdx.x * 4u + (threadIdx.x >> 6);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_zero; i += gridDim.x * 256u) zero_words[i] = 0u;
+  if (b >= nq) return;
+  const float* p = q + (size_t)b * q_stride;
+  uint16_t* o = img + (size_t)b * img_stride;
+  const uint32_t d4 = dim / 4, s4 = (uint32_t)(img_stride / 4);
+  float acc = 0.0f;
+  double se = 0.0, sx = 0.0;
+  for (uint32_t c = lane; c < s4; c += 64) {
+    if (c < d4) {
+      const float4 x = ld4(p + c * 4);
+      acc = chain4<kOpDot>(acc, x, x);
+      const float xs[4] = {x.x, x.y, x.z, x.w};
+      uint16_t h[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        h[e] = bf16_rne(xs[e]);
+        if (rho_q) {
+          const float d = xs[e] - __uint_as_float((uint32_t)h[e] << 16);  // exact in f32
+          se += (double)d * (double)d;
+          sx += (double)xs[e] * (double)xs[e];
+        }
+      }
+      *reinterpret_cast<uint2*>(o + c * 4) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    } else {
+      *reinterpret_cast<uint2*>(o + c * 4) = make_uint2(0u, 0u);
+    }
+  }
+  const float n = sqrtf(butterfly_all(acc));
+  if (rho_q) {
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) {
+      se += __shfl_xor(se, s2, 64);
+      sx += __shfl_xor(sx, s2, 64);
+    }
+  }
+  if (lane == 0) {
+    qnorms[b] = n;
+    if (rho_q) rho_q[b] = sx > 0.0 ? (float)(sqrt(se / sx) * 1.0000002) : (sx == 0.0 ? 0.0f : __uint_as_float(0x7FC00000u));
+  }
+}
+void launch_sel16_prep_queries(const float* q, uint64_t q_stride, uint16_t* img, uint64_t img_stride, float* qnorms, float* rho_q,
+                               uint32_t* zero_words, uint32_t n_zero, uint32_t nq, uint32_t dim, hipStream_t st) {
+  hipLaunchKernelGGL(sel16_prep_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, q, q_stride, img, img_stride, qnorms, rho_q,
+                     zero_words, n_zero, nq, dim);
+}
 void launch_query_round_error(const float* q, uint64_t q_stride, float* rho_q, uint32_t nq, uint32_t dim, hipStream_t st) {
   hipLaunchKernelGGL(query_round_error_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, q, q_stride, rho_q, nq, dim);
 }
@@ -555,7 +608,7 @@ void launch_scatter_flagged(const uint32_t* qmap, const uint32_t* qcount, uint32
 // augmentation and the f32 accumulation over it.
 __global__ __launch_bounds__(256) void l2_augment_rows_kernel(const float* rows, uint64_t row_stride, const float* norms, uint16_t* img,
                                                               uint32_t dim_a, float* seed, uint32_t dim_s, uint32_t seed_rows,
-                                                              uint32_t row0, uint32_t n, uint32_t dim) {
+                                                              uint32_t row0, uint32_t n, uint32_t dim, uint32_t* rho_max_bits) {
   const int lane = lane_id();
   const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t nwaves = gridDim.x * 4;
@@ -563,11 +616,31 @@ __global__ __launch_bounds__(256) void l2_augment_rows_kernel(const float* rows,
     const uint32_t row = row0 + r;
     const float* p = rows + (size_t)row * row_stride;
     uint16_t* o = img + (size_t)row * dim_a;
+    double se = 0.0, sx = 0.0;  // the row's rounding residual ratio (select_eps_q), as prep_bf16_rows keeps it for the bf16 copy
     for (uint32_t i = lane * 4; i < dim; i += 256) {  // dim % 64 == 0
       const float4 x = ld4(p + i);
-      *reinterpret_cast<uint2*>(o + i) = make_uint2((uint32_t)bf16_rne(x.x) | ((uint32_t)bf16_rne(x.y) << 16),
-                                                    (uint32_t)bf16_rne(x.z) | ((uint32_t)bf16_rne(x.w) << 16));
+      const float xs[4] = {x.x, x.y, x.z, x.w};
+      uint16_t h[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        h[e] = bf16_rne(xs[e]);
+        const float d = xs[e] - __uint_as_float((uint32_t)h[e] << 16);  // exact in f32
+        se += (double)d * (double)d;
+        sx += (double)xs[e] * (double)xs[e];
+      }
+      *reinterpret_cast<uint2*>(o + i) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
       if (row < seed_rows) *reinterpret_cast<float4*>(seed + (size_t)row * dim_s + i) = x;
+    }
+    if (rho_max_bits) {
+#pragma unroll
+      for (int s2 = 32; s2 > 0; s2 >>= 1) {
+        se += __shfl_xor(se, s2, 64);
+        sx += __shfl_xor(sx, s2, 64);
+      }
+      if (lane == 0 && sx > 0.0) {
+        const float rho = (float)(sqrt(se / sx) * 1.0000002);
+        if (rho == rho && rho < __uint_as_float(0x7F800000u)) atomicMax(rho_max_bits, __float_as_uint(rho));
+      }
     }
     const float nn = norms[row];
     const float h = -0.5f * nn * nn;
@@ -578,11 +651,12 @@ __global__ __launch_bounds__(256) void l2_augment_rows_kernel(const float* rows,
   }
 }
 void launch_l2_augment_rows(const float* rows, uint64_t row_stride, const float* norms, uint16_t* img, uint32_t dim_a, float* seed,
-                            uint32_t dim_s, uint32_t seed_rows, uint32_t row0, uint32_t n, uint32_t dim, hipStream_t st) {
+                            uint32_t dim_s, uint32_t seed_rows, uint32_t row0, uint32_t n, uint32_t dim, hipStream_t st,
+                            uint32_t* rho_max_bits) {
   if (n == 0) return;
   const int blocks = (int)std::min<uint64_t>(((uint64_t)n + 3) / 4, 4096);
   hipLaunchKernelGGL(l2_augment_rows_kernel, dim3(blocks), dim3(256), 0, st, rows, row_stride, norms, img, dim_a, seed, dim_s, seed_rows,
-                     row0, n, dim);
+                     row0, n, dim, rho_max_bits);
 }
 __global__ __launch_bounds__(256) void l2_augment_queries_kernel(const float* q, uint64_t q_stride, uint16_t* img, uint32_t dim_a,
                                                                  float* qaug, uint32_t dim_s, uint32_t nq, uint32_t dim) {
@@ -611,15 +685,41 @@ void launch_l2_augment_queries(const float* q, uint64_t q_stride, uint16_t* img,
 __global__ __launch_bounds__(256) void l2_seed_kernel(const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms,
                                                       const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list,
                                                       uint64_t* blk_tau, uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist,
-                                                      uint32_t dim_a, float extra_rel) {
+                                                      uint32_t dim_a, float extra_rel, const float* rho_q, const uint32_t* rho_max_bits,
+                                                      uint32_t approx_seed_rows) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
   const float nmax = __uint_as_float(*norm_max_bits), hmax = 0.5f * nmax * nmax;
   const float acc = 16.0f * (float)dim_a * 5.9604645e-8f;
-  const float eps_r = 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f + acc + extra_rel;          // select_eps(dim_a, 2) (+ SQ8: level 3's extra)
+  // the q.v part: the constant bound of bf16's worst case, or — the image's largest residual ratio and the batch's own are
+  // known — the measured one (select_eps_q; the augmentation columns are exact to 2^-16 h and stay in the h term below)
+  float eps_r = 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f + acc + extra_rel;                // select_eps(dim_a, 2) (+ SQ8: level 3's extra)
+  if (rho_q && rho_max_bits) {
+    const float rm = __uint_as_float(*rho_max_bits), rq = rho_q[q];
+    eps_r = (rm + rq + 3.0f * rm * rq) * 1.002f + acc + extra_rel;
+  }
   const float d = eps_r * 1.001f * qnorms[q] * nmax + (1.6e-5f + acc + extra_rel) * hmax + 1e-30f;  // bf16 roundings of q.v + the augmentation
   const float d_seed = 4.0f * acc * (qnorms[q] * nmax + hmax) + 1e-30f;                 // f32 matrix-core s against the true s
   delta[q] = d;
+  if (approx_seed_rows) {
+    // the seed ran on the bf16 pipe over the selection's own image (seed_scores_bf16: every seed score as a key, the klist best
+    // merged): APPROXIMATE s on both sides — bound = s_k - 2 delta, slot 0 = the klist best as they are, and what slot 0 left
+    // out is bounded by its klist-th key, as a selection block reports it (split_seed_approx_kernel's rules)
+    const uint32_t c = min(n[q], klist);
+    uint64_t t = kKeyInvalid;
+    if (c >= k && k > 0) {
+      const float s = scores[(size_t)q * klist + k - 1];
+      const float lowered = s - 2.0f * d * 1.01f - fabsf(s) * 1e-6f;
+      t = lowered == lowered ? make_key<true>(lowered, 0u) : kKeyInvalid;
+    }
+    tau0[q] = t;
+    for (uint32_t e = 0; e < klist; e++)
+      list[(size_t)q * list_stride * klist + e] = e < c ? make_key<true>(scores[(size_t)q * klist + e], (uint32_t)ids[(size_t)q * klist + e]) : kKeyInvalid;
+    blk_tau[(size_t)q * list_stride] = (c == klist && approx_seed_rows > klist)
+                                           ? make_key<true>(scores[(size_t)q * klist + klist - 1], (uint32_t)ids[(size_t)q * klist + klist - 1])
+                                           : kKeyInvalid;
+    return;
+  }
   const uint32_t c = min(n[q], k);
   uint64_t t = kKeyInvalid, bt = kKeyInvalid;
   if (c >= k && k > 0) {
@@ -636,9 +736,10 @@ __global__ __launch_bounds__(256) void l2_seed_kernel(const uint64_t* ids, const
 }
 void launch_l2_seed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms, const uint32_t* norm_max_bits,
                     uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau, uint32_t list_stride, uint32_t nq, uint32_t k,
-                    uint32_t klist, uint32_t dim_a, float extra_rel, hipStream_t st) {
+                    uint32_t klist, uint32_t dim_a, float extra_rel, hipStream_t st, const float* rho_q, const uint32_t* rho_max_bits,
+                    uint32_t approx_seed_rows) {
   hipLaunchKernelGGL(l2_seed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits, tau0, delta, list,
-                     blk_tau, list_stride, nq, k, klist, dim_a, extra_rel);
+                     blk_tau, list_stride, nq, k, klist, dim_a, extra_rel, rho_q, rho_max_bits, approx_seed_rows);
 }
 
 // One block per query (the Euclidean sibling of split_rerank_verify): every candidate is re-scored with the canonical

@@ -249,6 +249,9 @@ void launch_split_seed(int metric, const uint64_t* ids, const float* scores, con
                        const float* rho_q = nullptr, const uint32_t* rho_max_bits = nullptr);
 // level 2's measured rounding residuals (sweep_split.hip select_eps_q): rho_q[nq] = |q - bf16(q)| / |q| of a batch
 void launch_query_round_error(const float* q, uint64_t q_stride, float* rho_q, uint32_t nq, uint32_t dim, hipStream_t st);
+// the front of a level-2 / 3 batch in one launch: bf16 image rows, canonical norms, rho_q (nullable), cleared flag words
+void launch_sel16_prep_queries(const float* q, uint64_t q_stride, uint16_t* img, uint64_t img_stride, float* qnorms, float* rho_q,
+                               uint32_t* zero_words, uint32_t n_zero, uint32_t nq, uint32_t dim, hipStream_t st);
 // level 2's seed on the bf16 pipe: a plain GEMM of the first rows x the batch into keys [nq][seed_rows], and the seed kernel for
 // approximate seed scores (tau = A_k - 2 delta; slot 0 of the pool with its bound)
 void launch_seed_scores_bf16(int metric, const uint16_t* rows16, uint64_t row_stride, const float* norms, const uint8_t* alive,
@@ -265,12 +268,14 @@ void launch_split_reseed(const uint64_t* ids, const float* scores, const uint32_
 void launch_split_rerank(int metric, const SplitRerankArgs& a, uint32_t nq, hipStream_t st);
 // Euclidean batches through the selection stage (sweep_split.hip): augmented images, seed, re-scoring + proof
 void launch_l2_augment_rows(const float* rows, uint64_t row_stride, const float* norms, uint16_t* img, uint32_t dim_a, float* seed,
-                            uint32_t dim_s, uint32_t seed_rows, uint32_t row0, uint32_t n, uint32_t dim, hipStream_t st);
+                            uint32_t dim_s, uint32_t seed_rows, uint32_t row0, uint32_t n, uint32_t dim, hipStream_t st,
+                            uint32_t* rho_max_bits = nullptr);
 void launch_l2_augment_queries(const float* q, uint64_t q_stride, uint16_t* img, uint32_t dim_a, float* qaug, uint32_t dim_s, uint32_t nq,
                                uint32_t dim, hipStream_t st);
 void launch_l2_seed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* qnorms, const uint32_t* norm_max_bits,
                     uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau, uint32_t list_stride, uint32_t nq, uint32_t k,
-                    uint32_t klist, uint32_t dim_a, float extra_rel, hipStream_t st);
+                    uint32_t klist, uint32_t dim_a, float extra_rel, hipStream_t st, const float* rho_q = nullptr,
+                    const uint32_t* rho_max_bits = nullptr, uint32_t approx_seed_rows = 0);
 void launch_l2_rerank(const SplitRerankArgs& a, uint32_t nq, hipStream_t st);
 // the flagged queries of a batch in ascending order: qmap[0 .. *qcount) (one block; nq <= 1024 per round)
 void launch_collect_flagged(const uint32_t* flags, uint32_t nq, uint32_t* qmap, uint32_t* qcount, hipStream_t st);
