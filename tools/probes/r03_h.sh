@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03h
 mkdir -p $O
-VELESDB_TRACE_LEVELS=2 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python $R/tools/probes/split_probe.py --reps 3 > $O/probe.log 2>&1
+VELESDB_TRACE_LEVELS=2 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python $R/tools/probes/split_probe.py --reps 3 ${METRIC:+--metric $METRIC} > $O/probe.log 2>&1
 tail -3 $O/probe.log
 python3 - <<'PY'
 import csv, glob, os
@@ -13,7 +13,7 @@ f = glob.glob(O + '/trace/*/*kernel_trace.csv')[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 # the last level-2 step: from the last round_queries_bf16 before the first level-1 step
 names = [r['Kernel_Name'] for r in rows]
-idx = [i for i, n in enumerate(names) if 'round_queries_bf16' in n]
+idx = [i for i, n in enumerate(names) if 'sel16_prep_queries' in n or 'l2_augment_queries' in n]
 # level 2 runs first: 2 warm-up + 3 timed = 5 steps; take the 5th
 s0 = idx[4]
 s1 = idx[5] if len(idx) > 5 else len(rows)
