@@ -43,7 +43,7 @@ int32_t vdb_hip_index_graph_info(vdb_hip_index* ix, uint32_t* num_layers, uint32
     if (group_mode(ix) != VDB_SHARD_REPLICA) return fail(VDB_ERR_UNSUPPORTED, "graph_info: one graph per shard on a range-sharded handle");
     return vdb_hip_index_graph_info(group_shard(ix, 0), num_layers, max_layer, entry_point);
   }
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   if (num_layers) *num_layers = (uint32_t)ix->layers.size();
   if (max_layer) *max_layer = ix->max_layer;
   if (entry_point) *entry_point = ix->graph_valid ? ix->entry_point : -1;
@@ -59,7 +59,7 @@ int32_t vdb_hip_index_get_neighbors(vdb_hip_index* ix, uint32_t layer, uint64_t 
     if (group_mode(ix) != VDB_SHARD_REPLICA) return fail(VDB_ERR_UNSUPPORTED, "get_neighbors: one graph per shard on a range-sharded handle");
     return vdb_hip_index_get_neighbors(group_shard(ix, 0), layer, node, out, cap, n);
   }
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   *n = 0;
   if (layer >= ix->layers.size() || node >= ix->n_rows) return VDB_OK;  // layer.rs:33-39: empty
   VDB_ENTER(ix);
@@ -86,7 +86,7 @@ int32_t vdb_hip_index_load_reference_files(vdb_hip_index* ix, const char* dir, c
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !dir || !basename) return fail(VDB_ERR_INVALID_ARG, "null argument");
   VDB_NO_GROUP(ix, "load_reference_files");
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   if (ix->n_rows != 0) return fail(VDB_ERR_STATE, "load_reference_files needs an empty index");
   VDB_ENTER(ix);
   const std::string vp = std::string(dir) + "/" + basename + ".vectors";
@@ -219,7 +219,7 @@ int32_t vdb_hip_index_save_reference_files(vdb_hip_index* ix, const char* dir, c
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !dir || !basename) return fail(VDB_ERR_INVALID_ARG, "null argument");
   VDB_NO_GROUP(ix, "save_reference_files");
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   if (!ix->graph_valid) return fail(VDB_ERR_STATE, "graph not built for all rows");
   VDB_ENTER(ix);
   const uint64_t count = ix->n_rows;
@@ -298,7 +298,7 @@ int32_t vdb_hip_index_save_dir(vdb_hip_index* ix, const char* dir) {
   }
   int32_t rc = vdb_hip_index_save_reference_files(ix, dir, "native_hnsw");
   if (rc != VDB_OK) return rc;
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   const std::string mp = std::string(dir) + "/native_mappings.bin";
   FILE* f = std::fopen(mp.c_str(), "wb");
   if (!f) return fail(VDB_ERR_IO, "cannot create " + mp);
@@ -378,7 +378,7 @@ int32_t vdb_hip_index_load_dir(const char* dir, int32_t device, vdb_hip_index** 
     vdb_hip_index_destroy(ix);
     return fail(VDB_ERR_IO, "bad " + mp);
   }
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   ix->id_to_idx.swap(id_to_idx);
   ix->idx_to_id = ids;
   ix->idx_live = live;

@@ -1724,7 +1724,7 @@ int32_t vdb_hip_index_last_split_stats(vdb_hip_index* ix, uint32_t* queries, uin
   return vdb::guarded([&]() -> int32_t {
     if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
     VDB_NO_GROUP(ix, "last_split_stats");
-    std::shared_lock<std::shared_mutex> g(ix->mu);
+    std::shared_lock<vdb::IndexMutex> g(ix->mu);
     ix = last_context(ix);  // the search context that served this thread's last search (the handle itself unless searches overlapped)
     std::lock_guard<std::mutex> cg(ix->ctx_mu);
     VDB_HIP(hipSetDevice(ix->device));
@@ -1745,7 +1745,7 @@ int32_t vdb_hip_index_last_select_level(vdb_hip_index* ix, int32_t* level) {
   return vdb::guarded([&]() -> int32_t {
     if (!ix || !level) return fail(VDB_ERR_INVALID_ARG, "null argument");
     VDB_NO_GROUP(ix, "last_select_level");
-    std::shared_lock<std::shared_mutex> g(ix->mu);
+    std::shared_lock<vdb::IndexMutex> g(ix->mu);
     ix = last_context(ix);  // the search context that served this thread's last search (the handle itself unless searches overlapped)
     std::lock_guard<std::mutex> cg(ix->ctx_mu);
     *level = ix->last_select_level;
@@ -1756,7 +1756,7 @@ int32_t vdb_hip_index_last_select_level(vdb_hip_index* ix, int32_t* level) {
 int32_t vdb_hip_index_last_kernels(vdb_hip_index* ix, uint32_t* mask) {
   return vdb::guarded([&]() -> int32_t {
     if (!ix || !mask) return fail(VDB_ERR_INVALID_ARG, "null argument");
-    std::shared_lock<std::shared_mutex> g(ix->mu);
+    std::shared_lock<vdb::IndexMutex> g(ix->mu);
     // a multi-device handle: what any shard ran; a plain handle: the context of this thread's last search
     uint32_t m = ix->group ? ix->last_kernels : last_context(ix)->last_kernels;
     if (ix->group)
@@ -1771,7 +1771,7 @@ int32_t vdb_hip_index_set_option(vdb_hip_index* ix, int32_t option, int64_t valu
     if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
     if (option < 0 || option > VDB_OPT_KERNEL_TIMING) return fail(VDB_ERR_INVALID_ARG, "unknown option");
     if (ix->group) return group_set_option(ix, option, value);
-    std::lock_guard<std::shared_mutex> g(ix->mu);
+    std::lock_guard<vdb::IndexMutex> g(ix->mu);
     mark_changed(ix);
     int32_t v = -1;  // negative: back to the process-wide default
     if (value >= 0) {
@@ -1803,7 +1803,7 @@ int32_t vdb_hip_index_get_option(vdb_hip_index* ix, int32_t option, int64_t* val
     if (!ix || !value) return fail(VDB_ERR_INVALID_ARG, "null argument");
     if (option < 0 || option > VDB_OPT_KERNEL_TIMING) return fail(VDB_ERR_INVALID_ARG, "unknown option");
     vdb_hip_index* c = ix->group ? group_first_shard(ix) : ix;
-    std::lock_guard<std::shared_mutex> g(c->mu);
+    std::lock_guard<vdb::IndexMutex> g(c->mu);
     switch (option) {
       case VDB_OPT_MAX_QUERY_TILE: *value = opt_max_tile(c); break;
       case VDB_OPT_SWEEP_ENGINE: *value = opt_engine(c); break;
@@ -1900,7 +1900,7 @@ int32_t vdb_hip_index_insert(vdb_hip_index* ix, uint64_t id, const float* vec, u
     int32_t grc = group_insert(ix, &id, vec, 1, 0, 1, &gi);
     return grc != VDB_OK ? grc : (gi ? VDB_OK : VDB_DUPLICATE_IGNORED);
   }
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   VDB_ENTER(ix);
   uint64_t ins = 0, first = 0;
   int32_t rc = append_host_rows(ix, &id, vec, 1, &ins, &first);
@@ -1920,7 +1920,7 @@ int32_t vdb_hip_index_insert_batch(vdb_hip_index* ix, const uint64_t* ids, const
   return vdb::guarded([&]() -> int32_t {
   if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_insert(ix, ids, vecs, n, 0, 1, inserted);
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   VDB_ENTER(ix);
   uint64_t ins = 0, first = 0;
   int32_t rc = append_host_rows(ix, ids, vecs, n, &ins, &first);
@@ -1938,7 +1938,7 @@ int32_t vdb_hip_index_insert_batch_parallel(vdb_hip_index* ix, const uint64_t* i
   return vdb::guarded([&]() -> int32_t {
   if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_insert(ix, ids, vecs, n, 1, max_batch, inserted);
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   VDB_ENTER(ix);
   uint64_t ins = 0, first = 0;
   int32_t rc = append_host_rows(ix, ids, vecs, n, &ins, &first);
@@ -1955,7 +1955,7 @@ int32_t vdb_hip_index_train_quantizer(vdb_hip_index* ix, uint32_t sample_rows) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_for_all(ix, 3, sample_rows);
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   VDB_ENTER(ix);
   int32_t rc = quantizer_train(ix, sample_rows);
   if (rc == VDB_OK) VDB_HIP(hipStreamSynchronize(ix->stream));
@@ -1976,7 +1976,7 @@ int32_t vdb_hip_index_enable_bf16(vdb_hip_index* ix) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_for_all(ix, 1, 0);
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   if (ix->bf16_enabled) return VDB_OK;
   if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT)
     return fail(VDB_ERR_UNSUPPORTED, "bf16 sweep: Cosine and DotProduct only");
@@ -2007,7 +2007,7 @@ int32_t vdb_hip_index_build_graph(vdb_hip_index* ix, uint32_t max_batch) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_for_all(ix, 0, max_batch);
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   VDB_ENTER(ix);
   int32_t rc = VDB_OK;
   if (ix->graph_nodes < ix->n_rows) rc = graph_insert_rows(ix, ix->graph_nodes, ix->n_rows - ix->graph_nodes, max_batch);
@@ -2021,7 +2021,7 @@ int32_t vdb_hip_index_upload(vdb_hip_index* ix, const uint64_t* ids, const float
   return vdb::guarded([&]() -> int32_t {
   if (!ix || (n && (!ids || !vecs))) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_insert(ix, ids, vecs, n, 2, 0, inserted);
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   VDB_ENTER(ix);
   uint64_t ins = 0, first = 0;
   int32_t rc = append_host_rows(ix, ids, vecs, n, &ins, &first);
@@ -2036,7 +2036,7 @@ int32_t vdb_hip_index_upload_dev(vdb_hip_index* ix, uint64_t id_base, const floa
   return vdb::guarded([&]() -> int32_t {
   if (!ix || (n && !d_vecs)) return fail(VDB_ERR_INVALID_ARG, "null argument");
   VDB_NO_GROUP(ix, "upload_dev (rows resident on one device)");
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   VDB_ENTER(ix);
   if (n == 0) return VDB_OK;
   for (uint64_t i = 0; i < n; i++)
@@ -2077,7 +2077,7 @@ int32_t vdb_hip_index_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return group_remove(ix, id, removed);
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   auto it = ix->id_to_idx.find(id);
   if (it == ix->id_to_idx.end()) {
     if (removed) *removed = 0;
@@ -2098,7 +2098,7 @@ int32_t vdb_hip_index_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed) {
 
 int32_t vdb_hip_index_len(const vdb_hip_index* ix, uint64_t* n) {  // trait_impl.rs:60-62 mappings.len()
   if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   *n = ix->live;
   return VDB_OK;
 }
@@ -2107,7 +2107,7 @@ int32_t vdb_hip_index_len(const vdb_hip_index* ix, uint64_t* n) {  // trait_impl
 int32_t vdb_hip_index_tombstone_count(const vdb_hip_index* ix, uint64_t* n) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   *n = ix->n_rows - ix->live;
   return VDB_OK;
   });
@@ -2122,7 +2122,7 @@ int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
   VDB_NO_GROUP(ix, "vacuum");
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   VDB_ENTER(ix);
   const uint64_t n_old = ix->n_rows, n_live = ix->live;
   if (count) *count = n_live;
@@ -2203,7 +2203,7 @@ int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
 int32_t vdb_hip_index_node_count(const vdb_hip_index* ix, uint64_t* n) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   *n = ix->n_rows;
   return VDB_OK;
   });
@@ -2234,8 +2234,8 @@ int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* ix, const float* d_queries
                             reinterpret_cast<hipStream_t>(stream));
   // searches share the handle (search.rs:80 takes the read lock); a member of a process group searches collectively on one
   // gather buffer: those calls stay exclusive
-  std::shared_lock<std::shared_mutex> rd(ix->mu, std::defer_lock);
-  std::unique_lock<std::shared_mutex> wr(ix->mu, std::defer_lock);
+  std::shared_lock<vdb::IndexMutex> rd(ix->mu, std::defer_lock);
+  std::unique_lock<vdb::IndexMutex> wr(ix->mu, std::defer_lock);
   if (ix->pcomm) wr.lock(); else rd.lock();
   CtxLease lease(ix);
   if (lease.rc != VDB_OK) return lease.rc;
@@ -2275,8 +2275,8 @@ static int32_t search_batch_host(vdb_hip_index* ix, const float* queries, uint32
     return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (nq == 0) return VDB_OK;
   if (ix->group) return group_search_host(ix, queries, nq, k, ef, mode, rerank_k, out_ids, out_scores, out_n);
-  std::shared_lock<std::shared_mutex> rd(ix->mu, std::defer_lock);
-  std::unique_lock<std::shared_mutex> wr(ix->mu, std::defer_lock);
+  std::shared_lock<vdb::IndexMutex> rd(ix->mu, std::defer_lock);
+  std::unique_lock<vdb::IndexMutex> wr(ix->mu, std::defer_lock);
   if (ix->pcomm) wr.lock(); else rd.lock();
   CtxLease lease(ix);  // this search's scratch + stream: the handle itself, or one of its search contexts when it is busy
   if (lease.rc != VDB_OK) return lease.rc;
@@ -2408,7 +2408,7 @@ int32_t vdb_hip_index_last_kernel_ms(vdb_hip_index* ix, float* ms, uint32_t* lau
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !ms) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return vdb_hip_index_last_kernel_ms(group_shard(ix, 0), ms, launches);
-  std::shared_lock<std::shared_mutex> g(ix->mu);
+  std::shared_lock<vdb::IndexMutex> g(ix->mu);
     ix = last_context(ix);  // the search context that served this thread's last search (the handle itself unless searches overlapped)
     std::lock_guard<std::mutex> cg(ix->ctx_mu);
   double total = 0.0;
@@ -2431,7 +2431,7 @@ int32_t vdb_hip_index_last_selection_ms(vdb_hip_index* ix, float* total_ms, uint
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !total_ms) return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (ix->group) return vdb_hip_index_last_selection_ms(group_shard(ix, 0), total_ms, launches);
-  std::shared_lock<std::shared_mutex> g(ix->mu);
+  std::shared_lock<vdb::IndexMutex> g(ix->mu);
     ix = last_context(ix);  // the search context that served this thread's last search (the handle itself unless searches overlapped)
     std::lock_guard<std::mutex> cg(ix->ctx_mu);
   double total = 0.0;
@@ -2465,7 +2465,7 @@ int32_t vdb_hip_index_last_search_stats(vdb_hip_index* ix, uint64_t* n_dist, uin
     if (n_expand) *n_expand = b;
     return VDB_OK;
   }
-  std::shared_lock<std::shared_mutex> g(ix->mu);
+  std::shared_lock<vdb::IndexMutex> g(ix->mu);
     ix = last_context(ix);  // the search context that served this thread's last search (the handle itself unless searches overlapped)
     std::lock_guard<std::mutex> cg(ix->ctx_mu);
   if (ix->stats_pending) {

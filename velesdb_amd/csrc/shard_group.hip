@@ -340,7 +340,7 @@ static int32_t child_insert(vdb_hip_index* c, const uint64_t* ids, const float* 
 int32_t group_insert(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, uint64_t n, int kind, uint32_t max_batch,
                      uint64_t* inserted) {
   ShardGroup* g = ix->group;
-  std::lock_guard<std::shared_mutex> lk(ix->mu);
+  std::lock_guard<vdb::IndexMutex> lk(ix->mu);
   if (inserted) *inserted = 0;
   if (g->broken) return fail(VDB_ERR_STATE, kBrokenMsg);
   // duplicates (against the index and inside the batch) are skipped once, here (trait_impl.rs:23-25)
@@ -412,7 +412,7 @@ int32_t group_insert(vdb_hip_index* ix, const uint64_t* ids, const float* vecs, 
 
 int32_t group_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed) {
   ShardGroup* g = ix->group;
-  std::lock_guard<std::shared_mutex> lk(ix->mu);
+  std::lock_guard<vdb::IndexMutex> lk(ix->mu);
   if (removed) *removed = 0;
   if (g->broken) return fail(VDB_ERR_STATE, kBrokenMsg);
   auto it = ix->id_to_idx.find(id);
@@ -435,7 +435,7 @@ int32_t group_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed) {
 
 int32_t group_for_all(vdb_hip_index* ix, int op, uint32_t arg) {
   ShardGroup* g = ix->group;
-  std::lock_guard<std::shared_mutex> lk(ix->mu);
+  std::lock_guard<vdb::IndexMutex> lk(ix->mu);
   if (g->broken) return fail(VDB_ERR_STATE, kBrokenMsg);
   if (op == 3 && g->mode == VDB_SHARD_RANGE)
     return fail(VDB_ERR_UNSUPPORTED, "the int8 quantiser is trained on the first rows of ONE index: replicas only");
@@ -452,7 +452,7 @@ int32_t group_for_all(vdb_hip_index* ix, int op, uint32_t arg) {
 
 int32_t group_set_option(vdb_hip_index* ix, int32_t option, int64_t value) {
   ShardGroup* g = ix->group;
-  std::lock_guard<std::shared_mutex> lk(ix->mu);
+  std::lock_guard<vdb::IndexMutex> lk(ix->mu);
   return for_each_shard(g, [&](size_t s) -> int32_t { return vdb_hip_index_set_option(g->shards[s], option, value); });
 }
 vdb_hip_index* group_first_shard(vdb_hip_index* ix) { return ix->group->shards[0]; }
@@ -541,7 +541,7 @@ int32_t group_search_host(vdb_hip_index* ix, const float* queries, uint32_t nq, 
                           uint32_t rerank_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
   ShardGroup* g = ix->group;
   if (nq == 0) return VDB_OK;
-  std::lock_guard<std::shared_mutex> lk(ix->mu);
+  std::lock_guard<vdb::IndexMutex> lk(ix->mu);
   if (g->broken) return fail(VDB_ERR_STATE, kBrokenMsg);
   const size_t S = g->shards.size();
   if (g->mode == VDB_SHARD_REPLICA) {
@@ -561,7 +561,7 @@ int32_t group_search_host(vdb_hip_index* ix, const float* queries, uint32_t nq, 
   if (m == VDB_SEARCH_HNSW_INT8) return fail(VDB_ERR_UNSUPPORTED, "int8 traversal: replicas only");
   int32_t rc = for_each_shard(g, [&](size_t s) -> int32_t {
     vdb_hip_index* c = g->shards[s];
-    std::lock_guard<std::shared_mutex> cl(c->mu);
+    std::lock_guard<vdb::IndexMutex> cl(c->mu);
     VDB_HIP(hipSetDevice(c->device));
     std::vector<uint32_t> hn(nq);
     if (c->n_rows == 0) {  // a shard no row has reached yet contributes nothing
@@ -601,7 +601,7 @@ int32_t group_search_dev(vdb_hip_index* ix, const float* d_q, uint32_t nq, uint3
                          uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st) {
   ShardGroup* g = ix->group;
   if (nq == 0) return VDB_OK;
-  std::lock_guard<std::shared_mutex> lk(ix->mu);
+  std::lock_guard<vdb::IndexMutex> lk(ix->mu);
   if (g->broken) return fail(VDB_ERR_STATE, kBrokenMsg);
   const size_t S = g->shards.size();
   VDB_HIP(hipSetDevice(g->shards[0]->device));
@@ -612,7 +612,7 @@ int32_t group_search_dev(vdb_hip_index* ix, const float* d_q, uint32_t nq, uint3
   const size_t kk = std::max<uint32_t>(k, 1);
   int32_t rc = for_each_shard(g, [&](size_t s) -> int32_t {
     vdb_hip_index* c = g->shards[s];
-    std::lock_guard<std::shared_mutex> cl(c->mu);
+    std::lock_guard<vdb::IndexMutex> cl(c->mu);
     VDB_HIP(hipSetDevice(c->device));
     uint32_t lo = 0, hi = nq;
     if (replica) query_slice(nq, s, S, &lo, &hi);
@@ -721,7 +721,7 @@ int32_t vdb_hip_index_join_group(vdb_hip_index* ix, const uint8_t* id, int32_t r
     if (!ix || !id) return fail(VDB_ERR_INVALID_ARG, "null argument");
     if (world < 1 || rank < 0 || rank >= world) return fail(VDB_ERR_INVALID_ARG, "bad rank / world");
     if (ix->group) return fail(VDB_ERR_STATE, "a multi-device handle cannot join a process group");
-    std::lock_guard<std::shared_mutex> lk(ix->mu);
+    std::lock_guard<vdb::IndexMutex> lk(ix->mu);
     if (ix->pcomm) return fail(VDB_ERR_STATE, "already member of a process group");
     Rccl* r = rccl();
     if (!r) return fail(VDB_ERR_UNSUPPORTED, "RCCL is not available: " + rccl_load_error());
@@ -741,7 +741,7 @@ int32_t vdb_hip_index_shard_info(vdb_hip_index* ix, int32_t* n_shards, int32_t* 
                                  int32_t* transport) {
   return guarded([&]() -> int32_t {
     if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<std::shared_mutex> lk(ix->mu);
+    std::lock_guard<vdb::IndexMutex> lk(ix->mu);
     if (n_shards) *n_shards = ix->group ? (int32_t)ix->group->shards.size() : 1;
     if (shard_mode) *shard_mode = ix->group ? ix->group->mode : (ix->pcomm ? VDB_SHARD_RANGE : VDB_SHARD_REPLICA);
     if (rank) *rank = ix->pcomm ? ix->pcomm->rank : 0;

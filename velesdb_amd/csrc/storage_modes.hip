@@ -737,7 +737,7 @@ int32_t vdb_hip_index_set_storage_mode(vdb_hip_index* ix, int32_t mode) {
   if (mode != VDB_STORAGE_FULL && mode != VDB_STORAGE_SQ8 && mode != VDB_STORAGE_BINARY)
     return fail(VDB_ERR_INVALID_ARG, "bad storage mode");
   if (ix->group) return group_for_all(ix, 2, (uint32_t)mode);
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   if (ix->storage_mode == mode) return VDB_OK;
   VDB_ENTER(ix);
   for (DevBuf* b : {&ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits, &ix->sq8_img, &ix->sq8_nrm, &ix->sq8_seed})
@@ -766,7 +766,7 @@ int32_t vdb_hip_index_get_quantized(vdb_hip_index* ix, uint64_t id, uint8_t* out
       if (rc == VDB_OK || s + 1 == group_size(ix)) return rc;
     }
   }
-  std::lock_guard<std::shared_mutex> g(ix->mu);
+  std::lock_guard<vdb::IndexMutex> g(ix->mu);
   if (ix->storage_mode == VDB_STORAGE_FULL) return fail(VDB_ERR_STATE, "storage mode is Full: nothing is quantised");
   auto it = ix->id_to_idx.find(id);
   if (it == ix->id_to_idx.end()) return fail(VDB_ERR_INVALID_ARG, "unknown id");

@@ -11,6 +11,7 @@
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -33,6 +34,31 @@ bool hip_ok(hipError_t e, const char* what);
   } while (0)
 
 // growable device buffer (never shrinks); content preserved on growth when keep=true
+// The handle's reader / writer lock.  std::shared_mutex on glibc prefers readers: with searches arriving back to back an
+// insert waited for a moment without any reader — 0.7 s per insert under eight searching threads
+// (tests/test_gpu_hardening.py::test_concurrent_search_and_insert).  Writers announce themselves and new readers step aside
+// while one waits (the reference's parking_lot::RwLock does not starve writers either, index/hnsw/index/search.rs:80).
+class IndexMutex {
+ public:
+  void lock() {
+    writers_waiting_.fetch_add(1, std::memory_order_acq_rel);
+    m_.lock();
+    writers_waiting_.fetch_sub(1, std::memory_order_acq_rel);
+  }
+  bool try_lock() { return m_.try_lock(); }
+  void unlock() { m_.unlock(); }
+  void lock_shared() {
+    while (writers_waiting_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    m_.lock_shared();
+  }
+  bool try_lock_shared() { return writers_waiting_.load(std::memory_order_acquire) == 0 && m_.try_lock_shared(); }
+  void unlock_shared() { m_.unlock_shared(); }
+
+ private:
+  std::shared_mutex m_;
+  std::atomic<int> writers_waiting_{0};
+};
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -189,7 +215,7 @@ struct vdb_hip_index {
   // Reader / writer lock of the handle (the reference's RwLock around the graph, index/hnsw/index/search.rs:80): searches
   // hold it SHARED while they enqueue (and, host entry points, until their results are back), everything that changes the
   // index holds it exclusively.
-  mutable std::shared_mutex mu;
+  mutable vdb::IndexMutex mu;
   // Search contexts.  A search needs scratch buffers, event pools and a stream of its own; concurrent searches on one handle
   // each lease a CONTEXT: this object itself (context 0) or one of `ctx_clones` — handles that alias this one's data buffers
   // (rows, norms, images, graph: non-owning copies of the DevBufs, refreshed when `version` moved) and own only their scratch
