@@ -287,6 +287,10 @@ __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearc
               // result set is full, so a neighbour rejected now would be rejected at its turn too
               uint64_t mask = __ballot(t < m_prev && (d < far || size < ef));
               if (LAT) mask &= spec_mask;
+              // two or more to admit: all at once (vdb_hnsw_device.hpp admit_batch) unless distances tie exactly
+              if (NS > 0 && (mask & (mask - 1)) != 0ull &&
+                  list.admit_batch(mask, d, t < m_prev ? nb_id[t] : 0u, lane, ef, keys, flags))
+                mask = 0ull;
               while (mask) {
                 const int src = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;

@@ -252,6 +252,70 @@ struct CandList {
       cnt += 1;
     }
   }
+  // Admission of a whole chunk of evaluated neighbours at once (round 3; the sequential loop of P_Z_ADMIT cost 2.6 us of a
+  // 7-us expansion: ~0.4 us per admitted neighbour).  `mask` = the lanes whose neighbour passed the chunk-start test of
+  // graph.rs:503 (d < furthest || len < ef), d / nb = the lane's distance and node.  Without exact distance ties the
+  // sequential process ends with the ef smallest keys of (list U candidates): a candidate among them is below the furthest
+  // distance at its turn whatever came before it (the furthest only falls, and removing one of the ef smallest leaves an
+  // ef-th that is strictly larger), and every other one is cut by the truncation behind its insert or rejected outright.
+  // So: every accepted key's rank among the old entries (two ballots) and among the candidates, every old entry shifted by
+  // the number of candidates below it, one scatter through LDS, one truncate.  Returns false — nothing changed — when the
+  // caller has to walk the chunk one by one: an exact tie of distances between a candidate and anything (the reference's
+  // strict compare decides those in arrival order; equal distances are neighbours in the merged order, so the test looks at
+  // neighbours after the scatter), a NaN distance, or more keys than the list holds.
+  __device__ __forceinline__ bool admit_batch(uint64_t mask, float d, uint32_t nb, int lane, uint32_t ef, volatile uint64_t* scratch_v,
+                                              volatile uint8_t*) {
+    const uint32_t n_acc = (uint32_t)__popcll(mask);
+    const uint32_t total = cnt + n_acc;
+    if (total > CAP) return false;
+    const bool mine = ((mask >> lane) & 1ull) != 0;
+    if (__ballot(mine && !(d == d))) return false;
+    const uint64_t mykey = mine ? enc(make_key<false>(d, nb)) : ~0ull;
+    uint32_t shift[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) shift[s] = 0;
+    uint32_t mypos = 0;
+    for (uint64_t rest = mask; rest; rest &= rest - 1) {
+      const int j = __ffsll((long long)rest) - 1;
+      const uint64_t kj = readlane64(mykey, j);
+      uint32_t r = (uint32_t)__popcll(__ballot(mine && mykey < kj));
+#pragma unroll
+      for (int s = 0; s < NS; s++)
+        if ((uint32_t)s * 64u < cnt) {  // (wave-uniform: slots past the list hold nothing)
+          const bool lt = k[s] < kj;    // keys are distinct (a node enters the list once): kj < k[s] is its negation
+          r += (uint32_t)__popcll(__ballot(lt));
+          shift[s] += lt ? 0u : 1u;     // (empty places, ~0, are shifted too: they are not written)
+        }
+      if (lane == j) mypos = r;
+    }
+    // Scatter through LDS — plain accesses (a volatile one waits for its own round trip: 20 of them were 3 us), ordered by
+    // the wave's in-order LDS queue and the compiler barriers: old entries behind the candidates below them, candidates at old
+    // rank + candidate rank; then everything is read back in one go, and every candidate looks at its two neighbours in the
+    // merged order (equal distances are neighbours there).
+    uint64_t* scratch = const_cast<uint64_t*>(scratch_v);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+      if ((uint32_t)s * 64u < cnt && k[s] != ~0ull) scratch[(uint32_t)s * 64u + (uint32_t)lane + shift[s]] = k[s];  // < total <= CAP
+    if (mine) scratch[mypos] = mykey;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint64_t nk[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      const uint32_t e = (uint32_t)s * 64u + (uint32_t)lane;
+      nk[s] = ((uint32_t)s * 64u < total && e < total) ? scratch[e] : ~0ull;
+    }
+    const uint64_t below = (mine && mypos > 0) ? scratch[mypos - 1] : ~0ull;
+    const uint64_t above = (mine && mypos + 1 < total) ? scratch[mypos + 1] : ~0ull;
+    asm volatile("" ::: "memory");
+    const bool tie = mine && ((below != ~0ull && key_dist(dec(below)) == d) || (above != ~0ull && key_dist(dec(above)) == d));
+    if (__ballot(tie)) return false;  // (k, cnt untouched)
+#pragma unroll
+    for (int s = 0; s < NS; s++) k[s] = nk[s];
+    cnt = total;
+    truncate(ef, lane);
+    return true;
+  }
   __device__ __forceinline__ uint32_t first_unexpanded(int) const {
 #pragma unroll
     for (int s = 0; s < NS; s++) {
@@ -327,6 +391,7 @@ struct CandList<0, UD> {
     list_insert(keys, flags, cnt, cap, ext, lane, dr, df);
     if (dr != kKeyInvalid && df == 0) overflow = 1;  // an unexpanded candidate fell off the list
   }
+  __device__ __forceinline__ bool admit_batch(uint64_t, float, uint32_t, int, uint32_t, volatile uint64_t*, volatile uint8_t*) { return false; }  // (LDS list: one by one)
   __device__ __forceinline__ uint32_t first_unexpanded(int lane) const {
     for (uint32_t c = 0; c < cnt; c += 64) {
       const uint32_t e = c + lane;
@@ -364,6 +429,10 @@ __device__ __forceinline__ void dist_phase_f32(const DistCtx& a, const float4* q
   const int d4 = (int)((a.dim + 3) / 4);
   for (uint32_t j0 = (uint32_t)wib * R; j0 < m; j0 += WAVES * R) {
     float acc[R];
+    // the row's norm (cosine) travels with the rows: requested behind the reduction it was a second dependent round trip
+    const uint32_t jn = j0 + (uint32_t)(lane & (R - 1));
+    float vnorm_early = 1.0f;
+    if (METRIC == kCosine && lane < R && jn < m) vnorm_early = a.norms[nb_id[jn]];
     if (CPL > 0) {
       float4 v[R][CPL > 0 ? CPL : 1];
 #pragma unroll
@@ -401,8 +470,7 @@ __device__ __forceinline__ void dist_phase_f32(const DistCtx& a, const float4* q
     reduce_rows<R>(acc, lane);
     const uint32_t j = j0 + (uint32_t)(lane & (R - 1));
     if (lane < R && j < m) {
-      float vnorm = 1.0f;
-      if (METRIC == kCosine) vnorm = a.norms[nb_id[j]];
+      const float vnorm = vnorm_early;
       const float s = finish_score<METRIC>(acc[0], qnorm, vnorm);
       // raw = HnswIndex::compute_distance (search.rs:30-38), otherwise DistanceEngine::distance
       nb_d[j] = raw ? s : ((METRIC == kCosine) ? 1.0f - s : ((METRIC == kDot) ? -s : s));
