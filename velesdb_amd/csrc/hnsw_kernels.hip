@@ -236,7 +236,7 @@ __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearc
                 if ((uint32_t)lane < lim) nb0 = L.nbr[(size_t)cnode * L.stride + lane];
                 uint32_t nc = rfl(L.cnt[cnode]);
                 nc = min(nc, lim);
-                if (LAT) {  // (nc <= 64, host) every neighbour is evaluated; the visited verdicts follow with the distances
+                if (LAT && a.lat_spec) {  // (nc <= 64, host) every neighbour is evaluated; the visited verdicts follow with the distances
                   if ((uint32_t)lane < nc) nb_id[lane] = nb0;
                   m = nc;
                   spec = nc != 0;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearc
               }
             }
           } else if (phase == P_Z_ADMIT) {
-            if (LAT) {  // the unvisited ones of the evaluated neighbours, in list order: counters and the undo log
+            if (LAT && a.lat_spec) {  // the unvisited ones of the evaluated neighbours, in list order: counters and the undo log
               n_dist += (uint32_t)__popcll(spec_mask);
               if (!VIS && (spec_mask >> lane & 1ull)) {
                 const uint32_t pos = logn + (uint32_t)__popcll(spec_mask & lt_mask(lane));
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearc
               // pre-filter against the furthest distance at chunk start: it only decreases while the
               // result set is full, so a neighbour rejected now would be rejected at its turn too
               uint64_t mask = __ballot(t < m_prev && (d < far || size < ef));
-              if (LAT) mask &= spec_mask;
+              if (LAT && a.lat_spec) mask &= spec_mask;
               // two or more to admit: all at once (vdb_hnsw_device.hpp admit_batch) unless distances tie exactly
               if (NS > 0 && (mask & (mask - 1)) != 0ull &&
                   list.admit_batch(mask, d, t < m_prev ? nb_id[t] : 0u, lane, ef, keys, flags))
@@ -554,8 +554,13 @@ hipError_t launch_hnsw_search(const HnswSearchArgs& a0, int slots, hipStream_t s
   // sit in the 256 MB Infinity Cache: the latency-mode kernel (f32 metrics,
   // register list, layer-0 lists of <= 64 neighbours).  Over a cache-resident corpus the walk is not latency-bound the same way
   // (10 K x 768: 408 us per query on the throughput kernel, 599 us in latency mode, whose speculation fetches visited rows too)
-  if (g_hnsw_lat && a.nq <= (g_hnsw_lat_max ? g_hnsw_lat_max : a.n_cus) && (g_hnsw_lat >= 2 || (uint64_t)a.n_rows * a.row_stride * 4 >= (256ull << 20)) && a.list_slots == kSearchRegSlots && a.rerank_k == 0 && a.layers[0].stride <= 64 &&
+  // (round 3: with the visited set in LDS the latency-mode kernel also serves cache-resident corpora — WITHOUT the speculation:
+  // test first, fetch the unvisited; VELESDB_HNSW_LATENCY_MODE=2 forces the speculative form, =3 the other one)
+  const bool beyond_cache = (uint64_t)a.n_rows * a.row_stride * 4 >= (256ull << 20);
+  const uint32_t lat_vis = pick_vis(a0, lds, true);
+  if (g_hnsw_lat && a.nq <= (g_hnsw_lat_max ? g_hnsw_lat_max : a.n_cus) && (g_hnsw_lat >= 2 || beyond_cache || lat_vis) && a.list_slots == kSearchRegSlots && a.rerank_k == 0 && a.layers[0].stride <= 64 &&
       a.nbmax >= 64 && (a.metric == kCosine || a.metric == kEuclidean || a.metric == kDot)) {
+    a.lat_spec = g_hnsw_lat == 2 ? 1u : (g_hnsw_lat == 3 ? 0u : (beyond_cache ? 1u : 0u));
     a.vis_log2 = pick_vis(a0, lds, true);
     a.vis_off = (uint32_t)lds;
     if (a.vis_log2) lds += (size_t)4 << a.vis_log2;

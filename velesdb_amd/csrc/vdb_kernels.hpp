@@ -132,6 +132,10 @@ struct HnswSearchArgs {
   uint32_t list_slots;  // 0: candidate list in LDS; kSearchRegSlots: in registers (ef + 64 <= slots * 64)
   uint32_t vis_log2;    // > 0: the visited set is an exact hash set of 2^vis_log2 entries in LDS at byte offset vis_off (VisSet,
   uint32_t vis_off;     // vdb_hnsw_device.hpp) instead of the HBM bitmap; a query that would pass 3/4 of it reports overflow
+  uint32_t lat_spec;    // latency-mode kernel: 1 = all neighbours' rows are fetched beside the visited test (corpora beyond the
+                        // Infinity Cache: the walk is a chain of memory round trips), 0 = the test (LDS set) first, then only
+                        // the unvisited neighbours' rows (cache-resident corpora: the round trip is short and small graphs
+                        // revisit most neighbours)
   uint32_t rerank_k;  // > 0: search_with_rerank (search.rs:118-160): the first rerank_k results are re-scored with the
                       // raw compute_distance, stable-sorted in the metric's order and cut to k
 };
