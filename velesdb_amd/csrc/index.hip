@@ -134,6 +134,7 @@ void copy_image_fields(vdb_hip_index* c, const vdb_hip_index* p) {
   c->l2_rows = p->l2_rows;
   c->sq8_img = p->sq8_img;
   c->sq8_nrm = p->sq8_nrm;
+  c->sq8_rho = p->sq8_rho;
   c->sq8_seed = p->sq8_seed;
   c->sq8_img_rows = p->sq8_img_rows;
 }
@@ -868,7 +869,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     return o;
   };
   // level 2 over the f32 rows: the seed runs on the bf16 pipe (sweep_split.hip seed_scores_bf16: every seed score as a key)
-  const bool bf16_seed = level == 2 && !sq8 && g_bf16_seed;
+  const bool bf16_seed = level >= 2 && g_bf16_seed;
   const size_t o_seedp = take(std::max((size_t)nqg * sp.G * k * 8, bf16_seed ? (size_t)nqg * R0 * 8 : (size_t)0)), o_ids = take((size_t)nqg * K2 * 8), o_sc = take((size_t)nqg * K2 * 4),
                o_n = take((size_t)nqg * 4), o_tau = take((size_t)nqg * 8), o_delta = take((size_t)nqg * 4),
                o_qn = take((size_t)nqg * 4), o_rho = take((size_t)nqg * 4), o_flags = take((size_t)nqg * 4 + 64 * 4 + 16), o_btau = take((size_t)nqg * lists * 8),
@@ -890,8 +891,8 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   float* delta = reinterpret_cast<float*>(sd + o_delta);
   float* qnorms = reinterpret_cast<float*>(sd + o_qn);
   // level 2 over the f32 rows: the error bound from MEASURED rounding residuals (sweep_split.hip select_eps_q)
-  const DevBuf& rho_buf = l2 ? ix->l2_rho : ix->bf16_rho;
-  float* rho_q = (level == 2 && !sq8 && rho_buf.p) ? reinterpret_cast<float*>(sd + o_rho) : nullptr;
+  const DevBuf& rho_buf = sq8 ? ix->sq8_rho : (l2 ? ix->l2_rho : ix->bf16_rho);
+  float* rho_q = (level >= 2 && rho_buf.p) ? reinterpret_cast<float*>(sd + o_rho) : nullptr;
   const uint32_t* rho_max = rho_q ? rho_buf.as<uint32_t>() : nullptr;
   uint32_t* flags = reinterpret_cast<uint32_t*>(sd + o_flags);
   uint32_t* tile_needed = flags + nqg;          // [<= 64]
@@ -960,7 +961,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     ms.k_out = ks;
     launch_merge(true, ms, nqg, st);
     if (l2)
-      launch_l2_seed(m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim_a, 0.0f, st, rho_q, rho_max, R0);
+      launch_l2_seed(m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim_a, sq8 ? 1.5e-4f : 0.0f, st, rho_q, rho_max, R0);
     else
       launch_split_seed_approx(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, R0, dim, level, st,
                                rho_q, rho_max);
@@ -1602,7 +1603,7 @@ std::vector<DevBuf*> index_buffers(vdb_hip_index* ix) {
       &ix->l2_img, &ix->l2_seed, &ix->l2_rho,                               // Euclidean selection images
       &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq,                // int8 traversal
       &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits,  // storage modes
-      &ix->sq8_img, &ix->sq8_nrm, &ix->sq8_seed,                            // SQ8 selection images
+      &ix->sq8_img, &ix->sq8_nrm, &ix->sq8_seed, &ix->sq8_rho,              // SQ8 selection images
       &ix->s_queries, &ix->s_part_keys, &ix->s_part_cnt, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits,
       &ix->s_misc, &ix->s_fb_keys, &ix->s_seed, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels, &ix->s_req_keys,
       &ix->s_req_vals, &ix->s_sort_tmp};

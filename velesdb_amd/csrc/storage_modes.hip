@@ -437,12 +437,14 @@ static hipError_t launch_sq8_m(int metric, const Sq8Args& a, int blocks, size_t 
 // rows of dim + 4 (slot dim = -nsq / 2)
 __global__ __launch_bounds__(256) void sq8_dequant_rows(const uint8_t* codes, uint64_t code_stride, const float* vmin, const float* vmax,
                                                         const float* nsq, uint16_t* img, float* nrm, float* seed, uint32_t seed_rows,
-                                                        uint32_t row0, uint32_t n_rows, uint32_t dim, uint32_t dim_a, uint32_t dim_s) {
+                                                        uint32_t row0, uint32_t n_rows, uint32_t dim, uint32_t dim_a, uint32_t dim_s,
+                                                        uint32_t* rho_max_bits) {
   const int lane = lane_id();
   const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t nwaves = gridDim.x * 4;
   for (uint32_t r = wave; r < n_rows; r += nwaves) {
     const uint32_t row = row0 + r;
+    double se = 0.0, sx = 0.0;  // the dequantised row's bf16 rounding residual ratio (sweep_split.hip select_eps_q)
     const float mn = vmin[row], range = __fsub_rn(vmax[row], mn);
     const bool flat = range < kF32Eps;
     const float scale = __fdiv_rn(range, 255.0f);
@@ -457,6 +459,9 @@ __global__ __launch_bounds__(256) void sq8_dequant_rows(const uint8_t* codes, ui
       for (int e = 0; e < 4; e++) {  // round to nearest even; NaN stays NaN
         uint32_t u = __float_as_uint(d[e]);
         h[e] = (u & 0x7FFFFFFFu) > 0x7F800000u ? ((u >> 16) | 0x0040u) : ((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        const float de = d[e] - __uint_as_float(h[e] << 16);  // exact in f32
+        se += (double)de * (double)de;
+        sx += (double)d[e] * (double)d[e];
       }
       *reinterpret_cast<uint2*>(img + (size_t)row * dim_a + i) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
       if (row < seed_rows) *reinterpret_cast<float4*>(seed + (size_t)row * dim_s + i) = make_float4(d[0], d[1], d[2], d[3]);
@@ -471,6 +476,17 @@ __global__ __launch_bounds__(256) void sq8_dequant_rows(const uint8_t* codes, ui
       if (row < seed_rows && lane < 4 && dim + lane < dim_s) seed[(size_t)row * dim_s + dim + lane] = lane == 0 ? hh : 0.0f;
     }
     if (lane == 0) nrm[row] = sqrtf(nsq[row]);
+    if (rho_max_bits) {
+#pragma unroll
+      for (int s2 = 32; s2 > 0; s2 >>= 1) {
+        se += __shfl_xor(se, s2, 64);
+        sx += __shfl_xor(sx, s2, 64);
+      }
+      if (lane == 0 && sx > 0.0) {
+        const float rho = (float)(sqrt(se / sx) * 1.0000002);
+        if (rho == rho && rho < __uint_as_float(0x7F800000u)) atomicMax(rho_max_bits, __float_as_uint(rho));
+      }
+    }
   }
 }
 
@@ -542,12 +558,18 @@ static int32_t ensure_sq8_select_impl(vdb_hip_index* ix, hipStream_t st) {
       (e = ix->sq8_nrm.reserve(cap * 4, true, st)) != hipSuccess ||
       (e = ix->sq8_seed.reserve((size_t)kSplitSeedRows * dim_s * 4, true, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("SQ8 selection image: ") + hipGetErrorString(e));
+  if (!ix->sq8_rho.p) {  // (the image is built from row 0 behind this: every row contributes)
+    if ((e = ix->sq8_rho.reserve(256, false, st)) != hipSuccess || (e = hipMemsetAsync(ix->sq8_rho.p, 0, 256, st)) != hipSuccess)
+      return fail(VDB_ERR_OOM, std::string("SQ8 residual bound: ") + hipGetErrorString(e));
+    ix->sq8_img_rows = 0;
+  }
   if (ix->sq8_img_rows < ix->n_rows) {
     const uint64_t first = ix->sq8_img_rows, n = ix->n_rows - first;
     const int blocks = (int)std::min<uint64_t>((n + 3) / 4, 4096);
     hipLaunchKernelGGL(sq8_dequant_rows, dim3(blocks), dim3(256), 0, st, ix->sq8_codes.as<uint8_t>(), ix->sq8_stride,
                        ix->sq8_min.as<float>(), ix->sq8_max.as<float>(), ix->sq8_nsq.as<float>(), ix->sq8_img.as<uint16_t>(),
-                       ix->sq8_nrm.as<float>(), ix->sq8_seed.as<float>(), kSplitSeedRows, (uint32_t)first, (uint32_t)n, ix->dim, dim_a, dim_s);
+                       ix->sq8_nrm.as<float>(), ix->sq8_seed.as<float>(), kSplitSeedRows, (uint32_t)first, (uint32_t)n, ix->dim, dim_a, dim_s,
+                       ix->sq8_rho.as<uint32_t>());
     ix->sq8_img_rows = ix->n_rows;
     VDB_HIP(hipGetLastError());
   }

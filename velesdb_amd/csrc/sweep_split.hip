@@ -97,9 +97,10 @@ __host__ __device__ inline float select_eps(uint32_t dim, int level) {
 // f64 (no underflow for any f32 row, rounding error far below the 1.002 pad).  Half the constant bound on the benchmark data:
 // a third of the candidates in front of the selection kernel's epilogue.
 __device__ __forceinline__ float select_eps_q(uint32_t dim, int level, const float* rho_q, const uint32_t* rho_max_bits, uint32_t q) {
-  if (level != 2 || !rho_q || !rho_max_bits) return select_eps(dim, level);
+  if (level < 2 || !rho_q || !rho_max_bits) return select_eps(dim, level);
   const float rm = __uint_as_float(*rho_max_bits), rq = rho_q[q];
-  return (rm + rq + 3.0f * rm * rq) * 1.002f + 16.0f * (float)dim * 5.9604645e-8f;  // (NaN query: NaN -> no bound, no proof)
+  // (level 3 = level 2 over the SQ8 storage mode's dequantised rows: + select_eps's extra term for the reference's own chain)
+  return (rm + rq + 3.0f * rm * rq) * 1.002f + 16.0f * (float)dim * 5.9604645e-8f + (level >= 3 ? 1.5e-4f : 0.0f);  // (NaN query: NaN -> no bound, no proof)
 }
 // rho_q per query: one wave per query
 __global__ __launch_bounds__(256) void query_round_error_kernel(const float* q, uint64_t q_stride, float* rho_q, uint32_t nq, uint32_t dim) {

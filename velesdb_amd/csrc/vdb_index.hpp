@@ -145,6 +145,7 @@ struct vdb_hip_index {
   // (prep_bf16_rows raises it; never lowered: a bound) — the level-2 selection's measured error bound (sweep_split.hip)
   vdb::DevBuf bf16_rho;
   vdb::DevBuf l2_rho;  // the same for the Euclidean selection image (its first dim columns are the bf16-rounded rows)
+  vdb::DevBuf sq8_rho;  // ... and for the SQ8 storage mode's image (bf16 of the dequantised rows)
   // optional scalar quantiser + u8 codes for the int8 traversal (hnsw_int8.hip)
   vdb::DevBuf sq_min, sq_scale, codes, codes_sq;
   uint32_t code_words = 0;
