@@ -64,7 +64,8 @@ def _run_case(metric, rows, qs, k, level, expect_unproven, remove):
 
 
 @pytest.mark.parametrize("metric", [DM.Cosine, DM.DotProduct])
-@pytest.mark.parametrize("n,dim,nq,k", [(70_000, 768, 256, 10), (150_001, 128, 1000, 10), (66_000, 64, 256, 1), (300_000, 96, 450, 7), (70_000, 128, 300, 5), (70_000, 128, 100, 10), (70_000, 128, 620, 10)])
+@pytest.mark.parametrize("n,dim,nq,k", [(70_000, 768, 256, 10), (150_001, 128, 1000, 10), (66_000, 64, 256, 1), (300_000, 96, 450, 7), (70_000, 128, 300, 5), (70_000, 128, 100, 10), (70_000, 128, 620, 10),
+                                        (70_000, 128, 16, 10), (70_003, 768, 33, 3), (150_001, 128, 384, 10), (70_000, 256, 1030, 5)])  # small batches, 1.5 tiles, 1 024 + 6
 def test_random_data_proven_and_bit_exact(gpu_required, metric, n, dim, nq, k):
     rng = np.random.default_rng(n + dim + int(metric))
     rows = rng.standard_normal((n, dim)).astype(np.float32)
@@ -166,7 +167,7 @@ def test_level2_parks_itself_at_level1_when_the_data_defeats_it(gpu_required):
     ix.close()
 
 
-@pytest.mark.parametrize("n,dim,nq,k", [(70_000, 128, 256, 10), (90_000, 256, 480, 3), (66_000, 768, 256, 1)])
+@pytest.mark.parametrize("n,dim,nq,k", [(70_000, 128, 256, 10), (90_000, 256, 480, 3), (66_000, 768, 256, 1), (70_000, 128, 48, 10), (70_001, 128, 384, 5)])
 def test_euclidean_batches_through_the_selection_stage(gpu_required, n, dim, nq, k):
     """Euclidean batches select on the bf16 matrix cores over the augmented form s = q.v - |v|^2 / 2, re-score 64 candidates
     with the canonical (q - v)^2 chain and prove the answer; unproven queries (here: duplicated rows = exact ties, a cluster of

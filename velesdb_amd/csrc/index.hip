@@ -710,17 +710,12 @@ static uint32_t select_min_queries() {
   }();
   return v;
 }
-static bool select_shape_ok(uint32_t nqg) {
-  const uint32_t nqt_big = (nqg + 255) / 256;
-  if (nqt_big == 1) return nqg >= select_min_queries();
-  return nqg >= kGemmBigMinQueries && (uint64_t)nqg * 8 >= (uint64_t)nqt_big * 256 * 7;
-}
-// the chunk of the remaining nq_left queries the selection stage takes next (0: none): up to 1 024, and when that leaves the
-// last 256-query tile too empty, the whole tiles in front of it (the rest is the next chunk: a single tile, or the exact kernels)
+// the chunk of the remaining nq_left queries the selection stage takes next (0: none): up to 1 024, whatever that leaves of the
+// last 256-query tile — a partly filled tile costs what a full one costs, a second pass costs the whole fixed part again
+// (384 queries as 256 + 128: 1.34 ms; as one pass of two tiles: what 512 cost, 1.01 ms)
 static uint32_t select_chunk(uint32_t nq_left) {
   const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
-  if (select_shape_ok(nqg)) return nqg;
-  return nqg >= 256 ? nqg / 256 * 256 : 0;
+  return nqg >= select_min_queries() ? nqg : 0;
 }
 
 // 0: no selection stage (exact kernel); 1: split-bf16 selection; 2: plain bf16 selection

@@ -168,7 +168,9 @@ struct GemmPlan {
 };
 constexpr uint64_t kRowSlack = 256;         // rows allocated past the capacity of the row arrays (whole-tile reads)
 constexpr uint32_t kGemmBigMinQueries = 224;
-constexpr uint32_t kSelectMinQueries = 80;     // selection stage: smallest single-tile batch (VELESDB_SELECT_MIN_QUERIES overrides)
+constexpr uint32_t kSelectMinQueries = 16;     // selection stage: smallest batch (VELESDB_SELECT_MIN_QUERIES overrides).  Round 3: 80 -> 16 — a
+                                               // 16-query call 0.57 ms against 0.71 on the exact streaming kernel, 64 queries 0.62 against 1.07
+                                               // (Euclidean 0.69 against 1.37): profiles/r03ab_select_min_queries.log
 constexpr uint32_t kGemmMinQueries = 64;    // below this the streaming kernels (HBM-bound) are faster
 constexpr uint32_t kGemmMaxK = 48;          // candidate buffers hold <= 64 keys per query (one per lane when compacted)
 constexpr uint32_t kGemmMaxQueries = 1024;  // per launch (bounds the partial-list scratch)
