@@ -213,7 +213,7 @@ int32_t vdb_hip_index_search_rerank(vdb_hip_index* idx, const float* queries_row
                                     uint32_t* out_n);
 /* device-resident variant: d_queries nq*dim f32 (16-byte aligned), outputs device buffers of
  * nq*k / nq; enqueued on `stream`, no host synchronisation (one exception: Euclidean VDB_SEARCH_BRUTE batches of >= 64 queries
- * outside the selection stage's shapes — < 80 queries, dim % 64 != 0, k > 10, < 65 536 rows — read their per-query verdicts back
+ * outside the selection stage's shapes — < 16 queries, dim % 64 != 0, k > 10, < 65 536 rows — read their per-query verdicts back
  * once per <= 1 024-query chunk).  In HNSW mode d_out_n[i] ==
  * 0xFFFFFFFF marks a query whose LDS candidate list overflowed (needs very many exact distance
  * ties) or, in calls of at most one query per CU, whose walk visited more nodes than the LDS visited set
@@ -304,7 +304,7 @@ int32_t vdb_hip_set_max_query_tile(uint32_t b);
  * Both are exact f32 arithmetic; scores differ in the last bits because the summation order does.  The choice
  * never depends on the batch size. */
 int32_t vdb_hip_set_sweep_engine(int32_t engine);
-/* Exact Cosine / DotProduct (and Euclidean, SQ8) batches of 80 .. 256 queries, or more that fill 256-query tiles to 7/8
+/* Exact Cosine / DotProduct (and Euclidean, SQ8) batches of >= 16 queries, up to 1 024 per pass (round 2: 80 .. 256, or more that filled 256-query tiles to 7/8)
  * (k <= 10, >= 65 536 rows, dim % 32 == 0):
  * the matrix cores SELECT candidates on a reduced-precision image of rows and queries, the best candidates per query are
  * re-scored with the exact chain (oracle mode M), and every query's answer is PROVEN from an error bound or recomputed by
