@@ -821,12 +821,17 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   // candidates per 256 x 256 tile through: the rows swept under a weak threshold are kept few (measured at 1 M x 1 024
   // queries, level 2: two launches 2 x 1.32 ms).
   const uint32_t R0 = kSplitSeedRows;
-  const uint32_t tiles_all = (n - R0 + 255) / 256;
+  // level >= 2: the seed runs on the bf16 pipe over the selection's own image (sweep_split.hip seed_scores_bf16) and is a SAMPLE:
+  // it only supplies the starting bounds — the selection launches sweep its rows again (0.4 % of the corpus), so it may keep
+  // one key per 16 rows instead of all of them (33 MB of keys and a 55-us merge per batch otherwise)
+  const bool bf16_seed = level >= 2 && g_bf16_seed;
+  const uint32_t row_first = bf16_seed ? 0u : R0;
+  const uint32_t tiles_all = (n - row_first + 255) / 256;
   const uint32_t G2 = (uint32_t)std::max(8, ix->n_cus / (int)((nqg + 255) / 256) / 8 * 8);
   Bf16GemmPlan bp[4];
   int n_launch = 0;
   {
-    uint32_t lo = R0, left = tiles_all;
+    uint32_t lo = row_first, left = tiles_all;
     // (VELESDB_SEL_STEPS="a,b,c": tiles per row group of the first launches — schedule probes)
     static const std::array<uint32_t, 3> mult = [] {
       std::array<uint32_t, 3> m{1, 4, 16};
@@ -864,8 +869,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     return o;
   };
   // level 2 over the f32 rows: the seed runs on the bf16 pipe (sweep_split.hip seed_scores_bf16: every seed score as a key)
-  const bool bf16_seed = level >= 2 && g_bf16_seed;
-  const size_t o_seedp = take(std::max((size_t)nqg * sp.G * k * 8, bf16_seed ? (size_t)nqg * R0 * 8 : (size_t)0)), o_ids = take((size_t)nqg * K2 * 8), o_sc = take((size_t)nqg * K2 * 4),
+  const size_t o_seedp = take(std::max((size_t)nqg * sp.G * k * 8, bf16_seed ? (size_t)nqg * (R0 / 16) * 8 : (size_t)0)), o_ids = take((size_t)nqg * K2 * 8), o_sc = take((size_t)nqg * K2 * 4),
                o_n = take((size_t)nqg * 4), o_tau = take((size_t)nqg * 8), o_delta = take((size_t)nqg * 4),
                o_qn = take((size_t)nqg * 4), o_rho = take((size_t)nqg * 4), o_flags = take((size_t)nqg * 4 + 64 * 4 + 16), o_btau = take((size_t)nqg * lists * 8),
                o_fid = take((size_t)nqg * k * 8), o_fsc = take((size_t)nqg * k * 4), o_fn = take((size_t)nqg * 4),
@@ -951,14 +955,15 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   if (bf16_seed) {
     launch_seed_scores_bf16(sel_metric, img_rows, img_stride, sel_norms, alive, q16, img_stride, qnorms, ag.part_keys, R0, nqg,
                             l2 ? dim_a : dim, st);
-    ms.n_lists = R0;  // one "list" of one key per seed row: the selection merge picks the ks best
+    ms.n_lists = R0 / 16;  // one "list" of one key per 16 seed rows (their best): the selection merge picks the ks best
     ms.k = 1;
     ms.k_out = ks;
     launch_merge(true, ms, nqg, st);
     if (l2)
-      launch_l2_seed(m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim_a, sq8 ? 1.5e-4f : 0.0f, st, rho_q, rho_max, R0);
+      launch_l2_seed(m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim_a, sq8 ? 1.5e-4f : 0.0f, st, rho_q, rho_max,
+                     kSeedIsSample);
     else
-      launch_split_seed_approx(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, R0, dim, level, st,
+      launch_split_seed_approx(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, kSeedIsSample, dim, level, st,
                                rho_q, rho_max);
   } else {
   e = launch_sweep_gemm(sel_metric, sp, ag, st);

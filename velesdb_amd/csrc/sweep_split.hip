@@ -227,7 +227,7 @@ void launch_split_seed(int metric, const uint64_t* ids, const float* scores, con
 // score stored as a key ([nq][seed_rows]; 32 MiB, L2 / MALL resident), merge_topk_select picks the ks best per query,
 // split_seed_approx_kernel turns them into list slot 0 of the pool (approximate keys like every other slot), the bound of
 // what slot 0 left out (its ks-th key: blk_tau, as a selection block reports it) and tau.
-// One wave = 16 rows x 64 queries; both operands straight from L2 in fragment shape (16 B per lane per fragment: lane (i = l &
+// One wave = 64 rows x 64 queries; both operands straight from L2 in fragment shape (16 B per lane per fragment: lane (i = l &
 // 15, kk = l >> 4) holds elements 32 s + 8 kk .. + 7 of row / query i), four 32-deep steps in flight.
 typedef float f32x4_s __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
@@ -236,48 +236,67 @@ __global__ __launch_bounds__(256) void seed_scores_bf16(const uint16_t* rows16, 
                                                         const uint16_t* q16, uint64_t q_stride, const float* qnorms, uint64_t* keys,
                                                         uint32_t seed_rows, uint32_t nq, uint32_t dim) {
   const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
-  const uint32_t row0 = (blockIdx.x * 4u + wib) * 16u;  // this wave's 16 rows
-  const uint32_t qb = blockIdx.y * 64u;                  // ... and 64 queries
+  // a wave = 64 rows x 64 queries (round 3: 16 x 64 — every query fragment fed ONE row fragment, 7.4 TB/s through L2 for 4 096
+  // seed rows, 66 us; now four): row blocks rb = 0..3 of 16 rows
+  const uint32_t row0 = (blockIdx.x * 4u + wib) * 64u;
+  const uint32_t qb = blockIdx.y * 64u;
   if (row0 >= seed_rows) return;
   const uint32_t i = lane & 15u, kk = lane >> 4;
-  const uint16_t* ap = rows16 + (size_t)(row0 + i) * row_stride + kk * 8u;
+  const uint16_t* ap[4];
+#pragma unroll
+  for (int rb = 0; rb < 4; rb++) ap[rb] = rows16 + (size_t)min(row0 + (uint32_t)rb * 16u + i, seed_rows - 1u) * row_stride + kk * 8u;
   const uint16_t* bp[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) bp[t] = q16 + (size_t)min(qb + (uint32_t)t * 16u + i, nq - 1u) * q_stride + kk * 8u;
-  f32x4_s acc[4] = {f32x4_s{0.f, 0.f, 0.f, 0.f}, f32x4_s{0.f, 0.f, 0.f, 0.f}, f32x4_s{0.f, 0.f, 0.f, 0.f}, f32x4_s{0.f, 0.f, 0.f, 0.f}};
-  for (uint32_t k0 = 0; k0 < dim; k0 += 128) {  // dim % 64 == 0 (level 2): steps past dim are skipped
-    bf16x8_s av[4], bv[4][4];
+  f32x4_s acc[4][4];
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+  for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[rb][t] = f32x4_s{0.f, 0.f, 0.f, 0.f};
+  for (uint32_t k0 = 0; k0 < dim; k0 += 64) {  // dim % 32 == 0: steps past dim are skipped
+    bf16x8_s av[4][2], bv[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
       const bool in = k0 + (uint32_t)s * 32u < dim;
-      av[s] = in ? *reinterpret_cast<const bf16x8_s*>(ap + k0 + s * 32) : bf16x8_s{};
+#pragma unroll
+      for (int rb = 0; rb < 4; rb++) av[rb][s] = in ? *reinterpret_cast<const bf16x8_s*>(ap[rb] + k0 + s * 32) : bf16x8_s{};
 #pragma unroll
       for (int t = 0; t < 4; t++) bv[s][t] = in ? *reinterpret_cast<const bf16x8_s*>(bp[t] + k0 + s * 32) : bf16x8_s{};
     }
 #pragma unroll
-    for (int s = 0; s < 4; s++)
+    for (int s = 0; s < 2; s++)
 #pragma unroll
-      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s], bv[s][t], acc[t], 0, 0, 0);
+      for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[rb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rb][s], bv[s][t], acc[rb][t], 0, 0, 0);
   }
-  // lane holds rows row0 + 4 kk + r (r = 0..3) of query column qb + 16 t + i
+  // lane holds rows row0 + 16 rb + 4 kk + r (rb, r = 0..3) of query column qb + 16 t + i: the best of those 16 as ONE key —
+  // keys[q][group], group = 4 (row0 / 64) + kk (the seed is a sample: sweep_split.hip file header, index.hip brute_split_dev)
+  const uint32_t ngrp = (seed_rows + 15u) / 16u;
 #pragma unroll
   for (int t = 0; t < 4; t++) {
     const uint32_t q = qb + (uint32_t)t * 16u + i;
     if (q >= nq) continue;
     const float qn = METRIC == kCosine ? qnorms[q] : 1.0f;
+    uint64_t best = kKeyInvalid;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const uint32_t row = row0 + 4u * kk + (uint32_t)r;
-      const float sc = finish_score<METRIC>(acc[t][r], qn, METRIC == kCosine ? norms[row] : 1.0f);
-      const bool live = !alive || alive[row] != 0;
-      keys[(size_t)q * seed_rows + row] = live ? make_key<true>(sc, row) : kKeyInvalid;
-    }
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const uint32_t row = row0 + (uint32_t)rb * 16u + 4u * kk + (uint32_t)r;
+        if (row >= seed_rows) continue;
+        const float sc = finish_score<METRIC>(acc[rb][t][r], qn, METRIC == kCosine ? norms[row] : 1.0f);
+        const bool live = !alive || alive[row] != 0;
+        const uint64_t key = live ? make_key<true>(sc, row) : kKeyInvalid;
+        best = key < best ? key : best;
+      }
+    keys[(size_t)q * ngrp + (row0 / 64u) * 4u + kk] = best;
   }
 }
 void launch_seed_scores_bf16(int metric, const uint16_t* rows16, uint64_t row_stride, const float* norms, const uint8_t* alive,
                              const uint16_t* q16, uint64_t q_stride, const float* qnorms, uint64_t* keys, uint32_t seed_rows,
                              uint32_t nq, uint32_t dim, hipStream_t st) {
-  const dim3 grid((seed_rows + 63) / 64, (nq + 63) / 64);
+  const dim3 grid((seed_rows + 255) / 256, (nq + 63) / 64);
   if (metric == kCosine)
     hipLaunchKernelGGL((seed_scores_bf16<kCosine>), grid, dim3(256), 0, st, rows16, row_stride, norms, alive, q16, q_stride, qnorms, keys, seed_rows, nq, dim);
   else
@@ -303,6 +322,11 @@ __global__ __launch_bounds__(256) void split_seed_approx_kernel(const uint64_t* 
     t = lowered == lowered ? make_key<true>(lowered, 0u) : kKeyInvalid;  // NaN: no bound
   }
   tau0[q] = t;
+  if (seed_rows == kSeedIsSample) {  // the seed rows are swept again: slot 0 holds nothing and excluded nothing
+    for (uint32_t e = 0; e < klist; e++) list[(size_t)q * list_stride * klist + e] = kKeyInvalid;
+    blk_tau[(size_t)q * list_stride] = kKeyInvalid;
+    return;
+  }
   for (uint32_t e = 0; e < klist; e++)
     list[(size_t)q * list_stride * klist + e] = e < c ? make_key<true>(scores[(size_t)q * klist + e], (uint32_t)ids[(size_t)q * klist + e]) : kKeyInvalid;
   // what slot 0 left out: every other seed row has a key >= its klist-th (nothing when the seed region had no more rows)
@@ -714,6 +738,11 @@ __global__ __launch_bounds__(256) void l2_seed_kernel(const uint64_t* ids, const
       t = lowered == lowered ? make_key<true>(lowered, 0u) : kKeyInvalid;
     }
     tau0[q] = t;
+    if (approx_seed_rows == kSeedIsSample) {  // the seed rows are swept again: slot 0 holds nothing and excluded nothing
+      for (uint32_t e = 0; e < klist; e++) list[(size_t)q * list_stride * klist + e] = kKeyInvalid;
+      blk_tau[(size_t)q * list_stride] = kKeyInvalid;
+      return;
+    }
     for (uint32_t e = 0; e < klist; e++)
       list[(size_t)q * list_stride * klist + e] = e < c ? make_key<true>(scores[(size_t)q * klist + e], (uint32_t)ids[(size_t)q * klist + e]) : kKeyInvalid;
     blk_tau[(size_t)q * list_stride] = (c == klist && approx_seed_rows > klist)

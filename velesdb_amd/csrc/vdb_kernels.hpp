@@ -219,7 +219,9 @@ void launch_max_norm(const float* norms, uint32_t n_rows, uint32_t* out_bits, hi
 // ---- exact f32 Cosine / Dot batches through split-bf16 selection + exact re-scoring + proof (sweep_split.hip) ----
 constexpr uint32_t kSplitPool = 32;  // candidates per query that are re-scored exactly (level 1: split selection)
 constexpr uint32_t kSelect16Pool = 64;  // the same for level 2 (plain bf16 selection: a wider error band to cover)
-constexpr uint32_t kSplitSeedRows = 4096;  // rows of the exact seed sweep
+constexpr uint32_t kSplitSeedRows = 4096;  // rows of the seed sweep
+constexpr uint32_t kSeedIsSample = 0xFFFFFFFFu;  // "seed rows" argument of the approximate seed kernels: the seed only supplied bounds,
+                                                 // its rows are swept again by the selection launches (pool slot 0 stays empty)
 struct SplitRerankArgs {
   const float* rows;            // f32 rows of the index
   const float* norms;           // canonical row norms (cosine)
