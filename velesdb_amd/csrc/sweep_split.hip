@@ -223,12 +223,13 @@ void launch_split_seed(int metric, const uint64_t* ids, const float* scores, con
 // with A_k the k-th best APPROXIMATE score over any set of rows and delta the bound of |approximate - exact|, the k rows
 // behind it have exact scores >= A_k - delta, so the exact k-th best over the corpus is >= A_k - delta, and a row of the exact
 // top k has an approximate score >= A_k - 2 delta: tau = A_k - 2 delta (what split_reseed_kernel already uses between
-// launches).  So: seed_scores_bf16 = a plain bf16 GEMM of the first rows x the batch over the selection's own images, every
-// score stored as a key ([nq][seed_rows]; 32 MiB, L2 / MALL resident), merge_topk_select picks the ks best per query,
-// split_seed_approx_kernel turns them into list slot 0 of the pool (approximate keys like every other slot), the bound of
-// what slot 0 left out (its ks-th key: blk_tau, as a selection block reports it) and tau.
+// launches).  So: seed_scores_bf16 = a plain bf16 GEMM of the first rows x the batch over the selection's own images.  The seed is
+// a SAMPLE: any k rows with approximate scores >= A' prove tau = A' - 2 delta, so the kernel keeps the best key of every 16 rows
+// ([nq][seed_rows / 16]: 2 MiB instead of 32), merge_topk_select picks the ks best per query, split_seed_approx_kernel (or
+// l2_seed_kernel in its approximate mode) turns their k-th into tau, and — kSeedIsSample — pool slot 0 stays empty: the selection
+// launches sweep the seed rows again (0.4 % of a 1 M corpus), which is what lets the seed drop rows.
 // One wave = 64 rows x 64 queries; both operands straight from L2 in fragment shape (16 B per lane per fragment: lane (i = l &
-// 15, kk = l >> 4) holds elements 32 s + 8 kk .. + 7 of row / query i), four 32-deep steps in flight.
+// 15, kk = l >> 4) holds elements 32 s + 8 kk .. + 7 of row / query i), two 32-deep steps in flight.
 typedef float f32x4_s __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
 template <int METRIC>
