@@ -427,6 +427,27 @@ def main():
         va.set_max_query_tile(a.tile)
         va.set_split_selector(0 if a.no_split else a.select_level)
 
+    # ---- the same batch sizes through the DEFAULT path (from 16 queries up: the selection stage; same result bits) ----
+    batch_sizes = []
+    if rank == 0 and not a.no_tiles and not a.no_split and a.metric in ("cosine", "dot"):
+        for nq_t in (16, 32, 64, 128, 256, 384, 512):
+            if nq_t > n_query_pool:
+                continue
+            t_ids = torch.empty((nq_t, K), dtype=torch.int64, device=dev)
+            t_sc = torch.empty((nq_t, K), dtype=torch.float32, device=dev)
+            t_n = torch.empty((nq_t,), dtype=torch.int32, device=dev)
+            for _ in range(2):
+                ix.search_batch_dev(queries.data_ptr(), nq_t, K, 0, va.MODE_BRUTE, t_ids.data_ptr(), t_sc.data_ptr(), t_n.data_ptr(), stream)
+            torch.cuda.synchronize()
+            reps = 10
+            tt = time.perf_counter()
+            for _ in range(reps):
+                ix.search_batch_dev(queries.data_ptr(), nq_t, K, 0, va.MODE_BRUTE, t_ids.data_ptr(), t_sc.data_ptr(), t_n.data_ptr(), stream)
+            torch.cuda.synchronize()
+            t_dt = (time.perf_counter() - tt) / reps
+            batch_sizes.append({"queries": nq_t, "ms_per_call": round(t_dt * 1e3, 4), "qps": round(nq_t / t_dt, 1),
+                                "select_level": int(ix.last_select_level())})
+
     # ---- single-query latency mode (one corpus pass per query) ----
     lat = {}
     if rank == 0:
@@ -1254,7 +1275,7 @@ def main():
                        "parallelism": "replicas x%d (query stream split, no collective)" % world},
             "recall_at_10": recall, "parity_check": check,
             "frac_step": (roofline.get("whole_batch") or {}).get("frac"),  # the headline's algorithmic flop over the WHOLE step's time / peak
-            "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "tiles": tiles, "sharded": sharded,
+            "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "tiles": tiles, "batch_sizes_default_path": batch_sizes, "sharded": sharded,
             "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb, "config0_10k": config0, "bf16_gemm": bf16_leg, "sq8_storage_mode": sq8_leg, "other_metrics": metrics_leg,
             "device": va.device_name(local), "device_state": device_state,
         }
