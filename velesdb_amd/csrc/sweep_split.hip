@@ -830,26 +830,42 @@ __global__ __launch_bounds__(256) void l2_rerank_verify(SplitRerankArgs a) {
       keys[c] = make_key<false>(sum, row);
     }
   } else
-  for (uint32_t c = wib; c < n; c += 4) {
-    const uint32_t row = (uint32_t)a.cand_rows[(size_t)qi * a.k2 + c];
-    const float* p = a.rows + (size_t)row * a.row_stride;
-    float acc = 0.0f;
+  // (a wave's candidates wib, wib + 4, ...: FOUR at a time — their rows' chunks are requested together; one after the other the
+  // sixteen of a wave were sixteen dependent round trips, 57 us per 1 024-query batch)
+  for (uint32_t c0 = wib; c0 < n; c0 += 16) {
+    const float* p[4];
+    uint32_t rowv[4];
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t c = min(c0 + 4u * (uint32_t)u, n - 1u);  // (a clamped duplicate: computed, not stored)
+      rowv[u] = (uint32_t)a.cand_rows[(size_t)qi * a.k2 + c];
+      p[u] = a.rows + (size_t)rowv[u] * a.row_stride;
+    }
     for (int ch = lane; ch < d4; ch += 64) {
       const int nv = (int)a.dim - ch * 4;
-      const float4 x = ld4(p + ch * 4);
+      float4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) x[u] = ld4(p[u] + ch * 4);
       float4 qq;
       if (nv >= 4) {
         qq = make_float4(q[ch * 4], q[ch * 4 + 1], q[ch * 4 + 2], q[ch * 4 + 3]);
-        acc = chain4<kOpL2>(acc, qq, x);
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] = chain4<kOpL2>(acc[u], qq, x[u]);
       } else {
         qq = make_float4(q[ch * 4], nv > 1 ? q[ch * 4 + 1] : 0.f, nv > 2 ? q[ch * 4 + 2] : 0.f, 0.f);
-        acc = chain4_tail<kOpL2>(acc, qq, x, nv);
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] = chain4_tail<kOpL2>(acc[u], qq, x[u], nv);
       }
     }
-    const float sum = butterfly_all(acc);
-    if (lane == 0) {
-      sums[c] = sum;
-      keys[c] = make_key<false>(finish_score<kEuclidean>(sum, 0.f, 0.f), row);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t c = c0 + 4u * (uint32_t)u;
+      const float sum = butterfly_all(acc[u]);
+      if (lane == 0 && c < n) {
+        sums[c] = sum;
+        keys[c] = make_key<false>(finish_score<kEuclidean>(sum, 0.f, 0.f), rowv[u]);
+      }
     }
   }
   __syncthreads();
