@@ -104,6 +104,37 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # ---- the reference's calling pattern (concurrent `search` from many threads, one query per call): T native host
+    # threads over the C ABI's HOST-pointer entry point vdb_hip_index_search (tools/callers_bench.cpp; Python threads would
+    # measure the interpreter lock).  Every answer is compared bit for bit with a batched reference call.
+    _cb = {}
+
+    def callers_leg(index, q_np, k_, ef_, mode_, ref, threads_list=(1, 4, 16, 64), seconds=1.2):
+        import ctypes as C
+        if "lib" not in _cb:
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "libcallers_bench.so")
+            if not os.path.exists(path):
+                return {"skipped": f"{path} missing (built by __graft_entry__.build())"}
+            L = C.CDLL(path)
+            L.callers_run.restype = C.c_int
+            L.callers_run.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_int,
+                                      C.c_double, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+            _cb["lib"] = L
+        rid, rsc, rn = [np.ascontiguousarray(x) for x in ref]
+        pts = []
+        for T in threads_list:
+            out = np.zeros(8, dtype=np.float64)
+            s0 = index.combine_stats()
+            rc = _cb["lib"].callers_run(index._h, q_np.ctypes.data, q_np.shape[0], q_np.shape[1], k_, ef_, mode_, T, seconds, 20, 1,
+                                        rid.ctypes.data, rsc.ctypes.data, rn.ctypes.data, out.ctypes.data)
+            s1 = index.combine_stats()
+            assert rc == 0
+            launches, calls = s1[0] - s0[0], s1[1] - s0[1]
+            pts.append({"threads": T, "qps": round(out[0], 1), "p50_us": round(out[1], 1), "p99_us": round(out[2], 1),
+                        "calls": int(out[4]), "calls_per_launch": round(calls / max(launches, 1), 2),
+                        "bitwise_mismatches_vs_batched_call": int(out[5]), "failed_calls": int(out[6])})
+        return pts
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available() and va.device_count() > 0, "bench.py needs a GPU"
@@ -448,6 +479,29 @@ def main():
             batch_sizes.append({"queries": nq_t, "ms_per_call": round(t_dt * 1e3, 4), "qps": round(nq_t / t_dt, 1),
                                 "select_level": int(ix.last_select_level())})
 
+    # ---- the HOST-pointer entry points on the headline workload (PCIe-inclusive; never `value`): what the shim's
+    # VectorIndex::search / search_batch_parallel bind (velesdb-hip/src/lib.rs) — queries from host memory, results back to host
+    # memory — and the reference's calling pattern, many threads x one query per call, through the combining front
+    host_entry = None
+    if rank == 0 and world == 1:
+        hq_np = queries[:min(n_query_pool, 4096)].cpu().numpy()
+        he = []
+        for nq_h in (Q, 256, 64, 16, 1):
+            if nq_h > hq_np.shape[0]:
+                continue
+            for _ in range(2):
+                ix._search_raw(hq_np[:nq_h], K, 0, va.MODE_BRUTE)
+            reps = 10
+            th_ = time.perf_counter()
+            for r_ in range(reps):
+                ix._search_raw(hq_np[(r_ * nq_h) % (hq_np.shape[0] - nq_h + 1):][:nq_h], K, 0, va.MODE_BRUTE)
+            hd_ = (time.perf_counter() - th_) / reps
+            he.append({"queries_per_call": nq_h, "ms_per_call": round(hd_ * 1e3, 4), "qps": round(nq_h / hd_, 1),
+                       "h2d_bytes": nq_h * D * 4, "d2h_bytes": nq_h * (K * 12 + 4)})
+        b_ref = ix._search_raw(hq_np, K, 0, va.MODE_BRUTE)
+        host_entry = {"entry_point": "vdb_hip_index_search_batch (host pointers), exact sweep over the headline corpus", "calls": he,
+                      "concurrent_callers": callers_leg(ix, hq_np, K, 0, va.MODE_BRUTE, b_ref)}
+
     # ---- single-query latency mode (one corpus pass per query) ----
     lat = {}
     if rank == 0:
@@ -572,6 +626,27 @@ def main():
                 lat_h.append({"queries_per_call": nq_l, "median_us_per_call": round(med * 1e6, 1),
                               "qps": round(nq_l / med, 1)})
             hnsw["latency_mode"] = lat_h
+            # many host threads, one query per vdb_hip_index_search call (host pointers): the combining front (search_front.hip)
+            cq_np = queries[:4096].cpu().numpy()
+            c_ref = ix._search_raw(cq_np, K, a.ef, va.MODE_HNSW)   # ONE batched call (launches alone)
+            hnsw["concurrent_callers"] = {
+                "entry_point": "vdb_hip_index_search (host pointers, one query per call, ef %d) from T native threads" % a.ef,
+                "points": callers_leg(ix, cq_np, K, a.ef, va.MODE_HNSW, c_ref),
+                "front": {"max_batch": ix.get_option(va.OPT_COMBINE_MAX_BATCH), "inflight": ix.get_option(va.OPT_COMBINE_INFLIGHT),
+                          "window_us": ix.get_option(va.OPT_COMBINE_WINDOW_US)}}
+            ix.set_option(va.OPT_COMBINE_MAX_BATCH, 0)
+            hnsw["concurrent_callers"]["without_the_front"] = callers_leg(ix, cq_np, K, a.ef, va.MODE_HNSW, c_ref, threads_list=(1, 16), seconds=0.8)
+            ix.set_option(va.OPT_COMBINE_MAX_BATCH, -1)
+            # the batch entry point from HOST memory (PCIe-inclusive; what the shim's search_batch_parallel binds)
+            he = []
+            for nq_h in (1024, 64):
+                ix._search_raw(cq_np[:nq_h], K, a.ef, va.MODE_HNSW)
+                th_ = time.perf_counter()
+                for r_ in range(10):
+                    ix._search_raw(cq_np[(r_ * nq_h) % (4096 - nq_h + 1):][:nq_h], K, a.ef, va.MODE_HNSW)
+                hd_ = (time.perf_counter() - th_) / 10
+                he.append({"queries_per_call": nq_h, "ms_per_call": round(hd_ * 1e3, 3), "qps": round(nq_h / hd_, 1)})
+            hnsw["host_entry"] = he
             hstep()
             torch.cuda.synchronize()
         # dual-precision leg: int8 graph walk (integer L2^2 between u8 codes) + exact f32 re-rank of
@@ -746,6 +821,16 @@ def main():
                                         "scores_bit_equal_oracle_canonical":
                                             bool(np.array_equal(gsim.view(np.uint32), exp_sim.view(np.uint32)))}
                 hnsw["gpu_over_cpu"] = round(hnsw["qps"] / (cq / hdt_cpu), 2)
+                if "concurrent_callers" in hnsw and isinstance(hnsw["concurrent_callers"].get("points"), list):
+                    # the oracle's search on the same number of host threads over the same graph (capped by the box's cores)
+                    for pt in hnsw["concurrent_callers"]["points"]:
+                        tc = min(pt["threads"], ncores)
+                        nqc_ = min(cq, 512 * tc)
+                        tcp = time.perf_counter()
+                        og.search_batch(qh[:nqc_], K, a.ef, po.TIE_REFERENCE, nthreads=tc)
+                        pt["cpu_threads"] = tc
+                        pt["cpu_qps"] = round(nqc_ / (time.perf_counter() - tcp), 1)
+                        pt["gpu_over_cpu"] = round(pt["qps"] / max(pt["cpu_qps"], 1e-9), 2)
                 del og, og_c
         if graph_dir is not None:
             shutil.rmtree(graph_dir, ignore_errors=True)
@@ -954,6 +1039,29 @@ def main():
                    "reference_published": {"search_us": 56.8, "qps": 9200, "host": "i9-14900KF, criterion (bench_hnsw_results.txt:86-87,114-116)"},
                    "note": "a single query cannot fill a GPU: the graph path pays kernel launch + synchronisation + a serial "
                            "walk per call; the GPU path overtakes one CPU thread from a few queries per call (one_call_100_queries_qps)"}
+        qs0b = np.stack([generate_vector(768, 100_000 + j) for j in range(512)])
+        ref0 = ix0._search_raw(qs0b, 10, 128, va.MODE_AUTO)
+        config0["concurrent_callers"] = {"entry_point": "vdb_hip_index_search (host pointers, one query per call, Balanced) from T native threads",
+                                         "points": callers_leg(ix0, qs0b, 10, 128, va.MODE_AUTO, ref0, seconds=0.8)}
+        if not a.no_cpu_baseline:
+            from oracle import pyoracle as po0
+            gd0 = tempfile.mkdtemp(prefix="vdb_bench0_")
+            try:
+                ix0.save(gd0, "native_hnsw")
+                og0 = po0.NativeHnsw.file_load(gd0, "native_hnsw", po0.COSINE, po0.MODE_R)
+                nc0 = po0.host_threads()
+                og0.search_batch(qs0b[:nc0], 10, 128, po0.TIE_REFERENCE, nthreads=nc0)
+                for pt in config0["concurrent_callers"]["points"]:
+                    tc = min(pt["threads"], nc0)
+                    tcp = time.perf_counter()
+                    for _ in range(4):
+                        og0.search_batch(qs0b, 10, 128, po0.TIE_REFERENCE, nthreads=tc)
+                    pt["cpu_threads"] = tc
+                    pt["cpu_qps"] = round(4 * 512 / (time.perf_counter() - tcp), 1)
+                    pt["gpu_over_cpu"] = round(pt["qps"] / max(pt["cpu_qps"], 1e-9), 2)
+                del og0
+            finally:
+                shutil.rmtree(gd0, ignore_errors=True)
         ix0.close()
 
     # ---- bf16 GEMM distance (BASELINE configs[3], N = 1 only): 10 M x 768 bf16 rows, 1 024 queries per batch contracted
@@ -1275,7 +1383,7 @@ def main():
                        "parallelism": "replicas x%d (query stream split, no collective)" % world},
             "recall_at_10": recall, "parity_check": check,
             "frac_step": (roofline.get("whole_batch") or {}).get("frac"),  # the headline's algorithmic flop over the WHOLE step's time / peak
-            "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "tiles": tiles, "batch_sizes_default_path": batch_sizes, "sharded": sharded,
+            "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "tiles": tiles, "batch_sizes_default_path": batch_sizes, "host_entry": host_entry, "sharded": sharded,
             "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb, "config0_10k": config0, "bf16_gemm": bf16_leg, "sq8_storage_mode": sq8_leg, "other_metrics": metrics_leg,
             "device": va.device_name(local), "device_state": device_state,
         }

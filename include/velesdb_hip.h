@@ -277,10 +277,31 @@ enum vdb_option {
   VDB_OPT_SWEEP_ENGINE = 1,     /* vdb_hip_set_sweep_engine      */
   VDB_OPT_SELECTOR_LEVEL = 2,   /* vdb_hip_set_split_selector    */
   VDB_OPT_INT8_OVERSAMPLING = 3,/* vdb_hip_set_int8_oversampling */
-  VDB_OPT_KERNEL_TIMING = 4     /* vdb_hip_set_kernel_timing     */
+  VDB_OPT_KERNEL_TIMING = 4,    /* vdb_hip_set_kernel_timing     */
+  /* The combining front of the host-pointer search entry points (vdb_hip_index_search / _search_batch / _search_rerank).  The
+   * reference serves many threads that each search ONE query under a read lock (index/hnsw/index/search.rs:80; the server calls
+   * collection.search once per request); a GPU serves that pattern at its own rate only when callers that arrive together share
+   * a launch.  Calls of <= 64 queries queue up; one of the waiting callers becomes the leader, gathers the queued calls with the
+   * same (k, ef, mode, rerank_k) into one batch of <= COMBINE_MAX_BATCH queries (default 256; 0 = every call launches alone),
+   * runs it and hands every caller its slice.  At most COMBINE_INFLIGHT batches run at a time (default 0 = by kind of search:
+   * two for graph walks — latency-bound, one CU per query, two launches overlap for free — and one for sweeps: an HBM-bound
+   * pass gains nothing from a second launch beside it, and callers that split into groups wait for each other).  Batches
+   * form from the calls that arrive while the launch in front of them runs; a leader that has evidence of company (the batch
+   * that finished last carried several calls) waits until as many calls have arrived as that batch had callers, at most
+   * COMBINE_WINDOW_US microseconds (default 100; 0 = never wait).  A lone caller is never delayed.
+   * Results are per-query independent: bits do not depend on the batch a call lands in. */
+  VDB_OPT_COMBINE_MAX_BATCH = 5,
+  VDB_OPT_COMBINE_WINDOW_US = 6,
+  VDB_OPT_COMBINE_INFLIGHT = 7,
+  VDB_OPT_COUNT_ = 8
 };
 int32_t vdb_hip_index_set_option(vdb_hip_index* idx, int32_t option, int64_t value);
 int32_t vdb_hip_index_get_option(vdb_hip_index* idx, int32_t option, int64_t* value); /* the effective value */
+
+/* counters of the combining front since the handle was created: launches it issued, calls and queries they carried, the largest
+ * batch (queries) — calls / launches is the average number of callers that shared a launch */
+int32_t vdb_hip_index_combine_stats(vdb_hip_index* idx, uint64_t* launches, uint64_t* calls, uint64_t* queries,
+                                    uint64_t* max_batch);
 
 /* ---- introspection used by tests and the bench ---- */
 /* neighbours of `node` on `layer`; returns count in *n, writes up to cap ids */

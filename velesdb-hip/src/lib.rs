@@ -616,6 +616,16 @@ impl HipHnswIndex {
         v
     }
 
+    /// Counters of the combining front of `search` / `search_batch_parallel` (many threads that each search one query share
+    /// launches): `(launches, calls, queries, largest batch)` since the handle was created.
+    #[must_use]
+    pub fn combine_stats(&self) -> (u64, u64, u64, u64) {
+        let (mut a, mut b, mut c, mut d) = (0u64, 0u64, 0u64, 0u64);
+        // SAFETY: live handle, valid out pointers.
+        check(unsafe { sys::vdb_hip_index_combine_stats(self.h, &mut a, &mut b, &mut c, &mut d) });
+        (a, b, c, d)
+    }
+
     /// The raw handle, for the entry points this wrapper does not cover (`sys::*`).
     #[must_use]
     pub fn as_raw(&self) -> *mut sys::VdbHipIndex {

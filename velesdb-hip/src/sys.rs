@@ -60,6 +60,11 @@ pub const VDB_OPT_SWEEP_ENGINE: i32 = 1;
 pub const VDB_OPT_SELECTOR_LEVEL: i32 = 2;
 pub const VDB_OPT_INT8_OVERSAMPLING: i32 = 3;
 pub const VDB_OPT_KERNEL_TIMING: i32 = 4;
+pub const VDB_OPT_COMBINE_MAX_BATCH: i32 = 5;
+pub const VDB_OPT_COMBINE_WINDOW_US: i32 = 6;
+pub const VDB_OPT_COMBINE_INFLIGHT: i32 = 7;
+#[allow(non_upper_case_globals)]
+pub const VDB_OPT_COUNT_: i32 = 8;
 
 // enum vdb_kernel_bit (vdb_hip_index_last_kernels)
 pub const VDB_KERNEL_SWEEP_VALU: i32 = 1;
@@ -131,6 +136,7 @@ extern "C" {
     pub fn vdb_hip_index_last_split_stats(idx: *mut VdbHipIndex, queries: *mut u32, unproven: *mut u32) -> i32;
     pub fn vdb_hip_index_last_select_level(idx: *mut VdbHipIndex, level: *mut i32) -> i32;
     pub fn vdb_hip_index_last_kernels(idx: *mut VdbHipIndex, mask: *mut u32) -> i32;
+    pub fn vdb_hip_index_combine_stats(idx: *mut VdbHipIndex, launches: *mut u64, calls: *mut u64, queries: *mut u64, max_batch: *mut u64) -> i32;
     pub fn vdb_hip_index_sweep_arith_mode(idx: *mut VdbHipIndex, k: u32, mode: *mut i32) -> i32;
     pub fn vdb_hip_index_last_kernel_ms(idx: *mut VdbHipIndex, ms: *mut f32, launches: *mut u32) -> i32;
     pub fn vdb_hip_index_last_selection_ms(idx: *mut VdbHipIndex, total_ms: *mut f32, launches: *mut u32) -> i32;

@@ -43,7 +43,7 @@ int32_t vdb_hip_index_graph_info(vdb_hip_index* ix, uint32_t* num_layers, uint32
     if (group_mode(ix) != VDB_SHARD_REPLICA) return fail(VDB_ERR_UNSUPPORTED, "graph_info: one graph per shard on a range-sharded handle");
     return vdb_hip_index_graph_info(group_shard(ix, 0), num_layers, max_layer, entry_point);
   }
-  std::lock_guard<vdb::IndexMutex> g(ix->mu);
+  std::shared_lock<vdb::IndexMutex> g(ix->mu);
   if (num_layers) *num_layers = (uint32_t)ix->layers.size();
   if (max_layer) *max_layer = ix->max_layer;
   if (entry_point) *entry_point = ix->graph_valid ? ix->entry_point : -1;
@@ -62,7 +62,7 @@ int32_t vdb_hip_index_get_neighbors(vdb_hip_index* ix, uint32_t layer, uint64_t 
   std::lock_guard<vdb::IndexMutex> g(ix->mu);
   *n = 0;
   if (layer >= ix->layers.size() || node >= ix->n_rows) return VDB_OK;  // layer.rs:33-39: empty
-  VDB_ENTER(ix);
+  VDB_ENTER_READONLY(ix);
   GraphLayer& L = ix->layers[layer];
   uint32_t c = 0;
   VDB_HIP(hipMemcpyAsync(&c, L.cnt.as<uint32_t>() + node, 4, hipMemcpyDeviceToHost, ix->stream));
@@ -221,7 +221,7 @@ int32_t vdb_hip_index_save_reference_files(vdb_hip_index* ix, const char* dir, c
   VDB_NO_GROUP(ix, "save_reference_files");
   std::lock_guard<vdb::IndexMutex> g(ix->mu);
   if (!ix->graph_valid) return fail(VDB_ERR_STATE, "graph not built for all rows");
-  VDB_ENTER(ix);
+  VDB_ENTER_READONLY(ix);
   const uint64_t count = ix->n_rows;
   std::vector<float> vecs((size_t)count * ix->dim);
   if (count) {

@@ -582,10 +582,15 @@ hipError_t launch_hnsw_search(const HnswSearchArgs& a0, int slots, hipStream_t s
   }
 }
 
-// one visited bitmap (capacity bits) + one id log per resident block, zero between launches
-int32_t ensure_traversal_scratch(vdb_hip_index* ix, hipStream_t st) {
+// one visited bitmap (capacity bits) + one id log per resident block, zero between launches.  want_slots = the blocks the
+// coming launch runs (0: as many as the chip holds of any walk kernel): a search context that only ever serves small calls — the
+// combining front's batches, search_front.hip — keeps 125 KB + 64 KB per query in flight at 1 M rows instead of 0.4 GB
+int32_t ensure_traversal_scratch(vdb_hip_index* ix, hipStream_t st, int want_slots) {
   const uint64_t vis_words = (ix->capacity + 31) / 32;
-  const int max_slots = ix->n_cus * kTraversalSlotsPerCu;
+  const int chip_slots = ix->n_cus * kTraversalSlotsPerCu;
+  int max_slots = want_slots > 0 ? std::min(want_slots, chip_slots) : chip_slots;
+  if (max_slots < chip_slots) max_slots = std::min(chip_slots, (max_slots + 63) / 64 * 64);
+  if (ix->vis_words == vis_words) max_slots = std::max<int>(max_slots, (int)std::min<size_t>((size_t)chip_slots, ix->s_visited.cap / std::max<uint64_t>(vis_words * 4, 1)));  // (never shrinks)
   if (ix->vis_words != vis_words || ix->s_visited.cap < (size_t)max_slots * vis_words * 4) {
     hipError_t e = ix->s_visited.reserve((size_t)max_slots * vis_words * 4, false, st);
     if (e == hipSuccess) e = ix->s_vlog.reserve((size_t)max_slots * kVlogCap * 4, false, st);
@@ -632,7 +637,7 @@ int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   // slots: resident blocks; 4 per CU unless LDS limits it
   int per_cu = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / lds));
   int slots = (int)std::min<int64_t>((int64_t)nq, (int64_t)ix->n_cus * per_cu);
-  int32_t rcs = ensure_traversal_scratch(ix, st);
+  int32_t rcs = ensure_traversal_scratch(ix, st, slots);
   if (rcs != VDB_OK) return rcs;
   const uint64_t vis_words = ix->vis_words;
   const uint32_t vlog_cap = kVlogCap;

@@ -34,6 +34,21 @@ static inline int opt_engine(const vdb_hip_index* ix) { return ix->opt[VDB_OPT_S
 static inline int opt_selector(const vdb_hip_index* ix) { return ix->opt[VDB_OPT_SELECTOR_LEVEL] >= 0 ? ix->opt[VDB_OPT_SELECTOR_LEVEL] : g_split_selector.load(); }
 static inline uint32_t opt_oversampling(const vdb_hip_index* ix) { return ix->opt[VDB_OPT_INT8_OVERSAMPLING] >= 0 ? (uint32_t)ix->opt[VDB_OPT_INT8_OVERSAMPLING] : (uint32_t)g_int8_oversampling.load(); }
 static inline bool opt_timing(const vdb_hip_index* ix) { return (ix->opt[VDB_OPT_KERNEL_TIMING] >= 0 ? ix->opt[VDB_OPT_KERNEL_TIMING] : g_timing.load()) != 0; }
+// the combining front's defaults (include/velesdb_hip.h): 256 queries per combined launch, returning callers are awaited for <= 100 us, batches in flight by kind (0: walks 2, sweeps 1)
+static constexpr int32_t kOptDefaultCombineMaxBatch = 256, kOptDefaultCombineWindowUs = 100, kOptDefaultCombineInflight = 0;
+int64_t opt_value(const vdb_hip_index* ix, int32_t option) {
+  switch (option) {
+    case VDB_OPT_MAX_QUERY_TILE: return opt_max_tile(ix);
+    case VDB_OPT_SWEEP_ENGINE: return opt_engine(ix);
+    case VDB_OPT_SELECTOR_LEVEL: return opt_selector(ix);
+    case VDB_OPT_INT8_OVERSAMPLING: return opt_oversampling(ix);
+    case VDB_OPT_KERNEL_TIMING: return opt_timing(ix) ? 1 : 0;
+    case VDB_OPT_COMBINE_MAX_BATCH: return ix->opt[option] >= 0 ? ix->opt[option] : kOptDefaultCombineMaxBatch;
+    case VDB_OPT_COMBINE_WINDOW_US: return ix->opt[option] >= 0 ? ix->opt[option] : kOptDefaultCombineWindowUs;
+    case VDB_OPT_COMBINE_INFLIGHT: return ix->opt[option] >= 0 ? ix->opt[option] : kOptDefaultCombineInflight;
+    default: return -1;
+  }
+}
 
 
 void set_last_error(const std::string& s) { g_last_error = s; }
@@ -67,6 +82,23 @@ void DevBuf::release() {
   p = nullptr;
   cap = 0;
 }
+hipError_t HostStage::reserve(size_t bytes) {
+  if (bytes <= cap) return hipSuccess;
+  size_t ncap = std::max<size_t>(std::max(bytes, cap + cap / 2), 4096);
+  ncap = (ncap + 4095) & ~(size_t)4095;
+  void* np = nullptr;
+  hipError_t e = hipHostMalloc(&np, ncap, hipHostMallocDefault);
+  if (e != hipSuccess) return e;
+  if (p) (void)hipHostFree(p);  // (contents are per call: nothing to keep)
+  p = np;
+  cap = ncap;
+  return hipSuccess;
+}
+void HostStage::release() {
+  if (p) (void)hipHostFree(p);
+  p = nullptr;
+  cap = 0;
+}
 
 // VELESDB_BF16_GLDS=0: big bf16 batches stay on the register-staged kernel of sweep_gemm.hip (A/B probes)
 static bool gemm_bf16_glds_enabled() {
@@ -94,13 +126,13 @@ static int32_t check_device(int32_t* n_out) {
   return VDB_OK;
 }
 
-int32_t enter_index(vdb_hip_index* ix, bool exclusive) {
+int32_t enter_index(vdb_hip_index* ix, bool exclusive, bool changes) {
   VDB_HIP(hipSetDevice(ix->device));
   if (ix->foreign_pending) {
     VDB_HIP(hipStreamWaitEvent(ix->stream, ix->ev_foreign, 0));
     ix->foreign_pending = false;
   }
-  if (exclusive) mark_changed(ix);  // (every exclusive entry point may change what searches read: contexts re-sync their views)
+  if (exclusive && changes) mark_changed(ix);  // (what searches read may change: contexts re-sync their views before their next search)
   // (exclusive callers only touch a primary: its search contexts may have device-resident searches in flight on callers' streams
   // or on their own; whatever changes the index waits for them — contexts are idle on the host side while mu is held exclusively)
   if (exclusive && !ix->primary)
@@ -162,7 +194,7 @@ static void copy_data_fields(vdb_hip_index* c, const vdb_hip_index* p) {
   c->codes_sq = p->codes_sq;
   c->code_words = p->code_words;
   c->quantizer_trained = p->quantizer_trained;
-  for (int i = 0; i < 5; i++) c->opt[i] = p->opt[i];
+  for (int i = 0; i < VDB_OPT_COUNT_; i++) c->opt[i] = p->opt[i];
   c->storage_mode = p->storage_mode;
   c->sq8_stride = p->sq8_stride;
   c->sq8_codes = p->sq8_codes;
@@ -181,10 +213,26 @@ static void copy_data_fields(vdb_hip_index* c, const vdb_hip_index* p) {
   copy_image_fields(c, p);
 }
 static thread_local vdb_hip_index* tl_ctx = nullptr;        // the context of this thread's last search ...
-static thread_local vdb_hip_index* tl_ctx_owner = nullptr;  // ... and the handle it belongs to
-vdb_hip_index* last_context(vdb_hip_index* ix) { return tl_ctx_owner == ix && tl_ctx ? tl_ctx : ix; }
+static thread_local vdb_hip_index* tl_ctx_owner = nullptr;  // ... the handle it belongs to ...
+static thread_local uint64_t tl_ctx_gen = 0;                // ... and that handle's generation: a new handle at a recycled address never matches
+static std::atomic<uint64_t> g_generation{0};
+// (shared lock on ix->mu held by the caller: clones are only destroyed with the handle)
+vdb_hip_index* last_context(vdb_hip_index* ix) {
+  if (tl_ctx_owner != ix || tl_ctx_gen != ix->generation || !tl_ctx || tl_ctx == ix) return ix;
+  std::lock_guard<std::mutex> pl(ix->pool_mu);
+  for (vdb_hip_index* c : ix->ctx_clones)
+    if (c == tl_ctx) return c;
+  return ix;
+}
+void note_last_context(vdb_hip_index* handle, vdb_hip_index* ctx) {
+  tl_ctx = ctx;
+  tl_ctx_owner = handle;
+  tl_ctx_gen = handle->generation;
+}
 
-constexpr size_t kMaxSearchContexts = 4;  // the primary + up to three clones (each owns its scratch: ~0.3 GB at 1 M rows once it walked a graph)
+// the primary + up to seven clones.  A context owns scratch and a stream; its graph-walk scratch is sized by the calls it has
+// served (ensure_traversal_scratch: one visited bitmap + id log per query in flight), so contexts that serve small calls stay small
+constexpr size_t kMaxSearchContexts = 8;
 CtxLease::CtxLease(vdb_hip_index* ix) {
   if (ix->ctx_mu.try_lock()) {
     ctx = ix;
@@ -228,8 +276,7 @@ CtxLease::CtxLease(vdb_hip_index* ix) {
     copy_data_fields(ctx, ix);
     ctx->synced_version = ix->version;
   }
-  tl_ctx = ctx;
-  tl_ctx_owner = ix;
+  note_last_context(ix, ctx);
 }
 CtxLease::~CtxLease() {
   if (ctx) ctx->ctx_mu.unlock();
@@ -620,19 +667,23 @@ static int32_t pinned_select_stats(vdb_hip_index* ix) {  // per context: the ada
 static int32_t ensure_split_impl(vdb_hip_index* ix, hipStream_t st);
 static int32_t ensure_sel16_impl(vdb_hip_index* ix, hipStream_t st);
 static int32_t ensure_l2_select_impl(vdb_hip_index* ix, hipStream_t st);
-template <class F>
-static int32_t build_image_on_primary(vdb_hip_index* ix, hipStream_t st, bool stale, F&& impl) {
+// `stale(p)` is evaluated under img_mu.  A build is enqueued on the building search's stream `st` — a caller's stream for the
+// device-resident entry point — and another context may take over the image (its fields say "complete") the moment img_mu is
+// released: whatever was built is therefore COMPLETE on the device before the lock is dropped.  (First use, and the first
+// search behind inserts for the images that are extended lazily: a synchronisation there is noise next to the build.)
+template <class S, class F>
+static int32_t build_image_on_primary(vdb_hip_index* ix, hipStream_t st, S&& stale, F&& impl) {
   vdb_hip_index* p = primary_of(ix);
   std::lock_guard<std::mutex> il(p->img_mu);
+  const bool was_stale = stale(p);
   const int32_t rc = impl(p, st);
   if (rc != VDB_OK) return rc;
-  if (stale && !p->ctx_clones.empty()) VDB_HIP(hipStreamSynchronize(st));
+  if (was_stale) VDB_HIP(hipStreamSynchronize(st));
   if (ix != p) copy_image_fields(ix, p);
   return VDB_OK;
 }
 static int32_t ensure_split(vdb_hip_index* ix, hipStream_t st) {
-  vdb_hip_index* p = primary_of(ix);
-  return build_image_on_primary(ix, st, !p->split_enabled || p->split_rows < p->n_rows, ensure_split_impl);
+  return build_image_on_primary(ix, st, [](const vdb_hip_index* p) { return !p->split_enabled || p->split_rows < p->n_rows; }, ensure_split_impl);
 }
 static int32_t ensure_split_impl(vdb_hip_index* ix, hipStream_t st) {
   if (!ix->split_enabled) {
@@ -654,8 +705,8 @@ static int32_t ensure_split_impl(vdb_hip_index* ix, hipStream_t st) {
 
 // level 2: the bf16 copy of the rows (what vdb_hip_index_enable_bf16 keeps) + canonical f32 norms for every metric
 static int32_t ensure_sel16(vdb_hip_index* ix, hipStream_t st) {
-  vdb_hip_index* p = primary_of(ix);
-  const int32_t rc = build_image_on_primary(ix, st, !p->bf16_enabled || p->bf16_rows < p->n_rows || !p->sel_norms, ensure_sel16_impl);
+  const int32_t rc = build_image_on_primary(ix, st, [](const vdb_hip_index* p) { return !p->bf16_enabled || p->bf16_rows < p->n_rows || !p->sel_norms; },
+                                            ensure_sel16_impl);
   return rc != VDB_OK ? rc : pinned_select_stats(ix);
 }
 // the residual-ratio scalar of a bf16 copy that is about to be (re)built from row 0
@@ -741,8 +792,7 @@ static int select_level(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
 
 // Euclidean batches: augmented bf16 image + augmented f32 seed prefix (sweep_split.hip), built at first use, extended lazily
 static int32_t ensure_l2_select(vdb_hip_index* ix, hipStream_t st) {
-  vdb_hip_index* p = primary_of(ix);
-  const int32_t rc = build_image_on_primary(ix, st, p->l2_img.cap == 0 || p->l2_rows < p->n_rows, ensure_l2_select_impl);
+  const int32_t rc = build_image_on_primary(ix, st, [](const vdb_hip_index* p) { return p->l2_img.cap == 0 || p->l2_rows < p->n_rows; }, ensure_l2_select_impl);
   return rc != VDB_OK ? rc : pinned_select_stats(ix);
 }
 static int32_t ensure_l2_select_impl(vdb_hip_index* ix, hipStream_t st) {
@@ -1572,6 +1622,8 @@ int32_t create_single(uint32_t dim, int32_t metric, uint32_t M, uint32_t ef_cons
   VDB_HIP(hipSetDevice(device));
   std::unique_ptr<vdb_hip_index, void (*)(vdb_hip_index*)> ix(new vdb_hip_index(), destroy_single);
   ix->device = device;
+  ix->generation = ++g_generation;
+  ix->combiner = combiner_new();
   hipDeviceProp_t p;
   VDB_HIP(hipGetDeviceProperties(&p, device));
   ix->n_cus = p.multiProcessorCount;
@@ -1604,7 +1656,7 @@ std::vector<DevBuf*> index_buffers(vdb_hip_index* ix) {
       &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq,                // int8 traversal
       &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits,  // storage modes
       &ix->sq8_img, &ix->sq8_nrm, &ix->sq8_seed, &ix->sq8_rho,              // SQ8 selection images
-      &ix->s_queries, &ix->s_part_keys, &ix->s_part_cnt, &ix->s_out_ids, &ix->s_out_scores, &ix->s_out_n, &ix->s_qbits,
+      &ix->s_queries, &ix->s_part_keys, &ix->s_part_cnt, &ix->s_out, &ix->s_qbits,
       &ix->s_misc, &ix->s_fb_keys, &ix->s_seed, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels, &ix->s_req_keys,
       &ix->s_req_vals, &ix->s_sort_tmp};
   for (auto& L : ix->layers) {
@@ -1623,6 +1675,9 @@ void destroy_single(vdb_hip_index* ix) {
   ix->ctx_clones.clear();
   proc_comm_free(ix->pcomm);
   for (DevBuf* b : index_buffers(ix)) b->release();
+  ix->h_in.release();
+  ix->h_out.release();
+  combiner_free(ix->combiner);
   for (auto* pool : {&ix->ev_pool, &ix->sel_ev})
     for (auto& e : *pool) {
       (void)hipEventDestroy(e.a);
@@ -1642,53 +1697,113 @@ bool mode_higher_is_better(int metric, int32_t mode) {
   return higher_is_better_host(metric);
 }
 
-// HnswIndex::search_batch_parallel (batch.rs:159-197) / search_with_quality / search_brute_force for host queries;
-// results stay in ix->s_out_* on the device.  queries == nullptr: they already sit in ix->s_queries (row_stride layout).
-int32_t search_to_device(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode,
-                         uint32_t rerank_k, uint32_t* out_n) {
+// the result block of a context: [ids nq*kk u64 | scores nq*kk f32 | n nq u32] in ONE allocation
+int32_t reserve_out(vdb_hip_index* ix, uint32_t nq, size_t kk, hipStream_t st) {
+  const size_t o_sc = (size_t)nq * kk * 8, o_n = o_sc + (size_t)nq * kk * 4, total = o_n + (size_t)nq * 4;
+  hipError_t e = ix->s_out.reserve(total, false, st);
+  if (e != hipSuccess) return fail(VDB_ERR_OOM, std::string("search scratch: ") + hipGetErrorString(e));
+  unsigned char* b = ix->s_out.as<unsigned char>();
+  ix->s_out_ids.p = b;
+  ix->s_out_scores.p = b + o_sc;
+  ix->s_out_n.p = b + o_n;
+  ix->s_out_bytes = total;
+  return VDB_OK;
+}
+
+// rows of `queries` (nq x dim, caller memory) into the context's pinned staging buffer at query slot `at` of a batch of
+// nq_total (row_stride layout; the padding floats zeroed so the device rows are fully defined)
+int32_t stage_queries(vdb_hip_index* ix, const float* queries, uint32_t at, uint32_t nq, uint32_t nq_total) {
+  hipError_t e = ix->h_in.reserve((size_t)nq_total * ix->row_stride * 4);
+  if (e != hipSuccess) return fail(VDB_ERR_OOM, std::string("pinned query staging: ") + hipGetErrorString(e));
+  float* h = ix->h_in.as<float>() + (size_t)at * ix->row_stride;
+  if (ix->row_stride == ix->dim) {
+    std::memcpy(h, queries, (size_t)nq * ix->dim * 4);
+  } else {
+    for (uint32_t i = 0; i < nq; i++) {
+      std::memcpy(h + (size_t)i * ix->row_stride, queries + (size_t)i * ix->dim, (size_t)ix->dim * 4);
+      std::memset(h + (size_t)i * ix->row_stride + ix->dim, 0, (ix->row_stride - ix->dim) * 4);
+    }
+  }
+  return VDB_OK;
+}
+
+// The staged rows (h_in) up, the search, the whole result block back into h_out, ONE synchronisation.  HnswIndex::
+// search_batch_parallel (batch.rs:159-197) / search_with_quality / search_brute_force.  staged = false: the queries already sit
+// in ix->s_queries (row_stride layout).  The traversal kernel reports (out_n = 0xFFFFFFFF) a query whose candidate list
+// overflowed its LDS capacity (only possible with many exact distance ties); such a batch is re-run with more room.
+static int32_t search_block(vdb_hip_index* ix, bool staged, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode, uint32_t rerank_k) {
   hipStream_t st = ix->stream;
   const size_t kk = std::max<uint32_t>(k, 1);
   hipError_t e;
-  if ((e = ix->s_queries.reserve((size_t)nq * ix->row_stride * 4, false, st)) != hipSuccess ||
-      (e = ix->s_out_ids.reserve((size_t)nq * kk * 8, false, st)) != hipSuccess ||
-      (e = ix->s_out_scores.reserve((size_t)nq * kk * 4, false, st)) != hipSuccess ||
-      (e = ix->s_out_n.reserve((size_t)nq * 4, false, st)) != hipSuccess)
+  if ((e = ix->s_queries.reserve((size_t)nq * ix->row_stride * 4, false, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("search scratch: ") + hipGetErrorString(e));
+  int32_t rc = reserve_out(ix, nq, kk, st);
+  if (rc != VDB_OK) return rc;
+  if ((e = ix->h_out.reserve(ix->s_out_bytes)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("pinned result staging: ") + hipGetErrorString(e));
   float* dq = ix->s_queries.as<float>();
-  if (queries) {
-    if (ix->row_stride != ix->dim) VDB_HIP(hipMemsetAsync(dq, 0, (size_t)nq * ix->row_stride * 4, st));
-    VDB_HIP(hipMemcpy2DAsync(dq, ix->row_stride * 4, queries, (size_t)ix->dim * 4, (size_t)ix->dim * 4, nq,
-                             hipMemcpyHostToDevice, st));
-  }
-  // The traversal kernel reports (out_n = 0xFFFFFFFF) a query whose candidate list overflowed its LDS
-  // capacity (only possible with many exact distance ties); such a batch is re-run with more room.
+  if (staged) VDB_HIP(hipMemcpyAsync(dq, ix->h_in.p, (size_t)nq * ix->row_stride * 4, hipMemcpyHostToDevice, st));
+  uint32_t* h_n = reinterpret_cast<uint32_t*>(ix->h_out.as<unsigned char>() + ((unsigned char*)ix->s_out_n.p - (unsigned char*)ix->s_out.p));
   for (uint32_t cap_mult = 1;; cap_mult *= 4) {
     bool used_hnsw = false;
-    int32_t rc = search_dev(ix, dq, ix->row_stride, nq, k, ef, mode, ix->s_out_ids.as<uint64_t>(),
-                            ix->s_out_scores.as<float>(), ix->s_out_n.as<uint32_t>(), st, cap_mult, &used_hnsw,
-                            rerank_k);
+    rc = search_dev(ix, dq, ix->row_stride, nq, k, ef, mode, ix->s_out_ids.as<uint64_t>(), ix->s_out_scores.as<float>(),
+                    ix->s_out_n.as<uint32_t>(), st, cap_mult, &used_hnsw, rerank_k);
     if (rc != VDB_OK) {
       (void)hipStreamSynchronize(st);
       return rc;
     }
-    VDB_HIP(hipMemcpyAsync(out_n, ix->s_out_n.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    VDB_HIP(hipMemcpyAsync(ix->h_out.p, ix->s_out.p, ix->s_out_bytes, hipMemcpyDeviceToHost, st));
     VDB_HIP(hipStreamSynchronize(st));
     bool overflow = false;
     if (used_hnsw)
-      for (uint32_t i = 0; i < nq; i++) overflow |= out_n[i] == 0xFFFFFFFFu;
+      for (uint32_t i = 0; i < nq; i++) overflow |= h_n[i] == 0xFFFFFFFFu;
     if (!overflow) {
       // rerank over the <=100-vector exact shortcut: at most rerank_k candidates exist (search.rs:124)
       if (rerank_k && !used_hnsw) {
         bool cut = false;
         for (uint32_t i = 0; i < nq; i++) {
-          cut |= out_n[i] > rerank_k;
-          out_n[i] = std::min(out_n[i], rerank_k);
+          cut |= h_n[i] > rerank_k;
+          h_n[i] = std::min(h_n[i], rerank_k);
         }
-        if (cut) VDB_HIP(hipMemcpyAsync(ix->s_out_n.p, out_n, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+        if (cut) VDB_HIP(hipMemcpyAsync(ix->s_out_n.p, h_n, (size_t)nq * 4, hipMemcpyHostToDevice, st));
       }
       break;
     }
   }
+  return VDB_OK;
+}
+int32_t search_staged(vdb_hip_index* ix, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode, uint32_t rerank_k) {
+  return search_block(ix, true, nq, k, ef, mode, rerank_k);
+}
+
+// host queries -> results in ix->s_out_* on the device AND in ix->h_out (same layout); out_n also in the caller's array.
+// queries == nullptr: they already sit in ix->s_queries.  The caller holds ix->mu.
+// Large uploads skip the pinned staging (a host-side copy of every byte in front of the DMA): the runtime pipelines a copy from
+// pageable memory through its own staging chunks.
+// (1 M x 768, 1 024 queries = 3 MB per call: 0.16 ms over the device-resident call from pageable memory, 0.26 ms through the pinned
+// buffer; 256 queries = 0.75 MB: 0.08 ms either way; one query: 33 us)
+constexpr size_t kStageMaxBytes = (size_t)1 << 20;
+int32_t search_to_device(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode,
+                         uint32_t rerank_k, uint32_t* out_n) {
+  bool staged = false;
+  if (queries) {
+    const size_t bytes = (size_t)nq * ix->row_stride * 4;
+    if (bytes <= kStageMaxBytes) {
+      const int32_t rs = stage_queries(ix, queries, 0, nq, nq);
+      if (rs != VDB_OK) return rs;
+      staged = true;
+    } else {
+      hipStream_t st = ix->stream;
+      if (ix->s_queries.reserve(bytes, false, st) != hipSuccess) return fail(VDB_ERR_OOM, "search scratch");
+      float* dq = ix->s_queries.as<float>();
+      if (ix->row_stride != ix->dim) VDB_HIP(hipMemsetAsync(dq, 0, bytes, st));
+      VDB_HIP(hipMemcpy2DAsync(dq, ix->row_stride * 4, queries, (size_t)ix->dim * 4, (size_t)ix->dim * 4, nq, hipMemcpyHostToDevice, st));
+    }
+  }
+  const int32_t rc = search_block(ix, staged, nq, k, ef, mode, rerank_k);
+  if (rc != VDB_OK) return rc;
+  if (out_n)
+    std::memcpy(out_n, ix->h_out.as<unsigned char>() + ((unsigned char*)ix->s_out_n.p - (unsigned char*)ix->s_out.p), (size_t)nq * 4);
   return VDB_OK;
 }
 
@@ -1770,7 +1885,7 @@ int32_t vdb_hip_index_last_kernels(vdb_hip_index* ix, uint32_t* mask) {
 int32_t vdb_hip_index_set_option(vdb_hip_index* ix, int32_t option, int64_t value) {
   return vdb::guarded([&]() -> int32_t {
     if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
-    if (option < 0 || option > VDB_OPT_KERNEL_TIMING) return fail(VDB_ERR_INVALID_ARG, "unknown option");
+    if (option < 0 || option >= VDB_OPT_COUNT_) return fail(VDB_ERR_INVALID_ARG, "unknown option");
     if (ix->group) return group_set_option(ix, option, value);
     std::lock_guard<vdb::IndexMutex> g(ix->mu);
     mark_changed(ix);
@@ -1791,6 +1906,18 @@ int32_t vdb_hip_index_set_option(vdb_hip_index* ix, int32_t option, int64_t valu
           if (value < 1 || value > 64) return fail(VDB_ERR_INVALID_ARG, "oversampling ratio: 1..64");
           v = (int32_t)value;
           break;
+        case VDB_OPT_COMBINE_MAX_BATCH:
+          if (value > 1024) return fail(VDB_ERR_INVALID_ARG, "combined batch: 0 (off) .. 1024 queries");
+          v = (int32_t)value;
+          break;
+        case VDB_OPT_COMBINE_WINDOW_US:
+          if (value > 10000) return fail(VDB_ERR_INVALID_ARG, "combining window: 0 .. 10000 us");
+          v = (int32_t)value;
+          break;
+        case VDB_OPT_COMBINE_INFLIGHT:
+          if (value > 7) return fail(VDB_ERR_INVALID_ARG, "combined batches in flight: 0 (by kind of search) .. 7");
+          v = (int32_t)value;
+          break;
         default: v = value ? 1 : 0; break;
       }
     }
@@ -1802,16 +1929,10 @@ int32_t vdb_hip_index_set_option(vdb_hip_index* ix, int32_t option, int64_t valu
 int32_t vdb_hip_index_get_option(vdb_hip_index* ix, int32_t option, int64_t* value) {
   return vdb::guarded([&]() -> int32_t {
     if (!ix || !value) return fail(VDB_ERR_INVALID_ARG, "null argument");
-    if (option < 0 || option > VDB_OPT_KERNEL_TIMING) return fail(VDB_ERR_INVALID_ARG, "unknown option");
+    if (option < 0 || option >= VDB_OPT_COUNT_) return fail(VDB_ERR_INVALID_ARG, "unknown option");
     vdb_hip_index* c = ix->group ? group_first_shard(ix) : ix;
-    std::lock_guard<vdb::IndexMutex> g(c->mu);
-    switch (option) {
-      case VDB_OPT_MAX_QUERY_TILE: *value = opt_max_tile(c); break;
-      case VDB_OPT_SWEEP_ENGINE: *value = opt_engine(c); break;
-      case VDB_OPT_SELECTOR_LEVEL: *value = opt_selector(c); break;
-      case VDB_OPT_INT8_OVERSAMPLING: *value = opt_oversampling(c); break;
-      default: *value = opt_timing(c) ? 1 : 0; break;
-    }
+    std::shared_lock<vdb::IndexMutex> g(c->mu);
+    *value = opt_value(c, option);
     return VDB_OK;
   });
 }
@@ -2099,7 +2220,7 @@ int32_t vdb_hip_index_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed) {
 
 int32_t vdb_hip_index_len(const vdb_hip_index* ix, uint64_t* n) {  // trait_impl.rs:60-62 mappings.len()
   if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
-  std::lock_guard<vdb::IndexMutex> g(ix->mu);
+  std::shared_lock<vdb::IndexMutex> g(ix->mu);  // (a pure read: searches go on)
   *n = ix->live;
   return VDB_OK;
 }
@@ -2108,7 +2229,7 @@ int32_t vdb_hip_index_len(const vdb_hip_index* ix, uint64_t* n) {  // trait_impl
 int32_t vdb_hip_index_tombstone_count(const vdb_hip_index* ix, uint64_t* n) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
-  std::lock_guard<vdb::IndexMutex> g(ix->mu);
+  std::shared_lock<vdb::IndexMutex> g(ix->mu);  // (a pure read: searches go on)
   *n = ix->n_rows - ix->live;
   return VDB_OK;
   });
@@ -2204,7 +2325,7 @@ int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
 int32_t vdb_hip_index_node_count(const vdb_hip_index* ix, uint64_t* n) {
   return vdb::guarded([&]() -> int32_t {
   if (!ix || !n) return fail(VDB_ERR_INVALID_ARG, "null argument");
-  std::lock_guard<vdb::IndexMutex> g(ix->mu);
+  std::shared_lock<vdb::IndexMutex> g(ix->mu);  // (a pure read: searches go on)
   *n = ix->n_rows;
   return VDB_OK;
   });
@@ -2268,55 +2389,6 @@ int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* ix, const float* d_queries
   });
 }
 
-// HnswIndex::search_batch_parallel (batch.rs:159-197) / search_with_quality / search_brute_force
-static int32_t search_batch_host(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef,
-                                 int32_t mode, uint32_t rerank_k, uint64_t* out_ids, float* out_scores,
-                                 uint32_t* out_n) {
-  if (!ix || (nq && (!queries || !out_n)) || (nq && k && (!out_ids || !out_scores)))
-    return fail(VDB_ERR_INVALID_ARG, "null argument");
-  if (nq == 0) return VDB_OK;
-  if (ix->group) return group_search_host(ix, queries, nq, k, ef, mode, rerank_k, out_ids, out_scores, out_n);
-  std::shared_lock<vdb::IndexMutex> rd(ix->mu, std::defer_lock);
-  std::unique_lock<vdb::IndexMutex> wr(ix->mu, std::defer_lock);
-  if (ix->pcomm) wr.lock(); else rd.lock();
-  CtxLease lease(ix);  // this search's scratch + stream: the handle itself, or one of its search contexts when it is busy
-  if (lease.rc != VDB_OK) return lease.rc;
-  ix = lease.ctx;
-  VDB_ENTER_SHARED(ix);
-  hipStream_t st = ix->stream;
-  int32_t rc = search_to_device(ix, queries, nq, k, ef, mode, rerank_k, out_n);
-  if (rc != VDB_OK) return rc;
-  if (ix->pcomm && k) {  // member of a process group: every rank ends with the global top-k
-    const int32_t m = (mode == VDB_SEARCH_AUTO) ? (ix->live <= 100 ? VDB_SEARCH_BRUTE : VDB_SEARCH_HNSW) : mode;
-    rc = pcomm_exchange_merge(ix, nq, k, mode_higher_is_better(ix->metric, rerank_k ? VDB_SEARCH_BRUTE : m),
-                              ix->s_out_ids.as<uint64_t>(), ix->s_out_scores.as<float>(), ix->s_out_n.as<uint32_t>(), st);
-    if (rc != VDB_OK) return rc;
-    VDB_HIP(hipMemcpyAsync(out_n, ix->s_out_n.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-  }
-  if (k) {
-    VDB_HIP(hipMemcpyAsync(out_ids, ix->s_out_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, st));
-    VDB_HIP(hipMemcpyAsync(out_scores, ix->s_out_scores.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, st));
-  }
-  VDB_HIP(hipStreamSynchronize(st));
-  return VDB_OK;
-}
-
-int32_t vdb_hip_index_search_batch(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef,
-                                   int32_t mode, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
-  return vdb::guarded([&]() -> int32_t {
-  return search_batch_host(ix, queries, nq, k, ef, mode, 0, out_ids, out_scores, out_n);
-  });
-}
-
-// HnswIndex::search_with_rerank / search_with_rerank_quality — search.rs:118-160,297-350
-int32_t vdb_hip_index_search_rerank(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t rerank_k,
-                                    uint32_t ef, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
-  return vdb::guarded([&]() -> int32_t {
-  if (rerank_k == 0) return fail(VDB_ERR_INVALID_ARG, "rerank_k must be > 0");
-  return search_batch_host(ix, queries, nq, k, ef, VDB_SEARCH_AUTO, rerank_k, out_ids, out_scores, out_n);
-  });
-}
-
 // which summation order the exact sweep uses for this index and k (tests / bench pick the oracle mode by it)
 int32_t vdb_hip_index_sweep_arith_mode(vdb_hip_index* ix, uint32_t k, int32_t* mode) {
   return vdb::guarded([&]() -> int32_t {
@@ -2326,18 +2398,6 @@ int32_t vdb_hip_index_sweep_arith_mode(vdb_hip_index* ix, uint32_t k, int32_t* m
                     sweep_mfma_lds_bytes(1, k, ix->dim) <= 160 * 1024;
   *mode = mfma ? 1 : 0;
   return VDB_OK;
-  });
-}
-
-// VectorIndex::search — index/mod.rs:58; trait_impl.rs:38-42
-int32_t vdb_hip_index_search(vdb_hip_index* ix, const float* query, uint32_t query_len, uint32_t k, uint32_t ef,
-                             int32_t mode, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
-  return vdb::guarded([&]() -> int32_t {
-  if (!ix || !query) return fail(VDB_ERR_INVALID_ARG, "null argument");
-  if (query_len != ix->dim)
-    return fail(VDB_ERR_DIM_MISMATCH, "Query dimension mismatch: expected " + std::to_string(ix->dim) + ", got " +
-                                          std::to_string(query_len));
-  return vdb_hip_index_search_batch(ix, query, 1, k, ef, mode, out_ids, out_scores, out_n);
   });
 }
 

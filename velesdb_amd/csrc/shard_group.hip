@@ -64,6 +64,7 @@ static Rccl* rccl() {
         err = std::string("cannot load ") + forced + " (VELESDB_RCCL_LIB): " + (de ? de : "unknown error");
         return;
       }
+      fprintf(stderr, "velesdb-hip: collective transport loaded from VELESDB_RCCL_LIB=%s\n", forced);
     } else {
       for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -263,8 +264,13 @@ int32_t group_create(vdb_hip_index* parent, const int32_t* devices, int32_t n_de
       if (devices[a] == devices[b]) g->distinct = false;
   // test hook: run the collective branch (ncclCommInitAll + grouped ncclAllGather) over co-located shards.  Real RCCL
   // refuses duplicate devices; the loop-back transport of tests/stub_rccl (VELESDB_RCCL_LIB) does not.
+  // (honoured only together with VELESDB_RCCL_LIB, and announced: neither belongs in a deployment's environment)
   if (const char* fc = getenv("VELESDB_SHARD_FORCE_COLLECTIVE"))
-    if (fc[0] == '1') g->distinct = true;
+    if (fc[0] == '1' && getenv("VELESDB_RCCL_LIB")) {
+      g->distinct = true;
+      fprintf(stderr, "velesdb-hip: VELESDB_SHARD_FORCE_COLLECTIVE=1 with VELESDB_RCCL_LIB=%s: co-located shards use the collective transport (test hook)\n",
+              getenv("VELESDB_RCCL_LIB"));
+    }
   g->gath.resize(S);
   g->ev.assign(S, nullptr);
   for (int32_t s = 0; s < n_devices; s++) {
@@ -565,10 +571,8 @@ int32_t group_search_host(vdb_hip_index* ix, const float* queries, uint32_t nq, 
     VDB_HIP(hipSetDevice(c->device));
     std::vector<uint32_t> hn(nq);
     if (c->n_rows == 0) {  // a shard no row has reached yet contributes nothing
-      if (c->s_out_n.reserve((size_t)nq * 4, false, c->stream) != hipSuccess ||
-          c->s_out_ids.reserve((size_t)nq * std::max<uint32_t>(k, 1) * 8, false, c->stream) != hipSuccess ||
-          c->s_out_scores.reserve((size_t)nq * std::max<uint32_t>(k, 1) * 4, false, c->stream) != hipSuccess)
-        return fail(VDB_ERR_OOM, "search scratch");
+      const int32_t ro = reserve_out(c, nq, std::max<uint32_t>(k, 1), c->stream);
+      if (ro != VDB_OK) return ro;
       VDB_HIP(hipMemsetAsync(c->s_out_n.p, 0, (size_t)nq * 4, c->stream));
       return VDB_OK;
     }
@@ -618,11 +622,9 @@ int32_t group_search_dev(vdb_hip_index* ix, const float* d_q, uint32_t nq, uint3
     if (replica) query_slice(nq, s, S, &lo, &hi);
     const uint32_t n = hi - lo;
     if (n == 0) return VDB_OK;
-    if (c->s_queries.reserve((size_t)n * c->row_stride * 4, false, c->stream) != hipSuccess ||
-        c->s_out_ids.reserve((size_t)n * kk * 8, false, c->stream) != hipSuccess ||
-        c->s_out_scores.reserve((size_t)n * kk * 4, false, c->stream) != hipSuccess ||
-        c->s_out_n.reserve((size_t)n * 4, false, c->stream) != hipSuccess)
-      return fail(VDB_ERR_OOM, "search scratch");
+    if (c->s_queries.reserve((size_t)n * c->row_stride * 4, false, c->stream) != hipSuccess) return fail(VDB_ERR_OOM, "search scratch");
+    const int32_t ro = reserve_out(c, n, kk, c->stream);
+    if (ro != VDB_OK) return ro;
     if (c->row_stride != c->dim) VDB_HIP(hipMemsetAsync(c->s_queries.p, 0, (size_t)n * c->row_stride * 4, c->stream));
     VDB_HIP(hipMemcpy2DAsync(c->s_queries.p, c->row_stride * 4, d_q + (size_t)lo * ix->dim, (size_t)ix->dim * 4,
                              (size_t)ix->dim * 4, n, hipMemcpyDefault, c->stream));
@@ -741,7 +743,7 @@ int32_t vdb_hip_index_shard_info(vdb_hip_index* ix, int32_t* n_shards, int32_t* 
                                  int32_t* transport) {
   return guarded([&]() -> int32_t {
     if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
-    std::lock_guard<vdb::IndexMutex> lk(ix->mu);
+    std::shared_lock<vdb::IndexMutex> lk(ix->mu);
     if (n_shards) *n_shards = ix->group ? (int32_t)ix->group->shards.size() : 1;
     if (shard_mode) *shard_mode = ix->group ? ix->group->mode : (ix->pcomm ? VDB_SHARD_RANGE : VDB_SHARD_REPLICA);
     if (rank) *rank = ix->pcomm ? ix->pcomm->rank : 0;

@@ -538,7 +538,7 @@ int32_t ensure_sq8_select(vdb_hip_index* cx, hipStream_t st) {  // (inside a sea
     const bool stale = p->sq8_img.cap == 0 || p->sq8_img_rows < p->n_rows;
     const int32_t rc = ensure_sq8_select_impl(p, st);
     if (rc != VDB_OK) return rc;
-    if (stale && !p->ctx_clones.empty()) VDB_HIP(hipStreamSynchronize(st));
+    if (stale) VDB_HIP(hipStreamSynchronize(st));  // complete before another context may take the image over (index.hip)
     if (cx != p) copy_image_fields(cx, p);
   }
   if (!cx->sel_stats) {

@@ -8,6 +8,8 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
@@ -47,6 +49,8 @@ class IndexMutex {
   }
   bool try_lock() { return m_.try_lock(); }
   void unlock() { m_.unlock(); }
+  // NOT recursive: a thread that holds the shared lock and asks for it again while a writer waits would wait for the writer,
+  // which waits for the first hold — no entry point nests them
   void lock_shared() {
     while (writers_waiting_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
     m_.lock_shared();
@@ -69,6 +73,33 @@ struct DevBuf {
     return reinterpret_cast<T*>(p);
   }
 };
+
+// non-owning typed view of a region inside a DevBuf (the three result arrays of a search live in ONE allocation)
+struct DevView {
+  void* p = nullptr;
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+// growable pinned host buffer (hipHostMalloc): staging of the host-pointer entry points — queries go up and results come back
+// through it with ONE truly asynchronous copy each way (copies from / to pageable caller memory are staged and synchronised by
+// the runtime, one at a time)
+struct HostStage {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes);
+  void release();
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+struct Combiner;  // search_front.hip: the combining front of the host-pointer search entry points
+Combiner* combiner_new();
+void combiner_free(Combiner*);
 
 struct GraphLayer {
   DevBuf nbr;  // [capacity][stride] u32
@@ -104,13 +135,21 @@ static inline int32_t guarded(F&& f) noexcept {
 // caller's stream
 // exclusive = the caller holds ix->mu exclusively (it is about to change the index): the primary's stream is also ordered behind
 // whatever its search contexts still have in flight
-int32_t enter_index(vdb_hip_index* ix, bool exclusive = true);
+// changes = false: an exclusive READER (get_neighbors, save_*: they use the primary's stream and scratch, nothing a search reads
+// is touched) — search contexts keep their views
+int32_t enter_index(vdb_hip_index* ix, bool exclusive = true, bool changes = true);
 // the handle that owns the data a search context reads (itself unless it is a clone)
 static inline vdb_hip_index* primary_of(vdb_hip_index* ix);
 #define VDB_ENTER(ix)                        \
   do {                                       \
     int32_t _erc = ::vdb::enter_index(ix);   \
     if (_erc != VDB_OK) return _erc;         \
+  } while (0)
+
+#define VDB_ENTER_READONLY(ix)                          \
+  do {                                                  \
+    int32_t _erc = ::vdb::enter_index(ix, true, false); \
+    if (_erc != VDB_OK) return _erc;                    \
   } while (0)
 
 #define VDB_ENTER_SHARED(ix)                        \
@@ -157,7 +196,7 @@ struct vdb_hip_index {
   // large exact Cosine / DotProduct batch and kept up to date from then on
   vdb::DevBuf rows_split;
   // per-handle options (vdb_hip_index_set_option): -1 = follow the process-wide default (vdb_hip_set_*)
-  int32_t opt[5] = {-1, -1, -1, -1, -1};
+  int32_t opt[VDB_OPT_COUNT_] = {-1, -1, -1, -1, -1, -1, -1, -1};
   bool split_enabled = false;
   bool sel_norms = false;    // canonical f32 norms are kept for every row whatever the metric (selection levels 1 / 2)
   // level 2 (plain bf16 selection) adaptivity: the verdict counts of finished batches arrive in pinned host memory
@@ -198,7 +237,13 @@ struct vdb_hip_index {
   bool any_dead = false;
 
   // scratch
-  vdb::DevBuf s_queries, s_part_keys, s_part_cnt, s_out_ids, s_out_scores, s_out_n, s_qbits, s_misc;
+  vdb::DevBuf s_queries, s_part_keys, s_part_cnt, s_qbits, s_misc;
+  // results of a host-pointer search: ONE allocation [ids nq*k u64 | scores nq*k f32 | n nq u32] (reserve_out), so that one
+  // copy brings everything back; the three views point into it
+  vdb::DevBuf s_out;
+  vdb::DevView s_out_ids, s_out_scores, s_out_n;
+  size_t s_out_bytes = 0;            // bytes of the block the views currently describe
+  vdb::HostStage h_in, h_out;        // pinned staging: queries up, the result block down
   vdb::DevBuf s_fb_keys;  // partial lists of the exact fallback launch behind the split-bf16 selection
   vdb::DevBuf s_seed;  // seeding pre-pass of the bf16 GEMM sweep: partial lists, merged prefix top-k, seed keys
   uint64_t euclid_fallbacks = 0;  // queries of Euclidean matrix-core batches re-run through the exact sweep (diagnostic)
@@ -225,6 +270,8 @@ struct vdb_hip_index {
   vdb_hip_index* primary = nullptr;            // set in a clone
   std::vector<vdb_hip_index*> ctx_clones;      // (primary only)
   std::mutex ctx_mu, pool_mu;
+  uint64_t generation = 0;                     // unique per created handle (the thread-local "last context" is keyed on it)
+  vdb::Combiner* combiner = nullptr;           // (primary only) callers of the host-pointer entry points that arrive together share one launch
   uint64_t version = 1, synced_version = 0;    // primary: bumped by every change; clone: the version its views were copied at
   // first-use construction of the selection images (split / bf16 / augmented / SQ8-dequantised) happens inside searches, i.e.
   // under the SHARED lock: serialised here, always on the primary's fields
@@ -274,6 +321,15 @@ int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint3
 // holds ix->mu.  Re-runs HNSW batches whose candidate list overflowed.
 int32_t search_to_device(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode,
                          uint32_t rerank_k, uint32_t* out_n);
+// the result block of a context for nq queries x kk results: sizes s_out and points the three views into it
+int32_t reserve_out(vdb_hip_index* ix, uint32_t nq, size_t kk, hipStream_t st);
+// the pieces of search_to_device (search_front.hip uses them directly): rows of `queries` into the pinned staging buffer at query
+// slot `at` (row_stride layout, padding zeroed); the staged rows up, the search, the whole result block back into h_out and ONE
+// synchronisation (re-runs HNSW batches whose candidate list overflowed)
+int32_t stage_queries(vdb_hip_index* ix, const float* queries, uint32_t at, uint32_t nq, uint32_t nq_total);
+int32_t search_staged(vdb_hip_index* ix, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode, uint32_t rerank_k);
+// effective option values (index.hip)
+int64_t opt_value(const vdb_hip_index* ix, int32_t option);
 bool mode_higher_is_better(int metric, int32_t mode);
 // shard_group.hip
 int32_t group_create(vdb_hip_index* parent, const int32_t* devices, int32_t n_devices, int32_t shard_mode,
@@ -307,7 +363,7 @@ int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
                         uint32_t rerank_k = 0);
 // hnsw_build.hip; max_batch 1 = the reference's sequential insert, 0 = default batched schedule
 int32_t graph_insert_rows(vdb_hip_index* ix, uint64_t first, uint64_t n, uint32_t max_batch);
-int32_t ensure_traversal_scratch(vdb_hip_index* ix, hipStream_t st);
+int32_t ensure_traversal_scratch(vdb_hip_index* ix, hipStream_t st, int want_slots = 0);
 // hnsw_int8.hip
 int32_t quantizer_train(vdb_hip_index* ix, uint32_t sample_rows);
 int32_t quantize_rows(vdb_hip_index* ix, uint64_t first, uint64_t n);

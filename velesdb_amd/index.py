@@ -22,6 +22,9 @@ from .params import DistanceMetric, HnswParams, SearchQuality
 
 MODE_AUTO, MODE_BRUTE, MODE_HNSW, MODE_BRUTE_BF16, MODE_HNSW_INT8, MODE_BRUTE_SQ8, MODE_BRUTE_BINARY = 0, 1, 2, 3, 4, 5, 6
 OPT_MAX_QUERY_TILE, OPT_SWEEP_ENGINE, OPT_SELECTOR_LEVEL, OPT_INT8_OVERSAMPLING, OPT_KERNEL_TIMING = 0, 1, 2, 3, 4
+# the combining front of the host-pointer search entry points (include/velesdb_hip.h): queries per combined launch (0 = off),
+# waiting window of a leader in microseconds, combined batches in flight
+OPT_COMBINE_MAX_BATCH, OPT_COMBINE_WINDOW_US, OPT_COMBINE_INFLIGHT = 5, 6, 7
 KIND_ENGINE, KIND_RAW = 0, 1
 # enum vdb_kernel_bit (HnswIndex.last_kernels)
 (KERNEL_SWEEP_VALU, KERNEL_SWEEP_MFMA_F32, KERNEL_GEMM_F32, KERNEL_SWEEP_MFMA_BF16, KERNEL_GEMM_BF16, KERNEL_GEMM_BF16_GLDS,
@@ -463,6 +466,12 @@ class HnswIndex:
         v = C.c_int64(0)
         check(lib().vdb_hip_index_get_option(self._h, int(option), C.byref(v)))
         return int(v.value)
+
+    def combine_stats(self):
+        """Counters of the combining front: (launches, calls, queries, largest batch) since the handle was created."""
+        v = [C.c_uint64(0) for _ in range(4)]
+        check(lib().vdb_hip_index_combine_stats(self._h, *[C.byref(x) for x in v]))
+        return tuple(int(x.value) for x in v)
 
     def last_select_level(self) -> int:
         """Selection level (0 / 1 / 2) the last exact batch of this handle ran at."""
