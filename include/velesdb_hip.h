@@ -357,7 +357,8 @@ enum vdb_kernel_bit {
   VDB_KERNEL_BITS = 256,           /* packed-bit sweeps (Hamming / Jaccard / sign-bit codes)                           */
   VDB_KERNEL_SQ8 = 512,            /* sweep_topk_sq8                                                                   */
   VDB_KERNEL_HNSW = 1024,          /* hnsw_search_kernel                                                               */
-  VDB_KERNEL_HNSW_INT8 = 2048      /* hnsw_search_int8_kernel                                                          */
+  VDB_KERNEL_HNSW_INT8 = 2048,     /* hnsw_search_int8_kernel                                                          */
+  VDB_KERNEL_BITS_GEMM = 4096      /* Hamming / Jaccard batches as an int8 GEMM distance (sweep_topk_gemm_bf16_pp<.., I8>) */
 };
 int32_t vdb_hip_index_last_kernels(vdb_hip_index* idx, uint32_t* mask);
 /* *mode = 1 if searches in VDB_SEARCH_BRUTE mode with this k run on the matrix-core kernel (mode M), else 0 */

@@ -498,3 +498,56 @@ def test_large_planted_neighbours_200k(gpu_required, metric):
     eid, esc = po.scan_topk(int(metric), rows, q, 10, sweep_mode(metric, d), nthreads=8)
     assert [i for i, _ in got] == eid[0].tolist()
     assert np.array_equal(bits(np.float32([s for _, s in got])), bits(esc[0]))
+
+
+@pytest.mark.parametrize("metric", [DM.Hamming, DM.Jaccard])
+@pytest.mark.parametrize("n,dim", [(70_077, 768), (66_600, 100), (140_000, 48), (66_100, 1000)])
+def test_bit_metric_batches_on_the_matrix_cores_exact(gpu_required, metric, n, dim):
+    """Hamming / Jaccard batches of >= 224 queries over >= 65 536 rows run as an int8 GEMM distance (bits_gemm.hip: the
+    intersection counts on v_mfma_i32_16x16x64_i8, the metric's bound and finish in the selection kernel's epilogue).  Integer
+    work: ids, ranks (ties by row: dim 48 ties almost everywhere) and score bits equal the oracle's on sampled queries and the
+    vector-ALU kernels' on every query; zero rows / zero queries (empty unions: Jaccard 1.0), duplicated rows, a ragged last
+    tile, soft deletes, rows appended after the image was built."""
+    rng = np.random.default_rng(n + dim + int(metric))
+    rows = rand_rows(rng, n, dim, metric)
+    rows[7] = 0.0
+    rows[n - 1] = 0.0
+    rows[1000:1040] = rows[999]                         # duplicates: exact ties across one tile
+    rows[n - 300:n - 290] = rows[5]                      # ... and with rows of another launch / the seed prefix
+    ids = np.arange(n, dtype=np.uint64) * 3 + 2
+    ix = va.HnswIndex(dim, metric)
+    assert ix.upload(ids[:n - 500], rows[:n - 500]) == n - 500
+    nthreads = po.host_threads()
+
+    def check(nq, k, live=None, n_now=n):
+        Q = rand_rows(rng, nq, dim, metric)
+        Q[1] = 0.0
+        Q[2] = rows[999]
+        Q[3] = rows[5]
+        gid, gsc, gcnt = ix.search_batch_brute_force(Q, k)
+        assert ix.last_kernels() & va.KERNEL_BITS_GEMM, "the matrix-core path did not serve the batch"
+        ix.set_option(va.OPT_SWEEP_ENGINE, 0)            # the vector-ALU kernels on the same batch
+        vid, vsc, vcnt = ix.search_batch_brute_force(Q, k)
+        assert not (ix.last_kernels() & va.KERNEL_BITS_GEMM)
+        ix.set_option(va.OPT_SWEEP_ENGINE, -1)
+        assert np.array_equal(gcnt, vcnt) and np.array_equal(gid, vid) and np.array_equal(bits(gsc), bits(vsc)), (metric, n, dim, nq, k)
+        sel = np.unique(np.concatenate([[0, 1, 2, 3, nq - 1], rng.choice(nq, 24, replace=False)]))
+        lv = np.arange(n_now) if live is None else np.nonzero(live[:n_now])[0]
+        r, s = po.scan_topk(int(metric), rows[lv], Q[sel], k, po.MODE_C, nthreads=nthreads)
+        for j, qi in enumerate(sel):
+            assert gcnt[qi] == k
+            assert np.array_equal(gid[qi], ids[lv[r[j].astype(np.int64)]]), (metric, n, dim, nq, k, qi)
+            assert np.array_equal(bits(gsc[qi]), bits(s[j]))
+
+    check(256, 10, n_now=n - 500)
+    check(300, 1, n_now=n - 500)                         # 256 on the matrix cores + 44 on the vector ALUs
+    assert ix.upload(ids[n - 500:], rows[n - 500:]) == 500   # the image follows the inserts
+    check(1024, 3)
+    check(700, 10)
+    dead = rng.choice(n, n // 9, replace=False)
+    for d in dead[:2000]:
+        assert ix.remove(int(ids[d]))
+    live = np.ones(n, bool)
+    live[dead[:2000]] = False
+    check(480, 10, live)
+    ix.close()

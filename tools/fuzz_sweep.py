@@ -29,6 +29,7 @@ p.add_argument("--engine", type=int, default=1, help="0 = vector-ALU kernels for
 p.add_argument("--only-it", type=int, default=0, help="replay: generate every case, run only this one (verbose)")
 p.add_argument("--euclid", action="store_true", help="Euclidean only (matrix-core batches + exact re-scoring)")
 p.add_argument("--bits", action="store_true", help="Hamming / Jaccard (packed-bit kernels) instead of cosine / dot")
+p.add_argument("--bits-big", action="store_true", help="Hamming / Jaccard batches that take the int8 GEMM path (>= 224 queries, >= 65 536 rows)")
 a = p.parse_args()
 rng = np.random.default_rng(a.seed)
 NT = po.host_threads()
@@ -95,6 +96,15 @@ while time.time() < t_end:
         va.set_split_selector(int(rng.choice([1, 2])))
         if rng.random() < 0.3:
             metric = DM.Euclidean
+    if a.bits_big:
+        a.bits = True
+        bf16 = False
+        metric = [DM.Hamming, DM.Jaccard][int(rng.integers(0, 2))]
+        n = int(rng.choice([65_536, 66_000, 70_077, 150_000, 300_001]))
+        dim = int(rng.choice([33, 64, 100, 256, 768, 1000]))
+        nq = int(rng.choice([224, 256, 300, 480, 600, 700, 1024, 1100]))
+        k = int(rng.choice([1, 3, 10]))
+        kind = str(rng.choice(["normal", "normal", "dups", "zeros_mixed"]))
     if a.bf16_big:
         bf16 = True
         metric = [DM.Cosine, DM.DotProduct][int(rng.integers(0, 2))]
@@ -202,6 +212,18 @@ while time.time() < t_end:
             else:
                 bf16_check(metric, pm, rows, Q, k, gi, gs, gc)
         stats["bf16"] += 1
+    elif a.bits_big:  # the int8 GEMM path: every query against the vector-ALU kernels, a sample against the oracle
+        gi, gs, gc = ix.search_batch_brute_force(Q, k)
+        assert ix.last_kernels() & va.KERNEL_BITS_GEMM, tag + " (not served by the int8 GEMM path)"
+        ix.set_option(va.OPT_SWEEP_ENGINE, 0)
+        vi, vs, vc = ix.search_batch_brute_force(Q, k)
+        ix.set_option(va.OPT_SWEEP_ENGINE, -1)
+        assert np.array_equal(gc, vc) and np.array_equal(gi, vi) and np.array_equal(bits(gs), bits(vs)), tag + " (GEMM vs vector-ALU kernels)"
+        sample = np.unique(np.concatenate([[0, nq - 1, 255 % nq, 256 % nq], rng.integers(0, nq, 12)]))
+        eid, esc = po.scan_topk(int(metric), rows, Q[sample], kk, po.MODE_C, nthreads=NT)
+        assert np.all(gc == kk), tag
+        assert np.array_equal(gi[sample][:, :kk], eid) and np.array_equal(bits(gs[sample][:, :kk]), bits(esc)), tag
+        stats["bits_gemm"] = stats.get("bits_gemm", 0) + 1
     else:
         gi, gs, gc = ix.search_batch_brute_force(Q, k)
         mode = po.MODE_M if ix.sweep_arith_mode(k) == "M" else po.MODE_C

@@ -79,6 +79,7 @@ pub const VDB_KERNEL_BITS: i32 = 256;
 pub const VDB_KERNEL_SQ8: i32 = 512;
 pub const VDB_KERNEL_HNSW: i32 = 1024;
 pub const VDB_KERNEL_HNSW_INT8: i32 = 2048;
+pub const VDB_KERNEL_BITS_GEMM: i32 = 4096;
 
 pub const VDB_COMM_ID_BYTES: usize = 128;
 

@@ -9,7 +9,7 @@ from .index import (GpuAccelerator, HipDistance, HnswIndex, NativeHnswIndex, MOD
                     MODE_BRUTE_SQ8, MODE_BRUTE_BINARY, OPT_INT8_OVERSAMPLING, OPT_KERNEL_TIMING, OPT_MAX_QUERY_TILE,
                     OPT_SELECTOR_LEVEL, OPT_SWEEP_ENGINE, OPT_COMBINE_MAX_BATCH, OPT_COMBINE_WINDOW_US, OPT_COMBINE_INFLIGHT, SHARD_RANGE, SHARD_REPLICA, comm_unique_id,
                     device_count, device_name, set_kernel_timing, set_max_query_tile, set_split_selector, set_sweep_engine)
-from .index import (KERNEL_BITS, KERNEL_GEMM_BF16, KERNEL_GEMM_BF16_GLDS, KERNEL_GEMM_F32, KERNEL_HNSW, KERNEL_HNSW_INT8,  # noqa: F401
+from .index import (KERNEL_BITS, KERNEL_BITS_GEMM, KERNEL_GEMM_BF16, KERNEL_GEMM_BF16_GLDS, KERNEL_GEMM_F32, KERNEL_HNSW, KERNEL_HNSW_INT8,  # noqa: F401
                     KERNEL_SELECT_BF16, KERNEL_SELECT_SPLIT, KERNEL_SQ8, KERNEL_SWEEP_MFMA_BF16, KERNEL_SWEEP_MFMA_F32,
                     KERNEL_SWEEP_VALU)
 from .params import DistanceMetric, HnswParams, SearchQuality, StorageMode  # noqa: F401

@@ -169,6 +169,9 @@ void copy_image_fields(vdb_hip_index* c, const vdb_hip_index* p) {
   c->sq8_rho = p->sq8_rho;
   c->sq8_seed = p->sq8_seed;
   c->sq8_img_rows = p->sq8_img_rows;
+  c->bits_img = p->bits_img;
+  c->bits_cnt = p->bits_cnt;
+  c->bits_img_rows = p->bits_img_rows;
 }
 // every field a search READS about the index (non-owning views of the device buffers); scratch, stream, events, diagnostics and
 // the adaptive selection state stay the context's own
@@ -322,6 +325,9 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
   if (ix->sq8_img.cap && ((e = ix->sq8_img.reserve((ncap + kRowSlack) * (size_t)(ix->dim + (ix->metric == VDB_EUCLIDEAN ? 64 : 0)) * 2, true, st)) != hipSuccess ||
                           (e = ix->sq8_nrm.reserve((ncap + kRowSlack) * 4, true, st)) != hipSuccess))
     return fail(VDB_ERR_OOM, std::string("grow SQ8 selection image: ") + hipGetErrorString(e));
+  if (ix->bits_img.cap && ((e = ix->bits_img.reserve((ncap + kRowSlack) * (size_t)bits_image_stride(ix->dim), true, st)) != hipSuccess ||
+                           (e = ix->bits_cnt.reserve((ncap + kRowSlack) * 4, true, st)) != hipSuccess))
+    return fail(VDB_ERR_OOM, std::string("grow bit-row byte image: ") + hipGetErrorString(e));
   for (auto& L : ix->layers) {
     if ((e = L.nbr.reserve(ncap * L.stride * 4, true, st)) != hipSuccess ||
         (e = L.cnt.reserve(ncap * 4, true, st)) != hipSuccess ||
@@ -362,6 +368,11 @@ static int32_t finish_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
     launch_split_vectors(ix->rows.as<float>(), ix->row_stride, ix->rows_split.as<uint16_t>(), nullptr, (uint32_t)first,
                          (uint32_t)n, ix->dim, ix->stream);
     ix->split_rows = first + n;
+  }
+  if (ix->bits_img.cap) {  // (behind prep_rows on the same stream: the packed bits of the new rows exist)
+    launch_bits_expand(ix->metric, ix->bits.as<uint32_t>(), ix->words, ix->bits_img.as<uint8_t>(), bits_image_stride(ix->dim), ix->bits_cnt.as<float>(),
+                       (uint32_t)first, (uint32_t)n, ix->dim, 0.0f, ix->stream);
+    ix->bits_img_rows = first + n;
   }
   if (ix->storage_mode != VDB_STORAGE_FULL) {  // crud.rs:66-82: the quantised code is built with every upsert
     int32_t rs = storage_mode_append(ix, first, n);
@@ -749,6 +760,25 @@ static int32_t ensure_sel16_impl(vdb_hip_index* ix, hipStream_t st) {
   }
   VDB_HIP(hipGetLastError());
   return VDB_OK;
+}
+
+// Hamming / Jaccard batches on the matrix cores (bits_gemm.hip): the {0,1} byte image of the packed bit rows + their bit counts
+static int32_t ensure_bits_image_impl(vdb_hip_index* ix, hipStream_t st) {
+  const uint64_t cap = std::max<uint64_t>(ix->capacity, 1) + kRowSlack;
+  const uint32_t stride = bits_image_stride(ix->dim);
+  hipError_t e;
+  if ((e = ix->bits_img.reserve(cap * (size_t)stride, true, st)) != hipSuccess || (e = ix->bits_cnt.reserve(cap * 4, true, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("bit-row byte image: ") + hipGetErrorString(e));
+  if (ix->bits_img_rows < ix->n_rows) {
+    launch_bits_expand(ix->metric, ix->bits.as<uint32_t>(), ix->words, ix->bits_img.as<uint8_t>(), stride, ix->bits_cnt.as<float>(), (uint32_t)ix->bits_img_rows,
+                       (uint32_t)(ix->n_rows - ix->bits_img_rows), ix->dim, 0.0f, st);
+    ix->bits_img_rows = ix->n_rows;
+    VDB_HIP(hipGetLastError());
+  }
+  return VDB_OK;
+}
+static int32_t ensure_bits_image(vdb_hip_index* ix, hipStream_t st) {
+  return build_image_on_primary(ix, st, [](const vdb_hip_index* p) { return p->bits_img.cap == 0 || p->bits_img_rows < p->n_rows; }, ensure_bits_image_impl);
 }
 
 // does a chunk of nqg queries take the selection stage?  Whole 256-query tiles filled to >= 7/8 — or ONE partly filled tile
@@ -1234,6 +1264,25 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     pa.dim = ix->dim;
     pa.words = ix->words;
     launch_prep_rows(pa, st);
+    // large batches: the intersection counts as an int8 GEMM on the matrix cores, exact (bits_gemm.hip); what is left of the batch
+    // (and every other shape) keeps the vector-ALU kernels below — the same keys either way
+    uint32_t qdone = 0;
+    while (opt_engine(ix) == 1 && opt_max_tile(ix) >= 128) {
+      const uint32_t nqg = bits_gemm_chunk(ix, nq - qdone, k);
+      if (!nqg) break;
+      int32_t rg = ensure_bits_image(ix, st);
+      if (rg == VDB_OK)
+        rg = brute_bits_gemm_dev(ix, ix->s_qbits.as<uint32_t>() + (size_t)qdone * ix->words, nqg, k, d_ids + (size_t)qdone * k,
+                                 d_scores + (size_t)qdone * k, d_n + qdone, st);
+      if (rg != VDB_OK) return rg;
+      qdone += nqg;
+    }
+    if (qdone == nq) return VDB_OK;
+    d_ids += (size_t)qdone * k;
+    d_scores += (size_t)qdone * k;
+    d_n += qdone;
+    nq -= qdone;
+    const uint32_t* qbits_rest = ix->s_qbits.as<uint32_t>() + (size_t)qdone * ix->words;
     const BitsPlan bp = plan_bits_sweep(ix->n_rows, ix->n_cus, ix->words, nq, k);
     const int blocks = bp.blocks;
     const uint32_t nw = (uint32_t)blocks;  // one list per block
@@ -1242,7 +1291,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
       return fail(VDB_ERR_OOM, "top-k scratch");
     BitsArgs ba{};
     ba.bits = ix->bits.as<uint32_t>();
-    ba.qbits = ix->s_qbits.as<uint32_t>();
+    ba.qbits = qbits_rest;
     ba.alive = alive;
     ba.part_keys = ix->s_part_keys.as<uint64_t>();
     ba.part_cnt = ix->s_part_cnt.as<uint32_t>();
@@ -1656,6 +1705,7 @@ std::vector<DevBuf*> index_buffers(vdb_hip_index* ix) {
       &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq,                // int8 traversal
       &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits,  // storage modes
       &ix->sq8_img, &ix->sq8_nrm, &ix->sq8_seed, &ix->sq8_rho,              // SQ8 selection images
+      &ix->bits_img, &ix->bits_cnt,                                         // byte image of the bit rows (Hamming / Jaccard GEMM)
       &ix->s_queries, &ix->s_part_keys, &ix->s_part_cnt, &ix->s_out, &ix->s_qbits,
       &ix->s_misc, &ix->s_fb_keys, &ix->s_seed, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels, &ix->s_req_keys,
       &ix->s_req_vals, &ix->s_sort_tmp};
@@ -2307,6 +2357,7 @@ int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
   ix->bf16_rows = 0;
   ix->split_rows = 0;
   ix->l2_rows = 0;
+  ix->bits_img_rows = 0;
   const uint64_t cap = ix->capacity;
   ix->capacity = 0;  // re-reserve the per-row arrays (rows keep their buffer; the new layer arrays are allocated)
   int32_t rc = ensure_capacity(ix, std::max<uint64_t>(cap, 1));

@@ -349,10 +349,12 @@ _Pragma("unroll") \
     }
     VDB_G16_STEP(a.KT - 1, false);  // the last k-tile: its closing barrier is the first sync point of the epilogue
     const bool more = it < total;
+#define VDB_G16_ACC_F(V) (V)
 #include "g16_quicktest.inc"
 #define VDB_G16_ACC_ELEM(X, A) asm volatile("v_mov_b32 %0, %1" : "=v"(X) : "v"(A))
 #include "g16_protocol.inc"
 #undef VDB_G16_ACC_ELEM
+#undef VDB_G16_ACC_F
   }
 #undef VDB_G16_STEP
 #undef VDB_G16_ADVANCE
@@ -400,11 +402,19 @@ _Pragma("unroll") \
 // conversely removing real bubbles (the scratch reloads and FLAT flag reads that used to drain the DMA queue in every
 // epilogue, the quick test of waves 0-3 moved beside the last products of waves 4-7) changed nothing measurable.
 // =====================================================================================================================
+// I8: the same 16-byte fragments hold 16 signed bytes instead of 8 bf16 — v_mfma_i32_16x16x64_i8, twice the k-extent per
+// instruction at the same issue cost (MI355X_MICROARCH.md: 2 x the bf16 rate), int32 accumulators in the same registers.  Both
+// operands are read with the same slot -> lane mapping, so whatever order the instruction assigns the k-values of a fragment
+// is the same for rows and queries: a dot product does not care.
+template <bool I8>
 __device__ __forceinline__ void mfma_acc(f32x4& c, const f32x4& a, const f32x4& b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  if (I8) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
+template <bool I8>
 __device__ __forceinline__ void mfma_acc_first(f32x4& c, const f32x4& a, const f32x4& b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));
+  if (I8) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));
 }
 // the barrier in front of a phase's products: this wave's fragment reads have completed (their stage slots may be
 // re-requested by anybody who has passed the barrier); "memory": no LDS access moves across
@@ -412,9 +422,13 @@ __device__ __forceinline__ void pp_barrier_reads_done() { asm volatile("s_waitcn
 __device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 __device__ __forceinline__ void pp_wait_dma6() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 
-template <int METRIC>
+// I8 instance (Hamming / Jaccard batches on {0,1} byte images, bits_gemm.hip): rows / queries are byte images addressed through the
+// same arguments — row_stride / q_stride / dim in units of TWO bytes, k-tiles of 128 bytes — and `norms` / `qnorms_half` carry
+// the bit counts |v|, |q| as floats; the accumulators hold the exact intersection counts.
+template <int METRIC, bool I8 = false>
 __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a) {
-  constexpr bool HIB = true;  // Cosine / DotProduct
+  static_assert(I8 == (METRIC == kHamming || METRIC == kJaccard), "the byte instance serves the bit metrics, the bf16 instance Cosine / DotProduct");
+  constexpr bool HIB = METRIC != kHamming;  // Cosine / DotProduct / Jaccard: higher is better; Hamming: a distance
   constexpr int BM = kG16BM, BN = kG16BN, WAVES = kG16Waves, CAP = kG16Cap, QCAP = kG16Queue;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* cand = reinterpret_cast<uint64_t*>(smem + kOffCand);   // [BN][CAP]
@@ -540,8 +554,8 @@ _Pragma("unroll") \
       for (int rf_ = 0; rf_ < 4; rf_++) \
 _Pragma("unroll") \
         for (int t_ = 0; t_ < 2; t_++) { \
-          if ((FIRST) && m_ == 0) mfma_acc_first(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
-          else mfma_acc(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
+          if ((FIRST) && m_ == 0) mfma_acc_first<I8>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
+          else mfma_acc<I8>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
         } \
   } while (0)
 
@@ -624,11 +638,17 @@ _Pragma("unroll") \
     for (uint32_t kt = 1; kt + 1 < a.KT; kt++) VDB_PP_KTILE(false, false);
     VDB_PP_KTILE(false, true);
     const bool more = c < total;
+    // (an accumulator element as the float the epilogue works with: the int32 count of the byte instance converts exactly)
+#define VDB_G16_ACC_F(V) (I8 ? (float)__float_as_int(V) : (V))
 #include "g16_quicktest.inc"  // (waves 0-3: beside the last products of waves 4-7)
     if (wr == 0) pp_barrier();  // waves 0-3 wait for the last products of waves 4-7: the block is aligned again
-#define VDB_G16_ACC_ELEM(X, A) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(X) : "a"(A))
+#define VDB_G16_ACC_ELEM(X, A) do { \
+      asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(X) : "a"(A)); \
+      if (I8) (X) = (float)__float_as_int(X); \
+    } while (0)
 #include "g16_protocol.inc"
 #undef VDB_G16_ACC_ELEM
+#undef VDB_G16_ACC_F
     // A rows 0-63 of the next row tile's first k-tile (landed: waited for in phase 3 above).  Unconditional — behind the last
     // row tile it reads a stage nobody uses: a conditional read would keep the OLD fragments alive across the epilogue
     VDB_PP_LANE();
@@ -673,21 +693,23 @@ void launch_query_norms_bf16(const uint16_t* q16, uint64_t q_stride, float* out,
 // From a merged prefix top-k (internal rows + raw scores, merge_topk with ext_ids = nullptr): the query's bound for the
 // next launch = k-th best key + 1 (the key itself must still pass `key < tauk`), and — list != nullptr — the top-k as a
 // key list in slot 0 of the launch-spanning list array (the seed rows are swept by a different kernel).
+template <bool HIB>
 __global__ __launch_bounds__(256) void seed_tau_kernel(const uint64_t* ids, const float* scores, const uint32_t* n, uint64_t* tau0,
                                                        uint64_t* list, uint32_t list_stride, uint32_t nq, uint32_t k) {
   const uint32_t q = blockIdx.x * 256 + threadIdx.x;
   if (q >= nq) return;
   const uint32_t c = min(n[q], k);
   uint64_t t = kKeyInvalid;
-  if (c >= k && k > 0) t = make_key<true>(scores[(size_t)q * k + k - 1], (uint32_t)ids[(size_t)q * k + k - 1]) + 1ull;
+  if (c >= k && k > 0) t = make_key<HIB>(scores[(size_t)q * k + k - 1], (uint32_t)ids[(size_t)q * k + k - 1]) + 1ull;
   tau0[q] = t;
   if (list)
     for (uint32_t e = 0; e < k; e++)
-      list[(size_t)q * list_stride * k + e] = e < c ? make_key<true>(scores[(size_t)q * k + e], (uint32_t)ids[(size_t)q * k + e]) : kKeyInvalid;
+      list[(size_t)q * list_stride * k + e] = e < c ? make_key<HIB>(scores[(size_t)q * k + e], (uint32_t)ids[(size_t)q * k + e]) : kKeyInvalid;
 }
 void launch_seed_tau(const uint64_t* ids, const float* scores, const uint32_t* n, uint64_t* tau0, uint64_t* list,
-                     uint32_t list_stride, uint32_t nq, uint32_t k, hipStream_t st) {
-  hipLaunchKernelGGL(seed_tau_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, tau0, list, list_stride, nq, k);
+                     uint32_t list_stride, uint32_t nq, uint32_t k, hipStream_t st, bool hib) {
+  if (hib) hipLaunchKernelGGL(seed_tau_kernel<true>, dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, tau0, list, list_stride, nq, k);
+  else hipLaunchKernelGGL(seed_tau_kernel<false>, dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, tau0, list, list_stride, nq, k);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------
@@ -721,6 +743,19 @@ static hipError_t launch_g16_pp(const Bf16GemmArgs& a, int blocks, hipStream_t s
     done = true;
   }
   hipLaunchKernelGGL((sweep_topk_gemm_bf16_pp<METRIC>), dim3(blocks), dim3(512), kG16Lds, st, a);
+  return hipGetLastError();
+}
+
+template <int METRIC>
+static hipError_t launch_g16_i8(const Bf16GemmArgs& a, int blocks, hipStream_t st) {
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_gemm_bf16_pp<METRIC, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  hipLaunchKernelGGL((sweep_topk_gemm_bf16_pp<METRIC, true>), dim3(blocks), dim3(512), kG16Lds, st, a);
   return hipGetLastError();
 }
 
@@ -760,13 +795,15 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
   a.dim = dim;
   a.nq = nq;
   a.k = k;
-  a.KT = split ? dim / 32 : dim / 64;
+  a.KT = split ? dim / 32 : dim / 64;  // (byte instance: dim in units of two bytes => k-tiles of 128 bytes)
   a.G = p.G;
   a.nqt = p.nqt;
   a.qper = p.qper;
   a.qnorms = qnorms;
   a.blk_tau = blk_tau;
   a.qnorms_half = qnorms_half;
+  if (metric == kHamming) return launch_g16_i8<kHamming>(a, p.blocks, st);
+  if (metric == kJaccard) return launch_g16_i8<kJaccard>(a, p.blocks, st);
   if (split)
     return metric == kCosine ? launch_g16<kCosine, true>(a, p.blocks, st) : launch_g16<kDot, true>(a, p.blocks, st);
   if (pingpong_enabled()) return metric == kCosine ? launch_g16_pp<kCosine>(a, p.blocks, st) : launch_g16_pp<kDot>(a, p.blocks, st);

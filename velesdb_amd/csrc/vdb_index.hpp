@@ -220,6 +220,10 @@ struct vdb_hip_index {
   // selection stage over SQ8 (level 3): bf16 image of the dequantised rows, their norms, f32 seed prefix
   vdb::DevBuf sq8_img, sq8_nrm, sq8_seed;
   uint64_t sq8_img_rows = 0;
+  // Hamming / Jaccard batches on the matrix cores (bits_gemm.hip): {0,1} byte image of the packed bit rows [capacity][stride], the
+  // rows' bit counts as floats; built at the first large batch, kept current by inserts from then on
+  vdb::DevBuf bits_img, bits_cnt;
+  uint64_t bits_img_rows = 0;
   uint32_t sq8_hold = 0;   // batches to answer with the exact SQ8 sweep after a batch the selection could not prove
   // graph
   std::vector<vdb::GraphLayer> layers;
@@ -383,6 +387,10 @@ int32_t sq8_fallback_flagged(vdb_hip_index* ix, const float* d_q, uint64_t q_str
 int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, uint64_t* d_ids,
                         float* d_scores, uint32_t* d_n, hipStream_t st, int level);
 int select_level_sq8(vdb_hip_index* ix, uint32_t nq_left, uint32_t k);
+// bits_gemm.hip
+uint32_t bits_gemm_chunk(const vdb_hip_index* ix, uint32_t nq_left, uint32_t k);
+int32_t brute_bits_gemm_dev(vdb_hip_index* ix, const uint32_t* qbits, uint32_t nqg, uint32_t k, uint64_t* d_ids, float* d_scores,
+                            uint32_t* d_n, hipStream_t st);
 int32_t brute_binary_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint64_t* d_ids,
                          float* d_scores, uint32_t* d_n, hipStream_t st);
 }  // namespace vdb

@@ -203,7 +203,11 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
 // norms of the rounded queries of a result-mode batch (qnorms_half above)
 void launch_query_norms_bf16(const uint16_t* q16, uint64_t q_stride, float* out, uint32_t nq, uint32_t dim, hipStream_t st);
 void launch_seed_tau(const uint64_t* ids, const float* scores, const uint32_t* n, uint64_t* tau0, uint64_t* list,
-                     uint32_t list_stride, uint32_t nq, uint32_t k, hipStream_t st);
+                     uint32_t list_stride, uint32_t nq, uint32_t k, hipStream_t st, bool hib = true);
+// bits_gemm.hip: {0,1} byte image of packed bit rows (+ bit counts as floats) for the int8 GEMM distance of Hamming / Jaccard
+void launch_bits_expand(int metric, const uint32_t* bits, uint32_t words, uint8_t* img, uint32_t img_stride, float* cnt, uint32_t row0,
+                        uint32_t n_rows, uint32_t dim, float fill, hipStream_t st);
+uint32_t bits_image_stride(uint32_t dim);
 // bf16 GEMM-distance sweep (cosine / dot over a bf16 copy of the rows): nqt in {1, 2, 4, 6} 16-query tiles
 constexpr int kBf16WavesBig = 16;    // waves per block for nqt >= 4 (one block per CU)
 constexpr int kBf16WavesSmall = 8;   // ... for nqt <= 2

@@ -28,7 +28,7 @@ OPT_COMBINE_MAX_BATCH, OPT_COMBINE_WINDOW_US, OPT_COMBINE_INFLIGHT = 5, 6, 7
 KIND_ENGINE, KIND_RAW = 0, 1
 # enum vdb_kernel_bit (HnswIndex.last_kernels)
 (KERNEL_SWEEP_VALU, KERNEL_SWEEP_MFMA_F32, KERNEL_GEMM_F32, KERNEL_SWEEP_MFMA_BF16, KERNEL_GEMM_BF16, KERNEL_GEMM_BF16_GLDS,
- KERNEL_SELECT_BF16, KERNEL_SELECT_SPLIT, KERNEL_BITS, KERNEL_SQ8, KERNEL_HNSW, KERNEL_HNSW_INT8) = (1 << i for i in range(12))
+ KERNEL_SELECT_BF16, KERNEL_SELECT_SPLIT, KERNEL_BITS, KERNEL_SQ8, KERNEL_HNSW, KERNEL_HNSW_INT8, KERNEL_BITS_GEMM) = (1 << i for i in range(13))
 SHARD_REPLICA, SHARD_RANGE = 0, 1
 COMM_ID_BYTES = 128
 
