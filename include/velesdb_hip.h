@@ -211,6 +211,13 @@ int32_t vdb_hip_index_search_batch(vdb_hip_index* idx, const float* queries_rowm
 int32_t vdb_hip_index_search_rerank(vdb_hip_index* idx, const float* queries_rowmajor, uint32_t nq, uint32_t k,
                                     uint32_t rerank_k, uint32_t ef, uint64_t* out_ids, float* out_scores,
                                     uint32_t* out_n);
+/* NativeHnsw::search_multi_entry (native/graph.rs:288-348; "improved recall on hard queries"): the layer-0 search starts from the
+ * descent's result AND up to min(num_probes, 4) - 1 further nodes drawn from the graph's own xorshift stream (the stream that
+ * draws insertion levels: like the reference, the call advances it — query i of the batch takes the draws nq sequential calls
+ * would give it; duplicates are skipped; no draw when num_probes <= 1 or the graph has <= 10 nodes), same ef.  Ids / scores as
+ * VDB_SEARCH_HNSW reports them.  ef = 0 => Balanced; ef >= 4 when several entry points are used. */
+int32_t vdb_hip_index_search_multi_entry(vdb_hip_index* idx, const float* queries_rowmajor, uint32_t nq, uint32_t k, uint32_t ef,
+                                         uint32_t num_probes, uint64_t* out_ids, float* out_scores, uint32_t* out_n);
 /* device-resident variant: d_queries nq*dim f32 (16-byte aligned), outputs device buffers of
  * nq*k / nq; enqueued on `stream`, no host synchronisation (one exception: Euclidean VDB_SEARCH_BRUTE batches of >= 64 queries
  * outside the selection stage's shapes — < 16 queries, dim % 64 != 0, k > 10, < 65 536 rows — read their per-query verdicts back

@@ -91,6 +91,10 @@ def _declare(L):
     L.vo_hnsw_vector.restype, L.vo_hnsw_vector.argtypes = C.POINTER(C.c_float), [vp, C.c_uint64]
     L.vo_hnsw_search.restype = C.c_uint32
     L.vo_hnsw_search.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_int, _u64p, _f32p]
+    L.vo_hnsw_search_multi_entry.restype = C.c_uint32
+    L.vo_hnsw_search_multi_entry.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _u64p, _f32p]
+    L.vo_hnsw_rng_state.restype = C.c_uint64
+    L.vo_hnsw_rng_state.argtypes = [vp]
     L.vo_hnsw_search_batch.restype = None
     L.vo_hnsw_search_batch.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, _u64p,
                                        _f32p, _u32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -440,6 +444,17 @@ class NativeHnsw:
         ds = np.empty(max(k, 1), dtype=np.float32)
         n = lib().vo_hnsw_search(self._h, q, k, ef, tie, ids, ds)
         return ids[:n].copy(), ds[:n].copy()
+
+    def search_multi_entry(self, q, k, ef, num_probes, tie=TIE_REFERENCE):
+        """NativeHnsw::search_multi_entry (graph.rs:288-348); advances the graph's level RNG like the reference."""
+        q = _f(q)
+        ids = np.empty(max(k, 1), dtype=np.uint64)
+        ds = np.empty(max(k, 1), dtype=np.float32)
+        n = lib().vo_hnsw_search_multi_entry(self._h, q, k, ef, num_probes, tie, ids, ds)
+        return ids[:n].copy(), ds[:n].copy()
+
+    def rng_state(self):
+        return int(lib().vo_hnsw_rng_state(self._h))
 
     def spread(self, nthreads):
         """re-place the vectors round-robin over the pool's threads (many-thread baselines on NUMA hosts)"""

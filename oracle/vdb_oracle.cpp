@@ -1111,6 +1111,34 @@ std::vector<std::pair<uint64_t, float>> hnsw_search(const vo_hnsw& g, const floa
   return out;
 }
 
+// graph.rs:288-348: the descent's result plus up to num_probes.min(4) - 1 ids drawn from the graph's OWN xorshift stream (the one
+// random_layer advances — without its zero-state reseed, :320-334), duplicates skipped, all of them entry points of ONE
+// search_layer with the full ef
+std::vector<std::pair<uint64_t, float>> hnsw_search_multi_entry(vo_hnsw& g, const float* q, size_t k, size_t ef, size_t num_probes,
+                                                                int tie) {
+  std::vector<std::pair<uint64_t, float>> out;
+  if (g.entry_point < 0) return out;
+  const uint64_t count = g.count;
+  if (count == 0) return out;
+  uint64_t cur = (uint64_t)g.entry_point;
+  for (size_t l = g.max_layer; l >= 1; l--) cur = search_layer_single(g, q, cur, l);
+  std::vector<uint64_t> eps{cur};
+  if (num_probes > 1 && count > 10) {
+    for (size_t p = 1; p < std::min<size_t>(num_probes, 4); p++) {
+      uint64_t s = g.rng_state;
+      s ^= s << 13;
+      s ^= s >> 7;
+      s ^= s << 17;
+      g.rng_state = s;
+      const uint64_t id = s % count;
+      if (std::find(eps.begin(), eps.end(), id) == eps.end()) eps.push_back(id);
+    }
+  }
+  out = search_layer(g, q, eps, ef, 0, tie);
+  if (out.size() > k) out.resize(k);
+  return out;
+}
+
 }  // namespace
 
 
@@ -1298,6 +1326,17 @@ uint32_t vo_hnsw_search(const vo_hnsw* g, const float* q, uint32_t k, uint32_t e
   }
   return (uint32_t)r.size();
 }
+uint32_t vo_hnsw_search_multi_entry(vo_hnsw* g, const float* q, uint32_t k, uint32_t ef, uint32_t num_probes, int tie, uint64_t* out_nodes,
+                                    float* out_dist) {
+  tl_n_dist = tl_n_expand = 0;
+  auto r = hnsw_search_multi_entry(*g, q, k, ef, num_probes, tie);
+  for (size_t i = 0; i < r.size(); i++) {
+    out_nodes[i] = r[i].first;
+    out_dist[i] = r[i].second;
+  }
+  return (uint32_t)r.size();
+}
+uint64_t vo_hnsw_rng_state(const vo_hnsw* g) { return g->rng_state; }
 void vo_hnsw_last_stats(uint64_t* n_dist, uint64_t* n_expand) {
   *n_dist = tl_n_dist;
   *n_expand = tl_n_expand;

@@ -123,6 +123,10 @@ uint32_t vo_hnsw_search(const vo_hnsw*, const float* q, uint32_t k, uint32_t ef,
 void vo_hnsw_search_batch(const vo_hnsw*, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int tie,
                           uint32_t nthreads, uint64_t* out_nodes, float* out_dist, uint32_t* out_n,
                           uint64_t* total_n_dist, uint64_t* total_n_expand);
+/* NativeHnsw::search_multi_entry (graph.rs:288-348): advances the graph's xorshift stream by min(num_probes, 4) - 1 draws */
+uint32_t vo_hnsw_search_multi_entry(vo_hnsw*, const float* q, uint32_t k, uint32_t ef, uint32_t num_probes, int tie,
+                                    uint64_t* out_nodes, float* out_dist);
+uint64_t vo_hnsw_rng_state(const vo_hnsw*);
 /* search statistics of the last vo_hnsw_search on this thread: distance evals, expansions */
 void vo_hnsw_last_stats(uint64_t* n_dist, uint64_t* n_expand);
 uint64_t vo_hnsw_search_layer_single(const vo_hnsw*, const float* q, uint64_t entry,

@@ -209,3 +209,48 @@ def test_search_with_rerank(tmp_path, metric):
             assert [x[0] for x in r] == eid.tolist(), (metric, k, rk)
             assert np.array_equal(bits([x[1] for x in r]), bits(esc))
     assert ix.search_with_rerank(qs[0], 10, 50) == ix.search_with_rerank_quality(qs[0], 10, 50, SQ.Accurate)
+
+
+@pytest.mark.parametrize("metric,n,dim", [(DM.Cosine, 700, 64), (DM.Euclidean, 400, 32), (DM.Hamming, 300, 96)])
+def test_search_multi_entry_follows_the_reference_stream(tmp_path, metric, n, dim):
+    """NativeHnsw::search_multi_entry (native/graph.rs:288-348): the descent's result plus up to min(num_probes, 4) - 1 nodes
+    drawn from the graph's own xorshift stream, one search_layer from all of them.  A batch on the GPU == the same queries
+    one after the other on the oracle (ids, score bits, counters), for every num_probes; afterwards both level streams stand
+    at the same place: the next insert draws the same level and links the same neighbours."""
+    rng = np.random.default_rng(n + dim)
+    rows = (rng.random((n + 1, dim)) > 0.6).astype(np.float32) if metric == DM.Hamming else rng.standard_normal((n + 1, dim)).astype(np.float32)
+    _, ix = build_pair(tmp_path, rows[:n], metric, 8, 60)
+    g = po.NativeHnsw.file_load(str(tmp_path), "native_hnsw", PO_METRIC[metric], po.MODE_C)   # fresh stream, like the loaded GPU index
+    g.set_build_tie(po.TIE_CANONICAL)
+    g.dim = dim   # (file_load leaves it open)
+    k, ef = 7, 40
+    for probes in (1, 2, 3, 4, 9):
+        Q = (rng.random((11, dim)) > 0.6).astype(np.float32) if metric == DM.Hamming else rng.standard_normal((11, dim)).astype(np.float32)
+        s0 = g.rng_state()
+        gid, gsc, gcnt = ix.search_multi_entry(Q, k, ef, probes)
+        nd_gpu, ne_gpu = ix.last_search_stats()
+        nd = ne = 0
+        for qi in range(Q.shape[0]):
+            oid, od = g.search_multi_entry(Q[qi], k, ef, probes, po.TIE_CANONICAL)
+            a, b = po.NativeHnsw.last_stats()
+            nd += a
+            ne += b
+            osc = np.array([po.transform_score(PO_METRIC[metric], float(x)) for x in od], dtype=np.float32)
+            assert gcnt[qi] == len(oid), (probes, qi)
+            assert np.array_equal(gid[qi, :gcnt[qi]], oid), (probes, qi, gid[qi], oid)
+            assert np.array_equal(bits(gsc[qi, :gcnt[qi]]), bits(osc)), (probes, qi)
+        assert (nd_gpu, ne_gpu) == (nd, ne), (probes, nd_gpu, nd, ne_gpu, ne)
+        assert (g.rng_state() != s0) == (probes > 1)   # the stream moves exactly when entry points are drawn
+    one = ix.search_multi_entry(Q[0], k, ef, 1)      # num_probes = 1 is the plain search
+    ref = ix._search_raw(Q[:1], k, ef, va.MODE_HNSW)
+    assert np.array_equal(one[0], ref[0]) and np.array_equal(bits(one[1]), bits(ref[1]))
+    # both level streams stand at the same place: the next (sequential) insert links the same neighbours on every layer
+    g.insert(rows[n])
+    ix.insert(n, rows[n])
+    nl, _, _ = ix.graph_info()
+    assert nl == g.num_layers
+    for layer in range(g.num_layers):
+        assert ix.neighbors(layer, n) == g.neighbors(layer, n), layer
+    with pytest.raises(va.VelesHipError):
+        ix.search_multi_entry(Q[:2], 2, 3, 3)         # several entry points need ef >= 4
+    ix.close()

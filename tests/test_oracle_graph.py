@@ -413,3 +413,48 @@ def test_hamming_canonical_vs_reference_tie_order():
         assert np.array_equal(d_r, d_c)  # same distance multiset (heap content is order-free)
         for a, b in zip(range(len(d_c) - 1), range(1, len(d_c))):
             assert (d_c[a], ids_c[a]) < (d_c[b], ids_c[b])
+
+
+def test_search_multi_entry_reference_fixtures():
+    """native/tests.rs:217-256 — the reference's two tests of NativeHnsw::search_multi_entry, on the oracle's restatement, plus
+    the stream it draws its entry points from (graph.rs:320-338): num_probes.min(4) - 1 xorshift draws per call, none for one
+    probe or a graph of <= 10 nodes."""
+    g = po.NativeHnsw(32, po.COSINE, 16, 100, po.MODE_R)
+    for i in range(50):
+        g.insert(np.array([np.sin((i + j) * 0.01) for j in range(32)], dtype=np.float32))
+    q = np.array([np.sin(j * 0.01) for j in range(32)], dtype=np.float32)
+    ids, ds = g.search_multi_entry(q, 5, 50, 3)
+    assert 0 < len(ids) <= 5 and np.all(np.diff(ds) >= 0)
+    g2 = po.NativeHnsw(32, po.EUCLIDEAN, 16, 100, po.MODE_R)
+    for i in range(30):
+        g2.insert(np.array([(i + j) * 0.1 for j in range(32)], dtype=np.float32))
+    q2 = np.array([j * 0.05 for j in range(32)], dtype=np.float32)
+    std, _ = g2.search(q2, 5, 50)
+    s0 = g2.rng_state()
+    multi, _ = g2.search_multi_entry(q2, 5, 50, 2)
+    assert len(std) > 0 and len(multi) > 0
+    s1 = g2.rng_state()
+    x = s0
+    x ^= (x << 13) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 7
+    x ^= (x << 17) & 0xFFFFFFFFFFFFFFFF
+    assert s1 == x, "two probes = one draw of the plain xorshift64 (13, 7, 17)"
+    g2.search_multi_entry(q2, 5, 50, 1)
+    assert g2.rng_state() == s1, "one probe draws nothing"
+    g2.search_multi_entry(q2, 5, 50, 9)
+    s2 = g2.rng_state()
+    for _ in range(3):   # num_probes.min(4) - 1
+        x ^= (x << 13) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 7
+        x ^= (x << 17) & 0xFFFFFFFFFFFFFFFF
+    assert s2 == x
+    small = po.NativeHnsw(4, po.EUCLIDEAN, 4, 20, po.MODE_R)
+    for i in range(10):
+        small.insert(np.full(4, float(i), dtype=np.float32))
+    t0 = small.rng_state()
+    small.search_multi_entry(np.zeros(4, np.float32), 3, 10, 4)
+    assert small.rng_state() == t0, "count <= 10: no extra entry points (graph.rs:314)"
+    # multi-entry with the full ef finds at least what the single entry finds here (same search_layer, a superset of starts)
+    same, _ = g.search_multi_entry(q, 5, 50, 1)
+    base, _ = g.search(q, 5, 50)
+    assert same.tolist() == base.tolist()

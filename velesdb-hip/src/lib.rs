@@ -376,6 +376,36 @@ impl HipHnswIndex {
         self.rerank(query, k, rerank_k, initial_quality.ef_search(rerank_k))
     }
 
+    /// `NativeHnsw::search_multi_entry` (`native/graph.rs:288-348`): the descent's result plus up to `num_probes.min(4) - 1`
+    /// nodes drawn from the graph's own xorshift stream as entry points of one layer-0 search (advances that stream, as the
+    /// reference does).
+    #[must_use]
+    pub fn search_multi_entry(&self, query: &[f32], k: usize, ef_search: usize, num_probes: usize) -> Vec<(u64, f32)> {
+        self.validate_dimension(query, "Query");
+        if k == 0 {
+            return Vec::new();
+        }
+        let mut ids = vec![0u64; k];
+        let mut scores = vec![0f32; k];
+        let mut n: u32 = 0;
+        // SAFETY: one query, k outputs.
+        check(unsafe {
+            sys::vdb_hip_index_search_multi_entry(
+                self.h,
+                query.as_ptr(),
+                1,
+                k as u32,
+                ef_search as u32,
+                num_probes as u32,
+                ids.as_mut_ptr(),
+                scores.as_mut_ptr(),
+                &mut n,
+            )
+        });
+        ids.truncate(n as usize);
+        ids.into_iter().zip(scores).collect()
+    }
+
     fn rerank(&self, query: &[f32], k: usize, rerank_k: usize, ef: usize) -> Vec<(u64, f32)> {
         self.validate_dimension(query, "Query");
         if k == 0 {

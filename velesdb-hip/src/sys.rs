@@ -112,6 +112,7 @@ extern "C" {
     pub fn vdb_hip_index_search(idx: *mut VdbHipIndex, query: *const f32, query_len: u32, k: u32, ef: u32, mode: i32, out_ids: *mut u64, out_scores: *mut f32, out_n: *mut u32) -> i32;
     pub fn vdb_hip_index_search_batch(idx: *mut VdbHipIndex, queries_rowmajor: *const f32, nq: u32, k: u32, ef: u32, mode: i32, out_ids: *mut u64, out_scores: *mut f32, out_n: *mut u32) -> i32;
     pub fn vdb_hip_index_search_rerank(idx: *mut VdbHipIndex, queries_rowmajor: *const f32, nq: u32, k: u32, rerank_k: u32, ef: u32, out_ids: *mut u64, out_scores: *mut f32, out_n: *mut u32) -> i32;
+    pub fn vdb_hip_index_search_multi_entry(idx: *mut VdbHipIndex, queries_rowmajor: *const f32, nq: u32, k: u32, ef: u32, num_probes: u32, out_ids: *mut u64, out_scores: *mut f32, out_n: *mut u32) -> i32;
     pub fn vdb_hip_index_search_batch_dev(idx: *mut VdbHipIndex, d_queries: *const f32, nq: u32, k: u32, ef: u32, mode: i32, d_out_ids: *mut u64, d_out_scores: *mut f32, d_out_n: *mut u32, stream: *mut c_void) -> i32;
     pub fn vdb_hip_batch_distance(device: i32, metric: i32, kind: i32, query: *const f32, vecs_rowmajor: *const f32, n: u64, dim: u32, out: *mut f32) -> i32;
     pub fn vdb_hip_batch_distance_dev(metric: i32, kind: i32, d_query: *const f32, d_vecs_rowmajor: *const f32, n: u64, dim: u32, d_out: *mut f32, stream: *mut c_void) -> i32;

@@ -62,6 +62,7 @@ SIGNATURES = {
     "vdb_hip_index_node_count": (_i32, [_vp, _pu64]),
     "vdb_hip_index_search": (_i32, [_vp, _vp, _u32, _u32, _u32, _i32, _vp, _vp, _pu32]),
     "vdb_hip_index_search_batch": (_i32, [_vp, _vp, _u32, _u32, _u32, _i32, _vp, _vp, _vp]),
+    "vdb_hip_index_search_multi_entry": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "vdb_hip_index_search_rerank": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "vdb_hip_index_search_batch_dev": (_i32, [_vp, _vp, _u32, _u32, _u32, _i32, _vp, _vp, _vp, _vp]),
     "vdb_hip_batch_distance": (_i32, [_i32, _i32, _i32, _vp, _vp, _u64, _u32, _vp]),

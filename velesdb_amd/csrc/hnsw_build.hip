@@ -31,7 +31,6 @@
 #include <cstring>
 #include <limits>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "vdb_hnsw_device.hpp"
 #include "vdb_index.hpp"
@@ -731,12 +730,8 @@ static int32_t graph_insert_rows_impl(vdb_hip_index* ix, uint64_t first, uint64_
   for (auto& L : ix->layers) per_node += L.stride;
   const uint32_t bmax = (uint32_t)std::min<uint64_t>(max_batch, n);
   const uint64_t req_cap = (uint64_t)bmax * per_node;
-  size_t sort_tmp = 0;
-  if (bmax > 1) {
-    e = rocprim::radix_sort_pairs(nullptr, sort_tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr,
-                                  (uint64_t*)nullptr, (size_t)req_cap, 0, 56, st);
-    if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("radix_sort size query: ") + hipGetErrorString(e));
-  }
+  const size_t sort_tmp = bmax > 1 ? radix_sort_scratch_bytes((uint32_t)std::min<uint64_t>(req_cap, 0xFFFFFFFFull)) : 0;
+  if (req_cap > 0xFFFFFFFFull) return fail(VDB_ERR_UNSUPPORTED, "graph construction: batch too large for the link-request sort");
   if ((e = ix->s_req_keys.reserve(req_cap * 8 * 2, false, st)) != hipSuccess ||
       (e = ix->s_req_vals.reserve(req_cap * 8 * 2, false, st)) != hipSuccess ||
       (e = ix->s_sort_tmp.reserve(std::max<size_t>(sort_tmp, 16), false, st)) != hipSuccess ||
@@ -800,12 +795,27 @@ static int32_t graph_insert_rows_impl(vdb_hip_index* ix, uint64_t first, uint64_
       fill_layers(ix, la.layers, nullptr);
       la.n = nreq;
       if (b > 1) {
-        size_t tmp = ix->s_sort_tmp.cap;
-        e = rocprim::radix_sort_pairs(ix->s_sort_tmp.p, tmp, keys_in, keys_out, vals_in, vals_out, (size_t)nreq, 0, 56,
-                                      st);
-        if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("radix_sort_pairs: ") + hipGetErrorString(e));
-        la.keys = keys_out;
-        la.vals = vals_out;
+        // requests grouped by (layer, target), inside a group by batch index = the order of the reference's sequential insert:
+        // stable LSD radix sort (radix_sort.hip) over the digits that can differ — batch index < b (key bits 0..), node id <
+        // node0 + b (bits 20..), layer (bits 52..55); unused slots (all ones) sort behind everything
+        RadixDigit dg[12];
+        int nd = 0;
+        auto add_field = [&](uint32_t shift, uint32_t bits) {
+          for (uint32_t o = 0; o < bits; o += 8) dg[nd++] = RadixDigit{shift + o, std::min<uint32_t>(8, bits - o)};
+        };
+        auto bits_for = [](uint64_t v) {
+          uint32_t nb = 1;
+          while (nb < 32 && (v >> nb)) nb++;
+          return nb;
+        };
+        add_field(0, std::min<uint32_t>(20, bits_for(b)));             // (all-ones slots need one bit more than b - 1: bits_for(b))
+        add_field(20, std::min<uint32_t>(32, bits_for(node0 + b)));
+        add_field(52, 4);
+        bool in_b = false;
+        e = radix_sort_pairs_u64(keys_in, vals_in, keys_out, vals_out, nreq, dg, nd, ix->s_sort_tmp.p, &in_b, st);
+        if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("link-request sort: ") + hipGetErrorString(e));
+        la.keys = in_b ? keys_out : keys_in;
+        la.vals = in_b ? vals_out : vals_in;
         la.singletons = 0;
       } else {
         la.keys = keys_in;

@@ -144,6 +144,16 @@ __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearc
           if (phase == P_START) {
             if (lane == 0) nb_id[0] = cur;
             m = 1;
+            if (layer == 0 && a.extra_eps) {  // search_multi_entry: the drawn ids that are not yet entry points (graph.rs:335-338)
+              uint32_t e0 = cur, e1 = 0xFFFFFFFFu, e2 = 0xFFFFFFFFu;
+              for (uint32_t j = 0; j < 3; j++) {
+                const uint32_t id = a.extra_eps[(size_t)qi * 3 + j];
+                if (id == 0xFFFFFFFFu || id == e0 || id == e1 || id == e2) continue;
+                if (lane == 0) nb_id[m] = id;
+                if (m == 1) e1 = id; else e2 = id;  // (a third new id has nothing behind it to be compared with)
+                m++;
+              }
+            }
             ready = true;
             phase = layer > 0 ? P_G_ENTRY : P_Z_ENTRY;
           } else if (phase == P_G_ENTRY) {
@@ -198,18 +208,22 @@ __global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearc
             layer -= 1;
             phase = P_START;
           } else if (phase == P_Z_ENTRY) {
-            const float d = rflf(nb_d[0]);
-            n_dist += 1;
-            list.insert(make_key<false>(d, cur), lane, overflow);
-            if (lane == 0) {
-              if (VIS) {
-                (void)vs.test_and_set(cur);
-              } else {
-                atomicOr(&vis[cur >> 5], 1u << (cur & 31));
-                if (a.vlog_cap) vlog[0] = cur;
+            // graph.rs:463-468: every entry point is evaluated, pushed to both heaps and marked visited (one unless search_multi_entry)
+            for (uint32_t t = 0; t < m_prev; t++) {
+              const float d = rflf(nb_d[t]);
+              const uint32_t ep = rfl(nb_id[t]);
+              n_dist += 1;
+              list.insert(make_key<false>(d, ep), lane, overflow);
+              if (lane == 0) {
+                if (VIS) {
+                  (void)vs.test_and_set(ep);
+                } else {
+                  atomicOr(&vis[ep >> 5], 1u << (ep & 31));
+                  if (a.vlog_cap) vlog[t] = ep;
+                }
               }
             }
-            logn = 1;
+            logn = m_prev;
             phase = P_Z_POP;
           } else if (phase == P_Z_POP) {
             const uint32_t idx = list.first_unexpanded(lane);
@@ -607,7 +621,7 @@ int32_t ensure_traversal_scratch(vdb_hip_index* ix, hipStream_t st, int want_slo
 // (search.rs:79-93).  Enqueues on `st`; no host synchronisation.
 int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint32_t ef,
                         uint32_t cap_mult, uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st,
-                        uint32_t rerank_k) {
+                        uint32_t rerank_k, const uint32_t* d_extra_eps) {
   if (!ix->graph_valid) return fail(VDB_ERR_STATE, "HNSW graph not built for all rows (use mode BRUTE or build it)");
   if (nq == 0) return VDB_OK;
   if (ix->entry_point < 0 || ix->graph_nodes == 0 || k == 0) {  // graph.rs:252-255: no entry point => empty
@@ -670,6 +684,7 @@ int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   a.entry_point = (uint32_t)ix->entry_point;
   a.metric = ix->metric;
   a.rerank_k = rerank_k;
+  a.extra_eps = d_extra_eps;
   a.list_slots = reg_list ? kSearchRegSlots : 0;
   a.vis_log2 = cap_mult == 1 ? 1u : 0u;  // "the LDS visited set is allowed" (a re-run after an overflow takes the bitmap)
   a.n_cus = (uint32_t)ix->n_cus;

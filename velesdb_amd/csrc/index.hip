@@ -1603,7 +1603,7 @@ static uint32_t balanced_ef(uint32_t k) { return std::max<uint32_t>(128, k * 4);
 // dispatch of search_with_quality (search.rs:59-94) for device-resident queries
 int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint32_t ef,
                    int32_t mode, uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st, uint32_t cap_mult,
-                   bool* used_hnsw, uint32_t rerank_k) {
+                   bool* used_hnsw, uint32_t rerank_k, const uint32_t* d_extra_eps) {
   if (used_hnsw) *used_hnsw = false;
   ix->ev_used = 0;
   ix->sel_ev_used = 0;
@@ -1656,7 +1656,7 @@ int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint3
   }
   if (used_hnsw) *used_hnsw = true;
   ix->last_kernels |= VDB_KERNEL_HNSW;
-  return hnsw_search_dev(ix, d_q, q_stride, nq, k, ef, cap_mult, d_ids, d_scores, d_n, st, rerank_k);
+  return hnsw_search_dev(ix, d_q, q_stride, nq, k, ef, cap_mult, d_ids, d_scores, d_n, st, rerank_k, d_extra_eps);
 }
 
 // one single-device index: HnswIndex::with_params — index/hnsw/index/constructors.rs:117-160
@@ -1781,7 +1781,8 @@ int32_t stage_queries(vdb_hip_index* ix, const float* queries, uint32_t at, uint
 // search_batch_parallel (batch.rs:159-197) / search_with_quality / search_brute_force.  staged = false: the queries already sit
 // in ix->s_queries (row_stride layout).  The traversal kernel reports (out_n = 0xFFFFFFFF) a query whose candidate list
 // overflowed its LDS capacity (only possible with many exact distance ties); such a batch is re-run with more room.
-static int32_t search_block(vdb_hip_index* ix, bool staged, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode, uint32_t rerank_k) {
+static int32_t search_block(vdb_hip_index* ix, bool staged, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode, uint32_t rerank_k,
+                            const uint32_t* d_extra_eps = nullptr) {
   hipStream_t st = ix->stream;
   const size_t kk = std::max<uint32_t>(k, 1);
   hipError_t e;
@@ -1797,7 +1798,7 @@ static int32_t search_block(vdb_hip_index* ix, bool staged, uint32_t nq, uint32_
   for (uint32_t cap_mult = 1;; cap_mult *= 4) {
     bool used_hnsw = false;
     rc = search_dev(ix, dq, ix->row_stride, nq, k, ef, mode, ix->s_out_ids.as<uint64_t>(), ix->s_out_scores.as<float>(),
-                    ix->s_out_n.as<uint32_t>(), st, cap_mult, &used_hnsw, rerank_k);
+                    ix->s_out_n.as<uint32_t>(), st, cap_mult, &used_hnsw, rerank_k, d_extra_eps);
     if (rc != VDB_OK) {
       (void)hipStreamSynchronize(st);
       return rc;
@@ -1822,8 +1823,8 @@ static int32_t search_block(vdb_hip_index* ix, bool staged, uint32_t nq, uint32_
   }
   return VDB_OK;
 }
-int32_t search_staged(vdb_hip_index* ix, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode, uint32_t rerank_k) {
-  return search_block(ix, true, nq, k, ef, mode, rerank_k);
+int32_t search_staged(vdb_hip_index* ix, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode, uint32_t rerank_k, const uint32_t* d_extra_eps) {
+  return search_block(ix, true, nq, k, ef, mode, rerank_k, d_extra_eps);
 }
 
 // host queries -> results in ix->s_out_* on the device AND in ix->h_out (same layout); out_n also in the caller's array.

@@ -332,6 +332,48 @@ int32_t vdb_hip_index_search(vdb_hip_index* ix, const float* query, uint32_t que
   });
 }
 
+// NativeHnsw::search_multi_entry — index/hnsw/native/graph.rs:288-348.  The extra entry points come out of the graph's own
+// xorshift stream (the one that draws insertion levels): the call CHANGES the index (exclusive lock), query i of the batch takes
+// draws i (min(num_probes, 4) - 1) .. of it, exactly as nq sequential calls of the reference would.
+int32_t vdb_hip_index_search_multi_entry(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, uint32_t num_probes,
+                                         uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
+  return vdb::guarded([&]() -> int32_t {
+    if (!ix || (nq && (!queries || !out_n)) || (nq && k && (!out_ids || !out_scores))) return fail(VDB_ERR_INVALID_ARG, "null argument");
+    VDB_NO_GROUP(ix, "search_multi_entry");
+    if (nq == 0) return VDB_OK;
+    if (ix->pcomm) return fail(VDB_ERR_UNSUPPORTED, "search_multi_entry: not available on a member of a process group");
+    std::lock_guard<vdb::IndexMutex> g(ix->mu);
+    VDB_ENTER(ix);
+    if (!ix->graph_valid) return fail(VDB_ERR_STATE, "HNSW graph not built for all rows (use mode BRUTE or build it)");
+    ef = std::max(ef ? ef : std::max<uint32_t>(128, 4 * k), k);  // (SearchQuality rules of vdb_hip_index_search)
+    const uint32_t draws = (num_probes > 1 && ix->graph_nodes > 10) ? std::min<uint32_t>(num_probes, 4) - 1 : 0;
+    if (draws && ef < 4) return fail(VDB_ERR_UNSUPPORTED, "search_multi_entry: ef_search >= 4 with several entry points");
+    const uint32_t* d_extra = nullptr;
+    if (draws) {
+      std::vector<uint32_t> extra((size_t)nq * 3, 0xFFFFFFFFu);
+      for (uint32_t q = 0; q < nq; q++)
+        for (uint32_t p = 0; p < draws; p++) {
+          uint64_t s = ix->rng_state;  // graph.rs:320-334 (no zero-state reseed here)
+          s ^= s << 13;
+          s ^= s >> 7;
+          s ^= s << 17;
+          ix->rng_state = s;
+          extra[(size_t)q * 3 + p] = (uint32_t)(s % ix->graph_nodes);
+        }
+      if (ix->s_part_cnt.reserve(extra.size() * 4, false, ix->stream) != hipSuccess) return fail(VDB_ERR_OOM, "entry-point scratch");
+      VDB_HIP(hipMemcpyAsync(ix->s_part_cnt.p, extra.data(), extra.size() * 4, hipMemcpyHostToDevice, ix->stream));
+      VDB_HIP(hipStreamSynchronize(ix->stream));  // `extra` is host memory
+      d_extra = ix->s_part_cnt.as<uint32_t>();
+    }
+    int32_t rc = stage_queries(ix, queries, 0, nq, nq);
+    if (rc != VDB_OK) return rc;
+    rc = search_staged(ix, nq, k, ef, VDB_SEARCH_HNSW, 0, d_extra);
+    if (rc != VDB_OK) return rc;
+    deliver_slice(ix, 0, nq, nq, k, out_ids, out_scores, out_n);
+    return VDB_OK;
+  });
+}
+
 int32_t vdb_hip_index_combine_stats(vdb_hip_index* ix, uint64_t* launches, uint64_t* calls, uint64_t* queries, uint64_t* max_batch) {
   return vdb::guarded([&]() -> int32_t {
     if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");

@@ -320,7 +320,7 @@ void destroy_single(vdb_hip_index* ix);
 // search_with_quality dispatch for device-resident queries (enqueue only; see index.hip)
 int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint32_t ef,
                    int32_t mode, uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st, uint32_t cap_mult = 1,
-                   bool* used_hnsw = nullptr, uint32_t rerank_k = 0);
+                   bool* used_hnsw = nullptr, uint32_t rerank_k = 0, const uint32_t* d_extra_eps = nullptr);
 // host queries -> results in ix->s_out_ids / s_out_scores / s_out_n on the device (out_n also on the host); the caller
 // holds ix->mu.  Re-runs HNSW batches whose candidate list overflowed.
 int32_t search_to_device(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode,
@@ -331,7 +331,8 @@ int32_t reserve_out(vdb_hip_index* ix, uint32_t nq, size_t kk, hipStream_t st);
 // slot `at` (row_stride layout, padding zeroed); the staged rows up, the search, the whole result block back into h_out and ONE
 // synchronisation (re-runs HNSW batches whose candidate list overflowed)
 int32_t stage_queries(vdb_hip_index* ix, const float* queries, uint32_t at, uint32_t nq, uint32_t nq_total);
-int32_t search_staged(vdb_hip_index* ix, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode, uint32_t rerank_k);
+int32_t search_staged(vdb_hip_index* ix, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode, uint32_t rerank_k,
+                      const uint32_t* d_extra_eps = nullptr);
 // effective option values (index.hip)
 int64_t opt_value(const vdb_hip_index* ix, int32_t option);
 bool mode_higher_is_better(int metric, int32_t mode);
@@ -364,7 +365,7 @@ EventPair* next_events(vdb_hip_index* ix);  // nullptr when kernel timing is off
 // hnsw_kernels.hip; cap_mult scales the room for tie candidates beyond ef (1 = default)
 int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint32_t ef,
                         uint32_t cap_mult, uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st,
-                        uint32_t rerank_k = 0);
+                        uint32_t rerank_k = 0, const uint32_t* d_extra_eps = nullptr);
 // hnsw_build.hip; max_batch 1 = the reference's sequential insert, 0 = default batched schedule
 int32_t graph_insert_rows(vdb_hip_index* ix, uint64_t first, uint64_t n, uint32_t max_batch);
 int32_t ensure_traversal_scratch(vdb_hip_index* ix, hipStream_t st, int want_slots = 0);

@@ -138,6 +138,9 @@ struct HnswSearchArgs {
                         // revisit most neighbours)
   uint32_t rerank_k;  // > 0: search_with_rerank (search.rs:118-160): the first rerank_k results are re-scored with the
                       // raw compute_distance, stable-sorted in the metric's order and cut to k
+  // NativeHnsw::search_multi_entry (graph.rs:288-348): nullable; [nq][3] node ids drawn by the host from the graph's xorshift
+  // stream (0xFFFFFFFF = no draw): further entry points of the layer-0 search beside the descent's result, duplicates skipped
+  const uint32_t* extra_eps;
 };
 size_t hnsw_lds_bytes(uint32_t cap, uint32_t nbmax, uint32_t dim, uint32_t words, int metric);  // without the visited set
 // returns hipSuccess or the launch error; grid = slots blocks of 256 threads
@@ -314,6 +317,13 @@ struct BitsPlan {
 };
 BitsPlan plan_bits_sweep(uint64_t n_rows, int n_cus, uint32_t words, uint32_t nq, uint32_t k);
 hipError_t launch_bits_plan(int metric, const BitsPlan& p, const BitsArgs& a, uint32_t nq, hipStream_t st);
+// radix_sort.hip: hand-written stable LSD radix sort of (u64 key, u64 value) pairs by a list of digits (<= 8 bits each)
+struct RadixDigit {
+  uint32_t shift, bits;
+};
+size_t radix_sort_scratch_bytes(uint32_t n);
+hipError_t radix_sort_pairs_u64(uint64_t* keys_a, uint64_t* vals_a, uint64_t* keys_b, uint64_t* vals_b, uint32_t n, const RadixDigit* digits,
+                                int n_digits, void* scratch, bool* result_in_b, hipStream_t st);
 void launch_prep_rows(const PrepArgs& a, hipStream_t st);
 void launch_score_rows(int metric, const ScoreArgs& a, hipStream_t st);
 

@@ -258,6 +258,21 @@ class HnswIndex:
         check(lib().vdb_hip_index_search_rerank(self._h, _ptr(q), 1, k, rerank_k, ef, _ptr(ids), _ptr(sc), _ptr(cnt)))
         return self._tuples(ids[0], sc[0], cnt[0])
 
+    def search_multi_entry(self, queries, k: int, ef_search: int, num_probes: int):
+        """NativeHnsw::search_multi_entry (native/graph.rs:288-348) for a batch: the descent's result plus up to
+        min(num_probes, 4) - 1 nodes drawn from the graph's own xorshift stream as entry points of one layer-0 search.  Like the
+        reference it advances that stream (query i takes the draws nq sequential calls would give it).  numpy outputs."""
+        qs = _f32(queries)
+        if qs.ndim == 1:
+            qs = qs.reshape(1, -1)
+        self._validate(qs)
+        nq, kk = qs.shape[0], max(k, 1)
+        ids = np.empty((nq, kk), dtype=np.uint64)
+        sc = np.empty((nq, kk), dtype=np.float32)
+        cnt = np.zeros(nq, dtype=np.uint32)
+        check(lib().vdb_hip_index_search_multi_entry(self._h, _ptr(qs), nq, k, ef_search, num_probes, _ptr(ids), _ptr(sc), _ptr(cnt)))
+        return ids, sc, cnt
+
     def train_quantizer(self, sample_rows: int = 0) -> None:
         """ScalarQuantizer::train on the first sample_rows rows (0 = min(1000, rows)) + u8 codes of every row."""
         check(lib().vdb_hip_index_train_quantizer(self._h, sample_rows))
