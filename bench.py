@@ -221,6 +221,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def gather_rows(vals, names):
+        """one row of floats per rank -> list of dicts on every rank (rank order)"""
+        mine_ = torch.tensor(vals, device=dev, dtype=torch.float64)
+        rows_ = [torch.zeros_like(mine_) for _ in range(world)] if use_dist else [mine_]
+        if use_dist:
+            dist.all_gather(rows_, mine_)
+        return [{n_: (int(v) if n_ in ("rank", "rows") else round(float(v), 4)) for n_, v in zip(names, r_.tolist())} for r_ in rows_]
+
     def max_over_ranks(x):
         if use_dist:
             t = torch.tensor([x], device=dev, dtype=torch.float64)
@@ -246,6 +254,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
+    torch.cuda.synchronize()
+    dt_mine = time.perf_counter() - t0  # this rank's own steps (the timed region below ends behind the barrier: the slowest rank's)
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms, kernel_launches = ix.last_kernel_ms()  # HIP events around the sweep kernel, last step
@@ -253,6 +263,7 @@ def main():
     va.set_kernel_timing(False)
     dt = max_over_ranks(dt)
     qps = world * Q * a.steps / dt
+    replicas_per_rank = gather_rows([float(rank), Q * a.steps / dt_mine], ("rank", "qps"))
 
     # ---- roofline of the dominant kernel (the sweep): algorithmic bytes / measured duration ----
     mfma = a.engine == 1 and a.metric in ("cosine", "dot")
@@ -546,7 +557,8 @@ def main():
         for _ in range(a.hnsw_steps):
             hstep()
         barrier()
-        hdt = max_over_ranks(time.perf_counter() - th)
+        hdt_mine = time.perf_counter() - th
+        hdt = max_over_ranks(hdt_mine)
         hk_ms, hk_n = ix.last_kernel_ms()
         va.set_kernel_timing(False)
         n_dist, n_expand = ix.last_search_stats()  # of the last batch
@@ -570,6 +582,11 @@ def main():
                              "kernel_ms": round(hk_ms, 4), "launches_timed": hk_n,
                              "alg_bytes_per_launch": hbytes,
                              "alg_bytes_rule": "n_dist*dim*4 + n_expand*M0*4, counters from the kernel"}}
+        # the replica leg of the graph path (the 3.3 GB index fits every GPU; the query stream is split, no collective):
+        # every rank's own rate and recall, so that a SCALE run shows the curve per GPU and not only the aggregate
+        hnsw["replicas"] = {"ranks": world, "parallelism": "replicas x%d (every rank holds the whole graph and answers its own %d queries per step; no collective)" % (world, HQ),
+                            "per_rank": gather_rows([float(rank), HQ * a.hnsw_steps / hdt_mine, recall_h, float(ix.len())],
+                                                    ("rank", "qps", "recall_at_10", "rows"))}
         # recall / QPS curve over ef_search (SearchQuality presets Fast 64 / Balanced 128 / ... , params.rs:309-319): the
         # "QPS @ recall@10" metric as a curve; the CPU baseline fills in its side of every point below
         ef_list = [int(x) for x in a.ef_curve.split(",") if x.strip()]
@@ -1351,7 +1368,15 @@ def main():
             for i in range(a.steps):
                 sharded_step(a.warmup + i)
             barrier()
-            sdt = max_over_ranks(time.perf_counter() - t2)
+            sdt_mine = time.perf_counter() - t2
+            sdt = max_over_ranks(sdt_mine)
+            # every rank ends every step with the GLOBAL top-k: the ranks' results must be identical (a checksum of checksums —
+            # the size-independent parity property of the sharded path; the world-1 run also compares with the unsharded bits)
+            torch.cuda.synchronize()
+            csum = float((out_ids.to(torch.float64).sum() + out_sc.to(torch.float64).sum()).item())
+            rows_sh = gather_rows([float(rank), Q * a.steps / sdt_mine, csum], ("rank", "qps", "result_checksum"))
+            sharded["per_rank_rate"] = rows_sh
+            sharded["results_identical_across_ranks"] = bool(all(r_["result_checksum"] == rows_sh[0]["result_checksum"] for r_ in rows_sh))
             sharded.update({"qps": round(Q * a.steps / sdt, 1), "corpus_rows": world * SR, "rows_per_shard": SR,
                             "ranks": world, "ms_per_step": round(sdt / a.steps * 1e3, 4),
                             "transport": ix_sh.shard_info()["transport"],
@@ -1391,17 +1416,31 @@ def main():
                                    f"({roofline['kernel']})",
                        "rows": N, "dim": D, "k": K, "queries_per_step": Q,
                        "parallelism": "replicas x%d (query stream split, no collective)" % world},
+            "replicas_per_rank": replicas_per_rank,
             "recall_at_10": recall, "parity_check": check,
             "frac_step": (roofline.get("whole_batch") or {}).get("frac"),  # the headline's algorithmic flop over the WHOLE step's time / peak
             "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "tiles": tiles, "batch_sizes_default_path": batch_sizes, "host_entry": host_entry, "sharded": sharded,
             "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb, "config0_10k": config0, "bf16_gemm": bf16_leg, "sq8_storage_mode": sq8_leg, "other_metrics": metrics_leg,
             "device": va.device_name(local), "device_state": device_state,
         }
+    # a multi-GPU run that is not what --gpus asked for must not pass for one: rank 0 checks the group the library reports
+    bad_group = None
+    if rank == 0 and world > 1:
+        if a.gpus != world:
+            bad_group = f"--gpus {a.gpus} but the process group has {world} ranks"
+        elif sharded is not None and not sharded.get("group_ok", False):
+            bad_group = "the shard group is not world == n_gpus over transport rccl on every rank: " + json.dumps(sharded.get("per_rank") or sharded.get("error"))
+        elif sharded is not None and sharded.get("results_identical_across_ranks") is False:
+            bad_group = "the ranks of the sharded leg ended with different merged results"
+        if bad_group:
+            line["error"] = bad_group
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
+        if bad_group:
+            raise SystemExit("bench.py: " + bad_group)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,55 @@
+"""DESIGN §6b claims that no result depends on a diagnostic environment switch (A / B probes read once when the library is
+loaded).  This file PROVES it for the switches that select another kernel or another schedule: the parity tests of the path a
+switch touches are run again, in a child process with the switch set — the same assertions (ids, ranks, score bits, counters
+against the oracle) must hold.
+
+  VELESDB_BF16_PP=0               lock-step LDS-DMA kernel instead of the ping-pong one      -> split / bf16 result-mode tests
+  VELESDB_BF16_SEED=0             exact f32 seed sweep instead of the bf16 sample seed       -> split tests
+  VELESDB_SEL_STEPS=2,0,0         another launch schedule of the selection stage             -> split tests
+  (VELESDB_SELECT_MIN_QUERIES only moves the size from which the stage takes a batch — tests/test_gpu_split.py compares the stage
+   with the exact kernels on both sides of it, and asserts WHICH path served a batch, so it is not re-run under another value)
+  VELESDB_HNSW_LATENCY_MODE=0|2|3 throughput kernel only / latency-mode kernel forced with and without row speculation -> graph tests
+  VELESDB_HNSW_VIS_LDS=1          LDS visited set in the throughput walk                      -> graph tests
+  VELESDB_INT8_VIS_LDS=1, VELESDB_I8_WAVES2=0   the int8 walk's variants                      -> int8 tests
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+va = pytest.importorskip("velesdb_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (a subset per switch keeps the file to a few minutes: the small random-data cases at both selection levels, the tie / duplicate /
+# non-finite / soft-delete cases, the Euclidean form)
+SPLIT = ["tests/test_gpu_split.py", "-k",
+         "(random_data and (70000-128 or 66000-64)) or massive_exact_ties or zero_huge or soft_deleted or (euclidean_batches and 70000-128-256)"]
+BF16 = ["tests/test_gpu_bf16.py", "-k", "glds_exact_products and 70077"]
+GRAPH = ["tests/test_gpu_hnsw.py"]
+INT8 = ["tests/test_gpu_int8.py"]
+
+CASES = [
+    ({"VELESDB_BF16_PP": "0"}, SPLIT),
+    ({"VELESDB_BF16_PP": "0"}, BF16),
+    ({"VELESDB_BF16_SEED": "0"}, SPLIT),
+    ({"VELESDB_SEL_STEPS": "2,0,0"}, SPLIT),
+    ({"VELESDB_HNSW_LATENCY_MODE": "0"}, GRAPH),
+    ({"VELESDB_HNSW_LATENCY_MODE": "2"}, GRAPH),
+    ({"VELESDB_HNSW_LATENCY_MODE": "3"}, GRAPH),
+    ({"VELESDB_HNSW_VIS_LDS": "1"}, GRAPH),
+    ({"VELESDB_INT8_VIS_LDS": "1"}, INT8),
+    ({"VELESDB_I8_WAVES2": "0"}, INT8),
+]
+
+
+@pytest.mark.parametrize("env,target", CASES, ids=[",".join(f"{k}={v}" for k, v in e.items()) + ":" + t[0].split("/")[-1] for e, t in CASES])
+def test_parity_holds_under_the_switch(gpu_required, env, target):
+    child_env = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", *target], cwd=ROOT, env=child_env,
+                       capture_output=True, text=True, timeout=900)
+    tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]
+    assert r.returncode == 0, f"parity broke under {env}:\n{tail}"
+    assert " passed" in r.stdout and " failed" not in r.stdout, tail

@@ -157,24 +157,15 @@ int32_t brute_bits_gemm_dev(vdb_hip_index* ix, const uint32_t* qbits, uint32_t n
   const bool hib = ix->metric == VDB_JACCARD;
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
   const uint32_t n = (uint32_t)ix->n_rows, stride = bits_image_stride(ix->dim), dim2 = stride / 2;  // the kernel's unit: two bytes
-  // Launch schedule: the sample seed over the first rows (bounds only), then the byte GEMM over [0, R1) and launches of <= 2 M
-  // rows; every launch starts from the k-th best key over all rows before it (as the bf16 result path, index.hip brute_bf16_dev)
+  // Launch schedule: the sample seed over the first rows (bounds only), then the byte GEMM in launches of growing size (gemm_schedule,
+  // vdb_kernels.hpp); every launch starts from the k-th best key over all rows before it
   const uint32_t R0 = kBitsSeedRows;
-  uint32_t R1 = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(1u << 18, ((uint64_t)n / 16 + 255) / 256 * 256));
-  if (n - R1 < (1u << 18)) R1 = n;
-  constexpr uint32_t kMaxLaunchRows = 1u << 21;
-  constexpr int kMaxLaunches = 64;
-  Bf16GemmPlan bp[kMaxLaunches];
-  int n_launch = 0;
-  sweep_gemm_bf16_plan(nqg, 0, R1, ix->n_cus, &bp[n_launch++]);
-  for (uint32_t lo = R1; lo < n;) {
-    uint32_t hi = (uint32_t)std::min<uint64_t>(n, (uint64_t)lo + kMaxLaunchRows);
-    if (n - hi < (1u << 19) || n_launch == kMaxLaunches - 1) hi = n;
-    sweep_gemm_bf16_plan(nqg, lo, hi, ix->n_cus, &bp[n_launch++]);
-    lo = hi;
+  GemmSchedule sch;
+  {
+    const uint32_t head[3] = {1u, 4u, 16u};  // (the bound of a 4 096-row sample is weak: the first launches stay small)
+    gemm_schedule(nqg, 0, n, ix->n_cus, head, 1u << 21, &sch);
   }
-  uint32_t lists = 0;
-  for (int j = 0; j < n_launch; j++) lists += bp[j].G;
+  const uint32_t lists = sch.lists;
   const uint32_t seed_lists = R0 / 16u;  // one key per 16 seed rows
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -219,21 +210,18 @@ int32_t brute_bits_gemm_dev(vdb_hip_index* ix, const uint32_t* qbits, uint32_t n
     ms.k_out = 0;
   }
   ms.k = k;
-  uint32_t list_off = 0;
-  for (int j = 0; j < n_launch; j++) {
-    e = launch_sweep_gemm_bf16_glds(ix->metric, bp[j], reinterpret_cast<const uint16_t*>(ix->bits_img.p), dim2, ix->bits_cnt.as<float>(), alive,
-                                    reinterpret_cast<const uint16_t*>(qimg), dim2, tau0, parts, lists, list_off, dim2, nqg, k, st,
-                                    /*split=*/false, nullptr, nullptr, qcnt);
-    if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("bit-metric GEMM launch: ") + hipGetErrorString(e));
-    list_off += bp[j].G;
-    if (j + 1 < n_launch) {  // bound of the next launch: k-th best key over everything swept so far
-      ms.part_keys = parts;
-      ms.n_lists = list_off;      // the lists written so far ...
-      ms.list_stride = lists;     // ... of `lists` per query
-      launch_merge(hib, ms, nqg, st);
-      launch_seed_tau(ms.out_ids, ms.out_scores, ms.out_n, tau0, nullptr, 0, nqg, k, st, hib);
-    }
-  }
+  e = run_gemm_schedule(
+      sch, ix->metric, reinterpret_cast<const uint16_t*>(ix->bits_img.p), dim2, ix->bits_cnt.as<float>(), alive, reinterpret_cast<const uint16_t*>(qimg), dim2,
+      tau0, parts, lists, /*list_first=*/0, dim2, nqg, k, st, /*split=*/false, nullptr, nullptr, qcnt, [](int) {},
+      [&](int, uint32_t list_off, bool last) {
+        if (last) return;  // bound of the next launch: k-th best key over everything swept so far
+        ms.part_keys = parts;
+        ms.n_lists = list_off;   // the lists written so far ...
+        ms.list_stride = lists;  // ... of `lists` per query
+        launch_merge(hib, ms, nqg, st);
+        launch_seed_tau(ms.out_ids, ms.out_scores, ms.out_n, tau0, nullptr, 0, nqg, k, st, hib);
+      });
+  if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("bit-metric GEMM launch: ") + hipGetErrorString(e));
   if (evg) (void)hipEventRecord(evg->b, st);
   MergeArgs mg{};
   mg.part_keys = parts;

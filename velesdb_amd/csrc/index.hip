@@ -413,24 +413,14 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
         // launches write their partial lists into one [nq][lists][k] array that the final merge scans once.
         const uint32_t n = (uint32_t)ix->n_rows;
         const uint32_t R0 = kGemmBf16SeedRows;
-        uint32_t R1 = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(R0 + (1u << 18), R0 + (n / 16 + 255) / 256 * 256));
-        if (n - R1 < (1u << 18)) R1 = n;  // a short tail is not worth a launch of its own
-        // ... and no launch longer than kGemmBf16MaxLaunchRows: the query tiles of a row group share their row tiles through one
-        // XCD's L2 only while they run in step, and over hundreds of row tiles they drift apart (10 M rows in one launch:
-        // FETCH_SIZE 2.1 x the corpus; in launches of 2 M rows: see profiles/).  A boundary costs one merge + re-seed (~20 us).
-        constexpr uint32_t kGemmBf16MaxLaunchRows = 1u << 21;
-        constexpr int kMaxLaunches = 64;
-        Bf16GemmPlan bp[kMaxLaunches];
-        int n_launch = 0;
-        sweep_gemm_bf16_plan(nqg, R0, R1, ix->n_cus, &bp[n_launch++]);
-        for (uint32_t lo = R1; lo < n;) {
-            uint32_t hi = (uint32_t)std::min<uint64_t>(n, (uint64_t)lo + kGemmBf16MaxLaunchRows);
-            if (n - hi < (1u << 19) || n_launch == kMaxLaunches - 1) hi = n;  // (a short tail joins the launch in front of it)
-            sweep_gemm_bf16_plan(nqg, lo, hi, ix->n_cus, &bp[n_launch++]);
-            lo = hi;
+        // first launch: ~max(2^18, n / 16) rows, then launches of <= 2 M rows (gemm_schedule, vdb_kernels.hpp)
+        GemmSchedule sch;
+        {
+          const uint32_t G2 = (uint32_t)std::max(8, ix->n_cus / (int)((nqg + 255) / 256) / 8 * 8);
+          const uint32_t head[3] = {(uint32_t)((std::max<uint64_t>(1u << 18, n / 16) + (uint64_t)G2 * 256 - 1) / ((uint64_t)G2 * 256)), 0u, 0u};
+          gemm_schedule(nqg, R0, n, ix->n_cus, head, 1u << 21, &sch);
         }
-        uint32_t lists = 1;
-        for (int j = 0; j < n_launch; j++) lists += bp[j].G;
+        const uint32_t lists = 1 + sch.lists;
         GemmPlan sp;  // seeding sweep over the first rows
         sweep_gemm_plan(nqg, R0, ix->n_cus, k, &sp, /*allow_big=*/false);
         const size_t off_ids = ((size_t)nqg * sp.G * k * 8 + 15) & ~(size_t)15, off_sc = off_ids + (size_t)nqg * k * 8,
@@ -468,20 +458,17 @@ static int32_t brute_bf16_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_st
         ms.k = k;
         launch_merge(true, ms, nqg, st);
         launch_seed_tau(ms.out_ids, ms.out_scores, ms.out_n, tau0, parts, lists, nqg, k, st);  // list 0 = the seed's top-k
-        uint32_t list_off = 1;
-        for (int j = 0; j < n_launch; j++) {
-          e3 = launch_sweep_gemm_bf16_glds(ix->metric, bp[j], ix->rows_bf16.as<uint16_t>(), ix->bf16_stride,
-                                           ix->norms_bf16.as<float>(), alive, q16, ix->bf16_stride, tau0, parts, lists,
-                                           list_off, ix->dim, nqg, k, st, /*split=*/false, nullptr, nullptr, qn_half);
-          if (e3 != hipSuccess) return fail(VDB_ERR_HIP, std::string("bf16 gemm sweep launch: ") + hipGetErrorString(e3));
-          list_off += bp[j].G;
-          if (j + 1 < n_launch) {  // bound for the next launch: k-th best key over everything swept so far
-            ms.part_keys = parts;
-            ms.n_lists = lists;
-            launch_merge(true, ms, nqg, st);
-            launch_seed_tau(ms.out_ids, ms.out_scores, ms.out_n, tau0, nullptr, 0, nqg, k, st);
-          }
-        }
+        e3 = run_gemm_schedule(
+            sch, ix->metric, ix->rows_bf16.as<uint16_t>(), ix->bf16_stride, ix->norms_bf16.as<float>(), alive, q16, ix->bf16_stride, tau0, parts, lists,
+            /*list_first=*/1, ix->dim, nqg, k, st, /*split=*/false, nullptr, nullptr, qn_half, [](int) {},
+            [&](int, uint32_t, bool last) {
+              if (last) return;  // bound for the next launch: k-th best key over everything swept so far
+              ms.part_keys = parts;
+              ms.n_lists = lists;
+              launch_merge(true, ms, nqg, st);
+              launch_seed_tau(ms.out_ids, ms.out_scores, ms.out_n, tau0, nullptr, 0, nqg, k, st);
+            });
+        if (e3 != hipSuccess) return fail(VDB_ERR_HIP, std::string("bf16 gemm sweep launch: ") + hipGetErrorString(e3));
         if (evg) (void)hipEventRecord(evg->b, st);
         MergeArgs mg{};
         mg.part_keys = parts;
@@ -906,12 +893,8 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   // one key per 16 rows instead of all of them (33 MB of keys and a 55-us merge per batch otherwise)
   const bool bf16_seed = level >= 2 && g_bf16_seed;
   const uint32_t row_first = bf16_seed ? 0u : R0;
-  const uint32_t tiles_all = (n - row_first + 255) / 256;
-  const uint32_t G2 = (uint32_t)std::max(8, ix->n_cus / (int)((nqg + 255) / 256) / 8 * 8);
-  Bf16GemmPlan bp[4];
-  int n_launch = 0;
+  GemmSchedule sch;
   {
-    uint32_t lo = row_first, left = tiles_all;
     // (VELESDB_SEL_STEPS="a,b,c": tiles per row group of the first launches — schedule probes)
     static const std::array<uint32_t, 3> mult = [] {
       std::array<uint32_t, 3> m{1, 4, 16};
@@ -922,21 +905,10 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
       }
       return m;
     }();
-    const uint32_t steps[3] = {mult[0] * G2, mult[1] * G2, mult[2] * G2};
-    int ns = 0;
-    while (ns < 3 && steps[ns]) ns++;
-    for (int j = 0; j < ns && left >= 2 * steps[j]; j++) {  // (the rest must be worth at least as much again)
-      uint32_t t = steps[j];
-      if (j == ns - 1 || left < 2 * steps[j + 1]) t += (left - t) % G2;  // the launch behind this one is the last: whole row tiles per row group
-      const uint32_t hi = lo + t * 256;
-      sweep_gemm_bf16_plan(nqg, lo, hi, ix->n_cus, &bp[n_launch++]);
-      lo = hi;
-      left -= t;
-    }
-    sweep_gemm_bf16_plan(nqg, lo, n, ix->n_cus, &bp[n_launch++]);
+    const uint32_t head[3] = {mult[0], mult[1], mult[2]};
+    gemm_schedule(nqg, row_first, n, ix->n_cus, head, 0, &sch);
   }
-  uint32_t lists = 1;
-  for (int j = 0; j < n_launch; j++) lists += bp[j].G;
+  const uint32_t lists = 1 + sch.lists;
   GemmPlan sp, fp;  // exact kernel: seed sweep over the first rows; fallback over everything
   sweep_gemm_plan(nqg, R0, ix->n_cus, k, &sp);
   sweep_gemm_plan(nqg, n, ix->n_cus, k, &fp);
@@ -1058,27 +1030,30 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   else
     launch_split_seed(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim, level, st, rho_q, rho_max);
   // selection launches over the split images
-  uint32_t list_off = 1;
-  for (int j = 0; j < n_launch; j++) {
-    EventPair* evs = next_sel_events(ix);
-    if (evs) (void)hipEventRecord(evs->a, st);
-    e = launch_sweep_gemm_bf16_glds(sel_metric, bp[j], img_rows, img_stride, sel_norms, alive, q16, img_stride, tau0, pool, lists, list_off,
-                                    l2 ? dim_a : dim, nqg, ks, st, /*split=*/level < 2, qnorms, blk_tau);
-    if (evs) (void)hipEventRecord(evs->b, st);
+  {
+    EventPair* evs = nullptr;
+    e = run_gemm_schedule(
+        sch, sel_metric, img_rows, img_stride, sel_norms, alive, q16, img_stride, tau0, pool, lists, /*list_first=*/1, l2 ? dim_a : dim, nqg, ks, st,
+        /*split=*/level < 2, qnorms, blk_tau, nullptr,
+        [&](int) {
+          evs = next_sel_events(ix);
+          if (evs) (void)hipEventRecord(evs->a, st);
+        },
+        [&](int, uint32_t list_off, bool last) {
+          if (evs) (void)hipEventRecord(evs->b, st);
+          if (last) return;  // bound of the next launch: k-th best pool score so far (the lists written so far)
+          ms.part_keys = pool;
+          ms.n_lists = list_off;
+          ms.list_stride = lists;
+          ms.k = ks;
+          ms.k_out = k;
+          ms.reseed_delta = delta;  // ... and the bound itself, in the merge's own pass (sweep_split.hip split_reseed_kernel's rule)
+          ms.reseed_tau = tau0;
+          ms.reseed_k = k;
+          launch_merge(true, ms, nqg, st);
+          ms.reseed_delta = nullptr;
+        });
     if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split selection launch: ") + hipGetErrorString(e));
-    list_off += bp[j].G;
-    if (j + 1 < n_launch) {  // bound of the next launch: k-th best pool score so far (the lists written so far)
-      ms.part_keys = pool;
-      ms.n_lists = list_off;
-      ms.list_stride = lists;
-      ms.k = ks;
-      ms.k_out = k;
-      ms.reseed_delta = delta;  // ... and the bound itself, in the merge's own pass (sweep_split.hip split_reseed_kernel's rule)
-      ms.reseed_tau = tau0;
-      ms.reseed_k = k;
-      launch_merge(true, ms, nqg, st);
-      ms.reseed_delta = nullptr;
-    }
   }
   // pool -> K2 best by pool score -> exact re-scoring, ranking, proof
   ms.part_keys = pool;

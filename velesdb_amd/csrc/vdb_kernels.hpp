@@ -203,10 +203,48 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
                                        const uint64_t* tau0, uint64_t* part_keys, uint32_t list_stride, uint32_t list_off,
                                        uint32_t dim, uint32_t nq, uint32_t k, hipStream_t st, bool split = false,
                                        const float* qnorms = nullptr, uint64_t* blk_tau = nullptr, const float* qnorms_half = nullptr);
+// ---- ONE launch schedule for every user of the 256 x 256 selection kernel (the bf16 result path and the exact / SQ8 selection
+// stage of index.hip, the bit metrics of bits_gemm.hip): a corpus is swept in a few launches of growing size, each starting from
+// bounds re-seeded out of everything swept before it — a block's epilogue costs ~0.2 us per candidate it has to finish, so the
+// rows swept under a weak bound are kept few.
+constexpr int kGemmMaxLaunches = 64;
+struct GemmSchedule {
+  Bf16GemmPlan bp[kGemmMaxLaunches];
+  int n_launch = 0;
+  uint32_t lists = 0;  // row groups (= partial lists per query) over all launches
+};
+// rows [row_first, n): `head_tiles[i]` (x the row groups the chip holds at once) 256-row tiles per row group for the first launches
+// (0 = none; a step is taken only while at least as much again is left), then launches of <= max_launch_rows rows (0 = one launch
+// for the rest).  A launch boundary costs one merge + re-seed (~20 us); launches longer than ~2 M rows let the query tiles of a row
+// group drift apart in L2 (10 M rows in one launch: 2.1 x the corpus from HBM).
+void gemm_schedule(uint32_t nq, uint32_t row_first, uint32_t n, int n_cus, const uint32_t head_tiles[3], uint32_t max_launch_rows, GemmSchedule* s);
+// the launches of a schedule: pre(j) in front of launch j, post(j, lists_written, last) behind it (the merge + re-seed between two
+// launches belongs there); partial lists land at list_first + the row groups before the launch
+template <class Pre, class Post>
+static inline hipError_t run_gemm_schedule(const GemmSchedule& s, int metric, const uint16_t* rows16, uint64_t row_stride, const float* norms,
+                                           const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride, const uint64_t* tau0, uint64_t* part_keys,
+                                           uint32_t list_stride, uint32_t list_first, uint32_t dim, uint32_t nq, uint32_t k, hipStream_t st, bool split,
+                                           const float* qnorms, uint64_t* blk_tau, const float* qnorms_half, Pre&& pre, Post&& post);
 // norms of the rounded queries of a result-mode batch (qnorms_half above)
 void launch_query_norms_bf16(const uint16_t* q16, uint64_t q_stride, float* out, uint32_t nq, uint32_t dim, hipStream_t st);
 void launch_seed_tau(const uint64_t* ids, const float* scores, const uint32_t* n, uint64_t* tau0, uint64_t* list,
                      uint32_t list_stride, uint32_t nq, uint32_t k, hipStream_t st, bool hib = true);
+template <class Pre, class Post>
+static inline hipError_t run_gemm_schedule(const GemmSchedule& s, int metric, const uint16_t* rows16, uint64_t row_stride, const float* norms,
+                                           const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride, const uint64_t* tau0, uint64_t* part_keys,
+                                           uint32_t list_stride, uint32_t list_first, uint32_t dim, uint32_t nq, uint32_t k, hipStream_t st, bool split,
+                                           const float* qnorms, uint64_t* blk_tau, const float* qnorms_half, Pre&& pre, Post&& post) {
+  uint32_t list_off = list_first;
+  for (int j = 0; j < s.n_launch; j++) {
+    pre(j);
+    const hipError_t e = launch_sweep_gemm_bf16_glds(metric, s.bp[j], rows16, row_stride, norms, alive, queries16, q_stride, tau0, part_keys, list_stride,
+                                                     list_off, dim, nq, k, st, split, qnorms, blk_tau, qnorms_half);
+    if (e != hipSuccess) return e;
+    list_off += s.bp[j].G;
+    post(j, list_off, j + 1 == s.n_launch);
+  }
+  return hipSuccess;
+}
 // bits_gemm.hip: {0,1} byte image of packed bit rows (+ bit counts as floats) for the int8 GEMM distance of Hamming / Jaccard
 void launch_bits_expand(int metric, const uint32_t* bits, uint32_t words, uint8_t* img, uint32_t img_stride, float* cnt, uint32_t row0,
                         uint32_t n_rows, uint32_t dim, float fill, hipStream_t st);
