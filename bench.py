@@ -418,7 +418,8 @@ def main():
             shutil.rmtree(tdir, ignore_errors=True)
 
     if rank == 0 and world == 1 and not a.no_traffic_pass:
-        tb_, tk_, tsrc_ = traffic_pass("headline", ("sweep_topk", "merge_topk", "split_rerank", "split_seed", "split_reseed", "select_fallback"), [])
+        tb_, tk_, tsrc_ = traffic_pass("headline", ("sweep_topk", "merge_topk", "split_rerank", "split_seed", "split_reseed", "select_fallback", "seed_scores_bf16", "sel16_prep_queries",
+                                                "l2_seed", "collect_flagged", "scatter_flagged", "select_stats"), [])
         roofline["traffic_source"] = tsrc_
         if tb_ is not None:
             roofline["traffic"] = tb_

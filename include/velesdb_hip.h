@@ -218,14 +218,14 @@ int32_t vdb_hip_index_search_rerank(vdb_hip_index* idx, const float* queries_row
  * VDB_SEARCH_HNSW reports them.  ef = 0 => Balanced; ef >= 4 when several entry points are used. */
 int32_t vdb_hip_index_search_multi_entry(vdb_hip_index* idx, const float* queries_rowmajor, uint32_t nq, uint32_t k, uint32_t ef,
                                          uint32_t num_probes, uint64_t* out_ids, float* out_scores, uint32_t* out_n);
-/* device-resident variant: d_queries nq*dim f32 (16-byte aligned), outputs device buffers of
- * nq*k / nq; enqueued on `stream`, no host synchronisation (one exception: Euclidean VDB_SEARCH_BRUTE batches of >= 64 queries
- * outside the selection stage's shapes — < 16 queries, dim % 64 != 0, k > 10, < 65 536 rows — read their per-query verdicts back
- * once per <= 1 024-query chunk).  In HNSW mode d_out_n[i] ==
- * 0xFFFFFFFF marks a query whose LDS candidate list overflowed (needs very many exact distance
- * ties) or, in calls of at most one query per CU, whose walk visited more nodes than the LDS visited set
- * holds (> ~24 000 at ef <= 270); the host variant above re-runs such batches with a larger list and
- * the HBM visited bitmaps by itself. */
+/* device-resident variant: d_queries nq*dim f32 (16-byte aligned), outputs device buffers of nq*k / nq; enqueued on `stream`,
+ * no host synchronisation — with two exceptions: (1) Euclidean VDB_SEARCH_BRUTE batches of >= 64 queries that the selection
+ * stage does not take (dim % 64 != 0, dim < 128, k > 10, or fewer than 65 536 rows) read their per-query verdicts back once per
+ * <= 1 024-query chunk; (2) the first search that needs a derived image of the rows (bf16 / split / augmented / SQ8-dequantised /
+ * bit-byte image) builds it on `stream` and waits for it, so that other search contexts may use it.
+ * In HNSW mode d_out_n[i] == 0xFFFFFFFF marks a query whose LDS candidate list overflowed (needs very many exact distance
+ * ties) or, in calls of at most one query per CU, whose walk visited more nodes than the LDS visited set holds (> ~24 000 at
+ * ef <= 270); the host variant above re-runs such batches with a larger list and the HBM visited bitmaps by itself. */
 int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* idx, const float* d_queries, uint32_t nq,
                                        uint32_t k, uint32_t ef, int32_t mode, uint64_t* d_out_ids,
                                        float* d_out_scores, uint32_t* d_out_n, void* stream);

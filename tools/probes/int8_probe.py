@@ -33,4 +33,6 @@ for mode, name in ((va.MODE_HNSW, "f32"), (va.MODE_HNSW_INT8, "int8")):
     nd, ne = ix.last_search_stats()
     per = (a.dim * 4 if name == "f32" else a.dim + 4)
     alg = nd * per + ne * 64 * 4 + (a.nq * 10 * 4 * a.dim * 4 if name == "int8" else 0)
-    print(f"{name}: {dt*1e3:.2f} ms / {a.nq} queries = {a.nq/dt:.0f} q/s; n_dist/q {nd/a.nq:.0f}; {alg/dt/1e9:.0f} GB/s = {alg/dt/8e12:.3f} of HBM", flush=True)
+    ck = int(ids.sum().item()) ^ int(sc.view(torch.int32).to(torch.int64).sum().item())
+    print(f"{name}: {dt*1e3:.2f} ms / {a.nq} queries = {a.nq/dt:.0f} q/s; n_dist/q {nd/a.nq:.0f}; {alg/dt/1e9:.0f} GB/s = {alg/dt/8e12:.3f} of HBM; "
+          f"result checksum {ck:x} counters {nd} {ne} (VELESDB_INT8_SPEC={os.environ.get('VELESDB_INT8_SPEC', 'default')})", flush=True)
