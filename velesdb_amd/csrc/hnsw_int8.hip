@@ -93,8 +93,12 @@ struct HnswInt8Args {
 // WAVES: 4 (a 256-thread block per query in flight) or 2: the traversal reads 772 bytes per visited node instead of 3 KB, so
 // a step's distance phase is short and the leader's serial part (pop, visited test-and-set, admission) dominates — at 142
 // registers a CU holds 12 waves: 3 queries in flight with four-wave blocks, 6 with two-wave blocks.
+// Round 4: __launch_bounds__(.., 4) = at most 128 registers (12 dwords of scratch): 16 waves per CU = 8 two-wave walks.  The walk is
+// bound by its chain of dependent memory round trips with too few of them in flight, not by bytes or by the vector ALUs:
+// 1 M x 768, ef 128, 8 192 queries on one box 25.1 ms at 3 waves per SIMD, 19.7 at 4, 19.2 at 5 (96 registers; needs scratch for
+// 10 walks per CU), 24.2 at 6 (80 registers: the spills cost more than the walks gain) — profiles/r04l_int8_occupancy_ab.log.
 template <int METRIC, int CPL, int NS, int WAVES, bool VIS = false>
-__global__ __launch_bounds__(WAVES * 64) void hnsw_search_int8_kernel(HnswInt8Args A) {
+__global__ __launch_bounds__(WAVES * 64, 4) void hnsw_search_int8_kernel(HnswInt8Args A) {
   const HnswSearchArgs& a = A.s;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id();
