@@ -59,8 +59,12 @@ enum Phase : int {
 // verdicts select, in list order, which of the evaluated distances are admitted.  Same ids, scores and counters (n_dist counts
 // the unvisited neighbours, as the reference's loop evaluates them); the rows of visited neighbours are wasted bandwidth that a
 // single query has to spare.
+// __launch_bounds__(.., 4): four waves per SIMD = four 256-thread walks per CU.  Left alone the register-list instance took 143
+// registers = three walks per CU; the walk is a chain of dependent memory round trips, and the rows in flight per CU are what
+// the chip's random-gather bandwidth follows: 126 registers (no scratch) took the 8 192-query launch at 1 M x 768, ef 128 from
+// 49.1 to 42.1 ms on one box (0.61 -> 0.72 of HBM; profiles/r04m_f32_walk_occupancy_ab.log), same ids / scores / counters.
 template <int METRIC, int CPL, int NS, bool LAT = false, bool VIS = false>
-__global__ __launch_bounds__(LAT ? 1024 : 256) void hnsw_search_kernel(HnswSearchArgs a) {
+__global__ __launch_bounds__(LAT ? 1024 : 256, 4) void hnsw_search_kernel(HnswSearchArgs a) {
   constexpr bool BITS = (METRIC == kHamming || METRIC == kJaccard);
   constexpr int WAVES = LAT ? 16 : 4, TPB = WAVES * 64, RR = LAT ? 4 : 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
