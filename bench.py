@@ -884,6 +884,8 @@ def main():
         ex_sc = out_sc[:min(nq_big, 64)].cpu().numpy().copy()
         dt_8 = sq8_run(8, 5)
         va.set_split_selector(0 if a.no_split else a.select_level)
+        dt_8d = sq8_run(8, 5)  # the default path: from 6 queries up the selection stage (one partly filled query tile) is ahead of the exact sweep
+        lvl_8d = ix.last_select_level()
         code_bytes = N * (D + 12 + (4 if a.metric == "cosine" else 0))
         sq8_leg = {"workload": f"{N}x{D} SQ8 codes ({a.metric}, asymmetric f32-query distances), k={K}",
                    "batch": {"queries": nq_big, "qps": round(nq_big / dt_sel, 1), "ms_per_batch": round(dt_sel * 1e3, 3),
@@ -896,6 +898,7 @@ def main():
                                                             np.array_equal(sel_sc[:len(ex_sc)].view(np.uint32), ex_sc.view(np.uint32))),
                    "eight_queries": {"qps": round(8 / dt_8, 1), "ms_per_call": round(dt_8 * 1e3, 4),
                                      "hbm_gbs": round(code_bytes / dt_8 / 1e9, 1), "hbm_frac": round(code_bytes / dt_8 / 1e9 / HBM_PEAK_GBS, 4)},
+                   "eight_queries_default_path": {"qps": round(8 / dt_8d, 1), "ms_per_call": round(dt_8d * 1e3, 4), "select_level": lvl_8d},
                    "alg_bytes_per_pass": code_bytes}
         if rank == 0 and host_full is not None and a.check_queries > 0:
             from oracle import pyoracle as po_s

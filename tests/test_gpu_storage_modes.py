@@ -174,6 +174,15 @@ def test_sq8_big_batches_select_on_the_matrix_cores_bit_exact(gpu_required, metr
     keep = np.ones(len(rows2), dtype=bool)
     keep[int(eid[7, 0])] = False
     gid2, gsc2, _ = ix.search_batch_sq8(Q, k)
+    # (a handle whose batch defeated the proof for > 1/16 of its queries answers the next 64 batches with the exact sweep)
+    strict = ix.last_select_level() == 3 and ix.last_split_stats()[1] * 16 <= nq
     eid2, esc2 = po.scan_topk_sq8(pm, rows2[keep], Q, k, nthreads=po.host_threads())
     assert np.array_equal(gid2, ids2[keep][eid2.astype(np.int64)]) and np.array_equal(bits(gsc2), bits(esc2))
+    # small batches: from 6 queries up the stage (one partly filled query tile) serves the batch, below it the exact sweep — same bits
+    # (queries 2.. : the tie and the zero query are unprovable by construction — two of six would park the handle on the exact sweep)
+    for nq_s, want_level in ((5, 0), (6, 3), (8, 3), (15, 3)):
+        gs_i, gs_s, gs_c = ix.search_batch_sq8(Q[2:2 + nq_s], k)
+        if strict and ix.last_split_stats()[1] == 0:
+            assert ix.last_select_level() == want_level, (nq_s, ix.last_select_level())
+        assert np.array_equal(gs_i, gid2[2:2 + nq_s]) and np.array_equal(bits(gs_s), bits(gsc2[2:2 + nq_s])), nq_s
     ix.close()

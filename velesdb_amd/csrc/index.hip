@@ -781,10 +781,14 @@ static uint32_t select_min_queries() {
 // the chunk of the remaining nq_left queries the selection stage takes next (0: none): up to 1 024, whatever that leaves of the
 // last 256-query tile — a partly filled tile costs what a full one costs, a second pass costs the whole fixed part again
 // (384 queries as 256 + 128: 1.34 ms; as one pass of two tiles: what 512 cost, 1.01 ms)
-static uint32_t select_chunk(uint32_t nq_left) {
+static uint32_t select_chunk(uint32_t nq_left, uint32_t min_queries = 0) {
   const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
-  return nqg >= select_min_queries() ? nqg : 0;
+  return nqg >= (min_queries ? min_queries : select_min_queries()) ? nqg : 0;
 }
+// the SQ8 storage mode's exact sweep keeps the reference's left-to-right chain — one lane per row, 0.39 ms per 4-query pass and
+// 0.73 ms per 8-query pass at 1 M x 768 — so the selection stage (0.55 ms whatever the fill of its one query tile) is ahead from 6
+// queries up, where the f32 kernels hold out until 16
+constexpr uint32_t kSelectMinQueriesSq8 = 6;
 
 // 0: no selection stage (exact kernel); 1: split-bf16 selection; 2: plain bf16 selection
 static int select_level(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
@@ -856,7 +860,7 @@ int select_level_sq8(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT && ix->metric != VDB_EUCLIDEAN) return 0;
   if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
-  if (!select_chunk(nq_left)) return 0;
+  if (!select_chunk(nq_left, kSelectMinQueriesSq8)) return 0;
   if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
     ix->sel_seq_seen = ix->sel_stats[2];
     if (ix->sel_stats[3] == 3u && (uint64_t)ix->sel_stats[0] * 16 > ix->sel_stats[1]) ix->sq8_hold = 64;
@@ -1599,7 +1603,7 @@ int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint3
     uint32_t q0 = 0;
     while (q0 < nq && k > 0 && ix->n_rows > 0) {
       if (select_level_sq8(ix, nq - q0, k) != 3) break;
-      const uint32_t nqg = select_chunk(nq - q0);
+      const uint32_t nqg = select_chunk(nq - q0, kSelectMinQueriesSq8);
       const int32_t rcs = brute_split_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nqg, k, d_ids + (size_t)q0 * k,
                                           d_scores + (size_t)q0 * k, d_n + q0, st, 3);
       if (rcs != VDB_OK) return rcs;

@@ -115,10 +115,16 @@ static int32_t search_direct(vdb_hip_index* handle, const float* queries, uint32
 }
 
 // the leader's part: one launch for `batch` (same shape; batch[0] is the leader's own request)
-static void run_batch(vdb_hip_index* handle, std::vector<CombineReq*>& batch) {
+static void run_batch(vdb_hip_index* handle, CombineReq* const* reqs, size_t n_reqs) {
+  struct Span {
+    CombineReq* const* b;
+    size_t n;
+    CombineReq* const* begin() const { return b; }
+    CombineReq* const* end() const { return b + n; }
+  } batch{reqs, n_reqs};
   uint32_t total = 0;
   for (CombineReq* r : batch) total += r->nq;
-  const CombineReq& s = *batch[0];
+  const CombineReq& s = *reqs[0];
   vdb_hip_index* served = nullptr;
   const int32_t rc = guarded([&]() -> int32_t {
     return run_search(
@@ -193,12 +199,23 @@ static int32_t search_combined(vdb_hip_index* handle, Combiner* cb, CombineReq& 
   if (lead) {
     std::unique_lock<std::mutex> lk(cb->mu);
     // my request first (the shape of the batch is mine), then every queued request of the same shape while the batch has room
-    std::vector<CombineReq*> batch{&me};
+    // (room for a full batch up front: nothing below can throw once other callers' requests are in it; without the room — out of
+    // host memory — the leader runs alone)
+    std::vector<CombineReq*> batch;
+    size_t room = 1;
+    try {
+      batch.reserve(std::max<uint32_t>(max_batch, 1u));
+      room = batch.capacity();
+    } catch (const std::bad_alloc&) {
+    }
+    CombineReq* alone[1] = {&me};
+    if (room > 1) batch.push_back(&me);
     uint32_t total = me.nq;
     auto gather = [&] {
+      if (room <= 1) return;
       for (auto it = cb->queue.begin(); it != cb->queue.end();) {
         CombineReq* r = *it;
-        if (r->state == CombineReq::kQueued && r->same_shape(me) && total + r->nq <= max_batch) {
+        if (batch.size() < room && r->state == CombineReq::kQueued && r->same_shape(me) && total + r->nq <= max_batch) {
           r->state = CombineReq::kTaken;
           batch.push_back(r);
           total += r->nq;
@@ -233,14 +250,15 @@ static int32_t search_combined(vdb_hip_index* handle, Combiner* cb, CombineReq& 
       }
       gather();
     }
+    const size_t n_calls = room > 1 ? batch.size() : 1;
     cb->launches++;
-    cb->calls += batch.size();
+    cb->calls += n_calls;
     cb->queries += total;
     cb->max_batch = std::max<uint64_t>(cb->max_batch, total);
     lk.unlock();
-    run_batch(handle, batch);
+    run_batch(handle, room > 1 ? batch.data() : alone, n_calls);
     lk.lock();
-    cb->last_batch_calls = (uint32_t)batch.size();
+    cb->last_batch_calls = (uint32_t)n_calls;
     cb->last_batch_done_at_arrival = cb->arrivals;
     cb->leaders--;
     // the freed slot goes to the first queued call that may lead (it takes the others of its shape with it)
