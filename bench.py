@@ -495,7 +495,7 @@ def main():
     # VectorIndex::search / search_batch_parallel bind (velesdb-hip/src/lib.rs) — queries from host memory, results back to host
     # memory — and the reference's calling pattern, many threads x one query per call, through the combining front
     host_entry = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.no_tiles:  # (--no-tiles: profiling passes of the headline step alone)
         hq_np = queries[:min(n_query_pool, 4096)].cpu().numpy()
         he = []
         for nq_h in (Q, 256, 64, 16, 1):
@@ -1239,13 +1239,13 @@ def main():
                 row[key] = {"queries": nq_m, "ms_per_call": round(mdt * 1e3, 4), "qps": round(nq_m / mdt, 1),
                             "sweep_kernel_ms": round(kms_m, 4), "launches": nl_m}
             if bits_metric and row["batch"]["sweep_kernel_ms"] > 0 and (ixm.last_kernels() & va.KERNEL_BITS_GEMM):
-                # the batch as an int8 GEMM distance on the matrix cores (bits_gemm.hip): exact integer intersection counts
+                # the batch as a four-bit GEMM distance on the matrix cores (bits_gemm.hip): exact integer dot products
                 bops = 2.0 * N * D * Q
                 btops = bops / (row["batch"]["sweep_kernel_ms"] * 1e-3) / 1e12
-                row["batch"]["roofline"] = {"bound": "mfma", "achieved": round(btops, 1), "peak": 3944.0, "unit": "TOP/s (int8)", "frac": round(btops / 3944.0, 4),
+                row["batch"]["roofline"] = {"bound": "mfma", "achieved": round(btops, 1), "peak": 10000.0, "unit": "TFLOP/s (fp4)", "frac": round(btops / 10000.0, 4),
                                             "traffic": None, "alg_ops_per_batch": bops,
-                                            "kernel": "sweep_topk_gemm_bf16_pp<%s, I8> (v_mfma_i32_16x16x64_i8; timed region = sample seed + launches + merges)" % mname,
-                                            "note": "int8 MFMA ceiling 3 944 TOP/s (MI355X_MICROARCH.md, 16x16x64); algorithmic operations = 2*rows*dim*queries"}
+                                            "kernel": "sweep_topk_gemm_bf16_pp<%s, FP4> (v_mfma_scale_f32_16x16x128_f8f6f4, unit scales; timed region = sample seed + launches + merges)" % mname,
+                                            "note": "dense FP4 MFMA peak ~10 PFLOP/s (MI355X_MICROARCH.md); algorithmic operations = 2*rows*dim*queries"}
             pass_bytes = N * ((D + 127) // 128 * 16) if bits_metric else N * D * 4
             sk = row["single_query"]["sweep_kernel_ms"]
             row["single_query"]["hbm_gbs"] = round(pass_bytes / (sk * 1e-3) / 1e9, 1) if sk > 0 else 0.0
@@ -1254,9 +1254,9 @@ def main():
             row["note"] = {"euclidean": "batch: selection on the bf16 matrix cores over s = q.v - |v|^2/2 (augmented DotProduct form), canonical "
                                         "(q - v)^2 re-scoring of 64 candidates, per-query proof, gathered exact pass for unproven queries",
                            "dot": "batch: the headline's selection stage (plain bf16 selection + exact re-scoring + proof)",
-                           "hamming": "packed bits (x > 0.5), 96 B/row; batches of >= 224 queries: +-1 byte image, dim - 2 |q ^ v| as an int8 GEMM on the "
+                           "hamming": "packed bits (x > 0.5), 96 B/row; batches of >= 224 queries: +-1 four-bit image (48 B per 96 values), dim - 2 |q ^ v| as a four-bit GEMM on the "
                                       "matrix cores with the fused top-k (exact integers); smaller batches: 32 queries per corpus pass, AND+popcount",
-                           "jaccard": "packed bits (x > 0.5), 96 B/row; batches of >= 224 queries: {0,1} byte image, |q & v| as an int8 GEMM on the matrix "
+                           "jaccard": "packed bits (x > 0.5), 96 B/row; batches of >= 224 queries: {0,1} four-bit image, |q & v| as a four-bit GEMM on the matrix "
                                       "cores, per-element bound d - c|v| >= c|q| in the epilogue (exact integers); smaller batches: AND+popcount"}[mname]
             if not a.no_cpu_baseline:
                 # the reference's exact path for this metric restated on the host cores (mode R: wide16 kernels; Hamming /

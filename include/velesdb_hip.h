@@ -222,7 +222,7 @@ int32_t vdb_hip_index_search_multi_entry(vdb_hip_index* idx, const float* querie
  * no host synchronisation — with two exceptions: (1) Euclidean VDB_SEARCH_BRUTE batches of >= 64 queries that the selection
  * stage does not take (dim % 64 != 0, dim < 128, k > 10, or fewer than 65 536 rows) read their per-query verdicts back once per
  * <= 1 024-query chunk; (2) the first search that needs a derived image of the rows (bf16 / split / augmented / SQ8-dequantised /
- * bit-byte image) builds it on `stream` and waits for it, so that other search contexts may use it.
+ * four-bit bit image) builds it on `stream` and waits for it, so that other search contexts may use it.
  * In HNSW mode d_out_n[i] == 0xFFFFFFFF marks a query whose LDS candidate list overflowed (needs very many exact distance
  * ties) or, in calls of at most one query per CU, whose walk visited more nodes than the LDS visited set holds (> ~24 000 at
  * ef <= 270); the host variant above re-runs such batches with a larger list and the HBM visited bitmaps by itself. */
@@ -365,7 +365,7 @@ enum vdb_kernel_bit {
   VDB_KERNEL_SQ8 = 512,            /* sweep_topk_sq8                                                                   */
   VDB_KERNEL_HNSW = 1024,          /* hnsw_search_kernel                                                               */
   VDB_KERNEL_HNSW_INT8 = 2048,     /* hnsw_search_int8_kernel                                                          */
-  VDB_KERNEL_BITS_GEMM = 4096      /* Hamming / Jaccard batches as an int8 GEMM distance (sweep_topk_gemm_bf16_pp<.., I8>) */
+  VDB_KERNEL_BITS_GEMM = 4096      /* Hamming / Jaccard batches as a four-bit GEMM distance (sweep_topk_gemm_bf16_pp<.., FP4>) */
 };
 int32_t vdb_hip_index_last_kernels(vdb_hip_index* idx, uint32_t* mask);
 /* *mode = 1 if searches in VDB_SEARCH_BRUTE mode with this k run on the matrix-core kernel (mode M), else 0 */

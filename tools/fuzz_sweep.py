@@ -29,7 +29,7 @@ p.add_argument("--engine", type=int, default=1, help="0 = vector-ALU kernels for
 p.add_argument("--only-it", type=int, default=0, help="replay: generate every case, run only this one (verbose)")
 p.add_argument("--euclid", action="store_true", help="Euclidean only (matrix-core batches + exact re-scoring)")
 p.add_argument("--bits", action="store_true", help="Hamming / Jaccard (packed-bit kernels) instead of cosine / dot")
-p.add_argument("--bits-big", action="store_true", help="Hamming / Jaccard batches that take the int8 GEMM path (>= 224 queries, >= 65 536 rows)")
+p.add_argument("--bits-big", action="store_true", help="Hamming / Jaccard batches that take the four-bit GEMM path (>= 224 queries, >= 65 536 rows)")
 a = p.parse_args()
 rng = np.random.default_rng(a.seed)
 NT = po.host_threads()
@@ -212,9 +212,9 @@ while time.time() < t_end:
             else:
                 bf16_check(metric, pm, rows, Q, k, gi, gs, gc)
         stats["bf16"] += 1
-    elif a.bits_big:  # the int8 GEMM path: every query against the vector-ALU kernels, a sample against the oracle
+    elif a.bits_big:  # the four-bit GEMM path: every query against the vector-ALU kernels, a sample against the oracle
         gi, gs, gc = ix.search_batch_brute_force(Q, k)
-        assert ix.last_kernels() & va.KERNEL_BITS_GEMM, tag + " (not served by the int8 GEMM path)"
+        assert ix.last_kernels() & va.KERNEL_BITS_GEMM, tag + " (not served by the four-bit GEMM path)"
         ix.set_option(va.OPT_SWEEP_ENGINE, 0)
         vi, vs, vc = ix.search_batch_brute_force(Q, k)
         ix.set_option(va.OPT_SWEEP_ENGINE, -1)

@@ -1,6 +1,6 @@
 set -x
 export TMPDIR=/tmp
-TAG=${TAG:-r02}
+TAG=${TAG:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O

@@ -2,16 +2,18 @@
 //
 // The reference's Hamming and Jaccard on f32 vectors are functions of bit counts (simd_explicit.rs:234-287,372-443 on the exact
 // re-encoding bit = x > 0.5, SURVEY 8a note 10):  jaccard = |q & v| / (|q| + |v| - |q & v|) (1.0 for an empty union), and
-// hamming = |q ^ v| = (dim - q' . v') / 2 for the +-1 re-encoding q' = 2 q - 1 (the XNOR form).  Both are dot products of small
-// integers — what the matrix cores compute EXACTLY in int32 (v_mfma_i32_16x16x64_i8, ~2 x the bf16 rate).  A batch therefore
-// runs as an int8 GEMM distance: rows and queries as byte images (dim bytes per row, padded with zeros to whole 128-byte
-// k-tiles; Hamming: +-1, Jaccard: {0,1} with |v| and |q| where the cosine kernel keeps its norms) through the byte instance of
-// the ping-pong selection kernel (sweep_gemm_bf16.hip, sweep_topk_gemm_bf16_pp<METRIC, true>) with the metric's own per-element
-// bound and finish in its epilogue.  Scores are exact integers (ratios of exact integers), so the
+// hamming = |q ^ v| = (dim - q' . v') / 2 for the +-1 re-encoding q' = 2 q - 1 (the XNOR form).  Both are dot products of the
+// values 0 and +-1 — which the matrix cores' four-bit format holds exactly (E2M1: +1.0 = 0b0010, -1.0 = 0b1010) and multiplies
+// at four times the bf16 rate: v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, f32 accumulators = exact integers.  A
+// batch therefore runs as a four-bit GEMM distance: rows and queries as nibble images (dim / 2 bytes per row, padded with zeros
+// to whole 128-byte k-tiles of 256 values; Hamming: +-1, Jaccard: {0,1} with |v| and |q| where the cosine kernel keeps its norms)
+// through the four-bit instance of the ping-pong selection kernel (sweep_gemm_bf16.hip, sweep_topk_gemm_bf16_pp<METRIC, true>)
+// with the metric's own per-element bound and finish in its epilogue.  Scores are exact integers (ratios of exact integers), so the
 // kernel's keys ARE the result: no re-scoring, no proof, the same keys the vector-ALU kernels of sweep.hip produce
 // ((score total order, row) — ties by internal row).
-// Bound: the int8 matrix pipe; algorithmic operations = 2 * rows * dim * queries.  The vector-ALU batch kernel
-// (sweep_topk_bits_tile<B = 32>, AND + popcount) takes 2.8 / 3.2 ms per 1 024 queries at 1 M x 768: vector-ALU issue-bound.
+// Bound: the four-bit matrix pipe (~10 PFLOP/s dense); algorithmic operations = 2 * rows * dim * queries.  The vector-ALU batch
+// kernel (sweep_topk_bits_tile<B = 32>, AND + popcount) takes 2.8 / 3.2 ms per 1 024 queries at 1 M x 768 (vector-ALU issue-bound);
+// this path 0.72 / 0.82 ms (the first version, on v_mfma_i32_16x16x64_i8 over byte images: 0.96 / 1.02 ms).
 #include <algorithm>
 #include <string>
 
@@ -21,8 +23,10 @@
 
 namespace vdb {
 
-// one thread = 16 bits of one row -> 16 bytes; the thread of a row's first chunk also leaves the row's bit count (or `fill`).
-// pm = false: bytes {0, 1}; pm = true: bytes {-1, +1} for the dim real columns, 0 for the padding (it must not contribute)
+// one thread = one 32-bit word of a packed row -> 32 nibbles = 16 bytes; the thread of a row's first word also leaves the row's bit
+// count (or `fill`).  pm = false: values {0, +1}; pm = true: {-1, +1} for the dim real columns, 0 for the padding (it must not
+// contribute).  E2M1: +1.0 = 0b0010, -1.0 = 0b1010.  Value i of a word sits in nibble i of the 16 bytes — any order would do: rows
+// and queries are packed alike and the kernels read both with the same fragment mapping.
 __global__ __launch_bounds__(256) void bits_expand_kernel(const uint32_t* __restrict__ bits, uint32_t words, uint8_t* __restrict__ img,
                                                           uint32_t img_stride, float* __restrict__ cnt, uint32_t row0, uint32_t n_rows,
                                                           uint32_t dim, bool pm, float fill) {
@@ -31,17 +35,13 @@ __global__ __launch_bounds__(256) void bits_expand_kernel(const uint32_t* __rest
   if (gid >= (uint64_t)n_rows * chunks) return;
   const uint32_t r = (uint32_t)(gid / chunks), c = (uint32_t)(gid % chunks);
   const uint32_t* w = bits + (size_t)(row0 + r) * words;
-  const uint32_t h = (c >> 1) < words ? (w[c >> 1] >> (16u * (c & 1u))) & 0xFFFFu : 0u;
-  uint32_t o[4];
+  const uint32_t h = c < words ? w[c] : 0u;
+  uint32_t o[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const uint32_t n4 = (h >> (4 * j)) & 15u;
-    o[j] = (n4 & 1u) | ((n4 & 2u) << 7) | ((n4 & 4u) << 14) | ((n4 & 8u) << 21);
-    if (pm) {  // a clear bit of a real column: -1
-      const uint32_t col = c * 16u + 4u * (uint32_t)j;
-      const uint32_t real = (col < dim ? 0xFFu : 0u) | (col + 1u < dim ? 0xFF00u : 0u) | (col + 2u < dim ? 0xFF0000u : 0u) | (col + 3u < dim ? 0xFF000000u : 0u);
-      o[j] |= (~(o[j] * 0xFFu)) & real;  // o * 0xFF spreads each 0x01 to 0xFF: the complement marks the clear bits
-    }
+  for (int i = 0; i < 32; i++) {
+    const uint32_t col = c * 32u + (uint32_t)i;
+    const uint32_t nib = ((h >> i) & 1u) ? 0x2u : ((pm && col < dim) ? 0xAu : 0u);
+    o[i >> 3] |= nib << (4 * (i & 7));
   }
   *reinterpret_cast<uint4*>(img + (size_t)(row0 + r) * img_stride + (size_t)c * 16u) = make_uint4(o[0], o[1], o[2], o[3]);
   if (c == 0 && cnt) {
@@ -59,15 +59,17 @@ void launch_bits_expand(int metric, const uint32_t* bits, uint32_t words, uint8_
                      dim, metric == VDB_HAMMING, fill);
 }
 
-// ---- the seed: a plain int8 GEMM of the first rows x the batch, straight from L2 (as seed_scores_bf16, sweep_split.hip) ----
+// ---- the seed: a plain four-bit GEMM of the first rows x the batch, straight from L2 (as seed_scores_bf16, sweep_split.hip) ----
 // The selection kernel needs a bound per query before its first row tile, or that tile's 65 536 elements all queue up.  The seed
 // is a SAMPLE: the k-th best score over ANY rows bounds the k-th best over all of them, so the kernel keeps the best key of
 // every 16 rows ([nq][seed_rows / 16] keys), merge_topk_select picks the k best, their k-th + 1 is the bound — and the launches
 // sweep the seed rows again (0.4 % of a 1 M corpus).  (The vector-ALU tile kernel over 16 384 rows did this first: 190 us of a
 // 1.0 ms batch, nearly all of it per-block start-up.)  One wave = 64 rows x 64 queries, 16-byte fragments from global memory.
 typedef int i32x4_s __attribute__((ext_vector_type(4)));
+typedef int i32x8_s __attribute__((ext_vector_type(8)));
+typedef float f32x4_q __attribute__((ext_vector_type(4)));
 template <int METRIC>
-__global__ __launch_bounds__(256) void seed_scores_i8(const uint8_t* rows8, uint32_t stride, const float* cnt, const uint8_t* alive,
+__global__ __launch_bounds__(256) void seed_scores_fp4(const uint8_t* rows8, uint32_t stride, const float* cnt, const uint8_t* alive,
                                                       const uint8_t* q8, const float* qcnt, uint64_t* keys, uint32_t seed_rows, uint32_t nq) {
   constexpr bool HIB = METRIC != kHamming;
   const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
@@ -81,12 +83,12 @@ __global__ __launch_bounds__(256) void seed_scores_i8(const uint8_t* rows8, uint
   const uint8_t* bp[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) bp[t] = q8 + (size_t)min(qb + (uint32_t)t * 16u + i, nq - 1u) * stride + kk * 16u;
-  i32x4_s acc[4][4];
+  f32x4_q acc[4][4];
 #pragma unroll
   for (int rb = 0; rb < 4; rb++)
 #pragma unroll
-    for (int t = 0; t < 4; t++) acc[rb][t] = i32x4_s{0, 0, 0, 0};
-  for (uint32_t k0 = 0; k0 < stride; k0 += 128) {  // stride % 128 == 0; two 64-deep steps in flight
+    for (int t = 0; t < 4; t++) acc[rb][t] = f32x4_q{0.f, 0.f, 0.f, 0.f};
+  for (uint32_t k0 = 0; k0 < stride; k0 += 128) {  // stride % 128 == 0; two steps of 128 values (64 bytes per row) in flight
     i32x4_s av[4][2], bv[2][4];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -100,7 +102,11 @@ __global__ __launch_bounds__(256) void seed_scores_i8(const uint8_t* rows8, uint
 #pragma unroll
       for (int rb = 0; rb < 4; rb++)
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[rb][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av[rb][s], bv[s][t], acc[rb][t], 0, 0, 0);
+        for (int t = 0; t < 4; t++) {  // (four-bit operands use the first four of the builtin's eight registers; scales 2^0)
+          const i32x8_s a8 = {av[rb][s][0], av[rb][s][1], av[rb][s][2], av[rb][s][3], 0, 0, 0, 0};
+          const i32x8_s b8 = {bv[s][t][0], bv[s][t][1], bv[s][t][2], bv[s][t][3], 0, 0, 0, 0};
+          acc[rb][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, b8, acc[rb][t], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        }
   }
   const uint32_t ngrp = (seed_rows + 15u) / 16u;
 #pragma unroll
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(256) void seed_scores_i8(const uint8_t* rows8, uint
       for (int r = 0; r < 4; r++) {
         const uint32_t row = row0 + (uint32_t)rb * 16u + 4u * kk + (uint32_t)r;
         if (row >= seed_rows) continue;
-        const float x = (float)acc[rb][t][r];
+        const float x = acc[rb][t][r];
         float sc;
         if (METRIC == kHamming) {
           sc = 0.5f * (qn - x);  // (the finish of the selection kernel: g16_protocol.inc)
@@ -130,17 +136,17 @@ __global__ __launch_bounds__(256) void seed_scores_i8(const uint8_t* rows8, uint
     keys[(size_t)q * ngrp + (row0 / 64u) * 4u + kk] = best;
   }
 }
-static void launch_seed_scores_i8(int metric, const uint8_t* rows8, uint32_t stride, const float* cnt, const uint8_t* alive, const uint8_t* q8,
+static void launch_seed_scores_fp4(int metric, const uint8_t* rows8, uint32_t stride, const float* cnt, const uint8_t* alive, const uint8_t* q8,
                                   const float* qcnt, uint64_t* keys, uint32_t seed_rows, uint32_t nq, hipStream_t st) {
   const dim3 grid((seed_rows + 255) / 256, (nq + 63) / 64);
   if (metric == VDB_HAMMING)
-    hipLaunchKernelGGL((seed_scores_i8<kHamming>), grid, dim3(256), 0, st, rows8, stride, cnt, alive, q8, qcnt, keys, seed_rows, nq);
+    hipLaunchKernelGGL((seed_scores_fp4<kHamming>), grid, dim3(256), 0, st, rows8, stride, cnt, alive, q8, qcnt, keys, seed_rows, nq);
   else
-    hipLaunchKernelGGL((seed_scores_i8<kJaccard>), grid, dim3(256), 0, st, rows8, stride, cnt, alive, q8, qcnt, keys, seed_rows, nq);
+    hipLaunchKernelGGL((seed_scores_fp4<kJaccard>), grid, dim3(256), 0, st, rows8, stride, cnt, alive, q8, qcnt, keys, seed_rows, nq);
 }
 constexpr uint32_t kBitsSeedRows = 4096;
 
-uint32_t bits_image_stride(uint32_t dim) { return std::max<uint32_t>(256u, (dim + 127u) / 128u * 128u); }  // bytes; >= 2 k-tiles
+uint32_t bits_image_stride(uint32_t dim) { return std::max<uint32_t>(256u, (dim + 255u) / 256u * 128u); }  // bytes (two values each); >= 2 k-tiles
 
 // does a chunk of the batch take the matrix cores?  Whole 256-query tiles filled to >= 7/8 (the rule of the bf16 result path)
 uint32_t bits_gemm_chunk(const vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
@@ -151,13 +157,13 @@ uint32_t bits_gemm_chunk(const vdb_hip_index* ix, uint32_t nq_left, uint32_t k) 
   return nqg >= kGemmBigMinQueries ? nqg : 0;
 }
 
-// nqg packed queries (qbits [nqg][words]) against the index's byte image: exact top-k per query into d_ids / d_scores / d_n
+// nqg packed queries (qbits [nqg][words]) against the index's four-bit image: exact top-k per query into d_ids / d_scores / d_n
 int32_t brute_bits_gemm_dev(vdb_hip_index* ix, const uint32_t* qbits, uint32_t nqg, uint32_t k, uint64_t* d_ids, float* d_scores,
                             uint32_t* d_n, hipStream_t st) {
   const bool hib = ix->metric == VDB_JACCARD;
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
   const uint32_t n = (uint32_t)ix->n_rows, stride = bits_image_stride(ix->dim), dim2 = stride / 2;  // the kernel's unit: two bytes
-  // Launch schedule: the sample seed over the first rows (bounds only), then the byte GEMM in launches of growing size (gemm_schedule,
+  // Launch schedule: the sample seed over the first rows (bounds only), then the four-bit GEMM in launches of growing size (gemm_schedule,
   // vdb_kernels.hpp); every launch starts from the k-th best key over all rows before it
   const uint32_t R0 = kBitsSeedRows;
   GemmSchedule sch;
@@ -200,7 +206,7 @@ int32_t brute_bits_gemm_dev(vdb_hip_index* ix, const uint32_t* qbits, uint32_t n
   {
     const uint32_t seed_rows = std::min(R0, n);
     uint64_t* skeys = reinterpret_cast<uint64_t*>(sd + o_seedp);
-    launch_seed_scores_i8(ix->metric, ix->bits_img.as<uint8_t>(), stride, ix->bits_cnt.as<float>(), alive, qimg, qcnt, skeys, seed_rows, nqg, st);
+    launch_seed_scores_fp4(ix->metric, ix->bits_img.as<uint8_t>(), stride, ix->bits_cnt.as<float>(), alive, qimg, qcnt, skeys, seed_rows, nqg, st);
     ms.part_keys = skeys;
     ms.n_lists = (seed_rows + 15u) / 16u;
     ms.k = 1;

@@ -327,7 +327,7 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
     return fail(VDB_ERR_OOM, std::string("grow SQ8 selection image: ") + hipGetErrorString(e));
   if (ix->bits_img.cap && ((e = ix->bits_img.reserve((ncap + kRowSlack) * (size_t)bits_image_stride(ix->dim), true, st)) != hipSuccess ||
                            (e = ix->bits_cnt.reserve((ncap + kRowSlack) * 4, true, st)) != hipSuccess))
-    return fail(VDB_ERR_OOM, std::string("grow bit-row byte image: ") + hipGetErrorString(e));
+    return fail(VDB_ERR_OOM, std::string("grow four-bit row image: ") + hipGetErrorString(e));
   for (auto& L : ix->layers) {
     if ((e = L.nbr.reserve(ncap * L.stride * 4, true, st)) != hipSuccess ||
         (e = L.cnt.reserve(ncap * 4, true, st)) != hipSuccess ||
@@ -749,13 +749,13 @@ static int32_t ensure_sel16_impl(vdb_hip_index* ix, hipStream_t st) {
   return VDB_OK;
 }
 
-// Hamming / Jaccard batches on the matrix cores (bits_gemm.hip): the {0,1} byte image of the packed bit rows + their bit counts
+// Hamming / Jaccard batches on the matrix cores (bits_gemm.hip): the four-bit image of the packed bit rows + their bit counts
 static int32_t ensure_bits_image_impl(vdb_hip_index* ix, hipStream_t st) {
   const uint64_t cap = std::max<uint64_t>(ix->capacity, 1) + kRowSlack;
   const uint32_t stride = bits_image_stride(ix->dim);
   hipError_t e;
   if ((e = ix->bits_img.reserve(cap * (size_t)stride, true, st)) != hipSuccess || (e = ix->bits_cnt.reserve(cap * 4, true, st)) != hipSuccess)
-    return fail(VDB_ERR_OOM, std::string("bit-row byte image: ") + hipGetErrorString(e));
+    return fail(VDB_ERR_OOM, std::string("four-bit row image: ") + hipGetErrorString(e));
   if (ix->bits_img_rows < ix->n_rows) {
     launch_bits_expand(ix->metric, ix->bits.as<uint32_t>(), ix->words, ix->bits_img.as<uint8_t>(), stride, ix->bits_cnt.as<float>(), (uint32_t)ix->bits_img_rows,
                        (uint32_t)(ix->n_rows - ix->bits_img_rows), ix->dim, 0.0f, st);
@@ -1243,7 +1243,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     pa.dim = ix->dim;
     pa.words = ix->words;
     launch_prep_rows(pa, st);
-    // large batches: the intersection counts as an int8 GEMM on the matrix cores, exact (bits_gemm.hip); what is left of the batch
+    // large batches: the dot products as a four-bit GEMM on the matrix cores, exact (bits_gemm.hip); what is left of the batch
     // (and every other shape) keeps the vector-ALU kernels below — the same keys either way
     uint32_t qdone = 0;
     while (opt_engine(ix) == 1 && opt_max_tile(ix) >= 128) {
@@ -1684,7 +1684,7 @@ std::vector<DevBuf*> index_buffers(vdb_hip_index* ix) {
       &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq,                // int8 traversal
       &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits,  // storage modes
       &ix->sq8_img, &ix->sq8_nrm, &ix->sq8_seed, &ix->sq8_rho,              // SQ8 selection images
-      &ix->bits_img, &ix->bits_cnt,                                         // byte image of the bit rows (Hamming / Jaccard GEMM)
+      &ix->bits_img, &ix->bits_cnt,                                         // four-bit image of the bit rows (Hamming / Jaccard GEMM)
       &ix->s_queries, &ix->s_part_keys, &ix->s_part_cnt, &ix->s_out, &ix->s_qbits,
       &ix->s_misc, &ix->s_fb_keys, &ix->s_seed, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels, &ix->s_req_keys,
       &ix->s_req_vals, &ix->s_sort_tmp};

@@ -402,19 +402,26 @@ _Pragma("unroll") \
 // conversely removing real bubbles (the scratch reloads and FLAT flag reads that used to drain the DMA queue in every
 // epilogue, the quick test of waves 0-3 moved beside the last products of waves 4-7) changed nothing measurable.
 // =====================================================================================================================
-// I8: the same 16-byte fragments hold 16 signed bytes instead of 8 bf16 — v_mfma_i32_16x16x64_i8, twice the k-extent per
-// instruction at the same issue cost (MI355X_MICROARCH.md: 2 x the bf16 rate), int32 accumulators in the same registers.  Both
-// operands are read with the same slot -> lane mapping, so whatever order the instruction assigns the k-values of a fragment
-// is the same for rows and queries: a dot product does not care.
-template <bool I8>
+// FP4: the same 16-byte fragments hold 32 four-bit values (E2M1: 0, +-1 are all the bit metrics need) instead of 8 bf16 —
+// v_mfma_scale_f32_16x16x128_f8f6f4 with both block scales 2^0 (E8M0 byte 0x7F): FOUR times the k-extent per instruction at the
+// same issue cost (MI355X_MICROARCH.md: ~10 PFLOP/s dense), f32 accumulators that hold the exact integer dot products (< 2^24).
+// Both operands are read with the same slot -> lane mapping, so whatever order the instruction assigns the k-values of a fragment
+// is the same for rows and queries: a dot product does not care.  (Round 4 ran this path on v_mfma_i32_16x16x64_i8 first —
+// byte images, twice the bytes and twice the products: 0.96 / 1.02 ms per 1 024 queries at 1 M x 768 against 0.72 / 0.82 here,
+// profiles/r04p_bit_metrics_fp4_vs_i8.log.)
+template <bool FP4>
 __device__ __forceinline__ void mfma_acc(f32x4& c, const f32x4& a, const f32x4& b) {
-  if (I8) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  if (FP4)
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+a"(c) : "v"(a), "v"(b), "v"(0x7F7F7F7Fu));
+  else
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
-template <bool I8>
+template <bool FP4>
 __device__ __forceinline__ void mfma_acc_first(f32x4& c, const f32x4& a, const f32x4& b) {
-  if (I8) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));
-  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));
+  if (FP4)
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "=&a"(c) : "v"(a), "v"(b), "v"(0x7F7F7F7Fu));
+  else
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));
 }
 // the barrier in front of a phase's products: this wave's fragment reads have completed (their stage slots may be
 // re-requested by anybody who has passed the barrier); "memory": no LDS access moves across
@@ -422,12 +429,12 @@ __device__ __forceinline__ void pp_barrier_reads_done() { asm volatile("s_waitcn
 __device__ __forceinline__ void pp_barrier() { asm volatile("s_barrier" ::: "memory"); }
 __device__ __forceinline__ void pp_wait_dma6() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 
-// I8 instance (Hamming / Jaccard batches on {0,1} byte images, bits_gemm.hip): rows / queries are byte images addressed through the
-// same arguments — row_stride / q_stride / dim in units of TWO bytes, k-tiles of 128 bytes — and `norms` / `qnorms_half` carry
-// the bit counts |v|, |q| as floats; the accumulators hold the exact intersection counts.
-template <int METRIC, bool I8 = false>
+// FP4 instance (Hamming / Jaccard batches on four-bit images, bits_gemm.hip): rows / queries are nibble images addressed through
+// the same arguments — row_stride / q_stride / dim in units of TWO bytes, k-tiles of 128 bytes = 256 values — and `norms` /
+// `qnorms_half` carry the bit counts |v|, |q| as floats (Hamming: dim); the accumulators hold the exact integer dot products.
+template <int METRIC, bool FP4 = false>
 __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a) {
-  static_assert(I8 == (METRIC == kHamming || METRIC == kJaccard), "the byte instance serves the bit metrics, the bf16 instance Cosine / DotProduct");
+  static_assert(FP4 == (METRIC == kHamming || METRIC == kJaccard), "the four-bit instance serves the bit metrics, the bf16 instance Cosine / DotProduct");
   constexpr bool HIB = METRIC != kHamming;  // Cosine / DotProduct / Jaccard: higher is better; Hamming: a distance
   constexpr int BM = kG16BM, BN = kG16BN, WAVES = kG16Waves, CAP = kG16Cap, QCAP = kG16Queue;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -554,8 +561,8 @@ _Pragma("unroll") \
       for (int rf_ = 0; rf_ < 4; rf_++) \
 _Pragma("unroll") \
         for (int t_ = 0; t_ < 2; t_++) { \
-          if ((FIRST) && m_ == 0) mfma_acc_first<I8>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
-          else mfma_acc<I8>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
+          if ((FIRST) && m_ == 0) mfma_acc_first<FP4>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
+          else mfma_acc<FP4>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
         } \
   } while (0)
 
@@ -638,14 +645,10 @@ _Pragma("unroll") \
     for (uint32_t kt = 1; kt + 1 < a.KT; kt++) VDB_PP_KTILE(false, false);
     VDB_PP_KTILE(false, true);
     const bool more = c < total;
-    // (an accumulator element as the float the epilogue works with: the int32 count of the byte instance converts exactly)
-#define VDB_G16_ACC_F(V) (I8 ? (float)__float_as_int(V) : (V))
+#define VDB_G16_ACC_F(V) (V)
 #include "g16_quicktest.inc"  // (waves 0-3: beside the last products of waves 4-7)
     if (wr == 0) pp_barrier();  // waves 0-3 wait for the last products of waves 4-7: the block is aligned again
-#define VDB_G16_ACC_ELEM(X, A) do { \
-      asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(X) : "a"(A)); \
-      if (I8) (X) = (float)__float_as_int(X); \
-    } while (0)
+#define VDB_G16_ACC_ELEM(X, A) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(X) : "a"(A))
 #include "g16_protocol.inc"
 #undef VDB_G16_ACC_ELEM
 #undef VDB_G16_ACC_F
@@ -777,7 +780,7 @@ static hipError_t launch_g16_pp(const Bf16GemmArgs& a, int blocks, hipStream_t s
 }
 
 template <int METRIC>
-static hipError_t launch_g16_i8(const Bf16GemmArgs& a, int blocks, hipStream_t st) {
+static hipError_t launch_g16_fp4(const Bf16GemmArgs& a, int blocks, hipStream_t st) {
   static bool done = false;
   if (!done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_gemm_bf16_pp<METRIC, true>),
@@ -825,15 +828,15 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
   a.dim = dim;
   a.nq = nq;
   a.k = k;
-  a.KT = split ? dim / 32 : dim / 64;  // (byte instance: dim in units of two bytes => k-tiles of 128 bytes)
+  a.KT = split ? dim / 32 : dim / 64;  // (four-bit instance: dim in units of two bytes => k-tiles of 128 bytes)
   a.G = p.G;
   a.nqt = p.nqt;
   a.qper = p.qper;
   a.qnorms = qnorms;
   a.blk_tau = blk_tau;
   a.qnorms_half = qnorms_half;
-  if (metric == kHamming) return launch_g16_i8<kHamming>(a, p.blocks, st);
-  if (metric == kJaccard) return launch_g16_i8<kJaccard>(a, p.blocks, st);
+  if (metric == kHamming) return launch_g16_fp4<kHamming>(a, p.blocks, st);
+  if (metric == kJaccard) return launch_g16_fp4<kJaccard>(a, p.blocks, st);
   if (split)
     return metric == kCosine ? launch_g16<kCosine, true>(a, p.blocks, st) : launch_g16<kDot, true>(a, p.blocks, st);
   if (pingpong_enabled()) return metric == kCosine ? launch_g16_pp<kCosine>(a, p.blocks, st) : launch_g16_pp<kDot>(a, p.blocks, st);

@@ -220,7 +220,7 @@ struct vdb_hip_index {
   // selection stage over SQ8 (level 3): bf16 image of the dequantised rows, their norms, f32 seed prefix
   vdb::DevBuf sq8_img, sq8_nrm, sq8_seed;
   uint64_t sq8_img_rows = 0;
-  // Hamming / Jaccard batches on the matrix cores (bits_gemm.hip): {0,1} byte image of the packed bit rows [capacity][stride], the
+  // Hamming / Jaccard batches on the matrix cores (bits_gemm.hip): four-bit image (E2M1 values 0 / +-1) of the packed bit rows [capacity][stride bytes], the
   // rows' bit counts as floats; built at the first large batch, kept current by inserts from then on
   vdb::DevBuf bits_img, bits_cnt;
   uint64_t bits_img_rows = 0;

@@ -245,7 +245,7 @@ static inline hipError_t run_gemm_schedule(const GemmSchedule& s, int metric, co
   }
   return hipSuccess;
 }
-// bits_gemm.hip: {0,1} byte image of packed bit rows (+ bit counts as floats) for the int8 GEMM distance of Hamming / Jaccard
+// bits_gemm.hip: four-bit image of packed bit rows (+ bit counts as floats) for the four-bit GEMM distance of Hamming / Jaccard
 void launch_bits_expand(int metric, const uint32_t* bits, uint32_t words, uint8_t* img, uint32_t img_stride, float* cnt, uint32_t row0,
                         uint32_t n_rows, uint32_t dim, float fill, hipStream_t st);
 uint32_t bits_image_stride(uint32_t dim);
