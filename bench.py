@@ -1254,9 +1254,9 @@ def main():
             row["note"] = {"euclidean": "batch: selection on the bf16 matrix cores over s = q.v - |v|^2/2 (augmented DotProduct form), canonical "
                                         "(q - v)^2 re-scoring of 64 candidates, per-query proof, gathered exact pass for unproven queries",
                            "dot": "batch: the headline's selection stage (plain bf16 selection + exact re-scoring + proof)",
-                           "hamming": "packed bits (x > 0.5), 96 B/row; batches of >= 224 queries: +-1 four-bit image (48 B per 96 values), dim - 2 |q ^ v| as a four-bit GEMM on the "
+                           "hamming": "packed bits (x > 0.5), 96 B/row; batches of >= 32 queries: +-1 four-bit image (48 B per 96 values), dim - 2 |q ^ v| as a four-bit GEMM on the "
                                       "matrix cores with the fused top-k (exact integers); smaller batches: 32 queries per corpus pass, AND+popcount",
-                           "jaccard": "packed bits (x > 0.5), 96 B/row; batches of >= 224 queries: {0,1} four-bit image, |q & v| as a four-bit GEMM on the matrix "
+                           "jaccard": "packed bits (x > 0.5), 96 B/row; batches of >= 32 queries: {0,1} four-bit image, |q & v| as a four-bit GEMM on the matrix "
                                       "cores, per-element bound d - c|v| >= c|q| in the epilogue (exact integers); smaller batches: AND+popcount"}[mname]
             if not a.no_cpu_baseline:
                 # the reference's exact path for this metric restated on the host cores (mode R: wide16 kernels; Hamming /

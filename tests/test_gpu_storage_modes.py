@@ -111,6 +111,47 @@ def test_binary_codes_and_scan_exact(gpu_required, n, dim):
     ix.close()
 
 
+@pytest.mark.parametrize("n,dim", [(70_077, 256), (66_100, 100)])
+def test_binary_batches_on_the_matrix_cores_exact(gpu_required, n, dim):
+    """Binary storage mode, batches of >= 32 queries over >= 65 536 rows: Hamming between the sign-bit codes as a four-bit GEMM
+    distance (bits_gemm.hip) — integer distances, ties by row: equal to the oracle's scan on sampled queries and to the vector-ALU
+    kernels on every query; rows appended later and soft deletes included; a metric that is not a bit metric (the codes do not
+    depend on it)."""
+    rng = np.random.default_rng(n + dim)
+    rows = special_rows(rng, n, dim)
+    rows[1000:1030] = rows[999]                    # duplicated codes: exact ties
+    ids = np.arange(n, dtype=np.uint64) * 2 + 1
+    ix = va.HnswIndex(dim, DM.Cosine)
+    ix.upload(ids[:n - 300], rows[:n - 300])
+    ix.set_storage_mode(SM.Binary)
+    live = np.ones(n, bool)
+
+    def check(nq, k, n_now):
+        Q = rng.standard_normal((nq, dim)).astype(np.float32)
+        Q[1] = rows[999]
+        Q[2] = 0.0
+        gid, gsc, gcnt = ix.search_batch_binary(Q, k)
+        assert ix.last_kernels() & va.KERNEL_BITS_GEMM, "the matrix-core path did not serve the batch"
+        ix.set_option(va.OPT_SWEEP_ENGINE, 0)
+        vid, vsc, vcnt = ix.search_batch_binary(Q, k)
+        assert not (ix.last_kernels() & va.KERNEL_BITS_GEMM)
+        ix.set_option(va.OPT_SWEEP_ENGINE, -1)
+        assert np.array_equal(gcnt, vcnt) and np.array_equal(gid, vid) and np.array_equal(gsc, vsc), (n, dim, nq, k)
+        sel = np.unique(np.concatenate([[0, 1, 2, nq - 1], rng.choice(nq, 12, replace=False)]))
+        lv = np.nonzero(live[:n_now])[0]
+        eid, esc = po.scan_topk_binary(rows[lv], Q[sel], k)
+        assert np.array_equal(gid[sel], ids[lv[eid.astype(np.int64)]]) and np.array_equal(gsc[sel], esc)
+
+    check(256, 10, n - 300)
+    check(40, 3, n - 300)
+    ix.upload(ids[n - 300:], rows[n - 300:])       # the image follows the inserts
+    for d in rng.choice(n, 500, replace=False):
+        assert ix.remove(int(ids[d]))
+        live[d] = False
+    check(600, 10, n)
+    ix.close()
+
+
 def test_storage_mode_state_errors(gpu_required):
     ix = va.HnswIndex(8, DM.Cosine)
     ix.upload(np.arange(4), np.eye(4, 8, dtype=np.float32))

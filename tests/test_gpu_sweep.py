@@ -503,7 +503,7 @@ def test_large_planted_neighbours_200k(gpu_required, metric):
 @pytest.mark.parametrize("metric", [DM.Hamming, DM.Jaccard])
 @pytest.mark.parametrize("n,dim", [(70_077, 768), (66_600, 100), (140_000, 48), (66_100, 1000)])
 def test_bit_metric_batches_on_the_matrix_cores_exact(gpu_required, metric, n, dim):
-    """Hamming / Jaccard batches of >= 224 queries over >= 65 536 rows run as a four-bit GEMM distance (bits_gemm.hip: the
+    """Hamming / Jaccard batches of >= 32 queries over >= 65 536 rows run as a four-bit GEMM distance (bits_gemm.hip: the
     dot products on v_mfma_scale_f32_16x16x128_f8f6f4 over E2M1 images, the metric's bound and finish in the selection kernel's epilogue).  Integer
     work: ids, ranks (ties by row: dim 48 ties almost everywhere) and score bits equal the oracle's on sampled queries and the
     vector-ALU kernels' on every query; zero rows / zero queries (empty unions: Jaccard 1.0), duplicated rows, a ragged last
@@ -540,7 +540,8 @@ def test_bit_metric_batches_on_the_matrix_cores_exact(gpu_required, metric, n, d
             assert np.array_equal(bits(gsc[qi]), bits(s[j]))
 
     check(256, 10, n_now=n - 500)
-    check(300, 1, n_now=n - 500)                         # 256 on the matrix cores + 44 on the vector ALUs
+    check(300, 1, n_now=n - 500)                         # one full query tile + a partly filled one
+    check(40, 10, n_now=n - 500)                         # the smallest batches that take the matrix cores (>= 32 queries)
     assert ix.upload(ids[n - 500:], rows[n - 500:]) == 500   # the image follows the inserts
     check(1024, 3)
     check(700, 10)

@@ -29,7 +29,7 @@ p.add_argument("--engine", type=int, default=1, help="0 = vector-ALU kernels for
 p.add_argument("--only-it", type=int, default=0, help="replay: generate every case, run only this one (verbose)")
 p.add_argument("--euclid", action="store_true", help="Euclidean only (matrix-core batches + exact re-scoring)")
 p.add_argument("--bits", action="store_true", help="Hamming / Jaccard (packed-bit kernels) instead of cosine / dot")
-p.add_argument("--bits-big", action="store_true", help="Hamming / Jaccard batches that take the four-bit GEMM path (>= 224 queries, >= 65 536 rows)")
+p.add_argument("--bits-big", action="store_true", help="Hamming / Jaccard batches that take the four-bit GEMM path (>= 32 queries, >= 65 536 rows)")
 a = p.parse_args()
 rng = np.random.default_rng(a.seed)
 NT = po.host_threads()
@@ -102,7 +102,7 @@ while time.time() < t_end:
         metric = [DM.Hamming, DM.Jaccard][int(rng.integers(0, 2))]
         n = int(rng.choice([65_536, 66_000, 70_077, 150_000, 300_001]))
         dim = int(rng.choice([33, 64, 100, 256, 768, 1000]))
-        nq = int(rng.choice([224, 256, 300, 480, 600, 700, 1024, 1100]))
+        nq = int(rng.choice([32, 33, 64, 100, 224, 256, 300, 480, 600, 700, 1024, 1100]))
         k = int(rng.choice([1, 3, 10]))
         kind = str(rng.choice(["normal", "normal", "dups", "zeros_mixed"]))
     if a.bf16_big:

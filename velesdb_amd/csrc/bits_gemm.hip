@@ -15,6 +15,7 @@
 // kernel (sweep_topk_bits_tile<B = 32>, AND + popcount) takes 2.8 / 3.2 ms per 1 024 queries at 1 M x 768 (vector-ALU issue-bound);
 // this path 0.72 / 0.82 ms (the first version, on v_mfma_i32_16x16x64_i8 over byte images: 0.96 / 1.02 ms).
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 
 #include "vdb_device.hpp"
@@ -145,22 +146,32 @@ static void launch_seed_scores_fp4(int metric, const uint8_t* rows8, uint32_t st
     hipLaunchKernelGGL((seed_scores_fp4<kJaccard>), grid, dim3(256), 0, st, rows8, stride, cnt, alive, q8, qcnt, keys, seed_rows, nq);
 }
 constexpr uint32_t kBitsSeedRows = 4096;
+// smallest batch that takes the matrix cores (VELESDB_BITS_GEMM_MIN_QUERIES overrides: probes).  1 M x 768 (profiles/
+// r04r_bits_gemm_min_queries.log): 16 queries 0.21 / 0.17 ms on the vector ALUs against 0.28 / 0.29 ms here (one partly filled
+// query tile costs what a full one costs), 32 queries 0.32 / 0.37 against 0.29 / 0.30, 64 queries 0.52 / 0.56 against 0.30 / 0.32
+constexpr uint32_t kBitsGemmMinQueries = 32;
 
 uint32_t bits_image_stride(uint32_t dim) { return std::max<uint32_t>(256u, (dim + 255u) / 256u * 128u); }  // bytes (two values each); >= 2 k-tiles
 
-// does a chunk of the batch take the matrix cores?  Whole 256-query tiles filled to >= 7/8 (the rule of the bf16 result path)
+// does a chunk of the batch take the matrix cores?
 uint32_t bits_gemm_chunk(const vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
-  if (nq_left < kGemmBigMinQueries) return 0;
-  uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
-  if ((uint64_t)nqg * 8 < (uint64_t)((nqg + 255) / 256) * 256 * 7) nqg = nqg / 256 * 256;
-  return nqg >= kGemmBigMinQueries ? nqg : 0;
+  // up to 1 024 queries, whatever that leaves of the last 256-query tile: a partly filled tile costs what a full one costs, a second
+  // pass costs the whole fixed part again (the selection stage's rule, index.hip select_chunk)
+  static const uint32_t min_q = [] {
+    const char* e = getenv("VELESDB_BITS_GEMM_MIN_QUERIES");
+    return e ? (uint32_t)atoi(e) : kBitsGemmMinQueries;
+  }();
+  const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);
+  return nqg >= min_q ? nqg : 0;
 }
 
 // nqg packed queries (qbits [nqg][words]) against the index's four-bit image: exact top-k per query into d_ids / d_scores / d_n
-int32_t brute_bits_gemm_dev(vdb_hip_index* ix, const uint32_t* qbits, uint32_t nqg, uint32_t k, uint64_t* d_ids, float* d_scores,
-                            uint32_t* d_n, hipStream_t st) {
-  const bool hib = ix->metric == VDB_JACCARD;
+// (metric, img, cnt: the index's own bit metric over bits_img / bits_cnt, or VDB_HAMMING over the sign-bit codes' image — the Binary
+// storage mode, storage_modes.hip)
+int32_t brute_bits_gemm_dev(vdb_hip_index* ix, int metric, const uint8_t* img, const float* cnt, const uint32_t* qbits, uint32_t nqg, uint32_t k,
+                            uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st) {
+  const bool hib = metric == VDB_JACCARD;
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
   const uint32_t n = (uint32_t)ix->n_rows, stride = bits_image_stride(ix->dim), dim2 = stride / 2;  // the kernel's unit: two bytes
   // Launch schedule: the sample seed over the first rows (bounds only), then the four-bit GEMM in launches of growing size (gemm_schedule,
@@ -191,7 +202,7 @@ int32_t brute_bits_gemm_dev(vdb_hip_index* ix, const uint32_t* qbits, uint32_t n
   uint64_t* tau0 = reinterpret_cast<uint64_t*>(sd + o_tau);
   float* qcnt = reinterpret_cast<float*>(sd + o_qc);
   uint8_t* qimg = ix->s_misc.as<uint8_t>();
-  launch_bits_expand(ix->metric, qbits, ix->words, qimg, stride, qcnt, 0, nqg, ix->dim, (float)ix->dim, st);  // (Hamming: qn[b] = dim)
+  launch_bits_expand(metric, qbits, ix->words, qimg, stride, qcnt, 0, nqg, ix->dim, (float)ix->dim, st);  // (Hamming: qn[b] = dim)
   // the kernel stages whole 256-query tiles: zero rows behind the batch
   if (nqg % 256u) VDB_HIP(hipMemsetAsync(qimg + (size_t)nqg * stride, 0, (size_t)256 * stride, st));
   // (no fill of the partial lists: every block writes all k slots of every query of its tile, and a merge reads only lists written)
@@ -206,7 +217,7 @@ int32_t brute_bits_gemm_dev(vdb_hip_index* ix, const uint32_t* qbits, uint32_t n
   {
     const uint32_t seed_rows = std::min(R0, n);
     uint64_t* skeys = reinterpret_cast<uint64_t*>(sd + o_seedp);
-    launch_seed_scores_fp4(ix->metric, ix->bits_img.as<uint8_t>(), stride, ix->bits_cnt.as<float>(), alive, qimg, qcnt, skeys, seed_rows, nqg, st);
+    launch_seed_scores_fp4(metric, img, stride, cnt, alive, qimg, qcnt, skeys, seed_rows, nqg, st);
     ms.part_keys = skeys;
     ms.n_lists = (seed_rows + 15u) / 16u;
     ms.k = 1;
@@ -217,7 +228,7 @@ int32_t brute_bits_gemm_dev(vdb_hip_index* ix, const uint32_t* qbits, uint32_t n
   }
   ms.k = k;
   e = run_gemm_schedule(
-      sch, ix->metric, reinterpret_cast<const uint16_t*>(ix->bits_img.p), dim2, ix->bits_cnt.as<float>(), alive, reinterpret_cast<const uint16_t*>(qimg), dim2,
+      sch, metric, reinterpret_cast<const uint16_t*>(img), dim2, cnt, alive, reinterpret_cast<const uint16_t*>(qimg), dim2,
       tau0, parts, lists, /*list_first=*/0, dim2, nqg, k, st, /*split=*/false, nullptr, nullptr, qcnt, [](int) {},
       [&](int, uint32_t list_off, bool last) {
         if (last) return;  // bound of the next launch: k-th best key over everything swept so far

@@ -1251,8 +1251,8 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
       if (!nqg) break;
       int32_t rg = ensure_bits_image(ix, st);
       if (rg == VDB_OK)
-        rg = brute_bits_gemm_dev(ix, ix->s_qbits.as<uint32_t>() + (size_t)qdone * ix->words, nqg, k, d_ids + (size_t)qdone * k,
-                                 d_scores + (size_t)qdone * k, d_n + qdone, st);
+        rg = brute_bits_gemm_dev(ix, ix->metric, ix->bits_img.as<uint8_t>(), ix->bits_cnt.as<float>(), ix->s_qbits.as<uint32_t>() + (size_t)qdone * ix->words,
+                                 nqg, k, d_ids + (size_t)qdone * k, d_scores + (size_t)qdone * k, d_n + qdone, st);
       if (rg != VDB_OK) return rg;
       qdone += nqg;
     }

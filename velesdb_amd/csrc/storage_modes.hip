@@ -699,6 +699,29 @@ int32_t brute_sq8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, ui
 
 // BinaryQuantizedVector::hamming_distance between the sign bits of the queries and of every row: the packed-bit
 // sweep of sweep.hip over the sign-bit array (scores = distance as f32, smallest first)
+// the four-bit image of the sign-bit codes (bits_gemm.hip: batches of >= 32 queries run on the matrix cores), in the storage mode's
+// image buffers (vdb_index.hpp); built at first use, extended lazily behind inserts — inside a search: see index.hip
+// build_image_on_primary for why a build is complete before the image is handed on
+static int32_t ensure_sign_image(vdb_hip_index* cx, hipStream_t st) {
+  vdb_hip_index* p = primary_of(cx);
+  std::lock_guard<std::mutex> il(p->img_mu);
+  const bool stale = p->sq8_img.cap == 0 || p->sq8_img_rows < p->n_rows;
+  const uint64_t cap = std::max<uint64_t>(p->capacity, 1) + kRowSlack;
+  const uint32_t stride = bits_image_stride(p->dim);
+  hipError_t e;
+  if ((e = p->sq8_img.reserve(cap * (size_t)stride, true, st)) != hipSuccess || (e = p->sq8_nrm.reserve(cap * 4, true, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("sign-bit image: ") + hipGetErrorString(e));
+  if (p->sq8_img_rows < p->n_rows) {
+    launch_bits_expand(VDB_HAMMING, p->sign_bits.as<uint32_t>(), p->words, p->sq8_img.as<uint8_t>(), stride, p->sq8_nrm.as<float>(), (uint32_t)p->sq8_img_rows,
+                       (uint32_t)(p->n_rows - p->sq8_img_rows), p->dim, 0.0f, st);
+    p->sq8_img_rows = p->n_rows;
+    VDB_HIP(hipGetLastError());
+  }
+  if (stale) VDB_HIP(hipStreamSynchronize(st));
+  if (cx != p) copy_image_fields(cx, p);
+  return VDB_OK;
+}
+
 int32_t brute_binary_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint64_t* d_ids,
                          float* d_scores, uint32_t* d_n, hipStream_t st) {
   if (ix->storage_mode != VDB_STORAGE_BINARY) return fail(VDB_ERR_STATE, "Binary search: set the storage mode to Binary first");
@@ -713,6 +736,25 @@ int32_t brute_binary_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
   if (e != hipSuccess) return fail(VDB_ERR_OOM, "qbits scratch");
   hipLaunchKernelGGL(sign_bits_rows, dim3((unsigned)std::min<uint32_t>((nq + 3) / 4, 4096)), dim3(256), 0, st, d_q, q_stride,
                      ix->s_qbits.as<uint32_t>(), ix->words, 0u, nq, ix->dim);
+  // large batches: Hamming between sign-bit codes as a four-bit GEMM distance on the matrix cores (bits_gemm.hip), exact; the rest of
+  // the batch and every other shape on the vector ALUs — the same keys either way
+  uint32_t qdone = 0;
+  while (opt_value(ix, VDB_OPT_SWEEP_ENGINE) == 1 && opt_value(ix, VDB_OPT_MAX_QUERY_TILE) >= 128) {
+    const uint32_t nqg = bits_gemm_chunk(ix, nq - qdone, k);
+    if (!nqg) break;
+    int32_t rg = ensure_sign_image(ix, st);
+    if (rg == VDB_OK)
+      rg = brute_bits_gemm_dev(ix, VDB_HAMMING, ix->sq8_img.as<uint8_t>(), ix->sq8_nrm.as<float>(), ix->s_qbits.as<uint32_t>() + (size_t)qdone * ix->words, nqg,
+                               k, d_ids + (size_t)qdone * k, d_scores + (size_t)qdone * k, d_n + qdone, st);
+    if (rg != VDB_OK) return rg;
+    qdone += nqg;
+  }
+  if (qdone == nq) return VDB_OK;
+  d_ids += (size_t)qdone * k;
+  d_scores += (size_t)qdone * k;
+  d_n += qdone;
+  const uint32_t* qbits_rest = ix->s_qbits.as<uint32_t>() + (size_t)qdone * ix->words;
+  nq -= qdone;
   const BitsPlan bp = plan_bits_sweep(ix->n_rows, ix->n_cus, ix->words, nq, k);  // batches: 8 / 32 queries per corpus pass
   const int blocks = bp.blocks;
   if ((e = ix->s_part_keys.reserve((size_t)nq * blocks * k * 8, false, st)) != hipSuccess ||
@@ -720,7 +762,7 @@ int32_t brute_binary_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     return fail(VDB_ERR_OOM, "top-k scratch");
   BitsArgs ba{};
   ba.bits = ix->sign_bits.as<uint32_t>();
-  ba.qbits = ix->s_qbits.as<uint32_t>();
+  ba.qbits = qbits_rest;
   ba.alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
   ba.part_keys = ix->s_part_keys.as<uint64_t>();
   ba.part_cnt = ix->s_part_cnt.as<uint32_t>();

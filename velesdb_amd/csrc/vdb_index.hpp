@@ -217,7 +217,8 @@ struct vdb_hip_index {
   int32_t storage_mode = 0;      // VDB_STORAGE_FULL
   uint64_t sq8_stride = 0;       // bytes per SQ8 row (multiple of 16)
   vdb::DevBuf sq8_codes, sq8_min, sq8_max, sq8_nsq, sign_bits;
-  // selection stage over SQ8 (level 3): bf16 image of the dequantised rows, their norms, f32 seed prefix
+  // selection stage over SQ8 (level 3): bf16 image of the dequantised rows, their norms, f32 seed prefix.  The Binary storage mode
+  // keeps the four-bit image of its sign-bit codes in the same two buffers (one storage mode at a time; sq8_img_rows = its progress)
   vdb::DevBuf sq8_img, sq8_nrm, sq8_seed;
   uint64_t sq8_img_rows = 0;
   // Hamming / Jaccard batches on the matrix cores (bits_gemm.hip): four-bit image (E2M1 values 0 / +-1) of the packed bit rows [capacity][stride bytes], the
@@ -390,8 +391,8 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
 int select_level_sq8(vdb_hip_index* ix, uint32_t nq_left, uint32_t k);
 // bits_gemm.hip
 uint32_t bits_gemm_chunk(const vdb_hip_index* ix, uint32_t nq_left, uint32_t k);
-int32_t brute_bits_gemm_dev(vdb_hip_index* ix, const uint32_t* qbits, uint32_t nqg, uint32_t k, uint64_t* d_ids, float* d_scores,
-                            uint32_t* d_n, hipStream_t st);
+int32_t brute_bits_gemm_dev(vdb_hip_index* ix, int metric, const uint8_t* img, const float* cnt, const uint32_t* qbits, uint32_t nqg, uint32_t k,
+                            uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st);
 int32_t brute_binary_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint64_t* d_ids,
                          float* d_scores, uint32_t* d_n, hipStream_t st);
 }  // namespace vdb
