@@ -305,7 +305,7 @@ def main():
     flops = 2.0 * N * D * tile  # algorithmic: one multiply-add per (row, query, dimension)
     tflops = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
     BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
-    # index.hip split_path_ok: large exact cosine / dot batches select on the bf16 matrix cores (sweep_split.hip)
+    # select_stage.hip split_path_ok: large exact cosine / dot batches select on the bf16 matrix cores (sweep_split.hip)
     split_active = (mfma and not a.no_split and a.select_level > 0 and a.tile >= 128 and Q >= 224 and Q * 8 >= ((Q + 255) // 256) * 256 * 7
                     and K <= 10 and N >= 65536 and D % 32 == 0 and D >= 64)
 

@@ -150,7 +150,7 @@ def test_bf16_gemm_big_tile_exact_and_deleted_rows():
 
 
 # ---- BASELINE configs[3]'s own kernel: sweep_topk_gemm_bf16_glds in RESULT mode (>= 65 536 rows, batches that fill
-# ---- 256-query tiles, k <= 10) — seed sweep + 1-2 LDS-DMA launches + merges (index.hip brute_bf16_dev) -------------------
+# ---- 256-query tiles, k <= 10) — seed sweep + 1-2 LDS-DMA launches + merges (select_stage.hip brute_bf16_dev) -------------------
 def check_sampled(metric, pm, rows, qs, k, gids, gsc, gcnt, sample, tol=1e-5):
     """The rule of check() for a SAMPLE of the batch's queries, with the f64 reference computed in row chunks (the whole
     f64 score matrix of 1 M rows does not fit)."""

@@ -134,7 +134,7 @@ def test_hnsw_1m_vs_oracle(corpus, index, tmp_path, record_property):
 
 def test_configs3_full_size_10m_bf16_vs_oracle(gpu_required):
     """BASELINE configs[3] at FULL size: 10 000 000 x 768 bf16, 1 024 queries per batch, k = 10 — the launch bench.py quotes
-    `bf16_gemm` on (seed sweep + two launches of sweep_topk_gemm_bf16_glds + merges, index.hip brute_bf16_dev).  The corpus is
+    `bf16_gemm` on (seed sweep + two launches of sweep_topk_gemm_bf16_glds + merges, select_stage.hip brute_bf16_dev).  The corpus is
     generated chunk-wise on the device exactly as bench.py does and uploaded chunk by chunk; every chunk is also copied to the
     host once, where the oracle (half_precision.rs:199-255 semantics) scans it for 32 sampled queries and the per-chunk lists are
     merged — the same scan an index over all 10 M rows would get.  Compared by the rule of tests/test_gpu_bf16.py: same ids

@@ -157,7 +157,7 @@ uint32_t bits_image_stride(uint32_t dim) { return std::max<uint32_t>(256u, (dim 
 uint32_t bits_gemm_chunk(const vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
   // up to 1 024 queries, whatever that leaves of the last 256-query tile: a partly filled tile costs what a full one costs, a second
-  // pass costs the whole fixed part again (the selection stage's rule, index.hip select_chunk)
+  // pass costs the whole fixed part again (the selection stage's rule, select_stage.hip select_chunk)
   static const uint32_t min_q = [] {
     const char* e = getenv("VELESDB_BITS_GEMM_MIN_QUERIES");
     return e ? (uint32_t)atoi(e) : kBitsGemmMinQueries;

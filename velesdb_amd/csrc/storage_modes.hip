@@ -430,7 +430,7 @@ static hipError_t launch_sq8_m(int metric, const Sq8Args& a, int blocks, size_t 
   return launch_sq8_t<kDot, B>(a, blocks, lds, st, groups);
 }
 
-// ---- selection stage over the SQ8 storage mode (index.hip brute_split_dev, level 3) -------------------------------------
+// ---- selection stage over the SQ8 storage mode (select_stage.hip brute_split_dev, level 3) -------------------------------------
 // The dequantised rows d = code * scale + min as a bf16 image (what the matrix cores select on), their norms sqrt(nsq), and
 // the first kSplitSeedRows dequantised rows in f32 (what the exact matrix-core kernel seeds the thresholds from).
 // Euclidean (aug): the augmented form of sweep_split.hip — image rows of dim + 64 (slots dim, dim + 1 = hi / lo of -nsq / 2), seed
@@ -531,7 +531,7 @@ int32_t storage_mode_append(vdb_hip_index* ix, uint64_t first, uint64_t n) {
 // selection stage (level 3): bf16 image of the dequantised rows, their norms, the f32 seed prefix — built at first use,
 // kept current by storage_mode_append
 static int32_t ensure_sq8_select_impl(vdb_hip_index* ix, hipStream_t st);
-int32_t ensure_sq8_select(vdb_hip_index* cx, hipStream_t st) {  // (inside a search: see index.hip build_image_on_primary)
+int32_t ensure_sq8_select(vdb_hip_index* cx, hipStream_t st) {  // (inside a search: see select_stage.hip build_image_on_primary)
   vdb_hip_index* p = primary_of(cx);
   {
     std::lock_guard<std::mutex> il(p->img_mu);

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void seed_scores_bf16(const uint16_t* rows16, 
         for (int t = 0; t < 4; t++) acc[rb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rb][s], bv[s][t], acc[rb][t], 0, 0, 0);
   }
   // lane holds rows row0 + 16 rb + 4 kk + r (rb, r = 0..3) of query column qb + 16 t + i: the best of those 16 as ONE key —
-  // keys[q][group], group = 4 (row0 / 64) + kk (the seed is a sample: sweep_split.hip file header, index.hip brute_split_dev)
+  // keys[q][group], group = 4 (row0 / 64) + kk (the seed is a sample: sweep_split.hip file header, select_stage.hip brute_split_dev)
   const uint32_t ngrp = (seed_rows + 15u) / 16u;
 #pragma unroll
   for (int t = 0; t < 4; t++) {

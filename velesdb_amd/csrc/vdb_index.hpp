@@ -385,7 +385,7 @@ int32_t brute_sq8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, ui
 int32_t ensure_sq8_select(vdb_hip_index* ix, hipStream_t st);
 int32_t sq8_fallback_flagged(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, const uint32_t* flags,
                              uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st);
-// index.hip: selection + exact re-scoring + proof for a chunk of <= 1024 queries (level 1 / 2: f32 rows, 3: SQ8 storage mode)
+// select_stage.hip: selection + exact re-scoring + proof for a chunk of <= 1024 queries (level 1 / 2: f32 rows, 3: SQ8 storage mode)
 int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, uint64_t* d_ids,
                         float* d_scores, uint32_t* d_n, hipStream_t st, int level);
 int select_level_sq8(vdb_hip_index* ix, uint32_t nq_left, uint32_t k);
