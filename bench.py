@@ -105,6 +105,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
 
+    def events_on_last(i, n):
+        """Inside a timed region of n steps: the library records the HIP events that time a kernel (roofline.kernel_ms, read back as
+        last_kernel_ms / last_selection_ms = the LAST step's launches) on step n - 1 only.  A record is not free: the GPU idles ~6 us on
+        either side of a launch bracketed by events (profiles/r04z_headline_step_timeline.txt: 8 records = 47 us of a 1.75 ms headline
+        step, 2.7 %), and the library's default — what a caller gets — is no events at all."""
+        if i == n - 1:
+            va.set_kernel_timing(True)
+
     # ---- the reference's calling pattern (SURVEY 8b: concurrent `search` from many threads, one query per call): T native host
     # threads over the C ABI's HOST-pointer entry point vdb_hip_index_search (tools/callers_bench.cpp; Python threads would
     # measure the interpreter lock).  Every answer is compared bit for bit with a batched reference call.
@@ -250,9 +258,9 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except OSError:
             pass
-    va.set_kernel_timing(True)
     t0 = time.perf_counter()
     for i in range(a.steps):
+        events_on_last(i, a.steps)
         step(a.warmup + i)
     torch.cuda.synchronize()
     dt_mine = time.perf_counter() - t0  # this rank's own steps (the timed region below ends behind the barrier: the slowest rank's)
@@ -338,7 +346,8 @@ def main():
                     "frac": round(sel_tf / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "kernel": sel_kernel,
                     "kernel_ms": round(sel_ms, 4), "launches_timed": sel_launches,
-                    "kernel_ms_note": "sum over the step's launches of the selection kernel (growing row ranges, thresholds re-seeded in between)",
+                    "kernel_ms_note": "sum over the step's launches of the selection kernel (growing row ranges, thresholds re-seeded in between); "
+                                      "HIP events on the last of the timed steps only (a record idles the GPU ~6 us either side of the launch)",
                     "select_level": level,
                     "alg_flops_per_launch": 2.0 * (N - 4096) * D * tile, "queries_per_launch": tile, "alg_bytes_per_launch": alg_bytes,
                     "mfmas_per_product": mfmas_per_product,
@@ -356,10 +365,10 @@ def main():
         for i in range(2):
             step(i)
         torch.cuda.synchronize()
-        va.set_kernel_timing(True)
         te = time.perf_counter()
         ne = max(2, min(a.steps, 5))
         for i in range(ne):
+            events_on_last(i, ne)
             step(a.warmup + i)
         torch.cuda.synchronize()
         e_dt = (time.perf_counter() - te) / ne
@@ -418,8 +427,8 @@ def main():
             shutil.rmtree(tdir, ignore_errors=True)
 
     if rank == 0 and world == 1 and not a.no_traffic_pass:
-        tb_, tk_, tsrc_ = traffic_pass("headline", ("sweep_topk", "merge_topk", "split_rerank", "split_seed", "split_reseed", "select_fallback", "seed_scores_bf16", "sel16_prep_queries",
-                                                "l2_seed", "collect_flagged", "scatter_flagged", "select_stats"), [])
+        tb_, tk_, tsrc_ = traffic_pass("headline", ("sweep_topk", "merge_topk", "split_rerank", "split_seed", "split_reseed", "seed_scores_bf16", "sel16_prep_queries",
+                                                "l2_seed", "select_finish"), [])
         roofline["traffic_source"] = tsrc_
         if tb_ is not None:
             roofline["traffic"] = tb_
@@ -450,10 +459,10 @@ def main():
                 ix.search_batch_dev(queries.data_ptr(), nq_t, K, 0, va.MODE_BRUTE, t_ids.data_ptr(),
                                     t_sc.data_ptr(), t_n.data_ptr(), stream)
             torch.cuda.synchronize()
-            va.set_kernel_timing(True)
             reps = 10
             tt = time.perf_counter()
-            for _ in range(reps):
+            for r_ in range(reps):
+                events_on_last(r_, reps)
                 ix.search_batch_dev(queries.data_ptr(), nq_t, K, 0, va.MODE_BRUTE, t_ids.data_ptr(),
                                     t_sc.data_ptr(), t_n.data_ptr(), stream)
             torch.cuda.synchronize()
@@ -518,10 +527,10 @@ def main():
     lat = {}
     if rank == 0:
         torch.cuda.synchronize()
-        va.set_kernel_timing(True)
         reps = 20
         t1 = time.perf_counter()
         for i in range(reps):
+            events_on_last(i, reps)
             ix.search_batch_dev(queries[i:i + 1].data_ptr(), 1, K, 0, va.MODE_BRUTE, out_ids.data_ptr(),
                                 out_sc.data_ptr(), out_n.data_ptr(), stream)
         torch.cuda.synchronize()
@@ -553,9 +562,9 @@ def main():
 
         hstep()
         barrier()
-        va.set_kernel_timing(True)
         th = time.perf_counter()
-        for _ in range(a.hnsw_steps):
+        for i_ in range(a.hnsw_steps):
+            events_on_last(i_, a.hnsw_steps)
             hstep()
         barrier()
         hdt_mine = time.perf_counter() - th
@@ -603,9 +612,9 @@ def main():
                                            c_n.data_ptr(), stream)
                 cstep()
                 torch.cuda.synchronize()
-                va.set_kernel_timing(True)
                 tc0 = time.perf_counter()
-                for _ in range(2):
+                for i_ in range(2):
+                    events_on_last(i_, 2)
                     cstep()
                 torch.cuda.synchronize()
                 cdt_ = (time.perf_counter() - tc0) / 2
@@ -679,9 +688,9 @@ def main():
 
             istep()
             barrier()
-            va.set_kernel_timing(True)
             ti = time.perf_counter()
-            for _ in range(a.hnsw_steps):
+            for i_ in range(a.hnsw_steps):
+                events_on_last(i_, a.hnsw_steps)
                 istep()
             barrier()
             idt = max_over_ranks(time.perf_counter() - ti)
@@ -948,9 +957,9 @@ def main():
 
         estep()
         torch.cuda.synchronize()
-        va.set_kernel_timing(True)
         te = time.perf_counter()
-        for _ in range(a.hnsw_steps):
+        for i_ in range(a.hnsw_steps):
+            events_on_last(i_, a.hnsw_steps)
             estep()
         torch.cuda.synchronize()
         edt = time.perf_counter() - te
@@ -1113,9 +1122,9 @@ def main():
 
         bstep()
         torch.cuda.synchronize()
-        va.set_kernel_timing(True)
         tb0 = time.perf_counter()
-        for _ in range(a.bf16_steps):
+        for i_ in range(a.bf16_steps):
+            events_on_last(i_, a.bf16_steps)
             bstep()
         torch.cuda.synchronize()
         bdt = (time.perf_counter() - tb0) / a.bf16_steps
@@ -1226,9 +1235,9 @@ def main():
                     ixm.search_batch_dev(qsrc.data_ptr(), nq_m, K, 0, va.MODE_BRUTE, out_ids.data_ptr(), out_sc.data_ptr(),
                                          out_n.data_ptr(), stream)
                 torch.cuda.synchronize()
-                va.set_kernel_timing(True)
                 tm = time.perf_counter()
-                for _ in range(reps):
+                for r_ in range(reps):
+                    events_on_last(r_, reps)
                     ixm.search_batch_dev(qsrc.data_ptr(), nq_m, K, 0, va.MODE_BRUTE, out_ids.data_ptr(), out_sc.data_ptr(),
                                          out_n.data_ptr(), stream)
                 torch.cuda.synchronize()

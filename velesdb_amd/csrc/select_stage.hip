@@ -356,7 +356,7 @@ int select_level(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (k == 0 || k > kGemmBf16MaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
   if (!select_chunk(nq_left)) return 0;
   if (want < 2 || ix->dim % 64 != 0 || ix->dim < 128) return 1;
-  // what did the finished level-2 batches of this handle look like?  (pinned host memory, written by select_stats_kernel)
+  // what did the finished level-2 batches of this handle look like?  (pinned host memory, written by the re-scoring launch, sweep_split.hip selection_batch_tail)
   if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
     ix->sel_seq_seen = ix->sel_stats[2];
     if (ix->sel_stats[3] == 2u && (uint64_t)ix->sel_stats[0] * 16 > ix->sel_stats[1]) ix->sel16_hold = 64;  // > 1/16 unproven
@@ -486,7 +486,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
                o_n = take((size_t)nqg * 4), o_tau = take((size_t)nqg * 8), o_delta = take((size_t)nqg * 4),
                o_qn = take((size_t)nqg * 4), o_rho = take((size_t)nqg * 4), o_flags = take((size_t)nqg * 4 + 64 * 4 + 16), o_btau = take((size_t)nqg * lists * 8),
                o_fid = take((size_t)nqg * k * 8), o_fsc = take((size_t)nqg * k * 4), o_fn = take((size_t)nqg * 4),
-               o_qmap = take((size_t)nqg * 4 + 16), o_gid = take((size_t)96 * k * 8), o_gsc = take((size_t)96 * k * 4),
+               o_qmap = take((size_t)nqg * 8), o_gid = take((size_t)96 * k * 8), o_gsc = take((size_t)96 * k * 4),
                o_gn = take((size_t)96 * 4);
   hipError_t e;
   if ((e = ix->s_seed.reserve(off, false, st)) != hipSuccess ||
@@ -509,6 +509,9 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   uint32_t* flags = reinterpret_cast<uint32_t*>(sd + o_flags);
   uint32_t* tile_needed = flags + nqg;          // [<= 64]
   uint32_t* norm_max = tile_needed + 64;
+  uint32_t* qcount = norm_max + 1;              // (cleared with the flags) the unproven queries list themselves: sweep_split.hip list_unproven
+  uint32_t* qmap = reinterpret_cast<uint32_t*>(sd + o_qmap);  // [nqg] slot -> query
+  uint32_t* qslot = qmap + nqg;                                // [nqg] query -> slot
   uint64_t* blk_tau = reinterpret_cast<uint64_t*>(sd + o_btau);
   uint16_t* q16 = ix->s_misc.as<uint16_t>();
 
@@ -544,7 +547,8 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   // every query of its tile — all ks keys, padded with invalid ones, and its bound — and every merge reads only the slots
   // written so far)
   if (!flags_cleared) VDB_HIP(hipMemsetAsync(flags, 0, (size_t)nqg * 4 + 64 * 4 + 16, st));
-  if (!sq8 && !l2) VDB_HIP(hipMemsetAsync(ix->s_fb_keys.p, 0xFF, (size_t)nqg * fp.G * k * 8, st));
+  // (s_fb_keys needs no fill: the whole-tile fallback writes every slot of every query of the tiles it runs for, and its merge
+  // only looks at the unproven queries — MergeArgs::gate)
   if (sel_metric == VDB_DOT) launch_max_norm(sel_norms, n, norm_max, st);
   // exact seed sweep over the first rows
   SweepArgs ag{};
@@ -655,18 +659,32 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   ra.lists = lists;
   ra.fb_qper = fp.qper;
   ra.norm_max_bits = norm_max;
+  ra.qcount = qcount;
+  ra.qmap = qmap;
+  ra.qslot = qslot;
+  SelectFinishArgs fin{};  // the batch's last launch: exact results for the unproven queries, the counts to pinned host memory
+  fin.flags = flags;
+  fin.qcount = qcount;
+  fin.qslot = qslot;
+  fin.out_ids = d_ids;
+  fin.out_scores = d_scores;
+  fin.out_n = d_n;
+  fin.nq = nqg;
+  fin.k = k;
+  if (ix->sel_stats) {
+    fin.stats_host = ix->sel_stats;
+    fin.stats_seq = ++ix->sel_seq;
+    fin.stats_level = sq8 ? 3u : (l2 ? 5u : (uint32_t)level);
+  }
   if (l2) launch_l2_rerank(ra, nqg, st);
   else launch_split_rerank(ix->metric, ra, nqg, st);
   if (sq8) {  // the reference chain for the unproven queries only, decided on the device
-    const int32_t rf = sq8_fallback_flagged(ix, d_q, q_stride, nqg, k, flags, d_ids, d_scores, d_n, st);
+    const int32_t rf = sq8_fallback_flagged(ix, d_q, q_stride, nqg, k, qmap, fin, st);
     if (rf != VDB_OK) return rf;
   } else if (l2) {  // the canonical vector-ALU sweep for the unproven queries only, listed and gathered on the device
-    uint32_t* qmap = reinterpret_cast<uint32_t*>(sd + o_qmap);
-    uint32_t* qcount = qmap + nqg;
     const uint32_t ngroups8 = (n + 7) / 8;
     const int f_blocks = blocks_for(ix, 8, ngroups8);
     if ((e = ix->s_part_cnt.reserve((size_t)nqg * f_blocks * k * 8, false, st)) != hipSuccess) return fail(VDB_ERR_OOM, "gathered fallback scratch");
-    launch_collect_flagged(flags, nqg, qmap, qcount, st);
     SweepArgs af{};
     af.rows = ix->rows.as<float>();
     af.norms = ix->norms.as<float>();
@@ -692,7 +710,10 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     mg.k = k;
     mg.active = qcount;
     launch_merge(false, mg, nqg, st);
-    launch_scatter_flagged(qmap, qcount, 0, mg.out_ids, mg.out_scores, mg.out_n, d_ids, d_scores, d_n, nqg, k, st);
+    fin.g_ids = mg.out_ids;
+    fin.g_scores = mg.out_scores;
+    fin.g_n = mg.out_n;
+    launch_select_finish(fin, st);
   } else {
     // Unproven queries, decided on the device.  A few (<= kFallbackGatherMax): listed, and the streaming matrix-core kernel
     // makes ONE gathered corpus pass per 48 of them (0.9 ms; same mode-M bits).  More: the GEMM-structured kernel for the
@@ -703,14 +724,12 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     const uint32_t g_B = (uint32_t)g_nqt * 16;
     const size_t g_lds = sweep_mfma_lds_bytes(g_nqt, k, dim);
     const bool gather_ok = g_lds <= 160 * 1024;
-    uint32_t* qmap = reinterpret_cast<uint32_t*>(sd + o_qmap);
-    uint32_t* qcount = qmap + nqg;
+    MergeArgs mg{};
     if (gather_ok) {
       const uint32_t ntiles16 = (n + 15) / 16;
       const int g_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ntiles16 + g_waves - 1) / g_waves, (int64_t)ix->n_cus));
       const size_t gk = (size_t)kFallbackGatherMax * g_blocks * k * 8;
       if ((e = ix->s_part_cnt.reserve(gk, false, st)) != hipSuccess) return fail(VDB_ERR_OOM, "gathered fallback scratch");
-      launch_collect_flagged(flags, nqg, qmap, qcount, st);
       SweepArgs am{};
       am.rows = ix->rows.as<float>();
       am.norms = ix->norms.as<float>();
@@ -728,7 +747,6 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
       am.qcount_max = kFallbackGatherMax;
       e = launch_sweep_mfma(ix->metric, g_nqt, am, g_blocks, st, (int)(kFallbackGatherMax / g_B));
       if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("gathered fallback launch: ") + hipGetErrorString(e));
-      MergeArgs mg{};
       mg.part_keys = am.part_keys;
       mg.ext_ids = ix->ext_ids.as<uint64_t>();
       mg.out_ids = reinterpret_cast<uint64_t*>(sd + o_gid);
@@ -739,7 +757,6 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
       mg.active = qcount;
       mg.active_max = kFallbackGatherMax;
       launch_merge(true, mg, kFallbackGatherMax, st);
-      launch_scatter_flagged(qmap, qcount, kFallbackGatherMax, mg.out_ids, mg.out_scores, mg.out_n, d_ids, d_scores, d_n, nqg, k, st);
       ag.qcount = qcount;
       ag.qcount_max = kFallbackGatherMax;
     }
@@ -756,20 +773,27 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     mf.out_n = reinterpret_cast<uint32_t*>(sd + o_fn);
     mf.n_lists = fp.G;
     mf.k = k;
+    mf.gate = flags;
     if (gather_ok) {  // (the GEMM pass did not run for a batch the gathered pass answered: nothing to merge)
       mf.skip_cnt = qcount;
       mf.skip_le = kFallbackGatherMax;
     }
     launch_merge(true, mf, nqg, st);
-    if (gather_ok)
-      launch_select_fallback(flags, mf.out_ids, mf.out_scores, mf.out_n, d_ids, d_scores, d_n, nqg, k, st, qcount, kFallbackGatherMax);
-    else
-      launch_select_fallback(flags, mf.out_ids, mf.out_scores, mf.out_n, d_ids, d_scores, d_n, nqg, k, st);
+    // one launch: an unproven query takes the gathered pass's slot or, when that pass stood aside, the whole-tile fallback's
+    if (gather_ok) {
+      fin.max_listed = kFallbackGatherMax;
+      fin.g_ids = mg.out_ids;
+      fin.g_scores = mg.out_scores;
+      fin.g_n = mg.out_n;
+    }
+    fin.fb_ids = mf.out_ids;
+    fin.fb_scores = mf.out_scores;
+    fin.fb_n = mf.out_n;
+    launch_select_finish(fin, st);
   }
   ix->split_flags_off = o_flags;
   ix->split_flags_n = nqg;
   ix->split_flags_stream = st;
-  if (ix->sel_stats) launch_select_stats(flags, nqg, ++ix->sel_seq, sq8 ? 3u : (l2 ? 5u : (uint32_t)level), ix->sel_stats, st);
   if (ev) (void)hipEventRecord(ev->b, st);
   VDB_HIP(hipGetLastError());
   return VDB_OK;

@@ -577,9 +577,12 @@ static int32_t ensure_sq8_select_impl(vdb_hip_index* ix, hipStream_t st) {
 }
 
 // the reference chain for the queries flagged by a selection batch, decided on the device: list them, one gathered launch of
-// the exact SQ8 sweep (block rows without a listed query exit at once), merge per listed query, scatter
-int32_t sq8_fallback_flagged(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, const uint32_t* flags,
-                             uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st) {
+// the exact SQ8 sweep (block rows without a listed query exit at once), merge per listed query, scatter.  qmap / fin.qcount / fin.qslot:
+// the list the re-scoring launch made (sweep_split.hip list_unproven); fin: the batch's last launch, completed and issued here
+int32_t sq8_fallback_flagged(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, const uint32_t* qmap,
+                             const SelectFinishArgs& fin_in, hipStream_t st) {
+  SelectFinishArgs fin = fin_in;
+  const uint32_t* qcount = fin.qcount;
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
   int B = 8;
   if (sq8_lds_bytes(8, k, ix->dim) > 160 * 1024) B = 4;
@@ -597,13 +600,10 @@ int32_t sq8_fallback_flagged(vdb_hip_index* ix, const float* d_q, uint64_t q_str
     return o;
   };
   const size_t o_keys = take((size_t)nqg * blocks * k * 8), o_ids = take((size_t)nqg * k * 8), o_sc = take((size_t)nqg * k * 4),
-               o_n = take((size_t)nqg * 4), o_map = take((size_t)nqg * 4), o_cnt = take(16);
+               o_n = take((size_t)nqg * 4);
   hipError_t e;
   if ((e = ix->s_fb_keys.reserve(off, false, st)) != hipSuccess) return fail(VDB_ERR_OOM, "SQ8 fallback scratch");
   unsigned char* sd = ix->s_fb_keys.as<unsigned char>();
-  uint32_t* qmap = reinterpret_cast<uint32_t*>(sd + o_map);
-  uint32_t* qcount = reinterpret_cast<uint32_t*>(sd + o_cnt);
-  launch_collect_flagged(flags, nqg, qmap, qcount, st);
   Sq8Args a{};
   a.codes = ix->sq8_codes.as<uint8_t>();
   a.vmin = ix->sq8_min.as<float>();
@@ -633,7 +633,10 @@ int32_t sq8_fallback_flagged(vdb_hip_index* ix, const float* d_q, uint64_t q_str
   m.k = k;
   m.active = qcount;
   launch_merge(ix->metric != VDB_EUCLIDEAN, m, nqg, st);
-  launch_scatter_flagged(qmap, qcount, 0, m.out_ids, m.out_scores, m.out_n, d_ids, d_scores, d_n, nqg, k, st);
+  fin.g_ids = m.out_ids;
+  fin.g_scores = m.out_scores;
+  fin.g_n = m.out_n;
+  launch_select_finish(fin, st);
   VDB_HIP(hipGetLastError());
   return VDB_OK;
 }

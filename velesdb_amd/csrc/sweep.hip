@@ -846,6 +846,7 @@ __global__ __launch_bounds__(256) void merge_topk(MergeArgs m) {
   const uint32_t qi = blockIdx.x;
   if (m.active && (qi >= *m.active || (m.active_max && *m.active > m.active_max))) return;  // (uniform per block)
   if (m.skip_cnt && *m.skip_cnt <= m.skip_le) return;
+  if (m.gate && m.gate[qi] == 0u) return;
   const uint32_t kin = m.k;                     // entries per partial list
   const uint32_t k = m.k_out ? m.k_out : m.k;   // entries kept (k_out > k: a candidate pool for a re-scoring stage)
   volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k;
@@ -916,6 +917,9 @@ __global__ __launch_bounds__(256) void merge_topk(MergeArgs m) {
 //   3. the <= k keys under the bound are compacted and ranked among themselves (one key per thread), and written in order.
 // Keys are distinct (a row sits in exactly one partial list; equal keys would still get distinct places: ties by position).
 // Output identical to merge_topk.
+// (Round 4, measured and rejected: ranking every valid key against all of them out of LDS broadcasts — no barrier per bit — when few
+// are valid.  256 keys x 1 024 queries: 15.1 us against 11.0 us for the bit-by-bit bound; 300 - 1 000 keys, four per thread: 32 - 71 us
+// against 15 - 22 us.  profiles/r04z_merge_rank_variants.txt.)
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kMergeSelectMaxKeys = 7900;  // x 8 B + counters + a 256-key selection buffer: inside the default 64-KiB window
 constexpr uint32_t kMergeSelectMaxK = 256;
@@ -927,6 +931,7 @@ __global__ __launch_bounds__(256) void merge_topk_select(MergeArgs m) {
   const uint32_t qi = blockIdx.x;
   if (m.active && (qi >= *m.active || (m.active_max && *m.active > m.active_max))) return;  // (uniform per block)
   if (m.skip_cnt && *m.skip_cnt <= m.skip_le) return;
+  if (m.gate && m.gate[qi] == 0u) return;
   const uint32_t kin = m.k;
   const uint32_t k = m.k_out ? m.k_out : m.k;
   const uint32_t total = m.n_lists * kin;

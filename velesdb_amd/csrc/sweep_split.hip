@@ -19,8 +19,10 @@
 //   3. and PROVES the answer per query: every row that was left out — by a block's threshold or by the cut at K2 — has
 //      an approximate score <= B, hence an exact score <= B + delta; if the k-th best exact score is above that, nothing
 //      outside can belong to the top k.  A query without proof (near-ties closer than the bound, non-finite data) is
-//      flagged; the exact matrix-core kernel then runs for the 128-query tiles that contain a flagged query — decided on
-//      the device (tile_needed), no host synchronisation — and select_fallback keeps its result for the flagged queries.
+//      flagged; the last block of that launch lists the flagged queries (selection_batch_tail), and the exact passes that follow
+//      decide on the device whether they have work — a gathered pass of the streaming matrix-core kernel for a few, the exact
+//      matrix-core GEMM kernel for the 128-query tiles that contain one (tile_needed) for many — no host synchronisation;
+//      select_finish hands each flagged query its exact result.
 #include <algorithm>
 
 #include "vdb_device.hpp"
@@ -366,6 +368,17 @@ void launch_split_reseed(const uint64_t* ids, const float* scores, const uint32_
   hipLaunchKernelGGL(split_reseed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, delta, tau0, nq, k, kout);
 }
 
+// An unproven query lists itself (the former one-block collect_flagged launch, ~4.6 us on every batch's critical path): slot j from
+// a device-scope counter, qmap[j] = the query, qslot[query] = j.  The order of the list is whatever the blocks' finishing order made
+// it — the gathered exact passes that read it answer every listed query on its own, and select_finish hands query q the result in
+// slot qslot[q], so no result depends on it.  Plain stores: the readers are later launches.
+__device__ __forceinline__ void list_unproven(const SplitRerankArgs& a, uint32_t qi) {
+  if (!a.qcount) return;
+  const uint32_t j = atomicAdd(a.qcount, 1u);
+  a.qmap[j] = qi;
+  a.qslot[qi] = j;
+}
+
 // One block per query: exact re-scoring of the K2 best of the pool, ranking, proof.  See the file header.
 // SQ8: the exact score is the reference's asymmetric distance over the row's SQ8 code (core/quantization.rs:410-554) — one
 // left-to-right chain per (query, row), multiplies and adds rounded separately (storage_modes.hip sweep_topk_sq8 computes
@@ -522,6 +535,7 @@ __global__ __launch_bounds__(256) void split_rerank_verify(SplitRerankArgs a) {
   if (lane == 0) {
     a.flags[qi] = ok ? 0u : 1u;
     if (!ok && a.tile_needed) a.tile_needed[qi / a.fb_qper] = 1u;
+    if (!ok) list_unproven(a, qi);
     a.out_n[qi] = kk;
   }
   for (uint32_t e = lane; e < a.k; e += 64) {
@@ -552,77 +566,30 @@ void launch_split_rerank(int metric, const SplitRerankArgs& a, uint32_t nq, hipS
 }
 
 
-__global__ __launch_bounds__(256) void select_stats_kernel(const uint32_t* flags, uint32_t nq, uint32_t seq, uint32_t level,
-                                                           volatile uint32_t* host) {
-  __shared__ uint32_t cnt;
-  if (threadIdx.x == 0) cnt = 0;
-  __syncthreads();
-  uint32_t c = 0;
-  for (uint32_t q = threadIdx.x; q < nq; q += 256) c += flags[q] ? 1u : 0u;
-  if (c) atomicAdd(&cnt, c);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    host[0] = cnt;
-    host[1] = nq;
-    host[3] = level;
+// the unproven queries take the exact passes' results; block 0 posts the batch's counts (vdb_kernels.hpp launch_select_finish)
+__global__ __launch_bounds__(64) void select_finish_kernel(SelectFinishArgs a) {
+  const uint32_t q = blockIdx.x, lane = threadIdx.x;
+  if (q == 0 && lane == 0 && a.stats_host) {  // (was a launch of its own: select_stats)
+    a.stats_host[0] = a.qcount ? *a.qcount : 0u;
+    a.stats_host[1] = a.nq;
+    a.stats_host[3] = a.stats_level;
     __threadfence_system();
-    host[2] = seq;  // last: a reader that sees the new sequence number sees the counts
+    a.stats_host[2] = a.stats_seq;  // last: a reader that sees the new sequence number sees the counts
   }
-}
-void launch_select_stats(const uint32_t* flags, uint32_t nq, uint32_t seq, uint32_t level, volatile uint32_t* host, hipStream_t st) {
-  hipLaunchKernelGGL(select_stats_kernel, dim3(1), dim3(256), 0, st, flags, nq, seq, level, host);
+  if (!a.flags[q]) return;
+  const bool gathered = a.g_ids && (a.max_listed == 0u || *a.qcount <= a.max_listed);
+  if (!gathered && !a.fb_ids) return;
+  const uint32_t slot = gathered ? a.qslot[q] : q;
+  const uint64_t* s_ids = gathered ? a.g_ids : a.fb_ids;
+  const float* s_sc = gathered ? a.g_scores : a.fb_scores;
+  for (uint32_t e = lane; e < a.k; e += 64) {
+    a.out_ids[(size_t)q * a.k + e] = s_ids[(size_t)slot * a.k + e];
+    a.out_scores[(size_t)q * a.k + e] = s_sc[(size_t)slot * a.k + e];
+  }
+  if (lane == 0) a.out_n[q] = (gathered ? a.g_n : a.fb_n)[slot];
 }
 
-// the queries a selection batch could not prove, in ascending order: qmap[0 .. *qcount)
-__global__ __launch_bounds__(1024) void collect_flagged_kernel(const uint32_t* flags, uint32_t nq, uint32_t* qmap, uint32_t* qcount) {
-  __shared__ uint32_t base;
-  if (threadIdx.x == 0) base = 0;
-  __syncthreads();
-  for (uint32_t q0 = 0; q0 < nq; q0 += 1024) {  // nq <= 1024 per chunk: one round
-    const uint32_t q = q0 + threadIdx.x;
-    const bool f = q < nq && flags[q] != 0;
-    const uint64_t m = __ballot(f);
-    __shared__ uint32_t wsum[16];
-    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    if (l == 0) wsum[w] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t off = base;
-    for (uint32_t i = 0; i < w; i++) off += wsum[i];
-    if (f) qmap[off + (uint32_t)__popcll(m & ((1ull << l) - 1ull))] = q;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t t = 0;
-      for (int i = 0; i < 16; i++) t += wsum[i];
-      base += t;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *qcount = base;
-}
-// listed query j takes the gathered exact pass's result (slot j)
-__global__ __launch_bounds__(64) void scatter_flagged_kernel(const uint32_t* qmap, const uint32_t* qcount, uint32_t max_listed,
-                                                             const uint64_t* fb_ids, const float* fb_scores, const uint32_t* fb_n,
-                                                             uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint32_t k) {
-  const uint32_t j = blockIdx.x;
-  if (j >= *qcount || (max_listed && *qcount > max_listed)) return;
-  const uint32_t q = qmap[j];
-  for (uint32_t e = threadIdx.x; e < k; e += 64) {
-    out_ids[(size_t)q * k + e] = fb_ids[(size_t)j * k + e];
-    out_scores[(size_t)q * k + e] = fb_scores[(size_t)j * k + e];
-  }
-  if (threadIdx.x == 0) out_n[q] = fb_n[j];
-}
-
-void launch_collect_flagged(const uint32_t* flags, uint32_t nq, uint32_t* qmap, uint32_t* qcount, hipStream_t st) {
-  hipLaunchKernelGGL(collect_flagged_kernel, dim3(1), dim3(1024), 0, st, flags, nq, qmap, qcount);
-}
-void launch_scatter_flagged(const uint32_t* qmap, const uint32_t* qcount, uint32_t max_listed, const uint64_t* fb_ids,
-                            const float* fb_scores, const uint32_t* fb_n, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
-                            uint32_t nq, uint32_t k, hipStream_t st) {
-  const uint32_t blocks = max_listed ? std::min(nq, max_listed) : nq;
-  hipLaunchKernelGGL(scatter_flagged_kernel, dim3(blocks), dim3(64), 0, st, qmap, qcount, max_listed, fb_ids, fb_scores, fb_n, out_ids,
-                     out_scores, out_n, k);
-}
+void launch_select_finish(const SelectFinishArgs& a, hipStream_t st) { hipLaunchKernelGGL(select_finish_kernel, dim3(a.nq), dim3(64), 0, st, a); }
 
 // ---- Euclidean batches through the same selection stage ----------------------------------------------------------------
 // |q - v|^2 = |q|^2 - 2 (q.v - |v|^2 / 2): the nearest rows are the rows with the largest s = q.v - h, h = |v|^2 / 2, and s is a
@@ -894,6 +861,7 @@ __global__ __launch_bounds__(256) void l2_rerank_verify(SplitRerankArgs a) {
   }
   if (lane == 0) {
     a.flags[qi] = ok ? 0u : 1u;
+    if (!ok) list_unproven(a, qi);
     a.out_n[qi] = kk;
   }
   for (uint32_t e = lane; e < a.k; e += 64) {
@@ -910,27 +878,6 @@ __global__ __launch_bounds__(256) void l2_rerank_verify(SplitRerankArgs a) {
 }
 void launch_l2_rerank(const SplitRerankArgs& a, uint32_t nq, hipStream_t st) {
   hipLaunchKernelGGL(l2_rerank_verify, dim3(nq), dim3(256), 0, st, a);
-}
-
-// flagged queries take the exact kernel's result
-__global__ __launch_bounds__(256) void select_fallback_kernel(const uint32_t* flags, const uint64_t* fb_ids, const float* fb_scores,
-                                                              const uint32_t* fb_n, uint64_t* out_ids, float* out_scores,
-                                                              uint32_t* out_n, uint32_t nq, uint32_t k, const uint32_t* qcount,
-                                                              uint32_t skip_le) {
-  const uint32_t q = blockIdx.x;
-  if (q >= nq || !flags[q]) return;
-  if (qcount && *qcount <= skip_le) return;  // the gathered pass answered this batch's flagged queries
-  for (uint32_t e = threadIdx.x; e < k; e += 256) {
-    out_ids[(size_t)q * k + e] = fb_ids[(size_t)q * k + e];
-    out_scores[(size_t)q * k + e] = fb_scores[(size_t)q * k + e];
-  }
-  if (threadIdx.x == 0) out_n[q] = fb_n[q];
-}
-void launch_select_fallback(const uint32_t* flags, const uint64_t* fb_ids, const float* fb_scores, const uint32_t* fb_n,
-                            uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint32_t nq, uint32_t k, hipStream_t st,
-                            const uint32_t* qcount, uint32_t skip_le) {
-  hipLaunchKernelGGL(select_fallback_kernel, dim3(nq), dim3(256), 0, st, flags, fb_ids, fb_scores, fb_n, out_ids, out_scores, out_n, nq, k,
-                     qcount, skip_le);
 }
 
 }  // namespace vdb

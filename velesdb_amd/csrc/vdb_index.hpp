@@ -383,8 +383,9 @@ int32_t storage_mode_append(vdb_hip_index* ix, uint64_t first, uint64_t n);
 int32_t brute_sq8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nq, uint32_t k, uint64_t* d_ids,
                       float* d_scores, uint32_t* d_n, hipStream_t st);
 int32_t ensure_sq8_select(vdb_hip_index* ix, hipStream_t st);
-int32_t sq8_fallback_flagged(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, const uint32_t* flags,
-                             uint64_t* d_ids, float* d_scores, uint32_t* d_n, hipStream_t st);
+struct SelectFinishArgs;  // vdb_kernels.hpp
+int32_t sq8_fallback_flagged(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, const uint32_t* qmap,
+                             const SelectFinishArgs& fin_in, hipStream_t st);
 // select_stage.hip: selection + exact re-scoring + proof for a chunk of <= 1024 queries (level 1 / 2: f32 rows, 3: SQ8 storage mode)
 int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, uint64_t* d_ids,
                         float* d_scores, uint32_t* d_n, hipStream_t st, int level);

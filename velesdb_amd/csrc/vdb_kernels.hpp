@@ -44,6 +44,7 @@ struct MergeArgs {
   uint32_t list_stride;       // lists per query in part_keys (0 = n_lists): merge only the first n_lists of them
   const uint32_t* skip_cnt;   // nullable: nothing to do when *skip_cnt <= skip_le (the pass that would have filled the lists did not run)
   uint32_t skip_le;
+  const uint32_t* gate;       // nullable: query q is merged only when gate[q] != 0 (the lists of the others may hold anything)
   // selection stage, between two launches (sweep_split.hip): the next launch's bound in the same pass — reseed_tau[q] = key of
   // (the reseed_k-th best merged score lowered by 2 reseed_delta[q]), kKeyInvalid while fewer than reseed_k keys exist
   const float* reseed_delta;  // nullable
@@ -293,6 +294,10 @@ struct SplitRerankArgs {
   const float* sq8_max;
   const float* sq8_nsq;
   uint64_t sq8_stride;
+  // the list of the unproven queries (sweep_split.hip list_unproven; nullable together)
+  uint32_t* qcount;             // device word, zero before the launch: how many
+  uint32_t* qmap;               // [nq] slot -> query, in the blocks' finishing order
+  uint32_t* qslot;              // [nq] query -> slot (unproven queries only)
 };
 void launch_split_vectors(const float* src, uint64_t src_stride, uint16_t* out, float* norms, uint32_t row0, uint32_t n,
                           uint32_t dim, hipStream_t st);
@@ -314,8 +319,6 @@ void launch_split_seed_approx(int metric, const uint64_t* ids, const float* scor
                               const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
                               uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t seed_rows, uint32_t dim, int level,
                               hipStream_t st, const float* rho_q = nullptr, const uint32_t* rho_max_bits = nullptr);
-// {unproven, queries, seq, level} of a finished selection batch -> pinned host memory (no synchronisation)
-void launch_select_stats(const uint32_t* flags, uint32_t nq, uint32_t seq, uint32_t level, volatile uint32_t* host, hipStream_t st);
 void launch_split_reseed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* delta, uint64_t* tau0,
                          uint32_t nq, uint32_t k, uint32_t kout, hipStream_t st);
 void launch_split_rerank(int metric, const SplitRerankArgs& a, uint32_t nq, hipStream_t st);
@@ -330,15 +333,29 @@ void launch_l2_seed(const uint64_t* ids, const float* scores, const uint32_t* n,
                     uint32_t klist, uint32_t dim_a, float extra_rel, hipStream_t st, const float* rho_q = nullptr,
                     const uint32_t* rho_max_bits = nullptr, uint32_t approx_seed_rows = 0);
 void launch_l2_rerank(const SplitRerankArgs& a, uint32_t nq, hipStream_t st);
-// the flagged queries of a batch in ascending order: qmap[0 .. *qcount) (one block; nq <= 1024 per round)
-void launch_collect_flagged(const uint32_t* flags, uint32_t nq, uint32_t* qmap, uint32_t* qcount, hipStream_t st);
-// listed query j takes slot j of a gathered exact pass; nothing happens when more than `max_listed` are listed (0 = no limit)
-void launch_scatter_flagged(const uint32_t* qmap, const uint32_t* qcount, uint32_t max_listed, const uint64_t* fb_ids,
-                            const float* fb_scores, const uint32_t* fb_n, uint64_t* out_ids, float* out_scores, uint32_t* out_n,
-                            uint32_t nq, uint32_t k, hipStream_t st);  // a.sq8_codes selects the SQ8 chain
-void launch_select_fallback(const uint32_t* flags, const uint64_t* fb_ids, const float* fb_scores, const uint32_t* fb_n,
-                            uint64_t* out_ids, float* out_scores, uint32_t* out_n, uint32_t nq, uint32_t k, hipStream_t st, const uint32_t* qcount = nullptr,
-                            uint32_t skip_le = 0);
+// The end of a selection batch, one launch.  An unproven query (flags[q] != 0) takes its exact result: the GATHERED pass's slot
+// qslot[q] when that pass ran — g_* given and (max_listed == 0 or *qcount <= max_listed) — otherwise the whole-tile fallback's own
+// slot q (fb_* nullable: no such pass).  Block 0 posts {unproven, queries, seq, level} to pinned host memory (stats_host nullable;
+// seq last, behind a system fence; no synchronisation).
+struct SelectFinishArgs {
+  const uint32_t* flags;
+  const uint32_t* qcount;
+  const uint32_t* qslot;
+  uint32_t max_listed;
+  const uint64_t* g_ids;
+  const float* g_scores;
+  const uint32_t* g_n;
+  const uint64_t* fb_ids;
+  const float* fb_scores;
+  const uint32_t* fb_n;
+  uint64_t* out_ids;
+  float* out_scores;
+  uint32_t* out_n;
+  uint32_t nq, k;
+  volatile uint32_t* stats_host;
+  uint32_t stats_seq, stats_level;
+};
+void launch_select_finish(const SelectFinishArgs& a, hipStream_t st);
 void launch_euclid_rerank(const EuclidRerankArgs& a, const float* norms, uint32_t n_rows, uint32_t nq, hipStream_t st);
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st);
 // B (8 or 32) queries per corpus pass; blocks = row blocks (= partial lists per query), grid.y = ceil(nq / B)
