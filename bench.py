@@ -650,8 +650,11 @@ def main():
                     torch.cuda.synchronize()
                     samples.append(time.perf_counter() - tl0)
                 med = float(np.median(samples))
+                l_nd, l_ne = ix.last_search_stats()  # of the last call
                 lat_h.append({"queries_per_call": nq_l, "median_us_per_call": round(med * 1e6, 1),
-                              "qps": round(nq_l / med, 1)})
+                              "qps": round(nq_l / med, 1),
+                              "neighbour_list_prediction_hit_rate": round(ix.last_prefetch_hits() / max(l_ne, 1), 3),
+                              "alg_bytes_per_query": int((l_nd * D * 4 + l_ne * 2 * a.M * 4) / nq_l)})
             hnsw["latency_mode"] = lat_h
             # many host threads, one query per vdb_hip_index_search call (host pointers): the combining front (search_front.hip)
             cq_np = queries[:4096].cpu().numpy()

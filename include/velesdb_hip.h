@@ -318,6 +318,10 @@ int32_t vdb_hip_index_graph_info(vdb_hip_index* idx, uint32_t* num_layers, uint3
                                  int64_t* entry_point);
 /* counters of the last HNSW search batch: distance evaluations and expansions */
 int32_t vdb_hip_index_last_search_stats(vdb_hip_index* idx, uint64_t* n_dist, uint64_t* n_expand);
+/* of the last HNSW search batch's expansions: how many found their neighbour list already requested — the walk kernel asks for the
+ * list of the nearest candidate it leaves unexpanded together with the list of the one it expands (the predicted next pop); a measure
+ * of the prediction, not a count the reference has */
+int32_t vdb_hip_index_last_prefetch_hits(vdb_hip_index* idx, uint64_t* hits);
 /* average duration (ms) of the dominant kernel in the last search call, measured with HIP
  * events on the launch stream; 0 if timing is off.  Enable with vdb_hip_set_kernel_timing(1). */
 int32_t vdb_hip_set_kernel_timing(int32_t on);

@@ -106,6 +106,30 @@ def test_random_all_metrics(tmp_path, metric, n, dim, M, efc):
     check_batch(g, ix, metric, qs[:6], 50, 200)   # ef > 128, k > ef/4
 
 
+def test_walk_prefetch_is_a_measure_not_a_result(tmp_path):
+    """The latency-mode walk asks for the neighbour list of the candidate it predicts to pop next together with the current one's
+    (hnsw_kernels.hip pf_ids).  Results and the reference's counters are the oracle's either way (check_batch); the hit counter is
+    bounded by the expansions, and non-zero whenever that kernel ran with the prediction on."""
+    import os
+    rng = np.random.default_rng(99)
+    rows = rng.standard_normal((1500, 768)).astype(np.float32)
+    g, ix = build_pair(tmp_path, rows, DM.Cosine, 16, 100)
+    qs = rng.standard_normal((24, 768)).astype(np.float32)
+    check_batch(g, ix, DM.Cosine, qs, 10, 64)
+    _, ne = ix.last_search_stats()
+    hits = ix.last_prefetch_hits()
+    assert 0 <= hits <= ne
+    lat_on = os.environ.get("VELESDB_HNSW_LATENCY_MODE", "1") != "0"
+    pf_on = os.environ.get("VELESDB_HNSW_PREFETCH_IDS", "1") != "0"
+    if lat_on and pf_on:
+        assert hits > 0
+    if not pf_on:
+        assert hits == 0
+    qmany = rng.standard_normal((600, 768)).astype(np.float32)  # more queries than CUs: the throughput kernel (no prediction)
+    ix.search_batch_parallel(qmany, 10, SQ.Custom(64))
+    assert ix.last_prefetch_hits() == 0
+
+
 def test_many_queries_more_than_slots(tmp_path):
     # nq > resident slots: blocks loop over the batch and must leave the visited bitmaps clean
     rng = np.random.default_rng(7)

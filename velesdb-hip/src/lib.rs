@@ -656,6 +656,16 @@ impl HipHnswIndex {
         (a, b, c, d)
     }
 
+    /// Expansions of the last graph search batch whose neighbour list had been requested one pop ahead (the walk kernel's
+    /// prediction of the next candidate; a measure, not a count the reference has).
+    #[must_use]
+    pub fn last_prefetch_hits(&self) -> u64 {
+        let mut a = 0u64;
+        // SAFETY: live handle, valid out pointer.
+        check(unsafe { sys::vdb_hip_index_last_prefetch_hits(self.h, &mut a) });
+        a
+    }
+
     /// The raw handle, for the entry points this wrapper does not cover (`sys::*`).
     #[must_use]
     pub fn as_raw(&self) -> *mut sys::VdbHipIndex {

@@ -72,6 +72,7 @@ SIGNATURES = {
     "vdb_hip_index_get_neighbors": (_i32, [_vp, _u32, _u64, _vp, _u32, _pu32]),
     "vdb_hip_index_graph_info": (_i32, [_vp, _pu32, _pu32, C.POINTER(C.c_int64)]),
     "vdb_hip_index_last_search_stats": (_i32, [_vp, _pu64, _pu64]),
+    "vdb_hip_index_last_prefetch_hits": (_i32, [_vp, _pu64]),
     "vdb_hip_set_kernel_timing": (_i32, [_i32]),
     "vdb_hip_set_max_query_tile": (_i32, [_u32]),
     "vdb_hip_set_sweep_engine": (_i32, [_i32]),

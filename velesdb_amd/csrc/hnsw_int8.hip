@@ -551,7 +551,7 @@ int32_t hnsw_search_int8_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_str
     return fail(VDB_ERR_UNSUPPORTED, "ef too large for the LDS-resident candidate list");
   int32_t rcs = ensure_traversal_scratch(ix, st);
   if (rcs != VDB_OK) return rcs;
-  VDB_HIP(hipMemsetAsync(ix->s_stats.p, 0, 16, st));
+  VDB_HIP(hipMemsetAsync(ix->s_stats.p, 0, 24, st));
   a.rows = ix->rows.as<float>();
   a.norms = ix->norms.as<float>();
   a.bits = nullptr;

@@ -135,6 +135,14 @@ __global__ __launch_bounds__(LAT ? 1024 : 256, 4) void hnsw_search_kernel(HnswSe
     uint32_t n_dist = 0, n_expand = 0, logn = 0, overflow = 0, m_prev = 0, rr_m = 0;
     bool spec = false;        // LAT: the distance phase in flight evaluates ALL neighbours of the expanded node ...
     uint64_t spec_mask = 0;   // ... and these lanes' neighbours were unvisited (known behind that phase)
+    // the neighbour list of the PREDICTED next pop — the nearest unexpanded candidate left behind by this pop — requested with this
+    // pop's own list: when the admission puts nothing in front of it (most expansions once the beam has settled), the next pop finds
+    // its ids in registers and the walk is one dependent memory round trip shorter.  A wrong guess costs 260 bytes.  Not counted:
+    // n_dist / n_expand are what the reference's loop counts (graph.rs:471-511).
+    uint32_t pf_node = 0xFFFFFFFFu, pf_nb = 0, pf_cnt = 0, pf_hits = 0;
+    // (latency-mode instances only: the throughput instances sit at the 128-register line that lets four walks share a CU, and the
+    // three registers this needs across the distance phase put 20 of theirs into scratch)
+    const bool PF = LAT && a.pf_ids != 0;
     int phase = P_START;
     int layer = (int)a.max_layer;
     uint32_t cur = a.entry_point;
@@ -250,9 +258,25 @@ __global__ __launch_bounds__(LAT ? 1024 : 256, 4) void hnsw_search_kernel(HnswSe
                 const HnswLayerRef L = a.layers[0];
                 // the neighbour ids are requested together with the count (one memory round trip instead of two)
                 const uint32_t lim = min(L.stride, nbmax);
-                uint32_t nb0 = 0;
-                if ((uint32_t)lane < lim) nb0 = L.nbr[(size_t)cnode * L.stride + lane];
-                uint32_t nc = rfl(L.cnt[cnode]);
+                uint32_t nb0 = 0, ncv = 0;
+                if (PF && pf_node == cnode) {
+                  nb0 = pf_nb;
+                  ncv = pf_cnt;
+                  pf_hits += 1;
+                } else {
+                  if ((uint32_t)lane < lim) nb0 = L.nbr[(size_t)cnode * L.stride + lane];
+                  ncv = L.cnt[cnode];
+                }
+                if (PF) {
+                  const uint32_t idx2 = list.first_unexpanded(lane);
+                  pf_node = 0xFFFFFFFFu;
+                  if (idx2 != kNoIndex) {
+                    pf_node = (uint32_t)list.key_at(idx2, lane);
+                    if ((uint32_t)lane < lim) pf_nb = L.nbr[(size_t)pf_node * L.stride + lane];
+                    pf_cnt = L.cnt[pf_node];
+                  }
+                }
+                uint32_t nc = rfl(ncv);
                 nc = min(nc, lim);
                 if (LAT && a.lat_spec) {  // (nc <= 64, host) every neighbour is evaluated; the visited verdicts follow with the distances
                   if ((uint32_t)lane < nc) nb_id[lane] = nb0;
@@ -410,6 +434,7 @@ __global__ __launch_bounds__(LAT ? 1024 : 256, 4) void hnsw_search_kernel(HnswSe
           if (a.stats) {
             atomicAdd(&a.stats[0], (unsigned long long)n_dist);
             atomicAdd(&a.stats[1], (unsigned long long)n_expand);
+            if (pf_hits) atomicAdd(&a.stats[2], (unsigned long long)pf_hits);
           }
         }
       }
@@ -444,6 +469,7 @@ __global__ __launch_bounds__(LAT ? 1024 : 256, 4) void hnsw_search_kernel(HnswSe
         if (a.stats) {
           atomicAdd(&a.stats[0], (unsigned long long)n_dist);
           atomicAdd(&a.stats[1], (unsigned long long)n_expand);
+          if (pf_hits) atomicAdd(&a.stats[2], (unsigned long long)pf_hits);
         }
       }
     }
@@ -545,6 +571,11 @@ static const uint32_t g_hnsw_lat_max = [] {  // 0: one query per CU (the default
   return e ? (uint32_t)atoi(e) : 0u;
 }();
 
+// VELESDB_HNSW_PREFETCH_IDS=0: every pop requests its own neighbour list (A / B measurements of the prediction)
+static const bool g_hnsw_pf = [] {
+  const char* e = getenv("VELESDB_HNSW_PREFETCH_IDS");
+  return !(e && e[0] == '0');
+}();
 // VELESDB_HNSW_VIS_LDS: 0 = HBM bitmaps everywhere, 1 = the exact LDS set in the throughput kernel too (two blocks per CU
 // instead of four), unset = the measured default (see pick_vis)
 static const int g_hnsw_vis = [] {
@@ -566,6 +597,7 @@ static uint32_t pick_vis(const HnswSearchArgs& a, size_t lds, bool lat) {
 
 hipError_t launch_hnsw_search(const HnswSearchArgs& a0, int slots, hipStream_t st) {
   HnswSearchArgs a = a0;
+  a.pf_ids = g_hnsw_pf ? 1u : 0u;
   size_t lds = hnsw_lds_bytes(a.cap, a.nbmax, a.dim, a.words, a.metric);
   // at most one query per CU (measured at 1 M x 768, ef 128: 64 queries 1.57 ms against 2.68 ms on the throughput kernel, 256
   // queries 2.12 against 3.21 ms — a 1 024-thread block per CU is all the chip holds of this kernel) over a corpus that does not
@@ -659,7 +691,7 @@ int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   if (rcs != VDB_OK) return rcs;
   const uint64_t vis_words = ix->vis_words;
   const uint32_t vlog_cap = kVlogCap;
-  VDB_HIP(hipMemsetAsync(ix->s_stats.p, 0, 16, st));
+  VDB_HIP(hipMemsetAsync(ix->s_stats.p, 0, 24, st));
   a.rows = ix->rows.as<float>();
   a.norms = ix->norms.as<float>();
   a.bits = ix->bits.as<uint32_t>();

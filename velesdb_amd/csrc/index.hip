@@ -1086,6 +1086,19 @@ int32_t search_to_device(vdb_hip_index* ix, const float* queries, uint32_t nq, u
 using namespace vdb;
 
 // =============================================================================================
+// the counters of the context's last graph search, device -> host (ctx_mu held; synchronises)
+static int32_t fetch_search_stats(vdb_hip_index* ix) {
+  unsigned long long h[3] = {0, 0, 0};
+  VDB_ENTER_SHARED(ix);
+  VDB_HIP(hipDeviceSynchronize());
+  VDB_HIP(hipMemcpy(h, ix->s_stats.p, 24, hipMemcpyDeviceToHost));
+  ix->last_n_dist = h[0];
+  ix->last_n_expand = h[1];
+  ix->last_pf_hits = h[2];
+  ix->stats_pending = false;
+  return VDB_OK;
+}
+
 extern "C" {
 
 const char* vdb_hip_last_error(void) { return g_last_error.c_str(); }
@@ -1805,16 +1818,37 @@ int32_t vdb_hip_index_last_search_stats(vdb_hip_index* ix, uint64_t* n_dist, uin
     ix = last_context(ix);  // the search context that served this thread's last search (the handle itself unless searches overlapped)
     std::lock_guard<std::mutex> cg(ix->ctx_mu);
   if (ix->stats_pending) {
-    unsigned long long h[2] = {0, 0};
-    VDB_ENTER_SHARED(ix);
-    VDB_HIP(hipDeviceSynchronize());
-    VDB_HIP(hipMemcpy(h, ix->s_stats.p, 16, hipMemcpyDeviceToHost));
-    ix->last_n_dist = h[0];
-    ix->last_n_expand = h[1];
-    ix->stats_pending = false;
+    const int32_t rc = fetch_search_stats(ix);
+    if (rc != VDB_OK) return rc;
   }
   if (n_dist) *n_dist = ix->last_n_dist;
   if (n_expand) *n_expand = ix->last_n_expand;
+  return VDB_OK;
+  });
+}
+
+int32_t vdb_hip_index_last_prefetch_hits(vdb_hip_index* ix, uint64_t* hits) {
+  return vdb::guarded([&]() -> int32_t {
+  if (!ix || !hits) return fail(VDB_ERR_INVALID_ARG, "null argument");
+  if (ix->group) {
+    uint64_t a = 0;
+    for (size_t s = 0; s < group_size(ix); s++) {
+      uint64_t x = 0;
+      int32_t rc = vdb_hip_index_last_prefetch_hits(group_shard(ix, s), &x);
+      if (rc != VDB_OK) return rc;
+      a += x;
+    }
+    *hits = a;
+    return VDB_OK;
+  }
+  std::shared_lock<vdb::IndexMutex> g(ix->mu);
+  ix = last_context(ix);
+  std::lock_guard<std::mutex> cg(ix->ctx_mu);
+  if (ix->stats_pending) {
+    const int32_t rc = fetch_search_stats(ix);
+    if (rc != VDB_OK) return rc;
+  }
+  *hits = ix->last_pf_hits;
   return VDB_OK;
   });
 }

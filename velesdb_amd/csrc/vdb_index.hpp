@@ -261,7 +261,7 @@ struct vdb_hip_index {
   size_t ev_used = 0;
   std::vector<vdb::EventPair> sel_ev;  // kernel timing: one pair per launch of the selection kernel in the last search call
   size_t sel_ev_used = 0;
-  uint64_t last_n_dist = 0, last_n_expand = 0;
+  uint64_t last_n_dist = 0, last_n_expand = 0, last_pf_hits = 0;
 
   // Reader / writer lock of the handle (the reference's RwLock around the graph, index/hnsw/index/search.rs:80): searches
   // hold it SHARED while they enqueue (and, host entry points, until their results are back), everything that changes the

@@ -126,13 +126,14 @@ struct HnswSearchArgs {
   uint64_t* out_ids;        // [nq][k]
   float* out_scores;        // [nq][k]
   uint32_t* out_n;          // [nq]; 0xFFFFFFFF = candidate list overflow (caller must re-run with a larger cap)
-  unsigned long long* stats;  // [2] += distance evaluations, expansions
+  unsigned long long* stats;  // [3] += distance evaluations, expansions, expansions whose neighbour ids were prefetched (pf_ids)
   uint32_t dim, words, n_rows, nq, k, ef, cap, nbmax, vlog_cap, max_layer, entry_point;
   int32_t metric;
   uint32_t n_cus;       // launch sizing only
   uint32_t list_slots;  // 0: candidate list in LDS; kSearchRegSlots: in registers (ef + 64 <= slots * 64)
   uint32_t vis_log2;    // > 0: the visited set is an exact hash set of 2^vis_log2 entries in LDS at byte offset vis_off (VisSet,
   uint32_t vis_off;     // vdb_hnsw_device.hpp) instead of the HBM bitmap; a query that would pass 3/4 of it reports overflow
+  uint32_t pf_ids;      // 1 = the neighbour list of the predicted next pop is requested with the current one's (hnsw_kernels.hip)
   uint32_t lat_spec;    // latency-mode kernel: 1 = all neighbours' rows are fetched beside the visited test (corpora beyond the
                         // Infinity Cache: the walk is a chain of memory round trips), 0 = the test (LDS set) first, then only
                         // the unvisited neighbours' rows (cache-resident corpora: the round trip is short and small graphs

@@ -467,6 +467,12 @@ class HnswIndex:
         check(lib().vdb_hip_index_last_search_stats(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    def last_prefetch_hits(self):
+        """Expansions of the last graph search batch whose neighbour ids had been requested one pop ahead (the walk's prediction)."""
+        a = C.c_uint64(0)
+        check(lib().vdb_hip_index_last_prefetch_hits(self._h, C.byref(a)))
+        return int(a.value)
+
     def last_split_stats(self):
         """(queries, unproven) of the last split-selector batch: unproven ones were answered by the exact fallback kernel."""
         a, b = C.c_uint32(0), C.c_uint32(0)
