@@ -109,7 +109,8 @@ def test_random_all_metrics(tmp_path, metric, n, dim, M, efc):
 def test_walk_prefetch_is_a_measure_not_a_result(tmp_path):
     """The latency-mode walk asks for the neighbour list of the candidate it predicts to pop next together with the current one's
     (hnsw_kernels.hip pf_ids).  Results and the reference's counters are the oracle's either way (check_batch); the hit counter is
-    bounded by the expansions, and non-zero whenever that kernel ran with the prediction on."""
+    bounded by the expansions, and non-zero whenever that kernel ran with the prediction on (default: corpora beyond the Infinity
+    Cache only; tests/test_gpu_switches.py runs this file with it forced on and off)."""
     import os
     rng = np.random.default_rng(99)
     rows = rng.standard_normal((1500, 768)).astype(np.float32)
@@ -120,10 +121,10 @@ def test_walk_prefetch_is_a_measure_not_a_result(tmp_path):
     hits = ix.last_prefetch_hits()
     assert 0 <= hits <= ne
     lat_on = os.environ.get("VELESDB_HNSW_LATENCY_MODE", "1") != "0"
-    pf_on = os.environ.get("VELESDB_HNSW_PREFETCH_IDS", "1") != "0"
-    if lat_on and pf_on:
+    pf = os.environ.get("VELESDB_HNSW_PREFETCH_IDS")  # unset: only over corpora beyond the Infinity Cache (not this one)
+    if lat_on and pf == "1":
         assert hits > 0
-    if not pf_on:
+    if pf != "1":
         assert hits == 0
     qmany = rng.standard_normal((600, 768)).astype(np.float32)  # more queries than CUs: the throughput kernel (no prediction)
     ix.search_batch_parallel(qmany, 10, SQ.Custom(64))

@@ -10,7 +10,7 @@ against the oracle) must hold.
    with the exact kernels on both sides of it, and asserts WHICH path served a batch, so it is not re-run under another value)
   VELESDB_HNSW_LATENCY_MODE=0|2|3 throughput kernel only / latency-mode kernel forced with and without row speculation -> graph tests
   VELESDB_HNSW_VIS_LDS=1          LDS visited set in the throughput walk                      -> graph tests
-  VELESDB_HNSW_PREFETCH_IDS=0     latency-mode walk without the neighbour-list prediction     -> graph tests
+  VELESDB_HNSW_PREFETCH_IDS=1     latency-mode walk with the neighbour-list prediction over cache-resident corpora too -> graph tests
   VELESDB_INT8_VIS_LDS=1, VELESDB_I8_WAVES2=0   the int8 walk's variants                      -> int8 tests
 """
 import os
@@ -41,7 +41,7 @@ CASES = [
     ({"VELESDB_HNSW_LATENCY_MODE": "2"}, GRAPH),
     ({"VELESDB_HNSW_LATENCY_MODE": "3"}, GRAPH),
     ({"VELESDB_HNSW_VIS_LDS": "1"}, GRAPH),
-    ({"VELESDB_HNSW_PREFETCH_IDS": "0"}, GRAPH),
+    ({"VELESDB_HNSW_PREFETCH_IDS": "1"}, GRAPH),
     ({"VELESDB_INT8_VIS_LDS": "1"}, INT8),
     ({"VELESDB_I8_WAVES2": "0"}, INT8),
 ]

@@ -87,13 +87,13 @@ __global__ __launch_bounds__(256) void hnsw_insert_kernel(HnswInsertArgs a) {
   const int lane = lane_id();
   const int wib = (int)rfl(threadIdx.x >> 6);
   const uint32_t cap = a.cap, nbmax = a.nbmax, ef = a.ef;
-  volatile uint64_t* keys = reinterpret_cast<volatile uint64_t*>(smem);
-  volatile uint32_t* nb_id = reinterpret_cast<volatile uint32_t*>(smem + (size_t)cap * 8);
-  volatile float* nb_d = reinterpret_cast<volatile float*>(nb_id + nbmax);
-  volatile uint32_t* nbx = nb_id + 2 * (size_t)nbmax;
-  volatile uint32_t* sel = nb_id + 3 * (size_t)nbmax;
-  volatile uint32_t* ctl = nb_id + 4 * (size_t)nbmax;
-  volatile uint8_t* flags = reinterpret_cast<volatile uint8_t*>(ctl + 8);
+  lds_vu64* keys = (lds_vu64*)(lds_void_p)(smem);
+  lds_vu32* nb_id = (lds_vu32*)(lds_void_p)(smem + (size_t)cap * 8);
+  lds_vf32* nb_d = (lds_vf32*)(nb_id + nbmax);
+  lds_vu32* nbx = nb_id + 2 * (size_t)nbmax;
+  lds_vu32* sel = nb_id + 3 * (size_t)nbmax;
+  lds_vu32* ctl = nb_id + 4 * (size_t)nbmax;
+  lds_vu8* flags = (lds_vu8*)(ctl + 8);
   const size_t qoff = (size_t)cap * 8 + (size_t)nbmax * 16 + 32 + (((size_t)cap + 15) & ~(size_t)15);
   float* qgen = reinterpret_cast<float*>(smem + qoff);
   uint32_t* qbits = reinterpret_cast<uint32_t*>(smem + qoff);
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void hnsw_link_kernel(HnswLinkArgs a, uint32_t
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id();
   const int wib = (int)rfl(threadIdx.x >> 6);
-  volatile uint64_t* sk = reinterpret_cast<volatile uint64_t*>(smem + (size_t)wib * lds_per_wave);
+  lds_vu64* sk = (lds_vu64*)(lds_void_p)(smem + (size_t)wib * lds_per_wave);
   const uint32_t nwaves = gridDim.x * 4;
   for (uint32_t p = blockIdx.x * 4 + wib; p < a.n; p += nwaves) {
     const uint64_t key = a.keys[p];
@@ -514,8 +514,8 @@ __global__ __launch_bounds__(256) void hnsw_ndist_kernel(HnswNdistArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id();
   const int wib = (int)rfl(threadIdx.x >> 6);
-  volatile uint32_t* nb_id = reinterpret_cast<volatile uint32_t*>(smem);
-  volatile float* nb_d = reinterpret_cast<volatile float*>(nb_id + a.nbmax);
+  lds_vu32* nb_id = (lds_vu32*)(lds_void_p)(smem);
+  lds_vf32* nb_d = (lds_vf32*)(nb_id + a.nbmax);
   float* qgen = reinterpret_cast<float*>(smem + (size_t)a.nbmax * 8);
   uint32_t* qbits = reinterpret_cast<uint32_t*>(smem + (size_t)a.nbmax * 8);
   const DistCtx& dc = a.dc;

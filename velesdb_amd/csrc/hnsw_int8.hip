@@ -104,16 +104,16 @@ __global__ __launch_bounds__(WAVES * 64, 4) void hnsw_search_int8_kernel(HnswInt
   const int lane = lane_id();
   const int wib = (int)rfl(threadIdx.x >> 6);
   const uint32_t cap = a.cap, nbmax = a.nbmax, ef = a.ef;
-  volatile uint64_t* keys = reinterpret_cast<volatile uint64_t*>(smem);
-  volatile uint32_t* nb_id = reinterpret_cast<volatile uint32_t*>(smem + (size_t)cap * 8);
-  volatile float* nb_d = reinterpret_cast<volatile float*>(smem + (size_t)cap * 8 + (size_t)nbmax * 4);
-  volatile uint32_t* ctl = reinterpret_cast<volatile uint32_t*>(smem + (size_t)cap * 8 + (size_t)nbmax * 8);
-  volatile uint8_t* flags = smem + (size_t)cap * 8 + (size_t)nbmax * 8 + 16;
+  lds_vu64* keys = (lds_vu64*)(lds_void_p)(smem);
+  lds_vu32* nb_id = (lds_vu32*)(lds_void_p)(smem + (size_t)cap * 8);
+  lds_vf32* nb_d = (lds_vf32*)(lds_void_p)(smem + (size_t)cap * 8 + (size_t)nbmax * 4);
+  lds_vu32* ctl = (lds_vu32*)(lds_void_p)(smem + (size_t)cap * 8 + (size_t)nbmax * 8);
+  lds_vu8* flags = (lds_vu8*)(lds_void_p)(smem + (size_t)cap * 8 + (size_t)nbmax * 8 + 16);
   const size_t qoff = (size_t)cap * 8 + (size_t)nbmax * 8 + 16 + (((size_t)cap + 15) & ~(size_t)15);
   const int d4 = (int)((a.dim + 3) / 4);
   float* qgen = reinterpret_cast<float*>(smem + qoff);
   uint32_t* qcw = reinterpret_cast<uint32_t*>(smem + qoff + (CPL > 0 ? 0 : (size_t)d4 * 16));
-  volatile uint64_t* outp = reinterpret_cast<volatile uint64_t*>(
+  lds_vu64* outp = (lds_vu64*)(lds_void_p)(
       smem + ((qoff + (CPL > 0 ? 0 : (size_t)d4 * 16) + (size_t)A.codes.code_words * 4 + 15) & ~(size_t)15));
 
   uint32_t* vis = a.visited + (size_t)blockIdx.x * a.vis_words;

@@ -71,11 +71,11 @@ __global__ __launch_bounds__(LAT ? 1024 : 256, 4) void hnsw_search_kernel(HnswSe
   const int lane = lane_id();
   const int wib = (int)rfl(threadIdx.x >> 6);
   const uint32_t cap = a.cap, nbmax = a.nbmax, ef = a.ef;
-  volatile uint64_t* keys = reinterpret_cast<volatile uint64_t*>(smem);
-  volatile uint32_t* nb_id = reinterpret_cast<volatile uint32_t*>(smem + (size_t)cap * 8);
-  volatile float* nb_d = reinterpret_cast<volatile float*>(smem + (size_t)cap * 8 + (size_t)nbmax * 4);
-  volatile uint32_t* ctl = reinterpret_cast<volatile uint32_t*>(smem + (size_t)cap * 8 + (size_t)nbmax * 8);
-  volatile uint8_t* flags = smem + (size_t)cap * 8 + (size_t)nbmax * 8 + 16;
+  lds_vu64* keys = (lds_vu64*)(lds_void_p)(smem);
+  lds_vu32* nb_id = (lds_vu32*)(lds_void_p)(smem + (size_t)cap * 8);
+  lds_vf32* nb_d = (lds_vf32*)(lds_void_p)(smem + (size_t)cap * 8 + (size_t)nbmax * 4);
+  lds_vu32* ctl = (lds_vu32*)(lds_void_p)(smem + (size_t)cap * 8 + (size_t)nbmax * 8);
+  lds_vu8* flags = (lds_vu8*)(lds_void_p)(smem + (size_t)cap * 8 + (size_t)nbmax * 8 + 16);
   const size_t qoff = (size_t)cap * 8 + (size_t)nbmax * 8 + 16 + (((size_t)cap + 15) & ~(size_t)15);
   float* qgen = reinterpret_cast<float*>(smem + qoff);
   uint32_t* qbits = reinterpret_cast<uint32_t*>(smem + qoff);
@@ -267,7 +267,11 @@ __global__ __launch_bounds__(LAT ? 1024 : 256, 4) void hnsw_search_kernel(HnswSe
                   if ((uint32_t)lane < lim) nb0 = L.nbr[(size_t)cnode * L.stride + lane];
                   ncv = L.cnt[cnode];
                 }
+                uint32_t nc = rfl(ncv);
+                nc = min(nc, lim);
                 if (PF) {
+                  // (behind the wait for this pop's own list: where the two paths above join, the compiler waits for EVERY load in
+                  // flight — requested in front of that, the prediction's round trip was paid by every pop: 2 % slower than none)
                   const uint32_t idx2 = list.first_unexpanded(lane);
                   pf_node = 0xFFFFFFFFu;
                   if (idx2 != kNoIndex) {
@@ -276,8 +280,6 @@ __global__ __launch_bounds__(LAT ? 1024 : 256, 4) void hnsw_search_kernel(HnswSe
                     pf_cnt = L.cnt[pf_node];
                   }
                 }
-                uint32_t nc = rfl(ncv);
-                nc = min(nc, lim);
                 if (LAT && a.lat_spec) {  // (nc <= 64, host) every neighbour is evaluated; the visited verdicts follow with the distances
                   if ((uint32_t)lane < nc) nb_id[lane] = nb0;
                   m = nc;
@@ -571,10 +573,12 @@ static const uint32_t g_hnsw_lat_max = [] {  // 0: one query per CU (the default
   return e ? (uint32_t)atoi(e) : 0u;
 }();
 
-// VELESDB_HNSW_PREFETCH_IDS=0: every pop requests its own neighbour list (A / B measurements of the prediction)
-static const bool g_hnsw_pf = [] {
+// VELESDB_HNSW_PREFETCH_IDS: 0 = every pop requests its own neighbour list, 1 = the latency-mode walk always asks for the predicted
+// next pop's list too, unset = the measured default: only over a corpus beyond the Infinity Cache (1 M x 768: 1 102 -> 1 091 us per
+// one-query call at a 48 % hit rate; 10 K x 768, cache-resident: 659 -> 671 us at 55 % — profiles/r04q2_*)
+static const int g_hnsw_pf = [] {
   const char* e = getenv("VELESDB_HNSW_PREFETCH_IDS");
-  return !(e && e[0] == '0');
+  return e ? atoi(e) : -1;
 }();
 // VELESDB_HNSW_VIS_LDS: 0 = HBM bitmaps everywhere, 1 = the exact LDS set in the throughput kernel too (two blocks per CU
 // instead of four), unset = the measured default (see pick_vis)
@@ -597,7 +601,6 @@ static uint32_t pick_vis(const HnswSearchArgs& a, size_t lds, bool lat) {
 
 hipError_t launch_hnsw_search(const HnswSearchArgs& a0, int slots, hipStream_t st) {
   HnswSearchArgs a = a0;
-  a.pf_ids = g_hnsw_pf ? 1u : 0u;
   size_t lds = hnsw_lds_bytes(a.cap, a.nbmax, a.dim, a.words, a.metric);
   // at most one query per CU (measured at 1 M x 768, ef 128: 64 queries 1.57 ms against 2.68 ms on the throughput kernel, 256
   // queries 2.12 against 3.21 ms — a 1 024-thread block per CU is all the chip holds of this kernel) over a corpus that does not
@@ -607,6 +610,7 @@ hipError_t launch_hnsw_search(const HnswSearchArgs& a0, int slots, hipStream_t s
   // (round 3: with the visited set in LDS the latency-mode kernel also serves cache-resident corpora — WITHOUT the speculation:
   // test first, fetch the unvisited; VELESDB_HNSW_LATENCY_MODE=2 forces the speculative form, =3 the other one)
   const bool beyond_cache = (uint64_t)a.n_rows * a.row_stride * 4 >= (256ull << 20);
+  a.pf_ids = g_hnsw_pf >= 0 ? (g_hnsw_pf ? 1u : 0u) : (beyond_cache ? 1u : 0u);
   const uint32_t lat_vis = pick_vis(a0, lds, true);
   if (g_hnsw_lat && a.nq <= (g_hnsw_lat_max ? g_hnsw_lat_max : a.n_cus) && (g_hnsw_lat >= 2 || beyond_cache || lat_vis) && a.list_slots == kSearchRegSlots && a.rerank_k == 0 && a.layers[0].stride <= 64 &&
       a.nbmax >= 64 && (a.metric == kCosine || a.metric == kEuclidean || a.metric == kDot)) {

@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
   unsigned char* tiles = smem + (size_t)dpad * B * 4;
   unsigned char* tile = tiles + (size_t)wib * 64 * kSq8TileStride;
   unsigned char* tail = tiles + (size_t)4 * 64 * kSq8TileStride;
-  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(tail);
-  volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(tail + (size_t)B * k * 8);
+  lds_vu64* lists = (lds_vu64*)(lds_void_p)(tail);
+  lds_vu32* cnts = (lds_vu32*)(lds_void_p)(tail + (size_t)B * k * 8);
   uint32_t* locks = reinterpret_cast<uint32_t*>(tail + (size_t)B * k * 8 + B * 4);
   float* qsum = reinterpret_cast<float*>(tail + (size_t)B * k * 8 + B * 8);
   float* qnsq = reinterpret_cast<float*>(tail + (size_t)B * k * 8 + B * 12);

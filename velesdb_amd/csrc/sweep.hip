@@ -39,8 +39,8 @@ __global__ __launch_bounds__(256) void sweep_topk_f32(SweepArgs a) {
   const uint32_t wave = blockIdx.x * 4 + wib;
   const uint32_t nwaves = gridDim.x * 4;
   const uint32_t k = a.k;
-  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(smem);
-  volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(smem + (size_t)B * k * 8);
+  lds_vu64* lists = (lds_vu64*)(lds_void_p)(smem);
+  lds_vu32* cnts = (lds_vu32*)(lds_void_p)(smem + (size_t)B * k * 8);
   uint32_t* locks = reinterpret_cast<uint32_t*>(smem + (size_t)B * k * 8 + (size_t)B * 4);
   float* qgen = reinterpret_cast<float*>(smem + ((((size_t)B * k * 8 + (size_t)B * 8) + 15) & ~(size_t)15));  // generic path only
   uint32_t nq_here = a.nq, slot0 = 0;
@@ -203,8 +203,8 @@ __global__ __launch_bounds__(WAVES * 64, (B == 32 ? 4 : 3)) void sweep_topk_f32_
   // ONE sorted k-list per query per block, shared by the block's waves under a per-query LDS lock: a wave
   // streams only n_rows / (#waves) rows, so per-wave lists would each need their own ~k*ln(rows/k) insertions
   // (x B queries x thousands of waves); shared, the threshold tightens WAVES times faster.
-  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(lbase);
-  volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(lbase + (size_t)B * k * 8);
+  lds_vu64* lists = (lds_vu64*)(lds_void_p)(lbase);
+  lds_vu32* cnts = (lds_vu32*)(lds_void_p)(lbase + (size_t)B * k * 8);
   uint32_t* locks = reinterpret_cast<uint32_t*>(lbase + (size_t)B * k * 8 + (size_t)B * 4);
   if (threadIdx.x < B) {
     cnts[threadIdx.x] = 0;
@@ -405,8 +405,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sweep_topk_mfma_f32(SweepArgs a
   const uint32_t k = a.k;
   float* qs = reinterpret_cast<float*>(smem);
   const size_t qbytes = (size_t)KU * NQT * 8192;
-  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(smem + qbytes);
-  volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(smem + qbytes + (size_t)B * k * 8);
+  lds_vu64* lists = (lds_vu64*)(lds_void_p)(smem + qbytes);
+  lds_vu32* cnts = (lds_vu32*)(lds_void_p)(smem + qbytes + (size_t)B * k * 8);
   uint32_t* locks = reinterpret_cast<uint32_t*>(smem + qbytes + (size_t)B * k * 8 + (size_t)B * 4);
   float* qn = reinterpret_cast<float*>(smem + qbytes + (size_t)B * k * 8 + (size_t)B * 8);
   const int d4 = (int)((a.dim + 3) / 4);
@@ -684,8 +684,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 16 ? 4 : 2)) void sweep_topk_
   const uint32_t k = a.k, KU = a.KU;
   uint16_t* qs = reinterpret_cast<uint16_t*>(smem);
   const size_t qbytes = (size_t)KU * NQT * 8192;
-  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(smem + qbytes);
-  volatile uint32_t* cnts = reinterpret_cast<volatile uint32_t*>(smem + qbytes + (size_t)B * k * 8);
+  lds_vu64* lists = (lds_vu64*)(lds_void_p)(smem + qbytes);
+  lds_vu32* cnts = (lds_vu32*)(lds_void_p)(smem + qbytes + (size_t)B * k * 8);
   uint32_t* locks = reinterpret_cast<uint32_t*>(smem + qbytes + (size_t)B * k * 8 + (size_t)B * 4);
   float* qn = reinterpret_cast<float*>(smem + qbytes + (size_t)B * k * 8 + (size_t)B * 8);
 
@@ -849,8 +849,8 @@ __global__ __launch_bounds__(256) void merge_topk(MergeArgs m) {
   if (m.gate && m.gate[qi] == 0u) return;
   const uint32_t kin = m.k;                     // entries per partial list
   const uint32_t k = m.k_out ? m.k_out : m.k;   // entries kept (k_out > k: a candidate pool for a re-scoring stage)
-  volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)wib * k;
-  volatile uint32_t* wcnt = reinterpret_cast<volatile uint32_t*>(smem + (size_t)4 * k * 8);
+  lds_vu64* list = (lds_vu64*)(lds_void_p)(smem) + (size_t)wib * k;
+  lds_vu32* wcnt = (lds_vu32*)(lds_void_p)(smem + (size_t)4 * k * 8);
   uint32_t cnt = 0;
   const uint64_t* keys = m.part_keys + (size_t)qi * (m.list_stride ? m.list_stride : m.n_lists) * kin;
   const uint32_t total = m.n_lists * kin;  // slots beyond a list's count hold kKeyInvalid
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256) void merge_topk(MergeArgs m) {
   __syncthreads();
   if (wib != 0) return;
   for (int w = 1; w < 4; w++) {
-    volatile uint64_t* src = reinterpret_cast<volatile uint64_t*>(smem) + (size_t)w * k;
+    lds_vu64* src = (lds_vu64*)(lds_void_p)(smem) + (size_t)w * k;
     const uint32_t cs = wcnt[w];
     for (uint32_t e = 0; e < cs; e++) {
       const uint64_t kk = src[e];
@@ -1032,8 +1032,8 @@ __global__ __launch_bounds__(256) void sweep_topk_bits(BitsArgs a) {
   const uint32_t k = a.k;
   const uint32_t W = a.words;  // multiple of 4
   // LDS: list[k] u64 (block-shared, locked) | cnt, lock | query words
-  volatile uint64_t* list = reinterpret_cast<volatile uint64_t*>(smem);
-  volatile uint32_t* cnt = reinterpret_cast<volatile uint32_t*>(smem + (size_t)k * 8);
+  lds_vu64* list = (lds_vu64*)(lds_void_p)(smem);
+  lds_vu32* cnt = (lds_vu32*)(lds_void_p)(smem + (size_t)k * 8);
   uint32_t* lock = reinterpret_cast<uint32_t*>(smem + (size_t)k * 8 + 4);
   uint32_t* qw = reinterpret_cast<uint32_t*>(smem + (((size_t)k * 8 + 8 + 15) & ~(size_t)15));
   if (threadIdx.x == 0) {
@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(256) void sweep_topk_bits(BitsArgs a) {
 // offers to the query's block-shared list, threshold refresh.  Not inlined: it runs for a few rows per thousand, and
 // keeping it out of line keeps the (R x B)-fold unrolled filter loop small enough to stay fully unrolled.
 template <int METRIC>
-__device__ __noinline__ void bits_offer(volatile uint64_t* list, volatile uint32_t* cnt, uint32_t* lock, uint32_t* thr,
+__device__ __noinline__ void bits_offer(lds_vu64* list, lds_vu32* cnt, uint32_t* lock, uint32_t* thr,
                                         uint32_t k, uint32_t pqb, uint32_t px, uint32_t inter, uint32_t row, uint64_t mask,
                                         const uint8_t* alive, int lane) {
   constexpr bool HIB = higher_is_better(METRIC);
@@ -1167,9 +1167,9 @@ __global__ __launch_bounds__(256) void sweep_topk_bits_batch(BitsArgs a, uint32_
   uint32_t* qw = reinterpret_cast<uint32_t*>(smem);
   uint32_t* pq = qw + (size_t)W * B;
   uint32_t* thr = pq + B;
-  volatile uint32_t* cnt = thr + B;
-  uint32_t* lock = const_cast<uint32_t*>(cnt) + B;
-  volatile uint64_t* lists = reinterpret_cast<volatile uint64_t*>(lock + B);
+  lds_vu32* cnt = (lds_vu32*)(lds_void_p)(thr + B);
+  uint32_t* lock = thr + 2 * B;
+  lds_vu64* lists = (lds_vu64*)(lds_void_p)(lock + B);
   for (uint32_t i = tid; i < W * B; i += 256) {
     const uint32_t b = i / W, w = i % W;
     const uint32_t src = min(q0 + b, nq - 1);  // padded slots repeat the last query (their lists are never written out)
@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(256) void sweep_topk_bits_tile(BitsArgs a, uint32_t
   uint32_t* pq = qw + (size_t)W * B;
   uint32_t* thr = pq + B;
   uint32_t* cnts = thr + B;
-  volatile uint32_t* ovf = cnts + B;
+  lds_vu32* ovf = (lds_vu32*)(lds_void_p)(cnts + B);
   uint64_t* tauk = reinterpret_cast<uint64_t*>(cnts + B + 4);
   uint64_t* cand = tauk + B;
   for (uint32_t i = tid; i < W * B; i += 256) {

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void sweep_topk_gem
   uint64_t* tauk = reinterpret_cast<uint64_t*>(tail + (size_t)BN * CAP * 8);    // [BN] k-th best key (invalid: none yet)
   uint32_t* cnts = reinterpret_cast<uint32_t*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 8);
   float* qn = reinterpret_cast<float*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 12);
-  volatile uint32_t* ovf = reinterpret_cast<volatile uint32_t*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 16);  // overflow token
+  lds_vu32* ovf = (lds_vu32*)(lds_void_p)(tail + (size_t)BN * CAP * 8 + (size_t)BN * 16);  // overflow token
   float* vns = reinterpret_cast<float*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 16 + 16);  // [BM] norms of the row tile
   uint64_t* wqueue_all = reinterpret_cast<uint64_t*>(tail + (size_t)BN * CAP * 8 + (size_t)BN * 16 + 16 + BM * 4);  // [WAVES][kGemmQueue]
 

@@ -142,10 +142,22 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// LDS state that waves of a block — or lanes of one wave — hand to each other (the walk / construction kernels' lists and control
+// words, the sweeps' top-k lists and counters) is accessed through volatile pointers, so that no access is cached in a register or
+// moved across another.  Typed as LDS pointers: a volatile access through a
+// GENERIC pointer stays a FLAT instruction (the address-space inference pass leaves volatile accesses alone) — `flat_store … sc0
+// sc1` + `s_waitcnt vmcnt(0)`, i.e. the LDS access queues behind every global load in flight (round 4: the walk's neighbour-list prefetch was
+// waited for by the first LDS store behind it; a sweep's per-tile threshold read waited for the next tile's rows).  Through these types the same accesses are `ds_read` / `ds_write`.
+typedef __attribute__((address_space(3))) void* lds_void_p;
+typedef volatile __attribute__((address_space(3))) uint64_t lds_vu64;
+typedef volatile __attribute__((address_space(3))) uint32_t lds_vu32;
+typedef volatile __attribute__((address_space(3))) float lds_vf32;
+typedef volatile __attribute__((address_space(3))) uint8_t lds_vu8;
+
 // ---- wave-owned sorted top-k list in LDS -------------------------------------------------
 // list[0..*cnt) ascending u64 keys, capacity k.  All 64 lanes call together with a
 // wave-uniform key.  Returns nothing; *cnt is updated by lane 0 semantics (uniform value).
-__device__ __forceinline__ void wave_list_insert(volatile uint64_t* list, uint32_t& cnt, uint32_t k,
+__device__ __forceinline__ void wave_list_insert(lds_vu64* list, uint32_t& cnt, uint32_t k,
                                                  uint64_t key, int lane) {
   if (cnt == k && key >= list[k - 1]) return;  // uniform
   // position = number of elements < key
@@ -176,7 +188,7 @@ __device__ __forceinline__ void wave_list_insert(volatile uint64_t* list, uint32
 // (#waves in the block) times faster.  The final content is the k smallest keys offered, whatever the
 // interleaving (keys are unique), so results stay deterministic.  Lane 0 spins; a wave never holds two
 // locks and never reaches a barrier while holding one.
-__device__ __forceinline__ void shared_list_offer(volatile uint64_t* list, volatile uint32_t* cnt, uint32_t* lock,
+__device__ __forceinline__ void shared_list_offer(lds_vu64* list, lds_vu32* cnt, uint32_t* lock,
                                                   uint32_t k, uint64_t key, int lane) {
   if (*cnt == k && key >= list[k - 1]) return;  // unlocked pre-check: the k-th best only ever improves
   if (lane == 0) {

@@ -42,7 +42,7 @@ __device__ __forceinline__ void reduce_rows(float* a, int lane) {
 
 // Sorted list insert with per-entry flags.  Wave-uniform arguments, all 64 lanes participate.
 // If the list is at capacity its last entry is dropped and reported (key + flag).
-__device__ __forceinline__ void list_insert(volatile uint64_t* keys, volatile uint8_t* flags, uint32_t& cnt,
+__device__ __forceinline__ void list_insert(lds_vu64* keys, lds_vu8* flags, uint32_t& cnt,
                                             uint32_t cap, uint64_t key, int lane, uint64_t& dropped,
                                             uint32_t& dropped_flag) {
   dropped = kKeyInvalid;
@@ -118,7 +118,7 @@ __device__ __forceinline__ bool key_dist_gt(uint64_t a, uint64_t b) {
 
 // entries past ef stay only up to the last one the termination test could still expand
 template <bool UD = false>
-__device__ __forceinline__ void list_truncate(volatile uint64_t* keys, uint32_t& cnt, uint32_t ef, int lane) {
+__device__ __forceinline__ void list_truncate(lds_vu64* keys, uint32_t& cnt, uint32_t ef, int lane) {
   if (cnt <= ef) return;
   const uint64_t wk = keys[ef - 1];
   uint32_t last = ef - 1;
@@ -163,7 +163,7 @@ struct CodeCtx {
 // nb_id[0..m) -> nb_d[0..m) as u32 bit patterns.  qw: this lane's query words (word w = lane + 64*j), QW of them.
 template <int QW, int WAVES = 4>
 __device__ __forceinline__ void dist_phase_int8(const CodeCtx& c, const uint32_t (&qw)[QW], uint32_t qsq, uint32_t m,
-                                                volatile uint32_t* nb_id, volatile float* nb_d, int lane, int wib) {
+                                                lds_vu32* nb_id, lds_vf32* nb_d, int lane, int wib) {
   constexpr int R = 8;
   for (uint32_t j0 = (uint32_t)wib * R; j0 < m; j0 += WAVES * R) {
     uint32_t dot[R];
@@ -224,7 +224,7 @@ struct CandList {
         (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(carry >> 32), (int)(uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
     return ((uint64_t)hi << 32) | lo;
   }
-  __device__ __forceinline__ void init(volatile uint64_t*, volatile uint8_t*, uint32_t) { reset(); }
+  __device__ __forceinline__ void init(lds_vu64*, lds_vu8*, uint32_t) { reset(); }
   __device__ __forceinline__ void reset() {
 #pragma unroll
     for (int s = 0; s < NS; s++) k[s] = ~0ull;
@@ -263,8 +263,8 @@ struct CandList {
   // caller has to walk the chunk one by one: an exact tie of distances between a candidate and anything (the reference's
   // strict compare decides those in arrival order; equal distances are neighbours in the merged order, so the test looks at
   // neighbours after the scatter), a NaN distance, or more keys than the list holds.
-  __device__ __forceinline__ bool admit_batch(uint64_t mask, float d, uint32_t nb, int lane, uint32_t ef, volatile uint64_t* scratch_v,
-                                              volatile uint8_t*) {
+  __device__ __forceinline__ bool admit_batch(uint64_t mask, float d, uint32_t nb, int lane, uint32_t ef, lds_vu64* scratch_v,
+                                              lds_vu8*) {
     const uint32_t n_acc = (uint32_t)__popcll(mask);
     const uint32_t total = cnt + n_acc;
     if (total > CAP) return false;
@@ -292,7 +292,7 @@ struct CandList {
     // the wave's in-order LDS queue and the compiler barriers: old entries behind the candidates below them, candidates at old
     // rank + candidate rank; then everything is read back in one go, and every candidate looks at its two neighbours in the
     // merged order (equal distances are neighbours there).
-    uint64_t* scratch = const_cast<uint64_t*>(scratch_v);
+    __attribute__((address_space(3))) uint64_t* scratch = (__attribute__((address_space(3))) uint64_t*)scratch_v;
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int s = 0; s < NS; s++)
@@ -363,7 +363,7 @@ struct CandList {
     return dec(v);
   }
   // copy the first n entries to LDS as external keys (construction: select_neighbors works on LDS arrays)
-  __device__ __forceinline__ void dump(volatile uint64_t* keys, uint32_t n, int lane) const {
+  __device__ __forceinline__ void dump(lds_vu64* keys, uint32_t n, int lane) const {
 #pragma unroll
     for (int s = 0; s < NS; s++) {
       const uint32_t e = (uint32_t)s * 64 + lane;
@@ -374,10 +374,10 @@ struct CandList {
 
 template <bool UD>
 struct CandList<0, UD> {
-  volatile uint64_t* keys;
-  volatile uint8_t* flags;
+  lds_vu64* keys;
+  lds_vu8* flags;
   uint32_t cnt, cap;
-  __device__ __forceinline__ void init(volatile uint64_t* k_, volatile uint8_t* f_, uint32_t cap_) {
+  __device__ __forceinline__ void init(lds_vu64* k_, lds_vu8* f_, uint32_t cap_) {
     keys = k_;
     flags = f_;
     cap = cap_;
@@ -391,7 +391,7 @@ struct CandList<0, UD> {
     list_insert(keys, flags, cnt, cap, ext, lane, dr, df);
     if (dr != kKeyInvalid && df == 0) overflow = 1;  // an unexpanded candidate fell off the list
   }
-  __device__ __forceinline__ bool admit_batch(uint64_t, float, uint32_t, int, uint32_t, volatile uint64_t*, volatile uint8_t*) { return false; }  // (LDS list: one by one)
+  __device__ __forceinline__ bool admit_batch(uint64_t, float, uint32_t, int, uint32_t, lds_vu64*, lds_vu8*) { return false; }  // (LDS list: one by one)
   __device__ __forceinline__ uint32_t first_unexpanded(int lane) const {
     for (uint32_t c = 0; c < cnt; c += 64) {
       const uint32_t e = c + lane;
@@ -406,7 +406,7 @@ struct CandList<0, UD> {
   }
   __device__ __forceinline__ void truncate(uint32_t ef, int lane) { list_truncate<UD>(keys, cnt, ef, lane); }
   __device__ __forceinline__ uint64_t chunk_key(uint32_t base, int lane) const { return keys[base + lane]; }
-  __device__ __forceinline__ void dump(volatile uint64_t*, uint32_t, int) const {}
+  __device__ __forceinline__ void dump(lds_vu64*, uint32_t, int) const {}
 };
 
 __device__ __forceinline__ float transform_score_dev(int metric, float d) {  // backend_adapter.rs:160-168
@@ -423,8 +423,8 @@ __device__ __forceinline__ float transform_score_dev(int metric, float d) {  // 
 // ---- distance evaluation of nb_id[0..m) -> nb_d[0..m): DistanceEngine::distance (native/distance.rs:75-85)
 template <int METRIC, int CPL, int WAVES = 4, int R = 8>
 __device__ __forceinline__ void dist_phase_f32(const DistCtx& a, const float4* q, float qnorm,
-                                               const float* qgen, uint32_t m, volatile uint32_t* nb_id,
-                                               volatile float* nb_d, int lane, int wib, bool raw = false) {
+                                               const float* qgen, uint32_t m, lds_vu32* nb_id,
+                                               lds_vf32* nb_d, int lane, int wib, bool raw = false) {
   constexpr int OP = (METRIC == kEuclidean) ? kOpL2 : kOpDot;
   const int d4 = (int)((a.dim + 3) / 4);
   for (uint32_t j0 = (uint32_t)wib * R; j0 < m; j0 += WAVES * R) {
@@ -480,7 +480,7 @@ __device__ __forceinline__ void dist_phase_f32(const DistCtx& a, const float4* q
 
 template <int METRIC>
 __device__ __forceinline__ void dist_phase_bits(const DistCtx& a, const uint32_t* qbits, uint32_t m,
-                                                volatile uint32_t* nb_id, volatile float* nb_d, bool raw = false) {
+                                                lds_vu32* nb_id, lds_vf32* nb_d, bool raw = false) {
   const uint32_t W = a.words;
   for (uint32_t t = threadIdx.x; t < m; t += 256) {
     const uint4* p = reinterpret_cast<const uint4*>(a.bits + (size_t)nb_id[t] * W);
