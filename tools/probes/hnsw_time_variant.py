@@ -11,9 +11,9 @@ def rep(old, new):
 rep('    uint32_t n_dist = 0, n_expand = 0, logn = 0, overflow = 0, m_prev = 0, rr_m = 0;',
     '    uint32_t n_dist = 0, n_expand = 0, logn = 0, overflow = 0, m_prev = 0, rr_m = 0;\n    unsigned long long tA = 0, tB = 0, tC = 0, tC1 = 0, tC2 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0; uint32_t nadm = 0, nbatch = 0;')
 rep('            const uint32_t idx = list.first_unexpanded(lane);', '            c0 = wall_clock64();\n            const uint32_t idx = list.first_unexpanded(lane);')
-rep('                uint32_t nc = rfl(L.cnt[cnode]);\n                nc = min(nc, lim);', '                uint32_t nc = rfl(L.cnt[cnode]);\n                nc = min(nc, lim);\n                { volatile uint32_t sink = rfl(nb0); (void)sink; }\n                c1 = wall_clock64(); tA += c1 - c0;')
+rep('                uint32_t nc = rfl(ncv);\n                nc = min(nc, lim);', '                uint32_t nc = rfl(ncv);\n                nc = min(nc, lim);\n                { volatile uint32_t sink = rfl(nb0); (void)sink; }\n                c1 = wall_clock64(); tA += c1 - c0;')
 rep('          } else if (phase == P_Z_ADMIT) {', '          } else if (phase == P_Z_ADMIT) {\n            c2 = wall_clock64(); tB += c2 - c1;')
-rep('              if (LAT) mask &= spec_mask;\n', '              if (LAT) mask &= spec_mask;\n              nadm += (uint32_t)__popcll(mask);\n              c3 = wall_clock64(); tC1 += c3 - c2;\n')
+rep('              if (LAT && a.lat_spec) mask &= spec_mask;\n', '              if (LAT && a.lat_spec) mask &= spec_mask;\n              nadm += (uint32_t)__popcll(mask);\n              c3 = wall_clock64(); tC1 += c3 - c2;\n')
 rep('                mask = 0ull;\n', '                { mask = 0ull; nbatch++; }\n              tC2 += wall_clock64() - c3;\n')
 i = t.index('            phase = P_Z_POP;\n          } else if (phase == P_FINISH) {')
 t = t[:i] + '            tC += wall_clock64() - c2;\n' + t[i:]
