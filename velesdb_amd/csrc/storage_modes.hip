@@ -378,6 +378,10 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
       }
     }
     const float vn2 = (METRIC == kCosine) ? a.nsq[rowc] : 0.0f;
+    uint64_t taus[B];  // the lists' bounds, read together (vdb_device.hpp list_tau_relaxed)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int b = 0; b < B; b++) taus[b] = list_tau_relaxed(lists, cnts, (uint32_t)b, k);
 #pragma unroll
     for (int b = 0; b < B; b++) {
       float score = acc[b];
@@ -387,8 +391,7 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
       }
       const bool ok = valid && (uint32_t)b < nq_here;
       const uint64_t key = ok ? make_key<HIB>(score, row) : kKeyInvalid;
-      const uint64_t tau = (cnts[b] == k) ? lists[(size_t)b * k + (k - 1)] : kKeyInvalid;
-      uint64_t mask = __ballot(key < tau);
+      uint64_t mask = __ballot(key < taus[b]);
       while (mask) {
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;

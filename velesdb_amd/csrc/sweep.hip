@@ -544,10 +544,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sweep_topk_mfma_f32(SweepArgs a
     // cheap conservative filter: an approximate score (multiply by a reciprocal, ~1 ulp) is compared with the
     // k-th best score of its query minus a 16-ulp margin; whatever passes is finished exactly and offered. ----
     float tau_f[NQT];  // k-th best score of this lane's query in tile t (-inf while the list is not full)
+    asm volatile("" ::: "memory");  // (fresh, plain LDS reads issued together: vdb_device.hpp list_tau_relaxed)
 #pragma unroll
     for (int t = 0; t < NQT; t++) {
       const uint32_t b = t * 16 + (lane & 15);
-      tau_f[t] = (cnts[b] == k) ? key_score<HIB>(lists[(size_t)b * k + (k - 1)]) : __uint_as_float(0xFF800000u);
+      const uint64_t tk = list_tau_relaxed(lists, cnts, b, k);
+      tau_f[t] = tk != kKeyInvalid ? key_score<HIB>(tk) : __uint_as_float(0xFF800000u);
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -786,10 +788,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 16 ? 4 : 2)) void sweep_topk_
       }
     }
     float tau_f[NQT];
+    asm volatile("" ::: "memory");  // (fresh, plain LDS reads issued together: vdb_device.hpp list_tau_relaxed)
 #pragma unroll
     for (int t = 0; t < NQT; t++) {
       const uint32_t b = t * 16 + (lane & 15);
-      tau_f[t] = (cnts[b] == k) ? key_score<HIB>(lists[(size_t)b * k + (k - 1)]) : __uint_as_float(0xFF800000u);
+      const uint64_t tk = list_tau_relaxed(lists, cnts, b, k);
+      tau_f[t] = tk != kKeyInvalid ? key_score<HIB>(tk) : __uint_as_float(0xFF800000u);
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) {

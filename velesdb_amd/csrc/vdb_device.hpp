@@ -202,6 +202,17 @@ __device__ __forceinline__ void shared_list_offer(lds_vu64* list, lds_vu32* cnt,
   if (lane == 0) atomicExch(lock, 0u);
 }
 
+// k-th best key of a block-shared list for the UNLOCKED pre-filter of a sweep's epilogue (kKeyInvalid while the list is not full).
+// Any value the list has held is a safe bound — the k-th best only ever improves and shared_list_offer re-checks under the lock —
+// so these are PLAIN LDS reads: the compiler may issue a tile's reads together and wait once (the volatile form waits for every
+// one of them; 16 per 64-row group in the SQ8 sweep).  The caller puts `asm volatile("" ::: "memory")` in front of a tile's reads,
+// which is what makes them fresh per tile.
+__device__ __forceinline__ uint64_t list_tau_relaxed(lds_vu64* lists, lds_vu32* cnts, uint32_t b, uint32_t k) {
+  const __attribute__((address_space(3))) uint32_t* c = (const __attribute__((address_space(3))) uint32_t*)cnts;
+  const __attribute__((address_space(3))) uint64_t* l = (const __attribute__((address_space(3))) uint64_t*)lists;
+  return c[b] == k ? l[(size_t)b * k + (k - 1)] : kKeyInvalid;
+}
+
 // ---- canonical per-lane chains (shared by the sweep, traversal and construction kernels) ----
 enum Op : int { kOpDot = 0, kOpL2 = 1 };
 
