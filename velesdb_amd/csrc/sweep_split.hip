@@ -238,6 +238,9 @@ template <int METRIC>
 __global__ __launch_bounds__(256) void seed_scores_bf16(const uint16_t* rows16, uint64_t row_stride, const float* norms, const uint8_t* alive,
                                                         const uint16_t* q16, uint64_t q_stride, const float* qnorms, uint64_t* keys,
                                                         uint32_t seed_rows, uint32_t nq, uint32_t dim) {
+  // (Round 4, measured and rejected: one 64 x 64 tile per BLOCK, its four waves splitting the k-extent and adding up through LDS —
+  // three request rounds per wave instead of twelve and four times the waves per CU: 81.6 us against this form's 40.
+  // profiles/r04seed_split_k_seed_rejected.txt)
   const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
   // a wave = 64 rows x 64 queries (round 3: 16 x 64 — every query fragment fed ONE row fragment, 7.4 TB/s through L2 for 4 096
   // seed rows, 66 us; now four): row blocks rb = 0..3 of 16 rows
