@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r03h
-mkdir -p $O
+rm -rf $O/trace; mkdir -p $O
 VELESDB_TRACE_LEVELS=2 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python $R/tools/probes/split_probe.py --reps 3 ${METRIC:+--metric $METRIC} > $O/probe.log 2>&1
 tail -3 $O/probe.log
 python3 - <<'PY'

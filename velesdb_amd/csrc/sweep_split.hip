@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void seed_scores_bf16(const uint16_t* rows16, 
                                                         const uint16_t* q16, uint64_t q_stride, const float* qnorms, uint64_t* keys,
                                                         uint32_t seed_rows, uint32_t nq, uint32_t dim) {
   // (Round 4, measured and rejected: one 64 x 64 tile per BLOCK, its four waves splitting the k-extent and adding up through LDS —
-  // three request rounds per wave instead of twelve and four times the waves per CU: 81.6 us against this form's 40.
+  // three request rounds per wave instead of twelve and four times the waves per CU: 81.6 us against 40 for a wave per tile.
   // profiles/r04seed_split_k_seed_rejected.txt)
   const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
   // a wave = 64 rows x 64 queries (round 3: 16 x 64 — every query fragment fed ONE row fragment, 7.4 TB/s through L2 for 4 096
@@ -259,22 +259,46 @@ __global__ __launch_bounds__(256) void seed_scores_bf16(const uint16_t* rows16, 
   for (int rb = 0; rb < 4; rb++)
 #pragma unroll
     for (int t = 0; t < 4; t++) acc[rb][t] = f32x4_s{0.f, 0.f, 0.f, 0.f};
-  for (uint32_t k0 = 0; k0 < dim; k0 += 64) {  // dim % 32 == 0: steps past dim are skipped
-    bf16x8_s av[4][2], bv[2][4];
+  // Every 64-deep step touches the NEXT 128-byte line of the wave's 64 rows — lines the previous batch's sweep evicted long ago —
+  // and a CU holds one such wave per SIMD: a chain of dim / 64 memory round trips (measured, round 4: 23 of the kernel's 40 us
+  // at dim 768, the epilogue 12; profiles/r04seedvar_*).  So the fragments are double-buffered in registers: step i + 1 is
+  // requested before step i multiplies.
+  bf16x8_s av[2][4][2], bv[2][2][4];
+  auto request = [&](int buf, uint32_t k0) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       const bool in = k0 + (uint32_t)s * 32u < dim;
 #pragma unroll
-      for (int rb = 0; rb < 4; rb++) av[rb][s] = in ? *reinterpret_cast<const bf16x8_s*>(ap[rb] + k0 + s * 32) : bf16x8_s{};
+      for (int rb = 0; rb < 4; rb++) av[buf][rb][s] = in ? *reinterpret_cast<const bf16x8_s*>(ap[rb] + k0 + s * 32) : bf16x8_s{};
 #pragma unroll
-      for (int t = 0; t < 4; t++) bv[s][t] = in ? *reinterpret_cast<const bf16x8_s*>(bp[t] + k0 + s * 32) : bf16x8_s{};
+      for (int t = 0; t < 4; t++) bv[buf][s][t] = in ? *reinterpret_cast<const bf16x8_s*>(bp[t] + k0 + s * 32) : bf16x8_s{};
     }
+  };
+  auto multiply = [&](int buf) {
 #pragma unroll
     for (int s = 0; s < 2; s++)
 #pragma unroll
       for (int rb = 0; rb < 4; rb++)
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc[rb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rb][s], bv[s][t], acc[rb][t], 0, 0, 0);
+        for (int t = 0; t < 4; t++) acc[rb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[buf][rb][s], bv[buf][s][t], acc[rb][t], 0, 0, 0);
+  };
+  request(0, 0);
+  // (the epilogue's norms ride along with the first request instead of starting a round trip of their own behind the loop)
+  float vn[4][4], qn_t[4];
+#pragma unroll
+  for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      vn[rb][r] = METRIC == kCosine ? norms[min(row0 + (uint32_t)rb * 16u + 4u * kk + (uint32_t)r, seed_rows - 1u)] : 1.0f;
+#pragma unroll
+  for (int t = 0; t < 4; t++) qn_t[t] = METRIC == kCosine ? qnorms[min(qb + (uint32_t)t * 16u + i, nq - 1u)] : 1.0f;
+  for (uint32_t k0 = 0; k0 < dim; k0 += 128) {  // dim % 32 == 0: steps past dim are zero fragments
+    if (k0 + 64 < dim) request(1, k0 + 64);
+    multiply(0);
+    if (k0 + 64 < dim) {
+      if (k0 + 128 < dim) request(0, k0 + 128);
+      multiply(1);
+    }
   }
   // lane holds rows row0 + 16 rb + 4 kk + r (rb, r = 0..3) of query column qb + 16 t + i: the best of those 16 as ONE key —
   // keys[q][group], group = 4 (row0 / 64) + kk (the seed is a sample: sweep_split.hip file header, select_stage.hip brute_split_dev)
@@ -283,7 +307,7 @@ __global__ __launch_bounds__(256) void seed_scores_bf16(const uint16_t* rows16, 
   for (int t = 0; t < 4; t++) {
     const uint32_t q = qb + (uint32_t)t * 16u + i;
     if (q >= nq) continue;
-    const float qn = METRIC == kCosine ? qnorms[q] : 1.0f;
+    const float qn = qn_t[t];
     uint64_t best = kKeyInvalid;
 #pragma unroll
     for (int rb = 0; rb < 4; rb++)
@@ -291,7 +315,7 @@ __global__ __launch_bounds__(256) void seed_scores_bf16(const uint16_t* rows16, 
       for (int r = 0; r < 4; r++) {
         const uint32_t row = row0 + (uint32_t)rb * 16u + 4u * kk + (uint32_t)r;
         if (row >= seed_rows) continue;
-        const float sc = finish_score<METRIC>(acc[rb][t][r], qn, METRIC == kCosine ? norms[row] : 1.0f);
+        const float sc = finish_score<METRIC>(acc[rb][t][r], qn, vn[rb][r]);
         const bool live = !alive || alive[row] != 0;
         const uint64_t key = live ? make_key<true>(sc, row) : kKeyInvalid;
         best = key < best ? key : best;
