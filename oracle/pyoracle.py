@@ -37,7 +37,8 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        # VDB_ORACLE_SO: another build of the same sources (oracle/Makefile's `sanitize` target; tools/oracle_sanitize.sh)
+        _lib = C.CDLL(os.environ.get("VDB_ORACLE_SO") or build())
         _declare(_lib)
     return _lib
 
