@@ -1,0 +1,171 @@
+// combiner_model.cpp — the combining front's protocol (velesdb_amd/csrc/vdb_combiner.hpp, the very text search_front.hip
+// instantiates over a handle) over a MOCK launch, for ThreadSanitizer: many host threads, one small call each, mixed shapes,
+// injected launch errors, callers that leave early.  Test infrastructure (tests/test_host_sync_tsan_cpu.py builds it with
+// -fsanitize=thread and runs it; no GPU, no HIP).  The calling pattern it models is the reference's: many threads, one query per
+// search under a read lock (index/hnsw/index/search.rs:80; stress tests index/hnsw/native/tests.rs:264-416).
+//
+// usage: combiner_model <threads> <iterations> <max_batch> <window_us> <launch_us>
+// Checks (any failure: message on stderr, exit code 1):
+//   * every caller gets the answer of ITS queries (ids / scores are functions of the query value and the shape), or the injected
+//     error with its message, whichever batch its request travelled in;
+//   * a batch holds one shape only, at most max_batch queries, only requests in state kTaken, and never more batches run beside
+//     each other than the shapes' leader limits allow;
+//   * nobody is stranded (the program ends), the queue is empty and no leader slot is held at the end, and the front's counters
+//     add up to the calls made.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "vdb_combiner.hpp"
+
+using vdb::CombineReq;
+using vdb::Combiner;
+
+static std::atomic<int> g_fail{0};
+#define CHECK(cond, ...)                 \
+  do {                                   \
+    if (!(cond)) {                       \
+      std::fprintf(stderr, "CHECK failed %s:%d: %s: ", __FILE__, __LINE__, #cond); \
+      std::fprintf(stderr, __VA_ARGS__); \
+      std::fprintf(stderr, "\n");        \
+      g_fail.store(1);                   \
+    }                                    \
+  } while (0)
+
+constexpr int32_t kErrInjected = -5;
+constexpr uint32_t kBadK = 7;  // a launch of this shape fails as a whole
+
+static uint64_t answer_id(float q, uint32_t k, uint32_t j) { return (uint64_t)(uint32_t)q * 131u + k * 17u + j; }
+static float answer_score(float q, uint32_t ef, uint32_t j) { return q * 0.5f + (float)ef + (float)j; }
+
+struct MockFront {
+  uint32_t mb, win, launch_us;
+  std::atomic<int> in_flight{0}, max_in_flight{0};
+  std::atomic<uint64_t> batches{0}, multi{0};
+  uint32_t max_batch() const { return mb; }
+  uint32_t window_us() const { return win; }
+  // the product's rule (search_front.hip leader_limit): graph walks overlap two launches, sweeps run one at a time
+  int leader_limit(const CombineReq& r) const { return r.mode == 0 ? 2 : 1; }
+  void run_batch(CombineReq* const* reqs, size_t n) {
+    const int now = in_flight.fetch_add(1) + 1;
+    int seen = max_in_flight.load();
+    while (now > seen && !max_in_flight.compare_exchange_weak(seen, now)) {
+    }
+    CHECK(n >= 1, "empty batch");
+    uint32_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+      CHECK(reqs[i]->same_shape(*reqs[0]), "two shapes in one batch");
+      CHECK(reqs[i]->state == CombineReq::kTaken, "a request outside a batch was launched");
+      if (i) CHECK(reqs[i]->word.load() == (uint32_t)CombineReq::kWait, "a launched request was already answered");
+      total += reqs[i]->nq;
+    }
+    CHECK(n == 1 || total <= mb, "batch of %u queries past max_batch %u", total, mb);
+    if (launch_us) std::this_thread::sleep_for(std::chrono::microseconds(launch_us));
+    const bool bad = reqs[0]->k == kBadK;
+    for (size_t i = 0; i < n; i++) {
+      CombineReq* r = reqs[i];
+      if (!bad)
+        for (uint32_t q = 0; q < r->nq; q++) {
+          for (uint32_t j = 0; j < r->k; j++) {
+            r->out_ids[(size_t)q * r->k + j] = answer_id(r->queries[q], r->k, j);
+            r->out_scores[(size_t)q * r->k + j] = answer_score(r->queries[q], r->ef, j);
+          }
+          r->out_n[q] = r->k;
+        }
+      r->rc = bad ? kErrInjected : 0;
+      r->err = bad ? "injected launch failure" : "";
+      r->served_by = reinterpret_cast<vdb_hip_index*>(this);
+    }
+    batches.fetch_add(1);
+    if (n > 1) multi.fetch_add(1);
+    in_flight.fetch_sub(1);
+  }
+  void finish(CombineReq& me) {
+    CHECK(me.served_by == reinterpret_cast<vdb_hip_index*>(this), "a finished request that no launch served");
+    if (me.rc != 0) CHECK(me.err == "injected launch failure", "error text lost: '%s'", me.err.c_str());
+  }
+};
+
+int main(int argc, char** argv) {
+  const int threads = argc > 1 ? std::atoi(argv[1]) : 64;
+  const int iters = argc > 2 ? std::atoi(argv[2]) : 200;
+  const uint32_t mb = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 256;
+  const uint32_t win = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 100;
+  const uint32_t launch_us = argc > 5 ? (uint32_t)std::atoi(argv[5]) : 100;
+  MockFront env;
+  env.mb = mb;
+  env.win = win;
+  env.launch_us = launch_us;
+  Combiner cb;
+  std::atomic<uint64_t> calls{0}, queries{0}, errors{0};
+  std::vector<std::thread> pool;
+  for (int t = 0; t < threads; t++)
+    pool.emplace_back([&, t] {
+      uint64_t s = 0x9E3779B97F4A7C15ull * (uint64_t)(t + 1);
+      auto rnd = [&] {
+        s ^= s << 13;
+        s ^= s >> 7;
+        s ^= s << 17;
+        return s;
+      };
+      const int mine = iters - (t % 4) * (iters / 8);  // callers leave at different times: nobody may wait for one that went away
+      for (int it = 0; it < mine; it++) {
+        static const uint32_t ks[4] = {3, 5, 10, kBadK};
+        const uint32_t k = ks[rnd() % (it % 16 == 5 ? 4 : 3)];  // the failing shape now and then
+        const uint32_t nq = 1 + (uint32_t)(rnd() % std::min<uint32_t>(4, mb));
+        float q[4];
+        uint64_t ids[40];
+        float sc[40];
+        uint32_t cnt[4];
+        std::memset(ids, 0xFF, sizeof ids);
+        for (uint32_t i = 0; i < nq; i++) q[i] = (float)((uint32_t)t * 4096u + (uint32_t)(it % 1024) * 4u + i);
+        CombineReq me;
+        me.queries = q;
+        me.nq = nq;
+        me.k = k;
+        me.ef = 64 + 64 * (uint32_t)(rnd() % 2);
+        me.mode = (int32_t)(rnd() % 2);
+        me.rerank_k = 0;
+        me.out_ids = ids;
+        me.out_scores = sc;
+        me.out_n = cnt;
+        const int32_t rc = vdb::search_combined(env, &cb, me);
+        calls.fetch_add(1);
+        queries.fetch_add(nq);
+        if (k == kBadK) {
+          CHECK(rc == kErrInjected, "thread %d: rc %d for the failing shape", t, rc);
+          errors.fetch_add(1);
+          continue;
+        }
+        CHECK(rc == 0, "thread %d: rc %d", t, rc);
+        for (uint32_t i = 0; i < nq; i++) {
+          CHECK(cnt[i] == k, "thread %d: count %u != k %u", t, cnt[i], k);
+          for (uint32_t j = 0; j < k; j++) {
+            CHECK(ids[(size_t)i * k + j] == answer_id(q[i], k, j), "thread %d it %d: somebody else's ids", t, it);
+            CHECK(sc[(size_t)i * k + j] == answer_score(q[i], me.ef, j), "thread %d it %d: somebody else's scores", t, it);
+          }
+        }
+        if (rnd() % 8 == 0) std::this_thread::sleep_for(std::chrono::microseconds(rnd() % 200));  // ragged arrivals
+      }
+    });
+  for (auto& th : pool) th.join();
+  {
+    std::lock_guard<std::mutex> lk(cb.mu);
+    CHECK(cb.queue.empty(), "%zu requests left in the queue", cb.queue.size());
+    CHECK(cb.leaders == 0, "%d leader slots still held", cb.leaders);
+    CHECK(cb.calls == calls.load(), "front counted %llu calls, callers made %llu", (unsigned long long)cb.calls, (unsigned long long)calls.load());
+    CHECK(cb.queries == queries.load(), "front counted %llu queries, callers sent %llu", (unsigned long long)cb.queries,
+          (unsigned long long)queries.load());
+    CHECK(cb.launches == env.batches.load(), "launch counter %llu != launches %llu", (unsigned long long)cb.launches,
+          (unsigned long long)env.batches.load());
+    CHECK(cb.arrivals == calls.load(), "arrivals %llu != calls %llu", (unsigned long long)cb.arrivals, (unsigned long long)calls.load());
+    CHECK(cb.max_batch <= std::max<uint64_t>(mb, 4), "largest batch %llu past max_batch", (unsigned long long)cb.max_batch);
+  }
+  CHECK(env.max_in_flight.load() <= 2, "%d batches ran beside each other", env.max_in_flight.load());
+  std::printf("{\"threads\": %d, \"calls\": %llu, \"queries\": %llu, \"launches\": %llu, \"multi_call_launches\": %llu, \"largest_batch\": %llu, "
+              "\"max_in_flight\": %d, \"failed_calls\": %llu, \"ok\": %s}\n",
+              threads, (unsigned long long)calls.load(), (unsigned long long)queries.load(), (unsigned long long)cb.launches,
+              (unsigned long long)env.multi.load(), (unsigned long long)cb.max_batch, env.max_in_flight.load(),
+              (unsigned long long)errors.load(), g_fail.load() ? "false" : "true");
+  return g_fail.load() ? 1 : 0;
+}

@@ -21,47 +21,15 @@
 // the callers of the batch that just finished to come back first (at most COMBINE_WINDOW_US; see search_combined).
 // Bits: every kernel behind search_dev answers a query independently of the batch it sits in (declared arithmetic per metric and
 // mode; the tests compare single-query and batched calls bit for bit), so combining never changes a result.
-#include <linux/futex.h>
-#include <sys/syscall.h>
-#include <unistd.h>
-
-#include <chrono>
 #include <cstring>
 
+#include "vdb_combiner.hpp"
 #include "vdb_index.hpp"
 
 namespace vdb {
 
 void note_last_context(vdb_hip_index* handle, vdb_hip_index* ctx);  // index.hip
 
-constexpr uint32_t kCombineMaxCall = 64;  // larger calls fill the chip by themselves: they launch alone
-
-struct CombineReq {
-  const float* queries;
-  uint32_t nq, k, ef;
-  int32_t mode;
-  uint32_t rerank_k;
-  uint64_t* out_ids;
-  float* out_scores;
-  uint32_t* out_n;
-  enum { kQueued, kTaken } state = kQueued;           // (under Combiner::mu) still in the queue / in some leader's batch
-  enum : uint32_t { kWait = 0, kDone = 1, kLead = 2 };
-  std::atomic<uint32_t> word{kWait};                  // what its sleeping caller waits on
-  int32_t rc = VDB_OK;
-  std::string err;
-  vdb_hip_index* served_by = nullptr;
-  bool same_shape(const CombineReq& o) const { return k == o.k && ef == o.ef && mode == o.mode && rerank_k == o.rerank_k; }
-};
-
-struct Combiner {
-  std::mutex mu;
-  std::deque<CombineReq*> queue;
-  int leaders = 0;  // batches in flight
-  uint64_t arrivals = 0;          // calls ever queued (a waiting leader watches it move)
-  uint32_t last_batch_calls = 1;  // calls the batch that finished last carried: > 1 = callers are arriving together
-  uint64_t last_batch_done_at_arrival = 0;  // `arrivals` when that batch finished (its callers re-arrive behind this mark)
-  uint64_t launches = 0, calls = 0, queries = 0, max_batch = 0;
-};
 void combiner_free(Combiner* c) { delete c; }
 
 // one search of nq host queries on a leased context of `handle`; results land in ctx->h_out (the layout of reserve_out) and
@@ -155,17 +123,6 @@ static void run_batch(vdb_hip_index* handle, CombineReq* const* reqs, size_t n_r
   }
 }
 
-// Sleeping callers wait on a word of their OWN request (futex): a finished batch wakes exactly its callers, and a freed leader
-// slot wakes exactly one queued caller.  (One condition variable for everybody was the first version: every completion woke
-// every sleeper into a fight for one mutex — with 64 callers on the box's 16 cores the stragglers came back after the next
-// launch had left and the callers split into groups that took turns.)
-static void futex_wait(std::atomic<uint32_t>* w, uint32_t expect) {
-  syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAIT_PRIVATE, expect, nullptr, nullptr, 0);
-}
-static void futex_wake_one(std::atomic<uint32_t>* w) {
-  syscall(SYS_futex, reinterpret_cast<uint32_t*>(w), FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
-}
-
 // how many batches may run beside each other when this request leads one: graph walks are latency-bound (one CU per query in a
 // small call: two launches overlap for free), sweeps are bandwidth-bound (a second launch beside the first only halves both
 // batches: 16 callers on the 1 M exact sweep 26 K q/s with one batch in flight, 15 K with two)
@@ -176,118 +133,18 @@ static int leader_limit(const vdb_hip_index* handle, const CombineReq& r) {
   return walk ? 2 : 1;
 }
 
-static int32_t search_combined(vdb_hip_index* handle, Combiner* cb, CombineReq& me) {
-  const uint32_t max_batch = (uint32_t)opt_value(handle, VDB_OPT_COMBINE_MAX_BATCH);
-  const uint32_t window_us = (uint32_t)opt_value(handle, VDB_OPT_COMBINE_WINDOW_US);
-  bool lead = false;
-  {
-    std::lock_guard<std::mutex> lk(cb->mu);
-    cb->arrivals++;
-    if (cb->leaders < leader_limit(handle, me)) {
-      cb->leaders++;
-      me.state = CombineReq::kTaken;
-      lead = true;
-    } else {
-      cb->queue.push_back(&me);
-    }
+// the protocol (vdb_combiner.hpp) over a handle: its options, one launch per batch
+struct HandleFront {
+  vdb_hip_index* handle;
+  uint32_t max_batch() const { return (uint32_t)opt_value(handle, VDB_OPT_COMBINE_MAX_BATCH); }
+  uint32_t window_us() const { return (uint32_t)opt_value(handle, VDB_OPT_COMBINE_WINDOW_US); }
+  int leader_limit(const CombineReq& r) const { return vdb::leader_limit(handle, r); }
+  void run_batch(CombineReq* const* reqs, size_t n) { vdb::run_batch(handle, reqs, n); }
+  void finish(CombineReq& me) {
+    if (me.served_by) note_last_context(handle, me.served_by);
+    if (me.rc != VDB_OK) set_last_error(me.err);
   }
-  if (!lead) {
-    uint32_t w;
-    while ((w = me.word.load(std::memory_order_acquire)) == CombineReq::kWait) futex_wait(&me.word, CombineReq::kWait);
-    if (w == CombineReq::kLead) lead = true;  // a leader slot came free while this call was queued: it was handed over, taken and counted
-  }
-  if (lead) {
-    std::unique_lock<std::mutex> lk(cb->mu);
-    // my request first (the shape of the batch is mine), then every queued request of the same shape while the batch has room
-    // (room for a full batch up front: nothing below can throw once other callers' requests are in it; without the room — out of
-    // host memory — the leader runs alone)
-    std::vector<CombineReq*> batch;
-    size_t room = 1;
-    try {
-      batch.reserve(std::max<uint32_t>(max_batch, 1u));
-      room = batch.capacity();
-    } catch (const std::bad_alloc&) {
-    }
-    CombineReq* alone[1] = {&me};
-    if (room > 1) batch.push_back(&me);
-    uint32_t total = me.nq;
-    auto gather = [&] {
-      if (room <= 1) return;
-      for (auto it = cb->queue.begin(); it != cb->queue.end();) {
-        CombineReq* r = *it;
-        if (batch.size() < room && r->state == CombineReq::kQueued && r->same_shape(me) && total + r->nq <= max_batch) {
-          r->state = CombineReq::kTaken;
-          batch.push_back(r);
-          total += r->nq;
-          it = cb->queue.erase(it);
-        } else {
-          ++it;
-        }
-      }
-    };
-    gather();
-    // The callers of a finished batch come back within tens of microseconds of each other (as fast as the host wakes their
-    // threads).  A leader that launched the moment it arrived would take the one or two that beat it to the queue and leave the
-    // rest to the next launch: the callers split into groups that take turns, every call waits for the other group's launch
-    // before its own, and each launch carries half of what it could (64 callers on the exact sweep: 1.33 ms per call where one
-    // batch of 64 takes 0.6).  So a leader with EVIDENCE of company — the batch that finished last carried several calls —
-    // waits for as many arrivals as that batch had callers, at most COMBINE_WINDOW_US.  A lone caller has no such evidence
-    // (the batch before it was its own) and never waits; callers that went away cost the ones that stayed one window.
-    if (window_us && total < max_batch && cb->last_batch_calls > 1) {
-      using clk = std::chrono::steady_clock;
-      const auto t_cap = clk::now() + std::chrono::microseconds(window_us);
-      const uint64_t want = cb->last_batch_done_at_arrival + cb->last_batch_calls;  // everybody of that batch is back
-      uint64_t seen = cb->arrivals;
-      while (total < max_batch && cb->arrivals < want) {
-        lk.unlock();
-        std::this_thread::yield();
-        lk.lock();
-        if (cb->arrivals != seen) {
-          seen = cb->arrivals;
-          gather();
-        }
-        if (clk::now() >= t_cap) break;
-      }
-      gather();
-    }
-    const size_t n_calls = room > 1 ? batch.size() : 1;
-    cb->launches++;
-    cb->calls += n_calls;
-    cb->queries += total;
-    cb->max_batch = std::max<uint64_t>(cb->max_batch, total);
-    lk.unlock();
-    run_batch(handle, room > 1 ? batch.data() : alone, n_calls);
-    lk.lock();
-    cb->last_batch_calls = (uint32_t)n_calls;
-    cb->last_batch_done_at_arrival = cb->arrivals;
-    cb->leaders--;
-    // the freed slot goes to the first queued call that may lead (it takes the others of its shape with it)
-    CombineReq* next = nullptr;
-    for (auto it = cb->queue.begin(); it != cb->queue.end(); ++it)
-      if ((*it)->state == CombineReq::kQueued && cb->leaders < leader_limit(handle, **it)) {
-        next = *it;
-        cb->queue.erase(it);
-        next->state = CombineReq::kTaken;
-        cb->leaders++;
-        break;
-      }
-    lk.unlock();
-    // (a request is not touched after its word is set: its caller may be gone the next instant)
-    for (size_t i = 1; i < batch.size(); i++) {
-      std::atomic<uint32_t>* w = &batch[i]->word;
-      w->store(CombineReq::kDone, std::memory_order_release);
-      futex_wake_one(w);
-    }
-    if (next) {
-      std::atomic<uint32_t>* w = &next->word;
-      w->store(CombineReq::kLead, std::memory_order_release);
-      futex_wake_one(w);
-    }
-  }
-  if (me.served_by) note_last_context(handle, me.served_by);
-  if (me.rc != VDB_OK) set_last_error(me.err);
-  return me.rc;
-}
+};
 
 // HnswIndex::search_batch_parallel (batch.rs:159-197) / search_with_quality / search_brute_force
 static int32_t search_batch_host(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode,
@@ -309,7 +166,8 @@ static int32_t search_batch_host(vdb_hip_index* ix, const float* queries, uint32
     me.out_ids = out_ids;
     me.out_scores = out_scores;
     me.out_n = out_n;
-    return search_combined(ix, ix->combiner, me);
+    HandleFront front{ix};
+    return search_combined(front, ix->combiner, me);
   }
   return search_direct(ix, queries, nq, k, ef, mode, rerank_k, out_ids, out_scores, out_n);
 }
