@@ -1356,7 +1356,19 @@ def main():
             dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)  # every rank agrees before the first data-path collective
             ok = int(t_ok.item())
         if ok == 1:
-            join_process_group(ix_sh, rank, world, dev)
+            # a group that cannot be formed (RCCL not loadable, id exchange refused ...) must cost the sharded leg, not the line: the
+            # replica headline above needs no collective.  (The agreement below runs on torch's own group, not on the library's.)
+            try:
+                join_process_group(ix_sh, rank, world, dev)
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] joining the shard group failed: {e}", file=sys.stderr)
+                sharded["join_error"] = str(e)[:300]
+                ok = -1
+            if use_dist:
+                t_ok = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+                ok = int(t_ok.item())
+        if ok == 1:
             # self-diagnosis of the first real multi-GPU run: what every rank's handle says about itself
             inf = ix_sh.shard_info()
             mine = torch.tensor([rank, inf["world"], inf["rank"], {"none": 0, "rccl": 1, "d2d-copy": 2}.get(inf["transport"], -1),
@@ -1405,7 +1417,9 @@ def main():
                     np.array_equal(out_ids.cpu().numpy(), ref_ids) and
                     np.array_equal(out_sc.cpu().numpy().view(np.uint32), ref_sc.view(np.uint32)))
         else:
-            sharded["error"] = "shard setup failed on at least one rank (see stderr)"
+            sharded["error"] = ("shard setup failed on at least one rank (see stderr)" if ok == 0 else
+                                "the shard group could not be joined on at least one rank (see stderr / join_error)")
+            sharded["group_ok"] = False
         if ix_sh is not ix:
             ix_sh.close()
             torch.cuda.empty_cache()
