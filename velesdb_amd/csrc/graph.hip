@@ -119,7 +119,7 @@ int32_t vdb_hip_index_load_reference_files(vdb_hip_index* ix, const char* dir, c
       return fail(VDB_ERR_DIM_MISMATCH, "file dimension " + std::to_string(dim) + " != index dimension " +
                                             std::to_string(ix->dim));
     const uint64_t payload = file_size(c.f) - 16;
-    if (count > 0xFFFFFFF0ull || (dim && count > payload / ((uint64_t)dim * 4))) return fail(VDB_ERR_IO, "truncated " + vp);
+    if (count > kMaxRowsPerIndex || (dim && count > payload / ((uint64_t)dim * 4))) return fail(VDB_ERR_IO, "truncated " + vp);
     vecs.resize((size_t)count * dim);
     if (std::fread(vecs.data(), 4, vecs.size(), c.f) != vecs.size()) return fail(VDB_ERR_IO, "truncated " + vp);
   }

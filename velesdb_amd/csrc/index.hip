@@ -386,9 +386,9 @@ int32_t append_host_rows(vdb_hip_index* ix, const uint64_t* ids, const float* ve
   *first_row = ix->n_rows;
   if (inserted) *inserted = m;
   if (m == 0) return VDB_OK;
-  if (ix->n_rows + m > 0xFFFFFFF0ull) {
+  if (ix->n_rows + m > kMaxRowsPerIndex) {
     for (uint64_t id : new_ids) ix->id_to_idx.erase(id);
-    return fail(VDB_ERR_UNSUPPORTED, "more than 2^32-16 rows per index");
+    return fail(VDB_ERR_UNSUPPORTED, "more than 2^32-512 rows per index");
   }
   int32_t rc = ensure_capacity(ix, ix->n_rows + m);
   if (rc != VDB_OK) {
@@ -1450,7 +1450,7 @@ int32_t vdb_hip_index_upload_dev(vdb_hip_index* ix, uint64_t id_base, const floa
   if (n == 0) return VDB_OK;
   for (uint64_t i = 0; i < n; i++)
     if (ix->id_to_idx.count(id_base + i)) return fail(VDB_ERR_INVALID_ARG, "upload_dev: id range overlaps existing ids");
-  if (ix->n_rows + n > 0xFFFFFFF0ull) return fail(VDB_ERR_UNSUPPORTED, "more than 2^32-16 rows per index");
+  if (ix->n_rows + n > kMaxRowsPerIndex) return fail(VDB_ERR_UNSUPPORTED, "more than 2^32-512 rows per index");
   int32_t rc = ensure_capacity(ix, ix->n_rows + n);
   if (rc != VDB_OK) return rc;
   hipStream_t caller = reinterpret_cast<hipStream_t>(stream);

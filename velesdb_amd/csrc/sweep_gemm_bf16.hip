@@ -716,48 +716,8 @@ void launch_seed_tau(const uint64_t* ids, const float* scores, const uint32_t* n
 }
 
 // ---- host side -------------------------------------------------------------------------------------------
-void sweep_gemm_bf16_plan(uint32_t nq, uint32_t row_lo, uint32_t row_hi, int n_cus, Bf16GemmPlan* p) {
-  p->nqt = (nq + kG16BN - 1) / kG16BN;
-  p->qper = (nq + p->nqt - 1) / p->nqt;
-  p->row_lo = row_lo;
-  p->row_hi = row_hi;
-  const uint32_t ntiles = (row_hi - row_lo + kG16BM - 1) / kG16BM;
-  // row groups: whole XCD rounds, never more blocks than the chip holds at once (one block per CU)
-  uint32_t G = (uint32_t)std::max(8, n_cus / (int)p->nqt / 8 * 8);
-  G = std::min(G, (ntiles + 7) / 8 * 8);
-  p->G = G;
-  p->blocks = (int)(G * p->nqt);
-}
-
-void gemm_schedule(uint32_t nq, uint32_t row_first, uint32_t n, int n_cus, const uint32_t head_tiles[3], uint32_t max_launch_rows, GemmSchedule* s) {
-  s->n_launch = 0;
-  s->lists = 0;
-  const uint32_t G2 = (uint32_t)std::max(8, n_cus / (int)((nq + kG16BN - 1) / kG16BN) / 8 * 8);  // row groups the chip holds at once
-  uint32_t lo = row_first, left = (n - row_first + kG16BM - 1) / kG16BM;
-  auto push = [&](uint32_t hi) {
-    sweep_gemm_bf16_plan(nq, lo, hi, n_cus, &s->bp[s->n_launch]);
-    s->lists += s->bp[s->n_launch].G;
-    s->n_launch++;
-    lo = hi;
-  };
-  int ns = 0;
-  while (ns < 3 && head_tiles[ns]) ns++;
-  for (int j = 0; j < ns && left >= 2 * head_tiles[j] * G2; j++) {  // (the rest must be worth at least as much again)
-    uint32_t t = head_tiles[j] * G2;
-    // the launch behind this one is the last of the head: whole row tiles per row group for the rest
-    if (j == ns - 1 || left < 2 * head_tiles[j + 1] * G2) t += (left - t) % G2;
-    push(lo + t * (uint32_t)kG16BM);
-    left -= t;
-  }
-  while (lo < n) {
-    uint32_t hi = n;
-    if (max_launch_rows && (uint64_t)lo + max_launch_rows < n) {
-      hi = lo + max_launch_rows;
-      if (n - hi < max_launch_rows / 4 || s->n_launch == kGemmMaxLaunches - 1) hi = n;  // (a short tail joins the launch in front of it)
-    }
-    push(hi);
-  }
-}
+// (sweep_gemm_bf16_plan, gemm_schedule: vdb_gemm_schedule.hpp — host arithmetic only, checked on the CPU by tests/gemm_schedule_model.cpp)
+static_assert(kG16BM == (int)kGemmTileRows && kG16BN == (int)kGemmTileQueries, "the schedule's tile is the kernel's");
 
 static bool pingpong_enabled() {
   static const bool on = [] {

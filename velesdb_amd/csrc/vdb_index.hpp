@@ -273,6 +273,9 @@ struct vdb_hip_index {
 
 namespace vdb {
 static inline vdb_hip_index* primary_of(vdb_hip_index* ix) { return ix->primary ? ix->primary : ix; }
+// rows per index: the tiled kernels count whole 256-row tiles of [0, n) in 32 bits — (n + 255) / 256 must not wrap
+// (tests/gemm_schedule_model.cpp walks the launch schedule up to this limit)
+constexpr uint64_t kMaxRowsPerIndex = 0xFFFFFE00ull;  // 2^32 - 512
 // after a change to the index (exclusive lock held): search contexts refresh their views before their next search
 static inline void mark_changed(vdb_hip_index* ix) { primary_of(ix)->version++; }
 // copies the selection-image state (buffers + progress counters) of the primary into a search context

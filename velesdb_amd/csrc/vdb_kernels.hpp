@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "vdb_gemm_schedule.hpp"
+
 namespace vdb {
 
 struct SweepArgs {
@@ -191,15 +193,10 @@ hipError_t launch_sweep_gemm_bf16(int metric, const GemmPlan& p, const uint16_t*
                                   uint64_t* part_keys, uint32_t n_rows, uint32_t dim, uint32_t nq, uint32_t k,
                                   hipStream_t st);
 // bf16 GEMM-distance sweep for big batches (sweep_gemm_bf16.hip): 256 x 256 block tile, LDS-DMA staging, seeded thresholds
-struct Bf16GemmPlan {
-  uint32_t nqt, qper, G;
-  uint32_t row_lo, row_hi;  // row range of the launch (row_lo a multiple of 256)
-  int blocks;
-};
+// (struct Bf16GemmPlan, sweep_gemm_bf16_plan: vdb_gemm_schedule.hpp)
 constexpr uint32_t kGemmBf16MaxK = 10;          // candidate buffers of 12 keys per query
 constexpr uint32_t kGemmBf16MinRows = 1u << 16; // below this the 128 x 128 kernel serves the batch alone
 constexpr uint32_t kGemmBf16SeedRows = 1u << 14; // rows of the seeding pre-pass (k-th best key over a prefix of the corpus)
-void sweep_gemm_bf16_plan(uint32_t nq, uint32_t row_lo, uint32_t row_hi, int n_cus, Bf16GemmPlan* p);
 hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const uint16_t* rows16, uint64_t row_stride,
                                        const float* norms, const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride,
                                        const uint64_t* tau0, uint64_t* part_keys, uint32_t list_stride, uint32_t list_off,
@@ -209,17 +206,7 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
 // stage of index.hip, the bit metrics of bits_gemm.hip): a corpus is swept in a few launches of growing size, each starting from
 // bounds re-seeded out of everything swept before it — a block's epilogue costs ~0.2 us per candidate it has to finish, so the
 // rows swept under a weak bound are kept few.
-constexpr int kGemmMaxLaunches = 64;
-struct GemmSchedule {
-  Bf16GemmPlan bp[kGemmMaxLaunches];
-  int n_launch = 0;
-  uint32_t lists = 0;  // row groups (= partial lists per query) over all launches
-};
-// rows [row_first, n): `head_tiles[i]` (x the row groups the chip holds at once) 256-row tiles per row group for the first launches
-// (0 = none; a step is taken only while at least as much again is left), then launches of <= max_launch_rows rows (0 = one launch
-// for the rest).  A launch boundary costs one merge + re-seed (~20 us); launches longer than ~2 M rows let the query tiles of a row
-// group drift apart in L2 (10 M rows in one launch: 2.1 x the corpus from HBM).
-void gemm_schedule(uint32_t nq, uint32_t row_first, uint32_t n, int n_cus, const uint32_t head_tiles[3], uint32_t max_launch_rows, GemmSchedule* s);
+// (kGemmMaxLaunches, struct GemmSchedule, gemm_schedule: vdb_gemm_schedule.hpp)
 // the launches of a schedule: pre(j) in front of launch j, post(j, lists_written, last) behind it (the merge + re-seed between two
 // launches belongs there); partial lists land at list_first + the row groups before the launch
 template <class Pre, class Post>
