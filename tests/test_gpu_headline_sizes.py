@@ -190,3 +190,81 @@ def test_configs3_full_size_10m_bf16_vs_oracle(gpu_required):
                 assert abs(e_s[r] - g_s[r]) <= tol, (qi, r)             # a different row at this rank: a near-tie of scores
     assert differing <= 2 * len(sample) // 10 + 2, differing               # (measured: 0)
     ix.close()
+
+
+def test_configs4_shard_size_6p25m_f32_vs_oracle(gpu_required):
+    """BASELINE configs[4] is 50 M x 768 f32 range-sharded over 8 GPUs: every GPU answers the exact sweep over ITS 6 250 000 rows
+    (19.2 GB of f32 rows — 4.8e9 elements, beyond 32-bit element offsets — plus their 9.6 GB bf16 selection image), then the merge of
+    tests/test_gpu_sharded.py / test_sharded_cpu.py.  This is one shard at full size on one GPU: 1 024 cosine queries, k = 10, through
+    the default path (selection on the bf16 matrix cores, exact re-scoring, proof; HnswIndex::search_brute_force,
+    index/hnsw/index/search.rs:176-219).  The rows are generated chunk-wise on the device as bench.py's sharded leg does; every chunk
+    is copied to the host once, where the oracle scans it for 36 sampled queries, and the per-chunk lists are merged in the canonical
+    order (score descending, row ascending) — the scan an index over all rows would get.  Bar: ids AND score bits equal."""
+    torch = pytest.importorskip("torch")
+    SR, BQ, chunk, nsample = 6_250_000, 1024, 1_000_000, 32
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(4242)
+    stream = torch.cuda.current_stream().cuda_stream
+    ix = va.HnswIndex(D, DM.Cosine, va.HnswParams(16, 100, SR))
+    gq = torch.Generator(device=dev)
+    gq.manual_seed(47)
+    qs = torch.randn((BQ, D), generator=gq, device=dev).cpu().numpy()
+    sample = np.unique(np.concatenate([[0, 255, 256, 1023], np.random.default_rng(8).integers(0, BQ, nsample)]))
+    mode = po.MODE_M if ix.sweep_arith_mode(K) == "M" else po.MODE_C
+    best_i = np.empty((len(sample), 0), np.int64)
+    best_s = np.empty((len(sample), 0), np.float32)
+    nt = po.host_threads()
+    for base in range(0, SR, chunk):
+        n_c = min(chunk, SR - base)
+        c = torch.randn((n_c, D), generator=g, device=dev)
+        torch.cuda.synchronize()
+        ix.upload_dev(base, c.data_ptr(), n_c, stream)
+        torch.cuda.synchronize()
+        host = c.cpu().numpy()
+        del c
+        ei, es = po.scan_topk(po.COSINE, host, qs[sample], K, mode, nthreads=nt)
+        del host
+        best_i = np.concatenate([best_i, ei.astype(np.int64) + base], axis=1)
+        best_s = np.concatenate([best_s, es], axis=1)
+        order = np.lexsort((best_i, -best_s.astype(np.float64)), axis=1)[:, :K]   # score descending, row ascending
+        best_i = np.take_along_axis(best_i, order, axis=1)
+        best_s = np.take_along_axis(best_s, order, axis=1)
+    assert ix.len() == SR
+    gi, gs, gc = ix.search_batch_brute_force(qs, K)
+    assert ix.last_select_level() == 2, "the selection stage did not serve the 6.25 M-row batch"
+    assert np.all(gc == K)
+    assert np.array_equal(gi[sample].astype(np.int64), best_i), "ids / ranks differ from the oracle's scan of the same rows"
+    assert np.array_equal(bits(gs[sample]), bits(best_s)), "score bits differ from the oracle's"
+    # the other exact kernels over the same 4.8e9 elements, same bits: the GEMM-structured exact f32 kernel (selection switched off,
+    # 72 queries), the small-batch streaming kernel (4 queries) and a single query
+    ix.set_option(va.OPT_SELECTOR_LEVEL, 0)
+    q72 = np.concatenate([qs[sample], qs[sample]])
+    i72, s72, _ = ix.search_batch_brute_force(q72, K)
+    ix.set_option(va.OPT_SELECTOR_LEVEL, -1)
+    assert ix.last_select_level() == 0
+    both = np.concatenate([best_i, best_i]), np.concatenate([best_s, best_s])
+    assert np.array_equal(i72.astype(np.int64), both[0]) and np.array_equal(bits(s72), bits(both[1]))
+    i4, s4, _ = ix.search_batch_brute_force(qs[sample[:4]], K)
+    assert np.array_equal(i4.astype(np.int64), best_i[:4]) and np.array_equal(bits(s4), bits(best_s[:4]))
+    i1, s1, _ = ix.search_batch_brute_force(qs[sample[5]], K)
+    assert np.array_equal(i1.astype(np.int64)[0], best_i[5]) and np.array_equal(bits(s1)[0], bits(best_s)[5])
+    # every query, not only the sampled ones: ordered, distinct, inside the shard
+    assert np.all(np.diff(gs.astype(np.float64), axis=1) <= 0) and np.all(gi < SR)
+    assert all(len(set(r.tolist())) == K for r in gi)
+    # the last rows of the shard (beyond 2^32 elements) are reachable: a query equal to one of them finds it first
+    tail_rows = [SR - 1, SR - 257, 5_600_000]
+    g2 = torch.Generator(device=dev)
+    g2.manual_seed(4242)
+    probe = np.empty((len(tail_rows), D), np.float32)
+    for base in range(0, SR, chunk):  # regenerate the stream: the same chunks, only the wanted rows kept
+        n_c = min(chunk, SR - base)
+        c = torch.randn((n_c, D), generator=g2, device=dev)
+        for j, r in enumerate(tail_rows):
+            if base <= r < base + n_c:
+                probe[j] = c[r - base].cpu().numpy()
+        del c
+    pi, ps, _ = ix.search_batch_brute_force(np.repeat(probe, 6, axis=0), K)   # 18 queries: the selection stage again (>= 16)
+    assert [int(pi[6 * j, 0]) for j in range(len(tail_rows))] == tail_rows
+    assert np.all(np.abs(ps[::6, 0] - 1.0) < 1e-6)
+    ix.close()
