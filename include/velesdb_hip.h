@@ -120,7 +120,8 @@ enum vdb_shard_mode {
  * device and every entry point below works on the whole; results (ids, ranks, score bits, tie order) of the exact
  * search modes are those of the single-device index over the same rows.  The same device may be named more than once
  * (co-located shards: the exchange is then a device-to-device copy instead of RCCL — a test configuration).
- * HNSW modes on a VDB_SHARD_RANGE handle search one graph per shard and merge (recall differs from one big graph). */
+ * HNSW modes on a VDB_SHARD_RANGE handle search one graph per shard and merge (recall differs from one big graph).
+ * A single-device index (one shard) holds at most 2^32 - 512 rows: inserts past that answer VDB_ERR_UNSUPPORTED. */
 int32_t vdb_hip_index_create(uint32_t dim, int32_t metric, uint32_t M, uint32_t ef_construction,
                              uint64_t max_elements, const int32_t* devices, int32_t n_devices, int32_t shard_mode,
                              vdb_hip_index** out);
