@@ -1,0 +1,35 @@
+#!/bin/bash
+# LDS-array and vector-memory-path counters of the headline step's selection kernel (sweep_topk_gemm_bf16_pp): is the array as busy
+# as DESIGN 4.1c's arithmetic says (~50-60 % at a full matrix pipe), and do the LDS-DMA requests queue in front of the texture
+# addresser?  Separate --pmc passes of bench.py's headline child (kernel-trace only), each under its own short timeout.
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/${TAG:-r04pmc}
+mkdir -p $O
+cd /tmp
+run() {
+  timeout ${T:-28} rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $O/$1 -- python $R/bench.py --pmc-child headline --steps 3 --warmup 1 > $O/$1.log 2>&1
+  echo "$1 rc=$?"
+  find $O/$1 -name "*_kernel_trace.csv" -size +4M -delete
+}
+run lds  "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_BUSY_CU_CYCLES"
+run vmem "SQ_ACTIVE_INST_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_BUSY_CU_CYCLES"
+run lvl  "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES"
+python - <<PY > $O/summary.txt 2>&1
+import csv, glob, collections
+for p in ("lds", "vmem", "lvl"):
+    fs = glob.glob("$O/%s/**/*counter_collection.csv" % p, recursive=True)
+    if not fs:
+        print(p, "no counter file"); continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+    for r in csv.DictReader(open(fs[0])):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        n[(k, r["Counter_Name"])] += 1
+    for k, cs in sorted(acc.items(), key=lambda kv: -max(kv[1].values())):
+        if "sweep_topk" not in k and "seed_scores" not in k and "split_rerank" not in k and "merge_topk" not in k:
+            continue
+        d = max(n[(k, c)] for c in cs)
+        print(p, k[:60], "dispatches", d, " ".join(f"{c}={v / d:.4g}" for c, v in sorted(cs.items())))
+PY
+cat $O/summary.txt | head -40
