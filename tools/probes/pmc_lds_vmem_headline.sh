@@ -12,12 +12,19 @@ run() {
   echo "$1 rc=$?"
   find $O/$1 -name "*_kernel_trace.csv" -size +4M -delete
 }
-run lds  "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_BUSY_CU_CYCLES"
-run vmem "SQ_ACTIVE_INST_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_BUSY_CU_CYCLES"
-run lvl  "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES"
+# PASSES="name:COUNTER COUNTER ...;name:..." (default: the LDS / vector-memory passes)
+PASSES=${PASSES:-"lds:SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_BUSY_CU_CYCLES;vmem:SQ_ACTIVE_INST_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_BUSY_CU_CYCLES;lvl:SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES"}
+IFS=';' read -ra PL <<< "$PASSES"
+NAMES=""
+for p in "${PL[@]}"; do
+  run "${p%%:*}" "${p#*:}"
+  NAMES="$NAMES ${p%%:*}"
+done
+export NAMES
 python - <<PY > $O/summary.txt 2>&1
 import csv, glob, collections
-for p in ("lds", "vmem", "lvl"):
+import os
+for p in os.environ["NAMES"].split():
     fs = glob.glob("$O/%s/**/*counter_collection.csv" % p, recursive=True)
     if not fs:
         print(p, "no counter file"); continue
@@ -31,5 +38,9 @@ for p in ("lds", "vmem", "lvl"):
             continue
         d = max(n[(k, c)] for c in cs)
         print(p, k[:60], "dispatches", d, " ".join(f"{c}={v / d:.4g}" for c, v in sorted(cs.items())))
+    for r in csv.DictReader(open(glob.glob("$O/%s/**/*kernel_trace.csv" % p, recursive=True)[0])):
+        if "gemm_bf16_pp" in r["Kernel_Name"]:
+            acc["dur"][r["Kernel_Name"].split("(")[0]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    print(p, "total us of the pp dispatches:", {k: round(v, 1) for k, v in acc["dur"].items()})
 PY
 cat $O/summary.txt | head -40
