@@ -96,6 +96,9 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # multi-process GPU work on this pool needs dmabuf IPC; the runtime reads the variable when it initialises (the first HIP call
+    # below), so it is set before torch is imported, not next to init_process_group
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch  # first: the HIP runtime it loads is the one libvelesdb_hip.so binds to
     import torch.distributed as dist
     import numpy as np
@@ -150,7 +153,6 @@ def main():
     dev = torch.device("cuda", local)
     use_dist = world > 1 or a.dist_single
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
