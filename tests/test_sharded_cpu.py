@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests (CPU) of the one-process-per-GPU composition: what the launcher side owns
+"""world_size-2 (and 4 / 8) gloo tests (CPU) of the one-process-per-GPU composition: what the launcher side owns
 (velesdb_amd/sharded.py: the wire record of the all-gather, the query split of replica mode) plus the merge rule the HIP
 kernel implements (restated in the oracle, vo_merge_shard_records).  Range-sharded exact search = per-shard top-k + ONE
 all-gather of packed 12-byte records + merge must equal the exact top-k over the whole corpus, ties included.  The
@@ -81,6 +81,20 @@ def test_range_sharded_topk_world2(metric, hib, n, dim, k):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, metric, hib, n, dim, 17, k, 1234, out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)
+
+
+@pytest.mark.parametrize("world,metric,hib,n,dim,k", [
+    (4, po.COSINE, True, 3000, 64, 10),
+    (8, po.HAMMING, False, 4000, 64, 10),   # BASELINE configs[4]'s shard count; integer distances tie across all eight shards
+    (8, po.DOT, True, 25, 16, 10),          # every shard holds 3-4 rows < k: the merged list is assembled from eight short ones
+])
+def test_range_sharded_topk_world4_and_8(world, metric, hib, n, dim, k):
+    """The same composition at the rank counts the scaling run uses (north_star: 1 / 2 / 4 / 8 GPUs)."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, metric, hib, n, dim, 17, k, 4321, out), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world)), dict(out)
 
 
