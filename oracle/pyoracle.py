@@ -136,6 +136,7 @@ def _declare(L):
     _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
     L.vo_sq_train.restype, L.vo_sq_train.argtypes = None, [_f32p, C.c_uint64, C.c_uint32, _f32p, _f32p, _f32p]
     L.vo_sq_quantize.restype, L.vo_sq_quantize.argtypes = None, [_f32p, C.c_uint64, C.c_uint32, _f32p, _f32p, _u8p]
+    L.vo_sq_l2.restype, L.vo_sq_l2.argtypes = C.c_uint32, [_u8p, _u8p, C.c_uint32]
     L.vo_dual_search_int8.restype = C.c_uint32
     L.vo_dual_search_int8.argtypes = [vp, _u8p, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, _u64p,
                                       _f32p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -349,6 +350,19 @@ class ScalarQuantizer:
         out = np.empty(r.shape, dtype=np.uint8)
         lib().vo_sq_quantize(r, r.shape[0], self.dim, self.min_vals, self.scales, out)
         return out
+
+
+    def dequantize(self, codes):
+        """quantization.rs:255-268: code * inv_scale + min"""
+        c = np.ascontiguousarray(codes, dtype=np.uint8).reshape(-1, self.dim)
+        return c.astype(np.float32) * self.inv_scales[None, :] + self.min_vals[None, :]
+
+    def distance_l2_quantized(self, a, b) -> int:
+        """quantization.rs:42-91 (scalar and SIMD forms agree: integer arithmetic): sum of squared code differences"""
+        a = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1)
+        b = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1)
+        assert a.size == self.dim and b.size == self.dim
+        return int(lib().vo_sq_l2(a, b, self.dim))
 
 
 def dual_search_int8(graph, sq, codes, q, k, ef, oversampling=4, tie=TIE_CANONICAL):
