@@ -69,6 +69,7 @@ def _declare(L):
     L.vo_higher_is_better.restype, L.vo_higher_is_better.argtypes = C.c_int, [C.c_int]
     L.vo_ef_search.restype, L.vo_ef_search.argtypes = C.c_uint64, [C.c_int, C.c_uint64, C.c_uint64]
     L.vo_total_cmp.restype, L.vo_total_cmp.argtypes = C.c_int, [C.c_float, C.c_float]
+    L.vo_sort_results.restype, L.vo_sort_results.argtypes = None, [C.c_int, _u64p, _f32p, C.c_uint64]
     L.vo_xorshift64_next.restype, L.vo_xorshift64_next.argtypes = C.c_uint64, [C.POINTER(C.c_uint64)]
     L.vo_random_layer.restype, L.vo_random_layer.argtypes = C.c_uint32, [C.POINTER(C.c_uint64), C.c_double]
     L.vo_heap_order_after_pushes.restype = None
@@ -280,6 +281,18 @@ def ef_search(quality, k, custom=0):
 
 def total_cmp(a, b):
     return int(lib().vo_total_cmp(float(a), float(b)))
+
+
+def sort_results(metric, results):
+    """DistanceMetric::sort_results (core/distance.rs:95-103) on a list of (id, score): stable, direction by metric"""
+    ids = np.array([r[0] for r in results], dtype=np.uint64)
+    sc = np.array([r[1] for r in results], dtype=np.float32)
+    lib().vo_sort_results(metric, ids, sc, len(results))
+    return list(zip(ids.tolist(), sc.tolist()))
+
+
+def higher_is_better(metric) -> bool:
+    return bool(lib().vo_higher_is_better(metric))
 
 
 def random_layers(n, M, seed=0x5DEECE66D1A4B5B5):

@@ -1266,6 +1266,16 @@ float vo_transform_score(int metric, float d) { return transform_score(metric, d
 int vo_higher_is_better(int metric) { return higher_is_better(metric) ? 1 : 0; }
 uint64_t vo_ef_search(int quality, uint64_t custom, uint64_t k) { return ef_search(quality, custom, k); }
 int vo_total_cmp(float a, float b) { return total_cmp(a, b); }
+// DistanceMetric::sort_results (core/distance.rs:95-103) on caller-supplied (id, score) pairs, in place
+void vo_sort_results(int metric, uint64_t* ids, float* scores, uint64_t n) {
+  std::vector<std::pair<uint64_t, float>> r(n);
+  for (uint64_t i = 0; i < n; i++) r[i] = {ids[i], scores[i]};
+  sort_results(metric, r);
+  for (uint64_t i = 0; i < n; i++) {
+    ids[i] = r[i].first;
+    scores[i] = r[i].second;
+  }
+}
 
 uint64_t vo_xorshift64_next(uint64_t* state) { return xorshift_next(*state); }
 uint32_t vo_random_layer(uint64_t* state, double level_mult) { return random_layer(*state, level_mult); }

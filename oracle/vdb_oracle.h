@@ -79,9 +79,10 @@ void vo_batch_distance(int metric, int mode, const float* q, const float* rows, 
 void vo_batch_compute_distance(int metric, int mode, const float* q, const float* rows,
                                size_t nrows, size_t dim, float* out);
 float vo_transform_score(int metric, float raw_distance); /* backend_adapter.rs:160-168 */
-int vo_higher_is_better(int metric);                      /* distance.rs:76-82 */
 uint64_t vo_ef_search(int quality, uint64_t custom, uint64_t k); /* params.rs:309-319 */
 int vo_total_cmp(float a, float b);                       /* f32::total_cmp */
+void vo_sort_results(int metric, uint64_t* ids, float* scores, uint64_t n); /* DistanceMetric::sort_results, distance.rs:95-103 (stable) */
+int vo_higher_is_better(int metric);                      /* distance.rs:76-82 */
 
 /* ---- level RNG (graph.rs:368-403) ---- */
 uint64_t vo_xorshift64_next(uint64_t* state); /* returns new state */
