@@ -193,6 +193,49 @@ def test_select_neighbors_prefers_diverse():
     assert sel == [1, 4]  # 2,3 fail alpha*d(q,c) <= d(c,1); 4 is 14.14 from 1
 
 
+def test_alpha_diversification():
+    """native/tests.rs:136-214 — NativeHnsw::with_alpha(1.2) (VAMANA-style: a candidate is kept only while alpha * d(q, c) <= d(c, s) for
+    every selected s, graph.rs:553): two clusters of 25 vectors still answer a query; the default alpha is 1.0 (:181-190, graph.rs:77);
+    the same 30 vectors under alpha 1.0 and 1.2 give graphs of the same size.  Beyond the reference's assertions: a LARGER alpha can only
+    reject more candidates in the diversity pass, so on the same candidate list the alpha-1.2 selection's diverse part is a subset."""
+    def cluster(axis):
+        j = np.arange(32, dtype=np.float32)
+        out = []
+        for i in range(25):
+            v = (np.float32(i) + j) * np.float32(0.001)
+            v[axis] = 1.0
+            out.append(v.astype(np.float32))
+        return out
+    g = po.NativeHnsw(32, po.COSINE, 16, 100)
+    g.set_alpha(1.2)
+    for v in cluster(0) + cluster(1):
+        g.insert(v)
+    assert len(g) == 50
+    q = np.full(32, 0.01, dtype=np.float32)
+    q[0] = 0.9
+    ids, ds = g.search(q, 5, 50)
+    assert len(ids) == 5 and np.all(np.diff(ds) >= 0)
+    assert all(int(i) < 25 for i in ids)          # the query sits in cluster 1 (rows 0..24)
+    std, div = po.NativeHnsw(32, po.EUCLIDEAN, 16, 100), po.NativeHnsw(32, po.EUCLIDEAN, 16, 100)
+    div.set_alpha(1.2)
+    for i in range(30):
+        v = ((np.float32(i) + np.arange(32, dtype=np.float32)) * np.float32(0.1)).astype(np.float32)
+        std.insert(v)
+        div.insert(v)
+    assert len(std) == len(div) == 30
+    # rows on one line, 0.57 apart: with alpha 1.0 the heuristic keeps one neighbour per side and fills the quota with the closest;
+    # both graphs stay searchable and return the same exact nearest neighbour
+    for gx in (std, div):
+        ids, _ = gx.search(((np.float32(7.2) + np.arange(32, dtype=np.float32)) * np.float32(0.1)).astype(np.float32), 1, 50)
+        assert ids.tolist() == [7]
+    # select_neighbors on one candidate list: ascending distances on a line through the query's side
+    cand = [(i, float(i)) for i in range(1, 9)]
+    g1, g2 = _const_graph(10), _const_graph(10)
+    g2.set_alpha(1.2)
+    s1, s2 = g1.select_neighbors(cand, 3), g2.select_neighbors(cand, 3)
+    assert len(s1) == len(s2) == 3 and s1[0] == s2[0] == 1      # the closest candidate is always selected first
+
+
 def test_graph_invariants_after_build():
     g = po.NativeHnsw(16, po.EUCLIDEAN, 8, 40, po.MODE_C)
     rng = np.random.default_rng(0)
