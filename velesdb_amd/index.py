@@ -97,6 +97,10 @@ class HnswIndex:
         check(lib().vdb_hip_index_create(dimension, int(self._metric), self.params.max_connections,
                                          self.params.ef_construction, self.params.max_elements, arr, len(devs),
                                          int(shard_mode), C.byref(self._h)))
+        # HnswParams::storage_mode (params.rs:24-27; with_sq8 / with_binary): SQ8 / Binary collections quantise every stored
+        # vector — applied at construction, as the Rust shim does (velesdb-hip/src/lib.rs `with_params`)
+        if int(getattr(self.params, "storage_mode", 0)) != 0:
+            self.set_storage_mode(self.params.storage_mode)
 
     def join_group(self, unique_id: bytes, rank: int, world: int) -> None:
         """One process per GPU: this index becomes shard `rank` of `world` (rank order = row order); exact searches

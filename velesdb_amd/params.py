@@ -18,12 +18,25 @@ class DistanceMetric(enum.IntEnum):
         return self in (DistanceMetric.Cosine, DistanceMetric.DotProduct, DistanceMetric.Jaccard)
 
 
+class StorageMode(enum.IntEnum):
+    """core/quantization.rs:17-29"""
+    Full = 0
+    SQ8 = 1
+    Binary = 2
+
+
 @dataclass(frozen=True)
 class HnswParams:
-    """params.rs:14-28 (storage_mode is out of scope: Full only)."""
+    """params.rs:14-28.  `storage_mode`: in the reference the collection layer acts on it (collection/core/crud.rs:66-82 quantises every
+    upserted vector); here the index constructor does (`HnswIndex.__init__` -> set_storage_mode), like the Rust shim."""
     max_connections: int
     ef_construction: int
     max_elements: int = 100_000
+    storage_mode: StorageMode = StorageMode.Full
+
+    @staticmethod
+    def default() -> "HnswParams":  # params.rs:28-32 (impl Default): auto(768)
+        return HnswParams.auto(768)
 
     @staticmethod
     def auto(dimension: int) -> "HnswParams":  # params.rs:41-57
@@ -41,6 +54,10 @@ class HnswParams:
         return HnswParams(64, 800, 1_500_000) if small else HnswParams(128, 1600, 1_500_000)
 
     @staticmethod
+    def large_dataset(dimension: int) -> "HnswParams":  # params.rs:149-151
+        return HnswParams.for_dataset_size(dimension, 500_000)
+
+    @staticmethod
     def million_scale(dimension: int) -> "HnswParams":  # params.rs:155-157
         return HnswParams.for_dataset_size(dimension, 1_000_000)
 
@@ -51,6 +68,32 @@ class HnswParams:
     @staticmethod
     def turbo() -> "HnswParams":  # params.rs:189-197
         return HnswParams(12, 100, 100_000)
+
+    @staticmethod
+    def high_recall(dimension: int) -> "HnswParams":  # params.rs:201-208: auto + (8, 200)
+        b = HnswParams.auto(dimension)
+        return HnswParams(b.max_connections + 8, b.ef_construction + 200, b.max_elements)
+
+    @staticmethod
+    def max_recall(dimension: int) -> "HnswParams":  # params.rs:212-233
+        if dimension <= 256:
+            return HnswParams(32, 500, 100_000)
+        return HnswParams(48, 800, 100_000) if dimension <= 768 else HnswParams(64, 1000, 100_000)
+
+    @staticmethod
+    def fast_indexing(dimension: int) -> "HnswParams":  # params.rs:237-244: auto halved, M >= 8
+        b = HnswParams.auto(dimension)
+        return HnswParams(max(b.max_connections // 2, 8), b.ef_construction // 2, b.max_elements)
+
+    @staticmethod
+    def with_sq8(dimension: int) -> "HnswParams":  # params.rs:263-268
+        b = HnswParams.auto(dimension)
+        return HnswParams(b.max_connections, b.ef_construction, b.max_elements, StorageMode.SQ8)
+
+    @staticmethod
+    def with_binary(dimension: int) -> "HnswParams":  # params.rs:271-276
+        b = HnswParams.auto(dimension)
+        return HnswParams(b.max_connections, b.ef_construction, b.max_elements, StorageMode.Binary)
 
     @staticmethod
     def custom(max_connections: int, ef_construction: int, max_elements: int) -> "HnswParams":  # :248-259
@@ -74,15 +117,19 @@ class SearchQuality:
     def __repr__(self):
         return f"SearchQuality.{self.kind}" + (f"({self.ef})" if self.kind == "custom" else "")
 
+    def __eq__(self, other):  # #[derive(PartialEq, Eq)]: Custom(a) == Custom(b) iff a == b
+        return isinstance(other, SearchQuality) and (self.kind, self.ef if self.kind == "custom" else 0) == \
+            (other.kind, other.ef if other.kind == "custom" else 0)
+
+    def __hash__(self):
+        return hash((self.kind, self.ef if self.kind == "custom" else 0))
+
+    @staticmethod
+    def default() -> "SearchQuality":  # #[default] Balanced (params.rs:289-292)
+        return SearchQuality.Balanced
+
 
 SearchQuality.Fast = SearchQuality("fast")
 SearchQuality.Balanced = SearchQuality("balanced")
 SearchQuality.Accurate = SearchQuality("accurate")
 SearchQuality.Perfect = SearchQuality("perfect")
-
-
-class StorageMode(enum.IntEnum):
-    """core/quantization.rs:17-29"""
-    Full = 0
-    SQ8 = 1
-    Binary = 2
