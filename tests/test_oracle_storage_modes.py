@@ -166,3 +166,21 @@ def test_scan_topk_storage_modes_small():
         d = np.array([qb.hamming_distance(c) for c in bc])
         order = np.lexsort((np.arange(200), d))[:7]
         assert ids[qi].tolist() == order.tolist() and sc[qi].tolist() == d[order].astype(np.float32).tolist()
+
+
+def test_recall_accuracy_high_dimension():
+    """quantization_tests.rs:296-355 — 100 x 768 vectors ((7 i + 13 j) mod 1000) / 1000 * 2 - 1, query = vector 0, dot product: the
+    top-10 over the SQ8 codes overlaps the f32 top-10 in >= 8 ids (here through the scan the GPU's SQ8 sweep is bit-compared with)"""
+    i = np.arange(100, dtype=np.int64)[:, None]
+    j = np.arange(768, dtype=np.int64)[None, :]
+    vectors = (((i * 7 + j * 13) % 1000).astype(np.float32) / np.float32(1000.0) * np.float32(2.0) - np.float32(1.0)).astype(np.float32)
+    q = vectors[0]
+    f32_scores = np.array([po.dot(q, v, po.MODE_SCALAR) for v in vectors], dtype=np.float64)
+    f32_top = set(np.argsort(-f32_scores, kind="stable")[:10].tolist())
+    ids, sc = po.scan_topk_sq8(po.DOT, vectors, q, 10)
+    recall = len(f32_top & set(ids[0].tolist())) / 10.0
+    assert recall >= 0.8, recall
+    assert np.all(np.diff(sc[0]) <= 0) and ids[0, 0] == 0     # the query's own code scores highest
+    # the per-pair function the reference's test calls (dot_product_quantized, quantization.rs:322-345) gives the same ranking
+    pair = np.float32([po.dot_product_quantized(q, po.QuantizedVector.from_f32(v)) for v in vectors])
+    assert len(f32_top & set(np.argsort(-pair.astype(np.float64), kind="stable")[:10].tolist())) >= 8
