@@ -105,3 +105,24 @@ def test_jaccard_threshold_form():
     assert abs(po.jaccard(sa.astype(F), sb.astype(F)) - exact) < 1e-4
     # the count form the GPU's packed-bit path uses (|a & b| / |a | b| in f32) is the same number to the last bit
     assert po.jaccard(sa.astype(F), sb.astype(F)) == float(F(np.count_nonzero(sa & sb)) / F(np.count_nonzero(sa | sb)))
+
+
+def test_jaccard_fast_aligned_unaligned_and_every_length():
+    """simd_tests.rs:326-412 (`jaccard_similarity_fast`, the entry point the engine calls): 768-d patterns stay within [0, 1]; an
+    8-aligned and a 67-long vector give 32 / 48 and 30 / 40; the modular patterns at 13 lengths (7 .. 768) equal the counted ratio —
+    exactly: numerator and denominator are small integers, the quotient is one f32 division"""
+    i = np.arange(768)
+    r = po.jaccard((i % 2 == 0).astype(F), (i % 3 == 0).astype(F))              # :326-339
+    assert 0.0 <= r <= 1.0 and r == float(F(128) / F(512))
+    i = np.arange(64)
+    assert abs(po.jaccard((i < 32).astype(F), (i < 48).astype(F)) - 32.0 / 48.0) < EPS    # :342-355
+    i = np.arange(67)
+    assert abs(po.jaccard((i < 30).astype(F), (i < 40).astype(F)) - 30.0 / 40.0) < EPS    # :358-371 (remainder handling)
+    for dim in (7, 8, 15, 16, 31, 32, 63, 64, 127, 128, 255, 256, 768):         # :374-412
+        i = np.arange(dim)
+        sa, sb = (i * 7) % 11 < 6, (i * 5) % 9 < 5
+        inter, union = np.count_nonzero(sa & sb), np.count_nonzero(sa | sb)
+        exp = 1.0 if union == 0 else float(F(inter) / F(union))
+        assert po.jaccard(sa.astype(F), sb.astype(F)) == exp, dim
+        assert po.distance(po.JACCARD, sa.astype(F), sb.astype(F), po.MODE_R) == float(F(1.0) - F(exp))   # engine distance = 1 - similarity
+
