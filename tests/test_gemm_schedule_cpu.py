@@ -28,7 +28,9 @@ def test_every_schedule_covers_every_tile_exactly_once(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-Wall", "-Wextra",
                            "-Werror", "-I", os.path.join(ROOT, "velesdb_amd", "csrc"), "-o", exe,
                            os.path.join(ROOT, "tests", "gemm_schedule_model.cpp")])
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=280, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    env.pop("LD_PRELOAD", None)   # the binary links its own sanitizer runtime
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=280, env=env)
     assert r.returncode == 0, r.stderr[-4000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["ok"] and line["violations"] == 0

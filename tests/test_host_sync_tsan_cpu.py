@@ -38,6 +38,7 @@ def model(tmp_path_factory):
 @pytest.mark.timeout(300)
 def test_protocol_is_race_free_and_every_caller_gets_its_own_answer(model, threads, iters, max_batch, window_us, launch_us):
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66 second_deadlock_stack=1")
+    env.pop("LD_PRELOAD", None)   # (tools/oracle_sanitize.sh preloads ASan for the oracle: a TSan binary cannot start under it)
     r = subprocess.run([model, str(threads), str(iters), str(max_batch), str(window_us), str(launch_us)], env=env, capture_output=True,
                        text=True, timeout=280)
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
@@ -67,6 +68,7 @@ def test_handle_lock_excludes_writers_shares_readers_and_does_not_starve_inserts
     searches arrive back to back (measured here: 12-15 ms worst; with the readers' step-aside removed: 229 ms and 140 x fewer
     inserts).  The reference's lock: parking_lot::RwLock, index/hnsw/index/search.rs:80."""
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    env.pop("LD_PRELOAD", None)
     r = subprocess.run([mutex_model, str(readers), str(writers), "1.0", "150"], env=env, capture_output=True, text=True, timeout=100)
     assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
