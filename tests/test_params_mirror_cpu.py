@@ -5,7 +5,7 @@ CPU only; pure host logic."""
 import pytest
 
 from oracle import pyoracle as po
-from velesdb_amd.params import HnswParams, SearchQuality, StorageMode
+from velesdb_amd.params import DualPrecisionConfig, HnswParams, SearchQuality, StorageMode
 
 # (constructor, args, (max_connections, ef_construction, max_elements or None), params_tests.rs lines)
 PRESETS = [
@@ -84,3 +84,57 @@ def test_search_quality_default_and_equality():
     assert SearchQuality.Perfect != SearchQuality.Accurate and SearchQuality.Custom(128) != SearchQuality.Balanced
     assert len({SearchQuality.Fast, SearchQuality("fast"), SearchQuality.Custom(3), SearchQuality.Custom(3)}) == 2
     assert HnswParams.custom(32, 400, 50_000) == HnswParams(32, 400, 50_000, StorageMode.Full)   # :213-218
+
+
+def test_dual_precision_config_defaults_and_rule():
+    """native/dual_precision_tests.rs:337-342 (defaults 4 / true / 10 000) and the rule of search_with_config
+    (dual_precision.rs:259-278) that decides between the int8 traversal and the plain f32 search — which is why the reference's own
+    200- and 500-vector tests of "int8 traversal" are answered by `inner.search` (tests/test_oracle_dual_precision.py)"""
+    c = DualPrecisionConfig()
+    assert (c.oversampling_ratio, c.use_int8_traversal, c.min_index_size, c.debug_timings) == (4, True, 10_000, False)
+    assert c.takes_int8_traversal(True, 10_000) and c.takes_int8_traversal(True, 1_000_000)
+    assert not c.takes_int8_traversal(True, 9_999) and not c.takes_int8_traversal(True, 200)     # below min_index_size
+    assert not c.takes_int8_traversal(False, 1_000_000)                                           # no trained quantiser
+    assert not DualPrecisionConfig(use_int8_traversal=False).takes_int8_traversal(True, 1_000_000)
+    assert DualPrecisionConfig(min_index_size=0).takes_int8_traversal(True, 1)
+
+
+def test_search_with_config_dispatches_by_the_rule():
+    """The mirror's HnswIndex.search_with_config sends the call to the int8 mode or to the plain graph mode by that rule and sets the
+    oversampling option — checked on the method itself with the C ABI stubbed out (the modes behind it: tests/test_gpu_int8.py)."""
+    import numpy as np
+    import velesdb_amd.index as vi
+
+    calls = []
+
+    class Stub(vi.HnswIndex):
+        def __init__(self, n, trained):               # no handle: nothing below reaches the library
+            self._dimension, self._n = 4, n
+            if trained:
+                self._quantizer_trained = True
+
+        def len(self):
+            return self._n
+
+        def set_option(self, option, value):
+            calls.append(("option", option, value))
+
+        def _search_raw(self, queries, k, ef, mode):
+            calls.append(("search", k, ef, mode))
+            return (np.array([[7] * k], dtype=np.uint64), np.array([[0.5] * k], dtype=np.float32), np.array([k], dtype=np.uint32))
+
+        def close(self):
+            pass
+
+    q = [0.0, 1.0, 0.0, 0.0]
+    assert Stub(200, True).search_with_config(q, 2, 50) == [(7, 0.5), (7, 0.5)]
+    assert calls == [("search", 2, 50, vi.MODE_HNSW)]                                             # 200 < min_index_size: f32 search
+    calls.clear()
+    Stub(20_000, True).search_with_config(q, 3, 64, DualPrecisionConfig(oversampling_ratio=8))
+    assert calls == [("option", vi.OPT_INT8_OVERSAMPLING, 8), ("search", 3, 64, vi.MODE_HNSW_INT8)]
+    calls.clear()
+    Stub(20_000, False).search_with_config(q, 3, 64)
+    assert calls == [("search", 3, 64, vi.MODE_HNSW)]                                             # quantiser never trained
+    with pytest.raises(AssertionError, match="dimension mismatch"):
+        Stub(20_000, True).search_with_config([0.0, 1.0], 3, 64)
+

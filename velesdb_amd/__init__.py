@@ -12,7 +12,7 @@ from .index import (GpuAccelerator, HipDistance, HnswIndex, NativeHnswIndex, MOD
 from .index import (KERNEL_BITS, KERNEL_BITS_GEMM, KERNEL_GEMM_BF16, KERNEL_GEMM_BF16_GLDS, KERNEL_GEMM_F32, KERNEL_HNSW, KERNEL_HNSW_INT8,  # noqa: F401
                     KERNEL_SELECT_BF16, KERNEL_SELECT_SPLIT, KERNEL_SQ8, KERNEL_SWEEP_MFMA_BF16, KERNEL_SWEEP_MFMA_F32,
                     KERNEL_SWEEP_VALU)
-from .params import DistanceMetric, HnswParams, SearchQuality, StorageMode  # noqa: F401
+from .params import DistanceMetric, DualPrecisionConfig, HnswParams, SearchQuality, StorageMode  # noqa: F401
 
-__all__ = ["HnswIndex", "NativeHnswIndex", "HipDistance", "GpuAccelerator", "DistanceMetric", "HnswParams", "SearchQuality", "StorageMode",
+__all__ = ["HnswIndex", "NativeHnswIndex", "HipDistance", "GpuAccelerator", "DistanceMetric", "HnswParams", "SearchQuality", "StorageMode", "DualPrecisionConfig",
            "device_count", "device_name", "comm_unique_id", "SHARD_RANGE", "SHARD_REPLICA", "set_kernel_timing", "set_max_query_tile", "set_sweep_engine", "set_split_selector", "lib", "VelesHipError"]

@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _ffi
 from ._ffi import check, lib
-from .params import DistanceMetric, HnswParams, SearchQuality
+from .params import DistanceMetric, DualPrecisionConfig, HnswParams, SearchQuality
 
 MODE_AUTO, MODE_BRUTE, MODE_HNSW, MODE_BRUTE_BF16, MODE_HNSW_INT8, MODE_BRUTE_SQ8, MODE_BRUTE_BINARY = 0, 1, 2, 3, 4, 5, 6
 OPT_MAX_QUERY_TILE, OPT_SWEEP_ENGINE, OPT_SELECTOR_LEVEL, OPT_INT8_OVERSAMPLING, OPT_KERNEL_TIMING = 0, 1, 2, 3, 4
@@ -280,6 +280,21 @@ class HnswIndex:
     def train_quantizer(self, sample_rows: int = 0) -> None:
         """ScalarQuantizer::train on the first sample_rows rows (0 = min(1000, rows)) + u8 codes of every row."""
         check(lib().vdb_hip_index_train_quantizer(self._h, sample_rows))
+        self._quantizer_trained = True
+
+    def search_with_config(self, query, k: int, ef_search: int, config: Optional[DualPrecisionConfig] = None) -> List[Tuple[int, float]]:
+        """DualPrecisionHnsw::search_with_config (native/dual_precision.rs:259-278): the int8 traversal only with a trained
+        quantiser, `use_int8_traversal` and at least `min_index_size` (default 10 000) vectors; otherwise the plain f32 graph
+        search.  `oversampling_ratio` sets how many of the int8 walk's best are re-scored exactly (k * ratio)."""
+        cfg = config or DualPrecisionConfig()
+        q = _f32(query).reshape(1, -1)
+        self._validate(q)
+        if cfg.takes_int8_traversal(getattr(self, "_quantizer_trained", False), self.len()):
+            self.set_option(OPT_INT8_OVERSAMPLING, cfg.oversampling_ratio)
+            ids, sc, cnt = self._search_raw(q, k, ef_search, MODE_HNSW_INT8)
+        else:
+            ids, sc, cnt = self._search_raw(q, k, ef_search, MODE_HNSW)
+        return self._tuples(ids[0], sc[0], cnt[0])
 
     def search_batch_int8(self, queries, k: int, ef_search: int):
         """DualPrecisionHnsw::search_with_config(use_int8_traversal): int8 graph walk + exact f32 re-rank."""

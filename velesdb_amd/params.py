@@ -133,3 +133,18 @@ SearchQuality.Fast = SearchQuality("fast")
 SearchQuality.Balanced = SearchQuality("balanced")
 SearchQuality.Accurate = SearchQuality("accurate")
 SearchQuality.Perfect = SearchQuality("perfect")
+
+
+@dataclass(frozen=True)
+class DualPrecisionConfig:
+    """native/dual_precision.rs:30-55 (Default: oversampling 4, int8 traversal on, min_index_size 10 000, no timings)."""
+    oversampling_ratio: int = 4
+    use_int8_traversal: bool = True
+    min_index_size: int = 10_000
+    debug_timings: bool = False
+
+    def takes_int8_traversal(self, quantizer_trained: bool, index_len: int) -> bool:
+        """The rule of DualPrecisionHnsw::search_with_config (:259-278): without a trained quantiser, with int8 traversal switched
+        off, or below min_index_size the plain f32 search answers (`inner.search`); otherwise search_int8_traversal."""
+        return bool(quantizer_trained) and self.use_int8_traversal and index_len >= self.min_index_size
+
