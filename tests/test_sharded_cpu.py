@@ -124,3 +124,41 @@ def test_query_slice_properties():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_merge_is_the_stable_sort_of_the_concatenation_property():
+    """The size-independent property of the sharded path (hypothesis): for any number of shards, any k, any per-shard lists that are
+    themselves in the metric's order — short lists, empty shards, heavy ties, infinities — the merged top-k is the first k of a
+    STABLE sort of the shard-order concatenation (equal scores: shard order, then position = global row order), and its count is
+    min(k, total).  This is DistanceMetric::sort_results (distance.rs:95-103) applied to what one big index would have sorted."""
+    from hypothesis import given, settings, strategies as st
+
+    scores = st.sampled_from([0.0, -0.0, 1.0, 1.0, 2.0, 2.5, -1.0, float("inf"), float("-inf"), 3.0])
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(1, 8), st.integers(1, 10), st.booleans(), st.data())
+    def prop(world, k, hib, data):
+        metric = po.COSINE if hib else po.EUCLIDEAN
+        lists, next_id = [], 0
+        for s in range(world):
+            n = data.draw(st.integers(0, k))
+            sc = [data.draw(scores) for _ in range(n)]
+            pairs = po.sort_results(metric, [(next_id + i, x) for i, x in enumerate(sc)])   # a shard's own top-k is in the metric's order
+            # ids inside a shard follow the shard's row order among equals (stable), shards own disjoint ascending id ranges
+            lists.append(pairs)
+            next_id += 1000
+        allrec = []
+        for pairs in lists:
+            ids = np.zeros((1, k), dtype=np.uint64)
+            sc = np.zeros((1, k), dtype=np.float32)
+            for i, (a, b) in enumerate(pairs):
+                ids[0, i], sc[0, i] = a, b
+            allrec.append(pack_records(ids, sc, np.array([len(pairs)], dtype=np.uint32)).view(np.uint32).reshape(1, k, 3))
+        gi, gs, gc = po.merge_shard_records(np.stack(allrec), k, hib)
+        concat = [p for pairs in lists for p in pairs]
+        exp = po.sort_results(metric, concat)[:k]
+        assert int(gc[0]) == len(exp) == min(k, len(concat))
+        assert gi[0, :len(exp)].tolist() == [a for a, _ in exp]
+        assert gs[0, :len(exp)].view(np.uint32).tolist() == np.array([b for _, b in exp], dtype=np.float32).view(np.uint32).tolist()
+
+    prop()
