@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle as po
+from velesdb_amd.metrics import recall_at_k
 from velesdb_amd.params import HnswParams
 
 QUALITIES = [("fast", po.Q_FAST), ("balanced", po.Q_BALANCED), ("accurate", po.Q_ACCURATE), ("perfect", po.Q_PERFECT)]
@@ -55,10 +56,10 @@ def recalls(data, ix, queries, k):
         tot = 0.0
         for qv in queries:
             sims = dn @ (qv.astype(np.float64) / np.linalg.norm(qv.astype(np.float64)))
-            truth = set(np.argsort(-sims, kind="stable")[:k].tolist())
+            truth = np.argsort(-sims, kind="stable")[:k].tolist()
             ids, sc = ix.search_with_quality(qv, k, q)
             assert len(ids) == k and np.all(np.diff(sc) <= 0)
-            tot += len(truth & set(ids.tolist())) / len(truth)
+            tot += recall_at_k(truth, ids.tolist())                       # metrics.rs:46-57, as the bench does (:137)
         out[name] = tot / len(queries)
     return out
 
