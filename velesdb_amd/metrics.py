@@ -28,3 +28,16 @@ def mrr(ground_truth: Sequence[Hashable], results: Sequence[Hashable]) -> float:
         if r in truth:
             return 1.0 / (rank + 1)
     return 0.0
+
+
+def compute_recall(retrieved: Sequence[Hashable], ground_truth: Sequence[Hashable], k: int) -> float:
+    """crates/velesdb-core/tests/recall_validation.rs:26-39: |top-k(retrieved) ∩ top-k(ground truth)| / k with
+    k = min(k, len(retrieved), len(ground_truth)); 0.0 when that k is 0."""
+    k = min(k, len(retrieved), len(ground_truth))
+    if k == 0:
+        return 0.0
+    return len(set(retrieved[:k]) & set(ground_truth[:k])) / k
+
+
+# the minimum acceptable recall values the reference declares (recall_validation.rs:221-230)
+MIN_RECALL_AT_1, MIN_RECALL_AT_10, MIN_RECALL_AT_100 = 0.99, 0.95, 0.90
