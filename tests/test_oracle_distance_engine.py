@@ -103,3 +103,25 @@ def test_native_engine_matches_simd_engine():
     assert d.shape == (5,) and np.all(np.abs(d - (-16.0 * np.arange(1, 6))) < 1e-3)
     d = po.batch_distance(po.EUCLIDEAN, np.zeros(8, dtype=F), np.stack([np.ones(8, dtype=F), np.full(8, 2.0, dtype=F)]), po.MODE_NATIVE)
     assert d.shape == (2,) and abs(d[0] - np.sqrt(8.0)) < 1e-5 and abs(d[1] - 2 * np.sqrt(8.0)) < 1e-5
+
+
+def test_gpu_accelerator_kats_on_the_function_the_gpu_is_compared_with():
+    """gpu/gpu_backend_tests.rs:30-178 — GpuAccelerator::batch_cosine_similarity / batch_euclidean_distance / batch_dot_product on flat
+    arrays (RAW similarities, within 0.01 in the reference).  The HIP side (`vdb_hip_batch_distance`, kind RAW) is bit-compared with
+    `batch_compute_distance` in mode C (tests/test_gpu_sweep.py::test_batch_distance_bit_exact); here that function meets the
+    reference's literals, exactly."""
+    def run(metric, vectors, query, dim):
+        v = np.asarray(vectors, dtype=F).reshape(-1, dim) if len(vectors) else np.empty((0, dim), dtype=F)
+        return po.batch_compute_distance(metric, np.asarray(query, dtype=F), v, po.MODE_C)
+
+    assert run(po.COSINE, [], [1.0, 0.0, 0.0], 3).size == 0                                     # :30-35
+    assert run(po.COSINE, [1.0, 0.0, 0.0], [1.0, 0.0, 0.0], 3).tolist() == [1.0]                # :39-54
+    assert run(po.COSINE, [0.0, 1.0, 0.0], [1.0, 0.0, 0.0], 3).tolist() == [0.0]                # :58-68
+    multi = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, -1.0, 0.0, 0.0]                                      # :72-89 same / orthogonal / opposite
+    assert run(po.COSINE, multi, [1.0, 0.0, 0.0], 3).tolist() == [1.0, 0.0, -1.0]
+    assert run(po.EUCLIDEAN, [], [1.0, 0.0, 0.0], 3).size == 0                                  # :97-102
+    assert run(po.EUCLIDEAN, [1.0, 2.0, 3.0], [1.0, 2.0, 3.0], 3).tolist() == [0.0]             # :106-116
+    assert run(po.EUCLIDEAN, [3.0, 4.0, 0.0], [0.0, 0.0, 0.0], 3).tolist() == [5.0]             # :120-134
+    assert run(po.DOT, [], [1.0, 0.0, 0.0], 3).size == 0                                        # :142-147
+    assert run(po.DOT, [0.0, 1.0, 0.0], [1.0, 0.0, 0.0], 3).tolist() == [0.0]                   # :151-161
+    assert run(po.DOT, [2.0, 3.0, 4.0], [2.0, 3.0, 4.0], 3).tolist() == [29.0]                  # :165-178
