@@ -47,3 +47,17 @@ def test_world_size_must_match_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300, env=env,
                        cwd=ROOT)
     assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr and r.stdout.strip() == ""
+
+
+def test_graft_entry_builds_and_smoke_refuses_to_run_without_a_gpu():
+    """__graft_entry__.build() is idempotent on a built tree (every product / checker / helper object present afterwards);
+    smoke() without a GPU stops at its first line instead of checking anything against anything"""
+    import pytest
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build()
+    for rel in ("velesdb_amd/lib/libvelesdb_hip.so", "oracle/libvdb_oracle.so", "tests/stub_rccl/libstub_rccl.so", "tests/abi_driver",
+                "tools/libcallers_bench.so"):
+        assert os.path.exists(os.path.join(ROOT, rel)), rel
+    with pytest.raises(AssertionError, match="needs a GPU"):
+        g.smoke()
