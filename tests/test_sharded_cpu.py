@@ -135,7 +135,7 @@ def test_merge_is_the_stable_sort_of_the_concatenation_property():
 
     scores = st.sampled_from([0.0, -0.0, 1.0, 1.0, 2.0, 2.5, -1.0, float("inf"), float("-inf"), 3.0])
 
-    @settings(max_examples=300, deadline=None)
+    @settings(max_examples=300, deadline=None, derandomize=True, database=None)   # the same 300 layouts on every run
     @given(st.integers(1, 8), st.integers(1, 10), st.booleans(), st.data())
     def prop(world, k, hib, data):
         metric = po.COSINE if hib else po.EUCLIDEAN
