@@ -285,7 +285,9 @@ class HnswIndex:
     def search_with_config(self, query, k: int, ef_search: int, config: Optional[DualPrecisionConfig] = None) -> List[Tuple[int, float]]:
         """DualPrecisionHnsw::search_with_config (native/dual_precision.rs:259-278): the int8 traversal only with a trained
         quantiser, `use_int8_traversal` and at least `min_index_size` (default 10 000) vectors; otherwise the plain f32 graph
-        search.  `oversampling_ratio` sets how many of the int8 walk's best are re-scored exactly (k * ratio)."""
+        search.  `oversampling_ratio` sets how many of the int8 walk's best are re-scored exactly (k * ratio) — through the handle's
+        VDB_OPT_INT8_OVERSAMPLING, i.e. per handle, not per call: callers that search one handle concurrently with DIFFERENT ratios
+        must serialise themselves (the reference passes the config per call; the C ABI has no per-call argument for it)."""
         cfg = config or DualPrecisionConfig()
         q = _f32(query).reshape(1, -1)
         self._validate(q)
