@@ -169,3 +169,21 @@ def test_declared_gpu_orders_bit_for_bit(n):
     a, b = rng.standard_normal(n).astype(F), rng.standard_normal(n).astype(F)
     assert F(po.dot(a, b, po.MODE_M)).view(np.uint32) == dot_mode_m(a, b).view(np.uint32)
     assert F(po.dot(a, b, po.MODE_C)).view(np.uint32) == dot_mode_c(list(a), list(b)).view(np.uint32)
+
+
+@pytest.mark.parametrize("n", [3, 64, 300, 768])
+def test_mode_c_cosine_and_euclidean_bit_for_bit(n):
+    """DESIGN §2, mode C: cosine = dot / (sqrt(sum a^2) * sqrt(sum b^2)) with every sum in the lane-chain order, 0 if a norm is 0;
+    L2 = sqrt of the same chain over rounded differences (diff * diff fused onto the lane's sum)"""
+    rng = np.random.default_rng(4000 + n)
+    a, b = rng.standard_normal(n).astype(F), rng.standard_normal(n).astype(F)
+    la, lb = list(a), list(b)
+    dot, na, nb = dot_mode_c(la, lb), dot_mode_c(la, la), dot_mode_c(lb, lb)
+    cos = rnd(fr(dot) / fr(rnd(fr(np.sqrt(na, dtype=F)) * fr(np.sqrt(nb, dtype=F)))))
+    assert F(po.cosine(a, b, po.MODE_C)).view(np.uint32) == cos.view(np.uint32)
+    assert F(po.norm_sq(a, po.MODE_C)).view(np.uint32) == na.view(np.uint32)
+    d = [sub(x, y) for x, y in zip(la, lb)]
+    l2sq = dot_mode_c(d, d)
+    assert F(po.sql2(a, b, po.MODE_C)).view(np.uint32) == l2sq.view(np.uint32)
+    assert F(po.euclidean(a, b, po.MODE_C)).view(np.uint32) == np.sqrt(l2sq, dtype=F).view(np.uint32)
+    assert po.cosine(np.zeros(n, F), a, po.MODE_C) == 0.0
