@@ -187,3 +187,26 @@ def test_mode_c_cosine_and_euclidean_bit_for_bit(n):
     assert F(po.sql2(a, b, po.MODE_C)).view(np.uint32) == l2sq.view(np.uint32)
     assert F(po.euclidean(a, b, po.MODE_C)).view(np.uint32) == np.sqrt(l2sq, dtype=F).view(np.uint32)
     assert po.cosine(np.zeros(n, F), a, po.MODE_C) == 0.0
+
+
+def dot_simd8(a, b):
+    """simd_explicit.rs:50-78 dot_product_simd: ONE f32x8 accumulator (fused), reduce_add, then the remainder as rounded products added
+    one by one — what `dot_product_auto` falls back to below 16 elements (simd_avx512.rs:90-96)"""
+    s = [F(0.0)] * 8
+    simd = len(a) // 8
+    for i in range(simd):
+        s = fma8(a[8 * i:8 * i + 8], b[8 * i:8 * i + 8], s)
+    result = reduce_add(s)
+    for i in range(8 * simd, len(a)):
+        result = add(result, rnd(fr(a[i]) * fr(b[i])))
+    return result
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 15, 24, 100, 768])
+def test_eight_lane_form_and_the_small_vector_fallback(n):
+    rng = np.random.default_rng(5000 + n)
+    a, b = rng.standard_normal(n).astype(F), rng.standard_normal(n).astype(F)
+    exp = dot_simd8(list(a), list(b))
+    assert F(po.dot_simd8(a, b)).view(np.uint32) == exp.view(np.uint32)
+    if n < 16:                                       # below 16 elements the production entry point IS this form
+        assert F(po.dot(a, b, po.MODE_R)).view(np.uint32) == exp.view(np.uint32)
