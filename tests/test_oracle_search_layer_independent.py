@@ -111,3 +111,43 @@ def test_full_search_is_descent_plus_layer0_expansion_and_counts_what_it_touches
         assert po.NativeHnsw.last_stats() == (descent[0] + n_dist, n_expand)
         # brute-force sanity: the graph's answer holds the true nearest neighbour
         assert int(np.argmin(((X - q) ** 2).sum(axis=1))) in nodes[:10]
+
+
+def select_neighbors_py(g, metric, mode, candidates, max_neighbors, alpha=1.0):
+    """graph.rs:522-578, statement for statement: all candidates when they fit; otherwise a candidate is kept while
+    alpha * d(q, c) <= d(c, s) holds for EVERY already selected s (the first candidate always), then the quota is filled with the
+    closest candidates not yet selected, in candidate order"""
+    if not candidates:
+        return []
+    if len(candidates) <= max_neighbors:
+        return [c for c, _ in candidates]
+    selected = []
+    for cid, cdist in candidates:
+        if len(selected) >= max_neighbors:
+            break
+        cv = g.vector(cid)
+        diverse = all(F(alpha) * F(cdist) <= F(po.distance(metric, cv, g.vector(s), mode)) for s in selected)
+        if diverse or not selected:
+            selected.append(cid)
+    if len(selected) < max_neighbors:
+        for cid, _ in candidates:
+            if len(selected) >= max_neighbors:
+                break
+            if cid not in selected:
+                selected.append(cid)
+    return selected
+
+
+@pytest.mark.parametrize("metric", [po.EUCLIDEAN, po.COSINE])
+@pytest.mark.parametrize("alpha", [1.0, 1.2])
+def test_select_neighbors_matches_the_plain_statement(metric, alpha):
+    """the candidate lists are what insert passes: search_layer's output at ef_construction, ascending (graph.rs:196-204)"""
+    g, X, rng = build(500, 16, metric, 8, 60, seed=21 + metric)
+    g.set_alpha(alpha)
+    for _ in range(10):
+        q = rng.standard_normal(16).astype(F)
+        ids, ds = g.search_layer(q, [int(g.entry_point)], 60, 0)
+        cand = list(zip(ids.tolist(), ds.tolist()))
+        for max_nb in (4, 8, 16, 59, 60, 100):
+            assert g.select_neighbors(cand, max_nb) == select_neighbors_py(g, metric, po.MODE_R, cand, max_nb, alpha), (max_nb, alpha)
+    assert g.select_neighbors([], 8) == []
