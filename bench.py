@@ -88,6 +88,108 @@ def parse():
     p.add_argument("--cpu-hnsw-queries", type=int, default=20000)
     return p.parse_args()
 
+# ---- the line the driver parses -------------------------------------------------------------------------------------------------
+COMPACT_LIMIT = 4096   # bytes; the driver's record keeps a bounded tail of stdout (round 4's 25 KB line was cut: BENCH_r04.parsed = null)
+_ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel", "kernel_ms", "launches_timed")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "cpu_model", "sample")
+
+
+def _pick(d, keys, clip=160):
+    out = {}
+    for k_ in keys:
+        if isinstance(d, dict) and k_ in d:
+            v = d[k_]
+            out[k_] = v[:clip] if isinstance(v, str) else v
+    return out
+
+
+def _ok(pc):
+    """one bool out of a parity_check object: every boolean field true (None when there is no check)"""
+    if not isinstance(pc, dict):
+        return None
+    flags = [v for v in pc.values() if isinstance(v, bool)]
+    return bool(flags) and all(flags)
+
+
+def compact_line(full, legs_file="bench_legs.json"):
+    """Pure function: the full record of a run -> the ONE line printed last on stdout.  Holds the contract's keys, the headline's
+    roofline and cpu_baseline objects (trimmed of prose) and one-number summaries of the other legs; everything else (tile tables, ef
+    curves, caller tables, notes) lives in `legs_file`.  Always <= COMPACT_LIMIT bytes: strings are clipped, and if a
+    pathological input still overflows, the leg summaries are dropped before the contract keys are."""
+    g = full.get
+    cfg = dict(g("config") or {})
+    if isinstance(cfg.get("workload"), str):
+        cfg["workload"] = cfg["workload"][:240]
+    line = {k_: g(k_) for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data")}
+    line["config"] = cfg
+    line["recall_at_10"] = g("recall_at_10")
+    line["parity_check"] = _ok(g("parity_check"))
+    line["frac_step"] = g("frac_step")
+    line["roofline"] = _pick(g("roofline") or {}, _ROOF_KEYS)
+    cpu = _pick(g("cpu_baseline") or {}, _CPU_KEYS, clip=200)
+    line["cpu_baseline"] = cpu if cpu else None
+    if g("error"):
+        line["error"] = str(g("error"))[:300]
+    legs = {}
+    h = g("hnsw")
+    if isinstance(h, dict):
+        r_ = h.get("roofline") or {}
+        legs["hnsw"] = {"qps": h.get("qps"), "recall": h.get("recall_at_10"), "frac": r_.get("frac"), "bound": r_.get("bound"),
+                        "kernel_ms": r_.get("kernel_ms"), "parity": _ok(h.get("parity_check")),
+                        "cpu_qps": (h.get("cpu_baseline") or {}).get("value"),
+                        "build_inserts_per_s": h.get("build_inserts_per_s"),
+                        "build_frac": ((h.get("build") or {}).get("roofline") or {}).get("frac"),
+                        "int8_frac": (h.get("int8") or {}).get("hbm_frac"), "int8_qps": (h.get("int8") or {}).get("qps")}
+        lm = h.get("latency_mode")
+        if isinstance(lm, list) and lm and isinstance(lm[0], dict):
+            legs["hnsw"]["one_query_us"] = lm[0].get("median_us_per_call")
+    b = g("bf16_gemm")
+    if isinstance(b, dict):
+        r_ = b.get("roofline") or {}
+        legs["bf16_gemm"] = {"qps": b.get("qps"), "frac": r_.get("frac"), "kernel_ms": r_.get("kernel_ms"),
+                             "traffic_over_algorithmic": r_.get("traffic_over_algorithmic"), "parity": _ok(b.get("parity_check"))}
+    s_ = g("sharded")
+    if isinstance(s_, dict):
+        legs["sharded"] = {"qps": s_.get("qps"), "group_ok": s_.get("group_ok"), "ranks": s_.get("ranks"),
+                           "rows_per_shard": s_.get("rows_per_shard"), "transport": s_.get("transport"),
+                           "identical_across_ranks": s_.get("results_identical_across_ranks"),
+                           "error": (str(s_["error"])[:120] if s_.get("error") else None)}
+    c0 = g("config0_10k")
+    if isinstance(c0, dict):
+        pts = ((c0.get("concurrent_callers") or {}).get("points")) or []
+        legs["config0_10k"] = {"search_median_us": c0.get("search_median_us"),
+                               "reference_published_us": (c0.get("reference_published") or {}).get("search_us"),
+                               "gpu_over_cpu_by_threads": {str(p_.get("threads")): p_.get("gpu_over_cpu") for p_ in pts[:6]}}
+    q8 = g("sq8_storage_mode")
+    if isinstance(q8, dict):
+        legs["sq8"] = {"batch_qps": (q8.get("batch") or {}).get("qps"), "eight_queries_hbm_frac": (q8.get("eight_queries") or {}).get("hbm_frac"),
+                       "parity": _ok(q8.get("parity_check"))}
+    om = g("other_metrics")
+    if isinstance(om, list):
+        legs["other_metrics"] = {}
+        for m_ in om[:6]:
+            if not isinstance(m_, dict):
+                continue
+            sq, bt = m_.get("single_query") or {}, m_.get("batch") or {}
+            legs["other_metrics"][str(m_.get("metric"))[:12]] = {
+                "one_query_ms": sq.get("ms_per_call"), "one_query_hbm_frac": sq.get("hbm_frac"), "batch_qps": bt.get("qps"),
+                "batch_frac": (bt.get("roofline") or {}).get("frac"), "parity": _ok(m_.get("parity_check"))}
+    line["legs"] = legs
+    line["legs_file"] = legs_file
+    line["device"] = (g("device") or "")[:80]
+    enc = json.dumps(line)
+    for drop in ("other_metrics", "config0_10k", "sq8", "sharded", "bf16_gemm", "hnsw"):   # never reached on a real run (tested)
+        if len(enc) <= COMPACT_LIMIT:
+            break
+        line["legs"].pop(drop, None)
+        enc = json.dumps(line)
+    if len(enc) > COMPACT_LIMIT:
+        line["roofline"] = _pick(line["roofline"], _ROOF_KEYS, clip=40)
+        line["cpu_baseline"] = _pick(line["cpu_baseline"] or {}, _CPU_KEYS, clip=40)
+        line["config"] = {"workload": str(cfg.get("workload"))[:120]}
+    return line
+
 
 def main():
     a = parse()
@@ -1469,8 +1571,24 @@ def main():
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
+        # the full record: a file next to the line (and under gpurun_out/ when that exists, so a gpurun call brings it home);
+        # stdout carries ONE compact line, last
+        full_txt = json.dumps(line)
+        here = os.path.dirname(os.path.abspath(__file__))
+        legs_file = "bench_legs.json" if world == 1 else "bench_legs_%dgpu.json" % world
+        for d_ in (here, os.path.join(here, "gpurun_out")):
+            try:
+                if os.path.isdir(d_):
+                    with open(os.path.join(d_, legs_file), "w") as f:
+                        f.write(full_txt + "\n")
+            except OSError as ex:
+                print(f"bench.py: could not write {legs_file} in {d_}: {ex}", file=sys.stderr)
+        # (not echoed to stderr: the driver's record keeps ONE bounded tail of stdout + stderr, and 25 KB of stderr would push the line
+        # out of it just as the 25 KB line pushed its own head out in round 4)
+        print(f"bench.py: full record ({len(full_txt)} bytes) in {legs_file}", file=sys.stderr)
+        sys.stderr.flush()
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        os.write(json_fd, (json.dumps(compact_line(line, legs_file)) + "\n").encode())
         if bad_group:
             raise SystemExit("bench.py: " + bad_group)
 

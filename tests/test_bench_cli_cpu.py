@@ -61,3 +61,99 @@ def test_graft_entry_builds_and_smoke_refuses_to_run_without_a_gpu():
         assert os.path.exists(os.path.join(ROOT, rel)), rel
     with pytest.raises(AssertionError, match="needs a GPU"):
         g.smoke()
+
+
+def _maximal_record(blow=1):
+    """a synthetic full record with every leg present and every prose field `blow` times longer than a real run's"""
+    prose = "x" * (400 * blow)
+    roof = {"bound": "mfma", "achieved": 1078.9, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.4316, "traffic": 2301561600,
+            "traffic_over_algorithmic": 0.747, "kernel": "sweep_topk_gemm_bf16_pp<cosine> " + prose, "kernel_ms": 1.4518, "launches_timed": 4,
+            "note": prose, "kernel_ms_note": prose, "traffic_by_kernel": {("k%d" % i) + prose: i for i in range(8)},
+            "exact_f32_kernel": {"roofline": {"note": prose}}}
+    cpu = {"value": 78.8, "unit": "queries/s", "cores": 16, "kind": "port", "cpu_model": "AMD EPYC 9575F 64-Core Processor " + prose,
+           "sample": prose, "shape_a": {"qps": 1.0}, "shape_b": {"qps": 1.0}, "cores_note": prose}
+    pts = [{"threads": t, "qps": 1.0, "gpu_over_cpu": 0.5, "note": prose} for t in (1, 4, 16, 64)]
+    return {
+        "metric": "qps_at_recall10_1Mx768_k10", "value": 598577.0, "unit": "queries/s", "n_gpus": 8, "steps": 20, "warmup": 3,
+        "ms_per_step": 1.7107, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "1000000x768 f32 cosine " + prose, "rows": 1000000, "dim": 768, "k": 10, "queries_per_step": 1024,
+                   "parallelism": "replicas x8 (query stream split, no collective)"},
+        "replicas_per_rank": [{"rank": r, "qps": 1.0} for r in range(8)], "recall_at_10": 1.0,
+        "parity_check": {"queries": 64, "ids_equal_oracle_canonical": True, "scores_bit_equal_oracle_canonical": True, "kernel": prose},
+        "frac_step": 0.38, "roofline": roof, "cpu_baseline": cpu, "latency_mode": {"note": prose},
+        "tiles": [{"tile": t, "note": prose} for t in range(12)], "batch_sizes_default_path": [{"n": prose}] * 8, "host_entry": {"note": prose},
+        "sharded": {"qps": 1.0, "group_ok": True, "ranks": 8, "rows_per_shard": 6250000, "transport": "rccl", "results_identical_across_ranks": True,
+                    "per_rank": [{"rank": r, "note": prose} for r in range(8)], "collective": prose},
+        "hnsw": {"qps": 167342.2, "recall_at_10": 0.99, "roofline": dict(roof, bound="hbm"), "parity_check": {"ok": True, "n": prose},
+                 "cpu_baseline": cpu, "build_inserts_per_s": 44566.8, "build": {"roofline": {"frac": 0.2, "note": prose}},
+                 "int8": {"qps": 1.0, "hbm_frac": 0.6, "note": prose}, "ef_curve": [{"ef": e, "note": prose} for e in (64, 128, 256, 512)],
+                 "latency_mode": [{"queries_per_call": 1, "median_us_per_call": 1051.8}], "concurrent_callers": {"points": pts}},
+        "hnsw_embedding_like": {"note": prose, "ef_curve": [{"note": prose}] * 4},
+        "config0_10k": {"search_median_us": 304.1, "reference_published": {"search_us": 56.8}, "concurrent_callers": {"points": pts}, "note": prose},
+        "bf16_gemm": {"qps": 1.0, "roofline": roof, "parity_check": {"ok": True, "rule": prose}, "cpu_baseline": cpu},
+        "sq8_storage_mode": {"batch": {"qps": 1.0, "kernel": prose}, "eight_queries": {"hbm_frac": 0.12}, "parity_check": {"ids_equal_oracle": True}},
+        "other_metrics": [{"metric": m, "single_query": {"ms_per_call": 0.5, "hbm_frac": 0.7}, "batch": {"qps": 1.0, "roofline": roof},
+                           "parity_check": {"ids_equal_oracle": True}, "note": prose, "cpu_baseline": cpu}
+                          for m in ("euclidean", "dot", "hamming", "jaccard")],
+        "device": "AMD Radeon Graphics (gfx950:sramecc+:xnack-, 256 CUs) " + prose, "device_state": [prose] * 7, "error": prose,
+    }
+
+
+def test_the_printed_line_is_bounded_and_carries_the_contract():
+    """round 4's 25 KB line was cut by the driver's bounded record (BENCH_r04.parsed = null).  The printed line is built by a pure
+    function; whatever the legs hold it stays under 4 KB, round-trips through json, and keeps the contract's keys plus the headline's
+    roofline and cpu_baseline objects"""
+    import json
+    b = load_bench()
+    for blow in (1, 10, 100):
+        full = _maximal_record(blow)
+        assert len(json.dumps(full)) > 25_000
+        line = b.compact_line(full, "bench_legs_8gpu.json")
+        enc = json.dumps(line)
+        assert len(enc) <= b.COMPACT_LIMIT < 8192, (blow, len(enc))
+        assert "\n" not in enc
+        back = json.loads(enc)
+        assert back == line
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                  "data", "config", "roofline", "cpu_baseline", "recall_at_10", "parity_check"):
+            assert k in back, k
+        assert back["value"] == full["value"] and back["ms_per_step"] == full["ms_per_step"] and back["n_gpus"] == 8
+        assert back["config"]["workload"].startswith("1000000x768 f32 cosine")
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert back["roofline"][k] == full["roofline"][k]
+        for k in ("value", "unit", "cores", "kind"):
+            assert back["cpu_baseline"][k] == full["cpu_baseline"][k]
+        assert back["parity_check"] is True and back["legs_file"] == "bench_legs_8gpu.json"
+    # at a real run's sizes nothing is dropped: every leg's one-number summary is on the line
+    back = b.compact_line(_maximal_record(1))
+    assert set(back["legs"]) == {"hnsw", "bf16_gemm", "sharded", "config0_10k", "sq8", "other_metrics"}
+    assert back["legs"]["hnsw"]["frac"] == 0.4316 and back["legs"]["hnsw"]["build_frac"] == 0.2 and back["legs"]["sharded"]["group_ok"] is True
+    assert back["legs"]["other_metrics"]["hamming"]["parity"] is True
+    # a failed parity flag anywhere in a check object reads as False on the line; no check object reads as None
+    bad = _maximal_record(1)
+    bad["parity_check"]["scores_bit_equal_oracle_canonical"] = False
+    assert b.compact_line(bad)["parity_check"] is False
+    bad.pop("parity_check")
+    assert b.compact_line(bad)["parity_check"] is None
+    # a minimal record (every optional leg skipped) still makes a line
+    mini = {k: v for k, v in _maximal_record(1).items() if k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                                 "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline")}
+    m = b.compact_line(mini)
+    assert m["legs"] == {} and m["cpu_baseline"] is None and m["roofline"]["frac"] == 0.4316
+
+
+def test_committed_full_records_compact_under_the_limit():
+    """every full bench record the builder committed under profiles/ goes through compact_line under the limit"""
+    import glob
+    import json
+    b = load_bench()
+    seen = 0
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench_line_1gpu.json"))):
+        full = json.loads(open(path).read().strip().splitlines()[-1])
+        if "legs_file" in full:     # already a compact line
+            continue
+        enc = json.dumps(b.compact_line(full))
+        assert len(enc) <= b.COMPACT_LIMIT, (path, len(enc))
+        assert json.loads(enc)["value"] == full["value"]
+        seen += 1
+    assert seen >= 10
