@@ -423,6 +423,31 @@ __device__ __forceinline__ void mfma_acc_first(f32x4& c, const f32x4& a, const f
   else
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));
 }
+// ACCV (round 5): the register classes SWAPPED — accumulators in the vector registers ("+v"), fragments in the accumulation
+// registers (gfx950's file is unified: `ds_read_b128 a[..]` loads straight into them and the matrix pipe takes A / B operands from
+// either class).  The k-loop is unchanged instruction for instruction; the epilogue's quick test no longer pays one
+// v_accvgpr_read per accumulator (128 per wave and row tile: the floor of the round-4 epilogue, profiles/r04_pmc_lds_vmem_*).
+template <bool FP4>
+__device__ __forceinline__ void mfma_accv(f32x4& c, const f32x4& a, const f32x4& b) {
+  if (FP4)
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+v"(c) : "a"(a), "a"(b), "v"(0x7F7F7F7Fu));
+  else
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(a), "a"(b));
+}
+template <bool FP4>
+__device__ __forceinline__ void mfma_accv_first(f32x4& c, const f32x4& a, const f32x4& b) {
+  if (FP4)
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "=&v"(c) : "a"(a), "a"(b), "v"(0x7F7F7F7Fu));
+  else
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "a"(a), "a"(b));
+}
+// one fragment read into accumulation registers: LDS byte address in a vector register + an immediate.  `asm volatile`: it keeps its
+// place among the barriers, requests and products of the phase; its completion is the explicit lgkmcnt(0) of pp_barrier_reads_done
+// (the compiler does not count it — every use of a fragment sits behind that wait)
+template <int OFF>
+__device__ __forceinline__ void lds_frag_read(f32x4& dst, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(addr), "n"(OFF));
+}
 // the barrier in front of a phase's products: this wave's fragment reads have completed (their stage slots may be
 // re-requested by anybody who has passed the barrier); "memory": no LDS access moves across
 __device__ __forceinline__ void pp_barrier_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -432,7 +457,7 @@ __device__ __forceinline__ void pp_wait_dma6() { asm volatile("s_waitcnt vmcnt(6
 // FP4 instance (Hamming / Jaccard batches on four-bit images, bits_gemm.hip): rows / queries are nibble images addressed through
 // the same arguments — row_stride / q_stride / dim in units of TWO bytes, k-tiles of 128 bytes = 256 values — and `norms` /
 // `qnorms_half` carry the bit counts |v|, |q| as floats (Hamming: dim); the accumulators hold the exact integer dot products.
-template <int METRIC, bool FP4 = false>
+template <int METRIC, bool FP4 = false, bool ACCV = true>
 __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a) {
   static_assert(FP4 == (METRIC == kHamming || METRIC == kJaccard), "the four-bit instance serves the bit metrics, the bf16 instance Cosine / DotProduct");
   constexpr bool HIB = METRIC != kHamming;  // Cosine / DotProduct / Jaccard: higher is better; Hamming: a distance
@@ -538,20 +563,36 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a
 
   // ---- fragment reads: lane (i = l & 15, kk = l >> 4) reads slot (4 m + kk) ^ ((i >> 1) & 7) of row i (+ 16 rows per fragment)
 #define VDB_PP_READ_A(DST, RF0, BUF) do { \
+    if (ACCV) { \
+      const uint32_t ad0_ = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)(a_rd0 + rd_x), ad1_ = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)(a_rd0 + (64 ^ rd_x)); \
+      lds_frag_read<((RF0) + 0) * 2048>(DST[0][0], ad0_); lds_frag_read<((RF0) + 0) * 2048>(DST[0][1], ad1_); \
+      lds_frag_read<((RF0) + 1) * 2048>(DST[1][0], ad0_); lds_frag_read<((RF0) + 1) * 2048>(DST[1][1], ad1_); \
+      lds_frag_read<((RF0) + 2) * 2048>(DST[2][0], ad0_); lds_frag_read<((RF0) + 2) * 2048>(DST[2][1], ad1_); \
+      lds_frag_read<((RF0) + 3) * 2048>(DST[3][0], ad0_); lds_frag_read<((RF0) + 3) * 2048>(DST[3][1], ad1_); \
+    } else { \
     const unsigned char* tb_ = smem + (size_t)(BUF) * 65536; \
 _Pragma("unroll") \
     for (int rf_ = 0; rf_ < 4; rf_++) \
 _Pragma("unroll") \
       for (int m_ = 0; m_ < 2; m_++) \
         DST[rf_][m_] = *reinterpret_cast<const f32x4*>(tb_ + a_rd0 + ((m_ * 64) ^ rd_x) + ((RF0) + rf_) * 2048); \
+    } \
   } while (0)
 #define VDB_PP_READ_B(BUF) do { \
+    if (ACCV) { \
+      const uint32_t bd0_ = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)(b_rd0 + rd_x), bd1_ = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)(b_rd0 + (64 ^ rd_x)); \
+      lds_frag_read<0 * 2048>(bv[0][0], bd0_); lds_frag_read<0 * 2048>(bv[0][1], bd1_); \
+      lds_frag_read<1 * 2048>(bv[1][0], bd0_); lds_frag_read<1 * 2048>(bv[1][1], bd1_); \
+      lds_frag_read<2 * 2048>(bv[2][0], bd0_); lds_frag_read<2 * 2048>(bv[2][1], bd1_); \
+      lds_frag_read<3 * 2048>(bv[3][0], bd0_); lds_frag_read<3 * 2048>(bv[3][1], bd1_); \
+    } else { \
     const unsigned char* tb_ = smem + (size_t)(BUF) * 65536; \
 _Pragma("unroll") \
     for (int t_ = 0; t_ < 4; t_++) \
 _Pragma("unroll") \
       for (int m_ = 0; m_ < 2; m_++) \
         bv[t_][m_] = *reinterpret_cast<const f32x4*>(tb_ + b_rd0 + ((m_ * 64) ^ rd_x) + t_ * 2048); \
+    } \
   } while (0)
   // 16 products: rows RF0 .. RF0 + 3 (fragments of AV) x queries T0, T0 + 1 x both 32-deep halves
 #define VDB_PP_MFMA(AV, RF0, T0, FIRST) do { \
@@ -561,7 +602,10 @@ _Pragma("unroll") \
       for (int rf_ = 0; rf_ < 4; rf_++) \
 _Pragma("unroll") \
         for (int t_ = 0; t_ < 2; t_++) { \
-          if ((FIRST) && m_ == 0) mfma_acc_first<FP4>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
+          if (ACCV) { \
+            if ((FIRST) && m_ == 0) mfma_accv_first<FP4>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
+            else mfma_accv<FP4>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
+          } else if ((FIRST) && m_ == 0) mfma_acc_first<FP4>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
           else mfma_acc<FP4>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
         } \
   } while (0)
@@ -648,7 +692,7 @@ _Pragma("unroll") \
 #define VDB_G16_ACC_F(V) (V)
 #include "g16_quicktest.inc"  // (waves 0-3: beside the last products of waves 4-7)
     if (wr == 0) pp_barrier();  // waves 0-3 wait for the last products of waves 4-7: the block is aligned again
-#define VDB_G16_ACC_ELEM(X, A) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(X) : "a"(A))
+#define VDB_G16_ACC_ELEM(X, A) do { if (ACCV) asm volatile("v_mov_b32 %0, %1" : "=v"(X) : "v"(A)); else asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(X) : "a"(A)); } while (0)
 #include "g16_protocol.inc"
 #undef VDB_G16_ACC_ELEM
 #undef VDB_G16_ACC_F
