@@ -155,6 +155,17 @@ int32_t vdb_hip_index_insert_batch_parallel(vdb_hip_index* idx, const uint64_t* 
 /* ScalarQuantizer::train (native/quantization.rs:191-233) on the first sample_rows rows (0 = min(1000, rows), what
  * DualPrecisionHnsw uses) + u8 codes for every present and future row (+1 byte per element of HBM). */
 int32_t vdb_hip_index_train_quantizer(vdb_hip_index* idx, uint32_t sample_rows);
+/* DualPrecisionHnsw::is_quantizer_trained (native/dual_precision.rs:117-120): *trained = 1 once vdb_hip_index_train_quantizer ran
+ * on this handle, else 0 (the codes are a derived image: they are not part of a saved directory, a loaded handle starts untrained). */
+int32_t vdb_hip_index_quantizer_trained(const vdb_hip_index* idx, int32_t* trained);
+/* DualPrecisionHnsw::search_with_config (native/dual_precision.rs:259-278) for a batch, the DualPrecisionConfig passed per call as
+ * the reference passes it: the int8 graph traversal + exact f32 re-scoring of the k * oversampling_ratio best (dual_precision.rs:
+ * 284-321) only when the quantiser is trained AND use_int8_traversal != 0 AND the index holds >= min_index_size vectors; otherwise
+ * the plain f32 graph search (VDB_SEARCH_HNSW).  oversampling_ratio = 0 => VDB_ERR_INVALID_ARG (reference default 4,
+ * min_index_size default 10 000).  Ids / scores as VDB_SEARCH_HNSW reports them.  Does not touch VDB_OPT_INT8_OVERSAMPLING. */
+int32_t vdb_hip_index_search_with_config(vdb_hip_index* idx, const float* queries_rowmajor, uint32_t nq, uint32_t k,
+                                         uint32_t ef_search, uint32_t oversampling_ratio, int32_t use_int8_traversal,
+                                         uint64_t min_index_size, uint64_t* out_ids, float* out_scores, uint32_t* out_n);
 /* DualPrecisionConfig::oversampling_ratio (default 4) of VDB_SEARCH_HNSW_INT8, process-wide */
 int32_t vdb_hip_set_int8_oversampling(uint32_t ratio);
 /* Collection StorageMode (quantization.rs:17-29; collection/core/crud.rs:66-82 quantises every upserted vector):
@@ -216,7 +227,9 @@ int32_t vdb_hip_index_search_rerank(vdb_hip_index* idx, const float* queries_row
  * descent's result AND up to min(num_probes, 4) - 1 further nodes drawn from the graph's own xorshift stream (the stream that
  * draws insertion levels: like the reference, the call advances it — query i of the batch takes the draws nq sequential calls
  * would give it; duplicates are skipped; no draw when num_probes <= 1 or the graph has <= 10 nodes), same ef.  Ids / scores as
- * VDB_SEARCH_HNSW reports them.  ef = 0 => Balanced; ef >= 4 when several entry points are used. */
+ * VDB_SEARCH_HNSW reports them.  `ef` is NativeHnsw's raw ef_search (graph.rs:343): no SearchQuality rule, no max(ef, k) — a call
+ * with ef < k returns at most ef results per query (with more entry points than ef: as many as there are entry points, which is what
+ * the reference's uncut `results` heap gives, graph.rs:463-468; ef = 0 therefore acts as ef = 1, NOT as "Balanced"). */
 int32_t vdb_hip_index_search_multi_entry(vdb_hip_index* idx, const float* queries_rowmajor, uint32_t nq, uint32_t k, uint32_t ef,
                                          uint32_t num_probes, uint64_t* out_ids, float* out_scores, uint32_t* out_n);
 /* device-resident variant: d_queries nq*dim f32 (16-byte aligned), outputs device buffers of nq*k / nq; enqueued on `stream`,

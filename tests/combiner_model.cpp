@@ -4,7 +4,7 @@
 // -fsanitize=thread and runs it; no GPU, no HIP).  The calling pattern it models is the reference's: many threads, one query per
 // search under a read lock (index/hnsw/index/search.rs:80; stress tests index/hnsw/native/tests.rs:264-416).
 //
-// usage: combiner_model <threads> <iterations> <max_batch> <window_us> <launch_us>
+// usage: combiner_model <threads> <iterations> <max_batch> <window_us> <launch_us> [starve]
 // Checks (any failure: message on stderr, exit code 1):
 //   * every caller gets the answer of ITS queries (ids / scores are functions of the query value and the shape), or the injected
 //     error with its message, whichever batch its request travelled in;
@@ -86,7 +86,114 @@ struct MockFront {
   }
 };
 
+// `starve` mode: endless graph-walk traffic — `threads - 1` callers of one walk shape, back to back, so that a walk
+// batch is (almost) always in flight — plus ONE sweep caller (leader limit 1: it needs an empty chip).  Without the fairness rule of
+// vdb_combiner.hpp the sweep caller sleeps for as long as the walkers keep coming; with it, at most kCombineMaxPassed leaders are
+// admitted ahead of it once it heads the queue.  Measured per sweep call: launches that STARTED between its arrival and its own launch.
+static int starve_mode(int threads, int iters, uint32_t mb, uint32_t win, uint32_t launch_us) {
+  MockFront env;
+  env.mb = mb;
+  env.win = win;
+  env.launch_us = launch_us;
+  Combiner cb;
+  std::atomic<bool> stop{false};
+  std::atomic<uint64_t> walk_calls{0};
+  std::vector<std::thread> pool;
+  for (int t = 0; t + 1 < threads; t++)
+    pool.emplace_back([&, t] {
+      while (!stop.load(std::memory_order_relaxed)) {
+        float q[1] = {(float)(t + 1)};
+        uint64_t ids[10];
+        float sc[10];
+        uint32_t cnt[1];
+        CombineReq me;
+        me.queries = q;
+        me.nq = 1;
+        me.k = 10;
+        me.ef = 128;
+        me.mode = 0;  // a walk: two batches may be in flight
+        me.rerank_k = 0;
+        me.out_ids = ids;
+        me.out_scores = sc;
+        me.out_n = cnt;
+        const int32_t rc = vdb::search_combined(env, &cb, me);
+        CHECK(rc == 0 && cnt[0] == 10 && ids[0] == answer_id(q[0], 10, 0), "walker %d: wrong answer", t);
+        walk_calls.fetch_add(1);
+      }
+    });
+  uint64_t worst_passed = 0;
+  double worst_ms = 0.0;
+  int done = 0;
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(20);
+  std::thread sweeper([&] {
+    for (int it = 0; it < iters; it++) {
+      float q[1] = {(float)(100000 + it)};
+      uint64_t ids[3];
+      float sc[3];
+      uint32_t cnt[1];
+      CombineReq me;
+      me.queries = q;
+      me.nq = 1;
+      me.k = 3;
+      me.ef = 0;
+      me.mode = 1;  // a sweep: runs alone
+      me.rerank_k = 0;
+      me.out_ids = ids;
+      me.out_scores = sc;
+      me.out_n = cnt;
+      uint64_t before;
+      {
+        std::lock_guard<std::mutex> lk(cb.mu);
+        before = cb.launches;
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      const int32_t rc = vdb::search_combined(env, &cb, me);
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      uint64_t after;
+      {
+        std::lock_guard<std::mutex> lk(cb.mu);
+        after = cb.launches;
+      }
+      CHECK(rc == 0 && cnt[0] == 3 && ids[0] == answer_id(q[0], 3, 0), "sweeper: wrong answer");
+      worst_passed = std::max(worst_passed, after - before);
+      worst_ms = std::max(worst_ms, ms);
+      done++;
+      if (std::chrono::steady_clock::now() > t_end) break;
+      std::this_thread::sleep_for(std::chrono::microseconds(launch_us * 3 + 50));  // it arrives into running walk traffic every time
+    }
+    stop.store(true);
+  });
+  // a watchdog instead of a hang: past the deadline the walkers go away, which un-starves the sweeper, and the run is a failure
+  std::thread dog([&] {
+    while (!stop.load() && std::chrono::steady_clock::now() < t_end + std::chrono::seconds(2)) std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    if (!stop.load()) {
+      CHECK(false, "the sweep caller was starved past the deadline (%d of %d calls done)", done, iters);
+      stop.store(true);
+    }
+  });
+  sweeper.join();
+  dog.join();
+  for (auto& th : pool) th.join();
+  // launches between arrival and completion: <= kCombineMaxPassed admitted ahead once it heads the queue + the queued walk requests
+  // in front of it (they share ONE launch: one shape) + the (<= 2) batches in flight + its own
+  const uint64_t bound = vdb::kCombineMaxPassed + 8;  // (measured: 7-10 at 4-24 callers)
+  CHECK(done == iters, "only %d of %d sweep calls finished", done, iters);
+  CHECK(worst_passed <= bound, "a sweep call saw %llu launches go first (bound %llu)", (unsigned long long)worst_passed, (unsigned long long)bound);
+  {
+    std::lock_guard<std::mutex> lk(cb.mu);
+    CHECK(cb.queue.empty() && cb.leaders == 0, "queue %zu / leaders %d at the end", cb.queue.size(), cb.leaders);
+  }
+  CHECK(env.max_in_flight.load() <= 2, "%d batches ran beside each other", env.max_in_flight.load());
+  std::printf("{\"mode\": \"starve\", \"threads\": %d, \"sweep_calls\": %d, \"walk_calls\": %llu, \"worst_launches_ahead\": %llu, \"bound\": %llu, "
+              "\"worst_ms\": %.3f, \"ok\": %s}\n",
+              threads, done, (unsigned long long)walk_calls.load(), (unsigned long long)worst_passed, (unsigned long long)bound, worst_ms,
+              g_fail.load() ? "false" : "true");
+  return g_fail.load() ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 6 && std::strcmp(argv[6], "starve") == 0)
+    return starve_mode(std::atoi(argv[1]), std::atoi(argv[2]), (uint32_t)std::atoi(argv[3]), (uint32_t)std::atoi(argv[4]), (uint32_t)std::atoi(argv[5]));
   const int threads = argc > 1 ? std::atoi(argv[1]) : 64;
   const int iters = argc > 2 ? std::atoi(argv[2]) : 200;
   const uint32_t mb = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 256;

@@ -276,6 +276,18 @@ def test_search_multi_entry_follows_the_reference_stream(tmp_path, metric, n, di
     assert nl == g.num_layers
     for layer in range(g.num_layers):
         assert ix.neighbors(layer, n) == g.neighbors(layer, n), layer
-    with pytest.raises(va.VelesHipError):
-        ix.search_multi_entry(Q[:2], 2, 3, 3)         # several entry points need ef >= 4
+    # NativeHnsw's raw ef_search (graph.rs:343): no max(ef, k) — ef < k gives at most ef results; fewer than the entry points
+    # (ef < 4 with several probes) gives as many as there are entry points (uncut `results`, graph.rs:463-468); ef = 0 acts as 1
+    for k2, ef2, probes in ((7, 3, 1), (7, 5, 2), (2, 3, 3), (9, 2, 4), (9, 1, 9), (5, 0, 1), (5, 0, 4), (3, 1, 1)):
+        gid, gsc, gcnt = ix.search_multi_entry(Q, k2, ef2, probes)
+        for qi in range(Q.shape[0]):
+            oid, od = g.search_multi_entry(Q[qi], k2, ef2, probes, po.TIE_CANONICAL)
+            osc = np.array([po.transform_score(PO_METRIC[metric], float(x)) for x in od], dtype=np.float32)
+            assert gcnt[qi] == len(oid) <= max(ef2, min(probes, 4), 1), (k2, ef2, probes, qi, gcnt[qi], len(oid))
+            assert np.array_equal(gid[qi, :gcnt[qi]], oid), (k2, ef2, probes, qi, gid[qi], oid)
+            assert np.array_equal(bits(gsc[qi, :gcnt[qi]]), bits(osc)), (k2, ef2, probes, qi)
+    # ... and the ordinary search entry points keep SearchQuality::Custom's max(ef, k) (params.rs:317)
+    r_small = ix._search_raw(Q[:1], 7, 3, va.MODE_HNSW)
+    r_k = ix._search_raw(Q[:1], 7, 7, va.MODE_HNSW)
+    assert np.array_equal(r_small[0], r_k[0]) and r_small[2][0] == 7
     ix.close()

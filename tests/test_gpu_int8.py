@@ -79,3 +79,49 @@ def test_int8_needs_training():
         ix.insert(i, np.random.default_rng(i).standard_normal(16).astype(np.float32))
     with pytest.raises(va.VelesHipError):
         ix.search_batch_int8(np.zeros((1, 16), np.float32), 5, 64)
+
+
+def test_search_with_config_applies_the_rule_natively_and_takes_the_ratio_per_call(tmp_path):
+    """DualPrecisionHnsw::search_with_config (native/dual_precision.rs:259-278) through vdb_hip_index_search_with_config: the int8
+    traversal only with a trained quantiser AND use_int8_traversal AND len >= min_index_size — decided inside the library from the
+    handle's own state (is_quantizer_trained is read from the handle too) — with the call's OWN oversampling ratio (the handle
+    option VDB_OPT_INT8_OVERSAMPLING is neither read nor written).  Every branch against the oracle: ids + score bits."""
+    rng = np.random.default_rng(77)
+    n, dim, M, efc = 2500, 48, 8, 60
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    g = po.NativeHnsw(dim, po.EUCLIDEAN, M, efc, po.MODE_C)
+    for v in rows:
+        g.insert(v)
+    g.file_dump(str(tmp_path), "native_hnsw")
+    ix = va.HnswIndex(dim, DM.Euclidean, va.HnswParams(M, efc, n))
+    ix.load_reference_files(str(tmp_path), "native_hnsw")
+    qs = rng.standard_normal((6, dim)).astype(np.float32)
+    k, ef = 10, 64
+
+    def f32_walk(q):
+        oid, od = g.search(q, k, ef, po.TIE_CANONICAL)
+        return oid.tolist(), np.array([po.transform_score(po.EUCLIDEAN, float(x)) for x in od], dtype=np.float32)
+
+    def same(res, oid, osc):
+        return [r[0] for r in res] == oid and np.array_equal(bits([r[1] for r in res]), bits(osc))
+
+    assert not ix.is_quantizer_trained()
+    cfg_small = va.DualPrecisionConfig(min_index_size=100)
+    for q in qs:                                   # no quantiser: the plain f32 graph search whatever the config says
+        assert same(ix.search_with_config(q, k, ef, cfg_small), *f32_walk(q))
+    ix.train_quantizer()
+    assert ix.is_quantizer_trained()
+    sq = po.ScalarQuantizer(rows[:1000])
+    codes = sq.quantize(rows)
+    opt_before = ix.get_option(va.OPT_INT8_OVERSAMPLING)
+    for ratio in (1, 4, 7):                        # the call's own ratio: k * ratio of the int8 walk's best are re-scored exactly
+        cfg = va.DualPrecisionConfig(oversampling_ratio=ratio, min_index_size=100)
+        for q in qs:
+            oid, od, _, _ = po.dual_search_int8(g, sq, codes, q, k, ef, ratio, po.TIE_CANONICAL)
+            osc = np.array([po.transform_score(po.EUCLIDEAN, float(x)) for x in od], dtype=np.float32)
+            assert same(ix.search_with_config(q, k, ef, cfg), oid.tolist(), osc), ratio
+    assert ix.get_option(va.OPT_INT8_OVERSAMPLING) == opt_before      # untouched
+    for q in qs:                                   # default config: 2 500 < min_index_size 10 000 => f32 search
+        assert same(ix.search_with_config(q, k, ef), *f32_walk(q))
+        assert same(ix.search_with_config(q, k, ef, va.DualPrecisionConfig(use_int8_traversal=False, min_index_size=0)), *f32_walk(q))
+    ix.close()

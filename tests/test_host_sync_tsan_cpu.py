@@ -51,6 +51,24 @@ def test_protocol_is_race_free_and_every_caller_gets_its_own_answer(model, threa
         assert line["multi_call_launches"] > 0  # callers that arrive together did share launches
 
 
+@pytest.mark.parametrize("threads,iters,max_batch,window_us,launch_us", [(8, 120, 256, 100, 100), (24, 80, 256, 0, 50), (4, 120, 8, 100, 200)])
+@pytest.mark.timeout(120)
+def test_a_sweep_caller_is_not_starved_by_endless_walk_traffic(model, threads, iters, max_batch, window_us, launch_us):
+    """sweeps lead only when NO batch is in flight, graph walks while fewer than two are — so back-to-back walk
+    callers kept a queued sweep caller asleep without bound (round 4's text under this very model: one sweep call waited 22 s while
+    261 782 walk launches went first).  The fairness rule of vdb_combiner.hpp bounds it: once the sweep heads the queue at most
+    kCombineMaxPassed leaders are admitted ahead of it; measured 7-10 launches, < 1.5 ms at a 100-us mock launch."""
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66 second_deadlock_stack=1")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([model, str(threads), str(iters), str(max_batch), str(window_us), str(launch_us), "starve"], env=env,
+                       capture_output=True, text=True, timeout=100)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0, (r.returncode, r.stderr[-4000:], r.stdout[-500:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["ok"] and line["sweep_calls"] == iters and line["worst_launches_ahead"] <= line["bound"]
+    assert line["walk_calls"] > 10 * iters      # the walk traffic really was dense
+
+
 @pytest.fixture(scope="module")
 def mutex_model(tmp_path_factory):
     if shutil.which("g++") is None:

@@ -99,42 +99,38 @@ def test_dual_precision_config_defaults_and_rule():
     assert DualPrecisionConfig(min_index_size=0).takes_int8_traversal(True, 1)
 
 
-def test_search_with_config_dispatches_by_the_rule():
-    """The mirror's HnswIndex.search_with_config sends the call to the int8 mode or to the plain graph mode by that rule and sets the
-    oversampling option — checked on the method itself with the C ABI stubbed out (the modes behind it: tests/test_gpu_int8.py)."""
+def test_search_with_config_passes_the_config_with_the_call(monkeypatch):
+    """The rule itself (trained quantiser AND use_int8_traversal AND len >= min_index_size, dual_precision.rs:259-278) is applied
+    inside the library from the handle's own state (vdb_hip_index_search_with_config; GPU side: tests/test_gpu_int8.py).  The mirror's
+    part is to hand the call's DualPrecisionConfig over unchanged — checked here with the C ABI stubbed out — and the mirror's
+    DualPrecisionConfig.takes_int8_traversal states the same rule for callers that want to know beforehand (test above)."""
     import numpy as np
     import velesdb_amd.index as vi
 
     calls = []
 
+    class FakeLib:
+        def vdb_hip_index_search_with_config(self, h, q, nq, k, ef, ratio, use_int8, min_size, ids, sc, cnt):
+            calls.append((nq, k, ef, ratio, use_int8, min_size))
+            np.ctypeslib.as_array(vi.C.cast(ids, vi.C.POINTER(vi.C.c_uint64)), (k,))[:] = 7
+            np.ctypeslib.as_array(vi.C.cast(sc, vi.C.POINTER(vi.C.c_float)), (k,))[:] = 0.5
+            np.ctypeslib.as_array(vi.C.cast(cnt, vi.C.POINTER(vi.C.c_uint32)), (1,))[:] = k
+            return 0
+
+    monkeypatch.setattr(vi, "lib", lambda: FakeLib())
+
     class Stub(vi.HnswIndex):
-        def __init__(self, n, trained):               # no handle: nothing below reaches the library
-            self._dimension, self._n = 4, n
-            if trained:
-                self._quantizer_trained = True
-
-        def len(self):
-            return self._n
-
-        def set_option(self, option, value):
-            calls.append(("option", option, value))
-
-        def _search_raw(self, queries, k, ef, mode):
-            calls.append(("search", k, ef, mode))
-            return (np.array([[7] * k], dtype=np.uint64), np.array([[0.5] * k], dtype=np.float32), np.array([k], dtype=np.uint32))
+        def __init__(self):               # no handle: nothing below reaches the library
+            self._dimension, self._h = 4, None
 
         def close(self):
             pass
 
     q = [0.0, 1.0, 0.0, 0.0]
-    assert Stub(200, True).search_with_config(q, 2, 50) == [(7, 0.5), (7, 0.5)]
-    assert calls == [("search", 2, 50, vi.MODE_HNSW)]                                             # 200 < min_index_size: f32 search
+    assert Stub().search_with_config(q, 2, 50) == [(7, 0.5), (7, 0.5)]
+    assert calls == [(1, 2, 50, 4, 1, 10_000)]                                                    # DualPrecisionConfig::default
     calls.clear()
-    Stub(20_000, True).search_with_config(q, 3, 64, DualPrecisionConfig(oversampling_ratio=8))
-    assert calls == [("option", vi.OPT_INT8_OVERSAMPLING, 8), ("search", 3, 64, vi.MODE_HNSW_INT8)]
-    calls.clear()
-    Stub(20_000, False).search_with_config(q, 3, 64)
-    assert calls == [("search", 3, 64, vi.MODE_HNSW)]                                             # quantiser never trained
+    Stub().search_with_config(q, 3, 64, DualPrecisionConfig(oversampling_ratio=8, use_int8_traversal=False, min_index_size=123))
+    assert calls == [(1, 3, 64, 8, 0, 123)]
     with pytest.raises(AssertionError, match="dimension mismatch"):
-        Stub(20_000, True).search_with_config([0.0, 1.0], 3, 64)
-
+        Stub().search_with_config([0.0, 1.0], 3, 64)

@@ -7,6 +7,8 @@
 //! | [`HipHnswIndex`] + `impl VectorIndex` | `HnswIndex` (`index/hnsw/index/*.rs`), `impl VectorIndex for HnswIndex` (`trait_impl.rs:8-71`) |
 //! | [`HipDistance`] + `impl DistanceEngine` | `SimdDistance` / `NativeSimdDistance` (`index/hnsw/native/distance.rs:14-28,60-160`) |
 //! | [`HipAccelerator`] | `GpuAccelerator` (`gpu/gpu_backend.rs:33,136,157,355,397`) |
+//! | [`HipDualPrecisionHnsw`] + [`DualPrecisionConfig`] | `DualPrecisionHnsw` (`index/hnsw/native/dual_precision.rs:32-57,88-321`) |
+//! | [`simd`] free functions | `simd::norm`, `normalize_inplace`, `simd_explicit::batch_dot_product`, `hamming_distance_binary`, `jaccard_similarity_binary` |
 //!
 //! Error behaviour follows the reference: dimension mismatches panic with the reference's messages
 //! (`index/hnsw/index/search.rs:16-27`, `trait_impl.rs:12-18`), a duplicate id is silently skipped (`trait_impl.rs:23-25`),
@@ -716,6 +718,141 @@ impl VectorIndex for HipHnswIndex {
 }
 
 impl HipHnswIndex {
+    /// `vdb_hip_index_shard_info`: (devices behind the handle, shard mode as created, rank, world, transport of the exchange:
+    /// 0 none, 1 RCCL, 2 device-to-device copies).
+    #[must_use]
+    pub fn shard_info(&self) -> (usize, ShardMode, usize, usize, i32) {
+        let (mut n, mut mode, mut rank, mut world, mut transport) = (0i32, 0i32, 0i32, 0i32, 0i32);
+        // SAFETY: live handle, five valid out pointers.
+        check(unsafe { sys::vdb_hip_index_shard_info(self.h, &mut n, &mut mode, &mut rank, &mut world, &mut transport) });
+        let mode = if mode == sys::VDB_SHARD_RANGE { ShardMode::Range } else { ShardMode::Replica };
+        (n as usize, mode, rank as usize, world as usize, transport)
+    }
+
+    /// Keeps a bf16 (round-to-nearest-even) copy of the rows for [`Self::search_batch_brute_force_bf16`]
+    /// (`half_precision.rs:199-255` semantics: bf16 operands, f32 accumulation).
+    pub fn enable_bf16(&self) {
+        // SAFETY: live handle.
+        check(unsafe { sys::vdb_hip_index_enable_bf16(self.h) });
+    }
+
+    fn search_batch_mode(&self, queries: &[&[f32]], k: usize, ef: usize, mode: i32) -> Vec<Vec<(u64, f32)>> {
+        if queries.is_empty() || k == 0 {
+            return queries.iter().map(|_| Vec::new()).collect();
+        }
+        let mut flat = Vec::with_capacity(queries.len() * self.dimension);
+        for q in queries {
+            self.validate_dimension(q, "Query");
+            flat.extend_from_slice(q);
+        }
+        let nq = queries.len();
+        let mut ids = vec![0u64; nq * k];
+        let mut scores = vec![0f32; nq * k];
+        let mut n = vec![0u32; nq];
+        // SAFETY: nq row-major queries of `dimension` floats; nq * k outputs; nq counts.
+        check(unsafe {
+            sys::vdb_hip_index_search_batch(
+                self.h,
+                flat.as_ptr(),
+                nq as u32,
+                k as u32,
+                ef as u32,
+                mode,
+                ids.as_mut_ptr(),
+                scores.as_mut_ptr(),
+                n.as_mut_ptr(),
+            )
+        });
+        (0..nq).map(|i| (0..n[i] as usize).map(|j| (ids[i * k + j], scores[i * k + j])).collect()).collect()
+    }
+
+    /// Exact scan with bf16 rows and queries on the matrix cores (BASELINE configs[3]); needs [`Self::enable_bf16`].
+    #[must_use]
+    pub fn search_batch_brute_force_bf16(&self, queries: &[&[f32]], k: usize) -> Vec<Vec<(u64, f32)>> {
+        self.search_batch_mode(queries, k, 0, sys::VDB_SEARCH_BRUTE_BF16)
+    }
+
+    /// `StorageMode::SQ8` collections: asymmetric distances against the stored codes (`quantization.rs:410-554`).
+    #[must_use]
+    pub fn search_batch_sq8(&self, queries: &[&[f32]], k: usize) -> Vec<Vec<(u64, f32)>> {
+        self.search_batch_mode(queries, k, 0, sys::VDB_SEARCH_BRUTE_SQ8)
+    }
+
+    /// `StorageMode::Binary` collections: Hamming distance between sign bits (`quantization.rs:48-136`).
+    #[must_use]
+    pub fn search_batch_binary(&self, queries: &[&[f32]], k: usize) -> Vec<Vec<(u64, f32)>> {
+        self.search_batch_mode(queries, k, 0, sys::VDB_SEARCH_BRUTE_BINARY)
+    }
+
+    /// The stored code of one vector in the reference's serialisation: `QuantizedVector::to_bytes`
+    /// (`quantization.rs:289-295`) or `BinaryQuantizedVector::to_bytes` (`:155-169`).  `None` for an unknown id.
+    #[must_use]
+    pub fn get_quantized(&self, id: u64) -> Option<Vec<u8>> {
+        let mut len: usize = 0;
+        // SAFETY: a size query: no output buffer, `len` a valid out pointer.
+        let rc = unsafe { sys::vdb_hip_index_get_quantized(self.h, id, ptr::null_mut(), 0, &mut len) };
+        if rc < 0 || len == 0 {
+            return None;
+        }
+        let mut out = vec![0u8; len];
+        // SAFETY: `out` holds `len` bytes.
+        check(unsafe { sys::vdb_hip_index_get_quantized(self.h, id, out.as_mut_ptr(), out.len(), &mut len) });
+        out.truncate(len);
+        Some(out)
+    }
+
+    /// Rows that already live in device memory (`d_vecs_rowmajor`: n x dimension f32, ids id_base ..), enqueued on `stream`.
+    ///
+    /// # Safety
+    /// `d_vecs_rowmajor` must be a device pointer to at least `n * dimension` floats that stays valid until the work
+    /// enqueued on `stream` (a `hipStream_t`, or null for the default stream) has completed.
+    pub unsafe fn upload_dev(&self, id_base: u64, d_vecs_rowmajor: *const f32, n: usize, stream: *mut c_void) {
+        check(sys::vdb_hip_index_upload_dev(self.h, id_base, d_vecs_rowmajor, n as u64, stream));
+    }
+
+    /// `NativeHnsw::file_dump` (`backend_adapter.rs:184-284`): `<dir>/<basename>.vectors` + `.graph`, reference format v1.
+    pub fn file_dump<P: AsRef<Path>>(&self, dir: P, basename: &str) -> io::Result<()> {
+        let d = c_path(dir)?;
+        let b = CString::new(basename).map_err(|e| io::Error::new(io::ErrorKind::InvalidInput, e))?;
+        // SAFETY: two NUL-terminated strings that outlive the call.
+        io_check(unsafe { sys::vdb_hip_index_save_reference_files(self.h, d.as_ptr(), b.as_ptr()) })
+    }
+
+    /// `NativeHnsw::file_load` (`backend_adapter.rs:286-381`) into this (empty) index.
+    pub fn file_load<P: AsRef<Path>>(&self, dir: P, basename: &str) -> io::Result<()> {
+        let d = c_path(dir)?;
+        let b = CString::new(basename).map_err(|e| io::Error::new(io::ErrorKind::InvalidInput, e))?;
+        // SAFETY: as above.
+        io_check(unsafe { sys::vdb_hip_index_load_reference_files(self.h, d.as_ptr(), b.as_ptr()) })
+    }
+
+    /// (layers, max layer, entry point) of the graph (`NativeHnsw` state, `graph.rs:36-70`).
+    #[must_use]
+    pub fn graph_info(&self) -> (usize, usize, Option<usize>) {
+        let (mut nl, mut ml, mut ep) = (0u32, 0u32, -1i64);
+        // SAFETY: live handle, three valid out pointers.
+        check(unsafe { sys::vdb_hip_index_graph_info(self.h, &mut nl, &mut ml, &mut ep) });
+        (nl as usize, ml as usize, if ep < 0 { None } else { Some(ep as usize) })
+    }
+
+    /// `Layer::get_neighbors` (`layer.rs:41-47`) of an internal node.
+    #[must_use]
+    pub fn neighbors(&self, layer: usize, node: usize) -> Vec<u32> {
+        let mut n: u32 = 0;
+        let mut out = vec![0u32; 256];
+        // SAFETY: `out` holds `cap` ids.
+        check(unsafe { sys::vdb_hip_index_get_neighbors(self.h, layer as u32, node as u64, out.as_mut_ptr(), out.len() as u32, &mut n) });
+        if n as usize > out.len() {
+            out.resize(n as usize, 0);
+            // SAFETY: as above, with room for all of them.
+            check(unsafe { sys::vdb_hip_index_get_neighbors(self.h, layer as u32, node as u64, out.as_mut_ptr(), out.len() as u32, &mut n) });
+        }
+        out.truncate(n as usize);
+        out
+    }
+}
+
+impl HipHnswIndex {
     /// The index side of `Collection::search_with_filter` (`collection/search/vector.rs:164-235`): post-filtering over an
     /// over-fetched candidate list — `candidates_k = max(4 k, k + 10)` through `VectorIndex::search`, the ids `keep` rejects
     /// dropped, the first `k` survivors kept, then a stable sort in the metric's order (`partial_cmp`, incomparable = Equal).
@@ -807,6 +944,229 @@ impl Drop for HipHnswIndex {
     fn drop(&mut self) {
         // SAFETY: the handle was created by the library and is destroyed exactly once.
         unsafe { sys::vdb_hip_index_destroy(self.h) }
+    }
+}
+
+/// `DualPrecisionConfig` (`native/dual_precision.rs:32-57`), passed with every call exactly as the reference passes it.
+#[derive(Debug, Clone)]
+pub struct DualPrecisionConfig {
+    /// Candidates of the int8 walk that are re-scored exactly = `k * oversampling_ratio` (default 4).
+    pub oversampling_ratio: usize,
+    /// Use int8 quantised distances for the graph traversal (default true).
+    pub use_int8_traversal: bool,
+    /// Smaller indexes use the f32 graph search (default 10 000).
+    pub min_index_size: usize,
+    /// Accepted for source compatibility; the library keeps its timings in `vdb_hip_index_last_kernel_ms`.
+    pub debug_timings: bool,
+}
+
+impl Default for DualPrecisionConfig {
+    fn default() -> Self {
+        // dual_precision.rs:47-56
+        Self { oversampling_ratio: 4, use_int8_traversal: true, min_index_size: 10_000, debug_timings: false }
+    }
+}
+
+/// `DualPrecisionHnsw` (`native/dual_precision.rs:59-321`): f32 graph + per-dimension min/max `ScalarQuantizer` codes
+/// (`native/quantization.rs:191-251`), int8 traversal with exact f32 re-scoring.  Node ids are insertion order, as in the
+/// reference (`insert` returns the `NodeId`).
+pub struct HipDualPrecisionHnsw {
+    inner: HipHnswIndex,
+    training_sample_size: usize,
+}
+
+impl HipDualPrecisionHnsw {
+    /// `DualPrecisionHnsw::new` (`dual_precision.rs:88-106`).  `None` without a HIP device.
+    #[must_use]
+    pub fn new(metric: DistanceMetric, dimension: usize, max_connections: usize, ef_construction: usize, max_elements: usize) -> Option<Self> {
+        let mut params = HnswParams::auto(dimension);
+        params.max_connections = max_connections;
+        params.ef_construction = ef_construction;
+        params.max_elements = max_elements;
+        let inner = HipHnswIndex::with_params(dimension, metric, params)?;
+        Some(Self { inner, training_sample_size: 1000.min(max_elements) })
+    }
+
+    /// `DualPrecisionHnsw::len` (`dual_precision.rs:108-111`)
+    #[must_use]
+    pub fn len(&self) -> usize {
+        VectorIndex::len(&self.inner)
+    }
+
+    /// `DualPrecisionHnsw::is_empty` (`dual_precision.rs:113-116`)
+    #[must_use]
+    pub fn is_empty(&self) -> bool {
+        self.len() == 0
+    }
+
+    /// `DualPrecisionHnsw::is_quantizer_trained` (`dual_precision.rs:118-121`), read from the handle.
+    #[must_use]
+    pub fn is_quantizer_trained(&self) -> bool {
+        let mut t: i32 = 0;
+        // SAFETY: live handle, valid out pointer.
+        check(unsafe { sys::vdb_hip_index_quantizer_trained(self.inner.h, &mut t) });
+        t != 0
+    }
+
+    /// `DualPrecisionHnsw::insert` (`dual_precision.rs:127-150`): the node id is the insertion order; the quantiser is trained
+    /// once `training_sample_size` vectors are in, later rows are encoded as they arrive (the library does that itself).
+    pub fn insert(&mut self, vector: Vec<f32>) -> usize {
+        let node_id = self.len();
+        VectorIndex::insert(&self.inner, node_id as u64, &vector);
+        if !self.is_quantizer_trained() && self.len() >= self.training_sample_size {
+            self.train(self.training_sample_size);
+        }
+        node_id
+    }
+
+    fn train(&self, sample_rows: usize) {
+        // SAFETY: live handle.
+        check(unsafe { sys::vdb_hip_index_train_quantizer(self.inner.h, sample_rows as u32) });
+    }
+
+    /// `DualPrecisionHnsw::force_train_quantizer` (`dual_precision.rs:181-185`): train on what is there.
+    pub fn force_train_quantizer(&mut self) {
+        if !self.is_quantizer_trained() && !self.is_empty() {
+            self.train(self.len().min(self.training_sample_size.max(1)));
+        }
+    }
+
+    /// `DualPrecisionHnsw::search` (`dual_precision.rs:195-205`): without a quantiser the f32 graph search; with one
+    /// `search_dual_precision` (`:216-250`) — an f32 walk for `max(2 ef, 4 k)` candidates re-ranked by exact distance, which
+    /// is `search_with_rerank_quality` of the index under it.
+    #[must_use]
+    pub fn search(&self, query: &[f32], k: usize, ef_search: usize) -> Vec<(u64, f32)> {
+        if !self.is_quantizer_trained() {
+            let q = [query];
+            return self.inner.search_batch_parallel(&q, k, SearchQuality::Custom(ef_search)).pop().unwrap_or_default();
+        }
+        let rerank_k = (ef_search * 2).max(k * 4);
+        self.inner.search_with_rerank_quality(query, k, rerank_k, SearchQuality::Custom(ef_search))
+    }
+
+    /// `DualPrecisionHnsw::search_with_config` (`dual_precision.rs:259-278`): int8 traversal only with a trained quantiser,
+    /// `use_int8_traversal` and at least `min_index_size` vectors — decided inside the library from the call's own config.
+    #[must_use]
+    pub fn search_with_config(&self, query: &[f32], k: usize, ef_search: usize, config: &DualPrecisionConfig) -> Vec<(u64, f32)> {
+        self.inner.validate_dimension(query, "Query");
+        if k == 0 {
+            return Vec::new();
+        }
+        let mut ids = vec![0u64; k];
+        let mut scores = vec![0f32; k];
+        let mut n: u32 = 0;
+        // SAFETY: one query of `dimension` floats, k outputs.
+        check(unsafe {
+            sys::vdb_hip_index_search_with_config(
+                self.inner.h,
+                query.as_ptr(),
+                1,
+                k as u32,
+                ef_search as u32,
+                config.oversampling_ratio.max(1) as u32,
+                i32::from(config.use_int8_traversal),
+                config.min_index_size as u64,
+                ids.as_mut_ptr(),
+                scores.as_mut_ptr(),
+                &mut n,
+            )
+        });
+        ids.truncate(n as usize);
+        scores.truncate(n as usize);
+        ids.into_iter().zip(scores).collect()
+    }
+
+    /// The index under it (exact search, persistence, options).
+    #[must_use]
+    pub fn inner(&self) -> &HipHnswIndex {
+        &self.inner
+    }
+}
+
+/// Process-wide default of the int8 walk's oversampling for callers of `VDB_SEARCH_HNSW_INT8` that pass none
+/// ([`HipDualPrecisionHnsw::search_with_config`] passes its own per call).
+pub fn set_default_int8_oversampling(ratio: usize) {
+    // SAFETY: no pointers.
+    check(unsafe { sys::vdb_hip_set_int8_oversampling(ratio as u32) });
+}
+
+/// The free functions of the reference's SIMD module on the path, n vectors per call on device 0 (`vec_utils.hip`).
+pub mod simd {
+    use super::{check, sys};
+
+    /// `simd::norm` / `simd_explicit::norm_simd` (`simd.rs:240-242`; `simd_explicit.rs:194-215`) for every row.
+    #[must_use]
+    pub fn batch_norm(vectors_rowmajor: &[f32], dimension: usize) -> Vec<f32> {
+        assert!(dimension > 0 && vectors_rowmajor.len() % dimension == 0, "rows must be whole vectors");
+        let n = vectors_rowmajor.len() / dimension;
+        let mut out = vec![0f32; n];
+        // SAFETY: n rows of `dimension` floats in, n floats out.
+        check(unsafe { sys::vdb_hip_batch_norm(0, vectors_rowmajor.as_ptr(), n as u64, dimension as u32, out.as_mut_ptr()) });
+        out
+    }
+
+    /// `simd::normalize_inplace` (`simd.rs:217-219`; `simd_explicit.rs:638-664`) for every row; a zero vector stays as it is.
+    pub fn normalize_rows(vectors_rowmajor: &mut [f32], dimension: usize) {
+        assert!(dimension > 0 && vectors_rowmajor.len() % dimension == 0, "rows must be whole vectors");
+        let n = vectors_rowmajor.len() / dimension;
+        // SAFETY: n rows of `dimension` floats, rewritten in place.
+        check(unsafe { sys::vdb_hip_normalize_rows(0, vectors_rowmajor.as_mut_ptr(), n as u64, dimension as u32) });
+    }
+
+    /// `simd_explicit::batch_dot_product` (`simd_explicit.rs:519-560`): `out[i * n + j] = dot(queries[i], vectors[j])`.
+    #[must_use]
+    pub fn batch_dot_product(queries_rowmajor: &[f32], vectors_rowmajor: &[f32], dimension: usize) -> Vec<f32> {
+        assert!(dimension > 0 && queries_rowmajor.len() % dimension == 0 && vectors_rowmajor.len() % dimension == 0, "rows must be whole vectors");
+        let (nq, n) = (queries_rowmajor.len() / dimension, vectors_rowmajor.len() / dimension);
+        let mut out = vec![0f32; nq * n];
+        // SAFETY: nq and n rows of `dimension` floats in, nq * n floats out.
+        check(unsafe {
+            sys::vdb_hip_batch_dot_product(0, queries_rowmajor.as_ptr(), nq as u32, vectors_rowmajor.as_ptr(), n as u64, dimension as u32, out.as_mut_ptr())
+        });
+        out
+    }
+
+    /// `hamming_distance_binary(_fast)` (`simd_explicit.rs:308-360`): one packed query against n packed rows of `words` u64.
+    #[must_use]
+    pub fn batch_hamming_binary(query_words: &[u64], rows_words: &[u64]) -> Vec<u32> {
+        let words = query_words.len();
+        assert!(words > 0 && rows_words.len() % words == 0, "rows must be whole bit vectors");
+        let n = rows_words.len() / words;
+        let mut out = vec![0u32; n];
+        // SAFETY: `words` u64 per vector, n outputs.
+        check(unsafe { sys::vdb_hip_batch_hamming_binary(0, query_words.as_ptr(), rows_words.as_ptr(), n as u64, words as u32, out.as_mut_ptr()) });
+        out
+    }
+
+    /// `jaccard_similarity_binary` (`simd_explicit.rs:457-500`): one packed query against n packed rows of `words` u64.
+    #[must_use]
+    pub fn batch_jaccard_binary(query_words: &[u64], rows_words: &[u64]) -> Vec<f32> {
+        let words = query_words.len();
+        assert!(words > 0 && rows_words.len() % words == 0, "rows must be whole bit vectors");
+        let n = rows_words.len() / words;
+        let mut out = vec![0f32; n];
+        // SAFETY: as above.
+        check(unsafe { sys::vdb_hip_batch_jaccard_binary(0, query_words.as_ptr(), rows_words.as_ptr(), n as u64, words as u32, out.as_mut_ptr()) });
+        out
+    }
+
+    /// `DistanceEngine::batch_distance` over rows that already live in device memory, enqueued on `stream`.
+    ///
+    /// # Safety
+    /// `d_query` (dim floats), `d_vectors_rowmajor` (n * dim floats) and `d_out` (n floats) must be device pointers that stay
+    /// valid until the work enqueued on `stream` has completed.
+    #[allow(clippy::too_many_arguments)]
+    pub unsafe fn batch_distance_dev(
+        metric: i32,
+        kind: i32,
+        d_query: *const f32,
+        d_vectors_rowmajor: *const f32,
+        n: usize,
+        dimension: usize,
+        d_out: *mut f32,
+        stream: *mut std::os::raw::c_void,
+    ) {
+        check(sys::vdb_hip_batch_distance_dev(metric, kind, d_query, d_vectors_rowmajor, n as u64, dimension as u32, d_out, stream));
     }
 }
 

@@ -95,6 +95,8 @@ extern "C" {
     pub fn vdb_hip_index_insert_batch(idx: *mut VdbHipIndex, ids: *const u64, vecs_rowmajor: *const f32, n: u64, inserted: *mut u64) -> i32;
     pub fn vdb_hip_index_insert_batch_parallel(idx: *mut VdbHipIndex, ids: *const u64, vecs_rowmajor: *const f32, n: u64, max_batch: u32, inserted: *mut u64) -> i32;
     pub fn vdb_hip_index_train_quantizer(idx: *mut VdbHipIndex, sample_rows: u32) -> i32;
+    pub fn vdb_hip_index_quantizer_trained(idx: *const VdbHipIndex, trained: *mut i32) -> i32;
+    pub fn vdb_hip_index_search_with_config(idx: *mut VdbHipIndex, queries_rowmajor: *const f32, nq: u32, k: u32, ef_search: u32, oversampling_ratio: u32, use_int8_traversal: i32, min_index_size: u64, out_ids: *mut u64, out_scores: *mut f32, out_n: *mut u32) -> i32;
     pub fn vdb_hip_set_int8_oversampling(ratio: u32) -> i32;
     pub fn vdb_hip_index_set_storage_mode(idx: *mut VdbHipIndex, mode: i32) -> i32;
     pub fn vdb_hip_index_get_quantized(idx: *mut VdbHipIndex, id: u64, out: *mut u8, cap: usize, len: *mut usize) -> i32;

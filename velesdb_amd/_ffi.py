@@ -52,6 +52,8 @@ SIGNATURES = {
     "vdb_hip_index_set_storage_mode": (_i32, [_vp, _i32]),
     "vdb_hip_index_get_quantized": (_i32, [_vp, _u64, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "vdb_hip_index_train_quantizer": (_i32, [_vp, _u32]),
+    "vdb_hip_index_quantizer_trained": (_i32, [_vp, _pi32]),
+    "vdb_hip_index_search_with_config": (_i32, [_vp, _vp, _u32, _u32, _u32, _u32, _i32, _u64, _vp, _vp, _vp]),
     "vdb_hip_set_int8_oversampling": (_i32, [_u32]),
     "vdb_hip_index_upload": (_i32, [_vp, _vp, _vp, _u64, _pu64]),
     "vdb_hip_index_upload_dev": (_i32, [_vp, _u64, _vp, _u64, _vp]),

@@ -63,14 +63,21 @@ enum Phase : int {
 // registers = three walks per CU; the walk is a chain of dependent memory round trips, and the rows in flight per CU are what
 // the chip's random-gather bandwidth follows: 126 registers (no scratch) took the 8 192-query launch at 1 M x 768, ef 128 from
 // 49.1 to 42.1 ms on one box (0.61 -> 0.72 of HBM; profiles/r04m_f32_walk_occupancy_ab.log), same ids / scores / counters.
-template <int METRIC, int CPL, int NS, bool LAT = false, bool VIS = false>
+// RAWEF: NativeHnsw-level calls whose ef_search may be smaller than the number of layer-0 entry points (search_multi_entry with
+// ef_search < 4 and several probes, or ef_search = 0): ef is then raised per query at the layer-0 start (see P_START).  Only the
+// generic instance (LDS list, any dimension) exists in this form: in every other instance ef stays the launch constant it was —
+// as a loop-carried value it put 48 bytes of the register-list instances into scratch memory.
+template <int METRIC, int CPL, int NS, bool LAT = false, bool VIS = false, bool RAWEF = false>
 __global__ __launch_bounds__(LAT ? 1024 : 256, 4) void hnsw_search_kernel(HnswSearchArgs a) {
   constexpr bool BITS = (METRIC == kHamming || METRIC == kJaccard);
   constexpr int WAVES = LAT ? 16 : 4, TPB = WAVES * 64, RR = LAT ? 4 : 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id();
   const int wib = (int)rfl(threadIdx.x >> 6);
-  const uint32_t cap = a.cap, nbmax = a.nbmax, ef = a.ef;
+  const uint32_t cap = a.cap, nbmax = a.nbmax;
+  const uint32_t ef_launch = a.ef;
+  uint32_t ef_query = a.ef;  // RAWEF only (wave-uniform)
+#define ef (RAWEF ? ef_query : ef_launch)
   lds_vu64* keys = (lds_vu64*)(lds_void_p)(smem);
   lds_vu32* nb_id = (lds_vu32*)(lds_void_p)(smem + (size_t)cap * 8);
   lds_vf32* nb_d = (lds_vf32*)(lds_void_p)(smem + (size_t)cap * 8 + (size_t)nbmax * 4);
@@ -166,6 +173,12 @@ __global__ __launch_bounds__(LAT ? 1024 : 256, 4) void hnsw_search_kernel(HnswSe
                 m++;
               }
             }
+            // graph.rs:463-468 pushes EVERY entry point into `results` with no cut, and graph.rs:503-509 pops at most one entry per
+            // push: with more entry points than ef_search the result set simply stays at that size — which is what a search with
+            // ef = the number of entry points does from its first step (results full from the start: same admission test
+            // `dist < furthest`, same single pop, same stop rule `len >= ef`).  Only NativeHnsw-level calls get here with ef < m:
+            // search_multi_entry with ef_search < 4 and several probes, or ef_search = 0 (which therefore acts as 1).
+            if (RAWEF && layer == 0) ef_query = max(ef_launch, m);
             ready = true;
             phase = layer > 0 ? P_G_ENTRY : P_Z_ENTRY;
           } else if (phase == P_G_ENTRY) {
@@ -500,6 +513,7 @@ size_t hnsw_lds_bytes(uint32_t cap, uint32_t nbmax, uint32_t dim, uint32_t words
 }
 
 // latency mode: one 1 024-thread block per query (at most one query per CU per call)
+#undef ef
 template <int METRIC, int CPL, bool VIS>
 static hipError_t launch_lat_v(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
   if (lds > 64 * 1024) {
@@ -599,9 +613,36 @@ static uint32_t pick_vis(const HnswSearchArgs& a, size_t lds, bool lat) {
   return 0;
 }
 
+template <int METRIC>
+static hipError_t launch_raw_ef(const HnswSearchArgs& a, int slots, size_t lds, hipStream_t st) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_search_kernel<METRIC, 0, 0, false, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  int occ = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, hnsw_search_kernel<METRIC, 0, 0, false, false, true>, 256, lds);
+  if (e != hipSuccess) return e;
+  occ = std::max(1, std::min(occ, 4));
+  const int grid = (int)std::min<int64_t>((int64_t)slots, (int64_t)a.n_cus * occ);
+  hipLaunchKernelGGL((hnsw_search_kernel<METRIC, 0, 0, false, false, true>), dim3(grid), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_hnsw_search(const HnswSearchArgs& a0, int slots, hipStream_t st) {
   HnswSearchArgs a = a0;
   size_t lds = hnsw_lds_bytes(a.cap, a.nbmax, a.dim, a.words, a.metric);
+  if (a.raw_small_ef) {  // NativeHnsw-level call with ef_search < 4: the generic instance that raises ef to the entry points per query
+    a.vis_log2 = 0;      // (HBM bitmaps)
+    a.pf_ids = 0;
+    switch (a.metric) {
+      case kCosine: return launch_raw_ef<kCosine>(a, slots, lds, st);
+      case kEuclidean: return launch_raw_ef<kEuclidean>(a, slots, lds, st);
+      case kDot: return launch_raw_ef<kDot>(a, slots, lds, st);
+      case kHamming: return launch_raw_ef<kHamming>(a, slots, lds, st);
+      default: return launch_raw_ef<kJaccard>(a, slots, lds, st);
+    }
+  }
   // at most one query per CU (measured at 1 M x 768, ef 128: 64 queries 1.57 ms against 2.68 ms on the throughput kernel, 256
   // queries 2.12 against 3.21 ms — a 1 024-thread block per CU is all the chip holds of this kernel) over a corpus that does not
   // sit in the 256 MB Infinity Cache: the latency-mode kernel (f32 metrics,
@@ -682,7 +723,8 @@ int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   uint64_t cap = (uint64_t)ef + std::max<uint64_t>(64, (uint64_t)ef * cap_mult / 2);
   cap = (cap + 63) / 64 * 64;
   // small ef: the list lives in registers (first attempt only; an overflow re-run uses the larger LDS list)
-  const bool reg_list = cap_mult == 1 && rerank_k == 0 && (uint64_t)ef + 64 <= (uint64_t)kSearchRegSlots * 64 &&
+  const bool raw_small = ix->raw_ef && ef < 4;  // (search_multi_entry: more entry points than ef_search are possible)
+  const bool reg_list = !raw_small && cap_mult == 1 && rerank_k == 0 && (uint64_t)ef + 64 <= (uint64_t)kSearchRegSlots * 64 &&
                         ix->n_rows < (1ull << 31);
   if (reg_list) cap = (uint64_t)kSearchRegSlots * 64;
   const size_t lds = hnsw_lds_bytes((uint32_t)cap, nbmax, ix->dim, ix->words, ix->metric);
@@ -725,6 +767,7 @@ int32_t hnsw_search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   a.metric = ix->metric;
   a.rerank_k = rerank_k;
   a.extra_eps = d_extra_eps;
+  a.raw_small_ef = raw_small ? 1u : 0u;
   a.list_slots = reg_list ? kSearchRegSlots : 0;
   a.vis_log2 = cap_mult == 1 ? 1u : 0u;  // "the LDS visited set is allowed" (a re-run after an overflow takes the bitmap)
   a.n_cus = (uint32_t)ix->n_cus;

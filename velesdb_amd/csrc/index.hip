@@ -309,7 +309,11 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
   // the lazily built selection images grow HERE (exclusive lock), never inside a search (shared lock: other contexts hold views)
   if (ix->l2_img.cap && (e = ix->l2_img.reserve((ncap + kRowSlack) * (size_t)(ix->dim + 64) * 2, true, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("grow Euclidean selection image: ") + hipGetErrorString(e));
-  if (ix->sq8_img.cap && ((e = ix->sq8_img.reserve((ncap + kRowSlack) * (size_t)(ix->dim + (ix->metric == VDB_EUCLIDEAN ? 64 : 0)) * 2, true, st)) != hipSuccess ||
+  // (storage mode Binary keeps its four-bit sign image in sq8_img, bits_image_stride(dim) bytes per row — storage_modes.hip
+  // ensure_sign_image; the SQ8 mode its dequantised bf16 image, dim [+ 64] two-byte elements per row)
+  const size_t sq8_img_row = ix->storage_mode == VDB_STORAGE_BINARY ? (size_t)bits_image_stride(ix->dim)
+                                                                    : (size_t)(ix->dim + (ix->metric == VDB_EUCLIDEAN ? 64 : 0)) * 2;
+  if (ix->sq8_img.cap && ((e = ix->sq8_img.reserve((ncap + kRowSlack) * sq8_img_row, true, st)) != hipSuccess ||
                           (e = ix->sq8_nrm.reserve((ncap + kRowSlack) * 4, true, st)) != hipSuccess))
     return fail(VDB_ERR_OOM, std::string("grow SQ8 selection image: ") + hipGetErrorString(e));
   if (ix->bits_img.cap && ((e = ix->bits_img.reserve((ncap + kRowSlack) * (size_t)bits_image_stride(ix->dim), true, st)) != hipSuccess ||
@@ -865,7 +869,8 @@ int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint3
   if (mode == VDB_SEARCH_HNSW_INT8) {
     if (used_hnsw) *used_hnsw = true;
     ix->last_kernels |= VDB_KERNEL_HNSW_INT8;
-    return hnsw_search_int8_dev(ix, d_q, q_stride, nq, k, ef == 0 ? balanced_ef(k) : ef, opt_oversampling(ix), cap_mult,
+    // (rerank_k in this mode: the call's own DualPrecisionConfig::oversampling_ratio, vdb_hip_index_search_with_config; 0 = the handle's option)
+    return hnsw_search_int8_dev(ix, d_q, q_stride, nq, k, ef == 0 ? balanced_ef(k) : ef, rerank_k ? rerank_k : opt_oversampling(ix), cap_mult,
                                 d_ids, d_scores, d_n, st);
   }
   if (mode != VDB_SEARCH_AUTO && mode != VDB_SEARCH_HNSW) return fail(VDB_ERR_INVALID_ARG, "bad search mode");
@@ -874,8 +879,8 @@ int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint3
     if (ef == 0) ef = std::max<uint32_t>(512, rerank_k * 16);  // SearchQuality::Accurate, params.rs:314
     ef = std::max(ef, rerank_k);
   } else {
-    if (ef == 0) ef = balanced_ef(k);
-    ef = std::max(ef, k);  // SearchQuality::Custom(ef) = max(ef, k), params.rs:317
+    if (ef == 0 && !ix->raw_ef) ef = balanced_ef(k);
+    if (!ix->raw_ef) ef = std::max(ef, k);  // SearchQuality::Custom(ef) = max(ef, k), params.rs:317 (NativeHnsw-level calls pass theirs as is)
   }
   if (used_hnsw) *used_hnsw = true;
   ix->last_kernels |= VDB_KERNEL_HNSW;

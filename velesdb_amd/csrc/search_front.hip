@@ -51,7 +51,7 @@ static int32_t run_search(vdb_hip_index* handle, uint32_t nq, uint32_t k, uint32
   if (ix->pcomm && k) {  // member of a process group: every rank ends with the global top-k
     hipStream_t st = ix->stream;
     const int32_t m = (mode == VDB_SEARCH_AUTO) ? (ix->live <= 100 ? VDB_SEARCH_BRUTE : VDB_SEARCH_HNSW) : mode;
-    rc = pcomm_exchange_merge(ix, nq, k, mode_higher_is_better(ix->metric, rerank_k ? VDB_SEARCH_BRUTE : m), ix->s_out_ids.as<uint64_t>(),
+    rc = pcomm_exchange_merge(ix, nq, k, mode_higher_is_better(ix->metric, (rerank_k && mode != VDB_SEARCH_HNSW_INT8) ? VDB_SEARCH_BRUTE : m), ix->s_out_ids.as<uint64_t>(),
                               ix->s_out_scores.as<float>(), ix->s_out_n.as<uint32_t>(), st);
     if (rc != VDB_OK) return rc;
     VDB_HIP(hipMemcpyAsync(ix->h_out.p, ix->s_out.p, ix->s_out_bytes, hipMemcpyDeviceToHost, st));
@@ -196,6 +196,31 @@ int32_t vdb_hip_index_search_rerank(vdb_hip_index* ix, const float* queries, uin
   });
 }
 
+// DualPrecisionHnsw::is_quantizer_trained — native/dual_precision.rs:117-120
+int32_t vdb_hip_index_quantizer_trained(const vdb_hip_index* ix, int32_t* trained) {
+  return vdb::guarded([&]() -> int32_t {
+    if (!ix || !trained) return fail(VDB_ERR_INVALID_ARG, "null argument");
+    *trained = ix->quantizer_trained ? 1 : 0;  // (a plain bool, written under the exclusive lock by train_quantizer only)
+    return VDB_OK;
+  });
+}
+
+// DualPrecisionHnsw::search_with_config — native/dual_precision.rs:259-278: the int8 traversal (+ exact f32 re-scoring of the
+// k * oversampling_ratio best) only with a trained quantiser, use_int8_traversal and at least min_index_size vectors; otherwise
+// the plain f32 graph search.  The configuration travels WITH the call, as in the reference.
+int32_t vdb_hip_index_search_with_config(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef_search,
+                                         uint32_t oversampling_ratio, int32_t use_int8_traversal, uint64_t min_index_size,
+                                         uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
+  return vdb::guarded([&]() -> int32_t {
+    if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+    if (oversampling_ratio == 0) return fail(VDB_ERR_INVALID_ARG, "oversampling_ratio must be > 0 (DualPrecisionConfig's default is 4)");
+    // (n_rows: NativeHnsw::len() counts inserted vectors; a racing insert moves it by one — the reference reads it under no lock either)
+    const bool int8 = ix->quantizer_trained && use_int8_traversal && ix->n_rows >= min_index_size;
+    return search_batch_host(ix, queries, nq, k, ef_search, int8 ? VDB_SEARCH_HNSW_INT8 : VDB_SEARCH_HNSW, int8 ? oversampling_ratio : 0, out_ids,
+                             out_scores, out_n);
+  });
+}
+
 // VectorIndex::search — index/mod.rs:58; trait_impl.rs:38-42
 int32_t vdb_hip_index_search(vdb_hip_index* ix, const float* query, uint32_t query_len, uint32_t k, uint32_t ef,
                              int32_t mode, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
@@ -221,9 +246,10 @@ int32_t vdb_hip_index_search_multi_entry(vdb_hip_index* ix, const float* queries
     std::lock_guard<vdb::IndexMutex> g(ix->mu);
     VDB_ENTER(ix);
     if (!ix->graph_valid) return fail(VDB_ERR_STATE, "HNSW graph not built for all rows (use mode BRUTE or build it)");
-    ef = std::max(ef ? ef : std::max<uint32_t>(128, 4 * k), k);  // (SearchQuality rules of vdb_hip_index_search)
+    // NativeHnsw level: ef_search goes to search_layer AS GIVEN (graph.rs:343) — no SearchQuality rule, no max(ef, k): a call with
+    // ef_search < k returns at most ef_search results (more entry points than ef_search: that many, graph.rs:463-468)
+    // (ef_search = 0 is legal there and acts as 1: the entry point is pushed uncut and every later push pops one)
     const uint32_t draws = (num_probes > 1 && ix->graph_nodes > 10) ? std::min<uint32_t>(num_probes, 4) - 1 : 0;
-    if (draws && ef < 4) return fail(VDB_ERR_UNSUPPORTED, "search_multi_entry: ef_search >= 4 with several entry points");
     const uint32_t* d_extra = nullptr;
     if (draws) {
       std::vector<uint32_t> extra((size_t)nq * 3, 0xFFFFFFFFu);
@@ -243,7 +269,9 @@ int32_t vdb_hip_index_search_multi_entry(vdb_hip_index* ix, const float* queries
     }
     int32_t rc = stage_queries(ix, queries, 0, nq, nq);
     if (rc != VDB_OK) return rc;
+    ix->raw_ef = true;  // (exclusive lock held: nobody else reads the flag)
     rc = search_staged(ix, nq, k, ef, VDB_SEARCH_HNSW, 0, d_extra);
+    ix->raw_ef = false;
     if (rc != VDB_OK) return rc;
     deliver_slice(ix, 0, nq, nq, k, out_ids, out_scores, out_n);
     return VDB_OK;

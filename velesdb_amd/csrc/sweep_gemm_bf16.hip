@@ -71,6 +71,7 @@ struct Bf16GemmArgs {
   uint64_t* blk_tau;        // [nq][list_stride]: the bound this block ends with per query (kKeyInvalid: it excluded nothing)
   // result mode (VDB_SEARCH_BRUTE_BF16): [nq] norms of the ROUNDED queries (query_norms_bf16), or nullptr: computed by every block
   const float* qnorms_half;
+  uint32_t prio;  // probe (VELESDB_PP_PRIO): 1 = waves 4-7 at s_setprio 1, 2 = waves 0-3
 };
 
 // The lane id, re-derived where it is needed: a value computed from threadIdx before the main loop stays live across it,
@@ -145,6 +146,7 @@ __device__ __forceinline__ void wait_glds() { asm volatile("s_waitcnt vmcnt(0)" 
 template <int METRIC, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs a) {
   constexpr bool HIB = true;  // Cosine / DotProduct
+  constexpr bool QT_DENSE = true;  // accumulators in vector registers: the round-5 quick test (g16_quicktest_dense.inc)
   constexpr int BM = kG16BM, BN = kG16BN, WAVES = kG16Waves, CAP = kG16Cap, QCAP = kG16Queue;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* cand = reinterpret_cast<uint64_t*>(smem + kOffCand);   // [BN][CAP]
@@ -351,6 +353,11 @@ _Pragma("unroll") \
     const bool more = it < total;
 #define VDB_G16_ACC_F(V) (V)
 #include "g16_quicktest.inc"
+    if constexpr (METRIC == kHamming || METRIC == kJaccard || !QT_DENSE) {
+#include "g16_quicktest_groups.inc"
+    } else {
+#include "g16_quicktest_dense.inc"
+    }
 #define VDB_G16_ACC_ELEM(X, A) asm volatile("v_mov_b32 %0, %1" : "=v"(X) : "v"(A))
 #include "g16_protocol.inc"
 #undef VDB_G16_ACC_ELEM
@@ -367,8 +374,8 @@ _Pragma("unroll") \
 // sweep_topk_gemm_bf16_pp — the plain-bf16 instance as a PING-PONG pipeline (round 3).  Same tile (256 rows x 256 queries,
 // eight waves as 2 x 4, wave tile 128 x 64), same LDS image (two 64-KiB stages of 128-B lines, swizzle on the DMA's source
 // address), same epilogue text (g16_quicktest.inc, g16_protocol.inc) and therefore the same results; what changes is WHEN things happen:
-//   * the accumulators live in the accumulation registers ("+a": 128 AGPRs), which leaves the wave's 128 vector registers
-//     to fragments: the B fragments of a whole k-tile (64 queries x 64 k = 32 registers) and BOTH halves of the A
+//   * (round 3-4: the accumulators in the accumulation registers, "+a"; round 5: everything in vector registers, see
+//     mfma_accv) the wave's other ~100 registers hold fragments: the B fragments of a whole k-tile (64 queries x 64 k = 32 registers) and BOTH halves of the A
 //     fragments (2 x 64 rows x 64 k = 2 x 32 registers) are resident, so fragment reads can be placed a phase or more ahead
 //     of the products that use them;
 //   * a k-tile is four PHASES of 16 products — one quadrant (64 rows x 32 queries x 64 k) of the wave tile each — and the
@@ -409,44 +416,32 @@ _Pragma("unroll") \
 // is the same for rows and queries: a dot product does not care.  (Round 4 ran this path on v_mfma_i32_16x16x64_i8 first —
 // byte images, twice the bytes and twice the products: 0.96 / 1.02 ms per 1 024 queries at 1 M x 768 against 0.72 / 0.82 here,
 // profiles/r04p_bit_metrics_fp4_vs_i8.log.)
-template <bool FP4>
-__device__ __forceinline__ void mfma_acc(f32x4& c, const f32x4& a, const f32x4& b) {
-  if (FP4)
-    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+a"(c) : "v"(a), "v"(b), "v"(0x7F7F7F7Fu));
-  else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-template <bool FP4>
-__device__ __forceinline__ void mfma_acc_first(f32x4& c, const f32x4& a, const f32x4& b) {
-  if (FP4)
-    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "=&a"(c) : "v"(a), "v"(b), "v"(0x7F7F7F7Fu));
-  else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));
-}
-// ACCV (round 5): the register classes SWAPPED — accumulators in the vector registers ("+v"), fragments in the accumulation
-// registers (gfx950's file is unified: `ds_read_b128 a[..]` loads straight into them and the matrix pipe takes A / B operands from
-// either class).  The k-loop is unchanged instruction for instruction; the epilogue's quick test no longer pays one
-// v_accvgpr_read per accumulator (128 per wave and row tile: the floor of the round-4 epilogue, profiles/r04_pmc_lds_vmem_*).
+// Register layout (round 5): accumulators AND fragments in the vector registers (128 + 96 of the wave's 256; no accumulation
+// registers at all, so the compiler grants the kernel the whole unified file as vector registers — with ANY "a" operand it splits
+// the file 128 / 128 and the 128 accumulators + addresses no longer fit the vector half).  Round 4 kept the accumulators in the
+// accumulation registers ("+a"): the epilogue's quick test then paid one v_accvgpr_read per accumulator, 128 per wave and row tile,
+// its floor.  Same k-loop, instruction for instruction; measured on one box, same run (profiles/r05b_accv_ab.log): selection
+// launches of a 1 024-query step 1.534-1.547 -> 1.463-1.474 ms, step 1.753 -> 1.671 ms, the 10 M bf16 batch 13.87-13.95 -> 13.26-13.30 ms.
 template <bool FP4>
 __device__ __forceinline__ void mfma_accv(f32x4& c, const f32x4& a, const f32x4& b) {
   if (FP4)
-    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+v"(c) : "a"(a), "a"(b), "v"(0x7F7F7F7Fu));
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+v"(c) : "v"(a), "v"(b), "v"(0x7F7F7F7Fu));
   else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(a), "a"(b));
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 template <bool FP4>
 __device__ __forceinline__ void mfma_accv_first(f32x4& c, const f32x4& a, const f32x4& b) {
   if (FP4)
-    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "=&v"(c) : "a"(a), "a"(b), "v"(0x7F7F7F7Fu));
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "=&v"(c) : "v"(a), "v"(b), "v"(0x7F7F7F7Fu));
   else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "a"(a), "a"(b));
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
 }
-// one fragment read into accumulation registers: LDS byte address in a vector register + an immediate.  `asm volatile`: it keeps its
+// one fragment read: LDS byte address in a vector register + an immediate.  `asm volatile`: it keeps its
 // place among the barriers, requests and products of the phase; its completion is the explicit lgkmcnt(0) of pp_barrier_reads_done
 // (the compiler does not count it — every use of a fragment sits behind that wait)
 template <int OFF>
 __device__ __forceinline__ void lds_frag_read(f32x4& dst, uint32_t addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
 // the barrier in front of a phase's products: this wave's fragment reads have completed (their stage slots may be
 // re-requested by anybody who has passed the barrier); "memory": no LDS access moves across
@@ -457,10 +452,11 @@ __device__ __forceinline__ void pp_wait_dma6() { asm volatile("s_waitcnt vmcnt(6
 // FP4 instance (Hamming / Jaccard batches on four-bit images, bits_gemm.hip): rows / queries are nibble images addressed through
 // the same arguments — row_stride / q_stride / dim in units of TWO bytes, k-tiles of 128 bytes = 256 values — and `norms` /
 // `qnorms_half` carry the bit counts |v|, |q| as floats (Hamming: dim); the accumulators hold the exact integer dot products.
-template <int METRIC, bool FP4 = false, bool ACCV = true>
+template <int METRIC, bool FP4 = false>
 __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a) {
   static_assert(FP4 == (METRIC == kHamming || METRIC == kJaccard), "the four-bit instance serves the bit metrics, the bf16 instance Cosine / DotProduct");
   constexpr bool HIB = METRIC != kHamming;  // Cosine / DotProduct / Jaccard: higher is better; Hamming: a distance
+  constexpr bool QT_DENSE = true;
   constexpr int BM = kG16BM, BN = kG16BN, WAVES = kG16Waves, CAP = kG16Cap, QCAP = kG16Queue;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* cand = reinterpret_cast<uint64_t*>(smem + kOffCand);   // [BN][CAP]
@@ -563,36 +559,18 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a
 
   // ---- fragment reads: lane (i = l & 15, kk = l >> 4) reads slot (4 m + kk) ^ ((i >> 1) & 7) of row i (+ 16 rows per fragment)
 #define VDB_PP_READ_A(DST, RF0, BUF) do { \
-    if (ACCV) { \
-      const uint32_t ad0_ = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)(a_rd0 + rd_x), ad1_ = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)(a_rd0 + (64 ^ rd_x)); \
-      lds_frag_read<((RF0) + 0) * 2048>(DST[0][0], ad0_); lds_frag_read<((RF0) + 0) * 2048>(DST[0][1], ad1_); \
-      lds_frag_read<((RF0) + 1) * 2048>(DST[1][0], ad0_); lds_frag_read<((RF0) + 1) * 2048>(DST[1][1], ad1_); \
-      lds_frag_read<((RF0) + 2) * 2048>(DST[2][0], ad0_); lds_frag_read<((RF0) + 2) * 2048>(DST[2][1], ad1_); \
-      lds_frag_read<((RF0) + 3) * 2048>(DST[3][0], ad0_); lds_frag_read<((RF0) + 3) * 2048>(DST[3][1], ad1_); \
-    } else { \
-    const unsigned char* tb_ = smem + (size_t)(BUF) * 65536; \
-_Pragma("unroll") \
-    for (int rf_ = 0; rf_ < 4; rf_++) \
-_Pragma("unroll") \
-      for (int m_ = 0; m_ < 2; m_++) \
-        DST[rf_][m_] = *reinterpret_cast<const f32x4*>(tb_ + a_rd0 + ((m_ * 64) ^ rd_x) + ((RF0) + rf_) * 2048); \
-    } \
+    const uint32_t ad0_ = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)(a_rd0 + rd_x), ad1_ = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)(a_rd0 + (64 ^ rd_x)); \
+    lds_frag_read<((RF0) + 0) * 2048>(DST[0][0], ad0_); lds_frag_read<((RF0) + 0) * 2048>(DST[0][1], ad1_); \
+    lds_frag_read<((RF0) + 1) * 2048>(DST[1][0], ad0_); lds_frag_read<((RF0) + 1) * 2048>(DST[1][1], ad1_); \
+    lds_frag_read<((RF0) + 2) * 2048>(DST[2][0], ad0_); lds_frag_read<((RF0) + 2) * 2048>(DST[2][1], ad1_); \
+    lds_frag_read<((RF0) + 3) * 2048>(DST[3][0], ad0_); lds_frag_read<((RF0) + 3) * 2048>(DST[3][1], ad1_); \
   } while (0)
 #define VDB_PP_READ_B(BUF) do { \
-    if (ACCV) { \
-      const uint32_t bd0_ = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)(b_rd0 + rd_x), bd1_ = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)(b_rd0 + (64 ^ rd_x)); \
-      lds_frag_read<0 * 2048>(bv[0][0], bd0_); lds_frag_read<0 * 2048>(bv[0][1], bd1_); \
-      lds_frag_read<1 * 2048>(bv[1][0], bd0_); lds_frag_read<1 * 2048>(bv[1][1], bd1_); \
-      lds_frag_read<2 * 2048>(bv[2][0], bd0_); lds_frag_read<2 * 2048>(bv[2][1], bd1_); \
-      lds_frag_read<3 * 2048>(bv[3][0], bd0_); lds_frag_read<3 * 2048>(bv[3][1], bd1_); \
-    } else { \
-    const unsigned char* tb_ = smem + (size_t)(BUF) * 65536; \
-_Pragma("unroll") \
-    for (int t_ = 0; t_ < 4; t_++) \
-_Pragma("unroll") \
-      for (int m_ = 0; m_ < 2; m_++) \
-        bv[t_][m_] = *reinterpret_cast<const f32x4*>(tb_ + b_rd0 + ((m_ * 64) ^ rd_x) + t_ * 2048); \
-    } \
+    const uint32_t bd0_ = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)(b_rd0 + rd_x), bd1_ = lds0 + (uint32_t)(BUF) * 65536u + (uint32_t)(b_rd0 + (64 ^ rd_x)); \
+    lds_frag_read<0 * 2048>(bv[0][0], bd0_); lds_frag_read<0 * 2048>(bv[0][1], bd1_); \
+    lds_frag_read<1 * 2048>(bv[1][0], bd0_); lds_frag_read<1 * 2048>(bv[1][1], bd1_); \
+    lds_frag_read<2 * 2048>(bv[2][0], bd0_); lds_frag_read<2 * 2048>(bv[2][1], bd1_); \
+    lds_frag_read<3 * 2048>(bv[3][0], bd0_); lds_frag_read<3 * 2048>(bv[3][1], bd1_); \
   } while (0)
   // 16 products: rows RF0 .. RF0 + 3 (fragments of AV) x queries T0, T0 + 1 x both 32-deep halves
 #define VDB_PP_MFMA(AV, RF0, T0, FIRST) do { \
@@ -602,11 +580,8 @@ _Pragma("unroll") \
       for (int rf_ = 0; rf_ < 4; rf_++) \
 _Pragma("unroll") \
         for (int t_ = 0; t_ < 2; t_++) { \
-          if (ACCV) { \
-            if ((FIRST) && m_ == 0) mfma_accv_first<FP4>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
-            else mfma_accv<FP4>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
-          } else if ((FIRST) && m_ == 0) mfma_acc_first<FP4>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
-          else mfma_acc<FP4>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
+          if ((FIRST) && m_ == 0) mfma_accv_first<FP4>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
+          else mfma_accv<FP4>(acc[(RF0) + rf_][(T0) + t_], AV[rf_][m_], bv[(T0) + t_][m_]); \
         } \
   } while (0)
 
@@ -648,6 +623,8 @@ _Pragma("unroll") \
     pp_wait_dma6();  // k-tile 0 has landed (this wave's share; the barrier: everybody's)
   }
   pp_barrier();
+  if (a.prio == 1u && wr == 1) __builtin_amdgcn_s_setprio(1);
+  if (a.prio == 2u && wr == 0) __builtin_amdgcn_s_setprio(1);
   if (total) VDB_PP_READ_A(a0v, 0, 0);  // A rows 0-63 of k-tile 0 (in the loop: read in phase 4 of the k-tile before)
   if (wr == 1) pp_barrier();  // waves 4-7 run one barrier behind
   // one k-tile: four phases (see the schedule above)
@@ -691,8 +668,13 @@ _Pragma("unroll") \
     const bool more = c < total;
 #define VDB_G16_ACC_F(V) (V)
 #include "g16_quicktest.inc"  // (waves 0-3: beside the last products of waves 4-7)
+    if constexpr (METRIC == kHamming || METRIC == kJaccard || !QT_DENSE) {
+#include "g16_quicktest_groups.inc"
+    } else {
+#include "g16_quicktest_dense.inc"
+    }
     if (wr == 0) pp_barrier();  // waves 0-3 wait for the last products of waves 4-7: the block is aligned again
-#define VDB_G16_ACC_ELEM(X, A) do { if (ACCV) asm volatile("v_mov_b32 %0, %1" : "=v"(X) : "v"(A)); else asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(X) : "a"(A)); } while (0)
+#define VDB_G16_ACC_ELEM(X, A) asm volatile("v_mov_b32 %0, %1" : "=v"(X) : "v"(A))
 #include "g16_protocol.inc"
 #undef VDB_G16_ACC_ELEM
 #undef VDB_G16_ACC_F
@@ -763,6 +745,7 @@ void launch_seed_tau(const uint64_t* ids, const float* scores, const uint32_t* n
 // (sweep_gemm_bf16_plan, gemm_schedule: vdb_gemm_schedule.hpp — host arithmetic only, checked on the CPU by tests/gemm_schedule_model.cpp)
 static_assert(kG16BM == (int)kGemmTileRows && kG16BN == (int)kGemmTileQueries, "the schedule's tile is the kernel's");
 
+// VELESDB_BF16_PP=0: the lock-step kernel (A / B probes)
 static bool pingpong_enabled() {
   static const bool on = [] {
     const char* e = getenv("VELESDB_BF16_PP");
@@ -839,6 +822,11 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
   a.qnorms = qnorms;
   a.blk_tau = blk_tau;
   a.qnorms_half = qnorms_half;
+  static const uint32_t prio = [] {
+    const char* e = getenv("VELESDB_PP_PRIO");
+    return e ? (uint32_t)atoi(e) : 0u;
+  }();
+  a.prio = prio;
   if (metric == kHamming) return launch_g16_fp4<kHamming>(a, p.blocks, st);
   if (metric == kJaccard) return launch_g16_fp4<kJaccard>(a, p.blocks, st);
   if (split)

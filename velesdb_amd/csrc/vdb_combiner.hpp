@@ -43,8 +43,17 @@ struct CombineReq {
   int32_t rc = 0;  // VDB_OK
   std::string err;
   vdb_hip_index* served_by = nullptr;
+  uint32_t passed = 0;  // (under Combiner::mu) leaders admitted AHEAD of this request while it headed the queue: the fairness rule's clock
   bool same_shape(const CombineReq& o) const { return k == o.k && ef == o.ef && mode == o.mode && rerank_k == o.rerank_k; }
 };
+// FAIRNESS.  A request may lead while fewer batches than its kind's limit are in flight (graph walks overlap two launches, sweeps run
+// alone), so without a rule a queued SWEEP needs `leaders == 0` — which back-to-back walk callers never let happen: every new walk leads
+// at once while one walk is in flight, and the hand-off of a finished walk skips the sweep.  The rule: once the request at the HEAD of
+// the queue has been passed kCombineMaxPassed times, nobody is admitted ahead of it any more — new arrivals queue behind it and a
+// freed slot is kept free — until the batches in flight have drained far enough for it to lead (at zero in flight every kind may).
+// Its wait is then bounded by kCombineMaxPassed admissions plus the batches in flight at that moment (tests/combiner_model.cpp
+// `starve` mode: endless walk traffic plus one sweep caller).
+constexpr uint32_t kCombineMaxPassed = 4;
 
 struct Combiner {
   std::mutex mu;
@@ -75,7 +84,9 @@ int32_t search_combined(Env& env, Combiner* cb, CombineReq& me) {
   {
     std::lock_guard<std::mutex> lk(cb->mu);
     cb->arrivals++;
-    if (cb->leaders < env.leader_limit(me)) {
+    const bool head_starving = !cb->queue.empty() && cb->queue.front()->passed >= kCombineMaxPassed;
+    if (!head_starving && cb->leaders < env.leader_limit(me)) {
+      if (!cb->queue.empty()) cb->queue.front()->passed++;  // (admitted ahead of the queue's head)
       cb->leaders++;
       me.state = CombineReq::kTaken;
       lead = true;
@@ -154,15 +165,20 @@ int32_t search_combined(Env& env, Combiner* cb, CombineReq& me) {
     cb->last_batch_done_at_arrival = cb->arrivals;
     cb->leaders--;
     // the freed slot goes to the first queued call that may lead (it takes the others of its shape with it)
+    // (fairness: a head that has been passed kCombineMaxPassed times is the only one that may take it — the slot stays free until
+    // the head can, which at the latest is when nothing is in flight)
     CombineReq* next = nullptr;
-    for (auto it = cb->queue.begin(); it != cb->queue.end(); ++it)
+    for (auto it = cb->queue.begin(); it != cb->queue.end(); ++it) {
       if ((*it)->state == CombineReq::kQueued && cb->leaders < env.leader_limit(**it)) {
         next = *it;
+        if (it != cb->queue.begin()) cb->queue.front()->passed++;
         cb->queue.erase(it);
         next->state = CombineReq::kTaken;
         cb->leaders++;
         break;
       }
+      if (it == cb->queue.begin() && (*it)->passed >= kCombineMaxPassed) break;
+    }
     lk.unlock();
     // (a request is not touched after its word is set: its caller may be gone the next instant)
     for (size_t i = 1; i < batch.size(); i++) {

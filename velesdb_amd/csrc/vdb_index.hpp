@@ -214,6 +214,7 @@ struct vdb_hip_index {
   std::vector<uint8_t> idx_live;
   uint64_t live = 0;
   bool any_dead = false;
+  bool raw_ef = false;  // transient, under the exclusive lock: the running call is NativeHnsw-level (search_multi_entry) — its ef is used as given
 
   // scratch
   vdb::DevBuf s_queries, s_part_keys, s_part_cnt, s_qbits, s_misc;

@@ -145,6 +145,7 @@ struct HnswSearchArgs {
   // NativeHnsw::search_multi_entry (graph.rs:288-348): nullable; [nq][3] node ids drawn by the host from the graph's xorshift
   // stream (0xFFFFFFFF = no draw): further entry points of the layer-0 search beside the descent's result, duplicates skipped
   const uint32_t* extra_eps;
+  uint32_t raw_small_ef;  // NativeHnsw-level call with ef_search < 4: the RAWEF instance (hnsw_kernels.hip)
 };
 size_t hnsw_lds_bytes(uint32_t cap, uint32_t nbmax, uint32_t dim, uint32_t words, int metric);  // without the visited set
 // returns hipSuccess or the launch error; grid = slots blocks of 256 threads

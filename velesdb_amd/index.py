@@ -280,22 +280,28 @@ class HnswIndex:
     def train_quantizer(self, sample_rows: int = 0) -> None:
         """ScalarQuantizer::train on the first sample_rows rows (0 = min(1000, rows)) + u8 codes of every row."""
         check(lib().vdb_hip_index_train_quantizer(self._h, sample_rows))
-        self._quantizer_trained = True
+
+    def is_quantizer_trained(self) -> bool:
+        """DualPrecisionHnsw::is_quantizer_trained (native/dual_precision.rs:117-120), read from the handle."""
+        t = C.c_int32(0)
+        check(lib().vdb_hip_index_quantizer_trained(self._h, C.byref(t)))
+        return bool(t.value)
 
     def search_with_config(self, query, k: int, ef_search: int, config: Optional[DualPrecisionConfig] = None) -> List[Tuple[int, float]]:
         """DualPrecisionHnsw::search_with_config (native/dual_precision.rs:259-278): the int8 traversal only with a trained
         quantiser, `use_int8_traversal` and at least `min_index_size` (default 10 000) vectors; otherwise the plain f32 graph
-        search.  `oversampling_ratio` sets how many of the int8 walk's best are re-scored exactly (k * ratio) — through the handle's
-        VDB_OPT_INT8_OVERSAMPLING, i.e. per handle, not per call: callers that search one handle concurrently with DIFFERENT ratios
-        must serialise themselves (the reference passes the config per call; the C ABI has no per-call argument for it)."""
+        search.  The config travels with the call (vdb_hip_index_search_with_config): the rule is applied inside the library from
+        the handle's own state, `oversampling_ratio` (k * ratio of the int8 walk's best are re-scored exactly) is this call's own —
+        no handle option is touched, concurrent callers may use different ratios."""
         cfg = config or DualPrecisionConfig()
         q = _f32(query).reshape(1, -1)
         self._validate(q)
-        if cfg.takes_int8_traversal(getattr(self, "_quantizer_trained", False), self.len()):
-            self.set_option(OPT_INT8_OVERSAMPLING, cfg.oversampling_ratio)
-            ids, sc, cnt = self._search_raw(q, k, ef_search, MODE_HNSW_INT8)
-        else:
-            ids, sc, cnt = self._search_raw(q, k, ef_search, MODE_HNSW)
+        kk = max(k, 1)
+        ids = np.empty((1, kk), dtype=np.uint64)
+        sc = np.empty((1, kk), dtype=np.float32)
+        cnt = np.zeros(1, dtype=np.uint32)
+        check(lib().vdb_hip_index_search_with_config(self._h, _ptr(q), 1, k, ef_search, max(int(cfg.oversampling_ratio), 1),
+                                                     1 if cfg.use_int8_traversal else 0, int(cfg.min_index_size), _ptr(ids), _ptr(sc), _ptr(cnt)))
         return self._tuples(ids[0], sc[0], cnt[0])
 
     def search_batch_int8(self, queries, k: int, ef_search: int):
