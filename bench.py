@@ -659,6 +659,18 @@ def main():
         ix.build_graph(0)
         torch.cuda.synchronize()
         build_s = time.perf_counter() - tb
+        # construction roofline: the insert kernel counts the rows whose distance it evaluates (search_layer at
+        # ef_construction + select_neighbors, graph.rs:158-237, 526-581); algorithmic bytes = rows x dim x 4 (random 3-KB gathers), over
+        # the WALL time of build_graph (insert + sort + link kernels and the host's batch loop: the insert kernel is ~97 % of it,
+        # profiles/r05*_build_kernel_stats.csv)
+        b_rows, b_phases, b_nodes = ix.build_stats()
+        build_bytes = b_rows * D * 4
+        build_roof = {"bound": "hbm", "achieved": round(build_bytes / build_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(build_bytes / build_s / 1e9 / HBM_PEAK_GBS, 4), "alg_bytes": build_bytes,
+                      "rows_evaluated_per_insert": round(b_rows / max(b_nodes, 1), 1),
+                      "distance_phases_per_insert": round(b_phases / max(b_nodes, 1), 1), "nodes": b_nodes, "seconds": round(build_s, 2),
+                      "kernel": "hnsw_insert_kernel + hnsw_link_kernel + radix sort of the link requests (wall time of build_graph)",
+                      "alg_bytes_rule": "rows whose distance the insert kernel evaluated x dim x 4 (counters from the kernel)"}
 
         def hstep():
             ix.search_batch_dev(queries.data_ptr(), HQ, K, a.ef, va.MODE_HNSW, h_ids.data_ptr(), h_sc.data_ptr(),
@@ -688,7 +700,7 @@ def main():
                             f"built on the GPU), k={K}, ef={a.ef}, {HQ} queries/step (BASELINE configs[2])",
                 "qps": round(world * HQ * a.hnsw_steps / hdt, 1), "ms_per_step": round(hdt / a.hnsw_steps * 1e3, 3),
                 "recall_at_10": round(recall_h, 4), "recall_queries": RQ,
-                "build_seconds": round(build_s, 2), "build_inserts_per_s": round(N / build_s, 1),
+                "build_seconds": round(build_s, 2), "build_inserts_per_s": round(N / build_s, 1), "build": {"roofline": build_roof},
                 "n_dist_per_query": round(n_dist / HQ, 1), "n_expand_per_query": round(n_expand / HQ, 1),
                 "roofline": {"bound": "hbm", "achieved": round(hgbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(hgbs / HBM_PEAK_GBS, 4), "traffic": None,
@@ -1384,11 +1396,25 @@ def main():
                 nq_c = min(ncores, Q)
                 qh = qsrc[:nq_c].cpu().numpy()
                 tc = time.perf_counter()
-                po.scan_topk(pm, host_rows, qh, K, po.MODE_R, nthreads=ncores)
+                r_ids, r_sc = po.scan_topk(pm, host_rows, qh, K, po.MODE_R, nthreads=ncores)
                 cdt = time.perf_counter() - tc
                 row["cpu_baseline"] = {"value": round(nq_c / cdt, 2), "unit": "queries/s", "cores": ncores, "kind": "port",
                                        "sample": f"oracle mode R exact scan of {N} rows x {nq_c} queries, {ncores} threads, {cdt:.2f} s"}
                 row["gpu_over_cpu_batch"] = round(row["batch"]["qps"] / max(nq_c / cdt, 1e-9), 1)
+                # parity of the batch just timed (its results are still in the output buffers): ids AND score bits against the oracle
+                # in the arithmetic the index declares (C / M; integer work for the bit metrics), and the distance to the reference's own
+                # summation order (mode R) — the north-star's 1e-5
+                c_mode = po.MODE_M if ixm.sweep_arith_mode(K) == "M" else po.MODE_C
+                c_ids, c_sc = po.scan_topk(pm, host_rows, qh, K, c_mode, nthreads=ncores)
+                g_ids = out_ids[:nq_c].cpu().numpy().astype(np.int64)
+                g_sc = out_sc[:nq_c].cpu().numpy()
+                denom = np.maximum(np.abs(r_sc.astype(np.float64)), 1e-30)
+                row["parity_check"] = {
+                    "queries": int(nq_c), "of_a_batch_of": int(Q),
+                    "ids_equal_oracle": bool(np.array_equal(g_ids, c_ids.astype(np.int64))),
+                    "scores_bit_equal_oracle": bool(np.array_equal(g_sc.view(np.uint32), np.ascontiguousarray(c_sc, dtype=np.float32).view(np.uint32))),
+                    "within_1e5_of_reference_order": bool(np.all(np.abs(g_sc.astype(np.float64) - r_sc.astype(np.float64)) / denom <= 1e-5)),
+                    "max_rel_diff_vs_reference_order": float(np.max(np.abs(g_sc.astype(np.float64) - r_sc.astype(np.float64)) / denom))}
                 del host_rows
             metrics_leg.append(row)
             ixm.close()

@@ -18,6 +18,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# A child pytest of tests/test_gpu_switches.py runs the parity tests under an environment switch: switches exist only in the probe build
+# of the library (csrc/vdb_probe_env.hpp), which this harness — not the package — selects.
+if os.environ.get("VDB_TEST_PROBE_LIB") == "1":
+    from velesdb_amd import _ffi as _vdb_ffi
+    _vdb_ffi.use_library(_vdb_ffi.PROBE_LIB_PATH)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -295,6 +295,8 @@ _LOOPBACK_SCRIPT = r'''
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.environ["VDB_TEST_ROOT"])
+from velesdb_amd import _ffi as _f
+_f.use_library(_f.PROBE_LIB_PATH)   # the test hooks below (VELESDB_RCCL_LIB, VELESDB_SHARD_FORCE_COLLECTIVE) exist in the probe build only
 import velesdb_amd as va
 from oracle import pyoracle as po
 DM = va.DistanceMetric
@@ -363,6 +365,8 @@ def test_distinct_devices_without_rccl_fail_loudly(gpu_required):
 import os, sys
 import numpy as np
 sys.path.insert(0, os.environ["VDB_TEST_ROOT"])
+from velesdb_amd import _ffi as _f
+_f.use_library(_f.PROBE_LIB_PATH)   # the test hooks below (VELESDB_RCCL_LIB, VELESDB_SHARD_FORCE_COLLECTIVE) exist in the probe build only
 import velesdb_amd as va
 sh = va.HnswIndex(16, va.DistanceMetric.Cosine, va.HnswParams(8, 50, 100), devices=[0, 0], shard_mode=va.SHARD_RANGE)
 sh.upload(np.arange(100), np.random.default_rng(0).standard_normal((100, 16)).astype(np.float32))

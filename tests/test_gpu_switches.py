@@ -1,5 +1,7 @@
-"""DESIGN §6b claims that no result depends on a diagnostic environment switch (A / B probes read once when the library is
-loaded).  This file PROVES it for the switches that select another kernel or another schedule: the parity tests of the path a
+"""The diagnostic environment switches (A / B probes) exist only in the PROBE build of the library (libvelesdb_hip_probe.so, the same
+sources with -DVDB_PROBE_SWITCHES: csrc/vdb_probe_env.hpp); the shipped libvelesdb_hip.so reads no environment variable
+(tests/test_abi_exports.py::test_shipped_library_reads_no_environment_variable).  DESIGN §6b claims that no result depends on a
+switch.  This file PROVES it for the switches that select another kernel or another schedule: the parity tests of the path a
 switch touches are run again, in a child process with the switch set — the same assertions (ids, ranks, score bits, counters
 against the oracle) must hold.
 
@@ -49,7 +51,7 @@ CASES = [
 
 @pytest.mark.parametrize("env,target", CASES, ids=[",".join(f"{k}={v}" for k, v in e.items()) + ":" + t[0].split("/")[-1] for e, t in CASES])
 def test_parity_holds_under_the_switch(gpu_required, env, target):
-    child_env = dict(os.environ, **env)
+    child_env = dict(os.environ, VDB_TEST_PROBE_LIB="1", **env)   # (tests/conftest.py binds the child to libvelesdb_hip_probe.so)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", *target], cwd=ROOT, env=child_env,
                        capture_output=True, text=True, timeout=900)
     tail = (r.stdout or "")[-1500:] + (r.stderr or "")[-500:]

@@ -9,8 +9,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# VELESDB_HIP_LIB selects another build of the same ABI (kernel-variant probes); the default is the in-tree library
-LIB_PATH = os.environ.get("VELESDB_HIP_LIB") or os.path.join(_HERE, "lib", "libvelesdb_hip.so")
+# the in-tree library.  The package reads no environment variable; a test harness or a probe script that wants another build of
+# the same ABI (the probe build with its environment switches, a kernel variant) says so in code, BEFORE the first call: use_library()
+LIB_PATH = os.path.join(_HERE, "lib", "libvelesdb_hip.so")
+PROBE_LIB_PATH = os.path.join(_HERE, "lib", "libvelesdb_hip_probe.so")
 
 VDB_OK = 0
 VDB_DUPLICATE_IGNORED = 1
@@ -86,6 +88,7 @@ SIGNATURES = {
     "vdb_hip_index_set_option": (_i32, [_vp, _i32, C.c_int64]),
     "vdb_hip_index_get_option": (_i32, [_vp, _i32, C.POINTER(C.c_int64)]),
     "vdb_hip_index_combine_stats": (_i32, [_vp, _pu64, _pu64, _pu64, _pu64]),
+    "vdb_hip_index_build_stats": (_i32, [_vp, _pu64, _pu64, _pu64]),
     "vdb_hip_index_sweep_arith_mode": (_i32, [_vp, _u32, _pi32]),
     "vdb_hip_index_last_kernel_ms": (_i32, [_vp, _pf32, _pu32]),
     "vdb_hip_last_error": (C.c_char_p, []),
@@ -99,6 +102,15 @@ class VelesHipError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"[vdb status {code}] {msg}")
         self.code = code
+
+
+def use_library(path: str) -> None:
+    """Binds the package to another build of libvelesdb_hip (tests/conftest.py: the probe build; tools/probes: kernel variants).
+    Must be called before anything touched the library."""
+    global LIB_PATH
+    if _lib is not None and os.path.abspath(path) != os.path.abspath(LIB_PATH):
+        raise RuntimeError(f"libvelesdb_hip is already loaded from {LIB_PATH}")
+    LIB_PATH = path
 
 
 def lib() -> C.CDLL:

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <string>
 
+#include "vdb_probe_env.hpp"
 #include "vdb_device.hpp"
 #include "vdb_index.hpp"
 #include "vdb_kernels.hpp"
@@ -159,7 +160,7 @@ uint32_t bits_gemm_chunk(const vdb_hip_index* ix, uint32_t nq_left, uint32_t k) 
   // up to 1 024 queries, whatever that leaves of the last 256-query tile: a partly filled tile costs what a full one costs, a second
   // pass costs the whole fixed part again (the selection stage's rule, select_stage.hip select_chunk)
   static const uint32_t min_q = [] {
-    const char* e = getenv("VELESDB_BITS_GEMM_MIN_QUERIES");
+    const char* e = probe_env("VELESDB_BITS_GEMM_MIN_QUERIES");
     return e ? (uint32_t)atoi(e) : kBitsGemmMinQueries;
   }();
   const uint32_t nqg = std::min<uint32_t>(nq_left, kGemmMaxQueries);

@@ -56,6 +56,8 @@ struct HnswInsertArgs {
   uint64_t* req_vals;  //                (source << 32 | f32 bits of the distance)
   uint32_t* req_n;
   uint32_t* overflow;  // [1] set when a candidate list or the request buffer overflowed
+  unsigned long long* stats;  // nullable; [0] += rows evaluated (search_layer + select_neighbors distance phases), [1] += distance
+                              // phases (dependent memory round trips), [2] += nodes inserted: the construction roofline's counters
   uint32_t first, B, ef, cap, nbmax, vlog_cap, max_layer, entry_point, req_cap;
   float alpha;
 };
@@ -111,6 +113,10 @@ __global__ __launch_bounds__(256) void hnsw_insert_kernel(HnswInsertArgs a) {
     uint32_t qrow_loaded = kNone;
 
     uint32_t cnt = 0, logn = 0, m_prev = 0, selc = 0, spos = 0, ssize = 0;
+    if (threadIdx.x == 0) {
+      ctl[4] = 0;
+      ctl[5] = 0;
+    }
     int phase = B_START;
     int layer = max((int)a.max_layer, lx);
     uint32_t cur = a.entry_point;
@@ -389,6 +395,10 @@ __global__ __launch_bounds__(256) void hnsw_insert_kernel(HnswInsertArgs a) {
       const uint32_t m = ctl[0];
       const uint32_t cmd = ctl[1];
       if (cmd == CMD_DONE) break;
+      if (cmd == CMD_DIST && threadIdx.x == 0 && a.stats) {  // the roofline's counters live in LDS (two registers more cost the kernel a wave per SIMD)
+        ctl[4] += m;
+        ctl[5] += 1;
+      }
       if (cmd == CMD_CLEAN) {
         const uint32_t nlog = ctl[2];
         if (nlog <= a.vlog_cap) {
@@ -422,6 +432,11 @@ __global__ __launch_bounds__(256) void hnsw_insert_kernel(HnswInsertArgs a) {
       else
         dist_phase_f32<METRIC, CPL>(dc, q, qnorm, qgen, m, nb_id, nb_d, lane, wib);
       __syncthreads();
+    }
+    if (a.stats && threadIdx.x == 0) {
+      atomicAdd(&a.stats[0], (unsigned long long)ctl[4]);
+      atomicAdd(&a.stats[1], (unsigned long long)ctl[5]);
+      atomicAdd(&a.stats[2], 1ull);
     }
     __syncthreads();
   }
@@ -749,6 +764,11 @@ static int32_t graph_insert_rows_impl(vdb_hip_index* ix, uint64_t first, uint64_
   a.req_n = d_req_n;
   a.overflow = d_overflow;
   a.levels = ix->s_levels.as<uint8_t>();
+  if (!ix->s_build_stats.p) {  // first construction on this handle: the cumulative counters start at zero
+    if ((e = ix->s_build_stats.reserve(64, false, st)) != hipSuccess || (e = hipMemsetAsync(ix->s_build_stats.p, 0, 64, st)) != hipSuccess)
+      return fail(VDB_ERR_OOM, std::string("construction counters: ") + hipGetErrorString(e));
+  }
+  a.stats = ix->s_build_stats.as<unsigned long long>();
 
   uint64_t pos = 0;
   while (pos < n) {

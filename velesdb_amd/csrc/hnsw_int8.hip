@@ -16,6 +16,7 @@
 #include <atomic>
 #include <cstdlib>
 
+#include "vdb_probe_env.hpp"
 #include "vdb_hnsw_device.hpp"
 #include "vdb_index.hpp"
 
@@ -23,7 +24,7 @@ namespace vdb {
 
 // VELESDB_I8_WAVES2=0 keeps four-wave blocks for every batch (A / B measurements)
 static std::atomic<bool> g_i8_waves2{[] {
-  const char* e = getenv("VELESDB_I8_WAVES2");
+  const char* e = probe_env("VELESDB_I8_WAVES2");
   return !(e && e[0] == '0');
 }()};
 
@@ -441,7 +442,7 @@ static hipError_t launch_i8_wv(const HnswInt8Args& A, int slots, size_t lds, hip
 // VELESDB_INT8_VIS_LDS: 0 = HBM bitmaps, 1 = the exact LDS visited set (2^14 entries = 64 KiB: two queries in flight per CU);
 // unset = the measured default
 static const int g_i8_vis = [] {
-  const char* e = getenv("VELESDB_INT8_VIS_LDS");
+  const char* e = probe_env("VELESDB_INT8_VIS_LDS");
   return e ? atoi(e) : -1;
 }();
 template <int METRIC, int CPL, int NS, int WAVES>

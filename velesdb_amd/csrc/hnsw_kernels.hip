@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "vdb_probe_env.hpp"
 #include "vdb_hnsw_device.hpp"
 #include "vdb_index.hpp"
 
@@ -579,11 +580,11 @@ static hipError_t launch_lat_cpl(const HnswSearchArgs& a, int slots, size_t lds,
 // VELESDB_HNSW_LATENCY_MODE=0 keeps the throughput kernel for every call (A / B measurements), =2 takes the latency-mode kernel
 // whatever the corpus size (fuzzing it over small graphs: tools/fuzz_hnsw.py)
 static const int g_hnsw_lat = [] {
-  const char* e = getenv("VELESDB_HNSW_LATENCY_MODE");
+  const char* e = probe_env("VELESDB_HNSW_LATENCY_MODE");
   return e ? atoi(e) : 1;
 }();
 static const uint32_t g_hnsw_lat_max = [] {  // 0: one query per CU (the default); VELESDB_HNSW_LATENCY_MAX_QUERIES overrides
-  const char* e = getenv("VELESDB_HNSW_LATENCY_MAX_QUERIES");
+  const char* e = probe_env("VELESDB_HNSW_LATENCY_MAX_QUERIES");
   return e ? (uint32_t)atoi(e) : 0u;
 }();
 
@@ -591,13 +592,13 @@ static const uint32_t g_hnsw_lat_max = [] {  // 0: one query per CU (the default
 // next pop's list too, unset = the measured default: only over a corpus beyond the Infinity Cache (1 M x 768: 1 102 -> 1 091 us per
 // one-query call at a 48 % hit rate; 10 K x 768, cache-resident: 659 -> 671 us at 55 % — profiles/r04q2_*)
 static const int g_hnsw_pf = [] {
-  const char* e = getenv("VELESDB_HNSW_PREFETCH_IDS");
+  const char* e = probe_env("VELESDB_HNSW_PREFETCH_IDS");
   return e ? atoi(e) : -1;
 }();
 // VELESDB_HNSW_VIS_LDS: 0 = HBM bitmaps everywhere, 1 = the exact LDS set in the throughput kernel too (two blocks per CU
 // instead of four), unset = the measured default (see pick_vis)
 static const int g_hnsw_vis = [] {
-  const char* e = getenv("VELESDB_HNSW_VIS_LDS");
+  const char* e = probe_env("VELESDB_HNSW_VIS_LDS");
   return e ? atoi(e) : -1;
 }();
 // the LDS visited set of a launch: 2^log2 entries behind the kernel's other LDS, or none.  A walk at ef visits ~75 ef nodes

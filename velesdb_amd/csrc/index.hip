@@ -935,7 +935,7 @@ std::vector<DevBuf*> index_buffers(vdb_hip_index* ix) {
       &ix->sq8_img, &ix->sq8_nrm, &ix->sq8_seed, &ix->sq8_rho,              // SQ8 selection images
       &ix->bits_img, &ix->bits_cnt,                                         // four-bit image of the bit rows (Hamming / Jaccard GEMM)
       &ix->s_queries, &ix->s_part_keys, &ix->s_part_cnt, &ix->s_out, &ix->s_qbits,
-      &ix->s_misc, &ix->s_fb_keys, &ix->s_seed, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_levels, &ix->s_req_keys,
+      &ix->s_misc, &ix->s_fb_keys, &ix->s_seed, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_build_stats, &ix->s_levels, &ix->s_req_keys,
       &ix->s_req_vals, &ix->s_sort_tmp};
   for (auto& L : ix->layers) {
     v.push_back(&L.nbr);
@@ -1800,6 +1800,25 @@ int32_t vdb_hip_index_last_selection_ms(vdb_hip_index* ix, float* total_ms, uint
   *total_ms = (float)total;
   if (launches) *launches = cnt;
   return VDB_OK;
+  });
+}
+
+// construction counters (hnsw_build.hip), cumulative since the handle was created; synchronises the device
+int32_t vdb_hip_index_build_stats(vdb_hip_index* ix, uint64_t* rows_evaluated, uint64_t* distance_phases, uint64_t* nodes) {
+  return vdb::guarded([&]() -> int32_t {
+    if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
+    if (ix->group) return fail(VDB_ERR_UNSUPPORTED, "build_stats: ask the shards");
+    std::lock_guard<vdb::IndexMutex> g(ix->mu);
+    VDB_ENTER(ix);
+    unsigned long long h[3] = {0, 0, 0};
+    if (ix->s_build_stats.p) {
+      VDB_HIP(hipDeviceSynchronize());
+      VDB_HIP(hipMemcpy(h, ix->s_build_stats.p, 24, hipMemcpyDeviceToHost));
+    }
+    if (rows_evaluated) *rows_evaluated = h[0];
+    if (distance_phases) *distance_phases = h[1];
+    if (nodes) *nodes = h[2];
+    return VDB_OK;
   });
 }
 

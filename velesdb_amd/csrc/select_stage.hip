@@ -11,6 +11,7 @@
 #include <cstring>
 #include <string>
 
+#include "vdb_probe_env.hpp"
 #include "vdb_select_stage.hpp"
 
 namespace vdb {
@@ -20,13 +21,13 @@ static inline int opt_engine(const vdb_hip_index* ix) { return (int)opt_value(ix
 static inline int opt_selector(const vdb_hip_index* ix) { return (int)opt_value(ix, VDB_OPT_SELECTOR_LEVEL); }
 // VELESDB_BF16_SEED=0: level 2 keeps the exact f32 seed sweep (A / B probes)
 static const bool g_bf16_seed = [] {
-  const char* e = getenv("VELESDB_BF16_SEED");
+  const char* e = probe_env("VELESDB_BF16_SEED");
   return !(e && e[0] == '0');
 }();
 // VELESDB_BF16_GLDS=0: big bf16 batches stay on the register-staged kernel of sweep_gemm.hip (A/B probes)
 static bool gemm_bf16_glds_enabled() {
   static const bool on = [] {
-    const char* e = getenv("VELESDB_BF16_GLDS");
+    const char* e = probe_env("VELESDB_BF16_GLDS");
     return !(e && e[0] == '0');
   }();
   return on;
@@ -331,7 +332,7 @@ int32_t ensure_bits_image(vdb_hip_index* ix, hipStream_t st) {
 // bf16 pipe still beats the f32 pipe's exact kernels (measured: see DESIGN 4.1b)
 static uint32_t select_min_queries() {
   static const uint32_t v = [] {
-    const char* e = getenv("VELESDB_SELECT_MIN_QUERIES");
+    const char* e = probe_env("VELESDB_SELECT_MIN_QUERIES");
     return e ? (uint32_t)atoi(e) : kSelectMinQueries;
   }();
   return v;
@@ -459,7 +460,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     // (VELESDB_SEL_STEPS="a,b,c": tiles per row group of the first launches — schedule probes)
     static const std::array<uint32_t, 3> mult = [] {
       std::array<uint32_t, 3> m{1, 4, 16};
-      if (const char* e = getenv("VELESDB_SEL_STEPS")) {
+      if (const char* e = probe_env("VELESDB_SEL_STEPS")) {
         unsigned a = 0, b = 0, c = 0;
         const int got = sscanf(e, "%u,%u,%u", &a, &b, &c);
         m = {got >= 1 ? a : 0u, got >= 2 ? b : 0u, got >= 3 ? c : 0u};

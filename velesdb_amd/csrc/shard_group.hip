@@ -24,6 +24,7 @@
 #include <functional>
 #include <thread>
 
+#include "vdb_probe_env.hpp"
 #include "vdb_device.hpp"
 #include "vdb_index.hpp"
 #include "vdb_kernels.hpp"
@@ -56,7 +57,7 @@ static Rccl* rccl() {
   static std::once_flag once;
   std::call_once(once, [] {
     std::string& err = rccl_load_error();
-    const char* forced = getenv("VELESDB_RCCL_LIB");
+    const char* forced = probe_env("VELESDB_RCCL_LIB");
     if (forced && forced[0]) {
       r.h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
       if (!r.h) {
@@ -265,11 +266,11 @@ int32_t group_create(vdb_hip_index* parent, const int32_t* devices, int32_t n_de
   // test hook: run the collective branch (ncclCommInitAll + grouped ncclAllGather) over co-located shards.  Real RCCL
   // refuses duplicate devices; the loop-back transport of tests/stub_rccl (VELESDB_RCCL_LIB) does not.
   // (honoured only together with VELESDB_RCCL_LIB, and announced: neither belongs in a deployment's environment)
-  if (const char* fc = getenv("VELESDB_SHARD_FORCE_COLLECTIVE"))
-    if (fc[0] == '1' && getenv("VELESDB_RCCL_LIB")) {
+  if (const char* fc = probe_env("VELESDB_SHARD_FORCE_COLLECTIVE"))
+    if (fc[0] == '1' && probe_env("VELESDB_RCCL_LIB")) {
       g->distinct = true;
       fprintf(stderr, "velesdb-hip: VELESDB_SHARD_FORCE_COLLECTIVE=1 with VELESDB_RCCL_LIB=%s: co-located shards use the collective transport (test hook)\n",
-              getenv("VELESDB_RCCL_LIB"));
+              probe_env("VELESDB_RCCL_LIB"));
     }
   g->gath.resize(S);
   g->ev.assign(S, nullptr);

@@ -39,6 +39,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "vdb_probe_env.hpp"
 #include "vdb_device.hpp"
 #include "vdb_kernels.hpp"
 
@@ -607,7 +608,7 @@ size_t sweep_gemm_lds_bytes(int nqf, uint32_t k, bool big) {
 
 void sweep_gemm_plan(uint32_t nq, uint32_t n_rows, int n_cus, uint32_t k, GemmPlan* p, bool allow_big) {
   static const bool env_big = [] {  // VELESDB_GEMM_BIG=0: never pick the 256 x 256 tile (A/B probes)
-    const char* e = getenv("VELESDB_GEMM_BIG");
+    const char* e = probe_env("VELESDB_GEMM_BIG");
     return !(e && e[0] == '0');
   }();
   // the 256 x 256 tile wins by ~20 % per (padded) query slot: taken when the batch fills its query tiles to >= 7/8

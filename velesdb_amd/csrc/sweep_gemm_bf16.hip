@@ -29,6 +29,7 @@
 // documented => parity with the oracle at the stated tolerance (tests/test_gpu_bf16.py), exactly as the kernel replaced.
 #include <algorithm>
 
+#include "vdb_probe_env.hpp"
 #include "vdb_device.hpp"
 #include "vdb_kernels.hpp"
 
@@ -71,7 +72,6 @@ struct Bf16GemmArgs {
   uint64_t* blk_tau;        // [nq][list_stride]: the bound this block ends with per query (kKeyInvalid: it excluded nothing)
   // result mode (VDB_SEARCH_BRUTE_BF16): [nq] norms of the ROUNDED queries (query_norms_bf16), or nullptr: computed by every block
   const float* qnorms_half;
-  uint32_t prio;  // probe (VELESDB_PP_PRIO): 1 = waves 4-7 at s_setprio 1, 2 = waves 0-3
 };
 
 // The lane id, re-derived where it is needed: a value computed from threadIdx before the main loop stays live across it,
@@ -623,8 +623,9 @@ _Pragma("unroll") \
     pp_wait_dma6();  // k-tile 0 has landed (this wave's share; the barrier: everybody's)
   }
   pp_barrier();
-  if (a.prio == 1u && wr == 1) __builtin_amdgcn_s_setprio(1);
-  if (a.prio == 2u && wr == 0) __builtin_amdgcn_s_setprio(1);
+  // (a static s_setprio 1 for either wave row — MI355X_MICROARCH.md "static priority for the younger half" — measured nothing here:
+  // step 1.602 / 1.586-1.594 / 1.588-1.592 ms for none / waves 4-7 / waves 0-3, profiles/r05c_setprio_ab.log; the phases of this
+  // loop hold no vector-ALU work the two rows could take from each other)
   if (total) VDB_PP_READ_A(a0v, 0, 0);  // A rows 0-63 of k-tile 0 (in the loop: read in phase 4 of the k-tile before)
   if (wr == 1) pp_barrier();  // waves 4-7 run one barrier behind
   // one k-tile: four phases (see the schedule above)
@@ -748,7 +749,7 @@ static_assert(kG16BM == (int)kGemmTileRows && kG16BN == (int)kGemmTileQueries, "
 // VELESDB_BF16_PP=0: the lock-step kernel (A / B probes)
 static bool pingpong_enabled() {
   static const bool on = [] {
-    const char* e = getenv("VELESDB_BF16_PP");
+    const char* e = probe_env("VELESDB_BF16_PP");
     return !(e && e[0] == '0');
   }();
   return on;
@@ -822,11 +823,6 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
   a.qnorms = qnorms;
   a.blk_tau = blk_tau;
   a.qnorms_half = qnorms_half;
-  static const uint32_t prio = [] {
-    const char* e = getenv("VELESDB_PP_PRIO");
-    return e ? (uint32_t)atoi(e) : 0u;
-  }();
-  a.prio = prio;
   if (metric == kHamming) return launch_g16_fp4<kHamming>(a, p.blocks, st);
   if (metric == kJaccard) return launch_g16_fp4<kJaccard>(a, p.blocks, st);
   if (split)

@@ -228,6 +228,7 @@ struct vdb_hip_index {
   vdb::DevBuf s_seed;  // seeding pre-pass of the bf16 GEMM sweep: partial lists, merged prefix top-k, seed keys
   uint64_t euclid_fallbacks = 0;  // queries of Euclidean matrix-core batches re-run through the exact sweep (diagnostic)
   vdb::DevBuf s_visited, s_vlog, s_stats;  // HNSW traversal scratch (hnsw_kernels.hip)
+  vdb::DevBuf s_build_stats;               // [3] u64, cumulative since creation: rows evaluated / distance phases / nodes of the insert kernel
   vdb::DevBuf s_levels, s_req_keys, s_req_vals, s_sort_tmp;  // construction scratch (hnsw_build.hip)
   bool ndist_valid = true;  // false for a graph loaded from files until the cache is recomputed
   uint64_t vis_words = 0;
