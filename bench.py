@@ -68,6 +68,7 @@ def parse():
     # the child of a traffic pass (run under rocprofv3 --pmc FETCH_SIZE by the parent): "headline" = the headline steps only,
     # "hnsw" = the traversal leg over the graph files in --graph-dir, "bf16" = the configs[3] leg
     p.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)
+    p.add_argument("--lib", default="", help="another build of libvelesdb_hip.so to measure (kernel-variant A / B runs; default: the in-tree library)")
     p.add_argument("--graph-dir", default="", help=argparse.SUPPRESS)
     p.add_argument("--no-latency-legs", action="store_true", help="skip the graph-path latency legs and the configs[0] leg")
     p.add_argument("--ef-curve", default="64,128,256,512", help="ef_search values of the recall / QPS curve of the graph legs")
@@ -204,6 +205,9 @@ def main():
     import torch  # first: the HIP runtime it loads is the one libvelesdb_hip.so binds to
     import torch.distributed as dist
     import numpy as np
+    if a.lib:
+        from velesdb_amd import _ffi as _vffi
+        _vffi.use_library(os.path.abspath(a.lib))
     import velesdb_amd as va
 
     rank = int(os.environ.get("RANK", "0"))
@@ -663,14 +667,18 @@ def main():
         # ef_construction + select_neighbors, graph.rs:158-237, 526-581); algorithmic bytes = rows x dim x 4 (random 3-KB gathers), over
         # the WALL time of build_graph (insert + sort + link kernels and the host's batch loop: the insert kernel is ~97 % of it,
         # profiles/r05*_build_kernel_stats.csv)
-        b_rows, b_phases, b_nodes = ix.build_stats()
-        build_bytes = b_rows * D * 4
+        b_rows, b_phases, b_nodes, b_sel = ix.build_stats()
+        # (the rows of select_neighbors are the node's own <= ef_construction candidates, evaluated again against every selected
+        # neighbour: they come out of L2, not out of HBM — the fraction is quoted on the search_layer rows alone, the total beside it)
+        build_bytes = (b_rows - b_sel) * D * 4
         build_roof = {"bound": "hbm", "achieved": round(build_bytes / build_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(build_bytes / build_s / 1e9 / HBM_PEAK_GBS, 4), "alg_bytes": build_bytes,
+                      "frac_with_select_neighbors_rereads": round(b_rows * D * 4 / build_s / 1e9 / HBM_PEAK_GBS, 4),
                       "rows_evaluated_per_insert": round(b_rows / max(b_nodes, 1), 1),
+                      "select_neighbors_rows_per_insert": round(b_sel / max(b_nodes, 1), 1),
                       "distance_phases_per_insert": round(b_phases / max(b_nodes, 1), 1), "nodes": b_nodes, "seconds": round(build_s, 2),
                       "kernel": "hnsw_insert_kernel + hnsw_link_kernel + radix sort of the link requests (wall time of build_graph)",
-                      "alg_bytes_rule": "rows whose distance the insert kernel evaluated x dim x 4 (counters from the kernel)"}
+                      "alg_bytes_rule": "rows whose distance to the NEW node the insert kernel evaluated (search_layer at ef_construction) x dim x 4; counters from the kernel"}
 
         def hstep():
             ix.search_batch_dev(queries.data_ptr(), HQ, K, a.ef, va.MODE_HNSW, h_ids.data_ptr(), h_sc.data_ptr(),

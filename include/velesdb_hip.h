@@ -333,8 +333,11 @@ int32_t vdb_hip_index_graph_info(vdb_hip_index* idx, uint32_t* num_layers, uint3
 /* counters of graph CONSTRUCTION (NativeHnsw::insert, graph.rs:158-237, with select_neighbors :526-581), cumulative since the
  * handle was created: rows whose distance to the inserted node (search_layer at ef_construction) or to a selected neighbour
  * (select_neighbors) was evaluated — the algorithmic gather traffic of the build is that x dim x 4 bytes —, the number of
- * distance phases (dependent memory round trips), and the nodes inserted.  Synchronises the device. */
-int32_t vdb_hip_index_build_stats(vdb_hip_index* idx, uint64_t* rows_evaluated, uint64_t* distance_phases, uint64_t* nodes);
+ * distance phases (dependent memory round trips), the nodes inserted, and how many of the evaluated rows were select_neighbors
+ * evaluations (the <= ef_construction candidate rows of a node re-read once per selected neighbour: cache hits, not HBM traffic).
+ * Synchronises the device. */
+int32_t vdb_hip_index_build_stats(vdb_hip_index* idx, uint64_t* rows_evaluated, uint64_t* distance_phases, uint64_t* nodes,
+                                  uint64_t* select_rows);
 /* counters of the last HNSW search batch: distance evaluations and expansions */
 int32_t vdb_hip_index_last_search_stats(vdb_hip_index* idx, uint64_t* n_dist, uint64_t* n_expand);
 /* of the last HNSW search batch's expansions: how many found their neighbour list already requested — the walk kernel asks for the

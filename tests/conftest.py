@@ -20,9 +20,10 @@ if ROOT not in sys.path:
 
 # A child pytest of tests/test_gpu_switches.py runs the parity tests under an environment switch: switches exist only in the probe build
 # of the library (csrc/vdb_probe_env.hpp), which this harness — not the package — selects.
-if os.environ.get("VDB_TEST_PROBE_LIB") == "1":
+# (VDB_TEST_LIB=<path>: the same for a kernel-variant build under tools/probes/out/ — A / B runs of the parity tests)
+if os.environ.get("VDB_TEST_PROBE_LIB") == "1" or os.environ.get("VDB_TEST_LIB"):
     from velesdb_amd import _ffi as _vdb_ffi
-    _vdb_ffi.use_library(_vdb_ffi.PROBE_LIB_PATH)
+    _vdb_ffi.use_library(os.environ.get("VDB_TEST_LIB") or _vdb_ffi.PROBE_LIB_PATH)
 
 
 def pytest_configure(config):

@@ -131,7 +131,7 @@ extern "C" {
     pub fn vdb_hip_index_set_option(idx: *mut VdbHipIndex, option: i32, value: i64) -> i32;
     pub fn vdb_hip_index_get_option(idx: *mut VdbHipIndex, option: i32, value: *mut i64) -> i32;
     pub fn vdb_hip_index_get_neighbors(idx: *mut VdbHipIndex, layer: u32, node: u64, out: *mut u32, cap: u32, n: *mut u32) -> i32;
-    pub fn vdb_hip_index_build_stats(idx: *mut VdbHipIndex, rows_evaluated: *mut u64, distance_phases: *mut u64, nodes: *mut u64) -> i32;
+    pub fn vdb_hip_index_build_stats(idx: *mut VdbHipIndex, rows_evaluated: *mut u64, distance_phases: *mut u64, nodes: *mut u64, select_rows: *mut u64) -> i32;
     pub fn vdb_hip_index_graph_info(idx: *mut VdbHipIndex, num_layers: *mut u32, max_layer: *mut u32, entry_point: *mut i64) -> i32;
     pub fn vdb_hip_index_last_search_stats(idx: *mut VdbHipIndex, n_dist: *mut u64, n_expand: *mut u64) -> i32;
     pub fn vdb_hip_index_last_prefetch_hits(idx: *mut VdbHipIndex, hits: *mut u64) -> i32;

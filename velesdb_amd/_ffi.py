@@ -88,7 +88,7 @@ SIGNATURES = {
     "vdb_hip_index_set_option": (_i32, [_vp, _i32, C.c_int64]),
     "vdb_hip_index_get_option": (_i32, [_vp, _i32, C.POINTER(C.c_int64)]),
     "vdb_hip_index_combine_stats": (_i32, [_vp, _pu64, _pu64, _pu64, _pu64]),
-    "vdb_hip_index_build_stats": (_i32, [_vp, _pu64, _pu64, _pu64]),
+    "vdb_hip_index_build_stats": (_i32, [_vp, _pu64, _pu64, _pu64, _pu64]),
     "vdb_hip_index_sweep_arith_mode": (_i32, [_vp, _u32, _pi32]),
     "vdb_hip_index_last_kernel_ms": (_i32, [_vp, _pf32, _pu32]),
     "vdb_hip_last_error": (C.c_char_p, []),

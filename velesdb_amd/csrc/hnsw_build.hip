@@ -57,7 +57,9 @@ struct HnswInsertArgs {
   uint32_t* req_n;
   uint32_t* overflow;  // [1] set when a candidate list or the request buffer overflowed
   unsigned long long* stats;  // nullable; [0] += rows evaluated (search_layer + select_neighbors distance phases), [1] += distance
-                              // phases (dependent memory round trips), [2] += nodes inserted: the construction roofline's counters
+                              // phases (dependent memory round trips), [2] += nodes inserted, [3] += the rows of [0] that were
+                              // select_neighbors evaluations (re-reads of <= ef_construction candidate rows: cache hits): the
+                              // construction roofline's counters
   uint32_t first, B, ef, cap, nbmax, vlog_cap, max_layer, entry_point, req_cap;
   float alpha;
 };
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(256) void hnsw_insert_kernel(HnswInsertArgs a) {
     if (threadIdx.x == 0) {
       ctl[4] = 0;
       ctl[5] = 0;
+      ctl[6] = 0;
     }
     int phase = B_START;
     int layer = max((int)a.max_layer, lx);
@@ -398,6 +401,7 @@ __global__ __launch_bounds__(256) void hnsw_insert_kernel(HnswInsertArgs a) {
       if (cmd == CMD_DIST && threadIdx.x == 0 && a.stats) {  // the roofline's counters live in LDS (two registers more cost the kernel a wave per SIMD)
         ctl[4] += m;
         ctl[5] += 1;
+        if (ctl[3] != x) ctl[6] += m;  // a select_neighbors phase: the rows are evaluated against a SELECTED neighbour, not the new node
       }
       if (cmd == CMD_CLEAN) {
         const uint32_t nlog = ctl[2];
@@ -437,6 +441,7 @@ __global__ __launch_bounds__(256) void hnsw_insert_kernel(HnswInsertArgs a) {
       atomicAdd(&a.stats[0], (unsigned long long)ctl[4]);
       atomicAdd(&a.stats[1], (unsigned long long)ctl[5]);
       atomicAdd(&a.stats[2], 1ull);
+      atomicAdd(&a.stats[3], (unsigned long long)ctl[6]);
     }
     __syncthreads();
   }

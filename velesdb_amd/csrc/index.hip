@@ -1804,20 +1804,21 @@ int32_t vdb_hip_index_last_selection_ms(vdb_hip_index* ix, float* total_ms, uint
 }
 
 // construction counters (hnsw_build.hip), cumulative since the handle was created; synchronises the device
-int32_t vdb_hip_index_build_stats(vdb_hip_index* ix, uint64_t* rows_evaluated, uint64_t* distance_phases, uint64_t* nodes) {
+int32_t vdb_hip_index_build_stats(vdb_hip_index* ix, uint64_t* rows_evaluated, uint64_t* distance_phases, uint64_t* nodes, uint64_t* select_rows) {
   return vdb::guarded([&]() -> int32_t {
     if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
     if (ix->group) return fail(VDB_ERR_UNSUPPORTED, "build_stats: ask the shards");
     std::lock_guard<vdb::IndexMutex> g(ix->mu);
     VDB_ENTER(ix);
-    unsigned long long h[3] = {0, 0, 0};
+    unsigned long long h[4] = {0, 0, 0, 0};
     if (ix->s_build_stats.p) {
       VDB_HIP(hipDeviceSynchronize());
-      VDB_HIP(hipMemcpy(h, ix->s_build_stats.p, 24, hipMemcpyDeviceToHost));
+      VDB_HIP(hipMemcpy(h, ix->s_build_stats.p, 32, hipMemcpyDeviceToHost));
     }
     if (rows_evaluated) *rows_evaluated = h[0];
     if (distance_phases) *distance_phases = h[1];
     if (nodes) *nodes = h[2];
+    if (select_rows) *select_rows = h[3];
     return VDB_OK;
   });
 }

@@ -1947,8 +1947,141 @@ hipError_t launch_bits_plan(int metric, const BitsPlan& p, const BitsArgs& a, ui
   return p.tile ? launch_sweep_bits_tile(metric, p.B, a, p.blocks, nq, st) : launch_sweep_bits_batch(metric, p.B, a, p.blocks, nq, st);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same per-query sweep with COALESCED row loads (round 5).  sweep_topk_bits gives every lane its own row: a 96-byte row (768
+// bits) is six 16-byte loads per lane at a 96-byte stride between lanes — every load instruction of a wave touches 48 cache lines
+// for 1 KiB of payload, and the kernel ran at 0.30 of HBM (40 us for the 96 MB of 1 M x 768 bits).  Here a wave's 64 rows are one
+// contiguous chunk of 64 P sixteen-byte pieces (P = words / 4): load j takes pieces 64 j + lane — 1 KiB per instruction, 8 whole
+// lines —, every lane reduces its piece against the query piece it belongs to (piece index mod P, stepped without a division), the
+// per-piece counts go through the wave's own LDS strip, and lane r sums the P counts of row r.  Integer work: the same counts, the
+// same scores, the same keys as the lane-per-row kernel (tests/test_gpu_sweep.py compares both with the oracle).
+// Per-piece counts: Hamming |x ^ q| <= 128; Jaccard |x & q| and |x | q| <= 128 each, packed as inter | uni << 16.
+// ------------------------------------------------------------------------------------------
+template <int METRIC, int P>
+__global__ __launch_bounds__(256) void sweep_topk_bits_co(BitsArgs a) {
+  constexpr bool HIB = higher_is_better(METRIC);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int wib = (int)(threadIdx.x >> 6);
+  const uint32_t wave = blockIdx.x * 4 + wib;
+  const uint32_t nwaves = gridDim.x * 4;
+  const uint32_t qi = blockIdx.y;
+  const uint32_t k = a.k;
+  constexpr uint32_t W = 4u * P;
+  // LDS: list[k] u64 (block-shared, locked) | cnt, lock | query words [W] | per-wave strips [4][64 P] u32
+  lds_vu64* list = (lds_vu64*)(lds_void_p)(smem);
+  lds_vu32* cnt = (lds_vu32*)(lds_void_p)(smem + (size_t)k * 8);
+  uint32_t* lock = reinterpret_cast<uint32_t*>(smem + (size_t)k * 8 + 4);
+  uint32_t* qw = reinterpret_cast<uint32_t*>(smem + (((size_t)k * 8 + 8 + 15) & ~(size_t)15));
+  uint32_t* strip = qw + W + (size_t)wib * 64 * P;
+  if (threadIdx.x == 0) {
+    *cnt = 0;
+    *lock = 0;
+  }
+  for (uint32_t i = threadIdx.x; i < W; i += 256) qw[i] = a.qbits[(size_t)qi * W + i];
+  __syncthreads();
+  // the query piece of (load j, lane): (64 j + lane) mod P — the lane's piece of load 0, then + (64 mod P) per load
+  uint4 qp[P];
+  {
+    uint32_t pc = (uint32_t)lane % P;
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+      qp[j] = *reinterpret_cast<const uint4*>(qw + pc * 4);
+      pc += 64u % P;
+      if (pc >= (uint32_t)P) pc -= P;
+    }
+  }
+  for (uint64_t base = (uint64_t)wave * 64; base < a.n_rows; base += (uint64_t)nwaves * 64) {
+    const uint32_t row = (uint32_t)base + lane;
+    const bool valid = row < a.n_rows;
+    const uint4* chunk = reinterpret_cast<const uint4*>(a.bits + base * W);  // 64 rows = 64 P pieces, contiguous
+    const uint64_t pieces_left = (a.n_rows - base) * P;                       // pieces that exist behind `chunk`
+    uint4 x[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+      const uint32_t pj = (uint32_t)j * 64u + (uint32_t)lane;
+      x[j] = pj < pieces_left ? chunk[pj] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+      uint32_t c;
+      if (METRIC == kHamming) {
+        c = __popc(x[j].x ^ qp[j].x) + __popc(x[j].y ^ qp[j].y) + __popc(x[j].z ^ qp[j].z) + __popc(x[j].w ^ qp[j].w);
+      } else {
+        const uint32_t in = __popc(x[j].x & qp[j].x) + __popc(x[j].y & qp[j].y) + __popc(x[j].z & qp[j].z) + __popc(x[j].w & qp[j].w);
+        const uint32_t un = __popc(x[j].x | qp[j].x) + __popc(x[j].y | qp[j].y) + __popc(x[j].z | qp[j].z) + __popc(x[j].w | qp[j].w);
+        c = in | (un << 16);
+      }
+      strip[j * 64 + lane] = c;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < P; i++) sum += strip[lane * P + i];  // the P pieces of row `lane` (packed halves cannot carry: P * 128 < 2^16)
+    __builtin_amdgcn_wave_barrier();  // strip reads done before the next chunk overwrites it
+    float score;
+    if (METRIC == kHamming) {
+      score = (float)sum;
+    } else {
+      const uint32_t inter = sum & 0xFFFFu, uni = sum >> 16;
+      score = (uni == 0) ? 1.0f : (float)inter / (float)uni;  // simd_explicit.rs:431-442
+    }
+    uint64_t key = valid ? make_key<HIB>(score, row) : kKeyInvalid;
+    const uint64_t tau = (*cnt == k) ? list[k - 1] : kKeyInvalid;
+    uint64_t mask = __ballot(key < tau);
+    if ((uint32_t)__popcll(mask) > k) {  // (as sweep_topk_bits: rank the passing keys among themselves first)
+      if (a.alive && (mask >> lane & 1ull) && a.alive[row] == 0) key = kKeyInvalid;
+      mask = __ballot(key < tau);
+      uint32_t rank = 0;
+      uint64_t rest = mask;
+      while (rest) {
+        const int src = __ffsll((long long)rest) - 1;
+        rest &= rest - 1;
+        rank += readlane64(key, src) < key ? 1u : 0u;
+      }
+      mask = __ballot((mask >> lane & 1ull) && rank < k);
+    }
+    while (mask) {
+      const int src = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const uint64_t kk = readlane64(key, src);
+      if (a.alive && a.alive[key_row(kk)] == 0) continue;
+      shared_list_offer(list, cnt, lock, k, kk, lane);
+    }
+  }
+  __syncthreads();
+  if (wib != 0) return;
+  const uint32_t c = *cnt;
+  uint64_t* dst = a.part_keys + ((size_t)qi * gridDim.x + blockIdx.x) * k;
+  for (uint32_t e = lane; e < k; e += 64) dst[e] = e < c ? list[e] : kKeyInvalid;
+}
+template <int P>
+static void launch_sweep_bits_co(int metric, const BitsArgs& a, int blocks, uint32_t nq, size_t lds, hipStream_t st) {
+  if (metric == kHamming)
+    hipLaunchKernelGGL((sweep_topk_bits_co<kHamming, P>), dim3(blocks, nq), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL((sweep_topk_bits_co<kJaccard, P>), dim3(blocks, nq), dim3(256), lds, st, a);
+}
+
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st) {
   const size_t lds = ((((size_t)a.k * 8 + 8 + 15) & ~(size_t)15) + (size_t)a.words * 4 + 15) & ~(size_t)15;
+  // rows of 1, 2, 3, 4, 6, 8 or 12 sixteen-byte pieces (128 .. 1 536 bits): the coalesced kernel (+ 4 x 64 P counts of LDS)
+  const uint32_t pcs = a.words / 4;
+  const size_t lds_co = lds + (size_t)4 * 64 * pcs * 4;
+  if (a.words % 4 == 0 && lds_co <= 64 * 1024) {
+    switch (pcs) {
+      case 1: return launch_sweep_bits_co<1>(metric, a, blocks, nq, lds_co, st);
+      case 2: return launch_sweep_bits_co<2>(metric, a, blocks, nq, lds_co, st);
+      case 3: return launch_sweep_bits_co<3>(metric, a, blocks, nq, lds_co, st);
+      case 4: return launch_sweep_bits_co<4>(metric, a, blocks, nq, lds_co, st);
+      case 6: return launch_sweep_bits_co<6>(metric, a, blocks, nq, lds_co, st);
+      case 8: return launch_sweep_bits_co<8>(metric, a, blocks, nq, lds_co, st);
+      case 12: return launch_sweep_bits_co<12>(metric, a, blocks, nq, lds_co, st);
+      default: break;
+    }
+  }
   if (metric == kHamming)
     hipLaunchKernelGGL((sweep_topk_bits<kHamming>), dim3(blocks, nq), dim3(256), lds, st, a);
   else

@@ -146,7 +146,6 @@ __device__ __forceinline__ void wait_glds() { asm volatile("s_waitcnt vmcnt(0)" 
 template <int METRIC, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs a) {
   constexpr bool HIB = true;  // Cosine / DotProduct
-  constexpr bool QT_DENSE = true;  // accumulators in vector registers: the round-5 quick test (g16_quicktest_dense.inc)
   constexpr int BM = kG16BM, BN = kG16BN, WAVES = kG16Waves, CAP = kG16Cap, QCAP = kG16Queue;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* cand = reinterpret_cast<uint64_t*>(smem + kOffCand);   // [BN][CAP]
@@ -353,8 +352,8 @@ _Pragma("unroll") \
     const bool more = it < total;
 #define VDB_G16_ACC_F(V) (V)
 #include "g16_quicktest.inc"
-    if constexpr (METRIC == kHamming || METRIC == kJaccard || !QT_DENSE) {
-#include "g16_quicktest_groups.inc"
+    if constexpr (METRIC == kHamming || METRIC == kJaccard) {
+#include "g16_quicktest_bits.inc"
     } else {
 #include "g16_quicktest_dense.inc"
     }
@@ -456,7 +455,6 @@ template <int METRIC, bool FP4 = false>
 __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a) {
   static_assert(FP4 == (METRIC == kHamming || METRIC == kJaccard), "the four-bit instance serves the bit metrics, the bf16 instance Cosine / DotProduct");
   constexpr bool HIB = METRIC != kHamming;  // Cosine / DotProduct / Jaccard: higher is better; Hamming: a distance
-  constexpr bool QT_DENSE = true;
   constexpr int BM = kG16BM, BN = kG16BN, WAVES = kG16Waves, CAP = kG16Cap, QCAP = kG16Queue;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* cand = reinterpret_cast<uint64_t*>(smem + kOffCand);   // [BN][CAP]
@@ -608,6 +606,9 @@ _Pragma("unroll") \
       } \
     } \
   } while (0)
+  // (Round 5, measured and rejected: the two requests of a phase issued BEHIND its 16 products — the multiplying wave row pays for
+  // them instead of the reading one, waits at vmcnt(4).  3-4 % slower: 1.497-1.504 against 1.454 ms per step's launches, the 10 M bf16
+  // batch 13.96-14.09 against 13.11 ms; profiles/r05e_requests_after_mfma_ab.log, tools/probes/pp_requests_after_mfma_experiment.patch.)
   uint32_t c = 0;  // k-tiles done
   if (total) {
     // prologue: k-tile 0 complete (stage 0), of k-tile 1 (stage 1) everything but B1 — the request order of the loop
@@ -669,8 +670,8 @@ _Pragma("unroll") \
     const bool more = c < total;
 #define VDB_G16_ACC_F(V) (V)
 #include "g16_quicktest.inc"  // (waves 0-3: beside the last products of waves 4-7)
-    if constexpr (METRIC == kHamming || METRIC == kJaccard || !QT_DENSE) {
-#include "g16_quicktest_groups.inc"
+    if constexpr (METRIC == kHamming || METRIC == kJaccard) {
+#include "g16_quicktest_bits.inc"
     } else {
 #include "g16_quicktest_dense.inc"
     }

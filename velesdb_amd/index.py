@@ -496,10 +496,11 @@ class HnswIndex:
 
     def build_stats(self):
         """Construction counters, cumulative since the handle was created: (rows whose distance was evaluated by the insert kernel's
-        search_layer / select_neighbors phases, distance phases = dependent memory round trips, nodes inserted)."""
-        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
-        check(lib().vdb_hip_index_build_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return int(a.value), int(b.value), int(c.value)
+        search_layer / select_neighbors phases, distance phases = dependent memory round trips, nodes inserted, the rows of the first
+        count that were select_neighbors evaluations — re-reads of a node's <= ef_construction candidate rows, cache hits)."""
+        a, b, c, d = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(lib().vdb_hip_index_build_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return int(a.value), int(b.value), int(c.value), int(d.value)
 
     def last_prefetch_hits(self):
         """Expansions of the last graph search batch whose neighbour ids had been requested one pop ahead (the walk's prediction)."""
