@@ -1,0 +1,55 @@
+"""Stamped timeline of the selection kernel's k-tile: runs the headline batch (1 M x 768 cosine, 1 024
+queries, k = 10) on a -DVDB_PP_STAMP variant of the library (tools/probes/pp_variants.sh) and prints, for one wave of each wave row
+of block 8, the average shader cycles per k-tile spent in each segment of the four-phase schedule of sweep_topk_gemm_bf16_pp.
+    python tools/probes/pp_stamp_probe.py tools/probes/out/libvelesdb_hip_stamp1.so [rows]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from velesdb_amd import _ffi  # noqa: E402
+
+lib_path = os.path.abspath(sys.argv[1])
+_ffi.use_library(lib_path)
+import torch  # noqa: E402,F401  (first: the HIP runtime it loads is the one the library binds to)
+import velesdb_amd as va  # noqa: E402
+
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+D, Q, K = 768, 1024, 10
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev)
+g.manual_seed(42)
+ix = va.HnswIndex(D, va.DistanceMetric.Cosine, va.HnswParams(16, 100, N))
+stream = torch.cuda.current_stream().cuda_stream
+for base in range(0, N, 250_000):
+    c = torch.randn((min(250_000, N - base), D), generator=g, device=dev)
+    torch.cuda.synchronize()
+    ix.upload_dev(base, c.data_ptr(), c.shape[0], stream)
+    torch.cuda.synchronize()
+    del c
+qs = torch.randn((Q, D), generator=g, device=dev).cpu().numpy()
+for _ in range(4):
+    ids, sc, cnt = ix.search_batch_brute_force(qs, K)
+assert ix.last_select_level() == 2, ix.last_select_level()
+L = C.CDLL(lib_path)
+buf = (C.c_ulonglong * 20)()
+rc = L.vdb_hip_debug_pp_stamps(buf)
+assert rc == 0, rc
+names = ["ph1-2: reads + requests + waits + opening barrier", "ph1-2: 16 products", "ph1-2: closing barrier", "ph1-2: (issue of reads + requests only)",
+         "ph3-4: requests (+ reads) + vmcnt/lgkmcnt waits + opening barrier", "ph3-4: 16 products", "ph3-4: closing barrier", "ph3-4: (issue only)",
+         "epilogue (quick test + protocol + re-read), per ROW TILE", "k-tiles"]
+for w, row in enumerate(("wave 0 (row 0)", "wave 4 (row 1)")):
+    v = [int(buf[w * 10 + i]) for i in range(10)]
+    kt = max(v[9], 1)
+    print(f"{row}: {kt} k-tiles of the batch's last (largest) selection launch, block 8")
+    tot = 0.0
+    for i in range(8):
+        per = v[i] / kt   # two phases of the pair per k-tile
+        tot += per
+        print(f"   {names[i]:70s} {per:9.1f} cycles per k-tile  ({per / 2:7.1f} per phase)")
+    print(f"   {'sum of the segments':70s} {tot:9.1f} cycles per k-tile  (the 64 products of a wave need 64 x 16 = 1 024; both rows' = 2 048 per SIMD)")
+    print(f"   {names[8]:70s} {v[8] / (kt / 12):9.1f} cycles per row tile (12 k-tiles)")
+ix.close()

@@ -72,6 +72,7 @@ struct Bf16GemmArgs {
   uint64_t* blk_tau;        // [nq][list_stride]: the bound this block ends with per query (kKeyInvalid: it excluded nothing)
   // result mode (VDB_SEARCH_BRUTE_BF16): [nq] norms of the ROUNDED queries (query_norms_bf16), or nullptr: computed by every block
   const float* qnorms_half;
+  unsigned long long* dbg;  // (-DVDB_PP_STAMP variant builds only; nullptr otherwise)
 };
 
 // The lane id, re-derived where it is needed: a value computed from threadIdx before the main loop stays live across it,
@@ -629,40 +630,96 @@ _Pragma("unroll") \
   // loop hold no vector-ALU work the two rows could take from each other)
   if (total) VDB_PP_READ_A(a0v, 0, 0);  // A rows 0-63 of k-tile 0 (in the loop: read in phase 4 of the k-tile before)
   if (wr == 1) pp_barrier();  // waves 4-7 run one barrier behind
+  // ---- wall-clock stamps of the phases (variant build only: -DVDB_PP_STAMP=1 = boundaries of every phase, =2 = also behind the
+  // ---- issue of a phase's reads / requests; tools/probes/pp_stamp_probe.py).  One wave of each row of block 8 of the bf16 cosine
+  // ---- instance reads the shader clock (s_memtime, waited for at once: ~60 cycles each, which the numbers include) and adds the time
+  // ---- since its previous stamp to the slot of the segment that just ended: slot = 4 x (phase pair: 0 = phases 1-2, 1 = phases 3-4) +
+  // ---- {0 reads + requests + waits + opening barrier, 1 the 16 products, 2 closing barrier, 3 (=2 only) issue of reads + requests};
+  // ---- slot 8 = epilogue, 9 = k-tiles counted.
+#ifndef VDB_PP_STAMP
+#define VDB_PP_STAMP 0
+#endif
+#if VDB_PP_STAMP
+  const bool st_on = a.dbg != nullptr && blockIdx.x == 8u && (wib == 0 || wib == 4) && !FP4 && METRIC == kCosine;
+  uint32_t st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t st_last = 0;
+#define VDB_PP_STAMP_AT(SLOT) do { \
+    if (st_on) { \
+      uint64_t t_; \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+      st_acc[SLOT] += (uint32_t)t_ - st_last; \
+      st_last = (uint32_t)t_; \
+    } \
+  } while (0)
+#define VDB_PP_STAMP_ISSUE(SLOT) do { if (VDB_PP_STAMP >= 2) VDB_PP_STAMP_AT(SLOT); } while (0)
+#else
+#define VDB_PP_STAMP_AT(SLOT) do { } while (0)
+#define VDB_PP_STAMP_ISSUE(SLOT) do { } while (0)
+#endif
+  // The reads-and-requests part of a phase is the longest segment of the loop (stamped timeline, profiles/r05g_*: "issue of reads +
+  // requests" 270-356 of a phase's ~870 cycles against 311 for its 16 products): an LDS-DMA request costs the issuing wave ~120-150
+  // cycles here whatever surrounds it.  Round 5 tried to move that cost, twice, and both forms are SLOWER: the requests behind the
+  // products (3-4 %, profiles/r05e_*) and the odd query columns of a row issuing requests first, the even ones reads first
+  // (4-5 %, the issue segment grows to 414 cycles: profiles/r05h_*; tools/probes/pp_stagger_experiment.patch).
+#define VDB_PP_LPART(READS, REQS) do { \
+    READS; \
+    REQS; \
+  } while (0)
   // one k-tile: four phases (see the schedule above)
 #define VDB_PP_KTILE(FIRST, LAST) do { \
     const uint32_t buf = c & 1u; \
     /* phase 1 */ \
-    VDB_PP_READ_B(buf); \
-    VDB_PP_REQ_B(1, kt1, buf ^ 1u); \
+    VDB_PP_LPART(VDB_PP_READ_B(buf), VDB_PP_REQ_B(1, kt1, buf ^ 1u)); \
     if ((FIRST) && wib == 0) /* the row tile's norms (vns was last read in the epilogue before) */ \
       glds_b128(make_rsrc_uniform(reinterpret_cast<const unsigned char*>(a.norms) + (size_t)rt * BM * 4, norm_records(a.n_rows, rt)), lane_now() * 16u, 0u, lds0 + (uint32_t)kOffVns); \
+    VDB_PP_STAMP_ISSUE(3); \
     pp_barrier_reads_done(); \
+    VDB_PP_STAMP_AT(0); \
     VDB_PP_MFMA(a0v, 0, 0, FIRST); \
+    VDB_PP_STAMP_AT(1); \
     pp_barrier(); \
+    VDB_PP_STAMP_AT(2); \
     /* phase 2 */ \
-    VDB_PP_READ_A(a1v, 4, buf); \
-    VDB_PP_REQ_B(0, kt2, buf); \
+    VDB_PP_LPART(VDB_PP_READ_A(a1v, 4, buf), VDB_PP_REQ_B(0, kt2, buf)); \
+    VDB_PP_STAMP_ISSUE(3); \
     pp_barrier_reads_done(); \
+    VDB_PP_STAMP_AT(0); \
     VDB_PP_MFMA(a0v, 0, 2, FIRST); \
+    VDB_PP_STAMP_AT(1); \
     pp_barrier(); \
+    VDB_PP_STAMP_AT(2); \
     /* phase 3 */ \
     VDB_PP_REQ_A(0, rt2, kt2, buf); \
+    VDB_PP_STAMP_ISSUE(7); \
     pp_wait_dma6(); \
     pp_barrier_reads_done(); \
+    VDB_PP_STAMP_AT(4); \
     VDB_PP_MFMA(a1v, 4, 2, FIRST); \
+    VDB_PP_STAMP_AT(5); \
     pp_barrier(); \
+    VDB_PP_STAMP_AT(6); \
     /* phase 4 */ \
-    if (!(LAST)) VDB_PP_READ_A(a0v, 0, buf ^ 1u); /* (the last k-tile of a row tile: read behind the epilogue, which gets the registers) */ \
-    VDB_PP_REQ_A(1, rt2, kt2, buf); \
+    /* (the last k-tile of a row tile: read behind the epilogue, which gets the registers) */ \
+    VDB_PP_LPART(if (!(LAST)) VDB_PP_READ_A(a0v, 0, buf ^ 1u), VDB_PP_REQ_A(1, rt2, kt2, buf)); \
+    VDB_PP_STAMP_ISSUE(7); \
     pp_wait_dma6(); \
     pp_barrier_reads_done(); \
+    VDB_PP_STAMP_AT(4); \
     VDB_PP_MFMA(a1v, 4, 0, FIRST); \
+    VDB_PP_STAMP_AT(5); \
     pp_barrier(); \
+    VDB_PP_STAMP_AT(6); \
     VDB_PP_NEXT2(); \
     c++; \
   } while (0)
 
+#if VDB_PP_STAMP
+  if (st_on) {  // the first stamp: everything before the loop is nobody's segment
+    uint64_t t_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+    st_last = (uint32_t)t_;
+  }
+#endif
   for (uint32_t rt = rt_first; rt < ntiles; rt += a.G) {
     VDB_PP_KTILE(true, false);
     for (uint32_t kt = 1; kt + 1 < a.KT; kt++) VDB_PP_KTILE(false, false);
@@ -685,6 +742,7 @@ _Pragma("unroll") \
     VDB_PP_LANE();
     VDB_PP_READ_A(a0v, 0, c & 1u);
     if (more && wr == 1) pp_barrier();  // ... and waves 4-7 fall one barrier behind again
+    VDB_PP_STAMP_AT(8);
   }
 #undef VDB_PP_KTILE
 #undef VDB_PP_LANE
@@ -695,6 +753,13 @@ _Pragma("unroll") \
 #undef VDB_PP_REQ_B
 #undef VDB_PP_REQ_A
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // requests past the end must not land in LDS that is no longer ours
+#if VDB_PP_STAMP
+  if (st_on && lane_now() == 0) {  // [launch-size class][wave row][10]: the LARGEST launch of the batch is what the probe reads
+    st_acc[9] = c;
+    unsigned long long* d = a.dbg + (size_t)(wib == 0 ? 0 : 1) * 10;
+    for (int i = 0; i < 10; i++) d[i] = st_acc[i];
+  }
+#endif
 #include "g16_writeout.inc"
 }
 
@@ -743,6 +808,16 @@ void launch_seed_tau(const uint64_t* ids, const float* scores, const uint32_t* n
   else hipLaunchKernelGGL(seed_tau_kernel<false>, dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, tau0, list, list_stride, nq, k);
 }
 
+#if VDB_PP_STAMP
+static unsigned long long* g_pp_stamp_buf = nullptr;
+}  // namespace vdb
+extern "C" int32_t vdb_hip_debug_pp_stamps(unsigned long long* out /* [2][10] */) {
+  if (!vdb::g_pp_stamp_buf) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  return hipMemcpy(out, vdb::g_pp_stamp_buf, 160, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+namespace vdb {
+#endif
 // ---- host side -------------------------------------------------------------------------------------------
 // (sweep_gemm_bf16_plan, gemm_schedule: vdb_gemm_schedule.hpp — host arithmetic only, checked on the CPU by tests/gemm_schedule_model.cpp)
 static_assert(kG16BM == (int)kGemmTileRows && kG16BN == (int)kGemmTileQueries, "the schedule's tile is the kernel's");
@@ -824,6 +899,17 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
   a.qnorms = qnorms;
   a.blk_tau = blk_tau;
   a.qnorms_half = qnorms_half;
+#if VDB_PP_STAMP
+  {
+    static unsigned long long* dbg = [] {
+      void* p = nullptr;
+      if (hipMalloc(&p, 256) == hipSuccess) (void)hipMemset(p, 0, 256);
+      return static_cast<unsigned long long*>(p);
+    }();
+    g_pp_stamp_buf = dbg;
+    a.dbg = dbg;  // (every launch of the batch writes it; the last — the largest — launch's numbers stay)
+  }
+#endif
   if (metric == kHamming) return launch_g16_fp4<kHamming>(a, p.blocks, st);
   if (metric == kJaccard) return launch_g16_fp4<kJaccard>(a, p.blocks, st);
   if (split)
