@@ -35,14 +35,14 @@ for _ in range(4):
     ids, sc, cnt = ix.search_batch_brute_force(qs, K)
 assert ix.last_select_level() == 2, ix.last_select_level()
 L = C.CDLL(lib_path)
-buf = (C.c_ulonglong * 20)()
+buf = (C.c_ulonglong * 40)()
 rc = L.vdb_hip_debug_pp_stamps(buf)
 assert rc == 0, rc
 names = ["ph1-2: reads + requests + waits + opening barrier", "ph1-2: 16 products", "ph1-2: closing barrier", "ph1-2: (issue of reads + requests only)",
          "ph3-4: requests (+ reads) + vmcnt/lgkmcnt waits + opening barrier", "ph3-4: 16 products", "ph3-4: closing barrier", "ph3-4: (issue only)",
          "epilogue (quick test + protocol + re-read), per ROW TILE", "k-tiles"]
 for w, row in enumerate(("wave 0 (row 0)", "wave 4 (row 1)")):
-    v = [int(buf[w * 10 + i]) for i in range(10)]
+    v = [int(buf[w * 20 + i]) for i in range(20)]
     kt = max(v[9], 1)
     print(f"{row}: {kt} k-tiles of the batch's last (largest) selection launch, block 8")
     tot = 0.0
@@ -51,5 +51,10 @@ for w, row in enumerate(("wave 0 (row 0)", "wave 4 (row 1)")):
         tot += per
         print(f"   {names[i]:70s} {per:9.1f} cycles per k-tile  ({per / 2:7.1f} per phase)")
     print(f"   {'sum of the segments':70s} {tot:9.1f} cycles per k-tile  (the 64 products of a wave need 64 x 16 = 1 024; both rows' = 2 048 per SIMD)")
-    print(f"   {names[8]:70s} {v[8] / (kt / 12):9.1f} cycles per row tile (12 k-tiles)")
+    rtiles = kt / 12
+    print(f"   {names[8]:70s} {v[8] / rtiles:9.1f} cycles per row tile (12 k-tiles)")
+    for slot, nm in ((10, "epilogue: quick test (waves 0-3: beside the last products of waves 4-7)"), (11, "epilogue: alignment barrier"),
+                     (12, "epilogue: look phase (scan of hot lanes + finish), all rounds"), (13, "epilogue: sync-point barrier(s)"),
+                     (14, "epilogue: compaction + its barrier (when one runs)"), (15, "epilogue: append"), (8, "epilogue: the rest (re-derive lane terms, re-read A fragments, fall-behind barrier)")):
+        print(f"   {nm:70s} {v[slot] / rtiles:9.1f} cycles per row tile")
 ix.close()

@@ -641,7 +641,7 @@ _Pragma("unroll") \
 #endif
 #if VDB_PP_STAMP
   const bool st_on = a.dbg != nullptr && blockIdx.x == 8u && (wib == 0 || wib == 4) && !FP4 && METRIC == kCosine;
-  uint32_t st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t st_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t st_last = 0;
 #define VDB_PP_STAMP_AT(SLOT) do { \
     if (st_on) { \
@@ -732,7 +732,9 @@ _Pragma("unroll") \
     } else {
 #include "g16_quicktest_dense.inc"
     }
+    VDB_PP_STAMP_AT(10);  // (epilogue legs, stamped builds: 10 quick test, 11 alignment barrier, 12-15 inside g16_protocol.inc, 8 the rest)
     if (wr == 0) pp_barrier();  // waves 0-3 wait for the last products of waves 4-7: the block is aligned again
+    VDB_PP_STAMP_AT(11);
 #define VDB_G16_ACC_ELEM(X, A) asm volatile("v_mov_b32 %0, %1" : "=v"(X) : "v"(A))
 #include "g16_protocol.inc"
 #undef VDB_G16_ACC_ELEM
@@ -756,8 +758,8 @@ _Pragma("unroll") \
 #if VDB_PP_STAMP
   if (st_on && lane_now() == 0) {  // [launch-size class][wave row][10]: the LARGEST launch of the batch is what the probe reads
     st_acc[9] = c;
-    unsigned long long* d = a.dbg + (size_t)(wib == 0 ? 0 : 1) * 10;
-    for (int i = 0; i < 10; i++) d[i] = st_acc[i];
+    unsigned long long* d = a.dbg + (size_t)(wib == 0 ? 0 : 1) * 20;
+    for (int i = 0; i < 20; i++) d[i] = st_acc[i];
   }
 #endif
 #include "g16_writeout.inc"
@@ -811,10 +813,10 @@ void launch_seed_tau(const uint64_t* ids, const float* scores, const uint32_t* n
 #if VDB_PP_STAMP
 static unsigned long long* g_pp_stamp_buf = nullptr;
 }  // namespace vdb
-extern "C" int32_t vdb_hip_debug_pp_stamps(unsigned long long* out /* [2][10] */) {
+extern "C" int32_t vdb_hip_debug_pp_stamps(unsigned long long* out /* [2][20] */) {
   if (!vdb::g_pp_stamp_buf) return -1;
   if (hipDeviceSynchronize() != hipSuccess) return -2;
-  return hipMemcpy(out, vdb::g_pp_stamp_buf, 160, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+  return hipMemcpy(out, vdb::g_pp_stamp_buf, 320, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
 namespace vdb {
 #endif
@@ -903,7 +905,7 @@ hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const 
   {
     static unsigned long long* dbg = [] {
       void* p = nullptr;
-      if (hipMalloc(&p, 256) == hipSuccess) (void)hipMemset(p, 0, 256);
+      if (hipMalloc(&p, 512) == hipSuccess) (void)hipMemset(p, 0, 512);
       return static_cast<unsigned long long*>(p);
     }();
     g_pp_stamp_buf = dbg;
