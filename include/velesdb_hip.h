@@ -338,7 +338,12 @@ int32_t vdb_hip_index_graph_info(vdb_hip_index* idx, uint32_t* num_layers, uint3
  * Synchronises the device. */
 int32_t vdb_hip_index_build_stats(vdb_hip_index* idx, uint64_t* rows_evaluated, uint64_t* distance_phases, uint64_t* nodes,
                                   uint64_t* select_rows);
-/* counters of the last HNSW search batch: distance evaluations and expansions */
+/* counters of the last HNSW search batch: distance evaluations and expansions.
+ * NOTE for every vdb_hip_index_last_* diagnostic below: with the combining front on (VDB_OPT_COMBINE_MAX_BATCH > 1, the default)
+ * a host-pointer call of <= 64 queries may have travelled in ONE launch with other callers' requests; the diagnostics then describe
+ * that whole combined launch (all its queries), not the caller's own call, and the next batch served by the same search context may
+ * overwrite them before they are read.  A caller that wants per-call numbers sets VDB_OPT_COMBINE_MAX_BATCH to 0 on the handle
+ * (bench.py reads them after single-threaded calls only). */
 int32_t vdb_hip_index_last_search_stats(vdb_hip_index* idx, uint64_t* n_dist, uint64_t* n_expand);
 /* of the last HNSW search batch's expansions: how many found their neighbour list already requested — the walk kernel asks for the
  * list of the nearest candidate it leaves unexpanded together with the list of the one it expands (the predicted next pop); a measure
