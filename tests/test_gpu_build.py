@@ -279,3 +279,28 @@ def test_build_with_massive_exact_ties_grows_the_candidate_list():
     for q, r in zip(qs, res):
         oid, _ = g.search(q, 10, 100, po.TIE_CANONICAL)
         assert [x[0] for x in r] == oid.tolist()
+
+
+def test_build_stats_are_cumulative_and_consistent():
+    """vdb_hip_index_build_stats (the construction roofline's counters, bench.py hnsw.build.roofline): rows evaluated by the insert
+    kernel (graph.rs:158-237: greedy descent + search_layer at ef_construction per layer; select_neighbors :526-581), distance
+    phases, nodes that searched a non-empty graph, and the select_neighbors share — a strict part of the total; cumulative over
+    sequential and batched inserts on one handle."""
+    rng = np.random.default_rng(31)
+    n, dim, M, efc = 400, 48, 8, 40
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    ix = va.HnswIndex(dim, DM.Euclidean, va.HnswParams(M, efc, n))
+    assert ix.build_stats() == (0, 0, 0, 0)
+    for i in range(n):
+        ix.insert(i, rows[i])
+    total, phases, nodes, sel = ix.build_stats()
+    assert nodes == n - 1                      # the first insert finds an empty graph: no search (graph.rs:161-169)
+    assert 0 < sel < total and phases >= nodes
+    assert total >= nodes * 2                  # every searching insert evaluates at least the entry point and a neighbour
+    # cumulative: a second handle-level build step adds to the same counters
+    more = rng.standard_normal((50, dim)).astype(np.float32)
+    ix2_before = ix.build_stats()
+    ix.insert_batch_parallel([(n + i, more[i]) for i in range(50)], 16)
+    t2, p2, n2, s2 = ix.build_stats()
+    assert n2 == ix2_before[2] + 50 and t2 > ix2_before[0] and p2 > ix2_before[1] and s2 >= ix2_before[3]
+    ix.close()
