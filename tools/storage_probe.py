@@ -33,6 +33,8 @@ for mode, name, smode, row_bytes in ((va.MODE_BRUTE_SQ8, "sq8", va.StorageMode.S
     ix.set_storage_mode(smode)
     print(f"{name}: encoded {a.rows} rows in {(time.perf_counter()-t0)*1e3:.1f} ms", flush=True)
     for nq in [int(x) for x in a.nqs.split(",")]:
+        if name == "sq8" and os.environ.get("SQ8_EXACT") == "1":
+            va.set_split_selector(0)
         ids = torch.empty((nq, a.k), dtype=torch.int64, device=dev)
         sc = torch.empty((nq, a.k), dtype=torch.float32, device=dev)
         n = torch.empty((nq,), dtype=torch.int32, device=dev)

@@ -142,6 +142,93 @@ struct Sq8Args {
 
 constexpr int kSq8TileStride = 80;  // bytes per row of the staging tile: 64 + 16 padding (conflict-free b128 reads)
 
+typedef float sq8_f32x4 __attribute__((ext_vector_type(4)));
+// One broadcast read of four queries' element (16 bytes at a wave-uniform LDS address), WRITTEN AS AN INSTRUCTION.  Left to the
+// compiler the unrolled 64-code chunk came out as [one ds_read, s_waitcnt lgkmcnt(0), four vector instructions] x 128: every LDS
+// round trip exposed, half of every wave's time in s_waitcnt (round 5 counters, profiles/r05k_*: vector ALU busy 0.54, LDS array
+// 0.43, SQ_WAIT_ANY 0.51 of the wave cycles).  Here the reads of a whole code word (4 codes x B queries) are issued together, ONE
+// WORD AHEAD of the arithmetic that uses them (two register sets), and one wait per word follows the arithmetic of the word before.
+// (Measured and dropped in the same round: the queries' elements through scalar loads from a transposed global copy — no gain, the
+// wait was the cost, not the broadcast's 64-fold write; plain instead of packed multiplies / adds — 18 % slower.)
+template <int OFF>
+__device__ __forceinline__ void sq8_lds_read4(sq8_f32x4& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+// (the wait names the values it makes valid: a use cannot be scheduled in front of it)
+__device__ __forceinline__ void sq8_lds_wait(sq8_f32x4 (&q)[4][1]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0][0]), "+v"(q[1][0]), "+v"(q[2][0]), "+v"(q[3][0])::"memory");
+}
+__device__ __forceinline__ void sq8_lds_wait(sq8_f32x4 (&q)[4][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[2][0]), "+v"(q[2][1]), "+v"(q[3][0]), "+v"(q[3][1])::"memory");
+}
+template <int B, int WI>
+__device__ __forceinline__ void sq8_read_word(sq8_f32x4 (&q)[4][B / 4], uint32_t qaddr) {
+  // element e of the word, queries 4 j .. 4 j + 3: byte offset ((4 WI + e) B + 4 j) 4 behind the chunk's first element
+  sq8_lds_read4<((4 * WI + 0) * B + 0) * 4>(q[0][0], qaddr);
+  sq8_lds_read4<((4 * WI + 1) * B + 0) * 4>(q[1][0], qaddr);
+  sq8_lds_read4<((4 * WI + 2) * B + 0) * 4>(q[2][0], qaddr);
+  sq8_lds_read4<((4 * WI + 3) * B + 0) * 4>(q[3][0], qaddr);
+  if constexpr (B == 8) {
+    sq8_lds_read4<((4 * WI + 0) * B + 4) * 4>(q[0][1], qaddr);
+    sq8_lds_read4<((4 * WI + 1) * B + 4) * 4>(q[1][1], qaddr);
+    sq8_lds_read4<((4 * WI + 2) * B + 4) * 4>(q[2][1], qaddr);
+    sq8_lds_read4<((4 * WI + 3) * B + 4) * 4>(q[3][1], qaddr);
+  }
+}
+// one code word (4 codes of the lane's row) against the B queries: the reference's chains, element by element in order
+// (dot: quantization.rs:452-466; squared L2: :495-507 — sum += ((f0^2 + f1^2) + f2^2) + f3^2 per group of four)
+template <int METRIC, int B>
+__device__ __forceinline__ void sq8_word_math(float (&acc)[B], uint32_t w, float scale, float mn, const sq8_f32x4 (&q)[4][B / 4]) {
+  float dq[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) dq[e] = __fadd_rn(__fmul_rn((float)((w >> (8 * e)) & 0xFFu), scale), mn);
+  constexpr int P = B / 2;  // query pairs: v_pk_mul_f32 / v_pk_add_f32 — each half is the same IEEE operation as the scalar form
+  if (METRIC == kEuclidean) {
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      f32x2 t = {0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const f32x2 f = f32x2{q[e][p / 2][2 * (p & 1)], q[e][p / 2][2 * (p & 1) + 1]} - f32x2{dq[e], dq[e]};
+        t = e == 0 ? f * f : t + f * f;
+      }
+      acc[2 * p] = __fadd_rn(acc[2 * p], t.x);
+      acc[2 * p + 1] = __fadd_rn(acc[2 * p + 1], t.y);
+    }
+  } else {
+    // the products of TWO codes first, then their additions in the reference's order (code e before code e + 1 on every chain): an
+    // addition then stands four to eight instructions behind the multiply it needs, instead of directly behind it
+#pragma unroll
+    for (int e0 = 0; e0 < 4; e0 += 2) {
+      f32x2 pr[2][P];
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int p = 0; p < P; p++) pr[e][p] = f32x2{q[e0 + e][p / 2][2 * (p & 1)], q[e0 + e][p / 2][2 * (p & 1) + 1]} * f32x2{dq[e0 + e], dq[e0 + e]};
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+          const f32x2 r = f32x2{acc[2 * p], acc[2 * p + 1]} + pr[e][p];
+          acc[2 * p] = r.x;
+          acc[2 * p + 1] = r.y;
+        }
+    }
+  }
+}
+// words WI, WI + 1 of a chunk: q0 holds word WI's elements (valid), q1 receives word WI + 1's while word WI is multiplied, and so on
+template <int METRIC, int B, int WI>
+__device__ __forceinline__ void sq8_word_pair(float (&acc)[B], const uint32_t (&wds)[16], float scale, float mn, uint32_t qaddr,
+                                              sq8_f32x4 (&q0)[4][B / 4], sq8_f32x4 (&q1)[4][B / 4]) {
+  sq8_read_word<B, WI + 1>(q1, qaddr);
+  sq8_word_math<METRIC, B>(acc, wds[WI], scale, mn, q0);
+  sq8_lds_wait(q1);
+  if constexpr (WI + 2 < 16) sq8_read_word<B, WI + 2>(q0, qaddr);
+  sq8_word_math<METRIC, B>(acc, wds[WI + 1], scale, mn, q1);
+  if constexpr (WI + 2 < 16) sq8_lds_wait(q0);
+}
+
 template <int METRIC, int B>
 __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
   constexpr bool HIB = METRIC != kEuclidean;  // cosine / dot similarity: larger is better; squared L2: smaller
@@ -206,25 +293,30 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
     // adjacent pairs, the operands of the packed multiplies below
     // staging loads run one 64-byte column chunk ahead of the arithmetic (registers), so their latency hides
     // behind the previous chunk's ~700 VALU instructions
+    // (the loads are RAW — clamped address, always in bounds — and the rows / columns past the end are zeroed where the staged value
+    // is USED, one chunk later: with the select beside the load, as rounds 1-4 had it, the compiler waited for the four loads
+    // (vmcnt) right where it had issued them, and every chunk paid the codes' trip from HBM in full — half of every wave's time,
+    // profiles/r05k_*: SQ_WAIT_ANY 0.51)
     uint4 stg[4];
     auto stage_load = [&](uint32_t c0) __attribute__((always_inline)) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const uint32_t rr = g * 64 + 16 * j + (lane >> 2);
         const uint32_t off = c0 + (lane & 3) * 16;
-        const uint32_t rc = rr < a.n_rows ? rr : a.n_rows - 1;          // branch-free: clamped address, selected below
+        const uint32_t rc = rr < a.n_rows ? rr : a.n_rows - 1;
         const uint32_t oc = off < a.code_stride ? off : 0u;
-        const uint4 v = *reinterpret_cast<const uint4*>(a.codes + (size_t)rc * a.code_stride + oc);
-        const bool ok = rr < a.n_rows && off < a.code_stride;
-        stg[j] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+        stg[j] = *reinterpret_cast<const uint4*>(a.codes + (size_t)rc * a.code_stride + oc);
       }
     };
     stage_load(0);
     for (uint32_t c0 = 0; c0 < dim; c0 += 64) {
       // stage 64 rows x 64 B: lane l moves 16 B of row 16 j + l/4, part l%4
 #pragma unroll
-      for (int j = 0; j < 4; j++)
-        *reinterpret_cast<uint4*>(tile + (16 * j + (lane >> 2)) * kSq8TileStride + (lane & 3) * 16) = stg[j];
+      for (int j = 0; j < 4; j++) {
+        const bool ok = g * 64 + 16 * j + (lane >> 2) < a.n_rows && c0 + (lane & 3) * 16 < a.code_stride;
+        *reinterpret_cast<uint4*>(tile + (16 * j + (lane >> 2)) * kSq8TileStride + (lane & 3) * 16) =
+            make_uint4(ok ? stg[j].x : 0u, ok ? stg[j].y : 0u, ok ? stg[j].z : 0u, ok ? stg[j].w : 0u);
+      }
       if (c0 + 64 < dim) stage_load(c0 + 64);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -235,7 +327,22 @@ __global__ __launch_bounds__(256) void sweep_topk_sq8(Sq8Args a) {
       __builtin_amdgcn_wave_barrier();  // tile reads done before the next chunk overwrites it
       const uint32_t wds[16] = {w4[0].x, w4[0].y, w4[0].z, w4[0].w, w4[1].x, w4[1].y, w4[1].z, w4[1].w,
                                 w4[2].x, w4[2].y, w4[2].z, w4[2].w, w4[3].x, w4[3].y, w4[3].z, w4[3].w};
-      if (c0 + 64 <= dim) {  // full chunk: no bounds tests => ONE basic block, the scheduler overlaps the LDS reads of
+      if ((B == 4 || B == 8) && c0 + 64 <= dim) {  // full chunk, 4 or 8 queries: grouped query reads, one word ahead
+        if constexpr (B == 4 || B == 8) {
+          const uint32_t qaddr = (uint32_t)(size_t)(lds_void_p)smem + c0 * (uint32_t)B * 4u;  // (qs starts the dynamic LDS; uniform)
+          sq8_f32x4 qa[4][B / 4], qb[4][B / 4];
+          sq8_read_word<B, 0>(qa, qaddr);
+          sq8_lds_wait(qa);
+          sq8_word_pair<METRIC, B, 0>(acc, wds, scale, mn, qaddr, qa, qb);
+          sq8_word_pair<METRIC, B, 2>(acc, wds, scale, mn, qaddr, qa, qb);
+          sq8_word_pair<METRIC, B, 4>(acc, wds, scale, mn, qaddr, qa, qb);
+          sq8_word_pair<METRIC, B, 6>(acc, wds, scale, mn, qaddr, qa, qb);
+          sq8_word_pair<METRIC, B, 8>(acc, wds, scale, mn, qaddr, qa, qb);
+          sq8_word_pair<METRIC, B, 10>(acc, wds, scale, mn, qaddr, qa, qb);
+          sq8_word_pair<METRIC, B, 12>(acc, wds, scale, mn, qaddr, qa, qb);
+          sq8_word_pair<METRIC, B, 14>(acc, wds, scale, mn, qaddr, qa, qb);
+        }
+      } else if (c0 + 64 <= dim) {  // full chunk: no bounds tests => ONE basic block, the scheduler overlaps the LDS reads of
                              // later groups with the arithmetic of earlier ones (per-group branches pinned them)
   #pragma unroll
         for (int wi = 0; wi < 16; wi++) {
