@@ -927,6 +927,7 @@ __global__ __launch_bounds__(256) void merge_topk(MergeArgs m) {
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kMergeSelectMaxKeys = 7900;  // x 8 B + counters + a 256-key selection buffer: inside the default 64-KiB window
 constexpr uint32_t kMergeSelectMaxK = 256;
+constexpr uint32_t kMergeHeadsMaxQueries = 64;  // merge_topk_heads: calls of few queries whose sweeps left many partial lists
 template <bool HIB>
 __global__ __launch_bounds__(256) void merge_topk_select(MergeArgs m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -995,6 +996,117 @@ __global__ __launch_bounds__(256) void merge_topk_select(MergeArgs m) {
   }
   __syncthreads();
   const uint32_t ns = min(cnt_s[65], kMergeSelectMaxK);  // == cnt for distinct keys
+  if (tid < ns) {
+    const uint64_t key = sel[tid];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < ns; j++) {
+      const uint64_t kj = sel[j];
+      rank += (kj < key || (kj == key && j < tid)) ? 1u : 0u;
+    }
+    if (rank < k) {
+      const uint32_t row = key_row(key);
+      m.out_ids[(size_t)qi * k + rank] = m.ext_ids ? m.ext_ids[row] : (uint64_t)row + m.row_base;
+      m.out_scores[(size_t)qi * k + rank] = key_score<HIB>(key);  // raw compute_distance value (search.rs:209)
+      if (m.reseed_delta && rank + 1 == m.reseed_k) m.reseed_tau[qi] = reseed_key(key_score<HIB>(key), m.reseed_delta[qi]);
+    }
+  }
+  for (uint32_t e = cnt + tid; e < k; e += 256) {
+    m.out_ids[(size_t)qi * k + e] = ~0ull;
+    m.out_scores[(size_t)qi * k + e] = __uint_as_float(0x7FC00000u);
+  }
+  if (tid == 0) {
+    m.out_n[qi] = cnt;
+    if (m.reseed_delta && (cnt < m.reseed_k || m.reseed_k == 0)) m.reseed_tau[qi] = kKeyInvalid;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The merge for FEW queries over MANY partial lists (a one-query sweep leaves 1 024 lists x k keys: beyond merge_topk_select's LDS
+// window, and merge_topk's serial insertions took 42.8 us of a 91-us one-query packed-bit call — as much as the sweep itself;
+// profiles/r05m_*).  Heads first:
+//   1. every list's smallest key (its "head"; the lists need not be sorted) goes to LDS — n_lists keys;
+//   2. the k-th smallest HEAD bounds the answer: k lists hold a key <= it, so the k-th smallest key overall is <= it, and a list
+//      whose head is larger holds nothing that matters.  Bit-by-bit selection as in merge_topk_select, over n_lists keys only;
+//   3. the keys <= that bound — they all sit in the (at most k, keys are distinct) lists whose head passes: <= k x k_in keys — are
+//      compacted and ranked among themselves, one key per thread.
+// Output identical to merge_topk.  Used when (k_out or k) x k_in <= kMergeSelectMaxK and n_lists >= that count.
+// ------------------------------------------------------------------------------------------
+template <bool HIB>
+__global__ __launch_bounds__(256) void merge_topk_heads(MergeArgs m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const uint32_t tid = threadIdx.x;
+  const uint32_t qi = blockIdx.x;
+  if (m.active && (qi >= *m.active || (m.active_max && *m.active > m.active_max))) return;  // (uniform per block)
+  if (m.skip_cnt && *m.skip_cnt <= m.skip_le) return;
+  if (m.gate && m.gate[qi] == 0u) return;
+  const uint32_t kin = m.k;
+  const uint32_t k = m.k_out ? m.k_out : m.k;
+  const uint32_t nl = m.n_lists;
+  uint64_t* heads = reinterpret_cast<uint64_t*>(smem);                     // [nl]
+  uint64_t* sel = heads + nl;                                               // [kMergeSelectMaxK] the keys under the bound
+  uint32_t* cnt_s = reinterpret_cast<uint32_t*>(sel + kMergeSelectMaxK);   // [64] one counter per bit, [64] valid heads, [65] selected
+  const uint64_t* keys = m.part_keys + (size_t)qi * (m.list_stride ? m.list_stride : m.n_lists) * kin;
+  if (tid < 66) cnt_s[tid] = 0;
+  __syncthreads();
+  auto mbcnt = [](uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); };
+  uint32_t nvalid_mine = 0;
+  for (uint32_t l = tid; l < nl; l += 256) {
+    uint64_t h = kKeyInvalid;
+    for (uint32_t e = 0; e < kin; e++) h = min(h, keys[(size_t)l * kin + e]);
+    heads[l] = h;
+    nvalid_mine += h != kKeyInvalid ? 1u : 0u;
+  }
+  {
+    uint32_t v = nvalid_mine;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
+    if (lane == 0 && v) atomicAdd(&cnt_s[64], v);
+  }
+  __syncthreads();
+  const uint32_t nh = cnt_s[64];  // lists that hold anything
+  uint64_t bound = kKeyInvalid;   // fewer than k non-empty lists: every key may matter (the caller keeps such shapes on the other kernels)
+  if (nh > k) {
+    uint64_t P = 0;
+    for (int bit = 63; bit >= 0; bit--) {
+      const uint64_t cand = P | ((1ull << bit) - 1ull);
+      uint32_t wc = 0;
+      for (uint32_t base = 0; base < nl; base += 256) {
+        const uint32_t i = base + tid;
+        wc += (uint32_t)__popcll(__ballot(i < nl && heads[i] <= cand));   // (an empty list's head is kKeyInvalid: above every bound)
+      }
+      if (lane == 0 && wc) atomicAdd(&cnt_s[bit], wc);
+      __syncthreads();
+      const uint32_t c = cnt_s[bit];
+      if (c == k) {  // (block-uniform)
+        bound = cand;
+        break;
+      }
+      if (c < k) P |= 1ull << bit;
+      bound = P;  // after the last bit: P is the k-th smallest head itself
+    }
+  }
+  // the keys under the bound: only lists whose head passes are read again
+  for (uint32_t base = 0; base < nl; base += 256) {
+    const uint32_t l = base + tid;
+    const bool mine = l < nl && heads[l] <= bound && heads[l] != kKeyInvalid;
+    for (uint32_t e = 0; e < kin; e++) {  // (kin is block-uniform: the ballots below are convergent)
+      const uint64_t key = mine ? keys[(size_t)l * kin + e] : kKeyInvalid;
+      const bool take = mine && key <= bound && key != kKeyInvalid;
+      const uint64_t mask = __ballot(take);
+      if (!mask) continue;
+      uint32_t off = 0;
+      if (lane == 0) off = atomicAdd(&cnt_s[65], (uint32_t)__popcll(mask));
+      off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+      if (take) {
+        const uint32_t slot = off + mbcnt(mask);
+        if (slot < kMergeSelectMaxK) sel[slot] = key;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t ns = min(cnt_s[65], kMergeSelectMaxK);
+  const uint32_t cnt = min(ns, k);
   if (tid < ns) {
     const uint64_t key = sel[tid];
     uint32_t rank = 0;
@@ -1861,6 +1973,16 @@ void launch_merge(bool hib, const MergeArgs& m, uint32_t nq, hipStream_t st) {
       hipLaunchKernelGGL((merge_topk_select<true>), dim3(nq), dim3(256), lds_r, st, m);
     else
       hipLaunchKernelGGL((merge_topk_select<false>), dim3(nq), dim3(256), lds_r, st, m);
+    return;
+  }
+  // few queries over many lists (one-query sweeps): heads first
+  const uint32_t kk = m.k_out ? m.k_out : m.k;
+  const size_t lds_h = (size_t)m.n_lists * 8 + (size_t)kMergeSelectMaxK * 8 + 66 * 4 + 8;
+  if (nq <= kMergeHeadsMaxQueries && (uint64_t)kk * m.k <= kMergeSelectMaxK && m.n_lists > 4 * kk && lds_h <= 64 * 1024) {
+    if (hib)
+      hipLaunchKernelGGL((merge_topk_heads<true>), dim3(nq), dim3(256), lds_h, st, m);
+    else
+      hipLaunchKernelGGL((merge_topk_heads<false>), dim3(nq), dim3(256), lds_h, st, m);
     return;
   }
   const size_t lds = ((size_t)4 * (m.k_out ? m.k_out : m.k) * 8 + 16 + 15) & ~(size_t)15;
