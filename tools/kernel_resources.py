@@ -144,6 +144,10 @@ def loops(blocks, want=lambda ins: True):
     out, taken = [], []
     for a, b in loop_regions(blocks):
         ins = [x for _, blk in blocks[a:b + 1] for x in blk]
+        # the closing block may go on behind its backward branch (a conditional one: the fall-through is the loop's exit path)
+        back = [i for i, x in enumerate(ins) if re.match(r"s_c?branch\w* %s$" % re.escape(blocks[a][0]), x)]
+        if back:
+            ins = ins[:back[-1] + 1]
         if want(ins) and not any(a <= ta and tb <= b for ta, tb in taken):
             taken.append((a, b))
             out.append((blocks[a][0], ins))

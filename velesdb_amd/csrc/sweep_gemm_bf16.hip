@@ -43,6 +43,11 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 constexpr int kG16BM = 256, kG16BN = 256, kG16Waves = 8;
 constexpr int kG16Cap = 12;     // candidate buffer entries per query (k <= kGemmBf16MaxK = 10)
 constexpr int kG16Queue = 39;   // per-wave queue of finished survivors (and, transiently, raw ones: g16_protocol.inc)
+#ifndef VDB_G16_DUMP_MAX_LANES
+#define VDB_G16_DUMP_MAX_LANES 6
+#endif
+constexpr int kG16DumpMaxLanes = VDB_G16_DUMP_MAX_LANES;  // hot lanes of a wave tile up to which the look phase skips the scan (g16_protocol.inc)
+static_assert(kG16Queue == 39, "g16_protocol.inc keeps two hot lanes' 64 accumulators in queue entries 8 .. 39");
 static_assert(kG16Queue <= 64 && kG16Queue >= 32, "the finish pass takes one queue entry per lane; one hot lane's 32 elements fit");
 // LDS map (bytes): two tile buffers (A 32 KiB + B 32 KiB each), candidate buffers, k-th best keys, counters, query norms,
 // row-tile norms, flags, per-wave queues (keys + query slots)
@@ -359,7 +364,9 @@ _Pragma("unroll") \
 #include "g16_quicktest_dense.inc"
     }
 #define VDB_G16_ACC_ELEM(X, A) asm volatile("v_mov_b32 %0, %1" : "=v"(X) : "v"(A))
+#define VDB_G16_NO_DUMP 1
 #include "g16_protocol.inc"
+#undef VDB_G16_NO_DUMP
 #undef VDB_G16_ACC_ELEM
 #undef VDB_G16_ACC_F
   }
@@ -639,9 +646,12 @@ _Pragma("unroll") \
 #ifndef VDB_PP_STAMP
 #define VDB_PP_STAMP 0
 #endif
+#ifndef VDB_PP_STAMP_METRIC
+#define VDB_PP_STAMP_METRIC kCosine
+#endif
 #if VDB_PP_STAMP
-  const bool st_on = a.dbg != nullptr && blockIdx.x == 8u && (wib == 0 || wib == 4) && !FP4 && METRIC == kCosine;
-  uint32_t st_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool st_on = a.dbg != nullptr && blockIdx.x == 8u && (wib == 0 || wib == 4) && METRIC == VDB_PP_STAMP_METRIC;  // (-DVDB_PP_STAMP_METRIC=3: Hamming, the four-bit instance)
+  uint32_t st_acc[28] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t st_last = 0;
 #define VDB_PP_STAMP_AT(SLOT) do { \
     if (st_on) { \
@@ -652,6 +662,8 @@ _Pragma("unroll") \
     } \
   } while (0)
 #define VDB_PP_STAMP_ISSUE(SLOT) do { if (VDB_PP_STAMP >= 2) VDB_PP_STAMP_AT(SLOT); } while (0)
+#define VDB_PP_STAMP_COUNT(SLOT) do { if (st_on) st_acc[SLOT] += 1u; } while (0)
+#define VDB_PP_STAMP_ADD(SLOT, N) do { if (st_on) st_acc[SLOT] += (uint32_t)(N); } while (0)
 #else
 #define VDB_PP_STAMP_AT(SLOT) do { } while (0)
 #define VDB_PP_STAMP_ISSUE(SLOT) do { } while (0)
@@ -725,16 +737,20 @@ _Pragma("unroll") \
     for (uint32_t kt = 1; kt + 1 < a.KT; kt++) VDB_PP_KTILE(false, false);
     VDB_PP_KTILE(false, true);
     const bool more = c < total;
+    // waves 0-3 wait for the last products of waves 4-7: the block is aligned again, and both wave rows run their quick tests at the same
+    // time.  (Rounds 3-5 had waves 0-3 test first, beside those last products, and align behind the test: waves 4-7 then waited at their
+    // closing barrier for that test and ran their own after it — the two tests of a SIMD in series, ~1 800 + ~2 200 cycles of the
+    // stamped timeline.  profiles/r05q_*: step 1.665-1.675 -> 1.646 ms, Jaccard batches 0.722-0.724 -> 0.677-0.687 ms.)
+    if (wr == 0) pp_barrier();
+    VDB_PP_STAMP_AT(11);
 #define VDB_G16_ACC_F(V) (V)
-#include "g16_quicktest.inc"  // (waves 0-3: beside the last products of waves 4-7)
+#include "g16_quicktest.inc"
     if constexpr (METRIC == kHamming || METRIC == kJaccard) {
 #include "g16_quicktest_bits.inc"
     } else {
 #include "g16_quicktest_dense.inc"
     }
-    VDB_PP_STAMP_AT(10);  // (epilogue legs, stamped builds: 10 quick test, 11 alignment barrier, 12-15 inside g16_protocol.inc, 8 the rest)
-    if (wr == 0) pp_barrier();  // waves 0-3 wait for the last products of waves 4-7: the block is aligned again
-    VDB_PP_STAMP_AT(11);
+    VDB_PP_STAMP_AT(10);  // (epilogue legs, stamped builds: 11 alignment barrier, 10 quick test, 12-24 inside g16_protocol.inc, 8 the rest)
 #define VDB_G16_ACC_ELEM(X, A) asm volatile("v_mov_b32 %0, %1" : "=v"(X) : "v"(A))
 #include "g16_protocol.inc"
 #undef VDB_G16_ACC_ELEM
@@ -758,8 +774,8 @@ _Pragma("unroll") \
 #if VDB_PP_STAMP
   if (st_on && lane_now() == 0) {  // [launch-size class][wave row][10]: the LARGEST launch of the batch is what the probe reads
     st_acc[9] = c;
-    unsigned long long* d = a.dbg + (size_t)(wib == 0 ? 0 : 1) * 20;
-    for (int i = 0; i < 20; i++) d[i] = st_acc[i];
+    unsigned long long* d = a.dbg + (size_t)(wib == 0 ? 0 : 1) * 28;
+    for (int i = 0; i < 28; i++) d[i] = st_acc[i];
   }
 #endif
 #include "g16_writeout.inc"
@@ -816,7 +832,7 @@ static unsigned long long* g_pp_stamp_buf = nullptr;
 extern "C" int32_t vdb_hip_debug_pp_stamps(unsigned long long* out /* [2][20] */) {
   if (!vdb::g_pp_stamp_buf) return -1;
   if (hipDeviceSynchronize() != hipSuccess) return -2;
-  return hipMemcpy(out, vdb::g_pp_stamp_buf, 320, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+  return hipMemcpy(out, vdb::g_pp_stamp_buf, 448, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
 namespace vdb {
 #endif
