@@ -188,3 +188,50 @@ def test_bit_metrics_1m_x_768_x_1024_queries_vs_oracle(gpu_required, metric):
         assert np.array_equal(gi, vi) and np.array_equal(bits(gs), bits(vs)) and np.array_equal(gc, vc)
     finally:
         ix.close()
+
+
+# ------------------------------------------------------------------ one or two packed-bit queries in ONE launch (sweep_bits_fused)
+@pytest.mark.parametrize("metric", [DM.Hamming, DM.Jaccard])
+@pytest.mark.parametrize("n,dim", [(1_200_000, 128), (300_000, 768), (70_001, 384), (4_100, 1536), (130, 256), (64, 128)])
+def test_one_launch_packed_bit_query_vs_oracle_and_three_launch_path(gpu_required, metric, n, dim):
+    """A call of one or two Hamming / Jaccard queries is ONE kernel (sweep.hip sweep_bits_fused: the blocks pack the query, keep their
+    keys in registers, extract the k best, and the block that draws the last ticket merges).  Ids, order (ties by row: dim 128 ties a
+    lot) and score bits must equal the oracle's (simd_explicit.rs:234-287, 372-443) and the three-launch path's (engine 0); 1.2 M rows
+    make a wave carry its list over a second batch of chunks; soft-deleted rows, external ids, k = 1 / 10 / 16, a ragged last chunk,
+    fewer rows than k, an empty query (Jaccard 1.0 against empty rows) and back-to-back calls (the ticket counter returns to zero)."""
+    rng = np.random.default_rng(n + dim + int(metric))
+    rows = (rng.random((n, dim)) > 0.6915).astype(np.float32)
+    rows[min(7, n - 1)] = 0.0
+    ids = np.arange(n, dtype=np.uint64) * 3 + 11
+    ix = va.HnswIndex(dim, metric)
+    assert ix.upload(ids, rows) == n
+    Q = (rng.random((6, dim)) > 0.6915).astype(np.float32)
+    Q[1] = 0.0
+    live = None
+    for phase in range(2):
+        for k in (10, 1, 16):
+            for q0, nq in ((0, 1), (1, 1), (2, 2), (4, 1), (5, 1)):
+                qs = Q[q0:q0 + nq]
+                ix.set_option(va.OPT_SWEEP_ENGINE, 1)
+                gid, gsc, gcnt = ix.search_batch_brute_force(qs, k)
+                assert ix.last_kernels() & va.KERNEL_BITS
+                ix.set_option(va.OPT_SWEEP_ENGINE, 0)
+                oid, osc, ocnt = ix.search_batch_brute_force(qs, k)
+                ix.set_option(va.OPT_SWEEP_ENGINE, -1)
+                sel = np.arange(n) if live is None else np.nonzero(live)[0]
+                kk = min(k, len(sel))
+                r, s = po.scan_topk(int(metric), rows[sel], qs, max(kk, 1), po.MODE_C)
+                for qi in range(nq):
+                    assert gcnt[qi] == kk == ocnt[qi], (metric, n, dim, k, q0, qi)
+                    assert np.array_equal(gid[qi, :kk], ids[sel[r[qi, :kk].astype(np.int64)]]), (metric, n, dim, k, q0, qi)
+                    assert np.array_equal(bits(gsc[qi, :kk]), bits(s[qi, :kk]))
+                    assert np.array_equal(gid[qi, :kk], oid[qi, :kk]) and np.array_equal(bits(gsc[qi, :kk]), bits(osc[qi, :kk]))
+        if phase == 0:   # soft deletes: a seventh of the rows, among them the best answers of query 0
+            dead = set(rng.choice(n, max(1, n // 7), replace=False).tolist())
+            first = ix.search_batch_brute_force(Q[:1], min(5, n))[0][0]
+            dead.update(int((i - 11) // 3) for i in first[:3])
+            for d in dead:
+                assert ix.remove(int(ids[d]))
+            live = np.ones(n, bool)
+            live[list(dead)] = False
+    ix.close()

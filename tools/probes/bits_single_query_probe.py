@@ -5,6 +5,9 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from velesdb_amd import _ffi  # noqa: E402
+if os.environ.get("VDB_PROBE_LIB"):  # the probe build: environment switches (VELESDB_BITS_FUSED, VELESDB_BITS_FUSED_PER_CU)
+    _ffi.use_library(_ffi.PROBE_LIB_PATH)
 import torch  # noqa: E402
 import velesdb_amd as va  # noqa: E402
 

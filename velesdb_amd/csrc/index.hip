@@ -9,6 +9,7 @@
 #include <memory>
 
 #include "vdb_index.hpp"
+#include "vdb_probe_env.hpp"
 #include "vdb_kernels.hpp"
 #include "vdb_select_stage.hpp"
 
@@ -26,7 +27,17 @@ static std::atomic<uint32_t> g_int8_oversampling{4};  // DualPrecisionConfig::de
 
 // effective option values of a handle: its own (vdb_hip_index_set_option) or the process-wide default
 static inline uint32_t opt_max_tile(const vdb_hip_index* ix) { return ix->opt[VDB_OPT_MAX_QUERY_TILE] >= 0 ? (uint32_t)ix->opt[VDB_OPT_MAX_QUERY_TILE] : (uint32_t)g_max_tile.load(); }
+// one-launch packed-bit search for calls of one or two queries: the default engine's path (engine 0 keeps the three-launch form, so
+// both stay under the parity tests); probe builds: VELESDB_BITS_FUSED=0 turns it off for A/B runs
+static inline bool opt_bits_fused(const vdb_hip_index* ix);
 static inline int opt_engine(const vdb_hip_index* ix) { return ix->opt[VDB_OPT_SWEEP_ENGINE] >= 0 ? ix->opt[VDB_OPT_SWEEP_ENGINE] : g_sweep_engine.load(); }
+static inline bool opt_bits_fused(const vdb_hip_index* ix) {
+  static const bool off = [] {
+    const char* e = vdb::probe_env("VELESDB_BITS_FUSED");
+    return e && e[0] == '0';
+  }();
+  return !off && opt_engine(ix) == 1;
+}
 static inline int opt_selector(const vdb_hip_index* ix) { return ix->opt[VDB_OPT_SELECTOR_LEVEL] >= 0 ? ix->opt[VDB_OPT_SELECTOR_LEVEL] : g_split_selector.load(); }
 static inline uint32_t opt_oversampling(const vdb_hip_index* ix) { return ix->opt[VDB_OPT_INT8_OVERSAMPLING] >= 0 ? (uint32_t)ix->opt[VDB_OPT_INT8_OVERSAMPLING] : (uint32_t)g_int8_oversampling.load(); }
 static inline bool opt_timing(const vdb_hip_index* ix) { return (ix->opt[VDB_OPT_KERNEL_TIMING] >= 0 ? ix->opt[VDB_OPT_KERNEL_TIMING] : g_timing.load()) != 0; }
@@ -115,6 +126,7 @@ static int32_t check_device(int32_t* n_out) {
 
 int32_t enter_index(vdb_hip_index* ix, bool exclusive, bool changes) {
   VDB_HIP(hipSetDevice(ix->device));
+  ix->own_dirty = true;  // (the caller is about to enqueue on ix->stream)
   if (ix->foreign_pending) {
     VDB_HIP(hipStreamWaitEvent(ix->stream, ix->ev_foreign, 0));
     ix->foreign_pending = false;
@@ -214,10 +226,20 @@ vdb_hip_index* last_context(vdb_hip_index* ix) {
     if (c == tl_ctx) return c;
   return ix;
 }
+// what this thread's last LEASED search ran, taken when the lease ends: another thread may lease the same context a moment later,
+// and the diagnostic getter of this thread must still describe this thread's search (tests/test_gpu_hardening.py
+// ::test_concurrent_searches_on_one_handle_overlap saw the mask of a neighbour's sweep, once, in round 5)
+static thread_local bool tl_kernels_valid = false;
+static thread_local uint32_t tl_kernels = 0;
+uint32_t last_kernels_of_this_thread(vdb_hip_index* ix) {
+  if (tl_kernels_valid && tl_ctx_owner == ix && tl_ctx_gen == ix->generation) return tl_kernels;
+  return last_context(ix)->last_kernels;
+}
 void note_last_context(vdb_hip_index* handle, vdb_hip_index* ctx) {
   tl_ctx = ctx;
   tl_ctx_owner = handle;
   tl_ctx_gen = handle->generation;
+  tl_kernels_valid = false;
 }
 
 // the primary + up to seven clones.  A context owns scratch and a stream; its graph-walk scratch is sized by the calls it has
@@ -269,7 +291,12 @@ CtxLease::CtxLease(vdb_hip_index* ix) {
   note_last_context(ix, ctx);
 }
 CtxLease::~CtxLease() {
-  if (ctx) ctx->ctx_mu.unlock();
+  if (!ctx) return;
+  if (tl_ctx == ctx) {
+    tl_kernels = ctx->last_kernels;
+    tl_kernels_valid = true;
+  }
+  ctx->ctx_mu.unlock();
 }
 // frees what a clone owns (scratch, stream, events); its views of the primary's buffers are dropped, not released
 static void destroy_clone(vdb_hip_index* c) {
@@ -480,8 +507,40 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
   if (is_bits_metric(ix->metric)) {
     if ((size_t)4 * k * 8 + (size_t)ix->words * 4 + 32 > 60 * 1024)
       return fail(VDB_ERR_UNSUPPORTED, "k too large for the fused top-k path");
+    hipError_t e;
+    // one or two queries: ONE launch — the blocks pack the query themselves, and the one that finishes last merges (sweep.hip)
+    if (opt_bits_fused(ix) && sweep_bits_fused_supported(ix->words, nq, k)) {
+      const int fblocks = sweep_bits_fused_blocks(ix->n_rows, ix->n_cus);
+      if (ix->s_tickets.cap == 0) {
+        if ((e = ix->s_tickets.reserve(16, false, st)) != hipSuccess) return fail(VDB_ERR_OOM, "ticket scratch");
+        VDB_HIP(hipMemsetAsync(ix->s_tickets.p, 0, 16, st));
+      }
+      if ((e = ix->s_part_keys.reserve((size_t)nq * fblocks * k * 8, false, st)) != hipSuccess) return fail(VDB_ERR_OOM, "top-k scratch");
+      BitsFusedArgs fa{};
+      fa.bits = ix->bits.as<uint32_t>();
+      fa.q = d_q;
+      fa.q_stride = q_stride;
+      fa.alive = alive;
+      fa.part_keys = ix->s_part_keys.as<uint64_t>();
+      fa.tickets = ix->s_tickets.as<uint32_t>();
+      fa.n_rows = (uint32_t)ix->n_rows;
+      fa.words = ix->words;
+      fa.dim = ix->dim;
+      fa.k = k;
+      fa.m.ext_ids = ix->ext_ids.as<uint64_t>();
+      fa.m.out_ids = d_ids;
+      fa.m.out_scores = d_scores;
+      fa.m.out_n = d_n;
+      ix->last_kernels |= VDB_KERNEL_BITS;
+      EventPair* evf = next_events(ix);
+      if (evf) (void)hipEventRecord(evf->a, st);
+      const hipError_t ef = launch_sweep_bits_fused(ix->metric, fa, fblocks, nq, st);
+      if (ef != hipSuccess) return fail(VDB_ERR_HIP, std::string("one-launch packed-bit search: ") + hipGetErrorString(ef));
+      if (evf) (void)hipEventRecord(evf->b, st);
+      return VDB_OK;
+    }
     // pack the queries with the same kernel that packs rows
-    hipError_t e = ix->s_qbits.reserve((size_t)nq * ix->words * 4, false, st);
+    e = ix->s_qbits.reserve((size_t)nq * ix->words * 4, false, st);
     if (e != hipSuccess) return fail(VDB_ERR_OOM, "qbits scratch");
     PrepArgs pa{};
     pa.rows = d_q;
@@ -934,7 +993,7 @@ std::vector<DevBuf*> index_buffers(vdb_hip_index* ix) {
       &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits,  // storage modes
       &ix->sq8_img, &ix->sq8_nrm, &ix->sq8_seed, &ix->sq8_rho,              // SQ8 selection images
       &ix->bits_img, &ix->bits_cnt,                                         // four-bit image of the bit rows (Hamming / Jaccard GEMM)
-      &ix->s_queries, &ix->s_part_keys, &ix->s_part_cnt, &ix->s_out, &ix->s_qbits,
+      &ix->s_queries, &ix->s_part_keys, &ix->s_part_cnt, &ix->s_out, &ix->s_qbits, &ix->s_tickets,
       &ix->s_misc, &ix->s_fb_keys, &ix->s_seed, &ix->s_visited, &ix->s_vlog, &ix->s_stats, &ix->s_build_stats, &ix->s_levels, &ix->s_req_keys,
       &ix->s_req_vals, &ix->s_sort_tmp};
   for (auto& L : ix->layers) {
@@ -1166,7 +1225,7 @@ int32_t vdb_hip_index_last_kernels(vdb_hip_index* ix, uint32_t* mask) {
     if (!ix || !mask) return fail(VDB_ERR_INVALID_ARG, "null argument");
     std::shared_lock<vdb::IndexMutex> g(ix->mu);
     // a multi-device handle: what any shard ran; a plain handle: the context of this thread's last search
-    uint32_t m = ix->group ? ix->last_kernels : last_context(ix)->last_kernels;
+    uint32_t m = ix->group ? ix->last_kernels : vdb::last_kernels_of_this_thread(ix);
     if (ix->group)
       for (size_t s = 0; s < group_size(ix); s++) m |= group_shard(ix, s)->last_kernels;
     *mask = m;
@@ -1662,8 +1721,11 @@ int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* ix, const float* d_queries
   if (st != ix->stream) {
     // the kernels below share this index's scratch, rows and graph with everything enqueued before: order the caller's
     // stream behind the work pending on ix->stream and behind an earlier device-resident search on ANOTHER stream
-    VDB_HIP(hipEventRecord(ix->ev_own, ix->stream));
-    VDB_HIP(hipStreamWaitEvent(st, ix->ev_own, 0));
+    if (ix->own_dirty || ix->last_foreign != st) {  // (a stream that has not waited since: it is ordered behind ev_foreign below at best)
+      VDB_HIP(hipEventRecord(ix->ev_own, ix->stream));
+      VDB_HIP(hipStreamWaitEvent(st, ix->ev_own, 0));
+      ix->own_dirty = false;
+    }
     if (ix->foreign_pending && ix->last_foreign != st) VDB_HIP(hipStreamWaitEvent(st, ix->ev_foreign, 0));
   } else {
     VDB_ENTER_SHARED(ix);

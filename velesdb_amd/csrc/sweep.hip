@@ -17,6 +17,7 @@
 // Algorithmic HBM bytes per launch: n_rows * dim * 4 (+ 4 B/row of norms for cosine).
 #include <algorithm>
 
+#include "vdb_probe_env.hpp"
 #include "vdb_device.hpp"
 #include "vdb_kernels.hpp"
 
@@ -1032,11 +1033,9 @@ __global__ __launch_bounds__(256) void merge_topk_select(MergeArgs m) {
 // Output identical to merge_topk.  Used when (k_out or k) x k_in <= kMergeSelectMaxK and n_lists >= that count.
 // ------------------------------------------------------------------------------------------
 template <bool HIB>
-__global__ __launch_bounds__(256) void merge_topk_heads(MergeArgs m) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void merge_topk_heads_body(const MergeArgs& m, const uint32_t qi, unsigned char* smem) {
   const int lane = lane_id();
   const uint32_t tid = threadIdx.x;
-  const uint32_t qi = blockIdx.x;
   if (m.active && (qi >= *m.active || (m.active_max && *m.active > m.active_max))) return;  // (uniform per block)
   if (m.skip_cnt && *m.skip_cnt <= m.skip_le) return;
   if (m.gate && m.gate[qi] == 0u) return;
@@ -1129,6 +1128,11 @@ __global__ __launch_bounds__(256) void merge_topk_heads(MergeArgs m) {
     m.out_n[qi] = cnt;
     if (m.reseed_delta && (cnt < m.reseed_k || m.reseed_k == 0)) m.reseed_tau[qi] = kKeyInvalid;
   }
+}
+template <bool HIB>
+__global__ __launch_bounds__(256) void merge_topk_heads(MergeArgs m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  merge_topk_heads_body<HIB>(m, blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2185,6 +2189,315 @@ static void launch_sweep_bits_co(int metric, const BitsArgs& a, int blocks, uint
     hipLaunchKernelGGL((sweep_topk_bits_co<kHamming, P>), dim3(blocks, nq), dim3(256), lds, st, a);
   else
     hipLaunchKernelGGL((sweep_topk_bits_co<kJaccard, P>), dim3(blocks, nq), dim3(256), lds, st, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// ONE launch for a call of one or two packed-bit queries (round 5).  Such a call was three launches — prep_rows packing the query,
+// the sweep, the merge of its partial lists — 68 us for the 96 MB of 1 M x 768 bits, of which the sweep was 40 (profiles/r05n_*).
+// Here a block packs the query itself (the rule of prep_rows: x > 0.5), sweeps with the coalesced loads of sweep_topk_bits_co,
+// keeps NO list while it sweeps: a lane's keys stay in registers (kBitsFusedR chunks per batch), and the wave's k best are
+// extracted afterwards — k times { the lane's smallest key, the wave's smallest of those (two 32-bit minimum butterflies on DPP /
+// permlane swaps: score word, then row word among the lanes that tie), drop it }; lane e ends with the e-th best, which is also
+// how a further batch (more than kBitsFusedR chunks per wave) carries the list on.  The block's four lists are merged the same
+// way by wave 0 (4 k <= 64 keys, one per lane), the block writes ONE list and takes a ticket; the block that draws the last
+// ticket merges all lists heads-first (merge_topk_heads_body) and writes the result.  Same keys as every other path: the same
+// integer counts, make_key, the canonical (score, row) order.  k <= kBitsFusedMaxK.
+// ------------------------------------------------------------------------------------------
+constexpr int kBitsFusedR = 16;
+constexpr uint32_t kBitsFusedMaxK = 16;
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  auto a32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  v = min(a32[0], a32[1]);
+  auto a16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = min(a16[0], a16[1]);
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));  // row_ror:8
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));  // row_ror:4
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false));  // row_ror:2
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+// the smallest of the wave's 64 keys, in every lane (all invalid: kKeyInvalid)
+__device__ __forceinline__ uint64_t wave_min_key(uint64_t m) {
+  const uint32_t hi = wave_min_u32((uint32_t)(m >> 32));
+  const uint32_t lo = wave_min_u32((uint32_t)(m >> 32) == hi ? (uint32_t)m : 0xFFFFFFFFu);
+  return ((uint64_t)hi << 32) | lo;
+}
+// the k smallest of a block's 256 keys (one per thread; kKeyInvalid = none): every wave extracts its k smallest (lane e: the e-th),
+// wave 0 the k smallest of those 4 k <= 64.  Returns, in wave 0, lane e < k: the block's e-th smallest; other waves / lanes: undefined.
+// wl: LDS scratch [4][kBitsFusedMaxK].  Block-uniform call (two barriers inside); k <= kBitsFusedMaxK.
+__device__ __forceinline__ uint64_t block_k_smallest(uint64_t mine, uint32_t k, uint64_t* wl) {
+  const uint32_t lane = (uint32_t)lane_id(), wib = threadIdx.x >> 6;
+  uint64_t out = kKeyInvalid;
+  for (uint32_t e = 0; e < k; e++) {
+    const uint64_t wm = wave_min_key(mine);
+    if (lane == e) out = wm;
+    if (wm == kKeyInvalid) break;  // (wave-uniform)
+    if (mine == wm) mine = kKeyInvalid;
+  }
+  __syncthreads();  // (wl may still be read from an earlier call)
+  if (lane < k) wl[(size_t)wib * kBitsFusedMaxK + lane] = out;
+  __syncthreads();
+  uint64_t res = kKeyInvalid;
+  if (wib == 0) {
+    const uint32_t wsrc = lane / k, esrc = lane % k;
+    uint64_t m2 = wsrc < 4u ? wl[(size_t)wsrc * kBitsFusedMaxK + esrc] : kKeyInvalid;
+    for (uint32_t e = 0; e < k; e++) {
+      const uint64_t wm = wave_min_key(m2);
+      if (lane == e) res = wm;
+      if (wm == kKeyInvalid) break;
+      if (m2 == wm) m2 = kKeyInvalid;
+    }
+  }
+  return res;
+}
+// The merge of the one-launch search, run by the block that drew the last ticket: n_lists <= 256 sorted lists of k keys (one per
+// thread).  Heads first, as merge_topk_heads — the k-th smallest first key bounds the answer, only the <= k lists under it matter —
+// but with the extraction above instead of a bit-by-bit selection over LDS (35 barriers): ~5 us instead of ~12 at 256 lists.
+template <bool HIB>
+__device__ __forceinline__ void fused_tail_merge(const MergeArgs& m, uint32_t qi, unsigned char* smem) {
+  const uint32_t tid = threadIdx.x, lane = (uint32_t)lane_id();
+  const uint32_t k = m.k;
+  uint64_t* wl = reinterpret_cast<uint64_t*>(smem);                 // [4][kBitsFusedMaxK]
+  uint64_t* sel = wl + 4 * kBitsFusedMaxK;                          // [256] the keys under the bound
+  uint64_t* bnd = sel + 256;                                        // [1]
+  uint32_t* cnt_s = reinterpret_cast<uint32_t*>(bnd + 1);           // [1]
+  const uint64_t* keys = m.part_keys + (size_t)qi * m.n_lists * k;
+  const uint64_t head = tid < m.n_lists ? keys[(size_t)tid * k] : kKeyInvalid;  // (a list is sorted: its first key is its smallest)
+  if (tid == 0) *cnt_s = 0u;
+  const uint64_t hk = block_k_smallest(head, k, wl);
+  if (tid == k - 1) *bnd = hk;  // the k-th smallest head (kKeyInvalid with fewer than k non-empty lists: every key may matter)
+  __syncthreads();
+  const uint64_t bound = *bnd;
+  if (head != kKeyInvalid && head <= bound) {  // at most k lists (keys are distinct); <= k x k <= 256 keys
+    uint64_t lk[kBitsFusedMaxK];  // the whole list first: independent loads, one round trip (a loop that stops at the bound makes k of them)
+#pragma unroll
+    for (uint32_t e = 0; e < kBitsFusedMaxK; e++) lk[e] = e < k ? keys[(size_t)tid * k + e] : kKeyInvalid;
+#pragma unroll
+    for (uint32_t e = 0; e < kBitsFusedMaxK; e++) {
+      if (lk[e] != kKeyInvalid && lk[e] <= bound) {
+        const uint32_t slot = atomicAdd(cnt_s, 1u);
+        if (slot < 256u) sel[slot] = lk[e];
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t ns = min(*cnt_s, 256u);
+  const uint64_t fin = block_k_smallest(tid < ns ? sel[tid] : kKeyInvalid, k, wl);
+  if (tid < 64u) {
+    const uint32_t cnt = min(ns, k);
+    if (lane < k) {
+      if (lane < cnt) {
+        const uint32_t row = key_row(fin);
+        m.out_ids[(size_t)qi * k + lane] = m.ext_ids ? m.ext_ids[row] : (uint64_t)row + m.row_base;
+        m.out_scores[(size_t)qi * k + lane] = key_score<HIB>(fin);  // raw compute_distance value (search.rs:209)
+      } else {
+        m.out_ids[(size_t)qi * k + lane] = ~0ull;
+        m.out_scores[(size_t)qi * k + lane] = __uint_as_float(0x7FC00000u);
+      }
+    }
+    if (lane == 0) m.out_n[qi] = cnt;
+  }
+}
+typedef unsigned int bits_u32x4 __attribute__((ext_vector_type(4)));
+template <int METRIC, int P>
+__global__ __launch_bounds__(256) void sweep_bits_fused(BitsFusedArgs a) {
+  constexpr bool HIB = higher_is_better(METRIC);
+  constexpr int R = kBitsFusedR;
+  constexpr uint32_t W = 4u * P;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (wave-uniform, and the compiler must know: the chunk descriptors live in scalar registers)
+  const uint32_t wave = blockIdx.x * 4 + wib;
+  const uint32_t nwaves = gridDim.x * 4;
+  const uint32_t qi = blockIdx.y;
+  const uint32_t k = a.k;
+  // LDS while sweeping: query words [W] | per-wave strips [4][64 P] u32 | the four wave lists [4][k] u64 | last-block flag
+  uint32_t* qw = reinterpret_cast<uint32_t*>(smem);
+  uint32_t* strip = qw + W + (size_t)wib * 64 * P;
+  uint64_t* wl = reinterpret_cast<uint64_t*>(smem + (((size_t)W * 4 + (size_t)4 * 64 * P * 4 + 15) & ~(size_t)15));
+  uint32_t* lastf = reinterpret_cast<uint32_t*>(wl + 4 * kBitsFusedMaxK);
+  {  // the query's bits (prep_rows: x > 0.5; NaN > 0.5 is false, as on the CPU)
+    const float* qp = a.q + (size_t)qi * a.q_stride;
+    for (uint32_t e0 = (uint32_t)wib * 64u; e0 < W * 32u; e0 += 256u) {
+      const uint32_t e = e0 + (uint32_t)lane;
+      const uint64_t mb = __ballot(e < a.dim && qp[e] > 0.5f);
+      if (lane == 0) {
+        qw[e0 / 32] = (uint32_t)mb;
+        if (e0 / 32 + 1 < W) qw[e0 / 32 + 1] = (uint32_t)(mb >> 32);
+      }
+    }
+  }
+  __syncthreads();
+  uint4 qpc[P];  // the query piece of (load j, lane): (64 j + lane) mod P
+  {
+    uint32_t pc = (uint32_t)lane % P;
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+      qpc[j] = *reinterpret_cast<const uint4*>(qw + pc * 4);
+      pc += 64u % P;
+      if (pc >= (uint32_t)P) pc -= P;
+    }
+  }
+  uint64_t best = kKeyInvalid;  // lane e < k: the wave's e-th best so far
+  for (uint64_t b0 = (uint64_t)wave * 64; b0 < a.n_rows; b0 += (uint64_t)R * nwaves * 64) {
+    uint64_t keys[R];
+    // chunks r + 1 .. r + 3 are requested before chunk r is counted (a wave's chunks are a dependent chain otherwise, and one block per
+    // CU is one wave per SIMD: nothing else hides the latency; the registers are there)
+    constexpr int AHEAD = 3;
+    uint4 x[AHEAD + 1][P];
+    // raw buffer loads: a chunk's descriptor says how many bytes exist behind its first row, lanes past them get zeros from the
+    // hardware's range check — no branch around a load, so the compiler counts the loads in flight (vmcnt(n)) instead of draining
+    // them all at every chunk, which is what the predicated global loads of the first version came to: 16 dependent round trips
+#define VDB_BITS_FUSED_LOAD(DST, RR) do { \
+      const uint64_t base_ = b0 + (uint64_t)(RR) * nwaves * 64; \
+      const uint64_t left_ = (base_ < a.n_rows && !(a.probe_skip & 4u)) ? (a.n_rows - base_) * (uint64_t)W * 4u : 0ull;  /* bytes behind the chunk's first row */ \
+      const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc( \
+          const_cast<uint32_t*>(a.bits) + (base_ < a.n_rows ? base_ : 0ull) * W, 0, (int)(uint32_t)(left_ < 0x7FFFFFFFull ? left_ : 0x7FFFFFFFull), 0x00020000); \
+_Pragma("unroll") \
+      for (int j = 0; j < P; j++) { \
+        const bits_u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rs_, (int)(((uint32_t)j * 64u + (uint32_t)lane) * 16u), 0, 0); \
+        DST[j] = make_uint4(v_[0], v_[1], v_[2], v_[3]); \
+      } \
+    } while (0)
+#pragma unroll
+    for (int r = 0; r < AHEAD; r++) VDB_BITS_FUSED_LOAD(x[r], r);
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const uint64_t base = b0 + (uint64_t)r * nwaves * 64;
+      keys[r] = kKeyInvalid;
+      if (r + AHEAD < R) VDB_BITS_FUSED_LOAD(x[(r + AHEAD) % (AHEAD + 1)], r + AHEAD);
+      if (base >= a.n_rows) continue;  // (wave-uniform)
+      const uint32_t row = (uint32_t)base + lane;
+      const uint4(&xc)[P] = x[r % (AHEAD + 1)];
+#pragma unroll
+      for (int j = 0; j < P; j++) {
+        uint32_t c;
+        if (METRIC == kHamming) {
+          c = __popc(xc[j].x ^ qpc[j].x) + __popc(xc[j].y ^ qpc[j].y) + __popc(xc[j].z ^ qpc[j].z) + __popc(xc[j].w ^ qpc[j].w);
+        } else {
+          const uint32_t in = __popc(xc[j].x & qpc[j].x) + __popc(xc[j].y & qpc[j].y) + __popc(xc[j].z & qpc[j].z) + __popc(xc[j].w & qpc[j].w);
+          const uint32_t un = __popc(xc[j].x | qpc[j].x) + __popc(xc[j].y | qpc[j].y) + __popc(xc[j].z | qpc[j].z) + __popc(xc[j].w | qpc[j].w);
+          c = in | (un << 16);
+        }
+        strip[j * 64 + lane] = c;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      uint32_t sum = 0;
+#pragma unroll
+      for (int i = 0; i < P; i++) sum += strip[lane * P + i];  // the P pieces of row `lane` (packed halves cannot carry: P * 128 < 2^16)
+      __builtin_amdgcn_wave_barrier();  // strip reads done before the next chunk overwrites it
+      float score;
+      if (METRIC == kHamming) {
+        score = (float)sum;
+      } else {
+        const uint32_t inter = sum & 0xFFFFu, uni = sum >> 16;
+        score = (uni == 0) ? 1.0f : (float)inter / (float)uni;  // simd_explicit.rs:431-442
+      }
+      bool valid = row < a.n_rows;
+      if (valid && a.alive) valid = a.alive[row] != 0;
+      if (valid) keys[r] = make_key<HIB>(score, row);
+    }
+#undef VDB_BITS_FUSED_LOAD
+    // the wave's k best of { best, keys[] }
+    uint64_t carry = best;
+    uint64_t out = kKeyInvalid;
+    for (uint32_t e = 0; e < ((a.probe_skip & 2u) ? 0u : k); e++) {
+      uint64_t mloc = carry;
+#pragma unroll
+      for (int r = 0; r < R; r++) mloc = min(mloc, keys[r]);
+      const uint64_t wm = wave_min_key(mloc);
+      if ((uint32_t)lane == e) out = wm;
+      if (wm == kKeyInvalid) break;  // (wave-uniform) nothing left
+      if (carry == wm) carry = kKeyInvalid;
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (keys[r] == wm) keys[r] = kKeyInvalid;
+    }
+    best = out;
+  }
+  if ((uint32_t)lane < k) wl[(size_t)wib * kBitsFusedMaxK + lane] = best;
+  __syncthreads();
+  if (wib == 0) {  // the block's list: the k best of the four wave lists (4 k <= 64 keys, one per lane)
+    const uint32_t wsrc = (uint32_t)lane / k, esrc = (uint32_t)lane % k;
+    uint64_t mine = wsrc < 4u ? wl[(size_t)wsrc * kBitsFusedMaxK + esrc] : kKeyInvalid;
+    uint64_t out = kKeyInvalid;
+    for (uint32_t e = 0; e < k; e++) {
+      const uint64_t wm = wave_min_key(mine);
+      if ((uint32_t)lane == e) out = wm;
+      if (wm == kKeyInvalid) break;  // (wave-uniform)
+      if (mine == wm) mine = kKeyInvalid;
+    }
+    uint64_t* dst = a.part_keys + ((size_t)qi * gridDim.x + blockIdx.x) * k;
+    if ((uint32_t)lane < k) dst[lane] = out;
+    __threadfence();  // the list is visible device-wide before the ticket is
+    if (lane == 0) {
+      const uint32_t t = atomicAdd(&a.tickets[qi], 1u);
+      *lastf = (t + 1u == gridDim.x) ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+  if (*lastf == 0u) return;
+  __threadfence();  // (acquire side: every other block's list was written before its ticket)
+  if (threadIdx.x == 0) a.tickets[qi] = 0u;  // the next call finds it zero
+  __syncthreads();  // (the merge re-uses the LDS from its start)
+  if (a.probe_skip & 1u) return;
+  fused_tail_merge<HIB>(a.m, qi, smem);
+}
+size_t sweep_bits_fused_lds_bytes(uint32_t words, uint32_t n_lists) {
+  const size_t sweep = (((size_t)words * 4 + (size_t)4 * 64 * (words / 4) * 4 + 15) & ~(size_t)15) + (size_t)4 * kBitsFusedMaxK * 8 + 16;
+  (void)n_lists;
+  const size_t merge = (size_t)4 * kBitsFusedMaxK * 8 + 256 * 8 + 8 + 16;  // fused_tail_merge
+  return std::max(sweep, merge);
+}
+template <int P>
+static void launch_sweep_bits_fused_p(int metric, const BitsFusedArgs& a, int blocks, uint32_t nq, size_t lds, hipStream_t st) {
+  if (metric == kHamming)
+    hipLaunchKernelGGL((sweep_bits_fused<kHamming, P>), dim3(blocks, nq), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL((sweep_bits_fused<kJaccard, P>), dim3(blocks, nq), dim3(256), lds, st, a);
+}
+// blocks for the one-launch path: every wave one batch of kBitsFusedR chunks when the corpus allows, at most one block per CU
+// (measured, 1 M x 768 bits: 256 / 512 / 768 / 1 024 blocks = 44.5 / 48.3 / 47.9 / 48.0 us per one-query call, 58 / 89 / 90 / 90 us for two
+// queries: fewer lists for the last block to merge, fewer extractions; profiles/r05u_*)
+int sweep_bits_fused_blocks(uint64_t n_rows, int n_cus) {
+  const uint64_t nchunks = (n_rows + 63) / 64;
+  static const int forced = [] {  // (probe builds: VELESDB_BITS_FUSED_BLOCKS)
+    const char* e = probe_env("VELESDB_BITS_FUSED_BLOCKS");
+    return e ? std::max(1, atoi(e)) : 0;
+  }();
+  const int64_t cap = std::min<int64_t>(forced ? forced : (int64_t)n_cus, 256);  // (fused_tail_merge: one list per thread of the last block)
+  return (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)(nchunks + 4 * kBitsFusedR - 1) / (4 * kBitsFusedR), cap));
+}
+bool sweep_bits_fused_supported(uint32_t words, uint32_t nq, uint32_t k) {
+  if (nq == 0 || nq > 2 || k == 0 || k > kBitsFusedMaxK || words % 4 != 0) return false;
+  switch (words / 4) {
+    case 1: case 2: case 3: case 4: case 6: case 8: case 12: return true;
+    default: return false;
+  }
+}
+hipError_t launch_sweep_bits_fused(int metric, BitsFusedArgs a, int blocks, uint32_t nq, hipStream_t st) {
+  static const uint32_t skip = [] {
+    const char* e = probe_env("VELESDB_BITS_FUSED_SKIP");
+    return e ? (uint32_t)atoi(e) : 0u;
+  }();
+  a.probe_skip = skip;
+  a.m.part_keys = a.part_keys;
+  a.m.n_lists = (uint32_t)blocks;
+  a.m.k = a.k;
+  const size_t lds = sweep_bits_fused_lds_bytes(a.words, (uint32_t)blocks);
+  switch (a.words / 4) {
+    case 1: launch_sweep_bits_fused_p<1>(metric, a, blocks, nq, lds, st); break;
+    case 2: launch_sweep_bits_fused_p<2>(metric, a, blocks, nq, lds, st); break;
+    case 3: launch_sweep_bits_fused_p<3>(metric, a, blocks, nq, lds, st); break;
+    case 4: launch_sweep_bits_fused_p<4>(metric, a, blocks, nq, lds, st); break;
+    case 6: launch_sweep_bits_fused_p<6>(metric, a, blocks, nq, lds, st); break;
+    case 8: launch_sweep_bits_fused_p<8>(metric, a, blocks, nq, lds, st); break;
+    case 12: launch_sweep_bits_fused_p<12>(metric, a, blocks, nq, lds, st); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 void launch_sweep_bits(int metric, const BitsArgs& a, int blocks, uint32_t nq, hipStream_t st) {

@@ -218,6 +218,7 @@ struct vdb_hip_index {
 
   // scratch
   vdb::DevBuf s_queries, s_part_keys, s_part_cnt, s_qbits, s_misc;
+  vdb::DevBuf s_tickets;  // [2] u32, zero between calls: the block tickets of the one-launch packed-bit search (sweep_bits_fused)
   // results of a host-pointer search: ONE allocation [ids nq*k u64 | scores nq*k f32 | n nq u32] (reserve_out), so that one
   // copy brings everything back; the three views point into it
   vdb::DevBuf s_out;
@@ -264,6 +265,9 @@ struct vdb_hip_index {
   hipEvent_t ev_foreign = nullptr, ev_own = nullptr;
   hipStream_t last_foreign = nullptr;
   bool foreign_pending = false;
+  // work was enqueued on `stream` (enter_index: every host entry point) since a caller's stream last waited for it: a device-resident
+  // search on a caller's stream records + waits for ev_own only then (two packets less per call in a loop of such searches)
+  bool own_dirty = true;
 
   // multi-device handle (vdb_hip_index_create with n_devices > 1): this object then owns no device memory, only the
   // id mappings / counters above and the children; every entry point dispatches through the group (shard_group.hip)

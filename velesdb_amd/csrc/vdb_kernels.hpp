@@ -359,6 +359,22 @@ struct BitsPlan {
   int B;       // queries per corpus pass (0: the per-query kernel)
   bool tile;   // lock-free selection (k <= kBitsTileMaxK)
 };
+// a call of one or two packed-bit queries in ONE launch (sweep.hip sweep_bits_fused): query packing, sweep, per-block lists and — in the
+// block that draws the last ticket — the merge
+struct BitsFusedArgs {
+  const uint32_t* bits;  // [n_rows][words]
+  const float* q;        // [nq][q_stride] f32 queries (device)
+  uint64_t q_stride;
+  const uint8_t* alive;  // nullable
+  uint64_t* part_keys;   // [nq][blocks][k]
+  uint32_t* tickets;     // [nq], zero on entry; the last block of a query leaves it zero
+  uint32_t n_rows, words, dim, k;
+  uint32_t probe_skip;   // probe builds only (VELESDB_BITS_FUSED_SKIP; results are WRONG with it): 1 = no last-block merge, 2 = no extraction, 4 = no loads
+  MergeArgs m;           // the output side (part_keys / n_lists / k are filled by the launcher)
+};
+bool sweep_bits_fused_supported(uint32_t words, uint32_t nq, uint32_t k);
+int sweep_bits_fused_blocks(uint64_t n_rows, int n_cus);
+hipError_t launch_sweep_bits_fused(int metric, BitsFusedArgs a, int blocks, uint32_t nq, hipStream_t st);
 BitsPlan plan_bits_sweep(uint64_t n_rows, int n_cus, uint32_t words, uint32_t nq, uint32_t k);
 hipError_t launch_bits_plan(int metric, const BitsPlan& p, const BitsArgs& a, uint32_t nq, hipStream_t st);
 // radix_sort.hip: hand-written stable LSD radix sort of (u64 key, u64 value) pairs by a list of digits (<= 8 bits each)
