@@ -1021,6 +1021,66 @@ __global__ __launch_bounds__(256) void merge_topk_select(MergeArgs m) {
   }
 }
 
+constexpr uint32_t kBitsFusedMaxK = 16;  // k of the extraction helpers below (4 k <= 64: their second level is one key per lane)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  auto a32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  v = min(a32[0], a32[1]);
+  auto a16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = min(a16[0], a16[1]);
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));  // row_ror:8
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));  // row_ror:4
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false));  // row_ror:2
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+// the smallest of the wave's 64 keys, in every lane (all invalid: kKeyInvalid): two 32-bit minimum butterflies on DPP / permlane
+// swaps — the score word, then the row word among the lanes that tie
+__device__ __forceinline__ uint64_t wave_min_key(uint64_t m) {
+  const uint32_t hi = wave_min_u32((uint32_t)(m >> 32));
+  const uint32_t lo = wave_min_u32((uint32_t)(m >> 32) == hi ? (uint32_t)m : 0xFFFFFFFFu);
+  return ((uint64_t)hi << 32) | lo;
+}
+// the k smallest of a wave's 64 x R keys (R per lane, kKeyInvalid = none; keys distinct): k times { the lane's smallest, the wave's
+// smallest of those, drop it }.  Lane e < k returns the e-th smallest; `mine` is consumed.
+template <int R>
+__device__ __forceinline__ uint64_t wave_k_smallest(uint64_t (&mine)[R], uint32_t k) {
+  const uint32_t lane = (uint32_t)lane_id();
+  uint64_t out = kKeyInvalid;
+  for (uint32_t e = 0; e < k; e++) {
+    uint64_t mloc = mine[0];
+#pragma unroll
+    for (int r = 1; r < R; r++) mloc = min(mloc, mine[r]);
+    const uint64_t wm = wave_min_key(mloc);
+    if (lane == e) out = wm;
+    if (wm == kKeyInvalid) break;  // (wave-uniform) nothing left
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (mine[r] == wm) mine[r] = kKeyInvalid;
+  }
+  return out;
+}
+// the k smallest of a block's 256 x R keys: every wave's k smallest, then wave 0 the k smallest of those 4 k <= 64.  Returns, in wave
+// 0, lane e < k: the block's e-th smallest; other waves / lanes: undefined.  wl: LDS scratch [4][kBitsFusedMaxK].  Block-uniform call
+// (two barriers inside); k <= kBitsFusedMaxK.
+template <int R>
+__device__ __forceinline__ uint64_t block_k_smallest(uint64_t (&mine)[R], uint32_t k, uint64_t* wl) {
+  const uint32_t lane = (uint32_t)lane_id(), wib = threadIdx.x >> 6;
+  const uint64_t out = wave_k_smallest<R>(mine, k);
+  __syncthreads();  // (wl may still be read from an earlier call)
+  if (lane < k) wl[(size_t)wib * kBitsFusedMaxK + lane] = out;
+  __syncthreads();
+  uint64_t res = kKeyInvalid;
+  if (wib == 0) {
+    const uint32_t wsrc = lane / k, esrc = lane % k;
+    uint64_t m2[1] = {wsrc < 4u ? wl[(size_t)wsrc * kBitsFusedMaxK + esrc] : kKeyInvalid};
+    res = wave_k_smallest<1>(m2, k);
+  }
+  return res;
+}
+__device__ __forceinline__ uint64_t block_k_smallest(uint64_t mine, uint32_t k, uint64_t* wl) {
+  uint64_t m1[1] = {mine};
+  return block_k_smallest<1>(m1, k, wl);
+}
 // ------------------------------------------------------------------------------------------
 // The merge for FEW queries over MANY partial lists (a one-query sweep leaves 1 024 lists x k keys: beyond merge_topk_select's LDS
 // window, and merge_topk's serial insertions took 42.8 us of a 91-us one-query packed-bit call — as much as the sweep itself;
@@ -1044,18 +1104,44 @@ __device__ __forceinline__ void merge_topk_heads_body(const MergeArgs& m, const 
   const uint32_t nl = m.n_lists;
   uint64_t* heads = reinterpret_cast<uint64_t*>(smem);                     // [nl]
   uint64_t* sel = heads + nl;                                               // [kMergeSelectMaxK] the keys under the bound
-  uint32_t* cnt_s = reinterpret_cast<uint32_t*>(sel + kMergeSelectMaxK);   // [64] one counter per bit, [64] valid heads, [65] selected
+  uint64_t* wl = sel + kMergeSelectMaxK;                                    // [4][kBitsFusedMaxK] block_k_smallest + [1] the bound
+  uint32_t* cnt_s = reinterpret_cast<uint32_t*>(wl + 4 * kBitsFusedMaxK + 1);  // [64] one counter per bit, [64] valid heads, [65] selected, [66] lists under the bound
+  uint32_t* plist = cnt_s + 68;                                             // [kMergeSelectMaxK] the lists under the bound
   const uint64_t* keys = m.part_keys + (size_t)qi * (m.list_stride ? m.list_stride : m.n_lists) * kin;
-  if (tid < 66) cnt_s[tid] = 0;
+  if (tid < 68) cnt_s[tid] = 0;
+  for (uint32_t l = tid; l < nl; l += 256) heads[l] = kKeyInvalid;
   __syncthreads();
   auto mbcnt = [](uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u)); };
-  uint32_t nvalid_mine = 0;
-  for (uint32_t l = tid; l < nl; l += 256) {
-    uint64_t h = kKeyInvalid;
-    for (uint32_t e = 0; e < kin; e++) h = min(h, keys[(size_t)l * kin + e]);
-    heads[l] = h;
-    nvalid_mine += h != kKeyInvalid ? 1u : 0u;
+  // 1. heads: ONE coalesced pass over all keys, eight independent loads per thread in flight, the minimum per list by LDS atomics.
+  //    (The first form gave a thread whole lists and walked each key by key — 40 dependent round trips at 1 024 lists of 10 — and the
+  //    third step did the same for the lists under the bound: 36 us per merge, profiles/r05u_*.)
+  {
+    const uint32_t total = nl * kin;
+    const uint32_t dl = 256u / kin, de = 256u % kin;  // a step of 256 keys in (list, entry) coordinates
+    uint32_t l = tid / kin, e = tid % kin;
+    for (uint32_t i0 = tid; i0 < total; i0 += 8u * 256u) {
+      uint64_t kk8[8];
+      uint32_t l8[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t i = i0 + (uint32_t)u * 256u;
+        kk8[u] = i < total ? keys[i] : kKeyInvalid;
+        l8[u] = l;
+        l += dl;
+        e += de;
+        if (e >= kin) {
+          e -= kin;
+          l++;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (kk8[u] != kKeyInvalid) atomicMin(reinterpret_cast<unsigned long long*>(&heads[l8[u]]), (unsigned long long)kk8[u]);
+    }
   }
+  __syncthreads();
+  uint32_t nvalid_mine = 0;
+  for (uint32_t l = tid; l < nl; l += 256) nvalid_mine += heads[l] != kKeyInvalid ? 1u : 0u;
   {
     uint32_t v = nvalid_mine;
 #pragma unroll
@@ -1064,8 +1150,18 @@ __device__ __forceinline__ void merge_topk_heads_body(const MergeArgs& m, const 
   }
   __syncthreads();
   const uint32_t nh = cnt_s[64];  // lists that hold anything
-  uint64_t bound = kKeyInvalid;   // fewer than k non-empty lists: every key may matter (the caller keeps such shapes on the other kernels)
-  if (nh > k) {
+  uint64_t bound = kKeyInvalid;   // fewer than k non-empty lists: every key may matter
+  if (nh > k && k <= kBitsFusedMaxK && nl <= 1024u) {
+    // 2a. the k-th smallest head by extraction (a thread holds <= 4 heads): two barriers instead of one per bit
+    uint64_t h4[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) h4[u] = tid + 256u * (uint32_t)u < nl ? heads[tid + 256u * (uint32_t)u] : kKeyInvalid;
+    const uint64_t hk = block_k_smallest<4>(h4, k, wl);
+    if (tid == k - 1) wl[4 * kBitsFusedMaxK] = hk;
+    __syncthreads();
+    bound = wl[4 * kBitsFusedMaxK];
+  } else if (nh > k) {
+    // 2b. bit by bit, as merge_topk_select
     uint64_t P = 0;
     for (int bit = 63; bit >= 0; bit--) {
       const uint64_t cand = P | ((1ull << bit) - 1ull);
@@ -1085,13 +1181,28 @@ __device__ __forceinline__ void merge_topk_heads_body(const MergeArgs& m, const 
       bound = P;  // after the last bit: P is the k-th smallest head itself
     }
   }
-  // the keys under the bound: only lists whose head passes are read again
+  // 3. the lists under the bound (at most k: keys are distinct), then ONE load per key of those lists
   for (uint32_t base = 0; base < nl; base += 256) {
     const uint32_t l = base + tid;
-    const bool mine = l < nl && heads[l] <= bound && heads[l] != kKeyInvalid;
-    for (uint32_t e = 0; e < kin; e++) {  // (kin is block-uniform: the ballots below are convergent)
-      const uint64_t key = mine ? keys[(size_t)l * kin + e] : kKeyInvalid;
-      const bool take = mine && key <= bound && key != kKeyInvalid;
+    const bool mine = l < nl && heads[l] != kKeyInvalid && heads[l] <= bound;
+    const uint64_t mask = __ballot(mine);
+    if (!mask) continue;
+    uint32_t off = 0;
+    if (lane == 0) off = atomicAdd(&cnt_s[66], (uint32_t)__popcll(mask));
+    off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+    if (mine) {
+      const uint32_t slot = off + mbcnt(mask);
+      if (slot < kMergeSelectMaxK) plist[slot] = l;
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t np = min(cnt_s[66], kMergeSelectMaxK);
+    const uint32_t nk = np * kin;  // <= k x k_in <= kMergeSelectMaxK (the launcher's condition)
+    for (uint32_t base = 0; base < nk; base += 256) {
+      const uint32_t t = base + tid;
+      const uint64_t key = t < nk ? keys[(size_t)plist[t / kin] * kin + t % kin] : kKeyInvalid;
+      const bool take = key != kKeyInvalid && key <= bound;
       const uint64_t mask = __ballot(take);
       if (!mask) continue;
       uint32_t off = 0;
@@ -1981,7 +2092,7 @@ void launch_merge(bool hib, const MergeArgs& m, uint32_t nq, hipStream_t st) {
   }
   // few queries over many lists (one-query sweeps): heads first
   const uint32_t kk = m.k_out ? m.k_out : m.k;
-  const size_t lds_h = (size_t)m.n_lists * 8 + (size_t)kMergeSelectMaxK * 8 + 66 * 4 + 8;
+  const size_t lds_h = (size_t)m.n_lists * 8 + (size_t)kMergeSelectMaxK * 8 + (size_t)(4 * kBitsFusedMaxK + 1) * 8 + 68 * 4 + (size_t)kMergeSelectMaxK * 4 + 8;
   if (nq <= kMergeHeadsMaxQueries && (uint64_t)kk * m.k <= kMergeSelectMaxK && m.n_lists > 4 * kk && lds_h <= 64 * 1024) {
     if (hib)
       hipLaunchKernelGGL((merge_topk_heads<true>), dim3(nq), dim3(256), lds_h, st, m);
@@ -2204,52 +2315,6 @@ static void launch_sweep_bits_co(int metric, const BitsArgs& a, int blocks, uint
 // integer counts, make_key, the canonical (score, row) order.  k <= kBitsFusedMaxK.
 // ------------------------------------------------------------------------------------------
 constexpr int kBitsFusedR = 16;
-constexpr uint32_t kBitsFusedMaxK = 16;
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-  auto a32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-  v = min(a32[0], a32[1]);
-  auto a16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-  v = min(a16[0], a16[1]);
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));  // row_ror:8
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));  // row_ror:4
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false));  // row_ror:2
-  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false));  // row_ror:1
-  return v;
-}
-// the smallest of the wave's 64 keys, in every lane (all invalid: kKeyInvalid)
-__device__ __forceinline__ uint64_t wave_min_key(uint64_t m) {
-  const uint32_t hi = wave_min_u32((uint32_t)(m >> 32));
-  const uint32_t lo = wave_min_u32((uint32_t)(m >> 32) == hi ? (uint32_t)m : 0xFFFFFFFFu);
-  return ((uint64_t)hi << 32) | lo;
-}
-// the k smallest of a block's 256 keys (one per thread; kKeyInvalid = none): every wave extracts its k smallest (lane e: the e-th),
-// wave 0 the k smallest of those 4 k <= 64.  Returns, in wave 0, lane e < k: the block's e-th smallest; other waves / lanes: undefined.
-// wl: LDS scratch [4][kBitsFusedMaxK].  Block-uniform call (two barriers inside); k <= kBitsFusedMaxK.
-__device__ __forceinline__ uint64_t block_k_smallest(uint64_t mine, uint32_t k, uint64_t* wl) {
-  const uint32_t lane = (uint32_t)lane_id(), wib = threadIdx.x >> 6;
-  uint64_t out = kKeyInvalid;
-  for (uint32_t e = 0; e < k; e++) {
-    const uint64_t wm = wave_min_key(mine);
-    if (lane == e) out = wm;
-    if (wm == kKeyInvalid) break;  // (wave-uniform)
-    if (mine == wm) mine = kKeyInvalid;
-  }
-  __syncthreads();  // (wl may still be read from an earlier call)
-  if (lane < k) wl[(size_t)wib * kBitsFusedMaxK + lane] = out;
-  __syncthreads();
-  uint64_t res = kKeyInvalid;
-  if (wib == 0) {
-    const uint32_t wsrc = lane / k, esrc = lane % k;
-    uint64_t m2 = wsrc < 4u ? wl[(size_t)wsrc * kBitsFusedMaxK + esrc] : kKeyInvalid;
-    for (uint32_t e = 0; e < k; e++) {
-      const uint64_t wm = wave_min_key(m2);
-      if (lane == e) res = wm;
-      if (wm == kKeyInvalid) break;
-      if (m2 == wm) m2 = kKeyInvalid;
-    }
-  }
-  return res;
-}
 // The merge of the one-launch search, run by the block that drew the last ticket: n_lists <= 256 sorted lists of k keys (one per
 // thread).  Heads first, as merge_topk_heads — the k-th smallest first key bounds the answer, only the <= k lists under it matter —
 // but with the extraction above instead of a bit-by-bit selection over LDS (35 barriers): ~5 us instead of ~12 at 256 lists.
