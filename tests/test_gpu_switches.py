@@ -14,6 +14,10 @@ against the oracle) must hold.
   VELESDB_HNSW_VIS_LDS=1          LDS visited set in the throughput walk                      -> graph tests
   VELESDB_HNSW_PREFETCH_IDS=1     latency-mode walk with the neighbour-list prediction over cache-resident corpora too -> graph tests
   VELESDB_INT8_VIS_LDS=1, VELESDB_I8_WAVES2=0   the int8 walk's variants                      -> int8 tests
+  VELESDB_BITS_FUSED_BLOCKS=37|3  the one-launch packed-bit search with another block count (every wave several batches of chunks, a
+                                  ragged block grid; 3 blocks: fewer lists than k)           -> the one-launch tests
+  VELESDB_BITS_FUSED=0            the three-launch form for one or two packed-bit queries     -> the one-launch tests
+  (VELESDB_BITS_FUSED_SKIP is an ablation that returns WRONG results by design — probe timing only, nothing to re-run)
 """
 import os
 import subprocess
@@ -33,6 +37,7 @@ SPLIT = ["tests/test_gpu_split.py", "-k",
 BF16 = ["tests/test_gpu_bf16.py", "-k", "glds_exact_products and 70077"]
 GRAPH = ["tests/test_gpu_hnsw.py"]
 INT8 = ["tests/test_gpu_int8.py"]
+ONE_LAUNCH = ["tests/test_gpu_round5_parity.py", "-k", "one_launch and (300000 or 70001 or 4100 or 130 or 64-128)"]
 
 CASES = [
     ({"VELESDB_BF16_PP": "0"}, SPLIT),
@@ -46,6 +51,9 @@ CASES = [
     ({"VELESDB_HNSW_PREFETCH_IDS": "1"}, GRAPH),
     ({"VELESDB_INT8_VIS_LDS": "1"}, INT8),
     ({"VELESDB_I8_WAVES2": "0"}, INT8),
+    ({"VELESDB_BITS_FUSED_BLOCKS": "37"}, ONE_LAUNCH),
+    ({"VELESDB_BITS_FUSED_BLOCKS": "3"}, ONE_LAUNCH),
+    ({"VELESDB_BITS_FUSED": "0"}, ONE_LAUNCH),
 ]
 
 
