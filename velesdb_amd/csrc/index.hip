@@ -235,6 +235,10 @@ uint32_t last_kernels_of_this_thread(vdb_hip_index* ix) {
   if (tl_kernels_valid && tl_ctx_owner == ix && tl_ctx_gen == ix->generation) return tl_kernels;
   return last_context(ix)->last_kernels;
 }
+void note_last_kernels(uint32_t mask) {  // (behind note_last_context: a search the combining front had another thread run)
+  tl_kernels = mask;
+  tl_kernels_valid = true;
+}
 void note_last_context(vdb_hip_index* handle, vdb_hip_index* ctx) {
   tl_ctx = ctx;
   tl_ctx_owner = handle;

@@ -29,6 +29,7 @@
 namespace vdb {
 
 void note_last_context(vdb_hip_index* handle, vdb_hip_index* ctx);  // index.hip
+void note_last_kernels(uint32_t mask);                               // index.hip
 
 void combiner_free(Combiner* c) { delete c; }
 
@@ -94,6 +95,7 @@ static void run_batch(vdb_hip_index* handle, CombineReq* const* reqs, size_t n_r
   for (CombineReq* r : batch) total += r->nq;
   const CombineReq& s = *reqs[0];
   vdb_hip_index* served = nullptr;
+  uint32_t served_kernels = 0;
   const int32_t rc = guarded([&]() -> int32_t {
     return run_search(
         handle, total, s.k, s.ef, s.mode, s.rerank_k,
@@ -108,6 +110,7 @@ static void run_batch(vdb_hip_index* handle, CombineReq* const* reqs, size_t n_r
           return search_staged(ix, total, s.k, s.ef, s.mode, s.rerank_k);
         },
         [&](vdb_hip_index* ix) {
+          served_kernels = ix->last_kernels;  // (the context is still leased: a later search on it cannot have overwritten the mask)
           uint32_t at = 0;
           for (CombineReq* r : batch) {
             deliver_slice(ix, at, r->nq, total, s.k, r->out_ids, r->out_scores, r->out_n);
@@ -120,6 +123,7 @@ static void run_batch(vdb_hip_index* handle, CombineReq* const* reqs, size_t n_r
     r->rc = rc;
     r->err = err;
     r->served_by = served;
+    r->kernels = served_kernels;
   }
 }
 
@@ -141,7 +145,10 @@ struct HandleFront {
   int leader_limit(const CombineReq& r) const { return vdb::leader_limit(handle, r); }
   void run_batch(CombineReq* const* reqs, size_t n) { vdb::run_batch(handle, reqs, n); }
   void finish(CombineReq& me) {
-    if (me.served_by) note_last_context(handle, me.served_by);
+    if (me.served_by) {
+      note_last_context(handle, me.served_by);
+      if (me.rc == VDB_OK) note_last_kernels(me.kernels);  // this thread's diagnostics describe ITS search, whoever ran it
+    }
     if (me.rc != VDB_OK) set_last_error(me.err);
   }
 };

@@ -43,6 +43,7 @@ struct CombineReq {
   int32_t rc = 0;  // VDB_OK
   std::string err;
   vdb_hip_index* served_by = nullptr;
+  uint32_t kernels = 0;  // what the batch that served it ran (the context's diagnostic mask, read while the leader still held the context)
   uint32_t passed = 0;  // (under Combiner::mu) leaders admitted AHEAD of this request while it headed the queue: the fairness rule's clock
   bool same_shape(const CombineReq& o) const { return k == o.k && ef == o.ef && mode == o.mode && rerank_k == o.rerank_k; }
 };
