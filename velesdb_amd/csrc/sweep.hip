@@ -2305,14 +2305,17 @@ static void launch_sweep_bits_co(int metric, const BitsArgs& a, int blocks, uint
 // ------------------------------------------------------------------------------------------
 // ONE launch for a call of one or two packed-bit queries (round 5).  Such a call was three launches — prep_rows packing the query,
 // the sweep, the merge of its partial lists — 68 us for the 96 MB of 1 M x 768 bits, of which the sweep was 40 (profiles/r05n_*).
-// Here a block packs the query itself (the rule of prep_rows: x > 0.5), sweeps with the coalesced loads of sweep_topk_bits_co,
+// Here a block packs the query itself (the rule of prep_rows: x > 0.5), sweeps with the coalesced layout of sweep_topk_bits_co (a
+// wave's 64 rows = one contiguous chunk) through range-checked raw buffer loads, three chunks ahead, one block per CU, and
 // keeps NO list while it sweeps: a lane's keys stay in registers (kBitsFusedR chunks per batch), and the wave's k best are
 // extracted afterwards — k times { the lane's smallest key, the wave's smallest of those (two 32-bit minimum butterflies on DPP /
 // permlane swaps: score word, then row word among the lanes that tie), drop it }; lane e ends with the e-th best, which is also
 // how a further batch (more than kBitsFusedR chunks per wave) carries the list on.  The block's four lists are merged the same
 // way by wave 0 (4 k <= 64 keys, one per lane), the block writes ONE list and takes a ticket; the block that draws the last
-// ticket merges all lists heads-first (merge_topk_heads_body) and writes the result.  Same keys as every other path: the same
-// integer counts, make_key, the canonical (score, row) order.  k <= kBitsFusedMaxK.
+// ticket merges all lists heads-first (fused_tail_merge) and writes the result.  Same keys as every other path: the same
+// integer counts, make_key, the canonical (score, row) order.  k <= kBitsFusedMaxK.  Measured: 91.5 -> 37.6 us per one-query call
+// at 1 M x 768 (an empty kernel of this shape 16.3, loads + 9, extraction + 4.5, last-block merge + 8-9;
+// profiles/r05t_v_one_launch_packed_bit_query.txt).
 // ------------------------------------------------------------------------------------------
 constexpr int kBitsFusedR = 16;
 // The merge of the one-launch search, run by the block that drew the last ticket: n_lists <= 256 sorted lists of k keys (one per
