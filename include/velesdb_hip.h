@@ -400,6 +400,9 @@ enum vdb_kernel_bit {
   VDB_KERNEL_HNSW_INT8 = 2048,     /* hnsw_search_int8_kernel                                                          */
   VDB_KERNEL_BITS_GEMM = 4096      /* Hamming / Jaccard batches as a four-bit GEMM distance (sweep_topk_gemm_bf16_pp<.., FP4>) */
 };
+/* which kernels served THIS THREAD's last search on the handle: taken when that search's context was released (or, for a call the
+ * combining front had another thread launch, handed back with the call's result), so a search of another thread that takes the same
+ * context a moment later does not change it. */
 int32_t vdb_hip_index_last_kernels(vdb_hip_index* idx, uint32_t* mask);
 /* *mode = 1 if searches in VDB_SEARCH_BRUTE mode with this k run on the matrix-core kernel (mode M), else 0 */
 int32_t vdb_hip_index_sweep_arith_mode(vdb_hip_index* idx, uint32_t k, int32_t* mode);
