@@ -108,6 +108,24 @@ def test_binary_codes_and_scan_exact(gpu_required, n, dim):
     assert np.array_equal(gid, ids[eid.astype(np.int64)])
     assert np.array_equal(gsc, esc)           # integer distances: exact
     assert gid[1, 0] == ids[20] and gsc[1, 0] == 0.0
+    # one or two queries per call: ONE launch (sweep.hip sweep_bits_fused with the sign rule x >= 0: -0.0 sets the bit, NaN does not);
+    # the same answers as the batch above, as engine 0 (three launches), and with soft deletes
+    Q[3, 0], Q[3, 1 % dim] = -0.0, np.nan
+    eid, esc = po.scan_topk_binary(rows, Q, 12)
+    for q0, nq in ((0, 1), (1, 2), (3, 1), (4, 2)):
+        gid1, gsc1, gcnt1 = ix.search_batch_binary(Q[q0:q0 + nq], 12)
+        ix.set_option(va.OPT_SWEEP_ENGINE, 0)
+        vid1, vsc1, _ = ix.search_batch_binary(Q[q0:q0 + nq], 12)
+        ix.set_option(va.OPT_SWEEP_ENGINE, -1)
+        assert np.array_equal(gid1, ids[eid[q0:q0 + nq].astype(np.int64)]) and np.array_equal(gsc1, esc[q0:q0 + nq]), (n, dim, q0, nq)
+        assert np.array_equal(gid1, vid1) and np.array_equal(gsc1, vsc1)
+    dead = rng.choice(n, n // 5, replace=False)
+    for d in dead:
+        assert ix.remove(int(ids[d]))
+    lv = np.setdiff1d(np.arange(n), dead)
+    eid, esc = po.scan_topk_binary(rows[lv], Q[:1], 12)
+    gid1, gsc1, _ = ix.search_batch_binary(Q[:1], 12)
+    assert np.array_equal(gid1, ids[lv[eid.astype(np.int64)]]) and np.array_equal(gsc1, esc)
     ix.close()
 
 

@@ -29,9 +29,9 @@ static std::atomic<uint32_t> g_int8_oversampling{4};  // DualPrecisionConfig::de
 static inline uint32_t opt_max_tile(const vdb_hip_index* ix) { return ix->opt[VDB_OPT_MAX_QUERY_TILE] >= 0 ? (uint32_t)ix->opt[VDB_OPT_MAX_QUERY_TILE] : (uint32_t)g_max_tile.load(); }
 // one-launch packed-bit search for calls of one or two queries: the default engine's path (engine 0 keeps the three-launch form, so
 // both stay under the parity tests); probe builds: VELESDB_BITS_FUSED=0 turns it off for A/B runs
-static inline bool opt_bits_fused(const vdb_hip_index* ix);
+bool opt_bits_fused(const vdb_hip_index* ix);
 static inline int opt_engine(const vdb_hip_index* ix) { return ix->opt[VDB_OPT_SWEEP_ENGINE] >= 0 ? ix->opt[VDB_OPT_SWEEP_ENGINE] : g_sweep_engine.load(); }
-static inline bool opt_bits_fused(const vdb_hip_index* ix) {
+bool opt_bits_fused(const vdb_hip_index* ix) {
   static const bool off = [] {
     const char* e = vdb::probe_env("VELESDB_BITS_FUSED");
     return e && e[0] == '0';

@@ -845,7 +845,39 @@ int32_t brute_binary_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
   }
   if ((size_t)4 * k * 8 + (size_t)ix->words * 4 + 32 > 60 * 1024)
     return fail(VDB_ERR_UNSUPPORTED, "k too large for the fused top-k path");
-  hipError_t e = ix->s_qbits.reserve((size_t)nq * ix->words * 4, false, st);
+  hipError_t e;
+  // one or two queries: ONE launch — the blocks take the query's sign bits themselves, the one that finishes last merges (sweep.hip)
+  if (opt_bits_fused(ix) && sweep_bits_fused_supported(ix->words, nq, k)) {
+    const int fblocks = sweep_bits_fused_blocks(ix->n_rows, ix->n_cus);
+    if (ix->s_tickets.cap == 0) {
+      if ((e = ix->s_tickets.reserve(16, false, st)) != hipSuccess) return fail(VDB_ERR_OOM, "ticket scratch");
+      VDB_HIP(hipMemsetAsync(ix->s_tickets.p, 0, 16, st));
+    }
+    if ((e = ix->s_part_keys.reserve((size_t)nq * fblocks * k * 8, false, st)) != hipSuccess) return fail(VDB_ERR_OOM, "top-k scratch");
+    BitsFusedArgs fa{};
+    fa.bits = ix->sign_bits.as<uint32_t>();
+    fa.q = d_q;
+    fa.q_stride = q_stride;
+    fa.alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
+    fa.part_keys = ix->s_part_keys.as<uint64_t>();
+    fa.tickets = ix->s_tickets.as<uint32_t>();
+    fa.n_rows = (uint32_t)ix->n_rows;
+    fa.words = ix->words;
+    fa.dim = ix->dim;
+    fa.k = k;
+    fa.sign_rule = 1u;
+    fa.m.ext_ids = ix->ext_ids.as<uint64_t>();
+    fa.m.out_ids = d_ids;
+    fa.m.out_scores = d_scores;
+    fa.m.out_n = d_n;
+    EventPair* evf = next_events(ix);
+    if (evf) (void)hipEventRecord(evf->a, st);
+    if ((e = launch_sweep_bits_fused(VDB_HAMMING, fa, fblocks, nq, st)) != hipSuccess)
+      return fail(VDB_ERR_HIP, std::string("one-launch sign-bit search: ") + hipGetErrorString(e));
+    if (evf) (void)hipEventRecord(evf->b, st);
+    return VDB_OK;
+  }
+  e = ix->s_qbits.reserve((size_t)nq * ix->words * 4, false, st);
   if (e != hipSuccess) return fail(VDB_ERR_OOM, "qbits scratch");
   hipLaunchKernelGGL(sign_bits_rows, dim3((unsigned)std::min<uint32_t>((nq + 3) / 4, 4096)), dim3(256), 0, st, d_q, q_stride,
                      ix->s_qbits.as<uint32_t>(), ix->words, 0u, nq, ix->dim);

@@ -2384,11 +2384,12 @@ __global__ __launch_bounds__(256) void sweep_bits_fused(BitsFusedArgs a) {
   uint32_t* strip = qw + W + (size_t)wib * 64 * P;
   uint64_t* wl = reinterpret_cast<uint64_t*>(smem + (((size_t)W * 4 + (size_t)4 * 64 * P * 4 + 15) & ~(size_t)15));
   uint32_t* lastf = reinterpret_cast<uint32_t*>(wl + 4 * kBitsFusedMaxK);
-  {  // the query's bits (prep_rows: x > 0.5; NaN > 0.5 is false, as on the CPU)
+  {  // the query's bits (prep_rows: x > 0.5; Binary storage mode, sign_bits_rows: x >= 0)
     const float* qp = a.q + (size_t)qi * a.q_stride;
     for (uint32_t e0 = (uint32_t)wib * 64u; e0 < W * 32u; e0 += 256u) {
       const uint32_t e = e0 + (uint32_t)lane;
-      const uint64_t mb = __ballot(e < a.dim && qp[e] > 0.5f);
+      const float xq = e < a.dim ? qp[e] : -1.0f;
+      const uint64_t mb = __ballot(e < a.dim && (a.sign_rule ? xq >= 0.0f : xq > 0.5f));  // (NaN: false under both rules, as on the CPU)
       if (lane == 0) {
         qw[e0 / 32] = (uint32_t)mb;
         if (e0 / 32 + 1 < W) qw[e0 / 32 + 1] = (uint32_t)(mb >> 32);

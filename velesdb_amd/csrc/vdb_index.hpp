@@ -295,6 +295,8 @@ struct CtxLease {
   CtxLease(const CtxLease&) = delete;
   CtxLease& operator=(const CtxLease&) = delete;
 };
+// one or two packed-bit queries per call take the one-launch kernel (index.hip: the default engine; probe builds: VELESDB_BITS_FUSED=0)
+bool opt_bits_fused(const vdb_hip_index* ix);
 // the context that served this thread's last search on `ix` (diagnostic getters read from it)
 vdb_hip_index* last_context(vdb_hip_index* ix);
 // index.hip

@@ -369,6 +369,7 @@ struct BitsFusedArgs {
   uint64_t* part_keys;   // [nq][blocks][k]
   uint32_t* tickets;     // [nq], zero on entry; the last block of a query leaves it zero
   uint32_t n_rows, words, dim, k;
+  uint32_t sign_rule;    // how a query value becomes a bit: 0 = x > 0.5 (prep_rows: Hamming / Jaccard indexes), 1 = x >= 0 (sign_bits_rows: Binary storage mode)
   uint32_t probe_skip;   // probe builds only (VELESDB_BITS_FUSED_SKIP; results are WRONG with it): 1 = no last-block merge, 2 = no extraction, 4 = no loads
   MergeArgs m;           // the output side (part_keys / n_lists / k are filled by the launcher)
 };
