@@ -17,6 +17,7 @@ against the oracle) must hold.
   VELESDB_BITS_FUSED_BLOCKS=37|3  the one-launch packed-bit search with another block count (every wave several batches of chunks, a
                                   ragged block grid; 3 blocks: fewer lists than k)           -> the one-launch tests
   VELESDB_BITS_FUSED=0            the three-launch form for one or two packed-bit queries     -> the one-launch tests
+  VELESDB_MERGE_EXTRACT=0         the small merges on merge_topk_select instead of merge_topk_extract -> split tests
   (VELESDB_BITS_FUSED_SKIP is an ablation that returns WRONG results by design — probe timing only, nothing to re-run)
 """
 import os
@@ -54,6 +55,7 @@ CASES = [
     ({"VELESDB_BITS_FUSED_BLOCKS": "37"}, ONE_LAUNCH),
     ({"VELESDB_BITS_FUSED_BLOCKS": "3"}, ONE_LAUNCH),
     ({"VELESDB_BITS_FUSED": "0"}, ONE_LAUNCH),
+    ({"VELESDB_MERGE_EXTRACT": "0"}, SPLIT),
 ]
 
 

@@ -97,7 +97,7 @@ def test_occupancy_budgets_of_the_hot_kernels(kernels):
     # construction: the insert kernel of the bench's shape (cosine, 768 dimensions) at four waves per SIMD
     assert one(kernels, "hnsw_insert_kernel<0, 3>")["waves_per_simd"] >= 4
     # the small kernels around the selection launches must never be the ones that limit a CU
-    for name in ("merge_topk", "merge_topk_select", "merge_topk_heads", "merge_shards_topk", "select_finish_kernel", "split_rerank_verify", "seed_tau_kernel",
+    for name in ("merge_topk", "merge_topk_select", "merge_topk_heads", "merge_topk_extract", "merge_shards_topk", "select_finish_kernel", "split_rerank_verify", "seed_tau_kernel",
                  "pack_shard_records", "rs_hist_kernel", "rs_scan_kernel", "rs_scatter_kernel"):
         assert all(k["waves_per_simd"] >= 7 for k in fam(kernels, name)), name
 

@@ -1082,6 +1082,83 @@ __device__ __forceinline__ uint64_t block_k_smallest(uint64_t mine, uint32_t k, 
   return block_k_smallest<1>(m1, k, wl);
 }
 // ------------------------------------------------------------------------------------------
+// The same merge by EXTRACTION, for the small merges between the launches of the selection stage (<= 2 048 keys, k <= 16: the seed's
+// 256 keys, 650 / 1 290 / 1 930 pool keys after the first three launches of a headline step).  merge_topk_select compacts into LDS
+// and builds the k-th smallest key bit by bit — ~35 barriers; here a thread keeps its <= 8 keys in registers and the block extracts
+// its k smallest (block_k_smallest: two barriers).  Equal keys keep their places (a seed row swept again may carry the same key):
+// one instance is dropped per extraction.  Output identical to merge_topk_select, the next bound included (reseed_*).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kMergeExtractMaxKeys = 8 * 256;
+// wave_k_smallest for keys that may repeat: an extraction drops ONE instance (the lowest lane's first register)
+template <int R>
+__device__ __forceinline__ uint64_t wave_k_smallest_dup(uint64_t (&mine)[R], uint32_t k) {
+  const uint32_t lane = (uint32_t)lane_id();
+  uint64_t out = kKeyInvalid;
+  for (uint32_t e = 0; e < k; e++) {
+    uint64_t mloc = mine[0];
+#pragma unroll
+    for (int r = 1; r < R; r++) mloc = min(mloc, mine[r]);
+    const uint64_t wm = wave_min_key(mloc);
+    if (lane == e) out = wm;
+    if (wm == kKeyInvalid) break;  // (wave-uniform) nothing left
+    const uint64_t holders = __ballot(mloc == wm);
+    if (lane == (uint32_t)__builtin_ctzll(holders)) {
+      bool dropped = false;
+#pragma unroll
+      for (int r = 0; r < R; r++)
+        if (!dropped && mine[r] == wm) {
+          mine[r] = kKeyInvalid;
+          dropped = true;
+        }
+    }
+  }
+  return out;
+}
+template <bool HIB>
+__global__ __launch_bounds__(256) void merge_topk_extract(MergeArgs m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = (uint32_t)lane_id(), tid = threadIdx.x, wib = tid >> 6;
+  const uint32_t qi = blockIdx.x;
+  if (m.active && (qi >= *m.active || (m.active_max && *m.active > m.active_max))) return;  // (uniform per block)
+  if (m.skip_cnt && *m.skip_cnt <= m.skip_le) return;
+  if (m.gate && m.gate[qi] == 0u) return;
+  const uint32_t kin = m.k;
+  const uint32_t k = m.k_out ? m.k_out : m.k;
+  const uint32_t total = m.n_lists * kin;
+  uint64_t* wl = reinterpret_cast<uint64_t*>(smem);  // [4][kBitsFusedMaxK]
+  const uint64_t* keys = m.part_keys + (size_t)qi * (m.list_stride ? m.list_stride : m.n_lists) * kin;
+  uint64_t r8[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const uint32_t i = tid + 256u * (uint32_t)u;
+    r8[u] = i < total ? keys[i] : kKeyInvalid;
+  }
+  const uint64_t mine = wave_k_smallest_dup<8>(r8, k);
+  if (lane < k) wl[(size_t)wib * kBitsFusedMaxK + lane] = mine;
+  __syncthreads();
+  if (wib != 0) return;
+  const uint32_t wsrc = lane / k, esrc = lane % k;
+  uint64_t m2[1] = {wsrc < 4u ? wl[(size_t)wsrc * kBitsFusedMaxK + esrc] : kKeyInvalid};
+  const uint64_t res = wave_k_smallest_dup<1>(m2, k);
+  const uint32_t cnt = (uint32_t)__popcll(__ballot(lane < k && res != kKeyInvalid));
+  if (lane < k) {
+    if (lane < cnt) {
+      const uint32_t row = key_row(res);
+      m.out_ids[(size_t)qi * k + lane] = m.ext_ids ? m.ext_ids[row] : (uint64_t)row + m.row_base;
+      m.out_scores[(size_t)qi * k + lane] = key_score<HIB>(res);  // raw compute_distance value (search.rs:209)
+      if (m.reseed_delta && lane + 1 == m.reseed_k) m.reseed_tau[qi] = reseed_key(key_score<HIB>(res), m.reseed_delta[qi]);
+    } else {
+      m.out_ids[(size_t)qi * k + lane] = ~0ull;
+      m.out_scores[(size_t)qi * k + lane] = __uint_as_float(0x7FC00000u);
+    }
+  }
+  if (lane == 0) {
+    m.out_n[qi] = cnt;
+    if (m.reseed_delta && (cnt < m.reseed_k || m.reseed_k == 0)) m.reseed_tau[qi] = kKeyInvalid;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // The merge for FEW queries over MANY partial lists (a one-query sweep leaves 1 024 lists x k keys: beyond merge_topk_select's LDS
 // window, and merge_topk's serial insertions took 42.8 us of a 91-us one-query packed-bit call — as much as the sweep itself;
 // profiles/r05m_*).  Heads first:
@@ -2082,6 +2159,18 @@ void launch_max_norm(const float* norms, uint32_t n_rows, uint32_t* out_bits, hi
 
 void launch_merge(bool hib, const MergeArgs& m, uint32_t nq, hipStream_t st) {
   const uint64_t total = (uint64_t)m.n_lists * m.k;
+  static const bool extract_on = [] {  // (probe builds: VELESDB_MERGE_EXTRACT=0 keeps these merges on merge_topk_select)
+    const char* e = probe_env("VELESDB_MERGE_EXTRACT");
+    return !(e && e[0] == '0');
+  }();
+  if (extract_on && total <= kMergeExtractMaxKeys && (m.k_out ? m.k_out : m.k) <= kBitsFusedMaxK) {  // small merges: registers + extraction
+    const size_t lds_x = (size_t)4 * kBitsFusedMaxK * 8;
+    if (hib)
+      hipLaunchKernelGGL((merge_topk_extract<true>), dim3(nq), dim3(256), lds_x, st, m);
+    else
+      hipLaunchKernelGGL((merge_topk_extract<false>), dim3(nq), dim3(256), lds_x, st, m);
+    return;
+  }
   if (total <= kMergeSelectMaxKeys && (m.k_out ? m.k_out : m.k) <= kMergeSelectMaxK) {  // selection: the whole query in LDS
     const size_t lds_r = (size_t)total * 8 + (size_t)kMergeSelectMaxK * 8 + 66 * 4 + 8;
     if (hib)
