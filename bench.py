@@ -176,7 +176,8 @@ def compact_line(full, legs_file="bench_legs.json"):
             sq, bt = m_.get("single_query") or {}, m_.get("batch") or {}
             legs["other_metrics"][str(m_.get("metric"))[:12]] = {
                 "one_query_ms": sq.get("ms_per_call"), "one_query_hbm_frac": sq.get("hbm_frac"), "batch_qps": bt.get("qps"),
-                "batch_frac": (bt.get("roofline") or {}).get("frac"), "parity": _ok(m_.get("parity_check"))}
+                "batch_frac": (bt.get("roofline") or {}).get("frac"), "batch_traffic_over_algorithmic": (bt.get("roofline") or {}).get("traffic_over_algorithmic"),
+                "parity": _ok(m_.get("parity_check"))}
     line["legs"] = legs
     line["legs_file"] = legs_file
     line["device"] = (g("device") or "")[:80]
@@ -271,9 +272,30 @@ def main():
               "dot": va.DistanceMetric.DotProduct}[a.metric]
     N, D, K, Q = a.rows, a.dim, a.k, a.batch
 
-    if a.pmc_child in ("hnsw", "bf16"):  # traffic pass of another leg: the same launches, nothing else
+    if a.pmc_child in ("hnsw", "bf16", "bits_hamming", "bits_jaccard"):  # traffic pass of another leg: the same launches, nothing else
         stream_c = torch.cuda.current_stream().cuda_stream
         gc_ = torch.Generator(device=dev)
+        if a.pmc_child.startswith("bits_"):  # the other_metrics leg's packed-bit batch (x > 0.5 of the same random rows / queries)
+            mm_c = va.DistanceMetric.Hamming if a.pmc_child == "bits_hamming" else va.DistanceMetric.Jaccard
+            ixc = va.HnswIndex(D, mm_c, va.HnswParams(a.M, a.efc, N), device=local)
+            gc_.manual_seed(42)
+            for base in range(0, N, 250_000):
+                n_c = min(250_000, N - base)
+                c = (torch.randn((n_c, D), generator=gc_, device=dev) > 0.5).float()
+                torch.cuda.synchronize()
+                ixc.upload_dev(base, c.data_ptr(), n_c, stream_c)
+                torch.cuda.synchronize()
+                del c
+            nqc = Q
+            gc_.manual_seed(43)
+            qc = (torch.randn((nqc, D), generator=gc_, device=dev, dtype=torch.float32) > 0.5).float()
+            c_ids = torch.empty((nqc, K), dtype=torch.int64, device=dev)
+            c_sc = torch.empty((nqc, K), dtype=torch.float32, device=dev)
+            c_n = torch.empty((nqc,), dtype=torch.int32, device=dev)
+            for _ in range(a.warmup + a.steps):
+                ixc.search_batch_dev(qc.data_ptr(), nqc, K, 0, va.MODE_BRUTE, c_ids.data_ptr(), c_sc.data_ptr(), c_n.data_ptr(), stream_c)
+            torch.cuda.synchronize()
+            return
         if a.pmc_child == "hnsw":
             ixc = va.HnswIndex(D, metric, va.HnswParams(a.M, a.efc, N), device=local)
             ixc.load_reference_files(a.graph_dir, "native_hnsw")
@@ -1396,9 +1418,17 @@ def main():
                 bops = 2.0 * N * D * Q
                 btops = bops / (row["batch"]["sweep_kernel_ms"] * 1e-3) / 1e12
                 row["batch"]["roofline"] = {"bound": "mfma", "achieved": round(btops, 1), "peak": 10000.0, "unit": "TFLOP/s (fp4)", "frac": round(btops / 10000.0, 4),
-                                            "traffic": None, "alg_ops_per_batch": bops,
+                                            "traffic": None, "alg_bytes_per_batch": N * ((D + 255) // 256 * 128), "alg_ops_per_batch": bops,
                                             "kernel": "sweep_topk_gemm_bf16_pp<%s, FP4> (v_mfma_scale_f32_16x16x128_f8f6f4, unit scales; timed region = sample seed + launches + merges)" % mname,
                                             "note": "dense FP4 MFMA peak ~10 PFLOP/s (MI355X_MICROARCH.md); algorithmic operations = 2*rows*dim*queries"}
+            if bits_metric and "roofline" in row["batch"] and not a.no_traffic_pass:
+                # HBM bytes of the batch's kernels (seed, selection launches over the four-bit image, merges), in a child pass of this run
+                tb_m, tk_m, tsrc_m = traffic_pass("bits_" + mname, ("sweep_topk_gemm_bf16_pp", "merge_topk", "seed_scores_fp4", "select_finish"), [])
+                row["batch"]["roofline"]["traffic_source"] = tsrc_m
+                if tb_m is not None:
+                    row["batch"]["roofline"]["traffic"] = tb_m
+                    row["batch"]["roofline"]["traffic_by_kernel"] = tk_m
+                    row["batch"]["roofline"]["traffic_over_algorithmic"] = round(tb_m / row["batch"]["roofline"]["alg_bytes_per_batch"], 3)
             pass_bytes = N * ((D + 127) // 128 * 16) if bits_metric else N * D * 4
             sk = row["single_query"]["sweep_kernel_ms"]
             row["single_query"]["hbm_gbs"] = round(pass_bytes / (sk * 1e-3) / 1e9, 1) if sk > 0 else 0.0
