@@ -86,13 +86,15 @@ def parse():
     p.add_argument("--M", type=int, default=32)
     p.add_argument("--efc", type=int, default=400)
     p.add_argument("--recall-queries", type=int, default=1000)
+    p.add_argument("--no-m128-leg", action="store_true", help="skip the graph leg at the reference's own preset for this corpus (HnswParams::million_scale)")
+    p.add_argument("--m128-rows", type=int, default=1_000_000, help="rows of the million_scale(768) leg (M 128 / ef_construction 1600)")
     p.add_argument("--cpu-hnsw-queries", type=int, default=20000)
     return p.parse_args()
 
 # ---- the line the driver parses -------------------------------------------------------------------------------------------------
 COMPACT_LIMIT = 4096   # bytes; the driver's record keeps a bounded tail of stdout (round 4's 25 KB line was cut: BENCH_r04.parsed = null)
 _ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel", "kernel_ms", "launches_timed")
-_CPU_KEYS = ("value", "unit", "cores", "kind", "cpu_model", "sample")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "cpu_model", "host_hardware_threads", "cores_of_socket", "sample")
 
 
 def _pick(d, keys, clip=160):
@@ -145,6 +147,30 @@ def compact_line(full, legs_file="bench_legs.json"):
         lm = h.get("latency_mode")
         if isinstance(lm, list) and lm and isinstance(lm[0], dict):
             legs["hnsw"]["one_query_us"] = lm[0].get("median_us_per_call")
+    he_ = g("host_entry")
+    if isinstance(he_, dict):  # what a VectorIndex caller gets: host pointers in, host pointers out (PCIe-inclusive; never `value`)
+        line["host_entry_qps"] = {str(c_.get("queries_per_call")): c_.get("qps") for c_ in (he_.get("calls") or [])[:3] if isinstance(c_, dict)}
+        for t_ in (he_.get("threads") or [])[:3]:
+            if isinstance(t_, dict):
+                line["host_entry_qps"]["%sx%s" % (t_.get("threads"), t_.get("queries_per_call"))] = t_.get("qps")
+    kc = g("k_curve")
+    if isinstance(kc, list):
+        line["k_curve_qps"] = {str(p_.get("k")): p_.get("qps") for p_ in kc[:6] if isinstance(p_, dict)}
+        for p_ in kc:
+            if isinstance(p_, dict) and p_.get("k") == 50:
+                line["k50_qps"] = p_.get("qps")
+    he2 = g("hnsw_embedding_like")
+    if isinstance(he2, dict):
+        legs["hnsw_embedding_like"] = {"qps": he2.get("qps"), "recall": he2.get("recall_at_10"), "frac": (he2.get("roofline") or {}).get("frac"),
+                                       "cpu_qps": (he2.get("cpu_baseline") or {}).get("value")}
+    hm = g("hnsw_m128")
+    if isinstance(hm, dict):
+        lm_ = hm.get("latency_mode")
+        legs["hnsw_m128"] = {"qps": hm.get("qps"), "recall": hm.get("recall_at_10"), "frac": (hm.get("roofline") or {}).get("frac"),
+                             "build_inserts_per_s": hm.get("build_inserts_per_s"), "build_frac": ((hm.get("build") or {}).get("roofline") or {}).get("frac"),
+                             "cpu_qps": (hm.get("cpu_baseline") or {}).get("value"), "cpu_recall": (hm.get("cpu_baseline") or {}).get("recall_at_10"),
+                             "one_query_us": (lm_[0].get("median_us_per_call") if isinstance(lm_, list) and lm_ and isinstance(lm_[0], dict) else None),
+                             "parity": _ok(hm.get("parity_check"))}
     b = g("bf16_gemm")
     if isinstance(b, dict):
         r_ = b.get("roofline") or {}
@@ -182,7 +208,7 @@ def compact_line(full, legs_file="bench_legs.json"):
     line["legs_file"] = legs_file
     line["device"] = (g("device") or "")[:80]
     enc = json.dumps(line)
-    for drop in ("other_metrics", "config0_10k", "sq8", "sharded", "bf16_gemm", "hnsw"):   # never reached on a real run (tested)
+    for drop in ("other_metrics", "config0_10k", "sq8", "sharded", "bf16_gemm", "hnsw_embedding_like", "hnsw_m128", "hnsw"):   # never reached on a real run (tested)
         if len(enc) <= COMPACT_LIMIT:
             break
         line["legs"].pop(drop, None)
@@ -229,7 +255,7 @@ def main():
     # measure the interpreter lock).  Every answer is compared bit for bit with a batched reference call.
     _cb = {}
 
-    def callers_leg(index, q_np, k_, ef_, mode_, ref, threads_list=(1, 4, 16, 64), seconds=1.2):
+    def callers_leg(index, q_np, k_, ef_, mode_, ref, threads_list=(1, 4, 16, 64), seconds=1.2, nq_per_call=1):
         import ctypes as C
         if "lib" not in _cb:
             path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "libcallers_bench.so")
@@ -245,12 +271,12 @@ def main():
         for T in threads_list:
             out = np.zeros(8, dtype=np.float64)
             s0 = index.combine_stats()
-            rc = _cb["lib"].callers_run(index._h, q_np.ctypes.data, q_np.shape[0], q_np.shape[1], k_, ef_, mode_, T, seconds, 20, 1,
+            rc = _cb["lib"].callers_run(index._h, q_np.ctypes.data, q_np.shape[0], q_np.shape[1], k_, ef_, mode_, T, seconds, 20, nq_per_call,
                                         rid.ctypes.data, rsc.ctypes.data, rn.ctypes.data, out.ctypes.data)
             s1 = index.combine_stats()
             assert rc == 0
             launches, calls = s1[0] - s0[0], s1[1] - s0[1]
-            pts.append({"threads": T, "qps": round(out[0], 1), "p50_us": round(out[1], 1), "p99_us": round(out[2], 1),
+            pts.append({"threads": T, "queries_per_call": nq_per_call, "qps": round(out[0], 1), "p50_us": round(out[1], 1), "p99_us": round(out[2], 1),
                         "calls": int(out[4]), "calls_per_launch": round(calls / max(launches, 1), 2),
                         "bitwise_mismatches_vs_batched_call": int(out[5]), "failed_calls": int(out[6])})
         return pts
@@ -631,6 +657,51 @@ def main():
             batch_sizes.append({"queries": nq_t, "ms_per_call": round(t_dt * 1e3, 4), "qps": round(nq_t / t_dt, 1),
                                 "select_level": int(ix.last_select_level())})
 
+    # ---- the headline batch at the k the reference also benches (benches/hnsw_benchmark.rs:152-159: k = 10, 50, 100; its brute-force /
+    # Perfect / rerank calls take any k, search.rs:118-160,176-219): device-resident, Q queries per step.  k = 10: the selection stage
+    # with block-local lists; 10 < k <= 128: the WIDE selection (csrc/sweep_wide.hip); same exact bits either way (tests/test_gpu_wide_k.py)
+    k_curve = None
+    if rank == 0 and not a.no_tiles and not a.no_split and a.metric in ("cosine", "dot"):
+        k_curve = []
+        for k_c in (10, 11, 50, 100):
+            kc_ids = torch.empty((Q, k_c), dtype=torch.int64, device=dev)
+            kc_sc = torch.empty((Q, k_c), dtype=torch.float32, device=dev)
+            kc_n = torch.empty((Q,), dtype=torch.int32, device=dev)
+
+            def kstep(i_):
+                off_ = (i_ * Q) % (n_query_pool - Q + 1)
+                ix.search_batch_dev(queries[off_:off_ + Q].data_ptr(), Q, k_c, 0, va.MODE_BRUTE, kc_ids.data_ptr(), kc_sc.data_ptr(), kc_n.data_ptr(), stream)
+            for i_ in range(3):
+                kstep(i_)
+            torch.cuda.synchronize()
+            reps = 10
+            tk0 = time.perf_counter()
+            for i_ in range(reps):
+                events_on_last(i_, reps)
+                kstep(3 + i_)
+            torch.cuda.synchronize()
+            kdt = (time.perf_counter() - tk0) / reps
+            ksel_ms, ksel_n = ix.last_selection_ms()
+            va.set_kernel_timing(False)
+            nq_k, unp_k = ix.last_split_stats()
+            k_curve.append({"k": k_c, "queries": Q, "ms_per_step": round(kdt * 1e3, 4), "qps": round(Q / kdt, 1), "select_level": int(ix.last_select_level()),
+                            "selection_kernel_ms": round(ksel_ms, 4), "selection_launches": ksel_n,
+                            "selection_frac_of_bf16_pipe": round(2.0 * N * D * Q / (ksel_ms * 1e-3) / 1e12 / 2500.0, 4) if ksel_ms > 0 else None,
+                            "unproven_queries_last_batch": unp_k})
+        if host_full is not None and a.check_queries > 0:   # parity of the k = 50 and k = 100 answers: ids + score bits against the oracle
+            from oracle import pyoracle as po_k
+            om_k = {"cosine": po_k.COSINE, "dot": po_k.DOT}[a.metric]
+            for pt in k_curve:
+                if pt["k"] not in (50, 100):
+                    continue
+                qk = queries[:Q].cpu().numpy()
+                gi_k, gs_k, _ = ix.search_batch_brute_force(qk, pt["k"])
+                pick = np.unique(np.linspace(0, Q - 1, 16).astype(np.int64))
+                ei_k, es_k = po_k.scan_topk(om_k, host_full, qk[pick], pt["k"], po_k.MODE_M if ix.sweep_arith_mode(pt["k"]) == "M" else po_k.MODE_C,
+                                            nthreads=po_k.host_threads())
+                pt["parity_check"] = {"queries": int(pick.size), "ids_equal_oracle": bool(np.array_equal(gi_k[pick], ei_k)),
+                                      "scores_bit_equal_oracle": bool(np.array_equal(gs_k[pick].view(np.uint32), es_k.view(np.uint32)))}
+
     # ---- the HOST-pointer entry points on the headline workload (PCIe-inclusive; never `value`): what the shim's
     # VectorIndex::search / search_batch_parallel bind (velesdb-hip/src/lib.rs) — queries from host memory, results back to host
     # memory — and the reference's calling pattern, many threads x one query per call, through the combining front
@@ -653,6 +724,13 @@ def main():
         b_ref = ix._search_raw(hq_np, K, 0, va.MODE_BRUTE)
         host_entry = {"entry_point": "vdb_hip_index_search_batch (host pointers), exact sweep over the headline corpus", "calls": he,
                       "concurrent_callers": callers_leg(ix, hq_np, K, 0, va.MODE_BRUTE, b_ref)}
+        # T threads, each issuing whole Q-query batches from host memory (search_batch_parallel from several request handlers): every
+        # call leases its own search context and stream, so one call's copies run beside another's kernels
+        if hq_np.shape[0] >= Q:
+            ix.set_option(va.OPT_COMBINE_MAX_BATCH, 0)   # (whole batches: nothing to combine)
+            thr = callers_leg(ix, hq_np, K, 0, va.MODE_BRUTE, b_ref, threads_list=(1, 2, 4), seconds=0.8, nq_per_call=Q)
+            ix.set_option(va.OPT_COMBINE_MAX_BATCH, -1)
+            host_entry["threads"] = thr if isinstance(thr, list) else [thr]
 
     # ---- single-query latency mode (one corpus pass per query) ----
     lat = {}
@@ -935,6 +1013,7 @@ def main():
                 st_samples.append(time.perf_counter() - t3)
             cpu = {"value": shapes["shape_a"]["qps"], "unit": "queries/s", "cores": ncores, "kind": "port",
                    "cpu_model": cpu_model, "host_hardware_threads": os.cpu_count(),
+                   "cores_of_socket": f"{ncores} CPUs (cgroup quota) of a socket with {os.cpu_count()} hardware threads: the whole socket is at best x{max(1, (os.cpu_count() or ncores) // max(ncores, 1))} of `value`",
                    "cores_note": "cores = CPUs this process may use (affinity mask capped by the cgroup cpu.max quota); "
                                  "one pool thread per CPU", "shape_a": shapes["shape_a"], "shape_b": shapes["shape_b"],
                    "single_thread_us": round(float(np.median(st_samples)) * 1e6 * N / sample_rows, 1),
@@ -1194,6 +1273,127 @@ def main():
             finally:
                 shutil.rmtree(gd, ignore_errors=True)
         ix2.close()
+
+    # ---- configs[2] as the REFERENCE would run it (N = 1 only): HnswParams::for_dataset_size / million_scale(768) (params.rs:72-157) =
+    # max_connections 128 (M0 = 256), ef_construction 1600 — the preset the reference picks for a 768-D corpus beyond 10 000 vectors.
+    # Same iid N(0,1) corpus and queries as the headline, same traversal kernel (throughput instance; lists of 256 neighbours), the
+    # construction roofline at ef_construction 1600, small calls (latency mode, test-first form) and the CPU restatement over the
+    # very same graph.  tests/test_gpu_m128.py holds the same path to the oracle (build link for link, traversal ids + bits + counters).
+    hnsw_m128 = None
+    if world == 1 and rank == 0 and not a.no_m128_leg:
+        from oracle import pyoracle as po
+        om = {"cosine": po.COSINE, "euclidean": po.EUCLIDEAN, "dot": po.DOT}[a.metric]
+        pm = va.HnswParams.million_scale(D)
+        MN = a.m128_rows
+        M1, EFC1 = pm.max_connections, pm.ef_construction
+        g.manual_seed(42)
+        rows3 = torch.randn((MN, D), generator=g, device=dev, dtype=torch.float32)  # (the headline corpus again when MN == N)
+        ix4 = va.HnswIndex(D, metric, va.HnswParams(M1, EFC1, MN), device=local)
+        torch.cuda.synchronize()
+        ix4.upload_dev(0, rows3.data_ptr(), MN, stream)
+        torch.cuda.synchronize()
+        del rows3
+        torch.cuda.empty_cache()
+        tb = time.perf_counter()
+        ix4.build_graph(0)
+        torch.cuda.synchronize()
+        build4 = time.perf_counter() - tb
+        b_rows, b_phases, b_nodes, b_sel = ix4.build_stats()
+        bb4 = (b_rows - b_sel) * D * 4
+        HQ4 = min(a.hnsw_batch, n_query_pool)
+        m_ids = torch.empty((HQ4, K), dtype=torch.int64, device=dev)
+        m_sc = torch.empty((HQ4, K), dtype=torch.float32, device=dev)
+        m_n = torch.empty((HQ4,), dtype=torch.int32, device=dev)
+
+        def mstep(nq_=HQ4, off_=0):
+            ix4.search_batch_dev(queries[off_:off_ + nq_].data_ptr(), nq_, K, a.ef, va.MODE_HNSW, m_ids.data_ptr(), m_sc.data_ptr(), m_n.data_ptr(), stream)
+
+        mstep()
+        torch.cuda.synchronize()
+        tm = time.perf_counter()
+        for i_ in range(a.hnsw_steps):
+            events_on_last(i_, a.hnsw_steps)
+            mstep()
+        torch.cuda.synchronize()
+        mdt = time.perf_counter() - tm
+        mk_ms, _ = ix4.last_kernel_ms()
+        va.set_kernel_timing(False)
+        m_nd, m_ne = ix4.last_search_stats()
+        mbytes = m_nd * D * 4 + m_ne * 2 * M1 * 4
+        RQ4 = min(a.recall_queries, HQ4)
+        gt4, _, _ = ix4.search_batch_brute_force(queries[:RQ4].cpu().numpy(), K)
+        mi = m_ids[:RQ4].cpu().numpy()
+        rec4 = float(np.mean([len(set(mi[i].tolist()) & set(gt4[i].tolist())) / K for i in range(RQ4)]))
+        hnsw_m128 = {"workload": f"{MN}x{D} f32 {a.metric} iid N(0,1), HnswParams::million_scale({D}) = M {M1} (M0 {2 * M1}), ef_construction {EFC1} "
+                                 f"(params.rs:124-157), built on the GPU, k={K}, ef={a.ef}, {HQ4} queries/step",
+                     "qps": round(HQ4 * a.hnsw_steps / mdt, 1), "ms_per_step": round(mdt / a.hnsw_steps * 1e3, 3), "recall_at_10": round(rec4, 4),
+                     "recall_queries": RQ4, "build_seconds": round(build4, 2), "build_inserts_per_s": round(MN / build4, 1),
+                     "build": {"roofline": {"bound": "hbm", "achieved": round(bb4 / build4 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": round(bb4 / build4 / 1e9 / HBM_PEAK_GBS, 4),
+                                            "frac_with_select_neighbors_rereads": round(b_rows * D * 4 / build4 / 1e9 / HBM_PEAK_GBS, 4),
+                                            "rows_evaluated_per_insert": round(b_rows / max(b_nodes, 1), 1),
+                                            "select_neighbors_rows_per_insert": round(b_sel / max(b_nodes, 1), 1),
+                                            "distance_phases_per_insert": round(b_phases / max(b_nodes, 1), 1), "seconds": round(build4, 2)}},
+                     "n_dist_per_query": round(m_nd / HQ4, 1), "n_expand_per_query": round(m_ne / HQ4, 1),
+                     "roofline": {"bound": "hbm", "achieved": round(mbytes / (mk_ms * 1e-3) / 1e9, 1) if mk_ms > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(mbytes / (mk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if mk_ms > 0 else 0.0, "traffic": None,
+                                  "kernel_ms": round(mk_ms, 4), "alg_bytes_per_launch": mbytes,
+                                  "alg_bytes_rule": "n_dist*dim*4 + n_expand*M0*4, counters from the kernel"}}
+        # small calls: 1 / 8 / 64 queries per call (device-resident), the latency-mode walk in its test-first form
+        lat4 = []
+        for nq_l in (1, 8, 64):
+            for _ in range(3):
+                mstep(nq_l)
+            torch.cuda.synchronize()
+            smp = []
+            for r_ in range(30):
+                t_l = time.perf_counter()
+                mstep(nq_l, (r_ * nq_l) % (n_query_pool - nq_l + 1))
+                torch.cuda.synchronize()
+                smp.append(time.perf_counter() - t_l)
+            lat4.append({"queries_per_call": nq_l, "median_us_per_call": round(float(np.median(smp)) * 1e6, 1), "qps": round(nq_l / float(np.median(smp)), 1)})
+        hnsw_m128["latency_mode"] = lat4
+        if not a.no_cpu_baseline:
+            gd4 = tempfile.mkdtemp(prefix="vdb_bench_m128_")
+            try:
+                ix4.save(gd4, "native_hnsw")
+                og4 = po.NativeHnsw.file_load(gd4, "native_hnsw", om, po.MODE_R)
+                nc4 = po.host_threads()
+                og4.spread(nc4)
+                cq4 = min(4096, n_query_pool)
+                qh4 = queries[:cq4].cpu().numpy()
+                og4.search_batch(qh4[:nc4], K, a.ef, po.TIE_REFERENCE, nthreads=nc4)  # pool / page warm-up
+                t4_ = time.perf_counter()
+                oi4, _, _, ond4, _ = og4.search_batch(qh4, K, a.ef, po.TIE_REFERENCE, nthreads=nc4)
+                cdt4 = time.perf_counter() - t4_
+                rq4 = min(RQ4, cq4)
+                rec_c4 = float(np.mean([len(set(oi4[i].tolist()) & set(gt4[i].tolist())) / K for i in range(rq4)]))
+                st4 = []
+                for i in range(40):
+                    t5_ = time.perf_counter()
+                    og4.search(qh4[i], K, a.ef, po.TIE_REFERENCE)
+                    st4.append(time.perf_counter() - t5_)
+                del og4
+                # parity: the canonical oracle over the same graph, a few queries of the timed batch (ids + score bits)
+                og4c = po.NativeHnsw.file_load(gd4, "native_hnsw", om, po.MODE_C)
+                pq4 = 8
+                mstep()
+                torch.cuda.synchronize()
+                ci4, cd4, _, _, _ = og4c.search_batch(qh4[:pq4], K, a.ef, po.TIE_CANONICAL, nthreads=pq4)
+                exp4 = np.array([[po.transform_score(om, float(x)) for x in row] for row in cd4], dtype=np.float32)
+                hnsw_m128["parity_check"] = {"queries": pq4,
+                                             "ids_equal_oracle_canonical": bool(np.array_equal(m_ids[:pq4].cpu().numpy().astype(np.uint64), ci4)),
+                                             "scores_bit_equal_oracle_canonical": bool(np.array_equal(m_sc[:pq4].cpu().numpy().view(np.uint32), exp4.view(np.uint32)))}
+                del og4c
+                hnsw_m128["cpu_baseline"] = {"value": round(cq4 / cdt4, 1), "unit": "queries/s", "cores": nc4, "kind": "port", "recall_at_10": round(rec_c4, 4),
+                                             "single_thread_us": round(float(np.median(st4[8:])) * 1e6, 1), "n_dist_per_query": round(ond4 / cq4, 1),
+                                             "sample": f"oracle NativeHnsw::search (mode R, reference tie order) over the same {MN}-node M {M1} graph, {cq4} queries, "
+                                                       f"ef={a.ef}, {nc4} pool threads, {cdt4:.2f} s"}
+                hnsw_m128["gpu_over_cpu"] = round(hnsw_m128["qps"] / (cq4 / cdt4), 2)
+            finally:
+                shutil.rmtree(gd4, ignore_errors=True)
+        ix4.close()
+        torch.cuda.empty_cache()
 
     # ---- BASELINE configs[0] on the GPU (N = 1 only): the reference's criterion workload — 10 000 x 768 `generate_vector`
     # rows, cosine, M 32 / ef_construction 400 — `index.search(query, 10)` one query per call through the HOST entry point
@@ -1633,9 +1833,11 @@ def main():
                        "parallelism": "replicas x%d (query stream split, no collective)" % world},
             "replicas_per_rank": replicas_per_rank,
             "recall_at_10": recall, "parity_check": check,
-            "frac_step": (roofline.get("whole_batch") or {}).get("frac"),  # the headline's algorithmic flop over the WHOLE step's time / peak
-            "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "tiles": tiles, "batch_sizes_default_path": batch_sizes, "host_entry": host_entry, "sharded": sharded,
-            "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb, "config0_10k": config0, "bf16_gemm": bf16_leg, "sq8_storage_mode": sq8_leg, "other_metrics": metrics_leg,
+            # the headline's algorithmic flop over the WHOLE step's time / peak — from ms_per_step (the timed region's wall clock over its
+            # steps, what `value` is computed from), not from the last step's event pair (roofline.whole_batch keeps that one)
+            "frac_step": (round(2.0 * N * D * Q / (dt / a.steps) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4) if split_active else (roofline.get("whole_batch") or {}).get("frac")),
+            "roofline": roofline, "cpu_baseline": cpu, "latency_mode": lat, "tiles": tiles, "batch_sizes_default_path": batch_sizes, "k_curve": k_curve, "host_entry": host_entry, "sharded": sharded,
+            "hnsw": hnsw, "hnsw_embedding_like": hnsw_emb, "hnsw_m128": hnsw_m128, "config0_10k": config0, "bf16_gemm": bf16_leg, "sq8_storage_mode": sq8_leg, "other_metrics": metrics_leg,
             "device": va.device_name(local), "device_state": device_state,
         }
     # a multi-GPU run that is not what --gpus asked for must not pass for one: rank 0 checks the group the library reports

@@ -55,7 +55,7 @@ def _declare(L):
         f.restype, f.argtypes = C.c_float, [C.c_int, _f32p, _f32p, sz]
     L.vo_norm_sq.restype, L.vo_norm_sq.argtypes = C.c_float, [C.c_int, _f32p, sz]
     L.vo_norm.restype, L.vo_norm.argtypes = C.c_float, [_f32p, sz]
-    for name in ("vo_hamming", "vo_jaccard", "vo_dot_simd8", "vo_sql2_simd8", "vo_cosine_simd8"):
+    for name in ("vo_hamming", "vo_jaccard", "vo_dot_simd8", "vo_sql2_simd8", "vo_cosine_simd8", "vo_dot_c_plain", "vo_sql2_c_plain"):
         f = getattr(L, name)
         f.restype, f.argtypes = C.c_float, [_f32p, _f32p, sz]
     L.vo_hamming_binary.restype, L.vo_hamming_binary.argtypes = C.c_uint32, [_u64p, _u64p, sz]
@@ -81,6 +81,7 @@ def _declare(L):
     L.vo_hnsw_insert.restype, L.vo_hnsw_insert.argtypes = C.c_uint64, [vp, _f32p]
     L.vo_hnsw_len.restype, L.vo_hnsw_len.argtypes = C.c_uint64, [vp]
     L.vo_hnsw_set_build_tie.restype, L.vo_hnsw_set_build_tie.argtypes = None, [vp, C.c_int]
+    L.vo_hnsw_set_build_threads.restype, L.vo_hnsw_set_build_threads.argtypes = None, [vp, C.c_uint32]
     L.vo_hnsw_insert_batch_sync.restype, L.vo_hnsw_insert_batch_sync.argtypes = None, [vp, _f32p, C.c_uint64]
     L.vo_build_batch_size.restype, L.vo_build_batch_size.argtypes = C.c_uint32, [C.c_uint64, C.c_uint32]
     L.vo_hnsw_build_batched.restype = None
@@ -230,6 +231,17 @@ def hamming_binary(a, b):
     a = np.ascontiguousarray(a, dtype=np.uint64)
     b = np.ascontiguousarray(b, dtype=np.uint64)
     return int(lib().vo_hamming_binary(a, b, a.size))
+
+
+def dot_c_plain(a, b):
+    """Mode C's dot product by the plain per-element loop (what the vectorised reduction of `dot(..., MODE_C)` must reproduce)."""
+    a, b = _f(a), _f(b)
+    return float(lib().vo_dot_c_plain(a, b, a.size))
+
+
+def sql2_c_plain(a, b):
+    a, b = _f(a), _f(b)
+    return float(lib().vo_sql2_c_plain(a, b, a.size))
 
 
 def dot_simd8(a, b):
@@ -433,6 +445,10 @@ class NativeHnsw:
 
     def set_build_tie(self, tie):
         lib().vo_hnsw_set_build_tie(self._h, tie)
+
+    def set_build_threads(self, nthreads):
+        """Host threads of the batch-synchronous build's search phase; the graph does not depend on it."""
+        lib().vo_hnsw_set_build_threads(self._h, int(nthreads))
 
     def insert_batch_sync(self, vecs):
         vecs = _f(vecs).reshape(-1, self.dim)

@@ -407,31 +407,88 @@ inline float butterfly64(float* t) {
   }
   return t[0];
 }
+// The whole 64-chunk blocks run eight lanes per AVX2 register (a 8 x 4 transposition per operand and block row; the lanes of a
+// register sit in the order kLanePerm leaves them in, undone before the tail and the butterfly): the same fmaf per lane in the
+// same order — vfmadd is the fused operation std::fmaf is — at a fifth of the scalar loop's time.  The butterfly only follows
+// lane 0's value: every lane holds the same bits after each stage (f32 add commutes), so t[0] = ((v0+v4)+(v2+v6)) + ... as written.
 template <int OP>
 float reduceC(const float* a, const float* b, size_t n) {
-  float t[64];
-  for (int l = 0; l < 64; l++) t[l] = 0.0f;
+  alignas(32) float t[64];
   size_t full = n / 4;  // complete chunks
   size_t c = 0;
-  // whole 64-chunk blocks: lane = c % 64 = index within block
-  for (; c + 64 <= full; c += 64) {
-    const float* pa = a + c * 4;
-    const float* pb = b + c * 4;
-    for (int l = 0; l < 64; l++) {
-      float acc = t[l];
-      for (int e = 0; e < 4; e++) {
-        float x = pa[l * 4 + e], y = pb[l * 4 + e];
-        if (OP == OP_SQL2) {
-          float d = x - y;
-          acc = std::fmaf(d, d, acc);
-        } else {
-          acc = std::fmaf(x, y, acc);
+  if (full >= 64) {
+    static const int kLanePerm[8] = {0, 2, 4, 6, 1, 3, 5, 7};  // register position p holds lane 8 g + kLanePerm[p]
+    __m256 acc[8];
+    for (int g = 0; g < 8; g++) acc[g] = _mm256_setzero_ps();
+    // whole 64-chunk blocks: lane = c % 64 = index within block
+    for (; c + 64 <= full; c += 64) {
+      for (int g = 0; g < 8; g++) {
+        const float* pa = a + c * 4 + g * 32;
+        const float* pb = b + c * 4 + g * 32;
+        __m256 x[4], y[4];
+        {
+          const __m256 r0 = _mm256_loadu_ps(pa), r1 = _mm256_loadu_ps(pa + 8), r2 = _mm256_loadu_ps(pa + 16), r3 = _mm256_loadu_ps(pa + 24);
+          const __m256 t0 = _mm256_unpacklo_ps(r0, r1), t1 = _mm256_unpackhi_ps(r0, r1), t2 = _mm256_unpacklo_ps(r2, r3), t3 = _mm256_unpackhi_ps(r2, r3);
+          x[0] = _mm256_castpd_ps(_mm256_unpacklo_pd(_mm256_castps_pd(t0), _mm256_castps_pd(t2)));
+          x[1] = _mm256_castpd_ps(_mm256_unpackhi_pd(_mm256_castps_pd(t0), _mm256_castps_pd(t2)));
+          x[2] = _mm256_castpd_ps(_mm256_unpacklo_pd(_mm256_castps_pd(t1), _mm256_castps_pd(t3)));
+          x[3] = _mm256_castpd_ps(_mm256_unpackhi_pd(_mm256_castps_pd(t1), _mm256_castps_pd(t3)));
         }
+        {
+          const __m256 r0 = _mm256_loadu_ps(pb), r1 = _mm256_loadu_ps(pb + 8), r2 = _mm256_loadu_ps(pb + 16), r3 = _mm256_loadu_ps(pb + 24);
+          const __m256 t0 = _mm256_unpacklo_ps(r0, r1), t1 = _mm256_unpackhi_ps(r0, r1), t2 = _mm256_unpacklo_ps(r2, r3), t3 = _mm256_unpackhi_ps(r2, r3);
+          y[0] = _mm256_castpd_ps(_mm256_unpacklo_pd(_mm256_castps_pd(t0), _mm256_castps_pd(t2)));
+          y[1] = _mm256_castpd_ps(_mm256_unpackhi_pd(_mm256_castps_pd(t0), _mm256_castps_pd(t2)));
+          y[2] = _mm256_castpd_ps(_mm256_unpacklo_pd(_mm256_castps_pd(t1), _mm256_castps_pd(t3)));
+          y[3] = _mm256_castpd_ps(_mm256_unpackhi_pd(_mm256_castps_pd(t1), _mm256_castps_pd(t3)));
+        }
+        __m256 v = acc[g];
+        for (int e = 0; e < 4; e++) {
+          if (OP == OP_SQL2) {
+            const __m256 d = _mm256_sub_ps(x[e], y[e]);
+            v = _mm256_fmadd_ps(d, d, v);
+          } else {
+            v = _mm256_fmadd_ps(x[e], y[e], v);
+          }
+        }
+        acc[g] = v;
       }
-      t[l] = acc;
     }
+    for (int g = 0; g < 8; g++) {
+      alignas(32) float tmp[8];
+      _mm256_store_ps(tmp, acc[g]);
+      for (int p = 0; p < 8; p++) t[8 * g + kLanePerm[p]] = tmp[p];
+    }
+  } else {
+    for (int l = 0; l < 64; l++) t[l] = 0.0f;
   }
   for (size_t i = c * 4; i < n; i++) {
+    int l = (int)((i / 4) % 64);
+    float x = a[i], y = b[i];
+    if (OP == OP_SQL2) {
+      float d = x - y;
+      t[l] = std::fmaf(d, d, t[l]);
+    } else {
+      t[l] = std::fmaf(x, y, t[l]);
+    }
+  }
+  // xor butterfly 32, 16, 8 across registers, 4, 2, 1 inside one
+  __m256 v[8];
+  for (int g = 0; g < 8; g++) v[g] = _mm256_load_ps(t + 8 * g);
+  for (int g = 0; g < 4; g++) v[g] = _mm256_add_ps(v[g], v[g + 4]);
+  for (int g = 0; g < 2; g++) v[g] = _mm256_add_ps(v[g], v[g + 2]);
+  __m256 w = _mm256_add_ps(v[0], v[1]);
+  w = _mm256_add_ps(w, _mm256_permute2f128_ps(w, w, 0x01));
+  w = _mm256_add_ps(w, _mm256_shuffle_ps(w, w, 0x4E));  // l ^ 2
+  w = _mm256_add_ps(w, _mm256_shuffle_ps(w, w, 0xB1));  // l ^ 1
+  return _mm256_cvtss_f32(w);
+}
+// (the plain statement of the same thing — tests/test_oracle_kernels.py holds the two against each other, bit for bit)
+template <int OP>
+float reduceC_plain(const float* a, const float* b, size_t n) {
+  float t[64];
+  for (int l = 0; l < 64; l++) t[l] = 0.0f;
+  for (size_t i = 0; i < n; i++) {
     int l = (int)((i / 4) % 64);
     float x = a[i], y = b[i];
     if (OP == OP_SQL2) {
@@ -819,20 +876,49 @@ struct vo_hnsw {
   double level_mult = 0.0;                                   // graph.rs:63
   float alpha = 1.0f;                                        // graph.rs:77
   int build_tie = VO_TIE_REFERENCE;                          // order among equal distances fed to select_neighbors
-  mutable std::vector<uint32_t> stamp;                       // visited set (membership only)
-  mutable uint32_t epoch = 0;
+  uint32_t build_threads = 1;                                // host threads of hnsw_insert_batch_sync's search phase (results do not depend on it)
+  // Cosine in modes C / M: sqrt(canonical sum of squares) of every stored vector, computed once where the vector is appended
+  // (note_vectors) instead of inside every distance — the value cosineC computes, so the bits of a distance do not change
+  std::vector<float> cnorm;
+  void note_vectors();
+  bool norm_of(const float* p, float* out) const {
+    const float* base = vectors.data();
+    if (p < base || p >= base + vectors.size()) return false;
+    const size_t off = (size_t)(p - base);
+    if (off % dim != 0 || off / dim >= cnorm.size()) return false;
+    *out = cnorm[off / dim];
+    return true;
+  }
 
   const float* vec(uint64_t id) const { return vectors.data() + (size_t)id * dim; }
   float dist(const float* a, const float* b) const {
     tl_n_dist++;
+    if (metric == VO_COSINE && (mode == VO_MODE_C || mode == VO_MODE_M) && !cnorm.empty()) return cosine_distance_cached(a, b);
     return engine_distance(metric, mode, a, b, dim);
   }
+  float cosine_distance_cached(const float* a, const float* b) const;
   const std::vector<uint64_t>& nbrs(size_t layer, uint64_t node) const {  // layer.rs:33-39
     static const std::vector<uint64_t> empty;
     if (layer >= layers.size() || node >= layers[layer].size()) return empty;
     return layers[layer][node];
   }
 };
+
+void vo_hnsw::note_vectors() {
+  if (metric != VO_COSINE || (mode != VO_MODE_C && mode != VO_MODE_M)) return;
+  const size_t nvec = vectors.size() / dim;
+  if (cnorm.size() > nvec) cnorm.clear();
+  for (size_t i = cnorm.size(); i < nvec; i++) cnorm.push_back(std::sqrt(normsqC(vec(i), dim)));
+}
+// k_cosine's modes C / M with the stored vectors' norms looked up (same values, same formula => same bits)
+float vo_hnsw::cosine_distance_cached(const float* a, const float* b) const {
+  float na, nb;
+  if (!norm_of(a, &na)) na = std::sqrt(normsqC(a, dim));
+  if (!norm_of(b, &nb)) nb = std::sqrt(normsqC(b, dim));
+  const float dot = mode == VO_MODE_M ? dotM(a, b, dim) : dotC(a, b, dim);
+  const float cosv = (na == 0.0f || nb == 0.0f) ? 0.0f : dot / (na * nb);
+  return 1.0f - cosv;
+}
 
 namespace {
 
@@ -880,15 +966,19 @@ uint64_t search_layer_single(const vo_hnsw& g, const float* q, uint64_t entry, s
 std::vector<std::pair<uint64_t, float>> search_layer(const vo_hnsw& g, const float* q,
                                                      const std::vector<uint64_t>& eps, size_t ef,
                                                      size_t layer, int tie) {
+  // visited set (membership only): stamps of the calling thread — an epoch per call, so one array serves every graph the thread
+  // searches, and the batch-synchronous build may run its searches on several threads
+  thread_local std::vector<uint32_t> stamp;
+  thread_local uint32_t epoch = 0;
   size_t nvec = g.vectors.size() / g.dim;
-  if (g.stamp.size() < nvec) g.stamp.resize(nvec, 0);
-  if (++g.epoch == 0) {
-    std::fill(g.stamp.begin(), g.stamp.end(), 0);
-    g.epoch = 1;
+  if (stamp.size() < nvec) stamp.resize(nvec, 0);
+  if (++epoch == 0) {
+    std::fill(stamp.begin(), stamp.end(), 0);
+    epoch = 1;
   }
   auto visit = [&](uint64_t n) -> bool {  // FxHashSet::insert -> true if newly inserted
-    if (g.stamp[n] == g.epoch) return false;
-    g.stamp[n] = g.epoch;
+    if (stamp[n] == epoch) return false;
+    stamp[n] = epoch;
     return true;
   };
   RustHeap<true> candidates;   // BinaryHeap<Reverse<(OrderedFloat, NodeId)>>
@@ -990,6 +1080,7 @@ void add_bidirectional_connection(vo_hnsw& g, uint64_t new_node, uint64_t neighb
 uint64_t hnsw_insert(vo_hnsw& g, const float* v) {
   uint64_t node_id = g.vectors.size() / g.dim;  // :160-165 id = insertion order
   g.vectors.insert(g.vectors.end(), v, v + g.dim);
+  g.note_vectors();
   size_t node_layer = random_layer(g.rng_state, g.level_mult);  // :168
   while (g.layers.size() <= node_layer) g.layers.emplace_back();  // :171-179
   for (auto& L : g.layers)
@@ -1033,6 +1124,7 @@ void hnsw_insert_batch_sync(vo_hnsw& g, const float* vecs, size_t n) {
   if (n == 0) return;
   const uint64_t first = g.vectors.size() / g.dim;
   g.vectors.insert(g.vectors.end(), vecs, vecs + n * g.dim);
+  g.note_vectors();
   std::vector<size_t> level(n);
   size_t top = 0;
   for (size_t b = 0; b < n; b++) {
@@ -1049,7 +1141,9 @@ void hnsw_insert_batch_sync(vo_hnsw& g, const float* vecs, size_t n) {
   std::vector<std::vector<std::vector<Sel>>> sel(n);  // [b][layer] -> selected (id, dist to the new node)
   const int64_t ep0 = g.entry_point;
   const size_t max0 = g.max_layer;
-  for (size_t b = 0; b < n && ep0 >= 0; b++) {
+  // every node of the batch against the graph as it was before the batch: read-only on g, sel[b] is the node's own => the
+  // nodes may be searched on several host threads (build_threads; the result is the same for any number)
+  auto search_one = [&](size_t b) {
     const uint64_t node_id = first + b;
     const float* qv = g.vec(node_id);
     const size_t node_layer = level[b];
@@ -1068,10 +1162,57 @@ void hnsw_insert_batch_sync(vo_hnsw& g, const float* vecs, size_t n) {
       }
       if (!neighbors.empty()) cur = neighbors[0].first;
     }
+  };
+  if (ep0 >= 0) {
+    const uint32_t nt = (uint32_t)std::min<size_t>(std::max<uint32_t>(g.build_threads, 1), n);
+    if (nt <= 1) {
+      for (size_t b = 0; b < n; b++) search_one(b);
+    } else {
+      std::atomic<size_t> next{0};
+      Pool::get().run(nt, [&](uint32_t) {
+        for (size_t b; (b = next.fetch_add(1)) < n;) search_one(b);
+      });
+    }
+  }
+  // Back-links.  A target is a node of the graph before the batch (nothing of the batch was visible to the searches), and its list
+  // only depends on the sources that select it, in ascending source order: with several build threads the (layer, target) groups
+  // are applied side by side, each in that order — the lists the sequential loop below leaves.
+  const uint32_t apply_threads = (uint32_t)std::min<size_t>(std::max<uint32_t>(g.build_threads, 1), n);
+  const bool grouped = ep0 >= 0 && apply_threads > 1;
+  if (grouped) {
+    struct Op {
+      uint64_t key;  // layer << 40 | target
+      uint64_t src;
+    };
+    std::vector<Op> ops;
+    for (size_t b = 0; b < n; b++)
+      for (size_t li = level[b] + 1; li-- > 0;) {
+        std::vector<uint64_t> ids;
+        for (auto& s : sel[b][li]) {
+          ids.push_back(s.node);
+          ops.push_back({((uint64_t)li << 40) | s.node, first + b});
+        }
+        g.layers[li][first + b] = ids;  // set_neighbors :213 (the new node's own list: nobody else's target)
+      }
+    std::stable_sort(ops.begin(), ops.end(), [](const Op& x, const Op& y) { return x.key < y.key; });  // sources stay ascending inside a group
+    std::vector<size_t> starts;
+    for (size_t i = 0; i < ops.size(); i++)
+      if (i == 0 || ops[i].key != ops[i - 1].key) starts.push_back(i);
+    starts.push_back(ops.size());
+    std::atomic<size_t> next{0};
+    Pool::get().run(apply_threads, [&](uint32_t) {
+      for (size_t gi; (gi = next.fetch_add(1)) + 1 < starts.size();) {
+        const size_t li = (size_t)(ops[starts[gi]].key >> 40);
+        const uint64_t target = ops[starts[gi]].key & ((1ull << 40) - 1);
+        const size_t max_conn = li == 0 ? g.M0 : g.M;
+        for (size_t i = starts[gi]; i < starts[gi + 1]; i++) add_bidirectional_connection(g, ops[i].src, target, li, max_conn);
+      }
+    });
   }
   for (size_t b = 0; b < n; b++) {
     const uint64_t node_id = first + b;
-    if (ep0 >= 0) {
+    if (grouped) {
+    } else if (ep0 >= 0) {
       for (size_t li = level[b] + 1; li-- > 0;) {
         size_t max_conn = li == 0 ? g.M0 : g.M;
         std::vector<uint64_t> ids;
@@ -1230,6 +1371,9 @@ extern "C" {
 
 float vo_dot(int mode, const float* a, const float* b, size_t n) { return k_dot(mode, a, b, n); }
 float vo_sql2(int mode, const float* a, const float* b, size_t n) { return k_sql2(mode, a, b, n); }
+/* mode C's sums by the plain per-element loop (the AVX2 form of reduceC is held against it) */
+float vo_dot_c_plain(const float* a, const float* b, size_t n) { return reduceC_plain<OP_DOT>(a, b, n); }
+float vo_sql2_c_plain(const float* a, const float* b, size_t n) { return reduceC_plain<OP_SQL2>(a, b, n); }
 float vo_euclidean(int mode, const float* a, const float* b, size_t n) { return std::sqrt(k_sql2(mode, a, b, n)); }
 float vo_cosine(int mode, const float* a, const float* b, size_t n) { return k_cosine(mode, a, b, n); }
 float vo_norm_sq(int mode, const float* a, size_t n) { return k_dot(mode, a, a, n); }
@@ -1301,6 +1445,7 @@ vo_hnsw* vo_hnsw_new(uint32_t dim, int metric, int mode, uint32_t M, uint32_t ef
 void vo_hnsw_free(vo_hnsw* g) { delete g; }
 void vo_hnsw_set_alpha(vo_hnsw* g, float alpha) { g->alpha = alpha; }
 void vo_hnsw_set_build_tie(vo_hnsw* g, int tie) { g->build_tie = tie; }
+void vo_hnsw_set_build_threads(vo_hnsw* g, uint32_t nthreads) { g->build_threads = nthreads < 1 ? 1 : nthreads; }
 void vo_hnsw_insert_batch_sync(vo_hnsw* g, const float* vecs, uint64_t n) { hnsw_insert_batch_sync(*g, vecs, n); }
 uint32_t vo_build_batch_size(uint64_t linked, uint32_t max_batch) { return build_batch_size(linked, max_batch); }
 /* whole build with the batched schedule: rows [0,n) appended to the graph */
@@ -1488,6 +1633,7 @@ vo_hnsw* vo_hnsw_file_load(const char* dir, const char* basename, int metric, in
   g->count = count;
   g->level_mult = 1.0 / std::log((double)M);
   g->alpha = 1.0f;
+  g->note_vectors();
   return g.release();
 }
 

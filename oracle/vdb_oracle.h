@@ -59,6 +59,9 @@ enum {
 /* ---- distance kernels (reference: simd.rs facade, simd_avx512.rs, simd_explicit.rs) ---- */
 float vo_dot(int mode, const float* a, const float* b, size_t n);
 float vo_sql2(int mode, const float* a, const float* b, size_t n);
+/* mode C's sums by the plain per-element loop: what the vectorised reduction must reproduce bit for bit */
+float vo_dot_c_plain(const float* a, const float* b, size_t n);
+float vo_sql2_c_plain(const float* a, const float* b, size_t n);
 float vo_euclidean(int mode, const float* a, const float* b, size_t n);
 float vo_cosine(int mode, const float* a, const float* b, size_t n);
 float vo_norm_sq(int mode, const float* a, size_t n); /* canonical/wide sum of squares */
@@ -103,6 +106,9 @@ uint64_t vo_hnsw_insert(vo_hnsw*, const float* vec); /* returns node id */
  * VO_TIE_REFERENCE (default, heap artefact) or VO_TIE_CANONICAL ((distance, node id) ascending, what
  * the GPU construction kernels use). Identical whenever no two candidates are at the same distance. */
 void vo_hnsw_set_build_tie(vo_hnsw*, int tie);
+/* host threads of the batch-synchronous build's search phase (every node of a batch is searched against the graph as it was before the
+ * batch: independent, read-only); the graph that results does not depend on it */
+void vo_hnsw_set_build_threads(vo_hnsw*, uint32_t nthreads);
 /* batch-synchronous insertion (deterministic stand-in for parallel_insert, backend_adapter.rs:110-123):
  * all n searches see the graph as it was before the call, links applied sources ascending. n==1 == insert */
 void vo_hnsw_insert_batch_sync(vo_hnsw*, const float* vecs, uint64_t n);

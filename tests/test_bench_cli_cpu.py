@@ -81,14 +81,20 @@ def _maximal_record(blow=1):
         "replicas_per_rank": [{"rank": r, "qps": 1.0} for r in range(8)], "recall_at_10": 1.0,
         "parity_check": {"queries": 64, "ids_equal_oracle_canonical": True, "scores_bit_equal_oracle_canonical": True, "kernel": prose},
         "frac_step": 0.38, "roofline": roof, "cpu_baseline": cpu, "latency_mode": {"note": prose},
-        "tiles": [{"tile": t, "note": prose} for t in range(12)], "batch_sizes_default_path": [{"n": prose}] * 8, "host_entry": {"note": prose},
+        "tiles": [{"tile": t, "note": prose} for t in range(12)], "batch_sizes_default_path": [{"n": prose}] * 8,
+        "host_entry": {"note": prose, "calls": [{"queries_per_call": n, "qps": 1000.0 * n, "note": prose} for n in (1024, 256, 64, 16, 1)],
+                       "threads": [{"threads": t, "queries_per_call": 1024, "qps": 2.0 * t, "note": prose} for t in (2, 4)]},
+        "k_curve": [{"k": k, "qps": 100.0 * k, "note": prose} for k in (10, 11, 50, 100)],
         "sharded": {"qps": 1.0, "group_ok": True, "ranks": 8, "rows_per_shard": 6250000, "transport": "rccl", "results_identical_across_ranks": True,
                     "per_rank": [{"rank": r, "note": prose} for r in range(8)], "collective": prose},
         "hnsw": {"qps": 167342.2, "recall_at_10": 0.99, "roofline": dict(roof, bound="hbm"), "parity_check": {"ok": True, "n": prose},
                  "cpu_baseline": cpu, "build_inserts_per_s": 44566.8, "build": {"roofline": {"frac": 0.2, "note": prose}},
                  "int8": {"qps": 1.0, "hbm_frac": 0.6, "note": prose}, "ef_curve": [{"ef": e, "note": prose} for e in (64, 128, 256, 512)],
                  "latency_mode": [{"queries_per_call": 1, "median_us_per_call": 1051.8}], "concurrent_callers": {"points": pts}},
-        "hnsw_embedding_like": {"note": prose, "ef_curve": [{"note": prose}] * 4},
+        "hnsw_embedding_like": {"note": prose, "ef_curve": [{"note": prose}] * 4, "qps": 232000.0, "recall_at_10": 0.985, "roofline": dict(roof, bound="hbm")},
+        "hnsw_m128": {"workload": prose, "qps": 51460.5, "recall_at_10": 0.1775, "roofline": dict(roof, bound="hbm"), "build_inserts_per_s": 4666.6,
+                      "build": {"roofline": {"frac": 0.43, "note": prose}}, "cpu_baseline": dict(cpu, recall_at_10=0.1775),
+                      "latency_mode": [{"queries_per_call": 1, "median_us_per_call": 2655.0}], "parity_check": {"ok": True, "n": prose}},
         "config0_10k": {"search_median_us": 304.1, "reference_published": {"search_us": 56.8}, "concurrent_callers": {"points": pts}, "note": prose},
         "bf16_gemm": {"qps": 1.0, "roofline": roof, "parity_check": {"ok": True, "rule": prose}, "cpu_baseline": cpu},
         "sq8_storage_mode": {"batch": {"qps": 1.0, "kernel": prose}, "eight_queries": {"hbm_frac": 0.12}, "parity_check": {"ids_equal_oracle": True}},
@@ -126,7 +132,12 @@ def test_the_printed_line_is_bounded_and_carries_the_contract():
         assert back["parity_check"] is True and back["legs_file"] == "bench_legs_8gpu.json"
     # at a real run's sizes nothing is dropped: every leg's one-number summary is on the line
     back = b.compact_line(_maximal_record(1))
-    assert set(back["legs"]) == {"hnsw", "bf16_gemm", "sharded", "config0_10k", "sq8", "other_metrics"}
+    assert set(back["legs"]) == {"hnsw", "hnsw_embedding_like", "hnsw_m128", "bf16_gemm", "sharded", "config0_10k", "sq8", "other_metrics"}
+    # round 6: what a VectorIndex caller gets (host pointers), the k the reference also benches, the graph legs that say something
+    assert back["host_entry_qps"] == {"1024": 1024000.0, "256": 256000.0, "64": 64000.0, "2x1024": 4.0, "4x1024": 8.0}
+    assert back["k50_qps"] == 5000.0 and back["k_curve_qps"] == {"10": 1000.0, "11": 1100.0, "50": 5000.0, "100": 10000.0}
+    assert back["legs"]["hnsw_embedding_like"] == {"qps": 232000.0, "recall": 0.985, "frac": 0.4316, "cpu_qps": None}
+    assert back["legs"]["hnsw_m128"]["build_frac"] == 0.43 and back["legs"]["hnsw_m128"]["one_query_us"] == 2655.0 and back["legs"]["hnsw_m128"]["parity"] is True
     assert back["legs"]["hnsw"]["frac"] == 0.4316 and back["legs"]["hnsw"]["build_frac"] == 0.2 and back["legs"]["sharded"]["group_ok"] is True
     assert back["legs"]["other_metrics"]["hamming"]["parity"] is True
     # a failed parity flag anywhere in a check object reads as False on the line; no check object reads as None

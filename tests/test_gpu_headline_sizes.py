@@ -60,12 +60,17 @@ def test_headline_1m_gemm_vs_oracle(corpus, index):
     assert index.sweep_arith_mode(K) == "M"
     nq = 320
     ids, sc, cnt = index.search_batch_brute_force(qs[:nq], K)
+    # WHICH kernel answered: the selection stage at level 2 (bf16 matrix cores + exact re-scoring + proof) — a silent fall-back to the
+    # exact f32 kernel would produce the same bits and pass everything below
+    assert index.last_select_level() == 2 and index.last_kernels() & va.KERNEL_SELECT_BF16, "the selection stage did not serve the 320-query call"
     eid, esc = po.scan_topk(po.COSINE, rows, qs[:nq], K, po.MODE_M, nthreads=ncores)
     assert np.all(cnt == K)
     assert np.array_equal(ids, eid), "ids / ranks differ from the oracle (mode M) at 1M x 320 queries"
     assert np.array_equal(bits(sc), bits(esc)), "score bits differ from the oracle (mode M)"
     # the bench's launch: 1 024 queries in one call; queries 320.. are new, every query tile is sampled
     ids2, sc2, cnt2 = index.search_batch_brute_force(qs, K)
+    assert index.last_select_level() == 2 and index.last_kernels() & va.KERNEL_SELECT_BF16, "the selection stage did not serve the 1 024-query call"
+    assert index.last_split_stats()[1] <= 2, "more unproven queries than the benchmark data ever produced (one in ~8 000): the bound has drifted"
     assert np.array_equal(ids2[:nq], ids) and np.array_equal(bits(sc2[:nq]), bits(sc)), "results depend on the batch size"
     sample = np.arange(nq + 3, 1024, 7)[:96]
     eid2, esc2 = po.scan_topk(po.COSINE, rows, qs[sample], K, po.MODE_M, nthreads=ncores)
@@ -78,6 +83,24 @@ def test_headline_1m_gemm_vs_oracle(corpus, index):
             diff = np.nonzero(ids[i] != rid[i])[0]
             gaps = np.abs(rsc[i][diff] - sc[i][diff]) / np.abs(rsc[i][diff])
             assert np.all(gaps < 1e-5), f"query {i}: ids differ from mode R outside a tie group"
+
+
+@pytest.mark.parametrize("k", [50, 100])
+def test_headline_1m_k50_k100_vs_oracle(corpus, index, k):
+    """configs[1]'s corpus at the k the reference also benches (benches/hnsw_benchmark.rs:152-159: 10 / 50 / 100): 1 024 queries in one
+    call through the WIDE selection (csrc/sweep_wide.hip), 40 of them — spread over every query tile — compared with the oracle."""
+    rows, qs = corpus
+    ids, sc, cnt = index.search_batch_brute_force(qs, k)
+    assert index.last_select_level() == 4 and index.last_kernels() & va.KERNEL_SELECT_BF16, "the WIDE selection did not serve the call"
+    assert index.last_split_stats()[1] <= 4, "unproven queries on the benchmark data: the bound or the list capacity has drifted"
+    assert np.all(cnt == k)
+    sample = np.arange(5, 1024, 26)[:40]
+    eid, esc = po.scan_topk(po.COSINE, rows, qs[sample], k, po.MODE_M, nthreads=po.host_threads())
+    assert np.array_equal(ids[sample], eid), f"ids / ranks differ from the oracle (mode M) at 1M x 1024 queries, k = {k}"
+    assert np.array_equal(bits(sc[sample]), bits(esc)), f"score bits differ from the oracle (mode M) at k = {k}"
+    # the first 10 of a k = 50 answer are the k = 10 answer (another kernel instance, another pool: the same exact scores)
+    ids10, sc10, _ = index.search_batch_brute_force(qs[:256], K)
+    assert np.array_equal(ids10, ids[:256, :K]) and np.array_equal(bits(sc10), bits(sc[:256, :K]))
 
 
 def test_hnsw_1m_vs_oracle(corpus, index, tmp_path, record_property):

@@ -291,3 +291,43 @@ def test_search_multi_entry_follows_the_reference_stream(tmp_path, metric, n, di
     r_k = ix._search_raw(Q[:1], 7, 7, va.MODE_HNSW)
     assert np.array_equal(r_small[0], r_k[0]) and r_small[2][0] == 7
     ix.close()
+
+
+# ---------------------------------------------------------------- the declared tie rule against the reference's own order, on the GPU
+@pytest.mark.parametrize("metric", [DM.Hamming, DM.Jaccard])
+def test_gpu_canonical_order_vs_reference_tie_order_on_integer_distances(tmp_path, metric):
+    """SURVEY 8(a) note 8 / 8(c) rule 3: among EQUAL distances the reference's order is an artefact of its heaps' backing arrays;
+    the ABI declares (distance, node id) ascending.  Integer distances (Hamming; Jaccard's few distinct ratios) tie in most result
+    lists, so here the rule is held on the GPU itself against the oracle run in the REFERENCE's tie order (Rust BinaryHeap restated,
+    VO_TIE_REFERENCE) over the same graph: the distance list is identical, ids are identical wherever a distance is unique in the
+    list, inside a group of equal distances the GPU's ids ascend, and a group that does not touch the cut holds the same id set.
+    (tests/test_oracle_graph.py::test_hamming_canonical_vs_reference_tie_order states the same rule CPU-side.)"""
+    rng = np.random.default_rng(31 + int(metric))
+    rows = (rng.random((900, 64)) > 0.6).astype(np.float32)
+    g, ix = build_pair(tmp_path, rows, metric, 8, 60, mode=po.MODE_R)
+    qs = (rng.random((48, 64)) > 0.6).astype(np.float32)
+    k, ef = 10, 48
+    res = ix.search_batch_parallel(qs, k, SQ.Custom(ef))
+    tied_lists = 0
+    for qi, q in enumerate(qs):
+        ids_r, d_r = g.search(q, k, ef, po.TIE_REFERENCE)
+        gid = np.array([r[0] for r in res[qi]], dtype=np.uint64)
+        gsc = np.array([r[1] for r in res[qi]], dtype=np.float32)
+        exp = np.array([po.transform_score(PO_METRIC[metric], float(x)) for x in d_r], dtype=np.float32)
+        assert np.array_equal(bits(gsc), bits(exp)), f"query {qi}: the distance list differs from the reference-order run"
+        n = len(gid)
+        i = 0
+        while i < n:
+            j = i + 1
+            while j < n and d_r[j] == d_r[i]:
+                j += 1
+            if j - i == 1:
+                assert j == n or gid[i] == ids_r[i], f"query {qi}: ids differ outside a tie group at rank {i}"
+            else:
+                tied_lists += 1
+                assert np.all(np.diff(gid[i:j].astype(np.int64)) > 0), f"query {qi}: ids inside a tie group do not ascend (canonical order)"
+                if j < n:  # (a group cut by k may hold other members of the same distance on either side)
+                    assert set(gid[i:j].tolist()) == set(ids_r[i:j].tolist()), f"query {qi}: a tie group inside the list holds different ids"
+            i = j
+    assert tied_lists > len(qs), "the data did not tie (fewer than one tie group per list): the test would be vacuous"
+    ix.close()

@@ -105,7 +105,8 @@ def test_occupancy_budgets_of_the_hot_kernels(kernels):
 @needs_objdump
 def test_selection_kernel_k_loop_is_spill_free(kernels):
     pp = fam(kernels, "sweep_topk_gemm_bf16_pp")
-    assert len(pp) == 4 and len({k["obj"] for k in pp}) == 1   # cosine / dot (bf16), Hamming / Jaccard (four-bit)
+    # cosine / dot (bf16), Hamming / Jaccard (four-bit), and the WIDE instances of cosine / dot (k > 10: sweep_wide.hip) — same k-loop text
+    assert len(pp) == 6 and len({k["obj"] for k in pp}) == 1
     funcs = dis(pp[0]["obj"])
     for k in pp + fam(kernels, "sweep_topk_gemm_bf16_glds"):
         blocks = funcs[k["symbol"]]

@@ -14,6 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import velesdb_amd as va  # noqa: E402
+if __import__("os").environ.get("VELESDB_HIP_LIB"):  # a kernel-variant build: the package reads no environment, probe scripts bind it themselves
+    from velesdb_amd import _ffi as _vffi  # noqa: E402
+    _vffi.use_library(__import__("os").environ["VELESDB_HIP_LIB"])
 from oracle import pyoracle as po  # noqa: E402
 
 p = argparse.ArgumentParser()

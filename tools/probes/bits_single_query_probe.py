@@ -10,6 +10,9 @@ if os.environ.get("VDB_PROBE_LIB"):  # the probe build: environment switches (VE
     _ffi.use_library(_ffi.PROBE_LIB_PATH)
 import torch  # noqa: E402
 import velesdb_amd as va  # noqa: E402
+if __import__("os").environ.get("VELESDB_HIP_LIB"):  # a kernel-variant build: the package reads no environment, probe scripts bind it themselves
+    from velesdb_amd import _ffi as _vffi  # noqa: E402
+    _vffi.use_library(__import__("os").environ["VELESDB_HIP_LIB"])
 
 metric = {"hamming": va.DistanceMetric.Hamming, "jaccard": va.DistanceMetric.Jaccard}[sys.argv[1] if len(sys.argv) > 1 else "hamming"]
 N, D, K = 1_000_000, 768, 10

@@ -2,6 +2,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import velesdb_amd as va
+if __import__("os").environ.get("VELESDB_HIP_LIB"):  # a kernel-variant build: the package reads no environment, probe scripts bind it themselves
+    from velesdb_amd import _ffi as _vffi  # noqa: E402
+    _vffi.use_library(__import__("os").environ["VELESDB_HIP_LIB"])
 from oracle import pyoracle as po
 n, dim = 70_000, 128
 rng = np.random.default_rng(n * 13 + dim)

@@ -4,6 +4,9 @@ import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import velesdb_amd as va
+if __import__("os").environ.get("VELESDB_HIP_LIB"):  # a kernel-variant build: the package reads no environment, probe scripts bind it themselves
+    from velesdb_amd import _ffi as _vffi  # noqa: E402
+    _vffi.use_library(__import__("os").environ["VELESDB_HIP_LIB"])
 p = argparse.ArgumentParser()
 p.add_argument("--rows", type=int, default=1_000_000)
 p.add_argument("--dim", type=int, default=768)

@@ -17,6 +17,9 @@ lib_path = os.path.abspath(sys.argv[1])
 _ffi.use_library(lib_path)
 import torch  # noqa: E402,F401  (first: the HIP runtime it loads is the one the library binds to)
 import velesdb_amd as va  # noqa: E402
+if __import__("os").environ.get("VELESDB_HIP_LIB"):  # a kernel-variant build: the package reads no environment, probe scripts bind it themselves
+    from velesdb_amd import _ffi as _vffi  # noqa: E402
+    _vffi.use_library(__import__("os").environ["VELESDB_HIP_LIB"])
 
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 METRIC = sys.argv[3] if len(sys.argv) > 3 else "cosine"

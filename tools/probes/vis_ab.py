@@ -24,6 +24,9 @@ a = p.parse_args()
 
 import torch  # noqa: E402
 import velesdb_amd as va  # noqa: E402
+if __import__("os").environ.get("VELESDB_HIP_LIB"):  # a kernel-variant build: the package reads no environment, probe scripts bind it themselves
+    from velesdb_amd import _ffi as _vffi  # noqa: E402
+    _vffi.use_library(__import__("os").environ["VELESDB_HIP_LIB"])
 
 dev = torch.device("cuda", 0)
 st = torch.cuda.current_stream().cuda_stream

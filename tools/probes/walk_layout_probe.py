@@ -6,6 +6,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import velesdb_amd as va
+if __import__("os").environ.get("VELESDB_HIP_LIB"):  # a kernel-variant build: the package reads no environment, probe scripts bind it themselves
+    from velesdb_amd import _ffi as _vffi  # noqa: E402
+    _vffi.use_library(__import__("os").environ["VELESDB_HIP_LIB"])
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 D, NQ = 768, 8192
 dev = torch.device("cuda", 0)

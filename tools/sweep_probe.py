@@ -9,6 +9,9 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import velesdb_amd as va  # noqa: E402
+if __import__("os").environ.get("VELESDB_HIP_LIB"):  # a kernel-variant build: the package reads no environment, probe scripts bind it themselves
+    from velesdb_amd import _ffi as _vffi  # noqa: E402
+    _vffi.use_library(__import__("os").environ["VELESDB_HIP_LIB"])
 
 p = argparse.ArgumentParser()
 p.add_argument("--rows", type=int, default=1_000_000)

@@ -53,8 +53,8 @@ enum Phase : int {
 // LDS: keys[cap] u64 | nb_id[nbmax] u32 | nb_d[nbmax] f32 | ctl[4] u32 | flags[cap] u8 (padded to 16)
 //      | query scratch: generic f32 dims: d4*4 floats; bit metrics: `words` u32
 // ------------------------------------------------------------------------------------------
-// LAT (latency mode: calls of at most one query per CU, f32 metrics, layer-0 lists of <= 64 neighbours): a 1 024-thread block per
-// query and a speculative layer-0 step.  A walk is a chain of dependent memory round trips — neighbour ids, visited
+// LAT (latency mode: calls of at most one query per CU, f32 metrics; the speculative step below: layer-0 lists of <= 64 neighbours,
+// longer lists take the test-first form — launch_hnsw_search): a 1 024-thread block per query and a speculative layer-0 step.  A walk is a chain of dependent memory round trips — neighbour ids, visited
 // test-and-set, rows — and a single query cannot hide them behind other queries: here all (<= 64) neighbours' rows are fetched
 // at once by 16 waves (4 rows each) WITHOUT waiting for the visited test, which the leader wave issues alongside; the
 // verdicts select, in list order, which of the evaluated distances are admitted.  Same ids, scores and counters (n_dist counts
@@ -654,9 +654,15 @@ hipError_t launch_hnsw_search(const HnswSearchArgs& a0, int slots, hipStream_t s
   const bool beyond_cache = (uint64_t)a.n_rows * a.row_stride * 4 >= (256ull << 20);
   a.pf_ids = g_hnsw_pf >= 0 ? (g_hnsw_pf ? 1u : 0u) : (beyond_cache ? 1u : 0u);
   const uint32_t lat_vis = pick_vis(a0, lds, true);
-  if (g_hnsw_lat && a.nq <= (g_hnsw_lat_max ? g_hnsw_lat_max : a.n_cus) && (g_hnsw_lat >= 2 || beyond_cache || lat_vis) && a.list_slots == kSearchRegSlots && a.rerank_k == 0 && a.layers[0].stride <= 64 &&
-      a.nbmax >= 64 && (a.metric == kCosine || a.metric == kEuclidean || a.metric == kDot)) {
-    a.lat_spec = g_hnsw_lat == 2 ? 1u : (g_hnsw_lat == 3 ? 0u : (beyond_cache ? 1u : 0u));
+  // Layer-0 lists of more than 64 neighbours (HnswParams::for_dataset_size, params.rs:72-147: M 128 => M0 256 from 10 001 vectors of
+  // more than 256 dimensions up): the speculative step holds one neighbour per lane of the leader wave, so such graphs take the
+  // latency-mode kernel in its test-first form — the LDS set answers in a few cycles, the 16 waves then fetch only the unvisited
+  // neighbours' rows (at M0 256 most of a list is already visited: fetching every row would be 768 KB per expansion) — and only
+  // when that set fits (otherwise the throughput kernel: same walk, four waves).
+  const bool wide_lists = a.layers[0].stride > 64;
+  if (g_hnsw_lat && a.nq <= (g_hnsw_lat_max ? g_hnsw_lat_max : a.n_cus) && (g_hnsw_lat >= 2 || beyond_cache || lat_vis) && a.list_slots == kSearchRegSlots && a.rerank_k == 0 &&
+      (!wide_lists || lat_vis) && a.nbmax >= 64 && (a.metric == kCosine || a.metric == kEuclidean || a.metric == kDot)) {
+    a.lat_spec = wide_lists ? 0u : (g_hnsw_lat == 2 ? 1u : (g_hnsw_lat == 3 ? 0u : (beyond_cache ? 1u : 0u)));
     a.vis_log2 = pick_vis(a0, lds, true);
     a.vis_off = (uint32_t)lds;
     if (a.vis_log2) lds += (size_t)4 << a.vis_log2;

@@ -126,7 +126,7 @@ static int32_t check_device(int32_t* n_out) {
 
 int32_t enter_index(vdb_hip_index* ix, bool exclusive, bool changes) {
   VDB_HIP(hipSetDevice(ix->device));
-  ix->own_dirty = true;  // (the caller is about to enqueue on ix->stream)
+  ix->own_dirty.store(true);  // (the caller is about to enqueue on ix->stream)
   if (ix->foreign_pending) {
     VDB_HIP(hipStreamWaitEvent(ix->stream, ix->ev_foreign, 0));
     ix->foreign_pending = false;
@@ -163,6 +163,9 @@ void copy_image_fields(vdb_hip_index* c, const vdb_hip_index* p) {
   c->l2_rho = p->l2_rho;
   c->l2_seed = p->l2_seed;
   c->l2_rows = p->l2_rows;
+  c->cosn_img = p->cosn_img;
+  c->cosn_rho = p->cosn_rho;
+  c->cosn_rows = p->cosn_rows;
   c->sq8_img = p->sq8_img;
   c->sq8_nrm = p->sq8_nrm;
   c->sq8_rho = p->sq8_rho;
@@ -340,6 +343,8 @@ int32_t ensure_capacity(vdb_hip_index* ix, uint64_t want) {
   // the lazily built selection images grow HERE (exclusive lock), never inside a search (shared lock: other contexts hold views)
   if (ix->l2_img.cap && (e = ix->l2_img.reserve((ncap + kRowSlack) * (size_t)(ix->dim + 64) * 2, true, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, std::string("grow Euclidean selection image: ") + hipGetErrorString(e));
+  if (ix->cosn_img.cap && (e = ix->cosn_img.reserve((ncap + kRowSlack) * (size_t)ix->dim * 2, true, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("grow normalised selection image: ") + hipGetErrorString(e));
   // (storage mode Binary keeps its four-bit sign image in sq8_img, bits_image_stride(dim) bytes per row — storage_modes.hip
   // ensure_sign_image; the SQ8 mode its dequantised bf16 image, dim [+ 64] two-byte elements per row)
   const size_t sq8_img_row = ix->storage_mode == VDB_STORAGE_BINARY ? (size_t)bits_image_stride(ix->dim)
@@ -623,6 +628,14 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     }
     // large Cosine / DotProduct batches over a large corpus: split-bf16 selection + exact re-scoring + proof (same bits
     // as the exact matrix-core kernel below, which remains the fallback for unproven queries and every other shape)
+    // ... and with 10 < k <= 128: the WIDE selection (sweep_wide.hip) — no block-local lists, every row above the bound is a candidate
+    if (mfma_nqt && select_level_wide(ix, nq - q0, k)) {
+      const uint32_t nqg = select_chunk(nq - q0);
+      const int32_t rcw = brute_wide_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nqg, k, d_ids + (size_t)q0 * k, d_scores + (size_t)q0 * k, d_n + q0, st);
+      if (rcw != VDB_OK) return rcw;
+      q0 += nqg;
+      continue;
+    }
     const int sel_level = mfma_nqt ? select_level(ix, nq - q0, k) : 0;
     if (sel_level) {
       const uint32_t nqg = select_chunk(nq - q0);
@@ -993,6 +1006,7 @@ std::vector<DevBuf*> index_buffers(vdb_hip_index* ix) {
       &ix->rows, &ix->norms, &ix->bits, &ix->alive, &ix->ext_ids,           // rows
       &ix->rows_bf16, &ix->norms_bf16, &ix->bf16_rho, &ix->rows_split,      // bf16 copy, split-bf16 image
       &ix->l2_img, &ix->l2_seed, &ix->l2_rho,                               // Euclidean selection images
+      &ix->cosn_img, &ix->cosn_rho,                                         // Cosine selection image (normalised rows)
       &ix->sq_min, &ix->sq_scale, &ix->codes, &ix->codes_sq,                // int8 traversal
       &ix->sq8_codes, &ix->sq8_min, &ix->sq8_max, &ix->sq8_nsq, &ix->sign_bits,  // storage modes
       &ix->sq8_img, &ix->sq8_nrm, &ix->sq8_seed, &ix->sq8_rho,              // SQ8 selection images
@@ -1662,6 +1676,7 @@ int32_t vdb_hip_index_vacuum(vdb_hip_index* ix, uint64_t* count) {
   ix->bf16_rows = 0;
   ix->split_rows = 0;
   ix->l2_rows = 0;
+  ix->cosn_rows = 0;
   ix->bits_img_rows = 0;
   const uint64_t cap = ix->capacity;
   ix->capacity = 0;  // re-reserve the per-row arrays (rows keep their buffer; the new layer arrays are allocated)
@@ -1725,10 +1740,11 @@ int32_t vdb_hip_index_search_batch_dev(vdb_hip_index* ix, const float* d_queries
   if (st != ix->stream) {
     // the kernels below share this index's scratch, rows and graph with everything enqueued before: order the caller's
     // stream behind the work pending on ix->stream and behind an earlier device-resident search on ANOTHER stream
-    if (ix->own_dirty || ix->last_foreign != st) {  // (a stream that has not waited since: it is ordered behind ev_foreign below at best)
+    // (cleared BEFORE the event is recorded: a mark set by an entry point that enqueues beside this call is then kept for the next one)
+    const bool dirty = ix->own_dirty.exchange(false);
+    if (dirty || ix->last_foreign != st) {  // (a stream that has not waited since: it is ordered behind ev_foreign below at best)
       VDB_HIP(hipEventRecord(ix->ev_own, ix->stream));
       VDB_HIP(hipStreamWaitEvent(st, ix->ev_own, 0));
-      ix->own_dirty = false;
     }
     if (ix->foreign_pending && ix->last_foreign != st) VDB_HIP(hipStreamWaitEvent(st, ix->ev_foreign, 0));
   } else {

@@ -154,8 +154,8 @@ struct HandleFront {
 };
 
 // HnswIndex::search_batch_parallel (batch.rs:159-197) / search_with_quality / search_brute_force
-static int32_t search_batch_host(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode,
-                                 uint32_t rerank_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
+int32_t search_batch_host(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode,
+                          uint32_t rerank_k, uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
   if (!ix || (nq && (!queries || !out_n)) || (nq && k && (!out_ids || !out_scores)))
     return fail(VDB_ERR_INVALID_ARG, "null argument");
   if (nq == 0) return VDB_OK;
@@ -207,7 +207,9 @@ int32_t vdb_hip_index_search_rerank(vdb_hip_index* ix, const float* queries, uin
 int32_t vdb_hip_index_quantizer_trained(const vdb_hip_index* ix, int32_t* trained) {
   return vdb::guarded([&]() -> int32_t {
     if (!ix || !trained) return fail(VDB_ERR_INVALID_ARG, "null argument");
-    *trained = ix->quantizer_trained ? 1 : 0;  // (a plain bool, written under the exclusive lock by train_quantizer only)
+    // (written under the exclusive lock by train_quantizer — on a replica group by group_for_all once every replica is trained)
+    std::shared_lock<IndexMutex> rd(const_cast<vdb_hip_index*>(ix)->mu);
+    *trained = ix->quantizer_trained ? 1 : 0;
     return VDB_OK;
   });
 }
@@ -220,9 +222,15 @@ int32_t vdb_hip_index_search_with_config(vdb_hip_index* ix, const float* queries
                                          uint64_t* out_ids, float* out_scores, uint32_t* out_n) {
   return vdb::guarded([&]() -> int32_t {
     if (!ix) return fail(VDB_ERR_INVALID_ARG, "null argument");
-    if (oversampling_ratio == 0) return fail(VDB_ERR_INVALID_ARG, "oversampling_ratio must be > 0 (DualPrecisionConfig's default is 4)");
-    // (n_rows: NativeHnsw::len() counts inserted vectors; a racing insert moves it by one — the reference reads it under no lock either)
-    const bool int8 = ix->quantizer_trained && use_int8_traversal && ix->n_rows >= min_index_size;
+    // the same bound vdb_hip_set_int8_oversampling holds the handle's option to: k * ratio sizes nbmax, ef and the LDS list of the walk
+    if (oversampling_ratio == 0 || oversampling_ratio > 64)
+      return fail(VDB_ERR_INVALID_ARG, "oversampling_ratio must be in 1..64 (DualPrecisionConfig's default is 4)");
+    // (n_rows: NativeHnsw::len() counts inserted vectors; the state is read under the shared lock, the search takes its own)
+    bool int8;
+    {
+      std::shared_lock<IndexMutex> rd(ix->mu);
+      int8 = ix->quantizer_trained && use_int8_traversal && ix->n_rows >= min_index_size;
+    }
     return search_batch_host(ix, queries, nq, k, ef_search, int8 ? VDB_SEARCH_HNSW_INT8 : VDB_SEARCH_HNSW, int8 ? oversampling_ratio : 0, out_ids,
                              out_scores, out_n);
   });
@@ -276,9 +284,15 @@ int32_t vdb_hip_index_search_multi_entry(vdb_hip_index* ix, const float* queries
     }
     int32_t rc = stage_queries(ix, queries, 0, nq, nq);
     if (rc != VDB_OK) return rc;
-    ix->raw_ef = true;  // (exclusive lock held: nobody else reads the flag)
-    rc = search_staged(ix, nq, k, ef, VDB_SEARCH_HNSW, 0, d_extra);
-    ix->raw_ef = false;
+    struct RawEf {  // (exclusive lock held: nobody else reads the flag; reset on every way out, an exception caught by guarded() included)
+      vdb_hip_index* h;
+      explicit RawEf(vdb_hip_index* x) : h(x) { h->raw_ef = true; }
+      ~RawEf() { h->raw_ef = false; }
+    };
+    {
+      RawEf raw(ix);
+      rc = search_staged(ix, nq, k, ef, VDB_SEARCH_HNSW, 0, d_extra);
+    }
     if (rc != VDB_OK) return rc;
     deliver_slice(ix, 0, nq, nq, k, out_ids, out_scores, out_n);
     return VDB_OK;

@@ -13,6 +13,7 @@
 
 #include "vdb_probe_env.hpp"
 #include "vdb_select_stage.hpp"
+#include "vdb_wide.hpp"
 
 namespace vdb {
 
@@ -395,6 +396,37 @@ static int32_t ensure_l2_select_impl(vdb_hip_index* ix, hipStream_t st) {
   }
   return VDB_OK;
 }
+// Cosine batches at level 2 (and the WIDE selection): the bf16 image of the NORMALISED rows (sweep_split.hip seln_rows_kernel), built at
+// first use, extended lazily, grown by ensure_capacity.  VELESDB_COSINE_NORMALISED=0 (probe builds): the round-5 path over the plain
+// bf16 copy + per-row norms in the kernel (A / B runs)
+static const bool g_cosn = [] {
+  const char* e = probe_env("VELESDB_COSINE_NORMALISED");
+  return !(e && e[0] == '0');
+}();
+static int32_t ensure_cosn_impl(vdb_hip_index* ix, hipStream_t st) {
+  const uint64_t cap = std::max<uint64_t>(ix->capacity, 1) + kRowSlack;
+  hipError_t e;
+  if ((e = ix->cosn_img.reserve(cap * (size_t)ix->dim * 2, true, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, std::string("normalised selection image: ") + hipGetErrorString(e));
+  if (!ix->cosn_rho.p) {  // (the image is built from row 0 behind this: every row contributes)
+    if ((e = ix->cosn_rho.reserve(256, false, st)) != hipSuccess || (e = hipMemsetAsync(ix->cosn_rho.p, 0, 256, st)) != hipSuccess)
+      return fail(VDB_ERR_OOM, std::string("normalised residual bound: ") + hipGetErrorString(e));
+    ix->cosn_rows = 0;
+  }
+  if (ix->cosn_rows < ix->n_rows) {
+    launch_seln_rows(ix->rows.as<float>(), ix->row_stride, ix->norms.as<float>(), ix->cosn_img.as<uint16_t>(), ix->dim, (uint32_t)ix->cosn_rows,
+                     (uint32_t)(ix->n_rows - ix->cosn_rows), ix->dim, ix->cosn_rho.as<uint32_t>(), st);
+    ix->cosn_rows = ix->n_rows;
+    VDB_HIP(hipGetLastError());
+  }
+  return VDB_OK;
+}
+static int32_t ensure_cosn(vdb_hip_index* ix, hipStream_t st) {
+  const int32_t rc = build_image_on_primary(ix, st, [](const vdb_hip_index* p) { return p->cosn_img.cap == 0 || p->cosn_rows < p->n_rows; }, ensure_cosn_impl);
+  return rc != VDB_OK ? rc : pinned_select_stats(ix);
+}
+static inline bool cosine_normalised(const vdb_hip_index* ix) { return g_cosn && ix->metric == VDB_COSINE && ix->dim % 64 == 0; }
+
 int select_level_l2(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (!opt_selector(ix) || opt_engine(ix) != 1 || opt_max_tile(ix) < 128) return 0;
   if (ix->metric != VDB_EUCLIDEAN) return 0;
@@ -434,8 +466,11 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
                         float* d_scores, uint32_t* d_n, hipStream_t st, int level) {
   const bool sq8 = level >= 3;
   const bool l2 = ix->metric == VDB_EUCLIDEAN;  // (level 2) the augmented DotProduct form of |q - v|^2, sweep_split.hip
-  const int sel_metric = l2 ? VDB_DOT : ix->metric;
-  int32_t rc = sq8 ? ensure_sq8_select(ix, st) : (l2 ? ensure_l2_select(ix, st) : (level >= 2 ? ensure_sel16(ix, st) : ensure_split(ix, st)));
+  // (level 2, Cosine) both sides normalised before the rounding: the selection is a DotProduct of unit vectors (sweep_split.hip seln_rows_kernel)
+  const bool cosn = level == 2 && !sq8 && !l2 && cosine_normalised(ix);
+  const int sel_metric = (l2 || cosn) ? VDB_DOT : ix->metric;
+  int32_t rc = sq8 ? ensure_sq8_select(ix, st)
+                   : (l2 ? ensure_l2_select(ix, st) : (cosn ? ensure_cosn(ix, st) : (level >= 2 ? ensure_sel16(ix, st) : ensure_split(ix, st))));
   if (rc != VDB_OK) return rc;
   ix->last_select_level = level;
   ix->last_kernels |= (level < 2 ? VDB_KERNEL_SELECT_SPLIT : VDB_KERNEL_SELECT_BF16) | VDB_KERNEL_GEMM_F32;  // (exact seed sweep)
@@ -504,7 +539,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   float* delta = reinterpret_cast<float*>(sd + o_delta);
   float* qnorms = reinterpret_cast<float*>(sd + o_qn);
   // level 2 over the f32 rows: the error bound from MEASURED rounding residuals (sweep_split.hip select_eps_q)
-  const DevBuf& rho_buf = sq8 ? ix->sq8_rho : (l2 ? ix->l2_rho : ix->bf16_rho);
+  const DevBuf& rho_buf = sq8 ? ix->sq8_rho : (l2 ? ix->l2_rho : (cosn ? ix->cosn_rho : ix->bf16_rho));
   float* rho_q = (level >= 2 && rho_buf.p) ? reinterpret_cast<float*>(sd + o_rho) : nullptr;
   const uint32_t* rho_max = rho_q ? rho_buf.as<uint32_t>() : nullptr;
   uint32_t* flags = reinterpret_cast<uint32_t*>(sd + o_flags);
@@ -519,9 +554,10 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   EventPair* ev = next_events(ix);
   if (ev) (void)hipEventRecord(ev->a, st);
   // queries: split image / bf16 image (+ canonical norms), zero rows behind the batch (the kernel stages whole 256-query tiles)
-  const uint64_t img_stride = l2 ? (uint64_t)dim_a : (sq8 ? (uint64_t)dim : (level >= 2 ? ix->bf16_stride : (uint64_t)dim * 2));  // elements per image row
+  const uint64_t img_stride = l2 ? (uint64_t)dim_a : ((sq8 || cosn) ? (uint64_t)dim : (level >= 2 ? ix->bf16_stride : (uint64_t)dim * 2));  // elements per image row
   const uint16_t* img_rows = sq8 ? ix->sq8_img.as<uint16_t>()
-                                 : (l2 ? ix->l2_img.as<uint16_t>() : (level >= 2 ? ix->rows_bf16.as<uint16_t>() : ix->rows_split.as<uint16_t>()));
+                                 : (l2 ? ix->l2_img.as<uint16_t>()
+                                       : (cosn ? ix->cosn_img.as<uint16_t>() : (level >= 2 ? ix->rows_bf16.as<uint16_t>() : ix->rows_split.as<uint16_t>())));
   const float* sel_norms = sq8 ? ix->sq8_nrm.as<float>() : ix->norms.as<float>();
   float* qaug = reinterpret_cast<float*>(ix->s_misc.as<unsigned char>() + ((size_t)nqg + 256) * (dim + 64) * 4);  // Euclidean: (q, 1, 0, 0, 0) f32
   bool flags_cleared = false;
@@ -536,6 +572,10 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     pq.dim = dim;
     pq.words = ix->words;
     launch_prep_rows(pq, st);
+  } else if (cosn) {
+    // one launch: image rows of q / |q|, canonical norms, residual ratios of the normalised queries, the cleared flag words
+    launch_seln_prep_queries(d_q, q_stride, q16, img_stride, qnorms, rho_q, flags, nqg + 64 + 4, nqg, dim, st);
+    flags_cleared = true;
   } else if (level >= 2) {
     // one launch: image rows, canonical norms, rounding residual ratios, the cleared flag words
     launch_sel16_prep_queries(d_q, q_stride, q16, img_stride, qnorms, rho_q, flags, nqg + 64 + 4, nqg, dim, st);
@@ -550,7 +590,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   if (!flags_cleared) VDB_HIP(hipMemsetAsync(flags, 0, (size_t)nqg * 4 + 64 * 4 + 16, st));
   // (s_fb_keys needs no fill: the whole-tile fallback writes every slot of every query of the tiles it runs for, and its merge
   // only looks at the unproven queries — MergeArgs::gate)
-  if (sel_metric == VDB_DOT) launch_max_norm(sel_norms, n, norm_max, st);
+  if (sel_metric == VDB_DOT && !cosn) launch_max_norm(sel_norms, n, norm_max, st);  // (unit vectors: the Cosine bound needs no norm)
   // exact seed sweep over the first rows
   SweepArgs ag{};
   ag.rows = sq8 ? ix->sq8_seed.as<float>() : (l2 ? ix->l2_seed.as<float>() : ix->rows.as<float>());  // SQ8: the dequantised prefix (f32)
@@ -792,6 +832,181 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     fin.fb_n = mf.out_n;
     launch_select_finish(fin, st);
   }
+  ix->split_flags_off = o_flags;
+  ix->split_flags_n = nqg;
+  ix->split_flags_stream = st;
+  if (ev) (void)hipEventRecord(ev->b, st);
+  VDB_HIP(hipGetLastError());
+  return VDB_OK;
+}
+
+
+// ---- exact Cosine / DotProduct batches with 10 < k <= kWideMaxK: the WIDE selection (sweep_wide.hip) -------------------------------
+// the same eligibility as level 2 (the bf16 image of the rows, whole 64-element k-tiles), its own park-after-failure state
+int select_level_wide(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
+  if (opt_selector(ix) < 2 || opt_engine(ix) != 1 || opt_max_tile(ix) < 128) return 0;
+  if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT) return 0;
+  if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
+  if (k <= kGemmBf16MaxK || k > kWideMaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
+  if (sweep_mfma_lds_bytes(1, k, ix->dim) > 160 * 1024) return 0;  // (the gathered exact pass of the unproven queries)
+  if (!select_chunk(nq_left)) return 0;
+  if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
+    ix->sel_seq_seen = ix->sel_stats[2];
+    if (ix->sel_stats[3] == 4u && (uint64_t)ix->sel_stats[0] * 16 > ix->sel_stats[1]) ix->wide_hold = 64;  // > 1/16 unproven
+  }
+  if (ix->wide_hold) {
+    ix->wide_hold--;
+    return 0;
+  }
+  return 4;
+}
+
+int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, uint64_t* d_ids, float* d_scores,
+                       uint32_t* d_n, hipStream_t st) {
+  const bool cosn = cosine_normalised(ix);  // Cosine: both sides normalised before the rounding, the DotProduct instance selects
+  const int sel_metric = cosn ? VDB_DOT : ix->metric;
+  int32_t rc = cosn ? ensure_cosn(ix, st) : ensure_sel16(ix, st);
+  if (rc != VDB_OK) return rc;
+  const uint16_t* img_rows = cosn ? ix->cosn_img.as<uint16_t>() : ix->rows_bf16.as<uint16_t>();
+  const uint64_t img_stride = cosn ? (uint64_t)ix->dim : ix->bf16_stride;
+  const DevBuf& rho_buf = cosn ? ix->cosn_rho : ix->bf16_rho;
+  ix->last_select_level = 4;
+  ix->last_kernels |= VDB_KERNEL_SELECT_BF16;
+  const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
+  const uint32_t n = (uint32_t)ix->n_rows, dim = ix->dim;
+  const uint32_t R0 = std::min<uint32_t>(kWideSeedRows, n), ngrp = (R0 + 15) / 16;
+  GemmSchedule sch;
+  {
+    const uint32_t head[3] = {1u, 4u, 16u};  // tiles per row group of the first launches, as the k <= 10 stage (brute_split_dev)
+    gemm_schedule(nqg, 0, n, ix->n_cus, head, 0, &sch);
+  }
+  // the gathered exact pass of the unproven queries: the streaming matrix-core kernel, as many 16-query tiles per pass as k leaves room for
+  int g_nqt = 3;
+  while (g_nqt > 1 && sweep_mfma_lds_bytes(g_nqt, k, dim) > 160 * 1024) g_nqt--;
+  const int g_waves = g_nqt >= 2 ? kMfmaWaves2 : kMfmaWaves1;
+  const uint32_t g_B = (uint32_t)g_nqt * 16;
+  const uint32_t ntiles16 = (n + 15) / 16;
+  const int g_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ntiles16 + g_waves - 1) / g_waves, (int64_t)ix->n_cus));
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = (off + bytes + 15) & ~(size_t)15;
+    return o;
+  };
+  const size_t o_tau = take((size_t)nqg * 8), o_delta = take((size_t)nqg * 4), o_qn = take((size_t)nqg * 4), o_rho = take((size_t)nqg * 4),
+               o_cnt = take((size_t)nqg * 4), o_state = take((size_t)nqg * 4), o_flags = take((size_t)nqg * 4 + 16), o_qmap = take((size_t)nqg * 8),
+               o_gid = take((size_t)nqg * k * 8), o_gsc = take((size_t)nqg * k * 4), o_gn = take((size_t)nqg * 4), o_nmax = take(16);
+  hipError_t e;
+  if ((e = ix->s_seed.reserve(off, false, st)) != hipSuccess || (e = ix->s_fb_keys.reserve((size_t)nqg * kWideCap * 8, false, st)) != hipSuccess ||
+      (e = ix->s_part_keys.reserve((size_t)nqg * ngrp * 8, false, st)) != hipSuccess ||
+      (e = ix->s_part_cnt.reserve((size_t)nqg * g_blocks * k * 8, false, st)) != hipSuccess ||
+      (e = ix->s_misc.reserve(((size_t)nqg + 256) * img_stride * 2, false, st)) != hipSuccess)
+    return fail(VDB_ERR_OOM, "wide selection scratch");
+  unsigned char* sd = ix->s_seed.as<unsigned char>();
+  uint16_t* q16 = ix->s_misc.as<uint16_t>();
+  float* qnorms = reinterpret_cast<float*>(sd + o_qn);
+  float* rho_q = rho_buf.p ? reinterpret_cast<float*>(sd + o_rho) : nullptr;
+  uint32_t* flags = reinterpret_cast<uint32_t*>(sd + o_flags);
+  uint32_t* qcount = flags + nqg;  // (cleared with the flags)
+  uint32_t* qmap = reinterpret_cast<uint32_t*>(sd + o_qmap);
+  uint32_t* qslot = qmap + nqg;
+  uint32_t* norm_max = reinterpret_cast<uint32_t*>(sd + o_nmax);
+  EventPair* ev = next_events(ix);
+  if (ev) (void)hipEventRecord(ev->a, st);
+  // queries: bf16 image rows, canonical norms, rounding residuals, cleared flag words — one launch; whole 256-query tiles are staged
+  if (cosn) launch_seln_prep_queries(d_q, q_stride, q16, img_stride, qnorms, rho_q, flags, nqg + 4, nqg, dim, st);
+  else launch_sel16_prep_queries(d_q, q_stride, q16, img_stride, qnorms, rho_q, flags, nqg + 4, nqg, dim, st);
+  if (nqg % 256u) VDB_HIP(hipMemsetAsync(q16 + (size_t)nqg * img_stride, 0, (size_t)256 * img_stride * 2, st));
+  if (ix->metric == VDB_DOT) launch_max_norm(ix->norms.as<float>(), n, norm_max, st);
+  WideArgs wa{};
+  wa.keys = ix->s_fb_keys.as<uint64_t>();
+  wa.cnt = reinterpret_cast<uint32_t*>(sd + o_cnt);
+  wa.state = reinterpret_cast<uint32_t*>(sd + o_state);
+  wa.tau = reinterpret_cast<uint64_t*>(sd + o_tau);
+  wa.delta = reinterpret_cast<float*>(sd + o_delta);
+  wa.qnorms = qnorms;
+  wa.rho_q = rho_q;
+  wa.rho_max_bits = rho_q ? rho_buf.as<uint32_t>() : nullptr;
+  wa.norm_max_bits = norm_max;
+  wa.cap = kWideCap;
+  wa.k = k;
+  wa.dim = dim;
+  // seed: a sample of the first rows on the bf16 pipe (one key per 16 rows), its k-th best -> the first bound
+  launch_seed_scores_bf16(sel_metric, img_rows, img_stride, ix->norms.as<float>(), alive, q16, img_stride, qnorms, ix->s_part_keys.as<uint64_t>(), R0,
+                          nqg, dim, st);
+  launch_wide_seed(ix->metric, wa, ix->s_part_keys.as<uint64_t>(), ngrp, nqg, st);
+  for (int j = 0; j < sch.n_launch; j++) {
+    EventPair* evs = next_sel_events(ix);
+    if (evs) (void)hipEventRecord(evs->a, st);
+    e = launch_sweep_gemm_bf16_wide(sel_metric, sch.bp[j], img_rows, img_stride, ix->norms.as<float>(), alive, q16, img_stride, wa.tau, wa.keys, wa.cnt,
+                                    wa.cap, dim, nqg, st, qnorms);
+    if (evs) (void)hipEventRecord(evs->b, st);
+    if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("wide selection launch: ") + hipGetErrorString(e));
+    launch_wide_reseed(wa, nqg, st);  // (behind the last launch: the final bound and the pool)
+  }
+  WideOutArgs wo{};
+  wo.rows = ix->rows.as<float>();
+  wo.norms = ix->norms.as<float>();
+  wo.queries = d_q;
+  wo.ext_ids = ix->ext_ids.as<uint64_t>();
+  wo.out_ids = d_ids;
+  wo.out_scores = d_scores;
+  wo.out_n = d_n;
+  wo.flags = flags;
+  wo.qcount = qcount;
+  wo.qmap = qmap;
+  wo.qslot = qslot;
+  wo.row_stride = ix->row_stride;
+  wo.q_stride = q_stride;
+  wo.dim_pad = (dim + 127) / 128 * 128;
+  launch_wide_rerank(ix->metric, wa, wo, nqg, st);
+  // unproven queries (an overflowed list, a pool beyond one block, non-finite data): listed on the device, answered by the exact
+  // streaming kernel in gathered mode — one corpus pass per g_B listed queries, none when nothing is listed
+  SweepArgs am{};
+  am.rows = ix->rows.as<float>();
+  am.norms = ix->norms.as<float>();
+  am.alive = alive;
+  am.queries = d_q;
+  am.part_keys = ix->s_part_cnt.as<uint64_t>();
+  am.row_stride = ix->row_stride;
+  am.q_stride = q_stride;
+  am.n_rows = n;
+  am.dim = dim;
+  am.nq = g_B;
+  am.k = k;
+  am.qmap = qmap;
+  am.qcount = qcount;
+  am.qcount_max = nqg;
+  e = launch_sweep_mfma(ix->metric, g_nqt, am, g_blocks, st, (int)((nqg + g_B - 1) / g_B));
+  if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("gathered fallback launch: ") + hipGetErrorString(e));
+  MergeArgs mg{};
+  mg.part_keys = am.part_keys;
+  mg.ext_ids = ix->ext_ids.as<uint64_t>();
+  mg.out_ids = reinterpret_cast<uint64_t*>(sd + o_gid);
+  mg.out_scores = reinterpret_cast<float*>(sd + o_gsc);
+  mg.out_n = reinterpret_cast<uint32_t*>(sd + o_gn);
+  mg.n_lists = (uint32_t)g_blocks;
+  mg.k = k;
+  mg.active = qcount;
+  launch_merge(true, mg, nqg, st);
+  SelectFinishArgs fin{};
+  fin.flags = flags;
+  fin.qcount = qcount;
+  fin.qslot = qslot;
+  fin.g_ids = mg.out_ids;
+  fin.g_scores = mg.out_scores;
+  fin.g_n = mg.out_n;
+  fin.out_ids = d_ids;
+  fin.out_scores = d_scores;
+  fin.out_n = d_n;
+  fin.nq = nqg;
+  fin.k = k;
+  if (ix->sel_stats) {
+    fin.stats_host = ix->sel_stats;
+    fin.stats_seq = ++ix->sel_seq;
+    fin.stats_level = 4u;
+  }
+  launch_select_finish(fin, st);
   ix->split_flags_off = o_flags;
   ix->split_flags_n = nqg;
   ix->split_flags_stream = st;

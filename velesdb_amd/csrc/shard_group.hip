@@ -28,6 +28,7 @@
 #include "vdb_device.hpp"
 #include "vdb_index.hpp"
 #include "vdb_kernels.hpp"
+#include "vdb_shard_wire.hpp"
 
 namespace vdb {
 
@@ -112,10 +113,7 @@ static int32_t rccl_fail(const char* what, ncclResult_t e) {
   } while (0)
 
 // ---- records and the merge kernel ---------------------------------------------------------------
-// record = 3 x u32 (id low, id high, score bits).  Slots past a shard's result count carry the sentinel (id ~0, score
-// bits 0xFFFFFFFF); a query whose traversal list overflowed in a device-resident call (d_n = 0xFFFFFFFF) is marked by
-// score bits 0xFFFFFFFE in its first record and comes out of the merge with d_n = 0xFFFFFFFF again.
-constexpr uint32_t kRecEmpty = 0xFFFFFFFFu, kRecOverflow = 0xFFFFFFFEu;
+// (the record layout, the sentinels, the selection key and the rank rule: vdb_shard_wire.hpp — shared with the host model of the CPU tests)
 
 __global__ __launch_bounds__(256) void pack_shard_records(const uint64_t* ids, const float* scores, const uint32_t* n,
                                                           uint32_t* rec, uint32_t nq, uint32_t k) {
@@ -123,25 +121,14 @@ __global__ __launch_bounds__(256) void pack_shard_records(const uint64_t* ids, c
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
     const uint32_t q = (uint32_t)(i / k), p = (uint32_t)(i % k);
     const uint32_t c = n[q];
-    uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu, sb = kRecEmpty;
-    if (c == 0xFFFFFFFFu) {
-      if (p == 0) sb = kRecOverflow;
-    } else if (p < c) {
-      const uint64_t id = ids[i];
-      lo = (uint32_t)id;
-      hi = (uint32_t)(id >> 32);
-      sb = __float_as_uint(scores[i]);
-    }
-    rec[i * 3 + 0] = lo;
-    rec[i * 3 + 1] = hi;
-    rec[i * 3 + 2] = sb;
+    const bool live = c != 0xFFFFFFFFu && p < c;  // (slots past the count are never read: the arrays hold k entries per query either way)
+    wire::pack(live ? ids[i] : 0ull, live ? __float_as_uint(scores[i]) : 0u, c, p, rec + i * 3);
   }
 }
 
 // One block per query.  rec = [S][nq][k] records, every shard's list best first (ascending selection key).  The rank of
 // record (s, p) in the merged order is p + sum over the other shards t of the number of their records that precede it:
-// a binary search per (record, shard) — strictly smaller keys for t > s, smaller-or-equal for t < s (equal scores keep
-// the global row order: shard, then position).  DistanceMetric::sort_results order (core/distance.rs:95-103).
+// a binary search per (record, shard) — wire::merged_rank.  DistanceMetric::sort_results order (core/distance.rs:95-103).
 template <bool HIB>
 __global__ __launch_bounds__(256) void merge_shards_topk(const uint32_t* rec, uint64_t* out_ids, float* out_scores,
                                                          uint32_t* out_n, uint32_t S, uint32_t nq, uint32_t k) {
@@ -156,13 +143,9 @@ __global__ __launch_bounds__(256) void merge_shards_topk(const uint32_t* rec, ui
   for (uint32_t i = tid; i < T; i += 256) {
     const uint32_t s = i / k, p = i - s * k;
     const uint32_t* r = rec + (((size_t)s * nq + q) * k + p) * 3;
-    const uint32_t lo = r[0], hi = r[1], sb = r[2];
-    const bool empty = lo == 0xFFFFFFFFu && hi == 0xFFFFFFFFu && (sb == kRecEmpty || sb == kRecOverflow);
-    if (empty && sb == kRecOverflow) *ovf = 1;
-    uint32_t key = asc_key(__uint_as_float(sb));
-    if (HIB) key = ~key;
-    keys[i] = empty ? 0xFFFFFFFFu : key;
-    if (!empty) atomicAdd(&ns[s], 1u);
+    if (wire::is_overflow(r)) *ovf = 1;
+    keys[i] = wire::select_key(r, HIB);
+    if (!wire::is_empty(r)) atomicAdd(&ns[s], 1u);
   }
   __syncthreads();
   uint32_t total = 0;
@@ -170,23 +153,10 @@ __global__ __launch_bounds__(256) void merge_shards_topk(const uint32_t* rec, ui
   for (uint32_t i = tid; i < T; i += 256) {
     const uint32_t s = i / k, p = i - s * k;
     if (p >= ns[s]) continue;
-    const uint32_t key = keys[i];
-    uint32_t rank = p;
-    for (uint32_t t = 0; t < S && rank < k; t++) {
-      if (t == s) continue;
-      const uint32_t* base = keys + (size_t)t * k;
-      uint32_t lo = 0, hi = ns[t];
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint32_t v = base[mid];
-        const bool before = t > s ? v < key : v <= key;
-        if (before) lo = mid + 1; else hi = mid;
-      }
-      rank += lo;
-    }
+    const uint32_t rank = wire::merged_rank(keys, ns, S, k, s, p);
     if (rank < k) {
       const uint32_t* r = rec + (((size_t)s * nq + q) * k + p) * 3;
-      out_ids[(size_t)q * k + rank] = ((uint64_t)r[1] << 32) | r[0];
+      out_ids[(size_t)q * k + rank] = wire::id_of(r);
       out_scores[(size_t)q * k + rank] = __uint_as_float(r[2]);
     }
   }
@@ -446,7 +416,7 @@ int32_t group_for_all(vdb_hip_index* ix, int op, uint32_t arg) {
   if (g->broken) return fail(VDB_ERR_STATE, kBrokenMsg);
   if (op == 3 && g->mode == VDB_SHARD_RANGE)
     return fail(VDB_ERR_UNSUPPORTED, "the int8 quantiser is trained on the first rows of ONE index: replicas only");
-  return for_each_shard(g, [&](size_t s) -> int32_t {
+  const int32_t rc = for_each_shard(g, [&](size_t s) -> int32_t {
     vdb_hip_index* c = g->shards[s];
     switch (op) {
       case 0: return vdb_hip_index_build_graph(c, arg);
@@ -455,6 +425,10 @@ int32_t group_for_all(vdb_hip_index* ix, int op, uint32_t arg) {
       default: return vdb_hip_index_train_quantizer(c, arg);
     }
   });
+  // the handle the caller holds answers is_quantizer_trained / search_with_config (search_front.hip): every replica is trained
+  // (exclusive lock held; a failure leaves the flag as it was — the replicas that did train simply keep their codes)
+  if (rc == VDB_OK && op == 3) ix->quantizer_trained = true;
+  return rc;
 }
 
 int32_t group_set_option(vdb_hip_index* ix, int32_t option, int64_t value) {
@@ -557,11 +531,10 @@ int32_t group_search_host(vdb_hip_index* ix, const float* queries, uint32_t nq, 
       query_slice(nq, s, S, &lo, &hi);
       if (hi == lo) return VDB_OK;
       const float* q = queries + (size_t)lo * ix->dim;
-      if (rerank_k)
-        return vdb_hip_index_search_rerank(g->shards[s], q, hi - lo, k, rerank_k, ef, out_ids + (size_t)lo * k,
-                                           out_scores + (size_t)lo * k, out_n + lo);
-      return vdb_hip_index_search_batch(g->shards[s], q, hi - lo, k, ef, mode, out_ids + (size_t)lo * k,
-                                        out_scores + (size_t)lo * k, out_n + lo);
+      // (mode AND rerank_k travel as they are: with VDB_SEARCH_HNSW_INT8 rerank_k is the call's oversampling ratio —
+      // search_with_config — not a rerank depth of the AUTO mode)
+      return search_batch_host(g->shards[s], q, hi - lo, k, ef, mode, rerank_k, out_ids + (size_t)lo * k, out_scores + (size_t)lo * k,
+                               out_n + lo);
     });
   }
   const int32_t m = resolve_mode(ix, mode);

@@ -78,6 +78,12 @@ struct Bf16GemmArgs {
   // result mode (VDB_SEARCH_BRUTE_BF16): [nq] norms of the ROUNDED queries (query_norms_bf16), or nullptr: computed by every block
   const float* qnorms_half;
   unsigned long long* dbg;  // (-DVDB_PP_STAMP variant builds only; nullptr otherwise)
+  // WIDE instance (k beyond the candidate buffers: sweep_wide.hip): no list is kept in the block — every row that passes the query's
+  // launch-constant bound tau0 is appended to the query's global list [nq][wide_cap] (a counter per query; entries past the capacity
+  // are dropped and show as a count above it)
+  uint64_t* wide_keys;
+  uint32_t* wide_cnt;
+  uint32_t wide_cap;
 };
 
 // The lane id, re-derived where it is needed: a value computed from threadIdx before the main loop stays live across it,
@@ -152,6 +158,7 @@ __device__ __forceinline__ void wait_glds() { asm volatile("s_waitcnt vmcnt(0)" 
 template <int METRIC, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs a) {
   constexpr bool HIB = true;  // Cosine / DotProduct
+  constexpr bool WIDE = false;  // (the epilogue text asks: g16_protocol.inc)
   constexpr int BM = kG16BM, BN = kG16BN, WAVES = kG16Waves, CAP = kG16Cap, QCAP = kG16Queue;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* cand = reinterpret_cast<uint64_t*>(smem + kOffCand);   // [BN][CAP]
@@ -459,7 +466,10 @@ __device__ __forceinline__ void pp_wait_dma6() { asm volatile("s_waitcnt vmcnt(6
 // FP4 instance (Hamming / Jaccard batches on four-bit images, bits_gemm.hip): rows / queries are nibble images addressed through
 // the same arguments — row_stride / q_stride / dim in units of TWO bytes, k-tiles of 128 bytes = 256 values — and `norms` /
 // `qnorms_half` carry the bit counts |v|, |q| as floats (Hamming: dim); the accumulators hold the exact integer dot products.
-template <int METRIC, bool FP4 = false>
+// WIDE: the instance for k beyond the candidate buffers (11 .. kWideMaxK, sweep_wide.hip): the same k-loop and quick test under a bound
+// that stays what the launch was given (tau0: the k-th best approximate score seen so far, lowered by twice the error bound); the
+// epilogue appends every survivor to the query's global list instead of a block-local top-k, and nothing is written out at the end.
+template <int METRIC, bool FP4 = false, bool WIDE = false>
 __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a) {
   static_assert(FP4 == (METRIC == kHamming || METRIC == kJaccard), "the four-bit instance serves the bit metrics, the bf16 instance Cosine / DotProduct");
   constexpr bool HIB = METRIC != kHamming;  // Cosine / DotProduct / Jaccard: higher is better; Hamming: a distance
@@ -862,6 +872,19 @@ static hipError_t launch_g16_pp(const Bf16GemmArgs& a, int blocks, hipStream_t s
 }
 
 template <int METRIC>
+static hipError_t launch_g16_wide(const Bf16GemmArgs& a, int blocks, hipStream_t st) {
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep_topk_gemm_bf16_pp<METRIC, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  hipLaunchKernelGGL((sweep_topk_gemm_bf16_pp<METRIC, false, true>), dim3(blocks), dim3(512), kG16Lds, st, a);
+  return hipGetLastError();
+}
+
+template <int METRIC>
 static hipError_t launch_g16_fp4(const Bf16GemmArgs& a, int blocks, hipStream_t st) {
   static bool done = false;
   if (!done) {
@@ -889,6 +912,35 @@ static hipError_t launch_g16(const Bf16GemmArgs& a, int blocks, hipStream_t st) 
 
 // split == false: rows16 / queries16 are bf16, strides in elements, k-tiles of 64 (dim % 64 == 0, dim >= 128).
 // split == true: split-bf16 images (sweep_split.hip), strides = 2 dim, k-tiles of 32 elements (dim % 32 == 0, dim >= 64).
+// WIDE instance over one launch of a schedule (sweep_wide.hip): bounds tau0 (launch-constant), survivors to the queries' global lists
+hipError_t launch_sweep_gemm_bf16_wide(int metric, const Bf16GemmPlan& p, const uint16_t* rows16, uint64_t row_stride, const float* norms,
+                                       const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride, const uint64_t* tau0,
+                                       uint64_t* wide_keys, uint32_t* wide_cnt, uint32_t wide_cap, uint32_t dim, uint32_t nq, hipStream_t st,
+                                       const float* qnorms) {
+  Bf16GemmArgs a{};
+  a.rows = rows16;
+  a.norms = norms;
+  a.alive = alive;
+  a.queries = queries16;
+  a.tau0 = tau0;
+  a.row_stride = row_stride;
+  a.q_stride = q_stride;
+  a.n_rows = p.row_hi;
+  a.row_tile0 = p.row_lo / kG16BM;
+  a.dim = dim;
+  a.nq = nq;
+  a.k = kGemmBf16MaxK;  // (unused by the WIDE epilogue; the candidate buffers stay empty)
+  a.KT = dim / 64;
+  a.G = p.G;
+  a.nqt = p.nqt;
+  a.qper = p.qper;
+  a.qnorms = qnorms;
+  a.wide_keys = wide_keys;
+  a.wide_cnt = wide_cnt;
+  a.wide_cap = wide_cap;
+  return metric == kCosine ? launch_g16_wide<kCosine>(a, p.blocks, st) : launch_g16_wide<kDot>(a, p.blocks, st);
+}
+
 hipError_t launch_sweep_gemm_bf16_glds(int metric, const Bf16GemmPlan& p, const uint16_t* rows16, uint64_t row_stride,
                                        const float* norms, const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride,
                                        const uint64_t* tau0, uint64_t* part_keys, uint32_t list_stride, uint32_t list_off,

@@ -102,7 +102,8 @@ __device__ __forceinline__ float select_eps_q(uint32_t dim, int level, const flo
   if (level < 2 || !rho_q || !rho_max_bits) return select_eps(dim, level);
   const float rm = __uint_as_float(*rho_max_bits), rq = rho_q[q];
   // (level 3 = level 2 over the SQ8 storage mode's dequantised rows: + select_eps's extra term for the reference's own chain)
-  return (rm + rq + 3.0f * rm * rq) * 1.002f + 16.0f * (float)dim * 5.9604645e-8f + (level >= 3 ? 1.5e-4f : 0.0f);  // (NaN query: NaN -> no bound, no proof)
+  // (+ 4e-6: the Cosine batches' NORMALISED images divide by a canonical f32 norm whose own rounding is ~6e-7 relative, both sides — seln_rows_kernel)
+  return (rm + rq + 3.0f * rm * rq) * 1.002f + 16.0f * (float)dim * 5.9604645e-8f + 4e-6f + (level >= 3 ? 1.5e-4f : 0.0f);  // (NaN query: NaN -> no bound, no proof)
 }
 // rho_q per query: one wave per query
 __global__ __launch_bounds__(256) void query_round_error_kernel(const float* q, uint64_t q_stride, float* rho_q, uint32_t nq, uint32_t dim) {
@@ -178,6 +179,110 @@ void launch_sel16_prep_queries(const float* q, uint64_t q_stride, uint16_t* img,
 }
 void launch_query_round_error(const float* q, uint64_t q_stride, float* rho_q, uint32_t nq, uint32_t dim, hipStream_t st) {
   hipLaunchKernelGGL(query_round_error_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, q, q_stride, rho_q, nq, dim);
+}
+
+// ---- Cosine batches over NORMALISED images (round 6) ------------------------------------------------------------------------------
+// cos(q, v) = (q / |q|) . (v / |v|): with both sides normalised BEFORE the bf16 rounding the selection is a DotProduct of unit
+// vectors — the selection kernel's DotProduct instance runs unchanged over these images, its quick test needs no row-norm statistics
+// and its bound is as tight for every element as for the lane's best row (the Cosine instance bounds a lane's 32 rows by the
+// smallest / largest of their norms: on N(0,1) data +-2.5 % of the cut, as much slack again as the error bound itself => two to three
+// times the hot lanes).  Error of a selection score against the exact cosine: (rho_v + rho_q + 3 rho_v rho_q) for the two bf16
+// roundings (measured residual ratios of the NORMALISED vectors: select_eps_q), the f32 accumulation term, and 4e-6 for the
+// division by the canonical f32 norms (their relative error ~6e-7 each).  A zero norm gives a zero image row — the exact cosine is
+// 0 by definition (simd_avx512.rs:344-351) and so is the approximation; a NaN / inf / huge norm still makes its lane hot in the
+// kernel (the real norms are handed to it: g16_quicktest_dense.inc `force`).
+__global__ __launch_bounds__(256) void seln_rows_kernel(const float* rows, uint64_t row_stride, const float* norms, uint16_t* out, uint64_t out_stride,
+                                                        uint32_t row0, uint32_t n_rows, uint32_t dim, uint32_t* rho_max_bits) {
+  const int lane = lane_id();
+  const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t nwaves = gridDim.x * 4;
+  for (uint32_t r = wave; r < n_rows; r += nwaves) {
+    const uint32_t row = row0 + r;
+    const float* p = rows + (size_t)row * row_stride;
+    uint16_t* o = out + (size_t)row * out_stride;
+    const float nn = norms[row];
+    double se = 0.0, sx = 0.0;
+    for (uint32_t i = lane * 4; i < dim; i += 256) {  // dim % 64 == 0
+      const float4 x = ld4(p + i);
+      const float xs[4] = {x.x, x.y, x.z, x.w};
+      uint16_t h[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float u = nn == 0.0f ? 0.0f : xs[e] / nn;
+        h[e] = bf16_rne(u);
+        const float d = u - __uint_as_float((uint32_t)h[e] << 16);  // exact in f32
+        se += (double)d * (double)d;
+        sx += (double)u * (double)u;
+      }
+      *reinterpret_cast<uint2*>(o + i) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    }
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) {
+      se += __shfl_xor(se, s2, 64);
+      sx += __shfl_xor(sx, s2, 64);
+    }
+    if (lane == 0 && sx > 0.0) {
+      const float rho = (float)(sqrt(se / sx) * 1.0000002);
+      if (rho == rho && rho < __uint_as_float(0x7F800000u)) atomicMax(rho_max_bits, __float_as_uint(rho));
+    }
+  }
+}
+void launch_seln_rows(const float* rows, uint64_t row_stride, const float* norms, uint16_t* out, uint64_t out_stride, uint32_t row0, uint32_t n,
+                      uint32_t dim, uint32_t* rho_max_bits, hipStream_t st) {
+  if (n == 0) return;
+  const int blocks = (int)std::min<uint64_t>(((uint64_t)n + 3) / 4, 4096);
+  hipLaunchKernelGGL(seln_rows_kernel, dim3(blocks), dim3(256), 0, st, rows, row_stride, norms, out, out_stride, row0, n, dim, rho_max_bits);
+}
+// the front of such a batch in one launch (sel16_prep_queries_kernel's counterpart): per query — one wave — the canonical f32 norm
+// (prep_rows' chain), the bf16 image row of q / |q| (zero-padded to the image stride), its residual ratio; the first threads clear the
+// batch's flag words.  dim % 4 == 0.
+__global__ __launch_bounds__(256) void seln_prep_queries_kernel(const float* q, uint64_t q_stride, uint16_t* img, uint64_t img_stride, float* qnorms,
+                                                                float* rho_q, uint32_t* zero_words, uint32_t n_zero, uint32_t nq, uint32_t dim) {
+  const uint32_t lane = threadIdx.x & 63u, b = blockIdx.x * 4u + (threadIdx.x >> 6);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_zero; i += gridDim.x * 256u) zero_words[i] = 0u;
+  if (b >= nq) return;
+  const float* p = q + (size_t)b * q_stride;
+  uint16_t* o = img + (size_t)b * img_stride;
+  const uint32_t d4 = dim / 4, s4 = (uint32_t)(img_stride / 4);
+  float acc = 0.0f;
+  for (uint32_t c = lane; c < d4; c += 64) {
+    const float4 x = ld4(p + c * 4);
+    acc = chain4<kOpDot>(acc, x, x);
+  }
+  const float n = sqrtf(butterfly_all(acc));
+  double se = 0.0, sx = 0.0;
+  for (uint32_t c = lane; c < s4; c += 64) {
+    if (c < d4) {
+      const float4 x = ld4(p + c * 4);
+      const float xs[4] = {x.x, x.y, x.z, x.w};
+      uint16_t h[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float u = n == 0.0f ? 0.0f : xs[e] / n;
+        h[e] = bf16_rne(u);
+        const float d = u - __uint_as_float((uint32_t)h[e] << 16);  // exact in f32
+        se += (double)d * (double)d;
+        sx += (double)u * (double)u;
+      }
+      *reinterpret_cast<uint2*>(o + c * 4) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    } else {
+      *reinterpret_cast<uint2*>(o + c * 4) = make_uint2(0u, 0u);
+    }
+  }
+#pragma unroll
+  for (int s2 = 32; s2 > 0; s2 >>= 1) {
+    se += __shfl_xor(se, s2, 64);
+    sx += __shfl_xor(sx, s2, 64);
+  }
+  if (lane == 0) {
+    qnorms[b] = n;
+    // (a zero query: every cosine is 0 and so is every approximation; a NaN query: NaN -> no bound, no proof)
+    if (rho_q) rho_q[b] = sx > 0.0 ? (float)(sqrt(se / sx) * 1.0000002) : (sx == 0.0 ? 0.0f : __uint_as_float(0x7FC00000u));
+  }
+}
+void launch_seln_prep_queries(const float* q, uint64_t q_stride, uint16_t* img, uint64_t img_stride, float* qnorms, float* rho_q,
+                              uint32_t* zero_words, uint32_t n_zero, uint32_t nq, uint32_t dim, hipStream_t st) {
+  hipLaunchKernelGGL(seln_prep_queries_kernel, dim3((nq + 3) / 4), dim3(256), 0, st, q, q_stride, img, img_stride, qnorms, rho_q, zero_words, n_zero, nq, dim);
 }
 
 // Seed from the EXACT sweep of the first rows (merged to rows + raw scores, best first): list slot 0 of the candidate pool

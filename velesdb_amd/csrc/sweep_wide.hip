@@ -1,0 +1,320 @@
+// sweep_wide.hip — the selection stage for k BEYOND the candidate buffers of the 256 x 256 selection kernel: exact f32 Cosine /
+// DotProduct batches with 10 < k <= kWideMaxK (HnswIndex::search_brute_force over a batch, index/hnsw/index/search.rs:176-219; the
+// reference benches k = 10, 50, 100: benches/hnsw_benchmark.rs:152-159).  Rounds 2-5 served such calls from the exact f32 kernels
+// (1/16 of the bf16 matrix rate: 80 K q/s at k = 11, the streaming kernels beyond k = 48).
+//
+// The block-local top-k' of the k <= 10 path does not scale (a block's LDS holds 12 keys for each of its 256 queries), and it is not
+// needed: with A_k the k-th best APPROXIMATE score over any set of rows and delta the bound of |approximate - exact|, a row of the
+// exact top k has an approximate score >= A_k - 2 delta (sweep_split.hip, seed_scores_bf16).  So the selection kernel's WIDE instance
+// (sweep_gemm_bf16.hip) keeps no list at all: under a bound tau = A_k - 2 delta that is constant for a launch, every row that passes
+// is appended to the query's GLOBAL list; between two launches of the schedule one block per query finds the k-th best of its list,
+// raises tau and drops what fell under it (wide_reseed); behind the last launch the list IS the candidate pool — every row outside it
+// has an approximate score below the final tau — and wide_rerank_verify re-scores it with the exact chain of the f32 kernels (oracle
+// mode M), ranks it and writes the k best.  The proof that k <= 10 needs per query holds here by construction:
+//     exact(outside) <= approx(outside) + delta < tau + delta = A_k - 1.02 delta - ... < A_k - delta <= E_k,
+// so a query is unproven only when a list overflowed, the pool is larger than what one block re-scores, or the data is not finite
+// — those queries take the exact streaming kernel in gathered mode (the k <= 10 path's own fallback).
+// Results: ids, ranks and score bits of the exact kernels, as everywhere else (tests/test_gpu_wide_k.py).
+#include <algorithm>
+
+#include "vdb_device.hpp"
+#include "vdb_kernels.hpp"
+#include "vdb_wide.hpp"
+
+namespace vdb {
+
+// level 2's error bound with measured residuals (sweep_split.hip select_eps_q, restated: that one is file-local)
+__device__ __forceinline__ float wide_eps(uint32_t dim, const float* rho_q, const uint32_t* rho_max_bits, uint32_t q) {
+  const float acc = 16.0f * (float)dim * 5.9604645e-8f;
+  if (!rho_q || !rho_max_bits) return 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f + acc;
+  const float rm = __uint_as_float(*rho_max_bits), rq = rho_q[q];
+  return (rm + rq + 3.0f * rm * rq) * 1.002f + acc + 4e-6f;  // (+ 4e-6: the normalised images' division by f32 norms; NaN query: NaN -> no bound)
+}
+
+// The k-th smallest of the block's keys by their HIGH words (the score keys; smaller = better): MSB-first radix select, 8 bits a
+// pass, histogram in LDS.  Every thread holds NPT keys in registers (kKeyInvalid = none); k >= 1 and at most the number of valid
+// keys; blockDim = 256.  Returns the high word of the k-th smallest key; *below = how many valid keys have a smaller high word.
+template <int NPT>
+__device__ uint32_t block_kth_hi(const uint64_t (&keys)[NPT], uint32_t k, uint32_t* hist, uint32_t* ctl) {
+  const uint32_t tid = threadIdx.x;
+  uint32_t prefix = 0, mask = 0, rem = k;
+#pragma unroll 1
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+      const uint32_t hi = (uint32_t)(keys[j] >> 32);
+      if (keys[j] != kKeyInvalid && (hi & mask) == prefix) atomicAdd(&hist[(hi >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {  // lane l: bins 4 l .. 4 l + 3; inclusive prefix over the lanes
+      const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+      const uint32_t s = c0 + c1 + c2 + c3;
+      uint32_t incl = s;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if ((int)tid >= o) incl += up;
+      }
+      const uint32_t excl = incl - s;
+      if (excl < rem && rem <= incl) {  // exactly one lane (rem <= the number of matching keys)
+        uint32_t r = rem - excl, bin = 4 * tid;
+        if (r > c0) { r -= c0; bin++; if (r > c1) { r -= c1; bin++; if (r > c2) { r -= c2; bin++; } } }
+        ctl[0] = bin;
+        ctl[1] = r;
+      }
+    }
+    __syncthreads();
+    prefix |= ctl[0] << shift;
+    mask |= 255u << shift;
+    rem = ctl[1];
+    __syncthreads();  // (hist and ctl are rewritten by the next pass)
+  }
+  return prefix;
+}
+
+// the bound a k-th best approximate score s_k yields: tau = s_k - 2 delta (both sides approximate), as a key of row 0 — a row passes
+// `key < tau` when its score is above it.  No bound (NaN / inf arithmetic): the query is given up (sweep_wide.hip header)
+__device__ __forceinline__ uint64_t wide_tau_key(float s_k, float delta, bool* ok) {
+  const float lowered = s_k - 2.0f * delta * 1.01f - fabsf(s_k) * 1e-6f;
+  *ok = lowered == lowered && fabsf(lowered) < 3.0e38f;
+  return make_key<true>(lowered, 0u);
+}
+// a bound nothing finite passes: the query is out of the selection (its list has overflowed or no bound exists) and the launches
+// that follow must not spend their epilogues on it
+__device__ __forceinline__ uint64_t wide_tau_closed() { return make_key<true>(3.0e38f, 0u); }
+
+// ---- seed: the k-th best of the sample keys (one per 16 seed rows: seed_scores_bf16) -> tau, delta; empty list -------------------
+template <int METRIC>
+__global__ __launch_bounds__(256) void wide_seed_kernel(WideArgs a, const uint64_t* seed_keys, uint32_t ngrp) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t ctl[2];
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  constexpr int NPT = kWideSeedGroups / 256;
+  uint64_t keys[NPT];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < NPT; j++) {
+    const uint32_t i = tid + 256u * (uint32_t)j;
+    keys[j] = i < ngrp ? seed_keys[(size_t)q * ngrp + i] : kKeyInvalid;
+    mine += keys[j] != kKeyInvalid ? 1u : 0u;
+  }
+  __shared__ uint32_t total;
+  if (tid == 0) total = 0;
+  __syncthreads();
+  if (mine) atomicAdd(&total, mine);
+  __syncthreads();
+  const uint32_t valid = total;  // (block-uniform)
+  const float eps = wide_eps(a.dim, a.rho_q, a.rho_max_bits, q);
+  const float d = METRIC == kCosine ? eps * 1.001f + 4e-7f : eps * 1.001f * a.qnorms[q] * __uint_as_float(*a.norm_max_bits) + 1e-30f;
+  bool ok = valid >= a.k && d == d;
+  uint64_t tau = wide_tau_closed();
+  if (ok) {  // (block-uniform)
+    const uint32_t hi = block_kth_hi<NPT>(keys, a.k, hist, ctl);
+    tau = wide_tau_key(key_score<true>((uint64_t)hi << 32), d, &ok);
+    if (!ok) tau = wide_tau_closed();
+  }
+  if (tid == 0) {
+    a.delta[q] = d;
+    a.tau[q] = tau;
+    a.cnt[q] = 0;
+    a.state[q] = ok ? 0u : kWideGivenUp;
+  }
+}
+
+// ---- between two launches, and behind the last: k-th best of the list -> tau; entries under the new tau leave the list ---------
+__global__ __launch_bounds__(256) void wide_reseed_kernel(WideArgs a) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t ctl[2];
+  __shared__ uint32_t wsum[4];
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  if (a.state[q] & kWideGivenUp) return;  // (block-uniform)
+  const uint32_t raw = a.cnt[q];
+  if (raw > a.cap) {  // entries were dropped: the list no longer holds every row above the bound
+    if (tid == 0) {
+      a.state[q] |= kWideGivenUp;
+      a.tau[q] = wide_tau_closed();
+    }
+    return;
+  }
+  constexpr int NPT = kWideCap / 256;
+  uint64_t* list = a.keys + (size_t)q * a.cap;
+  uint64_t keys[NPT];
+#pragma unroll
+  for (int j = 0; j < NPT; j++) {
+    const uint32_t i = tid + 256u * (uint32_t)j;
+    keys[j] = i < raw ? list[i] : kKeyInvalid;
+  }
+  if (raw < a.k) return;  // fewer than k rows passed so far: the bound stays (it is valid for any set of rows)
+  const uint32_t hi = block_kth_hi<NPT>(keys, a.k, hist, ctl);
+  bool ok;
+  uint64_t tau = wide_tau_key(key_score<true>((uint64_t)hi << 32), a.delta[q], &ok);
+  if (!ok) {
+    if (tid == 0) {
+      a.state[q] |= kWideGivenUp;
+      a.tau[q] = wide_tau_closed();
+    }
+    return;
+  }
+  const uint64_t old = a.tau[q];
+  if (tau > old) tau = old;  // (keys: smaller = a higher bound) never lower the bound the list was filled under
+  // compaction: the entries that still pass, in any order
+  uint32_t keep = 0;
+#pragma unroll
+  for (int j = 0; j < NPT; j++) keep += (keys[j] != kKeyInvalid && keys[j] < tau) ? 1u : 0u;
+  uint32_t incl = keep;
+  const uint32_t lane = tid & 63u, w = tid >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(incl, o, 64);
+    if ((int)lane >= o) incl += up;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();  // (every thread has read its entries: the list may be rewritten)
+  uint32_t base = incl - keep;
+  for (uint32_t x = 0; x < w; x++) base += wsum[x];
+#pragma unroll
+  for (int j = 0; j < NPT; j++)
+    if (keys[j] != kKeyInvalid && keys[j] < tau) list[base++] = keys[j];
+  if (tid == 0) {
+    a.cnt[q] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    a.tau[q] = tau;
+  }
+}
+
+// ---- the pool, re-scored exactly: one block per query ------------------------------------------------------------------------
+// Candidates in chunks of 64 through the staging scheme of split_rerank_verify (rows travel through LDS in steps of 64 elements,
+// double-buffered; one fmaf chain per candidate in oracle mode M's order k = 128 U + 16 m + 4 kk + c, the vector zero-padded to a
+// multiple of 128); then every candidate is ranked by counting among the exact keys and the k best are written in rank order.
+template <int METRIC>
+__global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArgs o) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr uint32_t kStep = 64, kStride = kStep + 4, kChunk = 64;
+  float* qs = reinterpret_cast<float*>(smem);                               // [dim_pad]
+  uint64_t* ekeys = reinterpret_cast<uint64_t*>(qs + o.dim_pad);             // [kWidePoolMax] exact keys
+  float* stage = reinterpret_cast<float*>(ekeys + kWidePoolMax);             // [2][kChunk][kStride]
+  uint32_t* crow = reinterpret_cast<uint32_t*>(stage + 2 * kChunk * kStride);  // [kChunk]
+  uint64_t* kth = reinterpret_cast<uint64_t*>(crow + kChunk);                // [1] exact key of rank k - 1
+  const uint32_t tid = threadIdx.x, qi = blockIdx.x;
+  const uint32_t raw = a.cnt[qi];
+  const bool given_up = (a.state[qi] & kWideGivenUp) != 0 || raw > kWidePoolMax || raw > a.cap;
+  const uint32_t n = given_up ? 0u : raw;
+  const float* q = o.queries + (size_t)qi * o.q_stride;
+  for (uint32_t i = tid; i < o.dim_pad; i += 256) qs[i] = i < a.dim ? q[i] : 0.0f;
+  if (tid == 0) *kth = kKeyInvalid;
+  const uint64_t* list = a.keys + (size_t)qi * a.cap;
+  const float qn = METRIC == kCosine ? a.qnorms[qi] : 0.0f;
+  for (uint32_t c0 = 0; c0 < n; c0 += kChunk) {
+    const uint32_t nc = min(kChunk, n - c0);
+    __syncthreads();  // (qs written; the previous chunk's chains are done with the stage and crow)
+    if (tid < nc) crow[tid] = key_row(list[c0 + tid]);
+    __syncthreads();
+    const uint32_t nf4 = nc * (kStep / 4);
+    float4 v[4];
+    auto fetch = [&](uint32_t U) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t f = tid + 256u * (uint32_t)i;
+        const uint32_t r = f / (kStep / 4), c4 = f % (kStep / 4);
+        v[i] = (f < nf4 && U + 4 * c4 < a.dim) ? ld4(o.rows + (size_t)crow[r] * o.row_stride + U + 4 * c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+    };
+    auto park = [&](uint32_t buf) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t f = tid + 256u * (uint32_t)i;
+        const uint32_t r = f / (kStep / 4), c4 = f % (kStep / 4);
+        if (f < nf4) *reinterpret_cast<float4*>(stage + ((size_t)buf * kChunk + r) * kStride + 4 * c4) = v[i];
+      }
+    };
+    fetch(0);
+    park(0);
+    __syncthreads();
+    float acc = 0.0f;
+    for (uint32_t U = 0, buf = 0; U < o.dim_pad; U += kStep, buf ^= 1u) {
+      const bool more = U + kStep < o.dim_pad;
+      if (more) fetch(U + kStep);
+      if (tid < nc) {
+        const float* x = stage + ((size_t)buf * kChunk + tid) * kStride;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          float xr[16];
+#pragma unroll
+          for (int e = 0; e < 16; e += 4) {
+            const float4 w = *reinterpret_cast<const float4*>(x + 16 * m + e);
+            xr[e] = w.x; xr[e + 1] = w.y; xr[e + 2] = w.z; xr[e + 3] = w.w;
+          }
+          const uint32_t base = U + 16 * m;
+#pragma unroll
+          for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) acc = __builtin_fmaf(xr[4 * kk + c], qs[base + 4 * kk + c], acc);
+        }
+      }
+      if (more) park(buf ^ 1u);
+      __syncthreads();
+    }
+    if (tid < nc) {
+      const uint32_t row = crow[tid];
+      const float score = finish_score<METRIC>(acc, qn, METRIC == kCosine ? o.norms[row] : 1.0f);
+      ekeys[c0 + tid] = make_key<true>(score, row);
+    }
+  }
+  __syncthreads();
+  // rank by counting (keys are unique: a row appears once in a list — every row is swept by exactly one block of one launch)
+  const uint32_t kk = min(a.k, n);
+  for (uint32_t i = tid; i < n; i += 256) {
+    const uint64_t key = ekeys[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; j++) rank += ekeys[j] < key ? 1u : 0u;
+    if (rank < kk) {
+      const uint32_t row = key_row(key);
+      o.out_ids[(size_t)qi * a.k + rank] = o.ext_ids ? o.ext_ids[row] : (uint64_t)row;
+      o.out_scores[(size_t)qi * a.k + rank] = key_score<true>(key);
+      if (rank + 1 == a.k) *kth = key;
+    }
+  }
+  for (uint32_t e = kk + tid; e < a.k; e += 256) {
+    o.out_ids[(size_t)qi * a.k + e] = ~0ull;
+    o.out_scores[(size_t)qi * a.k + e] = __uint_as_float(0x7FC00000u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // proof (file header): every row outside the list has an approximate score under the final bound
+    bool ok = !given_up && n >= a.k;
+    if (ok) {
+      const float A = key_score<true>(a.tau[qi]);
+      const double Ek = (double)key_score<true>(*kth);
+      ok = Ek > (double)A + (double)a.delta[qi];  // false for NaN anywhere
+    }
+    o.flags[qi] = ok ? 0u : 1u;
+    if (!ok) {  // the query lists itself for the gathered exact pass (sweep_split.hip list_unproven's rule)
+      const uint32_t j = atomicAdd(o.qcount, 1u);
+      o.qmap[j] = qi;
+      o.qslot[qi] = j;
+    }
+    o.out_n[qi] = kk;
+  }
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------------------------------
+void launch_wide_seed(int metric, const WideArgs& a, const uint64_t* seed_keys, uint32_t ngrp, uint32_t nq, hipStream_t st) {
+  if (metric == kCosine)
+    hipLaunchKernelGGL((wide_seed_kernel<kCosine>), dim3(nq), dim3(256), 0, st, a, seed_keys, ngrp);
+  else
+    hipLaunchKernelGGL((wide_seed_kernel<kDot>), dim3(nq), dim3(256), 0, st, a, seed_keys, ngrp);
+}
+void launch_wide_reseed(const WideArgs& a, uint32_t nq, hipStream_t st) { hipLaunchKernelGGL(wide_reseed_kernel, dim3(nq), dim3(256), 0, st, a); }
+size_t wide_rerank_lds_bytes(uint32_t dim_pad) {
+  return ((size_t)dim_pad * 4 + (size_t)kWidePoolMax * 8 + 2 * (size_t)64 * 68 * 4 + 64 * 4 + 8 + 15) & ~(size_t)15;
+}
+void launch_wide_rerank(int metric, const WideArgs& a, const WideOutArgs& o, uint32_t nq, hipStream_t st) {
+  const size_t lds = wide_rerank_lds_bytes(o.dim_pad);
+  if (metric == kCosine)
+    hipLaunchKernelGGL((wide_rerank_verify<kCosine>), dim3(nq), dim3(256), lds, st, a, o);
+  else
+    hipLaunchKernelGGL((wide_rerank_verify<kDot>), dim3(nq), dim3(256), lds, st, a, o);
+}
+
+}  // namespace vdb

@@ -177,11 +177,16 @@ struct vdb_hip_index {
   // ({unproven, queries, sequence, level}); too many unproven queries park the handle at level 1 for a while
   volatile uint32_t* sel_stats = nullptr;
   uint32_t sel_seq = 0, sel_seq_seen = 0, sel16_hold = 0;
+  uint32_t wide_hold = 0;   // batches with 10 < k answered by the exact kernels after a batch the WIDE selection could not prove (sweep_wide.hip)
   int last_select_level = 0;
   uint32_t last_kernels = 0;  // vdb_kernel_bit set of the last search call (vdb_hip_index_last_kernels)
   // Euclidean batches through the selection stage: augmented bf16 image [capacity][dim + 64], augmented f32 seed prefix
   vdb::DevBuf l2_img, l2_seed;
   uint64_t l2_rows = 0;     // rows converted so far
+  // Cosine batches (level 2, round 6): bf16 image of the NORMALISED rows v / |v| [capacity][dim] and its largest rounding residual ratio —
+  // the selection then runs as a DotProduct of unit vectors (no row norm in the kernel's bound): sweep_split.hip seln_rows_kernel
+  vdb::DevBuf cosn_img, cosn_rho;
+  uint64_t cosn_rows = 0;   // rows converted so far
   uint32_t l2_hold = 0;     // batches to answer on the f32 matrix-core path after a batch the selection could not prove
   uint64_t split_rows = 0;   // rows converted so far
   size_t split_flags_off = 0;     // where the last split batch left its per-query verdicts in s_seed
@@ -267,7 +272,8 @@ struct vdb_hip_index {
   bool foreign_pending = false;
   // work was enqueued on `stream` (enter_index: every host entry point) since a caller's stream last waited for it: a device-resident
   // search on a caller's stream records + waits for ev_own only then (two packets less per call in a loop of such searches)
-  bool own_dirty = true;
+  // (atomic: enter_index sets it under the SHARED lock too — read-only entry points — while a device-resident search clears it)
+  std::atomic<bool> own_dirty{true};
 
   // multi-device handle (vdb_hip_index_create with n_devices > 1): this object then owns no device memory, only the
   // id mappings / counters above and the children; every entry point dispatches through the group (shard_group.hip)
@@ -331,6 +337,9 @@ int32_t group_remove(vdb_hip_index* ix, uint64_t id, int32_t* removed);
 vdb_hip_index* group_shard(const vdb_hip_index* ix, size_t s);  // child s of a multi-device handle
 size_t group_size(const vdb_hip_index* ix);
 int group_mode(const vdb_hip_index* ix);
+// the host-pointer search of one handle (single device, group, combining front): search_front.hip
+int32_t search_batch_host(vdb_hip_index* ix, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, int32_t mode, uint32_t rerank_k,
+                          uint64_t* out_ids, float* out_scores, uint32_t* out_n);
 int32_t group_for_all(vdb_hip_index* ix, int op, uint32_t arg);
 int32_t group_set_option(vdb_hip_index* ix, int32_t option, int64_t value);
 vdb_hip_index* group_first_shard(vdb_hip_index* ix);  // op: 0 build_graph, 1 enable_bf16, 2 storage mode, 3 quantizer

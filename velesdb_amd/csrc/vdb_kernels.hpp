@@ -299,6 +299,12 @@ void launch_query_round_error(const float* q, uint64_t q_stride, float* rho_q, u
 // the front of a level-2 / 3 batch in one launch: bf16 image rows, canonical norms, rho_q (nullable), cleared flag words
 void launch_sel16_prep_queries(const float* q, uint64_t q_stride, uint16_t* img, uint64_t img_stride, float* qnorms, float* rho_q,
                                uint32_t* zero_words, uint32_t n_zero, uint32_t nq, uint32_t dim, hipStream_t st);
+// Cosine batches over NORMALISED images (sweep_split.hip): the rows' image (v / |v| rounded to bf16, + the largest residual ratio) and the
+// front of a batch (q / |q| image rows, canonical norms, residual ratios, cleared flag words)
+void launch_seln_rows(const float* rows, uint64_t row_stride, const float* norms, uint16_t* out, uint64_t out_stride, uint32_t row0, uint32_t n,
+                      uint32_t dim, uint32_t* rho_max_bits, hipStream_t st);
+void launch_seln_prep_queries(const float* q, uint64_t q_stride, uint16_t* img, uint64_t img_stride, float* qnorms, float* rho_q,
+                              uint32_t* zero_words, uint32_t n_zero, uint32_t nq, uint32_t dim, hipStream_t st);
 // level 2's seed on the bf16 pipe: a plain GEMM of the first rows x the batch into keys [nq][seed_rows], and the seed kernel for
 // approximate seed scores (tau = A_k - 2 delta; slot 0 of the pool with its bound)
 void launch_seed_scores_bf16(int metric, const uint16_t* rows16, uint64_t row_stride, const float* norms, const uint8_t* alive,

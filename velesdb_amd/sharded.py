@@ -10,9 +10,10 @@ import numpy as np
 
 from .index import COMM_ID_BYTES, HnswIndex, comm_unique_id
 
-# the record that travels in the all-gather (shard_group.hip pack_shard_records): id low, id high, score bits
+# the record that travels in the all-gather (csrc/vdb_shard_wire.hpp, shard_group.hip pack_shard_records): id low, id high, score bits
 RECORD_DTYPE = np.dtype([("id_lo", "<u4"), ("id_hi", "<u4"), ("score_bits", "<u4")])
 REC_EMPTY = 0xFFFFFFFF  # sentinel of a slot past the shard's result count (with id = ~0)
+REC_OVERFLOW = 0xFFFFFFFE  # first record of a query whose count is 0xFFFFFFFF (csrc/vdb_shard_wire.hpp)
 
 
 def query_slice(nq: int, rank: int, world: int):
@@ -26,11 +27,14 @@ def pack_records(ids: np.ndarray, scores: np.ndarray, counts: np.ndarray) -> np.
     """Host restatement of pack_shard_records (the wire format), for launchers and the CPU tests."""
     nq, k = ids.shape
     rec = np.empty((nq, k), dtype=RECORD_DTYPE)
-    live = np.arange(k)[None, :] < counts.astype(np.int64)[:, None]
+    c = counts.astype(np.int64)
+    overflow = c == 0xFFFFFFFF   # a device-resident call whose traversal list overflowed: no records, the marker in slot 0
+    live = (np.arange(k)[None, :] < c[:, None]) & ~overflow[:, None]
     u = ids.astype(np.uint64)
     rec["id_lo"] = np.where(live, (u & np.uint64(0xFFFFFFFF)).astype(np.uint32), np.uint32(0xFFFFFFFF))
     rec["id_hi"] = np.where(live, (u >> np.uint64(32)).astype(np.uint32), np.uint32(0xFFFFFFFF))
     rec["score_bits"] = np.where(live, np.ascontiguousarray(scores, dtype=np.float32).view(np.uint32), np.uint32(REC_EMPTY))
+    rec["score_bits"][overflow, 0] = np.uint32(REC_OVERFLOW)
     return rec
 
 
