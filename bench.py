@@ -427,6 +427,13 @@ def main():
     sel_ms, sel_launches = ix.last_selection_ms()      # HIP events around every launch of the selection kernel, last step
     va.set_kernel_timing(False)
     dt = max_over_ranks(dt)
+    # (diagnostic, not `value`: the same K steps once more, right behind the timed region — how much of ms_per_step is the chip still
+    # settling into the workload behind W warm-up steps)
+    t0r = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + a.steps + i)
+    torch.cuda.synchronize()
+    repeat_ms_per_step = (time.perf_counter() - t0r) / a.steps * 1e3
     qps = world * Q * a.steps / dt
     replicas_per_rank = gather_rows([float(rank), Q * a.steps / dt_mine], ("rank", "qps"))
 
@@ -980,14 +987,20 @@ def main():
             # reference), the corpus pages placed by the threads that scan them (NUMA); shape A = the production engine
             # (wide16: 4 x f32x8 FMA accumulators, oracle mode R), shape B = the true AVX-512F kernel of simd_native.rs
             # (one zmm accumulator, MODE_NATIVE); single-thread latency as criterion measures it (one query at a time)
-            cpu_model = ""
+            cpu_model, cpu_sockets, cpu_cores_per_socket = "", 1, ncores
             try:
+                phys, cores_ = set(), 0
                 with open("/proc/cpuinfo") as f:
                     for ln in f:
-                        if ln.startswith("model name"):
+                        if ln.startswith("model name") and not cpu_model:
                             cpu_model = ln.split(":", 1)[1].strip()
-                            break
-            except OSError:
+                        elif ln.startswith("physical id"):
+                            phys.add(ln.split(":", 1)[1].strip())
+                        elif ln.startswith("cpu cores") and not cores_:
+                            cores_ = int(ln.split(":", 1)[1])
+                cpu_sockets = max(1, len(phys))
+                cpu_cores_per_socket = cores_ or max(1, (os.cpu_count() or ncores) // cpu_sockets)
+            except (OSError, ValueError):
                 pass
             spread = po.SpreadRows(host_sample, ncores)
             hs = spread.array
@@ -1013,7 +1026,8 @@ def main():
                 st_samples.append(time.perf_counter() - t3)
             cpu = {"value": shapes["shape_a"]["qps"], "unit": "queries/s", "cores": ncores, "kind": "port",
                    "cpu_model": cpu_model, "host_hardware_threads": os.cpu_count(),
-                   "cores_of_socket": f"{ncores} CPUs (cgroup quota) of a socket with {os.cpu_count()} hardware threads: the whole socket is at best x{max(1, (os.cpu_count() or ncores) // max(ncores, 1))} of `value`",
+                   "cores_of_socket": f"{ncores} CPUs (cgroup quota) of a host with {os.cpu_count()} hardware threads ({cpu_sockets} x {cpu_model}): one whole "
+                                      f"{cpu_cores_per_socket}-core socket is at best x{max(1, cpu_cores_per_socket // max(ncores, 1))} of `value`, the whole host x{max(1, cpu_sockets * cpu_cores_per_socket // max(ncores, 1))}",
                    "cores_note": "cores = CPUs this process may use (affinity mask capped by the cgroup cpu.max quota); "
                                  "one pool thread per CPU", "shape_a": shapes["shape_a"], "shape_b": shapes["shape_b"],
                    "single_thread_us": round(float(np.median(st_samples)) * 1e6 * N / sample_rows, 1),
@@ -1831,7 +1845,7 @@ def main():
                                    f"({roofline['kernel']})",
                        "rows": N, "dim": D, "k": K, "queries_per_step": Q,
                        "parallelism": "replicas x%d (query stream split, no collective)" % world},
-            "replicas_per_rank": replicas_per_rank,
+            "replicas_per_rank": replicas_per_rank, "repeat_ms_per_step": round(repeat_ms_per_step, 4),
             "recall_at_10": recall, "parity_check": check,
             # the headline's algorithmic flop over the WHOLE step's time / peak — from ms_per_step (the timed region's wall clock over its
             # steps, what `value` is computed from), not from the last step's event pair (roofline.whole_batch keeps that one)

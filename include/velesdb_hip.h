@@ -376,12 +376,19 @@ int32_t vdb_hip_set_sweep_engine(int32_t engine);
  *   2 (default) = plain bf16 selection first (one MFMA per product over the bf16 copy of the rows, error ~2^-7; 64
  *       candidates; +2 bytes per element, dim % 64 == 0), level 1 where that does not apply; a handle whose data defeats
  *       the wider bound (> 1/16 of a batch unproven: near-duplicate clusters) moves itself to level 1 for the next 64
- *       batches and then tries again. */
+ *       batches and then tries again.  Cosine (round 6): the image holds the NORMALISED rows v / |v| and the batch the
+ *       normalised queries, so the selection is a DotProduct of unit vectors (no row norm in the kernel's bound).
+ * 10 < k <= 128 (round 6; Cosine / DotProduct, level 2's eligibility): the WIDE selection — no block-local top-k at all:
+ * every row whose approximate score passes the query's bound (k-th best approximate score seen so far - 2 x the error
+ * bound, raised between the launches of the batch) becomes a candidate, all of them are re-scored exactly; a query is
+ * unproven only when its candidate list overflows (4 096 per launch, 1 024 at the end) or its data is not finite.
+ * Reported as level 4 by vdb_hip_index_last_select_level.  Larger k, other metrics at k > 10: the exact kernels. */
 int32_t vdb_hip_set_split_selector(int32_t level);
 /* diagnostic: queries in the last split-selector batch (its last chunk of <= 1024) and how many of them the exact
  * fallback kernel answered because the selection could not be proven (near-ties inside the error bound, non-finite data) */
 int32_t vdb_hip_index_last_split_stats(vdb_hip_index* idx, uint32_t* queries, uint32_t* unproven);
-/* selection level (0 / 1 / 2, see vdb_hip_set_split_selector) the last exact batch of this handle actually ran at */
+/* selection level (0 / 1 / 2; 3 = the SQ8 storage mode's; 4 = the WIDE selection of 10 < k <= 128; see vdb_hip_set_split_selector) the last
+ * exact batch of this handle actually ran at */
 int32_t vdb_hip_index_last_select_level(vdb_hip_index* idx, int32_t* level);
 /* which kernel families served the last search call of this handle (a bit set; what a test asserts when it claims to have
  * driven a particular kernel — e.g. BASELINE configs[3] is VDB_KERNEL_GEMM_BF16_GLDS, which needs >= 65 536 rows) */

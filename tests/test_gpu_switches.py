@@ -18,6 +18,10 @@ against the oracle) must hold.
                                   ragged block grid; 3 blocks: fewer lists than k)           -> the one-launch tests
   VELESDB_BITS_FUSED=0            the three-launch form for one or two packed-bit queries     -> the one-launch tests
   VELESDB_MERGE_EXTRACT=0         the small merges on merge_topk_select instead of merge_topk_extract -> split tests
+  VELESDB_COSINE_NORMALISED=0     round 5's Cosine selection (plain bf16 copy + row norms in the kernel) instead of the normalised images
+                                                                                              -> split tests, the WIDE tests (k > 10)
+  VELESDB_POOL_SELECT=0           bounds / final pool of a selection batch by merge_topk_* instead of radix selection -> split tests
+  VELESDB_GATHER_ALL=0            unproven queries: gathered pass up to 96 + the GEMM-structured fallback beyond (rounds 2-5) -> split tests
   (VELESDB_BITS_FUSED_SKIP is an ablation that returns WRONG results by design — probe timing only, nothing to re-run)
 """
 import os
@@ -39,6 +43,9 @@ BF16 = ["tests/test_gpu_bf16.py", "-k", "glds_exact_products and 70077"]
 GRAPH = ["tests/test_gpu_hnsw.py"]
 INT8 = ["tests/test_gpu_int8.py"]
 ONE_LAUNCH = ["tests/test_gpu_round5_parity.py", "-k", "one_launch and (300000 or 70001 or 4100 or 130 or 64-128)"]
+# (everything of test_gpu_split.py that leaves queries unproven as well: near-duplicate clusters, NaN / inf rows, level parking)
+SPLIT_ALL = ["tests/test_gpu_split.py", "-k", "not 1000000 and not 300000 and not 150001"]
+WIDE = ["tests/test_gpu_wide_k.py", "-k", "vs_oracle or adversarial"]
 
 CASES = [
     ({"VELESDB_BF16_PP": "0"}, SPLIT),
@@ -56,6 +63,10 @@ CASES = [
     ({"VELESDB_BITS_FUSED_BLOCKS": "3"}, ONE_LAUNCH),
     ({"VELESDB_BITS_FUSED": "0"}, ONE_LAUNCH),
     ({"VELESDB_MERGE_EXTRACT": "0"}, SPLIT),
+    ({"VELESDB_COSINE_NORMALISED": "0"}, SPLIT),
+    ({"VELESDB_COSINE_NORMALISED": "0"}, WIDE),
+    ({"VELESDB_POOL_SELECT": "0"}, SPLIT),
+    ({"VELESDB_GATHER_ALL": "0"}, SPLIT_ALL),
 ]
 
 

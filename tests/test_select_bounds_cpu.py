@@ -117,3 +117,65 @@ def test_measured_residual_bound_of_level_2():
     g = [rho(rng.standard_normal(768).astype(np.float32))[0] for _ in range(200)]
     assert max(g) < 0.5 * 2.0 ** -8, max(g)       # Gaussian rows: ~0.41 x 2^-8
     assert max(r for r, _ in ratios) > 0.05       # ... while the denormal row shows why the constant was not a bound for ALL data
+
+
+def test_normalised_cosine_image_bound():
+    """Round 6 (sweep_split.hip seln_rows_kernel / seln_prep_queries_kernel): Cosine batches select over bf16 images of the NORMALISED
+    vectors, u = bf16(fl(v / fl|v|)), w = bf16(fl(q / fl|q|)); the selection score u.w must stay within
+        (rho_u + rho_w + 3 rho_u rho_w) + 4e-6
+    of the exact cosine, with rho measured on the normalised vectors (what the kernels store), for Gaussian rows, mixed scales,
+    boundary values, tiny and huge norms.  (The f32 accumulation term is on top and not exercised: the sums here are exact.)"""
+    rng = np.random.default_rng(4)
+
+    def norm_f32(v):   # the canonical norm is an f32 chain: any f32-rounded norm within a few ulps serves the bound
+        return np.float32(np.sqrt(np.float32(np.dot(v.astype(np.float64), v.astype(np.float64)))))
+
+    def image(v):
+        n = norm_f32(v)
+        u = (v / n).astype(np.float32) if n != 0 else np.zeros_like(v)
+        h = po.round_bf16(u).astype(np.float32)
+        u64 = u.astype(np.float64)
+        nu = float(np.linalg.norm(u64))
+        return h.astype(np.float64), (float(np.linalg.norm(u64 - h)) / nu if nu > 0 else 0.0)
+
+    worst = 0.0
+    data = list(cases(rng)) + [((rng.standard_normal(768) * 1e-18).astype(np.float32), (rng.standard_normal(768) * 1e15).astype(np.float32)),
+                               ((rng.standard_normal(768) * np.exp(rng.uniform(-8, 8, 768))).astype(np.float32), rng.standard_normal(768).astype(np.float32))]
+    for x, q in data:
+        x64, q64 = x.astype(np.float64), q.astype(np.float64)
+        nx, nq = float(np.linalg.norm(x64)), float(np.linalg.norm(q64))
+        if nx == 0.0 or nq == 0.0:
+            continue
+        exact = float(np.dot(x64, q64)) / (nx * nq)
+        u, ru = image(x)
+        w, rw = image(q)
+        approx = float(np.dot(u, w))
+        bound = (ru + rw + 3.0 * ru * rw) + 4e-6
+        worst = max(worst, abs(approx - exact) / bound)
+        assert abs(approx - exact) <= bound, (abs(approx - exact), bound, ru, rw)
+    assert worst > 0.3   # the boundary cases come close: the bound is not loose by an order of magnitude
+    # what the tighter bound buys on the benchmark data: no row norm enters the kernel's quick test.  The Cosine instance bounds a
+    # lane's 32 rows by the smallest of their norms; on N(0,1) x 768 that slack is as large as 2 delta itself
+    norms = np.linalg.norm(rng.standard_normal((4096, 768)), axis=1)
+    slack = float(np.mean(1.0 - norms.reshape(-1, 32).min(axis=1) / norms.reshape(-1, 32).mean(axis=1)))
+    assert 0.03 < slack < 0.08
+
+
+def test_wide_selection_keeps_every_row_of_the_exact_top_k():
+    """sweep_wide.hip's argument, on numbers: approximate scores within delta of the exact ones (any perturbation), tau = (k-th best
+    approximate score over ANY subset holding k rows) - 2 delta  =>  every row of the exact top k passes `approx > tau`, and the k-th
+    best exact score among the survivors stands more than delta above tau (the proof by construction)."""
+    rng = np.random.default_rng(6)
+    for trial in range(200):
+        n, k = int(rng.integers(200, 3000)), int(rng.integers(11, 129))
+        exact = rng.standard_normal(n) * 0.036
+        delta = float(rng.uniform(1e-4, 1e-2))
+        approx = exact + rng.uniform(-delta, delta, n)
+        subset = rng.choice(n, size=int(rng.integers(k, n + 1)), replace=False)     # the rows seen so far (a seed sample, a list)
+        a_k = np.sort(approx[subset])[::-1][k - 1]
+        tau = a_k - 2.0 * delta * 1.01 - abs(a_k) * 1e-6
+        survivors = np.nonzero(approx > tau)[0]
+        top = np.argsort(-exact, kind="stable")[:k]
+        assert set(top.tolist()) <= set(survivors.tolist())
+        e_k = np.sort(exact[survivors])[::-1][k - 1]
+        assert e_k > tau + delta

@@ -1152,8 +1152,12 @@ int32_t search_to_device(vdb_hip_index* ix, const float* queries, uint32_t nq, u
       hipStream_t st = ix->stream;
       if (ix->s_queries.reserve(bytes, false, st) != hipSuccess) return fail(VDB_ERR_OOM, "search scratch");
       float* dq = ix->s_queries.as<float>();
-      if (ix->row_stride != ix->dim) VDB_HIP(hipMemsetAsync(dq, 0, bytes, st));
-      VDB_HIP(hipMemcpy2DAsync(dq, ix->row_stride * 4, queries, (size_t)ix->dim * 4, (size_t)ix->dim * 4, nq, hipMemcpyHostToDevice, st));
+      if (ix->row_stride != ix->dim) {
+        VDB_HIP(hipMemsetAsync(dq, 0, bytes, st));
+        VDB_HIP(hipMemcpy2DAsync(dq, ix->row_stride * 4, queries, (size_t)ix->dim * 4, (size_t)ix->dim * 4, nq, hipMemcpyHostToDevice, st));
+      } else {
+        VDB_HIP(hipMemcpyAsync(dq, queries, bytes, hipMemcpyHostToDevice, st));  // (dense rows: one linear copy)
+      }
     }
   }
   const int32_t rc = search_block(ix, staged, nq, k, ef, mode, rerank_k);

@@ -25,6 +25,11 @@ static const bool g_bf16_seed = [] {
   const char* e = probe_env("VELESDB_BF16_SEED");
   return !(e && e[0] == '0');
 }();
+// VELESDB_POOL_SELECT=0: the bounds between the launches of a selection batch and its final pool come from merge_topk_select again (A / B probes)
+static const bool g_pool_select = [] {
+  const char* e = probe_env("VELESDB_POOL_SELECT");
+  return !(e && e[0] == '0');
+}();
 // VELESDB_BF16_GLDS=0: big bf16 batches stay on the register-staged kernel of sweep_gemm.hip (A/B probes)
 static bool gemm_bf16_glds_enabled() {
   static const bool on = [] {
@@ -510,6 +515,19 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   sweep_gemm_plan(nqg, R0, ix->n_cus, k, &sp);
   sweep_gemm_plan(nqg, n, ix->n_cus, k, &fp);
   if (sp.lds > 160 * 1024 || fp.lds > 160 * 1024) return fail(VDB_ERR_UNSUPPORTED, "k too large for the fused top-k path");
+  // Unproven queries of a Cosine / DotProduct batch take the exact streaming matrix-core kernel in GATHERED mode (one corpus pass per
+  // g_B listed queries, none when nothing is listed).  Round 6: for ANY number of them — rounds 2-5 sent batches with more than 96 to a
+  // launch of the GEMM-structured kernel, which (with its merge) had to be enqueued for every batch to stand aside on the device: two
+  // launches less per batch; a batch with hundreds of unproven queries costs a few more corpus passes, and parks the handle anyway.
+  // (VELESDB_GATHER_ALL=0, probe builds: the old pair)
+  int g_nqt = 3;
+  while (g_nqt > 1 && sweep_mfma_lds_bytes(g_nqt, k, dim) > 160 * 1024) g_nqt--;
+  const bool gather_ok = sweep_mfma_lds_bytes(g_nqt, k, dim) <= 160 * 1024;
+  static const bool g_gather_all = [] {
+    const char* e = probe_env("VELESDB_GATHER_ALL");
+    return !(e && e[0] == '0');
+  }();
+  const bool gather_all = gather_ok && g_gather_all && !sq8 && !l2;
   // scratch map (s_seed)
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -522,12 +540,12 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
                o_n = take((size_t)nqg * 4), o_tau = take((size_t)nqg * 8), o_delta = take((size_t)nqg * 4),
                o_qn = take((size_t)nqg * 4), o_rho = take((size_t)nqg * 4), o_flags = take((size_t)nqg * 4 + 64 * 4 + 16), o_btau = take((size_t)nqg * lists * 8),
                o_fid = take((size_t)nqg * k * 8), o_fsc = take((size_t)nqg * k * 4), o_fn = take((size_t)nqg * 4),
-               o_qmap = take((size_t)nqg * 8), o_gid = take((size_t)96 * k * 8), o_gsc = take((size_t)96 * k * 4),
-               o_gn = take((size_t)96 * 4);
+               o_qmap = take((size_t)nqg * 8), o_gid = take((size_t)nqg * k * 8), o_gsc = take((size_t)nqg * k * 4),
+               o_gn = take((size_t)nqg * 4);
   hipError_t e;
   if ((e = ix->s_seed.reserve(off, false, st)) != hipSuccess ||
       (e = ix->s_part_keys.reserve((size_t)nqg * lists * ks * 8, false, st)) != hipSuccess ||
-      (!sq8 && !l2 && (e = ix->s_fb_keys.reserve((size_t)nqg * fp.G * k * 8, false, st)) != hipSuccess) ||
+      (!sq8 && !l2 && !gather_all && (e = ix->s_fb_keys.reserve((size_t)nqg * fp.G * k * 8, false, st)) != hipSuccess) ||
       (e = ix->s_misc.reserve(((size_t)nqg + 256) * (dim + 64) * 4 + (size_t)nqg * dim_s * 4, false, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, "split sweep scratch");
   unsigned char* sd = ix->s_seed.as<unsigned char>();
@@ -613,6 +631,9 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
   if (bf16_seed) {
     launch_seed_scores_bf16(sel_metric, img_rows, img_stride, sel_norms, alive, q16, img_stride, qnorms, ag.part_keys, R0, nqg,
                             l2 ? dim_a : dim, st);
+    if (!l2 && g_pool_select && R0 / 16 <= 256) {  // the bound straight from the sample keys: one launch (sweep_split.hip split_seed_sample_kernel)
+      launch_split_seed_sample(ix->metric, ag.part_keys, R0 / 16, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, dim, level, st, rho_q, rho_max);
+    } else {
     ms.n_lists = R0 / 16;  // one "list" of one key per 16 seed rows (their best): the selection merge picks the ks best
     ms.k = 1;
     ms.k_out = ks;
@@ -623,8 +644,11 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     else
       launch_split_seed_approx(ix->metric, m_ids, m_sc, m_n, qnorms, norm_max, tau0, delta, pool, blk_tau, lists, nqg, k, ks, kSeedIsSample, dim, level, st,
                                rho_q, rho_max);
+    }
   } else {
-  e = launch_sweep_gemm(sel_metric, sp, ag, st);
+  // (the exact seed scores the index' OWN metric over the f32 rows — Cosine stays Cosine when the selection runs as a DotProduct of
+  // normalised images; Euclidean: the DotProduct of the augmented prefix)
+  e = launch_sweep_gemm(l2 ? VDB_DOT : ix->metric, sp, ag, st);
   if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split seed sweep launch: ") + hipGetErrorString(e));
   ms.n_lists = sp.G;
   ms.k = k;
@@ -648,6 +672,10 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
         [&](int, uint32_t list_off, bool last) {
           if (evs) (void)hipEventRecord(evs->b, st);
           if (last) return;  // bound of the next launch: k-th best pool score so far (the lists written so far)
+          if (g_pool_select && pool_select_supported(list_off, ks, K2)) {  // ... by selection, not by a merge (pool_select.hip)
+            launch_pool_kth_reseed(pool, list_off, lists, ks, k, delta, tau0, nqg, st);
+            return;
+          }
           ms.part_keys = pool;
           ms.n_lists = list_off;
           ms.list_stride = lists;
@@ -662,12 +690,16 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("split selection launch: ") + hipGetErrorString(e));
   }
   // pool -> K2 best by pool score -> exact re-scoring, ranking, proof
-  ms.part_keys = pool;
-  ms.n_lists = lists;
-  ms.list_stride = 0;
-  ms.k = ks;
-  ms.k_out = K2;
-  launch_merge(true, ms, nqg, st);
+  if (g_pool_select && pool_select_supported(lists, ks, K2)) {
+    launch_pool_topk(pool, lists, lists, ks, K2, m_ids, m_sc, m_n, nqg, st);
+  } else {
+    ms.part_keys = pool;
+    ms.n_lists = lists;
+    ms.list_stride = 0;
+    ms.k = ks;
+    ms.k_out = K2;
+    launch_merge(true, ms, nqg, st);
+  }
   SplitRerankArgs ra{};
   ra.rows = ix->rows.as<float>();
   ra.norms = ix->norms.as<float>();
@@ -760,11 +792,9 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
     // makes ONE gathered corpus pass per 48 of them (0.9 ms; same mode-M bits).  More: the GEMM-structured kernel for the
     // query tiles that hold one (a tile costs the whole launch's duration: its row groups are all it parallelises over).
     // Both are launched; the one whose turn it is not exits at once.
-    constexpr uint32_t kFallbackGatherMax = 96;
-    const int g_nqt = 3, g_waves = kMfmaWaves2;
+    const uint32_t kFallbackGatherMax = gather_all ? nqg : 96u;
+    const int g_waves = g_nqt >= 2 ? kMfmaWaves2 : kMfmaWaves1;
     const uint32_t g_B = (uint32_t)g_nqt * 16;
-    const size_t g_lds = sweep_mfma_lds_bytes(g_nqt, k, dim);
-    const bool gather_ok = g_lds <= 160 * 1024;
     MergeArgs mg{};
     if (gather_ok) {
       const uint32_t ntiles16 = (n + 15) / 16;
@@ -786,7 +816,7 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
       am.qmap = qmap;
       am.qcount = qcount;
       am.qcount_max = kFallbackGatherMax;
-      e = launch_sweep_mfma(ix->metric, g_nqt, am, g_blocks, st, (int)(kFallbackGatherMax / g_B));
+      e = launch_sweep_mfma(ix->metric, g_nqt, am, g_blocks, st, (int)((kFallbackGatherMax + g_B - 1) / g_B));
       if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("gathered fallback launch: ") + hipGetErrorString(e));
       mg.part_keys = am.part_keys;
       mg.ext_ids = ix->ext_ids.as<uint64_t>();
@@ -796,40 +826,42 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
       mg.n_lists = (uint32_t)g_blocks;
       mg.k = k;
       mg.active = qcount;
-      mg.active_max = kFallbackGatherMax;
+      mg.active_max = gather_all ? 0u : kFallbackGatherMax;
       launch_merge(true, mg, kFallbackGatherMax, st);
       ag.qcount = qcount;
       ag.qcount_max = kFallbackGatherMax;
     }
-    ag.part_keys = ix->s_fb_keys.as<uint64_t>();
-    ag.n_rows = n;
-    ag.rows = ix->rows.as<float>();
-    e = launch_sweep_gemm(ix->metric, fp, ag, st, tile_needed);
-    if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("exact fallback launch: ") + hipGetErrorString(e));
-    MergeArgs mf{};
-    mf.part_keys = ag.part_keys;
-    mf.ext_ids = ix->ext_ids.as<uint64_t>();
-    mf.out_ids = reinterpret_cast<uint64_t*>(sd + o_fid);
-    mf.out_scores = reinterpret_cast<float*>(sd + o_fsc);
-    mf.out_n = reinterpret_cast<uint32_t*>(sd + o_fn);
-    mf.n_lists = fp.G;
-    mf.k = k;
-    mf.gate = flags;
-    if (gather_ok) {  // (the GEMM pass did not run for a batch the gathered pass answered: nothing to merge)
-      mf.skip_cnt = qcount;
-      mf.skip_le = kFallbackGatherMax;
+    if (!gather_all) {
+      ag.part_keys = ix->s_fb_keys.as<uint64_t>();
+      ag.n_rows = n;
+      ag.rows = ix->rows.as<float>();
+      e = launch_sweep_gemm(ix->metric, fp, ag, st, tile_needed);
+      if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("exact fallback launch: ") + hipGetErrorString(e));
+      MergeArgs mf{};
+      mf.part_keys = ag.part_keys;
+      mf.ext_ids = ix->ext_ids.as<uint64_t>();
+      mf.out_ids = reinterpret_cast<uint64_t*>(sd + o_fid);
+      mf.out_scores = reinterpret_cast<float*>(sd + o_fsc);
+      mf.out_n = reinterpret_cast<uint32_t*>(sd + o_fn);
+      mf.n_lists = fp.G;
+      mf.k = k;
+      mf.gate = flags;
+      if (gather_ok) {  // (the GEMM pass did not run for a batch the gathered pass answered: nothing to merge)
+        mf.skip_cnt = qcount;
+        mf.skip_le = kFallbackGatherMax;
+      }
+      launch_merge(true, mf, nqg, st);
+      fin.fb_ids = mf.out_ids;
+      fin.fb_scores = mf.out_scores;
+      fin.fb_n = mf.out_n;
     }
-    launch_merge(true, mf, nqg, st);
     // one launch: an unproven query takes the gathered pass's slot or, when that pass stood aside, the whole-tile fallback's
     if (gather_ok) {
-      fin.max_listed = kFallbackGatherMax;
+      fin.max_listed = gather_all ? 0u : kFallbackGatherMax;
       fin.g_ids = mg.out_ids;
       fin.g_scores = mg.out_scores;
       fin.g_n = mg.out_n;
     }
-    fin.fb_ids = mf.out_ids;
-    fin.fb_scores = mf.out_scores;
-    fin.fb_n = mf.out_n;
     launch_select_finish(fin, st);
   }
   ix->split_flags_off = o_flags;

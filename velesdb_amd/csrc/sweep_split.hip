@@ -27,6 +27,7 @@
 
 #include "vdb_device.hpp"
 #include "vdb_kernels.hpp"
+#include "vdb_block_select.hpp"
 
 namespace vdb {
 
@@ -478,6 +479,52 @@ void launch_split_seed_approx(int metric, const uint64_t* ids, const float* scor
   else
     hipLaunchKernelGGL((split_seed_approx_kernel<kDot>), dim3((nq + 255) / 256), dim3(256), 0, st, ids, scores, n, qnorms, norm_max_bits,
                        tau0, delta, list, blk_tau, list_stride, nq, k, klist, seed_rows, dim, level, rho_q, rho_max_bits);
+}
+
+// The same for a seed that is a SAMPLE (kSeedIsSample: one key per 16 seed rows, [nq][ngrp <= 256]), straight from the sample keys: the
+// k-th best of them by radix selection (vdb_block_select.hpp) instead of a merge to the ks best + the kernel above — one launch for two
+// (round 6; same tau / delta bits: the bound is a function of the k-th best score alone, pool slot 0 stays empty either way).
+template <int METRIC>
+__global__ __launch_bounds__(256) void split_seed_sample_kernel(const uint64_t* keys, uint32_t ngrp, const float* qnorms, const uint32_t* norm_max_bits,
+                                                                uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau, uint32_t list_stride,
+                                                                uint32_t k, uint32_t klist, uint32_t dim, int level, const float* rho_q,
+                                                                const uint32_t* rho_max_bits) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t ctl[2];
+  __shared__ uint32_t total;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  uint64_t key1[1];
+  key1[0] = tid < ngrp ? keys[(size_t)q * ngrp + tid] : kKeyInvalid;
+  if (tid == 0) total = 0;
+  __syncthreads();
+  if (key1[0] != kKeyInvalid) atomicAdd(&total, 1u);
+  __syncthreads();
+  const uint32_t valid = total;
+  const float eps = select_eps_q(dim, level, rho_q, rho_max_bits, q);
+  const float d = METRIC == kCosine ? eps * 1.001f + 4e-7f : eps * 1.001f * qnorms[q] * __uint_as_float(*norm_max_bits) + 1e-30f;
+  uint64_t t = kKeyInvalid;
+  if (valid >= k && k > 0) {  // (block-uniform)
+    const uint32_t hi = block_kth_hi<1>(key1, k, hist, ctl);
+    const float s = key_score<true>((uint64_t)hi << 32);
+    const float lowered = s - 2.0f * d * 1.01f - fabsf(s) * 1e-6f;  // approximate scores on both sides: 2 delta
+    t = lowered == lowered ? make_key<true>(lowered, 0u) : kKeyInvalid;  // NaN: no bound
+  }
+  if (tid == 0) {
+    delta[q] = d;
+    tau0[q] = t;
+    blk_tau[(size_t)q * list_stride] = kKeyInvalid;  // the seed rows are swept again: slot 0 holds nothing and excluded nothing
+  }
+  for (uint32_t e = tid; e < klist; e += 256) list[(size_t)q * list_stride * klist + e] = kKeyInvalid;
+}
+void launch_split_seed_sample(int metric, const uint64_t* keys, uint32_t ngrp, const float* qnorms, const uint32_t* norm_max_bits, uint64_t* tau0,
+                              float* delta, uint64_t* list, uint64_t* blk_tau, uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim,
+                              int level, hipStream_t st, const float* rho_q, const uint32_t* rho_max_bits) {
+  if (metric == kCosine)
+    hipLaunchKernelGGL((split_seed_sample_kernel<kCosine>), dim3(nq), dim3(256), 0, st, keys, ngrp, qnorms, norm_max_bits, tau0, delta, list, blk_tau,
+                       list_stride, k, klist, dim, level, rho_q, rho_max_bits);
+  else
+    hipLaunchKernelGGL((split_seed_sample_kernel<kDot>), dim3(nq), dim3(256), 0, st, keys, ngrp, qnorms, norm_max_bits, tau0, delta, list, blk_tau,
+                       list_stride, k, klist, dim, level, rho_q, rho_max_bits);
 }
 
 // Between two selection launches: the next launch's bound = k-th best POOL score so far (approximate scores, exact ones for

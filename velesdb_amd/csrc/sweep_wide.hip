@@ -20,6 +20,7 @@
 #include "vdb_device.hpp"
 #include "vdb_kernels.hpp"
 #include "vdb_wide.hpp"
+#include "vdb_block_select.hpp"
 
 namespace vdb {
 
@@ -29,49 +30,6 @@ __device__ __forceinline__ float wide_eps(uint32_t dim, const float* rho_q, cons
   if (!rho_q || !rho_max_bits) return 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f + acc;
   const float rm = __uint_as_float(*rho_max_bits), rq = rho_q[q];
   return (rm + rq + 3.0f * rm * rq) * 1.002f + acc + 4e-6f;  // (+ 4e-6: the normalised images' division by f32 norms; NaN query: NaN -> no bound)
-}
-
-// The k-th smallest of the block's keys by their HIGH words (the score keys; smaller = better): MSB-first radix select, 8 bits a
-// pass, histogram in LDS.  Every thread holds NPT keys in registers (kKeyInvalid = none); k >= 1 and at most the number of valid
-// keys; blockDim = 256.  Returns the high word of the k-th smallest key; *below = how many valid keys have a smaller high word.
-template <int NPT>
-__device__ uint32_t block_kth_hi(const uint64_t (&keys)[NPT], uint32_t k, uint32_t* hist, uint32_t* ctl) {
-  const uint32_t tid = threadIdx.x;
-  uint32_t prefix = 0, mask = 0, rem = k;
-#pragma unroll 1
-  for (int shift = 24; shift >= 0; shift -= 8) {
-    hist[tid] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NPT; j++) {
-      const uint32_t hi = (uint32_t)(keys[j] >> 32);
-      if (keys[j] != kKeyInvalid && (hi & mask) == prefix) atomicAdd(&hist[(hi >> shift) & 255u], 1u);
-    }
-    __syncthreads();
-    if (tid < 64) {  // lane l: bins 4 l .. 4 l + 3; inclusive prefix over the lanes
-      const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
-      const uint32_t s = c0 + c1 + c2 + c3;
-      uint32_t incl = s;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, 64);
-        if ((int)tid >= o) incl += up;
-      }
-      const uint32_t excl = incl - s;
-      if (excl < rem && rem <= incl) {  // exactly one lane (rem <= the number of matching keys)
-        uint32_t r = rem - excl, bin = 4 * tid;
-        if (r > c0) { r -= c0; bin++; if (r > c1) { r -= c1; bin++; if (r > c2) { r -= c2; bin++; } } }
-        ctl[0] = bin;
-        ctl[1] = r;
-      }
-    }
-    __syncthreads();
-    prefix |= ctl[0] << shift;
-    mask |= 255u << shift;
-    rem = ctl[1];
-    __syncthreads();  // (hist and ctl are rewritten by the next pass)
-  }
-  return prefix;
 }
 
 // the bound a k-th best approximate score s_k yields: tau = s_k - 2 delta (both sides approximate), as a key of row 0 — a row passes

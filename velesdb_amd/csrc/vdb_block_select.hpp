@@ -1,0 +1,81 @@
+// vdb_block_select.hpp — selection of the k-th smallest key inside one 256-thread block whose keys sit in REGISTERS (device code;
+// sweep_wide.hip's lists, pool_select.hip's pools): MSB-first radix select, 8 bits a pass, one 256-bin histogram in LDS — 3 barriers a
+// pass, whatever the number of keys.  (The merge kernels of sweep.hip select bit by bit or extract key by key: one barrier per key
+// bit or per extracted key — 28 us for the 2 570 keys between two launches of a headline step, profiles/r05final2_*.)
+#pragma once
+#include "vdb_device.hpp"
+
+namespace vdb {
+
+// one pass: the bin (of the byte at `shift`, among the keys whose word matches `prefix` under `mask`) that holds the rem-th smallest,
+// and what is left of rem inside that bin.  word(j) = the 32-bit word of key j the pass works on; live(j) = key j takes part.
+template <int NPT, class Word, class Live>
+__device__ __forceinline__ void block_select_pass(Word&& word, Live&& live, uint32_t mask, uint32_t prefix, int shift, uint32_t& rem, uint32_t& bin_out,
+                                                  uint32_t* hist, uint32_t* ctl) {
+  const uint32_t tid = threadIdx.x;
+  hist[tid] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NPT; j++) {
+    const uint32_t w = word(j);
+    if (live(j) && (w & mask) == prefix) atomicAdd(&hist[(w >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (tid < 64) {  // lane l: bins 4 l .. 4 l + 3; inclusive prefix over the lanes
+    const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+    const uint32_t s = c0 + c1 + c2 + c3;
+    uint32_t incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o, 64);
+      if ((int)tid >= o) incl += up;
+    }
+    const uint32_t excl = incl - s;
+    if (excl < rem && rem <= incl) {  // exactly one lane (rem <= the number of matching keys)
+      uint32_t r = rem - excl, bin = 4 * tid;
+      if (r > c0) { r -= c0; bin++; if (r > c1) { r -= c1; bin++; if (r > c2) { r -= c2; bin++; } } }
+      ctl[0] = bin;
+      ctl[1] = r;
+    }
+  }
+  __syncthreads();
+  bin_out = ctl[0];
+  rem = ctl[1];
+  __syncthreads();  // (hist and ctl are rewritten by the next pass)
+}
+
+// The k-th smallest of the block's keys by their HIGH words (the score keys; smaller = better).  Every thread holds NPT keys
+// (kKeyInvalid = none); 1 <= k <= the number of valid keys; blockDim = 256; hist = 256 words, ctl = 2 words of LDS.  Returns the high
+// word of the k-th smallest key; *rem_out (nullable) = the k-th key's position among the keys that share that high word (1-based).
+template <int NPT>
+__device__ uint32_t block_kth_hi(const uint64_t (&keys)[NPT], uint32_t k, uint32_t* hist, uint32_t* ctl, uint32_t* rem_out = nullptr) {
+  uint32_t prefix = 0, mask = 0, rem = k;
+#pragma unroll 1
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    uint32_t bin;
+    block_select_pass<NPT>([&](int j) { return (uint32_t)(keys[j] >> 32); }, [&](int j) { return keys[j] != kKeyInvalid; }, mask, prefix, shift, rem, bin, hist, ctl);
+    prefix |= bin << shift;
+    mask |= 255u << shift;
+  }
+  if (rem_out) *rem_out = rem;
+  return prefix;
+}
+// the k-th smallest KEY, all 64 bits (keys are unique: the low word is the row): four more passes over the low words of the keys that
+// share the k-th key's high word — skipped when that high word belongs to one key only
+template <int NPT>
+__device__ uint64_t block_kth_key(const uint64_t (&keys)[NPT], uint32_t k, uint32_t* hist, uint32_t* ctl) {
+  uint32_t rem;
+  const uint32_t hi = block_kth_hi<NPT>(keys, k, hist, ctl, &rem);
+  uint32_t prefix = 0, mask = 0;
+#pragma unroll 1
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    uint32_t bin;
+    block_select_pass<NPT>([&](int j) { return (uint32_t)keys[j]; }, [&](int j) { return keys[j] != kKeyInvalid && (uint32_t)(keys[j] >> 32) == hi; }, mask, prefix,
+                           shift, rem, bin, hist, ctl);
+    prefix |= bin << shift;
+    mask |= 255u << shift;
+  }
+  return ((uint64_t)hi << 32) | prefix;
+}
+
+}  // namespace vdb

@@ -314,6 +314,17 @@ void launch_split_seed_approx(int metric, const uint64_t* ids, const float* scor
                               const uint32_t* norm_max_bits, uint64_t* tau0, float* delta, uint64_t* list, uint64_t* blk_tau,
                               uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t seed_rows, uint32_t dim, int level,
                               hipStream_t st, const float* rho_q = nullptr, const uint32_t* rho_max_bits = nullptr);
+// pool_select.hip: the next launch's bound / the K2 best of a candidate pool [nq][list_stride][ks] by radix selection, without a merge
+// (supported: <= 12 288 keys in the first n_lists lists of a query, k2 <= 128)
+bool pool_select_supported(uint32_t n_lists, uint32_t ks, uint32_t k2);
+void launch_pool_kth_reseed(const uint64_t* pool, uint32_t n_lists, uint32_t list_stride, uint32_t ks, uint32_t k, const float* delta, uint64_t* tau0,
+                            uint32_t nq, hipStream_t st);
+void launch_pool_topk(const uint64_t* pool, uint32_t n_lists, uint32_t list_stride, uint32_t ks, uint32_t k2, uint64_t* out_ids, float* out_scores,
+                      uint32_t* out_n, uint32_t nq, hipStream_t st);
+// the same straight from a SAMPLE seed's keys [nq][ngrp <= 256] (no merge in front): tau from their k-th best, delta, an empty pool slot 0
+void launch_split_seed_sample(int metric, const uint64_t* keys, uint32_t ngrp, const float* qnorms, const uint32_t* norm_max_bits, uint64_t* tau0,
+                              float* delta, uint64_t* list, uint64_t* blk_tau, uint32_t list_stride, uint32_t nq, uint32_t k, uint32_t klist, uint32_t dim,
+                              int level, hipStream_t st, const float* rho_q = nullptr, const uint32_t* rho_max_bits = nullptr);
 void launch_split_reseed(const uint64_t* ids, const float* scores, const uint32_t* n, const float* delta, uint64_t* tau0,
                          uint32_t nq, uint32_t k, uint32_t kout, hipStream_t st);
 void launch_split_rerank(int metric, const SplitRerankArgs& a, uint32_t nq, hipStream_t st);

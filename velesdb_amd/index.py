@@ -530,7 +530,8 @@ class HnswIndex:
         return tuple(int(x.value) for x in v)
 
     def last_select_level(self) -> int:
-        """Selection level (0 / 1 / 2) the last exact batch of this handle ran at."""
+        """Selection level the last exact batch of this handle ran at: 0 = exact kernels, 1 = split-bf16, 2 = plain bf16 (Cosine: normalised
+        images), 3 = the SQ8 storage mode's, 4 = the WIDE selection of 10 < k <= 128 (csrc/sweep_wide.hip)."""
         v = C.c_int32(0)
         check(lib().vdb_hip_index_last_select_level(self._h, C.byref(v)))
         return int(v.value)
