@@ -19,6 +19,7 @@ run fuzz_sweep_valu 60 tools/fuzz_sweep.py --engine 0
 run fuzz_sweep_big 90 tools/fuzz_sweep.py --big
 run fuzz_sweep_euclid 80 tools/fuzz_sweep.py --euclid
 run fuzz_sweep_select 150 tools/fuzz_sweep.py --select
+run fuzz_sweep_wide 150 tools/fuzz_sweep.py --wide
 run fuzz_sweep_bf16_big 80 tools/fuzz_sweep.py --bf16-big
 run fuzz_sweep_bits 60 tools/fuzz_sweep.py --bits
 run fuzz_sweep_bits_big 100 tools/fuzz_sweep.py --bits-big

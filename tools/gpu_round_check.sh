@@ -9,7 +9,9 @@ if [ -z "$SKIP_TESTS" ]; then
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 tail -5 $O/pytest_gpu.log
 fi
-timeout 1200 python bench.py > $O/bench_line.json 2> $O/bench.err; echo "bench rc=$?"
+SECONDS=0
+timeout 1200 python bench.py > $O/bench_line.json 2> $O/bench.err; echo "bench rc=$? wall ${SECONDS}s" | tee -a $O/bench.err
+cp bench_legs.json $O/bench_legs_1gpu.json
 tail -c 2500 $O/bench_line.json
 tail -5 $O/bench.err
 cd /tmp

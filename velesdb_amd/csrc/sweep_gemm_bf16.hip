@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_glds(Bf16GemmArgs
   uint32_t* cnts = reinterpret_cast<uint32_t*>(smem + kOffCnts);   // [BN]
   float* qn = reinterpret_cast<float*>(smem + kOffQn);             // [BN] query norms (cosine)
   float* vns = reinterpret_cast<float*>(smem + kOffVns);           // [BM] norms of the current row tile
-  // [0] / [3] again (even / odd rounds), [1] need, [2] last-again.  An LDS-typed pointer: a volatile access through a generic pointer is a FLAT instruction,
+  // [0] again (the latest round marked), [1] need, [2] last-again.  An LDS-typed pointer: a volatile access through a generic pointer is a FLAT instruction,
   // which counts on vmcnt as well — its wait drained every LDS-DMA request in flight, once per flag read
   volatile lds_u32_t* flags = (volatile lds_u32_t*)(lds_ptr_t)(smem + kOffFlags);
 
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void sweep_topk_gemm_bf16_pp(Bf16GemmArgs a
   uint32_t* cnts = reinterpret_cast<uint32_t*>(smem + kOffCnts);   // [BN]
   float* qn = reinterpret_cast<float*>(smem + kOffQn);             // [BN] query norms (cosine)
   float* vns = reinterpret_cast<float*>(smem + kOffVns);           // [BM] norms of the current row tile
-  // [0] / [3] again (even / odd rounds), [1] need, [2] last-again.  An LDS-typed pointer: a volatile access through a generic pointer is a FLAT instruction,
+  // [0] again (the latest round marked), [1] need, [2] last-again.  An LDS-typed pointer: a volatile access through a generic pointer is a FLAT instruction,
   // which counts on vmcnt as well — its wait drained every LDS-DMA request in flight, once per flag read
   volatile lds_u32_t* flags = (volatile lds_u32_t*)(lds_ptr_t)(smem + kOffFlags);
 
