@@ -378,7 +378,7 @@ int32_t vdb_hip_set_sweep_engine(int32_t engine);
  *       the wider bound (> 1/16 of a batch unproven: near-duplicate clusters) moves itself to level 1 for the next 64
  *       batches and then tries again.  Cosine (round 6): the image holds the NORMALISED rows v / |v| and the batch the
  *       normalised queries, so the selection is a DotProduct of unit vectors (no row norm in the kernel's bound).
- * 10 < k <= 128 (round 6; Cosine / DotProduct, level 2's eligibility): the WIDE selection — no block-local top-k at all:
+ * 10 < k <= 128 (round 6; Cosine / DotProduct / Euclidean, level 2's eligibility): the WIDE selection — no block-local top-k at all:
  * every row whose approximate score passes the query's bound (k-th best approximate score seen so far - 2 x the error
  * bound, raised between the launches of the batch) becomes a candidate, all of them are re-scored exactly; a query is
  * unproven only when its candidate list overflows (4 096 per launch, 1 024 at the end) or its data is not finite.

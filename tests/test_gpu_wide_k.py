@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 va = pytest.importorskip("velesdb_amd")
 DM = va.DistanceMetric
-PO = {DM.Cosine: po.COSINE, DM.DotProduct: po.DOT}
+PO = {DM.Cosine: po.COSINE, DM.DotProduct: po.DOT, DM.Euclidean: po.EUCLIDEAN}
 LEVEL_WIDE = 4
 
 
@@ -138,3 +138,40 @@ def test_wide_k_parks_itself_when_the_data_defeats_it(gpu_required):
         assert np.array_equal(ids, eid) and np.array_equal(bits(sc), bits(esc))
     assert levels[0] == LEVEL_WIDE and levels[-1] == 0, levels
     ix.close()
+
+
+def test_wide_k_euclidean_vs_oracle(corpus):
+    """Euclidean batches at k > 10 through the same WIDE selection over the augmented DotProduct form s = q.v - |v|^2 / 2
+    (sweep_split.hip): candidates re-scored with the canonical (q - v)^2 chain (oracle mode C — the bits a single query gets), the
+    proof checked per query in the squared-distance domain; near-duplicates of a query (distances far below the form's error bound)
+    leave the proof to the gathered exact pass."""
+    rows, qs = corpus
+    rows = rows.copy()
+    rows[500:540] = qs[5] + 1e-3 * np.random.default_rng(3).standard_normal((40, 768)).astype(np.float32)   # 40 near-copies of query 5
+    ix = va.HnswIndex(768, DM.Euclidean)
+    ix.upload(np.arange(len(rows), dtype=np.uint64), rows)
+    for k, nq in ((11, 96), (50, 300), (100, 64), (128, 17)):
+        ids, sc, cnt = ix.search_batch_brute_force(qs[:nq], k)
+        assert ix.last_select_level() == LEVEL_WIDE, (k, ix.last_select_level())
+        eid, esc = po.scan_topk(po.EUCLIDEAN, rows, qs[:nq], k, po.MODE_C, nthreads=po.host_threads())
+        assert np.all(cnt == k)
+        assert np.array_equal(ids, eid), f"Euclidean ids / ranks differ from the oracle (mode C) at k = {k}"
+        assert np.array_equal(bits(sc), bits(esc)), f"Euclidean score bits differ from the oracle at k = {k}"
+    nq_l, unproven = ix.last_split_stats()
+    # one query alone (the canonical vector-ALU kernel) gives the same bits as the batch
+    one, s1, _ = ix.search_batch_brute_force(qs[3:4], 50)
+    many, sm, _ = ix.search_batch_brute_force(qs[:64], 50)
+    assert np.array_equal(one[0], many[3]) and np.array_equal(bits(s1[0]), bits(sm[3]))
+    ix.close()
+    # other dims, a ragged corpus, a full query tile
+    rng = np.random.default_rng(17)
+    for dim, n, nq, k in ((128, 70_077, 256, 20), (256, 66_000, 300, 64)):
+        r2 = rng.standard_normal((n, dim), dtype=np.float32)
+        q2 = rng.standard_normal((nq, dim), dtype=np.float32)
+        ix = va.HnswIndex(dim, DM.Euclidean)
+        ix.upload(np.arange(n, dtype=np.uint64), r2)
+        ids, sc, cnt = ix.search_batch_brute_force(q2, k)
+        assert ix.last_select_level() == LEVEL_WIDE
+        eid, esc = po.scan_topk(po.EUCLIDEAN, r2, q2, k, po.MODE_C, nthreads=po.host_threads())
+        assert np.array_equal(ids, eid) and np.array_equal(bits(sc), bits(esc)), (dim, n, nq, k)
+        ix.close()

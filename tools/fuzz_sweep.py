@@ -26,7 +26,7 @@ p.add_argument("--seed", type=int, default=1)
 p.add_argument("--big", action="store_true", help="few cases over 100K-400K rows (many row tiles / groups per wave and block)")
 p.add_argument("--select", action="store_true", help="batches that take the selection stage (>= 224 queries, >= 65 536 rows, "
                "k <= 10; levels 1 and 2 at random) incl. data built to defeat the proofs (gathered / GEMM fallbacks, level parking)")
-p.add_argument("--wide", action="store_true", help="round 6: --select's shapes and data at 10 < k <= 128 (the WIDE selection, sweep_wide.hip; Cosine / DotProduct)")
+p.add_argument("--wide", action="store_true", help="round 6: --select's shapes and data at 10 < k <= 128 (the WIDE selection, sweep_wide.hip; Cosine / DotProduct / Euclidean)")
 p.add_argument("--bf16-big", action="store_true", help="bf16 result batches that the 256 x 256 LDS-DMA kernel serves (>= 65 536 rows, "
                ">= 224 queries, k <= 10 — BASELINE configs[3]'s kernel), asserted through last_kernels()")
 p.add_argument("--engine", type=int, default=1, help="0 = vector-ALU kernels for cosine / dot too")
@@ -108,6 +108,8 @@ while time.time() < t_end:
         nq = int(rng.choice([16, 17, 64, 100, 230, 256, 300, 513, 620, 1000, 1024]))
         k = int(rng.choice([11, 12, 20, 33, 50, 64, 65, 100, 127, 128]))
         kind = str(rng.choice(["normal", "normal", "dups", "small_ints", "ascending", "zeros_mixed", "clusters"]))
+        if rng.random() < 0.3:
+            metric = DM.Euclidean  # the augmented DotProduct form, canonical re-scoring, the proof checked per query
     if a.bits_big:
         a.bits = True
         bf16 = False

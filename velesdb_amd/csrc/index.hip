@@ -629,7 +629,7 @@ static int32_t brute_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride,
     // large Cosine / DotProduct batches over a large corpus: split-bf16 selection + exact re-scoring + proof (same bits
     // as the exact matrix-core kernel below, which remains the fallback for unproven queries and every other shape)
     // ... and with 10 < k <= 128: the WIDE selection (sweep_wide.hip) — no block-local lists, every row above the bound is a candidate
-    if (mfma_nqt && select_level_wide(ix, nq - q0, k)) {
+    if ((mfma_nqt || ix->metric == VDB_EUCLIDEAN) && q0 >= euclid_skip_until && select_level_wide(ix, nq - q0, k)) {
       const uint32_t nqg = select_chunk(nq - q0);
       const int32_t rcw = brute_wide_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nqg, k, d_ids + (size_t)q0 * k, d_scores + (size_t)q0 * k, d_n + q0, st);
       if (rcw != VDB_OK) return rcw;

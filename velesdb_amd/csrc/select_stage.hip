@@ -877,10 +877,10 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
 // the same eligibility as level 2 (the bf16 image of the rows, whole 64-element k-tiles), its own park-after-failure state
 int select_level_wide(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
   if (opt_selector(ix) < 2 || opt_engine(ix) != 1 || opt_max_tile(ix) < 128) return 0;
-  if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT) return 0;
+  if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT && ix->metric != VDB_EUCLIDEAN) return 0;
   if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
   if (k <= kGemmBf16MaxK || k > kWideMaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
-  if (sweep_mfma_lds_bytes(1, k, ix->dim) > 160 * 1024) return 0;  // (the gathered exact pass of the unproven queries)
+  if (ix->metric != VDB_EUCLIDEAN && sweep_mfma_lds_bytes(1, k, ix->dim) > 160 * 1024) return 0;  // (the gathered exact pass of the unproven queries)
   if (!select_chunk(nq_left)) return 0;
   if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
     ix->sel_seq_seen = ix->sel_stats[2];
@@ -896,12 +896,15 @@ int select_level_wide(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
 int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, uint64_t* d_ids, float* d_scores,
                        uint32_t* d_n, hipStream_t st) {
   const bool cosn = cosine_normalised(ix);  // Cosine: both sides normalised before the rounding, the DotProduct instance selects
-  const int sel_metric = cosn ? VDB_DOT : ix->metric;
-  int32_t rc = cosn ? ensure_cosn(ix, st) : ensure_sel16(ix, st);
+  const bool l2 = ix->metric == VDB_EUCLIDEAN;  // the augmented DotProduct form s = q.v - |v|^2 / 2 (sweep_split.hip), images of dim + 64 columns
+  const int sel_metric = (cosn || l2) ? VDB_DOT : ix->metric;
+  int32_t rc = l2 ? ensure_l2_select(ix, st) : (cosn ? ensure_cosn(ix, st) : ensure_sel16(ix, st));
   if (rc != VDB_OK) return rc;
-  const uint16_t* img_rows = cosn ? ix->cosn_img.as<uint16_t>() : ix->rows_bf16.as<uint16_t>();
-  const uint64_t img_stride = cosn ? (uint64_t)ix->dim : ix->bf16_stride;
-  const DevBuf& rho_buf = cosn ? ix->cosn_rho : ix->bf16_rho;
+  const uint32_t dim_a = ix->dim + 64, dim_s = ix->dim + 4;
+  const uint16_t* img_rows = l2 ? ix->l2_img.as<uint16_t>() : (cosn ? ix->cosn_img.as<uint16_t>() : ix->rows_bf16.as<uint16_t>());
+  const uint64_t img_stride = l2 ? (uint64_t)dim_a : (cosn ? (uint64_t)ix->dim : ix->bf16_stride);
+  const DevBuf& rho_buf = l2 ? ix->l2_rho : (cosn ? ix->cosn_rho : ix->bf16_rho);
+  const uint32_t sel_dim = l2 ? dim_a : ix->dim;  // the k-extent the selection kernel and the seed contract over
   ix->last_select_level = 4;
   ix->last_kernels |= VDB_KERNEL_SELECT_BF16;
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
@@ -912,13 +915,15 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
     const uint32_t head[3] = {1u, 4u, 16u};  // tiles per row group of the first launches, as the k <= 10 stage (brute_split_dev)
     gemm_schedule(nqg, 0, n, ix->n_cus, head, 0, &sch);
   }
-  // the gathered exact pass of the unproven queries: the streaming matrix-core kernel, as many 16-query tiles per pass as k leaves room for
+  // the gathered exact pass of the unproven queries: the streaming matrix-core kernel, as many 16-query tiles per pass as k leaves room
+  // for (Euclidean: the canonical vector-ALU sweep, 8 queries per pass)
   int g_nqt = 3;
   while (g_nqt > 1 && sweep_mfma_lds_bytes(g_nqt, k, dim) > 160 * 1024) g_nqt--;
   const int g_waves = g_nqt >= 2 ? kMfmaWaves2 : kMfmaWaves1;
-  const uint32_t g_B = (uint32_t)g_nqt * 16;
+  const uint32_t g_B = l2 ? 8u : (uint32_t)g_nqt * 16;
   const uint32_t ntiles16 = (n + 15) / 16;
-  const int g_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ntiles16 + g_waves - 1) / g_waves, (int64_t)ix->n_cus));
+  const int g_blocks = l2 ? blocks_for(ix, 8, (n + 7) / 8)
+                          : (int)std::max<int64_t>(1, std::min<int64_t>(((int64_t)ntiles16 + g_waves - 1) / g_waves, (int64_t)ix->n_cus));
   size_t off = 0;
   auto take = [&](size_t bytes) {
     const size_t o = off;
@@ -927,12 +932,13 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
   };
   const size_t o_tau = take((size_t)nqg * 8), o_delta = take((size_t)nqg * 4), o_qn = take((size_t)nqg * 4), o_rho = take((size_t)nqg * 4),
                o_cnt = take((size_t)nqg * 4), o_state = take((size_t)nqg * 4), o_flags = take((size_t)nqg * 4 + 16), o_qmap = take((size_t)nqg * 8),
-               o_gid = take((size_t)nqg * k * 8), o_gsc = take((size_t)nqg * k * 4), o_gn = take((size_t)nqg * 4), o_nmax = take(16);
+               o_gid = take((size_t)nqg * k * 8), o_gsc = take((size_t)nqg * k * 4), o_gn = take((size_t)nqg * 4), o_nmax = take(16),
+               o_extra = take((size_t)nqg * 4);
   hipError_t e;
   if ((e = ix->s_seed.reserve(off, false, st)) != hipSuccess || (e = ix->s_fb_keys.reserve((size_t)nqg * kWideCap * 8, false, st)) != hipSuccess ||
       (e = ix->s_part_keys.reserve((size_t)nqg * ngrp * 8, false, st)) != hipSuccess ||
       (e = ix->s_part_cnt.reserve((size_t)nqg * g_blocks * k * 8, false, st)) != hipSuccess ||
-      (e = ix->s_misc.reserve(((size_t)nqg + 256) * img_stride * 2, false, st)) != hipSuccess)
+      (e = ix->s_misc.reserve(((size_t)nqg + 256) * img_stride * 2 + (l2 ? (size_t)nqg * dim_s * 4 + 16 : 0), false, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, "wide selection scratch");
   unsigned char* sd = ix->s_seed.as<unsigned char>();
   uint16_t* q16 = ix->s_misc.as<uint16_t>();
@@ -946,10 +952,23 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
   EventPair* ev = next_events(ix);
   if (ev) (void)hipEventRecord(ev->a, st);
   // queries: bf16 image rows, canonical norms, rounding residuals, cleared flag words — one launch; whole 256-query tiles are staged
-  if (cosn) launch_seln_prep_queries(d_q, q_stride, q16, img_stride, qnorms, rho_q, flags, nqg + 4, nqg, dim, st);
+  if (l2) {
+    float* qaug = reinterpret_cast<float*>(ix->s_misc.as<unsigned char>() + ((((size_t)nqg + 256) * img_stride * 2 + 15) & ~(size_t)15));  // (written, unused here: the exact seed's operand)
+    launch_l2_augment_queries(d_q, q_stride, q16, dim_a, qaug, dim_s, nqg, dim, st);
+    if (rho_q) launch_query_round_error(d_q, q_stride, rho_q, nqg, dim, st);
+    PrepArgs pq{};
+    pq.rows = d_q;
+    pq.norms = qnorms;
+    pq.row_stride = q_stride;
+    pq.n_rows = nqg;
+    pq.dim = dim;
+    pq.words = ix->words;
+    launch_prep_rows(pq, st);
+    VDB_HIP(hipMemsetAsync(flags, 0, (size_t)nqg * 4 + 16, st));
+  } else if (cosn) launch_seln_prep_queries(d_q, q_stride, q16, img_stride, qnorms, rho_q, flags, nqg + 4, nqg, dim, st);
   else launch_sel16_prep_queries(d_q, q_stride, q16, img_stride, qnorms, rho_q, flags, nqg + 4, nqg, dim, st);
   if (nqg % 256u) VDB_HIP(hipMemsetAsync(q16 + (size_t)nqg * img_stride, 0, (size_t)256 * img_stride * 2, st));
-  if (ix->metric == VDB_DOT) launch_max_norm(ix->norms.as<float>(), n, norm_max, st);
+  if (ix->metric == VDB_DOT || l2) launch_max_norm(ix->norms.as<float>(), n, norm_max, st);
   WideArgs wa{};
   wa.keys = ix->s_fb_keys.as<uint64_t>();
   wa.cnt = reinterpret_cast<uint32_t*>(sd + o_cnt);
@@ -960,18 +979,20 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
   wa.rho_q = rho_q;
   wa.rho_max_bits = rho_q ? rho_buf.as<uint32_t>() : nullptr;
   wa.norm_max_bits = norm_max;
+  wa.extra = l2 ? reinterpret_cast<float*>(sd + o_extra) : nullptr;
   wa.cap = kWideCap;
   wa.k = k;
   wa.dim = dim;
   // seed: a sample of the first rows on the bf16 pipe (one key per 16 rows), its k-th best -> the first bound
   launch_seed_scores_bf16(sel_metric, img_rows, img_stride, ix->norms.as<float>(), alive, q16, img_stride, qnorms, ix->s_part_keys.as<uint64_t>(), R0,
-                          nqg, dim, st);
-  launch_wide_seed(ix->metric, wa, ix->s_part_keys.as<uint64_t>(), ngrp, nqg, st);
+                          nqg, sel_dim, st);
+  if (l2) launch_wide_seed_l2(wa, ix->s_part_keys.as<uint64_t>(), ngrp, dim_a, nqg, st);
+  else launch_wide_seed(ix->metric, wa, ix->s_part_keys.as<uint64_t>(), ngrp, nqg, st);
   for (int j = 0; j < sch.n_launch; j++) {
     EventPair* evs = next_sel_events(ix);
     if (evs) (void)hipEventRecord(evs->a, st);
     e = launch_sweep_gemm_bf16_wide(sel_metric, sch.bp[j], img_rows, img_stride, ix->norms.as<float>(), alive, q16, img_stride, wa.tau, wa.keys, wa.cnt,
-                                    wa.cap, dim, nqg, st, qnorms);
+                                    wa.cap, sel_dim, nqg, st, qnorms);
     if (evs) (void)hipEventRecord(evs->b, st);
     if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("wide selection launch: ") + hipGetErrorString(e));
     launch_wide_reseed(wa, nqg, st);  // (behind the last launch: the final bound and the pool)
@@ -991,7 +1012,8 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
   wo.row_stride = ix->row_stride;
   wo.q_stride = q_stride;
   wo.dim_pad = (dim + 127) / 128 * 128;
-  launch_wide_rerank(ix->metric, wa, wo, nqg, st);
+  if (l2) launch_wide_rerank_l2(wa, wo, nqg, st);
+  else launch_wide_rerank(ix->metric, wa, wo, nqg, st);
   // unproven queries (an overflowed list, a pool beyond one block, non-finite data): listed on the device, answered by the exact
   // streaming kernel in gathered mode — one corpus pass per g_B listed queries, none when nothing is listed
   SweepArgs am{};
@@ -1009,8 +1031,12 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
   am.qmap = qmap;
   am.qcount = qcount;
   am.qcount_max = nqg;
-  e = launch_sweep_mfma(ix->metric, g_nqt, am, g_blocks, st, (int)((nqg + g_B - 1) / g_B));
-  if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("gathered fallback launch: ") + hipGetErrorString(e));
+  if (l2) {
+    launch_sweep_f32(VDB_EUCLIDEAN, 8, am, g_blocks, st, (int)((nqg + 7) / 8));
+  } else {
+    e = launch_sweep_mfma(ix->metric, g_nqt, am, g_blocks, st, (int)((nqg + g_B - 1) / g_B));
+    if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("gathered fallback launch: ") + hipGetErrorString(e));
+  }
   MergeArgs mg{};
   mg.part_keys = am.part_keys;
   mg.ext_ids = ix->ext_ids.as<uint64_t>();
@@ -1020,7 +1046,7 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
   mg.n_lists = (uint32_t)g_blocks;
   mg.k = k;
   mg.active = qcount;
-  launch_merge(true, mg, nqg, st);
+  launch_merge(!l2, mg, nqg, st);
   SelectFinishArgs fin{};
   fin.flags = flags;
   fin.qcount = qcount;

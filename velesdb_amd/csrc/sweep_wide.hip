@@ -34,8 +34,8 @@ __device__ __forceinline__ float wide_eps(uint32_t dim, const float* rho_q, cons
 
 // the bound a k-th best approximate score s_k yields: tau = s_k - 2 delta (both sides approximate), as a key of row 0 — a row passes
 // `key < tau` when its score is above it.  No bound (NaN / inf arithmetic): the query is given up (sweep_wide.hip header)
-__device__ __forceinline__ uint64_t wide_tau_key(float s_k, float delta, bool* ok) {
-  const float lowered = s_k - 2.0f * delta * 1.01f - fabsf(s_k) * 1e-6f;
+__device__ __forceinline__ uint64_t wide_tau_key(float s_k, float delta, bool* ok, float extra = 0.0f) {
+  const float lowered = s_k - 2.0f * delta * 1.01f - extra - fabsf(s_k) * 1e-6f;
   *ok = lowered == lowered && fabsf(lowered) < 3.0e38f;
   return make_key<true>(lowered, 0u);
 }
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void wide_reseed_kernel(WideArgs a) {
   if (raw < a.k) return;  // fewer than k rows passed so far: the bound stays (it is valid for any set of rows)
   const uint32_t hi = block_kth_hi<NPT>(keys, a.k, hist, ctl);
   bool ok;
-  uint64_t tau = wide_tau_key(key_score<true>((uint64_t)hi << 32), a.delta[q], &ok);
+  uint64_t tau = wide_tau_key(key_score<true>((uint64_t)hi << 32), a.delta[q], &ok, a.extra ? a.extra[q] : 0.0f);
   if (!ok) {
     if (tid == 0) {
       a.state[q] |= kWideGivenUp;
@@ -256,6 +256,144 @@ __global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArg
   }
 }
 
+// ---- Euclidean batches: the augmented DotProduct form (sweep_split.hip: s = q.v - |v|^2 / 2 as a dot product of (v, -h_hi, -h_lo) and
+// (q, 1, 1)); the nearest rows are the rows with the largest s.  Error of a selection score against the true s: delta = eps |q| max|v|
+// (the bf16 roundings, measured residuals) + (2^-16 + acc) max h (l2_seed_kernel's formula).  The exact answer is ranked by the
+// CANONICAL squared sums (mode C: lane chains + butterfly), which differ from |q|^2 - 2 s_true by at most
+// slack = 8 dim 2^-24 (|q|^2 + max|v|^2): the bound is lowered by slack on top of 2 delta (in s: half of it would do), and the proof
+// is CHECKED per query in the squared-distance domain as l2_rerank_verify checks it — (E_k + slack) < |q|^2 - 2 (tau + delta) — instead
+// of holding by construction.
+__global__ __launch_bounds__(256) void wide_seed_l2_kernel(WideArgs a, const uint64_t* seed_keys, uint32_t ngrp, uint32_t dim_a) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t ctl[2];
+  __shared__ uint32_t total;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  constexpr int NPT = kWideSeedGroups / 256;
+  uint64_t keys[NPT];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int j = 0; j < NPT; j++) {
+    const uint32_t i = tid + 256u * (uint32_t)j;
+    keys[j] = i < ngrp ? seed_keys[(size_t)q * ngrp + i] : kKeyInvalid;
+    mine += keys[j] != kKeyInvalid ? 1u : 0u;
+  }
+  if (tid == 0) total = 0;
+  __syncthreads();
+  if (mine) atomicAdd(&total, mine);
+  __syncthreads();
+  const uint32_t valid = total;
+  const float nmax = __uint_as_float(*a.norm_max_bits), hmax = 0.5f * nmax * nmax, qn = a.qnorms[q];
+  const float acc = 16.0f * (float)dim_a * 5.9604645e-8f;
+  float eps_r = 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f + acc;
+  if (a.rho_q && a.rho_max_bits) {
+    const float rm = __uint_as_float(*a.rho_max_bits), rq = a.rho_q[q];
+    eps_r = (rm + rq + 3.0f * rm * rq) * 1.002f + acc;
+  }
+  const float d = eps_r * 1.001f * qn * nmax + (1.6e-5f + acc) * hmax + 1e-30f;
+  const float slack = 8.0f * (float)a.dim * 5.9604645e-8f * (qn * qn + nmax * nmax) * 1.01f + 1e-30f;
+  bool ok = valid >= a.k && d == d && slack == slack;
+  uint64_t tau = wide_tau_closed();
+  if (ok) {
+    const uint32_t hi = block_kth_hi<NPT>(keys, a.k, hist, ctl);
+    tau = wide_tau_key(key_score<true>((uint64_t)hi << 32), d, &ok, slack);
+    if (!ok) tau = wide_tau_closed();
+  }
+  if (tid == 0) {
+    a.delta[q] = d;
+    a.extra[q] = slack;
+    a.tau[q] = tau;
+    a.cnt[q] = 0;
+    a.state[q] = ok ? 0u : kWideGivenUp;
+  }
+}
+
+// the pool re-scored with the canonical (q - v)^2 chain of the small-batch kernels (l2_rerank_verify's arithmetic: float4 chunk c in
+// lane c mod 64, fmaf chains over (q - v)^2, xor butterfly, sqrt): a wave takes four candidates at a time; ranking by (distance, row)
+__global__ __launch_bounds__(256) void wide_rerank_l2(WideArgs a, WideOutArgs o) {
+  __shared__ uint64_t ekeys[kWidePoolMax];
+  __shared__ float esums[kWidePoolMax];
+  __shared__ float kth_sum;
+  const int lane = lane_id();
+  const uint32_t wib = threadIdx.x >> 6, tid = threadIdx.x, qi = blockIdx.x;
+  const uint32_t raw = a.cnt[qi];
+  const bool given_up = (a.state[qi] & kWideGivenUp) != 0 || raw > kWidePoolMax || raw > a.cap;
+  const uint32_t n = given_up ? 0u : raw;
+  const float* q = o.queries + (size_t)qi * o.q_stride;
+  const uint64_t* list = a.keys + (size_t)qi * a.cap;
+  const int d4 = (int)((a.dim + 3) / 4);
+  if (tid == 0) kth_sum = __uint_as_float(0x7FC00000u);
+  for (uint32_t c0 = wib; c0 < n; c0 += 16) {
+    const float* p[4];
+    uint32_t rowv[4];
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t c = min(c0 + 4u * (uint32_t)u, n - 1u);  // (a clamped duplicate: computed, not stored)
+      rowv[u] = key_row(list[c]);
+      p[u] = o.rows + (size_t)rowv[u] * o.row_stride;
+    }
+    for (int ch = lane; ch < d4; ch += 64) {
+      const int nv = (int)a.dim - ch * 4;
+      float4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) x[u] = ld4(p[u] + ch * 4);
+      float4 qq;
+      if (nv >= 4) {
+        qq = make_float4(q[ch * 4], q[ch * 4 + 1], q[ch * 4 + 2], q[ch * 4 + 3]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] = chain4<kOpL2>(acc[u], qq, x[u]);
+      } else {
+        qq = make_float4(q[ch * 4], nv > 1 ? q[ch * 4 + 1] : 0.f, nv > 2 ? q[ch * 4 + 2] : 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] = chain4_tail<kOpL2>(acc[u], qq, x[u], nv);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t c = c0 + 4u * (uint32_t)u;
+      const float sum = butterfly_all(acc[u]);
+      if (lane == 0 && c < n) {
+        esums[c] = sum;
+        ekeys[c] = make_key<false>(finish_score<kEuclidean>(sum, 0.f, 0.f), rowv[u]);
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t kk = min(a.k, n);
+  for (uint32_t i = tid; i < n; i += 256) {
+    const uint64_t key = ekeys[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; j++) rank += ekeys[j] < key ? 1u : 0u;
+    if (rank < kk) {
+      const uint32_t row = key_row(key);
+      o.out_ids[(size_t)qi * a.k + rank] = o.ext_ids ? o.ext_ids[row] : (uint64_t)row;
+      o.out_scores[(size_t)qi * a.k + rank] = key_score<false>(key);
+      if (rank + 1 == a.k) kth_sum = esums[i];
+    }
+  }
+  for (uint32_t e = kk + tid; e < a.k; e += 256) {
+    o.out_ids[(size_t)qi * a.k + e] = ~0ull;
+    o.out_scores[(size_t)qi * a.k + e] = __uint_as_float(0x7FC00000u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    bool ok = !given_up && n >= a.k;
+    if (ok) {  // every row outside the list has a selection score <= tau, a true s <= tau + delta, a true squared distance >= |q|^2 - 2 (tau + delta)
+      const double A = (double)key_score<true>(a.tau[qi]);
+      const double qn = (double)a.qnorms[qi];
+      const double Ek = (double)kth_sum;
+      ok = (Ek + (double)a.extra[qi] + 1e-6 * Ek) < qn * qn - 2.0 * (A + (double)a.delta[qi]);  // false for NaN anywhere
+    }
+    o.flags[qi] = ok ? 0u : 1u;
+    if (!ok) {
+      const uint32_t j = atomicAdd(o.qcount, 1u);
+      o.qmap[j] = qi;
+      o.qslot[qi] = j;
+    }
+    o.out_n[qi] = kk;
+  }
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------------------------------
 void launch_wide_seed(int metric, const WideArgs& a, const uint64_t* seed_keys, uint32_t ngrp, uint32_t nq, hipStream_t st) {
   if (metric == kCosine)
@@ -264,6 +402,12 @@ void launch_wide_seed(int metric, const WideArgs& a, const uint64_t* seed_keys, 
     hipLaunchKernelGGL((wide_seed_kernel<kDot>), dim3(nq), dim3(256), 0, st, a, seed_keys, ngrp);
 }
 void launch_wide_reseed(const WideArgs& a, uint32_t nq, hipStream_t st) { hipLaunchKernelGGL(wide_reseed_kernel, dim3(nq), dim3(256), 0, st, a); }
+void launch_wide_seed_l2(const WideArgs& a, const uint64_t* seed_keys, uint32_t ngrp, uint32_t dim_a, uint32_t nq, hipStream_t st) {
+  hipLaunchKernelGGL(wide_seed_l2_kernel, dim3(nq), dim3(256), 0, st, a, seed_keys, ngrp, dim_a);
+}
+void launch_wide_rerank_l2(const WideArgs& a, const WideOutArgs& o, uint32_t nq, hipStream_t st) {
+  hipLaunchKernelGGL(wide_rerank_l2, dim3(nq), dim3(256), 0, st, a, o);
+}
 size_t wide_rerank_lds_bytes(uint32_t dim_pad) {
   return ((size_t)dim_pad * 4 + (size_t)kWidePoolMax * 8 + 2 * (size_t)64 * 68 * 4 + 64 * 4 + 8 + 15) & ~(size_t)15;
 }

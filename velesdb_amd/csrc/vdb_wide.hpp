@@ -24,7 +24,8 @@ struct WideArgs {
   const float* qnorms;           // [nq] canonical norms of the f32 queries
   const float* rho_q;            // [nq] rounding residual ratios of the batch (nullable: constant bound)
   const uint32_t* rho_max_bits;  // device scalar: largest residual ratio of the row image (nullable)
-  const uint32_t* norm_max_bits; // device scalar: max |v| (DotProduct)
+  const uint32_t* norm_max_bits; // device scalar: max |v| (DotProduct, Euclidean)
+  float* extra;                  // [nq] Euclidean only (nullable): what a bound is lowered by on top of 2 delta — the canonical chain's own distance from the truth
   uint32_t cap, k, dim;
 };
 struct WideOutArgs {
@@ -46,6 +47,10 @@ struct WideOutArgs {
 void launch_wide_seed(int metric, const WideArgs& a, const uint64_t* seed_keys, uint32_t ngrp, uint32_t nq, hipStream_t st);
 void launch_wide_reseed(const WideArgs& a, uint32_t nq, hipStream_t st);
 void launch_wide_rerank(int metric, const WideArgs& a, const WideOutArgs& o, uint32_t nq, hipStream_t st);
+// Euclidean batches (the augmented DotProduct form s = q.v - |v|^2 / 2 of sweep_split.hip): seed with the form's own error bound, re-scoring
+// with the canonical (q - v)^2 lane chain, proof in the squared-distance domain.  dim_a = dim + 64 (the augmented image's width)
+void launch_wide_seed_l2(const WideArgs& a, const uint64_t* seed_keys, uint32_t ngrp, uint32_t dim_a, uint32_t nq, hipStream_t st);
+void launch_wide_rerank_l2(const WideArgs& a, const WideOutArgs& o, uint32_t nq, hipStream_t st);
 // the WIDE instance of the 256 x 256 selection kernel over one launch of a schedule (sweep_gemm_bf16.hip)
 hipError_t launch_sweep_gemm_bf16_wide(int metric, const Bf16GemmPlan& p, const uint16_t* rows16, uint64_t row_stride, const float* norms,
                                        const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride, const uint64_t* tau0,
