@@ -909,7 +909,9 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
   ix->last_kernels |= VDB_KERNEL_SELECT_BF16;
   const uint8_t* alive = ix->any_dead ? ix->alive.as<uint8_t>() : nullptr;
   const uint32_t n = (uint32_t)ix->n_rows, dim = ix->dim;
-  const uint32_t R0 = std::min<uint32_t>(kWideSeedRows, n), ngrp = (R0 + 15) / 16;
+  // the seed sample: one key per 16 rows, its k-th best is the first bound — 4 096 rows (256 keys) bound a small k well enough that the
+  // first launch passes ~100 rows per query; a k of 100 needs the 1 024 keys of 16 384 rows (seed_scores_bf16: 32 us against 100)
+  const uint32_t R0 = std::min<uint32_t>(k <= kWideSmallSeedMaxK ? kSplitSeedRows : kWideSeedRows, n), ngrp = (R0 + 15) / 16;
   GemmSchedule sch;
   {
     const uint32_t head[3] = {1u, 4u, 16u};  // tiles per row group of the first launches, as the k <= 10 stage (brute_split_dev)

@@ -22,14 +22,21 @@ __device__ __forceinline__ void block_select_pass(Word&& word, Live&& live, uint
     const uint32_t w = word(j);
     const bool take = live(j) && (w & mask) == prefix;
     const uint32_t bin = (w >> shift) & 255u;
-    const uint64_t tm = __ballot(take);
-    if (tm == 0ull) continue;  // (wave-uniform)
-    const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)bin, __builtin_ctzll(tm));
-    if (__ballot(take && bin == lead) == tm) {
-      if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(tm)) atomicAdd(&hist[lead], (uint32_t)__popcll(tm));
-    } else if (take) {
-      atomicAdd(&hist[bin], 1u);
+    bool mine = take;
+    uint64_t tm = __ballot(mine);
+    // (up to two rounds of "the lanes that share the first taker's bin add their count once", the rest one atomic per lane: the first
+    // passes see one or two bins per wave, the last ones 64 different bins)
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      if (tm == 0ull) break;  // (wave-uniform)
+      const int first = __builtin_ctzll(tm);
+      const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)bin, first);
+      const uint64_t same = __ballot(mine && bin == lead);
+      if ((int)(threadIdx.x & 63u) == first) atomicAdd(&hist[lead], (uint32_t)__popcll(same));
+      mine = mine && bin != lead;
+      tm &= ~same;
     }
+    if (mine) atomicAdd(&hist[bin], 1u);
   }
   __syncthreads();
   if (tid < 64) {  // lane l: bins 4 l .. 4 l + 3; inclusive prefix over the lanes

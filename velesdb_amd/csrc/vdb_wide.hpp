@@ -13,6 +13,7 @@ constexpr uint32_t kWideCap = 4096;        // entries of a query's global list (
 constexpr uint32_t kWidePoolMax = 1024;    // candidates one block re-scores exactly (a larger final list: the query is unproven)
 constexpr uint32_t kWideSeedRows = 16384;  // rows of the seed sample (one key per 16 rows: seed_scores_bf16)
 constexpr uint32_t kWideSeedGroups = kWideSeedRows / 16;
+constexpr uint32_t kWideSmallSeedMaxK = 32; // up to this k the k <= 10 stage's 4 096-row sample seeds the batch (256 keys: k-th best of them)
 constexpr uint32_t kWideGivenUp = 1u;      // state bit: no bound exists or the list overflowed — the exact fallback answers the query
 
 struct WideArgs {
