@@ -62,8 +62,8 @@ def parse():
     p.add_argument("--dist-single", action="store_true", help="self-test: initialise torch's RCCL process group even with one rank")
     p.add_argument("--no-sharded-leg", action="store_true", help="skip the range-sharded leg (profiling passes)")
     p.add_argument("--no-split", action="store_true", help="headline on the exact f32 matrix-core kernel (no selection stage)")
-    p.add_argument("--select-level", type=int, default=2, choices=[0, 1, 2],
-                   help="selection stage of large exact batches: 0 exact kernel, 1 split-bf16, 2 plain bf16 first (library default)")
+    p.add_argument("--select-level", type=int, default=3, choices=[0, 1, 2, 3],
+                   help="selection stage of large exact batches: 0 exact kernel, 1 split-bf16, 2 plain bf16 with block-local lists, 3 the WIDE selection at every k (library default)")
     p.add_argument("--no-traffic-pass", action="store_true", help="skip the rocprofv3 FETCH_SIZE child pass that fills roofline.traffic")
     # the child of a traffic pass (run under rocprofv3 --pmc FETCH_SIZE by the parent): "headline" = the headline steps only,
     # "hnsw" = the traversal leg over the graph files in --graph-dir, "bf16" = the configs[3] leg
@@ -505,7 +505,9 @@ def main():
         nq_last, unproven = ix.last_split_stats()
         level = ix.last_select_level()
         mfmas_per_product = 3.0 if level == 1 else 1.0
-        sel_kernel = (f"sweep_topk_gemm_bf16_glds<{a.metric},SPLIT>" if level == 1 else f"sweep_topk_gemm_bf16_pp<{a.metric}> (plain bf16 selection, ping-pong pipeline)")
+        sel_kernel = (f"sweep_topk_gemm_bf16_glds<{a.metric},SPLIT>" if level == 1 else
+                      (f"sweep_topk_gemm_bf16_pp<dot, WIDE> over normalised bf16 images of rows and queries ({a.metric}; ping-pong pipeline, candidates to global lists)"
+                       if level == 4 else f"sweep_topk_gemm_bf16_pp<{a.metric}> (plain bf16 selection, ping-pong pipeline)"))
         # the dominant kernel = the selection kernel: its launches of one step sweep every row behind the seed prefix once
         # (algorithmic flop 2 * rows * dim * queries per step), their durations are summed from HIP events around each launch
         sel_tf = (2.0 * (N - 4096) * D * tile) / (sel_ms * 1e-3) / 1e12 if sel_ms > 0 else 0.0

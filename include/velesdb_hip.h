@@ -373,7 +373,7 @@ int32_t vdb_hip_set_sweep_engine(int32_t engine);
  *   0 = no selection stage: the exact f32 matrix-core kernel;
  *   1 = split-bf16 selection (x = hi + lo, three bf16 MFMAs per product, error ~2^-15 + accumulation; 32 candidates);
  *       costs +4 bytes per element of HBM (the split image, built at first use);
- *   2 (default) = plain bf16 selection first (one MFMA per product over the bf16 copy of the rows, error ~2^-7; 64
+ *   2 = plain bf16 selection first (one MFMA per product over the bf16 copy of the rows, error ~2^-7; 64
  *       candidates; +2 bytes per element, dim % 64 == 0), level 1 where that does not apply; a handle whose data defeats
  *       the wider bound (> 1/16 of a batch unproven: near-duplicate clusters) moves itself to level 1 for the next 64
  *       batches and then tries again.  Cosine (round 6): the image holds the NORMALISED rows v / |v| and the batch the
@@ -382,7 +382,10 @@ int32_t vdb_hip_set_sweep_engine(int32_t engine);
  * every row whose approximate score passes the query's bound (k-th best approximate score seen so far - 2 x the error
  * bound, raised between the launches of the batch) becomes a candidate, all of them are re-scored exactly; a query is
  * unproven only when its candidate list overflows (4 096 per launch, 1 024 at the end) or its data is not finite.
- * Reported as level 4 by vdb_hip_index_last_select_level.  Larger k, other metrics at k > 10: the exact kernels. */
+ * Reported as level 4 by vdb_hip_index_last_select_level.  Larger k, other metrics at k > 10: the exact kernels.
+ *   3 (default since round 6) = level 2, and Cosine / DotProduct batches over f32 rows take the WIDE selection at EVERY k <= 128
+ *       (k <= 10 included: faster than the block-local lists, ~25 instead of 64 rows to re-score); a handle with > 1/16 of a
+ *       batch unproven there answers its next 64 batches by level 2's rules. */
 int32_t vdb_hip_set_split_selector(int32_t level);
 /* diagnostic: queries in the last split-selector batch (its last chunk of <= 1024) and how many of them the exact
  * fallback kernel answered because the selection could not be proven (near-ties inside the error bound, non-finite data) */

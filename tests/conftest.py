@@ -42,3 +42,16 @@ def _gpu_present() -> bool:
 def gpu_required():
     if not _gpu_present():
         pytest.skip("no HIP device visible")
+
+
+@pytest.fixture(autouse=True)
+def _library_defaults_for_gpu_tests(request):
+    """Every `-m gpu` test starts from the library's process-wide defaults: several tests pin a selection level / engine / tile and leave
+    it pinned (the knobs are process-wide), and what a later test asserts about WHICH path served a call must not depend on the order
+    of the files."""
+    if request.node.get_closest_marker("gpu") is not None and _gpu_present():
+        import velesdb_amd as va
+        va.set_split_selector(3)
+        va.set_sweep_engine(1)
+        va.set_max_query_tile(128)
+    yield

@@ -24,7 +24,7 @@ def test_defaults_are_the_baseline_configuration(monkeypatch):
     assert (a.rows, a.dim, a.k, a.batch, a.metric) == (1_000_000, 768, 10, 1024, "cosine")     # BASELINE.json configs[1]
     assert (a.hnsw_batch, a.ef, a.M, a.efc) == (8192, 128, 32, 400)                            # configs[2]: HnswParams::auto(768), Balanced
     assert a.bf16_rows == 10_000_000 and a.shard_rows == 0                                     # configs[3]; configs[4] = --shard-rows 6250000 at 8 GPUs
-    assert a.select_level == 2 and not a.no_split and a.engine == 1 and a.tile == 128          # the library's default path, nothing forced
+    assert a.select_level == 3 and not a.no_split and a.engine == 1 and a.tile == 128          # the library's default path, nothing forced
     assert b.HBM_PEAK_GBS == 8000.0
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
     a = b.parse()

@@ -336,7 +336,7 @@ def test_diagnostics_describe_the_last_call_only(gpu_required):
     ix = va.HnswIndex(128, DM.Cosine, va.HnswParams(8, 50, 66_000))
     ix.upload(np.arange(66_000), rows)
     ix.search_batch_brute_force(rows[:128], 5)
-    assert ix.last_select_level() == 2 and ix.last_split_stats()[0] == 128
+    assert ix.last_select_level() == 4 and ix.last_split_stats()[0] == 128
     assert ix.last_kernels() & va.KERNEL_SELECT_BF16
     ix.search_batch_brute_force(rows[:4], 5)     # a small batch: the streaming kernel, no selection stage
     assert ix.last_select_level() == 0 and ix.last_split_stats() == (0, 0)

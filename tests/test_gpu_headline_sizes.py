@@ -60,16 +60,22 @@ def test_headline_1m_gemm_vs_oracle(corpus, index):
     assert index.sweep_arith_mode(K) == "M"
     nq = 320
     ids, sc, cnt = index.search_batch_brute_force(qs[:nq], K)
-    # WHICH kernel answered: the selection stage at level 2 (bf16 matrix cores + exact re-scoring + proof) — a silent fall-back to the
-    # exact f32 kernel would produce the same bits and pass everything below
-    assert index.last_select_level() == 2 and index.last_kernels() & va.KERNEL_SELECT_BF16, "the selection stage did not serve the 320-query call"
+    # WHICH kernel answered: the selection stage (bf16 matrix cores + exact re-scoring + proof; level 4 = the WIDE selection, the default
+    # at every k since round 6) — a silent fall-back to the exact f32 kernel would produce the same bits and pass everything below
+    assert index.last_select_level() == 4 and index.last_kernels() & va.KERNEL_SELECT_BF16, "the selection stage did not serve the 320-query call"
     eid, esc = po.scan_topk(po.COSINE, rows, qs[:nq], K, po.MODE_M, nthreads=ncores)
     assert np.all(cnt == K)
     assert np.array_equal(ids, eid), "ids / ranks differ from the oracle (mode M) at 1M x 320 queries"
     assert np.array_equal(bits(sc), bits(esc)), "score bits differ from the oracle (mode M)"
     # the bench's launch: 1 024 queries in one call; queries 320.. are new, every query tile is sampled
     ids2, sc2, cnt2 = index.search_batch_brute_force(qs, K)
-    assert index.last_select_level() == 2 and index.last_kernels() & va.KERNEL_SELECT_BF16, "the selection stage did not serve the 1 024-query call"
+    assert index.last_select_level() == 4 and index.last_kernels() & va.KERNEL_SELECT_BF16, "the selection stage did not serve the 1 024-query call"
+    # pinned at level 2 (block-local candidate lists, the per-query proof): the same bits from the other kernel instance
+    index.set_option(va.OPT_SELECTOR_LEVEL, 2)
+    ids_l2, sc_l2, _ = index.search_batch_brute_force(qs, K)
+    assert index.last_select_level() == 2
+    index.set_option(va.OPT_SELECTOR_LEVEL, -1)
+    assert np.array_equal(ids_l2, ids2) and np.array_equal(bits(sc_l2), bits(sc2)), "levels 2 and 4 disagree at 1M x 1 024 queries"
     assert index.last_split_stats()[1] <= 2, "more unproven queries than the benchmark data ever produced (one in ~8 000): the bound has drifted"
     assert np.array_equal(ids2[:nq], ids) and np.array_equal(bits(sc2[:nq]), bits(sc)), "results depend on the batch size"
     sample = np.arange(nq + 3, 1024, 7)[:96]
@@ -255,7 +261,7 @@ def test_configs4_shard_size_6p25m_f32_vs_oracle(gpu_required):
         best_s = np.take_along_axis(best_s, order, axis=1)
     assert ix.len() == SR
     gi, gs, gc = ix.search_batch_brute_force(qs, K)
-    assert ix.last_select_level() == 2, "the selection stage did not serve the 6.25 M-row batch"
+    assert ix.last_select_level() == 4, "the selection stage did not serve the 6.25 M-row batch"
     assert np.all(gc == K)
     assert np.array_equal(gi[sample].astype(np.int64), best_i), "ids / ranks differ from the oracle's scan of the same rows"
     assert np.array_equal(bits(gs[sample]), bits(best_s)), "score bits differ from the oracle's"

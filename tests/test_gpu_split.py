@@ -23,10 +23,10 @@ def bits(a):
 
 def run_case(metric, rows, qs, k, expect_unproven=None, remove=()):
     out = None
-    for level in (1, 2):
-        u = _run_case(metric, rows, qs, k, level, expect_unproven, remove)
+    for level in (1, 2, 3):  # (3 = the library's default since round 6: the WIDE selection at every k <= 128 where level 2 applies)
+        u = _run_case(metric, rows, qs, k, level, expect_unproven if level < 3 else None, remove)
         out = u if out is None else out  # callers look at level 1's count
-    va.set_split_selector(2)  # the library default
+    va.set_split_selector(3)  # the library default
     return out
 
 
@@ -45,7 +45,9 @@ def _run_case(metric, rows, qs, k, level, expect_unproven, remove):
     ids, sc, cnt = ix.search_batch_brute_force(qs, k)
     nq_last, unproven = ix.last_split_stats()
     assert nq_last > 0, "the selection stage did not run"
-    assert ix.last_select_level() == (2 if level == 2 and dim % 64 == 0 and dim >= 128 else 1)
+    bf16_ok = dim % 64 == 0 and dim >= 128
+    wide = level == 3 and os.environ.get("VELESDB_WIDE_SMALL_K") != "0"   # (the probe build's switch keeps k <= 10 on the block-local lists)
+    assert ix.last_select_level() == ((4 if wide else 2) if level >= 2 and bf16_ok else 1)
     eid, esc = po.scan_topk(pm, rows[keep], qs, k, po.MODE_M, nthreads=NT)
     emap = ids_ext[keep]
     assert np.array_equal(ids, emap[eid.astype(np.int64)]), "ids / ranks differ from the oracle (mode M)"
@@ -153,7 +155,7 @@ def test_level2_parks_itself_at_level1_when_the_data_defeats_it(gpu_required):
         rows[where] = qs[j] + spread * rng.standard_normal((200, dim)).astype(np.float32)
     ix = va.HnswIndex(dim, DM.Cosine, va.HnswParams(8, 50, n))
     ix.upload(np.arange(n, dtype=np.uint64), rows)
-    va.set_split_selector(2)
+    va.set_split_selector(2)  # (pinned: level 3 answers this data from the WIDE selection — 200 near-copies per query fit its lists — proven by construction)
     eid, esc = po.scan_topk(po.COSINE, rows, qs, k, po.MODE_M, nthreads=NT)
     levels, unproven = [], []
     for rep in range(4):

@@ -60,8 +60,14 @@ def test_wide_k_vs_oracle(corpus, metric):
     a, sa = ix.search_batch_brute_force(qs[:40], 50)[:2]
     b, sb = ix.search_batch_brute_force(qs[:300], 50)[:2]
     assert np.array_equal(a, b[:40]) and np.array_equal(bits(sa), bits(sb[:40]))
-    # k = 10 keeps its own stage, k beyond the WIDE limit the exact kernels: the same oracle either way
+    # k <= 10 takes the WIDE selection too (selector level 3, the default); pinned at level 2 it keeps the block-local lists; k beyond
+    # the WIDE limit: the exact kernels — the same oracle every way
+    check(ix, metric, rows, qs[:96], 10, level=LEVEL_WIDE)
+    check(ix, metric, rows, qs[:96], 1, level=LEVEL_WIDE)
+    ix.set_option(va.OPT_SELECTOR_LEVEL, 2)
     check(ix, metric, rows, qs[:96], 10, level=2)
+    check(ix, metric, rows, qs[:96], 50, level=LEVEL_WIDE)
+    ix.set_option(va.OPT_SELECTOR_LEVEL, -1)
     check(ix, metric, rows, qs[:32], 129, level=0)
     # the selector switched off: the exact kernels answer k = 50 with the same bits
     ix.set_option(va.OPT_SELECTOR_LEVEL, 0)
@@ -175,3 +181,28 @@ def test_wide_k_euclidean_vs_oracle(corpus):
         eid, esc = po.scan_topk(po.EUCLIDEAN, r2, q2, k, po.MODE_C, nthreads=po.host_threads())
         assert np.array_equal(ids, eid) and np.array_equal(bits(sc), bits(esc)), (dim, n, nq, k)
         ix.close()
+
+
+@pytest.mark.parametrize("metric", [DM.Cosine, DM.DotProduct])
+def test_wide_k_sq8_storage_mode_vs_oracle(corpus, metric):
+    """StorageMode::SQ8 (core/quantization.rs:17-29): batches at k > 10 select over the dequantised bf16 image and re-score their
+    candidates with the reference's asymmetric chain over the codes (dot_product_quantized_simd / cosine_similarity_quantized_simd,
+    quantization.rs:410-554) — bit-identical to the oracle's restatement of that scalar code, as at k <= 10."""
+    rows, qs = corpus
+    ix = va.HnswIndex(768, metric)
+    ix.upload(np.arange(len(rows), dtype=np.uint64), rows)
+    ix.set_storage_mode(va.StorageMode.SQ8)
+    for k, nq in ((11, 40), (50, 300), (100, 64)):
+        ids, sc, cnt = ix.search_batch_sq8(qs[:nq], k)
+        assert ix.last_select_level() == LEVEL_WIDE, (k, ix.last_select_level())
+        eid, esc = po.scan_topk_sq8(PO[metric], rows, qs[:nq], k, nthreads=po.host_threads())
+        assert np.all(cnt == k)
+        assert np.array_equal(ids, eid.astype(np.uint64)), f"SQ8 ids / ranks differ from the oracle at k = {k}"
+        assert np.array_equal(bits(sc), bits(esc)), f"SQ8 score bits differ from the oracle at k = {k}"
+    # k = 10 keeps level 3 (block-local lists over the same image); a handful of queries the exact SQ8 sweep
+    ix.search_batch_sq8(qs[:64], 10)
+    assert ix.last_select_level() == 3
+    a, sa, _ = ix.search_batch_sq8(qs[:3], 50)
+    b, sb, _ = ix.search_batch_sq8(qs[:300], 50)
+    assert np.array_equal(a, b[:3]) and np.array_equal(bits(sa), bits(sb[:3]))
+    ix.close()

@@ -97,7 +97,7 @@ while time.time() < t_end:
         nq = int(rng.choice([80, 100, 150, 230, 256, 300, 480, 620, 1000]))
         k = int(rng.choice([1, 3, 10]))
         kind = str(rng.choice(["normal", "normal", "dups", "small_ints", "ascending", "zeros_mixed", "clusters"]))
-        va.set_split_selector(int(rng.choice([1, 2])))
+        va.set_split_selector(int(rng.choice([1, 2, 3])))
         if rng.random() < 0.3:
             metric = DM.Euclidean
     if a.wide:  # the WIDE selection: no block-local lists, candidate lists that can overflow (clusters, duplicates), gathered fallback

@@ -21,7 +21,7 @@ static thread_local std::string g_last_error;
 static std::atomic<int> g_timing{0};
 static std::atomic<int> g_sweep_engine{1};  // 1 (default): MFMA kernel for cosine / dot (oracle mode M); 0: VALU kernels (mode C)
 static std::atomic<uint32_t> g_max_tile{128};  // largest query tile of the exact sweep (vdb_hip_set_max_query_tile)
-static std::atomic<int> g_split_selector{2};  // large exact Cosine / Dot batches: 0 exact kernel, 1 split-bf16 selection + exact re-scoring + proof,
+static std::atomic<int> g_split_selector{3};  // large exact Cosine / Dot batches: 0 exact kernel, 1 split-bf16 selection + exact re-scoring + proof,
                                               // 2 plain bf16 selection first (same proof, wider bound), level 1 when a handle's data defeats it
 static std::atomic<uint32_t> g_int8_oversampling{4};  // DualPrecisionConfig::default().oversampling_ratio (dual_precision.rs:57)
 
@@ -926,6 +926,13 @@ int32_t search_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint3
     if (ix->storage_mode != VDB_STORAGE_SQ8) return fail(VDB_ERR_STATE, "SQ8 search: set the storage mode to SQ8 first");
     uint32_t q0 = 0;
     while (q0 < nq && k > 0 && ix->n_rows > 0) {
+      if (select_level_wide(ix, nq - q0, k, /*sq8=*/true)) {  // 10 < k <= 128: the WIDE selection over the dequantised image (sweep_wide.hip)
+        const uint32_t nqw = select_chunk(nq - q0, kSelectMinQueriesSq8);
+        const int32_t rcw = brute_wide_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nqw, k, d_ids + (size_t)q0 * k, d_scores + (size_t)q0 * k, d_n + q0, st, true);
+        if (rcw != VDB_OK) return rcw;
+        q0 += nqw;
+        continue;
+      }
       if (select_level_sq8(ix, nq - q0, k) != 3) break;
       const uint32_t nqg = select_chunk(nq - q0, kSelectMinQueriesSq8);
       const int32_t rcs = brute_split_dev(ix, d_q + (size_t)q0 * q_stride, q_stride, nqg, k, d_ids + (size_t)q0 * k,
@@ -1274,7 +1281,7 @@ int32_t vdb_hip_index_set_option(vdb_hip_index* ix, int32_t option, int64_t valu
           if (value > 1) return fail(VDB_ERR_INVALID_ARG, "sweep engine: 0 or 1");
           v = (int32_t)value;
           break;
-        case VDB_OPT_SELECTOR_LEVEL: v = value >= 2 ? 2 : (int32_t)value; break;
+        case VDB_OPT_SELECTOR_LEVEL: v = value >= 3 ? 3 : (int32_t)value; break;
         case VDB_OPT_INT8_OVERSAMPLING:
           if (value < 1 || value > 64) return fail(VDB_ERR_INVALID_ARG, "oversampling ratio: 1..64");
           v = (int32_t)value;
@@ -1311,7 +1318,7 @@ int32_t vdb_hip_index_get_option(vdb_hip_index* ix, int32_t option, int64_t* val
 }
 
 int32_t vdb_hip_set_split_selector(int32_t level) {
-  g_split_selector = level <= 0 ? 0 : (level >= 2 ? 2 : 1);
+  g_split_selector = level <= 0 ? 0 : (level >= 3 ? 3 : level);
   return VDB_OK;
 }
 

@@ -875,13 +875,22 @@ int32_t brute_split_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, 
 
 // ---- exact Cosine / DotProduct batches with 10 < k <= kWideMaxK: the WIDE selection (sweep_wide.hip) -------------------------------
 // the same eligibility as level 2 (the bf16 image of the rows, whole 64-element k-tiles), its own park-after-failure state
-int select_level_wide(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
-  if (opt_selector(ix) < 2 || opt_engine(ix) != 1 || opt_max_tile(ix) < 128) return 0;
-  if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT && ix->metric != VDB_EUCLIDEAN) return 0;
+// VELESDB_WIDE_SMALL_K=0 (probe builds): k <= 10 stays on the block-local lists whatever the selector level (A / B probes)
+static const bool g_wide_small_k = [] {
+  const char* e = probe_env("VELESDB_WIDE_SMALL_K");
+  return !(e && e[0] == '0');
+}();
+int select_level_wide(vdb_hip_index* ix, uint32_t nq_left, uint32_t k, bool sq8) {
+  if (opt_selector(ix) < 2 || (!sq8 && opt_engine(ix) != 1) || opt_max_tile(ix) < 128) return 0;
+  if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT && (sq8 || ix->metric != VDB_EUCLIDEAN)) return 0;  // (SQ8: Cosine / DotProduct)
   if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
-  if (k <= kGemmBf16MaxK || k > kWideMaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
-  if (ix->metric != VDB_EUCLIDEAN && sweep_mfma_lds_bytes(1, k, ix->dim) > 160 * 1024) return 0;  // (the gathered exact pass of the unproven queries)
-  if (!select_chunk(nq_left)) return 0;
+  // k <= 10: the block-local lists of levels 1 / 2 exist for it; selector level 3 (the default since round 6) sends Cosine / DotProduct
+  // batches over f32 rows through the WIDE selection all the same — measured faster at every k (no candidate buffers, no compaction,
+  // ~25 instead of 64 rows to re-score: DESIGN 4.1f) — and a handle the data defeats falls back to those levels, not to the exact kernels
+  if (k == 0 || k > kWideMaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
+  if (k <= kGemmBf16MaxK && (sq8 || opt_selector(ix) < 3 || !g_wide_small_k)) return 0;
+  if (!sq8 && ix->metric != VDB_EUCLIDEAN && sweep_mfma_lds_bytes(1, k, ix->dim) > 160 * 1024) return 0;  // (the gathered exact pass of the unproven queries)
+  if (!select_chunk(nq_left, sq8 ? kSelectMinQueriesSq8 : 0)) return 0;
   if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
     ix->sel_seq_seen = ix->sel_stats[2];
     if (ix->sel_stats[3] == 4u && (uint64_t)ix->sel_stats[0] * 16 > ix->sel_stats[1]) ix->wide_hold = 64;  // > 1/16 unproven
@@ -894,16 +903,21 @@ int select_level_wide(vdb_hip_index* ix, uint32_t nq_left, uint32_t k) {
 }
 
 int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, uint64_t* d_ids, float* d_scores,
-                       uint32_t* d_n, hipStream_t st) {
-  const bool cosn = cosine_normalised(ix);  // Cosine: both sides normalised before the rounding, the DotProduct instance selects
-  const bool l2 = ix->metric == VDB_EUCLIDEAN;  // the augmented DotProduct form s = q.v - |v|^2 / 2 (sweep_split.hip), images of dim + 64 columns
+                       uint32_t* d_n, hipStream_t st, bool sq8) {
+  // (sq8: the SQ8 storage mode's batches, VDB_SEARCH_BRUTE_SQ8 — selection over the dequantised bf16 image with its own norms, the
+  // candidates re-scored with the reference's chain over the codes, storage_modes.hip's gathered sweep for the unproven)
+  const bool cosn = !sq8 && cosine_normalised(ix);  // Cosine: both sides normalised before the rounding, the DotProduct instance selects
+  const bool l2 = !sq8 && ix->metric == VDB_EUCLIDEAN;  // the augmented DotProduct form s = q.v - |v|^2 / 2 (sweep_split.hip), images of dim + 64 columns
   const int sel_metric = (cosn || l2) ? VDB_DOT : ix->metric;
-  int32_t rc = l2 ? ensure_l2_select(ix, st) : (cosn ? ensure_cosn(ix, st) : ensure_sel16(ix, st));
+  int32_t rc = sq8 ? ensure_sq8_select(ix, st) : (l2 ? ensure_l2_select(ix, st) : (cosn ? ensure_cosn(ix, st) : ensure_sel16(ix, st)));
   if (rc != VDB_OK) return rc;
   const uint32_t dim_a = ix->dim + 64, dim_s = ix->dim + 4;
-  const uint16_t* img_rows = l2 ? ix->l2_img.as<uint16_t>() : (cosn ? ix->cosn_img.as<uint16_t>() : ix->rows_bf16.as<uint16_t>());
-  const uint64_t img_stride = l2 ? (uint64_t)dim_a : (cosn ? (uint64_t)ix->dim : ix->bf16_stride);
-  const DevBuf& rho_buf = l2 ? ix->l2_rho : (cosn ? ix->cosn_rho : ix->bf16_rho);
+  const uint16_t* img_rows = sq8 ? ix->sq8_img.as<uint16_t>()
+                                 : (l2 ? ix->l2_img.as<uint16_t>() : (cosn ? ix->cosn_img.as<uint16_t>() : ix->rows_bf16.as<uint16_t>()));
+  const uint64_t img_stride = l2 ? (uint64_t)dim_a : ((cosn || sq8) ? (uint64_t)ix->dim : ix->bf16_stride);
+  const DevBuf& rho_buf = sq8 ? ix->sq8_rho : (l2 ? ix->l2_rho : (cosn ? ix->cosn_rho : ix->bf16_rho));
+  const float* sel_norms = sq8 ? ix->sq8_nrm.as<float>() : ix->norms.as<float>();  // what the kernel's Cosine bound and `force` rule read
+  DevBuf& list_buf = sq8 ? ix->s_part_cnt : ix->s_fb_keys;  // (storage_modes.hip's gathered fallback keeps its lists in s_fb_keys)
   const uint32_t sel_dim = l2 ? dim_a : ix->dim;  // the k-extent the selection kernel and the seed contract over
   ix->last_select_level = 4;
   ix->last_kernels |= VDB_KERNEL_SELECT_BF16;
@@ -937,9 +951,9 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
                o_gid = take((size_t)nqg * k * 8), o_gsc = take((size_t)nqg * k * 4), o_gn = take((size_t)nqg * 4), o_nmax = take(16),
                o_extra = take((size_t)nqg * 4);
   hipError_t e;
-  if ((e = ix->s_seed.reserve(off, false, st)) != hipSuccess || (e = ix->s_fb_keys.reserve((size_t)nqg * kWideCap * 8, false, st)) != hipSuccess ||
+  if ((e = ix->s_seed.reserve(off, false, st)) != hipSuccess || (e = list_buf.reserve((size_t)nqg * kWideCap * 8, false, st)) != hipSuccess ||
       (e = ix->s_part_keys.reserve((size_t)nqg * ngrp * 8, false, st)) != hipSuccess ||
-      (e = ix->s_part_cnt.reserve((size_t)nqg * g_blocks * k * 8, false, st)) != hipSuccess ||
+      (!sq8 && (e = ix->s_part_cnt.reserve((size_t)nqg * g_blocks * k * 8, false, st)) != hipSuccess) ||
       (e = ix->s_misc.reserve(((size_t)nqg + 256) * img_stride * 2 + (l2 ? (size_t)nqg * dim_s * 4 + 16 : 0), false, st)) != hipSuccess)
     return fail(VDB_ERR_OOM, "wide selection scratch");
   unsigned char* sd = ix->s_seed.as<unsigned char>();
@@ -970,9 +984,10 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
   } else if (cosn) launch_seln_prep_queries(d_q, q_stride, q16, img_stride, qnorms, rho_q, flags, nqg + 4, nqg, dim, st);
   else launch_sel16_prep_queries(d_q, q_stride, q16, img_stride, qnorms, rho_q, flags, nqg + 4, nqg, dim, st);
   if (nqg % 256u) VDB_HIP(hipMemsetAsync(q16 + (size_t)nqg * img_stride, 0, (size_t)256 * img_stride * 2, st));
-  if (ix->metric == VDB_DOT || l2) launch_max_norm(ix->norms.as<float>(), n, norm_max, st);
+  if (ix->metric == VDB_DOT || l2) launch_max_norm(sel_norms, n, norm_max, st);
   WideArgs wa{};
-  wa.keys = ix->s_fb_keys.as<uint64_t>();
+  wa.keys = list_buf.as<uint64_t>();
+  wa.eps_extra = sq8 ? 1.5e-4f : 0.0f;  // (select_eps level 3: the matrix-core score against the reference's left-to-right chain)
   wa.cnt = reinterpret_cast<uint32_t*>(sd + o_cnt);
   wa.state = reinterpret_cast<uint32_t*>(sd + o_state);
   wa.tau = reinterpret_cast<uint64_t*>(sd + o_tau);
@@ -986,14 +1001,14 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
   wa.k = k;
   wa.dim = dim;
   // seed: a sample of the first rows on the bf16 pipe (one key per 16 rows), its k-th best -> the first bound
-  launch_seed_scores_bf16(sel_metric, img_rows, img_stride, ix->norms.as<float>(), alive, q16, img_stride, qnorms, ix->s_part_keys.as<uint64_t>(), R0,
+  launch_seed_scores_bf16(sel_metric, img_rows, img_stride, sel_norms, alive, q16, img_stride, qnorms, ix->s_part_keys.as<uint64_t>(), R0,
                           nqg, sel_dim, st);
   if (l2) launch_wide_seed_l2(wa, ix->s_part_keys.as<uint64_t>(), ngrp, dim_a, nqg, st);
   else launch_wide_seed(ix->metric, wa, ix->s_part_keys.as<uint64_t>(), ngrp, nqg, st);
   for (int j = 0; j < sch.n_launch; j++) {
     EventPair* evs = next_sel_events(ix);
     if (evs) (void)hipEventRecord(evs->a, st);
-    e = launch_sweep_gemm_bf16_wide(sel_metric, sch.bp[j], img_rows, img_stride, ix->norms.as<float>(), alive, q16, img_stride, wa.tau, wa.keys, wa.cnt,
+    e = launch_sweep_gemm_bf16_wide(sel_metric, sch.bp[j], img_rows, img_stride, sel_norms, alive, q16, img_stride, wa.tau, wa.keys, wa.cnt,
                                     wa.cap, sel_dim, nqg, st, qnorms);
     if (evs) (void)hipEventRecord(evs->b, st);
     if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("wide selection launch: ") + hipGetErrorString(e));
@@ -1014,6 +1029,36 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
   wo.row_stride = ix->row_stride;
   wo.q_stride = q_stride;
   wo.dim_pad = (dim + 127) / 128 * 128;
+  if (sq8) {
+    wo.sq8_codes = ix->sq8_codes.as<uint8_t>();
+    wo.sq8_min = ix->sq8_min.as<float>();
+    wo.sq8_max = ix->sq8_max.as<float>();
+    wo.sq8_nsq = ix->sq8_nsq.as<float>();
+    wo.sq8_stride = ix->sq8_stride;
+    launch_wide_rerank_sq8(ix->metric, wa, wo, nqg, st);
+    SelectFinishArgs fq{};  // the reference chain for the unproven queries only, listed and gathered on the device (storage_modes.hip)
+    fq.flags = flags;
+    fq.qcount = qcount;
+    fq.qslot = qslot;
+    fq.out_ids = d_ids;
+    fq.out_scores = d_scores;
+    fq.out_n = d_n;
+    fq.nq = nqg;
+    fq.k = k;
+    if (ix->sel_stats) {
+      fq.stats_host = ix->sel_stats;
+      fq.stats_seq = ++ix->sel_seq;
+      fq.stats_level = 4u;
+    }
+    const int32_t rf = sq8_fallback_flagged(ix, d_q, q_stride, nqg, k, qmap, fq, st);
+    if (rf != VDB_OK) return rf;
+    ix->split_flags_off = o_flags;
+    ix->split_flags_n = nqg;
+    ix->split_flags_stream = st;
+    if (ev) (void)hipEventRecord(ev->b, st);
+    VDB_HIP(hipGetLastError());
+    return VDB_OK;
+  }
   if (l2) launch_wide_rerank_l2(wa, wo, nqg, st);
   else launch_wide_rerank(ix->metric, wa, wo, nqg, st);
   // unproven queries (an overflowed list, a pool beyond one block, non-finite data): listed on the device, answered by the exact

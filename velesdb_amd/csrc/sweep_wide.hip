@@ -25,11 +25,11 @@
 namespace vdb {
 
 // level 2's error bound with measured residuals (sweep_split.hip select_eps_q, restated: that one is file-local)
-__device__ __forceinline__ float wide_eps(uint32_t dim, const float* rho_q, const uint32_t* rho_max_bits, uint32_t q) {
+__device__ __forceinline__ float wide_eps(uint32_t dim, const float* rho_q, const uint32_t* rho_max_bits, uint32_t q, float extra = 0.0f) {
   const float acc = 16.0f * (float)dim * 5.9604645e-8f;
-  if (!rho_q || !rho_max_bits) return 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f + acc;
+  if (!rho_q || !rho_max_bits) return 2.0f * 3.90625e-3f * 1.002f + 1.6e-5f + acc + extra;
   const float rm = __uint_as_float(*rho_max_bits), rq = rho_q[q];
-  return (rm + rq + 3.0f * rm * rq) * 1.002f + acc + 4e-6f;  // (+ 4e-6: the normalised images' division by f32 norms; NaN query: NaN -> no bound)
+  return (rm + rq + 3.0f * rm * rq) * 1.002f + acc + 4e-6f + extra;  // (+ 4e-6: the normalised images' division by f32 norms; NaN query: NaN -> no bound)
 }
 
 // the bound a k-th best approximate score s_k yields: tau = s_k - 2 delta (both sides approximate), as a key of row 0 — a row passes
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(WideArgs a, const uint64
   if (mine) atomicAdd(&total, mine);
   __syncthreads();
   const uint32_t valid = total;  // (block-uniform)
-  const float eps = wide_eps(a.dim, a.rho_q, a.rho_max_bits, q);
+  const float eps = wide_eps(a.dim, a.rho_q, a.rho_max_bits, q, a.eps_extra);
   const float d = METRIC == kCosine ? eps * 1.001f + 4e-7f : eps * 1.001f * a.qnorms[q] * __uint_as_float(*a.norm_max_bits) + 1e-30f;
   bool ok = valid >= a.k && d == d;
   uint64_t tau = wide_tau_closed();
@@ -394,6 +394,98 @@ __global__ __launch_bounds__(256) void wide_rerank_l2(WideArgs a, WideOutArgs o)
   }
 }
 
+// ---- SQ8 storage mode: the pool re-scored with the reference's asymmetric distances over the one-byte codes (split_rerank_verify<SQ8>'s
+// chain: core/quantization.rs:410-554 — one left-to-right chain per (query, row), multiplies and adds rounded separately; the bits
+// sweep_topk_sq8 computes for the whole corpus).  One thread per candidate; the proof holds by construction as for the f32 rows (the
+// error bound carries level 3's extra term for the chain's own distance from the dequantised dot product).
+template <int METRIC>
+__global__ __launch_bounds__(256) void wide_rerank_sq8(WideArgs a, WideOutArgs o) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* qs = reinterpret_cast<float*>(smem);                          // [dim]
+  uint64_t* ekeys = reinterpret_cast<uint64_t*>(qs + ((a.dim + 3) & ~3u));  // [kWidePoolMax]
+  float* qred = reinterpret_cast<float*>(ekeys + kWidePoolMax);         // sum(q), sum(q*q), left to right
+  uint64_t* kth = reinterpret_cast<uint64_t*>(qred + 2);
+  const uint32_t tid = threadIdx.x, qi = blockIdx.x;
+  const uint32_t raw = a.cnt[qi];
+  const bool given_up = (a.state[qi] & kWideGivenUp) != 0 || raw > kWidePoolMax || raw > a.cap;
+  const uint32_t n = given_up ? 0u : raw;
+  const float* q = o.queries + (size_t)qi * o.q_stride;
+  for (uint32_t i = tid; i < a.dim; i += 256) qs[i] = q[i];
+  if (tid == 0) *kth = kKeyInvalid;
+  __syncthreads();
+  if (tid == 64) {  // :330-334 sum(q); :528 sum(q*q) — two chains, two waves
+    float s1 = 0.0f;
+    for (uint32_t d = 0; d < a.dim; d++) s1 = __fadd_rn(s1, qs[d]);
+    qred[0] = s1;
+  }
+  if (tid == 128) {
+    float s2 = 0.0f;
+    for (uint32_t d = 0; d < a.dim; d++) s2 = __fadd_rn(s2, __fmul_rn(qs[d], qs[d]));
+    qred[1] = s2;
+  }
+  __syncthreads();
+  const uint64_t* list = a.keys + (size_t)qi * a.cap;
+  for (uint32_t c = tid; c < n; c += 256) {
+    const uint32_t row = key_row(list[c]);
+    const float mn = o.sq8_min[row], range = __fsub_rn(o.sq8_max[row], mn);
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(o.sq8_codes + (size_t)row * o.sq8_stride);
+    float acc = 0.0f;
+    if (range < 1.1920929e-07f) {
+      acc = __fmul_rn(qred[0], mn);
+    } else {
+      const float scale = __fdiv_rn(range, 255.0f);
+      for (uint32_t i = 0; i < a.dim; i += 4) {
+        const uint32_t w = cw[i >> 2];
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (i + e < a.dim) {
+            const float dq = __fadd_rn(__fmul_rn((float)((w >> (8 * e)) & 0xFFu), scale), mn);
+            acc = __fadd_rn(acc, __fmul_rn(qs[i + e], dq));
+          }
+      }
+    }
+    float score = acc;
+    if (METRIC == kCosine) {
+      const float denom = sqrtf(__fmul_rn(qred[1], o.sq8_nsq[row]));
+      score = denom < 1.1920929e-07f ? 0.0f : __fdiv_rn(acc, denom);
+    }
+    ekeys[c] = make_key<true>(score, row);
+  }
+  __syncthreads();
+  const uint32_t kk = min(a.k, n);
+  for (uint32_t i = tid; i < n; i += 256) {
+    const uint64_t key = ekeys[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n; j++) rank += ekeys[j] < key ? 1u : 0u;
+    if (rank < kk) {
+      const uint32_t row = key_row(key);
+      o.out_ids[(size_t)qi * a.k + rank] = o.ext_ids ? o.ext_ids[row] : (uint64_t)row;
+      o.out_scores[(size_t)qi * a.k + rank] = key_score<true>(key);
+      if (rank + 1 == a.k) *kth = key;
+    }
+  }
+  for (uint32_t e = kk + tid; e < a.k; e += 256) {
+    o.out_ids[(size_t)qi * a.k + e] = ~0ull;
+    o.out_scores[(size_t)qi * a.k + e] = __uint_as_float(0x7FC00000u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    bool ok = !given_up && n >= a.k;
+    if (ok) {
+      const float A = key_score<true>(a.tau[qi]);
+      const double Ek = (double)key_score<true>(*kth);
+      ok = Ek > (double)A + (double)a.delta[qi];  // false for NaN anywhere
+    }
+    o.flags[qi] = ok ? 0u : 1u;
+    if (!ok) {
+      const uint32_t j = atomicAdd(o.qcount, 1u);
+      o.qmap[j] = qi;
+      o.qslot[qi] = j;
+    }
+    o.out_n[qi] = kk;
+  }
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------------------------------
 void launch_wide_seed(int metric, const WideArgs& a, const uint64_t* seed_keys, uint32_t ngrp, uint32_t nq, hipStream_t st) {
   if (metric == kCosine)
@@ -407,6 +499,13 @@ void launch_wide_seed_l2(const WideArgs& a, const uint64_t* seed_keys, uint32_t 
 }
 void launch_wide_rerank_l2(const WideArgs& a, const WideOutArgs& o, uint32_t nq, hipStream_t st) {
   hipLaunchKernelGGL(wide_rerank_l2, dim3(nq), dim3(256), 0, st, a, o);
+}
+void launch_wide_rerank_sq8(int metric, const WideArgs& a, const WideOutArgs& o, uint32_t nq, hipStream_t st) {
+  const size_t lds = ((size_t)((a.dim + 3) & ~3u) * 4 + (size_t)kWidePoolMax * 8 + 8 + 8 + 15) & ~(size_t)15;
+  if (metric == kCosine)
+    hipLaunchKernelGGL((wide_rerank_sq8<kCosine>), dim3(nq), dim3(256), lds, st, a, o);
+  else
+    hipLaunchKernelGGL((wide_rerank_sq8<kDot>), dim3(nq), dim3(256), lds, st, a, o);
 }
 size_t wide_rerank_lds_bytes(uint32_t dim_pad) {
   return ((size_t)dim_pad * 4 + (size_t)kWidePoolMax * 8 + 2 * (size_t)64 * 68 * 4 + 64 * 4 + 8 + 15) & ~(size_t)15;

@@ -19,9 +19,9 @@ int select_level(vdb_hip_index* ix, uint32_t nq_left, uint32_t k);
 int select_level_l2(vdb_hip_index* ix, uint32_t nq_left, uint32_t k);
 uint32_t select_chunk(uint32_t nq_left, uint32_t min_queries = 0);
 // 10 < k <= kWideMaxK (sweep_wide.hip): 4 when the WIDE selection serves the next chunk of an exact Cosine / DotProduct batch
-int select_level_wide(vdb_hip_index* ix, uint32_t nq_left, uint32_t k);
+int select_level_wide(vdb_hip_index* ix, uint32_t nq_left, uint32_t k, bool sq8 = false);
 int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, uint32_t nqg, uint32_t k, uint64_t* d_ids, float* d_scores,
-                       uint32_t* d_n, hipStream_t st);
+                       uint32_t* d_n, hipStream_t st, bool sq8 = false);
 constexpr uint32_t kSelectMinQueriesSq8 = 6;  // (see select_stage.hip)
 // the four-bit image of the packed bit rows (Hamming / Jaccard batches on the matrix cores, bits_gemm.hip)
 int32_t ensure_bits_image(vdb_hip_index* ix, hipStream_t st);

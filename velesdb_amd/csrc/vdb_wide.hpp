@@ -28,6 +28,7 @@ struct WideArgs {
   const uint32_t* norm_max_bits; // device scalar: max |v| (DotProduct, Euclidean)
   float* extra;                  // [nq] Euclidean only (nullable): what a bound is lowered by on top of 2 delta — the canonical chain's own distance from the truth
   uint32_t cap, k, dim;
+  float eps_extra;               // added to the relative error bound (SQ8 storage mode: the reference chain's own distance, select_eps level 3)
 };
 struct WideOutArgs {
   const float* rows;     // f32 rows of the index
@@ -43,6 +44,12 @@ struct WideOutArgs {
   uint32_t* qslot;       // [nq] query -> slot
   uint64_t row_stride, q_stride;
   uint32_t dim_pad;
+  // SQ8 storage mode (wide_rerank_sq8): the candidates are re-scored with the reference's asymmetric chain over the codes
+  const uint8_t* sq8_codes;
+  const float* sq8_min;
+  const float* sq8_max;
+  const float* sq8_nsq;
+  uint64_t sq8_stride;
 };
 
 void launch_wide_seed(int metric, const WideArgs& a, const uint64_t* seed_keys, uint32_t ngrp, uint32_t nq, hipStream_t st);
@@ -52,6 +59,9 @@ void launch_wide_rerank(int metric, const WideArgs& a, const WideOutArgs& o, uin
 // with the canonical (q - v)^2 lane chain, proof in the squared-distance domain.  dim_a = dim + 64 (the augmented image's width)
 void launch_wide_seed_l2(const WideArgs& a, const uint64_t* seed_keys, uint32_t ngrp, uint32_t dim_a, uint32_t nq, hipStream_t st);
 void launch_wide_rerank_l2(const WideArgs& a, const WideOutArgs& o, uint32_t nq, hipStream_t st);
+// SQ8 storage mode (Cosine / DotProduct): selection over the dequantised bf16 image, candidates re-scored with dot_product_quantized_simd /
+// cosine_similarity_quantized_simd's chain (core/quantization.rs:410-554)
+void launch_wide_rerank_sq8(int metric, const WideArgs& a, const WideOutArgs& o, uint32_t nq, hipStream_t st);
 // the WIDE instance of the 256 x 256 selection kernel over one launch of a schedule (sweep_gemm_bf16.hip)
 hipError_t launch_sweep_gemm_bf16_wide(int metric, const Bf16GemmPlan& p, const uint16_t* rows16, uint64_t row_stride, const float* norms,
                                        const uint8_t* alive, const uint16_t* queries16, uint64_t q_stride, const uint64_t* tau0,

@@ -76,8 +76,9 @@ def set_sweep_engine(engine: int) -> None:
 
 def set_split_selector(level) -> None:
     """Large exact cosine / dot batches: 0 / False = the exact f32 matrix-core kernel for the whole batch; 1 / True =
-    split-bf16 selection + exact re-scoring + proof; 2 (the library's default) = plain bf16 selection first, level 1 as the
-    fallback level.  Results are identical at every level."""
+    split-bf16 selection + exact re-scoring + proof; 2 = plain bf16 selection first (block-local candidate lists for k <= 10, the WIDE
+    selection for 10 < k <= 128), level 1 as the fallback level; 3 (the library's default) = level 2 with the WIDE selection at every
+    k <= 128.  Results are identical at every level."""
     check(lib().vdb_hip_set_split_selector(int(level)))
 
 
