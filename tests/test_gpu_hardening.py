@@ -292,7 +292,7 @@ def test_compiled_cpp_caller_matches_the_ctypes_path(gpu_required, tmp_path):
     ix.close()
 
 
-@pytest.mark.parametrize("metric,setup", [(DM.Euclidean, "l2"), (DM.Cosine, "sq8"), (DM.Cosine, "bf16"), (DM.DotProduct, "split")])
+@pytest.mark.parametrize("metric,setup", [(DM.Euclidean, "l2"), (DM.Cosine, "sq8"), (DM.Cosine, "bf16"), (DM.DotProduct, "split"), (DM.Cosine, "wide"), (DM.Euclidean, "l2_level2")])
 def test_destroy_returns_all_device_memory(gpu_required, metric, setup):
     """the selection stage's corpus-sized images (l2_img / sq8_img / ...) were missing from destroy's list.
     Create / search / destroy in a loop: free device memory must come back (hipMemGetInfo through torch)."""
@@ -314,8 +314,13 @@ def test_destroy_returns_all_device_memory(gpu_required, metric, setup):
         else:
             if setup == "split":
                 ix.set_option(va.OPT_SELECTOR_LEVEL, 1)
+            if setup == "l2_level2":
+                ix.set_option(va.OPT_SELECTOR_LEVEL, 2)
             ix.search_batch_brute_force(qs, 10)
-            assert ix.last_select_level() in (1, 2)
+            # (round 6: the default is the WIDE selection — the normalised Cosine image, the global candidate lists — level 4)
+            assert ix.last_select_level() == {"split": 1, "l2_level2": 2}.get(setup, 4)
+            if setup == "wide":
+                ix.search_batch_brute_force(qs, 100)
         ix.close()
 
     cycle()  # warm-up: allocator pools, code objects

@@ -127,7 +127,11 @@ def test_configs4_shard_size_6p25m_euclidean_and_sq8_vs_oracle(gpu_required):
             del host
         # Euclidean, 1 024 queries: the selection stage over the augmented image
         gi, gs, gc = ixe.search_batch_brute_force(qs, K)
-        assert ixe.last_select_level() == 2, ixe.last_split_stats()
+        assert ixe.last_select_level() == 4, ixe.last_split_stats()   # (4 = the WIDE selection, the default at every k since round 6)
+        ixe.set_option(va.OPT_SELECTOR_LEVEL, 2)                      # ... and pinned at level 2 (block-local lists): the same bits
+        gi2, gs2, _ = ixe.search_batch_brute_force(qs, K)
+        assert ixe.last_select_level() == 2 and np.array_equal(gi2, gi) and np.array_equal(bits(gs2), bits(gs))
+        ixe.set_option(va.OPT_SELECTOR_LEVEL, -1)
         assert np.all(gc == K) and np.array_equal(gi[s_l2].astype(np.int64), acc["l2"][0])
         assert np.array_equal(bits(gs[s_l2]), bits(acc["l2"][1]))
         i4, s4, _ = ixe.search_batch_brute_force(qs[s_l2[:4]], K)      # the small-batch exact kernel over the same 4.8e9 elements
