@@ -21,6 +21,7 @@ against the oracle) must hold.
   VELESDB_COSINE_NORMALISED=0     round 5's Cosine selection (plain bf16 copy + row norms in the kernel) instead of the normalised images
                                                                                               -> split tests, the WIDE tests (k > 10)
   VELESDB_WIDE_SMALL_K=0          k <= 10 stays on the block-local lists at selector level 3 (the default) too           -> split tests
+  VELESDB_WIDE_FUSE=0             the WIDE selection's final bound / pool by a wide_reseed launch of its own             -> wide-k tests
   VELESDB_POOL_SELECT=0           bounds / final pool of a selection batch by merge_topk_* instead of radix selection -> split tests
   VELESDB_GATHER_ALL=0            unproven queries: gathered pass up to 96 + the GEMM-structured fallback beyond (rounds 2-5) -> split tests
   (VELESDB_BITS_FUSED_SKIP is an ablation that returns WRONG results by design — probe timing only, nothing to re-run)
@@ -67,6 +68,7 @@ CASES = [
     ({"VELESDB_COSINE_NORMALISED": "0"}, SPLIT),
     ({"VELESDB_COSINE_NORMALISED": "0"}, WIDE),
     ({"VELESDB_WIDE_SMALL_K": "0"}, SPLIT),
+    ({"VELESDB_WIDE_FUSE": "0"}, WIDE),
     ({"VELESDB_POOL_SELECT": "0"}, SPLIT),
     ({"VELESDB_GATHER_ALL": "0"}, SPLIT_ALL),
 ]

@@ -880,6 +880,11 @@ static const bool g_wide_small_k = [] {
   const char* e = probe_env("VELESDB_WIDE_SMALL_K");
   return !(e && e[0] == '0');
 }();
+// VELESDB_WIDE_FUSE=0 (probe builds): the final bound and the pool are taken by a wide_reseed launch of their own, as between launches
+static const bool g_wide_fuse = [] {
+  const char* e = probe_env("VELESDB_WIDE_FUSE");
+  return !(e && e[0] == '0');
+}();
 int select_level_wide(vdb_hip_index* ix, uint32_t nq_left, uint32_t k, bool sq8) {
   if (opt_selector(ix) < 2 || (!sq8 && opt_engine(ix) != 1) || opt_max_tile(ix) < 128) return 0;
   if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT && (sq8 || ix->metric != VDB_EUCLIDEAN)) return 0;  // (SQ8: Cosine / DotProduct)
@@ -928,7 +933,17 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
   const uint32_t R0 = std::min<uint32_t>(k <= kWideSmallSeedMaxK ? kSplitSeedRows : kWideSeedRows, n), ngrp = (R0 + 15) / 16;
   GemmSchedule sch;
   {
-    const uint32_t head[3] = {1u, 4u, 16u};  // tiles per row group of the first launches, as the k <= 10 stage (brute_split_dev)
+    // tiles per row group of the first launches (VELESDB_WIDE_STEPS="a,b,c": schedule probes)
+    static const std::array<uint32_t, 3> mult = [] {
+      std::array<uint32_t, 3> m{1, 4, 16};
+      if (const char* e = probe_env("VELESDB_WIDE_STEPS")) {
+        unsigned a = 0, b = 0, c = 0;
+        const int got = sscanf(e, "%u,%u,%u", &a, &b, &c);
+        m = {got >= 1 ? a : 0u, got >= 2 ? b : 0u, got >= 3 ? c : 0u};
+      }
+      return m;
+    }();
+    const uint32_t head[3] = {mult[0], mult[1], mult[2]};
     gemm_schedule(nqg, 0, n, ix->n_cus, head, 0, &sch);
   }
   // the gathered exact pass of the unproven queries: the streaming matrix-core kernel, as many 16-query tiles per pass as k leaves room
@@ -1012,7 +1027,8 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
                                     wa.cap, sel_dim, nqg, st, qnorms);
     if (evs) (void)hipEventRecord(evs->b, st);
     if (e != hipSuccess) return fail(VDB_ERR_HIP, std::string("wide selection launch: ") + hipGetErrorString(e));
-    launch_wide_reseed(wa, nqg, st);  // (behind the last launch: the final bound and the pool)
+    // (behind the last launch: the final bound and the pool — wide_rerank_verify takes that step itself for f32 rows)
+    if (j + 1 < sch.n_launch || l2 || sq8 || !g_wide_fuse) launch_wide_reseed(wa, nqg, st);
   }
   WideOutArgs wo{};
   wo.rows = ix->rows.as<float>();
@@ -1060,7 +1076,7 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
     return VDB_OK;
   }
   if (l2) launch_wide_rerank_l2(wa, wo, nqg, st);
-  else launch_wide_rerank(ix->metric, wa, wo, nqg, st);
+  else launch_wide_rerank(ix->metric, wa, wo, nqg, g_wide_fuse, st);
   // unproven queries (an overflowed list, a pool beyond one block, non-finite data): listed on the device, answered by the exact
   // streaming kernel in gathered mode — one corpus pass per g_B listed queries, none when nothing is listed
   SweepArgs am{};

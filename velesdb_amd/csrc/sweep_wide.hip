@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(WideArgs a, const uint64
   bool ok = valid >= a.k && d == d;
   uint64_t tau = wide_tau_closed();
   if (ok) {  // (block-uniform)
-    const uint32_t hi = block_kth_hi<NPT>(keys, a.k, hist, ctl);
+    __shared__ uint64_t s256[256];
+    const uint32_t hi = ngrp <= 256 ? block_kth_hi_256(keys[0], a.k, s256, ctl) : block_kth_hi<NPT>(keys, a.k, hist, ctl);
     tau = wide_tau_key(key_score<true>((uint64_t)hi << 32), d, &ok);
     if (!ok) tau = wide_tau_closed();
   }
@@ -82,41 +83,50 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(WideArgs a, const uint64
 }
 
 // ---- between two launches, and behind the last: k-th best of the list -> tau; entries under the new tau leave the list ---------
+// the list's next bound: its k-th best entry lowered by 2 delta (+ extra), never below the bound the list was filled under.  Block-uniform
+// result; 0 = the bound stays (fewer than k entries), 1 = new bound in *tau_out, 2 = the query is given up (entries were dropped, or no
+// finite bound exists).  keys = the list in registers (NPT per thread, kKeyInvalid past `raw`).
+template <int NPT>
+__device__ int wide_next_tau(const WideArgs& a, uint32_t q, uint32_t raw, const uint64_t (&keys)[NPT], uint32_t* hist, uint32_t* ctl, uint64_t* s256,
+                             uint64_t* tau_out) {
+  if (raw > a.cap) return 2;  // entries were dropped: the list no longer holds every row above the bound
+  if (raw < a.k) return 0;    // fewer than k rows passed so far: the bound stays (it is valid for any set of rows)
+  const uint32_t hi = raw <= 256 ? block_kth_hi_256(keys[0], a.k, s256, ctl) : block_kth_hi<NPT>(keys, a.k, hist, ctl);
+  bool ok;
+  uint64_t tau = wide_tau_key(key_score<true>((uint64_t)hi << 32), a.delta[q], &ok, a.extra ? a.extra[q] : 0.0f);
+  if (!ok) return 2;
+  const uint64_t old = a.tau[q];
+  if (tau > old) tau = old;  // (keys: smaller = a higher bound) never lower the bound the list was filled under
+  *tau_out = tau;
+  return 1;
+}
+
 __global__ __launch_bounds__(256) void wide_reseed_kernel(WideArgs a) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t ctl[2];
   __shared__ uint32_t wsum[4];
+  __shared__ uint64_t s256[256];
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
   if (a.state[q] & kWideGivenUp) return;  // (block-uniform)
   const uint32_t raw = a.cnt[q];
-  if (raw > a.cap) {  // entries were dropped: the list no longer holds every row above the bound
-    if (tid == 0) {
-      a.state[q] |= kWideGivenUp;
-      a.tau[q] = wide_tau_closed();
-    }
-    return;
-  }
   constexpr int NPT = kWideCap / 256;
   uint64_t* list = a.keys + (size_t)q * a.cap;
   uint64_t keys[NPT];
 #pragma unroll
   for (int j = 0; j < NPT; j++) {
     const uint32_t i = tid + 256u * (uint32_t)j;
-    keys[j] = i < raw ? list[i] : kKeyInvalid;
+    keys[j] = (i < raw && i < a.cap) ? list[i] : kKeyInvalid;
   }
-  if (raw < a.k) return;  // fewer than k rows passed so far: the bound stays (it is valid for any set of rows)
-  const uint32_t hi = block_kth_hi<NPT>(keys, a.k, hist, ctl);
-  bool ok;
-  uint64_t tau = wide_tau_key(key_score<true>((uint64_t)hi << 32), a.delta[q], &ok, a.extra ? a.extra[q] : 0.0f);
-  if (!ok) {
+  uint64_t tau = 0;
+  const int what = wide_next_tau<NPT>(a, q, raw, keys, hist, ctl, s256, &tau);
+  if (what == 0) return;
+  if (what == 2) {
     if (tid == 0) {
       a.state[q] |= kWideGivenUp;
       a.tau[q] = wide_tau_closed();
     }
     return;
   }
-  const uint64_t old = a.tau[q];
-  if (tau > old) tau = old;  // (keys: smaller = a higher bound) never lower the bound the list was filled under
   // compaction: the entries that still pass, in any order
   uint32_t keep = 0;
 #pragma unroll
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256) void wide_reseed_kernel(WideArgs a) {
 // double-buffered; one fmaf chain per candidate in oracle mode M's order k = 128 U + 16 m + 4 kk + c, the vector zero-padded to a
 // multiple of 128); then every candidate is ranked by counting among the exact keys and the k best are written in rank order.
 template <int METRIC>
-__global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArgs o) {
+__global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArgs o, bool fuse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr uint32_t kStep = 64, kStride = kStep + 4, kChunk = 64;
   float* qs = reinterpret_cast<float*>(smem);                               // [dim_pad]
@@ -154,27 +164,81 @@ __global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArg
   float* stage = reinterpret_cast<float*>(ekeys + kWidePoolMax);             // [2][kChunk][kStride]
   uint32_t* crow = reinterpret_cast<uint32_t*>(stage + 2 * kChunk * kStride);  // [kChunk]
   uint64_t* kth = reinterpret_cast<uint64_t*>(crow + kChunk);                // [1] exact key of rank k - 1
+  __shared__ uint32_t cand[kWidePoolMax];  // the pool: row numbers
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t ctl[2];
+  __shared__ uint32_t wsum[4];
+  __shared__ uint64_t s256[256];
   const uint32_t tid = threadIdx.x, qi = blockIdx.x;
   const uint32_t raw = a.cnt[qi];
-  const bool given_up = (a.state[qi] & kWideGivenUp) != 0 || raw > kWidePoolMax || raw > a.cap;
-  const uint32_t n = given_up ? 0u : raw;
+  const uint64_t* list = a.keys + (size_t)qi * a.cap;
+  bool given_up = (a.state[qi] & kWideGivenUp) != 0 || raw > a.cap;
+  uint64_t tau_fin = a.tau[qi];
+  uint32_t n = 0;
+  if (fuse) {
+    // the step wide_reseed_kernel takes behind the last launch, done here: the final bound from the whole list, the pool = the entries
+    // that pass it (the list itself is left as it is)
+    constexpr int NPT = kWideCap / 256;
+    uint64_t keys[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+      const uint32_t i = tid + 256u * (uint32_t)j;
+      keys[j] = (!given_up && i < raw) ? list[i] : kKeyInvalid;
+    }
+    if (!given_up) {  // (block-uniform)
+      uint64_t t = 0;
+      const int what = wide_next_tau<NPT>(a, qi, raw, keys, hist, ctl, s256, &t);
+      if (what == 2) given_up = true;
+      if (what == 1) tau_fin = t;
+    }
+    uint32_t keep = 0;
+#pragma unroll
+    for (int j = 0; j < NPT; j++) keep += (keys[j] != kKeyInvalid && keys[j] < tau_fin) ? 1u : 0u;
+    uint32_t incl = keep;
+    const uint32_t lane = tid & 63u, w = tid >> 6;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const uint32_t up = __shfl_up(incl, s, 64);
+      if ((int)lane >= s) incl += up;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t base = incl - keep;
+    for (uint32_t x = 0; x < w; x++) base += wsum[x];
+    const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (total > kWidePoolMax) given_up = true;
+    if (!given_up) {
+      n = total;
+#pragma unroll
+      for (int j = 0; j < NPT; j++)
+        if (keys[j] != kKeyInvalid && keys[j] < tau_fin) cand[base++] = key_row(keys[j]);
+    }
+  } else {
+    if (raw > kWidePoolMax) given_up = true;
+    n = given_up ? 0u : raw;
+    for (uint32_t i = tid; i < n; i += 256) cand[i] = key_row(list[i]);
+  }
   const float* q = o.queries + (size_t)qi * o.q_stride;
   for (uint32_t i = tid; i < o.dim_pad; i += 256) qs[i] = i < a.dim ? q[i] : 0.0f;
   if (tid == 0) *kth = kKeyInvalid;
-  const uint64_t* list = a.keys + (size_t)qi * a.cap;
   const float qn = METRIC == kCosine ? a.qnorms[qi] : 0.0f;
   for (uint32_t c0 = 0; c0 < n; c0 += kChunk) {
     const uint32_t nc = min(kChunk, n - c0);
-    __syncthreads();  // (qs written; the previous chunk's chains are done with the stage and crow)
-    if (tid < nc) crow[tid] = key_row(list[c0 + tid]);
+    __syncthreads();  // (qs and the pool written; the previous chunk's chains are done with the stage and crow)
+    if (tid < nc) crow[tid] = cand[c0 + tid];
     __syncthreads();
-    const uint32_t nf4 = nc * (kStep / 4);
+    // step width: a buffer holds 4 096 values (+ 4 of padding per row) — 64 columns of 64 rows, or more columns of fewer rows (a pool
+    // is ~25 rows at k = 10: steps of 128 columns halve the exposed fetch latencies of the chunk)
+    uint32_t sh = 0;
+    while (sh < 3 && (nc << (sh + 1)) <= kChunk) sh++;
+    const uint32_t W = kStep << sh, rowf4 = (kStep / 4) << sh, wstride = W + 4;
+    const uint32_t nf4 = nc * rowf4;
     float4 v[4];
     auto fetch = [&](uint32_t U) {
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const uint32_t f = tid + 256u * (uint32_t)i;
-        const uint32_t r = f / (kStep / 4), c4 = f % (kStep / 4);
+        const uint32_t r = f >> (4 + sh), c4 = f & (rowf4 - 1);
         v[i] = (f < nf4 && U + 4 * c4 < a.dim) ? ld4(o.rows + (size_t)crow[r] * o.row_stride + U + 4 * c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
     };
@@ -182,21 +246,22 @@ __global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArg
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const uint32_t f = tid + 256u * (uint32_t)i;
-        const uint32_t r = f / (kStep / 4), c4 = f % (kStep / 4);
-        if (f < nf4) *reinterpret_cast<float4*>(stage + ((size_t)buf * kChunk + r) * kStride + 4 * c4) = v[i];
+        const uint32_t r = f >> (4 + sh), c4 = f & (rowf4 - 1);
+        if (f < nf4) *reinterpret_cast<float4*>(stage + (size_t)buf * kChunk * kStride + (size_t)r * wstride + 4 * c4) = v[i];
       }
     };
     fetch(0);
     park(0);
     __syncthreads();
     float acc = 0.0f;
-    for (uint32_t U = 0, buf = 0; U < o.dim_pad; U += kStep, buf ^= 1u) {
-      const bool more = U + kStep < o.dim_pad;
-      if (more) fetch(U + kStep);
+    for (uint32_t U = 0, buf = 0; U < o.dim_pad; U += W, buf ^= 1u) {
+      const bool more = U + W < o.dim_pad;
+      if (more) fetch(U + W);
       if (tid < nc) {
-        const float* x = stage + ((size_t)buf * kChunk + tid) * kStride;
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
+        const float* x = stage + (size_t)buf * kChunk * kStride + (size_t)tid * wstride;
+        const uint32_t groups = min(W, o.dim_pad - U) / 16;  // (dim_pad is a multiple of 128: the padding the chain sees does not depend on W)
+#pragma unroll 4
+        for (uint32_t m = 0; m < groups; m++) {
           float xr[16];
 #pragma unroll
           for (int e = 0; e < 16; e += 4) {
@@ -242,10 +307,11 @@ __global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArg
     // proof (file header): every row outside the list has an approximate score under the final bound
     bool ok = !given_up && n >= a.k;
     if (ok) {
-      const float A = key_score<true>(a.tau[qi]);
+      const float A = key_score<true>(tau_fin);
       const double Ek = (double)key_score<true>(*kth);
       ok = Ek > (double)A + (double)a.delta[qi];  // false for NaN anywhere
     }
+    if (fuse) a.tau[qi] = tau_fin;
     o.flags[qi] = ok ? 0u : 1u;
     if (!ok) {  // the query lists itself for the gathered exact pass (sweep_split.hip list_unproven's rule)
       const uint32_t j = atomicAdd(o.qcount, 1u);
@@ -510,12 +576,12 @@ void launch_wide_rerank_sq8(int metric, const WideArgs& a, const WideOutArgs& o,
 size_t wide_rerank_lds_bytes(uint32_t dim_pad) {
   return ((size_t)dim_pad * 4 + (size_t)kWidePoolMax * 8 + 2 * (size_t)64 * 68 * 4 + 64 * 4 + 8 + 15) & ~(size_t)15;
 }
-void launch_wide_rerank(int metric, const WideArgs& a, const WideOutArgs& o, uint32_t nq, hipStream_t st) {
+void launch_wide_rerank(int metric, const WideArgs& a, const WideOutArgs& o, uint32_t nq, bool fuse_final_reseed, hipStream_t st) {
   const size_t lds = wide_rerank_lds_bytes(o.dim_pad);
   if (metric == kCosine)
-    hipLaunchKernelGGL((wide_rerank_verify<kCosine>), dim3(nq), dim3(256), lds, st, a, o);
+    hipLaunchKernelGGL((wide_rerank_verify<kCosine>), dim3(nq), dim3(256), lds, st, a, o, fuse_final_reseed);
   else
-    hipLaunchKernelGGL((wide_rerank_verify<kDot>), dim3(nq), dim3(256), lds, st, a, o);
+    hipLaunchKernelGGL((wide_rerank_verify<kDot>), dim3(nq), dim3(256), lds, st, a, o, fuse_final_reseed);
 }
 
 }  // namespace vdb

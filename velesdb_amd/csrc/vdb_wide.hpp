@@ -54,7 +54,8 @@ struct WideOutArgs {
 
 void launch_wide_seed(int metric, const WideArgs& a, const uint64_t* seed_keys, uint32_t ngrp, uint32_t nq, hipStream_t st);
 void launch_wide_reseed(const WideArgs& a, uint32_t nq, hipStream_t st);
-void launch_wide_rerank(int metric, const WideArgs& a, const WideOutArgs& o, uint32_t nq, hipStream_t st);
+// fuse_final_reseed: the kernel takes wide_reseed's step itself (final bound from the whole list, pool = the entries that pass it)
+void launch_wide_rerank(int metric, const WideArgs& a, const WideOutArgs& o, uint32_t nq, bool fuse_final_reseed, hipStream_t st);
 // Euclidean batches (the augmented DotProduct form s = q.v - |v|^2 / 2 of sweep_split.hip): seed with the form's own error bound, re-scoring
 // with the canonical (q - v)^2 lane chain, proof in the squared-distance domain.  dim_a = dim + 64 (the augmented image's width)
 void launch_wide_seed_l2(const WideArgs& a, const uint64_t* seed_keys, uint32_t ngrp, uint32_t dim_a, uint32_t nq, hipStream_t st);
