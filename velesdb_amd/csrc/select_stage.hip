@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "vdb_probe_env.hpp"
 #include "vdb_select_stage.hpp"
@@ -1075,8 +1076,44 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
     VDB_HIP(hipGetLastError());
     return VDB_OK;
   }
+  // VELESDB_WIDE_STAMPS=1 (probe builds): where a block of wide_rerank_verify spends its time, printed per batch (synchronises)
+  static const bool g_wide_stamps = [] {
+    const char* e = probe_env("VELESDB_WIDE_STAMPS");
+    return e && e[0] == '1';
+  }();
+  static unsigned long long* stamp_buf = nullptr;
+  if (g_wide_stamps && !l2) {
+    if (!stamp_buf) VDB_HIP(hipMalloc(&stamp_buf, (size_t)65536 * 8 * 8));
+    if (nqg <= 65536) wo.stamps = stamp_buf;
+  }
   if (l2) launch_wide_rerank_l2(wa, wo, nqg, st);
   else launch_wide_rerank(ix->metric, wa, wo, nqg, g_wide_fuse, st);
+  if (wo.stamps) {
+    std::vector<unsigned long long> h((size_t)nqg * 8);
+    VDB_HIP(hipStreamSynchronize(st));
+    VDB_HIP(hipMemcpy(h.data(), stamp_buf, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (uint32_t b = 0; b < nqg; b++) {
+      t0 = std::min(t0, h[(size_t)b * 8]);
+      t1 = std::max(t1, h[(size_t)b * 8 + 6]);
+    }
+    double seg[6] = {0, 0, 0, 0, 0, 0}, start = 0, raw = 0, pool = 0;
+    uint32_t late = 0;
+    for (uint32_t b = 0; b < nqg; b++) {
+      const unsigned long long* s = &h[(size_t)b * 8];
+      for (int i = 0; i < 6; i++) seg[i] += (double)(s[i + 1] - s[i]) * 0.01;
+      start += (double)(s[0] - t0) * 0.01;
+      late += (s[0] - t0) > 500 ? 1u : 0u;  // started more than 5 us behind the first block
+      raw += (double)(s[7] >> 32);
+      pool += (double)(s[7] & 0xFFFFFFFFu);
+    }
+    fprintf(stderr,
+            "[wide stamps] %u blocks, first start -> last end %.1f us; mean per block (us): list+bound+pool %.2f | query + first step %.2f | first "
+            "chunk's chains %.2f | other chunks %.2f | rank+write %.2f | proof %.2f; mean start offset %.2f us, %u blocks started > 5 us late; "
+            "mean list %.1f, pool %.1f\n",
+            nqg, (double)(t1 - t0) * 0.01, seg[0] / nqg, seg[1] / nqg, seg[2] / nqg, seg[3] / nqg, seg[4] / nqg, seg[5] / nqg, start / nqg, late,
+            raw / nqg, pool / nqg);
+  }
   // unproven queries (an overflowed list, a pool beyond one block, non-finite data): listed on the device, answered by the exact
   // streaming kernel in gathered mode — one corpus pass per g_B listed queries, none when nothing is listed
   SweepArgs am{};

@@ -58,14 +58,15 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(WideArgs a, const uint64
     keys[j] = i < ngrp ? seed_keys[(size_t)q * ngrp + i] : kKeyInvalid;
     mine += keys[j] != kKeyInvalid ? 1u : 0u;
   }
+  // (the query's words are read beside the keys, not behind the barriers)
+  const float eps = wide_eps(a.dim, a.rho_q, a.rho_max_bits, q, a.eps_extra);
+  const float d = METRIC == kCosine ? eps * 1.001f + 4e-7f : eps * 1.001f * a.qnorms[q] * __uint_as_float(*a.norm_max_bits) + 1e-30f;
   __shared__ uint32_t total;
   if (tid == 0) total = 0;
   __syncthreads();
   if (mine) atomicAdd(&total, mine);
   __syncthreads();
   const uint32_t valid = total;  // (block-uniform)
-  const float eps = wide_eps(a.dim, a.rho_q, a.rho_max_bits, q, a.eps_extra);
-  const float d = METRIC == kCosine ? eps * 1.001f + 4e-7f : eps * 1.001f * a.qnorms[q] * __uint_as_float(*a.norm_max_bits) + 1e-30f;
   bool ok = valid >= a.k && d == d;
   uint64_t tau = wide_tau_closed();
   if (ok) {  // (block-uniform)
@@ -83,19 +84,18 @@ __global__ __launch_bounds__(256) void wide_seed_kernel(WideArgs a, const uint64
 }
 
 // ---- between two launches, and behind the last: k-th best of the list -> tau; entries under the new tau leave the list ---------
-// the list's next bound: its k-th best entry lowered by 2 delta (+ extra), never below the bound the list was filled under.  Block-uniform
-// result; 0 = the bound stays (fewer than k entries), 1 = new bound in *tau_out, 2 = the query is given up (entries were dropped, or no
+// the list's next bound: its k-th best entry lowered by 2 delta (+ extra), never below the bound the list was filled under
+// (delta, extra, old = the query's words, read by the caller beside its list, not behind the selection).  Block-uniform result; 0 = the bound stays (fewer than k entries), 1 = new bound in *tau_out, 2 = the query is given up (entries were dropped, or no
 // finite bound exists).  keys = the list in registers (NPT per thread, kKeyInvalid past `raw`).
 template <int NPT>
-__device__ int wide_next_tau(const WideArgs& a, uint32_t q, uint32_t raw, const uint64_t (&keys)[NPT], uint32_t* hist, uint32_t* ctl, uint64_t* s256,
-                             uint64_t* tau_out) {
+__device__ int wide_next_tau(const WideArgs& a, uint32_t raw, const uint64_t (&keys)[NPT], float delta, float extra, uint64_t old, uint32_t* hist,
+                             uint32_t* ctl, uint64_t* s256, uint64_t* tau_out) {
   if (raw > a.cap) return 2;  // entries were dropped: the list no longer holds every row above the bound
   if (raw < a.k) return 0;    // fewer than k rows passed so far: the bound stays (it is valid for any set of rows)
-  const uint32_t hi = raw <= 256 ? block_kth_hi_256(keys[0], a.k, s256, ctl) : block_kth_hi<NPT>(keys, a.k, hist, ctl);
+  const uint32_t hi = raw <= 256 ? block_kth_hi_256(keys[0], a.k, s256, ctl, (raw + 7u) & ~7u) : block_kth_hi<NPT>(keys, a.k, hist, ctl);
   bool ok;
-  uint64_t tau = wide_tau_key(key_score<true>((uint64_t)hi << 32), a.delta[q], &ok, a.extra ? a.extra[q] : 0.0f);
+  uint64_t tau = wide_tau_key(key_score<true>((uint64_t)hi << 32), delta, &ok, extra);
   if (!ok) return 2;
-  const uint64_t old = a.tau[q];
   if (tau > old) tau = old;  // (keys: smaller = a higher bound) never lower the bound the list was filled under
   *tau_out = tau;
   return 1;
@@ -107,18 +107,22 @@ __global__ __launch_bounds__(256) void wide_reseed_kernel(WideArgs a) {
   __shared__ uint32_t wsum[4];
   __shared__ uint64_t s256[256];
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
-  if (a.state[q] & kWideGivenUp) return;  // (block-uniform)
-  const uint32_t raw = a.cnt[q];
+  const uint32_t state = a.state[q], raw = a.cnt[q];
+  const float delta = a.delta[q], extra = a.extra ? a.extra[q] : 0.0f;
+  const uint64_t old = a.tau[q];
+  if (state & kWideGivenUp) return;  // (block-uniform)
   constexpr int NPT = kWideCap / 256;
   uint64_t* list = a.keys + (size_t)q * a.cap;
   uint64_t keys[NPT];
+  keys[0] = list[tid];  // (requested beside the count, not behind it: the buffer holds `cap` entries whatever the count says)
+  if (tid >= raw) keys[0] = kKeyInvalid;
 #pragma unroll
-  for (int j = 0; j < NPT; j++) {
+  for (int j = 1; j < NPT; j++) {
     const uint32_t i = tid + 256u * (uint32_t)j;
     keys[j] = (i < raw && i < a.cap) ? list[i] : kKeyInvalid;
   }
   uint64_t tau = 0;
-  const int what = wide_next_tau<NPT>(a, q, raw, keys, hist, ctl, s256, &tau);
+  const int what = wide_next_tau<NPT>(a, raw, keys, delta, extra, old, hist, ctl, s256, &tau);
   if (what == 0) return;
   if (what == 2) {
     if (tid == 0) {
@@ -170,24 +174,41 @@ __global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArg
   __shared__ uint32_t wsum[4];
   __shared__ uint64_t s256[256];
   const uint32_t tid = threadIdx.x, qi = blockIdx.x;
-  const uint32_t raw = a.cnt[qi];
+  // (probe builds: where a block's time goes — 100 MHz wall clock, stamps of thread 0)
+  auto stamp = [&](int i) {
+    if (o.stamps && tid == 0) o.stamps[(size_t)qi * 8 + i] = wall_clock64();
+  };
+  stamp(0);
+  // everything that depends on nothing is requested first: the query (its first 1 024 elements), the list's first 256 entries
+  const float* q = o.queries + (size_t)qi * o.q_stride;
   const uint64_t* list = a.keys + (size_t)qi * a.cap;
+  float qreg[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t i = tid + 256u * (uint32_t)j;
+    qreg[j] = i < a.dim ? q[i] : 0.0f;
+  }
+  const uint64_t first = list[tid];  // (the buffer holds `cap` entries whatever the count says)
+  const float qn = METRIC == kCosine ? a.qnorms[qi] : 0.0f;
+  const uint32_t raw = a.cnt[qi];
   bool given_up = (a.state[qi] & kWideGivenUp) != 0 || raw > a.cap;
   uint64_t tau_fin = a.tau[qi];
+  const float delta = a.delta[qi], extra = a.extra ? a.extra[qi] : 0.0f;
   uint32_t n = 0;
   if (fuse) {
     // the step wide_reseed_kernel takes behind the last launch, done here: the final bound from the whole list, the pool = the entries
     // that pass it (the list itself is left as it is)
     constexpr int NPT = kWideCap / 256;
     uint64_t keys[NPT];
+    keys[0] = (!given_up && tid < raw) ? first : kKeyInvalid;
 #pragma unroll
-    for (int j = 0; j < NPT; j++) {
+    for (int j = 1; j < NPT; j++) {
       const uint32_t i = tid + 256u * (uint32_t)j;
       keys[j] = (!given_up && i < raw) ? list[i] : kKeyInvalid;
     }
     if (!given_up) {  // (block-uniform)
       uint64_t t = 0;
-      const int what = wide_next_tau<NPT>(a, qi, raw, keys, hist, ctl, s256, &t);
+      const int what = wide_next_tau<NPT>(a, raw, keys, delta, extra, tau_fin, hist, ctl, s256, &t);
       if (what == 2) given_up = true;
       if (what == 1) tau_fin = t;
     }
@@ -216,12 +237,17 @@ __global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArg
   } else {
     if (raw > kWidePoolMax) given_up = true;
     n = given_up ? 0u : raw;
-    for (uint32_t i = tid; i < n; i += 256) cand[i] = key_row(list[i]);
+    if (tid < n) cand[tid] = key_row(first);
+    for (uint32_t i = tid + 256; i < n; i += 256) cand[i] = key_row(list[i]);
   }
-  const float* q = o.queries + (size_t)qi * o.q_stride;
-  for (uint32_t i = tid; i < o.dim_pad; i += 256) qs[i] = i < a.dim ? q[i] : 0.0f;
+  stamp(1);  // the list read, the final bound found, the pool formed
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t i = tid + 256u * (uint32_t)j;
+    if (i < o.dim_pad) qs[i] = qreg[j];
+  }
+  for (uint32_t i = tid + 1024; i < o.dim_pad; i += 256) qs[i] = i < a.dim ? q[i] : 0.0f;
   if (tid == 0) *kth = kKeyInvalid;
-  const float qn = METRIC == kCosine ? a.qnorms[qi] : 0.0f;
   for (uint32_t c0 = 0; c0 < n; c0 += kChunk) {
     const uint32_t nc = min(kChunk, n - c0);
     __syncthreads();  // (qs and the pool written; the previous chunk's chains are done with the stage and crow)
@@ -233,8 +259,12 @@ __global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArg
     while (sh < 3 && (nc << (sh + 1)) <= kChunk) sh++;
     const uint32_t W = kStep << sh, rowf4 = (kStep / 4) << sh, wstride = W + 4;
     const uint32_t nf4 = nc * rowf4;
-    float4 v[4];
-    auto fetch = [&](uint32_t U) {
+    // three steps in flight: while step s multiplies out of its buffer, step s + 1 sits in a register set (requested two steps
+    // ago), steps s + 2 and s + 3 are on their way into two more.  Measured with stamped blocks (profiles/r06u_*): one request in
+    // flight per block cost 292 us per batch at k = 100 (pools of ~256 rows = 0.8 GB of rows), two 207 us, three the same — the
+    // steps then run at the rate HBM delivers 256-byte segments of rows spread over the corpus (3.9 TB/s), not at a latency.
+    float4 vr[4][4];
+    auto fetch = [&](float4 (&v)[4], uint32_t U) {
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const uint32_t f = tid + 256u * (uint32_t)i;
@@ -242,7 +272,7 @@ __global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArg
         v[i] = (f < nf4 && U + 4 * c4 < a.dim) ? ld4(o.rows + (size_t)crow[r] * o.row_stride + U + 4 * c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
     };
-    auto park = [&](uint32_t buf) {
+    auto park = [&](const float4 (&v)[4], uint32_t buf) {
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const uint32_t f = tid + 256u * (uint32_t)i;
@@ -250,13 +280,8 @@ __global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArg
         if (f < nf4) *reinterpret_cast<float4*>(stage + (size_t)buf * kChunk * kStride + (size_t)r * wstride + 4 * c4) = v[i];
       }
     };
-    fetch(0);
-    park(0);
-    __syncthreads();
     float acc = 0.0f;
-    for (uint32_t U = 0, buf = 0; U < o.dim_pad; U += W, buf ^= 1u) {
-      const bool more = U + W < o.dim_pad;
-      if (more) fetch(U + W);
+    auto chain = [&](uint32_t U, uint32_t buf) {
       if (tid < nc) {
         const float* x = stage + (size_t)buf * kChunk * kStride + (size_t)tid * wstride;
         const uint32_t groups = min(W, o.dim_pad - U) / 16;  // (dim_pad is a multiple of 128: the padding the chain sees does not depend on W)
@@ -275,16 +300,36 @@ __global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArg
             for (int kk = 0; kk < 4; kk++) acc = __builtin_fmaf(xr[4 * kk + c], qs[base + 4 * kk + c], acc);
         }
       }
-      if (more) park(buf ^ 1u);
-      __syncthreads();
+    };
+    const uint32_t nsteps = (o.dim_pad + W - 1) / W;
+    fetch(vr[0], 0);
+    if (1 < nsteps) fetch(vr[1], W);
+    if (2 < nsteps) fetch(vr[2], 2 * W);
+    const float vnorm = (METRIC == kCosine && tid < nc) ? o.norms[crow[tid]] : 1.0f;  // (beside the rows, not behind the chain)
+    park(vr[0], 0);
+    __syncthreads();
+    if (c0 == 0) stamp(2);  // the first chunk's first step has arrived
+    for (uint32_t s0 = 0; s0 < nsteps; s0 += 4) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {  // (unrolled: the register sets are named at compile time)
+        const uint32_t st = s0 + (uint32_t)j;
+        if (st < nsteps) {  // (block-uniform)
+          if (st + 3 < nsteps) fetch(vr[(j + 3) & 3], (st + 3) * W);
+          chain(st * W, st & 1u);
+          if (st + 1 < nsteps) park(vr[(j + 1) & 3], (st + 1) & 1u);
+          __syncthreads();
+        }
+      }
     }
+    if (c0 == 0) stamp(3);  // the first chunk's chains
     if (tid < nc) {
       const uint32_t row = crow[tid];
-      const float score = finish_score<METRIC>(acc, qn, METRIC == kCosine ? o.norms[row] : 1.0f);
+      const float score = finish_score<METRIC>(acc, qn, vnorm);
       ekeys[c0 + tid] = make_key<true>(score, row);
     }
   }
   __syncthreads();
+  stamp(4);  // every chunk
   // rank by counting (keys are unique: a row appears once in a list — every row is swept by exactly one block of one launch)
   const uint32_t kk = min(a.k, n);
   for (uint32_t i = tid; i < n; i += 256) {
@@ -303,13 +348,14 @@ __global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArg
     o.out_scores[(size_t)qi * a.k + e] = __uint_as_float(0x7FC00000u);
   }
   __syncthreads();
+  stamp(5);  // ranked and written
   if (tid == 0) {
     // proof (file header): every row outside the list has an approximate score under the final bound
     bool ok = !given_up && n >= a.k;
     if (ok) {
       const float A = key_score<true>(tau_fin);
       const double Ek = (double)key_score<true>(*kth);
-      ok = Ek > (double)A + (double)a.delta[qi];  // false for NaN anywhere
+      ok = Ek > (double)A + (double)delta;  // false for NaN anywhere
     }
     if (fuse) a.tau[qi] = tau_fin;
     o.flags[qi] = ok ? 0u : 1u;
@@ -319,6 +365,10 @@ __global__ __launch_bounds__(256) void wide_rerank_verify(WideArgs a, WideOutArg
       o.qslot[qi] = j;
     }
     o.out_n[qi] = kk;
+    if (o.stamps) {
+      o.stamps[(size_t)qi * 8 + 6] = wall_clock64();
+      o.stamps[(size_t)qi * 8 + 7] = ((unsigned long long)raw << 32) | n;
+    }
   }
 }
 

@@ -81,13 +81,13 @@ __device__ uint32_t block_kth_hi(const uint64_t (&keys)[NPT], uint32_t k, uint32
 // The same for at most 256 keys, one per thread (kKeyInvalid = none; keys are unique): every thread counts the keys smaller than its
 // own in LDS — two barriers instead of sixteen.  s256 = 256 keys of LDS, out = one word.  Returns the high word of the k-th smallest key
 // (1 <= k <= the number of valid keys).
-__device__ __forceinline__ uint32_t block_kth_hi_256(uint64_t key, uint32_t k, uint64_t* s256, uint32_t* out) {
+__device__ __forceinline__ uint32_t block_kth_hi_256(uint64_t key, uint32_t k, uint64_t* s256, uint32_t* out, uint32_t n = 256) {
   const uint32_t tid = threadIdx.x;
   s256[tid] = key;
   __syncthreads();
   uint32_t rank = 0;
 #pragma unroll 8
-  for (uint32_t j = 0; j < 256; j++) rank += s256[j] < key ? 1u : 0u;
+  for (uint32_t j = 0; j < n; j++) rank += s256[j] < key ? 1u : 0u;  // (n = the threads that may hold a valid key: block-uniform)
   if (key != kKeyInvalid && rank + 1 == k) *out = (uint32_t)(key >> 32);
   __syncthreads();
   const uint32_t hi = *out;

@@ -50,6 +50,8 @@ struct WideOutArgs {
   const float* sq8_max;
   const float* sq8_nsq;
   uint64_t sq8_stride;
+  // probe builds (VELESDB_WIDE_STAMPS=1): 8 wall-clock stamps per block of wide_rerank_verify, nullptr otherwise
+  unsigned long long* stamps;
 };
 
 void launch_wide_seed(int metric, const WideArgs& a, const uint64_t* seed_keys, uint32_t ngrp, uint32_t nq, hipStream_t st);
