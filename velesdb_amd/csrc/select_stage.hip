@@ -931,7 +931,13 @@ int32_t brute_wide_dev(vdb_hip_index* ix, const float* d_q, uint64_t q_stride, u
   const uint32_t n = (uint32_t)ix->n_rows, dim = ix->dim;
   // the seed sample: one key per 16 rows, its k-th best is the first bound — 4 096 rows (256 keys) bound a small k well enough that the
   // first launch passes ~100 rows per query; a k of 100 needs the 1 024 keys of 16 384 rows (seed_scores_bf16: 32 us against 100)
-  const uint32_t R0 = std::min<uint32_t>(k <= kWideSmallSeedMaxK ? kSplitSeedRows : kWideSeedRows, n), ngrp = (R0 + 15) / 16;
+  // (VELESDB_WIDE_SEED_ROWS=n, probe builds: the sample's size for k <= kWideSmallSeedMaxK)
+  static const uint32_t g_small_seed_rows = [] {
+    const char* e = probe_env("VELESDB_WIDE_SEED_ROWS");
+    const long v = e ? atol(e) : 0;
+    return v >= 1024 && v <= (long)kWideSeedRows ? (uint32_t)v / 256u * 256u : kSplitSeedRows;
+  }();
+  const uint32_t R0 = std::min<uint32_t>(k <= kWideSmallSeedMaxK ? g_small_seed_rows : kWideSeedRows, n), ngrp = (R0 + 15) / 16;
   GemmSchedule sch;
   {
     // tiles per row group of the first launches (VELESDB_WIDE_STEPS="a,b,c": schedule probes)
