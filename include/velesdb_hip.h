@@ -161,8 +161,11 @@ int32_t vdb_hip_index_quantizer_trained(const vdb_hip_index* idx, int32_t* train
 /* DualPrecisionHnsw::search_with_config (native/dual_precision.rs:259-278) for a batch, the DualPrecisionConfig passed per call as
  * the reference passes it: the int8 graph traversal + exact f32 re-scoring of the k * oversampling_ratio best (dual_precision.rs:
  * 284-321) only when the quantiser is trained AND use_int8_traversal != 0 AND the index holds >= min_index_size vectors; otherwise
- * the plain f32 graph search (VDB_SEARCH_HNSW).  oversampling_ratio = 0 => VDB_ERR_INVALID_ARG (reference default 4,
- * min_index_size default 10 000).  Ids / scores as VDB_SEARCH_HNSW reports them.  Does not touch VDB_OPT_INT8_OVERSAMPLING. */
+ * the plain f32 graph search — NativeHnsw::search with ef_search AS GIVEN (dual_precision.rs:269,274; graph.rs:251-270): the same
+ * answer as VDB_SEARCH_HNSW when 0 < k <= ef_search; with ef_search < k at most ef_search results, ef_search = 0 acts as 1 (no
+ * SearchQuality rule at this level; a device group keeps the HnswIndex rule).  oversampling_ratio = 0 or > 64 =>
+ * VDB_ERR_INVALID_ARG (reference default 4, min_index_size default 10 000).  Ids / scores as VDB_SEARCH_HNSW reports them.  Does
+ * not touch VDB_OPT_INT8_OVERSAMPLING. */
 int32_t vdb_hip_index_search_with_config(vdb_hip_index* idx, const float* queries_rowmajor, uint32_t nq, uint32_t k,
                                          uint32_t ef_search, uint32_t oversampling_ratio, int32_t use_int8_traversal,
                                          uint64_t min_index_size, uint64_t* out_ids, float* out_scores, uint32_t* out_n);

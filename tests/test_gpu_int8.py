@@ -124,4 +124,15 @@ def test_search_with_config_applies_the_rule_natively_and_takes_the_ratio_per_ca
     for q in qs:                                   # default config: 2 500 < min_index_size 10 000 => f32 search
         assert same(ix.search_with_config(q, k, ef), *f32_walk(q))
         assert same(ix.search_with_config(q, k, ef, va.DualPrecisionConfig(use_int8_traversal=False, min_index_size=0)), *f32_walk(q))
+    # the f32 branch is NativeHnsw::search with ef_search AS GIVEN (dual_precision.rs:269,274 -> graph.rs:251-270): with ef_search < k
+    # at most ef_search results, ef_search = 0 acts as 1 — not HnswIndex's max(ef, k) / "0 = Balanced" rules
+    for ef_small in (4, 1, 0, 9):
+        for q in qs:
+            oid, od = g.search(q, k, ef_small, po.TIE_CANONICAL)
+            assert len(oid) == max(ef_small, 1), "the oracle's NativeHnsw::search returns what search_layer(ef_search) holds"
+            osc = np.array([po.transform_score(po.EUCLIDEAN, float(x)) for x in od], dtype=np.float32)
+            res = ix.search_with_config(q, k, ef_small)
+            assert same(res, oid.tolist(), osc), ef_small
+            mid, msc, mcnt = ix.search_multi_entry(q, k, ef_small, 1)   # what the Rust shim's DualPrecisionHnsw::search binds
+            assert int(mcnt[0]) == len(oid) and mid[0, :len(oid)].tolist() == oid.tolist() and np.array_equal(bits(msc[0, :len(oid)]), bits(osc))
     ix.close()

@@ -1031,17 +1031,16 @@ impl HipDualPrecisionHnsw {
         }
     }
 
-    /// `DualPrecisionHnsw::search` (`dual_precision.rs:195-205`): without a quantiser the f32 graph search; with one
-    /// `search_dual_precision` (`:216-250`) — an f32 walk for `max(2 ef, 4 k)` candidates re-ranked by exact distance, which
-    /// is `search_with_rerank_quality` of the index under it.
+    /// `DualPrecisionHnsw::search` (`dual_precision.rs:191-200`).  Both branches are `NativeHnsw::search` with the caller's
+    /// `ef_search` AS GIVEN (`graph.rs:251-270`: `search_layer(ef_search)`, cut to k — no `SearchQuality` rule, no `max(ef, k)`):
+    /// without a quantiser directly; with one, `search_dual_precision` (`:209-243`) asks that search for
+    /// `rerank_k = max(2 ef, 4 k)` candidates — it returns the at most `ef_search` it has —, re-computes their distances with the
+    /// same f32 function the walk used, sorts them stably and keeps k: the first k of the same list.  The NativeHnsw-level entry
+    /// point of the library with ONE entry point is that search (`vdb_hip_index_search_multi_entry`, `num_probes = 1`: no draw
+    /// from the graph's stream, `graph.rs:303`).
     #[must_use]
     pub fn search(&self, query: &[f32], k: usize, ef_search: usize) -> Vec<(u64, f32)> {
-        if !self.is_quantizer_trained() {
-            let q = [query];
-            return self.inner.search_batch_parallel(&q, k, SearchQuality::Custom(ef_search)).pop().unwrap_or_default();
-        }
-        let rerank_k = (ef_search * 2).max(k * 4);
-        self.inner.search_with_rerank_quality(query, k, rerank_k, SearchQuality::Custom(ef_search))
+        self.inner.search_multi_entry(query, k, ef_search, 1)
     }
 
     /// `DualPrecisionHnsw::search_with_config` (`dual_precision.rs:259-278`): int8 traversal only with a trained quantiser,

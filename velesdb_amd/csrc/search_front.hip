@@ -231,6 +231,13 @@ int32_t vdb_hip_index_search_with_config(vdb_hip_index* ix, const float* queries
       std::shared_lock<IndexMutex> rd(ix->mu);
       int8 = ix->quantizer_trained && use_int8_traversal && ix->n_rows >= min_index_size;
     }
+    // The f32 branch is NativeHnsw::search with ITS ef_search (dual_precision.rs:269,274 -> graph.rs:251-270: search_layer(ef_search)
+    // as given, results cut to k): VDB_SEARCH_HNSW applies HnswIndex's SearchQuality rules on top (0 = Balanced, max(ef, k)).  The
+    // two agree whenever 0 < k <= ef_search; the other calls — at most ef_search results, ef_search = 0 acting as 1 — take the
+    // NativeHnsw-level entry point with one entry point (no draw from the graph's stream: graph.rs:303).  A device group has no such
+    // entry point: its f32 branch keeps the HnswIndex rule.
+    if (!int8 && !ix->group && !ix->pcomm && nq && k && (ef_search == 0 || ef_search < k))
+      return vdb_hip_index_search_multi_entry(ix, queries, nq, k, ef_search, 1, out_ids, out_scores, out_n);
     return search_batch_host(ix, queries, nq, k, ef_search, int8 ? VDB_SEARCH_HNSW_INT8 : VDB_SEARCH_HNSW, int8 ? oversampling_ratio : 0, out_ids,
                              out_scores, out_n);
   });
