@@ -80,7 +80,7 @@ def _maximal_record(blow=1):
                    "parallelism": "replicas x8 (query stream split, no collective)"},
         "replicas_per_rank": [{"rank": r, "qps": 1.0} for r in range(8)], "recall_at_10": 1.0,
         "parity_check": {"queries": 64, "ids_equal_oracle_canonical": True, "scores_bit_equal_oracle_canonical": True, "kernel": prose},
-        "frac_step": 0.38, "roofline": roof, "cpu_baseline": cpu, "latency_mode": {"note": prose},
+        "frac_step": 0.38, "settle_steps": 40, "repeat_ms_per_step": 1.7001, "roofline": roof, "cpu_baseline": cpu, "latency_mode": {"note": prose},
         "tiles": [{"tile": t, "note": prose} for t in range(12)], "batch_sizes_default_path": [{"n": prose}] * 8,
         "host_entry": {"note": prose, "calls": [{"queries_per_call": n, "qps": 1000.0 * n, "note": prose} for n in (1024, 256, 64, 16, 1)],
                        "threads": [{"threads": t, "queries_per_call": 1024, "qps": 2.0 * t, "note": prose} for t in (2, 4)]},
@@ -136,6 +136,9 @@ def test_the_printed_line_is_bounded_and_carries_the_contract():
     # round 6: what a VectorIndex caller gets (host pointers), the k the reference also benches, the graph legs that say something
     assert back["host_entry_qps"] == {"1024": 1024000.0, "256": 256000.0, "64": 64000.0, "2x1024": 4.0, "4x1024": 8.0}
     assert back["k50_qps"] == 5000.0 and back["k_curve_qps"] == {"10": 1000.0, "11": 1100.0, "50": 5000.0, "100": 10000.0}
+    # the untimed steps in front of the W warm-up steps are SAID on the line, with the diagnostic that shows what they are for
+    assert "settle_steps" in back and "repeat_ms_per_step" in back
+    assert back["settle_steps"] == 40 and back["repeat_ms_per_step"] == 1.7001
     assert back["legs"]["hnsw_embedding_like"] == {"qps": 232000.0, "recall": 0.985, "frac": 0.4316, "cpu_qps": None}
     assert back["legs"]["hnsw_m128"]["build_frac"] == 0.43 and back["legs"]["hnsw_m128"]["one_query_us"] == 2655.0 and back["legs"]["hnsw_m128"]["parity"] is True
     assert back["legs"]["hnsw"]["frac"] == 0.4316 and back["legs"]["hnsw"]["build_frac"] == 0.2 and back["legs"]["sharded"]["group_ok"] is True
