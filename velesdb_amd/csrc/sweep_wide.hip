@@ -15,6 +15,10 @@
 // so a query is unproven only when a list overflowed, the pool is larger than what one block re-scores, or the data is not finite
 // — those queries take the exact streaming kernel in gathered mode (the k <= 10 path's own fallback).
 // Results: ids, ranks and score bits of the exact kernels, as everywhere else (tests/test_gpu_wide_k.py).
+// Since selector level 3 (the library's default, round 6) the same path serves k <= 10 as well — it measured faster at every k
+// (select_stage.hip select_level_wide) — and Euclidean batches (their augmented DotProduct form) and the SQ8 storage mode have
+// their own seed / re-scoring kernels below.  Behind the LAST launch wide_rerank_verify takes wide_reseed's step itself (final
+// bound from the whole list, the pool formed in LDS): one launch less per batch.
 #include <algorithm>
 
 #include "vdb_device.hpp"
