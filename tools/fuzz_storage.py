@@ -21,7 +21,7 @@ from oracle import pyoracle as po  # noqa: E402
 p = argparse.ArgumentParser()
 p.add_argument("--seconds", type=float, default=240)
 p.add_argument("--seed", type=int, default=1)
-p.add_argument("--select", action="store_true", help="SQ8 batches that take the selection stage (>= 80 queries, >= 65 536 rows, dim % 64 == 0, k <= 10)")
+p.add_argument("--select", action="store_true", help="SQ8 batches that take the selection stage (>= 80 queries, >= 65 536 rows, dim % 64 == 0; k <= 10: block-local lists, k <= 128: WIDE)")
 a = p.parse_args()
 rng = np.random.default_rng(a.seed)
 DM, SM = va.DistanceMetric, va.StorageMode
@@ -65,7 +65,7 @@ while time.time() < t_end:
         n = int(rng.choice([66_000, 120_000]))
         dim = int(rng.choice([128, 256, 768]))
         nq = int(rng.choice([80, 150, 256, 480]))
-        k = int(rng.choice([1, 5, 10]))
+        k = int(rng.choice([1, 5, 10, 11, 31, 64, 100, 128]))   # (k > 10: the WIDE selection over the SQ8 image, Cosine / DotProduct)
     rows = make(kind, n, dim)
     Q = make(kind if kind != "dups" else "normal", nq, dim)
     ids = rng.permutation(n).astype(np.uint64) * 3 + 1
@@ -88,7 +88,8 @@ while time.time() < t_end:
         gi, gs, gc = ix.search_batch_sq8(Q, k)
         ei, es = po.scan_topk_sq8(pm, rows[sel], Q, max(kk, 1), nthreads=po.host_threads())
         if a.select:
-            stats["selected"] = stats.get("selected", 0) + (1 if ix.last_select_level() == 3 else 0)
+            stats["selected"] = stats.get("selected", 0) + (1 if ix.last_select_level() in (3, 4) else 0)
+            stats["wide"] = stats.get("wide", 0) + (1 if ix.last_select_level() == 4 else 0)
             stats["unproven"] = stats.get("unproven", 0) + ix.last_split_stats()[1]
     else:
         gi, gs, gc = ix.search_batch_binary(Q, k)
