@@ -394,7 +394,7 @@ def test_concurrent_searches_on_one_handle_overlap(gpu_required):
     assert all(m & va.KERNEL_HNSW for m in masks), masks
     print(f"\n[concurrency] 30 searches on one thread: {t_one * 1e3:.1f} ms; 4 x 30 on four threads: {t_four * 1e3:.1f} ms "
           f"({t_four / t_one:.2f} x)")
-    assert t_four < 2.6 * t_one, (t_one, t_four)   # serialised by one mutex this is >= 4 x
+    assert t_four < 3.2 * t_one, (t_one, t_four)   # serialised by one mutex this is >= 4 x (measured ~2.0 x: profiles/r03l_pytest_concurrency.log; the margin is for a busy host)
     # a change of the index reaches every context: the new row is the nearest neighbour of itself from any thread
     ix.insert(n, rows[n])
     hits = []
