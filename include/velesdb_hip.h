@@ -393,7 +393,7 @@ int32_t vdb_hip_set_split_selector(int32_t level);
 /* diagnostic: queries in the last split-selector batch (its last chunk of <= 1024) and how many of them the exact
  * fallback kernel answered because the selection could not be proven (near-ties inside the error bound, non-finite data) */
 int32_t vdb_hip_index_last_split_stats(vdb_hip_index* idx, uint32_t* queries, uint32_t* unproven);
-/* selection level (0 / 1 / 2; 3 = the SQ8 storage mode's; 4 = the WIDE selection of 10 < k <= 128; see vdb_hip_set_split_selector) the last
+/* selection level (0 / 1 / 2; 3 = the SQ8 storage mode's block-local form; 4 = the WIDE selection; see vdb_hip_set_split_selector) the last
  * exact batch of this handle actually ran at */
 int32_t vdb_hip_index_last_select_level(vdb_hip_index* idx, int32_t* level);
 /* which kernel families served the last search call of this handle (a bit set; what a test asserts when it claims to have
