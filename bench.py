@@ -1169,7 +1169,8 @@ def main():
         sq8_leg = {"workload": f"{N}x{D} SQ8 codes ({a.metric}, asymmetric f32-query distances), k={K}",
                    "batch": {"queries": nq_big, "qps": round(nq_big / dt_sel, 1), "ms_per_batch": round(dt_sel * 1e3, 3),
                              "select_level": lvl, "unproven_queries_last_batch": unp,
-                             "kernel": "sweep_topk_gemm_bf16_pp over the dequantised bf16 image + split_rerank_verify<SQ8> + "
+                             "kernel": ("sweep_topk_gemm_bf16_pp<WIDE> over the dequantised bf16 image + wide_rerank_sq8 + " if lvl == 4 else
+                                        "sweep_topk_gemm_bf16_pp over the dequantised bf16 image + split_rerank_verify<SQ8> + ") +
                                        "gathered sweep_topk_sq8 for unproven queries"},
                    "exact_sweep_same_batch": {"qps": round(nq_big / dt_exact, 1), "ms_per_batch": round(dt_exact * 1e3, 3),
                                               "note": "sweep_topk_sq8<B=8> for every query (selection off), extrapolated from 64 queries"},

@@ -386,9 +386,9 @@ int32_t vdb_hip_set_sweep_engine(int32_t engine);
  * bound, raised between the launches of the batch) becomes a candidate, all of them are re-scored exactly; a query is
  * unproven only when its candidate list overflows (4 096 per launch, 1 024 at the end) or its data is not finite.
  * Reported as level 4 by vdb_hip_index_last_select_level.  Larger k, other metrics at k > 10: the exact kernels.
- *   3 (default since round 6) = level 2, and Cosine / DotProduct / Euclidean batches over f32 rows take the WIDE selection at EVERY k <= 128
- *       (k <= 10 included: faster than the block-local lists, ~25 instead of 64 rows to re-score); a handle with > 1/16 of a
- *       batch unproven there answers its next 64 batches by level 2's rules. */
+ *   3 (default since round 6) = level 2, and Cosine / DotProduct / Euclidean batches over f32 rows and Cosine / DotProduct batches of the
+ *       SQ8 storage mode take the WIDE selection at EVERY k <= 128 (k <= 10 included: faster than the block-local lists, ~30 instead
+ *       of 64 rows to re-score); a handle with > 1/16 of a batch unproven there answers its next 64 batches by level 2's rules. */
 int32_t vdb_hip_set_split_selector(int32_t level);
 /* diagnostic: queries in the last split-selector batch (its last chunk of <= 1024) and how many of them the exact
  * fallback kernel answered because the selection could not be proven (near-ties inside the error bound, non-finite data) */

@@ -141,9 +141,14 @@ def test_configs4_shard_size_6p25m_euclidean_and_sq8_vs_oracle(gpu_required):
         torch.cuda.empty_cache()
         # SQ8 storage mode, 1 024 queries: selection over the dequantised image + the reference's chain; then the exact code sweep
         gi, gs, gc = ixs.search_batch_sq8(qs, K)
-        assert ixs.last_select_level() == 3, ixs.last_split_stats()
+        assert ixs.last_select_level() == 4, ixs.last_split_stats()    # (selector level 3, the default: the WIDE selection at every k)
         assert np.all(gc == K) and np.array_equal(gi[s_sq].astype(np.int64), acc["sq"][0])
         assert np.array_equal(bits(gs[s_sq]), bits(acc["sq"][1]))
+        va.set_split_selector(2)                                       # pinned: the block-local lists of the SQ8 mode, same bits
+        gi2, gs2, _ = ixs.search_batch_sq8(qs, K)
+        assert ixs.last_select_level() == 3, ixs.last_split_stats()
+        va.set_split_selector(3)
+        assert np.array_equal(gi2, gi) and np.array_equal(bits(gs2), bits(gs))
         i4, s4, _ = ixs.search_batch_sq8(qs[s_sq[:4]], K)
         assert np.array_equal(i4.astype(np.int64), acc["sq"][0][:4]) and np.array_equal(bits(s4), bits(acc["sq"][1][:4]))
     finally:

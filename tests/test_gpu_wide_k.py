@@ -6,6 +6,8 @@ Bar, as for every exact path: ids, ranks and score BITS of the exact kernels (or
 kernel answered; `last_select_level() == 4` says the WIDE selection did.  Adversarial data (duplicates = exact ties by the
 thousand, NaN / inf / zero rows, soft deletes, clusters tighter than the error bound) must come out exact too — through the proof
 by construction or through the gathered exact pass of the queries the selection gave up."""
+import os
+
 import numpy as np
 import pytest
 
@@ -199,9 +201,17 @@ def test_wide_k_sq8_storage_mode_vs_oracle(corpus, metric):
         assert np.all(cnt == k)
         assert np.array_equal(ids, eid.astype(np.uint64)), f"SQ8 ids / ranks differ from the oracle at k = {k}"
         assert np.array_equal(bits(sc), bits(esc)), f"SQ8 score bits differ from the oracle at k = {k}"
-    # k = 10 keeps level 3 (block-local lists over the same image); a handful of queries the exact SQ8 sweep
-    ix.search_batch_sq8(qs[:64], 10)
+    # k = 10 takes the WIDE selection too at selector level 3 (the default); pinned to level 2 it runs the block-local lists over
+    # the same image (level 3 of the SQ8 mode) — the same bits either way; a handful of queries: the exact SQ8 sweep
+    w10 = ix.search_batch_sq8(qs[:64], 10)
+    assert ix.last_select_level() == (LEVEL_WIDE if os.environ.get("VELESDB_WIDE_SMALL_K") != "0" else 3)
+    va.set_split_selector(2)
+    l10 = ix.search_batch_sq8(qs[:64], 10)
     assert ix.last_select_level() == 3
+    va.set_split_selector(3)
+    assert np.array_equal(w10[0], l10[0]) and np.array_equal(bits(w10[1]), bits(l10[1]))
+    e10i, e10s = po.scan_topk_sq8(PO[metric], rows, qs[:64], 10, nthreads=po.host_threads())
+    assert np.array_equal(w10[0], e10i.astype(np.uint64)) and np.array_equal(bits(w10[1]), bits(e10s))
     a, sa, _ = ix.search_batch_sq8(qs[:3], 50)
     b, sb, _ = ix.search_batch_sq8(qs[:300], 50)
     assert np.array_equal(a, b[:3]) and np.array_equal(bits(sa), bits(sb[:3]))

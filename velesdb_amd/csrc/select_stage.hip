@@ -891,10 +891,10 @@ int select_level_wide(vdb_hip_index* ix, uint32_t nq_left, uint32_t k, bool sq8)
   if (ix->metric != VDB_COSINE && ix->metric != VDB_DOT && (sq8 || ix->metric != VDB_EUCLIDEAN)) return 0;  // (SQ8: Cosine / DotProduct)
   if (ix->dim % 64 != 0 || ix->dim < 128 || ix->row_stride != ix->dim) return 0;
   // k <= 10: the block-local lists of levels 1 / 2 exist for it; selector level 3 (the default since round 6) sends Cosine / DotProduct
-  // batches over f32 rows through the WIDE selection all the same — measured faster at every k (no candidate buffers, no compaction,
+  // / Euclidean batches over f32 rows and the SQ8 mode's Cosine / DotProduct batches through the WIDE selection all the same — measured faster at every k (no candidate buffers, no compaction,
   // ~25 instead of 64 rows to re-score: DESIGN 4.1f) — and a handle the data defeats falls back to those levels, not to the exact kernels
   if (k == 0 || k > kWideMaxK || ix->n_rows < kGemmBf16MinRows || ix->n_rows >= 0xFFFFFF00ull) return 0;
-  if (k <= kGemmBf16MaxK && (sq8 || opt_selector(ix) < 3 || !g_wide_small_k)) return 0;
+  if (k <= kGemmBf16MaxK && (opt_selector(ix) < 3 || !g_wide_small_k)) return 0;
   if (!sq8 && ix->metric != VDB_EUCLIDEAN && sweep_mfma_lds_bytes(1, k, ix->dim) > 160 * 1024) return 0;  // (the gathered exact pass of the unproven queries)
   if (!select_chunk(nq_left, sq8 ? kSelectMinQueriesSq8 : 0)) return 0;
   if (ix->sel_stats && ix->sel_stats[2] != ix->sel_seq_seen) {
